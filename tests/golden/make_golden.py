@@ -1,0 +1,440 @@
+#!/usr/bin/env python3
+# -*- coding: utf-8 -*-
+"""
+Generate the golden vectors in this directory by EXECUTING THE REFERENCE'S OWN CODE
+(tasoc/photometry @ /root/reference, imported through ``_refstub``) on small seeded
+inputs.  Runs only in the dev container; the ``.npz`` files it writes are data
+(inputs + the reference's outputs) and are committed.  Usage::
+
+    python tests/golden/make_golden.py
+
+Fixtures:
+
+* ``golden_misc.npz``     quality bitmasks, mag2flux, mad_to_sigma, move_median_central,
+                          integratedGaussian  (quality.py, utilities.py)
+* ``golden_sumimage.npz`` ``BasePhotometry.sumimage`` TPF branch (BasePhotometry.py:1008-1019)
+* ``golden_aperture.npz`` ``AperturePhotometry.do_photometry`` with ``k2p2FixFromSum`` patched
+                          to return prescribed masks (photometry.py:44-257) -> A5b/A6/A7
+* ``golden_k2p2.npz``     the reference's ``k2p2FixFromSum`` control flow (k2p2v2.py:344-623)
+                          executed with real scipy + scikit-learn and with the oracle's
+                          stand-ins for the four statsmodels / scikit-image functions that
+                          cannot be installed here (a *partial* oracle)
+* ``golden_psf.npz``      ``PSF.integrate_to_image`` (psf.py:122-148) on a synthetic spline
+* ``golden_linpsf.npz``   ``lsfit`` and ``LinPSFPhotometry.do_photometry``
+                          (linpsf_photometry.py:22-34, 79-219)
+"""
+
+import os
+import sys
+import warnings
+import configparser
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import _refstub # noqa: E402
+
+#--------------------------------------------------------------------------------------------------
+# Register stand-ins for the un-installable third-party functions BEFORE importing the reference
+#--------------------------------------------------------------------------------------------------
+from oracle import kde as okde, k2p2 as ok2p2, psf as opsf # noqa: E402
+
+
+def _peak_local_max(image, exclude_border=False, threshold_rel=None, footprint=None, **kw):
+	assert exclude_border is False
+	return ok2p2.peak_local_max(image, threshold_rel=threshold_rel, footprint=footprint)
+
+
+def _install_standins():
+	import statsmodels.nonparametric.kde as smkde
+	import statsmodels.nonparametric.bandwidths as smbw
+	import skimage.feature as skf
+	import skimage.segmentation as sks
+	smkde.KDEUnivariate = okde.KDE
+	smbw.select_bandwidth = okde.select_bandwidth
+	skf.peak_local_max = _peak_local_max
+	sks.watershed = ok2p2.watershed
+
+
+sys.meta_path.insert(0, _refstub._StubFinder())
+_install_standins()
+photometry = _refstub.import_reference()
+from photometry import STATUS # noqa: E402
+ap_module = sys.modules['photometry.AperturePhotometry.photometry'] # noqa: E402
+k2p2v2 = sys.modules['photometry.AperturePhotometry.k2p2v2'] # noqa: E402
+AperturePhotometry = ap_module.AperturePhotometry # noqa: E402
+from photometry.linpsf_photometry import LinPSFPhotometry, lsfit # noqa: E402
+from photometry.psf import PSF # noqa: E402
+from photometry.BasePhotometry import BasePhotometry # noqa: E402
+from photometry import quality as refquality, utilities as refutil # noqa: E402
+from scipy.interpolate import RectBivariateSpline # noqa: E402
+
+from photometry_amd import simulate # noqa: E402
+
+
+def _settings():
+	s = configparser.ConfigParser()
+	s.read(os.path.join(_refstub.REFERENCE_PATH, 'photometry', 'data', 'settings.ini'))
+	return s
+
+
+def make_fake(cls, scene, i, sumimage):
+	"""Fake plugin object: no-op ctor, private fields set directly."""
+	class Fake(cls):
+		def __init__(self):
+			pass
+
+		def __del__(self):
+			pass
+	f = Fake()
+	T = scene.n_cad
+	f.starid = int(scene.target_starid[i])
+	f.target = {'tmag': float(scene.target_tmag[i])}
+	f.plot = False
+	f.plot_folder = None
+	f.datasource = 'ffi'
+	f._stamp = tuple(int(v) for v in scene.stamps[i])
+	f._max_stamp = f._stamp # fixed-size cube: resize_stamp() -> False
+	f.pixel_offset_row = 0
+	f.pixel_offset_col = 0
+	f._details = {}
+	f.target_pos_row = float(scene.target_pos_row[i])
+	f.target_pos_column = float(scene.target_pos_column[i])
+	f.target_pos_row_stamp = f.target_pos_row - f._stamp[0]
+	f.target_pos_column_stamp = f.target_pos_column - f._stamp[2]
+	f._sumimage = sumimage
+	f._images_cube = scene.images[i]
+	f._images_err_cube = scene.images_err[i]
+	f._backgrounds_cube = scene.backgrounds[i]
+	f._images_cube_full = f._images_err_cube_full = f._backgrounds_cube_full = None
+	f.Ntimes = T
+	f._aperture = scene.aperture[i]
+	c = scene.catalog_of(i)
+	f._catalog = _refstub.FakeCatalog(**c)
+	f.lightcurve = {
+		'time': scene.time.copy(), 'timecorr': scene.timecorr.copy(), 'quality': scene.quality.copy(),
+		'flux': np.zeros(T), 'flux_err': np.zeros(T), 'flux_background': np.zeros(T),
+		'pos_centroid': np.zeros((T, 2)),
+	}
+	f._settings = _settings()
+	f.additional_headers = {}
+	f.final_phot_mask = None
+	f.final_position_mask = None
+	f.message_queue = []
+	return f
+
+
+#--------------------------------------------------------------------------------------------------
+def golden_misc():
+	out = {}
+	q = np.array([0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 4335, 16 | 256], dtype='int32')
+	out['quality_in'] = q
+	out['quality_default_bitmask'] = np.int64(refquality.TESSQualityFlags.DEFAULT_BITMASK)
+	out['quality_filter'] = refquality.TESSQualityFlags.filter(q)
+	pf = np.arange(8, dtype='uint8')
+	out['pixelflags_in'] = pf
+	out['pixelflags_filter'] = refquality.PixelQualityFlags.filter(pf)
+	mags = np.array([0.0, 5.5, 8.0, 10.0, 13.7, 20.451, 25.0])
+	out['mag_in'] = mags
+	out['mag2flux'] = refutil.mag2flux(mags)
+	out['mad_to_sigma'] = np.float64(refutil.mad_to_sigma)
+	x_1d = np.array([4, 2, 2, 0, 0, np.nan, 0, 2, 2, 4])
+	out['mmc_in'] = x_1d
+	out['mmc_out'] = refutil.move_median_central(x_1d, 3)
+	X, Y = np.meshgrid(np.arange(-1, 2), np.arange(-1, 2))
+	out['ig_out'] = refutil.integratedGaussian(X, Y, 10, 0, 0)
+	np.savez_compressed(os.path.join(HERE, 'golden_misc.npz'), **out)
+	print('golden_misc', {k: np.shape(v) for k, v in out.items()})
+
+
+#--------------------------------------------------------------------------------------------------
+def golden_sumimage():
+	scene = simulate.make_scene(3, 40, 9, 11, seed=11)
+	simulate.fill_cubes(scene, nan_fraction=0.02)
+	# force some special pixels: one pixel NaN at all good cadences, one pixel NaN always
+	scene.images[0, 2, 3, :] = np.nan
+	scene.images[1, 0, 0, scene.quality == 0] = np.nan
+	q = scene.quality.copy()
+	q[5] = 4096; q[6] = 16; q[7] = 128 | 1; q[8] = 256
+	outs = []
+	for i in range(3):
+		class Fake(BasePhotometry):
+			def __init__(self):
+				pass
+
+			def __del__(self):
+				pass
+		f = Fake()
+		f.datasource = 'tpf'
+		f.plot = False
+		f._stamp = tuple(int(v) for v in scene.stamps[i])
+		f._sumimage = None
+		f._images_cube = scene.images[i].copy() # the reference zeroes NaNs in-place (:1013)
+		f.Ntimes = scene.n_cad
+		f.lightcurve = {'quality': q}
+		outs.append(np.array(f.sumimage))
+	np.savez_compressed(os.path.join(HERE, 'golden_sumimage.npz'), images=scene.images, quality=q, sumimage=np.array(outs))
+	print('golden_sumimage', np.array(outs).shape, 'nan count', np.isnan(outs).sum())
+
+
+#--------------------------------------------------------------------------------------------------
+def golden_aperture():
+	H, W, T = 11, 11, 24
+	scene = simulate.make_scene(10, T, H, W, seed=21)
+	simulate.fill_cubes(scene, nan_fraction=0.01)
+	from oracle import sumimage as osum
+	S = osum.sumimage_batch(scene.images, scene.quality)
+
+	cases = []
+	def base_mask(i):
+		cat = scene.catalog_of(i)
+		c = np.column_stack((cat['column_stamp'], cat['row_stamp'], cat['tmag']))
+		mm, _ = ok2p2.k2p2FixFromSum(S[i], catalog=c, thresh=0.8, min_no_pixels_in_mask=4, min_for_cluster=4,
+			cluster_radius=np.sqrt(2) + np.finfo(np.float64).eps, segmentation=True, ws_blur=0.5, ws_thres=0,
+			ws_footprint=3, extend_overflow=True)
+		return mm
+
+	# 0-3: ordinary targets, masks from the oracle's K2P2
+	for i in range(4):
+		cases.append((i, 'masks', base_mask(i)))
+	# 4: special frames
+	i = 4
+	mm = base_mask(i)
+	r, c = int(round(scene.star_params[i, 0, 0])), int(round(scene.star_params[i, 0, 1]))
+	main = np.asarray(mm, dtype=bool)[np.asarray(mm, dtype=bool)[:, r, c]][0]
+	scene.images[i, :, :, 2][main] = np.nan            # all-NaN in mask
+	scene.images[i, :, :, 3][main] = 0                 # all-zero in mask
+	scene.images[i, :, :, 4][main] = -np.abs(scene.images[i, :, :, 4][main]) - 1 # no positive flux -> centroid NaN
+	scene.backgrounds[i, :, :, 5][main] = np.nan       # all-NaN background
+	scene.backgrounds[i, r, c, 6] = np.nan             # one NaN background pixel -> nansum
+	scene.images[i, r, c, 7] = np.nan                  # one NaN flux pixel -> NaN flux (np.sum)
+	scene.images_err[i, r, c, 8] = np.nan
+	cases.append((i, 'masks', mm))
+	# 5: K2P2 returns None
+	cases.append((5, 'none', None))
+	# 6: K2P2NoStars raised
+	cases.append((6, 'nostars', None))
+	# 7: mask not under the target -> minimum aperture
+	m = np.zeros((1, H, W)); m[0, 0:2, 0:3] = 1
+	cases.append((7, 'masks', m))
+	# 8: two masks overlapping the target pixel -> ERROR
+	i = 8
+	r, c = int(round(scene.star_params[i, 0, 0])), int(round(scene.star_params[i, 0, 1]))
+	m = np.zeros((2, H, W)); m[0, r-1:r+2, c-1:c+2] = 1; m[1, r:r+3, c:c+3] = 1
+	cases.append((8, 'masks', m))
+	# 9: big mask touching three edges and containing every catalog star -> contamination, skip targets
+	m = np.zeros((1, H, W)); m[0, 0:H-1, :] = 1
+	cases.append((9, 'masks', m))
+	# 10: mask (with the target pixel) whose catalog star positions are elsewhere -> "No targets in mask"
+	i = 0
+	r, c = int(round(scene.star_params[i, 0, 0])), int(round(scene.star_params[i, 0, 1]))
+	m = np.zeros((1, H, W)); m[0, r, c] = 1; m[0, r, c+1] = 1
+	cases.append((0, 'masks_shifted_catalog', m))
+
+	out = {'images': scene.images, 'images_err': scene.images_err, 'backgrounds': scene.backgrounds,
+		'sumimage': S, 'stamps': scene.stamps, 'target_pos_row': scene.target_pos_row, 'target_pos_column': scene.target_pos_column,
+		'target_tmag': scene.target_tmag, 'target_starid': scene.target_starid, 'aperture': scene.aperture,
+		'cat_offsets': scene.cat_offsets, 'quality': scene.quality}
+	for k, v in scene.catalog.items():
+		out['cat_' + k] = v
+	out['n_cases'] = len(cases)
+
+	for n, (i, kind, mm) in enumerate(cases):
+		f = make_fake(AperturePhotometry, scene, i, S[i])
+		if kind == 'masks_shifted_catalog':
+			cat = scene.catalog_of(i)
+			cat = {k: v.copy() for k, v in cat.items()}
+			cat['row'] = cat['row'] + 4
+			cat['column'] = cat['column'] - 3
+			f._catalog = _refstub.FakeCatalog(**cat)
+			out[f'case{n}_cat_row'] = cat['row']
+			out[f'case{n}_cat_column'] = cat['column']
+
+		def fake_k2p2(SumImage, _kind=kind, _mm=mm, **kwargs):
+			if _kind == 'nostars':
+				raise k2p2v2.K2P2NoStars("No flux above threshold")
+			return (None if _mm is None else np.array(_mm, dtype='float64')), 1.0
+		ap_module.k2p2.k2p2FixFromSum = fake_k2p2
+		with warnings.catch_warnings():
+			warnings.simplefilter('ignore')
+			status = AperturePhotometry.do_photometry(f)
+		out[f'case{n}_target'] = i
+		out[f'case{n}_kind'] = kind
+		out[f'case{n}_masks'] = np.zeros((0, H, W)) if mm is None else np.asarray(mm, dtype='float64')
+		out[f'case{n}_status'] = status.value
+		out[f'case{n}_flux'] = np.asarray(f.lightcurve['flux'])
+		out[f'case{n}_flux_err'] = np.asarray(f.lightcurve['flux_err'])
+		out[f'case{n}_flux_background'] = np.asarray(f.lightcurve['flux_background'])
+		out[f'case{n}_pos_centroid'] = np.asarray(f.lightcurve['pos_centroid'])
+		out[f'case{n}_final_mask'] = np.zeros((H, W), dtype=bool) if f.final_phot_mask is None else np.asarray(f.final_phot_mask, dtype=bool)
+		out[f'case{n}_has_mask'] = f.final_phot_mask is not None
+		cont = f.additional_headers.get('AP_CONT', (np.nan,))[0]
+		out[f'case{n}_contamination'] = np.float64(cont)
+		out[f'case{n}_skip_targets'] = np.asarray(f._details.get('skip_targets', []), dtype='int64')
+		print('aperture case', n, kind, 'target', i, status, 'cont', cont, 'skip', f._details.get('skip_targets'))
+	# restore
+	ap_module.k2p2.k2p2FixFromSum = k2p2v2.k2p2FixFromSum
+	np.savez_compressed(os.path.join(HERE, 'golden_aperture.npz'), **out)
+
+
+#--------------------------------------------------------------------------------------------------
+def golden_k2p2():
+	"""Reference k2p2FixFromSum control flow with stand-ins (partial oracle)."""
+	out = {}
+	n = 0
+	settings = dict(thresh=0.8, min_no_pixels_in_mask=4, min_for_cluster=4,
+		cluster_radius=np.sqrt(2) + np.finfo(np.float64).eps, segmentation=True, ws_blur=0.5, ws_thres=0,
+		ws_footprint=3, extend_overflow=True)
+	from oracle import sumimage as osum
+	for (H, W, T, seed, nt, kw) in ((15, 15, 120, 31, 24, {}), (11, 11, 60, 32, 12, {}),
+			(15, 15, 200, 33, 12, dict(tmag_range=(4.0, 7.5), neighbour_tmag_range=(6.0, 9.0))),
+			(21, 17, 80, 34, 8, dict(max_neighbours=4, neighbour_tmag_range=(8.0, 12.0)))):
+		scene = simulate.make_scene(nt, T, H, W, seed=seed, **kw)
+		simulate.fill_cubes(scene, nan_fraction=0.002)
+		S = osum.sumimage_batch(scene.images, scene.quality)
+		if seed == 33:
+			# emulate saturated bleed columns for the bright cases
+			for i in range(nt):
+				c = int(round(scene.star_params[i, 0, 1]))
+				r = int(round(scene.star_params[i, 0, 0]))
+				sat = 0.6*np.nanmax(S[i])
+				for rr in range(max(r-5, 0), min(r+6, H)):
+					S[i, rr, c] = sat*(1 + 0.001*np.sin(rr))
+		for i in range(nt):
+			cat = scene.catalog_of(i)
+			c = np.column_stack((cat['column_stamp'], cat['row_stamp'], cat['tmag']))
+			try:
+				with warnings.catch_warnings():
+					warnings.simplefilter('ignore')
+					masks, bw = k2p2v2.k2p2FixFromSum(S[i], plot_folder=None, show_plot=False, catalog=c, **settings)
+				err = ''
+			except k2p2v2.K2P2NoStars:
+				masks, bw, err = None, np.nan, 'K2P2NoStars'
+			except k2p2v2.K2P2NoFlux:
+				masks, bw, err = None, np.nan, 'K2P2NoFlux'
+			except Exception as e: # noqa: B902
+				masks, bw, err = None, np.nan, type(e).__name__
+			out[f'k{n}_sumimage'] = S[i]
+			out[f'k{n}_catalog'] = c
+			out[f'k{n}_masks'] = np.zeros((0, H, W)) if masks is None else np.asarray(masks)
+			out[f'k{n}_bw'] = np.float64(bw)
+			out[f'k{n}_err'] = err
+			print('k2p2 case', n, (H, W), 'nmasks', 0 if masks is None else len(masks), err)
+			n += 1
+	out['n_cases'] = n
+	np.savez_compressed(os.path.join(HERE, 'golden_k2p2.npz'), **out)
+
+
+#--------------------------------------------------------------------------------------------------
+def _synthetic_spline():
+	prf = opsf.synthetic_prf(seed=5)
+	x = prf['prfColumn']
+	img = prf['values'][7]
+	img = img / (np.nansum(img) * np.median(np.diff(x))**2)
+	return x, img, RectBivariateSpline(x, x, img)
+
+
+def golden_psf():
+	x, img, spline = _synthetic_spline()
+	out = {'prf_x': x, 'prf_img': img}
+	n = 0
+	for shape, params, cutoff in (
+			((15, 15), np.array([[7.31, 6.82, 1000.0]]), 5),
+			((15, 15), np.array([[7.0, 7.0, 1.0]]), 5),
+			((11, 13), np.array([[5.2, 6.9, 500.0], [2.05, 10.4, 120.0], [9.99, 0.51, 33.0]]), 5),
+			((11, 11), np.array([[5.5, 5.5, 10.0], [-1.2, 3.3, 7.0], [12.4, 11.9, 3.0]]), None),
+			((15, 15), np.array([[0.49, 14.2, 77.0], [7.5, 7.5, 2.0]]), 3.3)):
+		p = PSF.__new__(PSF)
+		p.shape = shape
+		p.stamp = (0, shape[0], 0, shape[1])
+		p.splineInterpolation = spline
+		res = p.integrate_to_image(params, cutoff_radius=cutoff)
+		out[f'p{n}_shape'] = np.array(shape)
+		out[f'p{n}_params'] = params
+		out[f'p{n}_cutoff'] = np.float64(np.nan if cutoff is None else cutoff)
+		out[f'p{n}_img'] = res
+		print('psf case', n, shape, res.sum())
+		n += 1
+	out['n_cases'] = n
+	np.savez_compressed(os.path.join(HERE, 'golden_psf.npz'), **out)
+
+
+def golden_linpsf():
+	x, img, spline = _synthetic_spline()
+	out = {'prf_x': x, 'prf_img': img}
+	rng = np.random.default_rng(77)
+	# lsfit cases
+	n = 0
+	for (m, k, kind) in ((50, 3, 'ok'), (121, 1, 'ok'), (80, 4, 'dup'), (30, 2, 'zero')):
+		A = rng.random((m, k))
+		if kind == 'dup':
+			A[:, 3] = A[:, 1]
+		if kind == 'zero':
+			A[:, 1] = 0
+		b = rng.normal(size=m)
+		out[f'ls{n}_A'] = A
+		out[f'ls{n}_b'] = b
+		out[f'ls{n}_x'] = lsfit(A, b)
+		n += 1
+	out['n_lsfit'] = n
+
+	# LinPSF loop
+	H, W, T = 11, 11, 12
+	scene = simulate.make_scene(4, T, H, W, seed=41, max_neighbours=3, neighbour_tmag_range=(9.0, 17.0))
+	simulate.fill_cubes(scene, nan_fraction=0.01)
+	# catalog positions per cadence (what catalog_attime would return): reference + jitter
+	n = 0
+	for i in range(4):
+		f = make_fake(LinPSFPhotometry, scene, i, None)
+		f.cutoff_radius = 5
+		p = PSF.__new__(PSF)
+		p.shape = (H, W)
+		p.stamp = f._stamp
+		p.splineInterpolation = spline
+		f._psf = p
+		cat0 = scene.catalog_of(i)
+		nall = len(cat0['starid'])
+		positions = np.empty((T, nall, 2))
+		for k in range(T):
+			positions[k, :, 0] = cat0['row_stamp'] + scene.jitter[k, 1]
+			positions[k, :, 1] = cat0['column_stamp'] + scene.jitter[k, 0]
+		times = np.asarray(f.lightcurve['time']) - np.asarray(f.lightcurve['timecorr'])
+
+		def catalog_attime(t, _cat0=cat0, _pos=positions, _times=times):
+			k = int(np.argmin(np.abs(_times - t)))
+			c = {kk: vv.copy() for kk, vv in _cat0.items()}
+			c['row_stamp'] = _pos[k, :, 0].copy()
+			c['column_stamp'] = _pos[k, :, 1].copy()
+			return _refstub.FakeCatalog(**c)
+		f.catalog_attime = catalog_attime
+		with warnings.catch_warnings():
+			warnings.simplefilter('ignore')
+			status = LinPSFPhotometry.do_photometry(f)
+		out[f'lp{n}_target'] = i
+		out[f'lp{n}_positions'] = positions
+		out[f'lp{n}_status'] = status.value
+		out[f'lp{n}_flux'] = np.asarray(f.lightcurve['flux'])
+		out[f'lp{n}_flux_err'] = np.asarray(f.lightcurve['flux_err'])
+		out[f'lp{n}_contamination'] = np.float64(f.additional_headers.get('PSF_CONT', (np.nan,))[0])
+		print('linpsf case', n, status, 'cont', out[f'lp{n}_contamination'], 'flux[0]', f.lightcurve['flux'][0], 'true', scene.star_params[i, 0, 2])
+		n += 1
+	out['n_linpsf'] = n
+	out['images'] = scene.images
+	out['stamps'] = scene.stamps
+	out['aperture'] = scene.aperture
+	out['target_pos_row'] = scene.target_pos_row
+	out['target_pos_column'] = scene.target_pos_column
+	out['target_starid'] = scene.target_starid
+	out['cat_offsets'] = scene.cat_offsets
+	for k, v in scene.catalog.items():
+		out['cat_' + k] = v
+	np.savez_compressed(os.path.join(HERE, 'golden_linpsf.npz'), **out)
+
+
+if __name__ == '__main__':
+	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf']
+	for w in which:
+		globals()['golden_' + w]()

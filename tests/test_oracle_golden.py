@@ -1,0 +1,145 @@
+# -*- coding: utf-8 -*-
+"""
+Pin the oracle (CPU restatement) against the golden vectors produced by executing the
+reference's own code (tests/golden/make_golden.py).  CPU only.
+"""
+import os
+import numpy as np
+import pytest
+from oracle import quality, utilities, sumimage, aperture, psf as opsf, linpsf, k2p2
+from scipy.interpolate import RectBivariateSpline
+
+
+def _load(golden_dir, name):
+	return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_misc(golden_dir):
+	g = _load(golden_dir, 'golden_misc.npz')
+	assert quality.TESS_DEFAULT_BITMASK == int(g['quality_default_bitmask']) == 4335
+	np.testing.assert_array_equal(quality.tess_filter(g['quality_in']), g['quality_filter'])
+	np.testing.assert_array_equal(quality.pixel_filter(g['pixelflags_in']), g['pixelflags_filter'])
+	np.testing.assert_array_equal(utilities.mag2flux(g['mag_in']), g['mag2flux'])
+	assert utilities.mad_to_sigma == float(g['mad_to_sigma'])
+	# reference's own known answers: tests/test_utilities.py:24-35, utilities.py:121-126
+	np.testing.assert_allclose(utilities.move_median_central(g['mmc_in'], 3), [3, 2, 2, 0, 0, 0, 1, 2, 2, 3])
+	np.testing.assert_allclose(utilities.move_median_central(g['mmc_in'], 3), g['mmc_out'])
+	X, Y = np.meshgrid(np.arange(-1, 2), np.arange(-1, 2))
+	np.testing.assert_array_equal(utilities.integratedGaussian(X, Y, 10, 0, 0), g['ig_out'])
+	np.testing.assert_allclose(g['ig_out'], [[0.58433556, 0.92564571, 0.58433556],
+		[0.92564571, 1.46631496, 0.92564571], [0.58433556, 0.92564571, 0.58433556]], rtol=1e-7)
+
+
+def test_sumimage(golden_dir):
+	g = _load(golden_dir, 'golden_sumimage.npz')
+	S = sumimage.sumimage_batch(g['images'], g['quality'])
+	np.testing.assert_array_equal(S, g['sumimage']) # bit-exact incl. NaN positions
+	assert np.isnan(S).sum() == 2
+
+
+def _catalog(g, i, prefix='cat_'):
+	a, b = g['cat_offsets'][i], g['cat_offsets'][i+1]
+	return {k[len(prefix):]: g[k][a:b] for k in g.files if k.startswith(prefix) and k != 'cat_offsets'}
+
+
+def test_aperture(golden_dir):
+	g = _load(golden_dir, 'golden_aperture.npz')
+	for n in range(int(g['n_cases'])):
+		i = int(g[f'case{n}_target'])
+		kind = str(g[f'case{n}_kind'])
+		cat = _catalog(g, i)
+		if f'case{n}_cat_row' in g.files:
+			cat['row'] = g[f'case{n}_cat_row']
+			cat['column'] = g[f'case{n}_cat_column']
+		masks = g[f'case{n}_masks']
+		masks = None if (kind in ('none', 'nostars') or masks.shape[0] == 0) else masks.astype(bool)
+		res = aperture.do_photometry(g['sumimage'][i], g['images'][i], g['images_err'][i], g['backgrounds'][i],
+			tuple(g['stamps'][i]), g['target_pos_row'][i], g['target_pos_column'][i], g['target_tmag'][i],
+			g['target_starid'][i], cat, g['aperture'][i], masks=masks)
+		assert res['status'] == int(g[f'case{n}_status']), f"case {n}"
+		if bool(g[f'case{n}_has_mask']):
+			np.testing.assert_array_equal(res['mask'], g[f'case{n}_final_mask'])
+			# float32 np.sum / sqrt: bit-exact
+			np.testing.assert_array_equal(res['flux'], g[f'case{n}_flux'])
+			np.testing.assert_array_equal(res['flux_err'], g[f'case{n}_flux_err'])
+			np.testing.assert_allclose(res['pos_centroid'], g[f'case{n}_pos_centroid'], rtol=1e-14)
+			# golden used np.nansum (pairwise float32) in place of bottleneck.nansum (sequential float32)
+			np.testing.assert_allclose(res['flux_background'], g[f"case{n}_flux_background"], rtol=1e-5)
+			np.testing.assert_array_equal(np.isnan(res['flux_background']), np.isnan(g[f'case{n}_flux_background']))
+			cont = float(g[f'case{n}_contamination'])
+			if np.isnan(cont):
+				assert np.isnan(res['contamination'])
+			else:
+				assert abs(res['contamination'] - cont) < 1e-6
+			np.testing.assert_array_equal(np.asarray(res['skip_targets'], dtype='int64'), g[f'case{n}_skip_targets'])
+	# special frames of case 4 behaved as designed
+	f = g['case4_flux']
+	assert np.isnan(f[2]) and np.isnan(f[3]) and np.isfinite(f[4]) and np.isnan(f[7])
+	assert np.all(np.isnan(g['case4_pos_centroid'][4]))
+	assert np.isnan(g['case4_flux_background'][5]) and np.isfinite(g['case4_flux_background'][6])
+
+
+def test_k2p2_reference_control_flow(golden_dir):
+	"""The reference's own k2p2FixFromSum (real scipy/sklearn + stand-ins) vs the oracle restatement."""
+	g = _load(golden_dir, 'golden_k2p2.npz')
+	settings = dict(thresh=0.8, min_no_pixels_in_mask=4, min_for_cluster=4,
+		cluster_radius=np.sqrt(2) + np.finfo(np.float64).eps, segmentation=True, ws_blur=0.5, ws_thres=0,
+		ws_footprint=3, extend_overflow=True)
+	nmulti = 0
+	for n in range(int(g['n_cases'])):
+		S = g[f'k{n}_sumimage']
+		cat = g[f'k{n}_catalog']
+		ref = g[f'k{n}_masks']
+		assert str(g[f'k{n}_err']) == ''
+		# golden was made with the scipy installed here (bracket validation on):
+		masks, bw = k2p2.k2p2FixFromSum(S, catalog=cat, validate_bracket=True, **settings)
+		assert bw == float(g[f'k{n}_bw'])
+		if ref.shape[0] == 0:
+			assert masks is None
+			continue
+		assert masks.shape == ref.shape
+		nmulti += ref.shape[0] > 1
+		# order of equally-sized masks is unspecified in the reference (unstable argsort): compare as sets
+		a = sorted(m.astype(bool).tobytes() for m in masks)
+		b = sorted(m.astype(bool).tobytes() for m in ref)
+		assert a == b, f"case {n}"
+	assert nmulti >= 5
+
+
+def test_psf_integrate(golden_dir):
+	g = _load(golden_dir, 'golden_psf.npz')
+	x = g['prf_x']
+	spline = RectBivariateSpline(x, x, g['prf_img'])
+	for n in range(int(g['n_cases'])):
+		shape = tuple(int(v) for v in g[f'p{n}_shape'])
+		cutoff = float(g[f'p{n}_cutoff'])
+		cutoff = None if np.isnan(cutoff) else cutoff
+		p = opsf.PSF.from_spline(spline, shape)
+		img = p.integrate_to_image(g[f'p{n}_params'], cutoff_radius=cutoff)
+		ref = g[f'p{n}_img']
+		np.testing.assert_allclose(img, ref, rtol=1e-11, atol=1e-15*np.abs(ref).max())
+		np.testing.assert_array_equal(img == 0, ref == 0)
+	# reference test tests/test_psf.py:37-63: unit star at a pixel centre peaks at that pixel
+	p = opsf.PSF.from_spline(spline, (15, 15))
+	img = p.integrate_to_image(np.array([[7.0, 7.0, 1.0]]))
+	assert np.unravel_index(np.argmax(img), img.shape) == (7, 7)
+
+
+def test_linpsf(golden_dir):
+	g = _load(golden_dir, 'golden_linpsf.npz')
+	for n in range(int(g['n_lsfit'])):
+		x = linpsf.lsfit(g[f'ls{n}_A'], g[f'ls{n}_b'])
+		np.testing.assert_array_equal(x, g[f'ls{n}_x'])
+	x = g['prf_x']
+	spline = RectBivariateSpline(x, x, g['prf_img'])
+	for n in range(int(g['n_linpsf'])):
+		i = int(g[f'lp{n}_target'])
+		cat = _catalog(g, i)
+		H, W = g['images'].shape[1:3]
+		p = opsf.PSF.from_spline(spline, (H, W))
+		res = linpsf.do_photometry(g['images'][i], p, cat, g['target_starid'][i], g[f'lp{n}_positions'],
+			tuple(g['stamps'][i]), g['target_pos_row'][i], g['target_pos_column'][i], g['aperture'][i])
+		assert res['status'] == int(g[f'lp{n}_status'])
+		np.testing.assert_allclose(res['flux'], g[f'lp{n}_flux'], rtol=1e-9)
+		assert np.all(np.isnan(res['flux_err']))
+		np.testing.assert_allclose(res['contamination'], float(g[f'lp{n}_contamination']), rtol=1e-8, atol=1e-12)
