@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+# -*- coding: utf-8 -*-
+"""
+bench.py -- whole-job throughput of the per-target photometry hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one batch of synthetic stamp cubes that is already
+resident in HBM: A1 sum image -> A2..A5b K2P2 masks (+A7) -> A6 aperture extraction
+(AperturePhotometry.do_photometry for every target).  Workload (BASELINE.json configs[2], the one
+the metric is quoted on): 10 000 targets x 1 300 cadences x 15x15 stamps per GPU, aperture +
+background cubes.  For N > 1 the driver launches one rank per GPU through torch.distributed.run;
+targets are sharded by index (weak scaling: 10 000 targets per GPU), the only data-path exchange
+is ONE RCCL gather of the light-curve block at the end of the timed region.
+
+Prints ONE JSON line on rank 0 (see the bench contract in the task description) with the
+``roofline`` and ``cpu_baseline`` objects.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+	sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0 # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+	p = argparse.ArgumentParser()
+	p.add_argument('--gpus', type=int, default=1)
+	p.add_argument('--steps', type=int, default=10)
+	p.add_argument('--warmup', type=int, default=3)
+	p.add_argument('--targets', type=int, default=10000, help='targets per GPU')
+	p.add_argument('--cadences', type=int, default=1300)
+	p.add_argument('--stamp', type=int, default=15)
+	p.add_argument('--cpu-sample', type=int, default=160, help='targets in the CPU-baseline sample (0 = skip)')
+	p.add_argument('--seed', type=int, default=1)
+	p.add_argument('--no-gather', action='store_true')
+	p.add_argument('--placeholder-masks', action='store_true', help='5x5 box masks instead of the on-device K2P2 (bring-up only)')
+	return p.parse_args()
+
+
+def _cpu_worker(job):
+	"""Oracle (reference-equivalent numpy restatement) on a list of targets; returns seconds + results."""
+	import numpy as np
+	from oracle import sumimage as osum, aperture as oap
+	sub = job
+	t0 = time.perf_counter()
+	out = []
+	for i in range(sub.n_targets):
+		S = osum.sumimage(sub.images[i], sub.quality)
+		r = oap.do_photometry(S, sub.images[i], sub.images_err[i], sub.backgrounds[i], tuple(sub.stamps[i]),
+			sub.target_pos_row[i], sub.target_pos_column[i], sub.target_tmag[i], sub.target_starid[i],
+			sub.catalog_of(i), sub.aperture[i])
+		out.append({k: r.get(k) for k in ('status', 'flux', 'flux_err', 'flux_background', 'pos_centroid', 'mask', 'contamination')})
+	return time.perf_counter() - t0, out
+
+
+def main():
+	args = parse_args()
+	rank = int(os.environ.get('RANK', '0'))
+	local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+	world = int(os.environ.get('WORLD_SIZE', '1'))
+	if world != args.gpus and world > 1:
+		args.gpus = world
+
+	# torch is plumbing only (rendezvous, barrier, device sync); import it BEFORE the HIP library
+	# so that a single HIP runtime is shared by both.
+	dist = None
+	torch = None
+	try:
+		if os.environ.get('TP_BENCH_NO_TORCH') and world == 1:
+			raise ImportError
+		import torch
+		if world > 1:
+			import torch.distributed as dist
+			os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+			dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+	except ImportError:
+		torch = None
+
+	import numpy as np
+	from photometry_amd import simulate, engine, pipeline
+	from photometry_amd.device import Context
+	from photometry_amd import comm as tpcomm
+
+	def device_sync():
+		ctx.sync()
+		if torch is not None and torch.cuda.is_available():
+			torch.cuda.synchronize(local_rank)
+
+	def barrier():
+		if dist is not None:
+			dist.barrier()
+
+	ctx = Context(local_rank)
+	if torch is not None and torch.cuda.is_available():
+		torch.cuda.set_device(local_rank)
+
+	Nt, T, H = args.targets, args.cadences, args.stamp
+	W = H
+	# every rank gets its own contiguous shard of the global target list (weak scaling)
+	scene = simulate.make_scene(Nt, T, H, W, seed=args.seed * 1000 + rank)
+	scene.aperture = None
+	cubes = engine.synth_fill(ctx, scene)
+	batch = pipeline.ApertureBatch(ctx, scene, cubes=cubes)
+	work = pipeline.ApertureWork(ctx, batch)
+
+	if world > 1:
+		tpcomm.init_from_torch(ctx, dist, rank, world)
+	gather_buf = None
+	lc_bytes = work.lc.block.nbytes
+	if world > 1 and not args.no_gather and rank == 0:
+		gather_buf = ctx.empty((world, lc_bytes // 8), 'float64')
+
+	masks_from = None
+	if args.placeholder_masks:
+		m = np.zeros((Nt, H, W), dtype='uint8')
+		rr = np.rint(scene.star_params[:, 0, 0]).astype(int)
+		cc = np.rint(scene.star_params[:, 0, 1]).astype(int)
+		for d in range(-2, 3):
+			for e in range(-2, 3):
+				m[np.arange(Nt), np.clip(rr + d, 0, H-1), np.clip(cc + e, 0, W-1)] = 1
+		masks_from = (ctx.array(m), ctx.array(np.ones(Nt, dtype='int32')))
+		work.mask, work.status = masks_from
+
+	for _ in range(args.warmup):
+		pipeline.aperture_step(ctx, batch, work, masks_from=masks_from)
+	device_sync()
+	barrier()
+	ctx.profile(True)
+	ctx.profile_reset()
+	t0 = time.perf_counter()
+	for _ in range(args.steps):
+		pipeline.aperture_step(ctx, batch, work, masks_from=masks_from)
+	if world > 1 and not args.no_gather:
+		tpcomm.gather(ctx, work.lc.block, gather_buf, root=0)
+	device_sync()
+	barrier()
+	elapsed = time.perf_counter() - t0
+	ctx.profile(False)
+	if dist is not None:
+		t = torch.tensor([elapsed], dtype=torch.float64)
+		dist.all_reduce(t, op=dist.ReduceOp.MAX)
+		elapsed = float(t[0])
+
+	prof = ctx.profile_report()
+
+	result = None
+	if rank == 0:
+		total_targets = Nt * world * args.steps
+		value = total_targets / elapsed
+		P = H * W
+		# algorithmic bytes per target
+		alg = {
+			'tp_sumimage_kernel': P*T*4 + T*4 + P*8,
+			'tp_aperture_kernel': 3*P*T*4 + P + 5*T*8,
+		}
+		kernels = {}
+		for name, (n, ms) in prof.items():
+			avg = ms / n
+			k = {'launches': n, 'avg_ms': avg}
+			if name in alg:
+				k['algorithmic_bytes_per_launch'] = alg[name] * Nt
+				k['achieved_GBps'] = alg[name] * Nt / (avg * 1e-3) / 1e9
+			kernels[name] = k
+		dom = max((k for k in kernels if k in alg), key=lambda k: kernels[k]['avg_ms'])
+		roofline = {
+			'kernel': dom, 'bound': 'hbm', 'achieved': kernels[dom]['achieved_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+			'frac': kernels[dom]['achieved_GBps'] / HBM_PEAK_GBS, 'traffic': None,
+			'avg_kernel_ms': kernels[dom]['avg_ms'],
+		}
+		result = {
+			'metric': 'targets/sec (whole node), 10k targets x 1300 cad x 15x15, aperture + background',
+			'value': value, 'unit': 'targets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+			'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+			'dtype': 'f32', 'data': 'synthetic',
+			'config': {'workload': f'{Nt} targets/GPU x {T} cadences x {H}x{W} stamps, aperture photometry '
+				'(sum image + K2P2 masks + extraction) with images/err/background cubes resident in HBM',
+				'targets_per_gpu': Nt, 'cadences': T, 'stamp': [H, W], 'parallelism': f'targets sharded over {world} GPU(s)'},
+			'roofline': roofline,
+			'kernels': kernels,
+		}
+
+	# ---- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample of the same cubes -----
+	if rank == 0 and world == 1 and args.cpu_sample > 0 and not args.placeholder_masks:
+		ns = min(args.cpu_sample, Nt)
+		sub = scene.subset(slice(0, ns))
+		for name in ('images', 'images_err', 'backgrounds'):
+			cube = cubes[name]
+			host = np.empty((ns, H, W, cube.t_pitch), dtype='float32')
+			ctx._check(ctx.lib.tp_memcpy_d2h(ctx.handle, host.ctypes.data, cube.ptr, host.nbytes))
+			setattr(sub, name, np.ascontiguousarray(host[..., :T]))
+		sub.aperture = np.ones((ns, H, W), dtype='int32')
+		cores = len(os.sched_getaffinity(0))
+		# (a) one process, one core -- the analogue of one MPI worker
+		n1 = max(1, min(ns, 24))
+		t1, res1 = _cpu_worker(sub.subset(slice(0, n1)))
+		# (b) all host cores
+		import multiprocessing as mp
+		chunks = [sub.subset(slice(c, ns, cores)) for c in range(cores) if c < ns]
+		tw0 = time.perf_counter()
+		with mp.get_context('fork').Pool(len(chunks)) as pool:
+			rr = pool.map(_cpu_worker, chunks)
+		twall = time.perf_counter() - tw0
+		result['cpu_baseline'] = {
+			'value': ns / twall, 'unit': 'targets/s', 'cores': len(chunks), 'kind': 'port',
+			'sample': f'{ns} of the {Nt} targets (same device-generated cubes), oracle = numpy restatement of the reference per-cadence loop, '
+				f'{len(chunks)} processes',
+			'single_core_targets_per_s': n1 / t1,
+		}
+		result['speedup_vs_cpu_host'] = result['value'] / (ns / twall)
+		# parity of the sample while we are here
+		lc = work.lc.to_host()
+		masks = work.mask.to_host()
+		status = work.status.to_host()
+		bad = 0
+		for c, (_, out) in enumerate(rr):
+			for j, r in enumerate(out):
+				i = c + j * cores
+				ok = int(status[i]) == r['status']
+				if ok and r['mask'] is not None:
+					ok = np.array_equal(masks[i].astype(bool), r['mask']) and np.array_equal(lc['flux'][i], r['flux'], equal_nan=True) \
+						and np.array_equal(lc['flux_err'][i], r['flux_err'], equal_nan=True)
+				bad += (not ok)
+		result['parity_sample'] = {'targets': ns, 'mismatches': int(bad)}
+
+	if rank == 0:
+		print(json.dumps(result))
+	if dist is not None:
+		dist.barrier()
+		dist.destroy_process_group()
+	ctx.close()
+
+
+if __name__ == '__main__':
+	main()

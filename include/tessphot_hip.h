@@ -1,0 +1,161 @@
+/*
+ * tessphot_hip.h -- C ABI of libtessphot_hip.so: the MI355X (gfx950) native per-target
+ * photometry engine for the tasoc/photometry hot path.
+ *
+ * The reference is pure Python and has no FFI of its own; each entry point below names the
+ * reference code (file:line, relative to the reference repository root) whose work it
+ * replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ * -----------
+ *  - every function returns int: 0 = TP_OK, < 0 = error code; tp_last_error(ctx) returns a
+ *    ctx-owned, NUL-terminated description of the last failure on that ctx.
+ *  - bulk data pointers named d_* are DEVICE pointers (HBM) obtained from tp_malloc (or any
+ *    hipMalloc in the same process); pointers named h_* are host pointers.
+ *  - the caller allocates and owns every buffer; the library never frees caller memory and
+ *    keeps no pointer past the call.
+ *  - all work is enqueued on the ctx's own HIP stream, in call order.  Calls return when
+ *    the work is enqueued; tp_sync() (or a d2h copy) waits for it.
+ *  - per-target failure is reported through int32 status arrays holding the reference's
+ *    STATUS integers (photometry/BasePhotometry.py:48-59): 0 UNKNOWN, 1 OK, 2 ERROR,
+ *    3 WARNING, 4 ABORT, 5 SKIPPED, 6 STARTED.  No C++ exception crosses the ABI.
+ *  - one ctx per host thread; calls on one ctx are not thread-safe.
+ *
+ * Cube layout
+ * -----------
+ *  A stamp cube is float32 [n_targets][height][width][t_pitch]: per target exactly the
+ *  reference's (rows, cols, times) C-order cube with TIME as the fastest axis
+ *  (photometry/BasePhotometry.py:732), t_pitch >= n_cad elements between the time series
+ *  of consecutive pixels.  t_pitch % 4 == 0 and a 16-byte aligned base select the
+ *  128-bit load path; anything else still works on the scalar path.
+ */
+#ifndef TESSPHOT_HIP_H
+#define TESSPHOT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TP_OK               0
+#define TP_ERR_INVALID     -1   /* bad argument */
+#define TP_ERR_HIP         -2   /* HIP runtime error (text in tp_last_error) */
+#define TP_ERR_NOMEM       -3
+#define TP_ERR_COMM        -4   /* RCCL error */
+#define TP_ERR_UNSUPPORTED -5
+
+/* STATUS integers, photometry/BasePhotometry.py:48-59 */
+#define TP_STATUS_UNKNOWN 0
+#define TP_STATUS_OK      1
+#define TP_STATUS_ERROR   2
+#define TP_STATUS_WARNING 3
+#define TP_STATUS_ABORT   4
+#define TP_STATUS_SKIPPED 5
+#define TP_STATUS_STARTED 6
+
+typedef struct tp_ctx tp_ctx;
+
+typedef struct tp_cube_desc {
+	int32_t n_targets;
+	int32_t n_cad;      /* T: number of cadences */
+	int32_t height;     /* H: stamp rows */
+	int32_t width;      /* W: stamp columns */
+	int64_t t_pitch;    /* elements between consecutive pixels' time series (>= n_cad) */
+} tp_cube_desc;
+
+/* ---- context, memory, timing ------------------------------------------------------------ */
+int tp_version(void);
+int tp_device_count(int* n);
+int tp_ctx_create(int device, tp_ctx** out);
+int tp_ctx_destroy(tp_ctx* ctx);
+const char* tp_last_error(tp_ctx* ctx);      /* ctx may be NULL: last tp_ctx_create failure */
+int tp_device_info(tp_ctx* ctx, char* name, int name_len, int32_t* n_cu, uint64_t* hbm_bytes);
+
+int tp_malloc(tp_ctx* ctx, uint64_t nbytes, void** d_ptr);
+int tp_free(tp_ctx* ctx, void* d_ptr);
+int tp_memset(tp_ctx* ctx, void* d_ptr, int value, uint64_t nbytes);
+int tp_memcpy_h2d(tp_ctx* ctx, void* d_dst, const void* h_src, uint64_t nbytes);
+int tp_memcpy_d2h(tp_ctx* ctx, void* h_dst, const void* d_src, uint64_t nbytes);   /* waits */
+int tp_memcpy_d2d(tp_ctx* ctx, void* d_dst, const void* d_src, uint64_t nbytes);
+/* Copy n_rows time series of n_cad float32 between pitched layouts (host -> device): the host
+ * cube of BasePhotometry._load_cube (BasePhotometry.py:720-751) has pitch n_cad. */
+int tp_upload_cube(tp_ctx* ctx, float* d_dst, int64_t dst_pitch, const float* h_src, int64_t src_pitch,
+	int64_t n_rows, int64_t n_cad);
+int tp_sync(tp_ctx* ctx);
+
+/* HIP-event stopwatch on the ctx stream; slot in [0, 16). */
+int tp_timer_start(tp_ctx* ctx, int slot);
+int tp_timer_stop(tp_ctx* ctx, int slot);
+int tp_timer_elapsed_ms(tp_ctx* ctx, int slot, float* ms);   /* waits for the stop event */
+
+/* Per-kernel profile: when enabled every kernel launch is bracketed by HIP events on the
+ * ctx stream.  kernel ids are dense in [0, tp_kernel_count()). */
+int tp_profile_enable(tp_ctx* ctx, int on);
+int tp_profile_reset(tp_ctx* ctx);
+int tp_kernel_count(void);
+const char* tp_kernel_name(int kernel_id);
+int tp_profile_get(tp_ctx* ctx, int kernel_id, int64_t* n_launches, double* total_ms);   /* waits */
+
+/* ---- A1: sum image ------------------------------------------------------------------------
+ * replaces BasePhotometry.sumimage (photometry/BasePhotometry.py:1008-1019) and the FFI
+ * accumulation of prepare.py:450-453,459: per-pixel mean over the cadences with
+ * (quality & bitmask) == 0 (TESSQualityFlags.DEFAULT_BITMASK = 4335, quality.py:123-124),
+ * non-finite pixels excluded from sum and count, zero count -> NaN.  float64 accumulation.
+ *   d_quality: int32 [n_cad] shared by all targets (quality_target_stride = 0) or
+ *              [n_targets][quality_target_stride].
+ *   d_sumimage: float64 [n_targets][height*width].                                          */
+int tp_sumimage(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
+	const int32_t* d_quality, int64_t quality_target_stride, uint32_t bitmask, double* d_sumimage);
+
+/* ---- A6: aperture extraction ---------------------------------------------------------------
+ * replaces the per-cadence loop of AperturePhotometry.do_photometry
+ * (photometry/AperturePhotometry/photometry.py:172-201): in-mask flux (float32 np.sum order,
+ * bit-exact), flux error sqrt(sum err^2), flux-weighted centroid over pixels with flux > 0 in
+ * 1-based CCD (column, row) coordinates, nansum of the background; NaN rules of :182-201.
+ *   d_backgrounds: bkg_mode 0: cube with the layout of desc;
+ *                  bkg_mode 1: one series per target, float32 [n_targets][bkg_series_pitch]
+ *                  (a stamp-constant background: every pixel of a cadence has the same value).
+ *   d_mask:   uint8 [n_targets][height*width], non-zero = in aperture (final_phot_mask).
+ *   d_stamps: int32 [n_targets][4] = (row_min, row_max, col_min, col_max), BasePhotometry.stamp.
+ *   d_status: optional int32 [n_targets]; targets whose status is TP_STATUS_ERROR are skipped
+ *             (outputs untouched), like the early returns of photometry.py:116,163,170.
+ *   outputs:  float64 [n_targets][out_pitch] each (lightcurve columns, BasePhotometry.py:425-428);
+ *             d_centroid_col / d_centroid_row are pos_centroid[:,0] / [:,1].                   */
+int tp_aperture_extract(tp_ctx* ctx, const tp_cube_desc* desc,
+	const float* d_images, const float* d_images_err, const float* d_backgrounds,
+	int32_t bkg_mode, int64_t bkg_series_pitch,
+	const uint8_t* d_mask, const int32_t* d_stamps, const int32_t* d_status,
+	double* d_flux, double* d_flux_err, double* d_flux_background,
+	double* d_centroid_col, double* d_centroid_row, int64_t out_pitch);
+
+/* ---- multi-GPU: the final light-curve gather (RCCL over xGMI) --------------------------------
+ * replaces the pickled result messages of run_tessphot_mpi.py:114-132,163-191: targets are
+ * statically sharded over the ranks (one process per GPU) and the only data-path exchange is one
+ * gather of the output block.  Rank 0 obtains the 128-byte id and distributes it out of band
+ * (torch.distributed store, mpi4py bcast, a file ...), then every rank calls tp_comm_init.
+ * With a single rank (no tp_comm_init) gather/allgather degenerate to a device copy.           */
+int tp_comm_unique_id(char* id_out, int id_len);                       /* id_len >= 128 */
+int tp_comm_init(tp_ctx* ctx, const char* id, int id_len, int rank, int n_ranks);
+int tp_comm_destroy(tp_ctx* ctx);
+int tp_comm_info(tp_ctx* ctx, int* rank, int* n_ranks);
+/* d_recv (root only) holds n_ranks * nbytes_per_rank bytes, rank r's block at r * nbytes_per_rank */
+int tp_comm_gather(tp_ctx* ctx, const void* d_send, void* d_recv, uint64_t nbytes_per_rank, int root);
+int tp_comm_allgather(tp_ctx* ctx, const void* d_send, void* d_recv, uint64_t nbytes_per_rank);
+
+/* ---- synthetic data (bench / test utility, not part of the reference path) -----------------
+ * Fill images / images_err / backgrounds cubes on the device from scene parameters, following
+ * the data model of simulation/simulateFITS.py:338-405 (see photometry_amd/simulate.py).
+ *   d_star_params: float64 [n_targets][n_slots][3] = (row_stamp, col_stamp, flux); flux 0 = unused
+ *   d_sigma_psf, d_bkg_level, d_bkg_phase: float64 [n_targets]
+ *   d_jitter: float64 [n_cad][2] (column, row) per-cadence shift
+ *   any of d_images / d_images_err / d_backgrounds / d_raw may be NULL.                        */
+int tp_synth_fill(tp_ctx* ctx, const tp_cube_desc* desc, int32_t n_slots,
+	const double* d_star_params, const double* d_sigma_psf, const double* d_bkg_level,
+	const double* d_bkg_phase, const double* d_jitter, double readnoise, double nan_fraction,
+	uint64_t seed, float* d_images, float* d_images_err, float* d_backgrounds, float* d_raw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TESSPHOT_HIP_H */

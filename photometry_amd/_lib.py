@@ -1,0 +1,110 @@
+# -*- coding: utf-8 -*-
+"""
+ctypes binding of ``libtessphot_hip.so`` (declared in ``include/tessphot_hip.h``).
+
+There is deliberately NO fallback: if the shared library is missing or cannot be loaded
+:func:`load` raises :class:`TessphotLibraryError`, and every compute entry point of the
+package goes through :func:`load`.
+"""
+
+import os
+import ctypes
+from ctypes import (c_int, c_int32, c_int64, c_uint32, c_uint64, c_uint8, c_float, c_double, c_char_p, c_void_p, POINTER,
+	Structure, byref)
+
+LIB_NAME = 'libtessphot_hip.so'
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+
+class TessphotLibraryError(RuntimeError):
+	"""The HIP library is missing / not loadable: the engine cannot run."""
+
+
+class TessphotError(RuntimeError):
+	"""A library call returned an error code."""
+	def __init__(self, code, message):
+		super().__init__(f"libtessphot_hip error {code}: {message}")
+		self.code = code
+
+
+class tp_cube_desc(Structure):
+	_fields_ = [('n_targets', c_int32), ('n_cad', c_int32), ('height', c_int32), ('width', c_int32), ('t_pitch', c_int64)]
+
+
+class tp_k2p2_params(Structure):
+	_fields_ = [('thresh', c_double), ('min_no_pixels_in_mask', c_int32), ('min_for_cluster', c_int32),
+		('ws_footprint', c_int32), ('extend_overflow', c_int32), ('ws_thres', c_double), ('saturation_limit', c_double)]
+
+
+_p = c_void_p # device / host data pointers are passed as integers
+_desc_p = POINTER(tp_cube_desc)
+
+#: name -> (restype, argtypes); mirrors include/tessphot_hip.h exactly.
+SIGNATURES = {
+	'tp_version': (c_int, []),
+	'tp_device_count': (c_int, [POINTER(c_int)]),
+	'tp_ctx_create': (c_int, [c_int, POINTER(c_void_p)]),
+	'tp_ctx_destroy': (c_int, [c_void_p]),
+	'tp_last_error': (c_char_p, [c_void_p]),
+	'tp_device_info': (c_int, [c_void_p, c_char_p, c_int, POINTER(c_int32), POINTER(c_uint64)]),
+	'tp_malloc': (c_int, [c_void_p, c_uint64, POINTER(c_void_p)]),
+	'tp_free': (c_int, [c_void_p, _p]),
+	'tp_memset': (c_int, [c_void_p, _p, c_int, c_uint64]),
+	'tp_memcpy_h2d': (c_int, [c_void_p, _p, _p, c_uint64]),
+	'tp_memcpy_d2h': (c_int, [c_void_p, _p, _p, c_uint64]),
+	'tp_memcpy_d2d': (c_int, [c_void_p, _p, _p, c_uint64]),
+	'tp_upload_cube': (c_int, [c_void_p, _p, c_int64, _p, c_int64, c_int64, c_int64]),
+	'tp_sync': (c_int, [c_void_p]),
+	'tp_timer_start': (c_int, [c_void_p, c_int]),
+	'tp_timer_stop': (c_int, [c_void_p, c_int]),
+	'tp_timer_elapsed_ms': (c_int, [c_void_p, c_int, POINTER(c_float)]),
+	'tp_profile_enable': (c_int, [c_void_p, c_int]),
+	'tp_profile_reset': (c_int, [c_void_p]),
+	'tp_kernel_count': (c_int, []),
+	'tp_kernel_name': (c_char_p, [c_int]),
+	'tp_profile_get': (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_double)]),
+	'tp_sumimage': (c_int, [c_void_p, _desc_p, _p, _p, c_int64, c_uint32, _p]),
+	'tp_aperture_extract': (c_int, [c_void_p, _desc_p, _p, _p, _p, c_int32, c_int64, _p, _p, _p,
+		_p, _p, _p, _p, _p, c_int64]),
+	'tp_comm_unique_id': (c_int, [c_char_p, c_int]),
+	'tp_comm_init': (c_int, [c_void_p, c_char_p, c_int, c_int, c_int]),
+	'tp_comm_destroy': (c_int, [c_void_p]),
+	'tp_comm_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+	'tp_comm_gather': (c_int, [c_void_p, _p, _p, c_uint64, c_int]),
+	'tp_comm_allgather': (c_int, [c_void_p, _p, _p, c_uint64]),
+	'tp_synth_fill': (c_int, [c_void_p, _desc_p, c_int32, _p, _p, _p, _p, _p, c_double, c_double, c_uint64, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+def load():
+	"""Load (once) and return the ctypes library; raises TessphotLibraryError if impossible."""
+	global _lib
+	if _lib is not None:
+		return _lib
+	if not os.path.exists(LIB_PATH):
+		raise TessphotLibraryError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+			"(or `make -C photometry_amd/csrc`).  photometry_amd has no CPU fallback.")
+	try:
+		lib = ctypes.CDLL(LIB_PATH)
+	except OSError as e:
+		raise TessphotLibraryError(f"could not load {LIB_PATH}: {e}") from e
+	for name, (restype, argtypes) in SIGNATURES.items():
+		try:
+			fn = getattr(lib, name)
+		except AttributeError as e:
+			raise TessphotLibraryError(f"{LIB_PATH} does not export {name}") from e
+		fn.restype = restype
+		fn.argtypes = argtypes
+	_lib = lib
+	return lib
+
+
+def exported_symbols():
+	"""Names declared in the header table (used by the CPU symbol test)."""
+	return sorted(SIGNATURES.keys())
+
+
+__all__ = ['load', 'TessphotError', 'TessphotLibraryError', 'tp_cube_desc', 'tp_k2p2_params', 'SIGNATURES', 'LIB_PATH',
+	'byref', 'c_void_p', 'c_int', 'c_int32', 'c_int64', 'c_uint64', 'c_float', 'c_double', 'c_uint8']

@@ -1,0 +1,460 @@
+// aperture.hip -- A6: per-cadence in-mask flux / error / centroid / background sums.
+//
+// Replaces the extraction loop of AperturePhotometry.do_photometry
+// (photometry/AperturePhotometry/photometry.py:172-201).
+//
+// Mapping (gfx950): one workgroup per target, one THREAD per group of 4 consecutive cadences.
+// The cube is time-fastest (BasePhotometry.py:732), so for a given mask pixel the 64 lanes of a
+// wavefront read 64 x 16 B = 1 KiB of consecutive cadences: fully coalesced 128-bit loads, and
+// only the rows of pixels that are IN the mask are ever touched.  Every thread owns its cadences'
+// accumulators, so there is no cross-lane reduction at all; the only LDS use is the ordered list of
+// mask pixels (raster order), built once per workgroup by wavefront 0 with ballot compaction.
+//
+// Arithmetic is the reference's, bit for bit where the reference is float32:
+//  * flux     = numpy float32 pairwise np.sum over the mask pixels in raster order (:188):
+//               n < 8 sequential from 0; n <= 128: 8 strided accumulators, combined
+//               ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), tail added sequentially; n > 128: recursive
+//               halves with n2 = n/2 - (n/2)%8  (numpy/core/src/umath/loops_utils.h.src).
+//  * flux_err = sqrtf(pairwise float32 sum of err*err)  (:189)
+//  * centroid = float64 sums of w*col, w*row, w over pixels with flux > 0 (np.average, :192-196),
+//               1-based CCD coordinates (BasePhotometry.get_pixel_grid, BasePhotometry.py:696-706)
+//  * background = bottleneck.nansum: sequential float32 skipping NaN; NaN if all NaN (:198-201)
+//  * all-NaN or all-zero flux in the mask -> flux, flux_err, centroid = NaN (:182-185)
+#include "common.h"
+#include <cmath>
+
+namespace {
+
+constexpr int kMaxList = 128;      // small kernel: mask pixels held in LDS
+constexpr int kChunk = 1024;       // big kernel: ordered mask pixels staged per round
+constexpr int kMaxLeaves = 4096;   // big kernel: pairwise leaves (each 65..128 pixels)
+constexpr int kMaxDepth = 24;
+
+template <int VEC> struct Vec;
+template <> struct Vec<4> {
+	static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+		float4 t = *reinterpret_cast<const float4*>(p);
+		v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+	}
+};
+template <> struct Vec<1> {
+	static __device__ __forceinline__ void load(const float* p, float (&v)[1]) { v[0] = *p; }
+};
+
+// Per-thread state for VEC cadences
+template <int VEC>
+struct CadState {
+	float r[VEC][8];      // pairwise accumulators: flux
+	float e[VEC][8];      // pairwise accumulators: err^2
+	float fres[VEC], eres[VEC];
+	float bsum[VEC];
+	double cw[VEC], ccol[VEC], crow[VEC];
+	bool f_allnan[VEC], f_allzero[VEC], b_allnan[VEC];
+
+	__device__ __forceinline__ void init() {
+#pragma unroll
+		for (int c = 0; c < VEC; c++) {
+			fres[c] = 0.f; eres[c] = 0.f; bsum[c] = 0.f;
+			cw[c] = 0.0; ccol[c] = 0.0; crow[c] = 0.0;
+			f_allnan[c] = true; f_allzero[c] = true; b_allnan[c] = true;
+		}
+	}
+	// everything except the pairwise flux / err sums
+	__device__ __forceinline__ void side(const float (&v)[VEC], const float (&b)[VEC], double col, double row) {
+#pragma unroll
+		for (int c = 0; c < VEC; c++) {
+			const float x = v[c];
+			f_allnan[c] = f_allnan[c] && (x != x);
+			f_allzero[c] = f_allzero[c] && (x == 0.f);
+			if (x > 0.f) {
+				const double w = (double)x;
+				cw[c] += w;
+				ccol[c] += col * w;
+				crow[c] += row * w;
+			}
+			const float y = b[c];
+			if (y == y) { bsum[c] += y; b_allnan[c] = false; }
+		}
+	}
+};
+
+__device__ __forceinline__ float combine8(const float (&r)[8]) {
+	return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+}
+
+struct Args {
+	const float* images; const float* images_err; const float* backgrounds;
+	int32_t bkg_mode; int64_t bkg_series_pitch;
+	const uint8_t* mask; const int32_t* stamps; const int32_t* status;
+	double* flux; double* flux_err; double* flux_bkg; double* ccol; double* crow;
+	int64_t out_pitch; int n_cad; int height; int width; int64_t t_pitch;
+};
+
+template <int VEC>
+__device__ __forceinline__ void store_outputs(const Args& a, int target, int k0, const CadState<VEC>& st, int M) {
+	const int64_t ob = (int64_t)target * a.out_pitch;
+	const double nan = __builtin_nan("");
+#pragma unroll
+	for (int c = 0; c < VEC; c++) {
+		const int k = k0 + c;
+		if (k >= a.n_cad) continue;
+		const bool bad = (M == 0) || st.f_allnan[c] || st.f_allzero[c];
+		a.flux[ob + k] = bad ? nan : (double)st.fres[c];
+		a.flux_err[ob + k] = bad ? nan : (double)sqrtf(st.eres[c]);
+		const bool haspos = st.cw[c] > 0.0;
+		a.ccol[ob + k] = (bad || !haspos) ? nan : st.ccol[c] / st.cw[c];
+		a.crow[ob + k] = (bad || !haspos) ? nan : st.crow[c] / st.cw[c];
+		a.flux_bkg[ob + k] = (M == 0 || st.b_allnan[c]) ? nan : (double)st.bsum[c];
+	}
+}
+
+// Ordered (raster) compaction of the next mask pixels starting at *p_next into list[0..cap), by
+// ONE wavefront.  Returns the number stored; advances *p_next.  With count_rest, keeps counting
+// (without storing) to the end of the mask and returns the total in *total.
+__device__ __forceinline__ int compact_mask(const uint8_t* m, int P, int& p_next, int* list, int cap, int lane,
+	bool count_rest, int* total)
+{
+	int n = 0;
+	int p0 = p_next;
+	for (; p0 < P; p0 += 64) {
+		const int p = p0 + lane;
+		const bool in = (p < P) && (m[p] != 0);
+		const unsigned long long bal = __ballot(in);
+		const int pos = n + __popcll(bal & ((1ull << lane) - 1ull));
+		const int cnt = __popcll(bal);
+		if (n + cnt > cap) {
+			if (!count_rest) {
+				// store only what fits, stop *inside* this group: find the pixel where the list fills
+				if (in && pos < cap) list[pos] = p;
+				// p_next = index of the first pixel NOT stored
+				const unsigned long long notstored = __ballot(in && pos >= cap);
+				p_next = p0 + (int)__ffsll((long long)notstored) - 1;
+				return cap;
+			}
+			if (in && pos < cap) list[pos] = p;
+			n += cnt;
+			continue;
+		}
+		if (in && pos < cap) list[pos] = p;
+		n += cnt;
+	}
+	p_next = P;
+	if (total) *total = n;
+	return n < cap ? n : cap;
+}
+
+//--------------------------------------------------------------------------------------------------
+// Small kernel: 0 <= M <= 128 mask pixels (a single pairwise leaf)
+//--------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(512) void tp_aperture_kernel(Args a)
+{
+	__shared__ int s_list[kMaxList];
+	__shared__ int s_M;
+	const int target = blockIdx.x;
+	if (a.status && a.status[target] == TP_STATUS_ERROR) return;
+	const int P = a.height * a.width;
+	const int tid = threadIdx.x;
+	const uint8_t* m = a.mask + (int64_t)target * P;
+	if (tid < 64) {
+		int pn = 0, total = 0;
+		compact_mask(m, P, pn, s_list, kMaxList, tid, true, &total);
+		if (tid == 0) s_M = total;
+	}
+	__syncthreads();
+	const int M = s_M;
+	if (M > kMaxList) return; // handled by tp_aperture_big_kernel
+
+	const int col0 = a.stamps[target * 4 + 2] + 1; // 1-based CCD column of stamp column 0
+	const int row0 = a.stamps[target * 4 + 0] + 1;
+	const int64_t tb = (int64_t)target * P * a.t_pitch;
+	const float* img = a.images + tb;
+	const float* err = a.images_err + tb;
+	const float* bkg = (a.bkg_mode == 0) ? (a.backgrounds + tb) : (a.backgrounds + (int64_t)target * a.bkg_series_pitch);
+	const int nq = (a.n_cad + VEC - 1) / VEC;
+	const int nblk = M - (M & 7);
+
+	for (int q = tid; q < nq; q += blockDim.x) {
+		const int k0 = q * VEC;
+		CadState<VEC> st;
+		st.init();
+		float bser[VEC];
+		if (a.bkg_mode != 0) Vec<VEC>::load(bkg + k0, bser);
+
+		auto fetch = [&](int idx, float (&v)[VEC], float (&e2)[VEC]) {
+			const int p = s_list[idx];
+			const int64_t off = (int64_t)p * a.t_pitch + k0;
+			float ee[VEC], bb[VEC];
+			Vec<VEC>::load(img + off, v);
+			Vec<VEC>::load(err + off, ee);
+			if (a.bkg_mode == 0) Vec<VEC>::load(bkg + off, bb);
+			else {
+#pragma unroll
+				for (int c = 0; c < VEC; c++) bb[c] = bser[c];
+			}
+			const int pr = p / a.width;
+			const int pc = p - pr * a.width;
+#pragma unroll
+			for (int c = 0; c < VEC; c++) e2[c] = ee[c] * ee[c];
+			st.side(v, bb, (double)(col0 + pc), (double)(row0 + pr));
+		};
+
+		if (M < 8) {
+			for (int i = 0; i < M; i++) {
+				float v[VEC], e2[VEC];
+				fetch(i, v, e2);
+#pragma unroll
+				for (int c = 0; c < VEC; c++) { st.fres[c] += v[c]; st.eres[c] += e2[c]; }
+			}
+		} else {
+			for (int g = 0; g < nblk; g += 8) {
+#pragma unroll
+				for (int j = 0; j < 8; j++) {
+					float v[VEC], e2[VEC];
+					fetch(g + j, v, e2);
+#pragma unroll
+					for (int c = 0; c < VEC; c++) {
+						if (g == 0) { st.r[c][j] = v[c]; st.e[c][j] = e2[c]; }
+						else { st.r[c][j] += v[c]; st.e[c][j] += e2[c]; }
+					}
+				}
+			}
+#pragma unroll
+			for (int c = 0; c < VEC; c++) { st.fres[c] = combine8(st.r[c]); st.eres[c] = combine8(st.e[c]); }
+			for (int i = nblk; i < M; i++) {
+				float v[VEC], e2[VEC];
+				fetch(i, v, e2);
+#pragma unroll
+				for (int c = 0; c < VEC; c++) { st.fres[c] += v[c]; st.eres[c] += e2[c]; }
+			}
+		}
+		// np.sum = 0 + pairwise_sum (identity-initialised reduce)
+#pragma unroll
+		for (int c = 0; c < VEC; c++) { st.fres[c] = 0.f + st.fres[c]; st.eres[c] = 0.f + st.eres[c]; }
+		store_outputs<VEC>(a, target, k0, st, M);
+	}
+}
+
+//--------------------------------------------------------------------------------------------------
+// Big kernel: M > 128 (numpy's recursive pairwise tree).  Every leaf except the last is a
+// multiple of 8 long, so the ordered pixel stream is consumed in groups of 8.
+//--------------------------------------------------------------------------------------------------
+__device__ void build_leaves(int n, int* leaf_len, unsigned char* leaf_merges, int* n_leaves)
+{
+	// iterative post-order of:  rec(n): n <= 128 ? leaf : (rec(n2), rec(n - n2), merge)
+	int stack_n[kMaxDepth * 2];
+	unsigned char stack_state[kMaxDepth * 2];
+	int sp = 0, nl = 0;
+	stack_n[0] = n; stack_state[0] = 0; sp = 1;
+	while (sp > 0) {
+		const int cur = stack_n[sp - 1];
+		const int state = stack_state[sp - 1];
+		if (cur <= 128) {
+			if (nl < kMaxLeaves) { leaf_len[nl] = cur; leaf_merges[nl] = 0; }
+			nl++;
+			sp--;
+			continue;
+		}
+		int n2 = cur / 2;
+		n2 -= n2 % 8;
+		if (state == 0) { stack_state[sp - 1] = 1; stack_n[sp] = n2; stack_state[sp] = 0; sp++; }
+		else if (state == 1) { stack_state[sp - 1] = 2; stack_n[sp] = cur - n2; stack_state[sp] = 0; sp++; }
+		else { if (nl - 1 < kMaxLeaves) leaf_merges[nl - 1]++; sp--; }
+	}
+	*n_leaves = nl;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
+{
+	__shared__ int s_list[kChunk];
+	__shared__ int s_leaf_len[kMaxLeaves];
+	__shared__ unsigned char s_leaf_merges[kMaxLeaves];
+	__shared__ int s_M, s_nleaves, s_n, s_pnext;
+	const int target = blockIdx.x;
+	if (a.status && a.status[target] == TP_STATUS_ERROR) return;
+	const int P = a.height * a.width;
+	const int tid = threadIdx.x;
+	const uint8_t* m = a.mask + (int64_t)target * P;
+	if (tid < 64) {
+		int pn = 0, total = 0;
+		compact_mask(m, P, pn, s_list, 0, tid, true, &total);
+		if (tid == 0) s_M = total;
+	}
+	__syncthreads();
+	const int M = s_M;
+	if (M <= kMaxList) return; // handled by tp_aperture_kernel
+	if (tid == 0) { build_leaves(M, s_leaf_len, s_leaf_merges, &s_nleaves); s_pnext = 0; }
+	__syncthreads();
+	if (s_nleaves > kMaxLeaves) return; // host validates height*width so this cannot trigger
+
+	const int col0 = a.stamps[target * 4 + 2] + 1;
+	const int row0 = a.stamps[target * 4 + 0] + 1;
+	const int64_t tb = (int64_t)target * P * a.t_pitch;
+	const float* img = a.images + tb;
+	const float* err = a.images_err + tb;
+	const float* bkg = (a.bkg_mode == 0) ? (a.backgrounds + tb) : (a.backgrounds + (int64_t)target * a.bkg_series_pitch);
+	const int nq = (a.n_cad + VEC - 1) / VEC;
+	const int nrounds_q = (nq + (int)blockDim.x - 1) / (int)blockDim.x;
+
+	for (int qr = 0; qr < nrounds_q; qr++) {
+		const int q = qr * blockDim.x + tid;
+		const bool active = q < nq;
+		const int k0 = q * VEC;
+		CadState<VEC> st;
+		st.init();
+		float bser[VEC];
+		if (active && a.bkg_mode != 0) Vec<VEC>::load(bkg + k0, bser);
+		float stk_f[VEC][kMaxDepth], stk_e[VEC][kMaxDepth];
+		int sp = 0;
+		int leaf = 0, pos_in_leaf = 0;
+		int done = 0; // mask pixels consumed so far
+
+		__syncthreads();
+		if (tid == 0) s_pnext = 0;
+		__syncthreads();
+
+		while (done < M) {
+			// stage the next <= kChunk ordered mask pixels (a multiple of 8 unless it is the end)
+			if (tid < 64) {
+				int pn = s_pnext;
+				const int n = compact_mask(m, P, pn, s_list, kChunk, tid, false, nullptr);
+				if (tid == 0) { s_n = n; s_pnext = pn; }
+			}
+			__syncthreads();
+			const int n = s_n;
+			if (active) {
+				int i = 0;
+				while (i < n) {
+					const int L = s_leaf_len[leaf];
+					const int Lblk = L - (L & 7);
+					if (pos_in_leaf < Lblk) {
+						// a full group of 8 (groups never straddle a chunk: kChunk % 8 == 0 and only the last leaf has a tail)
+#pragma unroll
+						for (int j = 0; j < 8; j++) {
+							const int p = s_list[i + j];
+							const int64_t off = (int64_t)p * a.t_pitch + k0;
+							float v[VEC], ee[VEC], bb[VEC];
+							Vec<VEC>::load(img + off, v);
+							Vec<VEC>::load(err + off, ee);
+							if (a.bkg_mode == 0) Vec<VEC>::load(bkg + off, bb);
+							else {
+#pragma unroll
+								for (int c = 0; c < VEC; c++) bb[c] = bser[c];
+							}
+							const int pr = p / a.width;
+							const int pc = p - pr * a.width;
+							st.side(v, bb, (double)(col0 + pc), (double)(row0 + pr));
+#pragma unroll
+							for (int c = 0; c < VEC; c++) {
+								const float e2 = ee[c] * ee[c];
+								if (pos_in_leaf == 0) { st.r[c][j] = v[c]; st.e[c][j] = e2; }
+								else { st.r[c][j] += v[c]; st.e[c][j] += e2; }
+							}
+						}
+						i += 8;
+						pos_in_leaf += 8;
+						if (pos_in_leaf == Lblk) {
+#pragma unroll
+							for (int c = 0; c < VEC; c++) { st.fres[c] = combine8(st.r[c]); st.eres[c] = combine8(st.e[c]); }
+						}
+					} else {
+						// tail element of the (last) leaf
+						const int p = s_list[i];
+						const int64_t off = (int64_t)p * a.t_pitch + k0;
+						float v[VEC], ee[VEC], bb[VEC];
+						Vec<VEC>::load(img + off, v);
+						Vec<VEC>::load(err + off, ee);
+						if (a.bkg_mode == 0) Vec<VEC>::load(bkg + off, bb);
+						else {
+#pragma unroll
+							for (int c = 0; c < VEC; c++) bb[c] = bser[c];
+						}
+						const int pr = p / a.width;
+						const int pc = p - pr * a.width;
+						st.side(v, bb, (double)(col0 + pc), (double)(row0 + pr));
+#pragma unroll
+						for (int c = 0; c < VEC; c++) { st.fres[c] += v[c]; st.eres[c] += ee[c] * ee[c]; }
+						i += 1;
+						pos_in_leaf += 1;
+					}
+					if (pos_in_leaf == L) {
+						// leaf complete: push, then perform the merges that follow it in post-order
+#pragma unroll
+						for (int c = 0; c < VEC; c++) { stk_f[c][sp] = st.fres[c]; stk_e[c][sp] = st.eres[c]; }
+						sp++;
+						for (int mm = 0; mm < (int)s_leaf_merges[leaf]; mm++) {
+#pragma unroll
+							for (int c = 0; c < VEC; c++) {
+								stk_f[c][sp - 2] = stk_f[c][sp - 2] + stk_f[c][sp - 1];
+								stk_e[c][sp - 2] = stk_e[c][sp - 2] + stk_e[c][sp - 1];
+							}
+							sp--;
+						}
+						leaf++;
+						pos_in_leaf = 0;
+					}
+				}
+			}
+			done += n;
+			__syncthreads();
+		}
+		if (active) {
+#pragma unroll
+			for (int c = 0; c < VEC; c++) { st.fres[c] = 0.f + stk_f[c][0]; st.eres[c] = 0.f + stk_e[c][0]; }
+			store_outputs<VEC>(a, target, k0, st, M);
+		}
+	}
+}
+
+} // namespace
+
+extern "C" int tp_aperture_extract(tp_ctx* ctx, const tp_cube_desc* desc,
+	const float* d_images, const float* d_images_err, const float* d_backgrounds,
+	int32_t bkg_mode, int64_t bkg_series_pitch,
+	const uint8_t* d_mask, const int32_t* d_stamps, const int32_t* d_status,
+	double* d_flux, double* d_flux_err, double* d_flux_background,
+	double* d_centroid_col, double* d_centroid_row, int64_t out_pitch)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, tp_desc_ok(desc), "tp_aperture_extract: bad cube descriptor");
+	TP_REQUIRE(ctx, d_images && d_images_err && d_backgrounds && d_mask && d_stamps, "tp_aperture_extract: null input pointer");
+	TP_REQUIRE(ctx, d_flux && d_flux_err && d_flux_background && d_centroid_col && d_centroid_row, "tp_aperture_extract: null output pointer");
+	TP_REQUIRE(ctx, out_pitch >= desc->n_cad, "tp_aperture_extract: out_pitch < n_cad");
+	TP_REQUIRE(ctx, bkg_mode == 0 || bkg_mode == 1, "tp_aperture_extract: bkg_mode must be 0 (cube) or 1 (series)");
+	TP_REQUIRE(ctx, bkg_mode == 0 || bkg_series_pitch >= desc->n_cad, "tp_aperture_extract: bad bkg_series_pitch");
+	TP_REQUIRE(ctx, (int64_t)desc->height * desc->width <= (int64_t)kMaxLeaves * 64, "tp_aperture_extract: stamp too large");
+	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
+
+	Args a;
+	a.images = d_images; a.images_err = d_images_err; a.backgrounds = d_backgrounds;
+	a.bkg_mode = bkg_mode; a.bkg_series_pitch = bkg_series_pitch;
+	a.mask = d_mask; a.stamps = d_stamps; a.status = d_status;
+	a.flux = d_flux; a.flux_err = d_flux_err; a.flux_bkg = d_flux_background;
+	a.ccol = d_centroid_col; a.crow = d_centroid_row;
+	a.out_pitch = out_pitch; a.n_cad = desc->n_cad; a.height = desc->height; a.width = desc->width;
+	a.t_pitch = desc->t_pitch;
+
+	bool vec4 = tp_vec4_ok(d_images, desc->t_pitch) && tp_vec4_ok(d_images_err, desc->t_pitch);
+	if (bkg_mode == 0) vec4 = vec4 && tp_vec4_ok(d_backgrounds, desc->t_pitch);
+	else vec4 = vec4 && tp_vec4_ok(d_backgrounds, bkg_series_pitch);
+	const int vec = vec4 ? 4 : 1;
+	const int nq = (desc->n_cad + vec - 1) / vec;
+	int threads = ((nq + 63) / 64) * 64;
+	if (threads > 512) threads = 512;
+	dim3 grid((unsigned)desc->n_targets), block((unsigned)threads);
+	if (vec4) {
+		TP_LAUNCH(ctx, TPK_APERTURE, tp_aperture_kernel<4>, grid, block, 0, a);
+		TP_LAUNCH_CHECK(ctx, "tp_aperture_kernel");
+		TP_LAUNCH(ctx, TPK_APERTURE_BIG, tp_aperture_big_kernel<4>, grid, block, 0, a);
+		TP_LAUNCH_CHECK(ctx, "tp_aperture_big_kernel");
+	} else {
+		TP_LAUNCH(ctx, TPK_APERTURE, tp_aperture_kernel<1>, grid, block, 0, a);
+		TP_LAUNCH_CHECK(ctx, "tp_aperture_kernel");
+		TP_LAUNCH(ctx, TPK_APERTURE_BIG, tp_aperture_big_kernel<1>, grid, block, 0, a);
+		TP_LAUNCH_CHECK(ctx, "tp_aperture_big_kernel");
+	}
+	return TP_OK;
+	TP_API_END(ctx)
+}

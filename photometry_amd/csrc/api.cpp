@@ -1,0 +1,271 @@
+// api.cpp -- context, memory, timers and the per-kernel profile of libtessphot_hip.so.
+#include "common.h"
+#include <cstring>
+#include <exception>
+
+thread_local std::string tp_global_err;
+
+static const char* const kKernelNames[TPK_COUNT] = {
+	"tp_sumimage_kernel",
+	"tp_aperture_kernel",
+	"tp_aperture_big_kernel",
+	"tp_k2p2_kernel",
+	"tp_bkg_stamp_kernel",
+	"tp_bkg_smooth_kernel",
+	"tp_bkg_subtract_kernel",
+	"tp_linpsf_prf_kernel",
+	"tp_linpsf_fit_kernel",
+	"tp_synth_kernel",
+};
+
+extern "C" {
+
+int tp_version(void) { return 100; } // 0.1.0
+
+int tp_device_count(int* n) {
+	if (!n) return TP_ERR_INVALID;
+	int c = 0;
+	hipError_t e = hipGetDeviceCount(&c);
+	if (e != hipSuccess) {
+		tp_global_err = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+		*n = 0;
+		return TP_ERR_HIP;
+	}
+	*n = c;
+	return TP_OK;
+}
+
+int tp_ctx_create(int device, tp_ctx** out) {
+	if (!out) return TP_ERR_INVALID;
+	*out = nullptr;
+	TP_API_BEGIN
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) {
+		tp_global_err = std::string("no HIP device available: ") + hipGetErrorString(e);
+		return TP_ERR_HIP;
+	}
+	if (device < 0 || device >= n) {
+		tp_global_err = "device index out of range";
+		return TP_ERR_INVALID;
+	}
+	e = hipSetDevice(device);
+	if (e != hipSuccess) {
+		tp_global_err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+		return TP_ERR_HIP;
+	}
+	hipDeviceProp_t prop;
+	e = hipGetDeviceProperties(&prop, device);
+	if (e != hipSuccess) {
+		tp_global_err = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+		return TP_ERR_HIP;
+	}
+	if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+		tp_global_err = std::string("libtessphot_hip is built for gfx950 only, device is ") + prop.gcnArchName;
+		return TP_ERR_UNSUPPORTED;
+	}
+	tp_ctx* ctx = new tp_ctx();
+	ctx->device = device;
+	e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+	if (e != hipSuccess) {
+		tp_global_err = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+		delete ctx;
+		return TP_ERR_HIP;
+	}
+	for (int i = 0; i < 16; i++) {
+		(void)hipEventCreate(&ctx->tstart[i]);
+		(void)hipEventCreate(&ctx->tstop[i]);
+	}
+	*out = ctx;
+	return TP_OK;
+	TP_API_END((tp_ctx*)nullptr)
+}
+
+int tp_comm_destroy(tp_ctx* ctx);
+
+int tp_ctx_destroy(tp_ctx* ctx) {
+	if (!ctx) return TP_OK;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	(void)tp_comm_destroy(ctx);
+	for (int k = 0; k < TPK_COUNT; k++)
+		for (auto& p : ctx->pending[k]) {
+			(void)hipEventDestroy(p.first);
+			(void)hipEventDestroy(p.second);
+		}
+	for (auto e : ctx->pool) (void)hipEventDestroy(e);
+	for (int i = 0; i < 16; i++) {
+		(void)hipEventDestroy(ctx->tstart[i]);
+		(void)hipEventDestroy(ctx->tstop[i]);
+	}
+	(void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+	return TP_OK;
+}
+
+const char* tp_last_error(tp_ctx* ctx) {
+	return ctx ? ctx->err.c_str() : tp_global_err.c_str();
+}
+
+int tp_device_info(tp_ctx* ctx, char* name, int name_len, int32_t* n_cu, uint64_t* hbm_bytes) {
+	TP_CHECK_CTX(ctx);
+	hipDeviceProp_t prop;
+	TP_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+	if (name && name_len > 0) {
+		std::snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+	}
+	if (n_cu) *n_cu = prop.multiProcessorCount;
+	if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
+	return TP_OK;
+}
+
+int tp_malloc(tp_ctx* ctx, uint64_t nbytes, void** d_ptr) {
+	TP_CHECK_CTX(ctx);
+	TP_REQUIRE(ctx, d_ptr != nullptr, "tp_malloc: null output pointer");
+	*d_ptr = nullptr;
+	if (nbytes == 0) nbytes = 16;
+	hipError_t e = hipMalloc(d_ptr, (size_t)nbytes);
+	if (e == hipErrorOutOfMemory) return ctx->fail(TP_ERR_NOMEM, "tp_malloc: out of device memory");
+	if (e != hipSuccess) return ctx->fail(TP_ERR_HIP, "hipMalloc", e);
+	return TP_OK;
+}
+
+int tp_free(tp_ctx* ctx, void* d_ptr) {
+	TP_CHECK_CTX(ctx);
+	if (!d_ptr) return TP_OK;
+	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	TP_HIP(ctx, hipFree(d_ptr));
+	return TP_OK;
+}
+
+int tp_memset(tp_ctx* ctx, void* d_ptr, int value, uint64_t nbytes) {
+	TP_CHECK_CTX(ctx);
+	if (nbytes == 0) return TP_OK;
+	TP_REQUIRE(ctx, d_ptr != nullptr, "tp_memset: null pointer");
+	TP_HIP(ctx, hipMemsetAsync(d_ptr, value, (size_t)nbytes, ctx->stream));
+	return TP_OK;
+}
+
+int tp_memcpy_h2d(tp_ctx* ctx, void* d_dst, const void* h_src, uint64_t nbytes) {
+	TP_CHECK_CTX(ctx);
+	if (nbytes == 0) return TP_OK;
+	TP_REQUIRE(ctx, d_dst && h_src, "tp_memcpy_h2d: null pointer");
+	// pageable host memory: the async copy is staged, the call returns once h_src is consumed
+	TP_HIP(ctx, hipMemcpyAsync(d_dst, h_src, (size_t)nbytes, hipMemcpyHostToDevice, ctx->stream));
+	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return TP_OK;
+}
+
+int tp_memcpy_d2h(tp_ctx* ctx, void* h_dst, const void* d_src, uint64_t nbytes) {
+	TP_CHECK_CTX(ctx);
+	if (nbytes == 0) return TP_OK;
+	TP_REQUIRE(ctx, h_dst && d_src, "tp_memcpy_d2h: null pointer");
+	TP_HIP(ctx, hipMemcpyAsync(h_dst, d_src, (size_t)nbytes, hipMemcpyDeviceToHost, ctx->stream));
+	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return TP_OK;
+}
+
+int tp_memcpy_d2d(tp_ctx* ctx, void* d_dst, const void* d_src, uint64_t nbytes) {
+	TP_CHECK_CTX(ctx);
+	if (nbytes == 0) return TP_OK;
+	TP_REQUIRE(ctx, d_dst && d_src, "tp_memcpy_d2d: null pointer");
+	TP_HIP(ctx, hipMemcpyAsync(d_dst, d_src, (size_t)nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+	return TP_OK;
+}
+
+int tp_upload_cube(tp_ctx* ctx, float* d_dst, int64_t dst_pitch, const float* h_src, int64_t src_pitch,
+	int64_t n_rows, int64_t n_cad) {
+	TP_CHECK_CTX(ctx);
+	if (n_rows == 0 || n_cad == 0) return TP_OK;
+	TP_REQUIRE(ctx, d_dst && h_src, "tp_upload_cube: null pointer");
+	TP_REQUIRE(ctx, dst_pitch >= n_cad && src_pitch >= n_cad && n_rows > 0 && n_cad > 0, "tp_upload_cube: bad geometry");
+	if (dst_pitch == n_cad && src_pitch == n_cad) {
+		TP_HIP(ctx, hipMemcpyAsync(d_dst, h_src, (size_t)(n_rows * n_cad) * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+	} else {
+		TP_HIP(ctx, hipMemcpy2DAsync(d_dst, (size_t)dst_pitch * sizeof(float), h_src, (size_t)src_pitch * sizeof(float),
+			(size_t)n_cad * sizeof(float), (size_t)n_rows, hipMemcpyHostToDevice, ctx->stream));
+	}
+	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return TP_OK;
+}
+
+int tp_sync(tp_ctx* ctx) {
+	TP_CHECK_CTX(ctx);
+	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return TP_OK;
+}
+
+int tp_timer_start(tp_ctx* ctx, int slot) {
+	TP_CHECK_CTX(ctx);
+	TP_REQUIRE(ctx, slot >= 0 && slot < 16, "timer slot out of range");
+	TP_HIP(ctx, hipEventRecord(ctx->tstart[slot], ctx->stream));
+	return TP_OK;
+}
+
+int tp_timer_stop(tp_ctx* ctx, int slot) {
+	TP_CHECK_CTX(ctx);
+	TP_REQUIRE(ctx, slot >= 0 && slot < 16, "timer slot out of range");
+	TP_HIP(ctx, hipEventRecord(ctx->tstop[slot], ctx->stream));
+	return TP_OK;
+}
+
+int tp_timer_elapsed_ms(tp_ctx* ctx, int slot, float* ms) {
+	TP_CHECK_CTX(ctx);
+	TP_REQUIRE(ctx, slot >= 0 && slot < 16 && ms, "timer slot out of range");
+	TP_HIP(ctx, hipEventSynchronize(ctx->tstop[slot]));
+	TP_HIP(ctx, hipEventElapsedTime(ms, ctx->tstart[slot], ctx->tstop[slot]));
+	return TP_OK;
+}
+
+int tp_profile_enable(tp_ctx* ctx, int on) {
+	TP_CHECK_CTX(ctx);
+	ctx->profile = (on != 0);
+	return TP_OK;
+}
+
+static int tp_profile_drain(tp_ctx* ctx) {
+	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	for (int k = 0; k < TPK_COUNT; k++) {
+		for (auto& p : ctx->pending[k]) {
+			float ms = 0.f;
+			if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+				ctx->prof_ms[k] += (double)ms;
+				ctx->prof_n[k] += 1;
+			}
+			ctx->pool.push_back(p.first);
+			ctx->pool.push_back(p.second);
+		}
+		ctx->pending[k].clear();
+	}
+	return TP_OK;
+}
+
+int tp_profile_reset(tp_ctx* ctx) {
+	TP_CHECK_CTX(ctx);
+	int rc = tp_profile_drain(ctx);
+	if (rc != TP_OK) return rc;
+	for (int k = 0; k < TPK_COUNT; k++) {
+		ctx->prof_ms[k] = 0.0;
+		ctx->prof_n[k] = 0;
+	}
+	return TP_OK;
+}
+
+int tp_kernel_count(void) { return TPK_COUNT; }
+
+const char* tp_kernel_name(int kernel_id) {
+	if (kernel_id < 0 || kernel_id >= TPK_COUNT) return "";
+	return kKernelNames[kernel_id];
+}
+
+int tp_profile_get(tp_ctx* ctx, int kernel_id, int64_t* n_launches, double* total_ms) {
+	TP_CHECK_CTX(ctx);
+	TP_REQUIRE(ctx, kernel_id >= 0 && kernel_id < TPK_COUNT, "kernel id out of range");
+	int rc = tp_profile_drain(ctx);
+	if (rc != TP_OK) return rc;
+	if (n_launches) *n_launches = ctx->prof_n[kernel_id];
+	if (total_ms) *total_ms = ctx->prof_ms[kernel_id];
+	return TP_OK;
+}
+
+} // extern "C"

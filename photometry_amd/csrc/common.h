@@ -1,0 +1,105 @@
+// common.h -- context, error handling, launch/profile helpers shared by every translation unit
+// of libtessphot_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include <utility>
+#include "../../include/tessphot_hip.h"
+
+// Dense kernel ids for the per-kernel profile (tp_kernel_name / tp_profile_get).
+enum tp_kernel_id {
+	TPK_SUMIMAGE = 0,
+	TPK_APERTURE,
+	TPK_APERTURE_BIG,
+	TPK_K2P2,
+	TPK_BKG_STAMP,
+	TPK_BKG_SMOOTH,
+	TPK_BKG_SUBTRACT,
+	TPK_LINPSF_PRF,
+	TPK_LINPSF_FIT,
+	TPK_SYNTH,
+	TPK_COUNT
+};
+
+struct tp_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string err;
+	hipEvent_t tstart[16] = {};
+	hipEvent_t tstop[16] = {};
+	bool profile = false;
+	// pending (start, stop) event pairs per kernel id + accumulated totals
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[TPK_COUNT];
+	std::vector<hipEvent_t> pool;
+	int64_t prof_n[TPK_COUNT] = {};
+	double prof_ms[TPK_COUNT] = {};
+	void* comm = nullptr;       // ncclComm_t (comm.cpp)
+	int comm_rank = 0, comm_size = 1;
+
+	int fail(int code, const char* what, hipError_t e = hipSuccess) {
+		err = what;
+		if (e != hipSuccess) {
+			err += ": ";
+			err += hipGetErrorString(e);
+		}
+		return code;
+	}
+	hipEvent_t get_event() {
+		if (!pool.empty()) {
+			hipEvent_t e = pool.back();
+			pool.pop_back();
+			return e;
+		}
+		hipEvent_t e = nullptr;
+		(void)hipEventCreate(&e);
+		return e;
+	}
+};
+
+extern thread_local std::string tp_global_err;
+
+#define TP_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) return (ctx)->fail(TP_ERR_HIP, #call, _e); } while (0)
+#define TP_REQUIRE(ctx, cond, msg) do { if (!(cond)) return (ctx)->fail(TP_ERR_INVALID, msg); } while (0)
+#define TP_CHECK_CTX(ctx) do { if ((ctx) == nullptr) { tp_global_err = "null ctx"; return TP_ERR_INVALID; } (void)hipSetDevice((ctx)->device); } while (0)
+
+// Brackets one kernel launch with events when profiling is on.
+struct tp_prof_scope {
+	tp_ctx* ctx;
+	int kid;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	tp_prof_scope(tp_ctx* c, int k) : ctx(c), kid(k) {
+		if (ctx->profile) {
+			e0 = ctx->get_event();
+			e1 = ctx->get_event();
+			(void)hipEventRecord(e0, ctx->stream);
+		}
+	}
+	~tp_prof_scope() {
+		if (ctx->profile) {
+			(void)hipEventRecord(e1, ctx->stream);
+			ctx->pending[kid].emplace_back(e0, e1);
+		}
+	}
+};
+
+#define TP_LAUNCH(ctx, kid, kernel, grid, block, shmem, ...) do { \
+	tp_prof_scope _ps((ctx), (kid)); \
+	hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__); \
+} while (0)
+
+#define TP_LAUNCH_CHECK(ctx, name) do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) return (ctx)->fail(TP_ERR_HIP, name, _e); } while (0)
+
+static inline bool tp_desc_ok(const tp_cube_desc* d) {
+	return d && d->n_targets >= 0 && d->n_cad >= 0 && d->height > 0 && d->width > 0 && d->t_pitch >= d->n_cad;
+}
+
+// 16-byte aligned base and pitch % 4 == 0 -> 128-bit load path
+static inline bool tp_vec4_ok(const void* p, int64_t pitch) {
+	return ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) && (pitch % 4 == 0);
+}
+
+#define TP_API_BEGIN try {
+#define TP_API_END(ctx) } catch (const std::exception& ex) { if (ctx) { (ctx)->err = ex.what(); } else { tp_global_err = ex.what(); } return TP_ERR_INVALID; } catch (...) { if (ctx) { (ctx)->err = "unknown C++ exception"; } return TP_ERR_INVALID; }

@@ -1,0 +1,186 @@
+# -*- coding: utf-8 -*-
+"""
+Thin object layer over the C ABI: :class:`Context` (one ``tp_ctx`` = one GPU + one HIP
+stream) and :class:`DeviceArray` (a typed HBM buffer owned by the caller).
+No torch, no numpy-on-GPU: numpy is only used for host staging.
+"""
+
+import ctypes
+import numpy as np
+from . import _lib
+from ._lib import TessphotError, tp_cube_desc
+
+
+def round_up(n, m):
+	return ((int(n) + m - 1) // m) * m
+
+
+class DeviceArray(object):
+	"""A typed buffer in HBM.  ``shape`` / ``dtype`` describe the logical contents."""
+
+	def __init__(self, ctx, shape, dtype, zero=False):
+		self.ctx = ctx
+		self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+		self.dtype = np.dtype(dtype)
+		self.nbytes = int(np.prod(self.shape, dtype='int64')) * self.dtype.itemsize
+		p = ctypes.c_void_p()
+		ctx._check(ctx.lib.tp_malloc(ctx.handle, max(self.nbytes, 16), ctypes.byref(p)))
+		self.ptr = p.value
+		if zero:
+			self.fill_bytes(0)
+
+	@classmethod
+	def from_host(cls, ctx, array, dtype=None):
+		a = np.ascontiguousarray(array, dtype=dtype)
+		d = cls(ctx, a.shape, a.dtype)
+		if a.nbytes:
+			ctx._check(ctx.lib.tp_memcpy_h2d(ctx.handle, d.ptr, a.ctypes.data, a.nbytes))
+		return d
+
+	def to_host(self):
+		out = np.empty(self.shape, dtype=self.dtype)
+		if self.nbytes:
+			self.ctx._check(self.ctx.lib.tp_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
+		return out
+
+	def fill_bytes(self, value):
+		if self.nbytes:
+			self.ctx._check(self.ctx.lib.tp_memset(self.ctx.handle, self.ptr, int(value), self.nbytes))
+
+	def free(self):
+		if self.ptr is not None and self.ctx is not None and self.ctx.handle is not None:
+			self.ctx.lib.tp_free(self.ctx.handle, self.ptr)
+		self.ptr = None
+
+	def __del__(self):
+		try:
+			self.free()
+		except Exception: # noqa: B902
+			pass
+
+
+class DeviceCube(object):
+	"""
+	A float32 stamp cube ``[n_targets][H][W][t_pitch]`` in HBM (time fastest, the reference's
+	``(rows, cols, times)`` cube per target, BasePhotometry.py:732).  ``t_pitch`` is rounded up
+	to a multiple of 4 so that every pixel's series starts 16-byte aligned.
+	"""
+
+	def __init__(self, ctx, n_targets, n_cad, height, width, t_pitch=None):
+		self.ctx = ctx
+		self.n_targets, self.n_cad, self.height, self.width = int(n_targets), int(n_cad), int(height), int(width)
+		self.t_pitch = round_up(n_cad, 4) if t_pitch is None else int(t_pitch)
+		self.data = DeviceArray(ctx, (self.n_targets, self.height, self.width, self.t_pitch), 'float32')
+
+	@property
+	def ptr(self):
+		return self.data.ptr
+
+	@property
+	def desc(self):
+		return tp_cube_desc(self.n_targets, self.n_cad, self.height, self.width, self.t_pitch)
+
+	@classmethod
+	def from_host(cls, ctx, cube):
+		"""``cube``: float32 ``(Nt, H, W, T)`` (or ``(H, W, T)`` for a single target)."""
+		cube = np.asarray(cube)
+		if cube.ndim == 3:
+			cube = cube[None]
+		cube = np.ascontiguousarray(cube, dtype='float32')
+		Nt, H, W, T = cube.shape
+		d = cls(ctx, Nt, T, H, W)
+		if d.t_pitch != T:
+			d.data.fill_bytes(0)
+		ctx._check(ctx.lib.tp_upload_cube(ctx.handle, d.ptr, d.t_pitch, cube.ctypes.data, T, Nt*H*W, T))
+		return d
+
+	def to_host(self):
+		full = self.data.to_host()
+		return np.ascontiguousarray(full[..., :self.n_cad])
+
+	def free(self):
+		self.data.free()
+
+
+class Context(object):
+	"""One GPU, one stream.  Not thread-safe (one Context per host thread)."""
+
+	def __init__(self, device=0):
+		self.lib = _lib.load()
+		h = ctypes.c_void_p()
+		rc = self.lib.tp_ctx_create(int(device), ctypes.byref(h))
+		if rc != 0:
+			raise TessphotError(rc, (self.lib.tp_last_error(None) or b'').decode())
+		self.handle = h.value
+		self.device = int(device)
+
+	def _check(self, rc):
+		if rc != 0:
+			raise TessphotError(rc, (self.lib.tp_last_error(self.handle) or b'').decode())
+
+	def close(self):
+		if getattr(self, 'handle', None) is not None:
+			self.lib.tp_ctx_destroy(self.handle)
+			self.handle = None
+
+	def __enter__(self):
+		return self
+
+	def __exit__(self, *args):
+		self.close()
+
+	def __del__(self):
+		# DeviceArrays may outlive us at interpreter shutdown; the driver reclaims them.
+		pass
+
+	def sync(self):
+		self._check(self.lib.tp_sync(self.handle))
+
+	def info(self):
+		name = ctypes.create_string_buffer(256)
+		ncu = ctypes.c_int32()
+		hbm = ctypes.c_uint64()
+		self._check(self.lib.tp_device_info(self.handle, name, 256, ctypes.byref(ncu), ctypes.byref(hbm)))
+		return {'name': name.value.decode(), 'n_cu': ncu.value, 'hbm_bytes': hbm.value}
+
+	# -- allocation helpers ------------------------------------------------------------------
+	def empty(self, shape, dtype):
+		return DeviceArray(self, shape, dtype)
+
+	def zeros(self, shape, dtype):
+		return DeviceArray(self, shape, dtype, zero=True)
+
+	def array(self, host, dtype=None):
+		return DeviceArray.from_host(self, host, dtype=dtype)
+
+	def cube(self, host):
+		return DeviceCube.from_host(self, host)
+
+	# -- timing ------------------------------------------------------------------------------
+	def timer_start(self, slot=0):
+		self._check(self.lib.tp_timer_start(self.handle, slot))
+
+	def timer_stop(self, slot=0):
+		self._check(self.lib.tp_timer_stop(self.handle, slot))
+
+	def timer_ms(self, slot=0):
+		ms = ctypes.c_float()
+		self._check(self.lib.tp_timer_elapsed_ms(self.handle, slot, ctypes.byref(ms)))
+		return float(ms.value)
+
+	def profile(self, on=True):
+		self._check(self.lib.tp_profile_enable(self.handle, 1 if on else 0))
+
+	def profile_reset(self):
+		self._check(self.lib.tp_profile_reset(self.handle))
+
+	def profile_report(self):
+		"""dict kernel name -> (launches, total_ms)."""
+		out = {}
+		for k in range(self.lib.tp_kernel_count()):
+			n = ctypes.c_int64()
+			ms = ctypes.c_double()
+			self._check(self.lib.tp_profile_get(self.handle, k, ctypes.byref(n), ctypes.byref(ms)))
+			if n.value:
+				out[self.lib.tp_kernel_name(k).decode()] = (int(n.value), float(ms.value))
+		return out

@@ -1,0 +1,112 @@
+# -*- coding: utf-8 -*-
+"""
+Batched device operations: thin, typed Python wrappers over the C-ABI entry points.
+All inputs/outputs are :class:`~photometry_amd.device.DeviceArray` /
+:class:`~photometry_amd.device.DeviceCube` objects resident in HBM.
+"""
+
+import ctypes
+import numpy as np
+from .device import DeviceArray, DeviceCube, round_up
+from ._lib import tp_cube_desc
+
+#: TESSQualityFlags.DEFAULT_BITMASK (photometry/quality.py:123-124)
+TESS_DEFAULT_BITMASK = 1 | 2 | 4 | 8 | 32 | 64 | 128 | 4096
+
+
+def _ptr(x):
+	if x is None:
+		return None
+	return x.ptr
+
+
+def sumimage(ctx, images, quality, bitmask=TESS_DEFAULT_BITMASK, out=None):
+	"""
+	A1 (BasePhotometry.py:1008-1019).  ``images``: DeviceCube; ``quality``: int32 DeviceArray
+	``(T,)`` shared or ``(Nt, T)``.  Returns float64 DeviceArray ``(Nt, H, W)``.
+	"""
+	if out is None:
+		out = ctx.empty((images.n_targets, images.height, images.width), 'float64')
+	if len(quality.shape) == 1:
+		assert quality.shape[0] >= images.n_cad
+		qstride = 0
+	else:
+		assert quality.shape[0] == images.n_targets and quality.shape[1] >= images.n_cad
+		qstride = quality.shape[1]
+	desc = images.desc
+	ctx._check(ctx.lib.tp_sumimage(ctx.handle, ctypes.byref(desc), images.ptr, quality.ptr, qstride, int(bitmask), out.ptr))
+	return out
+
+
+class LightCurves(object):
+	"""Device-resident light-curve block: float64 ``(Nt, T)`` per column."""
+	COLUMNS = ('flux', 'flux_err', 'flux_background', 'centroid_col', 'centroid_row')
+
+	def __init__(self, ctx, n_targets, n_cad):
+		self.ctx = ctx
+		self.n_targets, self.n_cad = int(n_targets), int(n_cad)
+		# one allocation [5][Nt][T] so that the final gather moves a single block
+		self.block = ctx.zeros((5, self.n_targets, self.n_cad), 'float64')
+		stride = self.n_targets * self.n_cad * 8
+		self.ptrs = [self.block.ptr + i*stride for i in range(5)]
+
+	def to_host(self):
+		b = self.block.to_host()
+		lc = {name: b[i] for i, name in enumerate(self.COLUMNS)}
+		lc['pos_centroid'] = np.stack((b[3], b[4]), axis=-1) # (Nt, T, 2): column then row (BasePhotometry.py:428)
+		return lc
+
+
+def aperture_extract(ctx, images, images_err, backgrounds, mask, stamps, status=None, out=None):
+	"""
+	A6 (photometry.py:172-201).  ``backgrounds``: DeviceCube, or a float32 DeviceArray ``(Nt, pitch)``
+	holding one background series per target (stamp-constant background).
+	``mask``: uint8 DeviceArray ``(Nt, H, W)``; ``stamps``: int32 ``(Nt, 4)``.
+	"""
+	if out is None:
+		out = LightCurves(ctx, images.n_targets, images.n_cad)
+	desc = images.desc
+	assert images_err.t_pitch == images.t_pitch and images_err.data.shape == images.data.shape
+	if isinstance(backgrounds, DeviceCube):
+		assert backgrounds.t_pitch == images.t_pitch and backgrounds.data.shape == images.data.shape
+		bkg_mode, bpitch = 0, 0
+	else:
+		assert backgrounds.dtype == np.float32 and backgrounds.shape[0] == images.n_targets
+		bkg_mode, bpitch = 1, backgrounds.shape[1]
+	assert mask.dtype == np.uint8 and stamps.dtype == np.int32
+	ctx._check(ctx.lib.tp_aperture_extract(ctx.handle, ctypes.byref(desc), images.ptr, images_err.ptr, backgrounds.ptr,
+		bkg_mode, bpitch, mask.ptr, stamps.ptr, _ptr(status), out.ptrs[0], out.ptrs[1], out.ptrs[2], out.ptrs[3], out.ptrs[4],
+		out.n_cad))
+	return out
+
+
+def synth_fill(ctx, scene, n_targets=None, target_offset=0, nan_fraction=1e-3, images=True, images_err=True, backgrounds=True, raw=False):
+	"""
+	Fill device cubes for ``scene`` (``photometry_amd.simulate.make_scene``) with the device RNG.
+	Returns dict of DeviceCube (keys ``images, images_err, backgrounds, raw`` as requested).
+	"""
+	Nt = scene.n_targets if n_targets is None else int(n_targets)
+	sl = slice(target_offset, target_offset + Nt)
+	T, H, W = scene.n_cad, scene.height, scene.width
+	out = {}
+	for name, want in (('images', images), ('images_err', images_err), ('backgrounds', backgrounds), ('raw', raw)):
+		out[name] = DeviceCube(ctx, Nt, T, H, W) if want else None
+	any_cube = next(v for v in out.values() if v is not None)
+	desc = any_cube.desc
+	sp = ctx.array(scene.star_params[sl], dtype='float64')
+	sig = ctx.array(scene.sigma_psf[sl], dtype='float64')
+	lev = ctx.array(scene.bkg_level[sl], dtype='float64')
+	pha = ctx.array(scene.bkg_phase[sl], dtype='float64')
+	jit = ctx.array(scene.jitter, dtype='float64')
+	ctx._check(ctx.lib.tp_synth_fill(ctx.handle, ctypes.byref(desc), scene.star_params.shape[1], sp.ptr, sig.ptr, lev.ptr, pha.ptr,
+		jit.ptr, float(scene.readnoise), float(nan_fraction), int(scene.seed) * 7919 + int(target_offset) * 104729 + 1,
+		_ptr(out['images']), _ptr(out['images_err']), _ptr(out['backgrounds']), _ptr(out['raw'])))
+	ctx.sync()
+	for a in (sp, sig, lev, pha, jit):
+		a.free()
+	return {k: v for k, v in out.items() if v is not None}
+
+
+def k2p2_masks(ctx, batch, work):
+	"""A2..A5b + A7 on the device (filled in by the K2P2 kernel)."""
+	raise NotImplementedError("tp_k2p2_masks is not built yet")

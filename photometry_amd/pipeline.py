@@ -1,0 +1,112 @@
+# -*- coding: utf-8 -*-
+"""
+Batched per-target pipelines over a stamp cube resident in HBM.
+
+``run_aperture``: A1 sum image -> A2..A5b K2P2 masks + A7 contamination -> A6 extraction,
+i.e. ``AperturePhotometry.do_photometry`` (photometry/AperturePhotometry/photometry.py:44-257)
+for every target of the batch at once.
+"""
+
+import numpy as np
+from . import engine
+from .device import DeviceCube
+
+
+class ApertureBatch(object):
+	"""Device-resident inputs of a batch (cubes + per-target metadata)."""
+
+	def __init__(self, ctx, scene, cubes='host'):
+		self.ctx = ctx
+		self.scene = scene
+		if isinstance(cubes, str) and cubes == 'host':
+			self.images = DeviceCube.from_host(ctx, scene.images)
+			self.images_err = DeviceCube.from_host(ctx, scene.images_err)
+			self.backgrounds = DeviceCube.from_host(ctx, scene.backgrounds)
+		else:
+			self.images, self.images_err, self.backgrounds = cubes['images'], cubes['images_err'], cubes['backgrounds']
+		q = np.asarray(scene.quality, dtype='int32')
+		self.quality = ctx.array(q)
+		self.stamps = ctx.array(np.asarray(scene.stamps, dtype='int32'))
+		self.n_targets = self.images.n_targets
+		self.n_cad = self.images.n_cad
+		self.height, self.width = self.images.height, self.images.width
+		# catalog (ragged) and target metadata for the mask kernel
+		c = scene.catalog
+		self.cat_offsets = ctx.array(np.asarray(scene.cat_offsets, dtype='int64'))
+		self.cat_starid = ctx.array(np.asarray(c['starid'], dtype='int64'))
+		self.cat_tmag = ctx.array(np.asarray(c['tmag'], dtype='float32'))
+		self.cat_row = ctx.array(np.asarray(c['row'], dtype='float32'))
+		self.cat_column = ctx.array(np.asarray(c['column'], dtype='float32'))
+		self.cat_row_stamp = ctx.array(np.asarray(c['row_stamp'], dtype='float32'))
+		self.cat_column_stamp = ctx.array(np.asarray(c['column_stamp'], dtype='float32'))
+		self.target_pos_row = ctx.array(np.asarray(scene.target_pos_row, dtype='float64'))
+		self.target_pos_column = ctx.array(np.asarray(scene.target_pos_column, dtype='float64'))
+		self.target_tmag = ctx.array(np.asarray(scene.target_tmag, dtype='float64'))
+		self.target_starid = ctx.array(np.asarray(scene.target_starid, dtype='int64'))
+		ap = getattr(scene, 'aperture', None)
+		if ap is None:
+			ap = np.ones((self.n_targets, self.height, self.width), dtype='int32')
+		self.aperture = ctx.array(np.asarray(ap, dtype='int32'))
+
+
+class ApertureWork(object):
+	"""Device-resident outputs / scratch of the aperture pipeline (allocated once, reused per step)."""
+
+	def __init__(self, ctx, batch):
+		Nt, T, H, W = batch.n_targets, batch.n_cad, batch.height, batch.width
+		self.sumimage = ctx.empty((Nt, H, W), 'float64')
+		self.mask = ctx.zeros((Nt, H, W), 'uint8')
+		self.status = ctx.zeros((Nt,), 'int32')
+		self.flags = ctx.zeros((Nt,), 'int32')
+		self.contamination = ctx.zeros((Nt,), 'float64')
+		self.diag = ctx.zeros((Nt, 8), 'float64')
+		self.cat_in_mask = ctx.zeros((max(int(batch.scene.cat_offsets[-1]), 1),), 'uint8')
+		self.lc = engine.LightCurves(ctx, Nt, T)
+
+
+def aperture_step(ctx, batch, work, masks_from=None):
+	"""
+	One pass of the aperture hot path over the batch; everything stays in HBM.
+
+	``masks_from``: optional ``(mask uint8 DeviceArray, status int32 DeviceArray)`` to bypass the
+	on-device K2P2 (used by tests that inject the oracle's masks).
+	"""
+	engine.sumimage(ctx, batch.images, batch.quality, out=work.sumimage)
+	if masks_from is None:
+		engine.k2p2_masks(ctx, batch, work)
+		mask, status = work.mask, work.status
+	else:
+		mask, status = masks_from
+	engine.aperture_extract(ctx, batch.images, batch.images_err, batch.backgrounds, mask, batch.stamps, status=status, out=work.lc)
+	return work
+
+
+def run_aperture(ctx, scene, cubes='host', masks=None):
+	"""
+	Convenience: upload (or adopt device cubes), run one :func:`aperture_step`, download.
+
+	Returns a dict of host arrays: ``sumimage, mask, status, flags, contamination, diag, cat_in_mask,
+	flux, flux_err, flux_background, pos_centroid``.
+	"""
+	batch = ApertureBatch(ctx, scene, cubes=cubes)
+	work = ApertureWork(ctx, batch)
+	masks_from = None
+	if masks is not None:
+		m = ctx.array(np.asarray(masks, dtype='uint8'))
+		st = ctx.array(np.ones(batch.n_targets, dtype='int32'))
+		masks_from = (m, st)
+	aperture_step(ctx, batch, work, masks_from=masks_from)
+	ctx.sync()
+	out = work.lc.to_host()
+	out['sumimage'] = work.sumimage.to_host()
+	if masks_from is None:
+		out['mask'] = work.mask.to_host()
+		out['status'] = work.status.to_host()
+		out['flags'] = work.flags.to_host()
+		out['contamination'] = work.contamination.to_host()
+		out['diag'] = work.diag.to_host()
+		out['cat_in_mask'] = work.cat_in_mask.to_host()
+	else:
+		out['mask'] = masks_from[0].to_host()
+		out['status'] = masks_from[1].to_host()
+	return out

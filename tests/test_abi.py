@@ -1,0 +1,63 @@
+# -*- coding: utf-8 -*-
+"""CPU-side checks of the C-ABI library: it builds, loads, and exports every declared symbol."""
+import os
+import re
+import ctypes
+import pytest
+import conftest
+
+HEADER = os.path.join(conftest.ROOT, 'include', 'tessphot_hip.h')
+
+
+@pytest.fixture(scope='session')
+def built_lib():
+	import __graft_entry__ as g
+	g.build()
+	from photometry_amd import _lib
+	return _lib
+
+
+def header_functions():
+	src = open(HEADER).read()
+	src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+	return sorted(set(re.findall(r'\b(tp_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+	lib = ctypes.CDLL(built_lib.LIB_PATH)
+	names = header_functions()
+	assert len(names) >= 20
+	for name in names:
+		assert hasattr(lib, name), f"{name} declared in include/tessphot_hip.h but not exported"
+	# and the ctypes table covers the header exactly
+	assert sorted(built_lib.SIGNATURES.keys()) == names
+
+
+def test_version_and_names(built_lib):
+	lib = built_lib.load()
+	assert lib.tp_version() >= 100
+	n = lib.tp_kernel_count()
+	names = [lib.tp_kernel_name(k).decode() for k in range(n)]
+	assert 'tp_aperture_kernel' in names and 'tp_sumimage_kernel' in names
+	assert lib.tp_kernel_name(n + 5) == b''
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+	from photometry_amd import _lib
+	monkeypatch.setattr(_lib, '_lib', None)
+	monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libtessphot_hip.so')
+	with pytest.raises(_lib.TessphotLibraryError):
+		_lib.load()
+
+
+def test_no_gpu_is_an_error_not_a_fallback(built_lib):
+	"""Without a GPU, creating a context must raise (there is no CPU fallback)."""
+	lib = built_lib.load()
+	n = ctypes.c_int(0)
+	lib.tp_device_count(ctypes.byref(n))
+	if n.value > 0:
+		pytest.skip("a GPU is visible")
+	from photometry_amd.device import Context
+	from photometry_amd._lib import TessphotError
+	with pytest.raises(TessphotError):
+		Context(0)
