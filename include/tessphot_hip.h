@@ -108,6 +108,45 @@ int tp_profile_get(tp_ctx* ctx, int kernel_id, int64_t* n_launches, double* tota
 int tp_sumimage(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
 	const int32_t* d_quality, int64_t quality_target_stride, uint32_t bitmask, double* d_sumimage);
 
+/* ---- A2..A5b + A7: K2P2 aperture masks -------------------------------------------------------
+ * replaces k2p2.k2p2FixFromSum (photometry/AperturePhotometry/k2p2v2.py:344-623: KDE-mode/MAD
+ * threshold, DBSCAN clustering, watershed segmentation, size filter, hole filling, overflow
+ * columns) and the mask selection, minimum aperture, edge test and contamination of
+ * AperturePhotometry.do_photometry (photometry/AperturePhotometry/photometry.py:31-41, 93-131,
+ * 220-254), for every target of the batch.  Stamps are fixed-size cubes: resize_stamp() cannot
+ * grow them (BasePhotometry.py:605-612 -> False), so edge-touching masks are used as they are
+ * and reported through the edge bits of d_flags for a host-side retry on a bigger cut-out.
+ *   catalog (ragged, CSR): d_cat_offsets int64 [n_targets+1]; per star float32 column_stamp,
+ *     row_stamp, tmag, column, row (BasePhotometry.catalog, BasePhotometry.py:1153-1178), int64 starid.
+ *   d_target_pos_row/column: float64 CCD position (target_pos_row/column); d_target_tmag float64.
+ *   d_aperture: int32 [n_targets][H*W] pixel flags (BasePhotometry.aperture; bit 1 = collected).
+ *   d_cut_override: optional float64 [n_targets] replacing the KDE/Powell threshold CUT.
+ *   params: NULL = the plugin's settings (photometry.py:54-64).
+ * outputs: d_mask uint8 [n_targets][H*W] (final_phot_mask); d_status int32 STATUS;
+ *   d_flags int32: bit0 minimum aperture used, bits1-4 mask touches stamp edge (row 0, last row,
+ *   column 0, last column), bit5 K2P2NoStars, bit6 no mask passed the size filter,
+ *   bits 8+ error kind (1 no flux, 2 zero KDE bandwidth, 3 no watershed peak, 4 target outside
+ *   stamp, 5 too many masks, 6 no catalog star in mask);
+ *   d_contamination float64 (AP_CONT, NaN if undefined); d_diag optional float64 [n_targets][8] =
+ *   (CUT, MODE, MAD1, KDE bandwidth, FFT-grid mode guess, n positive pixels, min|S-CUT|, n masks);
+ *   d_cat_in_mask optional uint8 [n_catalog]: star falls inside the final mask (skip_targets).   */
+typedef struct tp_k2p2_params {
+	double thresh;                  /* 0.8 */
+	int32_t min_no_pixels_in_mask;  /* 4 */
+	int32_t min_for_cluster;        /* 4 */
+	int32_t extend_overflow;        /* 1 */
+	int32_t reserved;
+	double ws_thres;                /* 0 */
+	double saturation_limit;        /* 7.0 */
+} tp_k2p2_params;
+int tp_k2p2_masks(tp_ctx* ctx, int32_t n_targets, int32_t height, int32_t width,
+	const double* d_sumimage,
+	const int64_t* d_cat_offsets, const float* d_cat_column_stamp, const float* d_cat_row_stamp, const float* d_cat_tmag,
+	const float* d_cat_column, const float* d_cat_row, const int64_t* d_cat_starid,
+	const double* d_target_pos_row, const double* d_target_pos_column, const double* d_target_tmag, const int64_t* d_target_starid,
+	const int32_t* d_stamps, const int32_t* d_aperture, const double* d_cut_override, const tp_k2p2_params* params,
+	uint8_t* d_mask, int32_t* d_status, int32_t* d_flags, double* d_contamination, double* d_diag, uint8_t* d_cat_in_mask);
+
 /* ---- A6: aperture extraction ---------------------------------------------------------------
  * replaces the per-cadence loop of AperturePhotometry.do_photometry
  * (photometry/AperturePhotometry/photometry.py:172-201): in-mask flux (float32 np.sum order,

@@ -33,7 +33,7 @@ class tp_cube_desc(Structure):
 
 class tp_k2p2_params(Structure):
 	_fields_ = [('thresh', c_double), ('min_no_pixels_in_mask', c_int32), ('min_for_cluster', c_int32),
-		('ws_footprint', c_int32), ('extend_overflow', c_int32), ('ws_thres', c_double), ('saturation_limit', c_double)]
+		('extend_overflow', c_int32), ('reserved', c_int32), ('ws_thres', c_double), ('saturation_limit', c_double)]
 
 
 _p = c_void_p # device / host data pointers are passed as integers
@@ -64,6 +64,8 @@ SIGNATURES = {
 	'tp_kernel_name': (c_char_p, [c_int]),
 	'tp_profile_get': (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_double)]),
 	'tp_sumimage': (c_int, [c_void_p, _desc_p, _p, _p, c_int64, c_uint32, _p]),
+	'tp_k2p2_masks': (c_int, [c_void_p, c_int32, c_int32, c_int32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+		POINTER(tp_k2p2_params), _p, _p, _p, _p, _p, _p]),
 	'tp_aperture_extract': (c_int, [c_void_p, _desc_p, _p, _p, _p, c_int32, c_int64, _p, _p, _p,
 		_p, _p, _p, _p, _p, c_int64]),
 	'tp_comm_unique_id': (c_int, [c_char_p, c_int]),

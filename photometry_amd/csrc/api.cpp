@@ -88,6 +88,7 @@ int tp_ctx_destroy(tp_ctx* ctx) {
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
 	(void)tp_comm_destroy(ctx);
+	if (ctx->twiddle) (void)hipFree(ctx->twiddle);
 	for (int k = 0; k < TPK_COUNT; k++)
 		for (auto& p : ctx->pending[k]) {
 			(void)hipEventDestroy(p.first);

@@ -36,6 +36,7 @@ struct tp_ctx {
 	std::vector<hipEvent_t> pool;
 	int64_t prof_n[TPK_COUNT] = {};
 	double prof_ms[TPK_COUNT] = {};
+	void* twiddle = nullptr;    // device table of the K2P2 128-point DFT (k2p2.hip)
 	void* comm = nullptr;       // ncclComm_t (comm.cpp)
 	int comm_rank = 0, comm_size = 1;
 

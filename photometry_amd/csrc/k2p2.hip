@@ -1,0 +1,78 @@
+// k2p2.hip -- A2..A5b + A7 on the device: one wavefront (64 threads) per target, all work arrays
+// in LDS (see k2p2_core.h for the algorithm and its reference citations).
+//
+// This stage is O(1) in the number of cadences (it sees only the 15x15 sum image), latency-bound
+// integer / float64 work; it is NOT on the HBM roofline -- 10 000 targets x ~23 KB of LDS each.
+#include "common.h"
+#include "k2p2_args.h"
+#include <cmath>
+
+namespace {
+
+__global__ __launch_bounds__(64, 2) void tp_k2p2_kernel(k2p2::BatchArgs a, k2p2::Params prm, const double* __restrict__ twid)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	const int target = blockIdx.x;
+	k2p2::Shared k;
+	k2p2::shared_carve(k, smem, a.H, a.W, (int)threadIdx.x, twid);
+	k2p2::Target t;
+	k2p2::make_target(a, target, t);
+	k2p2::run_target(k, prm, t);
+}
+
+} // namespace
+
+extern "C" int tp_k2p2_masks(tp_ctx* ctx, int32_t n_targets, int32_t height, int32_t width,
+	const double* d_sumimage,
+	const int64_t* d_cat_offsets, const float* d_cat_column_stamp, const float* d_cat_row_stamp, const float* d_cat_tmag,
+	const float* d_cat_column, const float* d_cat_row, const int64_t* d_cat_starid,
+	const double* d_target_pos_row, const double* d_target_pos_column, const double* d_target_tmag, const int64_t* d_target_starid,
+	const int32_t* d_stamps, const int32_t* d_aperture, const double* d_cut_override, const tp_k2p2_params* params,
+	uint8_t* d_mask, int32_t* d_status, int32_t* d_flags, double* d_contamination, double* d_diag, uint8_t* d_cat_in_mask)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, n_targets >= 0 && height > 0 && width > 0, "tp_k2p2_masks: bad geometry");
+	TP_REQUIRE(ctx, d_sumimage && d_cat_offsets && d_target_pos_row && d_target_pos_column && d_target_tmag && d_target_starid
+		&& d_stamps && d_aperture, "tp_k2p2_masks: null input pointer");
+	TP_REQUIRE(ctx, d_mask && d_status && d_flags && d_contamination, "tp_k2p2_masks: null output pointer");
+	if (n_targets == 0) return TP_OK;
+	const size_t shmem = k2p2::shared_bytes(height * width);
+	TP_REQUIRE(ctx, shmem <= 160 * 1024, "tp_k2p2_masks: stamp too large for the LDS-resident mask builder (about 44x44 pixels)");
+
+	k2p2::Params prm = k2p2::default_params();
+	if (params) {
+		prm.thresh = params->thresh;
+		prm.min_no_pixels_in_mask = params->min_no_pixels_in_mask;
+		prm.min_for_cluster = params->min_for_cluster;
+		prm.extend_overflow = params->extend_overflow;
+		prm.ws_thres = params->ws_thres;
+		prm.saturation_limit = params->saturation_limit;
+	}
+	// twiddle table of the 128-point DFT (cos, sin), once per context
+	if (!ctx->twiddle) {
+		double h[2 * k2p2::kGrid];
+		for (int j = 0; j < k2p2::kGrid; ++j) {
+			h[j] = std::cos(2.0 * k2p2::kPi * (double)j / (double)k2p2::kGrid);
+			h[k2p2::kGrid + j] = std::sin(2.0 * k2p2::kPi * (double)j / (double)k2p2::kGrid);
+		}
+		TP_HIP(ctx, hipMalloc(&ctx->twiddle, sizeof(h)));
+		TP_HIP(ctx, hipMemcpy(ctx->twiddle, h, sizeof(h), hipMemcpyHostToDevice));
+	}
+	if (shmem > 64 * 1024) {
+		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_k2p2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+	}
+
+	k2p2::BatchArgs a;
+	a.n_targets = n_targets; a.H = height; a.W = width; a.sumimage = d_sumimage; a.cat_offsets = d_cat_offsets;
+	a.cat_column_stamp = d_cat_column_stamp; a.cat_row_stamp = d_cat_row_stamp; a.cat_tmag = d_cat_tmag;
+	a.cat_column = d_cat_column; a.cat_row = d_cat_row; a.cat_starid = d_cat_starid;
+	a.target_pos_row = d_target_pos_row; a.target_pos_column = d_target_pos_column; a.target_tmag = d_target_tmag;
+	a.target_starid = d_target_starid; a.stamps = d_stamps; a.aperture = d_aperture; a.cut_override = d_cut_override;
+	a.mask = d_mask; a.status = d_status; a.flags = d_flags; a.contamination = d_contamination; a.diag = d_diag;
+	a.cat_in_mask = d_cat_in_mask;
+	TP_LAUNCH(ctx, TPK_K2P2, tp_k2p2_kernel, dim3((unsigned)n_targets), dim3(64), shmem, a, prm, (const double*)ctx->twiddle);
+	TP_LAUNCH_CHECK(ctx, "tp_k2p2_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}

@@ -1,0 +1,1224 @@
+// k2p2_core.h -- A2..A5b + A7: K2P2 pixel-mask creation for ONE target by ONE wavefront.
+//
+// Replaces k2p2FixFromSum and its helpers (photometry/AperturePhotometry/k2p2v2.py:63-86, 89-288,
+// 291-341, 344-623) plus the mask selection / minimum aperture / contamination logic of
+// AperturePhotometry.do_photometry (photometry/AperturePhotometry/photometry.py:31-41, 93-131,
+// 220-254).  Third-party algorithms are restated from their published form:
+//   statsmodels 0.13.2  bw_scott/_select_sigma, kdensityfft (linear binning + Silverman transform),
+//                       KDEUnivariate.evaluate            (k2p2v2.py:410-420)
+//   scipy 1.7.3         stats.trim1, optimize bracket/Brent/_minimize_powell (k2p2v2.py:402,421),
+//                       ndimage.gaussian_filter(sigma=.5) (5 taps, reflect), ndimage.label
+//   scikit-learn 1.0.2  DBSCAN(eps=sqrt2+eps, min_samples=4) on a pixel grid
+//   scikit-image 0.19.2 peak_local_max, watershed (priority flood, label at push)
+//
+// Execution model.  The code is written in SPMD "phase" style: all cross-lane communication goes
+// through the per-target shared arrays (LDS), phases are separated by TP_SYNC(), parallel loops
+// use TP_PAR_FOR (independent iterations), inherently sequential parts (priority-flood watershed)
+// run under TP_SERIAL on lane 0, and scalar control flow (Brent/Powell iterations) is executed
+// redundantly and identically by all 64 lanes.  Reductions are "per-lane partials, then every lane
+// sums the 64 partials in lane order" so that the arithmetic is order-deterministic.
+//
+// The same source compiles for the host with TP_HOSTSIM (lanes become loops) -- used ONLY by the
+// CPU unit tests to debug the logic where no GPU is available; the product never runs it.
+// Built with -ffp-contract=off on both sides; exp() is an own implementation, so host-sim and
+// device results are bit-identical.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#ifdef TP_HOSTSIM
+#define TP_DEV
+#define TP_HD
+#define TP_LANE_LOOP(l) for (int l = 0; l < 64; ++l)
+#define TP_PAR_FOR(i, n) for (int i = 0; i < (n); ++i)
+#define TP_SYNC() do {} while (0)
+#define TP_SERIAL if (true)
+#else
+#define TP_DEV __device__
+#define TP_HD __host__ __device__
+#define TP_LANE_LOOP(l) for (int l = k.lane, _once = 0; _once < 1; ++_once)
+#define TP_PAR_FOR(i, n) for (int i = k.lane; i < (n); i += 64)
+#define TP_SYNC() __syncthreads()
+#define TP_SERIAL if (k.lane == 0)
+#endif
+
+namespace k2p2 {
+
+constexpr int kGrid = 128;          // KDE FFT grid: gridsize=100 -> next power of two (kde.py kdensityfft)
+constexpr double kMadToSigma = 1.482602218505602;   // photometry/utilities.py:25
+constexpr double kPi = 3.141592653589793;
+
+// status / flag encodings (per target)
+enum : int32_t {
+	FLAG_MIN_APERTURE = 1,      // photometry.py:99-112 (status WARNING)
+	FLAG_EDGE_DOWN = 2, FLAG_EDGE_UP = 4, FLAG_EDGE_LEFT = 8, FLAG_EDGE_RIGHT = 16,   // photometry.py:123-131
+	FLAG_NOSTARS = 32,          // K2P2NoStars (k2p2v2.py:454-455)
+	FLAG_NOMASKS = 64,          // k2p2FixFromSum returned None (k2p2v2.py:530-531)
+	ERR_SHIFT = 8,
+	ERR_NOFLUX = 1,             // K2P2NoFlux, uncaught by the plugin (k2p2v2.py:398-399)
+	ERR_BANDWIDTH_ZERO = 2,     // statsmodels RuntimeError "Selected KDE bandwidth is 0"
+	ERR_NO_PEAKS = 3,           // np.argmin of an empty distance array (k2p2v2.py:146)
+	ERR_TARGET_OUTSIDE = 4,     // IndexError at photometry.py:107
+	ERR_TOO_MANY_MASKS = 5,     // photometry.py:114-116
+	ERR_NO_TARGETS_IN_MASK = 6, // photometry.py:227-230
+};
+
+struct Params {
+	double thresh;                 // 0.8   (photometry.py:55)
+	int32_t min_no_pixels_in_mask; // 4
+	int32_t min_for_cluster;       // 4
+	int32_t extend_overflow;       // 1
+	int32_t reserved;
+	double ws_thres;               // 0
+	double saturation_limit;       // 7.0 (k2p2v2.py:49)
+	double gauss_w0, gauss_w1, gauss_w2; // ndimage.gaussian_filter(sigma=0.5) normalised taps
+};
+
+// Per-target inputs / outputs (global memory)
+struct Target {
+	const double* S;          // sum image [H*W]
+	int H, W;
+	int ncat;
+	const float* cat_col;     // column_stamp
+	const float* cat_row;     // row_stamp
+	const float* cat_tmag;
+	const float* cat_ccd_col; // column (CCD)
+	const float* cat_ccd_row; // row (CCD)
+	const int64_t* cat_starid;
+	double tpos_row, tpos_col;   // target CCD position (target_pos_row/column)
+	int stamp_row0, stamp_col0;  // stamp[0], stamp[2]
+	double target_tmag;
+	int64_t target_starid;
+	const int32_t* aperture;     // [H*W]
+	const double* cut_override;  // optional: replace CUT (tests of the integer pipeline)
+	// outputs
+	uint8_t* mask;            // [H*W] final_phot_mask
+	int32_t* status;          // STATUS integer
+	int32_t* flags;
+	double* contamination;
+	double* diag;             // [8]: CUT, MODE, MAD1, bandwidth, max_guess, nflux, margin, nmasks
+	uint8_t* cat_in_mask;     // [ncat] 1 if the catalog star falls in the final mask (skip_targets source)
+};
+
+// Shared (LDS) work arrays of one target.  Sizes in elements; P = H*W, Pp = pow2 >= P.
+struct Shared {
+	int lane;
+	int P, Pp, H, W;
+	double* S;        // [P]
+	double* srt;      // [Pp] sorted positive fluxes (+inf padding)
+	double* Z;        // [P]
+	double* dist;     // [P]
+	double* tmp;      // [P]
+	double* hval;     // [P] heap values
+	double* red;      // [64]
+	double* grid;     // [4*kGrid]: binned, dens, Yre, Yim
+	int32_t* lab;     // [P] DBSCAN labels
+	int32_t* lab2;    // [P] labels after watershed
+	int32_t* mark;    // [P] markers / component labels
+	int32_t* wsout;   // [P]
+	int32_t* hage;    // [P]
+	int32_t* hpix;    // [P]
+	int32_t* ired;    // [64]
+	int32_t* scal;    // [32] uniform scalars
+	uint8_t* idx;     // [P]
+	uint8_t* core;    // [P]
+	uint8_t* lmax;    // [P]
+	uint8_t* msk;     // [P] current mask
+	uint8_t* sat;     // [P] saturated additions for the current mask
+	uint8_t* res;     // [P] result mask
+	const double* twid; // [2*kGrid] cos, sin of 2*pi*j/kGrid (global / constant)
+};
+
+inline TP_HD size_t shared_bytes(int P) {
+	if (P < 64) P = 64; // several P-sized arrays double as 64-entry per-lane scratch
+	int Pp = 1;
+	while (Pp < P) Pp <<= 1;
+	size_t d = (size_t)P * 5 + Pp + 64 + 4 * kGrid;   // doubles
+	size_t i = (size_t)P * 6 + 64 + 32;               // int32
+	size_t b = (size_t)P * 6;                          // bytes
+	return d * 8 + i * 4 + ((b + 15) & ~(size_t)15) + 64;
+}
+
+inline TP_DEV void shared_carve(Shared& k, void* base, int H, int W, int lane, const double* twid) {
+	int P = H * W;
+	const int Pa = (P < 64) ? 64 : P; // allocation size (see shared_bytes)
+	int Pp = 1;
+	while (Pp < Pa) Pp <<= 1;
+	int Pp_sort = 1;
+	while (Pp_sort < P) Pp_sort <<= 1;
+	k.lane = lane; k.P = P; k.Pp = Pp_sort; k.H = H; k.W = W; k.twid = twid;
+	double* d = (double*)base;
+	k.S = d; d += Pa;
+	k.srt = d; d += Pp;
+	k.Z = d; d += Pa;
+	k.dist = d; d += Pa;
+	k.tmp = d; d += Pa;
+	k.hval = d; d += Pa;
+	k.red = d; d += 64;
+	k.grid = d; d += 4 * kGrid;
+	int32_t* i = (int32_t*)d;
+	k.lab = i; i += Pa;
+	k.lab2 = i; i += Pa;
+	k.mark = i; i += Pa;
+	k.wsout = i; i += Pa;
+	k.hage = i; i += Pa;
+	k.hpix = i; i += Pa;
+	k.ired = i; i += 64;
+	k.scal = i; i += 32;
+	uint8_t* b = (uint8_t*)i;
+	k.idx = b; b += Pa;
+	k.core = b; b += Pa;
+	k.lmax = b; b += Pa;
+	k.msk = b; b += Pa;
+	k.sat = b; b += Pa;
+	k.res = b; b += Pa;
+}
+
+//--------------------------------------------------------------------------------------------------
+// deterministic math
+//--------------------------------------------------------------------------------------------------
+inline TP_DEV double tp_inf() { return __builtin_inf(); }
+inline TP_DEV double tp_nan() { return __builtin_nan(""); }
+inline TP_DEV bool tp_isnan(double x) { return x != x; }
+
+inline TP_DEV double tp_pow2(int e) { // 2^e for -1022 <= e <= 1023
+	union { uint64_t u; double d; } c;
+	c.u = (uint64_t)(e + 1023) << 52;
+	return c.d;
+}
+
+// exp(x): range reduction x = k ln2 + r, 13-term Taylor in Horner form (|r| <= 0.3466 -> < 1 ulp),
+// plain IEEE mul/add only so that host-sim and device agree bit for bit.
+inline TP_DEV double tp_exp(double x) {
+	if (x != x) return x;
+	if (x > 709.782712893384) return tp_inf();
+	if (x < -745.2) return 0.0;
+	const double LOG2E = 1.4426950408889634074;
+	const double LN2_HI = 6.93147180369123816490e-01;
+	const double LN2_LO = 1.90821492927058770002e-10;
+	double kf = __builtin_floor(x * LOG2E + 0.5);
+	int ki = (int)kf;
+	double r = (x - kf * LN2_HI) - kf * LN2_LO;
+	double p = 1.0 / 6227020800.0;            // 1/13!
+	p = p * r + 1.0 / 479001600.0;            // 1/12!
+	p = p * r + 1.0 / 39916800.0;
+	p = p * r + 1.0 / 3628800.0;
+	p = p * r + 1.0 / 362880.0;
+	p = p * r + 1.0 / 40320.0;
+	p = p * r + 1.0 / 5040.0;
+	p = p * r + 1.0 / 720.0;
+	p = p * r + 1.0 / 120.0;
+	p = p * r + 1.0 / 24.0;
+	p = p * r + 1.0 / 6.0;
+	p = p * r + 0.5;
+	p = p * r + 1.0;
+	p = p * r + 1.0;
+	int k1 = ki / 2, k2 = ki - k1;
+	return (p * tp_pow2(k1)) * tp_pow2(k2);
+}
+
+// Sum of the 64 per-lane partials in lane order (every lane computes the same value).
+inline TP_DEV double sum_red(const Shared& k) {
+	double s = 0.0;
+	for (int l = 0; l < 64; ++l) s += k.red[l];
+	return s;
+}
+inline TP_DEV int sum_ired(const Shared& k) {
+	int s = 0;
+	for (int l = 0; l < 64; ++l) s += k.ired[l];
+	return s;
+}
+
+//--------------------------------------------------------------------------------------------------
+// A2: threshold
+//--------------------------------------------------------------------------------------------------
+// Bitonic sort of k.srt[0..Pp) ascending (NaN-free input; +inf padding).
+inline TP_DEV void bitonic_sort(Shared& k) {
+	const int n = k.Pp;
+	for (int size = 2; size <= n; size <<= 1) {
+		for (int stride = size >> 1; stride > 0; stride >>= 1) {
+			TP_PAR_FOR(t, n >> 1) {
+				const int lo = (t / stride) * (stride << 1) + (t % stride);
+				const int hi = lo + stride;
+				const bool up = ((lo & size) == 0);
+				const double a = k.srt[lo], b = k.srt[hi];
+				if ((a > b) == up) { k.srt[lo] = b; k.srt[hi] = a; }
+			}
+			TP_SYNC();
+		}
+	}
+}
+
+// scipy.stats.scoreatpercentile(x, per) on sorted data (interpolation 'fraction')
+inline TP_DEV double score_at_percentile(const double* sorted, int n, double per) {
+	const double idxf = per / 100.0 * (double)(n - 1);
+	const int i = (int)idxf;
+	if ((double)i == idxf) return sorted[i];
+	const double w0 = (double)(i + 1) - idxf, w1 = idxf - (double)i;
+	const double sumval = w0 + w1;
+	return (sorted[i] * w0 + sorted[i + 1] * w1) / sumval;
+}
+
+// -KDE(x): direct Gaussian sum over the nc values k.srt[0..nc) with bandwidth h
+// (statsmodels kernels.Gaussian: 0.3989422804014327*exp(-z**2/2); density = 1/(h n) * sum)
+inline TP_DEV double neg_kde(Shared& k, int nc, double h, double x) {
+	TP_LANE_LOOP(l) {
+		double s = 0.0;
+		for (int i = l; i < nc; i += 64) {
+			const double z = (k.srt[i] - x) / h;
+			s += 0.3989422804014327 * tp_exp(-(z * z) / 2.0);
+		}
+		k.red[l] = s;
+	}
+	TP_SYNC();
+	const double tot = sum_red(k);
+	TP_SYNC();
+	return -1.0 * ((1.0 / (h * (double)nc)) * tot);
+}
+
+struct KdeFn {
+	Shared* k; int nc; double h; double p; double xi; int* ncalls;
+	inline TP_DEV double operator()(double alpha) const { ++(*ncalls); return neg_kde(*k, nc, h, p + alpha * xi); }
+};
+
+// scipy.optimize.bracket(func, xa=0, xb=1) -- optimize.py (mnbrak)
+template <class F>
+inline TP_DEV void sp_bracket(const F& func, double& xa, double& xb, double& xc, double& fa, double& fb, double& fc) {
+	const double gold = 1.618034, verysmall = 1e-21, grow_limit = 110.0;
+	xa = 0.0; xb = 1.0;
+	fa = func(xa);
+	fb = func(xb);
+	if (fa < fb) { double t = xa; xa = xb; xb = t; t = fa; fa = fb; fb = t; }
+	xc = xb + gold * (xb - xa);
+	fc = func(xc);
+	int iter = 0;
+	while (fc < fb) {
+		const double tmp1 = (xb - xa) * (fb - fc);
+		const double tmp2 = (xb - xc) * (fb - fa);
+		const double val = tmp2 - tmp1;
+		double denom;
+		if (fabs(val) < verysmall) denom = 2.0 * verysmall;
+		else denom = 2.0 * val;
+		double w = xb - ((xb - xc) * tmp2 - (xb - xa) * tmp1) / denom;
+		const double wlim = xb + grow_limit * (xc - xb);
+		if (iter > 1000) break; // scipy raises RuntimeError here
+		iter += 1;
+		double fw;
+		if ((w - xc) * (xb - w) > 0.0) {
+			fw = func(w);
+			if (fw < fc) { xa = xb; xb = w; fa = fb; fb = fw; break; }
+			else if (fw > fb) { xc = w; fc = fw; break; }
+			w = xc + gold * (xc - xb);
+			fw = func(w);
+		} else if ((w - wlim) * (wlim - xc) >= 0.0) {
+			w = wlim;
+			fw = func(w);
+		} else if ((w - wlim) * (xc - w) > 0.0) {
+			fw = func(w);
+			if (fw < fc) {
+				xb = xc; xc = w; w = xc + gold * (xc - xb);
+				fb = fc; fc = fw; fw = func(w);
+			}
+		} else {
+			w = xc + gold * (xc - xb);
+			fw = func(w);
+		}
+		xa = xb; xb = xc; xc = w;
+		fa = fb; fb = fc; fc = fw;
+	}
+}
+
+// scipy.optimize.Brent(func, tol).optimize() with brack=None (scipy 1.7.3: no bracket validation)
+template <class F>
+inline TP_DEV void sp_brent(const F& func, double tol, double& xmin, double& fval) {
+	const double mintol = 1.0e-11, cg = 0.3819660;
+	double xa, xb, xc, fa, fb, fc;
+	sp_bracket(func, xa, xb, xc, fa, fb, fc);
+	double x = xb, w = xb, v = xb;
+	double fw = fb, fv = fb, fx = fb;
+	double a, b;
+	if (xa < xc) { a = xa; b = xc; } else { a = xc; b = xa; }
+	double deltax = 0.0, rat = 0.0;
+	int iter = 0;
+	while (iter < 500) {
+		const double tol1 = tol * fabs(x) + mintol;
+		const double tol2 = 2.0 * tol1;
+		const double xmid = 0.5 * (a + b);
+		if (fabs(x - xmid) < (tol2 - 0.5 * (b - a))) break;
+		if (fabs(deltax) <= tol1) {
+			if (x >= xmid) deltax = a - x; else deltax = b - x;
+			rat = cg * deltax;
+		} else {
+			double tmp1 = (x - w) * (fx - fv);
+			double tmp2 = (x - v) * (fx - fw);
+			double p = (x - v) * tmp2 - (x - w) * tmp1;
+			tmp2 = 2.0 * (tmp2 - tmp1);
+			if (tmp2 > 0.0) p = -p;
+			tmp2 = fabs(tmp2);
+			const double dx_temp = deltax;
+			deltax = rat;
+			if ((p > tmp2 * (a - x)) && (p < tmp2 * (b - x)) && (fabs(p) < fabs(0.5 * tmp2 * dx_temp))) {
+				rat = p * 1.0 / tmp2;
+				const double u = x + rat;
+				if ((u - a) < tol2 || (b - u) < tol2) {
+					if (xmid - x >= 0) rat = tol1; else rat = -tol1;
+				}
+			} else {
+				if (x >= xmid) deltax = a - x; else deltax = b - x;
+				rat = cg * deltax;
+			}
+		}
+		double u;
+		if (fabs(rat) < tol1) {
+			if (rat >= 0) u = x + tol1; else u = x - tol1;
+		} else {
+			u = x + rat;
+		}
+		const double fu = func(u);
+		if (fu > fx) {
+			if (u < x) a = u; else b = u;
+			if ((fu <= fw) || (w == x)) { v = w; w = u; fv = fw; fw = fu; }
+			else if ((fu <= fv) || (v == x) || (v == w)) { v = u; fv = fu; }
+		} else {
+			if (u >= x) a = x; else b = x;
+			v = w; w = x; x = u;
+			fv = fw; fw = fx; fx = fu;
+		}
+		iter += 1;
+	}
+	xmin = x;
+	fval = fx;
+}
+
+// scipy.optimize.minimize(f, x0, method='Powell').x for one parameter (xtol = ftol = 1e-4)
+inline TP_DEV double powell_mode(Shared& k, int nc, double h, double x0) {
+	const double xtol = 1e-4, ftol = 1e-4;
+	int ncalls = 0;
+	double x = x0;
+	double direc = 1.0;
+	double fval = neg_kde(k, nc, h, x); ncalls++;
+	double x1 = x;
+	int iter = 0;
+	while (true) {
+		const double fx = fval;
+		double delta = 0.0;
+		double direc1 = direc;
+		double fx2 = fval;
+		if (direc1 != 0.0) { // _linesearch_powell
+			KdeFn fn{&k, nc, h, x, direc1, &ncalls};
+			double alpha_min, fret;
+			sp_brent(fn, xtol * 100, alpha_min, fret);
+			direc1 = alpha_min * direc1;
+			x = x + direc1;
+			fval = fret;
+		}
+		if ((fx2 - fval) > delta) delta = fx2 - fval;
+		iter += 1;
+		const double bnd = ftol * (fabs(fx) + fabs(fval)) + 1e-20;
+		if (2.0 * (fx - fval) <= bnd) break;
+		if (ncalls >= 1000) break;
+		if (iter >= 1000) break;
+		if (tp_isnan(fx) && tp_isnan(fval)) break;
+		direc1 = x - x1;
+		x1 = x;
+		const double x2 = x + 1 * direc1;
+		fx2 = neg_kde(k, nc, h, x2); ncalls++;
+		if (fx > fx2) {
+			double t = 2.0 * (fx + fx2 - 2.0 * fval);
+			double temp = (fx - fval - delta);
+			t *= temp * temp;
+			temp = fx - fx2;
+			t -= delta * temp * temp;
+			if (t < 0.0) {
+				if (direc1 != 0.0) {
+					KdeFn fn{&k, nc, h, x, direc1, &ncalls};
+					double alpha_min, fret;
+					sp_brent(fn, xtol * 100, alpha_min, fret);
+					direc1 = alpha_min * direc1;
+					x = x + direc1;
+					fval = fret;
+				}
+				if (direc1 != 0.0) direc = direc1;
+			}
+		}
+	}
+	return x;
+}
+
+// Returns 0 ok, or an ERR_* code; fills diag[0..5] and leaves CUT in *cut (may be NaN).
+inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, double* cut) {
+	const int P = k.P;
+	// Flux = S[~isnan(S)]; Flux = Flux[Flux > 0]   (k2p2v2.py:394-395) -> compacted in raster order
+	TP_LANE_LOOP(l) {
+		int c = 0;
+		for (int p = l; p < P; p += 64) c += (k.S[p] > 0.0) ? 1 : 0;
+		k.ired[l] = c;
+	}
+	TP_SYNC();
+	const int nflux = sum_ired(k);
+	TP_SYNC();
+	if (nflux == 0) return ERR_NOFLUX;
+	// fill the sort buffer (order is irrelevant before sorting)
+	TP_PAR_FOR(p, k.Pp) k.srt[p] = (p < P && k.S[p] > 0.0) ? k.S[p] : tp_inf();
+	TP_SYNC();
+	bitonic_sort(k);
+	// count of finite entries == nflux unless some flux is +inf (kept, as numpy would)
+	// trim1(sorted, 0.15): keep the n - int(0.15 n) smallest (scipy/stats trim1, tail='right')
+	int nc = nflux - (int)(0.15 * (double)nflux);
+	// flux_cut = flux_cut[flux_cut < 70000]  (k2p2v2.py:407): a prefix of the sorted array
+	TP_LANE_LOOP(l) {
+		int c = 0;
+		for (int i = l; i < nc; i += 64) c += (k.srt[i] < 70000.0) ? 1 : 0;
+		k.ired[l] = c;
+	}
+	TP_SYNC();
+	nc = sum_ired(k);
+	TP_SYNC();
+	if (t.diag) { TP_SERIAL { t.diag[5] = (double)nflux; } }
+
+	// --- bw_scott: 1.059 * min(std(ddof=1), IQR/1.349) * n^-0.2   (bandwidths.py)
+	double bw;
+	{
+		TP_LANE_LOOP(l) { double s = 0.0; for (int i = l; i < nc; i += 64) s += k.srt[i]; k.red[l] = s; }
+		TP_SYNC();
+		const double mean = sum_red(k) / (double)nc;
+		TP_SYNC();
+		TP_LANE_LOOP(l) { double s = 0.0; for (int i = l; i < nc; i += 64) { const double d = k.srt[i] - mean; s += d * d; } k.red[l] = s; }
+		TP_SYNC();
+		const double var = sum_red(k) / (double)(nc - 1); // nc == 1 -> 0/0 = NaN like numpy
+		TP_SYNC();
+		const double std_dev = sqrt(var);
+		double A = std_dev;
+		if (nc > 0) {
+			const double IQR = (score_at_percentile(k.srt, nc, 75.0) - score_at_percentile(k.srt, nc, 25.0)) / 1.349;
+			if (IQR > 0) A = (std_dev < IQR || tp_isnan(std_dev)) ? std_dev : IQR; // np.minimum propagates NaN
+		}
+		// n ** (-0.2) via exp/log would not be bit-stable; use pow from the toolchain only here
+		bw = 1.059 * A * pow((double)nc, -0.2);
+	}
+	if (nc == 0) bw = tp_nan();
+	if (bw == 0.0) return ERR_BANDWIDTH_ZERO;
+
+	// --- kdensityfft: linear binning on a 128-point grid, Silverman transform, inverse transform
+	double max_guess;
+	{
+		const int M = kGrid;
+		const double a = k.srt[0] - 3.0 * bw;
+		const double b = ((nc > 0) ? k.srt[nc - 1] : tp_nan()) + 3.0 * bw;
+		const double delta = (b - a) / (double)(M - 1);   // np.linspace retstep
+		const double RANGE = b - a;
+		double* binned = k.grid; double* dens = k.grid + M; double* Yre = k.grid + 2 * M; double* Yim = k.grid + 3 * M;
+		// fast_linbin: bin m accumulates, in data order, (1 - rem) from points with li == m and rem from li == m-1
+		TP_PAR_FOR(m, M) {
+			double g = 0.0;
+			for (int i = 0; i < nc; ++i) {
+				const double lxi = (k.srt[i] - a) / delta;
+				const int li = (int)lxi;
+				const double rem = lxi - (double)li;
+				if (li > 1 && li < M) {
+					if (li == m) g = g + 1 - rem;
+					else if (li + 1 == m) g = g + rem;
+				}
+			}
+			binned[m] = g / (delta * (double)nc);
+		}
+		TP_SYNC();
+		// forward real DFT (Y = rfft(binned)), k = 0..M/2
+		TP_PAR_FOR(kk, M / 2 + 1) {
+			double re = 0.0, im = 0.0;
+			for (int n = 0; n < M; ++n) {
+				const int j = (kk * n) & (M - 1);
+				re += binned[n] * k.twid[j];
+				im -= binned[n] * k.twid[M + j];
+			}
+			// zstar = silverman_transform * forrt(binned): FAC[k] * Y[k] / M
+			const double FAC1 = 2.0 * ((kPi * bw / RANGE) * (kPi * bw / RANGE));
+			const double J = (double)kk;
+			const double BC = 1.0 - 1.0 / 3.0 * ((J * 1.0 / (double)M * kPi) * (J * 1.0 / (double)M * kPi));
+			const double FAC = tp_exp(-(J * J * FAC1)) / BC;
+			Yre[kk] = FAC * (re / (double)M);
+			Yim[kk] = FAC * (im / (double)M);
+		}
+		TP_SYNC();
+		// revrt: irfft(Z) * M  ->  f[m] = Z0 + 2 sum_{k=1}^{M/2-1} Re(Z_k e^{+2 pi i k m / M}) + Z_{M/2} (-1)^m
+		TP_PAR_FOR(m, M) {
+			double f = Yre[0];
+			for (int kk = 1; kk < M / 2; ++kk) {
+				const int j = (kk * m) & (M - 1);
+				f += 2.0 * (Yre[kk] * k.twid[j] - Yim[kk] * k.twid[M + j]);
+			}
+			f += Yre[M / 2] * ((m & 1) ? -1.0 : 1.0);
+			dens[m] = f;
+		}
+		TP_SYNC();
+		// support[argmax(density)]: np.argmax returns the first maximum, NaN counts as maximum
+		int am = 0;
+		double best = dens[0];
+		if (!tp_isnan(best)) {
+			for (int m = 1; m < M; ++m) {
+				const double d = dens[m];
+				if (tp_isnan(d)) { am = m; break; }
+				if (d > best) { best = d; am = m; }
+			}
+		}
+		// np.linspace(a, b, M)[am] = a + am*step, last point set to b exactly
+		max_guess = (am == M - 1) ? b : (a + (double)am * delta);
+		TP_SYNC();
+	}
+
+	const double MODE = powell_mode(k, nc, bw, max_guess);
+
+	// MAD1 = mad_to_sigma * nanmedian(|Flux[Flux < MODE] - MODE|)   (k2p2v2.py:424)
+	// Flux sorted ascending: the selection is the prefix [0, c)
+	TP_LANE_LOOP(l) {
+		int c = 0;
+		for (int i = l; i < nflux; i += 64) c += (k.srt[i] < MODE) ? 1 : 0;
+		k.ired[l] = c;
+	}
+	TP_SYNC();
+	const int c = sum_ired(k);
+	TP_SYNC();
+	double med;
+	if (c == 0) med = tp_nan();
+	else if (c & 1) med = fabs(k.srt[c / 2] - MODE);
+	else {
+		const double d0 = fabs(k.srt[c / 2] - MODE), d1 = fabs(k.srt[c / 2 - 1] - MODE);
+		med = (d0 + d1) / 2.0; // np.median: mean of the two middle values (ascending order: d0 <= d1)
+	}
+	const double MAD1 = kMadToSigma * med;
+	const double CUT = MODE + prm.thresh * MAD1;
+	*cut = CUT;
+	if (t.diag) {
+		TP_SERIAL { t.diag[0] = CUT; t.diag[1] = MODE; t.diag[2] = MAD1; t.diag[3] = bw; t.diag[4] = max_guess; }
+	}
+	return 0;
+}
+
+//--------------------------------------------------------------------------------------------------
+// small image helpers
+//--------------------------------------------------------------------------------------------------
+// Connected-component labelling of the non-zero pixels of `in` by min-index propagation;
+// conn8: 8- or 4-connectivity.  out[p] = 1-based component number in raster order of first pixel
+// (scipy.ndimage.label numbering), 0 for background.  Returns the number of components.
+inline TP_DEV int label_components(Shared& k, const uint8_t* in, int32_t* out, bool conn8) {
+	const int P = k.P, H = k.H, W = k.W;
+	TP_PAR_FOR(p, P) out[p] = in[p] ? p : -1;
+	TP_SYNC();
+	while (true) {
+		TP_LANE_LOOP(l) {
+			int changed = 0;
+			for (int p = l; p < P; p += 64) {
+				int cur = out[p];
+				if (cur < 0) continue;
+				const int r = p / W, c = p - r * W;
+				int best = cur;
+				for (int dr = -1; dr <= 1; ++dr) {
+					for (int dc = -1; dc <= 1; ++dc) {
+						if (dr == 0 && dc == 0) continue;
+						if (!conn8 && dr != 0 && dc != 0) continue;
+						const int rr = r + dr, cc = c + dc;
+						if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+						const int v = out[rr * W + cc];
+						if (v >= 0 && v < best) best = v;
+					}
+				}
+				if (best < cur) { out[p] = best; changed = 1; }
+			}
+			k.ired[l] = changed;
+		}
+		TP_SYNC();
+		const int any = sum_ired(k);
+		TP_SYNC();
+		if (!any) break;
+	}
+	// roots -> consecutive numbers in raster order (serial prefix over P, cheap)
+	TP_SERIAL {
+		int n = 0;
+		for (int p = 0; p < P; ++p) {
+			if (out[p] == p) { n++; k.hpix[p] = n; }
+		}
+		k.scal[0] = n;
+	}
+	TP_SYNC();
+	TP_PAR_FOR(p, P) { const int root = out[p]; k.hage[p] = (root >= 0) ? k.hpix[root] : 0; }
+	TP_SYNC();
+	TP_PAR_FOR(p, P) out[p] = k.hage[p];
+	TP_SYNC();
+	const int n = k.scal[0];
+	TP_SYNC();
+	return n;
+}
+
+// bottleneck.nanmedian of v[0..n) (n small); returns NaN for no valid value.  Serial.
+inline TP_DEV double nanmedian_small(const double* v, int n, double* scratch) {
+	int m = 0;
+	for (int i = 0; i < n; ++i) {
+		const double x = v[i];
+		if (tp_isnan(x)) continue;
+		int j = m++;
+		while (j > 0 && scratch[j - 1] > x) { scratch[j] = scratch[j - 1]; --j; }
+		scratch[j] = x;
+	}
+	if (m == 0) return tp_nan();
+	if (m & 1) return scratch[m / 2];
+	return (scratch[m / 2 - 1] + scratch[m / 2]) / 2.0;
+}
+
+// k2p2_saturated for ONE mask (k2p2v2.py:291-341): mask in k.msk -> additions in k.sat.
+// Uses k.tmp / k.hval as column scratch.  Returns (uniform) number of pixels set in k.sat.
+inline TP_DEV int saturated_one(Shared& k) {
+	const int P = k.P, H = k.H, W = k.W;
+	TP_PAR_FOR(p, P) k.sat[p] = 0;
+	// mask_max = nanmax(S[mask])
+	TP_LANE_LOOP(l) {
+		double m = -tp_inf(); int any = 0;
+		for (int p = l; p < P; p += 64) if (k.msk[p] && !tp_isnan(k.S[p])) { if (!any || k.S[p] > m) m = k.S[p]; any = 1; }
+		k.red[l] = m; k.ired[l] = any;
+	}
+	TP_SYNC();
+	double mask_max = tp_nan();
+	{
+		int any = 0; double m = 0;
+		for (int l = 0; l < 64; ++l) if (k.ired[l]) { if (!any || k.red[l] > m) m = k.red[l]; any = 1; }
+		if (any) mask_max = m;
+	}
+	TP_SYNC();
+	// one column per lane (columns are independent: k2p2v2.py:312-339)
+	TP_PAR_FOR(c, W) {
+		double* pix = k.tmp + (size_t)c * H;      // [H] per column (W*H = P doubles)
+		double* scr = k.hval + (size_t)c * H;
+		int n = 0;
+		for (int r = 0; r < H; ++r) if (k.msk[r * W + c]) pix[n++] = k.S[r * W + c];
+		if (n == 0) continue;
+		// ratio = |nanmedian(diff(pixels))| / nanmax(pixels)
+		double pmax = tp_nan(); { int any = 0; for (int i = 0; i < n; ++i) if (!tp_isnan(pix[i])) { if (!any || pix[i] > pmax) pmax = pix[i]; any = 1; } }
+		const double medpix = nanmedian_small(pix, n, scr);
+		// diff in place (pix no longer needed afterwards except through medpix/pmax)
+		for (int i = 0; i + 1 < n; ++i) pix[i] = pix[i + 1] - pix[i];
+		const double meddiff = nanmedian_small(pix, n - 1, scr);
+		const double ratio = fabs(meddiff) / pmax;
+		if (ratio < 0.01 && medpix >= mask_max / 2) {
+			// imax = nanargmax(S * mask * column_mask) over the whole image (first maximum in raster order)
+			int imax = -1; double best = 0.0;
+			for (int p = 0; p < P; ++p) {
+				const int pr = p / W, pc = p - pr * W;
+				const double v = k.S[p] * (double)(k.msk[p] ? 1 : 0) * (double)(pc == c ? 1 : 0);
+				if (tp_isnan(v)) continue;
+				if (imax < 0 || v > best) { best = v; imax = p; }
+			}
+			if (imax >= 0) {
+				const int ir = imax / W, ic = imax - ir * W;
+				// add_to_mask = idx & column; keep the 4-connected (vertical) run containing imax
+				if (ic == c && k.idx[imax]) {
+					int r0 = ir, r1 = ir;
+					while (r0 > 0 && k.idx[(r0 - 1) * W + c]) --r0;
+					while (r1 + 1 < H && k.idx[(r1 + 1) * W + c]) ++r1;
+					for (int r = r0; r <= r1; ++r) k.sat[r * W + c] = 1;
+				}
+			}
+		}
+	}
+	TP_SYNC();
+	TP_LANE_LOOP(l) { int c = 0; for (int p = l; p < P; p += 64) c += k.sat[p]; k.ired[l] = c; }
+	TP_SYNC();
+	const int n = sum_ired(k);
+	TP_SYNC();
+	return n;
+}
+
+// ndimage.gaussian_filter(Z, 0.5): radius 2, correlate1d along axis 0 then axis 1, mode 'reflect',
+// symmetric-kernel summation order of ni_filters.c: c*w0 + (l1+r1)*w1 + (l2+r2)*w2
+inline TP_DEV int reflect_idx(int i, int n) {
+	// scipy 'reflect' (d c b a | a b c d | d c b a), valid for any offset
+	if (n == 1) return 0;
+	const int n2 = 2 * n;
+	if (i < 0) { i = -i - 1; }
+	i = i % n2;
+	if (i >= n) i = n2 - 1 - i;
+	return i;
+}
+inline TP_DEV void gaussian_blur(Shared& k, const Params& prm, const double* in, double* out) {
+	const int P = k.P, H = k.H, W = k.W;
+	const double w0 = prm.gauss_w0, w1 = prm.gauss_w1, w2 = prm.gauss_w2;
+	// axis 0 (rows) -> tmp
+	TP_PAR_FOR(p, P) {
+		const int r = p / W, c = p - r * W;
+		double v = in[p] * w0;
+		v += (in[reflect_idx(r - 1, H) * W + c] + in[reflect_idx(r + 1, H) * W + c]) * w1;
+		v += (in[reflect_idx(r - 2, H) * W + c] + in[reflect_idx(r + 2, H) * W + c]) * w2;
+		k.tmp[p] = v;
+	}
+	TP_SYNC();
+	TP_PAR_FOR(p, P) {
+		const int r = p / W, c = p - r * W;
+		double v = k.tmp[p] * w0;
+		v += (k.tmp[r * W + reflect_idx(c - 1, W)] + k.tmp[r * W + reflect_idx(c + 1, W)]) * w1;
+		v += (k.tmp[r * W + reflect_idx(c - 2, W)] + k.tmp[r * W + reflect_idx(c + 2, W)]) * w2;
+		out[p] = v;
+	}
+	TP_SYNC();
+}
+
+// skimage.segmentation.watershed(-Z, markers, mask=Z) (connectivity 1).  Serial on lane 0.
+// image value of pixel p is -Z[p]; in: k.mark (markers, already multiplied by mask); out: k.wsout.
+inline TP_DEV void watershed(Shared& k) {
+	const int P = k.P, H = k.H, W = k.W;
+	TP_PAR_FOR(p, P) k.wsout[p] = (k.Z[p] != 0.0) ? k.mark[p] : 0;
+	TP_SYNC();
+	TP_SERIAL {
+		int hn = 0;
+		int age = 1;
+		// binary min-heap on (value, age); entries in hval/hage/hpix
+		auto less = [&](int a, int b) -> bool {
+			if (k.hval[a] != k.hval[b]) return k.hval[a] < k.hval[b];
+			return k.hage[a] < k.hage[b];
+		};
+		auto push = [&](double v, int ag, int px) {
+			int i = hn++;
+			k.hval[i] = v; k.hage[i] = ag; k.hpix[i] = px;
+			while (i > 0) {
+				const int par = (i - 1) >> 1;
+				if (!less(i, par)) break;
+				double tv = k.hval[i]; k.hval[i] = k.hval[par]; k.hval[par] = tv;
+				int ta = k.hage[i]; k.hage[i] = k.hage[par]; k.hage[par] = ta;
+				int tp = k.hpix[i]; k.hpix[i] = k.hpix[par]; k.hpix[par] = tp;
+				i = par;
+			}
+		};
+		for (int p = 0; p < P; ++p) if (k.wsout[p] != 0) push(-k.Z[p], 0, p);
+		while (hn > 0) {
+			const int px = k.hpix[0];
+			// pop
+			hn--;
+			if (hn > 0) {
+				k.hval[0] = k.hval[hn]; k.hage[0] = k.hage[hn]; k.hpix[0] = k.hpix[hn];
+				int i = 0;
+				while (true) {
+					const int lft = 2 * i + 1, rgt = lft + 1;
+					int sm = i;
+					if (lft < hn && less(lft, sm)) sm = lft;
+					if (rgt < hn && less(rgt, sm)) sm = rgt;
+					if (sm == i) break;
+					double tv = k.hval[i]; k.hval[i] = k.hval[sm]; k.hval[sm] = tv;
+					int ta = k.hage[i]; k.hage[i] = k.hage[sm]; k.hage[sm] = ta;
+					int tp = k.hpix[i]; k.hpix[i] = k.hpix[sm]; k.hpix[sm] = tp;
+					i = sm;
+				}
+			}
+			const int r = px / W, c = px - r * W;
+			const int nbr[4] = {r - 1, r, r, r + 1};
+			const int nbc[4] = {c, c - 1, c + 1, c};
+			for (int q = 0; q < 4; ++q) {
+				const int rr = nbr[q], cc = nbc[q];
+				if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+				const int nb = rr * W + cc;
+				if (k.Z[nb] == 0.0) continue;      // not in mask
+				if (k.wsout[nb] != 0) continue;    // already labelled
+				age += 1;
+				k.wsout[nb] = k.wsout[px];
+				push(-k.Z[nb], age, nb);
+			}
+		}
+	}
+	TP_SYNC();
+}
+
+//--------------------------------------------------------------------------------------------------
+// the whole per-target pipeline
+//--------------------------------------------------------------------------------------------------
+inline TP_DEV float mags_total_f32(const float* tmag, const uint8_t* sel, int n) {
+	// -2.5*log10(nansum(10**(-0.4*mags)))  in float32 like numpy on a float32 column
+	float s = 0.f;
+	for (int i = 0; i < n; ++i) {
+		if (!sel[i]) continue;
+		const float v = powf(10.0f, -0.4f * tmag[i]);
+		if (v == v) s += v;
+	}
+	return -2.5f * log10f(s);
+}
+
+inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
+	const int P = k.P, H = k.H, W = k.W;
+	TP_PAR_FOR(p, P) { k.S[p] = t.S[p]; k.res[p] = 0; }
+	TP_SYNC();
+	int flags = 0;
+	int status = 1; // STATUS.OK
+	int err = 0;
+	bool have_masks = false;
+	int hits = 0;
+
+	// ---------------- A2 ----------------
+	double CUT = tp_nan();
+	if (t.cut_override) { CUT = *t.cut_override; if (t.diag) { TP_SERIAL { t.diag[0] = CUT; } } }
+	else err = threshold(k, prm, t, &CUT);
+
+	// target pixel (photometry.py:107): Python round() = round-half-even; negative indices wrap
+	int tr = (int)rint(t.tpos_row - (double)t.stamp_row0);
+	int tc = (int)rint(t.tpos_col - (double)t.stamp_col0);
+	bool target_inside = true;
+	if (tr < 0) tr += H;
+	if (tc < 0) tc += W;
+	if (tr < 0 || tr >= H || tc < 0 || tc >= W) target_inside = false;
+
+	int nmasks_total = 0;
+	if (!err) {
+		// idx = S > CUT (NaN -> False)  (k2p2v2.py:449-450)
+		TP_LANE_LOOP(l) {
+			int c = 0; double margin = tp_inf();
+			for (int p = l; p < P; p += 64) {
+				const double s = k.S[p];
+				const uint8_t v = (s > CUT) ? 1 : 0;
+				k.idx[p] = v; c += v;
+				if (!tp_isnan(s)) { const double d = fabs(s - CUT); if (d < margin) margin = d; }
+			}
+			k.ired[l] = c; k.red[l] = margin;
+		}
+		TP_SYNC();
+		const int nidx = sum_ired(k);
+		double margin = tp_inf();
+		for (int l = 0; l < 64; ++l) if (k.red[l] < margin) margin = k.red[l];
+		TP_SYNC();
+		if (t.diag) { TP_SERIAL { t.diag[6] = margin; } }
+		if (nidx == 0) {
+			flags |= FLAG_NOSTARS; // K2P2NoStars -> minimum aperture
+		} else {
+			// ---------------- A3: DBSCAN on the grid ----------------
+			TP_PAR_FOR(p, P) {
+				const int r = p / W, c = p - r * W;
+				int cnt = 0;
+				for (int dr = -1; dr <= 1; ++dr) for (int dc = -1; dc <= 1; ++dc) {
+					const int rr = r + dr, cc = c + dc;
+					if (rr >= 0 && rr < H && cc >= 0 && cc < W) cnt += k.idx[rr * W + cc];
+				}
+				k.core[p] = (k.idx[p] && cnt >= prm.min_for_cluster) ? 1 : 0;
+			}
+			TP_SYNC();
+			const int nclusters = label_components(k, k.core, k.mark, true);
+			// lab: -2 outside idx, -1 noise, cluster id (0-based) for core; border = min neighbouring cluster
+			TP_PAR_FOR(p, P) {
+				int v = -2;
+				if (k.idx[p]) {
+					v = -1;
+					if (k.core[p]) v = k.mark[p] - 1;
+					else {
+						const int r = p / W, c = p - r * W;
+						int best = 0x7fffffff;
+						for (int dr = -1; dr <= 1; ++dr) for (int dc = -1; dc <= 1; ++dc) {
+							const int rr = r + dr, cc = c + dc;
+							if (rr >= 0 && rr < H && cc >= 0 && cc < W && k.core[rr * W + cc]) {
+								const int q = k.mark[rr * W + cc] - 1;
+								if (q < best) best = q;
+							}
+						}
+						if (best != 0x7fffffff) v = best;
+					}
+				}
+				k.lab[p] = v;
+			}
+			TP_SYNC();
+
+			// ---------------- A4: watershed per cluster (segmentation=True, any cluster) ----------------
+			// Labels after k2p2WS: non-core -> noise (k2p2v2.py:112)
+			TP_PAR_FOR(p, P) k.lab2[p] = (k.idx[p]) ? ((k.core[p]) ? k.lab[p] : -1) : -2;
+			TP_SYNC();
+			int max_label = nclusters - 1;
+			for (int lab = 0; lab < nclusters && !err; ++lab) {
+				// pre-pass saturated mask of the un-split cluster incl. border points (k2p2v2.py:465-492)
+				TP_PAR_FOR(p, P) k.msk[p] = (k.lab[p] == lab) ? 1 : 0;
+				TP_SYNC();
+				const int nsat = saturated_one(k);
+				// Z = flux on the core pixels of this cluster
+				TP_PAR_FOR(p, P) k.Z[p] = (k.lab2[p] == lab) ? k.S[p] : 0.0;
+				TP_SYNC();
+				gaussian_blur(k, prm, k.Z, k.dist);
+				// peak_local_max(distance, exclude_border=False, threshold_rel=ws_thres, footprint=ones(3,3))
+				TP_LANE_LOOP(l) {
+					double mn = tp_inf(), mx = -tp_inf();
+					for (int p = l; p < P; p += 64) { const double d = k.dist[p]; if (d < mn) mn = d; if (d > mx) mx = d; }
+					k.red[l] = mn; k.hval[l] = mx;
+				}
+				TP_SYNC();
+				double dmin = tp_inf(), dmax = -tp_inf();
+				for (int l = 0; l < 64; ++l) { if (k.red[l] < dmin) dmin = k.red[l]; if (k.hval[l] > dmax) dmax = k.hval[l]; }
+				TP_SYNC();
+				double pk_thr = dmin;
+				{ const double rel = prm.ws_thres * dmax; if (rel > pk_thr) pk_thr = rel; } // max(min, rel*max)
+				TP_LANE_LOOP(l) {
+					int allpk = 1;
+					for (int p = l; p < P; p += 64) {
+						const int r = p / W, c = p - r * W;
+						double m = 0.0; // mode='constant', cval=0: out-of-image neighbours count as 0
+						bool first = true;
+						for (int dr = -1; dr <= 1; ++dr) for (int dc = -1; dc <= 1; ++dc) {
+							const int rr = r + dr, cc = c + dc;
+							const double v = (rr >= 0 && rr < H && cc >= 0 && cc < W) ? k.dist[rr * W + cc] : 0.0;
+							if (first || v > m) { m = v; first = false; }
+						}
+						const uint8_t pk = (k.dist[p] == m) ? 1 : 0;
+						k.lmax[p] = pk; // candidate peaks
+						if (!pk) allpk = 0;
+					}
+					k.ired[l] = allpk;
+				}
+				TP_SYNC();
+				int trivial = 1;
+				for (int l = 0; l < 64; ++l) if (!k.ired[l]) trivial = 0;
+				TP_SYNC();
+				TP_LANE_LOOP(l) {
+					int c = 0;
+					for (int p = l; p < P; p += 64) {
+						const uint8_t pk = (!trivial && k.lmax[p] && k.dist[p] > pk_thr) ? 1 : 0;
+						k.lmax[p] = pk; c += pk;
+					}
+					k.ired[l] = c;
+				}
+				TP_SYNC();
+				const int npeaks = sum_ired(k);
+				TP_SYNC();
+				// peaks matched to catalog stars (k2p2v2.py:144-153); candidates stay in lmax, selection in sat? no:
+				// selection goes to k.core-independent temp: reuse wsout as "selected" flags
+				TP_PAR_FOR(p, P) k.wsout[p] = 0;
+				TP_SYNC();
+				if (t.ncat > 0 && npeaks == 0) { err = ERR_NO_PEAKS; break; }
+				TP_PAR_FOR(s, t.ncat) {
+					const double c0 = (double)t.cat_col[s], c1 = (double)t.cat_row[s];
+					int bi = -1; double bd = 0.0, bint = 0.0;
+					for (int p = 0; p < P; ++p) {
+						if (!k.lmax[p]) continue;
+						const int r = p / W, c = p - r * W;
+						const double dx = (double)c - c0, dy = (double)r - c1;
+						const double d = sqrt(dx * dx + dy * dy);
+						// np.argmin over peaks sorted by decreasing intensity (stable): first minimum
+						const double inten = k.dist[p];
+						bool better;
+						if (bi < 0) better = true;
+						else if (tp_isnan(bd)) better = false;     // np.argmin returns the first NaN
+						else if (tp_isnan(d)) better = true;       // ... so a NaN distance earlier in the list would win
+						else if (d < bd) better = true;
+						else if (d == bd && inten > bint) better = true;
+						else better = false;
+						if (better) { bi = p; bd = d; bint = inten; }
+					}
+					if (bi >= 0) {
+						const double dist_factor = ((double)t.cat_tmag[s] > prm.saturation_limit) ? 2.0 : 5.0;
+						if (bd < dist_factor * 1.4142135623730951) k.wsout[bi] = 1; // benign same-value race
+					}
+				}
+				TP_SYNC();
+				TP_PAR_FOR(p, P) k.lmax[p] = k.wsout[p] ? 1 : 0; // local_maxi
+				TP_SYNC();
+				// de-duplicate maxima inside saturated patches (k2p2v2.py:193-212)
+				if (nsat > 0) {
+					const int ncomp = label_components(k, k.sat, k.mark, false);
+					for (int cc = 1; cc <= ncomp; ++cc) {
+						TP_LANE_LOOP(l) {
+							int c = 0;
+							for (int p = l; p < P; p += 64) c += (k.lmax[p] && k.mark[p] == cc) ? 1 : 0;
+							k.ired[l] = c;
+						}
+						TP_SYNC();
+						const int nin = sum_ired(k);
+						TP_SYNC();
+						if (nin > 1) {
+							TP_SERIAL {
+								// imax = nanargmax(distance * local_maxi * sp): first maximum in raster order
+								int imax = -1; double best = 0.0;
+								for (int p = 0; p < P; ++p) {
+									const double v = k.dist[p] * (double)k.lmax[p] * (double)((k.mark[p] == cc) ? 1 : 0);
+									if (tp_isnan(v)) continue;
+									if (imax < 0 || v > best) { best = v; imax = p; }
+								}
+								for (int p = 0; p < P; ++p) if (k.mark[p] == cc) k.lmax[p] = 0;
+								if (imax >= 0) k.lmax[imax] = 1;
+							}
+							TP_SYNC();
+						}
+					}
+				}
+				// markers = ndimage.label(local_maxi) (4-connectivity)
+				const int nmark = label_components(k, k.lmax, k.mark, false);
+				if (nmark == 0) {
+					// "No maxima were found": the cluster is rejected (k2p2v2.py:218-223)
+					TP_PAR_FOR(p, P) if (k.lab2[p] == lab) k.lab2[p] = -1;
+					TP_SYNC();
+				} else {
+					watershed(k); // k.mark -> k.wsout
+					// no_labels = number of distinct values in labels_ws, zero included (k2p2v2.py:230)
+					TP_SERIAL {
+						// distinct values among wsout: marker ids are 1..nmark (some may have vanished)
+						int distinct = 0; bool has0 = false;
+						for (int m = 1; m <= nmark; ++m) {
+							bool f = false;
+							for (int p = 0; p < P && !f; ++p) if (k.wsout[p] == m) f = true;
+							if (f) distinct++;
+						}
+						for (int p = 0; p < P && !has0; ++p) if (k.wsout[p] == 0) has0 = true;
+						k.scal[1] = distinct + (has0 ? 1 : 0);
+					}
+					TP_SYNC();
+					const int no_labels = k.scal[1];
+					TP_SYNC();
+					TP_PAR_FOR(p, P) {
+						if (k.lab2[p] == lab) {
+							int v = -1;
+							const int wlab = k.wsout[p]; // Z != 0 here by construction
+							if (wlab == 1) v = lab;
+							else if (wlab >= 2 && (wlab - 2) < (no_labels - 2)) v = max_label + (wlab - 1);
+							k.lab2[p] = v;
+						}
+					}
+					TP_SYNC();
+					if (no_labels - 2 > 0) max_label += (no_labels - 2);
+				}
+			}
+
+			// ---------------- A5: mask assembly, one candidate mask at a time ----------------
+			if (!err) {
+				for (int lab = 0; lab <= max_label && !err; ++lab) {
+					TP_LANE_LOOP(l) { int c = 0; for (int p = l; p < P; p += 64) c += (k.lab2[p] == lab) ? 1 : 0; k.ired[l] = c; }
+					TP_SYNC();
+					const int npx = sum_ired(k);
+					TP_SYNC();
+					if (npx < prm.min_no_pixels_in_mask) continue;
+					nmasks_total++;
+					have_masks = true;
+					TP_PAR_FOR(p, P) k.msk[p] = (k.lab2[p] == lab) ? 1 : 0;
+					TP_SYNC();
+					// fill holes: not in mask and all four neighbours in mask (k2p2v2.py:549-554)
+					TP_PAR_FOR(p, P) {
+						const int r = p / W, c = p - r * W;
+						uint8_t fill = 0;
+						if (!k.msk[p] && r > 0 && r < H - 1 && c > 0 && c < W - 1)
+							fill = (k.msk[p - W] && k.msk[p + W] && k.msk[p - 1] && k.msk[p + 1]) ? 1 : 0;
+						k.lmax[p] = fill;
+					}
+					TP_SYNC();
+					TP_PAR_FOR(p, P) if (k.lmax[p]) k.msk[p] = 1;
+					TP_SYNC();
+					// extend overflow columns (k2p2v2.py:579-623)
+					if (prm.extend_overflow) {
+						const int nsat = saturated_one(k);
+						if (nsat > 0) {
+							// stars inside the (hole-filled) mask decide whether the extension is allowed
+							TP_SERIAL {
+								float s = 0.f; int nst = 0;
+								for (int i = 0; i < t.ncat; ++i) {
+									const int c = (int)rintf(t.cat_col[i]), r = (int)rintf(t.cat_row[i]);
+									if (c < 0 || c >= W || r < 0 || r >= H) continue;
+									if (!k.msk[r * W + c]) continue;
+									const float v = powf(10.0f, -0.4f * t.cat_tmag[i]);
+									if (v == v) s += v;
+									nst++;
+								}
+								int allow = 0;
+								if (nst > 0) {
+									const float mt = -2.5f * log10f(s);
+									allow = !((double)mt > prm.saturation_limit);
+								}
+								k.scal[2] = allow;
+							}
+							TP_SYNC();
+							if (k.scal[2]) { TP_PAR_FOR(p, P) if (k.sat[p]) k.msk[p] = 1; }
+							TP_SYNC();
+						}
+					}
+					// does this mask contain the target pixel?  (photometry.py:107)
+					if (!target_inside) { err = ERR_TARGET_OUTSIDE; break; }
+					if (k.msk[tr * W + tc]) {
+						hits++;
+						TP_PAR_FOR(p, P) k.res[p] = k.msk[p];
+					}
+					TP_SYNC();
+				}
+			}
+		}
+	}
+
+	bool using_min = false;
+	if (!err) {
+		if (!have_masks) { using_min = true; if (!(flags & FLAG_NOSTARS)) flags |= FLAG_NOMASKS; }
+		else if (hits == 0) using_min = true;
+		else if (hits > 1) err = ERR_TOO_MANY_MASKS;
+	}
+	if (!err && using_min) {
+		// _minimum_aperture (photometry.py:31-41)
+		TP_PAR_FOR(p, P) {
+			const int r = p / W, c = p - r * W;
+			const double dc = ((double)(t.stamp_col0 + c + 1) - t.tpos_col) - 1.0;
+			const double dr = ((double)(t.stamp_row0 + r + 1) - t.tpos_row) - 1.0;
+			k.res[p] = (fabs(dc) <= 1.0 && fabs(dr) <= 1.0 && (t.aperture[p] & 1) != 0) ? 1 : 0;
+		}
+		TP_SYNC();
+		flags |= FLAG_MIN_APERTURE;
+	}
+
+	double contamination = tp_nan();
+	if (!err) {
+		// edges (photometry.py:123-131)
+		TP_LANE_LOOP(l) {
+			int e = 0;
+			for (int p = l; p < P; p += 64) if (k.res[p]) {
+				const int r = p / W, c = p - r * W;
+				if (r == 0) e |= FLAG_EDGE_DOWN;
+				if (r == H - 1) e |= FLAG_EDGE_UP;
+				if (c == 0) e |= FLAG_EDGE_LEFT;
+				if (c == W - 1) e |= FLAG_EDGE_RIGHT;
+			}
+			k.ired[l] = e;
+		}
+		TP_SYNC();
+		for (int l = 0; l < 64; ++l) flags |= k.ired[l];
+		TP_SYNC();
+
+		// ---------------- A7: contamination (photometry.py:220-238) ----------------
+		TP_PAR_FOR(s, t.ncat) {
+			// rows == np.round(t['row'])+1 with 1-based grid rows: stamp index = round(row) - stamp_row0
+			const int r = (int)rintf(t.cat_ccd_row[s]) - t.stamp_row0;
+			const int c = (int)rintf(t.cat_ccd_col[s]) - t.stamp_col0;
+			uint8_t in = 0;
+			if (r >= 0 && r < H && c >= 0 && c < W) in = k.res[r * W + c] ? 1 : 0;
+			if (t.cat_in_mask) t.cat_in_mask[s] = in;
+		}
+		TP_SYNC();
+		// serial tail on every lane (uniform, reads global cat_in_mask written above)
+		int nin = 0, only = -1;
+		float ssum = 0.f;
+		for (int s = 0; s < t.ncat; ++s) {
+			const int r = (int)rintf(t.cat_ccd_row[s]) - t.stamp_row0;
+			const int c = (int)rintf(t.cat_ccd_col[s]) - t.stamp_col0;
+			bool in = false;
+			if (r >= 0 && r < H && c >= 0 && c < W) in = k.res[r * W + c] != 0;
+			if (!in) continue;
+			nin++; only = s;
+			const float v = powf(10.0f, -0.4f * t.cat_tmag[s]);
+			if (v == v) ssum += v;
+		}
+		if (nin == 0) { err = ERR_NO_TARGETS_IN_MASK; }
+		else if (nin == 1 && t.cat_starid[only] == t.target_starid) contamination = 0.0;
+		else {
+			// numpy 1.21 scalar promotion: float32 mags_total widened to float64 before the subtraction
+			const double mags_total = -2.5 * (double)log10f(ssum);
+			double cont = 1.0 - pow(10.0, 0.4 * (mags_total - t.target_tmag));
+			if (cont < 0.0) cont = 0.0;
+			contamination = cont;
+		}
+	}
+
+	if (err) {
+		status = 2; // STATUS.ERROR
+		if (err == ERR_NO_TARGETS_IN_MASK && (flags & FLAG_MIN_APERTURE)) status = 3; // photometry.py:253-254 overrides
+	} else if (flags & FLAG_MIN_APERTURE) status = 3; // STATUS.WARNING
+	flags |= (err << ERR_SHIFT);
+
+	const bool keep_mask = (status != 2) || (err == ERR_NO_TARGETS_IN_MASK); // photometry.py:204 ran before :227
+	TP_PAR_FOR(p, P) t.mask[p] = keep_mask ? k.res[p] : 0;
+	TP_SERIAL {
+		*t.status = status;
+		*t.flags = flags;
+		*t.contamination = contamination;
+		if (t.diag) t.diag[7] = (double)nmasks_total;
+	}
+	TP_SYNC();
+}
+
+} // namespace k2p2

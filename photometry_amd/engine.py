@@ -107,6 +107,15 @@ def synth_fill(ctx, scene, n_targets=None, target_offset=0, nan_fraction=1e-3, i
 	return {k: v for k, v in out.items() if v is not None}
 
 
-def k2p2_masks(ctx, batch, work):
-	"""A2..A5b + A7 on the device (filled in by the K2P2 kernel)."""
-	raise NotImplementedError("tp_k2p2_masks is not built yet")
+def k2p2_masks(ctx, batch, work, cut_override=None, params=None):
+	"""
+	A2..A5b + A7 on the device (k2p2v2.py:344-623, photometry.py:93-131, 220-254).
+	``batch``: :class:`photometry_amd.pipeline.ApertureBatch`; ``work``: ``ApertureWork`` (needs ``sumimage``).
+	"""
+	ctx._check(ctx.lib.tp_k2p2_masks(ctx.handle, batch.n_targets, batch.height, batch.width, work.sumimage.ptr,
+		batch.cat_offsets.ptr, batch.cat_column_stamp.ptr, batch.cat_row_stamp.ptr, batch.cat_tmag.ptr,
+		batch.cat_column.ptr, batch.cat_row.ptr, batch.cat_starid.ptr,
+		batch.target_pos_row.ptr, batch.target_pos_column.ptr, batch.target_tmag.ptr, batch.target_starid.ptr,
+		batch.stamps.ptr, batch.aperture.ptr, _ptr(cut_override), None if params is None else ctypes.byref(params),
+		work.mask.ptr, work.status.ptr, work.flags.ptr, work.contamination.ptr, work.diag.ptr, work.cat_in_mask.ptr))
+	return work

@@ -23,7 +23,7 @@ class ApertureBatch(object):
 			self.images_err = DeviceCube.from_host(ctx, scene.images_err)
 			self.backgrounds = DeviceCube.from_host(ctx, scene.backgrounds)
 		else:
-			self.images, self.images_err, self.backgrounds = cubes['images'], cubes['images_err'], cubes['backgrounds']
+			self.images, self.images_err, self.backgrounds = cubes['images'], cubes.get('images_err'), cubes.get('backgrounds')
 		q = np.asarray(scene.quality, dtype='int32')
 		self.quality = ctx.array(q)
 		self.stamps = ctx.array(np.asarray(scene.stamps, dtype='int32'))

@@ -1,0 +1,102 @@
+# -*- coding: utf-8 -*-
+"""
+GPU parity of the K2P2 mask builder (A2..A5b, A7) and of the whole aperture pipeline
+(A1 -> K2P2 -> A6) through the C ABI, against the oracle.
+
+Masks / indices / statuses: bit-exact.  The KDE/Powell threshold CUT: 2e-6 relative (see
+tests/k2p2_common.py for why it cannot be tighter even between two CPUs); mask bit-exactness is
+asserted whenever no pixel lies within 4*|dCUT| of the oracle's CUT, and unconditionally when the
+oracle's CUT is fed to the kernel.
+"""
+import numpy as np
+import pytest
+from k2p2_common import make_cases, oracle_batch, compare
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+	from photometry_amd.device import Context
+	c = Context(0)
+	yield c
+	c.close()
+
+
+def run_device(ctx, s, S, cut_override=None):
+	from photometry_amd import engine, pipeline
+	# cubes are irrelevant for the mask stage: feed the (possibly doctored) sum image directly
+	class _B(pipeline.ApertureBatch):
+		def __init__(self, ctx, scene):
+			self.images = type('C', (), {'n_targets': scene.n_targets, 'n_cad': scene.n_cad, 'height': scene.height, 'width': scene.width})()
+			pipeline.ApertureBatch.__init__(self, ctx, scene, cubes={'images': self.images, 'images_err': None, 'backgrounds': None})
+	batch = _B(ctx, s)
+	work = pipeline.ApertureWork(ctx, batch)
+	work.sumimage = ctx.array(np.ascontiguousarray(S, dtype='float64'))
+	co = None if cut_override is None else ctx.array(np.ascontiguousarray(cut_override, dtype='float64'))
+	engine.k2p2_masks(ctx, batch, work, cut_override=co)
+	ctx.sync()
+	return {'mask': work.mask.to_host(), 'status': work.status.to_host(), 'flags': work.flags.to_host(),
+		'contamination': work.contamination.to_host(), 'diag': work.diag.to_host(), 'cat_in_mask': work.cat_in_mask.to_host()}
+
+
+@pytest.mark.parametrize("kind,seed", [('faint15', 1), ('small11', 2), ('crowded', 3), ('bright', 4), ('tiny', 5), ('faint15', 6)])
+def test_k2p2_matches_oracle(ctx, kind, seed):
+	s, S = make_cases(kind, seed)
+	got = run_device(ctx, s, S)
+	ref = oracle_batch(s, S)
+	stats = compare(s, S, got, ref)
+	print(kind, stats)
+	assert stats['n_exact'] >= s.n_targets // 2 and stats['n_razor'] <= 1
+
+
+def test_k2p2_given_oracle_cut(ctx):
+	from oracle import k2p2 as ok2p2
+	s, S = make_cases('crowded', 11)
+	cuts = np.full(s.n_targets, np.nan)
+	for i in range(s.n_targets):
+		try:
+			cuts[i] = ok2p2.threshold(S[i], 0.8)
+		except Exception: # noqa: B902
+			cuts[i] = np.nan
+	cuts[~np.isfinite(cuts)] = 1e30
+	got = run_device(ctx, s, S, cut_override=cuts)
+	ref = oracle_batch(s, S, cut_override=cuts)
+	stats = compare(s, S, got, ref, check_cut=False)
+	assert stats['n_exact'] >= 20
+
+
+def test_full_aperture_pipeline(ctx):
+	"""A1 -> K2P2 -> A6 on the device == the oracle's do_photometry, target by target."""
+	from photometry_amd import simulate, pipeline
+	from oracle import sumimage as osum, aperture as oap
+	s = simulate.make_scene(40, 90, 15, 15, seed=77)
+	simulate.fill_cubes(s)
+	res = pipeline.run_aperture(ctx, s, cubes='host')
+	S = osum.sumimage_batch(s.images, s.quality)
+	np.testing.assert_allclose(res['sumimage'], S, rtol=1e-12, equal_nan=True)
+	n = 0
+	for i in range(s.n_targets):
+		# use the DEVICE sum image for the oracle so that last-bit differences of A1 do not enter
+		ref = oap.do_photometry(res['sumimage'][i], s.images[i], s.images_err[i], s.backgrounds[i], tuple(s.stamps[i]),
+			s.target_pos_row[i], s.target_pos_column[i], s.target_tmag[i], s.target_starid[i], s.catalog_of(i), s.aperture[i])
+		assert int(res['status'][i]) == ref['status']
+		if 'mask' not in ref:
+			continue
+		np.testing.assert_array_equal(res['mask'][i].astype(bool), ref['mask'])
+		np.testing.assert_array_equal(res['flux'][i], ref['flux'])
+		np.testing.assert_array_equal(res['flux_err'][i], ref['flux_err'])
+		np.testing.assert_array_equal(res['flux_background'][i], ref['flux_background'])
+		np.testing.assert_allclose(res['pos_centroid'][i], ref['pos_centroid'], rtol=1e-12, equal_nan=True)
+		n += 1
+	assert n >= 35
+
+
+def test_k2p2_stamp_too_large_is_an_error(ctx):
+	from photometry_amd._lib import TessphotError
+	from photometry_amd import simulate
+	s = simulate.make_scene(1, 4, 64, 64, seed=1)
+	s.aperture = np.ones((1, 64, 64), dtype='int32')
+	with pytest.raises(TessphotError) as e:
+		run_device(ctx, s, np.ones((1, 64, 64)))
+	assert 'too large' in str(e.value)

@@ -1,0 +1,74 @@
+# -*- coding: utf-8 -*-
+"""
+CPU check of the K2P2 KERNEL LOGIC: photometry_amd/csrc/k2p2_core.h compiled for the host
+(TP_HOSTSIM: lanes become loops; test-only, see tests/hostsim/k2p2_hostsim.cpp) against the
+oracle.  The real parity test of the HIP kernel is tests/test_gpu_k2p2.py.
+"""
+import os
+import ctypes
+import subprocess
+import numpy as np
+import pytest
+import conftest
+from k2p2_common import make_cases, oracle_batch, compare
+
+SRC = os.path.join(conftest.ROOT, 'tests', 'hostsim', 'k2p2_hostsim.cpp')
+OUT_DIR = os.path.join(conftest.ROOT, 'tests', 'hostsim', 'build')
+OUT = os.path.join(OUT_DIR, 'k2p2_hostsim.so')
+
+
+@pytest.fixture(scope='module')
+def hostsim():
+	os.makedirs(OUT_DIR, exist_ok=True)
+	subprocess.run(['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-o', OUT, SRC], check=True)
+	lib = ctypes.CDLL(OUT)
+	lib.hostsim_k2p2.restype = ctypes.c_int
+	return lib
+
+
+def run_hostsim(lib, s, S, cut_override=None):
+	Nt, H, W = s.n_targets, s.height, s.width
+	c = s.catalog
+	f32 = lambda a: np.ascontiguousarray(a, dtype='float32')
+	arrs = dict(S=np.ascontiguousarray(S, dtype='float64'), off=np.ascontiguousarray(s.cat_offsets, dtype='int64'),
+		ccs=f32(c['column_stamp']), crs=f32(c['row_stamp']), tm=f32(c['tmag']), cc=f32(c['column']), cr=f32(c['row']),
+		sid=np.ascontiguousarray(c['starid'], dtype='int64'), tr=np.ascontiguousarray(s.target_pos_row, dtype='float64'),
+		tc=np.ascontiguousarray(s.target_pos_column, dtype='float64'), tt=np.ascontiguousarray(s.target_tmag, dtype='float64'),
+		tsid=np.ascontiguousarray(s.target_starid, dtype='int64'), st=np.ascontiguousarray(s.stamps, dtype='int32'),
+		ap=np.ascontiguousarray(s.aperture, dtype='int32'))
+	out = dict(mask=np.zeros((Nt, H, W), dtype='uint8'), status=np.zeros(Nt, dtype='int32'), flags=np.zeros(Nt, dtype='int32'),
+		contamination=np.zeros(Nt), diag=np.zeros((Nt, 8)), cat_in_mask=np.zeros(max(len(c['starid']), 1), dtype='uint8'))
+	p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+	co = None if cut_override is None else p(np.ascontiguousarray(cut_override, dtype='float64'))
+	lib.hostsim_k2p2(ctypes.c_int(Nt), ctypes.c_int(H), ctypes.c_int(W), p(arrs['S']), p(arrs['off']), p(arrs['ccs']), p(arrs['crs']),
+		p(arrs['tm']), p(arrs['cc']), p(arrs['cr']), p(arrs['sid']), p(arrs['tr']), p(arrs['tc']), p(arrs['tt']), p(arrs['tsid']),
+		p(arrs['st']), p(arrs['ap']), co, ctypes.c_double(0.8),
+		p(out['mask']), p(out['status']), p(out['flags']), p(out['contamination']), p(out['diag']), p(out['cat_in_mask']))
+	return out
+
+
+@pytest.mark.parametrize("kind,seed", [('faint15', 1), ('small11', 2), ('crowded', 3), ('bright', 4), ('tiny', 5), ('faint15', 6)])
+def test_hostsim_matches_oracle(hostsim, kind, seed):
+	s, S = make_cases(kind, seed)
+	got = run_hostsim(hostsim, s, S)
+	ref = oracle_batch(s, S)
+	stats = compare(s, S, got, ref)
+	print(kind, stats)
+	assert stats['n_exact'] >= s.n_targets // 2 and stats['n_razor'] <= 1
+
+
+def test_hostsim_given_oracle_cut(hostsim):
+	"""Integer part of the pipeline (A3..A5b) in isolation: feed the oracle's CUT."""
+	s, S = make_cases('crowded', 11)
+	from oracle import k2p2 as ok2p2
+	cuts = np.full(s.n_targets, np.nan)
+	for i in range(s.n_targets):
+		try:
+			cuts[i] = ok2p2.threshold(S[i], 0.8)
+		except Exception: # noqa: B902
+			cuts[i] = np.nan
+	ok = np.isfinite(cuts)
+	cuts[~ok] = 1e30
+	got = run_hostsim(hostsim, s, S, cut_override=cuts)
+	ref = oracle_batch(s, S, cut_override=cuts)
+	compare(s, S, got, ref, check_cut=False)
