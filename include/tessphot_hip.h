@@ -104,9 +104,12 @@ int tp_profile_get(tp_ctx* ctx, int kernel_id, int64_t* n_launches, double* tota
  * non-finite pixels excluded from sum and count, zero count -> NaN.  float64 accumulation.
  *   d_quality: int32 [n_cad] shared by all targets (quality_target_stride = 0) or
  *              [n_targets][quality_target_stride].
+ *   d_subtract: optional float32 [n_targets][subtract_pitch]: a stamp-constant background series
+ *              subtracted on the fly (images := raw - background, prepare.py:419-420), or NULL.
  *   d_sumimage: float64 [n_targets][height*width].                                          */
 int tp_sumimage(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
-	const int32_t* d_quality, int64_t quality_target_stride, uint32_t bitmask, double* d_sumimage);
+	const int32_t* d_quality, int64_t quality_target_stride, uint32_t bitmask,
+	const float* d_subtract, int64_t subtract_pitch, double* d_sumimage);
 
 /* ---- A2..A5b + A7: K2P2 aperture masks -------------------------------------------------------
  * replaces k2p2.k2p2FixFromSum (photometry/AperturePhotometry/k2p2v2.py:344-623: KDE-mode/MAD
@@ -155,6 +158,8 @@ int tp_k2p2_masks(tp_ctx* ctx, int32_t n_targets, int32_t height, int32_t width,
  *   d_backgrounds: bkg_mode 0: cube with the layout of desc;
  *                  bkg_mode 1: one series per target, float32 [n_targets][bkg_series_pitch]
  *                  (a stamp-constant background: every pixel of a cadence has the same value).
+ *   d_subtract: optional float32 [n_targets][subtract_pitch] subtracted from d_images on the fly
+ *                  (d_images then holds the raw, not background-subtracted, flux), or NULL.
  *   d_mask:   uint8 [n_targets][height*width], non-zero = in aperture (final_phot_mask).
  *   d_stamps: int32 [n_targets][4] = (row_min, row_max, col_min, col_max), BasePhotometry.stamp.
  *   d_status: optional int32 [n_targets]; targets whose status is TP_STATUS_ERROR are skipped
@@ -163,10 +168,30 @@ int tp_k2p2_masks(tp_ctx* ctx, int32_t n_targets, int32_t height, int32_t width,
  *             d_centroid_col / d_centroid_row are pos_centroid[:,0] / [:,1].                   */
 int tp_aperture_extract(tp_ctx* ctx, const tp_cube_desc* desc,
 	const float* d_images, const float* d_images_err, const float* d_backgrounds,
-	int32_t bkg_mode, int64_t bkg_series_pitch,
+	int32_t bkg_mode, int64_t bkg_series_pitch, const float* d_subtract, int64_t subtract_pitch,
 	const uint8_t* d_mask, const int32_t* d_stamps, const int32_t* d_status,
 	double* d_flux, double* d_flux_err, double* d_flux_background,
 	double* d_centroid_col, double* d_centroid_row, int64_t out_pitch);
+
+/* ---- B*, B2, B3: background on stamps -----------------------------------------------------------
+ * tp_background_stamp (B*): build-defined stamp analogue of backgrounds.fit_background
+ *   (photometry/backgrounds.py:52-211, which needs 64x64 tiles of a full frame): per (target, cadence)
+ *   mask non-finite / > flux_cutoff / < 0 pixels (backgrounds.py:89-94), SigmaClip(3 sigma, 5 iterations,
+ *   median / std), SExtractor mode estimate; more than exclude_percentile % masked pixels -> NaN.
+ *   d_raw: cube of raw (not background-subtracted) flux; d_bkg: float32 [n_targets][bkg_pitch].
+ * tp_smooth_time (B2): prepare.py:317-335, out[k] = nanmean(in[max(k-w,0) : min(k+w+1,T)]),
+ *   w = time_smooth/2 (time_smooth = 3 at 1800 s cadence, 9 at 600 s; prepare.py:258), float32.
+ * tp_subtract_background (B3): prepare.py:419-425, images = raw - bkg[k] (float32); pixels whose
+ *   flag & flag_mask != 0 (PixelQualityFlags.ManualExclude = 2) become NaN in image and error.
+ *   d_pixel_flags: optional uint8 [n_targets][H*W][n_cad]; d_raw_err / d_images_err optional;
+ *   in-place (d_images == d_raw) is allowed; bkg_pitch >= t_pitch.                               */
+int tp_background_stamp(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_raw,
+	double flux_cutoff, double exclude_percentile, float* d_bkg, int64_t bkg_pitch);
+int tp_smooth_time(tp_ctx* ctx, int32_t n_targets, int32_t n_cad, int64_t pitch, int32_t time_smooth,
+	const float* d_in, float* d_out);
+int tp_subtract_background(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_raw, const float* d_raw_err,
+	const float* d_bkg, int64_t bkg_pitch, const uint8_t* d_pixel_flags, uint32_t flag_mask,
+	float* d_images, float* d_images_err);
 
 /* ---- multi-GPU: the final light-curve gather (RCCL over xGMI) --------------------------------
  * replaces the pickled result messages of run_tessphot_mpi.py:114-132,163-191: targets are

@@ -1,0 +1,141 @@
+# -*- coding: utf-8 -*-
+"""
+ORACLE (test infrastructure only) -- B* / B2 / B3: background estimation on stamps.
+
+B2 and B3 restate ``photometry/prepare.py``: the time smoothing of the backgrounds
+(:258, :317-335) and the subtraction + manual-exclude masking (:419-425).
+
+B* is BUILD-DEFINED.  The reference's estimator (``photometry/backgrounds.py:52-211``) only
+exists for full 2048x2048 frames: photutils ``Background2D`` on 64x64 tiles (:200-206) plus a
+radial component for TESS FFIs; a 15x15 stamp is smaller than one tile.  The stamp-level
+analogue stated here keeps every ingredient that still has a meaning on a single tile
+(SURVEY.md section 8a, row B*):
+
+* pixel mask exactly as ``backgrounds.py:89-94``: non-finite, > flux_cutoff (8e4), < 0, plus an
+  optional manual-exclude image;
+* ONE mesh cell = the whole stamp; a cell with more than ``exclude_percentile`` = 50 % masked
+  pixels has no estimate (photutils raises for a frame without any usable cell) -> NaN;
+* ``SigmaClip(sigma=3, maxiters=5)`` with median centre and population std (astropy 5.1);
+* ``SExtractorBackground``: ``std == 0 -> mean``; ``|mean - median| / std < 0.3 ->
+  2.5*median - 1.5*mean``; else ``median`` (photutils 1.3.0);
+* the 3x3 median filter and the bicubic zoom of a 1x1 mesh are identities -> the background is
+  constant over the stamp for each cadence.
+
+Statistics are float64 on the float32 pixel values.  **Parity unpinned** against
+photutils/astropy (not installable here); pinned by the reference's own known answer
+``tests/test_background.py:36-54`` (constant image 1000 -> background 1000, nothing masked).
+"""
+
+import numpy as np
+from .quality import pixel_filter
+
+
+def stamp_mask(img, flux_cutoff=8e4, exclude=None):
+	"""backgrounds.py:89-97 -- True where the pixel is NOT used."""
+	img = np.asarray(img)
+	with np.errstate(invalid='ignore'):
+		mask = ~np.isfinite(img)
+		mask |= (img > flux_cutoff)
+		mask |= (img < 0)
+	if exclude is not None:
+		mask |= np.asarray(exclude, dtype=bool)
+	return mask
+
+
+def sigma_clip(data, sigma=3.0, maxiters=5):
+	"""astropy.stats.SigmaClip(sigma, maxiters) on 1-D data (cenfunc=median, stdfunc=std)."""
+	data = np.asarray(data, dtype='float64')
+	for _ in range(maxiters):
+		if data.size == 0:
+			break
+		med = np.median(data)
+		std = np.std(data)
+		keep = (data >= med - sigma*std) & (data <= med + sigma*std)
+		if np.all(keep):
+			break
+		data = data[keep]
+	return data
+
+
+def sextractor_background(data):
+	"""photutils.SExtractorBackground.calc_background on already clipped 1-D data."""
+	if data.size == 0:
+		return np.nan
+	med = np.median(data)
+	mean = np.mean(data)
+	std = np.std(data)
+	if std == 0:
+		return mean
+	if np.abs(mean - med) / std < 0.3:
+		return 2.5*med - 1.5*mean
+	return med
+
+
+def fit_background_stamp(img, flux_cutoff=8e4, exclude=None, exclude_percentile=50.0):
+	"""
+	B*: one cadence of one stamp.  Returns ``(background scalar float64, mask bool (H, W))``.
+	"""
+	img = np.asarray(img)
+	mask = stamp_mask(img, flux_cutoff, exclude)
+	if np.all(mask):
+		return np.nan, mask
+	if np.sum(mask) > exclude_percentile/100.0 * img.size:
+		return np.nan, mask
+	data = sigma_clip(img[~mask])
+	return sextractor_background(data), mask
+
+
+def background_series(raw, flux_cutoff=8e4, exclude=None):
+	"""B* for a ``(H, W, T)`` cube -> float32 ``(T,)`` (stored like the reference's float32 blocks, prepare.py:327)."""
+	T = raw.shape[2]
+	out = np.empty(T, dtype='float32')
+	for k in range(T):
+		ex = None if exclude is None else exclude[:, :, k]
+		out[k] = fit_background_stamp(raw[:, :, k], flux_cutoff, ex)[0]
+	return out
+
+
+def time_smooth_width(cadence):
+	"""prepare.py:258"""
+	return {1800: 3, 600: 9}[int(cadence)]
+
+
+def smooth_time(bkg_raw, time_smooth=3):
+	"""
+	B2 (prepare.py:317-335): ``bck[k] = nanmean(block[k-w : k+w+1])``, ``w = time_smooth//2``,
+	float32 block, bottleneck nanmean = sequential float32 accumulation / count.
+	``bkg_raw``: float32 ``(..., T)`` smoothing along the last axis.
+	"""
+	x = np.asarray(bkg_raw, dtype='float32')
+	N = x.shape[-1]
+	w = time_smooth // 2
+	out = np.empty_like(x)
+	for k in range(N):
+		indx1 = max(k - w, 0)
+		indx2 = min(k + w + 1, N)
+		asum = np.zeros(x.shape[:-1], dtype='float32')
+		cnt = np.zeros(x.shape[:-1], dtype='int64')
+		for n in range(indx1, indx2):
+			v = x[..., n]
+			ok = ~np.isnan(v)
+			asum = np.where(ok, (asum + np.where(ok, v, np.float32(0))).astype('float32'), asum)
+			cnt += ok
+		with np.errstate(invalid='ignore', divide='ignore'):
+			out[..., k] = np.where(cnt > 0, asum / cnt.astype('float32'), np.float32(np.nan))
+	return out
+
+
+def subtract_background(raw, raw_err, bkg, pixel_flags=None, backapp=False):
+	"""
+	B3 (prepare.py:419-425): ``flux0 -= backgrounds`` (unless BACKAPP) and manual-exclude pixels
+	-> NaN in image and error.  ``bkg`` broadcastable to ``raw`` (float32).
+	"""
+	img = np.array(raw, dtype='float32', copy=True)
+	err = np.array(raw_err, dtype='float32', copy=True)
+	if not backapp:
+		img -= np.asarray(bkg, dtype='float32')
+	if pixel_flags is not None:
+		excl = ~pixel_filter(np.asarray(pixel_flags))
+		img[excl] = np.nan
+		err[excl] = np.nan
+	return img, err

@@ -85,6 +85,7 @@ __device__ __forceinline__ float combine8(const float (&r)[8]) {
 struct Args {
 	const float* images; const float* images_err; const float* backgrounds;
 	int32_t bkg_mode; int64_t bkg_series_pitch;
+	const float* subtract; int64_t subtract_pitch;
 	const uint8_t* mask; const int32_t* stamps; const int32_t* status;
 	double* flux; double* flux_err; double* flux_bkg; double* ccol; double* crow;
 	int64_t out_pitch; int n_cad; int height; int width; int64_t t_pitch;
@@ -178,14 +179,19 @@ __global__ __launch_bounds__(512) void tp_aperture_kernel(Args a)
 		const int k0 = q * VEC;
 		CadState<VEC> st;
 		st.init();
-		float bser[VEC];
+		float bser[VEC], ssub[VEC];
 		if (a.bkg_mode != 0) Vec<VEC>::load(bkg + k0, bser);
+		if (a.subtract) Vec<VEC>::load(a.subtract + (int64_t)target * a.subtract_pitch + k0, ssub);
 
 		auto fetch = [&](int idx, float (&v)[VEC], float (&e2)[VEC]) {
 			const int p = s_list[idx];
 			const int64_t off = (int64_t)p * a.t_pitch + k0;
 			float ee[VEC], bb[VEC];
 			Vec<VEC>::load(img + off, v);
+			if (a.subtract) {
+#pragma unroll
+				for (int c = 0; c < VEC; c++) v[c] = v[c] - ssub[c];
+			}
 			Vec<VEC>::load(err + off, ee);
 			if (a.bkg_mode == 0) Vec<VEC>::load(bkg + off, bb);
 			else {
@@ -303,8 +309,9 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 		const int k0 = q * VEC;
 		CadState<VEC> st;
 		st.init();
-		float bser[VEC];
+		float bser[VEC], ssub[VEC];
 		if (active && a.bkg_mode != 0) Vec<VEC>::load(bkg + k0, bser);
+		if (active && a.subtract) Vec<VEC>::load(a.subtract + (int64_t)target * a.subtract_pitch + k0, ssub);
 		float stk_f[VEC][kMaxDepth], stk_e[VEC][kMaxDepth];
 		int sp = 0;
 		int leaf = 0, pos_in_leaf = 0;
@@ -336,6 +343,10 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 							const int64_t off = (int64_t)p * a.t_pitch + k0;
 							float v[VEC], ee[VEC], bb[VEC];
 							Vec<VEC>::load(img + off, v);
+							if (a.subtract) {
+#pragma unroll
+								for (int c = 0; c < VEC; c++) v[c] = v[c] - ssub[c];
+							}
 							Vec<VEC>::load(err + off, ee);
 							if (a.bkg_mode == 0) Vec<VEC>::load(bkg + off, bb);
 							else {
@@ -364,6 +375,10 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 						const int64_t off = (int64_t)p * a.t_pitch + k0;
 						float v[VEC], ee[VEC], bb[VEC];
 						Vec<VEC>::load(img + off, v);
+						if (a.subtract) {
+#pragma unroll
+							for (int c = 0; c < VEC; c++) v[c] = v[c] - ssub[c];
+						}
 						Vec<VEC>::load(err + off, ee);
 						if (a.bkg_mode == 0) Vec<VEC>::load(bkg + off, bb);
 						else {
@@ -411,7 +426,7 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 
 extern "C" int tp_aperture_extract(tp_ctx* ctx, const tp_cube_desc* desc,
 	const float* d_images, const float* d_images_err, const float* d_backgrounds,
-	int32_t bkg_mode, int64_t bkg_series_pitch,
+	int32_t bkg_mode, int64_t bkg_series_pitch, const float* d_subtract, int64_t subtract_pitch,
 	const uint8_t* d_mask, const int32_t* d_stamps, const int32_t* d_status,
 	double* d_flux, double* d_flux_err, double* d_flux_background,
 	double* d_centroid_col, double* d_centroid_row, int64_t out_pitch)
@@ -430,6 +445,7 @@ extern "C" int tp_aperture_extract(tp_ctx* ctx, const tp_cube_desc* desc,
 	Args a;
 	a.images = d_images; a.images_err = d_images_err; a.backgrounds = d_backgrounds;
 	a.bkg_mode = bkg_mode; a.bkg_series_pitch = bkg_series_pitch;
+	a.subtract = d_subtract; a.subtract_pitch = subtract_pitch;
 	a.mask = d_mask; a.stamps = d_stamps; a.status = d_status;
 	a.flux = d_flux; a.flux_err = d_flux_err; a.flux_bkg = d_flux_background;
 	a.ccol = d_centroid_col; a.crow = d_centroid_row;
@@ -439,6 +455,8 @@ extern "C" int tp_aperture_extract(tp_ctx* ctx, const tp_cube_desc* desc,
 	bool vec4 = tp_vec4_ok(d_images, desc->t_pitch) && tp_vec4_ok(d_images_err, desc->t_pitch);
 	if (bkg_mode == 0) vec4 = vec4 && tp_vec4_ok(d_backgrounds, desc->t_pitch);
 	else vec4 = vec4 && tp_vec4_ok(d_backgrounds, bkg_series_pitch);
+	TP_REQUIRE(ctx, d_subtract == nullptr || subtract_pitch >= desc->n_cad, "tp_aperture_extract: bad subtract pitch");
+	if (d_subtract) vec4 = vec4 && tp_vec4_ok(d_subtract, subtract_pitch);
 	const int vec = vec4 ? 4 : 1;
 	const int nq = (desc->n_cad + vec - 1) / vec;
 	int threads = ((nq + 63) / 64) * 64;

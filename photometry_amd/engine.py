@@ -20,7 +20,7 @@ def _ptr(x):
 	return x.ptr
 
 
-def sumimage(ctx, images, quality, bitmask=TESS_DEFAULT_BITMASK, out=None):
+def sumimage(ctx, images, quality, bitmask=TESS_DEFAULT_BITMASK, out=None, subtract=None):
 	"""
 	A1 (BasePhotometry.py:1008-1019).  ``images``: DeviceCube; ``quality``: int32 DeviceArray
 	``(T,)`` shared or ``(Nt, T)``.  Returns float64 DeviceArray ``(Nt, H, W)``.
@@ -34,7 +34,9 @@ def sumimage(ctx, images, quality, bitmask=TESS_DEFAULT_BITMASK, out=None):
 		assert quality.shape[0] == images.n_targets and quality.shape[1] >= images.n_cad
 		qstride = quality.shape[1]
 	desc = images.desc
-	ctx._check(ctx.lib.tp_sumimage(ctx.handle, ctypes.byref(desc), images.ptr, quality.ptr, qstride, int(bitmask), out.ptr))
+	spitch = 0 if subtract is None else subtract.shape[1]
+	ctx._check(ctx.lib.tp_sumimage(ctx.handle, ctypes.byref(desc), images.ptr, quality.ptr, qstride, int(bitmask),
+		_ptr(subtract), spitch, out.ptr))
 	return out
 
 
@@ -57,7 +59,7 @@ class LightCurves(object):
 		return lc
 
 
-def aperture_extract(ctx, images, images_err, backgrounds, mask, stamps, status=None, out=None):
+def aperture_extract(ctx, images, images_err, backgrounds, mask, stamps, status=None, out=None, subtract=None):
 	"""
 	A6 (photometry.py:172-201).  ``backgrounds``: DeviceCube, or a float32 DeviceArray ``(Nt, pitch)``
 	holding one background series per target (stamp-constant background).
@@ -75,7 +77,7 @@ def aperture_extract(ctx, images, images_err, backgrounds, mask, stamps, status=
 		bkg_mode, bpitch = 1, backgrounds.shape[1]
 	assert mask.dtype == np.uint8 and stamps.dtype == np.int32
 	ctx._check(ctx.lib.tp_aperture_extract(ctx.handle, ctypes.byref(desc), images.ptr, images_err.ptr, backgrounds.ptr,
-		bkg_mode, bpitch, mask.ptr, stamps.ptr, _ptr(status), out.ptrs[0], out.ptrs[1], out.ptrs[2], out.ptrs[3], out.ptrs[4],
+		bkg_mode, bpitch, _ptr(subtract), 0 if subtract is None else subtract.shape[1], mask.ptr, stamps.ptr, _ptr(status), out.ptrs[0], out.ptrs[1], out.ptrs[2], out.ptrs[3], out.ptrs[4],
 		out.n_cad))
 	return out
 
@@ -105,6 +107,35 @@ def synth_fill(ctx, scene, n_targets=None, target_offset=0, nan_fraction=1e-3, i
 	for a in (sp, sig, lev, pha, jit):
 		a.free()
 	return {k: v for k, v in out.items() if v is not None}
+
+
+def background_stamp(ctx, raw, flux_cutoff=8e4, exclude_percentile=50.0, out=None):
+	"""B* (build-defined stamp analogue of backgrounds.py:52-211).  Returns float32 DeviceArray ``(Nt, t_pitch)``."""
+	if out is None:
+		out = ctx.zeros((raw.n_targets, raw.t_pitch), 'float32')
+	desc = raw.desc
+	ctx._check(ctx.lib.tp_background_stamp(ctx.handle, ctypes.byref(desc), raw.ptr, float(flux_cutoff), float(exclude_percentile),
+		out.ptr, out.shape[1]))
+	return out
+
+
+def smooth_time(ctx, series, n_cad, time_smooth=3, out=None):
+	"""B2 (prepare.py:317-335) on float32 series ``(Nt, pitch)``."""
+	if out is None:
+		out = ctx.zeros(series.shape, 'float32')
+	ctx._check(ctx.lib.tp_smooth_time(ctx.handle, series.shape[0], int(n_cad), series.shape[1], int(time_smooth), series.ptr, out.ptr))
+	return out
+
+
+def subtract_background(ctx, raw, bkg_series, raw_err=None, pixel_flags=None, flag_mask=2, images=None, images_err=None):
+	"""B3 (prepare.py:419-425).  ``images`` defaults to in-place on ``raw``."""
+	images = raw if images is None else images
+	if raw_err is not None and images_err is None:
+		images_err = raw_err
+	desc = raw.desc
+	ctx._check(ctx.lib.tp_subtract_background(ctx.handle, ctypes.byref(desc), raw.ptr, _ptr(raw_err), bkg_series.ptr, bkg_series.shape[1],
+		_ptr(pixel_flags), int(flag_mask), images.ptr, _ptr(images_err)))
+	return images, images_err
 
 
 def k2p2_masks(ctx, batch, work, cut_override=None, params=None):
