@@ -8,15 +8,20 @@
 // backgrounds.py:89-94, one mesh cell = the stamp, SigmaClip(3 sigma, 5 iterations, median/std),
 // SExtractor mode estimator, "more than 50 % masked -> no estimate".  See oracle/backgrounds.py.
 //
-// Mapping (gfx950).  The cube is time-fastest, so a THREAD owns one cadence of one target and reads
-// its P pixel values straight from HBM with wavefront-coalesced loads (lane = cadence, 256 B per
-// load instruction) -- no LDS transposition at all.  The P values live in VGPRs; they are sorted by a
-// fully unrolled bitonic network (v_min_f32 / v_max_f32 on compile-time register indices: no
-// divergence, no memory traffic), after which sigma clipping only moves the two ends [a, b) of the
-// kept range of the sorted array.  Per clip iteration two predicated passes over the register
-// array: (S1, S2, median) and (count below / above the bounds).  Statistics are float64.
-// 64 frames are processed per wavefront instruction, which is what makes an exact sigma-clipped
-// median affordable: ~13 k VALU instructions per 64 frames at 15x15.
+// Mapping (gfx950).  The cube is time-fastest, so consecutive lanes read consecutive cadences of a
+// pixel's time series (coalesced) and NO LDS transposition is needed to get a frame into registers.
+// A frame (one cadence of one target, <= 256 pixels) is owned by a QUAD of lanes, 64 pixel values per
+// lane in VGPRs; a wavefront holds 16 frames, a 256-thread workgroup 64 consecutive cadences.
+//   1. each lane sorts its 64 values with a fully unrolled bitonic network (v_min_f32 / v_max_f32 on
+//      compile-time register indices: no divergence, no memory traffic);
+//   2. three cross-lane bitonic stages (DPP quad_perm exchanges with lane^1 / lane^2) merge the four
+//      sorted runs into one sorted 256-sequence distributed over the quad (rank r lives in lane r/64);
+//   3. sigma clipping stays in registers: the kept set is always a contiguous rank range [a, b) of the
+//      sorted values, so per clipping pass each lane sums its own registers under a rank predicate
+//      (float64 S1, S2) and COUNTS the values beyond the two thresholds; a DPP quad reduction gives the
+//      frame totals, the new bounds follow from the counts, the median is picked by rank.
+// No LDS, no divergence inside a pass, ~12 KB of code: the earlier one-thread-per-frame variant (256 values per lane, 110 KB of
+// unrolled code, 1 wavefront per SIMD) was instruction-cache and issue bound at 33 ms for the C3 cube.
 #include "common.h"
 #include <cmath>
 
@@ -70,80 +75,133 @@ __device__ __forceinline__ float sextractor_mode(double med, double mean, double
 	return (float)bkg;
 }
 
-template <int N>
+// DPP quad permutes: value of lane^1 / lane^2 within the quad
+__device__ __forceinline__ float quad_xor1(float x) {
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false)); // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float quad_xor2(float x) {
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, false)); // quad_perm [2,3,0,1]
+}
+template <int XOR>
+__device__ __forceinline__ void cross_stage(float (&v)[64], bool keepmin) {
+#pragma unroll
+	for (int j = 0; j < 64; ++j) {
+		const float p = (XOR == 1) ? quad_xor1(v[j]) : quad_xor2(v[j]);
+		const float mn = fminf(v[j], p), mx = fmaxf(v[j], p);
+		v[j] = keepmin ? mn : mx;
+	}
+}
+__device__ __forceinline__ void flip_sign(float (&v)[64], bool flip) {
+	const int m = flip ? (int)0x80000000 : 0;
+#pragma unroll
+	for (int j = 0; j < 64; ++j) v[j] = __int_as_float(__float_as_int(v[j]) ^ m);
+}
+// ascending bitonic MERGE of a lane's 64 values (strides 32..1); descending when desc (sign trick)
+__device__ __forceinline__ void local_merge(float (&v)[64], bool desc) {
+	flip_sign(v, desc);
+	BitonicStage<64, 64, 32>::run(v);
+	flip_sign(v, desc);
+}
+
+constexpr int kFramesPerWave = 16;
+constexpr int kFramesPerBlock = 64;
+
+__device__ __forceinline__ double quad_sum(double x) { x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); return x; }
+__device__ __forceinline__ float quad_sum(float x) { x += quad_xor1(x); x += quad_xor2(x); return x; }
+__device__ __forceinline__ int quad_sum(int x) { x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); return x; }
+
 __global__ __launch_bounds__(256) void tp_bkg_stamp_kernel(BkgArgs a)
 {
 	const int target = blockIdx.x;
-	const int k = blockIdx.y * blockDim.x + threadIdx.x;
-	if (k >= a.n_cad) return;
-	const float* base = a.raw + (int64_t)target * a.n_pix * a.t_pitch + k;
+	const int tid = threadIdx.x;
+	const int wave = tid >> 6, lane = tid & 63;
+	const int f = lane >> 2, q = lane & 3;   // frame within the wavefront, quarter of the frame
+	const int k = blockIdx.y * kFramesPerBlock + wave * kFramesPerWave + f;
+	const bool active = k < a.n_cad;
+	const float* base = a.raw + (int64_t)target * a.n_pix * a.t_pitch + (active ? k : 0);
 	const float inf = __builtin_inff();
-	float v[N];
+	float v[64];
 	int n = 0;
 #pragma unroll
-	for (int i = 0; i < N; ++i) {
+	for (int j = 0; j < 64; ++j) {
+		const int i = q * 64 + j;
 		float x = inf;
-		if (i < a.n_pix) {
-			x = base[(int64_t)i * a.t_pitch];
-			// backgrounds.py:91-94: mask = ~isfinite | > flux_cutoff | < 0
-			const bool ok = (fabsf(x) <= 3.402823466e+38f) && !(x > a.flux_cutoff) && !(x < 0.f);
-			n += ok ? 1 : 0;
-			x = ok ? x : inf;
-		}
-		v[i] = x;
+		if (i < a.n_pix) x = base[(int64_t)i * a.t_pitch];
+		// backgrounds.py:91-94: mask = ~isfinite | > flux_cutoff | < 0   (+inf padding is "masked" too)
+		const bool ok = (fabsf(x) <= 3.402823466e+38f) && !(x > a.flux_cutoff) && !(x < 0.f);
+		n += ok ? 1 : 0;
+		v[j] = ok ? x : inf;
 	}
-	float result = __builtin_nanf("");
+	n = quad_sum(n);
+
+	// --- distributed bitonic sort of the 256 values of the quad: global index (= rank) g = q*64 + j ---
+	BitonicLevel<64, 32>::run(v);                       // sizes 2..32: directions fixed by the local index
+	local_merge(v, (q & 1) != 0);                       // size 64: ascending iff (g & 64) == 0
+	cross_stage<1>(v, ((q & 1) == 0) == ((q & 2) == 0)); // size 128, stride 64: keep min iff (is-low == up)
+	local_merge(v, (q & 2) != 0);                       // size 128, strides 32..1: ascending iff (g & 128) == 0
+	cross_stage<2>(v, (q & 2) == 0);                    // size 256, stride 128
+	cross_stage<1>(v, (q & 1) == 0);                    // size 256, stride 64
+	local_merge(v, false);                              // size 256, strides 32..1
+
+	// --- sigma clipping on the sorted registers.  The kept set is always the contiguous rank range
+	// [lo_i, hi_i): sums are predicated passes over the lane's 64 registers + a quad reduction, the new
+	// bounds come from COUNTING the values beyond the thresholds (sortedness), the median element is
+	// picked by rank.  No LDS, no divergence inside a pass; all four lanes of a quad carry the same scalars.
 	const int nmasked = a.n_pix - n;
-	if (n > 0 && !((float)nmasked > a.exclude_fraction * (float)a.n_pix)) {
-		BitonicLevel<N, N>::run(v);
-		int lo_i = 0, hi_i = n;      // kept range [lo_i, hi_i) of the sorted values
+	const bool usable = active && (n > 0) && !((float)nmasked > a.exclude_fraction * (float)a.n_pix);
+	float result = __builtin_nanf("");
+	if (usable) {
+		const int rbase = q * 64;
+		int lo_i = 0, hi_i = n;
 		double med = 0.0, mean = 0.0, sd = 0.0;
 #pragma unroll 1
 		for (int it = 0; it <= 5; ++it) {
-			// pass A: S1, S2 and the median over [lo_i, hi_i)
 			const int m = hi_i - lo_i;
-			const int m1 = lo_i + (m >> 1);          // upper middle
-			const int m0 = (m & 1) ? m1 : (m1 - 1);  // lower middle
+			const int m1 = lo_i + (m >> 1);          // upper middle rank
+			const int m0 = (m & 1) ? m1 : (m1 - 1);  // lower middle rank
+			const int off = rbase - lo_i, l0 = m0 - rbase, l1 = m1 - rbase;
 			double s1 = 0.0, s2 = 0.0;
 			float e0 = 0.f, e1 = 0.f;
 #pragma unroll
-			for (int i = 0; i < N; ++i) {
-				float xf = ((i >= lo_i) && (i < hi_i)) ? v[i] : 0.f;
-				// keep the float->double conversion inside the loop: without this the optimiser hoists
-				// all N conversions out of the clip loop and needs 2N extra registers
-				asm volatile("" : "+v"(xf));
+			for (int j = 0; j < 64; ++j) {
+				const bool in = (unsigned)(j + off) < (unsigned)m;      // lo_i <= rank < hi_i
+				float xf = in ? v[j] : 0.f;
+				asm volatile("" : "+v"(xf));   // keep the conversion in the loop (else 64 doubles stay live across iterations)
 				const double x = (double)xf;
 				s1 += x;
 				s2 = __builtin_fma(x, x, s2);
-				e0 = (i == m0) ? v[i] : e0;
-				e1 = (i == m1) ? v[i] : e1;
+				e0 = (j == l0) ? v[j] : e0;
+				e1 = (j == l1) ? v[j] : e1;
 			}
+			s1 = quad_sum(s1); s2 = quad_sum(s2);
+			e0 = quad_sum(e0); e1 = quad_sum(e1);
 			med = ((double)e0 + (double)e1) / 2.0;
 			mean = s1 / (double)m;
 			double var = s2 / (double)m - mean * mean;
 			if (var < 0.0) var = 0.0;
 			sd = sqrt(var);
-			if (it == 5) break;                        // maxiters = 5 clipping passes, then final statistics
-			// pass B in float32, exactly: for float x,  (double)x < lo  <=>  x < round_up(lo);  (double)x > hi  <=>  x > round_down(hi)
+			if (it == 5) break;                        // maxiters = 5 clipping passes, then the final statistics
+			// exact float32 thresholds: for float x, (double)x < lo <=> x < round_up(lo); (double)x > hi <=> x > round_down(hi)
 			const float lo_f = __double2float_ru(med - 3.0 * sd);
 			const float hi_f = __double2float_rd(med + 3.0 * sd);
 			int cnt_lt = 0, cnt_gt = 0;
 #pragma unroll
-			for (int i = 0; i < N; ++i) {
-				cnt_lt += (v[i] < lo_f) ? 1 : 0;
-				cnt_gt += (v[i] > hi_f) ? 1 : 0;
+			for (int j = 0; j < 64; ++j) {
+				cnt_lt += (v[j] < lo_f) ? 1 : 0;
+				cnt_gt += (v[j] > hi_f) ? 1 : 0;
 			}
-			cnt_gt -= (N - n);                          // the +inf sentinels
-			// sorted: the values < lo are the first cnt_lt, the values > hi the last cnt_gt of [0, n)
-			int new_lo = (cnt_lt > lo_i) ? cnt_lt : lo_i;
-			int new_hi = (n - cnt_gt < hi_i) ? (n - cnt_gt) : hi_i;
+			cnt_lt = quad_sum(cnt_lt);
+			cnt_gt = quad_sum(cnt_gt) - (256 - n);     // the +inf sentinels
+			// sorted: the values < lo are the first cnt_lt ranks, the values > hi the last cnt_gt ranks of [0, n)
+			const int new_lo = (cnt_lt > lo_i) ? cnt_lt : lo_i;
+			const int new_hi = (n - cnt_gt < hi_i) ? (n - cnt_gt) : hi_i;
 			if (new_lo == lo_i && new_hi == hi_i) break; // nchanged == 0: the statistics of this range are final
 			lo_i = new_lo;
 			hi_i = new_hi;
 		}
 		result = sextractor_mode(med, mean, sd);
 	}
-	a.out[(int64_t)target * a.out_pitch + k] = result;
+	if (q == 0 && active) a.out[(int64_t)target * a.out_pitch + k] = result;
 }
 
 // Generic fallback for stamps with more than 256 pixels: one wavefront per (target, cadence), values
@@ -293,9 +351,8 @@ extern "C" int tp_background_stamp(tp_ctx* ctx, const tp_cube_desc* desc, const 
 	a.t_pitch = desc->t_pitch; a.out_pitch = bkg_pitch;
 	a.flux_cutoff = (float)flux_cutoff; a.exclude_fraction = (float)(exclude_percentile / 100.0);
 	if (a.n_pix <= 256) {
-		dim3 block(256), grid((unsigned)desc->n_targets, (unsigned)((desc->n_cad + 255) / 256));
-		if (a.n_pix <= 128) TP_LAUNCH(ctx, TPK_BKG_STAMP, tp_bkg_stamp_kernel<128>, grid, block, 0, a);
-		else TP_LAUNCH(ctx, TPK_BKG_STAMP, tp_bkg_stamp_kernel<256>, grid, block, 0, a);
+		dim3 block(256), grid((unsigned)desc->n_targets, (unsigned)((desc->n_cad + kFramesPerBlock - 1) / kFramesPerBlock));
+		TP_LAUNCH(ctx, TPK_BKG_STAMP, tp_bkg_stamp_kernel, grid, block, 0, a);
 	} else {
 		int np2 = 1;
 		while (np2 < a.n_pix) np2 <<= 1;

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void tp_synth_kernel(
 		const uint64_t h2 = splitmix64(h);
 		const bool isnan_px = u01((uint32_t)h2) < nan_fraction;
 		const float v = signal + gn * sigma;
-		rw[j] = v + b;
+		rw[j] = isnan_px ? __builtin_nanf("") : (v + b);
 		img[j] = isnan_px ? __builtin_nanf("") : v;
 		err[j] = isnan_px ? __builtin_nanf("") : sigma;
 		bkg[j] = b;

@@ -18,12 +18,24 @@ class ApertureBatch(object):
 	def __init__(self, ctx, scene, cubes='host'):
 		self.ctx = ctx
 		self.scene = scene
+		# raw mode: the cubes hold the RAW flux; the background is estimated on the device (B*, B2) and
+		# subtracted on the fly (B3) -- nothing but the raw + error cubes ever lives in HBM.
+		self.raw_mode = False
 		if isinstance(cubes, str) and cubes == 'host':
 			self.images = DeviceCube.from_host(ctx, scene.images)
 			self.images_err = DeviceCube.from_host(ctx, scene.images_err)
 			self.backgrounds = DeviceCube.from_host(ctx, scene.backgrounds)
+		elif isinstance(cubes, str) and cubes == 'host_raw':
+			self.images = DeviceCube.from_host(ctx, scene.raw)
+			self.images_err = DeviceCube.from_host(ctx, scene.raw_err)
+			self.backgrounds = None
+			self.raw_mode = True
+		elif 'raw' in cubes:
+			self.images, self.images_err, self.backgrounds = cubes['raw'], cubes.get('raw_err', cubes.get('images_err')), None
+			self.raw_mode = True
 		else:
 			self.images, self.images_err, self.backgrounds = cubes['images'], cubes.get('images_err'), cubes.get('backgrounds')
+		self.time_smooth = {1800: 3, 600: 9}.get(int(round(getattr(scene, 'cadence_s', 1800))), 3) # prepare.py:258
 		q = np.asarray(scene.quality, dtype='int32')
 		self.quality = ctx.array(q)
 		self.stamps = ctx.array(np.asarray(scene.stamps, dtype='int32'))
@@ -62,6 +74,11 @@ class ApertureWork(object):
 		self.diag = ctx.zeros((Nt, 8), 'float64')
 		self.cat_in_mask = ctx.zeros((max(int(batch.scene.cat_offsets[-1]), 1),), 'uint8')
 		self.lc = engine.LightCurves(ctx, Nt, T)
+		self.bkg_raw = self.bkg = None
+		if batch.raw_mode:
+			pitch = batch.images.t_pitch
+			self.bkg_raw = ctx.zeros((Nt, pitch), 'float32')
+			self.bkg = ctx.zeros((Nt, pitch), 'float32')
 
 
 def aperture_step(ctx, batch, work, masks_from=None):
@@ -71,13 +88,19 @@ def aperture_step(ctx, batch, work, masks_from=None):
 	``masks_from``: optional ``(mask uint8 DeviceArray, status int32 DeviceArray)`` to bypass the
 	on-device K2P2 (used by tests that inject the oracle's masks).
 	"""
-	engine.sumimage(ctx, batch.images, batch.quality, out=work.sumimage)
+	subtract, backgrounds = None, batch.backgrounds
+	if batch.raw_mode:
+		engine.background_stamp(ctx, batch.images, out=work.bkg_raw)                           # B*
+		engine.smooth_time(ctx, work.bkg_raw, batch.n_cad, batch.time_smooth, out=work.bkg)    # B2
+		subtract = backgrounds = work.bkg                                                      # B3 on the fly
+	engine.sumimage(ctx, batch.images, batch.quality, out=work.sumimage, subtract=subtract)    # A1
 	if masks_from is None:
-		engine.k2p2_masks(ctx, batch, work)
+		engine.k2p2_masks(ctx, batch, work)                                                    # A2..A5b, A7
 		mask, status = work.mask, work.status
 	else:
 		mask, status = masks_from
-	engine.aperture_extract(ctx, batch.images, batch.images_err, batch.backgrounds, mask, batch.stamps, status=status, out=work.lc)
+	engine.aperture_extract(ctx, batch.images, batch.images_err, backgrounds, mask, batch.stamps, status=status, out=work.lc,
+		subtract=subtract)                                                                     # A6
 	return work
 
 
@@ -99,6 +122,9 @@ def run_aperture(ctx, scene, cubes='host', masks=None):
 	ctx.sync()
 	out = work.lc.to_host()
 	out['sumimage'] = work.sumimage.to_host()
+	if batch.raw_mode:
+		out['background'] = work.bkg.to_host()[:, :batch.n_cad]
+		out['background_raw'] = work.bkg_raw.to_host()[:, :batch.n_cad]
 	if masks_from is None:
 		out['mask'] = work.mask.to_host()
 		out['status'] = work.status.to_host()

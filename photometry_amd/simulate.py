@@ -179,9 +179,11 @@ def fill_cubes(s, nan_fraction=1e-3, with_raw=False, dtype='float32'):
 		sigma = np.sqrt(signal + bkg + s.readnoise**2)
 		noise = rng.standard_normal((H, W, T)) * sigma
 		img = signal + noise
-		if with_raw:
-			raw[i] = (img + bkg).astype(dtype)
 		nanmask = rng.random((H, W, T)) < nan_fraction
+		if with_raw:
+			r = (img + bkg).astype(dtype)
+			r[nanmask] = np.nan
+			raw[i] = r
 		img = img.astype(dtype)
 		err = sigma.astype(dtype)
 		img[nanmask] = np.nan

@@ -226,5 +226,5 @@ def test_extract_empty_batch_and_errors(ctx):
 	from photometry_amd._lib import tp_cube_desc
 	bad = tp_cube_desc(1, 8, 5, 5, 4)
 	with pytest.raises(TessphotError) as e:
-		ctx._check(ctx.lib.tp_sumimage(ctx.handle, ctypes.byref(bad), img.ptr, img.ptr, 0, 4335, img.ptr))
+		ctx._check(ctx.lib.tp_sumimage(ctx.handle, ctypes.byref(bad), img.ptr, img.ptr, 0, 4335, None, 0, img.ptr))
 	assert 'descriptor' in str(e.value)
