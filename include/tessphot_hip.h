@@ -193,6 +193,40 @@ int tp_subtract_background(tp_ctx* ctx, const tp_cube_desc* desc, const float* d
 	const float* d_bkg, int64_t bkg_pitch, const uint8_t* d_pixel_flags, uint32_t flag_mask,
 	float* d_images, float* d_images_err);
 
+/* ---- P1..P4: linear PSF photometry ----------------------------------------------------------------
+ * tp_linpsf_prf (P1) replaces the per-target PRF construction of PSF.__init__ (photometry/psf.py:
+ *   101-119).  The interpolating-spline fit is linear in the data, so the coefficient table of the
+ *   inverse-distance blend is the same blend of the per-sample tables (fitted once per camera/CCD on
+ *   the host with the reference's own scipy call, see photometry_amd/psf.py):
+ *     d_coef[t][c] = sum_s d_weights[t][s] * d_base_coef[s][c]
+ *   d_base_coef float64 [n_samples][n_coef], d_weights float64 [n_targets][n_samples] (already divided
+ *   by the normalisation of psf.py:116), d_coef float64 [n_targets][n_coef].  n_samples <= 32.
+ * tp_linpsf_fit (P2-P4) replaces PSF.integrate_to_image (psf.py:122-148), lsfit and the loop / status
+ *   logic of LinPSFPhotometry.do_photometry (photometry/linpsf_photometry.py:22-34, 79-219).
+ *   d_coef: [n_targets][n*n] spline coefficients, first axis = column direction (psf.py:119,146);
+ *   d_knots_x / d_knots_y: [n+4] FITPACK knots; the PRF grid must be uniform with 9 samples per pixel
+ *   (the SPOC PRF files) and cutoff_radius <= 5.25 px so that only the uniform part of the knot vector
+ *   is touched (LinPSFPhotometry uses 5, linpsf_photometry.py:63).
+ *   fitted stars (ragged, CSR): d_star_offsets int64 [n_targets+1]; d_target_index int32 [n_targets]
+ *   = index of the main target among its fitted stars (the selection of linpsf_photometry.py:93-104 is
+ *   host catalogue work); d_pos_row / d_pos_col float64 [n_fit_stars][pos_pitch] = row_stamp /
+ *   column_stamp of every fitted star at every cadence, i.e. what catalog_attime() returns
+ *   (BasePhotometry.py:1224-1258: WCS / jitter interpolation on the host).  max_stars <= 8.
+ *   d_subtract: optional background series subtracted from d_images on the fly (as in tp_sumimage).
+ *   outputs: d_flux / d_flux_err float64 [n_targets][out_pitch] (flux_err is NaN, :169);
+ *   d_fluxes_all float64 [n_fit_stars][out_pitch] every fitted flux; d_contamination float64 (PSF_CONT,
+ *   :203-211); d_status int32 (OK, WARNING if contamination > 0.1, ERROR if all fluxes are NaN);
+ *   d_fluxes_mean optional float64 [n_fit_stars].                                                    */
+int tp_linpsf_prf(tp_ctx* ctx, int32_t n_targets, int32_t n_samples, int32_t n_coef,
+	const double* d_base_coef, const double* d_weights, double* d_coef);
+int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
+	const float* d_subtract, int64_t subtract_pitch,
+	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis, int32_t max_stars,
+	const int64_t* d_star_offsets, const int32_t* d_target_index,
+	const double* d_pos_row, const double* d_pos_col, int64_t pos_pitch, double cutoff_radius,
+	double* d_flux, double* d_flux_err, double* d_fluxes_all, int64_t out_pitch,
+	double* d_contamination, int32_t* d_status, double* d_fluxes_mean);
+
 /* ---- multi-GPU: the final light-curve gather (RCCL over xGMI) --------------------------------
  * replaces the pickled result messages of run_tessphot_mpi.py:114-132,163-191: targets are
  * statically sharded over the ranks (one process per GPU) and the only data-path exchange is one

@@ -71,6 +71,9 @@ SIGNATURES = {
 	'tp_background_stamp': (c_int, [c_void_p, _desc_p, _p, c_double, c_double, _p, c_int64]),
 	'tp_smooth_time': (c_int, [c_void_p, c_int32, c_int32, c_int64, c_int32, _p, _p]),
 	'tp_subtract_background': (c_int, [c_void_p, _desc_p, _p, _p, _p, c_int64, _p, c_uint32, _p, _p]),
+	'tp_linpsf_prf': (c_int, [c_void_p, c_int32, c_int32, c_int32, _p, _p, _p]),
+	'tp_linpsf_fit': (c_int, [c_void_p, _desc_p, _p, _p, c_int64, _p, _p, _p, c_int32, c_int32, _p, _p, _p, _p, c_int64, c_double,
+		_p, _p, _p, c_int64, _p, _p, _p]),
 	'tp_comm_unique_id': (c_int, [c_char_p, c_int]),
 	'tp_comm_init': (c_int, [c_void_p, c_char_p, c_int, c_int, c_int]),
 	'tp_comm_destroy': (c_int, [c_void_p]),

@@ -15,6 +15,7 @@ static const char* const kKernelNames[TPK_COUNT] = {
 	"tp_bkg_subtract_kernel",
 	"tp_linpsf_prf_kernel",
 	"tp_linpsf_fit_kernel",
+	"tp_linpsf_finalize_kernel",
 	"tp_synth_kernel",
 };
 

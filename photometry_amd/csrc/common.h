@@ -20,6 +20,7 @@ enum tp_kernel_id {
 	TPK_BKG_SUBTRACT,
 	TPK_LINPSF_PRF,
 	TPK_LINPSF_FIT,
+	TPK_LINPSF_FIN,
 	TPK_SYNTH,
 	TPK_COUNT
 };

@@ -1,0 +1,483 @@
+// linpsf.hip -- P1..P4: linear PSF photometry (fixed centroids, simultaneous linear least squares).
+//
+// Replaces photometry/psf.py (PSF.__init__ :35-119, PSF.integrate_to_image :122-148) and
+// photometry/linpsf_photometry.py (lsfit :22-34, LinPSFPhotometry.do_photometry :79-219).
+//
+// P1 (tp_linpsf_prf).  The reference builds, per target, PRF = sum_i PRF_i / dist_i (inverse-distance
+// blend of the 25 SPOC PRF samples to the stamp centre, psf.py:101-113), normalises it (:116) and
+// fits an interpolating bicubic spline (:119).  The spline fit is LINEAR in the data, so the
+// coefficient table of the blend is the same blend of the 25 per-sample coefficient tables, which the
+// host fits once per (camera, CCD) with the same scipy call the reference uses.  The kernel is a
+// register-stationary AXPY: each thread keeps one coefficient of all samples in VGPRs and streams
+// over the targets, so the base tables are read once and only the per-target table is written.
+//
+// P2..P4 (tp_linpsf_fit).  One THREAD per cadence of a target, the target's 117x117 float64
+// coefficient table (110 KB) resident in LDS for the whole workgroup.  The FITPACK box integral of
+// the bicubic spline over a pixel is separable (psf.py:146 -> dblint/fpintb):
+//     integral = sum_ab wx[a] C[a][b] wy[b],  w = integrals of the B-spline basis over the pixel edge.
+// The PRF grid is uniform (9 samples per pixel) and a pixel is exactly 9 knot intervals wide, so
+// for a pixel whose lower edge sits at fraction phi of knot interval l the 13 non-zero weights are
+//     [1-M(phi+3), 1-M(phi+2), 1-M(phi+1), 1-M(phi), 1, 1, 1, 1, 1, M(phi+3), M(phi+2), M(phi+1), M(phi)] * h
+// with M the cumulative cardinal cubic B-spline: 4 numbers per axis per star, the same for every pixel
+// of the stamp (pixels are whole multiples of 9 knots apart).  All 64 lanes of a wavefront work on the
+// same star and pixel of 64 consecutive cadences, so the 169 table reads per pixel are LDS *broadcast*
+// reads (one address, +-1 knot between lanes): one ds_read_b64 feeds 64 float64 FMAs.
+// The normal equations (A^T A, A^T b) are accumulated on the fly; x = pinv(A^T A) A^T b via a cyclic
+// Jacobi eigen-decomposition with numpy's pinv cutoff (rcond = 1e-15 * largest singular value).
+//
+// Roofline: FP64 vector FMA (about 13.5 k FMA per star-cadence inside the 5-pixel cut-off), not HBM:
+// the image cube is read once (P*T*4 bytes per target).  MFMA is not used: the design matrix product is
+// banded (13 of 117), the dense GEMM form would do 13x the flops.
+#include "common.h"
+#include <cmath>
+
+namespace {
+
+constexpr int kMaxStars = 8;
+constexpr int kMaxSamples = 32;
+
+//--------------------------------------------------------------------------------------------------
+// P1: per-target blend of the per-sample coefficient tables
+//--------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tp_linpsf_prf_kernel(const double* __restrict__ base, int n_samples, int n_coef,
+	const double* __restrict__ weights, int n_targets, double* __restrict__ out)
+{
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= n_coef) return;
+	double b[kMaxSamples];
+#pragma unroll
+	for (int s = 0; s < kMaxSamples; ++s) b[s] = (s < n_samples) ? base[(int64_t)s * n_coef + c] : 0.0;
+	for (int t = blockIdx.y; t < n_targets; t += gridDim.y) {
+		const double* w = weights + (int64_t)t * n_samples;
+		double acc = 0.0;
+#pragma unroll
+		for (int s = 0; s < kMaxSamples; ++s) if (s < n_samples) acc += w[s] * b[s];
+		out[(int64_t)t * n_coef + c] = acc;
+	}
+}
+
+//--------------------------------------------------------------------------------------------------
+// P2..P4
+//--------------------------------------------------------------------------------------------------
+// cumulative cardinal cubic B-spline M(z) = int_0^z N(t) dt, N supported on [0, 4]
+__device__ __forceinline__ double cumspline01(double w) { const double w2 = w * w; return w2 * w2 / 24.0; }               // z in [0,1], w = z
+__device__ __forceinline__ double cumspline12(double w) { return 1.0 / 24.0 + (w + 1.5 * w * w + w * w * w - 0.75 * (w * w) * (w * w)) / 6.0; } // z in [1,2], w = z-1
+
+struct FitArgs {
+	const float* images; const float* subtract; int64_t subtract_pitch;
+	int n_cad, height, width; int64_t t_pitch;
+	const double* coef;          // [n_targets][n*n]
+	const double* knots_x;       // [n+4] knots along the first spline axis (columns)
+	const double* knots_y;       // [n+4] knots along the second spline axis (rows)
+	int n;                       // coefficients per axis (117)
+	const int64_t* star_offsets; // [n_targets+1] into the fitted-star arrays
+	const int32_t* target_index; // [n_targets] index of the main target inside its fitted stars
+	const double* pos_row;       // [n_fit_stars][pos_pitch] row_stamp per cadence
+	const double* pos_col;       // [n_fit_stars][pos_pitch]
+	int64_t pos_pitch;
+	double cutoff;
+	double* flux;                // [n_targets][out_pitch]  lightcurve flux (target star)
+	double* flux_err;            // [n_targets][out_pitch]  NaN (linpsf_photometry.py:169)
+	double* fluxes_all;          // [n_fit_stars][out_pitch] fitted flux of every star (for the mean fluxes)
+	int64_t out_pitch;
+};
+
+// pixel-edge weights of one axis for a star at stamp coordinate `pos`: m[k] = M(phi + k), k = 0..3,
+// and `first` such that pixel j uses table rows first + 9*j .. first + 9*j + 12.
+// phi is the same for every pixel (pixels are 9 knot intervals apart); it is measured at the pixel
+// nearest to the star, whose lower edge is guaranteed to lie inside the uniform part of the knot vector.
+__device__ __forceinline__ void axis_weights(const double* kn, int n, double pos, double h, double (&m)[4], int& first)
+{
+	if (!(fabs(pos) < 1e6)) { m[0] = m[1] = m[2] = m[3] = 0.0; first = 4; return; } // NaN / absurd position: never inside the cut-off (psf.py:142)
+	const int jstar = (int)rint(pos);
+	const double x0 = ((double)jstar - pos) - 0.5;   // lower edge of pixel jstar relative to the star, in [-1, 0]
+	// knot interval l with kn[l] <= x0 < kn[l+1]  (uniform interior knots, spacing h)
+	int l = 4 + (int)floor((x0 - kn[4]) / h);
+	if (l < 4) l = 4;
+	if (l > n - 2) l = n - 2;
+	if (x0 < kn[l] && l > 4) --l;
+	else if (x0 >= kn[l + 1] && l < n - 2) ++l;
+	const double phi = (x0 - kn[l]) / (kn[l + 1] - kn[l]);
+	m[0] = cumspline01(phi);
+	m[1] = cumspline12(phi);
+	m[2] = 1.0 - cumspline12(1.0 - phi);  // M(2+phi) = 1 - M(2-phi), 2-phi in (1,2]
+	m[3] = 1.0 - cumspline01(1.0 - phi);  // M(3+phi) = 1 - M(1-phi)
+	first = (l - 3) - 9 * jstar;           // table index of weight p = 0 for pixel 0
+}
+
+// Cyclic Jacobi eigen-decomposition based pseudo-inverse solve:  x = pinv(G) g,  G symmetric S x S.
+template <int S>
+__device__ __forceinline__ void pinv_solve(double (&G)[S][S], const double (&g)[S], int ns, double (&x)[S])
+{
+	double V[S][S];
+#pragma unroll
+	for (int i = 0; i < S; ++i)
+#pragma unroll
+		for (int j = 0; j < S; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+	for (int sweep = 0; sweep < 30; ++sweep) {
+		double off = 0.0;
+#pragma unroll
+		for (int p = 0; p < S; ++p)
+#pragma unroll
+			for (int q = p + 1; q < S; ++q) if (q < ns) off += G[p][q] * G[p][q];
+		double d2 = 0.0;
+#pragma unroll
+		for (int p = 0; p < S; ++p) if (p < ns) d2 += G[p][p] * G[p][p];
+		if (!(off > 1e-34 * d2)) break; // off-diagonal below 1e-17 relative: converged (or NaN)
+#pragma unroll
+		for (int p = 0; p < S; ++p) {
+#pragma unroll
+			for (int q = p + 1; q < S; ++q) {
+				if (q >= ns) continue;
+				const double apq = G[p][q];
+				if (apq == 0.0) continue;
+				const double theta = (G[q][q] - G[p][p]) / (2.0 * apq);
+				const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+				const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+				for (int k = 0; k < S; ++k) {
+					const double gkp = G[k][p], gkq = G[k][q];
+					G[k][p] = c * gkp - s * gkq;
+					G[k][q] = s * gkp + c * gkq;
+				}
+#pragma unroll
+				for (int k = 0; k < S; ++k) {
+					const double gpk = G[p][k], gqk = G[q][k];
+					G[p][k] = c * gpk - s * gqk;
+					G[q][k] = s * gpk + c * gqk;
+				}
+#pragma unroll
+				for (int k = 0; k < S; ++k) {
+					const double vkp = V[k][p], vkq = V[k][q];
+					V[k][p] = c * vkp - s * vkq;
+					V[k][q] = s * vkp + c * vkq;
+				}
+			}
+		}
+	}
+	// numpy.linalg.pinv: singular values (= |eigenvalues|) <= 1e-15 * max are treated as zero
+	double smax = 0.0;
+#pragma unroll
+	for (int i = 0; i < S; ++i) if (i < ns) { const double a = fabs(G[i][i]); if (a > smax || a != a) smax = a; }
+	const double cut = 1e-15 * smax;
+#pragma unroll
+	for (int i = 0; i < S; ++i) x[i] = 0.0;
+#pragma unroll
+	for (int e = 0; e < S; ++e) {
+		if (e >= ns) continue;
+		const double lam = G[e][e];
+		double proj = 0.0;
+#pragma unroll
+		for (int k = 0; k < S; ++k) if (k < ns) proj += V[k][e] * g[k];
+		const double inv = (fabs(lam) > cut) ? (1.0 / lam) : ((lam != lam) ? lam : 0.0);
+		const double coef = proj * inv;
+#pragma unroll
+		for (int k = 0; k < S; ++k) if (k < ns) x[k] += V[k][e] * coef;
+	}
+}
+
+// value of the pixel-integrated unit PRF of one star at pixel (i, j): h^2 * sum_pq wx[p] wy[q] C[ax+p][by+q]
+__device__ __forceinline__ double prf_pixel(const double* __restrict__ C, int n, int ax, int by,
+	const double (&mx)[4], const double (&my)[4])
+{
+	const double* c0 = C + (int64_t)ax * n + by;
+	double acc = 0.0;
+#pragma unroll
+	for (int p = 0; p < 13; ++p) {
+		const double* r = c0 + p * n;
+		// inner contraction over q with weights [1-m3, 1-m2, 1-m1, 1-m0, 1,1,1,1,1, m3, m2, m1, m0]
+		double t = ((r[4] + r[5]) + (r[6] + r[7])) + r[8];
+		t += (r[0] + my[3] * (r[9] - r[0]));
+		t += (r[1] + my[2] * (r[10] - r[1]));
+		t += (r[2] + my[1] * (r[11] - r[2]));
+		t += (r[3] + my[0] * (r[12] - r[3]));
+		double wx;
+		if (p < 4) wx = 1.0 - mx[3 - p];
+		else if (p < 9) wx = 1.0;
+		else wx = mx[12 - p];
+		acc += wx * t;
+	}
+	return acc;
+}
+
+template <int S>
+__global__ __launch_bounds__(512) void tp_linpsf_fit_kernel(FitArgs a)
+{
+	extern __shared__ __align__(16) double lds[]; // [n*n] coefficient table + 2 x [n+4] knots
+	const int target = blockIdx.x;
+	const int tid = threadIdx.x;
+	const int n = a.n;
+	double* C = lds;
+	double* kn = lds + (size_t)n * n;
+	double* kny = kn + n + 4;
+	const double* cg = a.coef + (int64_t)target * n * n;
+	for (int i = tid; i < n * n; i += blockDim.x) C[i] = cg[i];
+	for (int i = tid; i < n + 4; i += blockDim.x) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
+	__syncthreads();
+
+	const int k = blockIdx.y * blockDim.x + tid;
+	if (k >= a.n_cad) return;
+	const int64_t s0 = a.star_offsets[target];
+	int ns = (int)(a.star_offsets[target + 1] - s0);
+	if (ns > S) ns = S; // host guarantees ns <= S for this instantiation
+	const int H = a.height, W = a.width;
+	const double h = kn[5] - kn[4], hy = kny[5] - kny[4];
+	const double cutoff = a.cutoff;
+
+	// per star: edge weights (same for every pixel) and table origin of pixel 0
+	double mx[S][4], my[S][4], srow[S], scol[S];
+	int ax0[S], by0[S];
+#pragma unroll
+	for (int s = 0; s < S; ++s) {
+		if (s < ns) {
+			srow[s] = a.pos_row[(s0 + s) * a.pos_pitch + k];
+			scol[s] = a.pos_col[(s0 + s) * a.pos_pitch + k];
+			// x <-> column (first spline axis), y <-> row  (psf.py:146)
+			axis_weights(kn, n, scol[s], h, mx[s], ax0[s]);
+			axis_weights(kny, n, srow[s], hy, my[s], by0[s]);
+		} else {
+			srow[s] = scol[s] = 0.0; ax0[s] = by0[s] = 4;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { mx[s][q] = 0.0; my[s][q] = 0.0; }
+		}
+	}
+
+	double G[S][S], g[S];
+#pragma unroll
+	for (int i = 0; i < S; ++i) { g[i] = 0.0;
+#pragma unroll
+		for (int j = 0; j < S; ++j) G[i][j] = 0.0; }
+
+	const float* img = a.images + (int64_t)target * H * W * a.t_pitch + k;
+	const float sub = a.subtract ? a.subtract[(int64_t)target * a.subtract_pitch + k] : 0.f;
+	const double h2 = h * hy;
+	for (int i = 0; i < H; ++i) {
+		for (int j = 0; j < W; ++j) {
+			float bf = img[(int64_t)(i * W + j) * a.t_pitch];
+			if (a.subtract) bf = bf - sub;
+			if (!(fabsf(bf) <= 3.402823466e+38f)) continue; // good_pixels = isfinite(img) (linpsf_photometry.py:123)
+			const double b = (double)bf;
+			double av[S];
+#pragma unroll
+			for (int s = 0; s < S; ++s) {
+				av[s] = 0.0;
+				if (s < ns) {
+					const double dc = (double)j - scol[s], dr = (double)i - srow[s];
+					// psf.py:142  sqrt((j-col)^2 + (i-row)^2) < cutoff_radius  (a NaN position is never inside: zero column)
+					const bool inside = sqrt(dc * dc + dr * dr) < cutoff;
+					if (inside) {
+						int ax = ax0[s] + 9 * j, by = by0[s] + 9 * i;
+						ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
+						by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
+						av[s] = h2 * prf_pixel(C, n, ax, by, mx[s], my[s]);
+					}
+				}
+			}
+#pragma unroll
+			for (int s = 0; s < S; ++s) {
+				g[s] += av[s] * b;
+#pragma unroll
+				for (int u = 0; u < S; ++u) if (u >= s) G[s][u] += av[s] * av[u];
+			}
+		}
+	}
+#pragma unroll
+	for (int s = 0; s < S; ++s)
+#pragma unroll
+		for (int u = 0; u < S; ++u) if (u < s) G[s][u] = G[u][s];
+
+	double x[S];
+	pinv_solve<S>(G, g, ns, x);
+	const int ti = a.target_index[target];
+	double tf = __builtin_nan("");
+#pragma unroll
+	for (int s = 0; s < S; ++s) {
+		if (s < ns) {
+			a.fluxes_all[(s0 + s) * a.out_pitch + k] = x[s];
+			if (s == ti) tf = x[s];
+		}
+	}
+	a.flux[(int64_t)target * a.out_pitch + k] = tf;
+	a.flux_err[(int64_t)target * a.out_pitch + k] = __builtin_nan("");
+}
+
+// Finalise (linpsf_photometry.py:197-219): mean fitted fluxes over the cadences with a valid target
+// flux, contamination from the design matrix of the LAST cadence, status.
+struct FinArgs {
+	FitArgs f;
+	double* contamination; int32_t* status; double* fluxes_mean;
+};
+
+template <int S>
+__global__ __launch_bounds__(256) void tp_linpsf_finalize_kernel(FinArgs fa)
+{
+	extern __shared__ __align__(16) double lds[];
+	const FitArgs& a = fa.f;
+	const int target = blockIdx.x;
+	const int tid = threadIdx.x;
+	const int n = a.n;
+	double* C = lds;
+	double* kn = lds + (size_t)n * n;
+	double* kny = kn + n + 4;
+	double* red = kny + n + 4;           // [256]
+	const double* cg = a.coef + (int64_t)target * n * n;
+	for (int i = tid; i < n * n; i += blockDim.x) C[i] = cg[i];
+	for (int i = tid; i < n + 4; i += blockDim.x) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
+	__syncthreads();
+	const int64_t s0 = a.star_offsets[target];
+	int ns = (int)(a.star_offsets[target + 1] - s0);
+	if (ns > S) ns = S;
+	const int ti = a.target_index[target];
+	const double* ftar = a.flux + (int64_t)target * a.out_pitch;
+
+	// count of valid cadences and per-star flux sums (only over cadences whose fit succeeded)
+	double mean[S];
+	double cntd = 0.0;
+	for (int s = -1; s < ns; ++s) {
+		double acc = 0.0;
+		for (int k = tid; k < a.n_cad; k += blockDim.x) {
+			const bool ok = ftar[k] == ftar[k];
+			if (s < 0) acc += ok ? 1.0 : 0.0;
+			else acc += ok ? a.fluxes_all[(s0 + s) * a.out_pitch + k] : 0.0;
+		}
+		red[tid] = acc;
+		__syncthreads();
+		double tot = 0.0;
+		for (int l = 0; l < (int)blockDim.x; ++l) tot += red[l];
+		__syncthreads();
+		if (s < 0) cntd = tot;
+		else {
+#pragma unroll
+			for (int u = 0; u < S; ++u) if (u == s) mean[u] = tot / cntd;
+		}
+	}
+	if (cntd == 0.0) { // allnan(flux) -> ERROR (linpsf_photometry.py:198-200)
+		if (tid == 0) { fa.status[target] = TP_STATUS_ERROR; fa.contamination[target] = __builtin_nan(""); }
+		return;
+	}
+	// contamination = sum_p (A[p, others] . mean[others]) * A[p, target] / mean[target], A of the last cadence
+	const int k = a.n_cad - 1;
+	const int H = a.height, W = a.width;
+	const double h = kn[5] - kn[4], hy = kny[5] - kny[4], h2 = h * hy;
+	double mx[S][4], my[S][4], srow[S], scol[S];
+	int ax0[S], by0[S];
+#pragma unroll
+	for (int s = 0; s < S; ++s) {
+		if (s < ns) {
+			srow[s] = a.pos_row[(s0 + s) * a.pos_pitch + k];
+			scol[s] = a.pos_col[(s0 + s) * a.pos_pitch + k];
+			axis_weights(kn, n, scol[s], h, mx[s], ax0[s]);
+			axis_weights(kny, n, srow[s], hy, my[s], by0[s]);
+		} else { srow[s] = scol[s] = 0.0; ax0[s] = by0[s] = 4;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { mx[s][q] = 0.0; my[s][q] = 0.0; } }
+	}
+	const float* img = a.images + (int64_t)target * H * W * a.t_pitch + k;
+	const float sub = a.subtract ? a.subtract[(int64_t)target * a.subtract_pitch + k] : 0.f;
+	double acc = 0.0;
+	for (int p = tid; p < H * W; p += blockDim.x) {
+		const int i = p / W, j = p - i * W;
+		float bf = img[(int64_t)p * a.t_pitch];
+		if (a.subtract) bf = bf - sub;
+		if (!(fabsf(bf) <= 3.402823466e+38f)) continue;
+		double others = 0.0, at = 0.0;
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			if (s >= ns) continue;
+			const double dc = (double)j - scol[s], dr = (double)i - srow[s];
+			double v = 0.0;
+			if (sqrt(dc * dc + dr * dr) < a.cutoff) {
+				int ax = ax0[s] + 9 * j, by = by0[s] + 9 * i;
+				ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
+				by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
+				v = h2 * prf_pixel(C, n, ax, by, mx[s], my[s]);
+			}
+			if (s == ti) at = v; else others += v * mean[s];
+		}
+		acc += others * at;
+	}
+	red[tid] = acc;
+	__syncthreads();
+	if (tid == 0) {
+		double tot = 0.0;
+		for (int l = 0; l < (int)blockDim.x; ++l) tot += red[l];
+		double mt = 0.0;
+#pragma unroll
+		for (int u = 0; u < S; ++u) if (u == ti) mt = mean[u];
+		const double cont = tot / mt;
+		fa.contamination[target] = cont;
+		fa.status[target] = (cont > 0.1) ? TP_STATUS_WARNING : TP_STATUS_OK; // :214-219
+		if (fa.fluxes_mean) {
+#pragma unroll
+			for (int u = 0; u < S; ++u) if (u < ns) fa.fluxes_mean[s0 + u] = mean[u];
+		}
+	}
+}
+
+} // namespace
+
+extern "C" int tp_linpsf_prf(tp_ctx* ctx, int32_t n_targets, int32_t n_samples, int32_t n_coef,
+	const double* d_base_coef, const double* d_weights, double* d_coef)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, n_targets >= 0 && n_samples > 0 && n_samples <= kMaxSamples && n_coef > 0, "tp_linpsf_prf: bad sizes (at most 32 PRF samples)");
+	TP_REQUIRE(ctx, d_base_coef && d_weights && d_coef, "tp_linpsf_prf: null pointer");
+	if (n_targets == 0) return TP_OK;
+	const unsigned gy = (unsigned)((n_targets < 64) ? n_targets : 64);
+	dim3 block(256), grid((unsigned)((n_coef + 255) / 256), gy);
+	TP_LAUNCH(ctx, TPK_LINPSF_PRF, tp_linpsf_prf_kernel, grid, block, 0, d_base_coef, (int)n_samples, (int)n_coef, d_weights, (int)n_targets, d_coef);
+	TP_LAUNCH_CHECK(ctx, "tp_linpsf_prf_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
+	const float* d_subtract, int64_t subtract_pitch,
+	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis, int32_t max_stars,
+	const int64_t* d_star_offsets, const int32_t* d_target_index,
+	const double* d_pos_row, const double* d_pos_col, int64_t pos_pitch, double cutoff_radius,
+	double* d_flux, double* d_flux_err, double* d_fluxes_all, int64_t out_pitch,
+	double* d_contamination, int32_t* d_status, double* d_fluxes_mean)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, tp_desc_ok(desc), "tp_linpsf_fit: bad cube descriptor");
+	TP_REQUIRE(ctx, d_images && d_coef && d_knots_x && d_knots_y && d_star_offsets && d_target_index && d_pos_row && d_pos_col, "tp_linpsf_fit: null input pointer");
+	TP_REQUIRE(ctx, d_flux && d_flux_err && d_fluxes_all && d_contamination && d_status, "tp_linpsf_fit: null output pointer");
+	TP_REQUIRE(ctx, pos_pitch >= desc->n_cad && out_pitch >= desc->n_cad, "tp_linpsf_fit: pitch < n_cad");
+	TP_REQUIRE(ctx, d_subtract == nullptr || subtract_pitch >= desc->n_cad, "tp_linpsf_fit: bad subtract pitch");
+	TP_REQUIRE(ctx, n_coef_axis >= 32 && n_coef_axis <= 140, "tp_linpsf_fit: coefficient table must be 32..140 per axis (LDS resident)");
+	TP_REQUIRE(ctx, max_stars >= 1 && max_stars <= kMaxStars, "tp_linpsf_fit: at most 8 stars fitted per target");
+	TP_REQUIRE(ctx, cutoff_radius > 0 && cutoff_radius <= 5.25, "tp_linpsf_fit: cutoff_radius must be in (0, 5.25] (uniform-knot region of the PRF spline)");
+	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
+
+	FitArgs a;
+	a.images = d_images; a.subtract = d_subtract; a.subtract_pitch = subtract_pitch;
+	a.n_cad = desc->n_cad; a.height = desc->height; a.width = desc->width; a.t_pitch = desc->t_pitch;
+	a.coef = d_coef; a.knots_x = d_knots_x; a.knots_y = d_knots_y; a.n = n_coef_axis;
+	a.star_offsets = d_star_offsets; a.target_index = d_target_index;
+	a.pos_row = d_pos_row; a.pos_col = d_pos_col; a.pos_pitch = pos_pitch; a.cutoff = cutoff_radius;
+	a.flux = d_flux; a.flux_err = d_flux_err; a.fluxes_all = d_fluxes_all; a.out_pitch = out_pitch;
+
+	const size_t shmem = ((size_t)n_coef_axis * n_coef_axis + 2 * (n_coef_axis + 4)) * sizeof(double);
+	const int nblk = (desc->n_cad + 511) / 512;
+	int threads = (((desc->n_cad + nblk - 1) / nblk) + 63) / 64 * 64;
+	dim3 grid((unsigned)desc->n_targets, (unsigned)nblk), block((unsigned)threads);
+	const size_t shmem_fin = shmem + 256 * sizeof(double);
+	FinArgs fa; fa.f = a; fa.contamination = d_contamination; fa.status = d_status; fa.fluxes_mean = d_fluxes_mean;
+#define TP_LINPSF_LAUNCH(SS) do { \
+		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_kernel<SS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+		TP_LAUNCH(ctx, TPK_LINPSF_FIT, tp_linpsf_fit_kernel<SS>, grid, block, shmem, a); \
+		TP_LAUNCH_CHECK(ctx, "tp_linpsf_fit_kernel"); \
+		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_finalize_kernel<SS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_fin)); \
+		TP_LAUNCH(ctx, TPK_LINPSF_FIN, tp_linpsf_finalize_kernel<SS>, dim3((unsigned)desc->n_targets), dim3(256), shmem_fin, fa); \
+		TP_LAUNCH_CHECK(ctx, "tp_linpsf_finalize_kernel"); \
+	} while (0)
+	if (max_stars <= 2) TP_LINPSF_LAUNCH(2);
+	else if (max_stars <= 4) TP_LINPSF_LAUNCH(4);
+	else TP_LINPSF_LAUNCH(8);
+#undef TP_LINPSF_LAUNCH
+	return TP_OK;
+	TP_API_END(ctx)
+}

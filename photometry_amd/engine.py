@@ -150,3 +150,43 @@ def k2p2_masks(ctx, batch, work, cut_override=None, params=None):
 		batch.stamps.ptr, batch.aperture.ptr, _ptr(cut_override), None if params is None else ctypes.byref(params),
 		work.mask.ptr, work.status.ptr, work.flags.ptr, work.contamination.ptr, work.diag.ptr, work.cat_in_mask.ptr))
 	return work
+
+
+class LinPSFResult(object):
+	"""Device-resident outputs of the LinPSF pipeline."""
+	def __init__(self, ctx, n_targets, n_fit_stars, n_cad):
+		self.n_cad = int(n_cad)
+		self.flux = ctx.zeros((n_targets, n_cad), 'float64')
+		self.flux_err = ctx.zeros((n_targets, n_cad), 'float64')
+		self.fluxes_all = ctx.zeros((max(n_fit_stars, 1), n_cad), 'float64')
+		self.contamination = ctx.zeros((n_targets,), 'float64')
+		self.status = ctx.zeros((n_targets,), 'int32')
+		self.fluxes_mean = ctx.zeros((max(n_fit_stars, 1),), 'float64')
+
+	def to_host(self):
+		return {k: getattr(self, k).to_host() for k in ('flux', 'flux_err', 'fluxes_all', 'contamination', 'status', 'fluxes_mean')}
+
+
+def linpsf_prf(ctx, base_coef, weights, out=None):
+	"""P1 (psf.py:101-119): per-target spline coefficient tables ``(Nt, n*n)`` from the sample tables."""
+	n_samples, n_coef = base_coef.shape
+	Nt = weights.shape[0]
+	assert weights.shape[1] == n_samples
+	if out is None:
+		out = ctx.empty((Nt, n_coef), 'float64')
+	ctx._check(ctx.lib.tp_linpsf_prf(ctx.handle, Nt, n_samples, n_coef, base_coef.ptr, weights.ptr, out.ptr))
+	return out
+
+
+def linpsf_fit(ctx, images, coef, knots_x, knots_y, star_offsets, target_index, pos_row, pos_col, max_stars,
+	cutoff_radius=5.0, subtract=None, out=None):
+	"""P2-P4 (psf.py:122-148, linpsf_photometry.py:22-34, 79-219)."""
+	n = knots_x.shape[0] - 4
+	if out is None:
+		out = LinPSFResult(ctx, images.n_targets, pos_row.shape[0], images.n_cad)
+	desc = images.desc
+	ctx._check(ctx.lib.tp_linpsf_fit(ctx.handle, ctypes.byref(desc), images.ptr, _ptr(subtract), 0 if subtract is None else subtract.shape[1],
+		coef.ptr, knots_x.ptr, knots_y.ptr, n, int(max_stars), star_offsets.ptr, target_index.ptr,
+		pos_row.ptr, pos_col.ptr, pos_row.shape[1], float(cutoff_radius),
+		out.flux.ptr, out.flux_err.ptr, out.fluxes_all.ptr, out.n_cad, out.contamination.ptr, out.status.ptr, out.fluxes_mean.ptr))
+	return out

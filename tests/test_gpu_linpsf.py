@@ -1,0 +1,115 @@
+# -*- coding: utf-8 -*-
+"""
+GPU parity of the LinPSF path (P1 PRF blend, P2 pixel-integrated PRF, P3 least squares, P4 loop)
+against the oracle and against the golden vectors produced by the reference's own
+``LinPSFPhotometry.do_photometry``.  Float64 throughout; north_star tolerance on flux is 1e-5
+relative, asserted here at 1e-8.
+"""
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+	from photometry_amd.device import Context
+	c = Context(0)
+	yield c
+	c.close()
+
+
+def _positions(s, sel, T):
+	"""catalog_attime stand-in: reference position + per-cadence jitter (BasePhotometry.py:1224-1258)."""
+	rs = s.catalog['row_stamp'][sel].astype('float64')
+	cs = s.catalog['column_stamp'][sel].astype('float64')
+	pos_row = rs[:, None] + s.jitter[None, :, 1]
+	pos_col = cs[:, None] + s.jitter[None, :, 0]
+	return np.ascontiguousarray(pos_row), np.ascontiguousarray(pos_col)
+
+
+def test_prf_blend_matches_reference_construction(ctx):
+	"""P1: device blend of per-sample spline tables == spline of the blended PRF (psf.py:101-119)."""
+	from photometry_amd import engine, psf as hpsf
+	from oracle import psf as opsf
+	prf = opsf.synthetic_prf(seed=3)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	stamps = np.array([[100, 115, 300, 315], [0, 15, 44, 59], [2030, 2045, 2070, 2085], [1000, 1011, 1200, 1213]])
+	w = model.weights(stamps)
+	coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(w)).to_host()
+	for i, st in enumerate(stamps):
+		ref = opsf.PSF(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'], tuple(st))
+		np.testing.assert_allclose(coef[i].reshape(model.n, model.n), ref.coeffs, rtol=1e-9, atol=1e-13*np.abs(ref.coeffs).max())
+		np.testing.assert_array_equal(model.tx, ref.tx)
+
+
+@pytest.mark.parametrize("max_neigh,T,H,W", [(3, 40, 11, 11), (1, 70, 15, 15), (6, 16, 13, 12)])
+def test_linpsf_matches_oracle(ctx, max_neigh, T, H, W):
+	from photometry_amd import simulate, engine, psf as hpsf
+	from photometry_amd.device import DeviceCube
+	from oracle import psf as opsf, linpsf as olin
+	s = simulate.make_scene(6, T, H, W, seed=50 + max_neigh, max_neighbours=max_neigh, neighbour_tmag_range=(9.0, 17.0))
+	simulate.fill_cubes(s, nan_fraction=0.01)
+	s.images[0, :, :, 3] = np.nan       # a frame without a single good pixel -> flux 0 (pinv of a zero matrix)
+	prf = opsf.synthetic_prf(seed=7)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	sel, star_offsets, target_index = hpsf.select_stars(s.catalog, s.cat_offsets, s.target_starid)
+	pos_row, pos_col = _positions(s, sel, T)
+	max_stars = int(np.diff(star_offsets).max())
+	coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(model.weights(s.stamps)))
+	res = engine.linpsf_fit(ctx, DeviceCube.from_host(ctx, s.images), coef, ctx.array(model.tx), ctx.array(model.ty),
+		ctx.array(star_offsets), ctx.array(target_index), ctx.array(pos_row), ctx.array(pos_col), max_stars).to_host()
+	for i in range(s.n_targets):
+		cat = s.catalog_of(i)
+		ncat = len(cat['starid'])
+		positions = np.empty((T, ncat, 2))
+		positions[:, :, 0] = cat['row_stamp'][None, :] + s.jitter[:, 1][:, None]
+		positions[:, :, 1] = cat['column_stamp'][None, :] + s.jitter[:, 0][:, None]
+		p = opsf.PSF(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'], tuple(s.stamps[i]))
+		ref = olin.do_photometry(s.images[i], p, cat, s.target_starid[i], positions, tuple(s.stamps[i]),
+			s.target_pos_row[i], s.target_pos_column[i], s.aperture[i])
+		assert ref['nstars'] == star_offsets[i+1] - star_offsets[i] and ref['staridx'] == target_index[i]
+		scale = np.nanmax(np.abs(ref['flux']))
+		np.testing.assert_allclose(res['flux'][i], ref['flux'], rtol=1e-8, atol=1e-9*scale)
+		assert np.all(np.isnan(res['flux_err'][i]))
+		assert int(res['status'][i]) == ref['status']
+		np.testing.assert_allclose(res['contamination'][i], ref['contamination'], rtol=1e-7, atol=1e-11)
+		np.testing.assert_allclose(res['fluxes_mean'][star_offsets[i]:star_offsets[i+1]], ref['fluxes_mean'], rtol=1e-8, atol=1e-9*scale)
+	assert res['flux'][0, 3] == 0.0
+
+
+def test_linpsf_golden(ctx, golden_dir):
+	"""The reference's own LinPSFPhotometry.do_photometry (golden) through the device kernels."""
+	from photometry_amd import engine, psf as hpsf
+	from photometry_amd.device import DeviceCube
+	from scipy.interpolate import RectBivariateSpline
+	g = np.load(os.path.join(golden_dir, 'golden_linpsf.npz'))
+	x = g['prf_x']
+	model = hpsf.PRFModel.from_spline(RectBivariateSpline(x, x, g['prf_img']))
+	Nt, H, W, T = g['images'].shape
+	catalog = {k[4:]: g[k] for k in g.files if k.startswith('cat_') and k != 'cat_offsets'}
+	sel, star_offsets, target_index = hpsf.select_stars(catalog, g['cat_offsets'], g['target_starid'])
+	pos_row = np.concatenate([g[f'lp{i}_positions'][:, :, 0].T for i in range(Nt)])[sel]
+	pos_col = np.concatenate([g[f'lp{i}_positions'][:, :, 1].T for i in range(Nt)])[sel]
+	coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(model.weights(g['stamps'])))
+	res = engine.linpsf_fit(ctx, DeviceCube.from_host(ctx, g['images']), coef, ctx.array(model.tx), ctx.array(model.ty),
+		ctx.array(star_offsets), ctx.array(target_index), ctx.array(np.ascontiguousarray(pos_row)), ctx.array(np.ascontiguousarray(pos_col)),
+		int(np.diff(star_offsets).max())).to_host()
+	for i in range(int(g['n_linpsf'])):
+		ref = g[f'lp{i}_flux']
+		np.testing.assert_allclose(res['flux'][i], ref, rtol=1e-8, atol=1e-9*np.abs(ref).max())
+		assert int(res['status'][i]) == int(g[f'lp{i}_status'])
+		np.testing.assert_allclose(res['contamination'][i], float(g[f'lp{i}_contamination']), rtol=1e-7, atol=1e-11)
+
+
+def test_linpsf_argument_checks(ctx):
+	from photometry_amd import engine
+	from photometry_amd.device import DeviceCube
+	from photometry_amd._lib import TessphotError
+	img = DeviceCube(ctx, 1, 8, 5, 5)
+	z = ctx.zeros((200,), 'float64')
+	with pytest.raises(TessphotError) as e:
+		engine.linpsf_fit(ctx, img, z, ctx.zeros((121,), 'float64'), ctx.zeros((121,), 'float64'), ctx.zeros((2,), 'int64'),
+			ctx.zeros((1,), 'int32'), ctx.zeros((1, 8), 'float64'), ctx.zeros((1, 8), 'float64'), 1, cutoff_radius=7.0)
+	assert 'cutoff_radius' in str(e.value)
