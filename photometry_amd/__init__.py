@@ -9,3 +9,5 @@ There is no CPU fallback: every compute entry point raises if the library is mis
 from .status import STATUS  # noqa: F401
 
 __version__ = '0.1.0'
+from .plugins import BasePhotometry, AperturePhotometry, LinPSFPhotometry, PSFPhotometry, HaloPhotometry  # noqa: F401,E402
+from .tessphot import tessphot, tessphot_batch  # noqa: F401,E402

@@ -1,0 +1,134 @@
+# -*- coding: utf-8 -*-
+"""
+GPU tests of the drop-in plugin API: they read like the reference's tests/test_aperturephotometry.py
+(status in {OK, WARNING}; no NaN in the sum image; flux / err / centroid not all 0 / NaN; aperture bits
+2 and 8 set in the saved file; header keys) plus parity against the oracle, the stamp-resize retry
+loop, tessphot() dispatch and the batch API.
+"""
+import os
+import numpy as np
+import pytest
+from photometry_amd import STATUS, tessphot, tessphot_batch, simulate
+from photometry_amd.plugins import AperturePhotometry, LinPSFPhotometry
+from photometry_amd.source import MemoryStampSource, source_from_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+	from photometry_amd.device import Context
+	c = Context(0)
+	yield c
+	c.close()
+
+
+def _scene(n=6, T=50, H=15, W=15, seed=5, **kw):
+	s = simulate.make_scene(n, T, H, W, seed=seed, **kw)
+	simulate.fill_cubes(s)
+	return s
+
+
+def test_aperturephotometry_like_the_reference(ctx, tmp_path):
+	s = _scene()
+	from oracle import aperture as oap
+	for i in range(s.n_targets):
+		src = source_from_scene(s, i)
+		with AperturePhotometry(int(s.target_starid[i]), src, str(tmp_path), datasource='ffi', ctx=ctx) as pho:
+			pho.photometry()
+			assert pho.status in (STATUS.OK, STATUS.WARNING)
+			assert not np.any(np.isnan(pho.sumimage))
+			assert not np.all(pho.lightcurve['flux'] == 0) and not np.all(np.isnan(pho.lightcurve['flux']))
+			assert not np.all(pho.lightcurve['flux_err'] == 0) and not np.all(np.isnan(pho.lightcurve['pos_centroid']))
+			# parity with the oracle (same stamp, fixed cube)
+			ref = oap.do_photometry(pho.sumimage, s.images[i], s.images_err[i], s.backgrounds[i], tuple(s.stamps[i]),
+				s.target_pos_row[i], s.target_pos_column[i], s.target_tmag[i], s.target_starid[i], s.catalog_of(i), pho.aperture)
+			assert pho.status.value == ref['status']
+			np.testing.assert_array_equal(pho.final_phot_mask, ref['mask'])
+			np.testing.assert_array_equal(pho.lightcurve['flux'], ref['flux'])
+			np.testing.assert_array_equal(pho.lightcurve['flux_err'], ref['flux_err'])
+			np.testing.assert_array_equal(pho.lightcurve['flux_background'], ref['flux_background'])
+			assert pho._details.get('skip_targets', []) == ref['skip_targets']
+			for key in ('mean_flux', 'variance', 'rms_hour', 'ptp', 'pos_centroid', 'variability', 'mask_size', 'edge_flux'):
+				assert key in pho._details
+			assert pho._details['mask_size'] == int(ref['mask'].sum())
+			assert pho.additional_headers['KP_THRES'][0] == 0.8 and pho.additional_headers['KP_MIPIX'][0] == 4
+			fname = pho.save_lightcurve()
+		# saved file: same table, aperture bits 2 and 8 set (tests/test_aperturephotometry.py:70-96)
+		f = np.load(fname)
+		np.testing.assert_array_equal(f['FLUX_RAW'], ref['flux'])
+		np.testing.assert_array_equal(f['MOM_CENTR1'], pho.lightcurve['pos_centroid'][:, 0])
+		assert np.any(f['APERTURE'] & 2 != 0) and np.any(f['APERTURE'] & 8 != 0) and np.all(f['APERTURE'] & 1 != 0)
+		assert 'KP_THRES' in list(f['HEADER_KEYS'])
+
+
+def test_tessphot_dispatch_and_details(ctx, tmp_path):
+	s = _scene(n=3, seed=8)
+	for method in ('aperture', None):
+		pho = tessphot(method, int(s.target_starid[1]), source_from_scene(s, 1), str(tmp_path), ctx=ctx)
+		assert pho.status in (STATUS.OK, STATUS.WARNING) and pho.method == 'aperture'
+		assert 'filepath_lightcurve' in pho._details and os.path.exists(os.path.join(str(tmp_path), pho._details['filepath_lightcurve']))
+		assert pho._details['stamp'] == tuple(int(v) for v in s.stamps[1])
+
+
+def test_stamp_resize_retry(ctx, tmp_path):
+	"""A bright star in a large frame: the mask touches the default stamp's edge -> resize_stamp(+10) and retry (photometry.py:123-165)."""
+	from photometry_amd import simulate as sim
+	R = C = 61
+	T = 40
+	s = sim.make_scene(1, T, R, C, seed=3, tmag_range=(6.5, 6.6), max_neighbours=0, sigma_psf=2.2)
+	sim.fill_cubes(s, nan_fraction=0.0)
+	st = s.stamps[0]
+	frames = {'images': s.images[0], 'images_err': s.images_err[0], 'backgrounds': s.backgrounds[0]}
+	cat = s.catalog_of(0)
+	src = MemoryStampSource(frames, st[0], st[2], s.time, s.timecorr, np.arange(T), s.quality,
+		{'starid': cat['starid'], 'tmag': cat['tmag'], 'row': cat['row'], 'column': cat['column']},
+		targets={'starid': s.target_starid, 'tmag': s.target_tmag, 'row': s.target_pos_row, 'column': s.target_pos_column})
+	with AperturePhotometry(int(s.target_starid[0]), src, str(tmp_path), ctx=ctx) as pho:
+		first = pho.stamp
+		assert (first[1] - first[0], first[3] - first[2]) == (17, 17) # default stamp at Tmag 6.5 (BasePhotometry.py:541-564)
+		pho.photometry()
+		assert pho.status in (STATUS.OK, STATUS.WARNING)
+		assert pho._details.get('stamp_resizes', 0) >= 1
+		assert pho.stamp != first and pho.final_phot_mask.shape == (pho.stamp[1] - pho.stamp[0], pho.stamp[3] - pho.stamp[2])
+		m = pho.final_phot_mask
+		assert not (m[0].any() or m[-1].any() or m[:, 0].any() or m[:, -1].any()) or pho.stamp == tuple(src.max_stamp)
+
+
+def test_linpsf_plugin(ctx, tmp_path):
+	from photometry_amd import psf as hpsf
+	from oracle import psf as opsf, linpsf as olin
+	s = simulate.make_scene(3, 20, 11, 11, seed=61, max_neighbours=2, neighbour_tmag_range=(9.0, 15.0))
+	simulate.fill_cubes(s, nan_fraction=0.005)
+	prf = opsf.synthetic_prf(seed=2)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	for i in range(3):
+		src = source_from_scene(s, i)
+		src.prf = model
+		pho = tessphot('linpsf', int(s.target_starid[i]), src, str(tmp_path), ctx=ctx)
+		# flux_err is all NaN in the reference's LinPSF (linpsf_photometry.py:169), which photometry() rejects
+		# (BasePhotometry.py:1348-1349) -> STATUS.ERROR exactly like upstream; the fluxes are still filled in:
+		assert pho.status == STATUS.ERROR and any('errors are all NaNs' in e for e in pho._details['errors'])
+		cat = pho.catalog
+		T = s.n_cad
+		positions = np.empty((T, len(cat), 2))
+		for k in range(T):
+			ck = pho.catalog_attime(pho.lightcurve['time'][k] - pho.lightcurve['timecorr'][k])
+			positions[k, :, 0] = ck['row_stamp']
+			positions[k, :, 1] = ck['column_stamp']
+		p = opsf.PSF(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'], pho.stamp)
+		ref = olin.do_photometry(s.images[i], p, {k: cat[k] for k in ('starid', 'tmag', 'row_stamp', 'column_stamp')},
+			s.target_starid[i], positions, pho.stamp, pho.target_pos_row, pho.target_pos_column, np.ones((11, 11), dtype='int32'))
+		np.testing.assert_allclose(pho.lightcurve['flux'], ref['flux'], rtol=1e-8, atol=1e-9*np.nanmax(np.abs(ref['flux'])))
+
+
+def test_batch_api(ctx):
+	s = _scene(n=12, T=30, seed=9)
+	res = tessphot_batch(ctx, s)
+	assert len(res) == 12
+	for i, r in enumerate(res):
+		pho = None
+		assert r.starid == s.target_starid[i] and r.method == 'aperture'
+		assert r.status in (STATUS.OK, STATUS.WARNING, STATUS.ERROR)
+		if r.status != STATUS.ERROR:
+			assert r.lightcurve['flux'].shape == (30,) and r._details['mask_size'] == r.final_phot_mask.sum()

@@ -1,0 +1,147 @@
+# -*- coding: utf-8 -*-
+"""
+CPU tests of the host-side plugin API: stamp geometry (known answers of the reference's
+tests/test_basephotometry.py), dispatch and error conventions (tessphot.py), table helpers,
+target sharding and skip-target replay.  No GPU needed: numerics run only in the gpu tests.
+"""
+import numpy as np
+import pytest
+import photometry_amd
+from photometry_amd import STATUS, tessphot, simulate
+from photometry_amd.plugins import BasePhotometry, AperturePhotometry, Table
+from photometry_amd.source import MemoryStampSource, source_from_scene
+from photometry_amd import comm as tpcomm
+
+
+def _region_source(R=60, C=80, T=6, row0=30, col0=44, tmag=10.0):
+	frames = {k: np.zeros((R, C, T), dtype='float32') for k in ('images', 'images_err', 'backgrounds')}
+	cat = {'starid': np.array([1, 2]), 'tmag': np.array([tmag, 12.0], dtype='float32'),
+		'row': np.array([55.2, 57.0], dtype='float32'), 'column': np.array([60.7, 63.0], dtype='float32')}
+	return MemoryStampSource(frames, row0, col0, np.arange(T)*0.02, np.zeros(T), np.arange(T), np.zeros(T, dtype='int32'), cat)
+
+
+def test_status_values():
+	# photometry/BasePhotometry.py:48-59
+	assert [STATUS.UNKNOWN.value, STATUS.OK.value, STATUS.ERROR.value, STATUS.WARNING.value, STATUS.ABORT.value,
+		STATUS.SKIPPED.value, STATUS.STARTED.value] == [0, 1, 2, 3, 4, 5, 6]
+
+
+def test_stamp_geometry_known_answers():
+	"""tests/test_basephotometry.py:59-173 of the reference: default stamp, 1-based pixel grid, resize."""
+	src = _region_source()
+	with BasePhotometry(1, src, None, datasource='ffi') as pho:
+		assert pho.stamp == (48, 63, 54, 69) # round(55.2)=55, round(60.7)=61; 15 rows / cols: pos - 7 .. pos + 8
+		cols, rows = pho.get_pixel_grid()
+		assert rows.shape == (15, 15) and cols.shape == (15, 15)
+		assert rows[0, 0] == 49 and cols[0, 0] == 55 and rows[-1, 0] == 63 and cols[0, -1] == 69 # 1-based
+		assert abs(pho.target_pos_row_stamp - (55.2 - 48)) < 1e-5 and abs(pho.target_pos_column_stamp - (60.7 - 54)) < 1e-5
+		# resize (BasePhotometry.py:567-613)
+		assert pho.resize_stamp(up=12)
+		assert pho.stamp == (48, 75, 54, 69)
+		assert pho.resize_stamp(down=2, left=3, right=4)
+		assert pho.stamp == (46, 75, 51, 73)
+		assert pho._details['stamp_resizes'] == 2
+		assert pho.resize_stamp(width=11, height=17)
+		assert pho.stamp == (55 - 8, 55 + 9, 61 - 5, 61 + 6)
+		# growing beyond the frame is clipped; no change -> False
+		assert pho.resize_stamp(up=1000) and pho.stamp[1] == 90
+		assert pho.resize_stamp(up=10) is False
+		# the explicit stamp of the reference's test: (50, 60, 50, 70) -> rows 51..60, cols 51..70
+		pho._stamp = (50, 60, 50, 70)
+		cols, rows = pho.get_pixel_grid()
+		assert rows[0, 0] == 51 and rows[-1, 0] == 60 and cols[0, 0] == 51 and cols[0, -1] == 70
+
+
+def test_default_stamp_bright_star():
+	src = _region_source(tmag=2.0)
+	with BasePhotometry(1, src, None) as pho:
+		Nrows, Ncols = pho.default_stamp()
+		assert Nrows > 100 and Ncols > 50 # BasePhotometry.py:541-564 lookup table
+		assert pho.stamp[:2] == tuple(src.max_stamp[:2]) # rows clipped to the frame
+		assert pho.stamp[2] == 44 and pho.stamp[3] == 61 + int(Ncols)//2 + 1
+
+
+def test_catalog_and_table():
+	src = _region_source()
+	with BasePhotometry(1, src, None) as pho:
+		cat = pho.catalog
+		assert len(cat) == 2 and cat['row_stamp'].dtype == np.float32
+		np.testing.assert_allclose(cat['row_stamp'], cat['row'] - pho.stamp[0], atol=1e-4)
+		rows = list(cat)
+		assert rows[0]['starid'] == 1
+		sub = cat[[1]]
+		assert len(sub) == 1 and sub[0]['starid'] == 2
+		assert len(cat[[]]) == 0
+	t = Table(a=np.arange(3))
+	t['b'] = np.arange(3) * 2
+	assert 'b' in t and t[2]['b'] == 4
+
+
+def test_invalid_inputs():
+	src = _region_source()
+	with pytest.raises(ValueError):
+		tessphot('nonexistent', 1, src, None) # tessphot.py:128-129
+	with pytest.raises(ValueError):
+		BasePhotometry(1, src, None, datasource='invalid')
+	with pytest.raises(FileNotFoundError):
+		BasePhotometry(1, '/not/a/source', None)
+	with pytest.raises(RuntimeError):
+		BasePhotometry(12345, src, None) # star not in catalog (BasePhotometry.py:413-414)
+	with BasePhotometry(1, src, None) as pho:
+		with pytest.raises(NotImplementedError):
+			pho.do_photometry()
+
+
+def test_errors_become_status_error(tmp_path):
+	"""tessphot.py:37-49: any exception in the plugin -> STATUS.ERROR + traceback in details."""
+	src = _region_source()
+	pho = tessphot('halo', 1, src, str(tmp_path))
+	assert pho.status == STATUS.ERROR and pho.method == 'halo'
+	assert any('NotImplementedError' in e for e in pho._details['errors'])
+	# constructor failure -> error dummy
+	pho = tessphot('aperture', 999, src, str(tmp_path))
+	assert pho.status == STATUS.ERROR and pho.method == 'error'
+
+
+def test_aperture_without_gpu_is_error_not_fallback(tmp_path):
+	import ctypes
+	from photometry_amd import _lib
+	n = ctypes.c_int(0)
+	_lib.load().tp_device_count(ctypes.byref(n))
+	if n.value > 0:
+		pytest.skip("a GPU is visible")
+	s = simulate.make_scene(1, 8, 11, 11, seed=1)
+	simulate.fill_cubes(s)
+	pho = tessphot('aperture', int(s.target_starid[0]), source_from_scene(s, 0), str(tmp_path))
+	assert pho.status == STATUS.ERROR
+	assert any('libtessphot_hip' in e or 'HIP' in e for e in pho._details['errors'])
+
+
+def test_shard_ranges_and_assembly():
+	for n, w in ((10, 2), (10, 3), (100000, 8), (5, 8), (0, 2)):
+		rs = [tpcomm.shard_range(n, w, r) for r in range(w)]
+		assert rs[0][0] == 0 and rs[-1][1] == n
+		assert all(rs[i][1] == rs[i+1][0] for i in range(w-1))
+		assert sum(tpcomm.shard_sizes(n, w)) == n
+	rng = np.random.default_rng(0)
+	full = rng.normal(size=(5, 11, 7))
+	sizes = tpcomm.shard_sizes(11, 3)
+	cap = max(sizes)
+	blocks = []
+	for r in range(3):
+		a, b = tpcomm.shard_range(11, 3, r)
+		blk = np.zeros((5, cap, 7))
+		blk[:, :b-a] = full[:, a:b]
+		blocks.append(blk)
+	np.testing.assert_array_equal(tpcomm.assemble_gathered(blocks, sizes), full)
+
+
+def test_replay_skip_targets():
+	"""photometry.py:244-250 -> taskmanager.py:460-532: the fainter star inside a brighter star's mask is skipped."""
+	starids = [10, 11, 12, 13]
+	tmags = [9.0, 12.0, 8.0, 11.0]
+	skip = [[11], [10], [], []]       # 10 and 11 sit in each other's masks
+	st = tpcomm.replay_skip_targets(starids, tmags, skip, [1, 1, 1, 3])
+	assert list(st) == [1, 5, 1, 3]
+	st = tpcomm.replay_skip_targets(starids, tmags, [[], [10], [], []], [1, 1, 2, 1])
+	assert list(st) == [1, 5, 2, 1] # 11 lies in the mask of the brighter 10 -> 11 is skipped
