@@ -42,6 +42,8 @@ def parse_args():
 	p.add_argument('--cpu-procs', type=int, default=16, help='worker processes of the CPU baseline')
 	p.add_argument('--seed', type=int, default=1)
 	p.add_argument('--no-gather', action='store_true')
+	p.add_argument('--workload', choices=['aperture', 'linpsf'], default='aperture',
+		help="'aperture' = BASELINE configs[2] (the headline); 'linpsf' = configs[3], the LinPSF fit on the same cube size")
 	p.add_argument('--placeholder-masks', action='store_true', help='5x5 box masks instead of the on-device K2P2 (bring-up only)')
 	return p.parse_args()
 
@@ -76,6 +78,82 @@ def _cpu_worker(job, bkg_given=None):
 
 
 _CPU_JOBS = None
+
+
+def main_linpsf(args, ctx, rank, world, dist, torch, device_sync, barrier):
+	"""BASELINE configs[3]: linpsf_photometry PSF-fit path over the same cube size (images cube resident)."""
+	import numpy as np
+	from photometry_amd import simulate, engine, pipeline, psf as hpsf
+	from oracle import psf as opsf
+	Nt, T, H = args.targets, args.cadences, args.stamp
+	W = H
+	scene = simulate.make_scene(Nt, T, H, W, seed=args.seed * 1000 + rank)
+	cubes = engine.synth_fill(ctx, scene, images=True, images_err=False, backgrounds=False)
+	prf = opsf.synthetic_prf(seed=1) # synthetic stand-in for the SPOC PRF file (git-LFS object upstream)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	batch = pipeline.LinPSFBatch(ctx, scene, model, images=cubes['images'])
+	for _ in range(args.warmup):
+		pipeline.linpsf_step(ctx, batch)
+	device_sync(); barrier()
+	ctx.profile(True); ctx.profile_reset()
+	t0 = time.perf_counter()
+	for _ in range(args.steps):
+		pipeline.linpsf_step(ctx, batch)
+	device_sync(); barrier()
+	elapsed = time.perf_counter() - t0
+	ctx.profile(False)
+	if dist is not None:
+		t = torch.tensor([elapsed], dtype=torch.float64)
+		dist.all_reduce(t, op=dist.ReduceOp.MAX)
+		elapsed = float(t[0])
+	prof = ctx.profile_report()
+	if rank == 0:
+		nfit = batch.n_fit_stars
+		# FP64 flops of the fit kernel: per fitted star-cadence ~79 pixels inside the 5 px cut-off x (169 + 13) x 2
+		flops = nfit * T * 79 * 182 * 2.0
+		kernels = {name: {'launches': n, 'avg_ms': ms / n} for name, (n, ms) in prof.items()}
+		fit = kernels['tp_linpsf_fit_kernel']
+		fit['fp64_TFLOPs'] = flops / (fit['avg_ms'] * 1e-3) / 1e12
+		result = {
+			'metric': 'targets/sec (whole node), 10k targets x 1300 cad x 15x15, linpsf_photometry PSF fit',
+			'value': Nt * world * args.steps / elapsed, 'unit': 'targets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+			'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+			'dtype': 'f64', 'data': 'synthetic',
+			'config': {'workload': f'{Nt} targets/GPU x {T} cadences x {H}x{W} stamps, LinPSF fit of {nfit} stars (P1 table blend + P2-P4), '
+				'image cube resident in HBM', 'fitted_stars': int(nfit)},
+			'roofline': {'kernel': 'tp_linpsf_fit_kernel', 'bound': 'fp64-valu', 'achieved': fit['fp64_TFLOPs'], 'peak': 78.6, 'unit': 'TFLOP/s',
+				'frac': fit['fp64_TFLOPs'] / 78.6, 'traffic': None, 'avg_kernel_ms': fit['avg_ms']},
+			'kernels': kernels,
+		}
+		if world == 1 and args.cpu_sample > 0:
+			# CPU baseline: the oracle loop (reference-equivalent, scipy FITPACK integral per pixel) on a few targets
+			from oracle import linpsf as olin
+			ns = min(Nt, 4)
+			tsub = min(T, 100)
+			host = np.empty((ns, H, W, cubes['images'].t_pitch), dtype='float32')
+			ctx._check(ctx.lib.tp_memcpy_d2h(ctx.handle, host.ctypes.data, cubes['images'].ptr, host.nbytes))
+			res = batch.out.to_host()
+			t1 = time.perf_counter()
+			bad = 0
+			for i in range(ns):
+				cat = scene.catalog_of(i)
+				positions = np.empty((tsub, len(cat['starid']), 2))
+				positions[:, :, 0] = cat['row_stamp'][None, :] + scene.jitter[:tsub, 1][:, None]
+				positions[:, :, 1] = cat['column_stamp'][None, :] + scene.jitter[:tsub, 0][:, None]
+				p = opsf.PSF(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'], tuple(scene.stamps[i]))
+				p.integrate_to_image = p.integrate_to_image_scipy # literal reference loop (psf.py:136-146)
+				ref = olin.do_photometry(host[i][:, :, :tsub], p, cat, scene.target_starid[i], positions, tuple(scene.stamps[i]),
+					scene.target_pos_row[i], scene.target_pos_column[i], np.ones((H, W), dtype='int32'))
+				bad += not np.allclose(res['flux'][i][:tsub], ref['flux'], rtol=1e-7, atol=1e-8*np.nanmax(np.abs(ref['flux'])))
+			dt = time.perf_counter() - t1
+			result['cpu_baseline'] = {'value': ns / (dt * T / tsub), 'unit': 'targets/s', 'cores': 1, 'kind': 'port',
+				'sample': f'{ns} targets x first {tsub} cadences, extrapolated linearly to {T} cadences; oracle = literal per-pixel FITPACK loop of the reference'}
+			result['parity_sample'] = {'targets': ns, 'cadences': tsub, 'mismatches': int(bad)}
+		print(json.dumps(result))
+	if dist is not None:
+		dist.barrier()
+		dist.destroy_process_group()
+	ctx.close()
 
 
 def _cpu_worker_indexed(c):
@@ -125,6 +203,8 @@ def main():
 
 	Nt, T, H = args.targets, args.cadences, args.stamp
 	W = H
+	if args.workload == 'linpsf':
+		return main_linpsf(args, ctx, rank, world, dist, torch, device_sync, barrier)
 	# every rank gets its own contiguous shard of the global target list (weak scaling)
 	scene = simulate.make_scene(Nt, T, H, W, seed=args.seed * 1000 + rank)
 	scene.aperture = None

@@ -184,6 +184,7 @@ def linpsf_fit(ctx, images, coef, knots_x, knots_y, star_offsets, target_index, 
 	n = knots_x.shape[0] - 4
 	if out is None:
 		out = LinPSFResult(ctx, images.n_targets, pos_row.shape[0], images.n_cad)
+	assert pos_row.shape[1] >= images.n_cad and pos_col.shape == pos_row.shape
 	desc = images.desc
 	ctx._check(ctx.lib.tp_linpsf_fit(ctx.handle, ctypes.byref(desc), images.ptr, _ptr(subtract), 0 if subtract is None else subtract.shape[1],
 		coef.ptr, knots_x.ptr, knots_y.ptr, n, int(max_stars), star_offsets.ptr, target_index.ptr,

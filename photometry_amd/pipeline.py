@@ -136,3 +136,44 @@ def run_aperture(ctx, scene, cubes='host', masks=None):
 		out['mask'] = masks_from[0].to_host()
 		out['status'] = masks_from[1].to_host()
 	return out
+
+
+class LinPSFBatch(object):
+	"""
+	Device-resident inputs of the LinPSF pipeline (linpsf_photometry.py:79-219) for a batch:
+	image cube, per-target spline tables (P1), fitted-star lists and their per-cadence positions
+	(``catalog_attime``: reference position + jitter, host geometry).
+	"""
+
+	def __init__(self, ctx, scene, prf_model, images=None, subtract=None):
+		from . import psf as hpsf
+		self.ctx, self.scene, self.model = ctx, scene, prf_model
+		self.images = DeviceCube.from_host(ctx, scene.images) if images is None else images
+		self.subtract = subtract
+		sel, star_offsets, target_index = hpsf.select_stars(scene.catalog, scene.cat_offsets, scene.target_starid)
+		self.sel, self.star_offsets_h, self.target_index_h = sel, star_offsets, target_index
+		self.max_stars = int(np.diff(star_offsets).max()) if len(star_offsets) > 1 else 1
+		rs = scene.catalog['row_stamp'][sel].astype('float64')
+		cs = scene.catalog['column_stamp'][sel].astype('float64')
+		T = scene.n_cad
+		pitch = self.images.t_pitch
+		pos_row = np.zeros((len(rs), pitch))
+		pos_col = np.zeros((len(rs), pitch))
+		pos_row[:, :T] = rs[:, None] + scene.jitter[None, :, 1]
+		pos_col[:, :T] = cs[:, None] + scene.jitter[None, :, 0]
+		self.pos_row, self.pos_col = ctx.array(pos_row), ctx.array(pos_col)
+		self.star_offsets, self.target_index = ctx.array(star_offsets), ctx.array(target_index)
+		self.base_coef = ctx.array(prf_model.base_coef)
+		self.weights = ctx.array(prf_model.weights(scene.stamps))
+		self.tx, self.ty = ctx.array(prf_model.tx), ctx.array(prf_model.ty)
+		self.coef = ctx.empty((scene.n_targets, prf_model.base_coef.shape[1]), 'float64')
+		self.out = engine.LinPSFResult(ctx, scene.n_targets, len(rs), T)
+		self.n_fit_stars = len(rs)
+
+
+def linpsf_step(ctx, batch, cutoff_radius=5.0):
+	"""One pass of the LinPSF hot path: P1 table blend, P2-P4 fit + contamination."""
+	engine.linpsf_prf(ctx, batch.base_coef, batch.weights, out=batch.coef)
+	engine.linpsf_fit(ctx, batch.images, batch.coef, batch.tx, batch.ty, batch.star_offsets, batch.target_index,
+		batch.pos_row, batch.pos_col, batch.max_stars, cutoff_radius=cutoff_radius, subtract=batch.subtract, out=batch.out)
+	return batch.out

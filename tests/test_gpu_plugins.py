@@ -76,8 +76,12 @@ def test_stamp_resize_retry(ctx, tmp_path):
 	from photometry_amd import simulate as sim
 	R = C = 61
 	T = 40
-	s = sim.make_scene(1, T, R, C, seed=3, tmag_range=(6.5, 6.6), max_neighbours=0, sigma_psf=2.2)
+	s = sim.make_scene(1, T, R, C, seed=3, tmag_range=(6.5, 6.6), max_neighbours=0, sigma_psf=2.0)
 	sim.fill_cubes(s, nan_fraction=0.0)
+	# a bleed trail: +-15 rows of extra flux in the target's column -> the mask touches the top and bottom
+	# edge of the 19x19 default stamp and fits after one resize by 10 pixels
+	r0, c0 = int(round(s.star_params[0, 0, 0])), int(round(s.star_params[0, 0, 1]))
+	s.images[0, r0-15:r0+16, c0:c0+2, :] += 4000.0 # 2 pixels wide: DBSCAN core pixels need 4 neighbours (k2p2v2.py:79)
 	st = s.stamps[0]
 	frames = {'images': s.images[0], 'images_err': s.images_err[0], 'backgrounds': s.backgrounds[0]}
 	cat = s.catalog_of(0)
@@ -86,7 +90,7 @@ def test_stamp_resize_retry(ctx, tmp_path):
 		targets={'starid': s.target_starid, 'tmag': s.target_tmag, 'row': s.target_pos_row, 'column': s.target_pos_column})
 	with AperturePhotometry(int(s.target_starid[0]), src, str(tmp_path), ctx=ctx) as pho:
 		first = pho.stamp
-		assert (first[1] - first[0], first[3] - first[2]) == (17, 17) # default stamp at Tmag 6.5 (BasePhotometry.py:541-564)
+		assert (first[1] - first[0], first[3] - first[2]) == (19, 19) # default stamp at Tmag 6.5: ceil(17.8) = 18 -> 2*9+1 (BasePhotometry.py:541-564, :646-651)
 		pho.photometry()
 		assert pho.status in (STATUS.OK, STATUS.WARNING)
 		assert pho._details.get('stamp_resizes', 0) >= 1
