@@ -98,7 +98,7 @@ int tp_comm_allgather(tp_ctx* ctx, const void* d_send, void* d_recv, uint64_t nb
 	TP_CHECK_CTX(ctx);
 	if (nbytes_per_rank == 0) return TP_OK;
 	TP_REQUIRE(ctx, d_send && d_recv, "tp_comm_allgather: null buffer");
-	if (ctx->comm_size == 1 || ctx->comm == nullptr) {
+	if (ctx->comm == nullptr) {
 		TP_REQUIRE(ctx, ctx->comm_size == 1, "tp_comm_allgather: communicator not initialised");
 		if (d_recv != d_send)
 			TP_HIP(ctx, hipMemcpyAsync(d_recv, d_send, (size_t)nbytes_per_rank, hipMemcpyDeviceToDevice, ctx->stream));
