@@ -33,6 +33,8 @@
 #define TP_PAR_FOR(i, n) for (int i = 0; i < (n); ++i)
 #define TP_SYNC() do {} while (0)
 #define TP_SERIAL if (true)
+#define TP_ATOMIC_INC(ptr) ((*(ptr))++)
+#define TP_STAMP(id) do {} while (0)
 #else
 #define TP_DEV __device__
 #define TP_HD __host__ __device__
@@ -40,6 +42,9 @@
 #define TP_PAR_FOR(i, n) for (int i = k.lane; i < (n); i += 64)
 #define TP_SYNC() __syncthreads()
 #define TP_SERIAL if (k.lane == 0)
+#define TP_ATOMIC_INC(ptr) atomicAdd((ptr), 1)
+// optional per-phase cycle accounting (diagnostic builds / runs only: t.timing == nullptr in production)
+#define TP_STAMP(id) do { if (t.timing && k.lane == 0) { const long long _now = clock64(); t.timing[id] += (double)(_now - _tlast); _tlast = _now; } } while (0)
 #endif
 
 namespace k2p2 {
@@ -98,6 +103,7 @@ struct Target {
 	double* contamination;
 	double* diag;             // [8]: CUT, MODE, MAD1, bandwidth, max_guess, nflux, margin, nmasks
 	uint8_t* cat_in_mask;     // [ncat] 1 if the catalog star falls in the final mask (skip_targets source)
+	double* timing;           // optional [16] per-phase cycle counters (diagnostics)
 };
 
 // Shared (LDS) work arrays of one target.  Sizes in elements; P = H*W, Pp = pow2 >= P.
@@ -217,17 +223,32 @@ inline TP_DEV double tp_exp(double x) {
 	return (p * tp_pow2(k1)) * tp_pow2(k2);
 }
 
-// Sum of the 64 per-lane partials in lane order (every lane computes the same value).
-inline TP_DEV double sum_red(const Shared& k) {
-	double s = 0.0;
-	for (int l = 0; l < 64; ++l) s += k.red[l];
-	return s;
-}
-inline TP_DEV int sum_ired(const Shared& k) {
-	int s = 0;
-	for (int l = 0; l < 64; ++l) s += k.ired[l];
-	return s;
-}
+// Reductions over the 64 per-lane partials in k.red / k.ired (written by a TP_LANE_LOOP, followed by
+// TP_SYNC).  Fixed binary-tree association: a[l] (op)= a[l+32], then +16, ... so that the host
+// simulation and the device (DPP / permute shuffles, result broadcast from lane 0) agree bit for bit.
+#ifdef TP_HOSTSIM
+#define TP_TREE(T, arr, OP) T a_[64]; for (int l = 0; l < 64; ++l) a_[l] = (arr)[l]; \
+	for (int off = 32; off > 0; off >>= 1) for (int l = 0; l < off; ++l) { const T x_ = a_[l], y_ = a_[l + off]; a_[l] = OP; } return a_[0];
+inline double sum_red(const Shared& k) { TP_TREE(double, k.red, x_ + y_) }
+inline int sum_ired(const Shared& k) { TP_TREE(int, k.ired, x_ + y_) }
+inline int or_ired(const Shared& k) { TP_TREE(int, k.ired, x_ | y_) }
+inline int and_ired(const Shared& k) { TP_TREE(int, k.ired, x_ & y_) }
+inline int max_ired(const Shared& k) { TP_TREE(int, k.ired, (y_ > x_) ? y_ : x_) }
+inline double min_arr(const Shared&, const double* arr) { TP_TREE(double, arr, (y_ < x_) ? y_ : x_) }
+inline double max_arr(const Shared&, const double* arr) { TP_TREE(double, arr, (y_ > x_) ? y_ : x_) }
+#undef TP_TREE
+#else
+#define TP_TREE(T, arr, OP) T x_ = (arr)[k.lane]; \
+	for (int off = 32; off > 0; off >>= 1) { const T y_ = __shfl_down(x_, off, 64); x_ = OP; } return __shfl(x_, 0, 64);
+inline TP_DEV double sum_red(const Shared& k) { TP_TREE(double, k.red, x_ + y_) }
+inline TP_DEV int sum_ired(const Shared& k) { TP_TREE(int, k.ired, x_ + y_) }
+inline TP_DEV int or_ired(const Shared& k) { TP_TREE(int, k.ired, x_ | y_) }
+inline TP_DEV int and_ired(const Shared& k) { TP_TREE(int, k.ired, x_ & y_) }
+inline TP_DEV int max_ired(const Shared& k) { TP_TREE(int, k.ired, (y_ > x_) ? y_ : x_) }
+inline TP_DEV double min_arr(const Shared& k, const double* arr) { TP_TREE(double, arr, (y_ < x_) ? y_ : x_) }
+inline TP_DEV double max_arr(const Shared& k, const double* arr) { TP_TREE(double, arr, (y_ > x_) ? y_ : x_) }
+#undef TP_TREE
+#endif
 
 //--------------------------------------------------------------------------------------------------
 // A2: threshold
@@ -259,20 +280,34 @@ inline TP_DEV double score_at_percentile(const double* sorted, int n, double per
 	return (sorted[i] * w0 + sorted[i + 1] * w1) / sumval;
 }
 
+// Tree sum (same association as sum_red) of per-lane partials produced by f(lane), without touching LDS
+// on the device: the partial stays in a register and goes straight into the shuffle tree.
+template <class F>
+inline TP_DEV double wave_sum_f(const Shared& k, const F& f) {
+#ifdef TP_HOSTSIM
+	double a_[64];
+	for (int l = 0; l < 64; ++l) a_[l] = f(l);
+	for (int off = 32; off > 0; off >>= 1) for (int l = 0; l < off; ++l) a_[l] = a_[l] + a_[l + off];
+	return a_[0];
+#else
+	double x_ = f(k.lane);
+	for (int off = 32; off > 0; off >>= 1) x_ = x_ + __shfl_down(x_, off, 64);
+	return __shfl(x_, 0, 64);
+#endif
+}
+
 // -KDE(x): direct Gaussian sum over the nc values k.srt[0..nc) with bandwidth h
 // (statsmodels kernels.Gaussian: 0.3989422804014327*exp(-z**2/2); density = 1/(h n) * sum)
 inline TP_DEV double neg_kde(Shared& k, int nc, double h, double x) {
-	TP_LANE_LOOP(l) {
+	const double* srt = k.srt;
+	const double tot = wave_sum_f(k, [=](int l) {
 		double s = 0.0;
 		for (int i = l; i < nc; i += 64) {
-			const double z = (k.srt[i] - x) / h;
+			const double z = (srt[i] - x) / h;
 			s += 0.3989422804014327 * tp_exp(-(z * z) / 2.0);
 		}
-		k.red[l] = s;
-	}
-	TP_SYNC();
-	const double tot = sum_red(k);
-	TP_SYNC();
+		return s;
+	});
 	return -1.0 * ((1.0 / (h * (double)nc)) * tot);
 }
 
@@ -508,16 +543,23 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 		const double delta = (b - a) / (double)(M - 1);   // np.linspace retstep
 		const double RANGE = b - a;
 		double* binned = k.grid; double* dens = k.grid + M; double* Yre = k.grid + 2 * M; double* Yim = k.grid + 3 * M;
-		// fast_linbin: bin m accumulates, in data order, (1 - rem) from points with li == m and rem from li == m-1
+		// fast_linbin: bin m accumulates, in data order, (1 - rem) from points with li == m and rem from li == m-1.
+		// (li, rem) of every point once (k.hage / k.tmp), then each lane owns two bins
+		TP_PAR_FOR(i, nc) {
+			const double lxi = (k.srt[i] - a) / delta;
+			int li = (int)lxi;
+			if (!(lxi > -1.0e9 && lxi < 1.0e9)) li = -1; // NaN / absurd: the point is dropped like in the reference (li > 1 fails)
+			k.hage[i] = li;
+			k.tmp[i] = lxi - (double)li;
+		}
+		TP_SYNC();
 		TP_PAR_FOR(m, M) {
 			double g = 0.0;
 			for (int i = 0; i < nc; ++i) {
-				const double lxi = (k.srt[i] - a) / delta;
-				const int li = (int)lxi;
-				const double rem = lxi - (double)li;
+				const int li = k.hage[i];
 				if (li > 1 && li < M) {
-					if (li == m) g = g + 1 - rem;
-					else if (li + 1 == m) g = g + rem;
+					if (li == m) g = g + 1 - k.tmp[i];
+					else if (li + 1 == m) g = g + k.tmp[i];
 				}
 			}
 			binned[m] = g / (delta * (double)nc);
@@ -552,15 +594,25 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 		}
 		TP_SYNC();
 		// support[argmax(density)]: np.argmax returns the first maximum, NaN counts as maximum
-		int am = 0;
-		double best = dens[0];
-		if (!tp_isnan(best)) {
-			for (int m = 1; m < M; ++m) {
-				const double d = dens[m];
-				if (tp_isnan(d)) { am = m; break; }
-				if (d > best) { best = d; am = m; }
-			}
+		// (two grid points per lane, then the tree picks the larger value / the smaller index on ties)
+		TP_LANE_LOOP(l) {
+			const double d0 = dens[l], d1 = dens[l + 64];
+			// key: NaN beats everything (earliest NaN wins), else larger value, ties -> smaller index
+			int idx; double val;
+			if (tp_isnan(d0)) { idx = l; val = tp_inf(); }
+			else if (tp_isnan(d1)) { idx = l + 64; val = tp_inf(); }
+			else if (d1 > d0) { idx = l + 64; val = d1; }
+			else { idx = l; val = d0; }
+			k.red[l] = val; k.ired[l] = idx;
 		}
+		TP_SYNC();
+		const double vmax = max_arr(k, k.red);
+		TP_SYNC();
+		// among the lanes holding the maximum, the smallest grid index (NaN candidates carry +inf and their index)
+		TP_LANE_LOOP(l) { k.ired[l] = (k.red[l] == vmax) ? -k.ired[l] : -(1 << 30); }
+		TP_SYNC();
+		const int am = -max_ired(k);
+		TP_SYNC();
 		// np.linspace(a, b, M)[am] = a + am*step, last point set to b exactly
 		max_guess = (am == M - 1) ? b : (a + (double)am * delta);
 		TP_SYNC();
@@ -627,24 +679,33 @@ inline TP_DEV int label_components(Shared& k, const uint8_t* in, int32_t* out, b
 			k.ired[l] = changed;
 		}
 		TP_SYNC();
-		const int any = sum_ired(k);
+		const int any = or_ired(k);
 		TP_SYNC();
 		if (!any) break;
+		// pointer jumping: every pixel adopts the label of the pixel it points to (labels only decrease and
+		// stay inside the component, so the fixed point -- the component's smallest index -- is unchanged)
+		TP_PAR_FOR(p, P) { const int cur = out[p]; if (cur >= 0) { const int nxt = out[cur]; if (nxt < cur) out[p] = nxt; } }
+		TP_SYNC();
 	}
-	// roots -> consecutive numbers in raster order (serial prefix over P, cheap)
-	TP_SERIAL {
-		int n = 0;
-		for (int p = 0; p < P; ++p) {
-			if (out[p] == p) { n++; k.hpix[p] = n; }
-		}
-		k.scal[0] = n;
+	// roots -> consecutive numbers in raster order: every lane owns a contiguous chunk of pixels, counts its
+	// roots, an exclusive scan over the 64 per-lane counts gives the chunk's first number
+	const int chunk = (P + 63) / 64;
+	TP_LANE_LOOP(l) {
+		int c = 0;
+		for (int p = l * chunk; p < (l + 1) * chunk && p < P; ++p) c += (out[p] == p) ? 1 : 0;
+		k.ired[l] = c;
 	}
 	TP_SYNC();
+	TP_LANE_LOOP(l) {
+		int base = 0;
+		for (int m = 0; m < l; ++m) base += k.ired[m];
+		for (int p = l * chunk; p < (l + 1) * chunk && p < P; ++p) if (out[p] == p) k.hpix[p] = ++base;
+	}
+	TP_SYNC();
+	const int n = sum_ired(k);
 	TP_PAR_FOR(p, P) { const int root = out[p]; k.hage[p] = (root >= 0) ? k.hpix[root] : 0; }
 	TP_SYNC();
 	TP_PAR_FOR(p, P) out[p] = k.hage[p];
-	TP_SYNC();
-	const int n = k.scal[0];
 	TP_SYNC();
 	return n;
 }
@@ -678,8 +739,8 @@ inline TP_DEV int saturated_one(Shared& k) {
 	TP_SYNC();
 	double mask_max = tp_nan();
 	{
-		int any = 0; double m = 0;
-		for (int l = 0; l < 64; ++l) if (k.ired[l]) { if (!any || k.red[l] > m) m = k.red[l]; any = 1; }
+		const int any = or_ired(k);
+		const double m = max_arr(k, k.red);
 		if (any) mask_max = m;
 	}
 	TP_SYNC();
@@ -692,6 +753,9 @@ inline TP_DEV int saturated_one(Shared& k) {
 		if (n == 0) continue;
 		// ratio = |nanmedian(diff(pixels))| / nanmax(pixels)
 		double pmax = tp_nan(); { int any = 0; for (int i = 0; i < n; ++i) if (!tp_isnan(pix[i])) { if (!any || pix[i] > pmax) pmax = pix[i]; any = 1; } }
+		// necessary condition of k2p2v2.py:321 (median(pixels) >= mask_max/2) fails whenever the column maximum
+		// is below mask_max/2 (or everything is NaN): skip the two medians
+		if (!(pmax >= mask_max / 2)) continue;
 		const double medpix = nanmedian_small(pix, n, scr);
 		// diff in place (pix no longer needed afterwards except through medpix/pmax)
 		for (int i = 0; i + 1 < n; ++i) pix[i] = pix[i + 1] - pix[i];
@@ -759,52 +823,75 @@ inline TP_DEV void gaussian_blur(Shared& k, const Params& prm, const double* in,
 	TP_SYNC();
 }
 
-// skimage.segmentation.watershed(-Z, markers, mask=Z) (connectivity 1).  Serial on lane 0.
-// image value of pixel p is -Z[p]; in: k.mark (markers, already multiplied by mask); out: k.wsout.
-inline TP_DEV void watershed(Shared& k) {
+// skimage.segmentation.watershed(-Z, markers, mask=Z) (connectivity 1, no compactness / lines):
+// priority flood, a neighbour is labelled when it is pushed, pops in (value, age) order.
+// in: k.mark (markers); out: k.wsout.  The image values -Z[p] of a cluster are distinct floats, so the
+// pop order is the order of the values: every in-mask pixel gets its RANK (brightest = 0; computed in
+// parallel, exact ties broken by pixel index instead of push age), and the heap becomes a bit set of
+// ranks with a two-level find-first-set -- O(1) per push / pop instead of LDS heap sifts.
+inline TP_DEV void watershed(Shared& k, int nmark) {
 	const int P = k.P, H = k.H, W = k.W;
+	// How many marker labels survive `markers *= mask`?  With a single one the flood is simply "every in-mask
+	// pixel 4-connected to the marker gets its label" -- a parallel connected-component labelling, no queue.
+	TP_PAR_FOR(m, nmark + 1) k.hage[m] = 0;
+	TP_SYNC();
+	TP_PAR_FOR(p, P) if (k.Z[p] != 0.0 && k.mark[p] != 0) k.hage[k.mark[p]] = 1; // benign same-value stores
+	TP_SYNC();
+	TP_LANE_LOOP(l) { int c = 0, v = 0; for (int m = 1 + l; m <= nmark; m += 64) if (k.hage[m]) { c++; v = m; } k.ired[l] = c; k.red[l] = (double)v; }
+	TP_SYNC();
+	const int nm_in = sum_ired(k);
+	const int the_label = (int)max_arr(k, k.red);
+	TP_SYNC();
+	if (nm_in <= 1) {
+		TP_PAR_FOR(p, P) k.msk[p] = (k.Z[p] != 0.0) ? 1 : 0;
+		TP_SYNC();
+		const int ncomp = label_components(k, k.msk, k.wsout, false);
+		TP_PAR_FOR(m, ncomp + 1) k.hage[m] = 0;
+		TP_SYNC();
+		TP_PAR_FOR(p, P) if (k.msk[p] && k.mark[p] != 0) k.hage[k.wsout[p]] = 1;
+		TP_SYNC();
+		TP_PAR_FOR(p, P) { const int c = k.wsout[p]; k.wsout[p] = (nm_in == 1 && c > 0 && k.hage[c]) ? the_label : 0; }
+		TP_SYNC();
+		return;
+	}
+	int32_t* rank = k.hpix;          // [P] rank of pixel (only where Z != 0)
+	int32_t* ord = (int32_t*)k.hval; // [P] pixel of rank r (hval is free here; 2 int32 per double slot)
+	uint32_t* words = (uint32_t*)k.hage; // [ceil(P/32)] bit set of pushed ranks
 	TP_PAR_FOR(p, P) k.wsout[p] = (k.Z[p] != 0.0) ? k.mark[p] : 0;
+	TP_PAR_FOR(p, P) {
+		int r = -1;
+		const double zp = k.Z[p];
+		if (zp != 0.0) {
+			r = 0;
+			for (int q = 0; q < P; ++q) {
+				const double zq = k.Z[q];
+				if (zq == 0.0) continue;
+				r += (zq > zp || (zq == zp && q < p)) ? 1 : 0;
+			}
+		}
+		rank[p] = r;
+	}
+	TP_SYNC();
+	TP_PAR_FOR(p, P) if (rank[p] >= 0) ord[rank[p]] = p;
+	const int nwords = (P + 31) / 32;
+	TP_PAR_FOR(w, nwords) words[w] = 0u;
 	TP_SYNC();
 	TP_SERIAL {
-		int hn = 0;
-		int age = 1;
-		// binary min-heap on (value, age); entries in hval/hage/hpix
-		auto less = [&](int a, int b) -> bool {
-			if (k.hval[a] != k.hval[b]) return k.hval[a] < k.hval[b];
-			return k.hage[a] < k.hage[b];
-		};
-		auto push = [&](double v, int ag, int px) {
-			int i = hn++;
-			k.hval[i] = v; k.hage[i] = ag; k.hpix[i] = px;
-			while (i > 0) {
-				const int par = (i - 1) >> 1;
-				if (!less(i, par)) break;
-				double tv = k.hval[i]; k.hval[i] = k.hval[par]; k.hval[par] = tv;
-				int ta = k.hage[i]; k.hage[i] = k.hage[par]; k.hage[par] = ta;
-				int tp = k.hpix[i]; k.hpix[i] = k.hpix[par]; k.hpix[par] = tp;
-				i = par;
-			}
-		};
-		for (int p = 0; p < P; ++p) if (k.wsout[p] != 0) push(-k.Z[p], 0, p);
-		while (hn > 0) {
-			const int px = k.hpix[0];
-			// pop
-			hn--;
-			if (hn > 0) {
-				k.hval[0] = k.hval[hn]; k.hage[0] = k.hage[hn]; k.hpix[0] = k.hpix[hn];
-				int i = 0;
-				while (true) {
-					const int lft = 2 * i + 1, rgt = lft + 1;
-					int sm = i;
-					if (lft < hn && less(lft, sm)) sm = lft;
-					if (rgt < hn && less(rgt, sm)) sm = rgt;
-					if (sm == i) break;
-					double tv = k.hval[i]; k.hval[i] = k.hval[sm]; k.hval[sm] = tv;
-					int ta = k.hage[i]; k.hage[i] = k.hage[sm]; k.hage[sm] = ta;
-					int tp = k.hpix[i]; k.hpix[i] = k.hpix[sm]; k.hpix[sm] = tp;
-					i = sm;
-				}
-			}
+		uint32_t sum0 = 0u, sum1 = 0u; // summary: bit w set <=> words[w] != 0   (nwords <= 64)
+		for (int p = 0; p < P; ++p) if (k.wsout[p] != 0) {
+			const int r = rank[p], w = r >> 5;
+			words[w] |= (1u << (r & 31));
+			if (w < 32) sum0 |= (1u << w); else sum1 |= (1u << (w - 32));
+		}
+		while (sum0 | sum1) {
+			const int w = sum0 ? __builtin_ctz(sum0) : (32 + __builtin_ctz(sum1));
+			uint32_t bits = words[w];
+			const int b = __builtin_ctz(bits);
+			bits &= bits - 1u;
+			words[w] = bits;
+			if (bits == 0u) { if (w < 32) sum0 &= ~(1u << w); else sum1 &= ~(1u << (w - 32)); }
+			const int px = ord[w * 32 + b];
+			const int lbl = k.wsout[px];
 			const int r = px / W, c = px - r * W;
 			const int nbr[4] = {r - 1, r, r, r + 1};
 			const int nbc[4] = {c, c - 1, c + 1, c};
@@ -814,9 +901,10 @@ inline TP_DEV void watershed(Shared& k) {
 				const int nb = rr * W + cc;
 				if (k.Z[nb] == 0.0) continue;      // not in mask
 				if (k.wsout[nb] != 0) continue;    // already labelled
-				age += 1;
-				k.wsout[nb] = k.wsout[px];
-				push(-k.Z[nb], age, nb);
+				k.wsout[nb] = lbl;
+				const int rn = rank[nb], wn = rn >> 5;
+				words[wn] |= (1u << (rn & 31));
+				if (wn < 32) sum0 |= (1u << wn); else sum1 |= (1u << (wn - 32));
 			}
 		}
 	}
@@ -839,6 +927,9 @@ inline TP_DEV float mags_total_f32(const float* tmag, const uint8_t* sel, int n)
 
 inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 	const int P = k.P, H = k.H, W = k.W;
+#ifndef TP_HOSTSIM
+	long long _tlast = clock64();
+#endif
 	TP_PAR_FOR(p, P) { k.S[p] = t.S[p]; k.res[p] = 0; }
 	TP_SYNC();
 	int flags = 0;
@@ -851,6 +942,7 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 	double CUT = tp_nan();
 	if (t.cut_override) { CUT = *t.cut_override; if (t.diag) { TP_SERIAL { t.diag[0] = CUT; } } }
 	else err = threshold(k, prm, t, &CUT);
+	TP_STAMP(1);
 
 	// target pixel (photometry.py:107): Python round() = round-half-even; negative indices wrap
 	int tr = (int)rint(t.tpos_row - (double)t.stamp_row0);
@@ -875,8 +967,7 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 		}
 		TP_SYNC();
 		const int nidx = sum_ired(k);
-		double margin = tp_inf();
-		for (int l = 0; l < 64; ++l) if (k.red[l] < margin) margin = k.red[l];
+		const double margin = min_arr(k, k.red);
 		TP_SYNC();
 		if (t.diag) { TP_SERIAL { t.diag[6] = margin; } }
 		if (nidx == 0) {
@@ -894,6 +985,7 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 			}
 			TP_SYNC();
 			const int nclusters = label_components(k, k.core, k.mark, true);
+			TP_STAMP(2);
 			// lab: -2 outside idx, -1 noise, cluster id (0-based) for core; border = min neighbouring cluster
 			TP_PAR_FOR(p, P) {
 				int v = -2;
@@ -927,6 +1019,7 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 				TP_PAR_FOR(p, P) k.msk[p] = (k.lab[p] == lab) ? 1 : 0;
 				TP_SYNC();
 				const int nsat = saturated_one(k);
+				TP_STAMP(3);
 				// Z = flux on the core pixels of this cluster
 				TP_PAR_FOR(p, P) k.Z[p] = (k.lab2[p] == lab) ? k.S[p] : 0.0;
 				TP_SYNC();
@@ -938,8 +1031,7 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 					k.red[l] = mn; k.hval[l] = mx;
 				}
 				TP_SYNC();
-				double dmin = tp_inf(), dmax = -tp_inf();
-				for (int l = 0; l < 64; ++l) { if (k.red[l] < dmin) dmin = k.red[l]; if (k.hval[l] > dmax) dmax = k.hval[l]; }
+				const double dmin = min_arr(k, k.red), dmax = max_arr(k, k.hval);
 				TP_SYNC();
 				double pk_thr = dmin;
 				{ const double rel = prm.ws_thres * dmax; if (rel > pk_thr) pk_thr = rel; } // max(min, rel*max)
@@ -961,8 +1053,7 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 					k.ired[l] = allpk;
 				}
 				TP_SYNC();
-				int trivial = 1;
-				for (int l = 0; l < 64; ++l) if (!k.ired[l]) trivial = 0;
+				const int trivial = and_ired(k);
 				TP_SYNC();
 				TP_LANE_LOOP(l) {
 					int c = 0;
@@ -975,28 +1066,40 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 				TP_SYNC();
 				const int npeaks = sum_ired(k);
 				TP_SYNC();
+				TP_STAMP(4);
 				// peaks matched to catalog stars (k2p2v2.py:144-153); candidates stay in lmax, selection in sat? no:
 				// selection goes to k.core-independent temp: reuse wsout as "selected" flags
 				TP_PAR_FOR(p, P) k.wsout[p] = 0;
 				TP_SYNC();
 				if (t.ncat > 0 && npeaks == 0) { err = ERR_NO_PEAKS; break; }
+				// compact list of the peak pixels (order irrelevant: the selection below is a total order)
+				TP_SERIAL { k.scal[3] = 0; }
+				TP_SYNC();
+				TP_PAR_FOR(p, P) if (k.lmax[p]) { const int slot = TP_ATOMIC_INC(&k.scal[3]); k.hpix[slot] = p; }
+				TP_SYNC();
 				TP_PAR_FOR(s, t.ncat) {
 					const double c0 = (double)t.cat_col[s], c1 = (double)t.cat_row[s];
 					int bi = -1; double bd = 0.0, bint = 0.0;
-					for (int p = 0; p < P; ++p) {
-						if (!k.lmax[p]) continue;
+					for (int e = 0; e < npeaks; ++e) {
+						const int p = k.hpix[e];
 						const int r = p / W, c = p - r * W;
 						const double dx = (double)c - c0, dy = (double)r - c1;
 						const double d = sqrt(dx * dx + dy * dy);
-						// np.argmin over peaks sorted by decreasing intensity (stable): first minimum
+						// np.argmin over the peaks sorted by decreasing intensity (stable: raster order among equal
+						// intensities): first minimum of d; np.argmin treats NaN as the minimum
 						const double inten = k.dist[p];
 						bool better;
 						if (bi < 0) better = true;
-						else if (tp_isnan(bd)) better = false;     // np.argmin returns the first NaN
-						else if (tp_isnan(d)) better = true;       // ... so a NaN distance earlier in the list would win
-						else if (d < bd) better = true;
-						else if (d == bd && inten > bint) better = true;
-						else better = false;
+						else {
+							const bool dn = tp_isnan(d), bn = tp_isnan(bd);
+							const bool earlier = (inten > bint) || (inten == bint && p < bi); // position in the sorted peak list
+							if (dn && bn) better = earlier;
+							else if (bn) better = false;
+							else if (dn) better = true;
+							else if (d < bd) better = true;
+							else if (d == bd) better = earlier;
+							else better = false;
+						}
 						if (better) { bi = p; bd = d; bint = inten; }
 					}
 					if (bi >= 0) {
@@ -1007,6 +1110,7 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 				TP_SYNC();
 				TP_PAR_FOR(p, P) k.lmax[p] = k.wsout[p] ? 1 : 0; // local_maxi
 				TP_SYNC();
+				TP_STAMP(5);
 				// de-duplicate maxima inside saturated patches (k2p2v2.py:193-212)
 				if (nsat > 0) {
 					const int ncomp = label_components(k, k.sat, k.mark, false);
@@ -1037,24 +1141,23 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 				}
 				// markers = ndimage.label(local_maxi) (4-connectivity)
 				const int nmark = label_components(k, k.lmax, k.mark, false);
+				TP_STAMP(6);
 				if (nmark == 0) {
 					// "No maxima were found": the cluster is rejected (k2p2v2.py:218-223)
 					TP_PAR_FOR(p, P) if (k.lab2[p] == lab) k.lab2[p] = -1;
 					TP_SYNC();
 				} else {
-					watershed(k); // k.mark -> k.wsout
+					watershed(k, nmark); // k.mark -> k.wsout
+					TP_STAMP(7);
 					// no_labels = number of distinct values in labels_ws, zero included (k2p2v2.py:230)
-					TP_SERIAL {
-						// distinct values among wsout: marker ids are 1..nmark (some may have vanished)
-						int distinct = 0; bool has0 = false;
-						for (int m = 1; m <= nmark; ++m) {
-							bool f = false;
-							for (int p = 0; p < P && !f; ++p) if (k.wsout[p] == m) f = true;
-							if (f) distinct++;
-						}
-						for (int p = 0; p < P && !has0; ++p) if (k.wsout[p] == 0) has0 = true;
-						k.scal[1] = distinct + (has0 ? 1 : 0);
-					}
+					TP_PAR_FOR(m, nmark + 1) k.hage[m] = 0;
+					TP_SYNC();
+					TP_PAR_FOR(p, P) k.hage[k.wsout[p]] = 1; // benign same-value stores
+					TP_SYNC();
+					TP_LANE_LOOP(l) { int c = 0; for (int m = l; m <= nmark; m += 64) c += k.hage[m]; k.ired[l] = c; }
+					TP_SYNC();
+					const int ndistinct = sum_ired(k);
+					TP_SERIAL { k.scal[1] = ndistinct; }
 					TP_SYNC();
 					const int no_labels = k.scal[1];
 					TP_SYNC();
@@ -1069,6 +1172,7 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 					}
 					TP_SYNC();
 					if (no_labels - 2 > 0) max_label += (no_labels - 2);
+					TP_STAMP(8);
 				}
 			}
 
@@ -1079,6 +1183,7 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 					TP_SYNC();
 					const int npx = sum_ired(k);
 					TP_SYNC();
+					TP_STAMP(9);
 					if (npx < prm.min_no_pixels_in_mask) continue;
 					nmasks_total++;
 					have_masks = true;
@@ -1095,6 +1200,7 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 					TP_SYNC();
 					TP_PAR_FOR(p, P) if (k.lmax[p]) k.msk[p] = 1;
 					TP_SYNC();
+					TP_STAMP(10);
 					// extend overflow columns (k2p2v2.py:579-623)
 					if (prm.extend_overflow) {
 						const int nsat = saturated_one(k);
@@ -1122,6 +1228,7 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 							TP_SYNC();
 						}
 					}
+					TP_STAMP(11);
 					// does this mask contain the target pixel?  (photometry.py:107)
 					if (!target_inside) { err = ERR_TARGET_OUTSIDE; break; }
 					if (k.msk[tr * W + tc]) {
@@ -1167,7 +1274,7 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 			k.ired[l] = e;
 		}
 		TP_SYNC();
-		for (int l = 0; l < 64; ++l) flags |= k.ired[l];
+		flags |= or_ired(k);
 		TP_SYNC();
 
 		// ---------------- A7: contamination (photometry.py:220-238) ----------------
@@ -1210,6 +1317,7 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 	} else if (flags & FLAG_MIN_APERTURE) status = 3; // STATUS.WARNING
 	flags |= (err << ERR_SHIFT);
 
+	TP_STAMP(12);
 	const bool keep_mask = (status != 2) || (err == ERR_NO_TARGETS_IN_MASK); // photometry.py:204 ran before :227
 	TP_PAR_FOR(p, P) t.mask[p] = keep_mask ? k.res[p] : 0;
 	TP_SERIAL {
