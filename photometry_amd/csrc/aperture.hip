@@ -3,7 +3,8 @@
 // Replaces the extraction loop of AperturePhotometry.do_photometry
 // (photometry/AperturePhotometry/photometry.py:172-201).
 //
-// Mapping (gfx950): one workgroup per target, one THREAD per group of 4 consecutive cadences.
+// Mapping (gfx950): workgroups of 256 threads, one THREAD per group of 2 consecutive cadences of a target
+// (grid.x = cadence blocks of the target, so consecutive workgroups touch the same DRAM pages).
 // The cube is time-fastest (BasePhotometry.py:732), so for a given mask pixel the 64 lanes of a
 // wavefront read 64 x 16 B = 1 KiB of consecutive cadences: fully coalesced 128-bit loads, and
 // only the rows of pixels that are IN the mask are ever touched.  Every thread owns its cadences'
@@ -35,6 +36,12 @@ template <> struct Vec<4> {
 	static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
 		float4 t = *reinterpret_cast<const float4*>(p);
 		v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+	}
+};
+template <> struct Vec<2> {
+	static __device__ __forceinline__ void load(const float* p, float (&v)[2]) {
+		float2 t = *reinterpret_cast<const float2*>(p);
+		v[0] = t.x; v[1] = t.y;
 	}
 };
 template <> struct Vec<1> {
@@ -88,7 +95,7 @@ struct Args {
 	const float* subtract; int64_t subtract_pitch;
 	const uint8_t* mask; const int32_t* stamps; const int32_t* status;
 	double* flux; double* flux_err; double* flux_bkg; double* ccol; double* crow;
-	int64_t out_pitch; int n_cad; int height; int width; int64_t t_pitch;
+	int64_t out_pitch; int n_cad; int height; int width; int64_t t_pitch; int n_targets;
 };
 
 template <int VEC>
@@ -148,11 +155,12 @@ __device__ __forceinline__ int compact_mask(const uint8_t* m, int P, int& p_next
 // Small kernel: 0 <= M <= 128 mask pixels (a single pairwise leaf)
 //--------------------------------------------------------------------------------------------------
 template <int VEC>
-__global__ __launch_bounds__(512) void tp_aperture_kernel(Args a)
+__global__ __launch_bounds__(256) void tp_aperture_kernel(Args a)
 {
 	__shared__ int s_list[kMaxList];
 	__shared__ int s_M;
-	const int target = blockIdx.x;
+	const int target = blockIdx.y + blockIdx.z * 65535;
+	if (target >= a.n_targets) return;
 	if (a.status && a.status[target] == TP_STATUS_ERROR) return;
 	const int P = a.height * a.width;
 	const int tid = threadIdx.x;
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(512) void tp_aperture_kernel(Args a)
 	const int nq = (a.n_cad + VEC - 1) / VEC;
 	const int nblk = M - (M & 7);
 
-	for (int q = tid; q < nq; q += blockDim.x) {
+	for (int q = blockIdx.x * blockDim.x + tid; q < nq; q += gridDim.x * blockDim.x) {
 		const int k0 = q * VEC;
 		CadState<VEC> st;
 		st.init();
@@ -450,27 +458,36 @@ extern "C" int tp_aperture_extract(tp_ctx* ctx, const tp_cube_desc* desc,
 	a.flux = d_flux; a.flux_err = d_flux_err; a.flux_bkg = d_flux_background;
 	a.ccol = d_centroid_col; a.crow = d_centroid_row;
 	a.out_pitch = out_pitch; a.n_cad = desc->n_cad; a.height = desc->height; a.width = desc->width;
-	a.t_pitch = desc->t_pitch;
+	a.t_pitch = desc->t_pitch; a.n_targets = desc->n_targets;
 
 	bool vec4 = tp_vec4_ok(d_images, desc->t_pitch) && tp_vec4_ok(d_images_err, desc->t_pitch);
 	if (bkg_mode == 0) vec4 = vec4 && tp_vec4_ok(d_backgrounds, desc->t_pitch);
 	else vec4 = vec4 && tp_vec4_ok(d_backgrounds, bkg_series_pitch);
 	TP_REQUIRE(ctx, d_subtract == nullptr || subtract_pitch >= desc->n_cad, "tp_aperture_extract: bad subtract pitch");
 	if (d_subtract) vec4 = vec4 && tp_vec4_ok(d_subtract, subtract_pitch);
-	const int vec = vec4 ? 4 : 1;
-	const int nq = (desc->n_cad + vec - 1) / vec;
-	int threads = ((nq + 63) / 64) * 64;
-	if (threads > 512) threads = 512;
-	dim3 grid((unsigned)desc->n_targets), block((unsigned)threads);
-	if (vec4) {
-		TP_LAUNCH(ctx, TPK_APERTURE, tp_aperture_kernel<4>, grid, block, 0, a);
+	// Small masks (the common case): 2 cadences per thread (64-bit loads, 512 B per wavefront instruction) keep the
+	// kernel near 100 VGPRs so that several 256-thread workgroups share a CU and overlap their mask-list prologue,
+	// loads and stores; 4 cadences per thread needed 256 VGPRs -> one workgroup per CU.
+	{
+		const int vec = vec4 ? 2 : 1;
+		const int nq = (desc->n_cad + vec - 1) / vec;
+		const int threads = 256;
+		const unsigned gy = (unsigned)((desc->n_targets < 65535) ? desc->n_targets : 65535);
+		const unsigned gz = (unsigned)((desc->n_targets + 65534) / 65535);
+		dim3 grid((unsigned)((nq + threads - 1) / threads), gy, gz), block((unsigned)threads);
+		if (vec4) TP_LAUNCH(ctx, TPK_APERTURE, tp_aperture_kernel<2>, grid, block, 0, a);
+		else TP_LAUNCH(ctx, TPK_APERTURE, tp_aperture_kernel<1>, grid, block, 0, a);
 		TP_LAUNCH_CHECK(ctx, "tp_aperture_kernel");
-		TP_LAUNCH(ctx, TPK_APERTURE_BIG, tp_aperture_big_kernel<4>, grid, block, 0, a);
-		TP_LAUNCH_CHECK(ctx, "tp_aperture_big_kernel");
-	} else {
-		TP_LAUNCH(ctx, TPK_APERTURE, tp_aperture_kernel<1>, grid, block, 0, a);
-		TP_LAUNCH_CHECK(ctx, "tp_aperture_kernel");
-		TP_LAUNCH(ctx, TPK_APERTURE_BIG, tp_aperture_big_kernel<1>, grid, block, 0, a);
+	}
+	// Masks above 128 pixels (rare): the recursive pairwise tree, one workgroup per target
+	{
+		const int vec = vec4 ? 4 : 1;
+		const int nq = (desc->n_cad + vec - 1) / vec;
+		int threads = ((nq + 63) / 64) * 64;
+		if (threads > 512) threads = 512;
+		dim3 grid((unsigned)desc->n_targets), block((unsigned)threads);
+		if (vec4) TP_LAUNCH(ctx, TPK_APERTURE_BIG, tp_aperture_big_kernel<4>, grid, block, 0, a);
+		else TP_LAUNCH(ctx, TPK_APERTURE_BIG, tp_aperture_big_kernel<1>, grid, block, 0, a);
 		TP_LAUNCH_CHECK(ctx, "tp_aperture_big_kernel");
 	}
 	return TP_OK;
