@@ -44,7 +44,8 @@ def parse_args():
 	p.add_argument('--no-gather', action='store_true')
 	p.add_argument('--workload', choices=['aperture', 'linpsf'], default='aperture',
 		help="'aperture' = BASELINE configs[2] (the headline); 'linpsf' = configs[3], the LinPSF fit on the same cube size")
-	p.add_argument('--placeholder-masks', action='store_true', help='5x5 box masks instead of the on-device K2P2 (bring-up only)')
+	p.add_argument('--unfused', action='store_true', help='time the three stand-alone kernels (A1, K2P2, A6) back to back '
+		'instead of the fused per-target kernel')
 	return p.parse_args()
 
 
@@ -211,38 +212,50 @@ def main():
 	if world > 1 and not args.no_gather and rank == 0:
 		gather_buf = ctx.empty((world, lc_bytes // 8), 'float64')
 
-	masks_from = None
-	if args.placeholder_masks:
-		m = np.zeros((Nt, H, W), dtype='uint8')
-		rr = np.rint(scene.star_params[:, 0, 0]).astype(int)
-		cc = np.rint(scene.star_params[:, 0, 1]).astype(int)
-		for d in range(-2, 3):
-			for e in range(-2, 3):
-				m[np.arange(Nt), np.clip(rr + d, 0, H-1), np.clip(cc + e, 0, W-1)] = 1
-		masks_from = (ctx.array(m), ctx.array(np.ones(Nt, dtype='int32')))
-		work.mask, work.status = masks_from
+	def do_step():
+		pipeline.aperture_step(ctx, batch, work, fused=not args.unfused)
+
+	def profiling(on):
+		ctx.profile(on)
+		if on:
+			ctx.profile_reset()
 
 	for _ in range(args.warmup):
-		pipeline.aperture_step(ctx, batch, work, masks_from=masks_from)
+		do_step()
 	device_sync()
 	barrier()
-	ctx.profile(True)
-	ctx.profile_reset()
+	profiling(True)
 	t0 = time.perf_counter()
 	for _ in range(args.steps):
-		pipeline.aperture_step(ctx, batch, work, masks_from=masks_from)
+		do_step()
 	if world > 1 and not args.no_gather:
 		tpcomm.gather(ctx, work.lc.block, gather_buf, root=0)
 	device_sync()
 	barrier()
 	elapsed = time.perf_counter() - t0
-	ctx.profile(False)
+	profiling(False)
 	if dist is not None:
 		t = torch.tensor([elapsed], dtype=torch.float64)
 		dist.all_reduce(t, op=dist.ReduceOp.MAX)
 		elapsed = float(t[0])
 
 	prof = ctx.profile_report()
+
+	# ---- the same arithmetic as three stand-alone kernels back to back (A1, K2P2, A6): per-stage durations when a
+	# stage owns the GPU.  Not part of `value`.
+	prof_serial = None
+	if not args.unfused and rank == 0:
+		pipeline.aperture_step(ctx, batch, work, fused=False)
+		device_sync()
+		ctx.profile(True)
+		ctx.profile_reset()
+		ts0 = time.perf_counter()
+		for _ in range(2):
+			pipeline.aperture_step(ctx, batch, work, fused=False)
+		device_sync()
+		serial_ms = (time.perf_counter() - ts0) / 2 * 1e3
+		ctx.profile(False)
+		prof_serial = ctx.profile_report()
 
 	# ---- the stamp-level background stage (B*, B2, B3), timed the same way right after the headline region:
 	# raw cube -> per-cadence sigma-clipped background series -> time smoothing -> subtraction (in place)
@@ -271,20 +284,24 @@ def main():
 		alg = {
 			'tp_sumimage_kernel': P*T*4 + T*4 + P*8,             # A1
 			'tp_aperture_kernel': 3*P*T*4 + P + 5*T*8,           # A6 (three cubes)
+			# A1 + A6 in one kernel: the same reads and writes minus nothing (the sum image is still written, the mask too)
+			'tp_aperture_fused_kernel': (P*T*4 + T*4 + P*8) + (3*P*T*4 + P + 5*T*8),
 			'tp_bkg_stamp_kernel': P*T*4 + T*4,                  # B*
 			'tp_bkg_smooth_kernel': 2*T*4,                       # B2
 			'tp_bkg_subtract_kernel': 2*P*T*4 + T*4,             # B3 (materialised)
 		}
-		prof_all = dict(prof)
-		prof_all.update(prof_bkg)
-		kernels = {}
-		for name, (n, ms) in prof_all.items():
-			avg = ms / n
-			k = {'launches': n, 'avg_ms': avg}
-			if name in alg:
-				k['algorithmic_bytes_per_launch'] = alg[name] * Nt
-				k['achieved_GBps'] = alg[name] * Nt / (avg * 1e-3) / 1e9
-			kernels[name] = k
+		def kernel_table(report, targets_per_launch):
+			out = {}
+			for name, (n, ms) in report.items():
+				avg = ms / n
+				k = {'launches': n, 'avg_ms': avg}
+				if name in alg:
+					k['algorithmic_bytes_per_launch'] = alg[name] * targets_per_launch
+					k['achieved_GBps'] = alg[name] * targets_per_launch / (avg * 1e-3) / 1e9
+				out[name] = k
+			return out
+		kernels = kernel_table(prof, Nt)
+		kernels.update(kernel_table(prof_bkg, Nt))
 		# the dominant kernel of the TIMED step (the background-stage kernels are reported in `kernels` only)
 		dom = max((k for k in prof if True), key=lambda k: kernels[k]['avg_ms'])
 		if dom not in alg: # a latency-bound kernel (K2P2) dominates: report the largest HBM-bound one and say so
@@ -297,11 +314,25 @@ def main():
 			# HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/run_profile.sh),
 			# FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE
 			traffic = json.load(open(tfile)).get(dom_hbm)
+		# bytes this implementation cannot avoid: A1 needs every pixel of the images cube, A6 only the rows of the
+		# pixels that ended up in a mask (three cubes), plus the outputs -- the SURVEY 8d figure charges A6 with all rows
+		n_mask = float(work.mask.to_host().astype('int64').sum())
+		necessary = {
+			'tp_sumimage_kernel': Nt * (P*T*4 + T*4 + P*8),
+			'tp_aperture_kernel': 3 * n_mask * T * 4 + Nt * (P + 5*T*8),
+		}
+		necessary['tp_aperture_fused_kernel'] = necessary['tp_sumimage_kernel'] + necessary['tp_aperture_kernel']
 		roofline = {
 			'kernel': dom_hbm, 'bound': 'hbm', 'achieved': kernels[dom_hbm]['achieved_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
 			'frac': kernels[dom_hbm]['achieved_GBps'] / HBM_PEAK_GBS, 'traffic': traffic,
 			'avg_kernel_ms': kernels[dom_hbm]['avg_ms'], 'longest_kernel_of_step': dom,
+			'targets_per_launch': Nt,
 		}
+		if dom_hbm in necessary:
+			nb = necessary[dom_hbm] / (kernels[dom_hbm]['avg_ms'] * 1e-3) / 1e9
+			roofline['necessary'] = {'what': 'bytes per launch the kernel cannot avoid (A1: whole images cube; A6: only the rows of the '
+				'in-mask pixels of the three cubes; outputs) -- `achieved` uses the SURVEY 8d figure, which charges A6 with every row',
+				'bytes_per_launch': necessary[dom_hbm], 'achieved': nb, 'frac': nb / HBM_PEAK_GBS, 'mean_mask_pixels': n_mask / Nt}
 		result = {
 			'metric': 'targets/sec (whole node), 10k targets x 1300 cad x 15x15, aperture + background',
 			'value': value, 'unit': 'targets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -318,8 +349,12 @@ def main():
 				'targets_per_s_including_it': Nt * world / (elapsed / args.steps + bkg_stage_ms * 1e-3)},
 		}
 
+		if prof_serial is not None:
+			result['three_kernel_path'] = kernel_table(prof_serial, Nt)
+			result['three_kernel_path']['ms_per_step'] = serial_ms
+
 	# ---- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample of the same cubes -----
-	if rank == 0 and world == 1 and args.cpu_sample > 0 and not args.placeholder_masks:
+	if rank == 0 and world == 1 and args.cpu_sample > 0:
 		cores_avail = len(os.sched_getaffinity(0))
 		nproc = max(1, min(cores_avail, args.cpu_procs))
 		ns = min(Nt, max(args.cpu_sample, nproc * 24) // nproc * nproc)

@@ -68,6 +68,9 @@ typedef struct tp_cube_desc {
 int tp_version(void);
 int tp_device_count(int* n);
 int tp_ctx_create(int device, tp_ctx** out);
+/* An additional context (= one more HIP stream) on the same device; high_priority != 0 asks for the
+ * device's greatest stream priority (used for the latency-bound K2P2 stage of the chunked pipeline). */
+int tp_ctx_create_stream(int device, int high_priority, tp_ctx** out);
 int tp_ctx_destroy(tp_ctx* ctx);
 const char* tp_last_error(tp_ctx* ctx);      /* ctx may be NULL: last tp_ctx_create failure */
 int tp_device_info(tp_ctx* ctx, char* name, int name_len, int32_t* n_cu, uint64_t* hbm_bytes);
@@ -83,6 +86,14 @@ int tp_memcpy_d2d(tp_ctx* ctx, void* d_dst, const void* d_src, uint64_t nbytes);
 int tp_upload_cube(tp_ctx* ctx, float* d_dst, int64_t dst_pitch, const float* h_src, int64_t src_pitch,
 	int64_t n_rows, int64_t n_cad);
 int tp_sync(tp_ctx* ctx);
+
+/* Cross-stream ordering: several contexts on one device each own a HIP stream; an event recorded on one
+ * context's stream can be waited for by another's (hipStreamWaitEvent), so independent stages of the
+ * pipeline (memory-bound A1 / A6, latency-bound K2P2) of different target chunks overlap on the GPU. */
+int tp_event_create(tp_ctx* ctx, void** event);
+int tp_event_destroy(tp_ctx* ctx, void* event);
+int tp_event_record(tp_ctx* ctx, void* event);           /* on ctx's stream */
+int tp_stream_wait_event(tp_ctx* ctx, void* event);      /* ctx's stream waits for the event */
 
 /* HIP-event stopwatch on the ctx stream; slot in [0, 16). */
 int tp_timer_start(tp_ctx* ctx, int slot);
@@ -172,6 +183,24 @@ int tp_aperture_extract(tp_ctx* ctx, const tp_cube_desc* desc,
 	const uint8_t* d_mask, const int32_t* d_stamps, const int32_t* d_status,
 	double* d_flux, double* d_flux_err, double* d_flux_background,
 	double* d_centroid_col, double* d_centroid_row, int64_t out_pitch);
+
+/* ---- A1 + A2..A5b + A7 + A6 fused: AperturePhotometry.do_photometry for a batch -------------------
+ * replaces one pass of photometry/AperturePhotometry/photometry.py:75-257 over a fixed stamp for every
+ * target: sum image, K2P2 mask (+ minimum aperture, contamination), extraction.  One wavefront owns a
+ * target from the first load to the last store, the sum image and the mask stay in LDS in between; the
+ * outputs are bit-identical to tp_sumimage + tp_k2p2_masks + tp_aperture_extract called in turn
+ * (argument meaning as documented there; d_sumimage is an OUTPUT here).                              */
+int tp_aperture_photometry(tp_ctx* ctx, const tp_cube_desc* desc,
+	const float* d_images, const float* d_images_err, const float* d_backgrounds, int32_t bkg_mode, int64_t bkg_series_pitch,
+	const float* d_subtract, int64_t subtract_pitch,
+	const int32_t* d_quality, int64_t quality_target_stride, uint32_t bitmask,
+	const int64_t* d_cat_offsets, const float* d_cat_column_stamp, const float* d_cat_row_stamp, const float* d_cat_tmag,
+	const float* d_cat_column, const float* d_cat_row, const int64_t* d_cat_starid,
+	const double* d_target_pos_row, const double* d_target_pos_column, const double* d_target_tmag, const int64_t* d_target_starid,
+	const int32_t* d_stamps, const int32_t* d_aperture, const tp_k2p2_params* params,
+	double* d_sumimage, uint8_t* d_mask, int32_t* d_status, int32_t* d_flags, double* d_contamination, double* d_diag,
+	uint8_t* d_cat_in_mask,
+	double* d_flux, double* d_flux_err, double* d_flux_background, double* d_centroid_col, double* d_centroid_row, int64_t out_pitch);
 
 /* ---- B*, B2, B3: background on stamps -----------------------------------------------------------
  * tp_background_stamp (B*): build-defined stamp analogue of backgrounds.fit_background

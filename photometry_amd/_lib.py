@@ -44,6 +44,7 @@ SIGNATURES = {
 	'tp_version': (c_int, []),
 	'tp_device_count': (c_int, [POINTER(c_int)]),
 	'tp_ctx_create': (c_int, [c_int, POINTER(c_void_p)]),
+	'tp_ctx_create_stream': (c_int, [c_int, c_int, POINTER(c_void_p)]),
 	'tp_ctx_destroy': (c_int, [c_void_p]),
 	'tp_last_error': (c_char_p, [c_void_p]),
 	'tp_device_info': (c_int, [c_void_p, c_char_p, c_int, POINTER(c_int32), POINTER(c_uint64)]),
@@ -55,6 +56,10 @@ SIGNATURES = {
 	'tp_memcpy_d2d': (c_int, [c_void_p, _p, _p, c_uint64]),
 	'tp_upload_cube': (c_int, [c_void_p, _p, c_int64, _p, c_int64, c_int64, c_int64]),
 	'tp_sync': (c_int, [c_void_p]),
+	'tp_event_create': (c_int, [c_void_p, POINTER(c_void_p)]),
+	'tp_event_destroy': (c_int, [c_void_p, c_void_p]),
+	'tp_event_record': (c_int, [c_void_p, c_void_p]),
+	'tp_stream_wait_event': (c_int, [c_void_p, c_void_p]),
 	'tp_timer_start': (c_int, [c_void_p, c_int]),
 	'tp_timer_stop': (c_int, [c_void_p, c_int]),
 	'tp_timer_elapsed_ms': (c_int, [c_void_p, c_int, POINTER(c_float)]),
@@ -67,6 +72,13 @@ SIGNATURES = {
 	'tp_k2p2_masks': (c_int, [c_void_p, c_int32, c_int32, c_int32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
 		POINTER(tp_k2p2_params), _p, _p, _p, _p, _p, _p]),
 	'tp_aperture_extract': (c_int, [c_void_p, _desc_p, _p, _p, _p, c_int32, c_int64, _p, c_int64, _p, _p, _p,
+		_p, _p, _p, _p, _p, c_int64]),
+	'tp_aperture_photometry': (c_int, [c_void_p, _desc_p, _p, _p, _p, c_int32, c_int64, _p, c_int64,
+		_p, c_int64, c_uint32,
+		_p, _p, _p, _p, _p, _p, _p,
+		_p, _p, _p, _p,
+		_p, _p, POINTER(tp_k2p2_params),
+		_p, _p, _p, _p, _p, _p, _p,
 		_p, _p, _p, _p, _p, c_int64]),
 	'tp_background_stamp': (c_int, [c_void_p, _desc_p, _p, c_double, c_double, _p, c_int64]),
 	'tp_smooth_time': (c_int, [c_void_p, c_int32, c_int32, c_int64, c_int32, _p, _p]),

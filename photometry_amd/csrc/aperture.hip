@@ -21,135 +21,11 @@
 //               1-based CCD coordinates (BasePhotometry.get_pixel_grid, BasePhotometry.py:696-706)
 //  * background = bottleneck.nansum: sequential float32 skipping NaN; NaN if all NaN (:198-201)
 //  * all-NaN or all-zero flux in the mask -> flux, flux_err, centroid = NaN (:182-185)
-#include "common.h"
-#include <cmath>
+#include "aperture_dev.h"
 
 namespace {
 
-constexpr int kMaxList = 128;      // small kernel: mask pixels held in LDS
-constexpr int kChunk = 1024;       // big kernel: ordered mask pixels staged per round
-constexpr int kMaxLeaves = 4096;   // big kernel: pairwise leaves (each 65..128 pixels)
-constexpr int kMaxDepth = 24;
-
-template <int VEC> struct Vec;
-template <> struct Vec<4> {
-	static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
-		float4 t = *reinterpret_cast<const float4*>(p);
-		v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-	}
-};
-template <> struct Vec<2> {
-	static __device__ __forceinline__ void load(const float* p, float (&v)[2]) {
-		float2 t = *reinterpret_cast<const float2*>(p);
-		v[0] = t.x; v[1] = t.y;
-	}
-};
-template <> struct Vec<1> {
-	static __device__ __forceinline__ void load(const float* p, float (&v)[1]) { v[0] = *p; }
-};
-
-// Per-thread state for VEC cadences
-template <int VEC>
-struct CadState {
-	float r[VEC][8];      // pairwise accumulators: flux
-	float e[VEC][8];      // pairwise accumulators: err^2
-	float fres[VEC], eres[VEC];
-	float bsum[VEC];
-	double cw[VEC], ccol[VEC], crow[VEC];
-	bool f_allnan[VEC], f_allzero[VEC], b_allnan[VEC];
-
-	__device__ __forceinline__ void init() {
-#pragma unroll
-		for (int c = 0; c < VEC; c++) {
-			fres[c] = 0.f; eres[c] = 0.f; bsum[c] = 0.f;
-			cw[c] = 0.0; ccol[c] = 0.0; crow[c] = 0.0;
-			f_allnan[c] = true; f_allzero[c] = true; b_allnan[c] = true;
-		}
-	}
-	// everything except the pairwise flux / err sums
-	__device__ __forceinline__ void side(const float (&v)[VEC], const float (&b)[VEC], double col, double row) {
-#pragma unroll
-		for (int c = 0; c < VEC; c++) {
-			const float x = v[c];
-			f_allnan[c] = f_allnan[c] && (x != x);
-			f_allzero[c] = f_allzero[c] && (x == 0.f);
-			if (x > 0.f) {
-				const double w = (double)x;
-				cw[c] += w;
-				ccol[c] += col * w;
-				crow[c] += row * w;
-			}
-			const float y = b[c];
-			if (y == y) { bsum[c] += y; b_allnan[c] = false; }
-		}
-	}
-};
-
-__device__ __forceinline__ float combine8(const float (&r)[8]) {
-	return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-}
-
-struct Args {
-	const float* images; const float* images_err; const float* backgrounds;
-	int32_t bkg_mode; int64_t bkg_series_pitch;
-	const float* subtract; int64_t subtract_pitch;
-	const uint8_t* mask; const int32_t* stamps; const int32_t* status;
-	double* flux; double* flux_err; double* flux_bkg; double* ccol; double* crow;
-	int64_t out_pitch; int n_cad; int height; int width; int64_t t_pitch; int n_targets;
-};
-
-template <int VEC>
-__device__ __forceinline__ void store_outputs(const Args& a, int target, int k0, const CadState<VEC>& st, int M) {
-	const int64_t ob = (int64_t)target * a.out_pitch;
-	const double nan = __builtin_nan("");
-#pragma unroll
-	for (int c = 0; c < VEC; c++) {
-		const int k = k0 + c;
-		if (k >= a.n_cad) continue;
-		const bool bad = (M == 0) || st.f_allnan[c] || st.f_allzero[c];
-		a.flux[ob + k] = bad ? nan : (double)st.fres[c];
-		a.flux_err[ob + k] = bad ? nan : (double)sqrtf(st.eres[c]);
-		const bool haspos = st.cw[c] > 0.0;
-		a.ccol[ob + k] = (bad || !haspos) ? nan : st.ccol[c] / st.cw[c];
-		a.crow[ob + k] = (bad || !haspos) ? nan : st.crow[c] / st.cw[c];
-		a.flux_bkg[ob + k] = (M == 0 || st.b_allnan[c]) ? nan : (double)st.bsum[c];
-	}
-}
-
-// Ordered (raster) compaction of the next mask pixels starting at *p_next into list[0..cap), by
-// ONE wavefront.  Returns the number stored; advances *p_next.  With count_rest, keeps counting
-// (without storing) to the end of the mask and returns the total in *total.
-__device__ __forceinline__ int compact_mask(const uint8_t* m, int P, int& p_next, int* list, int cap, int lane,
-	bool count_rest, int* total)
-{
-	int n = 0;
-	int p0 = p_next;
-	for (; p0 < P; p0 += 64) {
-		const int p = p0 + lane;
-		const bool in = (p < P) && (m[p] != 0);
-		const unsigned long long bal = __ballot(in);
-		const int pos = n + __popcll(bal & ((1ull << lane) - 1ull));
-		const int cnt = __popcll(bal);
-		if (n + cnt > cap) {
-			if (!count_rest) {
-				// store only what fits, stop *inside* this group: find the pixel where the list fills
-				if (in && pos < cap) list[pos] = p;
-				// p_next = index of the first pixel NOT stored
-				const unsigned long long notstored = __ballot(in && pos >= cap);
-				p_next = p0 + (int)__ffsll((long long)notstored) - 1;
-				return cap;
-			}
-			if (in && pos < cap) list[pos] = p;
-			n += cnt;
-			continue;
-		}
-		if (in && pos < cap) list[pos] = p;
-		n += cnt;
-	}
-	p_next = P;
-	if (total) *total = n;
-	return n < cap ? n : cap;
-}
+using namespace tp_ap;
 
 //--------------------------------------------------------------------------------------------------
 // Small kernel: 0 <= M <= 128 mask pixels (a single pairwise leaf)
@@ -173,80 +49,7 @@ __global__ __launch_bounds__(256) void tp_aperture_kernel(Args a)
 	__syncthreads();
 	const int M = s_M;
 	if (M > kMaxList) return; // handled by tp_aperture_big_kernel
-
-	const int col0 = a.stamps[target * 4 + 2] + 1; // 1-based CCD column of stamp column 0
-	const int row0 = a.stamps[target * 4 + 0] + 1;
-	const int64_t tb = (int64_t)target * P * a.t_pitch;
-	const float* img = a.images + tb;
-	const float* err = a.images_err + tb;
-	const float* bkg = (a.bkg_mode == 0) ? (a.backgrounds + tb) : (a.backgrounds + (int64_t)target * a.bkg_series_pitch);
-	const int nq = (a.n_cad + VEC - 1) / VEC;
-	const int nblk = M - (M & 7);
-
-	for (int q = blockIdx.x * blockDim.x + tid; q < nq; q += gridDim.x * blockDim.x) {
-		const int k0 = q * VEC;
-		CadState<VEC> st;
-		st.init();
-		float bser[VEC], ssub[VEC];
-		if (a.bkg_mode != 0) Vec<VEC>::load(bkg + k0, bser);
-		if (a.subtract) Vec<VEC>::load(a.subtract + (int64_t)target * a.subtract_pitch + k0, ssub);
-
-		auto fetch = [&](int idx, float (&v)[VEC], float (&e2)[VEC]) {
-			const int p = s_list[idx];
-			const int64_t off = (int64_t)p * a.t_pitch + k0;
-			float ee[VEC], bb[VEC];
-			Vec<VEC>::load(img + off, v);
-			if (a.subtract) {
-#pragma unroll
-				for (int c = 0; c < VEC; c++) v[c] = v[c] - ssub[c];
-			}
-			Vec<VEC>::load(err + off, ee);
-			if (a.bkg_mode == 0) Vec<VEC>::load(bkg + off, bb);
-			else {
-#pragma unroll
-				for (int c = 0; c < VEC; c++) bb[c] = bser[c];
-			}
-			const int pr = p / a.width;
-			const int pc = p - pr * a.width;
-#pragma unroll
-			for (int c = 0; c < VEC; c++) e2[c] = ee[c] * ee[c];
-			st.side(v, bb, (double)(col0 + pc), (double)(row0 + pr));
-		};
-
-		if (M < 8) {
-			for (int i = 0; i < M; i++) {
-				float v[VEC], e2[VEC];
-				fetch(i, v, e2);
-#pragma unroll
-				for (int c = 0; c < VEC; c++) { st.fres[c] += v[c]; st.eres[c] += e2[c]; }
-			}
-		} else {
-			for (int g = 0; g < nblk; g += 8) {
-#pragma unroll
-				for (int j = 0; j < 8; j++) {
-					float v[VEC], e2[VEC];
-					fetch(g + j, v, e2);
-#pragma unroll
-					for (int c = 0; c < VEC; c++) {
-						if (g == 0) { st.r[c][j] = v[c]; st.e[c][j] = e2[c]; }
-						else { st.r[c][j] += v[c]; st.e[c][j] += e2[c]; }
-					}
-				}
-			}
-#pragma unroll
-			for (int c = 0; c < VEC; c++) { st.fres[c] = combine8(st.r[c]); st.eres[c] = combine8(st.e[c]); }
-			for (int i = nblk; i < M; i++) {
-				float v[VEC], e2[VEC];
-				fetch(i, v, e2);
-#pragma unroll
-				for (int c = 0; c < VEC; c++) { st.fres[c] += v[c]; st.eres[c] += e2[c]; }
-			}
-		}
-		// np.sum = 0 + pairwise_sum (identity-initialised reduce)
-#pragma unroll
-		for (int c = 0; c < VEC; c++) { st.fres[c] = 0.f + st.fres[c]; st.eres[c] = 0.f + st.eres[c]; }
-		store_outputs<VEC>(a, target, k0, st, M);
-	}
+	extract_small<VEC>(a, target, s_list, M, blockIdx.x * blockDim.x + tid, gridDim.x * blockDim.x);
 }
 
 //--------------------------------------------------------------------------------------------------
@@ -432,6 +235,19 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 
 } // namespace
 
+int tp_aperture_extract_big(tp_ctx* ctx, const tp_ap::Args& a, bool vec4)
+{
+	const int vec = vec4 ? 4 : 1;
+	const int nq = (a.n_cad + vec - 1) / vec;
+	int threads = ((nq + 63) / 64) * 64;
+	if (threads > 512) threads = 512;
+	dim3 grid((unsigned)a.n_targets), block((unsigned)threads);
+	if (vec4) TP_LAUNCH(ctx, TPK_APERTURE_BIG, tp_aperture_big_kernel<4>, grid, block, 0, a);
+	else TP_LAUNCH(ctx, TPK_APERTURE_BIG, tp_aperture_big_kernel<1>, grid, block, 0, a);
+	TP_LAUNCH_CHECK(ctx, "tp_aperture_big_kernel");
+	return TP_OK;
+}
+
 extern "C" int tp_aperture_extract(tp_ctx* ctx, const tp_cube_desc* desc,
 	const float* d_images, const float* d_images_err, const float* d_backgrounds,
 	int32_t bkg_mode, int64_t bkg_series_pitch, const float* d_subtract, int64_t subtract_pitch,
@@ -480,16 +296,6 @@ extern "C" int tp_aperture_extract(tp_ctx* ctx, const tp_cube_desc* desc,
 		TP_LAUNCH_CHECK(ctx, "tp_aperture_kernel");
 	}
 	// Masks above 128 pixels (rare): the recursive pairwise tree, one workgroup per target
-	{
-		const int vec = vec4 ? 4 : 1;
-		const int nq = (desc->n_cad + vec - 1) / vec;
-		int threads = ((nq + 63) / 64) * 64;
-		if (threads > 512) threads = 512;
-		dim3 grid((unsigned)desc->n_targets), block((unsigned)threads);
-		if (vec4) TP_LAUNCH(ctx, TPK_APERTURE_BIG, tp_aperture_big_kernel<4>, grid, block, 0, a);
-		else TP_LAUNCH(ctx, TPK_APERTURE_BIG, tp_aperture_big_kernel<1>, grid, block, 0, a);
-		TP_LAUNCH_CHECK(ctx, "tp_aperture_big_kernel");
-	}
-	return TP_OK;
+	return tp_aperture_extract_big(ctx, a, vec4);
 	TP_API_END(ctx)
 }

@@ -10,6 +10,7 @@ static const char* const kKernelNames[TPK_COUNT] = {
 	"tp_aperture_kernel",
 	"tp_aperture_big_kernel",
 	"tp_k2p2_kernel",
+	"tp_aperture_fused_kernel",
 	"tp_bkg_stamp_kernel",
 	"tp_bkg_smooth_kernel",
 	"tp_bkg_subtract_kernel",
@@ -36,7 +37,7 @@ int tp_device_count(int* n) {
 	return TP_OK;
 }
 
-int tp_ctx_create(int device, tp_ctx** out) {
+static int tp_ctx_create_impl(int device, int high_priority, tp_ctx** out) {
 	if (!out) return TP_ERR_INVALID;
 	*out = nullptr;
 	TP_API_BEGIN
@@ -67,7 +68,13 @@ int tp_ctx_create(int device, tp_ctx** out) {
 	}
 	tp_ctx* ctx = new tp_ctx();
 	ctx->device = device;
-	e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+	if (high_priority) {
+		int least = 0, greatest = 0;
+		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+		e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest);
+	} else {
+		e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+	}
 	if (e != hipSuccess) {
 		tp_global_err = std::string("hipStreamCreate: ") + hipGetErrorString(e);
 		delete ctx;
@@ -83,6 +90,14 @@ int tp_ctx_create(int device, tp_ctx** out) {
 }
 
 int tp_comm_destroy(tp_ctx* ctx);
+
+int tp_ctx_create(int device, tp_ctx** out) {
+	return tp_ctx_create_impl(device, 0, out);
+}
+
+int tp_ctx_create_stream(int device, int high_priority, tp_ctx** out) {
+	return tp_ctx_create_impl(device, high_priority, out);
+}
 
 int tp_ctx_destroy(tp_ctx* ctx) {
 	if (!ctx) return TP_OK;
@@ -194,6 +209,35 @@ int tp_upload_cube(tp_ctx* ctx, float* d_dst, int64_t dst_pitch, const float* h_
 int tp_sync(tp_ctx* ctx) {
 	TP_CHECK_CTX(ctx);
 	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return TP_OK;
+}
+
+int tp_event_create(tp_ctx* ctx, void** event) {
+	TP_CHECK_CTX(ctx);
+	TP_REQUIRE(ctx, event != nullptr, "tp_event_create: null output pointer");
+	hipEvent_t e = nullptr;
+	TP_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	*event = (void*)e;
+	return TP_OK;
+}
+
+int tp_event_destroy(tp_ctx* ctx, void* event) {
+	TP_CHECK_CTX(ctx);
+	if (event) TP_HIP(ctx, hipEventDestroy((hipEvent_t)event));
+	return TP_OK;
+}
+
+int tp_event_record(tp_ctx* ctx, void* event) {
+	TP_CHECK_CTX(ctx);
+	TP_REQUIRE(ctx, event != nullptr, "tp_event_record: null event");
+	TP_HIP(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
+	return TP_OK;
+}
+
+int tp_stream_wait_event(tp_ctx* ctx, void* event) {
+	TP_CHECK_CTX(ctx);
+	TP_REQUIRE(ctx, event != nullptr, "tp_stream_wait_event: null event");
+	TP_HIP(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)event, 0));
 	return TP_OK;
 }
 

@@ -15,6 +15,7 @@ enum tp_kernel_id {
 	TPK_APERTURE,
 	TPK_APERTURE_BIG,
 	TPK_K2P2,
+	TPK_FUSED,
 	TPK_BKG_STAMP,
 	TPK_BKG_SMOOTH,
 	TPK_BKG_SUBTRACT,

@@ -1,0 +1,256 @@
+// fused.hip -- the whole aperture hot path of one target in ONE wavefront:
+//   A1 sum image -> A2..A5b K2P2 mask (+A7 contamination) -> A6 extraction,
+// i.e. AperturePhotometry.do_photometry (photometry/AperturePhotometry/photometry.py:44-257, the first
+// pass over a fixed stamp) without the sum image or the mask ever leaving the compute unit.
+//
+// Why fuse (gfx950): A1 and A6 are HBM streaming, K2P2 is ~250 us of latency-bound LDS work per target that
+// leaves the memory system idle; as three kernels each phase runs alone on the chip.  Here a wavefront owns a
+// target from the first load to the last store; the ~7 wavefronts resident per CU (LDS: ~23 KB each) are at
+// different phases at any time, so the streaming of some targets hides the mask building of the others, and the
+// whole batch is one launch (no launch gaps, no sum image / mask round trip through HBM).
+//
+// Arithmetic is that of the three stand-alone kernels (same device functions: sumimage_dev.h, k2p2_core.h,
+// aperture_dev.h), so the outputs are bit-identical to tp_sumimage + tp_k2p2_masks + tp_aperture_extract.
+// Masks above 128 pixels (rare) are left to tp_aperture_big_kernel, launched right after on the same stream.
+//
+// LDS plan per wavefront: the K2P2 work arrays (k2p2::shared_bytes); during A1 the good-cadence flags alias the
+// phase-shared region of the K2P2 arrays (k.srt), during A6 the mask pixel list aliases k.lab.
+#include "sumimage_dev.h"
+#include "aperture_dev.h"
+#include "k2p2_args.h"
+#include <cstdlib>
+
+namespace {
+
+constexpr int kRows = 8; // pixel rows per A1 step: 8 x 1 KiB loads in flight per lane
+
+template <int VEC, bool VEC4, bool HAS_SUB, bool BKG_CUBE>
+__global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a, k2p2::BatchArgs ka, k2p2::Params prm,
+	const double* __restrict__ twid, const int32_t* __restrict__ quality, int64_t quality_stride, uint32_t bitmask,
+	double* __restrict__ sumimage_out, int dbg)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	const int target = blockIdx.x;
+	const int lane = threadIdx.x;
+	k2p2::Shared k;
+	k2p2::shared_carve(k, smem, ka.H, ka.W, lane, twid);
+	const int P = ka.H * ka.W;
+
+	// ---------------- A1: sum image into LDS (k.S) and HBM ----------------
+	unsigned char* good = reinterpret_cast<unsigned char*>(k.srt);
+	if (!(dbg & 1)) {
+	tp_sum::stage_good(good, quality + (int64_t)target * quality_stride, bitmask, a.n_cad, lane, 64);
+	__syncthreads();
+	{
+		const float* base = a.images + (int64_t)target * P * a.t_pitch;
+		const float* sub = a.subtract ? (a.subtract + (int64_t)target * a.subtract_pitch) : nullptr;
+		double* o = sumimage_out + (int64_t)target * P;
+		int p = 0;
+		if (VEC4) {
+			// Flat software pipeline over (row group, quad step): the loads of step i+1 are issued before step i is
+			// accumulated, also across row groups, so every lane keeps kRows..2*kRows 16-byte loads in flight all the
+			// time (the wavefront count per CU is fixed by the K2P2 LDS footprint, bytes in flight must come from here).
+			// Per lane the cadences are still added in increasing order and reduced by the same tree: same result.
+			const int nq = ((a.n_cad + 3) & ~3) >> 2;
+			const int spg = (nq + 63) >> 6;               // quad steps per row group
+			const int ngroups = (P + kRows - 1) / kRows;  // the last group may be partial: rows clamp to P-1, results dropped
+			const uint32_t* good4 = reinterpret_cast<const uint32_t*>(good);
+			const float4* sub4 = reinterpret_cast<const float4*>(sub);
+			const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+			const int total = ngroups * spg;
+			// ping-pong register buffers: no copy between "next" and "current", so the waitcnt before a consume only
+			// covers the older buffer and the newer one stays in flight
+			float4 bufA[kRows], bufB[kRows];
+			float4 subA = zero4, subB = zero4; // the step's quad of the subtracted series travels with the buffer
+			auto issue = [&](float4 (&buf)[kRows], float4& sbuf, int st) {
+				// unconditional straight-line loads (steps past the end re-read the last one, lanes past the row end re-read
+				// its last quad; both are ignored by consume) so that nothing but the ping-pong order decides the waitcnts
+				st = (st < total) ? st : (total - 1);
+				const int g = st / spg, i = st - g * spg;
+				int qd = lane + (i << 6);
+				qd = (qd < nq) ? qd : (nq - 1);
+				if (HAS_SUB) sbuf = sub4[qd];
+#pragma unroll
+				for (int j = 0; j < kRows; j++) {
+					int r = g * kRows + j;
+					r = (r < P) ? r : (P - 1);
+					buf[j] = reinterpret_cast<const float4*>(base + (int64_t)r * a.t_pitch)[qd];
+				}
+			};
+			double sacc[kRows];
+			int nacc[kRows];
+#pragma unroll
+			for (int j = 0; j < kRows; j++) { sacc[j] = 0.0; nacc[j] = 0; }
+			auto consume = [&](const float4 (&buf)[kRows], const float4& sa, int st) {
+				const bool valid = st < total;
+				const int g = st / spg, i = st - g * spg;
+				const int qd = lane + (i << 6);
+				if (valid && qd < nq) {
+					const uint32_t gd = good4[qd];
+#pragma unroll
+					for (int j = 0; j < kRows; j++) {
+						float4 v = buf[j];
+						if (HAS_SUB) { v.x -= sa.x; v.y -= sa.y; v.z -= sa.z; v.w -= sa.w; }
+						tp_sum::acc1(v.x, gd & 0xffu, sacc[j], nacc[j]); tp_sum::acc1(v.y, gd & 0xff00u, sacc[j], nacc[j]);
+						tp_sum::acc1(v.z, gd & 0xff0000u, sacc[j], nacc[j]); tp_sum::acc1(v.w, gd & 0xff000000u, sacc[j], nacc[j]);
+					}
+				}
+				if (valid && i == spg - 1) {
+					// the kRows shuffle trees interleaved (independent chains), same tree per row as tp_sum::wave_sum_*
+#pragma unroll
+					for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+						for (int j = 0; j < kRows; j++) { sacc[j] += __shfl_down(sacc[j], off, 64); nacc[j] += __shfl_down(nacc[j], off, 64); }
+					}
+					if (lane == 0) {
+#pragma unroll
+						for (int j = 0; j < kRows; j++) {
+							const int r = g * kRows + j;
+							if (r < P) { const double m = (nacc[j] > 0) ? sacc[j] / (double)nacc[j] : __builtin_nan(""); k.S[r] = m; o[r] = m; }
+						}
+					}
+#pragma unroll
+					for (int j = 0; j < kRows; j++) { sacc[j] = 0.0; nacc[j] = 0; }
+				}
+			};
+			issue(bufA, subA, 0);
+			issue(bufB, subB, 1);
+			for (int st = 0; st < total; st += 2) {
+				consume(bufA, subA, st);
+				issue(bufA, subA, st + 2);
+				consume(bufB, subB, st + 1);
+				issue(bufB, subB, st + 3);
+			}
+		} else {
+			for (; p < P; p++) {
+				const double m = tp_sum::row_mean_scalar(base + (int64_t)p * a.t_pitch, sub, good, a.n_cad, lane);
+				if (lane == 0) { k.S[p] = m; o[p] = m; }
+			}
+		}
+	}
+	} else { for (int p = lane; p < P; p += 64) k.S[p] = sumimage_out[(int64_t)target * P + p]; }
+	__syncthreads();
+
+	// ---------------- A2..A5b, A7: the mask, from the LDS-resident sum image ----------------
+	k2p2::Target t;
+	k2p2::make_target(ka, target, t);
+	t.S = k.S;
+	int status = 1;
+	if (!(dbg & 2)) status = k2p2::run_target(k, prm, t);
+	else { for (int p = lane; p < P; p += 64) k.res[p] = ka.mask[(int64_t)target * P + p]; status = ka.status[target]; __syncthreads(); }
+	if (dbg & 4) return;
+	if (status == TP_STATUS_ERROR) return; // photometry.py: the plugin stops, nothing is extracted
+
+	// ---------------- A6: extraction over the mask pixels (k.res), all cadences ----------------
+	int* s_list = reinterpret_cast<int*>(k.lab);
+	int pn = 0, M = 0;
+	tp_ap::compact_mask(k.res, P, pn, s_list, tp_ap::kMaxList, lane, true, &M);
+	__syncthreads();
+	if (M > tp_ap::kMaxList) return; // tp_aperture_big_kernel takes it from the mask in HBM
+	tp_ap::extract_small_stream<VEC, HAS_SUB, BKG_CUBE>(a, target, s_list, M, lane, 64);
+}
+
+} // namespace
+
+extern "C" int tp_aperture_photometry(tp_ctx* ctx, const tp_cube_desc* desc,
+	const float* d_images, const float* d_images_err, const float* d_backgrounds, int32_t bkg_mode, int64_t bkg_series_pitch,
+	const float* d_subtract, int64_t subtract_pitch,
+	const int32_t* d_quality, int64_t quality_target_stride, uint32_t bitmask,
+	const int64_t* d_cat_offsets, const float* d_cat_column_stamp, const float* d_cat_row_stamp, const float* d_cat_tmag,
+	const float* d_cat_column, const float* d_cat_row, const int64_t* d_cat_starid,
+	const double* d_target_pos_row, const double* d_target_pos_column, const double* d_target_tmag, const int64_t* d_target_starid,
+	const int32_t* d_stamps, const int32_t* d_aperture, const tp_k2p2_params* params,
+	double* d_sumimage, uint8_t* d_mask, int32_t* d_status, int32_t* d_flags, double* d_contamination, double* d_diag,
+	uint8_t* d_cat_in_mask,
+	double* d_flux, double* d_flux_err, double* d_flux_background, double* d_centroid_col, double* d_centroid_row, int64_t out_pitch)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, tp_desc_ok(desc), "tp_aperture_photometry: bad cube descriptor");
+	TP_REQUIRE(ctx, d_images && d_images_err && d_backgrounds && d_quality && d_stamps && d_aperture && d_cat_offsets
+		&& d_target_pos_row && d_target_pos_column && d_target_tmag && d_target_starid, "tp_aperture_photometry: null input pointer");
+	TP_REQUIRE(ctx, d_sumimage && d_mask && d_status && d_flags && d_contamination, "tp_aperture_photometry: null output pointer");
+	TP_REQUIRE(ctx, d_flux && d_flux_err && d_flux_background && d_centroid_col && d_centroid_row, "tp_aperture_photometry: null output pointer");
+	TP_REQUIRE(ctx, out_pitch >= desc->n_cad, "tp_aperture_photometry: out_pitch < n_cad");
+	TP_REQUIRE(ctx, bkg_mode == 0 || bkg_mode == 1, "tp_aperture_photometry: bkg_mode must be 0 (cube) or 1 (series)");
+	TP_REQUIRE(ctx, bkg_mode == 0 || bkg_series_pitch >= desc->n_cad, "tp_aperture_photometry: bad bkg_series_pitch");
+	TP_REQUIRE(ctx, quality_target_stride == 0 || quality_target_stride >= desc->n_cad, "tp_aperture_photometry: bad quality stride");
+	TP_REQUIRE(ctx, d_subtract == nullptr || subtract_pitch >= desc->n_cad, "tp_aperture_photometry: bad subtract pitch");
+	if (desc->n_targets == 0) return TP_OK;
+	const int P = desc->height * desc->width;
+	// LDS: the K2P2 arrays; the good-cadence flags must fit behind k.S while A1 runs
+	const k2p2::SharedLayout lay = k2p2::shared_layout(P);
+	size_t shmem = lay.total;
+	const size_t a1_bytes = lay.off_region + (size_t)((desc->n_cad + 3) & ~3) + 16; // flags live in the shared region
+	if (a1_bytes > shmem) shmem = a1_bytes;
+	TP_REQUIRE(ctx, shmem <= 160 * 1024, "tp_aperture_photometry: stamp / cadence count too large for the LDS-resident per-target state");
+
+	if (!ctx->twiddle) {
+		double h[2 * k2p2::kGrid];
+		for (int j = 0; j < k2p2::kGrid; ++j) {
+			h[j] = std::cos(2.0 * k2p2::kPi * (double)j / (double)k2p2::kGrid);
+			h[k2p2::kGrid + j] = std::sin(2.0 * k2p2::kPi * (double)j / (double)k2p2::kGrid);
+		}
+		TP_HIP(ctx, hipMalloc(&ctx->twiddle, sizeof(h)));
+		TP_HIP(ctx, hipMemcpy(ctx->twiddle, h, sizeof(h), hipMemcpyHostToDevice));
+	}
+
+	k2p2::Params prm = k2p2::default_params();
+	if (params) {
+		prm.thresh = params->thresh;
+		prm.min_no_pixels_in_mask = params->min_no_pixels_in_mask;
+		prm.min_for_cluster = params->min_for_cluster;
+		prm.extend_overflow = params->extend_overflow;
+		prm.ws_thres = params->ws_thres;
+		prm.saturation_limit = params->saturation_limit;
+	}
+	k2p2::BatchArgs ka;
+	ka.n_targets = desc->n_targets; ka.H = desc->height; ka.W = desc->width; ka.sumimage = d_sumimage; ka.cat_offsets = d_cat_offsets;
+	ka.cat_column_stamp = d_cat_column_stamp; ka.cat_row_stamp = d_cat_row_stamp; ka.cat_tmag = d_cat_tmag;
+	ka.cat_column = d_cat_column; ka.cat_row = d_cat_row; ka.cat_starid = d_cat_starid;
+	ka.target_pos_row = d_target_pos_row; ka.target_pos_column = d_target_pos_column; ka.target_tmag = d_target_tmag;
+	ka.target_starid = d_target_starid; ka.stamps = d_stamps; ka.aperture = d_aperture; ka.cut_override = nullptr;
+	ka.mask = d_mask; ka.status = d_status; ka.flags = d_flags; ka.contamination = d_contamination; ka.diag = d_diag;
+	ka.cat_in_mask = d_cat_in_mask; ka.timing = nullptr;
+
+	tp_ap::Args a;
+	a.images = d_images; a.images_err = d_images_err; a.backgrounds = d_backgrounds;
+	a.bkg_mode = bkg_mode; a.bkg_series_pitch = bkg_series_pitch;
+	a.subtract = d_subtract; a.subtract_pitch = subtract_pitch;
+	a.mask = d_mask; a.stamps = d_stamps; a.status = d_status;
+	a.flux = d_flux; a.flux_err = d_flux_err; a.flux_bkg = d_flux_background;
+	a.ccol = d_centroid_col; a.crow = d_centroid_row;
+	a.out_pitch = out_pitch; a.n_cad = desc->n_cad; a.height = desc->height; a.width = desc->width;
+	a.t_pitch = desc->t_pitch; a.n_targets = desc->n_targets;
+
+	bool vec4 = tp_vec4_ok(d_images, desc->t_pitch) && tp_vec4_ok(d_images_err, desc->t_pitch);
+	if (bkg_mode == 0) vec4 = vec4 && tp_vec4_ok(d_backgrounds, desc->t_pitch);
+	else vec4 = vec4 && tp_vec4_ok(d_backgrounds, bkg_series_pitch);
+	if (d_subtract) vec4 = vec4 && tp_vec4_ok(d_subtract, subtract_pitch);
+
+	// diagnostics only: TP_FUSED_DBG bit 0 / 1 / 2 switches the A1 / K2P2 / A6 phase off (the skipped phase's result is
+	// taken from d_sumimage / d_mask, d_status as left by a previous call) to time the phases separately (tools/fused_phases.py)
+	int dbg = 0;
+	if (const char* e = getenv("TP_FUSED_DBG")) dbg = atoi(e);
+	const dim3 grid((unsigned)desc->n_targets), block(64);
+#define TP_FUSED_LAUNCH(V, V4, HS, BC) do { \
+		auto kern = tp_aperture_fused_kernel<V, V4, HS, BC>; \
+		if (shmem > 64 * 1024) TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+		TP_LAUNCH(ctx, TPK_FUSED, kern, grid, block, shmem, a, ka, prm, (const double*)ctx->twiddle, d_quality, quality_target_stride, bitmask, d_sumimage, dbg); \
+	} while (0)
+	// the two configurations of the pipeline: resident (images, errors, background) cubes, or raw cubes with the
+	// stamp-constant background series subtracted on the fly (B3) and reported as the background (bkg_mode 1)
+	const bool cube = (bkg_mode == 0);
+	if (vec4) {
+		if (d_subtract) { if (cube) TP_FUSED_LAUNCH(2, true, true, true); else TP_FUSED_LAUNCH(2, true, true, false); }
+		else { if (cube) TP_FUSED_LAUNCH(2, true, false, true); else TP_FUSED_LAUNCH(2, true, false, false); }
+	} else {
+		if (d_subtract) { if (cube) TP_FUSED_LAUNCH(1, false, true, true); else TP_FUSED_LAUNCH(1, false, true, false); }
+		else { if (cube) TP_FUSED_LAUNCH(1, false, false, true); else TP_FUSED_LAUNCH(1, false, false, false); }
+	}
+#undef TP_FUSED_LAUNCH
+	TP_LAUNCH_CHECK(ctx, "tp_aperture_fused_kernel");
+	// masks above 128 pixels: the recursive pairwise tree kernel picks them from the mask / status in HBM
+	return tp_aperture_extract_big(ctx, a, vec4);
+	TP_API_END(ctx)
+}

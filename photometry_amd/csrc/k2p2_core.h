@@ -106,6 +106,10 @@ struct Target {
 	double* timing;           // optional [16] per-phase cycle counters (diagnostics)
 };
 
+// Labels, pixel indices and counters bounded by P (<= 44*44) are 16-bit: LDS footprint decides how many targets
+// (wavefronts) a CU holds at once.
+typedef int16_t lab_t;
+
 // Shared (LDS) work arrays of one target.  Sizes in elements; P = H*W, Pp = pow2 >= P.
 struct Shared {
 	int lane;
@@ -118,12 +122,12 @@ struct Shared {
 	double* hval;     // [P] heap values
 	double* red;      // [64]
 	double* grid;     // [4*kGrid]: binned, dens, Yre, Yim
-	int32_t* lab;     // [P] DBSCAN labels
-	int32_t* lab2;    // [P] labels after watershed
-	int32_t* mark;    // [P] markers / component labels
-	int32_t* wsout;   // [P]
-	int32_t* hage;    // [P]
-	int32_t* hpix;    // [P]
+	lab_t* lab;       // [P] DBSCAN labels
+	lab_t* lab2;      // [P] labels after watershed
+	lab_t* mark;      // [P] markers / component labels
+	lab_t* wsout;     // [P]
+	lab_t* hage;      // [P]
+	lab_t* hpix;      // [P]
 	int32_t* ired;    // [64]
 	int32_t* scal;    // [32] uniform scalars
 	uint8_t* idx;     // [P]
@@ -135,49 +139,72 @@ struct Shared {
 	const double* twid; // [2*kGrid] cos, sin of 2*pi*j/kGrid (global / constant)
 };
 
-inline TP_HD size_t shared_bytes(int P) {
-	if (P < 64) P = 64; // several P-sized arrays double as 64-entry per-lane scratch
-	int Pp = 1;
-	while (Pp < P) Pp <<= 1;
-	size_t d = (size_t)P * 5 + Pp + 64 + 4 * kGrid;   // doubles
-	size_t i = (size_t)P * 6 + 64 + 32;               // int32
-	size_t b = (size_t)P * 6;                          // bytes
-	return d * 8 + i * 4 + ((b + 15) & ~(size_t)15) + 64;
+// LDS plan.  The arrays of the threshold phase (A2: sorted fluxes + the KDE grids) are dead once CUT is known and the
+// arrays of the clustering / watershed / assembly phases (A3..A5) are not touched before, so the two sets share one
+// region: 16.7 KB instead of 22.9 KB per 15x15 target, i.e. 9 instead of 7 resident wavefronts per CU.
+struct SharedLayout {
+	int Pa, Pp, Pp_sort;
+	size_t off_region, region_bytes, off_ints, off_bytes, total;
+};
+
+inline TP_HD SharedLayout shared_layout(int P) {
+	SharedLayout L;
+	L.Pa = (P < 64) ? 64 : P; // several P-sized arrays double as 64-entry per-lane scratch
+	L.Pp = 1;
+	while (L.Pp < L.Pa) L.Pp <<= 1;
+	L.Pp_sort = 1;
+	while (L.Pp_sort < P) L.Pp_sort <<= 1;
+	const size_t Pa = (size_t)L.Pa;
+	L.off_region = (2 * Pa + 64) * 8;                                   // S, tmp, red
+	const size_t phase1 = ((size_t)L.Pp + 4 * kGrid) * 8;              // srt, grid
+	const size_t phase2 = 3 * Pa * 8 + 4 * Pa * sizeof(lab_t);         // Z, dist, hval | lab, lab2, mark, wsout
+	L.region_bytes = ((phase1 > phase2 ? phase1 : phase2) + 15) & ~(size_t)15;
+	L.off_ints = L.off_region + L.region_bytes;                         // hage, hpix, ired, scal
+	L.off_bytes = L.off_ints + (2 * ((Pa + 1) & ~(size_t)1) * sizeof(lab_t)) + (64 + 32) * 4; // idx, core, lmax, msk, sat, res
+	L.total = L.off_bytes + ((6 * Pa + 15) & ~(size_t)15) + 64;
+	return L;
 }
 
+inline TP_HD size_t shared_bytes(int P) { return shared_layout(P).total; }
+
 inline TP_DEV void shared_carve(Shared& k, void* base, int H, int W, int lane, const double* twid) {
-	int P = H * W;
-	const int Pa = (P < 64) ? 64 : P; // allocation size (see shared_bytes)
-	int Pp = 1;
-	while (Pp < Pa) Pp <<= 1;
-	int Pp_sort = 1;
-	while (Pp_sort < P) Pp_sort <<= 1;
-	k.lane = lane; k.P = P; k.Pp = Pp_sort; k.H = H; k.W = W; k.twid = twid;
-	double* d = (double*)base;
+	const int P = H * W;
+	const SharedLayout L = shared_layout(P);
+	const int Pa = L.Pa;
+	k.lane = lane; k.P = P; k.Pp = L.Pp_sort; k.H = H; k.W = W; k.twid = twid;
+	unsigned char* b0 = (unsigned char*)base;
+	double* d = (double*)b0;
 	k.S = d; d += Pa;
-	k.srt = d; d += Pp;
-	k.Z = d; d += Pa;
-	k.dist = d; d += Pa;
 	k.tmp = d; d += Pa;
-	k.hval = d; d += Pa;
 	k.red = d; d += 64;
-	k.grid = d; d += 4 * kGrid;
-	int32_t* i = (int32_t*)d;
-	k.lab = i; i += Pa;
-	k.lab2 = i; i += Pa;
-	k.mark = i; i += Pa;
-	k.wsout = i; i += Pa;
-	k.hage = i; i += Pa;
-	k.hpix = i; i += Pa;
+	// phase 1 view of the region
+	double* r1 = (double*)(b0 + L.off_region);
+	k.srt = r1; r1 += L.Pp;
+	k.grid = r1;
+	// phase 2 view of the region
+	double* r2 = (double*)(b0 + L.off_region);
+	k.Z = r2; r2 += Pa;
+	k.dist = r2; r2 += Pa;
+	k.hval = r2; r2 += Pa;
+	lab_t* ri = (lab_t*)r2;
+	k.lab = ri; ri += Pa;
+	k.lab2 = ri; ri += Pa;
+	k.mark = ri; ri += Pa;
+	k.wsout = ri;
+	// ired / scal first: 4-byte aligned whatever Pa is; hage doubles as a uint32 bit set (watershed) and follows them
+	int32_t* i = (int32_t*)(b0 + L.off_ints);
 	k.ired = i; i += 64;
 	k.scal = i; i += 32;
-	uint8_t* b = (uint8_t*)i;
+	lab_t* hi = (lab_t*)i;
+	k.hage = hi; hi += (Pa + 1) & ~1;
+	k.hpix = hi;
+	uint8_t* b = b0 + L.off_bytes;
 	k.idx = b; b += Pa;
 	k.core = b; b += Pa;
 	k.lmax = b; b += Pa;
 	k.msk = b; b += Pa;
 	k.sat = b; b += Pa;
-	k.res = b; b += Pa;
+	k.res = b;
 }
 
 //--------------------------------------------------------------------------------------------------
@@ -652,7 +679,7 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 // Connected-component labelling of the non-zero pixels of `in` by min-index propagation;
 // conn8: 8- or 4-connectivity.  out[p] = 1-based component number in raster order of first pixel
 // (scipy.ndimage.label numbering), 0 for background.  Returns the number of components.
-inline TP_DEV int label_components(Shared& k, const uint8_t* in, int32_t* out, bool conn8) {
+inline TP_DEV int label_components(Shared& k, const uint8_t* in, lab_t* out, bool conn8) {
 	const int P = k.P, H = k.H, W = k.W;
 	TP_PAR_FOR(p, P) out[p] = in[p] ? p : -1;
 	TP_SYNC();
@@ -854,7 +881,7 @@ inline TP_DEV void watershed(Shared& k, int nmark) {
 		TP_SYNC();
 		return;
 	}
-	int32_t* rank = k.hpix;          // [P] rank of pixel (only where Z != 0)
+	lab_t* rank = k.hpix;            // [P] rank of pixel (only where Z != 0)
 	int32_t* ord = (int32_t*)k.hval; // [P] pixel of rank r (hval is free here; 2 int32 per double slot)
 	uint32_t* words = (uint32_t*)k.hage; // [ceil(P/32)] bit set of pushed ranks
 	TP_PAR_FOR(p, P) k.wsout[p] = (k.Z[p] != 0.0) ? k.mark[p] : 0;
@@ -925,7 +952,8 @@ inline TP_DEV float mags_total_f32(const float* tmag, const uint8_t* sel, int n)
 	return -2.5f * log10f(s);
 }
 
-inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
+// Returns the STATUS integer; on return k.res holds the final mask (what was written to t.mask).
+inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 	const int P = k.P, H = k.H, W = k.W;
 #ifndef TP_HOSTSIM
 	long long _tlast = clock64();
@@ -1319,7 +1347,7 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 
 	TP_STAMP(12);
 	const bool keep_mask = (status != 2) || (err == ERR_NO_TARGETS_IN_MASK); // photometry.py:204 ran before :227
-	TP_PAR_FOR(p, P) t.mask[p] = keep_mask ? k.res[p] : 0;
+	TP_PAR_FOR(p, P) { const uint8_t v = keep_mask ? k.res[p] : 0; k.res[p] = v; t.mask[p] = v; }
 	TP_SERIAL {
 		*t.status = status;
 		*t.flags = flags;
@@ -1327,6 +1355,7 @@ inline TP_DEV void run_target(Shared& k, const Params& prm, const Target& t) {
 		if (t.diag) t.diag[7] = (double)nmasks_total;
 	}
 	TP_SYNC();
+	return status;
 }
 
 } // namespace k2p2

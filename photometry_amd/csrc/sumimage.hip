@@ -9,31 +9,12 @@
 // The good-quality flags are staged once per workgroup in LDS (one byte per cadence).  Each lane
 // keeps a float64 partial sum and an int count; one 64-lane DPP/shuffle reduction per pixel.
 // HBM-bound: algorithmic bytes per target = P*T*4 (images) + T*4 (quality) + P*8 (output).
-#include "common.h"
-#include <cmath>
+#include "sumimage_dev.h"
 
 namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
-
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-	return v;
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-	return v;
-}
-
-__device__ __forceinline__ void acc1(float v, unsigned g, double& s, int& n) {
-	// isfinite(v) && good  (BasePhotometry.py:1011-1015)
-	bool ok = (g != 0u) && (fabsf(v) <= 3.402823466e+38f);
-	s += ok ? (double)v : 0.0;
-	n += ok ? 1 : 0;
-}
 
 template <bool VEC4>
 __global__ __launch_bounds__(kBlock) void tp_sumimage_kernel(
@@ -46,55 +27,32 @@ __global__ __launch_bounds__(kBlock) void tp_sumimage_kernel(
 	const int tid = threadIdx.x;
 	const int lane = tid & 63;
 	const int wave = tid >> 6;
-	const int32_t* q = quality + (int64_t)target * quality_stride;
-	const int n_cad4 = (n_cad + 3) & ~3;
-	for (int k = tid; k < n_cad4; k += kBlock)
-		good[k] = (k < n_cad && ((uint32_t)q[k] & bitmask) == 0u) ? 1 : 0;
+	tp_sum::stage_good(good, quality + (int64_t)target * quality_stride, bitmask, n_cad, tid, kBlock);
 	__syncthreads();
 
 	const float* base = images + (int64_t)target * n_pix * t_pitch;
 	double* o = out + (int64_t)target * n_pix;
 	// optional on-the-fly background subtraction (prepare.py:419-420: float32 image - float32 background)
 	const float* sub = subtract ? (subtract + (int64_t)target * subtract_pitch) : nullptr;
-	const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-	for (int p = wave; p < n_pix; p += kWaves) {
-		const float* row = base + (int64_t)p * t_pitch;
-		double s = 0.0;
-		int n = 0;
-		if (VEC4) {
-			const int nq = n_cad4 >> 2; // quads (the tail quad reads into the row padding: pitch % 4 == 0)
-			const float4* row4 = reinterpret_cast<const float4*>(row);
-			const float4* sub4 = reinterpret_cast<const float4*>(sub);
-			const uint32_t* good4 = reinterpret_cast<const uint32_t*>(good);
-			int qd = lane;
-			// two independent 1 KiB loads in flight per wavefront per iteration
-			for (; qd + 64 < nq; qd += 128) {
-				float4 a = row4[qd];
-				float4 b = row4[qd + 64];
-				const float4 sa = sub ? sub4[qd] : zero4;
-				const float4 sb = sub ? sub4[qd + 64] : zero4;
-				if (sub) { a.x -= sa.x; a.y -= sa.y; a.z -= sa.z; a.w -= sa.w; b.x -= sb.x; b.y -= sb.y; b.z -= sb.z; b.w -= sb.w; }
-				uint32_t ga = good4[qd];
-				uint32_t gb = good4[qd + 64];
-				acc1(a.x, ga & 0xffu, s, n); acc1(a.y, ga & 0xff00u, s, n);
-				acc1(a.z, ga & 0xff0000u, s, n); acc1(a.w, ga & 0xff000000u, s, n);
-				acc1(b.x, gb & 0xffu, s, n); acc1(b.y, gb & 0xff00u, s, n);
-				acc1(b.z, gb & 0xff0000u, s, n); acc1(b.w, gb & 0xff000000u, s, n);
-			}
-			for (; qd < nq; qd += 64) {
-				float4 a = row4[qd];
-				if (sub) { const float4 sa = sub4[qd]; a.x -= sa.x; a.y -= sa.y; a.z -= sa.z; a.w -= sa.w; }
-				uint32_t ga = good4[qd];
-				acc1(a.x, ga & 0xffu, s, n); acc1(a.y, ga & 0xff00u, s, n);
-				acc1(a.z, ga & 0xff0000u, s, n); acc1(a.w, ga & 0xff000000u, s, n);
-			}
-		} else {
-			for (int k = lane; k < n_cad; k += 64) acc1(sub ? (row[k] - sub[k]) : row[k], good[k], s, n);
+	if (VEC4) {
+		// two rows (2 x 1 KiB loads in flight per lane and step) per wavefront and iteration
+		int p = wave * 2;
+		for (; p + 1 < n_pix; p += kWaves * 2) {
+			double m[2];
+			tp_sum::rows_mean_vec4<2>(base, t_pitch, p, sub, good, n_cad, lane, m);
+			if (lane == 0) { o[p] = m[0]; o[p + 1] = m[1]; }
 		}
-		s = wave_sum_f64(s);
-		n = wave_sum_i32(n);
-		if (lane == 0) o[p] = (n > 0) ? s / (double)n : __builtin_nan("");
+		if (p < n_pix) {
+			double m[1];
+			tp_sum::rows_mean_vec4<1>(base, t_pitch, p, sub, good, n_cad, lane, m);
+			if (lane == 0) o[p] = m[0];
+		}
+	} else {
+		for (int p = wave; p < n_pix; p += kWaves) {
+			const double m = tp_sum::row_mean_scalar(base + (int64_t)p * t_pitch, sub, good, n_cad, lane);
+			if (lane == 0) o[p] = m;
+		}
 	}
 }
 

@@ -48,6 +48,9 @@ class DeviceArray(object):
 			self.ctx._check(self.ctx.lib.tp_memset(self.ctx.handle, self.ptr, int(value), self.nbytes))
 
 	def free(self):
+		if getattr(self, '_view', False):
+			self.ptr = None
+			return
 		if self.ptr is not None and self.ctx is not None and self.ctx.handle is not None:
 			self.ctx.lib.tp_free(self.ctx.handle, self.ptr)
 		self.ptr = None
@@ -57,6 +60,19 @@ class DeviceArray(object):
 			self.free()
 		except Exception: # noqa: B902
 			pass
+
+	def slice0(self, start, count):
+		"""Non-owning view of ``count`` entries along the first axis starting at ``start`` (same memory)."""
+		v = DeviceArray.__new__(DeviceArray)
+		v.ctx = self.ctx
+		v.dtype = self.dtype
+		v.shape = (int(count),) + self.shape[1:]
+		row = int(np.prod(self.shape[1:], dtype='int64')) * self.dtype.itemsize
+		v.nbytes = int(count) * row
+		v.ptr = self.ptr + int(start) * row
+		v._view = True
+		v._base = self
+		return v
 
 
 class DeviceCube(object):
@@ -101,14 +117,25 @@ class DeviceCube(object):
 	def free(self):
 		self.data.free()
 
+	def slice0(self, start, count):
+		"""Non-owning view of the targets ``[start, start+count)``."""
+		v = DeviceCube.__new__(DeviceCube)
+		v.ctx = self.ctx
+		v.n_targets, v.n_cad, v.height, v.width, v.t_pitch = int(count), self.n_cad, self.height, self.width, self.t_pitch
+		v.data = self.data.slice0(start, count)
+		return v
+
 
 class Context(object):
 	"""One GPU, one stream.  Not thread-safe (one Context per host thread)."""
 
-	def __init__(self, device=0):
+	def __init__(self, device=0, high_priority=None):
 		self.lib = _lib.load()
 		h = ctypes.c_void_p()
-		rc = self.lib.tp_ctx_create(int(device), ctypes.byref(h))
+		if high_priority is None:
+			rc = self.lib.tp_ctx_create(int(device), ctypes.byref(h))
+		else:
+			rc = self.lib.tp_ctx_create_stream(int(device), 1 if high_priority else 0, ctypes.byref(h))
 		if rc != 0:
 			raise TessphotError(rc, (self.lib.tp_last_error(None) or b'').decode())
 		self.handle = h.value
@@ -157,6 +184,18 @@ class Context(object):
 		return DeviceCube.from_host(self, host)
 
 	# -- timing ------------------------------------------------------------------------------
+	# -- cross-stream events -------------------------------------------------------------------
+	def event(self):
+		e = ctypes.c_void_p()
+		self._check(self.lib.tp_event_create(self.handle, ctypes.byref(e)))
+		return e.value
+
+	def record(self, event):
+		self._check(self.lib.tp_event_record(self.handle, event))
+
+	def wait_event(self, event):
+		self._check(self.lib.tp_stream_wait_event(self.handle, event))
+
 	def timer_start(self, slot=0):
 		self._check(self.lib.tp_timer_start(self.handle, slot))
 

@@ -52,6 +52,13 @@ class LightCurves(object):
 		stride = self.n_targets * self.n_cad * 8
 		self.ptrs = [self.block.ptr + i*stride for i in range(5)]
 
+	def slice0(self, start, count):
+		"""Non-owning view of the light curves of targets ``[start, start+count)`` (same block)."""
+		v = LightCurves.__new__(LightCurves)
+		v.ctx, v.n_targets, v.n_cad, v.block = self.ctx, int(count), self.n_cad, None
+		v.ptrs = [p + int(start) * self.n_cad * 8 for p in self.ptrs]
+		return v
+
 	def to_host(self):
 		b = self.block.to_host()
 		lc = {name: b[i] for i, name in enumerate(self.COLUMNS)}
@@ -149,6 +156,42 @@ def k2p2_masks(ctx, batch, work, cut_override=None, params=None):
 		batch.target_pos_row.ptr, batch.target_pos_column.ptr, batch.target_tmag.ptr, batch.target_starid.ptr,
 		batch.stamps.ptr, batch.aperture.ptr, _ptr(cut_override), None if params is None else ctypes.byref(params),
 		work.mask.ptr, work.status.ptr, work.flags.ptr, work.contamination.ptr, work.diag.ptr, work.cat_in_mask.ptr))
+	return work
+
+
+def aperture_photometry(ctx, batch, work, bitmask=TESS_DEFAULT_BITMASK, subtract=None, backgrounds=None, params=None):
+	"""
+	A1 + A2..A5b + A7 + A6 in one launch (photometry.py:75-257 for every target of the batch): fills
+	``work.sumimage, mask, status, flags, contamination, diag, cat_in_mask, lc``.
+	``backgrounds`` / ``subtract`` as in :func:`aperture_extract` (default: ``batch.backgrounds``).
+	"""
+	images, images_err = batch.images, batch.images_err
+	backgrounds = batch.backgrounds if backgrounds is None else backgrounds
+	desc = images.desc
+	assert images_err.t_pitch == images.t_pitch and images_err.data.shape == images.data.shape
+	if isinstance(backgrounds, DeviceCube):
+		assert backgrounds.t_pitch == images.t_pitch and backgrounds.data.shape == images.data.shape
+		bkg_mode, bpitch = 0, 0
+	else:
+		assert backgrounds.dtype == np.float32 and backgrounds.shape[0] == images.n_targets
+		bkg_mode, bpitch = 1, backgrounds.shape[1]
+	quality = batch.quality
+	if len(quality.shape) == 1:
+		assert quality.shape[0] >= images.n_cad
+		qstride = 0
+	else:
+		assert quality.shape[0] == images.n_targets and quality.shape[1] >= images.n_cad
+		qstride = quality.shape[1]
+	lc = work.lc
+	ctx._check(ctx.lib.tp_aperture_photometry(ctx.handle, ctypes.byref(desc), images.ptr, images_err.ptr, backgrounds.ptr, bkg_mode, bpitch,
+		_ptr(subtract), 0 if subtract is None else subtract.shape[1],
+		quality.ptr, qstride, int(bitmask),
+		batch.cat_offsets.ptr, batch.cat_column_stamp.ptr, batch.cat_row_stamp.ptr, batch.cat_tmag.ptr,
+		batch.cat_column.ptr, batch.cat_row.ptr, batch.cat_starid.ptr,
+		batch.target_pos_row.ptr, batch.target_pos_column.ptr, batch.target_tmag.ptr, batch.target_starid.ptr,
+		batch.stamps.ptr, batch.aperture.ptr, None if params is None else ctypes.byref(params),
+		work.sumimage.ptr, work.mask.ptr, work.status.ptr, work.flags.ptr, work.contamination.ptr, work.diag.ptr, work.cat_in_mask.ptr,
+		lc.ptrs[0], lc.ptrs[1], lc.ptrs[2], lc.ptrs[3], lc.ptrs[4], lc.n_cad))
 	return work
 
 

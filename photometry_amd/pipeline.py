@@ -60,6 +60,24 @@ class ApertureBatch(object):
 			ap = np.ones((self.n_targets, self.height, self.width), dtype='int32')
 		self.aperture = ctx.array(np.asarray(ap, dtype='int32'))
 
+	#: per-target arrays (sliced by :meth:`chunk`); the flat catalogue arrays are shared because the
+	#: CSR offsets are absolute
+	_PER_TARGET = ('images', 'images_err', 'backgrounds', 'stamps', 'target_pos_row', 'target_pos_column',
+		'target_tmag', 'target_starid', 'aperture')
+
+	def chunk(self, start, count):
+		"""Non-owning view of the targets ``[start, start+count)`` (same HBM)."""
+		v = ApertureBatch.__new__(ApertureBatch)
+		v.__dict__.update(self.__dict__)
+		for name in self._PER_TARGET:
+			a = getattr(self, name)
+			setattr(v, name, None if a is None else a.slice0(start, count))
+		v.cat_offsets = self.cat_offsets.slice0(start, count + 1)
+		if len(self.quality.shape) == 2:
+			v.quality = self.quality.slice0(start, count)
+		v.n_targets = int(count)
+		return v
+
 
 class ApertureWork(object):
 	"""Device-resident outputs / scratch of the aperture pipeline (allocated once, reused per step)."""
@@ -80,19 +98,33 @@ class ApertureWork(object):
 			self.bkg_raw = ctx.zeros((Nt, pitch), 'float32')
 			self.bkg = ctx.zeros((Nt, pitch), 'float32')
 
+	def chunk(self, start, count):
+		"""Non-owning view of the targets ``[start, start+count)`` (same HBM)."""
+		v = ApertureWork.__new__(ApertureWork)
+		v.__dict__.update(self.__dict__)
+		for name in ('sumimage', 'mask', 'status', 'flags', 'contamination', 'diag', 'lc', 'bkg_raw', 'bkg'):
+			a = getattr(self, name)
+			setattr(v, name, None if a is None else a.slice0(start, count))
+		return v
 
-def aperture_step(ctx, batch, work, masks_from=None):
+
+def aperture_step(ctx, batch, work, masks_from=None, fused=True):
 	"""
 	One pass of the aperture hot path over the batch; everything stays in HBM.
 
+	``fused``: one launch with a wavefront per target (``tp_aperture_photometry``); ``False`` runs the three
+	stand-alone kernels A1, K2P2, A6 back to back (bit-identical outputs).
 	``masks_from``: optional ``(mask uint8 DeviceArray, status int32 DeviceArray)`` to bypass the
-	on-device K2P2 (used by tests that inject the oracle's masks).
+	on-device K2P2 (used by tests that inject the oracle's masks; implies the stand-alone kernels).
 	"""
 	subtract, backgrounds = None, batch.backgrounds
 	if batch.raw_mode:
 		engine.background_stamp(ctx, batch.images, out=work.bkg_raw)                           # B*
 		engine.smooth_time(ctx, work.bkg_raw, batch.n_cad, batch.time_smooth, out=work.bkg)    # B2
 		subtract = backgrounds = work.bkg                                                      # B3 on the fly
+	if fused and masks_from is None:
+		engine.aperture_photometry(ctx, batch, work, subtract=subtract, backgrounds=backgrounds)   # A1..A7
+		return work
 	engine.sumimage(ctx, batch.images, batch.quality, out=work.sumimage, subtract=subtract)    # A1
 	if masks_from is None:
 		engine.k2p2_masks(ctx, batch, work)                                                    # A2..A5b, A7
