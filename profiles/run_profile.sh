@@ -14,7 +14,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REP
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log
 cd $REPO
 find $OUT -name "*.csv" | head -20
-python3 profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
+python3 profiles/summarize.py $OUT $OUT/traffic.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # keep only small files in the merged output
 find $OUT -name "*.csv" -size +8M -delete
