@@ -104,14 +104,16 @@ __device__ __forceinline__ void local_merge(float (&v)[64], bool desc) {
 }
 
 constexpr int kFramesPerWave = 16;
-constexpr int kFramesPerBlock = 64;
+constexpr int kBkgThreads = 128;
+constexpr int kFramesPerBlock = kFramesPerWave * (kBkgThreads / 64);
 
 __device__ __forceinline__ double quad_sum(double x) { x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); return x; }
 __device__ __forceinline__ float quad_sum(float x) { x += quad_xor1(x); x += quad_xor2(x); return x; }
 __device__ __forceinline__ int quad_sum(int x) { x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); return x; }
 
-__global__ __launch_bounds__(256) void tp_bkg_stamp_kernel(BkgArgs a)
+__global__ __launch_bounds__(kBkgThreads) void tp_bkg_stamp_kernel(BkgArgs a, int frame_stride)
 {
+	extern __shared__ __align__(16) float s_sorted[]; // [waves][kFramesPerWave][frame_stride]
 	const int target = blockIdx.x;
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63;
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(256) void tp_bkg_stamp_kernel(BkgArgs a)
 	const bool active = k < a.n_cad;
 	const float* base = a.raw + (int64_t)target * a.n_pix * a.t_pitch + (active ? k : 0);
 	const float inf = __builtin_inff();
+	float* fr = s_sorted + (size_t)(wave * kFramesPerWave + f) * frame_stride;
 	float v[64];
 	int n = 0;
 #pragma unroll
@@ -143,15 +146,34 @@ __global__ __launch_bounds__(256) void tp_bkg_stamp_kernel(BkgArgs a)
 	cross_stage<1>(v, (q & 1) == 0);                    // size 256, stride 64
 	local_merge(v, false);                              // size 256, strides 32..1
 
-	// --- sigma clipping on the sorted registers.  The kept set is always the contiguous rank range
-	// [lo_i, hi_i): sums are predicated passes over the lane's 64 registers + a quad reduction, the new
-	// bounds come from COUNTING the values beyond the thresholds (sortedness), the median element is
-	// picked by rank.  No LDS, no divergence inside a pass; all four lanes of a quad carry the same scalars.
+	// --- sigma clipping.  The kept set is always a contiguous rank range [lo_i, hi_i) of the sorted values.  One
+	// predicated pass over the lane's 64 registers gives the float64 sums of the whole frame; the sorted values are
+	// then staged in LDS (1 KiB per frame) where they can be indexed by rank: the median is two reads, the new bounds
+	// are two binary searches for the float32-exact thresholds, and the sums are UPDATED by subtracting only the
+	// ranks that leave the range (shared by the four lanes of the quad) -- a few dozen LDS reads per clipping pass
+	// instead of two 64-register passes of float64 arithmetic.  All four lanes of a quad carry the same scalars.
+	// A wavefront stages and reads only its own 16 frames and its LDS operations execute in order: no workgroup
+	// barrier.  Only the ranks below frame_stride are staged (ranks >= n_pix are +inf sentinels nobody reads).
+#pragma unroll
+	for (int j = 0; j < 64; j += 4)
+		if (q * 64 + j < frame_stride) *reinterpret_cast<float4*>(fr + q * 64 + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
 	const int nmasked = a.n_pix - n;
 	const bool usable = active && (n > 0) && !((float)nmasked > a.exclude_fraction * (float)a.n_pix);
+	const int rbase = q * 64;
+	double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+	for (int j = 0; j < 64; ++j) {
+		const bool in = (rbase + j) < n;              // ranks >= n are the +inf sentinels
+		float xf = in ? v[j] : 0.f;
+		asm volatile("" : "+v"(xf));   // keep the conversion in the loop (else 64 doubles stay live)
+		const double x = (double)xf;
+		s1 += x;
+		s2 = __builtin_fma(x, x, s2);
+	}
+	s1 = quad_sum(s1); s2 = quad_sum(s2);
+	__builtin_amdgcn_wave_barrier();
 	float result = __builtin_nanf("");
 	if (usable) {
-		const int rbase = q * 64;
 		int lo_i = 0, hi_i = n;
 		double med = 0.0, mean = 0.0, sd = 0.0;
 #pragma unroll 1
@@ -159,23 +181,7 @@ __global__ __launch_bounds__(256) void tp_bkg_stamp_kernel(BkgArgs a)
 			const int m = hi_i - lo_i;
 			const int m1 = lo_i + (m >> 1);          // upper middle rank
 			const int m0 = (m & 1) ? m1 : (m1 - 1);  // lower middle rank
-			const int off = rbase - lo_i, l0 = m0 - rbase, l1 = m1 - rbase;
-			double s1 = 0.0, s2 = 0.0;
-			float e0 = 0.f, e1 = 0.f;
-#pragma unroll
-			for (int j = 0; j < 64; ++j) {
-				const bool in = (unsigned)(j + off) < (unsigned)m;      // lo_i <= rank < hi_i
-				float xf = in ? v[j] : 0.f;
-				asm volatile("" : "+v"(xf));   // keep the conversion in the loop (else 64 doubles stay live across iterations)
-				const double x = (double)xf;
-				s1 += x;
-				s2 = __builtin_fma(x, x, s2);
-				e0 = (j == l0) ? v[j] : e0;
-				e1 = (j == l1) ? v[j] : e1;
-			}
-			s1 = quad_sum(s1); s2 = quad_sum(s2);
-			e0 = quad_sum(e0); e1 = quad_sum(e1);
-			med = ((double)e0 + (double)e1) / 2.0;
+			med = ((double)fr[m0] + (double)fr[m1]) / 2.0;
 			mean = s1 / (double)m;
 			double var = s2 / (double)m - mean * mean;
 			if (var < 0.0) var = 0.0;
@@ -184,18 +190,25 @@ __global__ __launch_bounds__(256) void tp_bkg_stamp_kernel(BkgArgs a)
 			// exact float32 thresholds: for float x, (double)x < lo <=> x < round_up(lo); (double)x > hi <=> x > round_down(hi)
 			const float lo_f = __double2float_ru(med - 3.0 * sd);
 			const float hi_f = __double2float_rd(med + 3.0 * sd);
-			int cnt_lt = 0, cnt_gt = 0;
+			// new_lo = first rank in range whose value is >= lo_f, new_hi = first rank whose value is > hi_f
+			int a0 = lo_i, b0 = hi_i, a1 = lo_i, b1 = hi_i;
 #pragma unroll
-			for (int j = 0; j < 64; ++j) {
-				cnt_lt += (v[j] < lo_f) ? 1 : 0;
-				cnt_gt += (v[j] > hi_f) ? 1 : 0;
+			for (int step = 0; step < 8; ++step) {     // the range holds at most 256 ranks
+				const int mid0 = (a0 + b0) >> 1, mid1 = (a1 + b1) >> 1;
+				const float x0 = fr[(a0 < b0) ? mid0 : lo_i], x1 = fr[(a1 < b1) ? mid1 : lo_i];
+				if (a0 < b0) { if (x0 < lo_f) a0 = mid0 + 1; else b0 = mid0; }
+				if (a1 < b1) { if (x1 > hi_f) b1 = mid1; else a1 = mid1 + 1; }
 			}
-			cnt_lt = quad_sum(cnt_lt);
-			cnt_gt = quad_sum(cnt_gt) - (256 - n);     // the +inf sentinels
-			// sorted: the values < lo are the first cnt_lt ranks, the values > hi the last cnt_gt ranks of [0, n)
-			const int new_lo = (cnt_lt > lo_i) ? cnt_lt : lo_i;
-			const int new_hi = (n - cnt_gt < hi_i) ? (n - cnt_gt) : hi_i;
+			if (a0 < b0) { if (fr[(a0 + b0) >> 1] < lo_f) a0 = ((a0 + b0) >> 1) + 1; else b0 = (a0 + b0) >> 1; }
+			if (a1 < b1) { if (fr[(a1 + b1) >> 1] > hi_f) b1 = (a1 + b1) >> 1; else a1 = ((a1 + b1) >> 1) + 1; }
+			const int new_lo = a0, new_hi = a1;
 			if (new_lo == lo_i && new_hi == hi_i) break; // nchanged == 0: the statistics of this range are final
+			// subtract the ranks that leave the range: [lo_i, new_lo) and [new_hi, hi_i), one of every four per lane
+			double r1 = 0.0, r2 = 0.0;
+			for (int r = lo_i + q; r < new_lo; r += 4) { const double x = (double)fr[r]; r1 += x; r2 = __builtin_fma(x, x, r2); }
+			for (int r = new_hi + q; r < hi_i; r += 4) { const double x = (double)fr[r]; r1 += x; r2 = __builtin_fma(x, x, r2); }
+			r1 = quad_sum(r1); r2 = quad_sum(r2);
+			s1 -= r1; s2 -= r2;
 			lo_i = new_lo;
 			hi_i = new_hi;
 		}
@@ -351,8 +364,12 @@ extern "C" int tp_background_stamp(tp_ctx* ctx, const tp_cube_desc* desc, const 
 	a.t_pitch = desc->t_pitch; a.out_pitch = bkg_pitch;
 	a.flux_cutoff = (float)flux_cutoff; a.exclude_fraction = (float)(exclude_percentile / 100.0);
 	if (a.n_pix <= 256) {
-		dim3 block(256), grid((unsigned)desc->n_targets, (unsigned)((desc->n_cad + kFramesPerBlock - 1) / kFramesPerBlock));
-		TP_LAUNCH(ctx, TPK_BKG_STAMP, tp_bkg_stamp_kernel, grid, block, 0, a);
+		// staged frame: the ranks that can hold a value, 16-byte aligned rows, +4 floats so that consecutive frames
+		// start 4 banks apart
+		const int frame_stride = ((a.n_pix + 3) & ~3) + 4;
+		const size_t shmem = (size_t)kFramesPerBlock * frame_stride * sizeof(float);
+		dim3 block(kBkgThreads), grid((unsigned)desc->n_targets, (unsigned)((desc->n_cad + kFramesPerBlock - 1) / kFramesPerBlock));
+		TP_LAUNCH(ctx, TPK_BKG_STAMP, tp_bkg_stamp_kernel, grid, block, shmem, a, frame_stride);
 	} else {
 		int np2 = 1;
 		while (np2 < a.n_pix) np2 <<= 1;
