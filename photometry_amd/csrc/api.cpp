@@ -16,6 +16,7 @@ static const char* const kKernelNames[TPK_COUNT] = {
 	"tp_bkg_subtract_kernel",
 	"tp_linpsf_prf_kernel",
 	"tp_linpsf_fit_kernel",
+	"tp_linpsf_fit_direct_kernel",
 	"tp_linpsf_finalize_kernel",
 	"tp_synth_kernel",
 };
@@ -105,6 +106,7 @@ int tp_ctx_destroy(tp_ctx* ctx) {
 	(void)hipStreamSynchronize(ctx->stream);
 	(void)tp_comm_destroy(ctx);
 	if (ctx->twiddle) (void)hipFree(ctx->twiddle);
+	if (ctx->scratch) (void)hipFree(ctx->scratch);
 	for (int k = 0; k < TPK_COUNT; k++)
 		for (auto& p : ctx->pending[k]) {
 			(void)hipEventDestroy(p.first);

@@ -21,6 +21,7 @@ enum tp_kernel_id {
 	TPK_BKG_SUBTRACT,
 	TPK_LINPSF_PRF,
 	TPK_LINPSF_FIT,
+	TPK_LINPSF_FIT_DIRECT,
 	TPK_LINPSF_FIN,
 	TPK_SYNTH,
 	TPK_COUNT
@@ -39,6 +40,8 @@ struct tp_ctx {
 	int64_t prof_n[TPK_COUNT] = {};
 	double prof_ms[TPK_COUNT] = {};
 	void* twiddle = nullptr;    // device table of the K2P2 128-point DFT (k2p2.hip)
+	void* scratch = nullptr;    // grow-only device scratch owned by the context (linpsf.hip)
+	size_t scratch_bytes = 0;
 	void* comm = nullptr;       // ncclComm_t (comm.cpp)
 	int comm_rank = 0, comm_size = 1;
 

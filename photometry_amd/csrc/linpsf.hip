@@ -200,11 +200,15 @@ __device__ __forceinline__ double prf_pixel(const double* __restrict__ C, int n,
 	return acc;
 }
 
-template <int S>
-__global__ __launch_bounds__(512) void tp_linpsf_fit_kernel(FitArgs a)
+// General path: direct evaluation of the 13x13 contraction per star, pixel and cadence.  Runs only for the
+// targets that tp_linpsf_fit_kernel could not take (`todo` flag set, or todo == nullptr).
+template <int S, int SLO>
+__global__ __launch_bounds__(512) void tp_linpsf_fit_direct_kernel(FitArgs a, const int32_t* __restrict__ todo)
 {
 	extern __shared__ __align__(16) double lds[]; // [n*n] coefficient table + 2 x [n+4] knots
 	const int target = blockIdx.x;
+	if (todo && !todo[target]) return;
+	{ const int nst = (int)(a.star_offsets[target + 1] - a.star_offsets[target]); if (nst < SLO || nst > S) return; } // another instantiation's targets
 	const int tid = threadIdx.x;
 	const int n = a.n;
 	double* C = lds;
@@ -301,6 +305,310 @@ __global__ __launch_bounds__(512) void tp_linpsf_fit_kernel(FitArgs a)
 	a.flux_err[(int64_t)target * a.out_pitch + k] = __builtin_nan("");
 }
 
+//--------------------------------------------------------------------------------------------------
+// Fast path.  For a fixed table origin (ax0, by0) -- i.e. fixed knot intervals of the star's sub-pixel phase --
+// the pixel-integrated PRF of a pixel is a BIQUARTIC polynomial of the two phases (phi_x, phi_y): the 13 edge
+// weights of an axis are the quartics below.  So per workgroup (one target, <= 512 cadences) the kernel
+//   A. finds, per fitted star, the rectangle of origins (ax0, by0) its cadences visit (jitter spans a few knot
+//      intervals) and, stamp row by stamp row, contracts the LDS-resident coefficient table into the 25
+//      polynomial coefficients K[a][b] of every (star, origin, pixel) of the row (separable: 13x13 + 5x13 FMAs
+//      per column b, one thread per (item, b));
+//   B. lets every thread (= cadence) evaluate its stars' PRF values of the row by Horner (24 FMAs and 25 LDS reads
+//      per star and pixel instead of 169 LDS reads and ~230 flops) and accumulate the normal equations.
+// The arithmetic differs from the direct contraction only by rounding (1e-15 relative).  A workgroup whose stars
+// visit more origins than the LDS buffer holds flags its target for the general kernel.
+//--------------------------------------------------------------------------------------------------
+// coefficients (powers 0..4 of phi) of the 13 pixel-edge weights [1-m3, 1-m2, 1-m1, 1-m0, 1,1,1,1,1, m3, m2, m1, m0]
+__constant__ double kEdgePoly[13][5] = {
+	{1.0 / 24.0, -1.0 / 6.0, 0.25, -1.0 / 6.0, 1.0 / 24.0},
+	{0.5, -2.0 / 3.0, 0.0, 1.0 / 3.0, -0.125},
+	{23.0 / 24.0, -1.0 / 6.0, -0.25, -1.0 / 6.0, 0.125},
+	{1.0, 0.0, 0.0, 0.0, -1.0 / 24.0},
+	{1.0, 0.0, 0.0, 0.0, 0.0}, {1.0, 0.0, 0.0, 0.0, 0.0}, {1.0, 0.0, 0.0, 0.0, 0.0}, {1.0, 0.0, 0.0, 0.0, 0.0}, {1.0, 0.0, 0.0, 0.0, 0.0},
+	{23.0 / 24.0, 1.0 / 6.0, -0.25, 1.0 / 6.0, -1.0 / 24.0},
+	{0.5, 2.0 / 3.0, 0.0, -1.0 / 3.0, 0.125},
+	{1.0 / 24.0, 1.0 / 6.0, 0.25, 1.0 / 6.0, -0.125},
+	{0.0, 0.0, 0.0, 0.0, 1.0 / 24.0},
+};
+
+// phase and table origin of one axis (same arithmetic as axis_weights); false for a NaN / absurd position
+__device__ __forceinline__ bool axis_phase(const double* kn, int n, double pos, double h, double& phi, int& first)
+{
+	phi = 0.0; first = 4;
+	if (!(fabs(pos) < 1e6)) return false;
+	const int jstar = (int)rint(pos);
+	const double x0 = ((double)jstar - pos) - 0.5;
+	int l = 4 + (int)floor((x0 - kn[4]) / h);
+	if (l < 4) l = 4;
+	if (l > n - 2) l = n - 2;
+	if (x0 < kn[l] && l > 4) --l;
+	else if (x0 >= kn[l + 1] && l < n - 2) ++l;
+	phi = (x0 - kn[l]) / (kn[l + 1] - kn[l]);
+	first = (l - 3) - 9 * jstar;
+	return true;
+}
+
+struct StarBox { int axmin, axmax, bymin, bymax, jmin, jmax, imin, imax; };
+
+template <int S, int SLO>
+__global__ __launch_bounds__(S <= 2 ? 1024 : 512) void tp_linpsf_fit_kernel(FitArgs a, int kcap, int32_t* __restrict__ todo)
+{
+	{ const int nst = (int)(a.star_offsets[blockIdx.x + 1] - a.star_offsets[blockIdx.x]); if (nst < SLO || nst > S) return; } // another instantiation's targets
+	extern __shared__ __align__(16) double lds[]; // table [n*n], knots 2 x [n+4], K buffer [kcap*25], then ints
+	const int target = blockIdx.x;
+	const int tid = threadIdx.x;
+	const int nthreads = blockDim.x;
+	const int n = a.n;
+	double* C = lds;
+	double* kn = lds + (size_t)n * n;
+	double* kny = kn + n + 4;
+	double* Kbuf = kny + n + 4;
+	StarBox* sbox = reinterpret_cast<StarBox*>(Kbuf + (size_t)kcap * 25);
+	int* s_flag = reinterpret_cast<int*>(sbox + kMaxStars); // [0] general-kernel flag, [1] chunk width
+	const double* cg = a.coef + (int64_t)target * n * n;
+	for (int i0 = 0; i0 < n * n; i0 += 8 * nthreads) {
+		double tmp[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) { const int i = i0 + u * nthreads + tid; tmp[u] = (i < n * n) ? cg[i] : 0.0; }
+#pragma unroll
+		for (int u = 0; u < 8; ++u) { const int i = i0 + u * nthreads + tid; if (i < n * n) C[i] = tmp[u]; }
+	}
+	for (int i = tid; i < n + 4; i += nthreads) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
+	// the table is loaded once; the workgroup then walks the cadences in passes of blockDim.x
+	const int npass = (a.n_cad + nthreads - 1) / nthreads;
+	for (int pass = 0; pass < npass; ++pass) {
+	__syncthreads(); // table / knots visible; previous pass done with the star boxes and the K buffer
+	if (tid < kMaxStars) {
+		sbox[tid].axmin = sbox[tid].bymin = sbox[tid].jmin = sbox[tid].imin = 0x7fffffff;
+		sbox[tid].axmax = sbox[tid].bymax = sbox[tid].jmax = sbox[tid].imax = -0x7fffffff;
+	}
+	if (tid == 0) *s_flag = 0;
+	__syncthreads();
+
+	const int k = pass * nthreads + tid;
+	const bool active = k < a.n_cad;
+	const int64_t s0 = a.star_offsets[target];
+	int ns = (int)(a.star_offsets[target + 1] - s0);
+	if (ns > S) ns = S; // host guarantees ns <= S for this instantiation
+	const int H = a.height, W = a.width;
+	const double h = kn[5] - kn[4], hy = kny[5] - kny[4];
+	const double cutoff = a.cutoff;
+
+	double phx[S], phy[S], srow[S], scol[S];
+	int ax0[S], by0[S];
+	bool valid[S];
+#pragma unroll
+	for (int s = 0; s < S; ++s) {
+		valid[s] = false; phx[s] = phy[s] = 0.0; srow[s] = scol[s] = 0.0; ax0[s] = by0[s] = 4;
+		if (s < ns && active) {
+			srow[s] = a.pos_row[(s0 + s) * a.pos_pitch + k];
+			scol[s] = a.pos_col[(s0 + s) * a.pos_pitch + k];
+			// x <-> column (first spline axis), y <-> row  (psf.py:146)
+			const bool vx = axis_phase(kn, n, scol[s], h, phx[s], ax0[s]);
+			const bool vy = axis_phase(kny, n, srow[s], hy, phy[s], by0[s]);
+			valid[s] = vx && vy;
+			if (valid[s]) {
+				atomicMin(&sbox[s].axmin, ax0[s]); atomicMax(&sbox[s].axmax, ax0[s]);
+				atomicMin(&sbox[s].bymin, by0[s]); atomicMax(&sbox[s].bymax, by0[s]);
+				// pixels that can be inside the cut-off of this cadence (strict test below): a conservative box
+				atomicMin(&sbox[s].jmin, (int)floor(scol[s] - cutoff)); atomicMax(&sbox[s].jmax, (int)ceil(scol[s] + cutoff));
+				atomicMin(&sbox[s].imin, (int)floor(srow[s] - cutoff)); atomicMax(&sbox[s].imax, (int)ceil(srow[s] + cutoff));
+			}
+		}
+	}
+	__syncthreads();
+	if (tid == 0) {
+		int tot = 0;
+		for (int s = 0; s < kMaxStars; ++s) {
+			StarBox& b = sbox[s];
+			if (s >= ns || b.axmax < b.axmin) { b.axmax = b.axmin - 1; b.bymax = b.bymin - 1; b.jmax = b.jmin - 1; b.imax = b.imin - 1; continue; }
+			if (b.jmin < 0) b.jmin = 0;
+			if (b.jmax > W - 1) b.jmax = W - 1;
+			if (b.imin < 0) b.imin = 0;
+			if (b.imax > H - 1) b.imax = H - 1;
+			tot += (b.axmax - b.axmin + 1) * (b.bymax - b.bymin + 1);
+		}
+		if (tot > kcap) *s_flag = 1; // even one stamp column of K does not fit: general kernel
+		// widest column chunk whose items fit the buffer whatever the row (uniform for the whole workgroup)
+		int wc = W;
+		for (; wc > 1; --wc) {
+			int items = 0;
+			for (int s = 0; s < kMaxStars; ++s) {
+				const StarBox& b = sbox[s];
+				const int ncols = b.jmax - b.jmin + 1;
+				items += (b.axmax - b.axmin + 1) * (b.bymax - b.bymin + 1) * (ncols < wc ? ncols : wc);
+			}
+			if (items <= kcap) break;
+		}
+		s_flag[1] = wc;
+	}
+	__syncthreads();
+	if (*s_flag) { // the general kernel redoes the whole target
+		if (tid == 0) todo[target] = 1;
+		return;
+	}
+	// per star: number of origins, this thread's origin index
+	int nc[S], cc[S], nby[S];
+#pragma unroll
+	for (int s = 0; s < S; ++s) {
+		const StarBox b = sbox[s];
+		nby[s] = b.bymax - b.bymin + 1;
+		nc[s] = (b.axmax - b.axmin + 1) * nby[s];
+		cc[s] = valid[s] ? ((ax0[s] - b.axmin) * nby[s] + (by0[s] - b.bymin)) : 0;
+	}
+
+	double G[S][S], g[S];
+#pragma unroll
+	for (int i = 0; i < S; ++i) { g[i] = 0.0;
+#pragma unroll
+		for (int j = 0; j < S; ++j) G[i][j] = 0.0; }
+
+	const float* img = a.images + (int64_t)target * H * W * a.t_pitch + (active ? k : 0);
+	const float sub = (a.subtract && active) ? a.subtract[(int64_t)target * a.subtract_pitch + k] : 0.f;
+	const double h2 = h * hy;
+	const int wc = s_flag[1];
+	int bjmin[S], bjmax[S], bimin[S], bimax[S], baxmin[S], bbymin[S];
+#pragma unroll
+	for (int s = 0; s < S; ++s) {
+		const StarBox b = sbox[s];
+		bjmin[s] = b.jmin; bjmax[s] = b.jmax; bimin[s] = b.imin; bimax[s] = b.imax; baxmin[s] = b.axmin; bbymin[s] = b.bymin;
+	}
+	for (int i = 0; i < H; ++i) {
+		for (int j0 = 0; j0 < W; j0 += wc) {
+			// ---- plan of the chunk = columns [j0, j1) of row i, computed identically by every thread (no serial step):
+			// per star the columns of its box inside the chunk and the offset of its items in the K buffer
+			const int j1 = (j0 + wc < W) ? (j0 + wc) : W;
+			int off[S], jlo[S], jhi[S];
+			int nitems = 0;
+#pragma unroll
+			for (int s = 0; s < S; ++s) {
+				const bool rowin = (i >= bimin[s]) && (i <= bimax[s]);
+				jlo[s] = (bjmin[s] > j0) ? bjmin[s] : j0;
+				jhi[s] = (bjmax[s] < j1 - 1) ? bjmax[s] : (j1 - 1);
+				if (!rowin) { jlo[s] = 0; jhi[s] = -1; }
+				off[s] = nitems;
+				if (jhi[s] >= jlo[s]) nitems += (jhi[s] - jlo[s] + 1) * nc[s];
+			}
+			if (nitems == 0) continue; // no star near this chunk: its pixels do not enter the normal equations
+			int jfirst = j1, jlast = j0 - 1; // union of the stars' columns: the other pixels have an all-zero design row
+			double dr2[S];
+#pragma unroll
+			for (int s = 0; s < S; ++s) {
+				if (jhi[s] >= jlo[s]) { jfirst = (jlo[s] < jfirst) ? jlo[s] : jfirst; jlast = (jhi[s] > jlast) ? jhi[s] : jlast; }
+				const double dr = (double)i - srow[s];
+				dr2[s] = dr * dr;
+			}
+			const int jend = jlast + 1;
+			// the chunk's pixels of this cadence: a ring of four loads stays in flight (issued here, before the coefficient
+			// phase, and refilled as the pixels are consumed); indices clamp instead of branching
+			const float* prow = img + (int64_t)(i * W) * a.t_pitch;
+			auto pix_load = [&](int j) { j = (j < jend) ? j : (jend - 1); return prow[(int64_t)j * a.t_pitch]; };
+			float p0 = pix_load(jfirst), p1 = pix_load(jfirst + 1), p2 = pix_load(jfirst + 2), p3 = pix_load(jfirst + 3);
+			// ---- A: polynomial coefficients of every (star, column, origin) item of this row chunk
+			for (int w = tid; w < nitems * 5; w += nthreads) {
+				int item = w / 5;
+				const int bcol = w - item * 5;
+				int offs = 0, jlos = 0, ncs = 1, nbys = 1, axm = 0, bym = 0;
+#pragma unroll
+				for (int u = 0; u < S; ++u) if (jhi[u] >= jlo[u] && item >= off[u]) { offs = off[u]; jlos = jlo[u]; ncs = nc[u]; nbys = nby[u]; axm = baxmin[u]; bym = bbymin[u]; }
+				const int rel = item - offs;
+				const int jj = rel / ncs, co = rel - jj * ncs;
+				const int cx = co / nbys, cy = co - cx * nbys;
+				const int j = jlos + jj;
+				int ax = (axm + cx) + 9 * j, by = (bym + cy) + 9 * i;
+				ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
+				by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
+				double yb[13];
+#pragma unroll
+				for (int q = 0; q < 13; ++q) yb[q] = kEdgePoly[q][bcol];
+				double kk[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+				const double* c0 = C + (int64_t)ax * n + by;
+#pragma unroll
+				for (int p = 0; p < 13; ++p) {
+					const double* r = c0 + p * n;
+					double t = 0.0;
+#pragma unroll
+					for (int q = 0; q < 13; ++q) t = __builtin_fma(yb[q], r[q], t);
+#pragma unroll
+					for (int e = 0; e < 5; ++e) kk[e] = __builtin_fma(kEdgePoly[p][e], t, kk[e]);
+				}
+				double* dst = Kbuf + (size_t)item * 25 + bcol;
+#pragma unroll
+				for (int e = 0; e < 5; ++e) dst[e * 5] = h2 * kk[e];
+			}
+			__syncthreads();
+			// ---- B: this cadence's design-matrix row values of the chunk's pixels, normal equations
+			if (active) {
+				auto consume = [&](float pv, int j) {
+					if (j >= jend) return;
+					float bf = pv;
+					if (a.subtract) bf = bf - sub;
+					if (!(fabsf(bf) <= 3.402823466e+38f)) return; // good_pixels = isfinite(img) (linpsf_photometry.py:123)
+					const double b = (double)bf;
+					double av[S];
+#pragma unroll
+					for (int s = 0; s < S; ++s) {
+						av[s] = 0.0;
+						if (s < ns && valid[s] && j >= jlo[s] && j <= jhi[s]) {
+							const double dc = (double)j - scol[s];
+							// psf.py:142  sqrt((j-col)^2 + (i-row)^2) < cutoff_radius; the squares decide unless they are within
+							// rounding of each other, then the reference's own expression does
+							const double d2 = dc * dc + dr2[s], c2 = cutoff * cutoff;
+							const bool inside = (fabs(d2 - c2) > 1e-9 * c2) ? (d2 < c2) : (sqrt(d2) < cutoff);
+							if (inside) {
+								const double* kp = Kbuf + (size_t)(off[s] + (j - jlo[s]) * nc[s] + cc[s]) * 25;
+								double val = 0.0;
+#pragma unroll
+								for (int e = 4; e >= 0; --e) {
+									double inner = kp[e * 5 + 4];
+#pragma unroll
+									for (int d = 3; d >= 0; --d) inner = __builtin_fma(inner, phy[s], kp[e * 5 + d]);
+									val = __builtin_fma(val, phx[s], inner);
+								}
+								av[s] = val;
+							}
+						}
+					}
+#pragma unroll
+					for (int s = 0; s < S; ++s) {
+						g[s] += av[s] * b;
+#pragma unroll
+						for (int u = 0; u < S; ++u) if (u >= s) G[s][u] += av[s] * av[u];
+					}
+				};
+				for (int jb = jfirst; jb < jend; jb += 4) {
+					consume(p0, jb); p0 = pix_load(jb + 4);
+					consume(p1, jb + 1); p1 = pix_load(jb + 5);
+					consume(p2, jb + 2); p2 = pix_load(jb + 6);
+					consume(p3, jb + 3); p3 = pix_load(jb + 7);
+				}
+			}
+			__syncthreads();
+		}
+	}
+	if (active) {
+#pragma unroll
+	for (int s = 0; s < S; ++s)
+#pragma unroll
+		for (int u = 0; u < S; ++u) if (u < s) G[s][u] = G[u][s];
+
+	double x[S];
+	pinv_solve<S>(G, g, ns, x);
+	const int ti = a.target_index[target];
+	double tf = __builtin_nan("");
+#pragma unroll
+	for (int s = 0; s < S; ++s) {
+		if (s < ns) {
+			a.fluxes_all[(s0 + s) * a.out_pitch + k] = x[s];
+			if (s == ti) tf = x[s];
+		}
+	}
+	a.flux[(int64_t)target * a.out_pitch + k] = tf;
+	a.flux_err[(int64_t)target * a.out_pitch + k] = __builtin_nan("");
+	}
+	} // pass
+}
+
 // Finalise (linpsf_photometry.py:197-219): mean fitted fluxes over the cadences with a valid target
 // flux, contamination from the design matrix of the LAST cadence, status.
 struct FinArgs {
@@ -308,9 +616,10 @@ struct FinArgs {
 	double* contamination; int32_t* status; double* fluxes_mean;
 };
 
-template <int S>
+template <int S, int SLO>
 __global__ __launch_bounds__(256) void tp_linpsf_finalize_kernel(FinArgs fa)
 {
+	{ const int nst = (int)(fa.f.star_offsets[blockIdx.x + 1] - fa.f.star_offsets[blockIdx.x]); if (nst < SLO || nst > S) return; } // another instantiation's targets
 	extern __shared__ __align__(16) double lds[];
 	const FitArgs& a = fa.f;
 	const int target = blockIdx.x;
@@ -466,17 +775,39 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	dim3 grid((unsigned)desc->n_targets, (unsigned)nblk), block((unsigned)threads);
 	const size_t shmem_fin = shmem + 256 * sizeof(double);
 	FinArgs fa; fa.f = a; fa.contamination = d_contamination; fa.status = d_status; fa.fluxes_mean = d_fluxes_mean;
-#define TP_LINPSF_LAUNCH(SS) do { \
-		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_kernel<SS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-		TP_LAUNCH(ctx, TPK_LINPSF_FIT, tp_linpsf_fit_kernel<SS>, grid, block, shmem, a); \
+	// fast path: whatever LDS the table leaves holds the K buffer (25 doubles per item); (target, block) pairs whose
+	// stars visit more table origins than fit are flagged and redone by the general kernel
+	const size_t tail = kMaxStars * sizeof(StarBox) + 64;
+	int kcap = (int)(((size_t)160 * 1024 - shmem - tail) / (25 * sizeof(double)));
+	if (kcap > 1024) kcap = 1024;
+	TP_REQUIRE(ctx, kcap >= 16, "tp_linpsf_fit: coefficient table leaves no LDS for the polynomial buffer");
+	const size_t shmem_fast = shmem + (size_t)kcap * 25 * sizeof(double) + tail;
+	const size_t todo_bytes = (size_t)desc->n_targets * sizeof(int32_t);
+	// fast kernel: up to 1024 (2-star class, 128 VGPRs suffice) or 512 threads (= cadences) per pass, the passes balanced
+	auto fast_block = [&](int maxthreads) { const int np = (desc->n_cad + maxthreads - 1) / maxthreads; return dim3((unsigned)((((desc->n_cad + np - 1) / np) + 63) / 64 * 64)); };
+	if (ctx->scratch_bytes < todo_bytes) {
+		if (ctx->scratch) TP_HIP(ctx, hipFree(ctx->scratch));
+		ctx->scratch = nullptr; ctx->scratch_bytes = 0;
+		TP_HIP(ctx, hipMalloc(&ctx->scratch, todo_bytes));
+		ctx->scratch_bytes = todo_bytes;
+	}
+	int32_t* d_todo = static_cast<int32_t*>(ctx->scratch);
+	TP_HIP(ctx, hipMemsetAsync(d_todo, 0, todo_bytes, ctx->stream));
+#define TP_LINPSF_LAUNCH(SS, SL) do { \
+		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_kernel<SS, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_fast)); \
+		TP_LAUNCH(ctx, TPK_LINPSF_FIT, (tp_linpsf_fit_kernel<SS, SL>), dim3((unsigned)desc->n_targets), fast_block(SS <= 2 ? 1024 : 512), shmem_fast, a, kcap, d_todo); \
 		TP_LAUNCH_CHECK(ctx, "tp_linpsf_fit_kernel"); \
-		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_finalize_kernel<SS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_fin)); \
-		TP_LAUNCH(ctx, TPK_LINPSF_FIN, tp_linpsf_finalize_kernel<SS>, dim3((unsigned)desc->n_targets), dim3(256), shmem_fin, fa); \
+		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_direct_kernel<SS, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+		TP_LAUNCH(ctx, TPK_LINPSF_FIT_DIRECT, (tp_linpsf_fit_direct_kernel<SS, SL>), grid, block, shmem, a, (const int32_t*)d_todo); \
+		TP_LAUNCH_CHECK(ctx, "tp_linpsf_fit_direct_kernel"); \
+		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_finalize_kernel<SS, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_fin)); \
+		TP_LAUNCH(ctx, TPK_LINPSF_FIN, (tp_linpsf_finalize_kernel<SS, SL>), dim3((unsigned)desc->n_targets), dim3(256), shmem_fin, fa); \
 		TP_LAUNCH_CHECK(ctx, "tp_linpsf_finalize_kernel"); \
 	} while (0)
-	if (max_stars <= 2) TP_LINPSF_LAUNCH(2);
-	else if (max_stars <= 4) TP_LINPSF_LAUNCH(4);
-	else TP_LINPSF_LAUNCH(8);
+	// one instantiation per star-count class; a workgroup whose target belongs to another class exits at once
+	TP_LINPSF_LAUNCH(2, 0);
+	if (max_stars > 2) TP_LINPSF_LAUNCH(4, 3);
+	if (max_stars > 4) TP_LINPSF_LAUNCH(8, 5);
 #undef TP_LINPSF_LAUNCH
 	return TP_OK;
 	TP_API_END(ctx)
