@@ -44,12 +44,18 @@ def test_prf_blend_matches_reference_construction(ctx):
 		np.testing.assert_array_equal(model.tx, ref.tx)
 
 
-@pytest.mark.parametrize("max_neigh,T,H,W", [(3, 40, 11, 11), (1, 70, 15, 15), (6, 16, 13, 12)])
-def test_linpsf_matches_oracle(ctx, max_neigh, T, H, W):
+# jitter scale 1: sigma 0.02 px (a few table origins per star: polynomial fast path, whole rows per chunk);
+# 6: sigma 0.12 px (dozens of origins: the K buffer forces column chunks); 30: sigma 0.6 px (more origins than the
+# buffer holds: the target is flagged and redone by the general direct kernel); 1300+ cadences: several passes
+@pytest.mark.parametrize("max_neigh,T,H,W,jit", [(3, 40, 11, 11, 1), (1, 70, 15, 15, 1), (6, 16, 13, 12, 1),
+	(3, 40, 11, 11, 6), (2, 33, 15, 15, 30), (1, 1301, 9, 9, 1), (3, 1100, 9, 9, 2)])
+def test_linpsf_matches_oracle(ctx, max_neigh, T, H, W, jit):
 	from photometry_amd import simulate, engine, psf as hpsf
 	from photometry_amd.device import DeviceCube
 	from oracle import psf as opsf, linpsf as olin
-	s = simulate.make_scene(6, T, H, W, seed=50 + max_neigh, max_neighbours=max_neigh, neighbour_tmag_range=(9.0, 17.0))
+	nt = 6 if T < 1000 else 2
+	s = simulate.make_scene(nt, T, H, W, seed=50 + max_neigh, max_neighbours=max_neigh, neighbour_tmag_range=(9.0, 17.0))
+	s.jitter = s.jitter * jit
 	simulate.fill_cubes(s, nan_fraction=0.01)
 	s.images[0, :, :, 3] = np.nan       # a frame without a single good pixel -> flux 0 (pinv of a zero matrix)
 	prf = opsf.synthetic_prf(seed=7)
