@@ -100,11 +100,12 @@ def main_linpsf(args, ctx, rank, world, dist, torch, device_sync, barrier):
 	prof = ctx.profile_report()
 	if rank == 0:
 		nfit = batch.n_fit_stars
-		# FP64 flops of the fit kernel: per fitted star-cadence ~79 pixels inside the 5 px cut-off x (169 + 13) x 2
+		# ALGORITHMIC FP64 flops of the fit (the reference's direct contraction): per fitted star-cadence ~79 pixels inside
+		# the 5 px cut-off x (169 + 13) multiply-adds.  The kernel's polynomial path executes about 8x fewer.
 		flops = nfit * T * 79 * 182 * 2.0
-		kernels = {name: {'launches': n, 'avg_ms': ms / n} for name, (n, ms) in prof.items()}
-		fit = kernels['tp_linpsf_fit_kernel']
-		fit['fp64_TFLOPs'] = flops / (fit['avg_ms'] * 1e-3) / 1e12
+		kernels = {name: {'launches': n, 'avg_ms': ms / n, 'ms_per_step': ms / args.steps} for name, (n, ms) in prof.items()}
+		fit = kernels['tp_linpsf_fit_kernel']  # one launch per star-count class: the step's fit time is their sum
+		fit['fp64_TFLOPs'] = flops / (fit['ms_per_step'] * 1e-3) / 1e12
 		result = {
 			'metric': 'targets/sec (whole node), 10k targets x 1300 cad x 15x15, linpsf_photometry PSF fit',
 			'value': Nt * world * args.steps / elapsed, 'unit': 'targets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -113,7 +114,8 @@ def main_linpsf(args, ctx, rank, world, dist, torch, device_sync, barrier):
 			'config': {'workload': f'{Nt} targets/GPU x {T} cadences x {H}x{W} stamps, LinPSF fit of {nfit} stars (P1 table blend + P2-P4), '
 				'image cube resident in HBM', 'fitted_stars': int(nfit)},
 			'roofline': {'kernel': 'tp_linpsf_fit_kernel', 'bound': 'fp64-valu', 'achieved': fit['fp64_TFLOPs'], 'peak': 78.6, 'unit': 'TFLOP/s',
-				'frac': fit['fp64_TFLOPs'] / 78.6, 'traffic': None, 'avg_kernel_ms': fit['avg_ms']},
+				'frac': fit['fp64_TFLOPs'] / 78.6, 'traffic': None, 'kernel_ms_per_step': fit['ms_per_step'],
+				'note': 'achieved = algorithmic flops of the direct 13x13 contraction / time; the polynomial fast path does ~8x fewer'},
 			'kernels': kernels,
 		}
 		if world == 1 and args.cpu_sample > 0:
