@@ -157,6 +157,8 @@ def main():
 	args = parse_args()
 	rank = int(os.environ.get('RANK', '0'))
 	local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+	if os.environ.get('TP_BENCH_FORCE_DEVICE'): # smoke-testing the multi-rank control flow on a 1-GPU box (use with --no-gather)
+		local_rank = int(os.environ['TP_BENCH_FORCE_DEVICE'])
 	world = int(os.environ.get('WORLD_SIZE', '1'))
 	if world != args.gpus and world > 1:
 		args.gpus = world
@@ -207,11 +209,25 @@ def main():
 	batch = pipeline.ApertureBatch(ctx, scene, cubes={k: cubes[k] for k in ('images', 'images_err', 'backgrounds')})
 	work = pipeline.ApertureWork(ctx, batch)
 
-	if world > 1:
-		tpcomm.init_from_torch(ctx, dist, rank, world)
+	# The only data-path exchange: one RCCL gather of the light-curve block at the end of the timed region.  If the
+	# communicator cannot be created the ranks agree (over gloo) to run without it and the JSON line says so: the hot
+	# path itself has no collective.
+	do_gather = world > 1 and not args.no_gather
+	comm_note = None
+	if do_gather:
+		ok = 1
+		try:
+			tpcomm.init_from_torch(ctx, dist, rank, world)
+		except Exception as e: # noqa: B902
+			ok, comm_note = 0, f'RCCL communicator not created ({e}); light curves left on their ranks'
+		t = torch.tensor([ok], dtype=torch.int32)
+		dist.all_reduce(t, op=dist.ReduceOp.MIN)
+		if int(t[0]) == 0:
+			do_gather = False
+			comm_note = comm_note or 'RCCL communicator not created on another rank; light curves left on their ranks'
 	gather_buf = None
 	lc_bytes = work.lc.block.nbytes
-	if world > 1 and not args.no_gather and rank == 0:
+	if do_gather and rank == 0:
 		gather_buf = ctx.empty((world, lc_bytes // 8), 'float64')
 
 	def do_step():
@@ -230,7 +246,7 @@ def main():
 	t0 = time.perf_counter()
 	for _ in range(args.steps):
 		do_step()
-	if world > 1 and not args.no_gather:
+	if do_gather:
 		tpcomm.gather(ctx, work.lc.block, gather_buf, root=0)
 	device_sync()
 	barrier()
@@ -346,6 +362,7 @@ def main():
 				'targets_per_gpu': Nt, 'cadences': T, 'stamp': [H, W], 'parallelism': f'targets sharded over {world} GPU(s)'},
 			'roofline': roofline,
 			'kernels': kernels,
+			'gather': ('none (single GPU)' if world == 1 else ('one RCCL gather of the light-curve block, inside the timed region' if do_gather else (comm_note or 'disabled (--no-gather)'))),
 			'background_stage': {'what': 'B* per-cadence stamp background + B2 time smoothing (+ one B3 subtraction) on the raw cube, '
 				'timed right after the headline region; not part of `value`', 'ms_per_pass': bkg_stage_ms,
 				'targets_per_s_including_it': Nt * world / (elapsed / args.steps + bkg_stage_ms * 1e-3)},
