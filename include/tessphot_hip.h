@@ -256,6 +256,28 @@ int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
 	double* d_flux, double* d_flux_err, double* d_fluxes_all, int64_t out_pitch,
 	double* d_contamination, int32_t* d_status, double* d_fluxes_mean);
 
+/* ---- light-curve diagnostics ---------------------------------------------
+ * replaces the diagnostics block of BasePhotometry.photometry (photometry/BasePhotometry.py:1343-1407)
+ * and utilities.rms_timescale (photometry/utilities.py:227-264) for a batch of light curves: the
+ * reductions whose results the scheduler stores in its `diagnostics` table (taskmanager.py:543-563).
+ *   d_flux, d_flux_err, d_centroid_col, d_centroid_row: float64 [n_targets][lc_pitch] (the outputs of
+ *            tp_aperture_extract / tp_aperture_photometry);  d_time: float64 [n_cad] (days);
+ *   d_quality / stride / bitmask as in tp_sumimage ("good" cadences, TESSQualityFlags.filter);
+ *   d_status: optional int32 [n_targets]; only TP_STATUS_OK / TP_STATUS_WARNING targets are processed
+ *            (all outputs NaN otherwise), like the `if self._status in (OK, WARNING)` of :1343;
+ *   d_sumimage / d_mask (both or neither): for mask_size and edge_flux (:1394-1403);
+ *   timescale_days: bin width of rms_hour (the reference uses 3600/86400);
+ *   d_diag: float64 [n_targets][10] = mean_flux, variance, rms_hour, ptp, pos_centroid column, row,
+ *            variability, mask_size, edge_flux, flags.  flags (as a float64 integer): 1 all fluxes NaN, 2 all
+ *            errors NaN (both ValueError upstream, :1346-1349), 4 invalid time vector (ValueError in
+ *            rms_timescale), 8 no detrending ("Could not detrend ..." warning: detrend = 0), 16 more
+ *            time bins than the LDS buffer holds (rms_hour = NaN).                                     */
+int tp_lightcurve_diagnostics(tp_ctx* ctx, int32_t n_targets, int32_t n_cad,
+	const double* d_flux, const double* d_flux_err, const double* d_centroid_col, const double* d_centroid_row, int64_t lc_pitch,
+	const double* d_time, const int32_t* d_quality, int64_t quality_target_stride, uint32_t bitmask,
+	const int32_t* d_status, const double* d_sumimage, const uint8_t* d_mask, int32_t height, int32_t width,
+	double timescale_days, double* d_diag);
+
 /* ---- multi-GPU: the final light-curve gather (RCCL over xGMI) --------------------------------
  * replaces the pickled result messages of run_tessphot_mpi.py:114-132,163-191: targets are
  * statically sharded over the ranks (one process per GPU) and the only data-path exchange is one

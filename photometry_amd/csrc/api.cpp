@@ -18,6 +18,7 @@ static const char* const kKernelNames[TPK_COUNT] = {
 	"tp_linpsf_fit_kernel",
 	"tp_linpsf_fit_direct_kernel",
 	"tp_linpsf_finalize_kernel",
+	"tp_diagnostics_kernel",
 	"tp_synth_kernel",
 };
 

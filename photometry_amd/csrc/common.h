@@ -23,6 +23,7 @@ enum tp_kernel_id {
 	TPK_LINPSF_FIT,
 	TPK_LINPSF_FIT_DIRECT,
 	TPK_LINPSF_FIN,
+	TPK_DIAGNOSTICS,
 	TPK_SYNTH,
 	TPK_COUNT
 };

@@ -195,6 +195,30 @@ def aperture_photometry(ctx, batch, work, bitmask=TESS_DEFAULT_BITMASK, subtract
 	return work
 
 
+#: columns of the diagnostics block (BasePhotometry.py:1357-1403)
+DIAGNOSTICS_COLUMNS = ('mean_flux', 'variance', 'rms_hour', 'ptp', 'pos_centroid_col', 'pos_centroid_row', 'variability',
+	'mask_size', 'edge_flux', 'flags')
+
+
+def lightcurve_diagnostics(ctx, lc, time, quality, status=None, sumimage=None, mask=None, bitmask=TESS_DEFAULT_BITMASK,
+	timescale=3600/86400, out=None):
+	"""
+	Light-curve diagnostics of a batch (BasePhotometry.py:1343-1407, utilities.py:227-264).
+	``lc``: :class:`LightCurves`; ``time``: float64 DeviceArray ``(T,)``; ``quality`` as in :func:`sumimage`.
+	Returns float64 DeviceArray ``(Nt, 10)`` with the columns :data:`DIAGNOSTICS_COLUMNS`.
+	"""
+	Nt, T = lc.n_targets, lc.n_cad
+	if out is None:
+		out = ctx.empty((Nt, 10), 'float64')
+	qstride = 0 if len(quality.shape) == 1 else quality.shape[1]
+	H = W = 0
+	if mask is not None:
+		H, W = int(mask.shape[1]), int(mask.shape[2])
+	ctx._check(ctx.lib.tp_lightcurve_diagnostics(ctx.handle, Nt, T, lc.ptrs[0], lc.ptrs[1], lc.ptrs[3], lc.ptrs[4], lc.n_cad,
+		time.ptr, quality.ptr, qstride, int(bitmask), _ptr(status), _ptr(sumimage), _ptr(mask), H, W, float(timescale), out.ptr))
+	return out
+
+
 class LinPSFResult(object):
 	"""Device-resident outputs of the LinPSF pipeline."""
 	def __init__(self, ctx, n_targets, n_fit_stars, n_cad):

@@ -38,6 +38,7 @@ class ApertureBatch(object):
 		self.time_smooth = {1800: 3, 600: 9}.get(int(round(getattr(scene, 'cadence_s', 1800))), 3) # prepare.py:258
 		q = np.asarray(scene.quality, dtype='int32')
 		self.quality = ctx.array(q)
+		self.time = ctx.array(np.asarray(scene.time, dtype='float64'))
 		self.stamps = ctx.array(np.asarray(scene.stamps, dtype='int32'))
 		self.n_targets = self.images.n_targets
 		self.n_cad = self.images.n_cad
@@ -92,6 +93,7 @@ class ApertureWork(object):
 		self.diag = ctx.zeros((Nt, 8), 'float64')
 		self.cat_in_mask = ctx.zeros((max(int(batch.scene.cat_offsets[-1]), 1),), 'uint8')
 		self.lc = engine.LightCurves(ctx, Nt, T)
+		self.diagnostics = ctx.zeros((Nt, 10), 'float64')
 		self.bkg_raw = self.bkg = None
 		if batch.raw_mode:
 			pitch = batch.images.t_pitch
@@ -102,7 +104,7 @@ class ApertureWork(object):
 		"""Non-owning view of the targets ``[start, start+count)`` (same HBM)."""
 		v = ApertureWork.__new__(ApertureWork)
 		v.__dict__.update(self.__dict__)
-		for name in ('sumimage', 'mask', 'status', 'flags', 'contamination', 'diag', 'lc', 'bkg_raw', 'bkg'):
+		for name in ('sumimage', 'mask', 'status', 'flags', 'contamination', 'diag', 'lc', 'diagnostics', 'bkg_raw', 'bkg'):
 			a = getattr(self, name)
 			setattr(v, name, None if a is None else a.slice0(start, count))
 		return v
@@ -136,12 +138,22 @@ def aperture_step(ctx, batch, work, masks_from=None, fused=True):
 	return work
 
 
-def run_aperture(ctx, scene, cubes='host', masks=None):
+def aperture_diagnostics(ctx, batch, work, status=None, mask=None):
+	"""
+	The light-curve diagnostics of the batch (BasePhotometry.py:1343-1407) from the device-resident outputs of
+	:func:`aperture_step`; fills ``work.diagnostics`` ``(Nt, 10)`` (columns ``engine.DIAGNOSTICS_COLUMNS``).
+	"""
+	engine.lightcurve_diagnostics(ctx, work.lc, batch.time, batch.quality, status=work.status if status is None else status,
+		sumimage=work.sumimage, mask=work.mask if mask is None else mask, out=work.diagnostics)
+	return work.diagnostics
+
+
+def run_aperture(ctx, scene, cubes='host', masks=None, diagnostics=True):
 	"""
 	Convenience: upload (or adopt device cubes), run one :func:`aperture_step`, download.
 
 	Returns a dict of host arrays: ``sumimage, mask, status, flags, contamination, diag, cat_in_mask,
-	flux, flux_err, flux_background, pos_centroid``.
+	flux, flux_err, flux_background, pos_centroid, diagnostics``.
 	"""
 	batch = ApertureBatch(ctx, scene, cubes=cubes)
 	work = ApertureWork(ctx, batch)
@@ -151,8 +163,14 @@ def run_aperture(ctx, scene, cubes='host', masks=None):
 		st = ctx.array(np.ones(batch.n_targets, dtype='int32'))
 		masks_from = (m, st)
 	aperture_step(ctx, batch, work, masks_from=masks_from)
+	if diagnostics and masks_from is None:
+		aperture_diagnostics(ctx, batch, work)
+	elif diagnostics:
+		aperture_diagnostics(ctx, batch, work, status=masks_from[1], mask=masks_from[0])
 	ctx.sync()
 	out = work.lc.to_host()
+	if diagnostics:
+		out['diagnostics'] = work.diagnostics.to_host()
 	out['sumimage'] = work.sumimage.to_host()
 	if batch.raw_mode:
 		out['background'] = work.bkg.to_host()[:, :batch.n_cad]

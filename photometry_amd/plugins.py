@@ -515,6 +515,7 @@ class _OneTargetScene(object):
 		self.images_err = cubes['images_err'][None]
 		self.backgrounds = cubes['backgrounds'][None]
 		self.quality = np.asarray(pho.lightcurve['quality'], dtype='int32')
+		self.time = np.asarray(pho.lightcurve['time'], dtype='float64')
 		self.stamps = np.asarray([pho._stamp], dtype='int32')
 		cat = pho.catalog
 		self.cat_offsets = np.array([0, len(cat)], dtype='int64')
@@ -550,7 +551,7 @@ class AperturePhotometry(BasePhotometry):
 		res = None
 		for retries in range(allow_retries):
 			scene = _OneTargetScene(self)
-			res = pipeline.run_aperture(ctx, scene, cubes='host')
+			res = pipeline.run_aperture(ctx, scene, cubes='host', diagnostics=False) # photometry() below computes them like the reference
 			self._sumimage = res['sumimage'][0]
 			# bit 0 of the aperture image needs the sum image of THIS stamp (BasePhotometry.py:1043)
 			flags = int(res['flags'][0])

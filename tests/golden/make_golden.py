@@ -22,6 +22,9 @@ Fixtures:
 * ``golden_psf.npz``      ``PSF.integrate_to_image`` (psf.py:122-148) on a synthetic spline
 * ``golden_linpsf.npz``   ``lsfit`` and ``LinPSFPhotometry.do_photometry``
                           (linpsf_photometry.py:22-34, 79-219)
+* ``golden_diagnostics.npz`` ``BasePhotometry.photometry`` (BasePhotometry.py:1337-1407): the light-curve
+                          diagnostics the scheduler stores, from the reference's own code run on light curves
+                          produced by its own ``AperturePhotometry.do_photometry``
 """
 
 import os
@@ -281,6 +284,72 @@ def golden_aperture():
 
 
 #--------------------------------------------------------------------------------------------------
+class FakeLC(object):
+	"""Minimal astropy-Table stand-in for ``self.lightcurve``: column access by name, row subset by boolean mask."""
+	def __init__(self, cols):
+		self.cols = cols
+
+	def __getitem__(self, key):
+		if isinstance(key, str):
+			return self.cols[key]
+		return FakeLC({k: v[key] for k, v in self.cols.items()})
+
+	def __setitem__(self, key, value):
+		self.cols[key] = value
+
+
+def golden_diagnostics():
+	"""BasePhotometry.photometry() executed for real: do_photometry (prescribed masks) + the diagnostics block."""
+	H, W, T = 11, 11, 96
+	scene = simulate.make_scene(8, T, H, W, seed=33)
+	simulate.fill_cubes(scene, nan_fraction=0.01)
+	# 30-minute cadence with a gap and a few flagged cadences: the one-hour bins of rms_timescale are non-trivial
+	scene.time = 1325.0 + np.arange(T) * (1800.0 / 86400.0)
+	scene.time[60:] += 0.9
+	scene.quality[:] = 0
+	scene.quality[[5, 6, 40, 77]] = 32      # desaturation (in the default bitmask)
+	scene.quality[[10]] = 16                # not in the default bitmask: stays a good cadence
+	from oracle import sumimage as osum
+	S = osum.sumimage_batch(scene.images, scene.quality)
+	out = {'time': scene.time, 'quality': scene.quality, 'sumimage': S, 'n_cases': scene.n_targets}
+	for i in range(scene.n_targets):
+		cat = scene.catalog_of(i)
+		c = np.column_stack((cat['column_stamp'], cat['row_stamp'], cat['tmag']))
+		mm, _ = ok2p2.k2p2FixFromSum(S[i], catalog=c, thresh=0.8, min_no_pixels_in_mask=4, min_for_cluster=4,
+			cluster_radius=np.sqrt(2) + np.finfo(np.float64).eps, segmentation=True, ws_blur=0.5, ws_thres=0,
+			ws_footprint=3, extend_overflow=True)
+		if i == 5: # a mask that touches the stamp edge: edge_flux != 0
+			mm = np.zeros((1, H, W)); mm[0, 0:7, 2:9] = 1
+		if i == 6: # NaN fluxes in some cadences (a NaN pixel inside the mask)
+			main = np.asarray(mm, dtype=bool)[0]
+			rr, cc = np.argwhere(main)[0]
+			scene.images[i, rr, cc, [3, 20, 21, 50]] = np.nan
+		f = make_fake(AperturePhotometry, scene, i, S[i])
+		f.lightcurve = FakeLC(f.lightcurve)
+		f._status = STATUS.UNKNOWN
+
+		def fake_k2p2(SumImage, _mm=mm, **kwargs):
+			return np.array(_mm, dtype='float64'), 1.0
+		ap_module.k2p2.k2p2FixFromSum = fake_k2p2
+		with warnings.catch_warnings():
+			warnings.simplefilter('ignore')
+			BasePhotometry.photometry(f)
+		d = f._details
+		lc = f.lightcurve
+		out[f'case{i}_status'] = f._status.value
+		out[f'case{i}_flux'] = np.asarray(lc['flux'])
+		out[f'case{i}_flux_err'] = np.asarray(lc['flux_err'])
+		out[f'case{i}_pos_centroid'] = np.asarray(lc['pos_centroid'])
+		out[f'case{i}_mask'] = np.asarray(f.final_phot_mask, dtype=bool)
+		for key in ('mean_flux', 'variance', 'rms_hour', 'ptp', 'variability', 'mask_size', 'edge_flux'):
+			out[f'case{i}_{key}'] = np.float64(d[key])
+		out[f'case{i}_det_pos_centroid'] = np.asarray(d['pos_centroid'], dtype='float64')
+		print('diagnostics case', i, f._status, {k: d[k] for k in ('mean_flux', 'variance', 'rms_hour', 'ptp', 'variability', 'mask_size', 'edge_flux')})
+	ap_module.k2p2.k2p2FixFromSum = k2p2v2.k2p2FixFromSum
+	np.savez_compressed(os.path.join(HERE, 'golden_diagnostics.npz'), **out)
+
+
+#--------------------------------------------------------------------------------------------------
 def golden_k2p2():
 	"""Reference k2p2FixFromSum control flow with stand-ins (partial oracle)."""
 	out = {}
@@ -435,6 +504,6 @@ def golden_linpsf():
 
 
 if __name__ == '__main__':
-	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf']
+	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics']
 	for w in which:
 		globals()['golden_' + w]()

@@ -136,3 +136,12 @@ def test_batch_api(ctx):
 		assert r.status in (STATUS.OK, STATUS.WARNING, STATUS.ERROR)
 		if r.status != STATUS.ERROR:
 			assert r.lightcurve['flux'].shape == (30,) and r._details['mask_size'] == r.final_phot_mask.sum()
+			# the batch carries the same diagnostics as the per-target plugin (host code mirroring BasePhotometry.py:1343-1407)
+			with AperturePhotometry(int(s.target_starid[i]), source_from_scene(s, i), '/tmp', datasource='ffi', ctx=ctx) as pho:
+				pho.photometry()
+				assert pho.status == r.status
+				for key in ('mean_flux', 'ptp', 'edge_flux'):
+					assert r._details[key] == pho._details[key], key
+				for key in ('variance', 'rms_hour', 'variability'):
+					np.testing.assert_allclose(r._details[key], pho._details[key], rtol=1e-9, err_msg=key)
+				np.testing.assert_array_equal(r._details['pos_centroid'], pho._details['pos_centroid'])

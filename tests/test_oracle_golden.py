@@ -143,3 +143,19 @@ def test_linpsf(golden_dir):
 		np.testing.assert_allclose(res['flux'], g[f'lp{n}_flux'], rtol=1e-9)
 		assert np.all(np.isnan(res['flux_err']))
 		np.testing.assert_allclose(res['contamination'], float(g[f'lp{n}_contamination']), rtol=1e-8, atol=1e-12)
+
+
+def test_diagnostics_golden(golden_dir):
+	"""oracle.diagnostics vs the reference's own BasePhotometry.photometry() (BasePhotometry.py:1343-1407)."""
+	from oracle import diagnostics as odiag
+	g = np.load(os.path.join(golden_dir, 'golden_diagnostics.npz'))
+	for i in range(int(g['n_cases'])):
+		assert int(g[f'case{i}_status']) in (1, 3)
+		d = odiag.diagnostics(g['time'], g['quality'], g[f'case{i}_flux'], g[f'case{i}_flux_err'], g[f'case{i}_pos_centroid'],
+			sumimage=g['sumimage'][i], mask=g[f'case{i}_mask'])
+		assert d['flags'] == 0
+		for key in ('mean_flux', 'ptp', 'mask_size', 'edge_flux'):
+			assert d[key] == float(g[f'case{i}_{key}']), key                      # selections / integer / same summation: exact
+		for key in ('variance', 'rms_hour', 'variability'):
+			np.testing.assert_allclose(d[key], float(g[f'case{i}_{key}']), rtol=1e-12, err_msg=key)
+		np.testing.assert_array_equal([d['pos_centroid_col'], d['pos_centroid_row']], g[f'case{i}_det_pos_centroid'])
