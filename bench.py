@@ -293,6 +293,19 @@ def main():
 	ctx.profile(False)
 	prof_bkg = ctx.profile_report()
 
+	# ---- the light-curve diagnostics of the batch, timed the same way; not part of `value`
+	ctx.profile(True)
+	ctx.profile_reset()
+	pipeline.aperture_diagnostics(ctx, batch, work)
+	device_sync()
+	td0 = time.perf_counter()
+	for _ in range(3):
+		pipeline.aperture_diagnostics(ctx, batch, work)
+	device_sync()
+	diag_stage_ms = (time.perf_counter() - td0) / 3 * 1e3
+	ctx.profile(False)
+	prof_bkg.update(ctx.profile_report())
+
 	result = None
 	if rank == 0:
 		total_targets = Nt * world * args.steps
@@ -366,6 +379,8 @@ def main():
 			'background_stage': {'what': 'B* per-cadence stamp background + B2 time smoothing (+ one B3 subtraction) on the raw cube, '
 				'timed right after the headline region; not part of `value`', 'ms_per_pass': bkg_stage_ms,
 				'targets_per_s_including_it': Nt * world / (elapsed / args.steps + bkg_stage_ms * 1e-3)},
+			'diagnostics_stage': {'what': 'light-curve diagnostics of every target (mean flux, variance, rms_hour, ptp, centroid, variability, '
+				'mask size, edge flux: BasePhotometry.py:1343-1407) from the device-resident outputs; not part of `value`', 'ms_per_pass': diag_stage_ms},
 		}
 
 		if prof_serial is not None:

@@ -37,61 +37,91 @@ enum { F_ALLNAN_FLUX = 1, F_ALLNAN_ERR = 2, F_BAD_TIME = 4, F_NO_DETREND = 8, F_
 __device__ __forceinline__ bool is_nan(double x) { return x != x; }
 __device__ __forceinline__ bool is_finite(double x) { return fabs(x) <= 1.7976931348623157e308; }
 
-// fixed-shape tree reductions over the workgroup (every thread gets the result)
-__device__ double block_sum(double v, double* red) {
+// fixed-shape reductions over the workgroup (every thread gets the result): a shuffle tree inside each wavefront,
+// then the four partial results in wavefront order -- deterministic, two barriers
+template <class OP>
+__device__ __forceinline__ double block_reduce(double v, double* red, OP op) {
 	const int tid = threadIdx.x;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_down(v, off, 64));
+	__syncthreads(); // the previous result in red[] has been consumed
+	if ((tid & 63) == 0) red[tid >> 6] = v;
 	__syncthreads();
-	red[tid] = v;
-	__syncthreads();
-	for (int s = kThreads / 2; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-	return red[0];
+	double r = red[0];
+#pragma unroll
+	for (int w = 1; w < kThreads / 64; ++w) r = op(r, red[w]);
+	return r;
 }
-__device__ double block_min(double v, double* red) {
-	const int tid = threadIdx.x;
-	__syncthreads();
-	red[tid] = v;
-	__syncthreads();
-	for (int s = kThreads / 2; s > 0; s >>= 1) { if (tid < s) { const double o = red[tid + s]; if (o < red[tid]) red[tid] = o; } __syncthreads(); }
-	return red[0];
-}
-__device__ double block_max(double v, double* red) {
-	const int tid = threadIdx.x;
-	__syncthreads();
-	red[tid] = v;
-	__syncthreads();
-	for (int s = kThreads / 2; s > 0; s >>= 1) { if (tid < s) { const double o = red[tid + s]; if (o > red[tid]) red[tid] = o; } __syncthreads(); }
-	return red[0];
+__device__ double block_sum(double v, double* red) { return block_reduce(v, red, [](double x, double y) { return x + y; }); }
+__device__ double block_min(double v, double* red) { return block_reduce(v, red, [](double x, double y) { return (y < x) ? y : x; }); }
+__device__ double block_max(double v, double* red) { return block_reduce(v, red, [](double x, double y) { return (y > x) ? y : x; }); }
+
+// order-preserving map double -> uint64 (negative values: all bits flipped, others: sign bit set)
+__device__ __forceinline__ unsigned long long sort_key(double x) {
+	const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+	return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
-// nanmedian of srt[0..m): NaN entries must already be +inf; returns NaN when no value is left.
-__device__ double block_median(double* srt, int m, double* red) {
+// nanmedian of v[0..m) (LDS, not modified) by an 8-pass radix SELECT on the 64-bit keys: per pass one 256-bin LDS
+// histogram of the digit among the candidates that share the prefix found so far, one wavefront picks the bin that
+// holds the wanted rank.  A few hundred cycles per pass instead of the 66 barrier-separated stages of a bitonic sort.
+// `hist` is a 260-entry LDS scratch.  Returns NaN when every entry is NaN.
+__device__ double block_median(const double* v, int m, double* red, unsigned int* hist) {
 	const int tid = threadIdx.x;
-	__syncthreads();
-	int p2 = 1;
-	while (p2 < m) p2 <<= 1;
-	int cnt = 0;
-	for (int i = tid; i < p2; i += kThreads) {
-		if (i >= m) srt[i] = __builtin_inf();
-		else if (!is_nan(srt[i])) cnt++;
-		if (i < m && is_nan(srt[i])) srt[i] = __builtin_inf();
-	}
-	const int n = (int)block_sum((double)cnt, red);
-	for (int size = 2; size <= p2; size <<= 1) {
-		for (int stride = size >> 1; stride > 0; stride >>= 1) {
-			for (int t = tid; t < p2 / 2; t += kThreads) {
-				const int lo = (t / stride) * (stride * 2) + (t % stride);
-				const int hi = lo + stride;
-				const bool up = ((lo & size) == 0);
-				const double x = srt[lo], y = srt[hi];
-				if ((x > y) == up) { srt[lo] = y; srt[hi] = x; }
-			}
-			__syncthreads();
+	int c = 0;
+	for (int i = tid; i < m; i += kThreads) c += !is_nan(v[i]);
+	const int n = (int)block_sum((double)c, red);
+	if (n == 0) return __builtin_nan("");
+	const int k_lo = (n - 1) >> 1, k_hi = n >> 1;
+	unsigned long long prefix = 0ull, pmask = 0ull;
+	int k = k_lo;
+	for (int pass = 7; pass >= 0; --pass) {
+		const int shift = pass * 8;
+		hist[tid] = 0u;
+		__syncthreads();
+		for (int i = tid; i < m; i += kThreads) {
+			const double x = v[i];
+			if (is_nan(x)) continue;
+			const unsigned long long key = sort_key(x);
+			if ((key & pmask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
 		}
+		__syncthreads();
+		if (tid < 64) { // one wavefront: lane l owns bins 4l..4l+3
+			const unsigned c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+			const unsigned tot = c0 + c1 + c2 + c3;
+			unsigned inc = tot;
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(inc, off, 64); if (tid >= off) inc += o; }
+			const unsigned exc = inc - tot;
+			if ((unsigned)k >= exc && (unsigned)k < inc) {
+				unsigned r = (unsigned)k - exc, d = 0;
+				if (r >= c0) { r -= c0; d = 1; if (r >= c1) { r -= c1; d = 2; if (r >= c2) { r -= c2; d = 3; } } }
+				hist[256] = 4u * tid + d;
+				hist[257] = r;
+			}
+		}
+		__syncthreads();
+		prefix |= ((unsigned long long)hist[256]) << shift;
+		pmask |= 255ull << shift;
+		k = (int)hist[257];
+		__syncthreads();
 	}
-	double med = __builtin_nan("");
-	if (n > 0) med = (n & 1) ? srt[n >> 1] : (srt[(n >> 1) - 1] + srt[n >> 1]) / 2.0;
-	__syncthreads();
-	return med;
+	// prefix is the key of the k_lo-th value: recover the double
+	const unsigned long long u = (prefix >> 63) ? (prefix & 0x7fffffffffffffffull) : ~prefix;
+	const double v_lo = __longlong_as_double((long long)u);
+	if (k_hi == k_lo) return v_lo;
+	// the next order statistic: v_lo again if enough values are <= v_lo, else the smallest value above it
+	int cle = 0;
+	double above = __builtin_inf();
+	for (int i = tid; i < m; i += kThreads) {
+		const double x = v[i];
+		if (is_nan(x)) continue;
+		if (x <= v_lo) cle++; else if (x < above) above = x;
+	}
+	const int nle = (int)block_sum((double)cle, red);
+	const double amin = block_min(above, red);
+	const double v_hi = (nle > k_hi) ? v_lo : amin;
+	return (v_lo + v_hi) / 2.0;
 }
 
 // numpy's pairwise add.reduce on n <= 128 contiguous doubles (loops_utils.h.src)
@@ -112,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 	const int target = blockIdx.x;
 	const int tid = threadIdx.x;
 	const int T = a.n_cad, TP2 = a.tp2;
-	double* srt = lds;                 // [TP2] sort buffer
+	double* srt = lds;                 // [TP2] scratch series (TP2 = max(T, 256))
 	double* fb = srt + TP2;            // [TP2] binned flux
 	double* gflux = fb + TP2;          // [T] relative flux of the good cadences
 	double* gerr = gflux + T;          // [T]
@@ -120,6 +150,8 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 	double* red = gtime + T;           // [kThreads]
 	int* gk = reinterpret_cast<int*>(red + kThreads); // [T] original index of the g-th good cadence
 	int* ired = gk + T;                // [kThreads + 1]
+	unsigned int* hist = reinterpret_cast<unsigned int*>(ired + kThreads + 1); // [260] radix-select scratch
+	int* bt = reinterpret_cast<int*>(hist + 260); // [T] time bin of every good cadence
 	double* o = a.out + (int64_t)target * 10;
 	const double nan = __builtin_nan("");
 
@@ -144,12 +176,31 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 		int c = 0;
 		for (int p = tid; p < P; p += kThreads) c += m[p] ? 1 : 0;
 		mask_size = block_sum((double)c, red);
-		if (tid == 0) { // the selected pixels in raster order, NaN -> 0, numpy pairwise sum
-			int n = 0;
-			for (int p = 0; p < P; ++p) {
+		// the selected pixels in raster order (ballot compaction, wavefront after wavefront), NaN -> 0
+		if (tid == 0) ired[0] = 0;
+		__syncthreads();
+		for (int p0 = 0; p0 < P; p0 += kThreads) {
+			const int p = p0 + tid;
+			bool sel = false;
+			double val = 0.0;
+			if (p < P) {
 				const int r = p / W, cc = p - r * W;
-				if (m[p] && (r == 0 || r == H - 1 || cc == 0 || cc == W - 1)) { const double v = S[p]; srt[n++] = is_nan(v) ? 0.0 : v; }
+				sel = m[p] && (r == 0 || r == H - 1 || cc == 0 || cc == W - 1);
+				if (sel) { val = S[p]; if (is_nan(val)) val = 0.0; }
 			}
+			const unsigned long long bal = __ballot(sel);
+			const int lane = tid & 63, wv = tid >> 6;
+			for (int w = 0; w < kThreads / 64; ++w) { // waves in order
+				if (wv == w) {
+					const int base = ired[0];
+					if (sel) srt[base + __popcll(bal & ((1ull << lane) - 1ull))] = val;
+					if (lane == 0) ired[0] = base + (int)__popcll(bal);
+				}
+				__syncthreads();
+			}
+		}
+		if (tid == 0) { // numpy pairwise sum of the gathered values
+			const int n = ired[0];
 			double tot;
 			if (n <= 128) tot = pairwise_leaf(srt, n);
 			else { int n2 = n / 2; n2 -= n2 % 8; tot = pairwise_leaf(srt, n2) + pairwise_leaf(srt + n2, n - n2); }
@@ -190,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 
 	// ---- mean flux, relative flux and error (:1357-1361)
 	for (int g = tid; g < Ng; g += kThreads) srt[g] = flux[gk[g]];
-	const double mean_flux = block_median(srt, Ng, red);
+	const double mean_flux = block_median(srt, Ng, red, hist);
 	const double ainv = fabs(1.0 / mean_flux);
 	for (int g = tid; g < Ng; g += kThreads) {
 		const int k = gk[g];
@@ -237,31 +288,42 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 					// numpy's arange fills start + i*delta with delta = (start + step) - start, rounded: NOT i*step
 					const double delta = (tmin + ts) - tmin;
 					// bin of every finite sample: searchsorted(right) on the edges tmin + i*delta (i < nb), tmax; the last bin is closed
-					int* bidx = reinterpret_cast<int*>(srt); // [T] ints in the sort buffer (TP2 doubles >= T ints)
+					int mono = 1;
 					for (int g = tid; g < Ng; g += kThreads) {
 						int b = -1;
 						const double x = gtime[g];
-						if (!is_nan(gflux[g]) && is_finite(gflux[g]) && !is_nan(x)) {
+						if (!is_nan(x)) {
 							b = (int)floor((x - tmin) / delta);
 							if (b < 0) b = 0;
 							if (b > nb - 1) b = nb - 1;
 							while (b + 1 <= nb - 1 && (tmin + (double)(b + 1) * delta) <= x) ++b;
 							while (b > 0 && (tmin + (double)b * delta) > x) --b;
 						}
-						bidx[g] = b;
+						bt[g] = b;
 					}
 					__syncthreads();
-					// nanmean per bin, samples added in time-series order (numpy's order inside binned_statistic)
+					for (int g = tid; g + 1 < Ng; g += kThreads) if (bt[g] < 0 || bt[g + 1] < bt[g]) mono = 0;
+					if (Ng > 0 && tid == 0 && bt[Ng - 1] < 0) mono = 0;
+					const bool sorted = block_min((double)mono, red) > 0.0;
+					// nanmean per bin, samples added in time-series order (numpy's order inside binned_statistic).  Time-ordered
+					// series (the normal case): the samples of a bin are a contiguous run found by two binary searches.
 					for (int b = tid; b < nb; b += kThreads) {
-						double s = 0.0; int c = 0;
-						for (int g = 0; g < Ng; ++g) if (bidx[g] == b) { s += gflux[g]; c++; }
-						fb[b] = c ? (0.0 + s) / (double)c : nan;
+						int g0 = 0, g1 = Ng;
+						if (sorted) {
+							int lo = 0, hi = Ng;
+							while (lo < hi) { const int mid = (lo + hi) >> 1; if (bt[mid] < b) lo = mid + 1; else hi = mid; }
+							g0 = lo; hi = Ng;
+							while (lo < hi) { const int mid = (lo + hi) >> 1; if (bt[mid] <= b) lo = mid + 1; else hi = mid; }
+							g1 = lo;
+						}
+						double sacc = 0.0; int c = 0;
+						for (int g = g0; g < g1; ++g) { const double y = gflux[g]; if (bt[g] == b && !is_nan(y) && is_finite(y)) { sacc += y; c++; } }
+						fb[b] = c ? (0.0 + sacc) / (double)c : nan;
 					}
 					__syncthreads();
-					for (int b = tid; b < nb; b += kThreads) srt[b] = fb[b];
-					const double med1 = block_median(srt, nb, red);
+					const double med1 = block_median(fb, nb, red, hist);
 					for (int b = tid; b < nb; b += kThreads) srt[b] = fabs(fb[b] - med1);
-					const double med2 = block_median(srt, nb, red);
+					const double med2 = block_median(srt, nb, red, hist);
 					rms_hour = 1.482602218505602 * med2; // utilities.mad_to_sigma (:25)
 				}
 			}
@@ -270,13 +332,13 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 
 	// ---- point-to-point scatter (:1366)
 	for (int g = tid; g + 1 < Ng; g += kThreads) srt[g] = fabs(gflux[g + 1] - gflux[g]);
-	const double ptp = block_median(srt, (Ng > 0) ? (Ng - 1) : 0, red);
+	const double ptp = block_median(srt, (Ng > 0) ? (Ng - 1) : 0, red, hist);
 
 	// ---- median centroid (:1369)
 	for (int g = tid; g < Ng; g += kThreads) srt[g] = ccol[gk[g]];
-	const double cen_col = block_median(srt, Ng, red);
+	const double cen_col = block_median(srt, Ng, red, hist);
 	for (int g = tid; g < Ng; g += kThreads) srt[g] = crow[gk[g]];
-	const double cen_row = block_median(srt, Ng, red);
+	const double cen_row = block_median(srt, Ng, red, hist);
 
 	// ---- variability (:1372-1393): weighted cubic fit, standard deviation of the residuals / median error
 	double variability;
@@ -338,8 +400,7 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 		for (int g = tid; g < Ng; g += kThreads) { const double d = srt[g]; if (!is_nan(d)) { const double e = d - avg; s2 += e * e; } }
 		const double tot2 = block_sum(s2, red);
 		const double sd = (cnt > 0.0) ? sqrt(tot2 / cnt) : nan;
-		for (int g = tid; g < Ng; g += kThreads) srt[g] = gerr[g];
-		const double med_err = block_median(srt, Ng, red);
+		const double med_err = block_median(gerr, Ng, red, hist);
 		variability = sd / med_err;
 	}
 
@@ -367,9 +428,8 @@ extern "C" int tp_lightcurve_diagnostics(tp_ctx* ctx, int32_t n_targets, int32_t
 	TP_REQUIRE(ctx, d_mask == nullptr || (height > 0 && width > 0 && 2 * (height + width) <= 256), "tp_lightcurve_diagnostics: bad stamp geometry");
 	TP_REQUIRE(ctx, timescale_days > 0, "tp_lightcurve_diagnostics: timescale must be positive");
 	if (n_targets == 0) return TP_OK;
-	int tp2 = 256;
-	while (tp2 < n_cad) tp2 <<= 1;
-	const size_t shmem = ((size_t)2 * tp2 + 3 * (size_t)n_cad + kThreads) * sizeof(double) + ((size_t)n_cad + kThreads + 1) * sizeof(int) + 16;
+	const int tp2 = (n_cad > 256) ? n_cad : 256; // scratch length: the series, the time bins (capped) and the <= 256 edge pixels
+	const size_t shmem = ((size_t)2 * tp2 + 3 * (size_t)n_cad + kThreads) * sizeof(double) + (2 * (size_t)n_cad + kThreads + 1 + 260) * sizeof(int) + 16;
 	TP_REQUIRE(ctx, shmem <= 160 * 1024, "tp_lightcurve_diagnostics: light curve too long for the LDS-resident reductions (about 4000 cadences)");
 	DiagArgs a;
 	a.flux = d_flux; a.flux_err = d_flux_err; a.ccol = d_centroid_col; a.crow = d_centroid_row; a.lc_pitch = lc_pitch;
