@@ -44,6 +44,7 @@ def parse_args():
 	p.add_argument('--no-gather', action='store_true')
 	p.add_argument('--workload', choices=['aperture', 'linpsf'], default='aperture',
 		help="'aperture' = BASELINE configs[2] (the headline); 'linpsf' = configs[3], the LinPSF fit on the same cube size")
+	p.add_argument('--frame', type=int, default=1024, help='side of the synthetic full-frame stack of the stamp-cutter stage (0 = skip)')
 	p.add_argument('--unfused', action='store_true', help='time the three stand-alone kernels (A1, K2P2, A6) back to back '
 		'instead of the fused per-target kernel')
 	return p.parse_args()
@@ -306,6 +307,29 @@ def main():
 	ctx.profile(False)
 	prof_bkg.update(ctx.profile_report())
 
+	# ---- the stamp cutter: the same 10k stamps cut from a 1024 x 1024 x T frame stack in HBM into the
+	# (no longer needed) raw cube; timed the same way, not part of `value`
+	cut_stage_ms = None
+	if args.frame > 0:
+		FR = args.frame
+		frames = ctx.zeros((T, FR, FR), 'float32')
+		rng = np.random.default_rng(args.seed)
+		r0 = rng.integers(0, FR - H, Nt)
+		c0 = rng.integers(0, FR - W, Nt)
+		cstamps = ctx.array(np.stack((r0, r0 + H, c0 + 44, c0 + 44 + W), axis=1).astype('int32'))
+		ctx.profile(True)
+		ctx.profile_reset()
+		engine.cut_stamps(ctx, frames, cstamps, H, W, 0, 44, out=cubes['raw'])
+		device_sync()
+		tc0 = time.perf_counter()
+		for _ in range(3):
+			engine.cut_stamps(ctx, frames, cstamps, H, W, 0, 44, out=cubes['raw'])
+		device_sync()
+		cut_stage_ms = (time.perf_counter() - tc0) / 3 * 1e3
+		ctx.profile(False)
+		prof_bkg.update(ctx.profile_report())
+		frames.free()
+
 	result = None
 	if rank == 0:
 		total_targets = Nt * world * args.steps
@@ -320,6 +344,7 @@ def main():
 			'tp_bkg_stamp_kernel': P*T*4 + T*4,                  # B*
 			'tp_bkg_smooth_kernel': 2*T*4,                       # B2
 			'tp_bkg_subtract_kernel': 2*P*T*4 + T*4,             # B3 (materialised)
+			'tp_cut_stamps_kernel': 2*P*T*4,                     # stamp cutter: read the stamp pixels, write the cube
 		}
 		def kernel_table(report, targets_per_launch):
 			out = {}
@@ -379,6 +404,8 @@ def main():
 			'background_stage': {'what': 'B* per-cadence stamp background + B2 time smoothing (+ one B3 subtraction) on the raw cube, '
 				'timed right after the headline region; not part of `value`', 'ms_per_pass': bkg_stage_ms,
 				'targets_per_s_including_it': Nt * world / (elapsed / args.steps + bkg_stage_ms * 1e-3)},
+			'cutout_stage': {'what': f'stamp cutter: the {Nt} stamps cut from a {args.frame} x {args.frame} x {T} float32 frame stack resident in HBM '
+				'(BasePhotometry._load_cube for the batch); one cube; not part of `value`', 'ms_per_cube': cut_stage_ms},
 			'diagnostics_stage': {'what': 'light-curve diagnostics of every target (mean flux, variance, rms_hour, ptp, centroid, variability, '
 				'mask size, edge flux: BasePhotometry.py:1343-1407) from the device-resident outputs; not part of `value`', 'ms_per_pass': diag_stage_ms},
 		}

@@ -278,6 +278,19 @@ int tp_lightcurve_diagnostics(tp_ctx* ctx, int32_t n_targets, int32_t n_cad,
 	const int32_t* d_status, const double* d_sumimage, const uint8_t* d_mask, int32_t height, int32_t width,
 	double timescale_days, double* d_diag);
 
+/* ---- stamp cutter -----------------------------------------------------------
+ * replaces BasePhotometry._load_cube, FFI branch (photometry/BasePhotometry.py:720-742), for a batch: cuts
+ * every target's stamp out of a full-frame image stack resident in HBM and writes the time-fastest cube.
+ *   d_frames: float32 [n_frames][frame_rows][row_pitch] (frame k at d_frames + k*frame_stride), the HDF5 group
+ *             `images/%04d` (or `images_err`, `backgrounds`) of the reference loaded once per CCD;
+ *   row_offset / col_offset: PIXEL_OFFSET_ROW / PIXEL_OFFSET_COLUMN (BasePhotometry.py:724-727; 0 and 44);
+ *   d_stamps: int32 [n_targets][4] = (row_min, row_max, col_min, col_max) in CCD coordinates; every stamp must be
+ *             desc->height x desc->width; pixels outside the frame become NaN;
+ *   d_cube:   float32 cube with the layout of desc (n_cad == n_frames).                                */
+int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+	int64_t row_pitch, int64_t frame_stride, int32_t row_offset, int32_t col_offset,
+	const int32_t* d_stamps, const tp_cube_desc* desc, float* d_cube);
+
 /* ---- multi-GPU: the final light-curve gather (RCCL over xGMI) --------------------------------
  * replaces the pickled result messages of run_tessphot_mpi.py:114-132,163-191: targets are
  * statically sharded over the ranks (one process per GPU) and the only data-path exchange is one

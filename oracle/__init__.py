@@ -14,7 +14,7 @@ when the HIP library is missing.
 Pinning status (see DESIGN.md "Oracle"):
 
 * A1 (TPF branch), A5b, A6, A7, P2, P3, P4, quality, utilities, the light-curve diagnostics
-  (``diagnostics.py``): pinned against golden
+  (``diagnostics.py``), the stamp cutter (``cutout.py``, rank 2): pinned against golden
   vectors produced by *executing the reference's own code* in the dev container
   (``tests/golden/make_golden.py``; fixtures in ``tests/golden/*.npz``).
 * A2-A5 (K2P2): control flow pinned by executing the reference's own
@@ -30,4 +30,4 @@ Pinning status (see DESIGN.md "Oracle"):
 """
 
 __all__ = ['quality', 'utilities', 'sumimage', 'aperture', 'kde', 'powell', 'k2p2',
-	'backgrounds', 'psf', 'linpsf', 'diagnostics']
+	'backgrounds', 'psf', 'linpsf', 'diagnostics', 'cutout']

@@ -88,6 +88,7 @@ SIGNATURES = {
 		_p, _p, _p, c_int64, _p, _p, _p]),
 	'tp_lightcurve_diagnostics': (c_int, [c_void_p, c_int32, c_int32, _p, _p, _p, _p, c_int64, _p, _p, c_int64, c_uint32,
 		_p, _p, _p, c_int32, c_int32, c_double, _p]),
+	'tp_cut_stamps': (c_int, [c_void_p, _p, c_int32, c_int32, c_int32, c_int64, c_int64, c_int32, c_int32, _p, _desc_p, _p]),
 	'tp_comm_unique_id': (c_int, [c_char_p, c_int]),
 	'tp_comm_init': (c_int, [c_void_p, c_char_p, c_int, c_int, c_int]),
 	'tp_comm_destroy': (c_int, [c_void_p]),

@@ -19,6 +19,7 @@ static const char* const kKernelNames[TPK_COUNT] = {
 	"tp_linpsf_fit_direct_kernel",
 	"tp_linpsf_finalize_kernel",
 	"tp_diagnostics_kernel",
+	"tp_cut_stamps_kernel",
 	"tp_synth_kernel",
 };
 

@@ -24,6 +24,7 @@ enum tp_kernel_id {
 	TPK_LINPSF_FIT_DIRECT,
 	TPK_LINPSF_FIN,
 	TPK_DIAGNOSTICS,
+	TPK_CUTOUT,
 	TPK_SYNTH,
 	TPK_COUNT
 };

@@ -195,6 +195,24 @@ def aperture_photometry(ctx, batch, work, bitmask=TESS_DEFAULT_BITMASK, subtract
 	return work
 
 
+def cut_stamps(ctx, frames, stamps, height, width, row_offset=0, col_offset=0, out=None):
+	"""
+	Stamp cutter (BasePhotometry._load_cube, BasePhotometry.py:720-742, for a batch).  ``frames``: float32 DeviceArray
+	``(T, R, C)`` (one HDF5 image group of a CCD resident in HBM); ``stamps``: int32 DeviceArray ``(Nt, 4)`` in CCD
+	coordinates, all ``height x width``.  Returns a :class:`DeviceCube`.
+	"""
+	T, R, C = frames.shape
+	Nt = stamps.shape[0]
+	if out is None:
+		out = DeviceCube(ctx, Nt, T, height, width)
+		if out.t_pitch != T:
+			out.data.fill_bytes(0)
+	desc = out.desc
+	ctx._check(ctx.lib.tp_cut_stamps(ctx.handle, frames.ptr, T, R, C, C, R * C, int(row_offset), int(col_offset), stamps.ptr,
+		ctypes.byref(desc), out.ptr))
+	return out
+
+
 #: columns of the diagnostics block (BasePhotometry.py:1357-1403)
 DIAGNOSTICS_COLUMNS = ('mean_flux', 'variance', 'rms_hour', 'ptp', 'pos_centroid_col', 'pos_centroid_row', 'variability',
 	'mask_size', 'edge_flux', 'flags')

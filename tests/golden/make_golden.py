@@ -22,6 +22,7 @@ Fixtures:
 * ``golden_psf.npz``      ``PSF.integrate_to_image`` (psf.py:122-148) on a synthetic spline
 * ``golden_linpsf.npz``   ``lsfit`` and ``LinPSFPhotometry.do_photometry``
                           (linpsf_photometry.py:22-34, 79-219)
+* ``golden_cutout.npz``   ``BasePhotometry._load_cube`` FFI branch (BasePhotometry.py:720-742) on a small frame stack
 * ``golden_diagnostics.npz`` ``BasePhotometry.photometry`` (BasePhotometry.py:1337-1407): the light-curve
                           diagnostics the scheduler stores, from the reference's own code run on light curves
                           produced by its own ``AperturePhotometry.do_photometry``
@@ -284,6 +285,47 @@ def golden_aperture():
 
 
 #--------------------------------------------------------------------------------------------------
+class FakeHDF(object):
+	"""h5py.File stand-in for ``_load_cube``: groups ``images`` ... holding one 2-D dataset per cadence (``%04d``)."""
+	def __init__(self, groups):
+		self.groups = groups
+
+	def __contains__(self, key):
+		return key in self.groups
+
+	def __getitem__(self, key):
+		group, name = key.split('/')
+		return self.groups[group][int(name)]
+
+
+def golden_cutout():
+	"""BasePhotometry._load_cube (FFI branch) executed for real on a (T, R, C) frame stack."""
+	rng = np.random.default_rng(5)
+	T, R, C = 70, 40, 57
+	frames = rng.normal(100, 20, (T, R, C)).astype('float32')
+	frames[rng.random((T, R, C)) < 0.01] = np.nan
+	offs = (3, 44) # PIXEL_OFFSET_ROW, PIXEL_OFFSET_COLUMN
+	stamps = np.array([[3, 14, 44, 55], [10, 21, 60, 71], [32, 43, 90, 101], [5, 16, 47, 58], [20, 31, 77, 88]], dtype='int32')
+	cubes = []
+	for st in stamps:
+		class Fake(BasePhotometry):
+			def __init__(self):
+				pass
+
+			def __del__(self):
+				pass
+		f = Fake()
+		f.datasource = 'ffi'
+		f._stamp = tuple(int(v) for v in st)
+		f.pixel_offset_row, f.pixel_offset_col = offs
+		f.Ntimes = T
+		f.hdf = FakeHDF({'images': frames})
+		cubes.append(BasePhotometry._load_cube(f, tpf_field='FLUX', hdf_group='images'))
+	np.savez_compressed(os.path.join(HERE, 'golden_cutout.npz'), frames=frames, stamps=stamps, offsets=np.array(offs), cubes=np.array(cubes))
+	print('golden_cutout', np.array(cubes).shape)
+
+
+#--------------------------------------------------------------------------------------------------
 class FakeLC(object):
 	"""Minimal astropy-Table stand-in for ``self.lightcurve``: column access by name, row subset by boolean mask."""
 	def __init__(self, cols):
@@ -504,6 +546,6 @@ def golden_linpsf():
 
 
 if __name__ == '__main__':
-	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics']
+	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics', 'cutout']
 	for w in which:
 		globals()['golden_' + w]()

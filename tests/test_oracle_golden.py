@@ -159,3 +159,12 @@ def test_diagnostics_golden(golden_dir):
 		for key in ('variance', 'rms_hour', 'variability'):
 			np.testing.assert_allclose(d[key], float(g[f'case{i}_{key}']), rtol=1e-12, err_msg=key)
 		np.testing.assert_array_equal([d['pos_centroid_col'], d['pos_centroid_row']], g[f'case{i}_det_pos_centroid'])
+
+
+def test_cutout_golden(golden_dir):
+	"""oracle.cutout.load_cube vs the reference's own BasePhotometry._load_cube (BasePhotometry.py:720-742)."""
+	from oracle import cutout
+	g = np.load(os.path.join(golden_dir, 'golden_cutout.npz'))
+	for st, ref in zip(g['stamps'], g['cubes']):
+		got = cutout.load_cube(g['frames'], tuple(st), *g['offsets'])
+		np.testing.assert_array_equal(got, ref)
