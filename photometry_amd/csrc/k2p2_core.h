@@ -137,6 +137,7 @@ struct Shared {
 	uint8_t* sat;     // [P] saturated additions for the current mask
 	uint8_t* res;     // [P] result mask
 	const double* twid; // [2*kGrid] cos, sin of 2*pi*j/kGrid (global / constant)
+	double* twl;      // [2*kGrid] LDS copy of twid, valid during the threshold phase
 };
 
 // LDS plan.  The arrays of the threshold phase (A2: sorted fluxes + the KDE grids) are dead once CUT is known and the
@@ -156,7 +157,7 @@ inline TP_HD SharedLayout shared_layout(int P) {
 	while (L.Pp_sort < P) L.Pp_sort <<= 1;
 	const size_t Pa = (size_t)L.Pa;
 	L.off_region = (2 * Pa + 64) * 8;                                   // S, tmp, red
-	const size_t phase1 = ((size_t)L.Pp + 4 * kGrid) * 8;              // srt, grid
+	const size_t phase1 = ((size_t)L.Pp + 4 * kGrid + 132) * 8;        // srt, grid (binned, dens, Yre[66], Yim[66]), twiddle copy [2*kGrid]
 	const size_t phase2 = 3 * Pa * 8 + 4 * Pa * sizeof(lab_t);         // Z, dist, hval | lab, lab2, mark, wsout
 	L.region_bytes = ((phase1 > phase2 ? phase1 : phase2) + 15) & ~(size_t)15;
 	L.off_ints = L.off_region + L.region_bytes;                         // hage, hpix, ired, scal
@@ -180,7 +181,8 @@ inline TP_DEV void shared_carve(Shared& k, void* base, int H, int W, int lane, c
 	// phase 1 view of the region
 	double* r1 = (double*)(b0 + L.off_region);
 	k.srt = r1; r1 += L.Pp;
-	k.grid = r1;
+	k.grid = r1; r1 += 2 * kGrid + 132;
+	k.twl = r1;
 	// phase 2 view of the region
 	double* r2 = (double*)(b0 + L.off_region);
 	k.Z = r2; r2 += Pa;
@@ -265,8 +267,28 @@ inline double min_arr(const Shared&, const double* arr) { TP_TREE(double, arr, (
 inline double max_arr(const Shared&, const double* arr) { TP_TREE(double, arr, (y_ > x_) ? y_ : x_) }
 #undef TP_TREE
 #else
+// lane l <- lane l + OFF: the two top steps go through the LDS crossbar (ds_bpermute), the four steps inside a row of 16
+// lanes are DPP row shifts (a few cycles instead of ~60 each); the result leaves lane 0 through v_readfirstlane.
+// Same pairs, same order as __shfl_down: the tree association is unchanged.
+template <int OFF> inline TP_DEV int tp_down(int x) {
+	if (OFF >= 16) return __shfl_down(x, OFF, 64);
+	return __builtin_amdgcn_update_dpp(0, x, 0x100 + OFF, 0xF, 0xF, true); // row_shl:OFF
+}
+template <int OFF> inline TP_DEV double tp_down(double x) {
+	const long long b = __double_as_longlong(x);
+	const int lo = tp_down<OFF>((int)(b & 0xffffffffll)), hi = tp_down<OFF>((int)(b >> 32));
+	return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+inline TP_DEV int tp_first(int x) { return __builtin_amdgcn_readfirstlane(x); }
+inline TP_DEV double tp_first(double x) {
+	const long long b = __double_as_longlong(x);
+	const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+	return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+#define TP_TREE_STEP(T, OFF, OP) { const T y_ = tp_down<OFF>(x_); x_ = OP; }
 #define TP_TREE(T, arr, OP) T x_ = (arr)[k.lane]; \
-	for (int off = 32; off > 0; off >>= 1) { const T y_ = __shfl_down(x_, off, 64); x_ = OP; } return __shfl(x_, 0, 64);
+	TP_TREE_STEP(T, 32, OP) TP_TREE_STEP(T, 16, OP) TP_TREE_STEP(T, 8, OP) TP_TREE_STEP(T, 4, OP) TP_TREE_STEP(T, 2, OP) TP_TREE_STEP(T, 1, OP) \
+	return tp_first(x_);
 inline TP_DEV double sum_red(const Shared& k) { TP_TREE(double, k.red, x_ + y_) }
 inline TP_DEV int sum_ired(const Shared& k) { TP_TREE(int, k.ired, x_ + y_) }
 inline TP_DEV int or_ired(const Shared& k) { TP_TREE(int, k.ired, x_ | y_) }
@@ -318,8 +340,9 @@ inline TP_DEV double wave_sum_f(const Shared& k, const F& f) {
 	return a_[0];
 #else
 	double x_ = f(k.lane);
-	for (int off = 32; off > 0; off >>= 1) x_ = x_ + __shfl_down(x_, off, 64);
-	return __shfl(x_, 0, 64);
+	x_ = x_ + tp_down<32>(x_); x_ = x_ + tp_down<16>(x_); x_ = x_ + tp_down<8>(x_);
+	x_ = x_ + tp_down<4>(x_); x_ = x_ + tp_down<2>(x_); x_ = x_ + tp_down<1>(x_);
+	return tp_first(x_);
 #endif
 }
 
@@ -510,6 +533,7 @@ inline TP_DEV double powell_mode(Shared& k, int nc, double h, double x0) {
 // Returns 0 ok, or an ERR_* code; fills diag[0..5] and leaves CUT in *cut (may be NaN).
 inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, double* cut) {
 	const int P = k.P;
+
 	// Flux = S[~isnan(S)]; Flux = Flux[Flux > 0]   (k2p2v2.py:394-395) -> compacted in raster order
 	TP_LANE_LOOP(l) {
 		int c = 0;
@@ -569,7 +593,9 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 		const double b = ((nc > 0) ? k.srt[nc - 1] : tp_nan()) + 3.0 * bw;
 		const double delta = (b - a) / (double)(M - 1);   // np.linspace retstep
 		const double RANGE = b - a;
-		double* binned = k.grid; double* dens = k.grid + M; double* Yre = k.grid + 2 * M; double* Yim = k.grid + 3 * M;
+		double* binned = k.grid; double* dens = k.grid + M; double* Yre = k.grid + 2 * M; double* Yim = k.grid + 2 * M + 66;
+		// the DFT twiddles next to the grids (LDS) for the two transforms below
+		TP_PAR_FOR(j, 2 * M) k.twl[j] = k.twid[j];
 		// fast_linbin: bin m accumulates, in data order, (1 - rem) from points with li == m and rem from li == m-1.
 		// (li, rem) of every point once (k.hage / k.tmp), then each lane owns two bins
 		TP_PAR_FOR(i, nc) {
@@ -580,10 +606,15 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 			k.tmp[i] = lxi - (double)li;
 		}
 		TP_SYNC();
+		// the points are sorted, so li never decreases: the contributors of bin m (li == m-1, then li == m, in data order
+		// like the reference's loop) are one contiguous run, found by binary search
 		TP_PAR_FOR(m, M) {
+			int lo = 0, hi = nc;
+			while (lo < hi) { const int mid = (lo + hi) >> 1; if (k.hage[mid] < m - 1) lo = mid + 1; else hi = mid; }
 			double g = 0.0;
-			for (int i = 0; i < nc; ++i) {
+			for (int i = lo; i < nc; ++i) {
 				const int li = k.hage[i];
+				if (li > m) break;
 				if (li > 1 && li < M) {
 					if (li == m) g = g + 1 - k.tmp[i];
 					else if (li + 1 == m) g = g + k.tmp[i];
@@ -597,8 +628,8 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 			double re = 0.0, im = 0.0;
 			for (int n = 0; n < M; ++n) {
 				const int j = (kk * n) & (M - 1);
-				re += binned[n] * k.twid[j];
-				im -= binned[n] * k.twid[M + j];
+				re += binned[n] * k.twl[j];
+				im -= binned[n] * k.twl[M + j];
 			}
 			// zstar = silverman_transform * forrt(binned): FAC[k] * Y[k] / M
 			const double FAC1 = 2.0 * ((kPi * bw / RANGE) * (kPi * bw / RANGE));
@@ -614,7 +645,7 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 			double f = Yre[0];
 			for (int kk = 1; kk < M / 2; ++kk) {
 				const int j = (kk * m) & (M - 1);
-				f += 2.0 * (Yre[kk] * k.twid[j] - Yim[kk] * k.twid[M + j]);
+				f += 2.0 * (Yre[kk] * k.twl[j] - Yim[kk] * k.twl[M + j]);
 			}
 			f += Yre[M / 2] * ((m & 1) ? -1.0 : 1.0);
 			dens[m] = f;
