@@ -88,7 +88,11 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 	__shared__ int s_leaf_len[kMaxLeaves];
 	__shared__ unsigned char s_leaf_merges[kMaxLeaves];
 	__shared__ int s_M, s_nleaves, s_n, s_pnext;
-	const int target = blockIdx.x;
+	int target = blockIdx.x;
+	if (a.big_list) { // work list from the fused kernel: most launches have nothing to do
+		if ((int)blockIdx.x >= a.big_list[0]) return;
+		target = a.big_list[1 + blockIdx.x];
+	}
 	if (a.status && a.status[target] == TP_STATUS_ERROR) return;
 	const int P = a.height * a.width;
 	const int tid = threadIdx.x;
@@ -235,6 +239,17 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 
 } // namespace
 
+void* tp_ctx_scratch(tp_ctx* ctx, size_t bytes)
+{
+	if (ctx->scratch_bytes < bytes) {
+		if (ctx->scratch) (void)hipFree(ctx->scratch);
+		ctx->scratch = nullptr; ctx->scratch_bytes = 0;
+		if (hipMalloc(&ctx->scratch, bytes) != hipSuccess) { ctx->scratch = nullptr; return nullptr; }
+		ctx->scratch_bytes = bytes;
+	}
+	return ctx->scratch;
+}
+
 int tp_aperture_extract_big(tp_ctx* ctx, const tp_ap::Args& a, bool vec4)
 {
 	const int vec = vec4 ? 4 : 1;
@@ -274,7 +289,7 @@ extern "C" int tp_aperture_extract(tp_ctx* ctx, const tp_cube_desc* desc,
 	a.flux = d_flux; a.flux_err = d_flux_err; a.flux_bkg = d_flux_background;
 	a.ccol = d_centroid_col; a.crow = d_centroid_row;
 	a.out_pitch = out_pitch; a.n_cad = desc->n_cad; a.height = desc->height; a.width = desc->width;
-	a.t_pitch = desc->t_pitch; a.n_targets = desc->n_targets;
+	a.t_pitch = desc->t_pitch; a.n_targets = desc->n_targets; a.big_list = nullptr;
 
 	bool vec4 = tp_vec4_ok(d_images, desc->t_pitch) && tp_vec4_ok(d_images_err, desc->t_pitch);
 	if (bkg_mode == 0) vec4 = vec4 && tp_vec4_ok(d_backgrounds, desc->t_pitch);

@@ -76,6 +76,8 @@ struct Args {
 	const uint8_t* mask; const int32_t* stamps; const int32_t* status;
 	double* flux; double* flux_err; double* flux_bkg; double* ccol; double* crow;
 	int64_t out_pitch; int n_cad; int height; int width; int64_t t_pitch; int n_targets;
+	// optional work list of the big-mask kernel: big_list[0] = count, big_list[1..] = targets (filled by the fused kernel)
+	int32_t* big_list;
 };
 
 template <int VEC>
@@ -318,3 +320,6 @@ __device__ __forceinline__ void extract_small_stream(const Args& a, int target, 
 
 // Launches tp_aperture_big_kernel (masks above kMaxList pixels; it skips all other targets) on ctx's stream.
 int tp_aperture_extract_big(tp_ctx* ctx, const tp_ap::Args& a, bool vec4);
+
+// Grow-only device scratch of the context (at least `bytes`), nullptr on failure.
+void* tp_ctx_scratch(tp_ctx* ctx, size_t bytes);

@@ -146,7 +146,10 @@ __global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a,
 	int pn = 0, M = 0;
 	tp_ap::compact_mask(k.res, P, pn, s_list, tp_ap::kMaxList, lane, true, &M);
 	__syncthreads();
-	if (M > tp_ap::kMaxList) return; // tp_aperture_big_kernel takes it from the mask in HBM
+	if (M > tp_ap::kMaxList) { // tp_aperture_big_kernel takes it from the mask in HBM
+		if (lane == 0 && a.big_list) a.big_list[1 + atomicAdd(&a.big_list[0], 1)] = target;
+		return;
+	}
 	tp_ap::extract_small_stream<VEC, HAS_SUB, BKG_CUBE>(a, target, s_list, M, lane, 64);
 }
 
@@ -222,6 +225,10 @@ extern "C" int tp_aperture_photometry(tp_ctx* ctx, const tp_cube_desc* desc,
 	a.ccol = d_centroid_col; a.crow = d_centroid_row;
 	a.out_pitch = out_pitch; a.n_cad = desc->n_cad; a.height = desc->height; a.width = desc->width;
 	a.t_pitch = desc->t_pitch; a.n_targets = desc->n_targets;
+	// work list of the big-mask kernel (count + targets), zeroed on the stream before the launch
+	a.big_list = static_cast<int32_t*>(tp_ctx_scratch(ctx, ((size_t)desc->n_targets + 1) * sizeof(int32_t)));
+	TP_REQUIRE(ctx, a.big_list != nullptr, "tp_aperture_photometry: out of device memory for the work list");
+	TP_HIP(ctx, hipMemsetAsync(a.big_list, 0, sizeof(int32_t), ctx->stream));
 
 	bool vec4 = tp_vec4_ok(d_images, desc->t_pitch) && tp_vec4_ok(d_images_err, desc->t_pitch);
 	if (bkg_mode == 0) vec4 = vec4 && tp_vec4_ok(d_backgrounds, desc->t_pitch);

@@ -31,6 +31,8 @@
 #include "common.h"
 #include <cmath>
 
+void* tp_ctx_scratch(tp_ctx* ctx, size_t bytes); // aperture.hip
+
 namespace {
 
 constexpr int kMaxStars = 8;
@@ -785,12 +787,7 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	const size_t todo_bytes = (size_t)desc->n_targets * sizeof(int32_t);
 	// fast kernel: up to 1024 (2-star class, 128 VGPRs suffice) or 512 threads (= cadences) per pass, the passes balanced
 	auto fast_block = [&](int maxthreads) { const int np = (desc->n_cad + maxthreads - 1) / maxthreads; return dim3((unsigned)((((desc->n_cad + np - 1) / np) + 63) / 64 * 64)); };
-	if (ctx->scratch_bytes < todo_bytes) {
-		if (ctx->scratch) TP_HIP(ctx, hipFree(ctx->scratch));
-		ctx->scratch = nullptr; ctx->scratch_bytes = 0;
-		TP_HIP(ctx, hipMalloc(&ctx->scratch, todo_bytes));
-		ctx->scratch_bytes = todo_bytes;
-	}
+	TP_REQUIRE(ctx, tp_ctx_scratch(ctx, todo_bytes) != nullptr, "tp_linpsf_fit: out of device memory for the class flags");
 	int32_t* d_todo = static_cast<int32_t*>(ctx->scratch);
 	TP_HIP(ctx, hipMemsetAsync(d_todo, 0, todo_bytes, ctx->stream));
 #define TP_LINPSF_LAUNCH(SS, SL) do { \
