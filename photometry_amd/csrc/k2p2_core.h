@@ -106,7 +106,7 @@ struct Target {
 	double* timing;           // optional [16] per-phase cycle counters (diagnostics)
 };
 
-// Labels, pixel indices and counters bounded by P (<= 44*44) are 16-bit: LDS footprint decides how many targets
+// Labels, pixel indices and counters bounded by P (<= 52*52, the LDS limit) are 16-bit: LDS footprint decides how many targets
 // (wavefronts) a CU holds at once.
 typedef int16_t lab_t;
 

@@ -1,0 +1,109 @@
+# -*- coding: utf-8 -*-
+"""
+Edge cases of the batched aperture path through the C ABI: empty batches for every entry, ragged catalogues with
+empty segments, a single cadence, light curves where every cadence is flagged, the largest LDS-resident stamp.
+The oracle (test infrastructure) is the checker, exactly as in the other parity tests.
+"""
+import ctypes
+import numpy as np
+import pytest
+from photometry_amd import simulate, pipeline, engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+	from photometry_amd.device import Context
+	c = Context(0)
+	yield c
+	c.close()
+
+
+def _oracle(s, S, i):
+	from oracle import aperture as oap
+	ap = np.ones((s.height, s.width), dtype='int32')
+	return oap.do_photometry(S[i], s.images[i], s.images_err[i], s.backgrounds[i], tuple(s.stamps[i]),
+		s.target_pos_row[i], s.target_pos_column[i], s.target_tmag[i], s.target_starid[i], s.catalog_of(i), ap)
+
+
+def _compare(s, got):
+	n_ok = 0
+	for i in range(s.n_targets):
+		ref = _oracle(s, got['sumimage'], i)
+		assert int(got['status'][i]) == ref['status'], (i, got['status'][i], ref['status'], got['flags'][i])
+		if ref.get('mask') is not None and ref['status'] != 2:
+			np.testing.assert_array_equal(got['mask'][i].astype(bool), ref['mask'], err_msg=str(i))
+			np.testing.assert_array_equal(got['flux'][i], ref['flux'], err_msg=str(i))
+			np.testing.assert_array_equal(got['flux_background'][i], ref['flux_background'], err_msg=str(i))
+			n_ok += 1
+	return n_ok
+
+
+def test_empty_batches_are_ok(ctx):
+	"""n_targets == 0 is a valid call for every entry point (the scheduler may hand over an empty chunk)."""
+	from photometry_amd._lib import tp_cube_desc
+	lib, h = ctx.lib, ctx.handle
+	desc = tp_cube_desc(0, 10, 5, 5, 32)
+	p = ctx.zeros((64,), 'float64').ptr # any valid device pointer
+	assert lib.tp_sumimage(h, ctypes.byref(desc), p, p, 0, 4335, None, 0, p) == 0
+	assert lib.tp_aperture_extract(h, ctypes.byref(desc), p, p, p, 0, 0, None, 0, p, p, None, p, p, p, p, p, 10) == 0
+	assert lib.tp_aperture_photometry(h, ctypes.byref(desc), p, p, p, 0, 0, None, 0, p, 0, 4335, p, p, p, p, p, p, p, p, p, p, p, p, p, None,
+		p, p, p, p, p, p, p, p, p, p, p, p, 10) == 0
+	assert lib.tp_background_stamp(h, ctypes.byref(desc), p, 8e4, 50.0, p, 32) == 0
+	assert lib.tp_lightcurve_diagnostics(h, 0, 10, p, p, p, p, 10, p, p, 0, 4335, None, None, None, 0, 0, 1/24, p) == 0
+	assert lib.tp_cut_stamps(h, p, 10, 4, 4, 4, 16, 0, 0, p, ctypes.byref(desc), p) == 0
+	ctx.sync()
+
+
+def test_ragged_catalogue_with_empty_segments(ctx):
+	"""Targets whose catalogue query returned nothing (CSR segment of length 0) next to ordinary ones."""
+	s = simulate.make_scene(9, 40, 11, 11, seed=21)
+	simulate.fill_cubes(s)
+	s.aperture = None
+	# drop the catalogue rows of targets 2 and 5
+	keep = np.ones(len(s.catalog['starid']), dtype=bool)
+	for i in (2, 5):
+		keep[s.cat_offsets[i]:s.cat_offsets[i+1]] = False
+	counts = np.diff(s.cat_offsets)
+	counts[[2, 5]] = 0
+	s.catalog = {k: v[keep] for k, v in s.catalog.items()}
+	s.cat_offsets = np.concatenate(([0], np.cumsum(counts))).astype('int64')
+	got = pipeline.run_aperture(ctx, s)
+	assert _compare(s, got) >= 5
+	# no catalogue star can fall in the mask: "No targets in mask" (photometry.py:227-230)
+	assert int(got['status'][2]) in (2, 3) and int(got['status'][5]) in (2, 3)
+
+
+def test_single_cadence_and_all_flagged(ctx):
+	s = simulate.make_scene(5, 1, 11, 11, seed=3)
+	simulate.fill_cubes(s)
+	s.aperture = None
+	got = pipeline.run_aperture(ctx, s)
+	assert _compare(s, got) >= 3
+	# every cadence fails the quality bitmask: the sum image is all NaN -> K2P2NoFlux -> ERROR, nothing extracted
+	s2 = simulate.make_scene(4, 33, 11, 11, seed=4)
+	simulate.fill_cubes(s2)
+	s2.aperture = None
+	s2.quality[:] = 32
+	got2 = pipeline.run_aperture(ctx, s2)
+	assert np.all(np.isnan(got2['sumimage']))
+	assert np.all(got2['status'] == 2)
+	assert not got2['mask'].any()
+	d = got2['diagnostics']
+	assert np.all(np.isnan(d)) # ERROR targets get no diagnostics
+
+
+def test_largest_lds_resident_stamp(ctx):
+	"""52 x 52 pixels is the limit of the LDS-resident mask builder; one pixel more is an error, not a fallback."""
+	from photometry_amd._lib import TessphotError
+	s = simulate.make_scene(2, 20, 52, 52, seed=6, tmag_range=(6.5, 8.0))
+	simulate.fill_cubes(s)
+	s.aperture = None
+	got = pipeline.run_aperture(ctx, s)
+	assert _compare(s, got) >= 1
+	s3 = simulate.make_scene(1, 8, 53, 53, seed=6)
+	simulate.fill_cubes(s3)
+	s3.aperture = None
+	with pytest.raises(TessphotError):
+		pipeline.run_aperture(ctx, s3)
