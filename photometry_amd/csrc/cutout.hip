@@ -41,15 +41,18 @@ __global__ __launch_bounds__(256) void tp_cut_stamps_kernel(CutArgs a)
 	const int seg = tid >> 4, lane16 = tid & 15;    // 16 segments in flight per pass
 	const int nseg = kCadBlock * H * wgrp;
 	constexpr int U = 8; // independent loads in flight per thread before the LDS writes
+	// (row, cadence, column group) of this thread's segment, advanced by 16 segments per step without divisions
+	// (the kernel is VALU-bound on index arithmetic otherwise: 78 % VALU busy with div / mod per load)
+	int g = seg % wgrp, rowk = seg / wgrp;
+	int i = rowk % H, kk = rowk / H;
+	const int dg = 16 % wgrp, drow = 16 / wgrp;     // advance of (g, rowk) per 16 segments
+	const int di = drow % H, dk = drow / H;
 	for (int base = seg; base < nseg; base += 16 * U) {
 		float v[U];
 		int dst[U];
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
 			const int sidx = base + 16 * u;
-			const int g = sidx % wgrp;
-			const int rowk = sidx / wgrp;
-			const int i = rowk % H, kk = rowk / H;
 			const int j = g * 16 + lane16;
 			const int k = k0 + kk;
 			const int r = r0 + i, c = c0 + j;
@@ -60,6 +63,12 @@ __global__ __launch_bounds__(256) void tp_cut_stamps_kernel(CutArgs a)
 			const float x = a.frames[off];
 			v[u] = inside ? x : nan;
 			dst[u] = want ? (kk * ldp + i * W + j) : -1;
+			// next segment of this thread: sidx + 16
+			g += dg; int carry = 0;
+			if (g >= wgrp) { g -= wgrp; carry = 1; }
+			i += di + carry; kk += dk;
+			if (i >= H) { i -= H; kk++; }
+			if (i >= H) { i -= H; kk++; } // di + carry < 2H
 		}
 #pragma unroll
 		for (int u = 0; u < U; ++u) if (dst[u] >= 0) tile[dst[u]] = v[u];
