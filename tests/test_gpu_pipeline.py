@@ -128,3 +128,35 @@ def test_fused_large_masks_and_unaligned_pitch(ctx):
 		ref, got = _collect(ref_work), _collect(work)
 		for k in KEYS:
 			np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
+def test_fused_with_per_target_quality(ctx):
+	"""quality as (Nt, T): every target has its own good-cadence set (A1 in the fused kernel and the diagnostics)."""
+	from oracle import sumimage as osum, diagnostics as odiag
+	s = simulate.make_scene(7, 90, 11, 11, seed=14)
+	simulate.fill_cubes(s)
+	s.aperture = None
+	rng = np.random.default_rng(2)
+	q = np.zeros((7, 90), dtype='int32')
+	q[rng.random((7, 90)) < 0.2] = 32
+	q[3, :] = 0
+	s.quality = q
+	batch = pipeline.ApertureBatch(ctx, s)
+	ref_work = pipeline.ApertureWork(ctx, batch)
+	pipeline.aperture_step(ctx, batch, ref_work, fused=False)
+	work = pipeline.ApertureWork(ctx, batch)
+	pipeline.aperture_step(ctx, batch, work, fused=True)
+	pipeline.aperture_diagnostics(ctx, batch, work)
+	ctx.sync()
+	ref, got = _collect(ref_work), _collect(work)
+	for k in KEYS:
+		np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+	np.testing.assert_allclose(got['sumimage'], osum.sumimage_batch(s.images, q), rtol=1e-12, equal_nan=True)
+	d = work.diagnostics.to_host()
+	for i in range(7):
+		if int(got['status'][i]) not in (1, 3):
+			continue
+		cen = np.stack((got['centroid_col'][i], got['centroid_row'][i]), axis=-1)
+		o = odiag.diagnostics(s.time, q[i], got['flux'][i], got['flux_err'][i], cen, sumimage=got['sumimage'][i], mask=got['mask'][i])
+		assert d[i][0] == o['mean_flux'] and d[i][3] == o['ptp']
+		np.testing.assert_allclose(d[i][2], o['rms_hour'], rtol=1e-12)
