@@ -467,11 +467,16 @@ class BasePhotometry(object):
 
 	def save_lightcurve(self, output_folder=None, version=None):
 		"""
-		Stand-in for the FITS writer (BasePhotometry.py:1417-1730; astropy is not available): writes
-		the same table columns (:1515-1530), the aperture bit image with bits 2 / 8 OR-ed in
-		(:1645-1649), the sum image and the header keywords as a compressed ``.npz`` file named like the
-		reference's light curves (:1709-1717).
+		FITS light-curve writer, FILEVER 1.5 (BasePhotometry.py:1417-1730) through :mod:`photometry_amd.fitsio` (astropy is
+		not available here): primary header (:1463-1505), the ``LIGHTCURVE`` binary table with the 14 columns and their
+		units / display formats (:1507-1600), the time keywords of the table header (:1602-1641), the ``SUMIMAGE`` and
+		``APERTURE`` image extensions with bits 2 (photometry) and 8 (position) OR-ed into the aperture image (:1643-1665),
+		``CHECKSUM`` / ``DATASUM`` (:1720), the reference's file name (:1708-1717).  Not written: the WCS keywords of the
+		image extensions and ``DATE-OBS`` / ``DATE-END`` (astropy ``WCS`` / ``Time`` upstream).
 		"""
+		import datetime
+		from . import fitsio
+		from .fitsio import card
 		if output_folder is None:
 			output_folder = self.output_folder
 		if version is None:
@@ -480,25 +485,105 @@ class BasePhotometry(object):
 			version = self.version
 		os.makedirs(output_folder, exist_ok=True)
 		cadence = int(self.cadence) if self.cadence else 1800
-		fname = f'tess{self.starid:011d}-s{int(self.sector):03d}-c{cadence:04d}-dr{0:02d}-v{int(version):02d}-tasoc_lc.npz'
-		mask = np.array(self.aperture, copy=True)
+		data_rel = int(getattr(self, 'data_rel', 0) or 0)
+		SumImage = np.asarray(self.sumimage, dtype='float64')
+		lc = self.lightcurve
+		indx = np.isfinite(lc['time']) # :1451-1452
+		col = {k: np.asarray(lc[k])[indx] for k in lc.keys()}
+		tgt = self.target
+		undef = fitsio.Undefined()
+
+		def opt(key):
+			v = tgt.get(key) if isinstance(tgt, dict) else None
+			return undef if not v else v
+
+		prim = [
+			card('NEXTEND', 3, 'number of standard extensions'), card('EXTNAME', 'PRIMARY', 'name of extension'),
+			card('ORIGIN', 'TASOC/Aarhus', 'institution responsible for creating this file'),
+			card('DATE', datetime.datetime.now().strftime("%Y-%m-%d"), 'date the file was created'),
+			card('TELESCOP', 'TESS', 'telescope'), card('INSTRUME', 'TESS Photometer', 'detector type'),
+			card('FILTER', 'TESS', 'Photometric bandpass filter'), card('OBJECT', f"TIC {self.starid:d}", 'string version of TICID'),
+			card('TICID', int(self.starid), 'unique TESS target identifier'), card('CAMERA', int(self.camera), 'Camera number'),
+			card('CCD', int(self.ccd), 'CCD number'), card('SECTOR', int(self.sector), 'Observing sector'),
+			card('PROCVER', 'photometry_amd-0.1', 'Version of photometry pipeline'), card('FILEVER', '1.5', 'File format version'),
+			card('DATA_REL', data_rel, 'Data release number'), card('VERSION', int(version), 'Version of the processing'),
+			card('PHOTMET', self.method, 'Photometric method used'),
+			card('RADESYS', 'ICRS', 'reference frame of celestial coordinates'), card('EQUINOX', 2000.0, 'equinox of celestial coordinate system'),
+			card('RA_OBJ', opt('ra_J2000'), '[deg] Right ascension'), card('DEC_OBJ', opt('decl_J2000'), '[deg] Declination'),
+			card('PMRA', opt('pm_ra'), '[mas/yr] RA proper motion'), card('PMDEC', opt('pm_decl'), '[mas/yr] Dec proper motion'),
+			card('TESSMAG', float(tgt['tmag']), '[mag] TESS magnitude'), card('TEFF', opt('teff'), '[K] Effective temperature'),
+		]
+		for key, value in self.additional_headers.items(): # K2P2 settings, AP_CONT, ... (:1497-1499)
+			if isinstance(value, tuple):
+				prim.append(card(key, value[0], value[1] if len(value) > 1 else None))
+			else:
+				prim.append(card(key, value))
+		prim.append(card('DATAVAL', 0, 'Data validation flags'))
+
+		n = len(col['time'])
+		nan = np.full(n, np.nan)
+		f64 = 'column format: 64-bit floating point'
+		i32 = 'column format: signed 32-bit integer'
+		disp = 'column display format'
+
+		def column(name, fmt, arr, unit=None, dsp=None, title=None, unitc=None):
+			return {'name': name, 'format': fmt, 'array': arr, 'unit': unit, 'disp': dsp,
+				'comments': {'TTYPE': title, 'TFORM': f64 if fmt == 'D' else ('column format: 32-bit floating point' if fmt == 'E' else i32),
+					'TUNIT': unitc, 'TDISP': disp}}
+		columns = [
+			column('TIME', 'D', col['time'], 'BJD - 2457000, days', 'D14.7', 'column title: data time stamps', 'column units: Barycenter corrected TESS Julian'),
+			column('TIMECORR', 'E', col['timecorr'], 'd', 'E13.6', 'column title: barycenter - timeslice correction', 'column units: day'),
+			column('CADENCENO', 'J', col['cadenceno'], None, 'I10', 'column title: unique cadence number'),
+			column('FLUX_RAW', 'D', col['flux'], 'e-/s', 'E26.17', 'column title: photometric flux', 'column units: electrons per second'),
+			column('FLUX_RAW_ERR', 'D', col['flux_err'], 'e-/s', 'E26.17', 'column title: photometric flux error', 'column units: electrons per second'),
+			column('FLUX_BKG', 'D', col['flux_background'], 'e-/s', 'E26.17', 'column title: photometric background flux', 'column units: electrons per second'),
+			column('FLUX_CORR', 'D', nan, 'ppm', 'E26.17', 'column title: corrected photometric flux', 'column units: rel. flux in parts-per-million'),
+			column('FLUX_CORR_ERR', 'D', nan, 'ppm', 'E26.17', 'column title: corrected photometric flux error', 'column units: parts-per-million'),
+			column('QUALITY', 'J', np.zeros(n, dtype='int32'), None, 'B16.16', 'column title: photometry quality flags'),
+			column('PIXEL_QUALITY', 'J', col['quality'], None, 'B16.16', 'column title: pixel quality flags'),
+			column('MOM_CENTR1', 'D', col['pos_centroid'][:, 0], 'pixels', 'F10.5', 'column title: moment-derived column centroid', 'column units: pixels'),
+			column('MOM_CENTR2', 'D', col['pos_centroid'][:, 1], 'pixels', 'F10.5', 'column title: moment-derived row centroid', 'column units: pixels'),
+			column('POS_CORR1', 'D', col['pos_corr'][:, 0], 'pixels', 'F14.7', 'column title: column position correction', 'column units: pixels'),
+			column('POS_CORR2', 'D', col['pos_corr'][:, 1], 'pixels', 'F14.7', 'column title: row position correction', 'column units: pixels'),
+		]
+		# time keywords (:1602-1641); without cosmic-ray mitigation information deadc = int_time / frametime
+		tdel = cadence / 86400
+		tstart = float(col['time'][0] - tdel/2) if n else float('nan')
+		tstop = float(col['time'][-1] + tdel/2) if n else float('nan')
+		telapse = tstop - tstart
+		frametime, int_time, readtime = 2.0, 1.98, 0.02
+		deadc = int_time / frametime
+		num_frm = int(round(cadence / frametime))
+		tcards = [
+			card('INHERIT', True, 'inherit the primary header'),
+			card('TIMEREF', 'SOLARSYSTEM', 'barycentric correction applied to times'),
+			card('TIMESYS', 'TDB', 'time system is Barycentric Dynamical Time (TDB)'),
+			card('BJDREFI', 2457000, 'integer part of BTJD reference date'), card('BJDREFF', 0.0, 'fraction of the day in BTJD reference date'),
+			card('TIMEUNIT', 'd', 'time unit for TIME, TSTART and TSTOP'),
+			card('TSTART', tstart, 'observation start time in BTJD'), card('TSTOP', tstop, 'observation stop time in BTJD'),
+			card('MJD-BEG', tstart + 2457000 - 2400000.5, 'observation start time in MJD'),
+			card('MJD-END', tstop + 2457000 - 2400000.5, 'observation start time in MJD'),
+			card('TELAPSE', telapse, '[d] TSTOP - TSTART'), card('LIVETIME', telapse*deadc, '[d] TELAPSE multiplied by DEADC'),
+			card('DEADC', deadc, 'deadtime correction'), card('EXPOSURE', telapse*deadc, '[d] time on source'),
+			card('XPOSURE', frametime*deadc*num_frm, '[s] Duration of exposure'),
+			card('TIMEPIXR', 0.5, 'bin time beginning=0 middle=0.5 end=1'), card('TIMEDEL', tdel, '[d] time resolution of data'),
+			card('INT_TIME', int_time, '[s] photon accumulation time per frame'), card('READTIME', readtime, '[s] readout time per frame'),
+			card('FRAMETIM', frametime, '[s] frame time (INT_TIME + READTIME)'), card('NUM_FRM', num_frm, 'number of frames per time stamp'),
+			card('NREADOUT', int(self.n_readout), 'number of read per cadence'),
+		]
+		mask = np.array(self.aperture, dtype='int32', copy=True) # :1643-1649
 		if self.final_phot_mask is not None:
 			mask[self.final_phot_mask] |= 2
 		if self.final_position_mask is not None:
 			mask[self.final_position_mask] |= 8
-		lc = self.lightcurve
-		headers = {k: v[0] if isinstance(v, tuple) else v for k, v in self.additional_headers.items()}
+		icards = [card('INHERIT', True, 'inherit the primary header'),
+			card('STAMP_R1', int(self._stamp[0]), 'first CCD row of the stamp'), card('STAMP_R2', int(self._stamp[1]), 'last CCD row + 1'),
+			card('STAMP_C1', int(self._stamp[2]), 'first CCD column of the stamp'), card('STAMP_C2', int(self._stamp[3]), 'last CCD column + 1')]
+		fname = (f'tess{self.starid:011d}-s{int(self.sector):03d}-{int(self.camera):d}-{int(self.ccd):d}-c{cadence:04d}'
+			f'-dr{data_rel:02d}-v{int(version):02d}-tasoc_lc.fits.gz')
 		path = os.path.join(output_folder, fname)
-		np.savez_compressed(path, TIME=lc['time'], TIMECORR=lc['timecorr'].astype('float32'), CADENCENO=lc['cadenceno'],
-			FLUX_RAW=lc['flux'], FLUX_RAW_ERR=lc['flux_err'], FLUX_BKG=lc['flux_background'],
-			FLUX_CORR=np.full(self.Ntimes, np.nan), FLUX_CORR_ERR=np.full(self.Ntimes, np.nan),
-			QUALITY=np.zeros(self.Ntimes, dtype='int32'), PIXEL_QUALITY=lc['quality'],
-			MOM_CENTR1=lc['pos_centroid'][:, 0], MOM_CENTR2=lc['pos_centroid'][:, 1],
-			POS_CORR1=lc['pos_corr'][:, 0], POS_CORR2=lc['pos_corr'][:, 1],
-			APERTURE=mask, SUMIMAGE=self.sumimage, STAMP=np.asarray(self._stamp),
-			HEADER_KEYS=np.array(list(headers.keys())), HEADER_VALUES=np.array([str(v) for v in headers.values()]),
-			STARID=self.starid, TESSMAG=self.target['tmag'], SECTOR=self.sector, CAMERA=self.camera, CCD=self.ccd,
-			PHOTMET=self.method, VERSION=version)
+		fitsio.write(path, [fitsio.primary_hdu(prim), fitsio.bintable_hdu('LIGHTCURVE', columns, tcards),
+			fitsio.image_hdu('SUMIMAGE', SumImage, icards), fitsio.image_hdu('APERTURE', mask, icards)])
 		self._details['filepath_lightcurve'] = os.path.relpath(path, os.path.abspath(self.output_folder_base)).replace('\\', '/')
 		return path
 

@@ -55,11 +55,17 @@ def test_aperturephotometry_like_the_reference(ctx, tmp_path):
 			assert pho.additional_headers['KP_THRES'][0] == 0.8 and pho.additional_headers['KP_MIPIX'][0] == 4
 			fname = pho.save_lightcurve()
 		# saved file: same table, aperture bits 2 and 8 set (tests/test_aperturephotometry.py:70-96)
-		f = np.load(fname)
-		np.testing.assert_array_equal(f['FLUX_RAW'], ref['flux'])
-		np.testing.assert_array_equal(f['MOM_CENTR1'], pho.lightcurve['pos_centroid'][:, 0])
-		assert np.any(f['APERTURE'] & 2 != 0) and np.any(f['APERTURE'] & 8 != 0) and np.all(f['APERTURE'] & 1 != 0)
-		assert 'KP_THRES' in list(f['HEADER_KEYS'])
+		from photometry_amd import fitsio
+		assert fname.endswith('-tasoc_lc.fits.gz')
+		hdus = fitsio.read(fname)
+		assert [h.get('EXTNAME') for h, _ in hdus] == ['PRIMARY', 'LIGHTCURVE', 'SUMIMAGE', 'APERTURE']
+		assert all(h['__checksum_ok__'] and h['__datasum_ok__'] for h, _ in hdus)
+		prim, tab, aper = hdus[0][0], hdus[1][1], hdus[3][1]
+		np.testing.assert_array_equal(tab['FLUX_RAW'], ref['flux'])
+		np.testing.assert_array_equal(tab['MOM_CENTR1'], pho.lightcurve['pos_centroid'][:, 0])
+		assert np.any(aper & 2 != 0) and np.any(aper & 8 != 0) and np.all(aper & 1 != 0)
+		assert prim['KP_THRES'] == 0.8 and prim['TICID'] == int(s.target_starid[i]) and prim['FILEVER'] == '1.5'
+		np.testing.assert_array_equal(hdus[2][1], pho.sumimage)
 
 
 def test_tessphot_dispatch_and_details(ctx, tmp_path):
