@@ -76,12 +76,11 @@ def main_linpsf(args, ctx, rank, world, dist, torch, device_sync, barrier):
 	"""BASELINE configs[3]: linpsf_photometry PSF-fit path over the same cube size (images cube resident)."""
 	import numpy as np
 	from photometry_amd import simulate, engine, pipeline, psf as hpsf
-	from oracle import psf as opsf
 	Nt, T, H = args.targets, args.cadences, args.stamp
 	W = H
 	scene = simulate.make_scene(Nt, T, H, W, seed=args.seed * 1000 + rank)
 	cubes = engine.synth_fill(ctx, scene, images=True, images_err=False, backgrounds=False)
-	prf = opsf.synthetic_prf(seed=1) # synthetic stand-in for the SPOC PRF file (git-LFS object upstream)
+	prf = simulate.synthetic_prf(seed=1) # synthetic stand-in for the SPOC PRF file (git-LFS object upstream)
 	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
 	batch = pipeline.LinPSFBatch(ctx, scene, model, images=cubes['images'])
 	for _ in range(args.warmup):
@@ -121,7 +120,7 @@ def main_linpsf(args, ctx, rank, world, dist, torch, device_sync, barrier):
 		}
 		if world == 1 and args.cpu_sample > 0:
 			# CPU baseline: the oracle loop (reference-equivalent, scipy FITPACK integral per pixel) on a few targets
-			from oracle import linpsf as olin
+			from oracle import linpsf as olin, psf as opsf
 			ns = min(Nt, 4)
 			tsub = min(T, 100)
 			host = np.empty((ns, H, W, cubes['images'].t_pitch), dtype='float32')

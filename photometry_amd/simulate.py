@@ -204,3 +204,24 @@ def fill_cubes(s, nan_fraction=1e-3, with_raw=False, dtype='float32'):
 	ap[(1581 <= cgrid) & (cgrid <= 2092)] |= 256
 	s.aperture = ap
 	return s
+
+
+def synthetic_prf(n_side=5, sigma=0.9, samples_per_pixel=9, halfwidth=6.5, seed=0):
+	"""
+	Synthetic stand-in for a SPOC ``*-characterized-prf.mat`` file (the real ones are git-LFS objects upstream; the
+	reference reads ``prfStruct.values / ccdRow / ccdColumn / prfRow / prfColumn``, psf.py:81-104): ``n_side**2`` PRF
+	samples spread over the CCD, each a 117 x 117 image at 9 samples per pixel over +-6.5 px, Gaussian
+	cores of slightly different widths plus a faint broad halo so that the inverse-distance blend (psf.py:101-113)
+	matters.  Returns ``dict(values, ccdColumn, ccdRow, prfColumn, prfRow)``.
+	"""
+	rng = np.random.default_rng(seed)
+	n = int(round(2 * halfwidth * samples_per_pixel))
+	grid = (np.arange(n) - (n - 1) / 2) / samples_per_pixel
+	cols, rows = np.meshgrid(np.linspace(45, 2092, n_side), np.linspace(1, 2048, n_side))
+	values = np.empty((n_side**2, n, n))
+	for i in range(n_side**2):
+		sx, sy = sigma * (1 + 0.08 * rng.standard_normal(2))
+		core = np.outer(np.exp(-0.5 * (grid / sx)**2), np.exp(-0.5 * (grid / sy)**2))
+		halo = np.outer(np.exp(-0.5 * (grid / (3 * sx))**2), np.exp(-0.5 * (grid / (3 * sy))**2))
+		values[i] = core + 1e-4 * halo
+	return {'values': values, 'ccdColumn': cols.ravel(), 'ccdRow': rows.ravel(), 'prfColumn': grid.copy(), 'prfRow': grid.copy()}
