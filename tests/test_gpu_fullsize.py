@@ -1,0 +1,115 @@
+# -*- coding: utf-8 -*-
+"""
+Parity at BASELINE.json's full size (configs[2]: 10 000 targets x 1 300 cadences x 15x15, three cubes = 35 GB in HBM)
+through size-independent properties, because the oracle needs ~40 ms per target:
+
+* the fused kernel and the three stand-alone kernels give bit-identical outputs for all 10 000 targets;
+* running the batch as two unequal chunks (views of the same cubes) gives the same bits as one launch
+  (targets are independent: no cross-target state, no launch-geometry dependence);
+* a second run reproduces the first bit for bit (fixed-shape reductions, no atomics on the data path);
+* a seeded sample of targets spread over the whole batch equals the oracle bit for bit;
+* an exact power-of-two rescaling of the inputs (medium size, host cubes) leaves masks unchanged and scales the fluxes exactly.
+"""
+import numpy as np
+import pytest
+from photometry_amd import simulate, engine, pipeline
+
+pytestmark = pytest.mark.gpu
+KEYS = ('sumimage', 'mask', 'status', 'flags', 'contamination', 'flux', 'flux_err', 'flux_background', 'centroid_col', 'centroid_row')
+
+
+def _collect(work):
+	out = work.lc.to_host()
+	for k in ('sumimage', 'mask', 'status', 'flags', 'contamination', 'cat_in_mask'):
+		out[k] = getattr(work, k).to_host()
+	return out
+
+
+def _checksum(out):
+	"""A checksum of checksums: one digest per output array (over the bit patterns, so NaN == NaN)."""
+	import hashlib
+	return {k: hashlib.sha256(np.ascontiguousarray(out[k]).tobytes()).hexdigest() for k in KEYS}
+
+
+def test_full_size_properties():
+	from photometry_amd.device import Context
+	from oracle import aperture as oap
+	ctx = Context(0)
+	hbm = ctx.info()['hbm_bytes']
+	if hbm < 60e9:
+		pytest.skip("needs the 288 GB device")
+	Nt, T, H, W = 10000, 1300, 15, 15
+	scene = simulate.make_scene(Nt, T, H, W, seed=4242)
+	scene.aperture = None
+	cubes = engine.synth_fill(ctx, scene)
+	batch = pipeline.ApertureBatch(ctx, scene, cubes=cubes)
+	w_fused = pipeline.ApertureWork(ctx, batch)
+	pipeline.aperture_step(ctx, batch, w_fused, fused=True)
+	ctx.sync()
+	a = _collect(w_fused)
+	ca = _checksum(a)
+	assert (a['status'] == 1).sum() > 0.8 * Nt
+
+	# fused == three kernels
+	w3 = pipeline.ApertureWork(ctx, batch)
+	pipeline.aperture_step(ctx, batch, w3, fused=False)
+	ctx.sync()
+	b = _collect(w3)
+	for k in KEYS:
+		np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+	del w3, b
+
+	# two unequal chunks == one launch; and the run is reproducible
+	w2 = pipeline.ApertureWork(ctx, batch)
+	cut = 3333
+	pipeline.aperture_step(ctx, batch.chunk(0, cut), w2.chunk(0, cut))
+	pipeline.aperture_step(ctx, batch.chunk(cut, Nt - cut), w2.chunk(cut, Nt - cut))
+	ctx.sync()
+	assert _checksum(_collect(w2)) == ca
+	pipeline.aperture_step(ctx, batch, w2)
+	ctx.sync()
+	assert _checksum(_collect(w2)) == ca
+
+	# a seeded sample across the batch against the oracle
+	rng = np.random.default_rng(7)
+	sample = np.sort(rng.choice(Nt, 24, replace=False))
+	ap = np.ones((H, W), dtype='int32')
+	for i in sample:
+		host = {}
+		for name in ('images', 'images_err', 'backgrounds'):
+			view = cubes[name].slice0(int(i), 1)
+			host[name] = view.to_host()[0]
+		ref = oap.do_photometry(a['sumimage'][i], host['images'], host['images_err'], host['backgrounds'], tuple(scene.stamps[i]),
+			scene.target_pos_row[i], scene.target_pos_column[i], scene.target_tmag[i], scene.target_starid[i], scene.catalog_of(int(i)), ap)
+		assert int(a['status'][i]) == ref['status']
+		if ref.get('mask') is not None and ref['status'] != 2:
+			np.testing.assert_array_equal(a['mask'][i].astype(bool), ref['mask'])
+			np.testing.assert_array_equal(a['flux'][i], ref['flux'])
+			np.testing.assert_array_equal(a['flux_err'][i], ref['flux_err'])
+			np.testing.assert_array_equal(a['flux_background'][i], ref['flux_background'])
+	ctx.close()
+
+
+def test_power_of_two_scaling():
+	"""x4 on the three cubes is exact in floating point: same masks, fluxes exactly x4 (centroids unchanged)."""
+	from photometry_amd.device import Context
+	ctx = Context(0)
+	s = simulate.make_scene(300, 120, 15, 15, seed=99)
+	simulate.fill_cubes(s)
+	s.aperture = None
+	a = pipeline.run_aperture(ctx, s)
+	s.images = s.images * np.float32(4)
+	s.images_err = s.images_err * np.float32(4)
+	s.backgrounds = s.backgrounds * np.float32(4)
+	b = pipeline.run_aperture(ctx, s)
+	same = (a['status'] == b['status'])
+	assert same.mean() > 0.98 # the KDE bandwidth goes through pow(n, -0.2) and exp(): scaling is exact there too, but allow razor edges
+	ok = same & (a['status'] != 2)
+	idx = np.flatnonzero(ok & np.all(a['mask'] == b['mask'], axis=(1, 2)))
+	assert len(idx) > 0.95 * ok.sum()
+	np.testing.assert_array_equal(b['flux'][idx], 4 * a['flux'][idx])
+	np.testing.assert_array_equal(b['flux_err'][idx], 4 * a['flux_err'][idx])
+	np.testing.assert_array_equal(b['flux_background'][idx], 4 * a['flux_background'][idx])
+	np.testing.assert_array_equal(b['sumimage'][idx], 4 * a['sumimage'][idx])
+	np.testing.assert_allclose(b['pos_centroid'][idx], a['pos_centroid'][idx], rtol=1e-15, equal_nan=True)
+	ctx.close()
