@@ -12,20 +12,25 @@
 // pixel's time series (coalesced) and NO LDS transposition is needed to get a frame into registers.
 // A frame (one cadence of one target, <= 256 pixels) is owned by a QUAD of lanes, 64 pixel values per
 // lane in VGPRs; a wavefront holds 16 frames, a 256-thread workgroup 64 consecutive cadences.
-//   1. each lane sorts its 64 values with a fully unrolled bitonic network (v_min_f32 / v_max_f32 on
-//      compile-time register indices: no divergence, no memory traffic);
-//   2. three cross-lane bitonic stages (DPP quad_perm exchanges with lane^1 / lane^2) merge the four
-//      sorted runs into one sorted 256-sequence distributed over the quad (rank r lives in lane r/64);
-//   3. sigma clipping stays in registers: the kept set is always a contiguous rank range [a, b) of the
-//      sorted values, so per clipping pass each lane sums its own registers under a rank predicate
-//      (float64 S1, S2) and COUNTS the values beyond the two thresholds; a DPP quad reduction gives the
-//      frame totals, the new bounds follow from the counts, the median is picked by rank.
-// No LDS, no divergence inside a pass, ~12 KB of code: the earlier one-thread-per-frame variant (256 values per lane, 110 KB of
-// unrolled code, 1 wavefront per SIMD) was instruction-cache and issue bound at 33 ms for the C3 cube.
+//   1. each lane sorts its 64 values with a fully unrolled bitonic network (v_min_f32 / v_max_f32 on compile-time
+//      register indices: no divergence, no memory traffic);
+//   2. the four sorted runs are merged across the quad: a MIRROR stage (register j against register 63-j of the partner
+//      lane, DPP quad_perm) turns two ascending runs into two bitonic halves, all further stages are ascending merges;
+//   3. one predicated pass over the registers gives the float64 sums of the frame; the sorted values are staged in LDS and
+//      indexed by rank for the clipping passes (median = two reads, bounds by binary search, sums updated by the ranks
+//      that leave the kept range).
+// Measured alternatives (C3 cube): one thread per frame with 256 registers 33.6 ms (instruction-cache bound); clipping as
+// two full register passes per iteration 14.1 ms; a register prefetch buffer 15.0 ms (one wave per SIMD); loads through a
+// coalescing LDS transpose tile (256-byte segments, two workgroup barriers) 14.2 ms; this version 10.8 ms.
 #include "common.h"
 #include <cmath>
 
 namespace {
+
+// v_min_f32 / v_max_f32 without the NaN-quieting canonicalisation fminf / fmaxf carry (no value is ever NaN here: masked
+// pixels are +inf sentinels); plain asm so that the scheduler is still free to reorder
+__device__ __forceinline__ float tp_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float tp_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // Compile-time bitonic network on a register array.  One template instantiation per (size, stride)
 // stage keeps every unrolled body small enough for the optimiser's full-unroll budget.
@@ -38,7 +43,7 @@ struct BitonicStage {
 			const int hi = lo + STRIDE;
 			const bool up = ((lo & SIZE) == 0);
 			const float a = v[lo], b = v[hi];
-			const float mn = fminf(a, b), mx = fmaxf(a, b);
+			const float mn = tp_min(a, b), mx = tp_max(a, b);
 			v[lo] = up ? mn : mx;
 			v[hi] = up ? mx : mn;
 		}
@@ -75,33 +80,39 @@ __device__ __forceinline__ float sextractor_mode(double med, double mean, double
 	return (float)bkg;
 }
 
-// DPP quad permutes: value of lane^1 / lane^2 within the quad
+// DPP quad permutes: value of lane^1 / lane^2 / lane^3 within the quad
 __device__ __forceinline__ float quad_xor1(float x) {
 	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false)); // quad_perm [1,0,3,2]
 }
 __device__ __forceinline__ float quad_xor2(float x) {
 	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, false)); // quad_perm [2,3,0,1]
 }
-template <int XOR>
-__device__ __forceinline__ void cross_stage(float (&v)[64], bool keepmin) {
+__device__ __forceinline__ float quad_rev(float x) {
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x1B, 0xF, 0xF, false)); // quad_perm [3,2,1,0]
+}
+// compare-exchange of register j with register j of lane^1: the lower lane keeps the minimum
+__device__ __forceinline__ void cross_stage_xor1(float (&v)[64], bool keepmin) {
 #pragma unroll
 	for (int j = 0; j < 64; ++j) {
-		const float p = (XOR == 1) ? quad_xor1(v[j]) : quad_xor2(v[j]);
-		const float mn = fminf(v[j], p), mx = fmaxf(v[j], p);
-		v[j] = keepmin ? mn : mx;
+		const float p = quad_xor1(v[j]);
+		v[j] = keepmin ? tp_min(v[j], p) : tp_max(v[j], p);
 	}
 }
-__device__ __forceinline__ void flip_sign(float (&v)[64], bool flip) {
-	const int m = flip ? (int)0x80000000 : 0;
+// MIRROR stage of a merge: register j against register 63-j of the partner lane (lane^1 for runs of 64, lane^3 for runs of
+// 128).  Two ascending runs become two bitonic halves whose merges are all ascending -- no direction flags, no sign flips.
+template <bool ACROSS_QUAD>
+__device__ __forceinline__ void mirror_stage(float (&v)[64], bool keepmin) {
+	float w[64];
 #pragma unroll
-	for (int j = 0; j < 64; ++j) v[j] = __int_as_float(__float_as_int(v[j]) ^ m);
+	for (int j = 0; j < 64; ++j) {
+		const float p = ACROSS_QUAD ? quad_rev(v[63 - j]) : quad_xor1(v[63 - j]);
+		w[j] = keepmin ? tp_min(v[j], p) : tp_max(v[j], p);
+	}
+#pragma unroll
+	for (int j = 0; j < 64; ++j) v[j] = w[j];
 }
-// ascending bitonic MERGE of a lane's 64 values (strides 32..1); descending when desc (sign trick)
-__device__ __forceinline__ void local_merge(float (&v)[64], bool desc) {
-	flip_sign(v, desc);
-	BitonicStage<64, 64, 32>::run(v);
-	flip_sign(v, desc);
-}
+// ascending bitonic MERGE of a lane's 64 values (strides 32..1)
+__device__ __forceinline__ void local_merge(float (&v)[64]) { BitonicStage<64, 64, 32>::run(v); }
 
 constexpr int kFramesPerWave = 16;
 constexpr int kBkgThreads = 128;
@@ -139,12 +150,12 @@ __global__ __launch_bounds__(kBkgThreads) void tp_bkg_stamp_kernel(BkgArgs a, in
 
 	// --- distributed bitonic sort of the 256 values of the quad: global index (= rank) g = q*64 + j ---
 	BitonicLevel<64, 32>::run(v);                       // sizes 2..32: directions fixed by the local index
-	local_merge(v, (q & 1) != 0);                       // size 64: ascending iff (g & 64) == 0
-	cross_stage<1>(v, ((q & 1) == 0) == ((q & 2) == 0)); // size 128, stride 64: keep min iff (is-low == up)
-	local_merge(v, (q & 2) != 0);                       // size 128, strides 32..1: ascending iff (g & 128) == 0
-	cross_stage<2>(v, (q & 2) == 0);                    // size 256, stride 128
-	cross_stage<1>(v, (q & 1) == 0);                    // size 256, stride 64
-	local_merge(v, false);                              // size 256, strides 32..1
+	local_merge(v);                                     // size 64: every lane ascending
+	mirror_stage<false>(v, (q & 1) == 0);               // size 128: mirror against lane^1 ...
+	local_merge(v);                                     //           ... then ascending merges: lanes (0,1) and (2,3) sorted
+	mirror_stage<true>(v, (q & 2) == 0);                // size 256: mirror against lane^3,
+	cross_stage_xor1(v, (q & 1) == 0);                  //           stride 64 against lane^1,
+	local_merge(v);                                     //           strides 32..1
 
 	// --- sigma clipping.  The kept set is always a contiguous rank range [lo_i, hi_i) of the sorted values.  One
 	// predicated pass over the lane's 64 registers gives the float64 sums of the whole frame; the sorted values are
