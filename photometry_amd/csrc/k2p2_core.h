@@ -142,7 +142,8 @@ struct Shared {
 
 // LDS plan.  The arrays of the threshold phase (A2: sorted fluxes + the KDE grids) are dead once CUT is known and the
 // arrays of the clustering / watershed / assembly phases (A3..A5) are not touched before, so the two sets share one
-// region: 16.7 KB instead of 22.9 KB per 15x15 target, i.e. 9 instead of 7 resident wavefronts per CU.
+// region; with 16-bit labels that is 14.0 KB instead of 22.9 KB per 15x15 target, i.e. 11 instead of 7 resident
+// wavefronts per CU.
 struct SharedLayout {
 	int Pa, Pp, Pp_sort;
 	size_t off_region, region_bytes, off_ints, off_bytes, total;
