@@ -39,7 +39,7 @@ extern "C" int tp_k2p2_masks(tp_ctx* ctx, int32_t n_targets, int32_t height, int
 	TP_REQUIRE(ctx, d_mask && d_status && d_flags && d_contamination, "tp_k2p2_masks: null output pointer");
 	if (n_targets == 0) return TP_OK;
 	const size_t shmem = k2p2::shared_bytes(height * width);
-	TP_REQUIRE(ctx, shmem <= 160 * 1024, "tp_k2p2_masks: stamp too large for the LDS-resident mask builder (about 52x52 pixels)");
+	TP_REQUIRE(ctx, shmem <= 160 * 1024, "tp_k2p2_masks: stamp too large for the LDS-resident mask builder (about 54x54 pixels)");
 
 	k2p2::Params prm = k2p2::default_params();
 	if (params) {

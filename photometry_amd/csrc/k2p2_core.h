@@ -106,7 +106,7 @@ struct Target {
 	double* timing;           // optional [16] per-phase cycle counters (diagnostics)
 };
 
-// Labels, pixel indices and counters bounded by P (<= 52*52, the LDS limit) are 16-bit: LDS footprint decides how many targets
+// Labels, pixel indices and counters bounded by P (<= 54*54, the LDS limit) are 16-bit: LDS footprint decides how many targets
 // (wavefronts) a CU holds at once.
 typedef int16_t lab_t;
 
@@ -119,9 +119,9 @@ struct Shared {
 	double* Z;        // [P]
 	double* dist;     // [P]
 	double* tmp;      // [P]
-	double* hval;     // [P] heap values
+	double* hval;     // [max(64, P/2 + 1)] per-lane scratch / the watershed's rank -> pixel table (int32)
 	double* red;      // [64]
-	double* grid;     // [4*kGrid]: binned, dens, Yre, Yim
+	double* grid;     // [kGrid + 132]: binned (later dens), Yre[66], Yim[66]
 	lab_t* lab;       // [P] DBSCAN labels
 	lab_t* lab2;      // [P] labels after watershed
 	lab_t* mark;      // [P] markers / component labels
@@ -142,10 +142,10 @@ struct Shared {
 
 // LDS plan.  The arrays of the threshold phase (A2: sorted fluxes + the KDE grids) are dead once CUT is known and the
 // arrays of the clustering / watershed / assembly phases (A3..A5) are not touched before, so the two sets share one
-// region; with 16-bit labels that is 14.0 KB instead of 22.9 KB per 15x15 target, i.e. 11 instead of 7 resident
-// wavefronts per CU.
+// region; with 16-bit labels and a half-size scratch that is 13.1 KB instead of 22.9 KB per 15x15 target,
+// i.e. 12 instead of 7 resident wavefronts per CU.
 struct SharedLayout {
-	int Pa, Pp, Pp_sort;
+	int Pa, Pp, Pp_sort, hval_len;
 	size_t off_region, region_bytes, off_ints, off_bytes, total;
 };
 
@@ -158,8 +158,9 @@ inline TP_HD SharedLayout shared_layout(int P) {
 	while (L.Pp_sort < P) L.Pp_sort <<= 1;
 	const size_t Pa = (size_t)L.Pa;
 	L.off_region = (2 * Pa + 64) * 8;                                   // S, tmp, red
-	const size_t phase1 = ((size_t)L.Pp + 4 * kGrid + 132) * 8;        // srt, grid (binned, dens, Yre[66], Yim[66]), twiddle copy [2*kGrid]
-	const size_t phase2 = 3 * Pa * 8 + 4 * Pa * sizeof(lab_t);         // Z, dist, hval | lab, lab2, mark, wsout
+	const size_t phase1 = ((size_t)L.Pp + 3 * kGrid + 132) * 8;        // srt, grid (binned = dens [kGrid], Yre[66], Yim[66]), twiddle copy [2*kGrid]
+	L.hval_len = (Pa / 2 + 1 > 64) ? (Pa / 2 + 1) : 64;
+	const size_t phase2 = (2 * Pa + (size_t)L.hval_len) * 8 + 4 * Pa * sizeof(lab_t); // Z, dist, hval | lab, lab2, mark, wsout
 	L.region_bytes = ((phase1 > phase2 ? phase1 : phase2) + 15) & ~(size_t)15;
 	L.off_ints = L.off_region + L.region_bytes;                         // hage, hpix, ired, scal
 	L.off_bytes = L.off_ints + (2 * ((Pa + 1) & ~(size_t)1) * sizeof(lab_t)) + (64 + 32) * 4; // idx, core, lmax, msk, sat, res
@@ -182,13 +183,13 @@ inline TP_DEV void shared_carve(Shared& k, void* base, int H, int W, int lane, c
 	// phase 1 view of the region
 	double* r1 = (double*)(b0 + L.off_region);
 	k.srt = r1; r1 += L.Pp;
-	k.grid = r1; r1 += 2 * kGrid + 132;
+	k.grid = r1; r1 += kGrid + 132;
 	k.twl = r1;
 	// phase 2 view of the region
 	double* r2 = (double*)(b0 + L.off_region);
 	k.Z = r2; r2 += Pa;
 	k.dist = r2; r2 += Pa;
-	k.hval = r2; r2 += Pa;
+	k.hval = r2; r2 += L.hval_len;
 	lab_t* ri = (lab_t*)r2;
 	k.lab = ri; ri += Pa;
 	k.lab2 = ri; ri += Pa;
@@ -594,7 +595,7 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 		const double b = ((nc > 0) ? k.srt[nc - 1] : tp_nan()) + 3.0 * bw;
 		const double delta = (b - a) / (double)(M - 1);   // np.linspace retstep
 		const double RANGE = b - a;
-		double* binned = k.grid; double* dens = k.grid + M; double* Yre = k.grid + 2 * M; double* Yim = k.grid + 2 * M + 66;
+		double* binned = k.grid; double* dens = k.grid; double* Yre = k.grid + M; double* Yim = k.grid + M + 66; // dens overwrites binned (dead after the forward transform)
 		// the DFT twiddles next to the grids (LDS) for the two transforms below
 		TP_PAR_FOR(j, 2 * M) k.twl[j] = k.twid[j];
 		// fast_linbin: bin m accumulates, in data order, (1 - rem) from points with li == m and rem from li == m-1.
@@ -785,7 +786,8 @@ inline TP_DEV double nanmedian_small(const double* v, int n, double* scratch) {
 }
 
 // k2p2_saturated for ONE mask (k2p2v2.py:291-341): mask in k.msk -> additions in k.sat.
-// Uses k.tmp / k.hval as column scratch.  Returns (uniform) number of pixels set in k.sat.
+// Uses k.tmp / k.dist as column scratch (dist holds no live data at either call site: before the cluster's blur, after the
+// watershed).  Returns (uniform) number of pixels set in k.sat.
 inline TP_DEV int saturated_one(Shared& k) {
 	const int P = k.P, H = k.H, W = k.W;
 	TP_PAR_FOR(p, P) k.sat[p] = 0;
@@ -806,7 +808,7 @@ inline TP_DEV int saturated_one(Shared& k) {
 	// one column per lane (columns are independent: k2p2v2.py:312-339)
 	TP_PAR_FOR(c, W) {
 		double* pix = k.tmp + (size_t)c * H;      // [H] per column (W*H = P doubles)
-		double* scr = k.hval + (size_t)c * H;
+		double* scr = k.dist + (size_t)c * H;
 		int n = 0;
 		for (int r = 0; r < H; ++r) if (k.msk[r * W + c]) pix[n++] = k.S[r * W + c];
 		if (n == 0) continue;

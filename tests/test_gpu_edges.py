@@ -95,14 +95,14 @@ def test_single_cadence_and_all_flagged(ctx):
 
 
 def test_largest_lds_resident_stamp(ctx):
-	"""52 x 52 pixels is the limit of the LDS-resident mask builder; one pixel more is an error, not a fallback."""
+	"""52 x 52 pixels run on the LDS-resident mask builder (the limit is 54 x 54); a stamp beyond it is an error, not a fallback."""
 	from photometry_amd._lib import TessphotError
 	s = simulate.make_scene(2, 20, 52, 52, seed=6, tmag_range=(6.5, 8.0))
 	simulate.fill_cubes(s)
 	s.aperture = None
 	got = pipeline.run_aperture(ctx, s)
 	assert _compare(s, got) >= 1
-	s3 = simulate.make_scene(1, 8, 53, 53, seed=6)
+	s3 = simulate.make_scene(1, 8, 60, 60, seed=6)
 	simulate.fill_cubes(s3)
 	s3.aperture = None
 	with pytest.raises(TessphotError):
