@@ -5,7 +5,7 @@
 //
 // Why fuse (gfx950): A1 and A6 are HBM streaming, K2P2 is ~250 us of latency-bound LDS work per target that
 // leaves the memory system idle; as three kernels each phase runs alone on the chip.  Here a wavefront owns a
-// target from the first load to the last store; the 11 wavefronts resident per CU (LDS: 14 KB each at 15x15) are at
+// target from the first load to the last store; the 12 wavefronts resident per CU (LDS: 13 KB each at 15x15) are at
 // different phases at any time, so the streaming of some targets hides the mask building of the others, and the
 // whole batch is one launch (no launch gaps, no sum image / mask round trip through HBM).
 //

@@ -2,7 +2,7 @@
 // in LDS (see k2p2_core.h for the algorithm and its reference citations).
 //
 // This stage is O(1) in the number of cadences (it sees only the 15x15 sum image), latency-bound
-// integer / float64 work; it is NOT on the HBM roofline -- 10 000 targets x 14 KB of LDS each (15x15 stamps).
+// integer / float64 work; it is NOT on the HBM roofline -- 10 000 targets x 13 KB of LDS each (15x15 stamps).
 #include "common.h"
 #include "k2p2_args.h"
 #include <cmath>
