@@ -271,7 +271,8 @@ int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
  *            variability, mask_size, edge_flux, flags.  flags (as a float64 integer): 1 all fluxes NaN, 2 all
  *            errors NaN (both ValueError upstream, :1346-1349), 4 invalid time vector (ValueError in
  *            rms_timescale), 8 no detrending ("Could not detrend ..." warning: detrend = 0), 16 more
- *            time bins than the LDS buffer holds (rms_hour = NaN).                                     */
+ *            time bins than cadences (rms_hour = NaN).  Light curves up to ~3 900 cadences are reduced out of
+ *            LDS, longer ones (2-minute data) out of a context-owned HBM scratch with the same code.    */
 int tp_lightcurve_diagnostics(tp_ctx* ctx, int32_t n_targets, int32_t n_cad,
 	const double* d_flux, const double* d_flux_err, const double* d_centroid_col, const double* d_centroid_row, int64_t lc_pitch,
 	const double* d_time, const int32_t* d_quality, int64_t quality_target_stride, uint32_t bitmask,

@@ -21,6 +21,8 @@
 #include "common.h"
 #include <cmath>
 
+void* tp_ctx_scratch(tp_ctx* ctx, size_t bytes); // aperture.hip
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -30,6 +32,7 @@ struct DiagArgs {
 	const double* time; const int32_t* quality; int64_t quality_stride; uint32_t bitmask;
 	const int32_t* status; const double* sumimage; const uint8_t* mask; int height, width;
 	int n_cad; int tp2; double timescale; double* out;
+	unsigned char* gscratch; size_t gscratch_per_target; // series arrays in HBM when they do not fit the LDS (long light curves)
 };
 
 enum { F_ALLNAN_FLUX = 1, F_ALLNAN_ERR = 2, F_BAD_TIME = 4, F_NO_DETREND = 8, F_TOO_MANY_BINS = 16 };
@@ -142,16 +145,20 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 	const int target = blockIdx.x;
 	const int tid = threadIdx.x;
 	const int T = a.n_cad, TP2 = a.tp2;
-	double* srt = lds;                 // [TP2] scratch series (TP2 = max(T, 256))
+	// small reduction scratch always in LDS; the series arrays in LDS when they fit, else in a per-target slice of HBM
+	// (2-minute-cadence light curves: ~20 000 cadences; same code, the reductions then run out of L2)
+	double* red = lds;                 // [kThreads]
+	int* ired = reinterpret_cast<int*>(red + kThreads); // [kThreads + 1]
+	unsigned int* hist = reinterpret_cast<unsigned int*>(ired + kThreads + 1); // [260] radix-select scratch
+	double* series = a.gscratch ? reinterpret_cast<double*>(a.gscratch + (size_t)blockIdx.x * a.gscratch_per_target)
+		: reinterpret_cast<double*>(hist + 260 + ((kThreads + 1 + 260) & 1)); // keep 8-byte alignment
+	double* srt = series;              // [TP2] scratch series (TP2 = max(T, 256))
 	double* fb = srt + TP2;            // [TP2] binned flux
 	double* gflux = fb + TP2;          // [T] relative flux of the good cadences
 	double* gerr = gflux + T;          // [T]
 	double* gtime = gerr + T;          // [T]
-	double* red = gtime + T;           // [kThreads]
-	int* gk = reinterpret_cast<int*>(red + kThreads); // [T] original index of the g-th good cadence
-	int* ired = gk + T;                // [kThreads + 1]
-	unsigned int* hist = reinterpret_cast<unsigned int*>(ired + kThreads + 1); // [260] radix-select scratch
-	int* bt = reinterpret_cast<int*>(hist + 260); // [T] time bin of every good cadence
+	int* gk = reinterpret_cast<int*>(gtime + T); // [T] original index of the g-th good cadence
+	int* bt = gk + T;                  // [T] time bin of every good cadence
 	double* o = a.out + (int64_t)target * 10;
 	const double nan = __builtin_nan("");
 
@@ -429,13 +436,21 @@ extern "C" int tp_lightcurve_diagnostics(tp_ctx* ctx, int32_t n_targets, int32_t
 	TP_REQUIRE(ctx, timescale_days > 0, "tp_lightcurve_diagnostics: timescale must be positive");
 	if (n_targets == 0) return TP_OK;
 	const int tp2 = (n_cad > 256) ? n_cad : 256; // scratch length: the series, the time bins (capped) and the <= 256 edge pixels
-	const size_t shmem = ((size_t)2 * tp2 + 3 * (size_t)n_cad + kThreads) * sizeof(double) + (2 * (size_t)n_cad + kThreads + 1 + 260) * sizeof(int) + 16;
-	TP_REQUIRE(ctx, shmem <= 160 * 1024, "tp_lightcurve_diagnostics: light curve too long for the LDS-resident reductions (about 4000 cadences)");
+	const size_t small_bytes = kThreads * sizeof(double) + ((size_t)kThreads + 1 + 260 + 1) * sizeof(int);
+	const size_t series_bytes = (((size_t)2 * tp2 + 3 * (size_t)n_cad) * sizeof(double) + 2 * (size_t)n_cad * sizeof(int) + 15) & ~(size_t)15;
+	size_t shmem = small_bytes + series_bytes + 16;
+	unsigned char* gscratch = nullptr;
+	if (shmem > 160 * 1024) { // long light curves: the series arrays move to HBM scratch, one slice per target
+		gscratch = static_cast<unsigned char*>(tp_ctx_scratch(ctx, series_bytes * (size_t)n_targets));
+		TP_REQUIRE(ctx, gscratch != nullptr, "tp_lightcurve_diagnostics: out of device memory for the series scratch");
+		shmem = small_bytes + 16;
+	}
 	DiagArgs a;
 	a.flux = d_flux; a.flux_err = d_flux_err; a.ccol = d_centroid_col; a.crow = d_centroid_row; a.lc_pitch = lc_pitch;
 	a.time = d_time; a.quality = d_quality; a.quality_stride = quality_target_stride; a.bitmask = bitmask;
 	a.status = d_status; a.sumimage = d_sumimage; a.mask = d_mask; a.height = height; a.width = width;
 	a.n_cad = n_cad; a.tp2 = tp2; a.timescale = timescale_days; a.out = d_diag;
+	a.gscratch = gscratch; a.gscratch_per_target = series_bytes;
 	if (shmem > 64 * 1024)
 		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_diagnostics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
 	TP_LAUNCH(ctx, TPK_DIAGNOSTICS, tp_diagnostics_kernel, dim3((unsigned)n_targets), dim3(kThreads), shmem, a);

@@ -67,7 +67,8 @@ def test_golden_reference_photometry(ctx, golden_dir):
 		_check(got[i], ref, tag=f'case{i}')
 
 
-@pytest.mark.parametrize('T', [7, 300, 1300, 2500])
+# 6000 and 19500 cadences (2-minute data of a sector): the series arrays no longer fit the LDS and move to HBM scratch
+@pytest.mark.parametrize('T', [7, 300, 1300, 2500, 6000, 19500])
 def test_against_oracle(ctx, T):
 	from oracle import diagnostics as odiag
 	rng = np.random.default_rng(T)
