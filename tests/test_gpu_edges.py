@@ -107,3 +107,20 @@ def test_largest_lds_resident_stamp(ctx):
 	s3.aperture = None
 	with pytest.raises(TessphotError):
 		pipeline.run_aperture(ctx, s3)
+
+
+def test_two_minute_cadence_length(ctx):
+	"""A sector of 2-minute data (19 500 cadences, the TPF data source): every stage of the batch path, against the oracle."""
+	s = simulate.make_scene(3, 19500, 11, 11, seed=12, cadence_s=120.0)
+	simulate.fill_cubes(s)
+	s.aperture = None
+	got = pipeline.run_aperture(ctx, s)
+	assert _compare(s, got) >= 2
+	d = got['diagnostics']
+	from oracle import diagnostics as odiag
+	for i in range(3):
+		if int(got['status'][i]) in (1, 3):
+			o = odiag.diagnostics(s.time, s.quality, got['flux'][i], got['flux_err'][i], got['pos_centroid'][i], sumimage=got['sumimage'][i], mask=got['mask'][i])
+			assert d[i][0] == o['mean_flux'] and d[i][3] == o['ptp']
+			np.testing.assert_allclose(d[i][[1, 2]], [o['variance'], o['rms_hour']], rtol=1e-12)
+			np.testing.assert_allclose(d[i][6], o['variability'], rtol=1e-9)
