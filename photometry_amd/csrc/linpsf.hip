@@ -409,12 +409,30 @@ __global__ __launch_bounds__(S <= 2 ? 1024 : 512) void tp_linpsf_fit_kernel(FitA
 			const bool vx = axis_phase(kn, n, scol[s], h, phx[s], ax0[s]);
 			const bool vy = axis_phase(kny, n, srow[s], hy, phy[s], by0[s]);
 			valid[s] = vx && vy;
-			if (valid[s]) {
-				atomicMin(&sbox[s].axmin, ax0[s]); atomicMax(&sbox[s].axmax, ax0[s]);
-				atomicMin(&sbox[s].bymin, by0[s]); atomicMax(&sbox[s].bymax, by0[s]);
-				// pixels that can be inside the cut-off of this cadence (strict test below): a conservative box
-				atomicMin(&sbox[s].jmin, (int)floor(scol[s] - cutoff)); atomicMax(&sbox[s].jmax, (int)ceil(scol[s] + cutoff));
-				atomicMin(&sbox[s].imin, (int)floor(srow[s] - cutoff)); atomicMax(&sbox[s].imax, (int)ceil(srow[s] + cutoff));
+		}
+		// box of the star over the workgroup's cadences: a shuffle tree inside the wavefront, then ONE LDS atomic per
+		// wavefront and bound (64 lanes hitting the same LDS word serialise)
+		if (s < ns) {
+			const int big = 0x7fffffff;
+			int lo[4] = {valid[s] ? ax0[s] : big, valid[s] ? by0[s] : big,
+				valid[s] ? (int)floor(scol[s] - cutoff) : big, valid[s] ? (int)floor(srow[s] - cutoff) : big};
+			int hi[4] = {valid[s] ? ax0[s] : -big, valid[s] ? by0[s] : -big,
+				valid[s] ? (int)ceil(scol[s] + cutoff) : -big, valid[s] ? (int)ceil(srow[s] + cutoff) : -big};
+#pragma unroll
+			for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					const int l2 = __shfl_xor(lo[c], off, 64), h2 = __shfl_xor(hi[c], off, 64);
+					lo[c] = (l2 < lo[c]) ? l2 : lo[c];
+					hi[c] = (h2 > hi[c]) ? h2 : hi[c];
+				}
+			}
+			if ((tid & 63) == 0 && hi[0] >= lo[0]) {
+				atomicMin(&sbox[s].axmin, lo[0]); atomicMax(&sbox[s].axmax, hi[0]);
+				atomicMin(&sbox[s].bymin, lo[1]); atomicMax(&sbox[s].bymax, hi[1]);
+				// pixels that can be inside the cut-off of some cadence (strict test below): a conservative box
+				atomicMin(&sbox[s].jmin, lo[2]); atomicMax(&sbox[s].jmax, hi[2]);
+				atomicMin(&sbox[s].imin, lo[3]); atomicMax(&sbox[s].imax, hi[3]);
 			}
 		}
 	}
