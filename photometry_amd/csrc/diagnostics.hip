@@ -76,9 +76,19 @@ __device__ double block_median(const double* v, int m, double* red, unsigned int
 	const int n = (int)block_sum((double)c, red);
 	if (n == 0) return __builtin_nan("");
 	const int k_lo = (n - 1) >> 1, k_hi = n >> 1;
+	// The values of a light curve share their sign, exponent and leading mantissa bits: in the top digits every
+	// candidate falls into ONE histogram bin, i.e. every lane of every wavefront does an atomic on the same LDS word.
+	// Those digits are known from the extreme keys: start below the common prefix of the smallest and the largest key.
+	double vmn = __builtin_inf(), vmx = -__builtin_inf();
+	for (int i = tid; i < m; i += kThreads) { const double x = v[i]; if (!is_nan(x)) { if (x < vmn) vmn = x; if (x > vmx) vmx = x; } }
+	const unsigned long long kmin = sort_key(block_min(vmn, red)), kmax = sort_key(block_max(vmx, red));
+	const unsigned long long diff = kmin ^ kmax;
+	int top = 7;
+	while (top >= 0 && ((diff >> (top * 8)) & 255ull) == 0ull) --top; // digits above `top` are common to all keys
 	unsigned long long prefix = 0ull, pmask = 0ull;
+	if (top < 7) { pmask = ~0ull << ((top + 1) * 8); prefix = kmin & pmask; }
 	int k = k_lo;
-	for (int pass = 7; pass >= 0; --pass) {
+	for (int pass = top; pass >= 0; --pass) {
 		const int shift = pass * 8;
 		hist[tid] = 0u;
 		__syncthreads();
