@@ -645,12 +645,12 @@ __global__ __launch_bounds__(256) void tp_linpsf_finalize_kernel(FinArgs fa)
 	const int target = blockIdx.x;
 	const int tid = threadIdx.x;
 	const int n = a.n;
-	double* C = lds;
-	double* kn = lds + (size_t)n * n;
+	// Only the design matrix of the LAST cadence is needed (about 140 star-pixel values x 169 table entries): the table is
+	// read straight from HBM / L2 instead of being staged (110 KB of LDS would allow a single workgroup per CU).
+	const double* C = a.coef + (int64_t)target * n * n;
+	double* kn = lds;
 	double* kny = kn + n + 4;
 	double* red = kny + n + 4;           // [256]
-	const double* cg = a.coef + (int64_t)target * n * n;
-	for (int i = tid; i < n * n; i += blockDim.x) C[i] = cg[i];
 	for (int i = tid; i < n + 4; i += blockDim.x) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
 	__syncthreads();
 	const int64_t s0 = a.star_offsets[target];
@@ -793,7 +793,7 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	const int nblk = (desc->n_cad + 511) / 512;
 	int threads = (((desc->n_cad + nblk - 1) / nblk) + 63) / 64 * 64;
 	dim3 grid((unsigned)desc->n_targets, (unsigned)nblk), block((unsigned)threads);
-	const size_t shmem_fin = shmem + 256 * sizeof(double);
+	const size_t shmem_fin = (2 * ((size_t)n_coef_axis + 4) + 256) * sizeof(double);
 	FinArgs fa; fa.f = a; fa.contamination = d_contamination; fa.status = d_status; fa.fluxes_mean = d_fluxes_mean;
 	// fast path: whatever LDS the table leaves holds the K buffer (25 doubles per item); (target, block) pairs whose
 	// stars visit more table origins than fit are flagged and redone by the general kernel
@@ -815,7 +815,6 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_direct_kernel<SS, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
 		TP_LAUNCH(ctx, TPK_LINPSF_FIT_DIRECT, (tp_linpsf_fit_direct_kernel<SS, SL>), grid, block, shmem, a, (const int32_t*)d_todo); \
 		TP_LAUNCH_CHECK(ctx, "tp_linpsf_fit_direct_kernel"); \
-		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_finalize_kernel<SS, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_fin)); \
 		TP_LAUNCH(ctx, TPK_LINPSF_FIN, (tp_linpsf_finalize_kernel<SS, SL>), dim3((unsigned)desc->n_targets), dim3(256), shmem_fin, fa); \
 		TP_LAUNCH_CHECK(ctx, "tp_linpsf_finalize_kernel"); \
 	} while (0)
