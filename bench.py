@@ -121,7 +121,7 @@ def main_linpsf(args, ctx, rank, world, dist, torch, device_sync, barrier):
 		if world == 1 and args.cpu_sample > 0:
 			# CPU baseline: the oracle loop (reference-equivalent, scipy FITPACK integral per pixel) on a few targets
 			from oracle import linpsf as olin, psf as opsf
-			ns = min(Nt, 4)
+			ns = min(Nt, max(1, args.cpu_sample // 96)) # 4 targets at the default --cpu-sample 384
 			tsub = min(T, 100)
 			host = np.empty((ns, H, W, cubes['images'].t_pitch), dtype='float32')
 			ctx._check(ctx.lib.tp_memcpy_d2h(ctx.handle, host.ctypes.data, cubes['images'].ptr, host.nbytes))
