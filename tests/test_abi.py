@@ -61,3 +61,16 @@ def test_no_gpu_is_an_error_not_a_fallback(built_lib):
 	from photometry_amd._lib import TessphotError
 	with pytest.raises(TessphotError):
 		Context(0)
+
+
+def test_ctypes_arity_matches_the_header(built_lib):
+	"""Every ctypes prototype has as many arguments as the declaration in include/tessphot_hip.h (catches signature drift
+	between the header, the library and the Python layer for the long argument lists)."""
+	src = open(HEADER).read()
+	src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+	for name, (restype, argtypes) in built_lib.SIGNATURES.items():
+		m = re.search(r'\b' + name + r'\s*\((.*?)\)\s*;', src, flags=re.S)
+		assert m, name
+		params = m.group(1).strip()
+		n = 0 if params in ('', 'void') else len([p for p in params.split(',') if p.strip()])
+		assert n == len(argtypes), f"{name}: header has {n} parameters, ctypes table has {len(argtypes)}"
