@@ -817,6 +817,14 @@ inline TP_DEV int saturated_one(Shared& k) {
 		// necessary condition of k2p2v2.py:321 (median(pixels) >= mask_max/2) fails whenever the column maximum
 		// is below mask_max/2 (or everything is NaN): skip the two medians
 		if (!(pmax >= mask_max / 2)) continue;
+		// sharper necessary condition for the same test: a median >= t needs at least ceil(m / 2) of the m non-NaN values
+		// >= t (odd m: the middle one; even m: the upper middle one).  Ordinary stars have one or two such pixels per
+		// column, so the two insertion-sort medians below are skipped for them.
+		{
+			int m = 0, cge = 0;
+			for (int i = 0; i < n; ++i) if (!tp_isnan(pix[i])) { ++m; cge += (pix[i] >= mask_max / 2) ? 1 : 0; }
+			if (cge < (m + 1) / 2) continue;
+		}
 		const double medpix = nanmedian_small(pix, n, scr);
 		// diff in place (pix no longer needed afterwards except through medpix/pmax)
 		for (int i = 0; i + 1 < n; ++i) pix[i] = pix[i + 1] - pix[i];
