@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64) void tp_bkg_stamp_generic_kernel(BkgArgs a, int
 	for (int size = 2; size <= np2; size <<= 1) {
 		for (int stride = size >> 1; stride > 0; stride >>= 1) {
 			for (int t = lane; t < np2 / 2; t += 64) {
-				const int lo = (t / stride) * (stride * 2) + (t % stride);
+				const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)); // stride is a power of two
 				const int hi = lo + stride;
 				const bool up = ((lo & size) == 0);
 				const float x = sv[lo], y = sv[hi];

@@ -310,7 +310,7 @@ inline TP_DEV void bitonic_sort(Shared& k) {
 	for (int size = 2; size <= n; size <<= 1) {
 		for (int stride = size >> 1; stride > 0; stride >>= 1) {
 			TP_PAR_FOR(t, n >> 1) {
-				const int lo = (t / stride) * (stride << 1) + (t % stride);
+				const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)); // stride is a power of two: no division
 				const int hi = lo + stride;
 				const bool up = ((lo & size) == 0);
 				const double a = k.srt[lo], b = k.srt[hi];
@@ -608,21 +608,28 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 			k.tmp[i] = lxi - (double)li;
 		}
 		TP_SYNC();
-		// the points are sorted, so li never decreases: the contributors of bin m (li == m-1, then li == m, in data order
-		// like the reference's loop) are one contiguous run, found by binary search
-		TP_PAR_FOR(m, M) {
-			int lo = 0, hi = nc;
-			while (lo < hi) { const int mid = (lo + hi) >> 1; if (k.hage[mid] < m - 1) lo = mid + 1; else hi = mid; }
-			double g = 0.0;
-			for (int i = lo; i < nc; ++i) {
-				const int li = k.hage[i];
-				if (li > m) break;
-				if (li > 1 && li < M) {
-					if (li == m) g = g + 1 - k.tmp[i];
-					else if (li + 1 == m) g = g + k.tmp[i];
+		// The points are sorted, so li never decreases: the contributors of bin m (li == m-1 adding rem, then li == m adding
+		// 1 - rem, in data order like the reference's loop) are two adjacent runs.  A lane owns bins 2l and 2l+1; the four
+		// run boundaries come from four interleaved binary searches, the sums are plain loops over known ranges (no
+		// data-dependent exit: the LDS reads pipeline).  Most points sit in a few bins (the sky level): without this a
+		// handful of lanes walked 100+ dependent iterations while the others idled.
+		TP_LANE_LOOP(l) {
+			int lo[4] = {0, 0, 0, 0}, hi[4] = {nc, nc, nc, nc};
+			for (int step = 0; step < 9; ++step) { // nc <= 256
+				for (int e = 0; e < 4; ++e) {
+					if (lo[e] < hi[e]) {
+						const int mid = (lo[e] + hi[e]) >> 1;
+						if (k.hage[mid] < 2 * l - 1 + e) lo[e] = mid + 1; else hi[e] = mid;
+					}
 				}
 			}
-			binned[m] = g / (delta * (double)nc);
+			for (int e = 0; e < 2; ++e) {
+				const int m = 2 * l + e;
+				double g = 0.0;
+				if (m - 1 > 1 && m - 1 < M) for (int i = lo[e]; i < lo[e + 1]; ++i) g = g + k.tmp[i];
+				if (m > 1 && m < M) for (int i = lo[e + 1]; i < lo[e + 2]; ++i) g = g + 1 - k.tmp[i];
+				binned[m] = g / (delta * (double)nc);
+			}
 		}
 		TP_SYNC();
 		// forward real DFT (Y = rfft(binned)), k = 0..M/2
