@@ -34,6 +34,7 @@
 #define TP_SYNC() do {} while (0)
 #define TP_SERIAL if (true)
 #define TP_ATOMIC_INC(ptr) ((*(ptr))++)
+#define TP_ATOMIC_OR(ptr, v) (*(ptr) |= (v))
 #define TP_STAMP(id) do {} while (0)
 #else
 #define TP_DEV __device__
@@ -43,6 +44,7 @@
 #define TP_SYNC() __syncthreads()
 #define TP_SERIAL if (k.lane == 0)
 #define TP_ATOMIC_INC(ptr) atomicAdd((ptr), 1)
+#define TP_ATOMIC_OR(ptr, v) atomicOr((ptr), (v))
 // optional per-phase cycle accounting (diagnostic builds / runs only: t.timing == nullptr in production)
 #define TP_STAMP(id) do { if (t.timing && k.lane == 0) { const long long _now = clock64(); t.timing[id] += (double)(_now - _tlast); _tlast = _now; } } while (0)
 #endif
@@ -933,54 +935,78 @@ inline TP_DEV void watershed(Shared& k, int nmark) {
 	lab_t* rank = k.hpix;            // [P] rank of pixel (only where Z != 0)
 	int32_t* ord = (int32_t*)k.hval; // [P] pixel of rank r (hval is free here; 2 int32 per double slot)
 	uint32_t* words = (uint32_t*)k.hage; // [ceil(P/32)] bit set of pushed ranks
-	TP_PAR_FOR(p, P) k.wsout[p] = (k.Z[p] != 0.0) ? k.mark[p] : 0;
-	TP_PAR_FOR(p, P) {
-		int r = -1;
-		const double zp = k.Z[p];
-		if (zp != 0.0) {
-			r = 0;
-			for (int q = 0; q < P; ++q) {
-				const double zq = k.Z[q];
-				if (zq == 0.0) continue;
-				r += (zq > zp || (zq == zp && q < p)) ? 1 : 0;
-			}
-		}
-		rank[p] = r;
+	TP_PAR_FOR(p, P) { k.wsout[p] = (k.Z[p] != 0.0) ? k.mark[p] : 0; rank[p] = -1; }
+	// rank of every in-mask pixel by decreasing Z (ties: raster order).  The in-mask pixels are first compacted in raster
+	// order (values in k.dist, pixel indices in k.tmp: both are free during the flood), so a pixel is compared with the
+	// few dozen pixels of its cluster instead of with the whole stamp.
+	double* cz = k.dist;
+	int32_t* cp = (int32_t*)k.tmp;
+	const int chunk = (P + 63) / 64;
+	TP_LANE_LOOP(l) {
+		int c = 0;
+		for (int p = l * chunk; p < (l + 1) * chunk && p < P; ++p) c += (k.Z[p] != 0.0) ? 1 : 0;
+		k.ired[l] = c;
 	}
 	TP_SYNC();
-	TP_PAR_FOR(p, P) if (rank[p] >= 0) ord[rank[p]] = p;
+	TP_LANE_LOOP(l) {
+		int base = 0;
+		for (int m = 0; m < l; ++m) base += k.ired[m];
+		for (int p = l * chunk; p < (l + 1) * chunk && p < P; ++p) if (k.Z[p] != 0.0) { cz[base] = k.Z[p]; cp[base] = p; ++base; }
+	}
+	TP_SYNC();
+	const int nz = sum_ired(k);
+	TP_SYNC();
+	TP_PAR_FOR(c, nz) {
+		const double zc = cz[c];
+		int r = 0;
+		for (int d = 0; d < nz; ++d) {
+			const double zd = cz[d];
+			r += (zd > zc || (zd == zc && d < c)) ? 1 : 0;
+		}
+		rank[cp[c]] = r;
+		ord[r] = cp[c];
+	}
 	const int nwords = (P + 31) / 32;
 	TP_PAR_FOR(w, nwords) words[w] = 0u;
 	TP_SYNC();
+	// seeds: the ranks of the marker pixels (parallel, the bit set is an OR)
+	TP_PAR_FOR(p, P) if (k.wsout[p] != 0) { const int r = rank[p]; TP_ATOMIC_OR(&words[r >> 5], 1u << (r & 31)); }
+	TP_SYNC();
 	TP_SERIAL {
-		uint32_t sum0 = 0u, sum1 = 0u; // summary: bit w set <=> words[w] != 0   (nwords <= 64)
-		for (int p = 0; p < P; ++p) if (k.wsout[p] != 0) {
-			const int r = rank[p], w = r >> 5;
-			words[w] |= (1u << (r & 31));
-			if (w < 32) sum0 |= (1u << w); else sum1 |= (1u << (w - 32));
-		}
-		while (sum0 | sum1) {
-			const int w = sum0 ? __builtin_ctz(sum0) : (32 + __builtin_ctz(sum1));
+		// summary: bit w of sum[w / 32] set <=> words[w] != 0.  Ranks count the in-mask pixels of ONE cluster, nwords <= 96
+		// covers the largest LDS-resident stamp (54 x 54) even if a single cluster filled it.
+		uint32_t sum0 = 0u, sum1 = 0u, sum2 = 0u;
+		for (int w = 0; w < nwords; ++w) if (words[w] != 0u) { if (w < 32) sum0 |= (1u << w); else if (w < 64) sum1 |= (1u << (w - 32)); else sum2 |= (1u << (w - 64)); }
+		while (sum0 | sum1 | sum2) {
+			const int w = sum0 ? __builtin_ctz(sum0) : (sum1 ? (32 + __builtin_ctz(sum1)) : (64 + __builtin_ctz(sum2)));
 			uint32_t bits = words[w];
 			const int b = __builtin_ctz(bits);
 			bits &= bits - 1u;
 			words[w] = bits;
-			if (bits == 0u) { if (w < 32) sum0 &= ~(1u << w); else sum1 &= ~(1u << (w - 32)); }
+			if (bits == 0u) { if (w < 32) sum0 &= ~(1u << w); else if (w < 64) sum1 &= ~(1u << (w - 32)); else sum2 &= ~(1u << (w - 64)); }
 			const int px = ord[w * 32 + b];
 			const int lbl = k.wsout[px];
 			const int r = px / W, c = px - r * W;
+			// the four neighbours: every LDS read first (independent, one latency), then the decisions and the writes.
+			// Two neighbours are never the same pixel, so reading ahead does not change the sequential semantics.
 			const int nbr[4] = {r - 1, r, r, r + 1};
 			const int nbc[4] = {c, c - 1, c + 1, c};
+			int nb[4], wl[4], rn[4];
+			double zn[4];
 			for (int q = 0; q < 4; ++q) {
-				const int rr = nbr[q], cc = nbc[q];
-				if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
-				const int nb = rr * W + cc;
-				if (k.Z[nb] == 0.0) continue;      // not in mask
-				if (k.wsout[nb] != 0) continue;    // already labelled
-				k.wsout[nb] = lbl;
-				const int rn = rank[nb], wn = rn >> 5;
-				words[wn] |= (1u << (rn & 31));
-				if (wn < 32) sum0 |= (1u << wn); else sum1 |= (1u << (wn - 32));
+				const bool in = !(nbr[q] < 0 || nbr[q] >= H || nbc[q] < 0 || nbc[q] >= W);
+				nb[q] = in ? (nbr[q] * W + nbc[q]) : px;       // out of the image: re-read the pixel itself (labelled: skipped)
+				zn[q] = k.Z[nb[q]];
+				wl[q] = k.wsout[nb[q]];
+				rn[q] = rank[nb[q]];
+			}
+			for (int q = 0; q < 4; ++q) {
+				if (zn[q] == 0.0) continue;      // not in mask
+				if (wl[q] != 0) continue;        // already labelled (or the out-of-image stand-in)
+				k.wsout[nb[q]] = lbl;
+				const int wn = rn[q] >> 5;
+				words[wn] |= (1u << (rn[q] & 31));
+				if (wn < 32) sum0 |= (1u << wn); else if (wn < 64) sum1 |= (1u << (wn - 32)); else sum2 |= (1u << (wn - 64));
 			}
 		}
 	}
