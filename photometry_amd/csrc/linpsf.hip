@@ -352,8 +352,22 @@ __device__ __forceinline__ bool axis_phase(const double* kn, int n, double pos, 
 
 struct StarBox { int axmin, axmax, bymin, bymax, jmin, jmax, imin, imax; };
 
-template <int S, int SLO>
-__global__ __launch_bounds__(S <= 2 ? 1024 : 512) void tp_linpsf_fit_kernel(FitArgs a, int kcap, int32_t* __restrict__ todo)
+// one cadence of the target held by a thread (a thread holds U of them: see the kernel)
+template <int S>
+struct CadSlot {
+	double phx[S], phy[S], srow[S], scol[S], dr2[S];
+	double G[S][S], g[S];
+	int ax0[S], by0[S], cc[S];
+	bool valid[S];
+	int k; bool active; float sub; const float* img;
+	float ring[4]; // the next pixels of the current stamp row
+};
+
+// U cadences per thread ("slots", cadences tid, tid + blockDim, ...): the polynomial coefficients of a stamp row are
+// built once for all of them (one pass instead of U over the same table), the U Horner / normal-equation chains of a
+// pixel are independent instruction streams for the scheduler, and the barriers are shared.
+template <int S, int SLO, int U>
+__global__ __launch_bounds__(U > 1 ? 768 : 512) void tp_linpsf_fit_kernel(FitArgs a, int kcap, int32_t* __restrict__ todo)
 {
 	{ const int nst = (int)(a.star_offsets[blockIdx.x + 1] - a.star_offsets[blockIdx.x]); if (nst < SLO || nst > S) return; } // another instantiation's targets
 	extern __shared__ __align__(16) double lds[]; // table [n*n], knots 2 x [n+4], K buffer [kcap*25], then ints
@@ -376,8 +390,13 @@ __global__ __launch_bounds__(S <= 2 ? 1024 : 512) void tp_linpsf_fit_kernel(FitA
 		for (int u = 0; u < 8; ++u) { const int i = i0 + u * nthreads + tid; if (i < n * n) C[i] = tmp[u]; }
 	}
 	for (int i = tid; i < n + 4; i += nthreads) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
-	// the table is loaded once; the workgroup then walks the cadences in passes of blockDim.x
-	const int npass = (a.n_cad + nthreads - 1) / nthreads;
+	// the table is loaded once; the workgroup then walks the cadences in passes of U * blockDim.x
+	const int per_pass = nthreads * U;
+	const int npass = (a.n_cad + per_pass - 1) / per_pass;
+	const int64_t s0 = a.star_offsets[target];
+	int ns = (int)(a.star_offsets[target + 1] - s0);
+	if (ns > S) ns = S; // host guarantees ns <= S for this instantiation
+	const int H = a.height, W = a.width;
 	for (int pass = 0; pass < npass; ++pass) {
 	__syncthreads(); // table / knots visible; previous pass done with the star boxes and the K buffer
 	if (tid < kMaxStars) {
@@ -387,44 +406,49 @@ __global__ __launch_bounds__(S <= 2 ? 1024 : 512) void tp_linpsf_fit_kernel(FitA
 	if (tid == 0) *s_flag = 0;
 	__syncthreads();
 
-	const int k = pass * nthreads + tid;
-	const bool active = k < a.n_cad;
-	const int64_t s0 = a.star_offsets[target];
-	int ns = (int)(a.star_offsets[target + 1] - s0);
-	if (ns > S) ns = S; // host guarantees ns <= S for this instantiation
-	const int H = a.height, W = a.width;
 	const double h = kn[5] - kn[4], hy = kny[5] - kny[4];
 	const double cutoff = a.cutoff;
-
-	double phx[S], phy[S], srow[S], scol[S];
-	int ax0[S], by0[S];
-	bool valid[S];
+	CadSlot<S> c[U];
+#pragma unroll
+	for (int u = 0; u < U; ++u) {
+		c[u].k = pass * per_pass + u * nthreads + tid;
+		c[u].active = c[u].k < a.n_cad;
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			c[u].valid[s] = false; c[u].phx[s] = c[u].phy[s] = 0.0; c[u].srow[s] = c[u].scol[s] = 0.0; c[u].ax0[s] = c[u].by0[s] = 4;
+			if (s < ns && c[u].active) {
+				c[u].srow[s] = a.pos_row[(s0 + s) * a.pos_pitch + c[u].k];
+				c[u].scol[s] = a.pos_col[(s0 + s) * a.pos_pitch + c[u].k];
+				// x <-> column (first spline axis), y <-> row  (psf.py:146)
+				const bool vx = axis_phase(kn, n, c[u].scol[s], h, c[u].phx[s], c[u].ax0[s]);
+				const bool vy = axis_phase(kny, n, c[u].srow[s], hy, c[u].phy[s], c[u].by0[s]);
+				c[u].valid[s] = vx && vy;
+			}
+		}
+	}
+	// box of every star over the workgroup's cadences: the thread's slots, a shuffle tree inside the wavefront, then ONE
+	// LDS atomic per wavefront and bound (64 lanes hitting the same LDS word serialise)
 #pragma unroll
 	for (int s = 0; s < S; ++s) {
-		valid[s] = false; phx[s] = phy[s] = 0.0; srow[s] = scol[s] = 0.0; ax0[s] = by0[s] = 4;
-		if (s < ns && active) {
-			srow[s] = a.pos_row[(s0 + s) * a.pos_pitch + k];
-			scol[s] = a.pos_col[(s0 + s) * a.pos_pitch + k];
-			// x <-> column (first spline axis), y <-> row  (psf.py:146)
-			const bool vx = axis_phase(kn, n, scol[s], h, phx[s], ax0[s]);
-			const bool vy = axis_phase(kny, n, srow[s], hy, phy[s], by0[s]);
-			valid[s] = vx && vy;
-		}
-		// box of the star over the workgroup's cadences: a shuffle tree inside the wavefront, then ONE LDS atomic per
-		// wavefront and bound (64 lanes hitting the same LDS word serialise)
 		if (s < ns) {
 			const int big = 0x7fffffff;
-			int lo[4] = {valid[s] ? ax0[s] : big, valid[s] ? by0[s] : big,
-				valid[s] ? (int)floor(scol[s] - cutoff) : big, valid[s] ? (int)floor(srow[s] - cutoff) : big};
-			int hi[4] = {valid[s] ? ax0[s] : -big, valid[s] ? by0[s] : -big,
-				valid[s] ? (int)ceil(scol[s] + cutoff) : -big, valid[s] ? (int)ceil(srow[s] + cutoff) : -big};
+			int lo[4] = {big, big, big, big}, hi[4] = {-big, -big, -big, -big};
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				if (c[u].valid[s]) {
+					const int v0[4] = {c[u].ax0[s], c[u].by0[s], (int)floor(c[u].scol[s] - cutoff), (int)floor(c[u].srow[s] - cutoff)};
+					const int v1[4] = {c[u].ax0[s], c[u].by0[s], (int)ceil(c[u].scol[s] + cutoff), (int)ceil(c[u].srow[s] + cutoff)};
+#pragma unroll
+					for (int e = 0; e < 4; ++e) { lo[e] = (v0[e] < lo[e]) ? v0[e] : lo[e]; hi[e] = (v1[e] > hi[e]) ? v1[e] : hi[e]; }
+				}
+			}
 #pragma unroll
 			for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-				for (int c = 0; c < 4; ++c) {
-					const int l2 = __shfl_xor(lo[c], off, 64), h2 = __shfl_xor(hi[c], off, 64);
-					lo[c] = (l2 < lo[c]) ? l2 : lo[c];
-					hi[c] = (h2 > hi[c]) ? h2 : hi[c];
+				for (int e = 0; e < 4; ++e) {
+					const int l2 = __shfl_xor(lo[e], off, 64), h2 = __shfl_xor(hi[e], off, 64);
+					lo[e] = (l2 < lo[e]) ? l2 : lo[e];
+					hi[e] = (h2 > hi[e]) ? h2 : hi[e];
 				}
 			}
 			if ((tid & 63) == 0 && hi[0] >= lo[0]) {
@@ -467,32 +491,30 @@ __global__ __launch_bounds__(S <= 2 ? 1024 : 512) void tp_linpsf_fit_kernel(FitA
 		if (tid == 0) todo[target] = 1;
 		return;
 	}
-	// per star: number of origins, this thread's origin index
-	int nc[S], cc[S], nby[S];
+	// per star: number of origins; per slot: the cadence's origin index, normal equations, image pointer
+	int nc[S], nby[S];
+	int bjmin[S], bjmax[S], bimin[S], bimax[S], baxmin[S], bbymin[S];
 #pragma unroll
 	for (int s = 0; s < S; ++s) {
 		const StarBox b = sbox[s];
 		nby[s] = b.bymax - b.bymin + 1;
 		nc[s] = (b.axmax - b.axmin + 1) * nby[s];
-		cc[s] = valid[s] ? ((ax0[s] - b.axmin) * nby[s] + (by0[s] - b.bymin)) : 0;
-	}
-
-	double G[S][S], g[S];
-#pragma unroll
-	for (int i = 0; i < S; ++i) { g[i] = 0.0;
-#pragma unroll
-		for (int j = 0; j < S; ++j) G[i][j] = 0.0; }
-
-	const float* img = a.images + (int64_t)target * H * W * a.t_pitch + (active ? k : 0);
-	const float sub = (a.subtract && active) ? a.subtract[(int64_t)target * a.subtract_pitch + k] : 0.f;
-	const double h2 = h * hy;
-	const int wc = s_flag[1];
-	int bjmin[S], bjmax[S], bimin[S], bimax[S], baxmin[S], bbymin[S];
-#pragma unroll
-	for (int s = 0; s < S; ++s) {
-		const StarBox b = sbox[s];
 		bjmin[s] = b.jmin; bjmax[s] = b.jmax; bimin[s] = b.imin; bimax[s] = b.imax; baxmin[s] = b.axmin; bbymin[s] = b.bymin;
 	}
+#pragma unroll
+	for (int u = 0; u < U; ++u) {
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			c[u].cc[s] = c[u].valid[s] ? ((c[u].ax0[s] - baxmin[s]) * nby[s] + (c[u].by0[s] - bbymin[s])) : 0;
+			c[u].g[s] = 0.0;
+#pragma unroll
+			for (int j = 0; j < S; ++j) c[u].G[s][j] = 0.0;
+		}
+		c[u].img = a.images + (int64_t)target * H * W * a.t_pitch + (c[u].active ? c[u].k : 0);
+		c[u].sub = (a.subtract && c[u].active) ? a.subtract[(int64_t)target * a.subtract_pitch + c[u].k] : 0.f;
+	}
+	const double h2 = h * hy;
+	const int wc = s_flag[1];
 	for (int i = 0; i < H; ++i) {
 		for (int j0 = 0; j0 < W; j0 += wc) {
 			// ---- plan of the chunk = columns [j0, j1) of row i, computed identically by every thread (no serial step):
@@ -511,19 +533,20 @@ __global__ __launch_bounds__(S <= 2 ? 1024 : 512) void tp_linpsf_fit_kernel(FitA
 			}
 			if (nitems == 0) continue; // no star near this chunk: its pixels do not enter the normal equations
 			int jfirst = j1, jlast = j0 - 1; // union of the stars' columns: the other pixels have an all-zero design row
-			double dr2[S];
 #pragma unroll
-			for (int s = 0; s < S; ++s) {
+			for (int s = 0; s < S; ++s)
 				if (jhi[s] >= jlo[s]) { jfirst = (jlo[s] < jfirst) ? jlo[s] : jfirst; jlast = (jhi[s] > jlast) ? jhi[s] : jlast; }
-				const double dr = (double)i - srow[s];
-				dr2[s] = dr * dr;
-			}
 			const int jend = jlast + 1;
-			// the chunk's pixels of this cadence: a ring of four loads stays in flight (issued here, before the coefficient
-			// phase, and refilled as the pixels are consumed); indices clamp instead of branching
-			const float* prow = img + (int64_t)(i * W) * a.t_pitch;
-			auto pix_load = [&](int j) { j = (j < jend) ? j : (jend - 1); return prow[(int64_t)j * a.t_pitch]; };
-			float p0 = pix_load(jfirst), p1 = pix_load(jfirst + 1), p2 = pix_load(jfirst + 2), p3 = pix_load(jfirst + 3);
+			// the chunk's pixels of the thread's cadences: a ring of four loads per slot stays in flight (issued here, before
+			// the coefficient phase, and refilled as the pixels are consumed); indices clamp instead of branching
+			auto pix_load = [&](const CadSlot<S>& cs, int j) { j = (j < jend) ? j : (jend - 1); return cs.img[((int64_t)(i * W) + j) * a.t_pitch]; };
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+#pragma unroll
+				for (int s = 0; s < S; ++s) { const double dr = (double)i - c[u].srow[s]; c[u].dr2[s] = dr * dr; }
+#pragma unroll
+				for (int r = 0; r < 4; ++r) c[u].ring[r] = pix_load(c[u], jfirst + r);
+			}
 			// ---- A: polynomial coefficients of every (star, column, origin) item of this row chunk
 			for (int w = tid; w < nitems * 5; w += nthreads) {
 				int item = w / 5;
@@ -557,74 +580,74 @@ __global__ __launch_bounds__(S <= 2 ? 1024 : 512) void tp_linpsf_fit_kernel(FitA
 				for (int e = 0; e < 5; ++e) dst[e * 5] = h2 * kk[e];
 			}
 			__syncthreads();
-			// ---- B: this cadence's design-matrix row values of the chunk's pixels, normal equations
-			if (active) {
-				auto consume = [&](float pv, int j) {
-					if (j >= jend) return;
-					float bf = pv;
-					if (a.subtract) bf = bf - sub;
-					if (!(fabsf(bf) <= 3.402823466e+38f)) return; // good_pixels = isfinite(img) (linpsf_photometry.py:123)
-					const double b = (double)bf;
-					double av[S];
+			// ---- B: the cadences' design-matrix row values of the chunk's pixels, normal equations
+			auto consume = [&](CadSlot<S>& cs, float pv, int j) {
+				if (!cs.active || j >= jend) return;
+				float bf = pv;
+				if (a.subtract) bf = bf - cs.sub;
+				if (!(fabsf(bf) <= 3.402823466e+38f)) return; // good_pixels = isfinite(img) (linpsf_photometry.py:123)
+				const double b = (double)bf;
+				double av[S];
 #pragma unroll
-					for (int s = 0; s < S; ++s) {
-						av[s] = 0.0;
-						if (s < ns && valid[s] && j >= jlo[s] && j <= jhi[s]) {
-							const double dc = (double)j - scol[s];
-							// psf.py:142  sqrt((j-col)^2 + (i-row)^2) < cutoff_radius; the squares decide unless they are within
-							// rounding of each other, then the reference's own expression does
-							const double d2 = dc * dc + dr2[s], c2 = cutoff * cutoff;
-							const bool inside = (fabs(d2 - c2) > 1e-9 * c2) ? (d2 < c2) : (sqrt(d2) < cutoff);
-							if (inside) {
-								const double* kp = Kbuf + (size_t)(off[s] + (j - jlo[s]) * nc[s] + cc[s]) * 25;
-								double val = 0.0;
+				for (int s = 0; s < S; ++s) {
+					av[s] = 0.0;
+					if (s < ns && cs.valid[s] && j >= jlo[s] && j <= jhi[s]) {
+						const double dc = (double)j - cs.scol[s];
+						// psf.py:142  sqrt((j-col)^2 + (i-row)^2) < cutoff_radius; the squares decide unless they are within
+						// rounding of each other, then the reference's own expression does
+						const double d2 = dc * dc + cs.dr2[s], c2 = cutoff * cutoff;
+						const bool inside = (fabs(d2 - c2) > 1e-9 * c2) ? (d2 < c2) : (sqrt(d2) < cutoff);
+						if (inside) {
+							const double* kp = Kbuf + (size_t)(off[s] + (j - jlo[s]) * nc[s] + cs.cc[s]) * 25;
+							double val = 0.0;
 #pragma unroll
-								for (int e = 4; e >= 0; --e) {
-									double inner = kp[e * 5 + 4];
+							for (int e = 4; e >= 0; --e) {
+								double inner = kp[e * 5 + 4];
 #pragma unroll
-									for (int d = 3; d >= 0; --d) inner = __builtin_fma(inner, phy[s], kp[e * 5 + d]);
-									val = __builtin_fma(val, phx[s], inner);
-								}
-								av[s] = val;
+								for (int d = 3; d >= 0; --d) inner = __builtin_fma(inner, cs.phy[s], kp[e * 5 + d]);
+								val = __builtin_fma(val, cs.phx[s], inner);
 							}
+							av[s] = val;
 						}
 					}
+				}
 #pragma unroll
-					for (int s = 0; s < S; ++s) {
-						g[s] += av[s] * b;
+				for (int s = 0; s < S; ++s) {
+					cs.g[s] += av[s] * b;
 #pragma unroll
-						for (int u = 0; u < S; ++u) if (u >= s) G[s][u] += av[s] * av[u];
-					}
-				};
-				for (int jb = jfirst; jb < jend; jb += 4) {
-					consume(p0, jb); p0 = pix_load(jb + 4);
-					consume(p1, jb + 1); p1 = pix_load(jb + 5);
-					consume(p2, jb + 2); p2 = pix_load(jb + 6);
-					consume(p3, jb + 3); p3 = pix_load(jb + 7);
+					for (int t = 0; t < S; ++t) if (t >= s) cs.G[s][t] += av[s] * av[t];
+				}
+			};
+			for (int jb = jfirst; jb < jend; jb += 4) {
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+#pragma unroll
+					for (int u = 0; u < U; ++u) { consume(c[u], c[u].ring[r], jb + r); c[u].ring[r] = pix_load(c[u], jb + r + 4); }
 				}
 			}
 			__syncthreads();
 		}
 	}
-	if (active) {
 #pragma unroll
-	for (int s = 0; s < S; ++s)
+	for (int u = 0; u < U; ++u) {
+		if (!c[u].active) continue;
 #pragma unroll
-		for (int u = 0; u < S; ++u) if (u < s) G[s][u] = G[u][s];
-
-	double x[S];
-	pinv_solve<S>(G, g, ns, x);
-	const int ti = a.target_index[target];
-	double tf = __builtin_nan("");
+		for (int s = 0; s < S; ++s)
 #pragma unroll
-	for (int s = 0; s < S; ++s) {
-		if (s < ns) {
-			a.fluxes_all[(s0 + s) * a.out_pitch + k] = x[s];
-			if (s == ti) tf = x[s];
+			for (int t = 0; t < S; ++t) if (t < s) c[u].G[s][t] = c[u].G[t][s];
+		double x[S];
+		pinv_solve<S>(c[u].G, c[u].g, ns, x);
+		const int ti = a.target_index[target];
+		double tf = __builtin_nan("");
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			if (s < ns) {
+				a.fluxes_all[(s0 + s) * a.out_pitch + c[u].k] = x[s];
+				if (s == ti) tf = x[s];
+			}
 		}
-	}
-	a.flux[(int64_t)target * a.out_pitch + k] = tf;
-	a.flux_err[(int64_t)target * a.out_pitch + k] = __builtin_nan("");
+		a.flux[(int64_t)target * a.out_pitch + c[u].k] = tf;
+		a.flux_err[(int64_t)target * a.out_pitch + c[u].k] = __builtin_nan("");
 	}
 	} // pass
 }
@@ -803,14 +826,16 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	TP_REQUIRE(ctx, kcap >= 16, "tp_linpsf_fit: coefficient table leaves no LDS for the polynomial buffer");
 	const size_t shmem_fast = shmem + (size_t)kcap * 25 * sizeof(double) + tail;
 	const size_t todo_bytes = (size_t)desc->n_targets * sizeof(int32_t);
-	// fast kernel: up to 1024 (2-star class, 128 VGPRs suffice) or 512 threads (= cadences) per pass, the passes balanced
-	auto fast_block = [&](int maxthreads) { const int np = (desc->n_cad + maxthreads - 1) / maxthreads; return dim3((unsigned)((((desc->n_cad + np - 1) / np) + 63) / 64 * 64)); };
+	// fast kernel: U cadences per thread (2 for the 2-star class, whose per-cadence state is small: one pass over 1 300
+	// cadences with 11 wavefronts), up to 768 / 512 threads, the passes balanced
+	auto fast_block = [&](int slots) { const int per = (slots > 1 ? 768 : 512) * slots; const int np = (desc->n_cad + per - 1) / per;
+		return dim3((unsigned)((((desc->n_cad + np * slots - 1) / (np * slots)) + 63) / 64 * 64)); };
 	TP_REQUIRE(ctx, tp_ctx_scratch(ctx, todo_bytes) != nullptr, "tp_linpsf_fit: out of device memory for the class flags");
 	int32_t* d_todo = static_cast<int32_t*>(ctx->scratch);
 	TP_HIP(ctx, hipMemsetAsync(d_todo, 0, todo_bytes, ctx->stream));
 #define TP_LINPSF_LAUNCH(SS, SL) do { \
-		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_kernel<SS, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_fast)); \
-		TP_LAUNCH(ctx, TPK_LINPSF_FIT, (tp_linpsf_fit_kernel<SS, SL>), dim3((unsigned)desc->n_targets), fast_block(SS <= 2 ? 1024 : 512), shmem_fast, a, kcap, d_todo); \
+		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_kernel<SS, SL, (SS <= 2 ? 2 : 1)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_fast)); \
+		TP_LAUNCH(ctx, TPK_LINPSF_FIT, (tp_linpsf_fit_kernel<SS, SL, (SS <= 2 ? 2 : 1)>), dim3((unsigned)desc->n_targets), fast_block(SS <= 2 ? 2 : 1), shmem_fast, a, kcap, d_todo); \
 		TP_LAUNCH_CHECK(ctx, "tp_linpsf_fit_kernel"); \
 		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_direct_kernel<SS, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
 		TP_LAUNCH(ctx, TPK_LINPSF_FIT_DIRECT, (tp_linpsf_fit_direct_kernel<SS, SL>), grid, block, shmem, a, (const int32_t*)d_todo); \
