@@ -826,16 +826,16 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	TP_REQUIRE(ctx, kcap >= 16, "tp_linpsf_fit: coefficient table leaves no LDS for the polynomial buffer");
 	const size_t shmem_fast = shmem + (size_t)kcap * 25 * sizeof(double) + tail;
 	const size_t todo_bytes = (size_t)desc->n_targets * sizeof(int32_t);
-	// fast kernel: U cadences per thread (2 for the 2-star class, whose per-cadence state is small: one pass over 1 300
-	// cadences with 11 wavefronts), up to 768 / 512 threads, the passes balanced
+	// fast kernel: U cadences per thread (2 for the classes up to 4 stars: one pass over 1 300 cadences with 11
+	// wavefronts), up to 768 / 512 threads, the passes balanced
 	auto fast_block = [&](int slots) { const int per = (slots > 1 ? 768 : 512) * slots; const int np = (desc->n_cad + per - 1) / per;
 		return dim3((unsigned)((((desc->n_cad + np * slots - 1) / (np * slots)) + 63) / 64 * 64)); };
 	TP_REQUIRE(ctx, tp_ctx_scratch(ctx, todo_bytes) != nullptr, "tp_linpsf_fit: out of device memory for the class flags");
 	int32_t* d_todo = static_cast<int32_t*>(ctx->scratch);
 	TP_HIP(ctx, hipMemsetAsync(d_todo, 0, todo_bytes, ctx->stream));
 #define TP_LINPSF_LAUNCH(SS, SL) do { \
-		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_kernel<SS, SL, (SS <= 2 ? 2 : 1)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_fast)); \
-		TP_LAUNCH(ctx, TPK_LINPSF_FIT, (tp_linpsf_fit_kernel<SS, SL, (SS <= 2 ? 2 : 1)>), dim3((unsigned)desc->n_targets), fast_block(SS <= 2 ? 2 : 1), shmem_fast, a, kcap, d_todo); \
+		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_kernel<SS, SL, (SS <= 4 ? 2 : 1)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_fast)); \
+		TP_LAUNCH(ctx, TPK_LINPSF_FIT, (tp_linpsf_fit_kernel<SS, SL, (SS <= 4 ? 2 : 1)>), dim3((unsigned)desc->n_targets), fast_block(SS <= 4 ? 2 : 1), shmem_fast, a, kcap, d_todo); \
 		TP_LAUNCH_CHECK(ctx, "tp_linpsf_fit_kernel"); \
 		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_direct_kernel<SS, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
 		TP_LAUNCH(ctx, TPK_LINPSF_FIT_DIRECT, (tp_linpsf_fit_direct_kernel<SS, SL>), grid, block, shmem, a, (const int32_t*)d_todo); \
