@@ -165,10 +165,13 @@ int tp_k2p2_masks(tp_ctx* ctx, int32_t n_targets, int32_t height, int32_t width,
  * replaces the per-cadence loop of AperturePhotometry.do_photometry
  * (photometry/AperturePhotometry/photometry.py:172-201): in-mask flux (float32 np.sum order,
  * bit-exact), flux error sqrt(sum err^2), flux-weighted centroid over pixels with flux > 0 in
- * 1-based CCD (column, row) coordinates, nansum of the background; NaN rules of :182-201.
+ * 1-based CCD (column, row) coordinates, np.nansum of the background (NaN -> 0, float32 np.sum order,
+ * bit-exact); NaN rules of :182-201.
  *   d_backgrounds: bkg_mode 0: cube with the layout of desc;
  *                  bkg_mode 1: one series per target, float32 [n_targets][bkg_series_pitch]
- *                  (a stamp-constant background: every pixel of a cadence has the same value).
+ *                  (a stamp-constant background: every pixel of a cadence has the same value);
+ *                  NULL: aperture-only (no background input): d_flux_background may be NULL too, and is
+ *                  filled with NaN otherwise.
  *   d_subtract: optional float32 [n_targets][subtract_pitch] subtracted from d_images on the fly
  *                  (d_images then holds the raw, not background-subtracted, flux), or NULL.
  *   d_mask:   uint8 [n_targets][height*width], non-zero = in aperture (final_phot_mask).

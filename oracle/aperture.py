@@ -10,8 +10,9 @@ Arithmetic notes (all reproduced here and on the device):
 * ``img``/``imgerr``/``bck`` are float32 ``(H, W)`` views of ``(H, W, T)`` cubes
   (BasePhotometry.py:732) so ``np.sum`` (photometry.py:188-189) is numpy's *float32
   pairwise* sum over the masked pixels in raster order.
-* flux uses ``np.sum`` (NaN-propagating, :188), background uses bottleneck ``nansum``
-  (:201) which for float32 input is a *sequential float32* accumulation.
+* flux uses ``np.sum`` (NaN-propagating, :188), background uses ``np.nansum`` (:201; only
+  ``allnan`` is imported from bottleneck, :10): NaN replaced by 0, then the same float32
+  pairwise ``np.sum``.
 * centroid = ``np.average(members, weights=float32)`` -> float64 accumulation (:194).
 * pixel coordinates are 1-based int32 CCD coordinates (BasePhotometry.py:696-706).
 """
@@ -40,15 +41,6 @@ K2P2_SETTINGS = {
 def allnan(x):
 	"""bottleneck.allnan (True for empty input)."""
 	return bool(np.all(np.isnan(x)))
-
-
-def bn_nansum_f32(x):
-	"""bottleneck.nansum on a contiguous float32 vector: sequential float32 accumulation
-	skipping NaN (bottleneck 1.3.5 reduce template; photometry.py:201)."""
-	x = np.asarray(x)
-	if x.size == 0:
-		return x.dtype.type(0)
-	return np.add.accumulate(np.where(np.isnan(x), x.dtype.type(0), x), dtype=x.dtype)[-1]
 
 
 def get_pixel_grid(stamp):
@@ -108,7 +100,8 @@ def extract(images, images_err, backgrounds, mask_main, stamp):
 	A6: the extraction loop (photometry.py:172-201).
 
 	Parameters:
-		images, images_err, backgrounds: ``(H, W, T)`` float32 cubes.
+		images, images_err, backgrounds: ``(H, W, T)`` float32 cubes; ``backgrounds=None`` (aperture-only
+			run, BASELINE configs[1]: no background cube exists) leaves ``flux_background`` NaN.
 		mask_main: ``(H, W)`` bool.
 		stamp: ``(row_min, row_max, col_min, col_max)``.
 
@@ -128,7 +121,7 @@ def extract(images, images_err, backgrounds, mask_main, stamp):
 	for k in range(T):
 		img = images[:, :, k]
 		imgerr = images_err[:, :, k]
-		bck = backgrounds[:, :, k]
+		bck = None if backgrounds is None else backgrounds[:, :, k]
 
 		flux_in_cluster = img[mask_main]
 
@@ -146,11 +139,14 @@ def extract(images, images_err, backgrounds, mask_main, stamp):
 			else:
 				lc['pos_centroid'][k, :] = np.nan
 
+		if bck is None:
+			lc['flux_background'][k] = np.nan
+			continue
 		bm = bck[mask_main]
 		if allnan(bm):
 			lc['flux_background'][k] = np.nan
 		else:
-			lc['flux_background'][k] = bn_nansum_f32(bm)
+			lc['flux_background'][k] = np.nansum(bm)
 	return lc
 
 

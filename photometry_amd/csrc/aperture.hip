@@ -19,7 +19,8 @@
 //  * flux_err = sqrtf(pairwise float32 sum of err*err)  (:189)
 //  * centroid = float64 sums of w*col, w*row, w over pixels with flux > 0 (np.average, :192-196),
 //               1-based CCD coordinates (BasePhotometry.get_pixel_grid, BasePhotometry.py:696-706)
-//  * background = bottleneck.nansum: sequential float32 skipping NaN; NaN if all NaN (:198-201)
+//  * background = np.nansum (:201): NaN -> 0, then the same float32 pairwise np.sum; NaN if all NaN (:198-201);
+//               no background cube (aperture-only, d_backgrounds NULL) -> flux_background NaN
 //  * all-NaN or all-zero flux in the mask -> flux, flux_err, centroid = NaN (:182-185)
 #include "aperture_dev.h"
 
@@ -125,9 +126,9 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 		CadState<VEC> st;
 		st.init();
 		float bser[VEC], ssub[VEC];
-		if (active && a.bkg_mode != 0) Vec<VEC>::load(bkg + k0, bser);
+		if (active && a.bkg_mode == 1) Vec<VEC>::load(bkg + k0, bser);
 		if (active && a.subtract) Vec<VEC>::load(a.subtract + (int64_t)target * a.subtract_pitch + k0, ssub);
-		float stk_f[VEC][kMaxDepth], stk_e[VEC][kMaxDepth];
+		float stk_f[VEC][kMaxDepth], stk_e[VEC][kMaxDepth], stk_b[VEC][kMaxDepth];
 		int sp = 0;
 		int leaf = 0, pos_in_leaf = 0;
 		int done = 0; // mask pixels consumed so far
@@ -166,23 +167,25 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 							if (a.bkg_mode == 0) Vec<VEC>::load(bkg + off, bb);
 							else {
 #pragma unroll
-								for (int c = 0; c < VEC; c++) bb[c] = bser[c];
+								for (int c = 0; c < VEC; c++) bb[c] = (a.bkg_mode == 1) ? bser[c] : 0.f;
 							}
 							const int pr = p / a.width;
 							const int pc = p - pr * a.width;
-							st.side(v, bb, (double)(col0 + pc), (double)(row0 + pr));
+							st.side(v, (double)(col0 + pc), (double)(row0 + pr));
+							float y[VEC];
+							st.bkg_terms(bb, y);
 #pragma unroll
 							for (int c = 0; c < VEC; c++) {
 								const float e2 = ee[c] * ee[c];
-								if (pos_in_leaf == 0) { st.r[c][j] = v[c]; st.e[c][j] = e2; }
-								else { st.r[c][j] += v[c]; st.e[c][j] += e2; }
+								if (pos_in_leaf == 0) { st.r[c][j] = v[c]; st.e[c][j] = e2; st.bk[c][j] = y[c]; }
+								else { st.r[c][j] += v[c]; st.e[c][j] += e2; st.bk[c][j] += y[c]; }
 							}
 						}
 						i += 8;
 						pos_in_leaf += 8;
 						if (pos_in_leaf == Lblk) {
 #pragma unroll
-							for (int c = 0; c < VEC; c++) { st.fres[c] = combine8(st.r[c]); st.eres[c] = combine8(st.e[c]); }
+							for (int c = 0; c < VEC; c++) { st.fres[c] = combine8(st.r[c]); st.eres[c] = combine8(st.e[c]); st.bres[c] = combine8(st.bk[c]); }
 						}
 					} else {
 						// tail element of the (last) leaf
@@ -198,26 +201,29 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 						if (a.bkg_mode == 0) Vec<VEC>::load(bkg + off, bb);
 						else {
 #pragma unroll
-							for (int c = 0; c < VEC; c++) bb[c] = bser[c];
+							for (int c = 0; c < VEC; c++) bb[c] = (a.bkg_mode == 1) ? bser[c] : 0.f;
 						}
 						const int pr = p / a.width;
 						const int pc = p - pr * a.width;
-						st.side(v, bb, (double)(col0 + pc), (double)(row0 + pr));
+						st.side(v, (double)(col0 + pc), (double)(row0 + pr));
+						float y[VEC];
+						st.bkg_terms(bb, y);
 #pragma unroll
-						for (int c = 0; c < VEC; c++) { st.fres[c] += v[c]; st.eres[c] += ee[c] * ee[c]; }
+						for (int c = 0; c < VEC; c++) { st.fres[c] += v[c]; st.eres[c] += ee[c] * ee[c]; st.bres[c] += y[c]; }
 						i += 1;
 						pos_in_leaf += 1;
 					}
 					if (pos_in_leaf == L) {
 						// leaf complete: push, then perform the merges that follow it in post-order
 #pragma unroll
-						for (int c = 0; c < VEC; c++) { stk_f[c][sp] = st.fres[c]; stk_e[c][sp] = st.eres[c]; }
+						for (int c = 0; c < VEC; c++) { stk_f[c][sp] = st.fres[c]; stk_e[c][sp] = st.eres[c]; stk_b[c][sp] = st.bres[c]; }
 						sp++;
 						for (int mm = 0; mm < (int)s_leaf_merges[leaf]; mm++) {
 #pragma unroll
 							for (int c = 0; c < VEC; c++) {
 								stk_f[c][sp - 2] = stk_f[c][sp - 2] + stk_f[c][sp - 1];
 								stk_e[c][sp - 2] = stk_e[c][sp - 2] + stk_e[c][sp - 1];
+								stk_b[c][sp - 2] = stk_b[c][sp - 2] + stk_b[c][sp - 1];
 							}
 							sp--;
 						}
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 		}
 		if (active) {
 #pragma unroll
-			for (int c = 0; c < VEC; c++) { st.fres[c] = 0.f + stk_f[c][0]; st.eres[c] = 0.f + stk_e[c][0]; }
+			for (int c = 0; c < VEC; c++) { st.fres[c] = 0.f + stk_f[c][0]; st.eres[c] = 0.f + stk_e[c][0]; st.bres[c] = 0.f + stk_b[c][0]; }
 			store_outputs<VEC>(a, target, k0, st, M);
 		}
 	}
@@ -273,11 +279,13 @@ extern "C" int tp_aperture_extract(tp_ctx* ctx, const tp_cube_desc* desc,
 	TP_CHECK_CTX(ctx);
 	TP_API_BEGIN
 	TP_REQUIRE(ctx, tp_desc_ok(desc), "tp_aperture_extract: bad cube descriptor");
-	TP_REQUIRE(ctx, d_images && d_images_err && d_backgrounds && d_mask && d_stamps, "tp_aperture_extract: null input pointer");
-	TP_REQUIRE(ctx, d_flux && d_flux_err && d_flux_background && d_centroid_col && d_centroid_row, "tp_aperture_extract: null output pointer");
+	TP_REQUIRE(ctx, d_images && d_images_err && d_mask && d_stamps, "tp_aperture_extract: null input pointer");
+	TP_REQUIRE(ctx, d_flux && d_flux_err && d_centroid_col && d_centroid_row, "tp_aperture_extract: null output pointer");
+	TP_REQUIRE(ctx, d_flux_background || !d_backgrounds, "tp_aperture_extract: backgrounds given but no flux_background output");
 	TP_REQUIRE(ctx, out_pitch >= desc->n_cad, "tp_aperture_extract: out_pitch < n_cad");
 	TP_REQUIRE(ctx, bkg_mode == 0 || bkg_mode == 1, "tp_aperture_extract: bkg_mode must be 0 (cube) or 1 (series)");
-	TP_REQUIRE(ctx, bkg_mode == 0 || bkg_series_pitch >= desc->n_cad, "tp_aperture_extract: bad bkg_series_pitch");
+	if (!d_backgrounds) bkg_mode = 2; // aperture-only: no background input, flux_background (if given) = NaN
+	TP_REQUIRE(ctx, bkg_mode != 1 || bkg_series_pitch >= desc->n_cad, "tp_aperture_extract: bad bkg_series_pitch");
 	TP_REQUIRE(ctx, (int64_t)desc->height * desc->width <= (int64_t)kMaxLeaves * 64, "tp_aperture_extract: stamp too large");
 	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
 
@@ -293,7 +301,7 @@ extern "C" int tp_aperture_extract(tp_ctx* ctx, const tp_cube_desc* desc,
 
 	bool vec4 = tp_vec4_ok(d_images, desc->t_pitch) && tp_vec4_ok(d_images_err, desc->t_pitch);
 	if (bkg_mode == 0) vec4 = vec4 && tp_vec4_ok(d_backgrounds, desc->t_pitch);
-	else vec4 = vec4 && tp_vec4_ok(d_backgrounds, bkg_series_pitch);
+	else if (bkg_mode == 1) vec4 = vec4 && tp_vec4_ok(d_backgrounds, bkg_series_pitch);
 	TP_REQUIRE(ctx, d_subtract == nullptr || subtract_pitch >= desc->n_cad, "tp_aperture_extract: bad subtract pitch");
 	if (d_subtract) vec4 = vec4 && tp_vec4_ok(d_subtract, subtract_pitch);
 	// Small masks (the common case): 2 cadences per thread (64-bit loads, 512 B per wavefront instruction) keep the

@@ -33,21 +33,21 @@ template <int VEC>
 struct CadState {
 	float r[VEC][8];      // pairwise accumulators: flux
 	float e[VEC][8];      // pairwise accumulators: err^2
-	float fres[VEC], eres[VEC];
-	float bsum[VEC];
+	float bk[VEC][8];     // pairwise accumulators: background (NaN -> 0, np.nansum)
+	float fres[VEC], eres[VEC], bres[VEC];
 	double cw[VEC], ccol[VEC], crow[VEC];
 	bool f_allnan[VEC], f_allzero[VEC], b_allnan[VEC];
 
 	__device__ __forceinline__ void init() {
 #pragma unroll
 		for (int c = 0; c < VEC; c++) {
-			fres[c] = 0.f; eres[c] = 0.f; bsum[c] = 0.f;
+			fres[c] = 0.f; eres[c] = 0.f; bres[c] = 0.f;
 			cw[c] = 0.0; ccol[c] = 0.0; crow[c] = 0.0;
 			f_allnan[c] = true; f_allzero[c] = true; b_allnan[c] = true;
 		}
 	}
-	// everything except the pairwise flux / err sums
-	__device__ __forceinline__ void side(const float (&v)[VEC], const float (&b)[VEC], double col, double row) {
+	// everything except the pairwise flux / err / background sums
+	__device__ __forceinline__ void side(const float (&v)[VEC], double col, double row) {
 #pragma unroll
 		for (int c = 0; c < VEC; c++) {
 			const float x = v[c];
@@ -59,8 +59,15 @@ struct CadState {
 				ccol[c] += col * w;
 				crow[c] += row * w;
 			}
-			const float y = b[c];
-			if (y == y) { bsum[c] += y; b_allnan[c] = false; }
+		}
+	}
+	// np.nansum (photometry.py:201) = np.sum of the values with NaN replaced by 0: the term that enters the pairwise tree
+	__device__ __forceinline__ void bkg_terms(const float (&b)[VEC], float (&y)[VEC]) {
+#pragma unroll
+		for (int c = 0; c < VEC; c++) {
+			const bool fin = (b[c] == b[c]);
+			b_allnan[c] = b_allnan[c] && !fin;
+			y[c] = fin ? b[c] : 0.f;
 		}
 	}
 };
@@ -71,7 +78,7 @@ __device__ __forceinline__ float combine8(const float (&r)[8]) {
 
 struct Args {
 	const float* images; const float* images_err; const float* backgrounds;
-	int32_t bkg_mode; int64_t bkg_series_pitch;
+	int32_t bkg_mode; int64_t bkg_series_pitch;   // 0 cube, 1 series per target, 2 no background (aperture-only)
 	const float* subtract; int64_t subtract_pitch;
 	const uint8_t* mask; const int32_t* stamps; const int32_t* status;
 	double* flux; double* flux_err; double* flux_bkg; double* ccol; double* crow;
@@ -94,7 +101,7 @@ __device__ __forceinline__ void store_outputs(const Args& a, int target, int k0,
 		const bool haspos = st.cw[c] > 0.0;
 		a.ccol[ob + k] = (bad || !haspos) ? nan : st.ccol[c] / st.cw[c];
 		a.crow[ob + k] = (bad || !haspos) ? nan : st.crow[c] / st.cw[c];
-		a.flux_bkg[ob + k] = (M == 0 || st.b_allnan[c]) ? nan : (double)st.bsum[c];
+		if (a.flux_bkg) a.flux_bkg[ob + k] = (M == 0 || a.bkg_mode == 2 || st.b_allnan[c]) ? nan : (double)st.bres[c];
 	}
 }
 
@@ -145,6 +152,7 @@ __device__ __forceinline__ void extract_small(const Args& a, int target, const i
 	const float* img = a.images + tb;
 	const float* err = a.images_err + tb;
 	const float* bkg = (a.bkg_mode == 0) ? (a.backgrounds + tb) : (a.backgrounds + (int64_t)target * a.bkg_series_pitch);
+	const bool has_bkg = (a.bkg_mode != 2);
 	const int nq = (a.n_cad + VEC - 1) / VEC;
 	const int nblk = M - (M & 7);
 
@@ -153,10 +161,10 @@ __device__ __forceinline__ void extract_small(const Args& a, int target, const i
 		CadState<VEC> st;
 		st.init();
 		float bser[VEC], ssub[VEC];
-		if (a.bkg_mode != 0) Vec<VEC>::load(bkg + k0, bser);
+		if (a.bkg_mode == 1) Vec<VEC>::load(bkg + k0, bser);
 		if (a.subtract) Vec<VEC>::load(a.subtract + (int64_t)target * a.subtract_pitch + k0, ssub);
 
-		auto fetch = [&](int idx, float (&v)[VEC], float (&e2)[VEC]) {
+		auto fetch = [&](int idx, float (&v)[VEC], float (&e2)[VEC], float (&y)[VEC]) {
 			const int p = s_list[idx];
 			const int64_t off = (int64_t)p * a.t_pitch + k0;
 			float ee[VEC], bb[VEC];
@@ -169,47 +177,48 @@ __device__ __forceinline__ void extract_small(const Args& a, int target, const i
 			if (a.bkg_mode == 0) Vec<VEC>::load(bkg + off, bb);
 			else {
 #pragma unroll
-				for (int c = 0; c < VEC; c++) bb[c] = bser[c];
+				for (int c = 0; c < VEC; c++) bb[c] = (a.bkg_mode == 1) ? bser[c] : 0.f;
 			}
 			const int pr = p / a.width;
 			const int pc = p - pr * a.width;
 #pragma unroll
 			for (int c = 0; c < VEC; c++) e2[c] = ee[c] * ee[c];
-			st.side(v, bb, (double)(col0 + pc), (double)(row0 + pr));
+			st.side(v, (double)(col0 + pc), (double)(row0 + pr));
+			if (has_bkg) st.bkg_terms(bb, y);
 		};
 
 		if (M < 8) {
 			for (int i = 0; i < M; i++) {
-				float v[VEC], e2[VEC];
-				fetch(i, v, e2);
+				float v[VEC], e2[VEC], y[VEC];
+				fetch(i, v, e2, y);
 #pragma unroll
-				for (int c = 0; c < VEC; c++) { st.fres[c] += v[c]; st.eres[c] += e2[c]; }
+				for (int c = 0; c < VEC; c++) { st.fres[c] += v[c]; st.eres[c] += e2[c]; if (has_bkg) st.bres[c] += y[c]; }
 			}
 		} else {
 			for (int g = 0; g < nblk; g += 8) {
 #pragma unroll
 				for (int j = 0; j < 8; j++) {
-					float v[VEC], e2[VEC];
-					fetch(g + j, v, e2);
+					float v[VEC], e2[VEC], y[VEC];
+					fetch(g + j, v, e2, y);
 #pragma unroll
 					for (int c = 0; c < VEC; c++) {
-						if (g == 0) { st.r[c][j] = v[c]; st.e[c][j] = e2[c]; }
-						else { st.r[c][j] += v[c]; st.e[c][j] += e2[c]; }
+						if (g == 0) { st.r[c][j] = v[c]; st.e[c][j] = e2[c]; if (has_bkg) st.bk[c][j] = y[c]; }
+						else { st.r[c][j] += v[c]; st.e[c][j] += e2[c]; if (has_bkg) st.bk[c][j] += y[c]; }
 					}
 				}
 			}
 #pragma unroll
-			for (int c = 0; c < VEC; c++) { st.fres[c] = combine8(st.r[c]); st.eres[c] = combine8(st.e[c]); }
+			for (int c = 0; c < VEC; c++) { st.fres[c] = combine8(st.r[c]); st.eres[c] = combine8(st.e[c]); if (has_bkg) st.bres[c] = combine8(st.bk[c]); }
 			for (int i = nblk; i < M; i++) {
-				float v[VEC], e2[VEC];
-				fetch(i, v, e2);
+				float v[VEC], e2[VEC], y[VEC];
+				fetch(i, v, e2, y);
 #pragma unroll
-				for (int c = 0; c < VEC; c++) { st.fres[c] += v[c]; st.eres[c] += e2[c]; }
+				for (int c = 0; c < VEC; c++) { st.fres[c] += v[c]; st.eres[c] += e2[c]; if (has_bkg) st.bres[c] += y[c]; }
 			}
 		}
 		// np.sum = 0 + pairwise_sum (identity-initialised reduce)
 #pragma unroll
-		for (int c = 0; c < VEC; c++) { st.fres[c] = 0.f + st.fres[c]; st.eres[c] = 0.f + st.eres[c]; }
+		for (int c = 0; c < VEC; c++) { st.fres[c] = 0.f + st.fres[c]; st.eres[c] = 0.f + st.eres[c]; st.bres[c] = 0.f + st.bres[c]; }
 		store_outputs<VEC>(a, target, k0, st, M);
 	}
 }
@@ -219,7 +228,7 @@ __device__ __forceinline__ void extract_small(const Args& a, int target, const i
 // of group g+1 -- also across cadence blocks -- are in flight while group g is accumulated, and every load is
 // unconditional straight-line code (indices clamp instead of branching) so that only the ping-pong order decides the
 // waitcnts.  Pixel order, accumulator assignment and operation order are those of extract_small: identical results.
-template <int VEC, bool HAS_SUB, bool BKG_CUBE>
+template <int VEC, bool HAS_SUB, int BKG>
 __device__ __forceinline__ void extract_small_stream(const Args& a, int target, const int* s_list, int M, int q_lane, int q_stride)
 {
 	const int P = a.height * a.width;
@@ -228,6 +237,7 @@ __device__ __forceinline__ void extract_small_stream(const Args& a, int target, 
 	const int64_t tb = (int64_t)target * P * a.t_pitch;
 	const float* img = a.images + tb;
 	const float* err = a.images_err + tb;
+	constexpr bool BKG_CUBE = (BKG == 0), BKG_SERIES = (BKG == 1), HAS_BKG = (BKG != 2);
 	const float* bkg = BKG_CUBE ? (a.backgrounds + tb) : (a.backgrounds + (int64_t)target * a.bkg_series_pitch);
 	const float* subp = HAS_SUB ? (a.subtract + (int64_t)target * a.subtract_pitch) : nullptr;
 	const int nq = (a.n_cad + VEC - 1) / VEC;
@@ -253,7 +263,7 @@ __device__ __forceinline__ void extract_small_stream(const Args& a, int target, 
 		int q = q_lane + it * q_stride;
 		q = (q < nq) ? q : (nq - 1);
 		const int k0 = q * VEC;
-		if (!BKG_CUBE) Vec<VEC>::load(bkg + k0, B.ser);
+		if (BKG_SERIES) Vec<VEC>::load(bkg + k0, B.ser);
 		if (HAS_SUB) Vec<VEC>::load(subp + k0, B.sub);
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
@@ -277,31 +287,32 @@ __device__ __forceinline__ void extract_small_stream(const Args& a, int target, 
 				const int p = s_list[g * 8 + j];
 				const int pr = p / a.width;
 				const int pc = p - pr * a.width;
-				float v[VEC], e2[VEC], bb[VEC];
+				float v[VEC], e2[VEC], bb[VEC], y[VEC];
 #pragma unroll
 				for (int c = 0; c < VEC; c++) {
 					v[c] = HAS_SUB ? (B.v[j][c] - B.sub[c]) : B.v[j][c];
 					e2[c] = B.e[j][c] * B.e[j][c];
-					bb[c] = BKG_CUBE ? B.b[BKG_CUBE ? j : 0][c] : B.ser[c];
+					bb[c] = BKG_CUBE ? B.b[BKG_CUBE ? j : 0][c] : (BKG_SERIES ? B.ser[c] : 0.f);
 				}
-				st.side(v, bb, (double)(col0 + pc), (double)(row0 + pr));
+				st.side(v, (double)(col0 + pc), (double)(row0 + pr));
+				if (HAS_BKG) st.bkg_terms(bb, y);
 #pragma unroll
 				for (int c = 0; c < VEC; c++) {
 					if (full) {
-						if (g == 0) { st.r[c][j] = v[c]; st.e[c][j] = e2[c]; }
-						else { st.r[c][j] += v[c]; st.e[c][j] += e2[c]; }
-					} else { st.fres[c] += v[c]; st.eres[c] += e2[c]; }
+						if (g == 0) { st.r[c][j] = v[c]; st.e[c][j] = e2[c]; if (HAS_BKG) st.bk[c][j] = y[c]; }
+						else { st.r[c][j] += v[c]; st.e[c][j] += e2[c]; if (HAS_BKG) st.bk[c][j] += y[c]; }
+					} else { st.fres[c] += v[c]; st.eres[c] += e2[c]; if (HAS_BKG) st.bres[c] += y[c]; }
 				}
 			}
 		}
 		if (full && g == nfull - 1) {
 #pragma unroll
-			for (int c = 0; c < VEC; c++) { st.fres[c] = combine8(st.r[c]); st.eres[c] = combine8(st.e[c]); }
+			for (int c = 0; c < VEC; c++) { st.fres[c] = combine8(st.r[c]); st.eres[c] = combine8(st.e[c]); if (HAS_BKG) st.bres[c] = combine8(st.bk[c]); }
 		}
 		if (g == spq - 1) {
 			// np.sum = 0 + pairwise_sum (identity-initialised reduce)
 #pragma unroll
-			for (int c = 0; c < VEC; c++) { st.fres[c] = 0.f + st.fres[c]; st.eres[c] = 0.f + st.eres[c]; }
+			for (int c = 0; c < VEC; c++) { st.fres[c] = 0.f + st.fres[c]; st.eres[c] = 0.f + st.eres[c]; st.bres[c] = 0.f + st.bres[c]; }
 			if (q < nq) store_outputs<VEC>(a, target, q * VEC, st, M);
 			st.init();
 		}

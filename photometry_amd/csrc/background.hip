@@ -8,20 +8,24 @@
 // backgrounds.py:89-94, one mesh cell = the stamp, SigmaClip(3 sigma, 5 iterations, median/std),
 // SExtractor mode estimator, "more than 50 % masked -> no estimate".  See oracle/backgrounds.py.
 //
-// Mapping (gfx950).  The cube is time-fastest, so consecutive lanes read consecutive cadences of a
-// pixel's time series (coalesced) and NO LDS transposition is needed to get a frame into registers.
-// A frame (one cadence of one target, <= 256 pixels) is owned by a QUAD of lanes, 64 pixel values per
-// lane in VGPRs; a wavefront holds 16 frames, a 256-thread workgroup 64 consecutive cadences.
-//   1. each lane sorts its 64 values with a fully unrolled bitonic network (v_min_f32 / v_max_f32 on compile-time
-//      register indices: no divergence, no memory traffic);
-//   2. the four sorted runs are merged across the quad: a MIRROR stage (register j against register 63-j of the partner
-//      lane, DPP quad_perm) turns two ascending runs into two bitonic halves, all further stages are ascending merges;
-//   3. one predicated pass over the registers gives the float64 sums of the frame; the sorted values are staged in LDS and
-//      indexed by rank for the clipping passes (median = two reads, bounds by binary search, sums updated by the ranks
-//      that leave the kept range).
-// Measured alternatives (C3 cube): one thread per frame with 256 registers 33.6 ms (instruction-cache bound); clipping as
-// two full register passes per iteration 14.1 ms; a register prefetch buffer 15.0 ms (one wave per SIMD); loads through a
-// coalescing LDS transpose tile (256-byte segments, two workgroup barriers) 14.2 ms; this version 10.8 ms.
+// Mapping (gfx950).  A frame (one cadence of one target, <= 256 pixels) is owned by EIGHT lanes, 32 pixel values per
+// lane in VGPRs; a wavefront holds 8 frames, a 256-thread workgroup 32 consecutive cadences (= one 128-byte line of
+// every pixel's time series).  With ~70 VGPRs and 1 KiB of LDS per frame 4-5 wavefronts per SIMD are resident, so the
+// loads of some wavefronts hide under the sorting of others (the round-1 kernel -- a quad per frame, 64 values per
+// lane, 185 VGPRs, 2 wavefronts per SIMD -- spent 40 % of its life waiting for its loads and ran at 10.9 ms).
+//   1. loads: buffer_load_dword with a per-lane voffset and a scalar soffset per pixel row (no address arithmetic on
+//      the vector ALU); pixel mask of backgrounds.py:89-94 and the float64 sums of the unclipped frame on the fly;
+//   2. each lane sorts its 32 values with an unrolled bitonic network (v_min_f32 / v_max_f32 on compile-time register
+//      indices), then three cross-lane merge levels (2, 4, 8 lanes): a MIRROR stage (register j against register 31-j
+//      of the partner lane: DPP quad_perm / row_half_mirror) turns two ascending runs into two bitonic halves, the
+//      remaining stages are ascending merges; a cross-lane compare-exchange is one DPP move + one v_med3_f32 against
+//      a per-lane -inf / +inf constant (min for the lower lane, max for the upper);
+//   3. the sorted values are staged in LDS where they can be indexed by rank.  The kept set of the sigma clipping is
+//      always a contiguous rank range: the median is two LDS reads, and the clipped ranks are found by walking in from
+//      both ends of the range, eight ranks per step (one per lane of the frame), summing what leaves the range as it
+//      goes.  The 3-sigma test is evaluated without division or square root: x is clipped iff
+//      ((x - med) m)^2 > 9 (m s2 - s1^2), with s1, s2 the float64 sums of the m kept values.
+// A wavefront stages and reads only its own 8 frames and its LDS operations execute in order: no workgroup barrier.
 #include "common.h"
 #include <cmath>
 
@@ -80,152 +84,159 @@ __device__ __forceinline__ float sextractor_mode(double med, double mean, double
 	return (float)bkg;
 }
 
-// DPP quad permutes: value of lane^1 / lane^2 / lane^3 within the quad
-__device__ __forceinline__ float quad_xor1(float x) {
-	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false)); // quad_perm [1,0,3,2]
-}
-__device__ __forceinline__ float quad_xor2(float x) {
-	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, false)); // quad_perm [2,3,0,1]
-}
-__device__ __forceinline__ float quad_rev(float x) {
-	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x1B, 0xF, 0xF, false)); // quad_perm [3,2,1,0]
-}
-// compare-exchange of register j with register j of lane^1: the lower lane keeps the minimum
-__device__ __forceinline__ void cross_stage_xor1(float (&v)[64], bool keepmin) {
-#pragma unroll
-	for (int j = 0; j < 64; ++j) {
-		const float p = quad_xor1(v[j]);
-		v[j] = keepmin ? tp_min(v[j], p) : tp_max(v[j], p);
-	}
-}
-// MIRROR stage of a merge: register j against register 63-j of the partner lane (lane^1 for runs of 64, lane^3 for runs of
-// 128).  Two ascending runs become two bitonic halves whose merges are all ascending -- no direction flags, no sign flips.
-template <bool ACROSS_QUAD>
-__device__ __forceinline__ void mirror_stage(float (&v)[64], bool keepmin) {
-	float w[64];
-#pragma unroll
-	for (int j = 0; j < 64; ++j) {
-		const float p = ACROSS_QUAD ? quad_rev(v[63 - j]) : quad_xor1(v[63 - j]);
-		w[j] = keepmin ? tp_min(v[j], p) : tp_max(v[j], p);
-	}
-#pragma unroll
-	for (int j = 0; j < 64; ++j) v[j] = w[j];
-}
-// ascending bitonic MERGE of a lane's 64 values (strides 32..1)
-__device__ __forceinline__ void local_merge(float (&v)[64]) { BitonicStage<64, 64, 32>::run(v); }
-
-constexpr int kFramesPerWave = 16;
-constexpr int kBkgThreads = 128;
+constexpr int kLanesPerFrame = 8;
+constexpr int kValsPerLane = 32;
+constexpr int kFramesPerWave = 64 / kLanesPerFrame;
+constexpr int kBkgThreads = 256;
 constexpr int kFramesPerBlock = kFramesPerWave * (kBkgThreads / 64);
 
-__device__ __forceinline__ double quad_sum(double x) { x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); return x; }
-__device__ __forceinline__ float quad_sum(float x) { x += quad_xor1(x); x += quad_xor2(x); return x; }
-__device__ __forceinline__ int quad_sum(int x) { x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); return x; }
+// DPP lane permutations inside the 8 lanes of a frame
+constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int kDppQuadRev = 0x1B;     // quad_perm [3,2,1,0]        (lane ^ 3)
+constexpr int kDppHalfMirror = 0x141; // row_half_mirror            (lane ^ 7)
+template <int CTRL> __device__ __forceinline__ int dpp_i(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true); }
+template <int CTRL> __device__ __forceinline__ float dpp_f(float x) { return __int_as_float(dpp_i<CTRL>(__float_as_int(x))); }
+template <int CTRL> __device__ __forceinline__ double dpp_d(double x) {
+	const int lo = dpp_i<CTRL>(__double2loint(x)), hi = dpp_i<CTRL>(__double2hiint(x));
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int frame_sum(int x) { x += dpp_i<kDppXor1>(x); x += dpp_i<kDppXor2>(x); x += dpp_i<kDppHalfMirror>(x); return x; }
+__device__ __forceinline__ double frame_sum(double x) { x += dpp_d<kDppXor1>(x); x += dpp_d<kDppXor2>(x); x += dpp_d<kDppHalfMirror>(x); return x; }
+
+// Cross-lane compare-exchange stage: register j against register j (MIRROR: 31 - j) of the partner lane; sel = -inf
+// keeps the minimum (v_med3_f32(a, b, -inf) = min), sel = +inf the maximum.
+template <int CTRL, bool MIRROR>
+__device__ __forceinline__ void cross_stage(float (&v)[kValsPerLane], float sel) {
+	if (MIRROR) {
+#pragma unroll
+		for (int j = 0; j < kValsPerLane / 2; ++j) {
+			const float a = v[j], b = v[kValsPerLane - 1 - j];
+			const float pa = dpp_f<CTRL>(b), pb = dpp_f<CTRL>(a);
+			v[j] = __builtin_amdgcn_fmed3f(a, pa, sel);
+			v[kValsPerLane - 1 - j] = __builtin_amdgcn_fmed3f(b, pb, sel);
+		}
+	} else {
+#pragma unroll
+		for (int j = 0; j < kValsPerLane; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], dpp_f<CTRL>(v[j]), sel);
+	}
+}
+// ascending bitonic MERGE of a lane's 32 values (strides 16..1)
+__device__ __forceinline__ void local_merge(float (&v)[kValsPerLane]) { BitonicStage<kValsPerLane, kValsPerLane, kValsPerLane / 2>::run(v); }
+
+// LDS index of rank r of a staged frame: every lane's run of 32 ranks is followed by 4 pad words, so that the eight
+// 16-byte stores of a staging instruction fall into different banks
+__device__ __forceinline__ int rank_idx(int r) { return r + ((r >> 5) << 2); }
 
 __global__ __launch_bounds__(kBkgThreads) void tp_bkg_stamp_kernel(BkgArgs a, int frame_stride)
 {
-	extern __shared__ __align__(16) float s_sorted[]; // [waves][kFramesPerWave][frame_stride]
+	extern __shared__ __align__(16) float s_sorted[]; // [kFramesPerBlock][frame_stride]
 	const int target = blockIdx.x;
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63;
-	const int f = lane >> 2, q = lane & 3;   // frame within the wavefront, quarter of the frame
+	const int f = lane >> 3, g = lane & 7;   // frame within the wavefront, lane within the frame
 	const int k = blockIdx.y * kFramesPerBlock + wave * kFramesPerWave + f;
 	const bool active = k < a.n_cad;
-	const float* base = a.raw + (int64_t)target * a.n_pix * a.t_pitch + (active ? k : 0);
 	const float inf = __builtin_inff();
 	float* fr = s_sorted + (size_t)(wave * kFramesPerWave + f) * frame_stride;
-	float v[64];
+
+	// --- loads: pixel i = 8 j + g of cadence k; the descriptor covers this target's cube, the row offset is scalar
+	const int pitch_b = (int)a.t_pitch * 4;
+	const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+		const_cast<float*>(a.raw + (int64_t)target * a.n_pix * a.t_pitch), 0, a.n_pix * pitch_b, 0x00020000);
+	const int voff = g * pitch_b + (active ? k : (a.n_cad - 1)) * 4;
+	float v[kValsPerLane];
+#pragma unroll
+	for (int j = 0; j < kValsPerLane; ++j) // all 32 loads in flight before the first use
+		v[j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, j * kLanesPerFrame * pitch_b, 0));
 	int n = 0;
-#pragma unroll
-	for (int j = 0; j < 64; ++j) {
-		const int i = q * 64 + j;
-		float x = inf;
-		if (i < a.n_pix) x = base[(int64_t)i * a.t_pitch];
-		// backgrounds.py:91-94: mask = ~isfinite | > flux_cutoff | < 0   (+inf padding is "masked" too)
-		const bool ok = (fabsf(x) <= 3.402823466e+38f) && !(x > a.flux_cutoff) && !(x < 0.f);
-		n += ok ? 1 : 0;
-		v[j] = ok ? x : inf;
-	}
-	n = quad_sum(n);
-
-	// --- distributed bitonic sort of the 256 values of the quad: global index (= rank) g = q*64 + j ---
-	BitonicLevel<64, 32>::run(v);                       // sizes 2..32: directions fixed by the local index
-	local_merge(v);                                     // size 64: every lane ascending
-	mirror_stage<false>(v, (q & 1) == 0);               // size 128: mirror against lane^1 ...
-	local_merge(v);                                     //           ... then ascending merges: lanes (0,1) and (2,3) sorted
-	mirror_stage<true>(v, (q & 2) == 0);                // size 256: mirror against lane^3,
-	cross_stage_xor1(v, (q & 1) == 0);                  //           stride 64 against lane^1,
-	local_merge(v);                                     //           strides 32..1
-
-	// --- sigma clipping.  The kept set is always a contiguous rank range [lo_i, hi_i) of the sorted values.  One
-	// predicated pass over the lane's 64 registers gives the float64 sums of the whole frame; the sorted values are
-	// then staged in LDS (1 KiB per frame) where they can be indexed by rank: the median is two reads, the new bounds
-	// are two binary searches for the float32-exact thresholds, and the sums are UPDATED by subtracting only the
-	// ranks that leave the range (shared by the four lanes of the quad) -- a few dozen LDS reads per clipping pass
-	// instead of two 64-register passes of float64 arithmetic.  All four lanes of a quad carry the same scalars.
-	// A wavefront stages and reads only its own 16 frames and its LDS operations execute in order: no workgroup
-	// barrier.  Only the ranks below frame_stride are staged (ranks >= n_pix are +inf sentinels nobody reads).
-#pragma unroll
-	for (int j = 0; j < 64; j += 4)
-		if (q * 64 + j < frame_stride) *reinterpret_cast<float4*>(fr + q * 64 + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
-	const int nmasked = a.n_pix - n;
-	const bool usable = active && (n > 0) && !((float)nmasked > a.exclude_fraction * (float)a.n_pix);
-	const int rbase = q * 64;
 	double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-	for (int j = 0; j < 64; ++j) {
-		const bool in = (rbase + j) < n;              // ranks >= n are the +inf sentinels
-		float xf = in ? v[j] : 0.f;
-		asm volatile("" : "+v"(xf));   // keep the conversion in the loop (else 64 doubles stay live)
-		const double x = (double)xf;
-		s1 += x;
-		s2 = __builtin_fma(x, x, s2);
+	for (int j = 0; j < kValsPerLane; ++j) {
+		const float x = v[j];
+		// backgrounds.py:91-94: mask = ~isfinite | > flux_cutoff | < 0; slots past the last pixel are masked too
+		const bool ok = (x >= 0.f) && (x <= a.flux_cutoff) && (j * kLanesPerFrame + g < a.n_pix);
+		n += ok ? 1 : 0;
+		v[j] = ok ? x : inf;
+		float z = ok ? x : 0.f;
+		asm("" : "+v"(z));   // keep the conversion in the loop (else 32 doubles stay live)
+		const double zd = (double)z;
+		s1 += zd;
+		s2 = __builtin_fma(zd, zd, s2);
 	}
-	s1 = quad_sum(s1); s2 = quad_sum(s2);
+	n = frame_sum(n);
+	s1 = frame_sum(s1);
+	s2 = frame_sum(s2);
+
+	// --- distributed bitonic sort of the 256 values of the frame: rank = 32 g + j
+	const float sel1 = (g & 1) ? inf : -inf, sel2 = (g & 2) ? inf : -inf, sel4 = (g & 4) ? inf : -inf;
+	BitonicLevel<kValsPerLane, kValsPerLane / 2>::run(v);      // sizes 2..16: directions fixed by the local index
+	local_merge(v);                                              // size 32: every lane ascending
+	cross_stage<kDppXor1, true>(v, sel1);                        // size 64: mirror against lane^1,
+	local_merge(v);                                              //          then ascending merges
+	cross_stage<kDppQuadRev, true>(v, sel2);                     // size 128: mirror against lane^3,
+	cross_stage<kDppXor1, false>(v, sel1);                       //           stride 32 against lane^1,
+	local_merge(v);                                              //           strides 16..1
+	cross_stage<kDppHalfMirror, true>(v, sel4);                  // size 256: mirror against lane^7,
+	cross_stage<kDppXor2, false>(v, sel2);                       //           stride 64 against lane^2,
+	cross_stage<kDppXor1, false>(v, sel1);                       //           stride 32 against lane^1,
+	local_merge(v);                                              //           strides 16..1
+
+	// --- stage the sorted frame (only the ranks that can hold a pixel; ranks >= n are +inf sentinels nobody reads)
+#pragma unroll
+	for (int j = 0; j < kValsPerLane; j += 4)
+		if (g * kValsPerLane + j < a.n_pix) *reinterpret_cast<float4*>(fr + g * (kValsPerLane + 4) + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
 	__builtin_amdgcn_wave_barrier();
+
+	// --- sigma clipping on the staged ranks; the eight lanes of a frame carry the same scalars
+	const int nmasked = a.n_pix - n;
+	const bool usable = active && (n > 0) && !((float)nmasked > a.exclude_fraction * (float)a.n_pix);
+	int lo_i = 0, hi_i = usable ? n : 1;
+	double med = 0.0;
+#pragma unroll 1
+	for (int it = 0; ; ++it) {
+		const int m = hi_i - lo_i;
+		const int m1 = lo_i + (m >> 1);          // upper middle rank
+		const int m0 = (m & 1) ? m1 : (m1 - 1);  // lower middle rank
+		med = ((double)fr[rank_idx(m0)] + (double)fr[rank_idx(m1)]) * 0.5;
+		if (it == 5) break;                        // maxiters = 5 clipping passes, then the final statistics
+		const double mm = (double)m;
+		double q9 = 9.0 * (mm * s2 - s1 * s1);    // 9 m^2 var
+		if (!(q9 > 0.0)) q9 = 0.0;
+		int top = 0, bot = 0;
+		double r1 = 0.0, r2 = 0.0;
+		bool more_t = usable, more_b = usable;
+#pragma unroll 1
+		for (int base = 0; ; base += kLanesPerFrame) {
+			const int rt = hi_i - 1 - g - base, rb = lo_i + g + base;
+			const bool vt = more_t && (rt >= lo_i), vb = more_b && (rb < hi_i);
+			const float xt = fr[rank_idx(vt ? rt : lo_i)], xb = fr[rank_idx(vb ? rb : lo_i)];
+			const double dt = ((double)xt - med) * mm, db = ((double)xb - med) * mm;
+			const bool ot = vt && (dt > 0.0) && (dt * dt > q9), ob = vb && (db < 0.0) && (db * db > q9);
+			// number of consecutive clipped ranks from the end of the range, among this step's eight
+			const unsigned bt = (unsigned)(__ballot(ot) >> (lane & 56)) & 0xFFu, bb = (unsigned)(__ballot(ob) >> (lane & 56)) & 0xFFu;
+			const int ct = __builtin_ctz(~bt), cb = __builtin_ctz(~bb);
+			if (g < ct) { const double x = (double)xt; r1 += x; r2 = __builtin_fma(x, x, r2); }
+			if (g < cb) { const double x = (double)xb; r1 += x; r2 = __builtin_fma(x, x, r2); }
+			top += ct; bot += cb;
+			more_t = (ct == kLanesPerFrame); more_b = (cb == kLanesPerFrame);
+			if (!__any(more_t || more_b)) break;
+		}
+		if (!__any((top | bot) != 0)) break;       // nchanged == 0 in every frame of the wavefront: the statistics are final
+		s1 -= frame_sum(r1);
+		s2 -= frame_sum(r2);
+		lo_i += bot;
+		hi_i -= top;
+	}
 	float result = __builtin_nanf("");
 	if (usable) {
-		int lo_i = 0, hi_i = n;
-		double med = 0.0, mean = 0.0, sd = 0.0;
-#pragma unroll 1
-		for (int it = 0; it <= 5; ++it) {
-			const int m = hi_i - lo_i;
-			const int m1 = lo_i + (m >> 1);          // upper middle rank
-			const int m0 = (m & 1) ? m1 : (m1 - 1);  // lower middle rank
-			med = ((double)fr[m0] + (double)fr[m1]) / 2.0;
-			mean = s1 / (double)m;
-			double var = s2 / (double)m - mean * mean;
-			if (var < 0.0) var = 0.0;
-			sd = sqrt(var);
-			if (it == 5) break;                        // maxiters = 5 clipping passes, then the final statistics
-			// exact float32 thresholds: for float x, (double)x < lo <=> x < round_up(lo); (double)x > hi <=> x > round_down(hi)
-			const float lo_f = __double2float_ru(med - 3.0 * sd);
-			const float hi_f = __double2float_rd(med + 3.0 * sd);
-			// new_lo = first rank in range whose value is >= lo_f, new_hi = first rank whose value is > hi_f
-			int a0 = lo_i, b0 = hi_i, a1 = lo_i, b1 = hi_i;
-#pragma unroll
-			for (int step = 0; step < 8; ++step) {     // the range holds at most 256 ranks
-				const int mid0 = (a0 + b0) >> 1, mid1 = (a1 + b1) >> 1;
-				const float x0 = fr[(a0 < b0) ? mid0 : lo_i], x1 = fr[(a1 < b1) ? mid1 : lo_i];
-				if (a0 < b0) { if (x0 < lo_f) a0 = mid0 + 1; else b0 = mid0; }
-				if (a1 < b1) { if (x1 > hi_f) b1 = mid1; else a1 = mid1 + 1; }
-			}
-			if (a0 < b0) { if (fr[(a0 + b0) >> 1] < lo_f) a0 = ((a0 + b0) >> 1) + 1; else b0 = (a0 + b0) >> 1; }
-			if (a1 < b1) { if (fr[(a1 + b1) >> 1] > hi_f) b1 = (a1 + b1) >> 1; else a1 = ((a1 + b1) >> 1) + 1; }
-			const int new_lo = a0, new_hi = a1;
-			if (new_lo == lo_i && new_hi == hi_i) break; // nchanged == 0: the statistics of this range are final
-			// subtract the ranks that leave the range: [lo_i, new_lo) and [new_hi, hi_i), one of every four per lane
-			double r1 = 0.0, r2 = 0.0;
-			for (int r = lo_i + q; r < new_lo; r += 4) { const double x = (double)fr[r]; r1 += x; r2 = __builtin_fma(x, x, r2); }
-			for (int r = new_hi + q; r < hi_i; r += 4) { const double x = (double)fr[r]; r1 += x; r2 = __builtin_fma(x, x, r2); }
-			r1 = quad_sum(r1); r2 = quad_sum(r2);
-			s1 -= r1; s2 -= r2;
-			lo_i = new_lo;
-			hi_i = new_hi;
-		}
-		result = sextractor_mode(med, mean, sd);
+		const double mm = (double)(hi_i - lo_i);
+		const double mean = s1 / mm;
+		double var = s2 / mm - mean * mean;
+		if (var < 0.0) var = 0.0;
+		result = sextractor_mode(med, mean, sqrt(var));
 	}
-	if (q == 0 && active) a.out[(int64_t)target * a.out_pitch + k] = result;
+	if (g == 0 && active) a.out[(int64_t)target * a.out_pitch + k] = result;
 }
 
 // Generic fallback for stamps with more than 256 pixels: one wavefront per (target, cadence), values
@@ -375,10 +386,11 @@ extern "C" int tp_background_stamp(tp_ctx* ctx, const tp_cube_desc* desc, const 
 	a.t_pitch = desc->t_pitch; a.out_pitch = bkg_pitch;
 	a.flux_cutoff = (float)flux_cutoff; a.exclude_fraction = (float)(exclude_percentile / 100.0);
 	if (a.n_pix <= 256) {
-		// staged frame: the ranks that can hold a value, 16-byte aligned rows, +4 floats so that consecutive frames
-		// start 4 banks apart
-		const int frame_stride = ((a.n_pix + 3) & ~3) + 4;
+		// staged frame: rank_idx of the last 16-byte store + 1
+		const int last = (a.n_pix - 1) | 3;
+		const int frame_stride = ((last + ((last >> 5) << 2) + 1) + 3) & ~3;
 		const size_t shmem = (size_t)kFramesPerBlock * frame_stride * sizeof(float);
+		TP_REQUIRE(ctx, (int64_t)a.n_pix * a.t_pitch * 4 < 2147483647ll, "tp_background_stamp: stamp cube too large");
 		dim3 block(kBkgThreads), grid((unsigned)desc->n_targets, (unsigned)((desc->n_cad + kFramesPerBlock - 1) / kFramesPerBlock));
 		TP_LAUNCH(ctx, TPK_BKG_STAMP, tp_bkg_stamp_kernel, grid, block, shmem, a, frame_stride);
 	} else {

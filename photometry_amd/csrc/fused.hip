@@ -18,16 +18,16 @@
 #include "sumimage_dev.h"
 #include "aperture_dev.h"
 #include "k2p2_args.h"
-#include <cstdlib>
 
 namespace {
 
 constexpr int kRows = 8; // pixel rows per A1 step: 8 x 1 KiB loads in flight per lane
 
-template <int VEC, bool VEC4, bool HAS_SUB, bool BKG_CUBE>
+// BKG: 0 = background cube, 1 = one background series per target, 2 = no background (aperture-only)
+template <int VEC, bool VEC4, bool HAS_SUB, int BKG>
 __global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a, k2p2::BatchArgs ka, k2p2::Params prm,
 	const double* __restrict__ twid, const int32_t* __restrict__ quality, int64_t quality_stride, uint32_t bitmask,
-	double* __restrict__ sumimage_out, int dbg)
+	double* __restrict__ sumimage_out)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
 	const int target = blockIdx.x;
@@ -38,7 +38,6 @@ __global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a,
 
 	// ---------------- A1: sum image into LDS (k.S) and HBM ----------------
 	unsigned char* good = reinterpret_cast<unsigned char*>(k.srt);
-	if (!(dbg & 1)) {
 	tp_sum::stage_good(good, quality + (int64_t)target * quality_stride, bitmask, a.n_cad, lane, 64);
 	__syncthreads();
 	{
@@ -128,17 +127,13 @@ __global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a,
 			}
 		}
 	}
-	} else { for (int p = lane; p < P; p += 64) k.S[p] = sumimage_out[(int64_t)target * P + p]; }
 	__syncthreads();
 
 	// ---------------- A2..A5b, A7: the mask, from the LDS-resident sum image ----------------
 	k2p2::Target t;
 	k2p2::make_target(ka, target, t);
 	t.S = k.S;
-	int status = 1;
-	if (!(dbg & 2)) status = k2p2::run_target(k, prm, t);
-	else { for (int p = lane; p < P; p += 64) k.res[p] = ka.mask[(int64_t)target * P + p]; status = ka.status[target]; __syncthreads(); }
-	if (dbg & 4) return;
+	const int status = k2p2::run_target(k, prm, t);
 	if (status == TP_STATUS_ERROR) return; // photometry.py: the plugin stops, nothing is extracted
 
 	// ---------------- A6: extraction over the mask pixels (k.res), all cadences ----------------
@@ -150,7 +145,7 @@ __global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a,
 		if (lane == 0 && a.big_list) a.big_list[1 + atomicAdd(&a.big_list[0], 1)] = target;
 		return;
 	}
-	tp_ap::extract_small_stream<VEC, HAS_SUB, BKG_CUBE>(a, target, s_list, M, lane, 64);
+	tp_ap::extract_small_stream<VEC, HAS_SUB, BKG>(a, target, s_list, M, lane, 64);
 }
 
 } // namespace
@@ -170,13 +165,15 @@ extern "C" int tp_aperture_photometry(tp_ctx* ctx, const tp_cube_desc* desc,
 	TP_CHECK_CTX(ctx);
 	TP_API_BEGIN
 	TP_REQUIRE(ctx, tp_desc_ok(desc), "tp_aperture_photometry: bad cube descriptor");
-	TP_REQUIRE(ctx, d_images && d_images_err && d_backgrounds && d_quality && d_stamps && d_aperture && d_cat_offsets
+	TP_REQUIRE(ctx, d_images && d_images_err && d_quality && d_stamps && d_aperture && d_cat_offsets
 		&& d_target_pos_row && d_target_pos_column && d_target_tmag && d_target_starid, "tp_aperture_photometry: null input pointer");
 	TP_REQUIRE(ctx, d_sumimage && d_mask && d_status && d_flags && d_contamination, "tp_aperture_photometry: null output pointer");
-	TP_REQUIRE(ctx, d_flux && d_flux_err && d_flux_background && d_centroid_col && d_centroid_row, "tp_aperture_photometry: null output pointer");
+	TP_REQUIRE(ctx, d_flux && d_flux_err && d_centroid_col && d_centroid_row, "tp_aperture_photometry: null output pointer");
+	TP_REQUIRE(ctx, d_flux_background || !d_backgrounds, "tp_aperture_photometry: backgrounds given but no flux_background output");
 	TP_REQUIRE(ctx, out_pitch >= desc->n_cad, "tp_aperture_photometry: out_pitch < n_cad");
 	TP_REQUIRE(ctx, bkg_mode == 0 || bkg_mode == 1, "tp_aperture_photometry: bkg_mode must be 0 (cube) or 1 (series)");
-	TP_REQUIRE(ctx, bkg_mode == 0 || bkg_series_pitch >= desc->n_cad, "tp_aperture_photometry: bad bkg_series_pitch");
+	if (!d_backgrounds) bkg_mode = 2; // aperture-only (BASELINE configs[1]): no background input, flux_background (if given) = NaN
+	TP_REQUIRE(ctx, bkg_mode != 1 || bkg_series_pitch >= desc->n_cad, "tp_aperture_photometry: bad bkg_series_pitch");
 	TP_REQUIRE(ctx, quality_target_stride == 0 || quality_target_stride >= desc->n_cad, "tp_aperture_photometry: bad quality stride");
 	TP_REQUIRE(ctx, d_subtract == nullptr || subtract_pitch >= desc->n_cad, "tp_aperture_photometry: bad subtract pitch");
 	if (desc->n_targets == 0) return TP_OK;
@@ -232,29 +229,23 @@ extern "C" int tp_aperture_photometry(tp_ctx* ctx, const tp_cube_desc* desc,
 
 	bool vec4 = tp_vec4_ok(d_images, desc->t_pitch) && tp_vec4_ok(d_images_err, desc->t_pitch);
 	if (bkg_mode == 0) vec4 = vec4 && tp_vec4_ok(d_backgrounds, desc->t_pitch);
-	else vec4 = vec4 && tp_vec4_ok(d_backgrounds, bkg_series_pitch);
+	else if (bkg_mode == 1) vec4 = vec4 && tp_vec4_ok(d_backgrounds, bkg_series_pitch);
 	if (d_subtract) vec4 = vec4 && tp_vec4_ok(d_subtract, subtract_pitch);
 
-	// diagnostics only: TP_FUSED_DBG bit 0 / 1 / 2 switches the A1 / K2P2 / A6 phase off (the skipped phase's result is
-	// taken from d_sumimage / d_mask, d_status as left by a previous call) to time the phases separately (tools/fused_phases.py)
-	int dbg = 0;
-	if (const char* e = getenv("TP_FUSED_DBG")) dbg = atoi(e);
 	const dim3 grid((unsigned)desc->n_targets), block(64);
-#define TP_FUSED_LAUNCH(V, V4, HS, BC) do { \
-		auto kern = tp_aperture_fused_kernel<V, V4, HS, BC>; \
+#define TP_FUSED_LAUNCH(V, V4, HS, BK) do { \
+		auto kern = tp_aperture_fused_kernel<V, V4, HS, BK>; \
 		if (shmem > 64 * 1024) TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-		TP_LAUNCH(ctx, TPK_FUSED, kern, grid, block, shmem, a, ka, prm, (const double*)ctx->twiddle, d_quality, quality_target_stride, bitmask, d_sumimage, dbg); \
+		TP_LAUNCH(ctx, TPK_FUSED, kern, grid, block, shmem, a, ka, prm, (const double*)ctx->twiddle, d_quality, quality_target_stride, bitmask, d_sumimage); \
 	} while (0)
-	// the two configurations of the pipeline: resident (images, errors, background) cubes, or raw cubes with the
-	// stamp-constant background series subtracted on the fly (B3) and reported as the background (bkg_mode 1)
-	const bool cube = (bkg_mode == 0);
-	if (vec4) {
-		if (d_subtract) { if (cube) TP_FUSED_LAUNCH(2, true, true, true); else TP_FUSED_LAUNCH(2, true, true, false); }
-		else { if (cube) TP_FUSED_LAUNCH(2, true, false, true); else TP_FUSED_LAUNCH(2, true, false, false); }
-	} else {
-		if (d_subtract) { if (cube) TP_FUSED_LAUNCH(1, false, true, true); else TP_FUSED_LAUNCH(1, false, true, false); }
-		else { if (cube) TP_FUSED_LAUNCH(1, false, false, true); else TP_FUSED_LAUNCH(1, false, false, false); }
-	}
+#define TP_FUSED_BKG(V, V4, HS) do { \
+		if (bkg_mode == 0) TP_FUSED_LAUNCH(V, V4, HS, 0); else if (bkg_mode == 1) TP_FUSED_LAUNCH(V, V4, HS, 1); else TP_FUSED_LAUNCH(V, V4, HS, 2); \
+	} while (0)
+	// the configurations of the pipeline: resident (images, errors, background) cubes; raw cubes with the stamp-constant
+	// background series subtracted on the fly (B3) and reported as the background (bkg_mode 1); aperture-only (no background)
+	if (vec4) { if (d_subtract) TP_FUSED_BKG(2, true, true); else TP_FUSED_BKG(2, true, false); }
+	else { if (d_subtract) TP_FUSED_BKG(1, false, true); else TP_FUSED_BKG(1, false, false); }
+#undef TP_FUSED_BKG
 #undef TP_FUSED_LAUNCH
 	TP_LAUNCH_CHECK(ctx, "tp_aperture_fused_kernel");
 	// masks above 128 pixels: the recursive pairwise tree kernel picks them from the mask / status in HBM

@@ -66,24 +66,31 @@ class LightCurves(object):
 		return lc
 
 
+def _background_mode(images, backgrounds):
+	"""(bkg_mode, series pitch) of a background argument: a cube, one series per target, or None (aperture-only)."""
+	if backgrounds is None:
+		return 0, 0
+	if isinstance(backgrounds, DeviceCube):
+		assert backgrounds.t_pitch == images.t_pitch and backgrounds.data.shape == images.data.shape
+		return 0, 0
+	assert backgrounds.dtype == np.float32 and backgrounds.shape[0] == images.n_targets
+	return 1, backgrounds.shape[1]
+
+
 def aperture_extract(ctx, images, images_err, backgrounds, mask, stamps, status=None, out=None, subtract=None):
 	"""
 	A6 (photometry.py:172-201).  ``backgrounds``: DeviceCube, or a float32 DeviceArray ``(Nt, pitch)``
-	holding one background series per target (stamp-constant background).
+	holding one background series per target (stamp-constant background), or None (aperture-only:
+	``flux_background`` comes out NaN).
 	``mask``: uint8 DeviceArray ``(Nt, H, W)``; ``stamps``: int32 ``(Nt, 4)``.
 	"""
 	if out is None:
 		out = LightCurves(ctx, images.n_targets, images.n_cad)
 	desc = images.desc
 	assert images_err.t_pitch == images.t_pitch and images_err.data.shape == images.data.shape
-	if isinstance(backgrounds, DeviceCube):
-		assert backgrounds.t_pitch == images.t_pitch and backgrounds.data.shape == images.data.shape
-		bkg_mode, bpitch = 0, 0
-	else:
-		assert backgrounds.dtype == np.float32 and backgrounds.shape[0] == images.n_targets
-		bkg_mode, bpitch = 1, backgrounds.shape[1]
+	bkg_mode, bpitch = _background_mode(images, backgrounds)
 	assert mask.dtype == np.uint8 and stamps.dtype == np.int32
-	ctx._check(ctx.lib.tp_aperture_extract(ctx.handle, ctypes.byref(desc), images.ptr, images_err.ptr, backgrounds.ptr,
+	ctx._check(ctx.lib.tp_aperture_extract(ctx.handle, ctypes.byref(desc), images.ptr, images_err.ptr, _ptr(backgrounds),
 		bkg_mode, bpitch, _ptr(subtract), 0 if subtract is None else subtract.shape[1], mask.ptr, stamps.ptr, _ptr(status), out.ptrs[0], out.ptrs[1], out.ptrs[2], out.ptrs[3], out.ptrs[4],
 		out.n_cad))
 	return out
@@ -169,12 +176,7 @@ def aperture_photometry(ctx, batch, work, bitmask=TESS_DEFAULT_BITMASK, subtract
 	backgrounds = batch.backgrounds if backgrounds is None else backgrounds
 	desc = images.desc
 	assert images_err.t_pitch == images.t_pitch and images_err.data.shape == images.data.shape
-	if isinstance(backgrounds, DeviceCube):
-		assert backgrounds.t_pitch == images.t_pitch and backgrounds.data.shape == images.data.shape
-		bkg_mode, bpitch = 0, 0
-	else:
-		assert backgrounds.dtype == np.float32 and backgrounds.shape[0] == images.n_targets
-		bkg_mode, bpitch = 1, backgrounds.shape[1]
+	bkg_mode, bpitch = _background_mode(images, backgrounds)
 	quality = batch.quality
 	if len(quality.shape) == 1:
 		assert quality.shape[0] >= images.n_cad
@@ -183,7 +185,7 @@ def aperture_photometry(ctx, batch, work, bitmask=TESS_DEFAULT_BITMASK, subtract
 		assert quality.shape[0] == images.n_targets and quality.shape[1] >= images.n_cad
 		qstride = quality.shape[1]
 	lc = work.lc
-	ctx._check(ctx.lib.tp_aperture_photometry(ctx.handle, ctypes.byref(desc), images.ptr, images_err.ptr, backgrounds.ptr, bkg_mode, bpitch,
+	ctx._check(ctx.lib.tp_aperture_photometry(ctx.handle, ctypes.byref(desc), images.ptr, images_err.ptr, _ptr(backgrounds), bkg_mode, bpitch,
 		_ptr(subtract), 0 if subtract is None else subtract.shape[1],
 		quality.ptr, qstride, int(bitmask),
 		batch.cat_offsets.ptr, batch.cat_column_stamp.ptr, batch.cat_row_stamp.ptr, batch.cat_tmag.ptr,

@@ -25,6 +25,11 @@ class ApertureBatch(object):
 			self.images = DeviceCube.from_host(ctx, scene.images)
 			self.images_err = DeviceCube.from_host(ctx, scene.images_err)
 			self.backgrounds = DeviceCube.from_host(ctx, scene.backgrounds)
+		elif isinstance(cubes, str) and cubes == 'host_aperture_only':
+			# BASELINE configs[1]: images + errors, no background cube (flux_background comes out NaN)
+			self.images = DeviceCube.from_host(ctx, scene.images)
+			self.images_err = DeviceCube.from_host(ctx, scene.images_err)
+			self.backgrounds = None
 		elif isinstance(cubes, str) and cubes == 'host_raw':
 			self.images = DeviceCube.from_host(ctx, scene.raw)
 			self.images_err = DeviceCube.from_host(ctx, scene.raw_err)

@@ -47,7 +47,8 @@ def test_k2p2_matches_oracle(ctx, kind, seed):
 	ref = oracle_batch(s, S)
 	stats = compare(s, S, got, ref)
 	print(kind, stats)
-	assert stats['n_exact'] >= s.n_targets // 2 and stats['n_razor'] <= 1
+	# the razor-edge escape of k2p2_common.compare is for new seeds only: on the committed seeds no target may use it
+	assert stats['n_exact'] >= s.n_targets // 2 and stats['n_razor'] == 0
 
 
 def test_k2p2_given_oracle_cut(ctx):
