@@ -26,8 +26,18 @@
 //      goes.  The 3-sigma test is evaluated without division or square root: x is clipped iff
 //      ((x - med) m)^2 > 9 (m s2 - s1^2), with s1, s2 the float64 sums of the m kept values.
 // A wavefront stages and reads only its own 8 frames and its LDS operations execute in order: no workgroup barrier.
+// Measured on the C3 cube (10 000 x 1 300 x 15x15, 13 M frames, 11.75 GB): 5.4 ms = 2.2 TB/s.  The kernel is bound by the
+// vector ALUs, not by HBM: ~2 500 vector instructions per wavefront of 8 frames, 1 340 of them the sorting network
+// (counters: 1.64 M waves, 4.3 G VALU instructions, VALU busy 57 % of the two-waves-per-SIMD issue peak, 15 of 20
+// possible waves per CU resident).  Phases timed by cutting the kernel short: loads + mask + sums 2.1 ms (HBM rate
+// 5.6 TB/s), + sort 2.3 ms, + clipping 1.8 ms.  Tried and dropped: staging the loads through a coalescing LDS tile
+// (16-byte loads, two barriers: 6.2 ms against 5.9 -- the load phase alone got faster, 2.1 against 2.9 ms, the kernel
+// did not, it is not waiting for memory); prefetching the next 32-cadence block into 32 more registers while sorting
+// (5.8 -> 6.2 ms at 4 or 5 waves per SIMD: nothing left to hide); a bitonic instead of Batcher's network for the
+// per-lane sort (5.9 ms); cross-lane exchanges in groups of 4 / 8 independent DPP moves (no change).
 #include "common.h"
 #include <cmath>
+#include <utility>
 
 namespace {
 
@@ -58,17 +68,31 @@ template <int N, int SIZE>
 struct BitonicStage<N, SIZE, 0> {
 	static __device__ __forceinline__ void run(float (&)[N]) {}
 };
-template <int N, int SIZE>
-struct BitonicLevel {
-	static __device__ __forceinline__ void run(float (&v)[N]) {
-		BitonicLevel<N, SIZE / 2>::run(v);
-		BitonicStage<N, SIZE, SIZE / 2>::run(v);
-	}
-};
-template <int N>
-struct BitonicLevel<N, 1> {
-	static __device__ __forceinline__ void run(float (&)[N]) {}
-};
+
+// Batcher's odd-even merge sort of 32 values as a compile-time list of compare-exchanges (Knuth 5.2.2 algorithm M)
+struct Oem32 { unsigned char a[256], b[256]; int n; };
+constexpr Oem32 make_oem32() {
+	Oem32 r{};
+	const int n = 32;
+	int c = 0;
+	for (int p = 1; p < n; p *= 2)
+		for (int k = p; k >= 1; k /= 2)
+			for (int j = k % p; j <= n - 1 - k; j += 2 * k)
+				for (int i = 0; i <= ((k - 1 < n - j - k - 1) ? (k - 1) : (n - j - k - 1)); ++i)
+					if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) { r.a[c] = (unsigned char)(i + j); r.b[c] = (unsigned char)(i + j + k); ++c; }
+	r.n = c;
+	return r;
+}
+constexpr Oem32 kOem32 = make_oem32();
+static_assert(kOem32.n == 191, "Batcher network of 32 keys");
+template <size_t I>
+__device__ __forceinline__ void oem_exchange(float (&v)[32]) {
+	const float x = v[kOem32.a[I]], y = v[kOem32.b[I]];
+	v[kOem32.a[I]] = tp_min(x, y);
+	v[kOem32.b[I]] = tp_max(x, y);
+}
+template <size_t... I>
+__device__ __forceinline__ void oem_sort32(float (&v)[32], std::index_sequence<I...>) { (oem_exchange<I>(v), ...); }
 
 struct BkgArgs {
 	const float* raw; float* out; int n_cad; int n_pix; int64_t t_pitch; int64_t out_pitch;
@@ -128,6 +152,9 @@ __device__ __forceinline__ void local_merge(float (&v)[kValsPerLane]) { BitonicS
 // 16-byte stores of a staging instruction fall into different banks
 __device__ __forceinline__ int rank_idx(int r) { return r + ((r >> 5) << 2); }
 
+// JFULL: number of complete 8-pixel rows (n_pix / 8) when known at compile time (the pixel-count test is then only made
+// for the last rows), -1 = test every slot.
+template <int JFULL>
 __global__ __launch_bounds__(kBkgThreads) void tp_bkg_stamp_kernel(BkgArgs a, int frame_stride)
 {
 	extern __shared__ __align__(16) float s_sorted[]; // [kFramesPerBlock][frame_stride]
@@ -155,7 +182,8 @@ __global__ __launch_bounds__(kBkgThreads) void tp_bkg_stamp_kernel(BkgArgs a, in
 	for (int j = 0; j < kValsPerLane; ++j) {
 		const float x = v[j];
 		// backgrounds.py:91-94: mask = ~isfinite | > flux_cutoff | < 0; slots past the last pixel are masked too
-		const bool ok = (x >= 0.f) && (x <= a.flux_cutoff) && (j * kLanesPerFrame + g < a.n_pix);
+		bool ok = (x >= 0.f) && (x <= a.flux_cutoff);
+		if (JFULL < 0 || j >= JFULL) ok = ok && (j * kLanesPerFrame + g < a.n_pix);
 		n += ok ? 1 : 0;
 		v[j] = ok ? x : inf;
 		float z = ok ? x : 0.f;
@@ -170,8 +198,7 @@ __global__ __launch_bounds__(kBkgThreads) void tp_bkg_stamp_kernel(BkgArgs a, in
 
 	// --- distributed bitonic sort of the 256 values of the frame: rank = 32 g + j
 	const float sel1 = (g & 1) ? inf : -inf, sel2 = (g & 2) ? inf : -inf, sel4 = (g & 4) ? inf : -inf;
-	BitonicLevel<kValsPerLane, kValsPerLane / 2>::run(v);      // sizes 2..16: directions fixed by the local index
-	local_merge(v);                                              // size 32: every lane ascending
+	oem_sort32(v, std::make_index_sequence<kOem32.n>());      // every lane ascending (Batcher: 191 instead of 240 exchanges)
 	cross_stage<kDppXor1, true>(v, sel1);                        // size 64: mirror against lane^1,
 	local_merge(v);                                              //          then ascending merges
 	cross_stage<kDppQuadRev, true>(v, sel2);                     // size 128: mirror against lane^3,
@@ -392,7 +419,10 @@ extern "C" int tp_background_stamp(tp_ctx* ctx, const tp_cube_desc* desc, const 
 		const size_t shmem = (size_t)kFramesPerBlock * frame_stride * sizeof(float);
 		TP_REQUIRE(ctx, (int64_t)a.n_pix * a.t_pitch * 4 < 2147483647ll, "tp_background_stamp: stamp cube too large");
 		dim3 block(kBkgThreads), grid((unsigned)desc->n_targets, (unsigned)((desc->n_cad + kFramesPerBlock - 1) / kFramesPerBlock));
-		TP_LAUNCH(ctx, TPK_BKG_STAMP, tp_bkg_stamp_kernel, grid, block, shmem, a, frame_stride);
+		const int jfull = a.n_pix / kLanesPerFrame;
+		if (jfull == 28) TP_LAUNCH(ctx, TPK_BKG_STAMP, tp_bkg_stamp_kernel<28>, grid, block, shmem, a, frame_stride);        // 15 x 15
+		else if (jfull == 15) TP_LAUNCH(ctx, TPK_BKG_STAMP, tp_bkg_stamp_kernel<15>, grid, block, shmem, a, frame_stride);   // 11 x 11
+		else TP_LAUNCH(ctx, TPK_BKG_STAMP, tp_bkg_stamp_kernel<-1>, grid, block, shmem, a, frame_stride);
 	} else {
 		int np2 = 1;
 		while (np2 < a.n_pix) np2 <<= 1;
