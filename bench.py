@@ -5,21 +5,36 @@ bench.py -- whole-job throughput of the per-target photometry hot path on MI355X
 
     python bench.py --gpus N --steps K --warmup W
 
-A *step* is one pass of the hot path over one batch of synthetic stamp cubes that is already
-resident in HBM: A1 sum image -> A2..A5b K2P2 masks (+A7) -> A6 aperture extraction
-(AperturePhotometry.do_photometry for every target).  Workload (BASELINE.json configs[2], the one
-the metric is quoted on): 10 000 targets x 1 300 cadences x 15x15 stamps per GPU, aperture +
-background cubes.  For N > 1 the driver launches one rank per GPU through torch.distributed.run;
-targets are sharded by index (weak scaling: 10 000 targets per GPU), the only data-path exchange
-is ONE RCCL gather of the light-curve block at the end of the timed region.
+A *step* is one pass of the hot path over one batch of synthetic stamp cubes already resident in HBM, for BASELINE.json
+configs[2] ("aperture + background", the configuration the metric is quoted on): 10 000 targets x 1 300 cadences x 15x15
+per GPU.  The resident inputs are the RAW flux cube and its error cube; one step =
 
-Prints ONE JSON line on rank 0 (see the bench contract in the task description) with the
-``roofline`` and ``cpu_baseline`` objects.
+    B*  per-cadence stamp background (sigma-clipped SExtractor mode)      tp_background_stamp
+    B2  time smoothing of the background series (prepare.py:317-335)      tp_smooth_time
+    A1 + A2..A5b + A7 + A6: AperturePhotometry.do_photometry for every target, with the background subtracted on the fly
+        (B3, prepare.py:419-420) and summed in the aperture                tp_aperture_photometry
+
+N > 1: one process per GPU.  Started as the driver starts it (torch.distributed.run: RANK / WORLD_SIZE in the environment)
+or plainly as `python bench.py --gpus N`, in which case this process spawns its N ranks itself before touching the GPU.
+Targets are sharded by index (weak scaling: 10 000 targets per GPU); the only data-path exchange is the gather of each
+step's output block (light curves + contamination + status + flags + mask, one message per rank) to rank 0 over RCCL,
+issued EVERY step on a second stream from the other half of a double-buffered output block, so that it overlaps the next
+step's compute; its duration is reported separately.
+
+Rank 0 prints ONE JSON line.  Besides the contract's fields it carries `roofline` (dominant kernel of the timed step),
+`rooflines` (every HBM-bound kernel of the step, necessary bytes / time / 8 TB/s -- a fraction above 1 is impossible by
+construction), `cpu_baseline`, and at N = 1 the extra legs `aperture_premade_cubes` (the per-target stage alone, SURVEY 8d's
+reading), `linpsf` (BASELINE configs[3]) and `end_to_end` (cubes start in pinned host memory: H2D overlapped with compute).
 """
+
+import os
+for _v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS', 'NUMEXPR_NUM_THREADS'):
+	os.environ.setdefault(_v, '1') # the CPU baseline runs one process per core: no BLAS / OpenMP oversubscription
 
 import argparse
 import json
-import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,10 +42,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
 	sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0 # MI355X HBM3E peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak (MI355X_MICROARCH.md)
+FP64_VALU_TFLOPS = 78.6  # MI355X FP64 vector peak
+XGMI_LINK_GBS = 153.0
 
 
-def parse_args():
+def parse_args(argv=None):
 	p = argparse.ArgumentParser()
 	p.add_argument('--gpus', type=int, default=1)
 	p.add_argument('--steps', type=int, default=10)
@@ -38,437 +55,648 @@ def parse_args():
 	p.add_argument('--targets', type=int, default=10000, help='targets per GPU')
 	p.add_argument('--cadences', type=int, default=1300)
 	p.add_argument('--stamp', type=int, default=15)
-	p.add_argument('--cpu-sample', type=int, default=384, help='targets in the CPU-baseline sample (0 = skip)')
-	p.add_argument('--cpu-procs', type=int, default=16, help='worker processes of the CPU baseline')
+	p.add_argument('--cpu-sample', type=int, default=4, help='targets per worker process of the CPU baseline (0 = skip)')
+	p.add_argument('--cpu-procs', type=int, default=0, help='worker processes of the all-core CPU baseline (0 = physical cores)')
 	p.add_argument('--seed', type=int, default=1)
 	p.add_argument('--no-gather', action='store_true')
-	p.add_argument('--workload', choices=['aperture', 'linpsf'], default='aperture',
-		help="'aperture' = BASELINE configs[2] (the headline); 'linpsf' = configs[3], the LinPSF fit on the same cube size")
-	p.add_argument('--frame', type=int, default=1024, help='side of the synthetic full-frame stack of the stamp-cutter stage (0 = skip)')
-	p.add_argument('--unfused', action='store_true', help='time the three stand-alone kernels (A1, K2P2, A6) back to back '
-		'instead of the fused per-target kernel')
-	return p.parse_args()
+	p.add_argument('--no-extra', action='store_true', help='skip the extra legs (premade cubes, LinPSF, end to end, stages)')
+	p.add_argument('--e2e-targets', type=int, default=2048, help='targets of the end-to-end (H2D included) leg (0 = skip)')
+	p.add_argument('--frame', type=int, default=1024, help='side of the frame stack of the stamp-cutter stage (0 = skip)')
+	return p.parse_args(argv)
+
+
+# --------------------------------------------------------------------------------------------------
+# rank spawning (python bench.py --gpus N without a launcher)
+# --------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+	"""Start one fresh child process per rank BEFORE anything in this process touches the GPU; relay rank 0's line."""
+	with socket.socket() as s:
+		s.bind(('127.0.0.1', 0))
+		port = s.getsockname()[1]
+	procs = []
+	for r in range(args.gpus):
+		env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+			MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+		procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+			stdout=None if r == 0 else subprocess.DEVNULL))
+	rc = 0
+	for p in procs:
+		rc = max(rc, abs(p.wait()))
+	return rc
+
+
+# --------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (reference-equivalent numpy restatement, per-cadence Python loops like the reference)
+# --------------------------------------------------------------------------------------------------
+_CPU_JOBS = None
 
 
 def _cpu_worker(job):
 	"""
-	Oracle (reference-equivalent numpy restatement, per-cadence Python loops like the reference) of one
-	step on a list of targets: A1 sum image, K2P2 masks, A6 extraction, A7.  Returns (seconds, results).
+	One step on a list of targets, as the reference would run it per target: B* per-cadence stamp background (oracle of the
+	build-defined estimator), B2 smoothing, B3 subtraction, A1 sum image, K2P2 masks, A6 extraction, A7.
+	The downstream stages use the DEVICE's background series so that their results can be compared bit for bit; the
+	oracle's own background is compared with it at 1e-6 and its time is counted.  Returns (seconds, results).
 	"""
 	import numpy as np
-	from oracle import sumimage as osum, aperture as oap
-	sub = job
+	try:
+		from threadpoolctl import threadpool_limits
+		threadpool_limits(1)
+	except Exception: # noqa: B902
+		pass
+	from oracle import sumimage as osum, aperture as oap, backgrounds as ob
 	t0 = time.perf_counter()
 	out = []
-	for i in range(sub.n_targets):
-		S = osum.sumimage(sub.images[i], sub.quality)
-		r = oap.do_photometry(S, sub.images[i], sub.images_err[i], sub.backgrounds[i], tuple(sub.stamps[i]),
-			sub.target_pos_row[i], sub.target_pos_column[i], sub.target_tmag[i], sub.target_starid[i],
-			sub.catalog_of(i), sub.aperture[i])
-		out.append({k: r.get(k) for k in ('status', 'flux', 'flux_err', 'flux_background', 'pos_centroid', 'mask', 'contamination')})
+	for i in range(job.n_targets):
+		raw = job.raw[i]
+		bkg_raw = ob.background_series(raw)                                   # B*
+		bkg = ob.smooth_time(job.dev_bkg_raw[i], job.time_smooth)              # B2 (on the device's series: bit-exact check)
+		ob.smooth_time(bkg_raw, job.time_smooth)                               # B2 of the oracle's own series (timed)
+		series = job.dev_bkg[i][None, None, :]
+		img, err = ob.subtract_background(raw, job.raw_err[i], series)         # B3
+		S = osum.sumimage(img, job.quality)                                    # A1
+		bcube = np.broadcast_to(series.astype('float32'), img.shape)
+		try:
+			r = oap.do_photometry(S, img, err, bcube, tuple(job.stamps[i]), job.target_pos_row[i], job.target_pos_column[i],
+				job.target_tmag[i], job.target_starid[i], job.catalog_of(i), job.aperture[i])
+		except Exception: # noqa: B902 -- tessphot.py:37-49: any exception is STATUS.ERROR
+			r = {'status': 2}
+		d = {k: r.get(k) for k in ('status', 'flux', 'flux_err', 'flux_background', 'mask')}
+		with np.errstate(invalid='ignore', divide='ignore'):
+			both = np.isfinite(bkg_raw) & np.isfinite(job.dev_bkg_raw[i])
+			d['bkg_nan_equal'] = bool(np.array_equal(np.isnan(bkg_raw), np.isnan(job.dev_bkg_raw[i])))
+			d['bkg_max_rel'] = float(np.max(np.abs(bkg_raw[both] / job.dev_bkg_raw[i][both] - 1))) if both.any() else 0.0
+		d['smooth_equal'] = bool(np.array_equal(bkg, job.dev_bkg[i], equal_nan=True))
+		out.append(d)
 	return time.perf_counter() - t0, out
-
-
-_CPU_JOBS = None
-
-
-def main_linpsf(args, ctx, rank, world, dist, torch, device_sync, barrier):
-	"""BASELINE configs[3]: linpsf_photometry PSF-fit path over the same cube size (images cube resident)."""
-	import numpy as np
-	from photometry_amd import simulate, engine, pipeline, psf as hpsf
-	Nt, T, H = args.targets, args.cadences, args.stamp
-	W = H
-	scene = simulate.make_scene(Nt, T, H, W, seed=args.seed * 1000 + rank)
-	cubes = engine.synth_fill(ctx, scene, images=True, images_err=False, backgrounds=False)
-	prf = simulate.synthetic_prf(seed=1) # synthetic stand-in for the SPOC PRF file (git-LFS object upstream)
-	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
-	batch = pipeline.LinPSFBatch(ctx, scene, model, images=cubes['images'])
-	for _ in range(args.warmup):
-		pipeline.linpsf_step(ctx, batch)
-	device_sync(); barrier()
-	ctx.profile(True); ctx.profile_reset()
-	t0 = time.perf_counter()
-	for _ in range(args.steps):
-		pipeline.linpsf_step(ctx, batch)
-	device_sync(); barrier()
-	elapsed = time.perf_counter() - t0
-	ctx.profile(False)
-	if dist is not None:
-		t = torch.tensor([elapsed], dtype=torch.float64)
-		dist.all_reduce(t, op=dist.ReduceOp.MAX)
-		elapsed = float(t[0])
-	prof = ctx.profile_report()
-	if rank == 0:
-		nfit = batch.n_fit_stars
-		# ALGORITHMIC FP64 flops of the fit (the reference's direct contraction): per fitted star-cadence ~79 pixels inside
-		# the 5 px cut-off x (169 + 13) multiply-adds.  The kernel's polynomial path executes about 8x fewer.
-		flops = nfit * T * 79 * 182 * 2.0
-		kernels = {name: {'launches': n, 'avg_ms': ms / n, 'ms_per_step': ms / args.steps} for name, (n, ms) in prof.items()}
-		fit = kernels['tp_linpsf_fit_kernel']  # one launch per star-count class: the step's fit time is their sum
-		fit['fp64_TFLOPs'] = flops / (fit['ms_per_step'] * 1e-3) / 1e12
-		result = {
-			'metric': 'targets/sec (whole node), 10k targets x 1300 cad x 15x15, linpsf_photometry PSF fit',
-			'value': Nt * world * args.steps / elapsed, 'unit': 'targets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-			'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-			'dtype': 'f64', 'data': 'synthetic',
-			'config': {'workload': f'{Nt} targets/GPU x {T} cadences x {H}x{W} stamps, LinPSF fit of {nfit} stars (P1 table blend + P2-P4), '
-				'image cube resident in HBM', 'fitted_stars': int(nfit)},
-			'roofline': {'kernel': 'tp_linpsf_fit_kernel', 'bound': 'fp64-valu', 'achieved': fit['fp64_TFLOPs'], 'peak': 78.6, 'unit': 'TFLOP/s',
-				'frac': fit['fp64_TFLOPs'] / 78.6, 'traffic': None, 'kernel_ms_per_step': fit['ms_per_step'],
-				'note': 'achieved = algorithmic flops of the direct 13x13 contraction / time; the polynomial fast path does ~8x fewer'},
-			'kernels': kernels,
-		}
-		if world == 1 and args.cpu_sample > 0:
-			# CPU baseline: the oracle loop (reference-equivalent, scipy FITPACK integral per pixel) on a few targets
-			from oracle import linpsf as olin, psf as opsf
-			ns = min(Nt, max(1, args.cpu_sample // 96)) # 4 targets at the default --cpu-sample 384
-			tsub = min(T, 100)
-			host = np.empty((ns, H, W, cubes['images'].t_pitch), dtype='float32')
-			ctx._check(ctx.lib.tp_memcpy_d2h(ctx.handle, host.ctypes.data, cubes['images'].ptr, host.nbytes))
-			res = batch.out.to_host()
-			t1 = time.perf_counter()
-			bad = 0
-			for i in range(ns):
-				cat = scene.catalog_of(i)
-				positions = np.empty((tsub, len(cat['starid']), 2))
-				positions[:, :, 0] = cat['row_stamp'][None, :] + scene.jitter[:tsub, 1][:, None]
-				positions[:, :, 1] = cat['column_stamp'][None, :] + scene.jitter[:tsub, 0][:, None]
-				p = opsf.PSF(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'], tuple(scene.stamps[i]))
-				p.integrate_to_image = p.integrate_to_image_scipy # literal reference loop (psf.py:136-146)
-				ref = olin.do_photometry(host[i][:, :, :tsub], p, cat, scene.target_starid[i], positions, tuple(scene.stamps[i]),
-					scene.target_pos_row[i], scene.target_pos_column[i], np.ones((H, W), dtype='int32'))
-				bad += not np.allclose(res['flux'][i][:tsub], ref['flux'], rtol=1e-7, atol=1e-8*np.nanmax(np.abs(ref['flux'])))
-			dt = time.perf_counter() - t1
-			result['cpu_baseline'] = {'value': ns / (dt * T / tsub), 'unit': 'targets/s', 'cores': 1, 'kind': 'port',
-				'sample': f'{ns} targets x first {tsub} cadences, extrapolated linearly to {T} cadences; oracle = literal per-pixel FITPACK loop of the reference'}
-			result['parity_sample'] = {'targets': ns, 'cadences': tsub, 'mismatches': int(bad)}
-		print(json.dumps(result))
-	if dist is not None:
-		dist.barrier()
-		dist.destroy_process_group()
-	ctx.close()
 
 
 def _cpu_worker_indexed(c):
 	return _cpu_worker(_CPU_JOBS[c])
 
 
+def physical_cores():
+	avail = len(os.sched_getaffinity(0))
+	try:
+		import psutil
+		phys = psutil.cpu_count(logical=False) or avail
+	except Exception: # noqa: B902
+		phys = avail
+	return max(1, min(avail, phys)), avail
+
+
+def cpu_baseline(ctx, scene, cubes, work, args, T, H, W, time_smooth):
+	"""Oracle on a bounded sample of the same device-generated cubes: one core, 16 processes, all physical cores."""
+	import numpy as np
+	import multiprocessing as mp
+	global _CPU_JOBS
+	phys, avail = physical_cores()
+	nproc = args.cpu_procs if args.cpu_procs > 0 else phys
+	per = max(1, args.cpu_sample)
+	ns = min(scene.n_targets, nproc * per)
+	nproc = max(1, ns // per)
+	ns = nproc * per
+	sub = scene.subset(slice(0, ns))
+	for name, key in (('raw', 'raw'), ('raw_err', 'raw_err')):
+		cube = cubes[key]
+		host = np.empty((ns, H, W, cube.t_pitch), dtype='float32')
+		ctx._check(ctx.lib.tp_memcpy_d2h(ctx.handle, host.ctypes.data, cube.ptr, host.nbytes))
+		setattr(sub, name, np.ascontiguousarray(host[..., :T]))
+		del host
+	sub.dev_bkg_raw = work.bkg_raw.slice0(0, ns).to_host()[:, :T]
+	sub.dev_bkg = work.bkg.slice0(0, ns).to_host()[:, :T]
+	sub.time_smooth = time_smooth
+	sub.aperture = np.ones((ns, H, W), dtype='int32')
+
+	def part(s, sl):
+		p = s.subset(sl)
+		for k in ('dev_bkg_raw', 'dev_bkg'):
+			setattr(p, k, getattr(s, k)[sl])
+		p.time_smooth = s.time_smooth
+		return p
+
+	# (a) one process, one core: the analogue of one MPI worker of run_tessphot_mpi.py
+	n1 = min(ns, max(2, per))
+	t1, _ = _cpu_worker(part(sub, slice(0, n1)))
+	# (b) worker processes (forked: the sample is shared copy-on-write, nothing is pickled in); rate = targets / slowest
+	#     worker's compute time.  All physical cores, and 16 processes as the round-1 reference point.
+	rates = {}
+	rr_all = None
+	for n in sorted({min(16, nproc), nproc}):
+		_CPU_JOBS = [part(sub, slice(c, n * per, n)) for c in range(n)]
+		with mp.get_context('fork').Pool(n) as pool:
+			rr = pool.map(_cpu_worker_indexed, range(n))
+		rates[n] = n * per / max(r[0] for r in rr)
+		if n == nproc:
+			rr_all = rr
+	# parity of the sample while we are here
+	lc = work.lc.to_host()
+	masks = work.mask.to_host()
+	status = work.status.to_host()
+	bad = bad_bkg = 0
+	max_rel = 0.0
+	for c, (_, out) in enumerate(rr_all):
+		for j, r in enumerate(out):
+			i = c + j * nproc
+			ok = int(status[i]) == r['status']
+			if ok and r.get('mask') is not None:
+				ok = np.array_equal(masks[i].astype(bool), r['mask']) and np.array_equal(lc['flux'][i], r['flux'], equal_nan=True) \
+					and np.array_equal(lc['flux_err'][i], r['flux_err'], equal_nan=True) \
+					and np.array_equal(lc['flux_background'][i], r['flux_background'], equal_nan=True)
+			bad += (not ok)
+			bad_bkg += (not r['bkg_nan_equal']) or (r['bkg_max_rel'] > 1e-6) or (not r['smooth_equal'])
+			max_rel = max(max_rel, r['bkg_max_rel'])
+	best = max(rates.values())
+	return {
+		'value': best, 'unit': 'targets/s', 'cores': max(rates, key=rates.get), 'kind': 'port',
+		'sample': f'{ns} of the {scene.n_targets} targets of the same device-generated raw cubes ({per} per worker process); oracle = numpy '
+			'restatement of the reference per-cadence loops: stamp background (B*, B2, B3) + sum image + K2P2 + extraction; rate = '
+			'targets / slowest worker compute time; BLAS / OpenMP threads pinned to 1',
+		'rates_by_process_count': {str(k): v for k, v in rates.items()},
+		'single_core_targets_per_s': n1 / t1,
+		'host_cores': {'physical': phys, 'usable_logical': avail},
+	}, {'targets': ns, 'mismatches': int(bad), 'background_mismatches': int(bad_bkg), 'background_max_rel_err': max_rel,
+		'what': 'status / mask / flux / flux_err / flux_background bit-exact given the device background; B* within 1e-6 of the oracle, '
+			'B2 bit-exact'}
+
+
+# --------------------------------------------------------------------------------------------------
+def kernel_rows(report, n_launch_units, alg=None, necessary=None):
+	out = {}
+	for name, (n, ms) in report.items():
+		avg = ms / n
+		k = {'launches': n, 'avg_ms': avg}
+		if necessary and name in necessary:
+			k['necessary_bytes_per_launch'] = necessary[name]
+			k['necessary_GBps'] = necessary[name] / (avg * 1e-3) / 1e9
+			k['frac_of_hbm_peak'] = k['necessary_GBps'] / HBM_PEAK_GBS
+		if alg and name in alg:
+			k['survey_8d_bytes_per_launch'] = alg[name] * n_launch_units
+		out[name] = k
+	return out
+
+
+def roofline_of(name, rows, traffic, note=None):
+	k = rows[name]
+	r = {'kernel': name, 'bound': 'hbm', 'achieved': k['necessary_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+		'frac': k['necessary_GBps'] / HBM_PEAK_GBS, 'traffic': (traffic or {}).get(name),
+		'avg_kernel_ms': k['avg_ms'], 'bytes_per_launch': k['necessary_bytes_per_launch'],
+		'bytes': 'necessary bytes per launch (what the kernel cannot avoid reading / writing) = SURVEY 8d per-target figure x targets '
+			'per launch, with A6 charged only for the rows of in-mask pixels it needs'}
+	if 'survey_8d_bytes_per_launch' in k:
+		r['survey_8d_bytes_per_launch_all_rows'] = k['survey_8d_bytes_per_launch']
+	if note:
+		r['note'] = note
+	return r
+
+
 def main():
 	args = parse_args()
+	if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+		sys.exit(spawn_ranks(args))
 	rank = int(os.environ.get('RANK', '0'))
 	local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-	if os.environ.get('TP_BENCH_FORCE_DEVICE'): # smoke-testing the multi-rank control flow on a 1-GPU box (use with --no-gather)
-		local_rank = int(os.environ['TP_BENCH_FORCE_DEVICE'])
 	world = int(os.environ.get('WORLD_SIZE', '1'))
-	if world != args.gpus and world > 1:
-		args.gpus = world
+	args.gpus = world
 
-	# torch is plumbing only (rendezvous, barrier, device sync); import it BEFORE the HIP library
-	# so that a single HIP runtime is shared by both.
+	# torch is plumbing only (rendezvous, barrier, device sync); imported BEFORE the HIP library so that one HIP runtime is shared
 	dist = None
 	torch = None
-	try:
-		if os.environ.get('TP_BENCH_NO_TORCH') and world == 1:
-			raise ImportError
-		import torch
-		if world > 1:
-			import torch.distributed as dist
-			os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-			dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-	except ImportError:
-		torch = None
+	if world > 1 or not os.environ.get('TP_BENCH_NO_TORCH'):
+		try:
+			import torch
+			if world > 1:
+				import torch.distributed as dist
+				os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+				# gloo announces its connections on stdout (C level): keep stdout for the ONE JSON line
+				sys.stdout.flush()
+				saved = os.dup(1)
+				os.dup2(2, 1)
+				try:
+					dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+				finally:
+					os.dup2(saved, 1)
+					os.close(saved)
+		except ImportError:
+			torch = None
+			if world > 1:
+				raise
 
 	import numpy as np
-	from photometry_amd import simulate, engine, pipeline
-	from photometry_amd.device import Context
+	from photometry_amd import simulate, engine, pipeline, _lib
+	from photometry_amd.device import Context, DeviceCube
 	from photometry_amd import comm as tpcomm
+	import ctypes
 
-	def device_sync():
-		ctx.sync()
-		if torch is not None and torch.cuda.is_available():
-			torch.cuda.synchronize(local_rank)
+	# ranks of one node use one GPU each; on a box with fewer GPUs than ranks they share devices (control-flow smoke run)
+	ndev = ctypes.c_int(0)
+	_lib.load().tp_device_count(ctypes.byref(ndev))
+	if ndev.value <= 0:
+		raise RuntimeError("bench.py needs a GPU: " + (_lib.load().tp_last_error(None) or b'').decode())
+	shared_device = world > ndev.value
+	device = local_rank % ndev.value
+	ctx = Context(device)
+	use_torch_cuda = torch is not None and torch.cuda.is_available()
+	if use_torch_cuda:
+		torch.cuda.set_device(device)
+
+	def device_sync(*ctxs):
+		for c in (ctx,) + ctxs:
+			c.sync()
+		if use_torch_cuda:
+			torch.cuda.synchronize(device)
 
 	def barrier():
 		if dist is not None:
 			dist.barrier()
 
-	ctx = Context(local_rank)
-	if torch is not None and torch.cuda.is_available():
-		torch.cuda.set_device(local_rank)
-
 	Nt, T, H = args.targets, args.cadences, args.stamp
 	W = H
-	if args.workload == 'linpsf':
-		return main_linpsf(args, ctx, rank, world, dist, torch, device_sync, barrier)
-	# every rank gets its own contiguous shard of the global target list (weak scaling)
+	P = H * W
 	scene = simulate.make_scene(Nt, T, H, W, seed=args.seed * 1000 + rank)
 	scene.aperture = None
-	# resident inputs (SURVEY.md 8d, C3): background-subtracted images, errors and the background cube
-	# (3 x 11.7 GB at the default size) + the raw cube for the separately timed background stage
-	cubes = engine.synth_fill(ctx, scene, raw=True)
-	batch = pipeline.ApertureBatch(ctx, scene, cubes={k: cubes[k] for k in ('images', 'images_err', 'backgrounds')})
-	work = pipeline.ApertureWork(ctx, batch)
+	extras = (world == 1) and not args.no_extra
+	# resident inputs: raw flux + error cubes (2 x 11.8 GB at the default size); the premade-cube leg adds the
+	# background-subtracted images and the background cube of the reference's per-target stage
+	cubes = engine.synth_fill(ctx, scene, images=extras, images_err=True, backgrounds=extras, raw=True)
+	cubes['raw_err'] = cubes['images_err']
+	batch = pipeline.ApertureBatch(ctx, scene, cubes={'raw': cubes['raw'], 'raw_err': cubes['raw_err']})
+	nbuf = 2 if world > 1 else 1
+	works = [pipeline.ApertureWork(ctx, batch, packed=True) for _ in range(nbuf)]
+	for w in works[1:]: # the background series are scratch of the step, not outputs: shared
+		w.bkg_raw, w.bkg = works[0].bkg_raw, works[0].bkg
 
-	# The only data-path exchange: one RCCL gather of the light-curve block at the end of the timed region.  If the
-	# communicator cannot be created the ranks agree (over gloo) to run without it and the JSON line says so: the hot
-	# path itself has no collective.
+	# ---- the per-step gather (world > 1): RCCL on a second stream, double-buffered ------------------------------
 	do_gather = world > 1 and not args.no_gather
-	comm_note = None
+	comm_ctx = None
+	gather_mode = 'none (single GPU)' if world == 1 else 'disabled (--no-gather)'
+	recv = [None, None]
+	block_bytes = works[0].block.nbytes
 	if do_gather:
-		ok = 1
-		try:
-			tpcomm.init_from_torch(ctx, dist, rank, world)
-		except Exception as e: # noqa: B902
-			ok, comm_note = 0, f'RCCL communicator not created ({e}); light curves left on their ranks'
+		comm_ctx = Context(device, high_priority=True) # its copy kernels must not queue behind a grid that fills every CU
+		ok, note = 1, None
+		if shared_device:
+			ok, note = 0, f'{world} ranks share {ndev.value} GPU(s): RCCL needs one device per rank'
+		else:
+			try:
+				tpcomm.init_from_torch(comm_ctx, dist, rank, world)
+			except Exception as e: # noqa: B902
+				ok, note = 0, f'RCCL communicator not created ({e})'
 		t = torch.tensor([ok], dtype=torch.int32)
 		dist.all_reduce(t, op=dist.ReduceOp.MIN)
-		if int(t[0]) == 0:
-			do_gather = False
-			comm_note = comm_note or 'RCCL communicator not created on another rank; light curves left on their ranks'
-	gather_buf = None
-	lc_bytes = work.lc.block.nbytes
-	if do_gather and rank == 0:
-		gather_buf = ctx.empty((world, lc_bytes // 8), 'float64')
+		if int(t[0]) == 1:
+			gather_mode = 'rccl'
+			if rank == 0:
+				recv = [ctx.empty((world, block_bytes), 'uint8') for _ in range(2)]
+		else:
+			# control-flow fallback (never on a real multi-GPU node): the block goes through host memory and gloo
+			gather_mode = 'host-gloo fallback: ' + (note or 'RCCL unavailable on another rank')
+	ev_done = [ctx.event() for _ in range(nbuf)]
+	ev_free = [ctx.event() for _ in range(nbuf)]
+	gather_ms = []
 
-	def do_step():
-		pipeline.aperture_step(ctx, batch, work, fused=not args.unfused)
+	def gather_block(b):
+		if gather_mode == 'rccl':
+			comm_ctx.wait_event(ev_done[b])
+			comm_ctx.timer_start(b)
+			tpcomm.gather(comm_ctx, works[b].block, recv[b], root=0)
+			comm_ctx.timer_stop(b)
+			comm_ctx.record(ev_free[b])
+		else:
+			ctx.sync()
+			t0 = time.perf_counter()
+			h = torch.from_numpy(works[b].block.to_host())
+			dist.gather(h, [torch.empty_like(h) for _ in range(world)] if rank == 0 else None, dst=0)
+			gather_ms.append((time.perf_counter() - t0) * 1e3)
 
-	def profiling(on):
-		ctx.profile(on)
-		if on:
-			ctx.profile_reset()
+	def run_steps(n, collect=False):
+		for s in range(n):
+			b = s % nbuf
+			if do_gather and gather_mode == 'rccl' and s >= nbuf:
+				if collect:
+					gather_ms.append(comm_ctx.timer_ms(b)) # waits for gather s - nbuf (long finished)
+				ctx.wait_event(ev_free[b]) # block b has left for rank 0: it may be overwritten
+			pipeline.aperture_step(ctx, batch, works[b])
+			if do_gather:
+				ctx.record(ev_done[b])
+				gather_block(b)
+		if do_gather and gather_mode == 'rccl' and collect:
+			for s in range(max(0, n - nbuf), n):
+				gather_ms.append(comm_ctx.timer_ms(s % nbuf))
 
-	for _ in range(args.warmup):
-		do_step()
-	device_sync()
+	run_steps(args.warmup)
+	device_sync(*([comm_ctx] if comm_ctx else []))
 	barrier()
-	profiling(True)
+	del gather_ms[:]
+	ctx.profile(True)
+	ctx.profile_reset()
 	t0 = time.perf_counter()
-	for _ in range(args.steps):
-		do_step()
-	if do_gather:
-		tpcomm.gather(ctx, work.lc.block, gather_buf, root=0)
-	device_sync()
+	run_steps(args.steps, collect=True)
+	device_sync(*([comm_ctx] if comm_ctx else []))
 	barrier()
 	elapsed = time.perf_counter() - t0
-	profiling(False)
+	ctx.profile(False)
 	if dist is not None:
 		t = torch.tensor([elapsed], dtype=torch.float64)
 		dist.all_reduce(t, op=dist.ReduceOp.MAX)
 		elapsed = float(t[0])
-
 	prof = ctx.profile_report()
+	work = works[(args.steps - 1) % nbuf] if args.steps > 0 else works[0]
 
-	# ---- the same arithmetic as three stand-alone kernels back to back (A1, K2P2, A6): per-stage durations when a
-	# stage owns the GPU.  Not part of `value`.
-	prof_serial = None
-	if not args.unfused and rank == 0:
-		pipeline.aperture_step(ctx, batch, work, fused=False)
-		device_sync()
-		ctx.profile(True)
-		ctx.profile_reset()
-		ts0 = time.perf_counter()
-		for _ in range(2):
-			pipeline.aperture_step(ctx, batch, work, fused=False)
-		device_sync()
-		serial_ms = (time.perf_counter() - ts0) / 2 * 1e3
-		ctx.profile(False)
-		prof_serial = ctx.profile_report()
+	result = None
+	if rank == 0:
+		n_mask = float(work.mask.to_host().astype('int64').sum())
+		# SURVEY 8d algorithmic bytes per target (A6 charged with every row of its cubes) ...
+		alg = {
+			'tp_bkg_stamp_kernel': P*T*4 + T*4,
+			'tp_bkg_smooth_kernel': 2*T*4,
+			'tp_aperture_fused_kernel': (P*T*4 + T*4 + P*8) + (2*P*T*4 + T*4 + P + 5*T*8),
+		}
+		# ... and the bytes per launch the kernels cannot avoid: A1 needs the whole raw cube, A6 only the rows of in-mask pixels
+		necessary = {
+			'tp_bkg_stamp_kernel': Nt * (P*T*4 + T*4),
+			'tp_bkg_smooth_kernel': Nt * 2*T*4,
+			'tp_aperture_fused_kernel': Nt * (P*T*4 + 2*T*4 + P*8) + 2 * n_mask * T * 4 + Nt * (T*4 + P + 5*T*8),
+		}
+		rows = kernel_rows(prof, Nt, alg, necessary)
+		traffic = None
+		tfile = os.path.join(ROOT, 'profiles', 'r2_traffic.json')
+		if os.path.exists(tfile) and (Nt, T, H) == (10000, 1300, 15):
+			traffic = json.load(open(tfile)).get('traffic_bytes_per_launch')
+		hbm_kernels = [k for k in rows if k in necessary and k != 'tp_bkg_smooth_kernel']
+		dom = max(hbm_kernels, key=lambda k: rows[k]['avg_ms'])
+		notes = {
+			'tp_bkg_stamp_kernel': 'B*: streams the raw cube once, but is bound by the vector ALUs (a 256-key sorting network per frame '
+				'for the sigma-clipped median), not by HBM; traffic = bytes (profiles/)',
+			'tp_aperture_fused_kernel': 'the aperture-sum kernel north_star names (A1 + K2P2 + A6 fused, one wavefront per target)',
+		}
+		rooflines = [roofline_of(k, rows, traffic, notes.get(k)) for k in sorted(hbm_kernels, key=lambda k: -rows[k]['avg_ms'])]
+		step_bytes = sum(necessary[k] for k in rows if k in necessary)
+		result = {
+			'metric': 'targets/sec (whole node), 10k targets x 1300 cad x 15x15, aperture + background',
+			'value': Nt * world * args.steps / elapsed, 'unit': 'targets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+			'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+			'dtype': 'f32', 'data': 'synthetic',
+			'config': {'workload': f'{Nt} targets/GPU x {T} cadences x {H}x{W} stamps, aperture + background (BASELINE configs[2]): raw flux and '
+				'error cubes resident in HBM; per step the stamp background of every cadence (B*), its time smoothing (B2), and '
+				'AperturePhotometry.do_photometry of every target (sum image, K2P2 mask, extraction of flux / error / centroid / '
+				'background) with the background subtracted on the fly (B3)',
+				'targets_per_gpu': Nt, 'cadences': T, 'stamp': [H, W], 'parallelism': f'targets sharded over {world} GPU(s), one process per GPU'},
+			'roofline': next(r for r in rooflines if r['kernel'] == dom),
+			'rooflines': rooflines,
+			'step_hbm': {'necessary_bytes_per_step': step_bytes, 'GBps_over_whole_step': step_bytes / (elapsed / args.steps) / 1e9,
+				'frac_of_hbm_peak': step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 'mean_mask_pixels': n_mask / Nt},
+			'kernels': rows,
+			'gather': {'mode': gather_mode, 'bytes_per_rank_per_step': block_bytes if world > 1 else 0,
+				'block': 'light curves [5][Nt][T] f64 + contamination f64 + status, flags i32 + mask u8 per target, one message per rank',
+				'issued': 'every step, second stream, double-buffered output block' if do_gather else None,
+				'mean_ms': (sum(gather_ms) / len(gather_ms)) if gather_ms else None,
+				'ideal_ms_one_xgmi_link': block_bytes / (XGMI_LINK_GBS * 1e9) * 1e3 if world > 1 else None},
+		}
+		if shared_device:
+			result['warning'] = f'{world} ranks shared {ndev.value} GPU(s): a control-flow run, not a scaling measurement'
 
-	# ---- the stamp-level background stage (B*, B2, B3), timed the same way right after the headline region:
-	# raw cube -> per-cadence sigma-clipped background series -> time smoothing -> subtraction (in place)
+	# ---- extra legs, N = 1 only -------------------------------------------------------------------------------
+	if rank == 0 and extras:
+		result['aperture_premade_cubes'] = leg_premade(ctx, scene, cubes, args, Nt, T, H, W, np, engine, pipeline)
+		result['stages'] = leg_stages(ctx, scene, cubes, batch, work, args, Nt, T, H, W, np, engine, pipeline)
+	if rank == 0 and world == 1 and args.cpu_sample > 0:
+		cb, parity = cpu_baseline(ctx, scene, cubes, work, args, T, H, W, batch.time_smooth)
+		result['cpu_baseline'] = cb
+		result['parity_sample'] = parity
+		result['speedup_vs_cpu_baseline'] = result['value'] / cb['value']
+		result['speedup_vs_one_core'] = result['value'] / cb['single_core_targets_per_s']
+	if rank == 0 and extras:
+		if args.e2e_targets > 0:
+			result['end_to_end'] = leg_end_to_end(ctx, scene, cubes, args, T, H, W, np, engine, pipeline, Context, DeviceCube)
+		for k in ('images', 'backgrounds'):
+			cubes[k].free()
+		result['linpsf'] = leg_linpsf(ctx, scene, cubes, work, args, Nt, T, H, W, np, engine, pipeline)
+
+	if rank == 0:
+		print(json.dumps(result))
+		sys.stdout.flush()
+	if dist is not None:
+		dist.barrier()
+		dist.destroy_process_group()
+	if comm_ctx is not None:
+		comm_ctx.close()
+	ctx.close()
+
+
+# --------------------------------------------------------------------------------------------------
+def leg_premade(ctx, scene, cubes, args, Nt, T, H, W, np, engine, pipeline):
+	"""The per-target stage alone on premade cubes (background-subtracted images, errors, background cube): SURVEY 8d's reading
+	of configs[2] and the round-1 headline.  Fused kernel only; same HIP-event timing."""
+	P = H * W
+	batch = pipeline.ApertureBatch(ctx, scene, cubes={k: cubes[k] for k in ('images', 'images_err', 'backgrounds')})
+	work = pipeline.ApertureWork(ctx, batch)
+	pipeline.aperture_step(ctx, batch, work)
+	ctx.sync()
 	ctx.profile(True)
 	ctx.profile_reset()
-	bkg_raw = ctx.zeros((Nt, cubes['raw'].t_pitch), 'float32')
-	bkg_s = ctx.zeros((Nt, cubes['raw'].t_pitch), 'float32')
-	device_sync()
-	tb0 = time.perf_counter()
-	nb = max(1, min(args.steps, 3))
-	for _ in range(nb):
-		engine.background_stamp(ctx, cubes['raw'], out=bkg_raw)
-		engine.smooth_time(ctx, bkg_raw, T, batch.time_smooth, out=bkg_s)
-	engine.subtract_background(ctx, cubes['raw'], bkg_s, images=cubes['raw'])
-	device_sync()
-	bkg_stage_ms = (time.perf_counter() - tb0) / nb * 1e3
+	n = max(3, min(args.steps, 10))
+	t0 = time.perf_counter()
+	for _ in range(n):
+		pipeline.aperture_step(ctx, batch, work)
+	ctx.sync()
+	ms = (time.perf_counter() - t0) / n * 1e3
 	ctx.profile(False)
-	prof_bkg = ctx.profile_report()
-
-	# ---- the light-curve diagnostics of the batch (SURVEY 8f rank 1), timed the same way; not part of `value`
+	prof = ctx.profile_report()
+	n_mask = float(work.mask.to_host().astype('int64').sum())
+	necessary = {'tp_aperture_fused_kernel': Nt * (P*T*4 + T*4 + P*8) + 3 * n_mask * T * 4 + Nt * (P + 5*T*8)}
+	alg = {'tp_aperture_fused_kernel': (P*T*4 + T*4 + P*8) + (3*P*T*4 + P + 5*T*8)}
+	rows = kernel_rows(prof, Nt, alg, necessary)
+	tfile = os.path.join(ROOT, 'profiles', 'r2_traffic.json')
+	traffic = json.load(open(tfile)).get('traffic_bytes_per_launch_premade') if os.path.exists(tfile) and (Nt, T, H) == (10000, 1300, 15) else None
+	# three stand-alone kernels (A1, K2P2, A6), per-stage durations when a stage owns the GPU
+	pipeline.aperture_step(ctx, batch, work, fused=False)
+	ctx.sync()
 	ctx.profile(True)
 	ctx.profile_reset()
-	pipeline.aperture_diagnostics(ctx, batch, work)
-	device_sync()
-	td0 = time.perf_counter()
+	for _ in range(2):
+		pipeline.aperture_step(ctx, batch, work, fused=False)
+	ctx.sync()
+	ctx.profile(False)
+	three = {k: {'launches': v[0], 'avg_ms': v[1] / v[0]} for k, v in ctx.profile_report().items()}
+	return {'what': 'tp_aperture_photometry on premade cubes (images, errors, background cube: the inputs of the reference per-target stage); '
+		'no background estimation in the step', 'targets_per_s': Nt / (ms * 1e-3), 'ms_per_step': ms,
+		'roofline': roofline_of('tp_aperture_fused_kernel', rows, traffic), 'kernels': rows, 'three_kernel_path': three}
+
+
+def leg_stages(ctx, scene, cubes, batch, work, args, Nt, T, H, W, np, engine, pipeline):
+	"""Stages beside the step: materialised B3, light-curve diagnostics, stamp cutter."""
+	P = H * W
+	out = {}
+	scratch = cubes['images'] # overwritten: the premade leg is done
+	ctx.profile(True)
+	ctx.profile_reset()
+	for _ in range(3):
+		engine.subtract_background(ctx, cubes['raw'], work.bkg, images=scratch)
+	ctx.sync()
+	r = ctx.profile_report()['tp_bkg_subtract_kernel']
+	nb = Nt * (2*P*T*4 + T*4)
+	out['subtract_materialised'] = {'what': 'B3 as its own pass (raw cube -> images cube); the step subtracts on the fly instead',
+		'avg_ms': r[1] / r[0], 'necessary_GBps': nb / (r[1] / r[0] * 1e-3) / 1e9, 'frac_of_hbm_peak': nb / (r[1] / r[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+	ctx.profile_reset()
 	for _ in range(3):
 		pipeline.aperture_diagnostics(ctx, batch, work)
-	device_sync()
-	diag_stage_ms = (time.perf_counter() - td0) / 3 * 1e3
-	ctx.profile(False)
-	prof_bkg.update(ctx.profile_report())
-
-	# ---- the stamp cutter (SURVEY 8f rank 2): the same 10k stamps cut from a 1024 x 1024 x T frame stack in HBM into the
-	# (no longer needed) raw cube; timed the same way, not part of `value`
-	cut_stage_ms = None
+	ctx.sync()
+	r = ctx.profile_report()['tp_diagnostics_kernel']
+	out['diagnostics'] = {'what': 'light-curve diagnostics of every target (BasePhotometry.py:1343-1407) from the device-resident outputs',
+		'avg_ms': r[1] / r[0]}
 	if args.frame > 0:
 		FR = args.frame
 		frames = ctx.zeros((T, FR, FR), 'float32')
 		rng = np.random.default_rng(args.seed)
 		r0 = rng.integers(0, FR - H, Nt)
 		c0 = rng.integers(0, FR - W, Nt)
-		cstamps = ctx.array(np.stack((r0, r0 + H, c0 + 44, c0 + 44 + W), axis=1).astype('int32'))
-		ctx.profile(True)
+		cst = ctx.array(np.stack((r0, r0 + H, c0 + 44, c0 + 44 + W), axis=1).astype('int32'))
+		engine.cut_stamps(ctx, frames, cst, H, W, 0, 44, out=scratch)
 		ctx.profile_reset()
-		engine.cut_stamps(ctx, frames, cstamps, H, W, 0, 44, out=cubes['raw'])
-		device_sync()
-		tc0 = time.perf_counter()
 		for _ in range(3):
-			engine.cut_stamps(ctx, frames, cstamps, H, W, 0, 44, out=cubes['raw'])
-		device_sync()
-		cut_stage_ms = (time.perf_counter() - tc0) / 3 * 1e3
-		ctx.profile(False)
-		prof_bkg.update(ctx.profile_report())
+			engine.cut_stamps(ctx, frames, cst, H, W, 0, 44, out=scratch)
+		ctx.sync()
+		r = ctx.profile_report()['tp_cut_stamps_kernel']
+		nb = Nt * 2*P*T*4
+		out['cutout'] = {'what': f'stamp cutter: {Nt} stamps cut from a {FR} x {FR} x {T} float32 frame stack resident in HBM '
+			'(BasePhotometry._load_cube for the batch), one cube', 'avg_ms': r[1] / r[0],
+			'necessary_GBps': nb / (r[1] / r[0] * 1e-3) / 1e9, 'frac_of_hbm_peak': nb / (r[1] / r[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
 		frames.free()
+	ctx.profile(False)
+	return out
 
-	result = None
-	if rank == 0:
-		total_targets = Nt * world * args.steps
-		value = total_targets / elapsed
-		P = H * W
-		# algorithmic bytes per target (SURVEY.md section 8d)
-		alg = {
-			'tp_sumimage_kernel': P*T*4 + T*4 + P*8,             # A1
-			'tp_aperture_kernel': 3*P*T*4 + P + 5*T*8,           # A6 (three cubes)
-			# A1 + A6 in one kernel: the same reads and writes minus nothing (the sum image is still written, the mask too)
-			'tp_aperture_fused_kernel': (P*T*4 + T*4 + P*8) + (3*P*T*4 + P + 5*T*8),
-			'tp_bkg_stamp_kernel': P*T*4 + T*4,                  # B*
-			'tp_bkg_smooth_kernel': 2*T*4,                       # B2
-			'tp_bkg_subtract_kernel': 2*P*T*4 + T*4,             # B3 (materialised)
-			'tp_cut_stamps_kernel': 2*P*T*4,                     # stamp cutter: read the stamp pixels, write the cube
-		}
-		def kernel_table(report, targets_per_launch):
-			out = {}
-			for name, (n, ms) in report.items():
-				avg = ms / n
-				k = {'launches': n, 'avg_ms': avg}
-				if name in alg:
-					k['algorithmic_bytes_per_launch'] = alg[name] * targets_per_launch
-					k['achieved_GBps'] = alg[name] * targets_per_launch / (avg * 1e-3) / 1e9
-				out[name] = k
-			return out
-		kernels = kernel_table(prof, Nt)
-		kernels.update(kernel_table(prof_bkg, Nt))
-		# the dominant kernel of the TIMED step (the background-stage kernels are reported in `kernels` only)
-		dom = max((k for k in prof if True), key=lambda k: kernels[k]['avg_ms'])
-		if dom not in alg: # a latency-bound kernel (K2P2) dominates: report the largest HBM-bound one and say so
-			dom_hbm = max((k for k in prof if k in alg), key=lambda k: kernels[k]['avg_ms'])
-		else:
-			dom_hbm = dom
-		traffic = None
-		tfile = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
-		if os.path.exists(tfile) and (Nt, T, H) == (10000, 1300, 15):
-			# HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/run_profile.sh),
-			# FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE
-			traffic = json.load(open(tfile)).get(dom_hbm)
-		# bytes this implementation cannot avoid: A1 needs every pixel of the images cube, A6 only the rows of the
-		# pixels that ended up in a mask (three cubes), plus the outputs -- the SURVEY 8d figure charges A6 with all rows
-		n_mask = float(work.mask.to_host().astype('int64').sum())
-		necessary = {
-			'tp_sumimage_kernel': Nt * (P*T*4 + T*4 + P*8),
-			'tp_aperture_kernel': 3 * n_mask * T * 4 + Nt * (P + 5*T*8),
-		}
-		necessary['tp_aperture_fused_kernel'] = necessary['tp_sumimage_kernel'] + necessary['tp_aperture_kernel']
-		roofline = {
-			'kernel': dom_hbm, 'bound': 'hbm', 'achieved': kernels[dom_hbm]['achieved_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-			'frac': kernels[dom_hbm]['achieved_GBps'] / HBM_PEAK_GBS, 'traffic': traffic,
-			'avg_kernel_ms': kernels[dom_hbm]['avg_ms'], 'longest_kernel_of_step': dom,
-			'targets_per_launch': Nt,
-		}
-		if dom_hbm in necessary:
-			nb = necessary[dom_hbm] / (kernels[dom_hbm]['avg_ms'] * 1e-3) / 1e9
-			roofline['necessary'] = {'what': 'bytes per launch the kernel cannot avoid (A1: whole images cube; A6: only the rows of the '
-				'in-mask pixels of the three cubes; outputs) -- `achieved` uses the SURVEY 8d figure, which charges A6 with every row',
-				'bytes_per_launch': necessary[dom_hbm], 'achieved': nb, 'frac': nb / HBM_PEAK_GBS, 'mean_mask_pixels': n_mask / Nt}
-		result = {
-			'metric': 'targets/sec (whole node), 10k targets x 1300 cad x 15x15, aperture + background',
-			'value': value, 'unit': 'targets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-			'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-			'dtype': 'f32', 'data': 'synthetic',
-			'config': {'workload': f'{Nt} targets/GPU x {T} cadences x {H}x{W} stamps, aperture + background (BASELINE configs[2]): '
-				'sum image + K2P2 masks + extraction of flux / error / centroid / background from the images, error and background '
-				'cubes resident in HBM',
-				'targets_per_gpu': Nt, 'cadences': T, 'stamp': [H, W], 'parallelism': f'targets sharded over {world} GPU(s)'},
-			'roofline': roofline,
-			'kernels': kernels,
-			'gather': ('none (single GPU)' if world == 1 else ('one RCCL gather of the light-curve block, inside the timed region' if do_gather else (comm_note or 'disabled (--no-gather)'))),
-			'background_stage': {'what': 'B* per-cadence stamp background + B2 time smoothing (+ one B3 subtraction) on the raw cube, '
-				'timed right after the headline region; not part of `value`', 'ms_per_pass': bkg_stage_ms,
-				'targets_per_s_including_it': Nt * world / (elapsed / args.steps + bkg_stage_ms * 1e-3)},
-			'cutout_stage': {'what': f'stamp cutter: the {Nt} stamps cut from a {args.frame} x {args.frame} x {T} float32 frame stack resident in HBM '
-				'(BasePhotometry._load_cube for the batch); one cube; not part of `value`', 'ms_per_cube': cut_stage_ms},
-			'diagnostics_stage': {'what': 'light-curve diagnostics of every target (mean flux, variance, rms_hour, ptp, centroid, variability, '
-				'mask size, edge flux: BasePhotometry.py:1343-1407) from the device-resident outputs; not part of `value`', 'ms_per_pass': diag_stage_ms},
-		}
 
-		if prof_serial is not None:
-			result['three_kernel_path'] = kernel_table(prof_serial, Nt)
-			result['three_kernel_path']['ms_per_step'] = serial_ms
+def leg_end_to_end(ctx, scene, cubes, args, T, H, W, np, engine, pipeline, Context, DeviceCube):
+	"""
+	SURVEY 8d timing (ii): the cubes start in HOST memory, as a drop-in plugin receives them from BasePhotometry._load_cube.
+	Pinned staging buffers, chunks of targets, the upload of chunk i+1 on a second stream while chunk i is processed, the
+	light curves copied back asynchronously.  PCIe-bound by construction (2.35 MB in per target, 52 KB out).
+	"""
+	n = min(args.e2e_targets, scene.n_targets)
+	chunk = 256
+	n = max(chunk, n // chunk * chunk)
+	sub = scene.subset(slice(0, n))
+	up = Context(ctx.device, high_priority=False)
+	host = {}
+	for key in ('raw', 'raw_err'):
+		host[key] = ctx.pinned((n, H, W, T), 'float32')
+		full = np.empty((chunk, H, W, cubes[key].t_pitch), dtype='float32')
+		for a in range(0, n, chunk):
+			ctx._check(ctx.lib.tp_memcpy_d2h(ctx.handle, full.ctypes.data, cubes[key].slice0(a, chunk).ptr, full.nbytes))
+			host[key].array[a:a + chunk] = full[..., :T]
+	out_host = ctx.pinned((n // chunk, 5, chunk, T), 'float64')
+	bufs = []
+	for _ in range(2):
+		dc = {k: DeviceCube(ctx, chunk, T, H, W) for k in ('raw', 'raw_err')}
+		for c in dc.values():
+			c.data.fill_bytes(0)
+		bufs.append(dc)
+	batches, works = [], []
+	for a in range(0, n, chunk):
+		b = pipeline.ApertureBatch(ctx, sub.subset(slice(a, a + chunk)), cubes=bufs[(a // chunk) % 2])
+		batches.append(b)
+		works.append(pipeline.ApertureWork(ctx, b))
+	ev_up = [ctx.event() for _ in range(2)]
+	ev_used = [ctx.event() for _ in range(2)]
 
-	# ---- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample of the same cubes -----
-	if rank == 0 and world == 1 and args.cpu_sample > 0:
-		cores_avail = len(os.sched_getaffinity(0))
-		nproc = max(1, min(cores_avail, args.cpu_procs))
-		ns = min(Nt, max(args.cpu_sample, nproc * 24) // nproc * nproc)
-		sub = scene.subset(slice(0, ns))
-		for name in ('images', 'images_err', 'backgrounds'):
-			cube = cubes[name]
-			host = np.empty((ns, H, W, cube.t_pitch), dtype='float32')
-			ctx._check(ctx.lib.tp_memcpy_d2h(ctx.handle, host.ctypes.data, cube.ptr, host.nbytes))
-			setattr(sub, name, np.ascontiguousarray(host[..., :T]))
-			del host
-		sub.aperture = np.ones((ns, H, W), dtype='int32')
-		# (a) one process, one core -- the analogue of one MPI worker of run_tessphot_mpi.py
-		n1 = min(ns, 32)
-		t1, _ = _cpu_worker(sub.subset(slice(0, n1)))
-		# (b) nproc worker processes (forked: the sample is shared copy-on-write, nothing is pickled in);
-		#     throughput = targets / slowest worker's compute time (process start-up excluded)
-		import multiprocessing as mp
-		global _CPU_JOBS
-		_CPU_JOBS = [sub.subset(slice(c, ns, nproc)) for c in range(nproc)]
-		with mp.get_context('fork').Pool(nproc) as pool:
-			rr = pool.map(_cpu_worker_indexed, range(nproc))
-		tmax = max(r[0] for r in rr)
-		result['cpu_baseline'] = {
-			'value': ns / tmax, 'unit': 'targets/s', 'cores': nproc, 'kind': 'port',
-			'sample': f'{ns} of the {Nt} targets of the same device-generated cubes ({ns // nproc} per worker process, {nproc} processes '
-				f'on a host with {cores_avail} usable cores); oracle = numpy restatement of the reference per-cadence loop '
-				'(sum image + K2P2 + extraction); rate = targets / slowest worker compute time',
-			'single_core_targets_per_s': n1 / t1,
-			'host_cores_available': cores_avail,
-		}
-		result['speedup_vs_cpu_baseline'] = result['value'] / (ns / tmax)
-		result['speedup_vs_one_core'] = result['value'] / (n1 / t1)
-		# parity of the sample while we are here (masks / statuses / float32 sums bit-exact)
-		lc = work.lc.to_host()
-		masks = work.mask.to_host()
-		status = work.status.to_host()
+	def run():
+		for i, a in enumerate(range(0, n, chunk)):
+			s = i % 2
+			if i >= 2:
+				up.wait_event(ev_used[s])
+			for key in ('raw', 'raw_err'):
+				bufs[s][key].upload_async(up, host[key], first_target=a)
+			up.record(ev_up[s])
+			ctx.wait_event(ev_up[s])
+			pipeline.aperture_step(ctx, batches[i], works[i])
+			ctx.record(ev_used[s])
+			ctx.download_async(out_host, works[i].lc.block, host_offset=i * 5 * chunk * T * 8)
+		up.sync()
+		ctx.sync()
+
+	run()
+	t0 = time.perf_counter()
+	reps = 2
+	for _ in range(reps):
+		run()
+	dt = (time.perf_counter() - t0) / reps
+	in_bytes = 2 * n * H * W * T * 4
+	res = {'what': f'{n} targets whose raw + error cubes start in pinned host memory (reference (H, W, T) layout): chunks of {chunk} targets, '
+		'H2D on a second stream overlapped with the step of the previous chunk, light curves copied back; file I/O excluded',
+		'targets_per_s': n / dt, 'h2d_GBps': in_bytes / dt / 1e9, 'bound': 'PCIe (2.35 MB in per target)', 'seconds': dt}
+	for h in list(host.values()) + [out_host]:
+		h.free()
+	up.close()
+	return res
+
+
+def leg_linpsf(ctx, scene, cubes, work, args, Nt, T, H, W, np, engine, pipeline):
+	"""BASELINE configs[3]: linpsf_photometry PSF-fit path over the same cube (raw cube + on-the-fly background subtraction)."""
+	from photometry_amd import simulate, psf as hpsf
+	prf = simulate.synthetic_prf(seed=1) # synthetic stand-in for the SPOC PRF file (git-LFS object upstream)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	batch = pipeline.LinPSFBatch(ctx, scene, model, images=cubes['raw'], subtract=work.bkg)
+	pipeline.linpsf_step(ctx, batch)
+	ctx.sync()
+	ctx.profile(True)
+	ctx.profile_reset()
+	n = max(3, min(args.steps, 5))
+	t0 = time.perf_counter()
+	for _ in range(n):
+		pipeline.linpsf_step(ctx, batch)
+	ctx.sync()
+	ms = (time.perf_counter() - t0) / n * 1e3
+	ctx.profile(False)
+	prof = ctx.profile_report()
+	kernels = {name: {'launches': c, 'avg_ms': t / c, 'ms_per_step': t / n} for name, (c, t) in prof.items()}
+	fit_ms = kernels['tp_linpsf_fit_kernel']['ms_per_step'] # one launch per star-count class: the step's fit time is their sum
+	nfit = batch.n_fit_stars
+	counts = np.diff(batch.star_offsets_h)
+	# flops the polynomial path EXECUTES (estimate): per star-cadence ~79 pixels inside the 5 px cut-off x 24 Horner FMAs; per
+	# cadence and finite pixel the normal equations S(S+1)/2 + S FMAs; per (star, visited table origin, pixel) item the
+	# 13x13 -> 5x5 contraction (~1 170 FMAs), ~3 origins per star
+	fma = nfit * T * 79 * 24 + float(np.sum(counts * (counts + 1) / 2 + counts)) * T * H * W + nfit * 3 * 79 * 1170
+	flops = 2.0 * fma
+	nbytes = Nt * (H*W*T*4 + T*4) + nfit * T * 16 + Nt * T * 8
+	res = {
+		'metric': 'targets/sec, 10k targets x 1300 cad x 15x15, linpsf_photometry PSF fit (BASELINE configs[3])',
+		'value': Nt / (ms * 1e-3), 'unit': 'targets/s', 'ms_per_step': ms, 'steps': n, 'dtype': 'f64', 'fitted_stars': int(nfit),
+		'config': {'workload': f'{Nt} targets x {T} cadences x {H}x{W}, LinPSF fit of {nfit} stars (P1 table blend + P2-P4), raw cube resident, '
+			'background series subtracted on the fly'},
+		'roofline': {'kernel': 'tp_linpsf_fit_kernel', 'bound': 'fp64 vector ALU / LDS (not HBM, not MFMA: the design-matrix product is banded)',
+			'achieved': flops / (fit_ms * 1e-3) / 1e12, 'peak': FP64_VALU_TFLOPS, 'unit': 'TFLOP/s', 'frac': flops / (fit_ms * 1e-3) / 1e12 / FP64_VALU_TFLOPS,
+			'flops': 'executed FP64 flops of the polynomial path (estimate, see bench.py:leg_linpsf)', 'kernel_ms_per_step': fit_ms,
+			'hbm': {'necessary_bytes_per_step': nbytes, 'GBps': nbytes / (fit_ms * 1e-3) / 1e9, 'frac_of_hbm_peak': nbytes / (fit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+			'traffic': None},
+		'kernels': kernels,
+	}
+	if args.cpu_sample > 0:
+		# CPU baseline: the oracle loop (reference-equivalent, scipy FITPACK integral per pixel) on a few targets, first cadences
+		from oracle import linpsf as olin, psf as opsf
+		ns, tsub = 4, min(T, 100)
+		host = np.empty((ns, H, W, cubes['raw'].t_pitch), dtype='float32')
+		ctx._check(ctx.lib.tp_memcpy_d2h(ctx.handle, host.ctypes.data, cubes['raw'].ptr, host.nbytes))
+		bkg = work.bkg.slice0(0, ns).to_host()
+		out = batch.out.to_host()
+		t1 = time.perf_counter()
 		bad = 0
-		for c, (_, out) in enumerate(rr):
-			for j, r in enumerate(out):
-				i = c + j * nproc
-				ok = int(status[i]) == r['status']
-				if ok and r['mask'] is not None:
-					ok = np.array_equal(masks[i].astype(bool), r['mask']) and np.array_equal(lc['flux'][i], r['flux'], equal_nan=True) \
-						and np.array_equal(lc['flux_err'][i], r['flux_err'], equal_nan=True) \
-						and np.array_equal(lc['flux_background'][i], r['flux_background'], equal_nan=True)
-				bad += (not ok)
-		result['parity_sample'] = {'targets': ns, 'mismatches': int(bad)}
-
-	if rank == 0:
-		print(json.dumps(result))
-	if dist is not None:
-		dist.barrier()
-		dist.destroy_process_group()
-	ctx.close()
+		for i in range(ns):
+			cat = scene.catalog_of(i)
+			positions = np.empty((tsub, len(cat['starid']), 2))
+			positions[:, :, 0] = cat['row_stamp'][None, :] + scene.jitter[:tsub, 1][:, None]
+			positions[:, :, 1] = cat['column_stamp'][None, :] + scene.jitter[:tsub, 0][:, None]
+			p = opsf.PSF(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'], tuple(scene.stamps[i]))
+			p.integrate_to_image = p.integrate_to_image_scipy # literal reference loop (psf.py:136-146)
+			img = host[i][:, :, :tsub] - bkg[i][None, None, :tsub]
+			ref = olin.do_photometry(img, p, cat, scene.target_starid[i], positions, tuple(scene.stamps[i]),
+				scene.target_pos_row[i], scene.target_pos_column[i], np.ones((H, W), dtype='int32'))
+			bad += not np.allclose(out['flux'][i][:tsub], ref['flux'], rtol=1e-7, atol=1e-8*np.nanmax(np.abs(ref['flux'])))
+		dt = time.perf_counter() - t1
+		res['cpu_baseline'] = {'value': ns / (dt * T / tsub), 'unit': 'targets/s', 'cores': 1, 'kind': 'port',
+			'sample': f'{ns} targets x first {tsub} cadences, extrapolated linearly to {T} cadences; oracle = literal per-pixel FITPACK loop of the reference'}
+		res['parity_sample'] = {'targets': ns, 'cadences': tsub, 'mismatches': int(bad), 'rtol': 1e-7}
+	return res
 
 
 if __name__ == '__main__':

@@ -85,6 +85,15 @@ int tp_memcpy_d2d(tp_ctx* ctx, void* d_dst, const void* d_src, uint64_t nbytes);
  * cube of BasePhotometry._load_cube (BasePhotometry.py:720-751) has pitch n_cad. */
 int tp_upload_cube(tp_ctx* ctx, float* d_dst, int64_t dst_pitch, const float* h_src, int64_t src_pitch,
 	int64_t n_rows, int64_t n_cad);
+/* Pinned (page-locked) host memory and copies that return as soon as they are enqueued on the ctx stream: with a
+ * second context (= stream) for the transfers and tp_event_* ordering, the upload of the next chunk of stamp cubes
+ * overlaps the photometry of the current one -- the regime of a plugin that receives host cubes from
+ * BasePhotometry._load_cube (BasePhotometry.py:720-751).  h_src / h_dst must come from tp_host_alloc. */
+int tp_host_alloc(tp_ctx* ctx, uint64_t nbytes, void** h_ptr);
+int tp_host_free(tp_ctx* ctx, void* h_ptr);
+int tp_upload_cube_async(tp_ctx* ctx, float* d_dst, int64_t dst_pitch, const float* h_src, int64_t src_pitch,
+	int64_t n_rows, int64_t n_cad);
+int tp_memcpy_d2h_async(tp_ctx* ctx, void* h_dst, const void* d_src, uint64_t nbytes);
 int tp_sync(tp_ctx* ctx);
 
 /* Cross-stream ordering: several contexts on one device each own a HIP stream; an event recorded on one

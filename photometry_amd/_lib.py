@@ -55,6 +55,10 @@ SIGNATURES = {
 	'tp_memcpy_d2h': (c_int, [c_void_p, _p, _p, c_uint64]),
 	'tp_memcpy_d2d': (c_int, [c_void_p, _p, _p, c_uint64]),
 	'tp_upload_cube': (c_int, [c_void_p, _p, c_int64, _p, c_int64, c_int64, c_int64]),
+	'tp_host_alloc': (c_int, [c_void_p, c_uint64, POINTER(c_void_p)]),
+	'tp_host_free': (c_int, [c_void_p, _p]),
+	'tp_upload_cube_async': (c_int, [c_void_p, _p, c_int64, _p, c_int64, c_int64, c_int64]),
+	'tp_memcpy_d2h_async': (c_int, [c_void_p, _p, _p, c_uint64]),
 	'tp_sync': (c_int, [c_void_p]),
 	'tp_event_create': (c_int, [c_void_p, POINTER(c_void_p)]),
 	'tp_event_destroy': (c_int, [c_void_p, c_void_p]),

@@ -210,6 +210,47 @@ int tp_upload_cube(tp_ctx* ctx, float* d_dst, int64_t dst_pitch, const float* h_
 	return TP_OK;
 }
 
+int tp_host_alloc(tp_ctx* ctx, uint64_t nbytes, void** h_ptr) {
+	TP_CHECK_CTX(ctx);
+	TP_REQUIRE(ctx, h_ptr != nullptr, "tp_host_alloc: null output pointer");
+	*h_ptr = nullptr;
+	if (nbytes == 0) nbytes = 16;
+	hipError_t e = hipHostMalloc(h_ptr, (size_t)nbytes, hipHostMallocDefault);
+	if (e == hipErrorOutOfMemory) return ctx->fail(TP_ERR_NOMEM, "tp_host_alloc: out of pinned host memory");
+	if (e != hipSuccess) return ctx->fail(TP_ERR_HIP, "hipHostMalloc", e);
+	return TP_OK;
+}
+
+int tp_host_free(tp_ctx* ctx, void* h_ptr) {
+	TP_CHECK_CTX(ctx);
+	if (!h_ptr) return TP_OK;
+	TP_HIP(ctx, hipHostFree(h_ptr));
+	return TP_OK;
+}
+
+int tp_upload_cube_async(tp_ctx* ctx, float* d_dst, int64_t dst_pitch, const float* h_src, int64_t src_pitch,
+	int64_t n_rows, int64_t n_cad) {
+	TP_CHECK_CTX(ctx);
+	if (n_rows == 0 || n_cad == 0) return TP_OK;
+	TP_REQUIRE(ctx, d_dst && h_src, "tp_upload_cube_async: null pointer");
+	TP_REQUIRE(ctx, dst_pitch >= n_cad && src_pitch >= n_cad && n_rows > 0 && n_cad > 0, "tp_upload_cube_async: bad geometry");
+	if (dst_pitch == n_cad && src_pitch == n_cad) {
+		TP_HIP(ctx, hipMemcpyAsync(d_dst, h_src, (size_t)(n_rows * n_cad) * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+	} else {
+		TP_HIP(ctx, hipMemcpy2DAsync(d_dst, (size_t)dst_pitch * sizeof(float), h_src, (size_t)src_pitch * sizeof(float),
+			(size_t)n_cad * sizeof(float), (size_t)n_rows, hipMemcpyHostToDevice, ctx->stream));
+	}
+	return TP_OK;
+}
+
+int tp_memcpy_d2h_async(tp_ctx* ctx, void* h_dst, const void* d_src, uint64_t nbytes) {
+	TP_CHECK_CTX(ctx);
+	if (nbytes == 0) return TP_OK;
+	TP_REQUIRE(ctx, h_dst && d_src, "tp_memcpy_d2h_async: null pointer");
+	TP_HIP(ctx, hipMemcpyAsync(h_dst, d_src, (size_t)nbytes, hipMemcpyDeviceToHost, ctx->stream));
+	return TP_OK;
+}
+
 int tp_sync(tp_ctx* ctx) {
 	TP_CHECK_CTX(ctx);
 	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));

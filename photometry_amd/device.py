@@ -75,6 +75,43 @@ class DeviceArray(object):
 		return v
 
 
+class PinnedArray(object):
+	"""
+	Page-locked host memory (``tp_host_alloc``) seen as a numpy array: the source / destination of the asynchronous copies
+	(:meth:`DeviceCube.upload_async`, :meth:`Context.download_async`) that overlap transfers with kernels.
+	"""
+
+	def __init__(self, ctx, shape, dtype):
+		self.ctx = ctx
+		self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+		self.dtype = np.dtype(dtype)
+		self.nbytes = int(np.prod(self.shape, dtype='int64')) * self.dtype.itemsize
+		p = ctypes.c_void_p()
+		ctx._check(ctx.lib.tp_host_alloc(ctx.handle, max(self.nbytes, 16), ctypes.byref(p)))
+		self.ptr = p.value
+		buf = (ctypes.c_char * max(self.nbytes, 1)).from_address(self.ptr)
+		self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape, dtype='int64'))).reshape(self.shape)
+
+	def free(self):
+		if self.ptr is not None and self.ctx.handle is not None:
+			self.array = None
+			self.ctx.lib.tp_host_free(self.ctx.handle, self.ptr)
+		self.ptr = None
+
+
+def device_view(ctx, ptr, shape, dtype, base=None):
+	"""A non-owning :class:`DeviceArray` over ``ptr`` (a piece of a larger allocation kept alive by ``base``)."""
+	v = DeviceArray.__new__(DeviceArray)
+	v.ctx = ctx
+	v.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+	v.dtype = np.dtype(dtype)
+	v.nbytes = int(np.prod(v.shape, dtype='int64')) * v.dtype.itemsize
+	v.ptr = int(ptr)
+	v._view = True
+	v._base = base
+	return v
+
+
 class DeviceCube(object):
 	"""
 	A float32 stamp cube ``[n_targets][H][W][t_pitch]`` in HBM (time fastest, the reference's
@@ -111,6 +148,18 @@ class DeviceCube(object):
 			d.data.fill_bytes(0)
 		ctx._check(ctx.lib.tp_upload_cube(ctx.handle, d.ptr, d.t_pitch, cube.ctypes.data, T, Nt*H*W, T))
 		return d
+
+	def upload_async(self, ctx, pinned, first_target=0, n_targets=None):
+		"""
+		Enqueue (on ``ctx``'s stream, without waiting) the upload of the targets ``[first_target, first_target + n_targets)``
+		of ``pinned`` (:class:`PinnedArray` ``(Nt_host, H, W, T)`` float32) into this cube's targets ``[0, n_targets)``.
+		"""
+		n = self.n_targets if n_targets is None else int(n_targets)
+		T = pinned.shape[3]
+		assert pinned.shape[1:3] == (self.height, self.width) and T == self.n_cad and n <= self.n_targets
+		rows = n * self.height * self.width
+		src = pinned.ptr + int(first_target) * self.height * self.width * T * 4
+		ctx._check(ctx.lib.tp_upload_cube_async(ctx.handle, self.ptr, self.t_pitch, src, T, rows, T))
 
 	def to_host(self):
 		full = self.data.to_host()
@@ -184,6 +233,14 @@ class Context(object):
 
 	def cube(self, host):
 		return DeviceCube.from_host(self, host)
+
+	def pinned(self, shape, dtype):
+		return PinnedArray(self, shape, dtype)
+
+	def download_async(self, pinned, device_array, nbytes=None, host_offset=0):
+		"""Enqueue a device -> pinned-host copy on this context's stream (returns at once)."""
+		n = device_array.nbytes if nbytes is None else int(nbytes)
+		self._check(self.lib.tp_memcpy_d2h_async(self.handle, pinned.ptr + int(host_offset), device_array.ptr, n))
 
 	# -- timing ------------------------------------------------------------------------------
 	# -- cross-stream events -------------------------------------------------------------------

@@ -44,11 +44,11 @@ class LightCurves(object):
 	"""Device-resident light-curve block: float64 ``(Nt, T)`` per column."""
 	COLUMNS = ('flux', 'flux_err', 'flux_background', 'centroid_col', 'centroid_row')
 
-	def __init__(self, ctx, n_targets, n_cad):
+	def __init__(self, ctx, n_targets, n_cad, block=None):
 		self.ctx = ctx
 		self.n_targets, self.n_cad = int(n_targets), int(n_cad)
-		# one allocation [5][Nt][T] so that the final gather moves a single block
-		self.block = ctx.zeros((5, self.n_targets, self.n_cad), 'float64')
+		# one allocation [5][Nt][T] (or a piece of the caller's packed output block) so that a gather moves a single block
+		self.block = ctx.zeros((5, self.n_targets, self.n_cad), 'float64') if block is None else block
 		stride = self.n_targets * self.n_cad * 8
 		self.ptrs = [self.block.ptr + i*stride for i in range(5)]
 

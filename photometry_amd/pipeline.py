@@ -9,7 +9,7 @@ for every target of the batch at once.
 
 import numpy as np
 from . import engine
-from .device import DeviceCube
+from .device import DeviceCube, device_view, round_up
 
 
 class ApertureBatch(object):
@@ -86,18 +86,40 @@ class ApertureBatch(object):
 
 
 class ApertureWork(object):
-	"""Device-resident outputs / scratch of the aperture pipeline (allocated once, reused per step)."""
+	"""
+	Device-resident outputs / scratch of the aperture pipeline (allocated once, reused per step).
 
-	def __init__(self, ctx, batch):
+	``packed=True`` carves the per-target results a scheduler consumes -- the light-curve block ``[5][Nt][T]`` float64,
+	``contamination`` float64, ``status`` / ``flags`` int32 and the ``mask`` uint8 (the output
+	block of a rank) -- out of ONE allocation (``self.block``), so that the per-step gather of a multi-GPU run is a
+	single message.
+	"""
+
+	def __init__(self, ctx, batch, packed=False):
 		Nt, T, H, W = batch.n_targets, batch.n_cad, batch.height, batch.width
 		self.sumimage = ctx.empty((Nt, H, W), 'float64')
-		self.mask = ctx.zeros((Nt, H, W), 'uint8')
-		self.status = ctx.zeros((Nt,), 'int32')
-		self.flags = ctx.zeros((Nt,), 'int32')
-		self.contamination = ctx.zeros((Nt,), 'float64')
+		self.block = None
+		if packed:
+			sizes = [5 * Nt * T * 8, Nt * 8, Nt * 4, Nt * 4, Nt * H * W]
+			offs = [0]
+			for n in sizes:
+				offs.append(round_up(offs[-1] + n, 256))
+			self.block = ctx.zeros((offs[-1],), 'uint8')
+			b = self.block
+			self.lc = engine.LightCurves(ctx, Nt, T, block=device_view(ctx, b.ptr + offs[0], (5, Nt, T), 'float64', base=b))
+			self.contamination = device_view(ctx, b.ptr + offs[1], (Nt,), 'float64', base=b)
+			self.status = device_view(ctx, b.ptr + offs[2], (Nt,), 'int32', base=b)
+			self.flags = device_view(ctx, b.ptr + offs[3], (Nt,), 'int32', base=b)
+			self.mask = device_view(ctx, b.ptr + offs[4], (Nt, H, W), 'uint8', base=b)
+			self.block_layout = dict(zip(('lc', 'contamination', 'status', 'flags', 'mask'), offs[:5]))
+		else:
+			self.mask = ctx.zeros((Nt, H, W), 'uint8')
+			self.status = ctx.zeros((Nt,), 'int32')
+			self.flags = ctx.zeros((Nt,), 'int32')
+			self.contamination = ctx.zeros((Nt,), 'float64')
+			self.lc = engine.LightCurves(ctx, Nt, T)
 		self.diag = ctx.zeros((Nt, 8), 'float64')
 		self.cat_in_mask = ctx.zeros((max(int(batch.scene.cat_offsets[-1]), 1),), 'uint8')
-		self.lc = engine.LightCurves(ctx, Nt, T)
 		self.diagnostics = ctx.zeros((Nt, 10), 'float64')
 		self.bkg_raw = self.bkg = None
 		if batch.raw_mode:

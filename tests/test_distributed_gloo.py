@@ -44,3 +44,22 @@ def test_shard_gather_assemble_two_ranks(tmp_path):
 	port = 29500 + (os.getpid() % 2000)
 	mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
 	assert bool(np.load(out)[0])
+
+
+def test_bench_spawns_its_own_ranks_and_fails_loudly_without_gpu():
+	"""`python bench.py --gpus 2` (no launcher, no WORLD_SIZE) must start two ranks itself; without a GPU every rank must
+	fail loudly -- never fall back to one rank or to the CPU."""
+	import subprocess
+	import ctypes
+	from photometry_amd import _lib
+	n = ctypes.c_int(0)
+	_lib.load().tp_device_count(ctypes.byref(n))
+	if n.value > 0:
+		pytest.skip("a GPU is visible")
+	env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+	r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--targets', '8'],
+		env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+	assert r.returncode != 0
+	err = r.stderr.decode()
+	assert err.count('bench.py needs a GPU') >= 2, err[-2000:]   # both ranks started, both refused to run
+	assert '{' not in r.stdout.decode()   # no result line

@@ -25,3 +25,63 @@ def test_rccl_single_rank_roundtrip():
 		recv3 = ctx.zeros((4096,), 'float64')
 		tpcomm.gather(ctx, send, recv3, root=0)
 		np.testing.assert_array_equal(recv3.to_host(), np.arange(4096))
+
+
+def _two_rank_worker(rank, uid_file, out_file):
+	import os, sys, time
+	sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+	import numpy as np
+	from photometry_amd.device import Context
+	from photometry_amd import comm as tpcomm
+	from photometry_amd._lib import TessphotError
+	ctx = Context(0)
+	if rank == 0:
+		uid = tpcomm.unique_id()
+		with open(uid_file + '.tmp', 'wb') as fh:
+			fh.write(uid)
+		os.replace(uid_file + '.tmp', uid_file)
+	else:
+		for _ in range(600):
+			if os.path.exists(uid_file):
+				break
+			time.sleep(0.05)
+		uid = open(uid_file, 'rb').read()
+	try:
+		tpcomm.init(ctx, uid, rank, 2)
+	except TessphotError as e:
+		if rank == 0:
+			np.save(out_file, np.array([-1.0]))
+			open(out_file + '.msg', 'w').write(str(e))
+		return
+	n = 1 << 16
+	send = ctx.array(np.full(n, rank + 1, dtype='float64') * np.arange(n))
+	recv = ctx.zeros((2, n), 'float64') if rank == 0 else None
+	for _ in range(3): # repeated, like the per-step gather of bench.py
+		tpcomm.gather(ctx, send, recv, root=0)
+	ctx.sync()
+	if rank == 0:
+		got = recv.to_host()
+		ok = np.array_equal(got[0], np.arange(n)) and np.array_equal(got[1], 2.0 * np.arange(n))
+		np.save(out_file, np.array([1.0 if ok else 0.0]))
+	ctx.close()
+
+
+def test_rccl_two_ranks_gather(tmp_path):
+	"""tp_comm_gather itself with TWO RCCL ranks (two processes).  A 1-GPU box can only offer both ranks the same device, which
+	RCCL may refuse (duplicate GPU): that refusal is reported as a skip with RCCL's message, anything else must work."""
+	import multiprocessing as mp
+	uid_file, out_file = str(tmp_path / 'uid.bin'), str(tmp_path / 'ok.npy')
+	mpc = mp.get_context('spawn')
+	procs = [mpc.Process(target=_two_rank_worker, args=(r, uid_file, out_file)) for r in range(2)]
+	for p in procs:
+		p.start()
+	for p in procs:
+		p.join(120)
+	for p in procs:
+		if p.is_alive():
+			p.terminate()
+			pytest.fail("two-rank gather hung")
+	res = float(np.load(out_file)[0])
+	if res < 0:
+		pytest.skip("RCCL refused two ranks on one device: " + open(out_file + '.msg').read()[:200])
+	assert res == 1.0
