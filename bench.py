@@ -135,6 +135,21 @@ def _cpu_worker_indexed(c):
 	return _cpu_worker(_CPU_JOBS[c])
 
 
+def cgroup_cpu_quota():
+	"""CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
+	try:
+		q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+		return None if q == 'max' else float(q) / float(p)
+	except Exception: # noqa: B902
+		pass
+	try:
+		q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+		p = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+		return None if q <= 0 else q / p
+	except Exception: # noqa: B902
+		return None
+
+
 def physical_cores():
 	avail = len(os.sched_getaffinity(0))
 	try:
@@ -214,7 +229,7 @@ def cpu_baseline(ctx, scene, cubes, work, args, T, H, W, time_smooth):
 			'targets / slowest worker compute time; BLAS / OpenMP threads pinned to 1',
 		'rates_by_process_count': {str(k): v for k, v in rates.items()},
 		'single_core_targets_per_s': n1 / t1,
-		'host_cores': {'physical': phys, 'usable_logical': avail},
+		'host_cores': {'physical': phys, 'usable_logical': avail, 'cgroup_cpu_quota': cgroup_cpu_quota()},
 	}, {'targets': ns, 'mismatches': int(bad), 'background_mismatches': int(bad_bkg), 'background_max_rel_err': max_rel,
 		'what': 'status / mask / flux / flux_err / flux_background bit-exact given the device background; B* within 1e-6 of the oracle, '
 			'B2 bit-exact'}
@@ -537,7 +552,8 @@ def leg_stages(ctx, scene, cubes, batch, work, args, Nt, T, H, W, np, engine, pi
 	r = ctx.profile_report()['tp_bkg_subtract_kernel']
 	nb = Nt * (2*P*T*4 + T*4)
 	out['subtract_materialised'] = {'what': 'B3 as its own pass (raw cube -> images cube); the step subtracts on the fly instead',
-		'avg_ms': r[1] / r[0], 'necessary_GBps': nb / (r[1] / r[0] * 1e-3) / 1e9, 'frac_of_hbm_peak': nb / (r[1] / r[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+		'kernel': 'tp_bkg_subtract_kernel', 'avg_ms': r[1] / r[0], 'necessary_bytes_per_launch': nb,
+		'necessary_GBps': nb / (r[1] / r[0] * 1e-3) / 1e9, 'frac_of_hbm_peak': nb / (r[1] / r[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
 	ctx.profile_reset()
 	for _ in range(3):
 		pipeline.aperture_diagnostics(ctx, batch, work)
@@ -560,8 +576,8 @@ def leg_stages(ctx, scene, cubes, batch, work, args, Nt, T, H, W, np, engine, pi
 		r = ctx.profile_report()['tp_cut_stamps_kernel']
 		nb = Nt * 2*P*T*4
 		out['cutout'] = {'what': f'stamp cutter: {Nt} stamps cut from a {FR} x {FR} x {T} float32 frame stack resident in HBM '
-			'(BasePhotometry._load_cube for the batch), one cube', 'avg_ms': r[1] / r[0],
-			'necessary_GBps': nb / (r[1] / r[0] * 1e-3) / 1e9, 'frac_of_hbm_peak': nb / (r[1] / r[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+			'(BasePhotometry._load_cube for the batch), one cube', 'kernel': 'tp_cut_stamps_kernel', 'avg_ms': r[1] / r[0],
+			'necessary_bytes_per_launch': nb, 'necessary_GBps': nb / (r[1] / r[0] * 1e-3) / 1e9, 'frac_of_hbm_peak': nb / (r[1] / r[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
 		frames.free()
 	ctx.profile(False)
 	return out

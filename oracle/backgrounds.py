@@ -3,7 +3,9 @@
 ORACLE (test infrastructure only) -- B* / B2 / B3: background estimation on stamps.
 
 B2 and B3 restate ``photometry/prepare.py``: the time smoothing of the backgrounds
-(:258, :317-335) and the subtraction + manual-exclude masking (:419-425).
+(:258, :317-335) and the subtraction + manual-exclude masking (:419-425); both are pinned bit for bit by
+``tests/golden/golden_background.npz``, produced by executing exactly those statements of the reference
+(tests/golden/make_golden.py:golden_background).
 
 B* is BUILD-DEFINED.  The reference's estimator (``photometry/backgrounds.py:52-211``) only
 exists for full 2048x2048 frames: photutils ``Background2D`` on 64x64 tiles (:200-206) plus a

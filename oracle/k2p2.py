@@ -19,10 +19,13 @@ Third-party pieces and how they are stated here:
   pixels numbered in raster order of their first core pixel; a non-core pixel gets the
   lowest label among its 8-neighbour core pixels, or -1 (noise)
   (``sklearn/cluster/_dbscan_inner.pyx``; pinned against the installed scikit-learn).
-* statsmodels KDE / bandwidth (:410-420): restated in :mod:`oracle.kde` (parity unpinned).
+* statsmodels KDE / bandwidth (:410-420): restated in :mod:`oracle.kde` (pinned independently against scipy's
+  Gaussian KDE, the direct sum and numpy percentiles: tests/test_oracle_pins.py).
 * scikit-image 0.19.2 ``peak_local_max`` (:141) and ``watershed`` (:227): restated below from
-  ``skimage/feature/peak.py`` and ``skimage/segmentation/_watershed(_cy.pyx)`` (parity
-  unpinned against scikit-image itself).
+  ``skimage/feature/peak.py`` and ``skimage/segmentation/_watershed(_cy.pyx)``; scikit-image itself cannot be run
+  here, so both are pinned by hand-derived fixtures written out in tests/test_oracle_pins.py (two basins with a
+  saddle, plateau ties broken by push order, a marker outside the mask, diagonal contact vs a one-pixel bridge; flat
+  image -> no peaks, border and corner peaks kept, plateau peaks, the ``max(min, threshold_rel * max)`` threshold).
 """
 
 import heapq

@@ -14,7 +14,12 @@ This module restates the published algorithms of that version
 (``statsmodels/nonparametric/bandwidths.py: _select_sigma, bw_scott, select_bandwidth``;
 ``kde.py: kdensityfft, KDEUnivariate.evaluate``; ``kdetools.py: forrt, revrt,
 silverman_transform``; ``linbin.pyx: fast_linbin``; ``kernels.py: Gaussian``).
-**Parity unpinned** against statsmodels itself.
+statsmodels itself cannot be run here, so the restatement is pinned INDEPENDENTLY in
+``tests/test_oracle_pins.py``: ``evaluate`` against ``scipy.stats.gaussian_kde`` with the same kernel width (1e-11), the
+FFT density's argmax against the argmax of the direct Gaussian sum on the same 128-point grid (the only thing the reference
+reads from it, k2p2v2.py:420), linear binning against its defining properties and a hand-computed case, ``_select_sigma`` /
+Scott's rule against numpy's percentile definition.  What stays unpinned is only agreement with statsmodels where that
+package deviates from the published algorithm in a way these properties cannot see.
 """
 
 import numpy as np

@@ -1,19 +1,19 @@
 #!/bin/bash
 # Profiles of the default bench (run on the GPU box through gpurun):
-#   bash profiles/run_profile.sh r1
-# 1. rocprofv3 kernel trace + stats (per-kernel durations)
-# 2./3. PMC passes for HBM traffic of every dispatch (FETCH_SIZE and WRITE_SIZE need separate passes)
-TAG=${1:-r1}
+#   bash profiles/run_profile.sh r2
+# 1. rocprofv3 kernel trace + stats (per-kernel durations) of the default bench command
+# 2./3. PMC passes for the HBM traffic of every dispatch (FETCH_SIZE and WRITE_SIZE need separate passes; never together with a trace)
+TAG=${1:-r2}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export TP_BENCH_NO_TORCH=1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 5 --warmup 2 --cpu-sample 0 > $OUT/bench_trace.json 2> $OUT/trace.log
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log
+ARGS="--steps 5 --warmup 2 --cpu-sample 0 --e2e-targets 0 --frame 512"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --e2e-targets 0 --frame 512 > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --e2e-targets 0 --frame 512 > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log
 cd $REPO
-find $OUT -name "*.csv" | head -20
 python3 profiles/summarize.py $OUT $OUT/traffic.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # keep only small files in the merged output

@@ -23,6 +23,10 @@ Fixtures:
 * ``golden_linpsf.npz``   ``lsfit`` and ``LinPSFPhotometry.do_photometry``
                           (linpsf_photometry.py:22-34, 79-219)
 * ``golden_cutout.npz``   ``BasePhotometry._load_cube`` FFI branch (BasePhotometry.py:720-742) on a small frame stack
+* ``golden_background.npz`` the background smoothing loop and the subtraction / manual-exclude block of
+                          ``prepare_photometry`` (prepare.py:317-335, 412-425): those statements live inside a 600-line
+                          function that needs h5py, so the generator reads exactly those lines from the reference's
+                          file at generation time and executes them on dict-backed stand-ins for the HDF5 groups
 * ``golden_diagnostics.npz`` ``BasePhotometry.photometry`` (BasePhotometry.py:1337-1407): the light-curve
                           diagnostics the scheduler stores, from the reference's own code run on light curves
                           produced by its own ``AperturePhotometry.do_photometry``
@@ -544,8 +548,84 @@ def golden_linpsf():
 		out['cat_' + k] = v
 	np.savez_compressed(os.path.join(HERE, 'golden_linpsf.npz'), **out)
 
+#--------------------------------------------------------------------------------------------------
+class _Group(dict):
+	"""h5py group stand-in for the statements executed out of prepare.py: ``create_dataset`` stores the array."""
+	def create_dataset(self, name, data=None, **kwargs):
+		self[name] = np.array(data, copy=True)
+
+
+def _reference_block(first_marker, last_marker):
+	"""The source lines of photometry/prepare.py from the line containing ``first_marker`` to the one containing
+	``last_marker`` (inclusive), dedented -- read from the reference at generation time, never stored in this repo."""
+	import textwrap
+	lines = open(os.path.join(_refstub.REFERENCE_PATH, 'photometry', 'prepare.py')).read().splitlines()
+	i0 = next(i for i, ln in enumerate(lines) if first_marker in ln)
+	i1 = next(i for i, ln in enumerate(lines) if i > i0 and last_marker in ln)
+	return textwrap.dedent('\n'.join(lines[i0:i1 + 1])), (i0 + 1, i1 + 1)
+
+
+def golden_background():
+	"""B2 / B3: execute the reference's own statements (prepare.py:317-335 and :412-425)."""
+	import logging
+	import bottleneck
+	from photometry.quality import PixelQualityFlags
+	rng = np.random.default_rng(77)
+	out = {}
+	# ---- B2: the smoothing loop.  bottleneck is not installable: for time_smooth = 3 numpy's nanmean adds the (at most 3)
+	# float32 values in the same sequential order as bottleneck's reduction; for time_smooth = 9 (numpy would add pairwise)
+	# a sequential float32 stand-in of bottleneck.nanmean is injected instead -- stated in the fixture.
+	src, span = _reference_block('w = time_smooth//2', 'backgrounds.create_dataset(dset_name, data=bck')
+	print('B2 statements: prepare.py:%d-%d' % span)
+	H, W, N = 6, 7, 23
+	frames = rng.normal(100, 4, (N, H, W)).astype('float32')
+	frames[5, 2, 3] = np.nan; frames[6, 2, 3] = np.nan; frames[7, 2, 3] = np.nan    # a pixel NaN in a whole window
+	frames[0, 0, 0] = np.nan; frames[N - 1, 5, 6] = np.nan; frames[11, :, :] = np.nan
+
+	def seq_nanmean(block, axis=2):
+		a = np.zeros(block.shape[:2], dtype='float32')
+		c = np.zeros(block.shape[:2], dtype='float32')
+		for i in range(block.shape[2]):
+			v = block[:, :, i]
+			ok = ~np.isnan(v)
+			a = np.where(ok, (a + np.where(ok, v, np.float32(0))).astype('float32'), a)
+			c = c + ok.astype('float32')
+		with np.errstate(invalid='ignore', divide='ignore'):
+			return (a / c).astype('float32')
+
+	for ts, nm, label in ((3, np.nanmean, 'numpy'), (9, seq_nanmean, 'sequential-float32 stand-in')):
+		ns = {'time_smooth': ts, 'numfiles': N, 'trange': lambda n, **kw: range(n), 'tqdm_settings': {}, 'default_timer': lambda: 0.0,
+			'backgrounds': _Group(), 'dset_bck_us': {f'{k:04d}': frames[k] for k in range(N)}, 'img_shape': (H, W), 'np': np,
+			'nanmean': nm, 'logger': logging.getLogger('golden'), 'imgchunks': None, 'args': {}}
+		with warnings.catch_warnings():
+			warnings.simplefilter('ignore')
+			exec(compile(src, 'prepare.py[B2]', 'exec'), ns)
+		out[f'b2_ts{ts}_smoothed'] = np.stack([ns['backgrounds'][f'{k:04d}'] for k in range(N)])
+		out[f'b2_ts{ts}_nanmean'] = label
+	out['b2_frames'] = frames
+	# ---- B3: subtraction + manual exclude
+	src, span = _reference_block("if not hdr.get('BACKAPP', False):", 'flux0_err[excl] = np.NaN')
+	print('B3 statements: prepare.py:%d-%d' % span)
+	from types import SimpleNamespace
+	raw = rng.normal(500, 10, (N, H, W)).astype('float32')
+	err = np.sqrt(np.abs(raw)).astype('float32')
+	flags = np.zeros((N, H, W), dtype='int32')
+	flags[3, 1, 1] = 2; flags[3, 2, 2] = 1; flags[4, 0, 0] = 3; flags[9, 5, 6] = 8
+	bk = out['b2_ts3_smoothed']
+	for backapp in (False, True):
+		imgs, errs = [], []
+		for k in range(N):
+			ns = {'hdr': {'BACKAPP': True} if backapp else {}, 'flux0': raw[k].copy(), 'flux0_err': err[k].copy(),
+				'backgrounds': {'x': bk[k]}, 'pixel_flags': {'x': flags[k]}, 'dset_name': 'x', 'np': np, 'PixelQualityFlags': PixelQualityFlags}
+			exec(compile(src, 'prepare.py[B3]', 'exec'), ns)
+			imgs.append(ns['flux0']); errs.append(ns['flux0_err'])
+		out[f'b3_images_backapp{int(backapp)}'] = np.stack(imgs)
+		out[f'b3_errors_backapp{int(backapp)}'] = np.stack(errs)
+	out['b3_raw'], out['b3_raw_err'], out['b3_flags'] = raw, err, flags
+	np.savez_compressed(os.path.join(HERE, 'golden_background.npz'), **out)
+
 
 if __name__ == '__main__':
-	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics', 'cutout']
+	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics', 'cutout', 'background']
 	for w in which:
 		globals()['golden_' + w]()

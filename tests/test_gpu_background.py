@@ -110,3 +110,30 @@ def test_on_the_fly_subtraction_equals_materialised(ctx):
 		ref = oap.extract(imgh[i], s.raw_err[i], np.broadcast_to(b[i][None, None, :], imgh[i].shape), m[i], tuple(s.stamps[i]))
 		np.testing.assert_array_equal(lc_fly['flux'][i], ref['flux'])
 		np.testing.assert_array_equal(lc_fly['flux_background'][i], ref['flux_background'])
+
+
+def test_b2_b3_golden_on_device(ctx, golden_dir):
+	"""The reference's own smoothing / subtraction statements (golden_background.npz, prepare.py:317-335, 419-425) through
+	tp_smooth_time and tp_subtract_background: every pixel of the small frame stack is one 1x1 'target'."""
+	import os
+	from photometry_amd import engine
+	from photometry_amd.device import DeviceCube
+	g = np.load(os.path.join(golden_dir, 'golden_background.npz'))
+	frames = g['b2_frames']
+	N, H, W = frames.shape
+	series = np.zeros((H * W, 32), dtype='float32')
+	series[:, :N] = frames.reshape(N, H * W).T
+	d = ctx.array(series)
+	sm = {}
+	for ts in (3, 9):
+		sm[ts] = engine.smooth_time(ctx, d, N, ts)
+		got = sm[ts].to_host()[:, :N].T.reshape(N, H, W)
+		np.testing.assert_array_equal(got, g[f'b2_ts{ts}_smoothed'])
+	def as_cube(a):   # (N, H, W) -> (H*W targets, 1, 1, N)
+		return np.ascontiguousarray(a.reshape(N, H * W).T.reshape(H * W, 1, 1, N).astype('float32'))
+	raw, err = DeviceCube.from_host(ctx, as_cube(g['b3_raw'])), DeviceCube.from_host(ctx, as_cube(g['b3_raw_err']))
+	img, ierr = DeviceCube(ctx, H * W, N, 1, 1), DeviceCube(ctx, H * W, N, 1, 1)
+	flags = ctx.array(np.ascontiguousarray(g['b3_flags'].reshape(N, H * W).T.reshape(H * W, 1, N).astype('uint8')))
+	engine.subtract_background(ctx, raw, sm[3], raw_err=err, pixel_flags=flags, images=img, images_err=ierr)
+	np.testing.assert_array_equal(img.to_host(), as_cube(g['b3_images_backapp0']))
+	np.testing.assert_array_equal(ierr.to_host(), as_cube(g['b3_errors_backapp0']))

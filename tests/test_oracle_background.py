@@ -72,3 +72,21 @@ def test_subtract_background():
 	ok = flags != 2
 	np.testing.assert_array_equal(img[ok], (raw - bkg)[ok])
 	np.testing.assert_array_equal(e[ok], err[ok])
+
+
+def test_b2_b3_against_the_reference_statements(golden_dir):
+	"""golden_background.npz = prepare.py:317-335 and :419-425 EXECUTED (tests/golden/make_golden.py reads those lines from the
+	reference and runs them on dict-backed HDF5 stand-ins): smoothing windows, edge clipping, float32 block, NaN handling,
+	BACKAPP switch, manual-exclude masking."""
+	import os
+	g = np.load(os.path.join(golden_dir, 'golden_background.npz'))
+	frames = g['b2_frames']                                   # (N, H, W): one background image per cadence
+	for ts in (3, 9):
+		got = ob.smooth_time(np.moveaxis(frames, 0, -1), ts)   # (H, W, N), smoothing along the last axis
+		np.testing.assert_array_equal(np.moveaxis(got, -1, 0), g[f'b2_ts{ts}_smoothed'])
+	bk = g['b2_ts3_smoothed']
+	for backapp in (0, 1):
+		img, err = ob.subtract_background(g['b3_raw'], g['b3_raw_err'], bk, g['b3_flags'], backapp=bool(backapp))
+		np.testing.assert_array_equal(img, g[f'b3_images_backapp{backapp}'])
+		np.testing.assert_array_equal(err, g[f'b3_errors_backapp{backapp}'])
+	assert np.isnan(g['b3_images_backapp0'][3, 1, 1]) and np.isfinite(g['b3_images_backapp0'][3, 2, 2])   # only ManualExclude (2) masks

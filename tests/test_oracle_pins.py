@@ -1,0 +1,188 @@
+# -*- coding: utf-8 -*-
+"""
+Independent pins of the oracle's restatements of third-party code that cannot be installed here (statsmodels 0.13.2,
+scikit-image 0.19.2): every check below holds them to something that is NOT the oracle itself --
+
+* scipy's own Gaussian KDE for ``KDE.evaluate`` (k2p2v2.py:419);
+* the direct Gaussian sum evaluated on the same 128-point grid for the FFT density whose argmax the reference uses
+  (k2p2v2.py:414-420), plus the defining properties of linear binning;
+* numpy's percentile definition for ``_select_sigma`` / Scott's rule (k2p2v2.py:410);
+* hand-derived label images for the priority-flood watershed and hand-derived peak lists for ``peak_local_max``
+  (k2p2v2.py:141, 227) -- the expected arrays are written out below, not computed.
+"""
+import numpy as np
+import pytest
+from scipy import stats
+from oracle import kde, k2p2
+
+
+# ---- statsmodels KDE --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed,n", [(0, 40), (1, 191), (2, 7), (3, 120)])
+def test_kde_evaluate_is_scipys_gaussian_kde(seed, n):
+	rng = np.random.default_rng(seed)
+	x = np.concatenate((rng.normal(100, 5, n), rng.normal(160, 20, n // 3 + 1)))
+	bw = kde.select_bandwidth(x)
+	k = kde.KDE(x).fit(bw=bw, fft=True, gridsize=100)
+	pts = np.linspace(x.min() - 3 * bw, x.max() + 3 * bw, 57)
+	# gaussian_kde uses bandwidth factor * std(ddof=1): make its kernel width exactly bw
+	g = stats.gaussian_kde(x, bw_method=bw / np.std(x, ddof=1))
+	np.testing.assert_allclose(k.evaluate(pts), g(pts), rtol=1e-11)
+	# a density: integrates to one
+	fine = np.linspace(x.min() - 8 * bw, x.max() + 8 * bw, 20001)
+	assert abs(np.trapezoid(k.evaluate(fine), fine) - 1) < 1e-6
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fft_grid_mode_guess_is_the_direct_sum_argmax(seed):
+	"""The reference only uses ``support[argmax(density)]`` of the FFT estimate (k2p2v2.py:420) as the starting point of
+	the Powell search: it must be the grid point where the direct Gaussian sum over the same grid peaks, up to the
+	binning error of one grid step when two neighbouring grid points are within 1e-3 of each other."""
+	rng = np.random.default_rng(100 + seed)
+	n = int(rng.integers(30, 192))
+	x = np.abs(np.concatenate((rng.normal(120, 8, n), rng.gamma(2.0, 60.0, n // 4))))
+	x = np.sort(x)[:int(0.85 * len(x))]   # like trim1(…, 0.15)
+	bw = kde.select_bandwidth(x)
+	k = kde.KDE(x).fit(bw=bw, fft=True, gridsize=100)
+	assert k.support.shape == (128,) and k.density.shape == (128,)        # gridsize 100 -> next power of two
+	assert k.support[0] == x.min() - 3 * bw and abs(k.support[-1] - (x.max() + 3 * bw)) < 1e-9 * abs(k.support[-1])
+	direct = k.evaluate(k.support)
+	i_fft, i_dir = int(np.argmax(k.density)), int(np.argmax(direct))
+	assert abs(i_fft - i_dir) <= 1
+	if i_fft != i_dir:
+		assert abs(direct[i_fft] - direct[i_dir]) < 1e-3 * direct[i_dir]
+	# and the FFT density approximates the direct sum everywhere (Silverman's AS 176 with linear binning)
+	assert np.max(np.abs(k.density - direct)) < 0.03 * direct.max()
+
+
+def test_linear_binning_properties():
+	"""Fan & Marron linear binning: weights are non-negative, each point's two weights sum to one and reproduce its
+	position; statsmodels' ``li > 1`` guard drops the points that fall in the first two cells (never the case for the
+	KDE grid, which starts 3 bandwidths below the minimum ... unless bw is tiny: keep the guard, as upstream)."""
+	a, b, M = 0.0, 127.0, 128
+	x = np.array([2.25, 50.5, 100.0, 126.5])
+	g = kde.fast_linbin(x, a, b, M)
+	assert g.min() >= 0 and abs(g.sum() - len(x)) < 1e-12
+	grid = np.linspace(a, b, M)
+	assert abs((g * grid).sum() - x.sum()) < 1e-9
+	expect = np.zeros(M)
+	expect[2], expect[3] = 0.75, 0.25
+	expect[50], expect[51] = 0.5, 0.5
+	expect[100] = 1.0
+	expect[126], expect[127] = 0.5, 0.5
+	np.testing.assert_allclose(g, expect, atol=1e-12)
+	# the guard of linbin.pyx: points with integer cell index <= 1 are not counted
+	assert kde.fast_linbin(np.array([0.5, 1.9]), a, b, M).sum() == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_select_sigma_and_scott_rule(seed):
+	rng = np.random.default_rng(seed)
+	x = rng.gamma(3.0, 10.0, int(rng.integers(8, 300)))
+	# scoreatpercentile == numpy's default (linear) percentile
+	q75, q25 = np.percentile(x, [75, 25])
+	iqr = (q75 - q25) / 1.349
+	sd = np.sqrt(np.sum((x - x.mean())**2) / (len(x) - 1))
+	expect = min(sd, iqr) if iqr > 0 else sd
+	assert abs(kde.select_sigma(x) - expect) <= 1e-13 * expect
+	assert abs(kde.bw_scott(x) - 1.059 * expect * len(x)**(-0.2)) <= 1e-13 * expect
+	# IQR == 0 falls back to the standard deviation; an all-equal sample has bandwidth 0 -> RuntimeError (backgrounds.py:30 matches its text)
+	y = np.array([5.0] * 9 + [6.0])
+	assert kde.select_sigma(y) == np.std(y, ddof=1)
+	with pytest.raises(RuntimeError, match="bandwidth is 0"):
+		kde.select_bandwidth(np.full(10, 3.0))
+
+
+# ---- scikit-image watershed (priority flood, connectivity 1, markers * mask, label at push) ------------------------
+def _ws(Z, markers):
+	return k2p2.watershed(-np.asarray(Z, dtype='float64'), np.asarray(markers), mask=np.asarray(Z))
+
+
+def test_watershed_two_peaks_with_a_saddle():
+	# flux (brighter = flooded first since the image is -Z); two peaks 9 and 8 joined by a saddle of 3
+	Z = np.array([
+		[1, 2, 1, 0, 1, 2, 1],
+		[2, 9, 4, 3, 4, 8, 2],
+		[1, 2, 1, 0, 1, 2, 1]])
+	m = np.zeros_like(Z)
+	m[1, 1], m[1, 5] = 1, 2
+	# hand flood: from 9 -> 4 (1,2) ... from 8 -> 4 (1,4); the saddle pixel (1,3)=3 is reached first by the basin whose
+	# neighbour was popped first: both 4s have the same value, the one pushed EARLIER (age) pops first = (1,2), pushed
+	# while expanding marker 1, which is processed before marker 2 -> the saddle goes to label 1.
+	expect = np.array([
+		[1, 1, 1, 0, 2, 2, 2],
+		[1, 1, 1, 1, 2, 2, 2],
+		[1, 1, 1, 0, 2, 2, 2]])
+	np.testing.assert_array_equal(_ws(Z, m), expect)
+
+
+def test_watershed_plateau_tie_is_broken_by_age():
+	# a flat plateau between two markers: equal values pop in push order (age), i.e. breadth-first from both markers,
+	# marker 1's neighbours first in every generation
+	Z = np.full((1, 8), 5)
+	m = np.zeros_like(Z)
+	m[0, 0], m[0, 7] = 1, 2
+	np.testing.assert_array_equal(_ws(Z, m), np.array([[1, 1, 1, 1, 2, 2, 2, 2]]))
+	Z = np.full((1, 7), 5)     # odd gap: the middle pixel is reached by label 1 one push earlier
+	m = np.zeros_like(Z)
+	m[0, 0], m[0, 6] = 1, 2
+	np.testing.assert_array_equal(_ws(Z, m), np.array([[1, 1, 1, 1, 2, 2, 2]]))
+
+
+def test_watershed_marker_outside_mask_is_dropped_and_mask_blocks_flow():
+	Z = np.array([
+		[5, 4, 0, 3, 6],
+		[4, 3, 0, 2, 3],
+		[0, 0, 0, 0, 0],
+		[1, 1, 0, 2, 7]])
+	m = np.zeros_like(Z)
+	m[0, 0] = 1
+	m[2, 2] = 2      # on a zero (masked-out) pixel: markers * mask removes it
+	m[3, 4] = 3
+	expect = np.array([
+		[1, 1, 0, 0, 0],      # the right-hand island has no marker inside the mask component -> stays 0
+		[1, 1, 0, 0, 0],
+		[0, 0, 0, 0, 0],
+		[0, 0, 0, 3, 3]])     # bottom-left island: no marker -> 0; bottom-right: label 3
+	np.testing.assert_array_equal(_ws(Z, m), expect)
+
+
+def test_watershed_one_pixel_bridge_and_no_diagonal_flow():
+	# connectivity 1: the diagonal contact between the two blobs does NOT connect them; the one-pixel bridge does
+	Z = np.array([
+		[9, 8, 0, 0],
+		[7, 6, 0, 0],
+		[0, 0, 5, 4],
+		[0, 0, 3, 2]])
+	m = np.zeros_like(Z)
+	m[0, 0] = 1
+	np.testing.assert_array_equal(_ws(Z, m), np.array([[1, 1, 0, 0], [1, 1, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]]))
+	Z[1, 2] = 1        # bridge (1,1)-(1,2)-(2,2)
+	np.testing.assert_array_equal(_ws(Z, m), np.array([[1, 1, 0, 0], [1, 1, 1, 0], [0, 0, 1, 1], [0, 0, 1, 1]]))
+
+
+# ---- scikit-image peak_local_max (3x3 footprint, exclude_border=False, threshold_rel=0) ----------------------------
+def test_peak_local_max_hand_cases():
+	fp = np.ones((3, 3), dtype=bool)
+	# flat image: every pixel equals its neighbourhood maximum -> "no peak for a trivial image"
+	assert len(k2p2.peak_local_max(np.full((5, 5), 2.0), footprint=fp)) == 0
+	# all zeros
+	assert len(k2p2.peak_local_max(np.zeros((4, 4)), footprint=fp)) == 0
+	# peaks on the border and in a corner are kept (exclude_border=False), sorted by decreasing intensity
+	img = np.zeros((5, 6))
+	img[0, 0] = 3.0       # corner
+	img[2, 5] = 7.0       # right border
+	img[3, 2] = 5.0       # interior
+	img[3, 3] = 4.0       # neighbour of a larger value: not a peak
+	np.testing.assert_array_equal(k2p2.peak_local_max(img, footprint=fp), np.array([[2, 5], [3, 2], [0, 0]]))
+	# a two-pixel plateau: both pixels equal the local maximum -> both are peaks (no plateau merging in 0.19.2)
+	img = np.zeros((4, 5))
+	img[1, 1] = img[1, 2] = 6.0
+	got = {tuple(p) for p in k2p2.peak_local_max(img, footprint=fp)}
+	assert got == {(1, 1), (1, 2)}
+	# threshold: image > max(image.min(), threshold_rel * image.max()); a pixel equal to the minimum is never a peak
+	img = np.array([[1.0, 1.0, 1.0], [1.0, 1.0, 1.0], [1.0, 1.0, 2.0]])
+	np.testing.assert_array_equal(k2p2.peak_local_max(img, footprint=fp), np.array([[2, 2]]))
+	# threshold = max(image.min(), 0 * image.max()) = 0 for a non-positive image: no pixel is above it, no peaks
+	img = -np.ones((3, 3))
+	img[1, 1] = -0.5
+	assert len(k2p2.peak_local_max(img, footprint=fp)) == 0
