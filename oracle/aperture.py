@@ -20,6 +20,7 @@ Arithmetic notes (all reproduced here and on the device):
 import logging
 import numpy as np
 from . import k2p2 as k2p2_oracle
+from . import sumimage as sumimage_oracle
 from .utilities import mag2flux
 
 STATUS_UNKNOWN, STATUS_OK, STATUS_ERROR, STATUS_WARNING, STATUS_ABORT, STATUS_SKIPPED, STATUS_STARTED = 0, 1, 2, 3, 4, 5, 6
@@ -278,4 +279,199 @@ def do_photometry(sumimage, images, images_err, backgrounds, stamp,
 		my_status = STATUS_WARNING
 	res['status'] = my_status
 	logger.debug("oracle aperture status %d", my_status)
+	return res
+
+
+#--------------------------------------------------------------------------------------------------
+# The plugin INCLUDING its stamp handling: what run_tessphot does for one FFI target
+#--------------------------------------------------------------------------------------------------
+def default_stamp(tmag):
+	"""``BasePhotometry.default_stamp`` (BasePhotometry.py:521-564)."""
+	tm = np.array([0.0, 0.52631579, 1.05263158, 1.57894737, 2.10526316,
+		2.63157895, 3.15789474, 3.68421053, 4.21052632, 4.73684211,
+		5.26315789, 5.78947368, 6.31578947, 6.84210526, 7.36842105,
+		7.89473684, 8.42105263, 8.94736842, 9.47368421, 10.0, 13.0])
+	height = np.array([831.98319063, 533.58494422, 344.0840884, 223.73963332,
+		147.31365728, 98.77856016, 67.95585074, 48.38157414,
+		35.95072974, 28.05639497, 23.043017, 19.85922009,
+		17.83731732, 16.5532873, 15.73785092, 15.21999971,
+		14.89113301, 14.68228285, 14.54965042, 14.46542084, 14.0])
+	width = np.array([157.71602062, 125.1238281, 99.99440209, 80.61896267,
+		65.6799962, 54.16166547, 45.28073365, 38.4333048,
+		33.15375951, 28.05639497, 23.043017, 19.85922009,
+		17.83731732, 16.5532873, 15.73785092, 15.21999971,
+		14.89113301, 14.68228285, 14.54965042, 14.46542084, 14.0])
+	Ncolumns = np.interp(tmag, tm, width)
+	Nrows = np.interp(tmag, tm, height)
+	Nrows = np.maximum(np.ceil(Nrows), 15)
+	Ncolumns = np.maximum(np.ceil(Ncolumns), 15)
+	return Nrows, Ncolumns
+
+
+class FrameTarget(object):
+	"""
+	The stamp state of one FFI target of the reference's ``BasePhotometry``: ``_set_stamp`` / ``resize_stamp``
+	(BasePhotometry.py:567-693), the FFI branch of ``_load_cube`` (:720-742), ``sumimage`` (:1008-1019), ``aperture`` (:1043)
+	and the catalogue of the stamp plus its 5-pixel buffer (:1094-1181), over frames held in memory.
+
+	``frames``: dict of float32 ``(R, C, T)`` arrays ``images, images_err, backgrounds`` covering CCD rows ``[row0, row0+R)``
+	and columns ``[col0, col0+C)``; ``catalog``: dict of arrays ``starid, tmag, row, column`` of every star of the region.
+	"""
+
+	def __init__(self, frames, row0, col0, quality, catalog, starid, tmag, pos_row, pos_column):
+		self.frames, self.row0, self.col0 = frames, int(row0), int(col0)
+		R, C, _ = frames['images'].shape
+		self._max_stamp = (self.row0, self.row0 + R, self.col0, self.col0 + C)
+		self.quality, self.catalog_all = np.asarray(quality), catalog
+		self.starid, self.tmag = starid, tmag
+		self.target_pos_row, self.target_pos_column = pos_row, pos_column
+		self._stamp = None
+		self.stamp_resizes = 0
+		self._set_stamp()
+
+	def _set_stamp(self, compare_stamp=None):
+		if not self._stamp:
+			Nrows, Ncolumns = default_stamp(self.tmag)
+			self._stamp = (
+				int(np.round(self.target_pos_row)) - Nrows//2,
+				int(np.round(self.target_pos_row)) + Nrows//2 + 1,
+				int(np.round(self.target_pos_column)) - Ncolumns//2,
+				int(np.round(self.target_pos_column)) + Ncolumns//2 + 1
+			)
+		st = list(self._stamp)
+		st[0] = int(np.maximum(st[0], self._max_stamp[0]))
+		st[1] = int(np.minimum(st[1], self._max_stamp[1]))
+		st[2] = int(np.maximum(st[2], self._max_stamp[2]))
+		st[3] = int(np.minimum(st[3], self._max_stamp[3]))
+		self._stamp = tuple(st)
+		if self._stamp[0] > self._stamp[1] or self._stamp[2] > self._stamp[3]:
+			raise ValueError("Invalid stamp selected")
+		if self._stamp == compare_stamp:
+			return False
+		self.target_pos_row_stamp = self.target_pos_row - self._stamp[0]
+		self.target_pos_column_stamp = self.target_pos_column - self._stamp[2]
+		return True
+
+	def resize_stamp(self, down=None, up=None, left=None, right=None):
+		old_stamp = self._stamp
+		st = list(self._stamp)
+		if up:
+			st[1] += up
+		if down:
+			st[0] -= down
+		if left:
+			st[2] -= left
+		if right:
+			st[3] += right
+		self._stamp = tuple(st)
+		stamp_changed = self._set_stamp(compare_stamp=old_stamp)
+		if stamp_changed:
+			self.stamp_resizes += 1
+		return stamp_changed
+
+	@property
+	def stamp(self):
+		return self._stamp
+
+	def cube(self, name):
+		r1, r2, c1, c2 = self._stamp
+		return np.ascontiguousarray(self.frames[name][r1 - self.row0:r2 - self.row0, c1 - self.col0:c2 - self.col0, :])
+
+	def sumimage(self):
+		return sumimage_oracle.sumimage(self.cube('images'), self.quality)
+
+	def catalog(self, buffer_size=5):
+		r1, r2, c1, c2 = self._stamp
+		row, col = np.asarray(self.catalog_all['row']), np.asarray(self.catalog_all['column'])
+		sel = (row >= r1 - 0.5 - buffer_size) & (row < r2 - 0.5 + buffer_size) & (col >= c1 - 0.5 - buffer_size) & (col < c2 - 0.5 + buffer_size)
+		c = {k: np.asarray(v)[sel] for k, v in self.catalog_all.items()}
+		col64, row64 = np.asarray(c['column'], dtype='float64'), np.asarray(c['row'], dtype='float64')
+		return {'starid': np.asarray(c['starid'], dtype='int64'), 'tmag': np.asarray(c['tmag'], dtype='float32'),
+			'column': col64.astype('float32'), 'row': row64.astype('float32'),
+			'column_stamp': (col64 - self._stamp[2]).astype('float32'), 'row_stamp': (row64 - self._stamp[0]).astype('float32')}
+
+
+def photometry_on_frames(tgt, haloswitch=(6.0, 0.01)):
+	"""
+	``AperturePhotometry.do_photometry`` (photometry.py:44-257) with its stamp-resize loop (:75-170) for a
+	:class:`FrameTarget`.  Returns the dict of :func:`do_photometry` plus ``stamp`` and ``stamp_resizes``.
+	"""
+	res = {'status': STATUS_UNKNOWN, 'errors': [], 'details': {}, 'additional_headers': {}}
+	ExpectedFlux = mag2flux(tgt.tmag)
+	haloswitch_tmag_limit, haloswitch_flux_limit = haloswitch
+	allow_retries = 5
+	if tgt.tmag < 6:
+		allow_retries = 10
+
+	resize_args = {}
+	for retries in range(allow_retries):
+		SumImage = tgt.sumimage()
+		catalog = tgt.catalog()
+		cat = np.column_stack((catalog['column_stamp'], catalog['row_stamp'], catalog['tmag']))
+		try:
+			mm, _ = k2p2_oracle.k2p2FixFromSum(SumImage, catalog=cat, **K2P2_SETTINGS)
+			mm = None if mm is None else np.asarray(mm, dtype='bool')
+		except k2p2_oracle.K2P2NoStars:
+			res['errors'].append('ERROR: No flux above threshold.')
+			mm = None
+		mask_main, using_minimum_mask, err = select_mask(mm, tgt.target_pos_row_stamp, tgt.target_pos_column_stamp)
+		if err is not None:
+			res['errors'].append('ERROR: ' + err)
+			res['status'] = STATUS_ERROR
+			res['stamp'], res['stamp_resizes'] = tgt.stamp, tgt.stamp_resizes
+			return res
+		if using_minimum_mask:
+			res['errors'].append('WARNING: No masks found. Using minimum aperture.' if mm is None
+				else 'WARNING: No mask found for main target. Using minimum aperture.')
+			aperture = np.asarray(np.isfinite(SumImage), dtype='int32') # BasePhotometry.py:1043
+			mask_main = minimum_aperture(tgt.stamp, tgt.target_pos_row, tgt.target_pos_column, aperture)
+
+		resize_args = edge_flags(mask_main)
+		if resize_args:
+			stamp_before = tgt.stamp
+			sumimage_before = SumImage
+			if not tgt.resize_stamp(**resize_args):
+				resize_args = {}
+				res['errors'].append('WARNING: Could not resize stamp any further.')
+				break
+			if tgt.tmag <= haloswitch_tmag_limit:
+				edge = np.zeros_like(mask_main, dtype='bool')
+				if resize_args.get('down') and tgt.stamp[0] == stamp_before[0]:
+					edge[0, :] = True
+				if resize_args.get('up') and tgt.stamp[1] == stamp_before[1]:
+					edge[-1, :] = True
+				if resize_args.get('left') and tgt.stamp[2] == stamp_before[2]:
+					edge[:, 0] = True
+				if resize_args.get('right') and tgt.stamp[3] == stamp_before[3]:
+					edge[:, -1] = True
+				if np.any(edge):
+					EdgeFlux = np.nansum(sumimage_before[mask_main & edge])
+					if EdgeFlux/ExpectedFlux > haloswitch_flux_limit:
+						res['errors'].append('ERROR: Stamp resize hit limit. Haloswitch quick break.')
+						res['details']['edge_flux'] = EdgeFlux
+						res['status'] = STATUS_ERROR
+						res['stamp'], res['stamp_resizes'] = tgt.stamp, tgt.stamp_resizes
+						return res
+		else:
+			break
+
+	res['stamp'], res['stamp_resizes'] = tgt.stamp, tgt.stamp_resizes
+	if resize_args:
+		res['errors'].append('ERROR: Too many stamp resizes.')
+		res['status'] = STATUS_ERROR
+		return res
+
+	lc = extract(tgt.cube('images'), tgt.cube('images_err'), tgt.cube('backgrounds'), mask_main, tgt.stamp)
+	res.update(lc)
+	res['mask'] = mask_main
+	res['sumimage'] = SumImage
+	res['using_minimum_mask'] = using_minimum_mask
+	cont, my_status, target_in_mask, skip_targets = contamination(mask_main, tgt.stamp, catalog, tgt.starid, tgt.tmag)
+	if my_status == STATUS_ERROR:
+		res['errors'].append('ERROR: No targets in mask.')
+	res['contamination'] = cont
+	res['skip_targets'] = skip_targets
+	if using_minimum_mask:
+		my_status = STATUS_WARNING
+	res['status'] = my_status
 	return res

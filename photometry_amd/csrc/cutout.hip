@@ -6,10 +6,13 @@
 // 1300 float32 = 21.8 GB per cube, three cubes fit several times into 288 GB) and ALL stamps of a batch are cut in
 // one launch: a transposing gather from image-major frames to the time-fastest cube layout.
 //
-// Mapping (gfx950): one 256-thread workgroup per (target, block of 64 cadences).  Load phase: 16 lanes per stamp
-// row segment (W <= 16 contiguous floats of a frame row), tile[k][pixel] in LDS; store phase: 64 consecutive
-// cadences of one pixel per wavefront instruction = 256 B contiguous in the cube.  LDS row stride = P | 1 floats, so
-// the transposed reads (stride P between lanes) fall on distinct banks.
+// Mapping (gfx950): one 256-thread workgroup per (target, block of 64 cadences, band of stamp rows).  Load phase: 16 lanes
+// per stamp row segment (W <= 16 contiguous floats of a frame row), tile[k][pixel of the band] in LDS; store phase: 64
+// consecutive cadences of one pixel per wavefront instruction = 256 B contiguous in the cube.  LDS row stride = band pixels | 1
+// floats, so the transposed reads (stride between lanes) fall on distinct banks.  The band (about 64 pixels: 4 rows of a 15-wide
+// stamp, 16 KB of LDS) is what lets 8+ workgroups share a CU: the reads are scattered 60-byte pieces whose latency only
+// occupancy hides (a whole 15x15 stamp per workgroup, 58 KB of LDS and 8 waves per CU, ran at 8.0 ms per 10 k-stamp cube),
+// and it removes any limit on the stamp size (the stamp-resize retries of the aperture plugin cut 39x19, 62x17 ... stamps).
 // HBM-bound: algorithmic bytes per target = 2 * P * T * 4 (read + write); the reads are 60-byte segments of 8 KiB
 // frame rows, so the real fetch traffic is about twice the algorithmic one (whole 128-byte lines).
 // Pixels outside the frame (the reference never produces such stamps: it clips them, BasePhotometry.py:643-679) are NaN.
@@ -25,15 +28,18 @@ struct CutArgs {
 	const int32_t* stamps; int height, width; int64_t t_pitch; float* cube;
 };
 
-__global__ __launch_bounds__(256) void tp_cut_stamps_kernel(CutArgs a)
+__global__ __launch_bounds__(256) void tp_cut_stamps_kernel(CutArgs a, int band_rows)
 {
 	extern __shared__ float tile[]; // [kCadBlock][ldp]
 	const int target = blockIdx.x;
 	const int k0 = blockIdx.y * kCadBlock;
 	const int tid = threadIdx.x;
-	const int H = a.height, W = a.width, P = H * W;
-	const int ldp = P | 1;
-	const int r0 = a.stamps[target * 4 + 0] - a.row_offset;
+	const int W = a.width;
+	const int row_first = blockIdx.z * band_rows;                                   // first stamp row of this band
+	const int H = (a.height - row_first < band_rows) ? (a.height - row_first) : band_rows;   // rows in this band
+	const int P = H * W;
+	const int ldp = (band_rows * W) | 1;
+	const int r0 = a.stamps[target * 4 + 0] - a.row_offset + row_first;
 	const int c0 = a.stamps[target * 4 + 2] - a.col_offset;
 	const float nan = __builtin_nanf("");
 	// ---- load: (cadence, stamp row) pairs, 16 lanes across the columns of a row segment
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256) void tp_cut_stamps_kernel(CutArgs a)
 	__syncthreads();
 	// ---- store: 64 consecutive cadences of one pixel per wavefront
 	const int lane = tid & 63, wave = tid >> 6;
-	float* out = a.cube + (int64_t)target * P * a.t_pitch;
+	float* out = a.cube + ((int64_t)target * a.height * W + (int64_t)row_first * W) * a.t_pitch;
 	if (k0 + lane < a.n_frames) {
 		for (int p = wave; p < P; p += 4) out[(int64_t)p * a.t_pitch + k0 + lane] = tile[lane * ldp + p];
 	}
@@ -95,17 +101,22 @@ extern "C" int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frame
 	TP_REQUIRE(ctx, n_frames == desc->n_cad, "tp_cut_stamps: the cube must have one cadence per frame");
 	TP_REQUIRE(ctx, frame_rows > 0 && frame_cols > 0 && row_pitch >= frame_cols && frame_stride >= (int64_t)frame_rows * row_pitch, "tp_cut_stamps: bad frame geometry");
 	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
-	const int P = desc->height * desc->width;
-	const size_t shmem = (size_t)kCadBlock * (P | 1) * sizeof(float);
-	TP_REQUIRE(ctx, shmem <= 160 * 1024, "tp_cut_stamps: stamp too large for the LDS transpose tile (about 25x25 pixels)");
+	// rows per band: about 64 pixels (16 KB of LDS); at least one row whatever the width
+	int band_rows = 64 / desc->width;
+	if (band_rows < 1) band_rows = 1;
+	if (band_rows > desc->height) band_rows = desc->height;
+	const size_t shmem = (size_t)kCadBlock * ((band_rows * desc->width) | 1) * sizeof(float);
+	TP_REQUIRE(ctx, shmem <= 160 * 1024, "tp_cut_stamps: stamp rows wider than 639 pixels are not supported");
+	const int n_bands = (desc->height + band_rows - 1) / band_rows;
+	TP_REQUIRE(ctx, n_bands <= 65535 && (desc->n_cad + kCadBlock - 1) / kCadBlock <= 65535, "tp_cut_stamps: too many bands / cadence blocks");
 	CutArgs a;
 	a.frames = d_frames; a.n_frames = n_frames; a.frame_rows = frame_rows; a.frame_cols = frame_cols;
 	a.row_pitch = row_pitch; a.frame_stride = frame_stride; a.row_offset = row_offset; a.col_offset = col_offset;
 	a.stamps = d_stamps; a.height = desc->height; a.width = desc->width; a.t_pitch = desc->t_pitch; a.cube = d_cube;
 	if (shmem > 64 * 1024)
 		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_cut_stamps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-	dim3 grid((unsigned)desc->n_targets, (unsigned)((desc->n_cad + kCadBlock - 1) / kCadBlock));
-	TP_LAUNCH(ctx, TPK_CUTOUT, tp_cut_stamps_kernel, grid, dim3(256), shmem, a);
+	dim3 grid((unsigned)desc->n_targets, (unsigned)((desc->n_cad + kCadBlock - 1) / kCadBlock), (unsigned)n_bands);
+	TP_LAUNCH(ctx, TPK_CUTOUT, tp_cut_stamps_kernel, grid, dim3(256), shmem, a, band_rows);
 	TP_LAUNCH_CHECK(ctx, "tp_cut_stamps_kernel");
 	return TP_OK;
 	TP_API_END(ctx)

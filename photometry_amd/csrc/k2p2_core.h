@@ -1356,7 +1356,11 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 			const int r = p / W, c = p - r * W;
 			const double dc = ((double)(t.stamp_col0 + c + 1) - t.tpos_col) - 1.0;
 			const double dr = ((double)(t.stamp_row0 + r + 1) - t.tpos_row) - 1.0;
-			k.res[p] = (fabs(dc) <= 1.0 && fabs(dr) <= 1.0 && (t.aperture[p] & 1) != 0) ? 1 : 0;
+			// bit 1 of BasePhotometry.aperture is "pixel collected" = finite sum image (BasePhotometry.py:1043): enforced here as well,
+			// so that a caller without the sum image (it is computed in this very launch) may pass an all-ones aperture
+			const double sv = t.S[p];
+			const bool collected = (t.aperture[p] & 1) != 0 && (fabs(sv) <= 1.7976931348623157e308);
+			k.res[p] = (fabs(dc) <= 1.0 && fabs(dr) <= 1.0 && collected) ? 1 : 0;
 		}
 		TP_SYNC();
 		flags |= FLAG_MIN_APERTURE;

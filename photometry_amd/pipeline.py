@@ -254,3 +254,185 @@ def linpsf_step(ctx, batch, cutoff_radius=5.0):
 	engine.linpsf_fit(ctx, batch.images, batch.coef, batch.tx, batch.ty, batch.star_offsets, batch.target_index,
 		batch.pos_row, batch.pos_col, batch.max_stars, cutoff_radius=cutoff_radius, subtract=batch.subtract, out=batch.out)
 	return batch.out
+
+
+#--------------------------------------------------------------------------------------------------
+# Aperture photometry of many targets of one CCD region, INCLUDING the stamp-resize retries
+#--------------------------------------------------------------------------------------------------
+class FrameStack(object):
+	"""
+	The image groups of one CCD region resident in HBM -- what the reference keeps in its HDF5 file as ``images/%04d``,
+	``images_err/%04d``, ``backgrounds/%04d`` (prepare.py:136-141) and reads back cut-out by cut-out for every target and every
+	stamp resize (BasePhotometry.py:720-751).  ``frames``: dict of float32 host arrays ``(T, R, C)`` covering CCD rows
+	``[row0, row0 + R)`` and columns ``[col0, col0 + C)`` (``row0 / col0`` = PIXEL_OFFSET_ROW / COLUMN of the file).
+	"""
+
+	def __init__(self, ctx, frames, row0, col0):
+		self.ctx = ctx
+		self.row0, self.col0 = int(row0), int(col0)
+		self.names = ('images', 'images_err', 'backgrounds')
+		self.dev = {k: ctx.array(np.ascontiguousarray(frames[k], dtype='float32')) for k in self.names}
+		self.n_cad, self.n_rows, self.n_cols = self.dev['images'].shape
+		self.limits = (self.row0, self.row0 + self.n_rows, self.col0, self.col0 + self.n_cols)
+
+	def cut(self, stamps_dev, height, width):
+		"""The three stamp cubes of a group of same-sized stamps (``tp_cut_stamps``)."""
+		return {k: engine.cut_stamps(self.ctx, self.dev[k], stamps_dev, height, width, self.row0, self.col0) for k in self.names}
+
+
+class _Messages(object):
+	"""Collects what the reference's plugin would have logged at WARNING level and above, as ``"LEVEL: message"`` strings."""
+	def __init__(self):
+		self.items = []
+
+	def error(self, msg, *a):
+		self.items.append('ERROR: ' + (msg % a if a else msg))
+
+	def warning(self, msg, *a):
+		self.items.append('WARNING: ' + (msg % a if a else msg))
+
+	def info(self, msg, *a):
+		pass
+
+
+def _catalog_of_stamp(catalog, stamp, buffer_size=5):
+	"""Stars inside the stamp plus its 5-pixel buffer with the float32 stamp coordinates of BasePhotometry.catalog
+	(BasePhotometry.py:1094-1181); the same selection as ``source.MemoryStampSource.catalog_in_stamp``."""
+	r1, r2, c1, c2 = stamp
+	row, col = catalog['row'], catalog['column']
+	sel = (row >= r1 - 0.5 - buffer_size) & (row < r2 - 0.5 + buffer_size) & (col >= c1 - 0.5 - buffer_size) & (col < c2 - 0.5 + buffer_size)
+	col64, row64 = np.asarray(col[sel], dtype='float64'), np.asarray(row[sel], dtype='float64')
+	return {'starid': np.asarray(catalog['starid'][sel], dtype='int64'), 'tmag': np.asarray(catalog['tmag'][sel], dtype='float32'),
+		'column': col64.astype('float32'), 'row': row64.astype('float32'),
+		'column_stamp': (col64 - c1).astype('float32'), 'row_stamp': (row64 - r1).astype('float32')}
+
+
+class _GroupScene(object):
+	"""The metadata of a group of same-sized stamps in the form ``ApertureBatch`` takes (no host cubes)."""
+	def __init__(self, stack, time, quality, cadence_s, stamps_list, cats, targets, idx):
+		self.n_targets = len(idx)
+		self.n_cad = stack.n_cad
+		self.height, self.width = stamps_list[0][1] - stamps_list[0][0], stamps_list[0][3] - stamps_list[0][2]
+		self.time, self.quality, self.cadence_s = time, quality, cadence_s
+		self.stamps = np.asarray(stamps_list, dtype='int32')
+		counts = [len(c['starid']) for c in cats]
+		self.cat_offsets = np.concatenate(([0], np.cumsum(counts))).astype('int64')
+		self.catalog = {k: (np.concatenate([c[k] for c in cats]) if cats else np.zeros(0)) for k in ('starid', 'tmag', 'row', 'column', 'row_stamp', 'column_stamp')}
+		self.target_pos_row = np.asarray(targets['row'], dtype='float64')[idx]
+		self.target_pos_column = np.asarray(targets['column'], dtype='float64')[idx]
+		self.target_tmag = np.asarray(targets['tmag'], dtype='float64')[idx]
+		self.target_starid = np.asarray(targets['starid'], dtype='int64')[idx]
+		self.aperture = None
+
+
+def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, cadence_s=1800, datasource='ffi'):
+	"""
+	``AperturePhotometry.do_photometry`` INCLUDING its stamp-resize loop (photometry.py:75-170) for every target of a CCD region
+	held in a :class:`FrameStack`: round after round, the targets still in play are grouped by stamp size, their stamps are cut
+	out of the frames on the device, one fused pass per group produces sum image, mask and light curve, and the edge flags
+	decide -- with the plugin's own rules (:mod:`photometry_amd.stamps`) -- who is finished, who gets a bigger stamp, and who
+	gives up ("Too many stamp resizes." / "Stamp resize hit limit. Haloswitch quick break.").
+
+	``targets``: dict of arrays ``starid, tmag, row, column`` (CCD positions, float64); ``catalog``: the same columns for every
+	star of the region.  Returns one dict per target (``status, stamp, stamp_resizes, errors`` and, unless it ended in an
+	error before the extraction, ``mask, sumimage, flux, flux_err, flux_background, pos_centroid, contamination,
+	skip_targets, diagnostics``).
+	"""
+	from . import stamps as st
+	from .plugins import load_settings, mag2flux, mask_outcome
+	from ._lib import TessphotError
+	settings = load_settings() if settings is None else settings
+	tmag_limit = settings.getfloat('haloswitch', 'tmag_limit')
+	flux_limit = settings.getfloat('haloswitch', 'flux_limit')
+	n = len(targets['starid'])
+	catalog = {k: np.asarray(v) for k, v in catalog.items()}
+	time = np.asarray(time, dtype='float64')
+	quality = np.asarray(quality, dtype='int32')
+	out = [{'status': 0, 'errors': [], 'stamp_resizes': 0} for _ in range(n)]
+	log = [_Messages() for _ in range(n)]
+	cur = []
+	for i in range(n):
+		try:
+			cur.append(st.default_stamp(targets['row'][i], targets['column'][i], targets['tmag'][i], stack.limits))
+		except ValueError as e: # BasePhotometry.py:671-672: the constructor raises -> STATUS.ERROR through tessphot
+			cur.append(None)
+			out[i].update(status=2, errors=['ValueError: ' + str(e)])
+	attempts_left = [st.retry_limit(targets['tmag'][i]) for i in range(n)]
+	active = [i for i in range(n) if cur[i] is not None]
+
+	def finish(i, status):
+		out[i]['status'] = int(status)
+		out[i]['stamp'] = cur[i]
+		out[i]['errors'] = out[i]['errors'] + log[i].items
+
+	while active:
+		groups = {}
+		for i in active:
+			groups.setdefault((cur[i][1] - cur[i][0], cur[i][3] - cur[i][2]), []).append(i)
+		still = []
+		for (H, W), idx in sorted(groups.items()):
+			cats = [_catalog_of_stamp(catalog, cur[i]) for i in idx]
+			scene = _GroupScene(stack, time, quality, cadence_s, [cur[i] for i in idx], cats, targets, np.asarray(idx))
+			try:
+				cubes = stack.cut(ctx.array(scene.stamps), H, W)
+				batch = ApertureBatch(ctx, scene, cubes=cubes)
+				work = ApertureWork(ctx, batch)
+				aperture_step(ctx, batch, work)
+				aperture_diagnostics(ctx, batch, work)
+				ctx.sync()
+			except TessphotError as e:
+				# e.g. a stamp beyond the LDS-resident mask kernel (54 x 54): the bright-star tail, Halo territory upstream
+				for i in idx:
+					log[i].error('Device pass failed for a %dx%d stamp: %s', H, W, str(e))
+					finish(i, 2)
+				continue
+			res = {k: getattr(work, k).to_host() for k in ('sumimage', 'mask', 'status', 'flags', 'contamination', 'cat_in_mask', 'diagnostics')}
+			lc = work.lc.to_host()
+			for c in cubes.values():
+				c.free()
+			for j, i in enumerate(idx):
+				attempts_left[i] -= 1
+				flags = int(res['flags'][j])
+				try:
+					if mask_outcome(flags, log[i]) == 'error':
+						finish(i, 2)
+						continue
+				except RuntimeError as e: # an uncaught exception of the reference's plugin -> STATUS.ERROR (tessphot.py:37-49)
+					out[i]['errors'].append('RuntimeError: ' + str(e))
+					finish(i, 2)
+					continue
+				mask = res['mask'][j].astype(bool)
+				wanted = st.edge_requests(flags)
+				if wanted:
+					new = st.moved(cur[i], stack.limits, **wanted)
+					if new == cur[i]:
+						log[i].warning("Could not resize stamp any further.")
+					else:
+						out[i]['stamp_resizes'] += 1
+						before, cur[i] = cur[i], new
+						bright = targets['tmag'][i] <= tmag_limit and not datasource.startswith('tpf:')
+						stuck = st.quick_break_flux(res['sumimage'][j], mask, before, new, wanted) if bright else None
+						if stuck is not None and stuck > flux_limit * mag2flux(targets['tmag'][i]):
+							log[i].error('Stamp resize hit limit. Haloswitch quick break.')
+							out[i]['edge_flux'] = stuck
+							finish(i, 2)
+						elif attempts_left[i] == 0:
+							log[i].error('Too many stamp resizes.')
+							finish(i, 2)
+						else:
+							still.append(i)
+						continue
+				# this attempt stands
+				a, b = scene.cat_offsets[j], scene.cat_offsets[j + 1]
+				inside = res['cat_in_mask'][a:b].astype(bool)
+				status = int(res['status'][j])
+				if flags >> 8 == 6:
+					log[i].error("No targets in mask.")
+				out[i].update(mask=mask, sumimage=res['sumimage'][j], flux=lc['flux'][j], flux_err=lc['flux_err'][j],
+					flux_background=lc['flux_background'][j], pos_centroid=lc['pos_centroid'][j],
+					contamination=float(res['contamination'][j]),
+					skip_targets=[int(s) for s in cats[j]['starid'][inside] if s != targets['starid'][i]],
+					diagnostics=dict(zip(engine.DIAGNOSTICS_COLUMNS, res['diagnostics'][j])))
+				finish(i, status)
+		active = still
+	return out

@@ -9,7 +9,7 @@ A plugin object handles ONE target exactly like the reference's: ``pho.photometr
 ``_details`` and returns a :class:`STATUS`.  Inside, the target is a batch of one for the same
 kernels the batched pipeline uses (``photometry_amd.pipeline``); there is no CPU implementation
 of the numerics in this module -- without the HIP library / a GPU ``do_photometry`` raises, which
-``tessphot._try_photometry`` turns into ``STATUS.ERROR`` with the traceback in ``_details['errors']``
+``tessphot.run_plugin`` turns into ``STATUS.ERROR`` with the traceback in ``_details['errors']``
 like the reference does for any exception (tessphot.py:37-49).
 
 File I/O (HDF5 cut-outs, SQLite catalogues, SPICE, WCS, FITS light curves) is replaced by a
@@ -21,20 +21,28 @@ import logging
 import configparser
 import numpy as np
 from .status import STATUS
-from . import engine, pipeline
+from . import engine, pipeline, stamps
 
-#: photometry/data/settings.ini of the reference
+#: the values of the reference's photometry/data/settings.ini, used when no settings file is given
 DEFAULT_SETTINGS = {'todolist': {'faint_limit': '15.0'}, 'fixes': {'time_offset': 'True'},
 	'haloswitch': {'tmag_limit': '6.0', 'flux_limit': '0.01'}}
 
 TESS_DEFAULT_BITMASK = engine.TESS_DEFAULT_BITMASK
-mad_to_sigma = 1.482602218505602 #: photometry/utilities.py:25
 
 
-def load_settings():
-	"""io.load_settings (photometry/io.py:96-107) with the reference's defaults."""
+def load_settings(path=None):
+	"""
+	The pipeline settings (``io.load_settings``, photometry/io.py:96-107).  ``path`` or the environment variable
+	``TESSPHOT_SETTINGS`` names the reference's own ``photometry/data/settings.ini`` -- a maintainer who drops this package into
+	an installation points it there; otherwise the file's shipped values (:data:`DEFAULT_SETTINGS`) apply.
+	"""
 	s = configparser.ConfigParser()
 	s.read_dict(DEFAULT_SETTINGS)
+	path = path or os.environ.get('TESSPHOT_SETTINGS')
+	if path:
+		if not os.path.isfile(path):
+			raise FileNotFoundError(f"settings file not found: {path}")
+		s.read(path)
 	return s
 
 
@@ -79,32 +87,16 @@ class Table(object):
 			yield {k: v[i] for k, v in self.cols.items()}
 
 
-class ListHandler(logging.Handler):
-	"""utilities.ListHandler (photometry/utilities.py:439-458): collects ``"LEVEL: msg"`` strings."""
-	def __init__(self, message_queue, *args, **kwargs):
-		super().__init__(*args, **kwargs)
-		self.message_queue = message_queue
+class _DetailLog(logging.Handler):
+	"""Keeps the WARNING-and-above records of this package as ``"LEVEL: message"`` strings: the reference appends exactly
+	such strings to ``_details['errors']`` (BasePhotometry.py:175-179, :1409-1414) and the halo switch matches on them."""
+
+	def __init__(self, sink):
+		super().__init__(level=logging.WARNING)
+		self.sink = sink
 
 	def emit(self, record):
-		self.message_queue.append(record.levelname + ': ' + record.getMessage())
-
-
-def rms_timescale(time, flux, timescale=3600/86400):
-	"""utilities.rms_timescale (photometry/utilities.py:227-264)."""
-	from scipy.stats import binned_statistic
-	time, flux = np.asarray(time), np.asarray(flux)
-	if len(flux) == 0 or np.all(np.isnan(flux)):
-		return np.nan
-	if len(time) == 0 or np.all(np.isnan(time)):
-		raise ValueError("Invalid time-vector specified. No valid timestamps.")
-	time_min, time_max = np.nanmin(time), np.nanmax(time)
-	if not np.isfinite(time_min) or not np.isfinite(time_max) or time_max - time_min <= 0:
-		raise ValueError("Invalid time-vector specified")
-	bins = np.append(np.arange(time_min, time_max, timescale), time_max)
-	indx = np.isfinite(flux)
-	flux_bin, _, _ = binned_statistic(time[indx], flux[indx], np.nanmean, bins=bins)
-	med = np.nanmedian(flux_bin) if np.any(np.isfinite(flux_bin)) else np.nan
-	return mad_to_sigma * np.nanmedian(np.abs(flux_bin - med))
+		self.sink.append(f"{record.levelname}: {record.getMessage()}")
 
 
 #--------------------------------------------------------------------------------------------------
@@ -150,7 +142,7 @@ class BasePhotometry(object):
 
 		# collect WARNING+ log records of this package like BasePhotometry.py:175-179
 		self.message_queue = []
-		self._handler = ListHandler(message_queue=self.message_queue, level=logging.WARNING)
+		self._handler = _DetailLog(self.message_queue)
 		logging.getLogger('photometry_amd').addHandler(self._handler)
 
 		tgt = src.target(starid)
@@ -212,84 +204,49 @@ class BasePhotometry(object):
 	def status(self):
 		return self._status
 
-	# -- stamp logic (BasePhotometry.py:521-706) ---------------------------------------------------
+	# -- stamp logic (BasePhotometry.py:521-706): geometry in photometry_amd.stamps --------------------
+	@property
+	def _stamp_limits(self):
+		"""The CCD region the source has data for, in stamp coordinates (``_max_stamp`` shifted by the pixel offsets)."""
+		m = self._max_stamp
+		return (m[0] + self.pixel_offset_row, m[1] + self.pixel_offset_row, m[2] + self.pixel_offset_col, m[3] + self.pixel_offset_col)
+
 	def default_stamp(self):
-		"""BasePhotometry.py:521-564: stamp size as a function of Tmag, at least 15x15."""
-		tmag = np.array([0.0, 0.52631579, 1.05263158, 1.57894737, 2.10526316,
-			2.63157895, 3.15789474, 3.68421053, 4.21052632, 4.73684211,
-			5.26315789, 5.78947368, 6.31578947, 6.84210526, 7.36842105,
-			7.89473684, 8.42105263, 8.94736842, 9.47368421, 10.0, 13.0])
-		height = np.array([831.98319063, 533.58494422, 344.0840884, 223.73963332,
-			147.31365728, 98.77856016, 67.95585074, 48.38157414,
-			35.95072974, 28.05639497, 23.043017, 19.85922009,
-			17.83731732, 16.5532873, 15.73785092, 15.21999971,
-			14.89113301, 14.68228285, 14.54965042, 14.46542084, 14.0])
-		width = np.array([157.71602062, 125.1238281, 99.99440209, 80.61896267,
-			65.6799962, 54.16166547, 45.28073365, 38.4333048,
-			33.15375951, 28.05639497, 23.043017, 19.85922009,
-			17.83731732, 16.5532873, 15.73785092, 15.21999971,
-			14.89113301, 14.68228285, 14.54965042, 14.46542084, 14.0])
-		Ncolumns = np.interp(self.target['tmag'], tmag, width)
-		Nrows = np.interp(self.target['tmag'], tmag, height)
-		Nrows = np.maximum(np.ceil(Nrows), 15)
-		Ncolumns = np.maximum(np.ceil(Ncolumns), 15)
-		return Nrows, Ncolumns
+		"""(rows, columns) of the default stamp for this target's magnitude (BasePhotometry.py:521-564)."""
+		return stamps.default_stamp_size(self.target['tmag'])
 
 	def resize_stamp(self, down=None, up=None, left=None, right=None, width=None, height=None):
-		"""BasePhotometry.py:567-613"""
-		old_stamp = self._stamp
-		st = list(self._stamp)
-		if up:
-			st[1] += up
-		if down:
-			st[0] -= down
-		if left:
-			st[2] -= left
-		if right:
-			st[3] += right
-		if height:
-			st[0] = int(np.round(self.target_pos_row)) - height//2
-			st[1] = int(np.round(self.target_pos_row)) + height//2 + 1
-		if width:
-			st[2] = int(np.round(self.target_pos_column)) - width//2
-			st[3] = int(np.round(self.target_pos_column)) + width//2 + 1
-		self._stamp = tuple(st)
-		stamp_changed = self._set_stamp(compare_stamp=old_stamp)
-		if stamp_changed:
+		"""Grow / re-centre the stamp (BasePhotometry.py:567-613); ``True`` if it changed."""
+		wanted = stamps.moved(self._stamp, self._stamp_limits, self.target_pos_row, self.target_pos_column,
+			down=down, up=up, left=left, right=right, width=width, height=height)
+		changed = self._adopt_stamp(wanted)
+		if changed:
 			self._details['stamp_resizes'] = self._details.get('stamp_resizes', 0) + 1
-		return stamp_changed
+		return changed
 
 	def _set_stamp(self, compare_stamp=None):
-		"""BasePhotometry.py:616-693"""
+		"""First call: the default stamp (FFI) or the whole target pixel file (BasePhotometry.py:616-693)."""
 		if not self._stamp:
 			if self.datasource == 'ffi':
-				Nrows, Ncolumns = self.default_stamp()
-				self._stamp = (
-					int(np.round(self.target_pos_row)) - Nrows//2,
-					int(np.round(self.target_pos_row)) + Nrows//2 + 1,
-					int(np.round(self.target_pos_column)) - Ncolumns//2,
-					int(np.round(self.target_pos_column)) + Ncolumns//2 + 1
-				)
+				n_rows, n_columns = self.default_stamp()
+				wanted = stamps.centred_stamp(self.target_pos_row, self.target_pos_column, n_rows, n_columns)
 			else:
-				self._stamp = self._max_stamp
-		st = list(self._stamp)
-		st[0] = int(np.maximum(st[0], self._max_stamp[0] + self.pixel_offset_row))
-		st[1] = int(np.minimum(st[1], self._max_stamp[1] + self.pixel_offset_row))
-		st[2] = int(np.maximum(st[2], self._max_stamp[2] + self.pixel_offset_col))
-		st[3] = int(np.minimum(st[3], self._max_stamp[3] + self.pixel_offset_col))
-		self._stamp = tuple(st)
-		if self._stamp[0] > self._stamp[1] or self._stamp[2] > self._stamp[3]:
-			raise ValueError("Invalid stamp selected")
+				wanted = self._max_stamp
+		else:
+			wanted = self._stamp
+		limits = self._stamp_limits if self.datasource == 'ffi' else self._max_stamp
+		return self._adopt_stamp(stamps.clip_stamp(wanted, limits), compare_stamp)
+
+	def _adopt_stamp(self, stamp, previous=None):
+		"""Make ``stamp`` current; everything derived from the old cut-out is dropped.  ``False`` if nothing changed."""
+		previous = self._stamp if previous is None else previous
+		self._stamp = tuple(int(v) for v in stamp)
 		self._details['stamp'] = self._stamp
-		if self._stamp == compare_stamp:
+		if previous and self._stamp == tuple(previous):
 			return False
 		self.target_pos_row_stamp = self.target_pos_row - self._stamp[0]
 		self.target_pos_column_stamp = self.target_pos_column - self._stamp[2]
-		self._sumimage = None
-		self._catalog = None
-		self._cubes = None
-		self._aperture = None
-		self._psf = None
+		self._sumimage = self._catalog = self._cubes = self._aperture = self._psf = None
 		return True
 
 	def get_pixel_grid(self):
@@ -419,51 +376,54 @@ class BasePhotometry(object):
 
 	# -- wrapper with diagnostics (BasePhotometry.py:1323-1414) --------------------------------------
 	def photometry(self, *args, **kwargs):
+		"""
+		Run ``do_photometry`` and derive the light-curve diagnostics the scheduler stores (BasePhotometry.py:1337-1414):
+		the reductions run on the device (``tp_lightcurve_diagnostics``, the same kernel the batch path uses).
+		"""
 		logger = logging.getLogger(__name__)
 		self._status = self.do_photometry(*args, **kwargs)
 		if self._status == STATUS.UNKNOWN:
 			raise ValueError("STATUS was not set by do_photometry")
 		if self._status in (STATUS.OK, STATUS.WARNING):
-			lc = self.lightcurve
-			if np.all(np.isnan(lc['flux'])):
+			d = self._device_diagnostics()
+			problems = int(d['flags'])
+			if problems & 1:
 				raise ValueError("Final lightcurve fluxes are all NaNs")
-			if np.all(np.isnan(lc['flux_err'])):
+			if problems & 2:
 				raise ValueError("Final lightcurve errors are all NaNs")
-			indx_good = (np.asarray(lc['quality']) & TESS_DEFAULT_BITMASK) == 0
-			gflux, gerr, gtime = lc['flux'][indx_good], lc['flux_err'][indx_good], lc['time'][indx_good]
-			with np.errstate(invalid='ignore', divide='ignore'):
-				self._details['mean_flux'] = np.nanmedian(gflux)
-				flux = (gflux / self._details['mean_flux']) - 1
-				flux_err = np.abs(1/self._details['mean_flux']) * gerr
-				self._details['variance'] = np.nanvar(flux, ddof=1)
-				self._details['rms_hour'] = rms_timescale(gtime, flux, timescale=3600/86400)
-				self._details['ptp'] = np.nanmedian(np.abs(np.diff(flux)))
-				self._details['pos_centroid'] = np.nanmedian(lc['pos_centroid'][indx_good], axis=0)
-				indx = np.isfinite(gtime) & np.isfinite(flux) & np.isfinite(flux_err)
-				detrend = 0
-				if np.any(indx):
-					mintime = np.nanmin(gtime[indx])
-					try:
-						p = np.polyfit(gtime[indx] - mintime, flux[indx], 3, w=1/flux_err[indx])
-						detrend = np.polyval(p, gtime - mintime)
-					except Exception: # noqa: B902  (np.RankWarning / LinAlgError -> no detrending, BasePhotometry.py:1385-1387)
-						logger.warning("Could not detrend lightcurve for variability calculation.")
-				else:
-					logger.warning("Could not detrend lightcurve for variability calculation.")
-				self._details['variability'] = np.nanstd(flux - detrend) / np.nanmedian(flux_err)
+			if problems & 4:
+				raise ValueError("Invalid time-vector specified")
+			if problems & 8:
+				logger.warning("Could not detrend lightcurve for variability calculation.")
+			for key in ('mean_flux', 'variance', 'rms_hour', 'ptp', 'variability'):
+				self._details[key] = float(d[key])
+			self._details['pos_centroid'] = np.array([d['pos_centroid_col'], d['pos_centroid_row']])
 			if self.final_phot_mask is not None:
-				self._details['mask_size'] = int(np.sum(self.final_phot_mask))
-				edge = np.zeros_like(self.sumimage, dtype='bool')
-				edge[:, (0, -1)] = True
-				edge[(0, -1), 1:-1] = True
-				self._details['edge_flux'] = np.nansum(self.sumimage[self.final_phot_mask & edge])
-			if self.additional_headers and 'AP_CONT' in self.additional_headers:
+				self._details['mask_size'] = int(d['mask_size'])
+				self._details['edge_flux'] = float(d['edge_flux'])
+			if 'AP_CONT' in self.additional_headers:
 				self._details['contamination'] = self.additional_headers['AP_CONT'][0]
 		if self.message_queue:
-			if not self._details.get('errors'):
-				self._details['errors'] = []
-			self._details['errors'] += self.message_queue
-			self.message_queue.clear()
+			self._details.setdefault('errors', []).extend(self.message_queue)
+			del self.message_queue[:]
+
+	def _device_diagnostics(self):
+		"""The diagnostics block as a dict (columns of ``engine.DIAGNOSTICS_COLUMNS``) for this one light curve."""
+		ctx = self.ctx
+		lc = self.lightcurve
+		T = self.Ntimes
+		block = np.zeros((5, 1, T))
+		block[0, 0], block[1, 0] = lc['flux'], lc['flux_err']
+		block[3, 0], block[4, 0] = lc['pos_centroid'][:, 0], lc['pos_centroid'][:, 1]
+		dlc = engine.LightCurves(ctx, 1, T, block=ctx.array(block))
+		mask = sumimage = None
+		if self.final_phot_mask is not None:
+			mask = ctx.array(np.asarray(self.final_phot_mask, dtype='uint8')[None])
+			sumimage = ctx.array(np.asarray(self.sumimage, dtype='float64')[None])
+		out = engine.lightcurve_diagnostics(ctx, dlc, ctx.array(np.asarray(lc['time'], dtype='float64')),
+			ctx.array(np.asarray(lc['quality'], dtype='int32')), status=ctx.array(np.array([self._status.value], dtype='int32')),
+			sumimage=sumimage, mask=mask).to_host()[0]
+		return dict(zip(engine.DIAGNOSTICS_COLUMNS, out))
 
 	def save_lightcurve(self, output_folder=None, version=None):
 		"""
@@ -613,124 +573,109 @@ class _OneTargetScene(object):
 		self.cadence_s = pho.cadence if pho.cadence else 1800
 
 
+#: the K2P2 settings of the aperture plugin (photometry.py:54-64) and the FITS keywords they are reported under (:203-211)
+K2P2_SETTINGS = {'thresh': 0.8, 'min_no_pixels_in_mask': 4, 'min_for_cluster': 4,
+	'cluster_radius': np.sqrt(2) + np.finfo(np.float64).eps, 'segmentation': True, 'ws_blur': 0.5,
+	'ws_thres': 0, 'ws_footprint': 3, 'extend_overflow': True}
+K2P2_HEADERS = (('KP_THRES', 'thresh', 'K2P2 sum-image threshold'), ('KP_MIPIX', 'min_no_pixels_in_mask', 'K2P2 min pixels in mask'),
+	('KP_MICLS', 'min_for_cluster', 'K2P2 min pix. for cluster'), ('KP_CLSRA', 'cluster_radius', 'K2P2 cluster radius'),
+	('KP_WS', 'segmentation', 'K2P2 watershed segmentation'), ('KP_WSBLR', 'ws_blur', 'K2P2 watershed blur'),
+	('KP_WSTHR', 'ws_thres', 'K2P2 watershed threshold'), ('KP_WSFOT', 'ws_footprint', 'K2P2 watershed footprint'),
+	('KP_EX', 'extend_overflow', 'K2P2 extend overflow'))
+
+#: error kinds of the device flags (include/tessphot_hip.h) that are uncaught exceptions in the reference's plugin
+_MASK_EXCEPTIONS = {1: "K2P2NoFlux: No measured flux in sum-image", 2: "Selected KDE bandwidth is 0. Cannot estimate density.",
+	3: "attempt to get argmin of an empty sequence", 4: "index out of bounds for the target pixel"}
+
+
+def mask_outcome(flags, logger):
+	"""
+	Log what the reference's plugin logs for the mask stage of one attempt and return ``'error'`` (the plugin returns
+	STATUS.ERROR: too many masks, photometry.py:113-115), or ``None`` to go on; raises for the conditions that are uncaught
+	exceptions upstream (they end as STATUS.ERROR through ``tessphot.run_plugin``).
+	"""
+	kind = flags >> 8
+	if flags & 32:
+		logger.error('No flux above threshold.')
+	if flags & 1:
+		logger.warning("No masks found. Using minimum aperture." if flags & (32 | 64) else 'No mask found for main target. Using minimum aperture.')
+	if kind == 5:
+		logger.error('Too many masks.')
+		return 'error'
+	if kind in _MASK_EXCEPTIONS:
+		raise RuntimeError(_MASK_EXCEPTIONS[kind])
+	return None
+
+
 class AperturePhotometry(BasePhotometry):
 	"""
-	Simple aperture photometry with K2P2 masks (AperturePhotometry/photometry.py:17-257): the whole
-	``do_photometry`` body -- sum image, mask creation, selection, extraction, contamination -- runs on
-	the device; the stamp-resize retry loop (:75-170) stays here because it needs new cut-outs.
+	Simple aperture photometry with K2P2 masks (AperturePhotometry/photometry.py:17-257).  One attempt -- sum image, mask
+	creation and selection, extraction, contamination -- is one pass of the fused device kernel over the current cut-out; the
+	loop around it grows the stamp while the mask touches an edge (:75-170, decisions in :mod:`photometry_amd.stamps`).
 	"""
+
+	def _attempt(self):
+		"""One pass over the current stamp: device results of this target as a dict of host arrays."""
+		res = pipeline.run_aperture(self.ctx, _OneTargetScene(self), cubes='host', diagnostics=False)
+		self._sumimage = res['sumimage'][0]
+		return res
 
 	def do_photometry(self):
 		logger = logging.getLogger(__name__)
 		logger.info("Running aperture photometry...")
-		k2p2_settings = {'thresh': 0.8, 'min_no_pixels_in_mask': 4, 'min_for_cluster': 4,
-			'cluster_radius': np.sqrt(2) + np.finfo(np.float64).eps, 'segmentation': True, 'ws_blur': 0.5,
-			'ws_thres': 0, 'ws_footprint': 3, 'extend_overflow': True}
-		ExpectedFlux = mag2flux(self.target['tmag'])
-		haloswitch_tmag_limit = self.settings.getfloat('haloswitch', 'tmag_limit')
-		haloswitch_flux_limit = self.settings.getfloat('haloswitch', 'flux_limit')
-		allow_retries = 10 if self.target['tmag'] < 6 else 5
-		ctx = self.ctx
+		tmag = self.target['tmag']
+		bright = tmag <= self.settings.getfloat('haloswitch', 'tmag_limit') and not self.datasource.startswith('tpf:')
+		flux_budget = self.settings.getfloat('haloswitch', 'flux_limit') * mag2flux(tmag)
 
-		resize_args = {}
-		res = None
-		for retries in range(allow_retries):
-			scene = _OneTargetScene(self)
-			res = pipeline.run_aperture(ctx, scene, cubes='host', diagnostics=False) # photometry() below computes them like the reference
-			self._sumimage = res['sumimage'][0]
-			# bit 0 of the aperture image needs the sum image of THIS stamp (BasePhotometry.py:1043)
+		attempts_left = stamps.retry_limit(tmag)
+		while True:
+			res = self._attempt()
+			attempts_left -= 1
 			flags = int(res['flags'][0])
-			status = int(res['status'][0])
-			err = flags >> 8
-			if flags & 32:
-				logger.error('No flux above threshold.')
-			if flags & 1:
-				logger.warning("No masks found. Using minimum aperture." if (flags & (32 | 64)) else
-					'No mask found for main target. Using minimum aperture.')
-			if err == 5:
-				logger.error('Too many masks.')
+			if mask_outcome(flags, logger) == 'error':
 				return STATUS.ERROR
-			if err in (1, 2, 3, 4):
-				raise RuntimeError({1: "K2P2NoFlux: No measured flux in sum-image", 2: "Selected KDE bandwidth is 0. Cannot estimate density.",
-					3: "attempt to get argmin of an empty sequence", 4: "index out of bounds for the target pixel"}[err])
 			mask_main = res['mask'][0].astype(bool)
-
-			resize_args = {}
-			if flags & 2:
-				resize_args['down'] = 10
-			if flags & 4:
-				resize_args['up'] = 10
-			if flags & 8:
-				resize_args['left'] = 10
-			if flags & 16:
-				resize_args['right'] = 10
-			if resize_args:
-				logger.info("Touching the edges! Retrying.")
-				stamp_before = self._stamp
-				sumimage_before = self._sumimage
-				if not self.resize_stamp(**resize_args):
-					resize_args = {}
-					self._sumimage = sumimage_before
-					logger.warning("Could not resize stamp any further.")
-					break
-				if self.target['tmag'] <= haloswitch_tmag_limit and not self.datasource.startswith('tpf:'):
-					edge = np.zeros_like(mask_main, dtype='bool')
-					if resize_args.get('down') and self._stamp[0] == stamp_before[0]:
-						edge[0, :] = True
-					if resize_args.get('up') and self._stamp[1] == stamp_before[1]:
-						edge[-1, :] = True
-					if resize_args.get('left') and self._stamp[2] == stamp_before[2]:
-						edge[:, 0] = True
-					if resize_args.get('right') and self._stamp[3] == stamp_before[3]:
-						edge[:, -1] = True
-					if np.any(edge):
-						EdgeFlux = np.nansum(sumimage_before[mask_main & edge])
-						if EdgeFlux/ExpectedFlux > haloswitch_flux_limit:
-							logger.error('Stamp resize hit limit. Haloswitch quick break.')
-							self._details['edge_flux'] = EdgeFlux
-							return STATUS.ERROR
-			else:
+			wanted = stamps.edge_requests(flags)
+			if not wanted:
 				break
-
-		if resize_args:
-			logger.error('Too many stamp resizes.')
-			return STATUS.ERROR
+			logger.info("Touching the edges! Retrying.")
+			before, sumimage_before = self._stamp, self._sumimage
+			if not self.resize_stamp(**wanted):
+				self._sumimage = sumimage_before      # nothing changed: the attempt just made stands
+				logger.warning("Could not resize stamp any further.")
+				break
+			if bright:
+				stuck_flux = stamps.quick_break_flux(sumimage_before, mask_main, before, self._stamp, wanted)
+				if stuck_flux is not None and stuck_flux > flux_budget:
+					logger.error('Stamp resize hit limit. Haloswitch quick break.')
+					self._details['edge_flux'] = stuck_flux
+					return STATUS.ERROR
+			if attempts_left == 0:
+				logger.error('Too many stamp resizes.')
+				return STATUS.ERROR
 
 		lc = self.lightcurve
-		lc['flux'] = res['flux'][0]
-		lc['flux_err'] = res['flux_err'][0]
-		lc['flux_background'] = res['flux_background'][0]
-		lc['pos_centroid'] = res['pos_centroid'][0]
-		self.final_phot_mask = mask_main
-		self.final_position_mask = mask_main
+		for key in ('flux', 'flux_err', 'flux_background', 'pos_centroid'):
+			lc[key] = res[key][0]
+		self.final_phot_mask = self.final_position_mask = mask_main
+		for key, name, comment in K2P2_HEADERS:
+			value = K2P2_SETTINGS[name]
+			self.additional_headers[key] = (bool(value) if isinstance(value, bool) else value, comment)
 
-		self.additional_headers['KP_THRES'] = (k2p2_settings['thresh'], 'K2P2 sum-image threshold')
-		self.additional_headers['KP_MIPIX'] = (k2p2_settings['min_no_pixels_in_mask'], 'K2P2 min pixels in mask')
-		self.additional_headers['KP_MICLS'] = (k2p2_settings['min_for_cluster'], 'K2P2 min pix. for cluster')
-		self.additional_headers['KP_CLSRA'] = (k2p2_settings['cluster_radius'], 'K2P2 cluster radius')
-		self.additional_headers['KP_WS'] = (bool(k2p2_settings['segmentation']), 'K2P2 watershed segmentation')
-		self.additional_headers['KP_WSBLR'] = (k2p2_settings['ws_blur'], 'K2P2 watershed blur')
-		self.additional_headers['KP_WSTHR'] = (k2p2_settings['ws_thres'], 'K2P2 watershed threshold')
-		self.additional_headers['KP_WSFOT'] = (k2p2_settings['ws_footprint'], 'K2P2 watershed footprint')
-		self.additional_headers['KP_EX'] = (bool(k2p2_settings['extend_overflow']), 'K2P2 extend overflow')
-
-		my_status = STATUS.OK
+		status = STATUS.OK
 		contamination = float(res['contamination'][0])
-		if err == 6:
+		if flags >> 8 == 6:      # no catalogue star inside the mask (photometry.py:243-246)
 			logger.error("No targets in mask.")
-			contamination = np.nan
-			my_status = STATUS.ERROR
+			contamination, status = np.nan, STATUS.ERROR
 		logger.info("Contamination: %f", contamination)
 		if not np.isnan(contamination):
 			self.additional_headers['AP_CONT'] = (contamination, 'AP contamination')
-		in_mask = res['cat_in_mask'][:len(self.catalog)].astype(bool)
-		skip_targets = [int(s) for s in self.catalog['starid'][in_mask] if s != self.starid]
-		if skip_targets:
-			logger.info("These stars could be skipped: %s", skip_targets)
-			self.report_details(skip_targets=skip_targets)
-		if flags & 1:
-			my_status = STATUS.WARNING
-		return my_status
+		inside = res['cat_in_mask'][:len(self.catalog)].astype(bool)
+		others = [int(sid) for sid in self.catalog['starid'][inside] if sid != self.starid]
+		if others:
+			logger.info("These stars could be skipped: %s", others)
+			self.report_details(skip_targets=others)
+		return STATUS.WARNING if flags & 1 else status
 
 
 class LinPSFPhotometry(BasePhotometry):
@@ -779,11 +724,15 @@ class LinPSFPhotometry(BasePhotometry):
 
 class PSFPhotometry(BasePhotometry):
 	"""Non-linear PSF photometry (psf_photometry.py) -- not part of this engine."""
+	available = False
+
 	def do_photometry(self):
 		raise NotImplementedError("PSFPhotometry is outside the hot path implemented by photometry_amd")
 
 
 class HaloPhotometry(BasePhotometry):
 	"""Halo photometry (halo/halo_photometry.py, third-party halophot) -- not part of this engine."""
+	available = False
+
 	def do_photometry(self):
 		raise NotImplementedError("HaloPhotometry is outside the hot path implemented by photometry_amd")

@@ -1,8 +1,18 @@
 # -*- coding: utf-8 -*-
 """
-``tessphot(method, **task)`` -- the dispatch function the schedulers call
-(photometry/tessphot.py:20-135; call sites run_tessphot.py:153, run_tessphot_mpi.py:178), with the
-same signature, return value and error conventions, plus ``tessphot_batch`` for throughput.
+``tessphot(method, **task)`` -- the entry point the schedulers call once per task (reference: photometry/tessphot.py:52-135;
+call sites run_tessphot.py:153, run_tessphot_mpi.py:178) with the contract they rely on:
+
+* ``method`` in ``{None, 'aperture', 'psf', 'linpsf', 'halo'}``, anything else -> ``ValueError("Invalid method: '...'")``;
+* the return value is always an object with ``status``, ``method`` and ``_details`` -- also when the plugin could not even be
+  constructed (then ``method == 'error'``, ``status == STATUS.ERROR``, the traceback in ``_details['errors']``);
+* an exception anywhere in the plugin becomes ``STATUS.ERROR`` with the traceback appended to the details; ``KeyboardInterrupt`` /
+  ``SystemExit`` become ``STATUS.ABORT``; a light curve is saved only for ``OK`` / ``WARNING``;
+* ``method=None`` runs aperture photometry and then asks whether a bright target (``Tmag <= haloswitch.tmag_limit``, not a
+  secondary TPF target) should have been done with Halo photometry instead: either the aperture run gave up on stamp resizes, or
+  the final mask still carries more than ``haloswitch.flux_limit`` of the expected flux on the stamp edge.
+
+``tessphot_batch`` / ``tessphot_frames`` are the throughput entries (not in the reference): a whole batch per device pass.
 """
 
 import logging
@@ -11,87 +21,93 @@ import numpy as np
 from .status import STATUS
 from .plugins import AperturePhotometry, PSFPhotometry, LinPSFPhotometry, HaloPhotometry, load_settings, mag2flux
 
+#: method keyword -> plugin class (tessphot.py:122-127)
+PLUGINS = {'aperture': AperturePhotometry, 'psf': PSFPhotometry, 'linpsf': LinPSFPhotometry, 'halo': HaloPhotometry}
 
-class _PhotErrorDummy(object):
-	"""tessphot.py:13-17"""
-	def __init__(self, traceback, *args, **kwargs):
+#: the two ways the aperture plugin reports that it ran out of stamp (photometry.py:156, :168), as they appear in the details
+_RESIZE_GAVE_UP = ('Too many stamp resizes.', 'Stamp resize hit limit. Haloswitch quick break.')
+
+
+class FailedTask(object):
+	"""Stands in for the photometry object when its constructor raised: what the scheduler can still store."""
+	method = 'error'
+
+	def __init__(self, tracebacks):
 		self.status = STATUS.ERROR
-		self.method = 'error'
-		self._details = {'errors': traceback} if traceback else {}
+		self._details = {'errors': list(tracebacks)} if tracebacks else {}
 
 
-def _try_photometry(PhotClass, *args, **kwargs):
-	"""tessphot.py:20-49: any exception -> STATUS.ERROR with the traceback in the details."""
+def run_plugin(plugin, *args, **kwargs):
+	"""Construct ``plugin``, run its photometry inside its context manager, save on success; never raises (see module doc)."""
 	logger = logging.getLogger(__name__)
-	tbcollect = []
-	pho = None
+	pho, lost = None, []
 	try:
-		with PhotClass(*args, **kwargs) as pho:
+		pho = plugin(*args, **kwargs)
+		with pho:
 			pho.photometry()
 			if pho.status in (STATUS.OK, STATUS.WARNING):
 				pho.save_lightcurve()
 	except (KeyboardInterrupt, SystemExit): # pragma: no cover
 		logger.info("Stopped by user or system")
-		try:
+		if pho is not None:
 			pho._status = STATUS.ABORT
-		except: # noqa: E722
-			pass
-	except: # noqa: E722
+	except BaseException: # noqa: B902 -- the scheduler must get a result for every task
 		logger.exception("Something happened")
-		tb = traceback.format_exc().strip()
-		try:
+		text = traceback.format_exc().strip()
+		if pho is not None:
 			pho._status = STATUS.ERROR
-			pho.report_details(error=tb)
-		except: # noqa: E722
-			tbcollect.append(tb)
-	if pho is None:
-		return _PhotErrorDummy(tbcollect, *args, **kwargs)
-	return pho
+			pho.report_details(error=text)
+		else:
+			lost.append(text)
+	return FailedTask(lost) if pho is None else pho
+
+
+def halo_switch_reason(pho, settings=None):
+	"""
+	Why the aperture result ``pho`` of a bright target should be redone with Halo photometry, or ``None``
+	(the predicate of tessphot.py:81-102).
+	"""
+	if isinstance(pho, FailedTask):
+		return None
+	settings = load_settings() if settings is None else settings
+	if pho.target['tmag'] > settings.getfloat('haloswitch', 'tmag_limit') or pho.datasource.startswith('tpf:'):
+		return None
+	messages = pho._details.get('errors', [])
+	if pho.status == STATUS.ERROR and any(m in messages for m in _RESIZE_GAVE_UP):
+		return "Too many stamp resizes. Let us try Halo instead."
+	edge_flux = pho._details.get('edge_flux')
+	if edge_flux is not None and edge_flux / mag2flux(pho.target['tmag']) > settings.getfloat('haloswitch', 'flux_limit'):
+		return "Target is still touching the edge. Let us try Halo instead."
+	return None
 
 
 def tessphot(method=None, *args, **kwargs):
-	"""
-	Run the photometry pipeline on a single star (tessphot.py:52-135).
-
-	``method``: ``'aperture'``, ``'halo'``, ``'psf'``, ``'linpsf'`` or ``None`` (aperture first, then the
-	halo switch for bright targets with flux on the stamp edge, :76-109).  Raises ``ValueError`` on an
-	invalid method; returns the photometry object.
-	"""
+	"""Run the photometry pipeline on a single star; see the module documentation for the contract."""
 	logger = logging.getLogger(__name__)
-	if method is None:
-		pho = _try_photometry(AperturePhotometry, *args, **kwargs)
-		settings = load_settings()
-		haloswitch_tmag_limit = settings.getfloat('haloswitch', 'tmag_limit')
-		haloswitch_flux_limit = settings.getfloat('haloswitch', 'flux_limit')
-		if not isinstance(pho, _PhotErrorDummy) and pho.target['tmag'] <= haloswitch_tmag_limit \
-			and not pho.datasource.startswith('tpf:'):
-			EdgeFlux = pho._details.get('edge_flux')
-			errors = pho._details.get('errors', [])
-			if pho.status == STATUS.ERROR \
-				and ('Too many stamp resizes.' in errors or 'Stamp resize hit limit. Haloswitch quick break.' in errors):
-				logger.warning("Too many stamp resizes. Let us try Halo instead.")
-				pho = _try_photometry(HaloPhotometry, *args, **kwargs)
-			elif EdgeFlux is not None:
-				ExpectedFlux = mag2flux(pho.target['tmag'])
-				if EdgeFlux/ExpectedFlux > haloswitch_flux_limit:
-					logger.warning("Target is still touching the edge. Let us try Halo instead.")
-					pho = _try_photometry(HaloPhotometry, *args, **kwargs)
-			if isinstance(pho, HaloPhotometry):
-				pho.report_details('Automatically switched to Halo photometry')
-				pho._details['edge_flux'] = EdgeFlux
+	if method is not None:
+		if method not in PLUGINS:
+			raise ValueError(f"Invalid method: '{method:s}'")
+		pho = run_plugin(PLUGINS[method], *args, **kwargs)
+	else:
+		pho = run_plugin(AperturePhotometry, *args, **kwargs)
+		reason = halo_switch_reason(pho)
+		if reason is not None:
+			logger.warning(reason)
+			edge_flux = pho._details.get('edge_flux')
+			if HaloPhotometry.available:
+				pho = run_plugin(HaloPhotometry, *args, **kwargs)
+				if isinstance(pho, HaloPhotometry):
+					# keep the diagnostics that led to the switch (tessphot.py:104-109)
+					pho.report_details('Automatically switched to Halo photometry')
+					pho._details['edge_flux'] = edge_flux
+			else:
+				# No Halo photometry in this engine (third-party halophot upstream): the finished aperture result is kept, not
+				# thrown away for a plugin that can only fail; a good light curve is downgraded to WARNING and the request recorded.
+				pho.report_details(error='Halo switch requested (' + reason + ') but Halo photometry is not available: aperture result kept')
+				if pho.status == STATUS.OK:
+					pho._status = STATUS.WARNING
 		if pho.status == STATUS.WARNING:
 			logger.warning("Do something else?")
-	else:
-		try:
-			PhotClass = {
-				'aperture': AperturePhotometry,
-				'psf': PSFPhotometry,
-				'linpsf': LinPSFPhotometry,
-				'halo': HaloPhotometry
-			}[method]
-		except KeyError:
-			raise ValueError(f"Invalid method: '{method:s}'")
-		pho = _try_photometry(PhotClass, *args, **kwargs)
 	logger.info("Done")
 	return pho
 
@@ -107,11 +123,64 @@ class BatchResult(object):
 		self.final_phot_mask = mask
 
 
+def _diagnostics_into(details, d, status):
+	"""Copy the device diagnostics into ``details`` the way ``BasePhotometry.photometry`` does (BasePhotometry.py:1343-1407);
+	returns the status, turned into ERROR where the reference raises ``ValueError``."""
+	problems = int(d['flags'])
+	if problems & 3:
+		details.setdefault('errors', []).append('ValueError: Final lightcurve fluxes are all NaNs' if problems & 1
+			else 'ValueError: Final lightcurve errors are all NaNs')
+		return STATUS.ERROR
+	if problems & 4:
+		details.setdefault('errors', []).append('ValueError: Invalid time-vector specified')
+		return STATUS.ERROR
+	for key in ('mean_flux', 'variance', 'rms_hour', 'ptp', 'variability', 'edge_flux'):
+		details[key] = float(d[key])
+	details['pos_centroid'] = np.array([d['pos_centroid_col'], d['pos_centroid_row']])
+	if problems & 8:
+		details.setdefault('errors', []).append('WARNING: Could not detrend lightcurve for variability calculation.')
+	return status
+
+
+def tessphot_frames(ctx, stack, targets, catalog, time, quality, settings=None, cadence_s=1800):
+	"""
+	Aperture photometry of every target of a CCD region resident in HBM (:class:`photometry_amd.pipeline.FrameStack`), stamp
+	resizes included: what ``tessphot('aperture', ...)`` returns per target, for the whole batch in a few device passes.
+	Returns one :class:`BatchResult` per target, in order.
+	"""
+	from . import pipeline
+	res = pipeline.aperture_frames(ctx, stack, targets, catalog, time, quality, settings=settings, cadence_s=cadence_s)
+	out = []
+	for i, r in enumerate(res):
+		status = STATUS(r['status'])
+		details = {'stamp': r.get('stamp'), 'stamp_resizes': r['stamp_resizes']}
+		if r['errors']:
+			details['errors'] = list(r['errors'])
+		if 'edge_flux' in r:
+			details['edge_flux'] = r['edge_flux']
+		lc = mask = None
+		if 'mask' in r:
+			mask = r['mask']
+			details['mask_size'] = int(mask.sum())
+			if r['skip_targets']:
+				details['skip_targets'] = r['skip_targets']
+			if not np.isnan(r['contamination']):
+				details['contamination'] = r['contamination']
+			lc = {k: r[k] for k in ('flux', 'flux_err', 'flux_background', 'pos_centroid')}
+			if status in (STATUS.OK, STATUS.WARNING):
+				status = _diagnostics_into(details, r['diagnostics'], status)
+		out.append(BatchResult(int(targets['starid'][i]), status, 'aperture', details, lc, mask))
+	return out
+
+
 def tessphot_batch(ctx, scene, cubes='host'):
 	"""
-	Aperture photometry of a whole batch of fixed-size stamps in one pass over the device
+	Aperture photometry of a whole batch of FIXED-size stamp cubes in one pass over the device
 	(``pipeline.run_aperture``); returns one :class:`BatchResult` per target, in order.
-	``scene`` carries the arrays of ``photometry_amd.simulate.Scene`` (cubes, catalogue, positions).
+	``scene`` carries the arrays of ``photometry_amd.simulate.Scene`` (cubes, catalogue, positions).  A cube cannot grow:
+	a mask that touches its edge is used as it is, like the reference does when ``resize_stamp`` returns False
+	(BasePhotometry.py:605-612), and reported in ``details['edge']``; use :func:`tessphot_frames` when the frames the
+	stamps were cut from are available, so that such targets get the reference's stamp-resize retries.
 	"""
 	from . import pipeline
 	from .engine import DIAGNOSTICS_COLUMNS
@@ -133,23 +202,9 @@ def tessphot_batch(ctx, scene, cubes='host'):
 			details['errors'] = [f'ERROR: aperture mask creation failed (kind {flags >> 8})']
 		if flags & 30:
 			details['edge'] = flags & 30
+			details.setdefault('errors', []).append('WARNING: Could not resize stamp any further.')  # photometry.py:141-144
 		if status in (STATUS.OK, STATUS.WARNING):
-			# BasePhotometry.py:1343-1407, computed on the device for the whole batch
-			d = dict(zip(DIAGNOSTICS_COLUMNS, res['diagnostics'][i]))
-			dflags = int(d['flags'])
-			if dflags & 3: # the reference raises ValueError -> STATUS.ERROR through tessphot.py:37-49
-				status = STATUS.ERROR
-				details.setdefault('errors', []).append('ValueError: Final lightcurve fluxes are all NaNs' if dflags & 1
-					else 'ValueError: Final lightcurve errors are all NaNs')
-			elif dflags & 4:
-				status = STATUS.ERROR
-				details.setdefault('errors', []).append('ValueError: Invalid time-vector specified')
-			else:
-				for key in ('mean_flux', 'variance', 'rms_hour', 'ptp', 'variability', 'edge_flux'):
-					details[key] = float(d[key])
-				details['pos_centroid'] = np.array([d['pos_centroid_col'], d['pos_centroid_row']])
-				if dflags & 8:
-					details.setdefault('errors', []).append('WARNING: Could not detrend lightcurve for variability calculation.')
+			status = _diagnostics_into(details, dict(zip(DIAGNOSTICS_COLUMNS, res['diagnostics'][i])), status)
 		lc = {k: res[k][i] for k in ('flux', 'flux_err', 'flux_background', 'pos_centroid')}
 		out.append(BatchResult(int(scene.target_starid[i]), status, 'aperture', details, lc, res['mask'][i].astype(bool)))
 	return out

@@ -59,7 +59,9 @@ def oracle_batch(s, S, cut_override=None):
 					mm = None
 				kw['masks'] = mm
 			r = oap.do_photometry(S[i], s.images[i], s.images_err[i], s.backgrounds[i], tuple(s.stamps[i]),
-				s.target_pos_row[i], s.target_pos_column[i], s.target_tmag[i], s.target_starid[i], cat, s.aperture[i], **kw)
+				s.target_pos_row[i], s.target_pos_column[i], s.target_tmag[i], s.target_starid[i], cat,
+				# bit 1 of BasePhotometry.aperture = finite sum image (BasePhotometry.py:1043)
+				s.aperture[i] & np.isfinite(S[i]).astype(s.aperture.dtype), **kw)
 		except Exception as e: # noqa: B902  -- the reference turns any exception into STATUS.ERROR (tessphot.py:37-49)
 			r = {'status': oap.STATUS_ERROR, 'exception': repr(e)}
 		if cut_override is None:

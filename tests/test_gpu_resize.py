@@ -1,0 +1,110 @@
+# -*- coding: utf-8 -*-
+"""
+The stamp-resize retry loop of the aperture plugin (photometry/AperturePhotometry/photometry.py:75-170,
+BasePhotometry.resize_stamp / _set_stamp, BasePhotometry.py:567-693) for a batch: targets of one CCD region resident in HBM,
+stamps re-cut on the device round after round (``pipeline.aperture_frames`` / ``tessphot_frames``).
+
+Three-way parity on a region with faint stars, bright stars with bleed trails, and trails running into the frame limit:
+batch == the per-target plugin (``AperturePhotometry`` over a ``MemoryStampSource`` of the same frames) == the oracle's
+restatement of the whole loop (``oracle.aperture.photometry_on_frames``): statuses, final stamps, resize counts, messages,
+masks bit for bit, float32 sums bit for bit.
+"""
+import numpy as np
+import pytest
+from scipy.special import erf
+
+pytestmark = pytest.mark.gpu
+
+
+def _region(seed=3, R=110, C=96, T=24):
+	rng = np.random.default_rng(seed)
+	row0, col0 = 200, 300
+	# (row, column, tmag, trail half-length in rows): CCD coordinates
+	stars = [
+		(row0 + 30.3, col0 + 25.6, 11.0, 0), (row0 + 31.9, col0 + 60.2, 9.5, 0), (row0 + 70.4, col0 + 20.7, 12.5, 0),   # faint, 15x15
+		(row0 + 60.2, col0 + 50.4, 6.5, 15),     # bleed trail longer than the 19x19 default stamp: one or two resizes
+		(row0 + 85.7, col0 + 75.1, 6.8, 30),     # trail into the upper frame limit: "Could not resize stamp any further."
+		(row0 + 12.1, col0 + 80.3, 5.5, 40),     # bright (Tmag < 6): 10 attempts, trail into the lower limit: haloswitch quick break
+		(row0 + 45.5, col0 + 8.2, 10.2, 0),      # close to the left limit: default stamp clipped
+		(row0 + 33.0, col0 + 27.9, 12.0, 0),     # neighbour inside the first target's stamp (skip_targets / contamination)
+	]
+	rr, cc = np.arange(R) + row0, np.arange(C) + col0
+	img = np.zeros((R, C))
+	for (r, c, tmag, trail) in stars:
+		flux = 10**(-0.4 * (tmag - 20.451))
+		# a narrow core for the trailed stars: star + trail stay within the 15 % of pixels K2P2 trims before estimating the sky mode
+		sig = 0.6 if trail else 0.9
+		pr = 0.5 * (erf((rr + 0.5 - r) / (np.sqrt(2) * sig)) - erf((rr - 0.5 - r) / (np.sqrt(2) * sig)))
+		pc = 0.5 * (erf((cc + 0.5 - c) / (np.sqrt(2) * sig)) - erf((cc - 0.5 - c) / (np.sqrt(2) * sig)))
+		img += flux * np.outer(pr, pc)
+		if trail:
+			ri, ci = int(round(r)) - row0, int(round(c)) - col0
+			lo, hi = max(ri - trail, 0), min(ri + trail + 1, R)
+			img[lo:hi, ci:ci + 2] += 0.02 * flux      # two pixels wide: DBSCAN core pixels need 4 neighbours
+	bkg = 100.0
+	cube = img[:, :, None] * (1 + 1e-3 * rng.normal(size=T))[None, None, :]
+	noise = np.sqrt(np.abs(cube) + bkg + 100.0)
+	# a small positive residual sky: K2P2 estimates the sky mode from the positive pixels of the sum image only
+	images = (cube + 30.0 + rng.normal(size=cube.shape) * noise).astype('float32')
+	images[rng.random(images.shape) < 5e-4] = np.nan
+	frames = {'images': images, 'images_err': noise.astype('float32'), 'backgrounds': np.full(images.shape, bkg, dtype='float32')}
+	time = 1500.0 + np.arange(T) * 1800.0 / 86400.0
+	quality = np.zeros(T, dtype='int32')
+	quality[5] = 32
+	cat = {'starid': np.arange(len(stars), dtype='int64') + 101, 'tmag': np.array([s[2] for s in stars], dtype='float32'),
+		'row': np.array([s[0] for s in stars], dtype='float32'), 'column': np.array([s[1] for s in stars], dtype='float32')}
+	targets = {'starid': cat['starid'].copy(), 'tmag': np.array([s[2] for s in stars]), 'row': np.array([s[0] for s in stars]),
+		'column': np.array([s[1] for s in stars])}
+	return frames, row0, col0, time, quality, cat, targets
+
+
+def test_batched_resize_equals_plugin_equals_oracle(tmp_path):
+	from photometry_amd import pipeline, tessphot_frames, STATUS
+	from photometry_amd.device import Context
+	from photometry_amd.plugins import AperturePhotometry
+	from photometry_amd.tessphot import run_plugin
+	from photometry_amd.source import MemoryStampSource
+	from oracle import aperture as oap
+	frames, row0, col0, time, quality, cat, targets = _region()
+	T = len(time)
+	ctx = Context(0)
+	stack = pipeline.FrameStack(ctx, {k: np.moveaxis(v, 2, 0) for k, v in frames.items()}, row0, col0)
+	batch = tessphot_frames(ctx, stack, targets, cat, time, quality)
+	src = MemoryStampSource(frames, row0, col0, time, np.zeros(T), np.arange(T), quality, cat, targets=targets)
+	n_resized = n_final = 0
+	seen = set()
+	for i in range(len(targets['starid'])):
+		b = batch[i]
+		# --- oracle: the reference's loop restated on the same frames
+		o = oap.photometry_on_frames(oap.FrameTarget(frames, row0, col0, quality, cat, int(targets['starid'][i]), float(targets['tmag'][i]),
+			float(targets['row'][i]), float(targets['column'][i])))
+		assert b.status.value == o['status'], (i, b.status, o['status'], b._details.get('errors'), o['errors'])
+		assert tuple(b._details['stamp']) == tuple(o['stamp']), (i, b._details['stamp'], o['stamp'])
+		assert b._details['stamp_resizes'] == o['stamp_resizes']
+		assert [e for e in b._details.get('errors', []) if not e.startswith('WARNING: Could not detrend')] == o['errors'], (i, b._details.get('errors'), o['errors'])
+		if 'edge_flux' in o['details']:
+			np.testing.assert_allclose(b._details['edge_flux'], o['details']['edge_flux'], rtol=1e-12)
+		if 'mask' in o:
+			np.testing.assert_array_equal(b.final_phot_mask, o['mask'])
+			np.testing.assert_array_equal(b.lightcurve['flux'], o['flux'])
+			np.testing.assert_array_equal(b.lightcurve['flux_err'], o['flux_err'])
+			np.testing.assert_array_equal(b.lightcurve['flux_background'], o['flux_background'])
+			np.testing.assert_allclose(b.lightcurve['pos_centroid'], o['pos_centroid'], rtol=1e-12, equal_nan=True)
+			assert b._details.get('skip_targets', []) == o['skip_targets']
+			n_final += 1
+		# --- the per-target plugin over the same frames
+		p = run_plugin(AperturePhotometry, int(targets['starid'][i]), src, str(tmp_path), ctx=ctx)
+		assert p.status == b.status, (i, p.status, b.status, p._details.get('errors'))
+		assert tuple(p._details['stamp']) == tuple(b._details['stamp'])
+		assert p._details.get('stamp_resizes', 0) == b._details['stamp_resizes']
+		if b.final_phot_mask is not None and p.status != STATUS.ERROR:
+			np.testing.assert_array_equal(p.final_phot_mask, b.final_phot_mask)
+			np.testing.assert_array_equal(p.lightcurve['flux'], b.lightcurve['flux'])
+			for key in ('mean_flux', 'variance', 'rms_hour', 'ptp', 'variability', 'edge_flux', 'mask_size'):
+				assert p._details[key] == b._details[key], key
+		n_resized += b._details['stamp_resizes'] > 0
+		seen.update(e for e in b._details.get('errors', []))
+	assert n_resized >= 3 and n_final >= 5
+	assert 'WARNING: Could not resize stamp any further.' in seen
+	assert 'ERROR: Stamp resize hit limit. Haloswitch quick break.' in seen or 'ERROR: Too many stamp resizes.' in seen
+	ctx.close()
