@@ -252,7 +252,9 @@ int tp_subtract_background(tp_ctx* ctx, const tp_cube_desc* desc, const float* d
  *   = index of the main target among its fitted stars (the selection of linpsf_photometry.py:93-104 is
  *   host catalogue work); d_pos_row / d_pos_col float64 [n_fit_stars][pos_pitch] = row_stamp /
  *   column_stamp of every fitted star at every cadence, i.e. what catalog_attime() returns
- *   (BasePhotometry.py:1224-1258: WCS / jitter interpolation on the host).  max_stars <= 8.
+ *   (BasePhotometry.py:1224-1258: WCS / jitter interpolation on the host).  max_stars = the largest number of
+ *   fitted stars of a target, <= 64 (up to 8 stars run out of registers; more -- rare, crowded fields -- out of an HBM
+ *   scratch with the same arithmetic: the reference's star selection has no limit, linpsf_photometry.py:93-104).
  *   d_subtract: optional background series subtracted from d_images on the fly (as in tp_sumimage).
  *   outputs: d_flux / d_flux_err float64 [n_targets][out_pitch] (flux_err is NaN, :169);
  *   d_fluxes_all float64 [n_fit_stars][out_pitch] every fitted flux; d_contamination float64 (PSF_CONT,
@@ -267,6 +269,29 @@ int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
 	const double* d_pos_row, const double* d_pos_col, int64_t pos_pitch, double cutoff_radius,
 	double* d_flux, double* d_flux_err, double* d_fluxes_all, int64_t out_pitch,
 	double* d_contamination, int32_t* d_status, double* d_fluxes_mean);
+
+/* ---- non-linear PSF photometry ------------------------------------------------
+ * replaces PSFPhotometry.do_photometry (photometry/psf_photometry.py:111-196) with its likelihood (:52-90, statistic
+ * 'Gaussian_d' with background) for a batch: per target and cadence a Nelder-Mead fit (scipy `_minimize_neldermead`, step for
+ * step) of (row_stamp, column_stamp, flux) of the selected stars, warm-started from the previous cadence (the first one from
+ * d_params0), then the aperture correction: flux = fitted flux + nansum(residuals in the mini aperture) (:164-171).
+ *   d_images, d_backgrounds: cubes with the layout of desc (backgrounds may be NULL = 0);
+ *   d_coef / d_knots_* / n_coef_axis: the PRF spline of every target, as for tp_linpsf_fit;
+ *   fitted stars (ragged, CSR, at most 5 per target, the main target first: the selection of :117-136 is host catalogue work):
+ *     d_star_offsets int64 [n_targets+1], d_params0 float64 [n_fit_stars][3] = (row_stamp, column_stamp, mag2flux(tmag));
+ *   d_mini_aperture uint8 [n_targets][H*W]: _minimum_aperture (:29-41);
+ *   variance_floor = n_readout * readnoise^2 / gain^2 (:84); maxiter_first / maxiter = 1500 / 500 upstream (:146-150);
+ *   outputs float64 [n_targets][out_pitch]: d_flux, d_flux_err (NaN, :175), d_centroid_row / _col = pos_centroid[:, 0] / [:, 1]
+ *     = the fitted (row_stamp, column_stamp) of the main target, as upstream (:176); a cadence whose fit did not finish within
+ *     its iteration limit is NaN and does not update the starting point (:190-194);
+ *   d_params_out optional float64 [n_fit_stars * 3][out_pitch] (every fitted parameter), d_nit optional int32
+ *     [n_targets][out_pitch] (iterations used), d_status int32 (OK, :196).                                              */
+int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images, const float* d_backgrounds,
+	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis,
+	const int64_t* d_star_offsets, const double* d_params0, const uint8_t* d_mini_aperture,
+	double variance_floor, double cutoff_radius, int32_t maxiter_first, int32_t maxiter,
+	double* d_flux, double* d_flux_err, double* d_centroid_row, double* d_centroid_col, int64_t out_pitch,
+	double* d_params_out, int32_t* d_nit, int32_t* d_status);
 
 /* ---- light-curve diagnostics ---------------------------------------------
  * replaces the diagnostics block of BasePhotometry.photometry (photometry/BasePhotometry.py:1343-1407)

@@ -20,6 +20,7 @@ static const char* const kKernelNames[TPK_COUNT] = {
 	"tp_linpsf_finalize_kernel",
 	"tp_diagnostics_kernel",
 	"tp_cut_stamps_kernel",
+	"tp_psf_fit_kernel",
 	"tp_synth_kernel",
 };
 

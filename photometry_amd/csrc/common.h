@@ -25,6 +25,7 @@ enum tp_kernel_id {
 	TPK_LINPSF_FIN,
 	TPK_DIAGNOSTICS,
 	TPK_CUTOUT,
+	TPK_PSF_FIT,
 	TPK_SYNTH,
 	TPK_COUNT
 };

@@ -29,11 +29,14 @@
 // the image cube is read once (P*T*4 bytes per target).  MFMA is not used: the design matrix product is
 // banded (13 of 117), the dense GEMM form would do 13x the flops.
 #include "common.h"
+#include "linpsf_dev.h"
 #include <cmath>
 
 void* tp_ctx_scratch(tp_ctx* ctx, size_t bytes); // aperture.hip
 
 namespace {
+
+using namespace tp_prf;
 
 constexpr int kMaxStars = 8;
 constexpr int kMaxSamples = 32;
@@ -61,10 +64,6 @@ __global__ __launch_bounds__(256) void tp_linpsf_prf_kernel(const double* __rest
 //--------------------------------------------------------------------------------------------------
 // P2..P4
 //--------------------------------------------------------------------------------------------------
-// cumulative cardinal cubic B-spline M(z) = int_0^z N(t) dt, N supported on [0, 4]
-__device__ __forceinline__ double cumspline01(double w) { const double w2 = w * w; return w2 * w2 / 24.0; }               // z in [0,1], w = z
-__device__ __forceinline__ double cumspline12(double w) { return 1.0 / 24.0 + (w + 1.5 * w * w + w * w * w - 0.75 * (w * w) * (w * w)) / 6.0; } // z in [1,2], w = z-1
-
 struct FitArgs {
 	const float* images; const float* subtract; int64_t subtract_pitch;
 	int n_cad, height, width; int64_t t_pitch;
@@ -83,29 +82,6 @@ struct FitArgs {
 	double* fluxes_all;          // [n_fit_stars][out_pitch] fitted flux of every star (for the mean fluxes)
 	int64_t out_pitch;
 };
-
-// pixel-edge weights of one axis for a star at stamp coordinate `pos`: m[k] = M(phi + k), k = 0..3,
-// and `first` such that pixel j uses table rows first + 9*j .. first + 9*j + 12.
-// phi is the same for every pixel (pixels are 9 knot intervals apart); it is measured at the pixel
-// nearest to the star, whose lower edge is guaranteed to lie inside the uniform part of the knot vector.
-__device__ __forceinline__ void axis_weights(const double* kn, int n, double pos, double h, double (&m)[4], int& first)
-{
-	if (!(fabs(pos) < 1e6)) { m[0] = m[1] = m[2] = m[3] = 0.0; first = 4; return; } // NaN / absurd position: never inside the cut-off (psf.py:142)
-	const int jstar = (int)rint(pos);
-	const double x0 = ((double)jstar - pos) - 0.5;   // lower edge of pixel jstar relative to the star, in [-1, 0]
-	// knot interval l with kn[l] <= x0 < kn[l+1]  (uniform interior knots, spacing h)
-	int l = 4 + (int)floor((x0 - kn[4]) / h);
-	if (l < 4) l = 4;
-	if (l > n - 2) l = n - 2;
-	if (x0 < kn[l] && l > 4) --l;
-	else if (x0 >= kn[l + 1] && l < n - 2) ++l;
-	const double phi = (x0 - kn[l]) / (kn[l + 1] - kn[l]);
-	m[0] = cumspline01(phi);
-	m[1] = cumspline12(phi);
-	m[2] = 1.0 - cumspline12(1.0 - phi);  // M(2+phi) = 1 - M(2-phi), 2-phi in (1,2]
-	m[3] = 1.0 - cumspline01(1.0 - phi);  // M(3+phi) = 1 - M(1-phi)
-	first = (l - 3) - 9 * jstar;           // table index of weight p = 0 for pixel 0
-}
 
 // Cyclic Jacobi eigen-decomposition based pseudo-inverse solve:  x = pinv(G) g,  G symmetric S x S.
 template <int S>
@@ -176,30 +152,6 @@ __device__ __forceinline__ void pinv_solve(double (&G)[S][S], const double (&g)[
 #pragma unroll
 		for (int k = 0; k < S; ++k) if (k < ns) x[k] += V[k][e] * coef;
 	}
-}
-
-// value of the pixel-integrated unit PRF of one star at pixel (i, j): h^2 * sum_pq wx[p] wy[q] C[ax+p][by+q]
-__device__ __forceinline__ double prf_pixel(const double* __restrict__ C, int n, int ax, int by,
-	const double (&mx)[4], const double (&my)[4])
-{
-	const double* c0 = C + (int64_t)ax * n + by;
-	double acc = 0.0;
-#pragma unroll
-	for (int p = 0; p < 13; ++p) {
-		const double* r = c0 + p * n;
-		// inner contraction over q with weights [1-m3, 1-m2, 1-m1, 1-m0, 1,1,1,1,1, m3, m2, m1, m0]
-		double t = ((r[4] + r[5]) + (r[6] + r[7])) + r[8];
-		t += (r[0] + my[3] * (r[9] - r[0]));
-		t += (r[1] + my[2] * (r[10] - r[1]));
-		t += (r[2] + my[1] * (r[11] - r[2]));
-		t += (r[3] + my[0] * (r[12] - r[3]));
-		double wx;
-		if (p < 4) wx = 1.0 - mx[3 - p];
-		else if (p < 9) wx = 1.0;
-		else wx = mx[12 - p];
-		acc += wx * t;
-	}
-	return acc;
 }
 
 // General path: direct evaluation of the 13x13 contraction per star, pixel and cadence.  Runs only for the
@@ -766,6 +718,227 @@ __global__ __launch_bounds__(256) void tp_linpsf_finalize_kernel(FinArgs fa)
 	}
 }
 
+
+//--------------------------------------------------------------------------------------------------
+// Any number of fitted stars.  select_stars (linpsf_photometry.py:93-104) has no upper limit: a crowded target can bring
+// more stars than the register-resident kernels above are instantiated for (8).  Those targets (rare) are fitted here with
+// run-time sized normal equations kept in a context-owned HBM scratch: one thread per cadence like the direct kernel,
+// element e of a thread's arrays at scratch[e * n_threads + thread] (coalesced across the cadences of a wavefront).
+// Same arithmetic (direct 13x13 contraction, cyclic Jacobi pseudo-inverse with numpy's cut-off), only slower.
+//--------------------------------------------------------------------------------------------------
+constexpr int kMaxManyStars = 64;
+
+struct ManyScratch {
+	double* base; int64_t n_threads; int64_t gt;
+	__device__ __forceinline__ double& at(int e) const { return base[(int64_t)e * n_threads + gt]; }
+};
+
+__global__ __launch_bounds__(256) void tp_linpsf_fit_many_kernel(FitArgs a, const int32_t* __restrict__ big_targets, int smax, double* __restrict__ scratch)
+{
+	extern __shared__ __align__(16) double lds[]; // [n*n] coefficient table + 2 x [n+4] knots
+	const int target = big_targets[blockIdx.x];
+	const int tid = threadIdx.x;
+	const int n = a.n;
+	double* C = lds;
+	double* kn = lds + (size_t)n * n;
+	double* kny = kn + n + 4;
+	const double* cg = a.coef + (int64_t)target * n * n;
+	for (int i = tid; i < n * n; i += blockDim.x) C[i] = cg[i];
+	for (int i = tid; i < n + 4; i += blockDim.x) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
+	__syncthreads();
+	const int k = blockIdx.y * blockDim.x + tid;
+	if (k >= a.n_cad) return;
+	const int64_t s0 = a.star_offsets[target];
+	const int ns = (int)(a.star_offsets[target + 1] - s0);
+	const int H = a.height, W = a.width;
+	const double h = kn[5] - kn[4], hy = kny[5] - kny[4], h2 = h * hy;
+	// layout of a thread's scratch: G[S*S] V[S*S] g[S] x[S] av[S] srow[S] scol[S] mx[4S] my[4S] ax0[S] by0[S]
+	const int S = smax, SS = S * S;
+	ManyScratch m{scratch, (int64_t)gridDim.x * gridDim.y * blockDim.x, ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * blockDim.x + tid};
+	const int oG = 0, oV = SS, og = 2 * SS, ox = og + S, oav = ox + S, orow = oav + S, ocol = orow + S, omx = ocol + S, omy = omx + 4 * S,
+		oax = omy + 4 * S, oby = oax + S;
+	for (int s = 0; s < ns; ++s) {
+		const double r = a.pos_row[(s0 + s) * a.pos_pitch + k], c = a.pos_col[(s0 + s) * a.pos_pitch + k];
+		double wx[4], wy[4];
+		int ax0, by0;
+		axis_weights(kn, n, c, h, wx, ax0);
+		axis_weights(kny, n, r, hy, wy, by0);
+		m.at(orow + s) = r; m.at(ocol + s) = c;
+		for (int q = 0; q < 4; ++q) { m.at(omx + 4 * s + q) = wx[q]; m.at(omy + 4 * s + q) = wy[q]; }
+		m.at(oax + s) = (double)ax0; m.at(oby + s) = (double)by0;
+		m.at(og + s) = 0.0;
+		for (int u = 0; u < ns; ++u) m.at(oG + s * S + u) = 0.0;
+	}
+	const float* img = a.images + (int64_t)target * H * W * a.t_pitch + k;
+	const float sub = a.subtract ? a.subtract[(int64_t)target * a.subtract_pitch + k] : 0.f;
+	for (int i = 0; i < H; ++i) {
+		for (int j = 0; j < W; ++j) {
+			float bf = img[(int64_t)(i * W + j) * a.t_pitch];
+			if (a.subtract) bf = bf - sub;
+			if (!(fabsf(bf) <= 3.402823466e+38f)) continue;
+			const double b = (double)bf;
+			bool any = false;
+			for (int s = 0; s < ns; ++s) {
+				double v = 0.0;
+				const double dc = (double)j - m.at(ocol + s), dr = (double)i - m.at(orow + s);
+				if (sqrt(dc * dc + dr * dr) < a.cutoff) {
+					double wx[4], wy[4];
+					for (int q = 0; q < 4; ++q) { wx[q] = m.at(omx + 4 * s + q); wy[q] = m.at(omy + 4 * s + q); }
+					int ax = (int)m.at(oax + s) + 9 * j, by = (int)m.at(oby + s) + 9 * i;
+					ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
+					by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
+					v = h2 * prf_pixel(C, n, ax, by, wx, wy);
+					any = true;
+				}
+				m.at(oav + s) = v;
+			}
+			if (!any) continue; // a pixel outside every cut-off disc adds nothing to A^T A or A^T b
+			for (int s = 0; s < ns; ++s) {
+				const double as = m.at(oav + s);
+				if (as == 0.0) continue;
+				m.at(og + s) += as * b;
+				for (int u = s; u < ns; ++u) m.at(oG + s * S + u) += as * m.at(oav + u);
+			}
+		}
+	}
+	for (int s = 0; s < ns; ++s) {
+		for (int u = 0; u < s; ++u) m.at(oG + s * S + u) = m.at(oG + u * S + s);
+		for (int u = 0; u < ns; ++u) m.at(oV + s * S + u) = (s == u) ? 1.0 : 0.0;
+	}
+	// cyclic Jacobi (same sweep order and stopping rule as pinv_solve)
+	for (int sweep = 0; sweep < 30; ++sweep) {
+		double off = 0.0, d2 = 0.0;
+		for (int p = 0; p < ns; ++p) {
+			const double d = m.at(oG + p * S + p);
+			d2 += d * d;
+			for (int q = p + 1; q < ns; ++q) { const double o = m.at(oG + p * S + q); off += o * o; }
+		}
+		if (!(off > 1e-34 * d2)) break;
+		for (int p = 0; p < ns; ++p) {
+			for (int q = p + 1; q < ns; ++q) {
+				const double apq = m.at(oG + p * S + q);
+				if (apq == 0.0) continue;
+				const double theta = (m.at(oG + q * S + q) - m.at(oG + p * S + p)) / (2.0 * apq);
+				const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+				const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+				for (int e = 0; e < ns; ++e) {
+					const double gp = m.at(oG + e * S + p), gq = m.at(oG + e * S + q);
+					m.at(oG + e * S + p) = c * gp - sn * gq;
+					m.at(oG + e * S + q) = sn * gp + c * gq;
+				}
+				for (int e = 0; e < ns; ++e) {
+					const double gp = m.at(oG + p * S + e), gq = m.at(oG + q * S + e);
+					m.at(oG + p * S + e) = c * gp - sn * gq;
+					m.at(oG + q * S + e) = sn * gp + c * gq;
+				}
+				for (int e = 0; e < ns; ++e) {
+					const double vp = m.at(oV + e * S + p), vq = m.at(oV + e * S + q);
+					m.at(oV + e * S + p) = c * vp - sn * vq;
+					m.at(oV + e * S + q) = sn * vp + c * vq;
+				}
+			}
+		}
+	}
+	double smx = 0.0;
+	for (int i = 0; i < ns; ++i) { const double v = fabs(m.at(oG + i * S + i)); if (v > smx || v != v) smx = v; }
+	const double cut = 1e-15 * smx;
+	for (int i = 0; i < ns; ++i) m.at(ox + i) = 0.0;
+	for (int e = 0; e < ns; ++e) {
+		const double lam = m.at(oG + e * S + e);
+		double proj = 0.0;
+		for (int i = 0; i < ns; ++i) proj += m.at(oV + i * S + e) * m.at(og + i);
+		const double inv = (fabs(lam) > cut) ? (1.0 / lam) : ((lam != lam) ? lam : 0.0);
+		const double coef = proj * inv;
+		for (int i = 0; i < ns; ++i) m.at(ox + i) += m.at(oV + i * S + e) * coef;
+	}
+	const int ti = a.target_index[target];
+	for (int s = 0; s < ns; ++s) a.fluxes_all[(s0 + s) * a.out_pitch + k] = m.at(ox + s);
+	a.flux[(int64_t)target * a.out_pitch + k] = (ti >= 0 && ti < ns) ? m.at(ox + ti) : __builtin_nan("");
+	a.flux_err[(int64_t)target * a.out_pitch + k] = __builtin_nan("");
+}
+
+// finalise for the targets of the kernel above (same rules as tp_linpsf_finalize_kernel, star loops at run time)
+__global__ __launch_bounds__(256) void tp_linpsf_finalize_many_kernel(FinArgs fa, const int32_t* __restrict__ big_targets)
+{
+	extern __shared__ __align__(16) double lds[];
+	const FitArgs& a = fa.f;
+	const int target = big_targets[blockIdx.x];
+	const int tid = threadIdx.x;
+	const int n = a.n;
+	const double* C = a.coef + (int64_t)target * n * n;
+	double* kn = lds;
+	double* kny = kn + n + 4;
+	double* red = kny + n + 4;            // [256]
+	double* mean = red + 256;             // [kMaxManyStars]
+	for (int i = tid; i < n + 4; i += blockDim.x) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
+	__syncthreads();
+	const int64_t s0 = a.star_offsets[target];
+	const int ns = (int)(a.star_offsets[target + 1] - s0);
+	const int ti = a.target_index[target];
+	const double* ftar = a.flux + (int64_t)target * a.out_pitch;
+	double cntd = 0.0;
+	for (int s = -1; s < ns; ++s) {
+		double acc = 0.0;
+		for (int k = tid; k < a.n_cad; k += blockDim.x) {
+			const bool ok = ftar[k] == ftar[k];
+			if (s < 0) acc += ok ? 1.0 : 0.0;
+			else acc += ok ? a.fluxes_all[(s0 + s) * a.out_pitch + k] : 0.0;
+		}
+		red[tid] = acc;
+		__syncthreads();
+		double tot = 0.0;
+		for (int l = 0; l < (int)blockDim.x; ++l) tot += red[l];
+		__syncthreads();
+		if (s < 0) cntd = tot;
+		else if (tid == 0) mean[s] = tot / cntd;
+	}
+	__syncthreads();
+	if (cntd == 0.0) {
+		if (tid == 0) { fa.status[target] = TP_STATUS_ERROR; fa.contamination[target] = __builtin_nan(""); }
+		return;
+	}
+	const int k = a.n_cad - 1;
+	const int H = a.height, W = a.width;
+	const double h = kn[5] - kn[4], hy = kny[5] - kny[4], h2 = h * hy;
+	const float* img = a.images + (int64_t)target * H * W * a.t_pitch + k;
+	const float sub = a.subtract ? a.subtract[(int64_t)target * a.subtract_pitch + k] : 0.f;
+	double acc = 0.0;
+	for (int p = tid; p < H * W; p += blockDim.x) {
+		const int i = p / W, j = p - i * W;
+		float bf = img[(int64_t)p * a.t_pitch];
+		if (a.subtract) bf = bf - sub;
+		if (!(fabsf(bf) <= 3.402823466e+38f)) continue;
+		double others = 0.0, at = 0.0;
+		for (int s = 0; s < ns; ++s) {
+			const double srow = a.pos_row[(s0 + s) * a.pos_pitch + k], scol = a.pos_col[(s0 + s) * a.pos_pitch + k];
+			const double dc = (double)j - scol, dr = (double)i - srow;
+			double v = 0.0;
+			if (sqrt(dc * dc + dr * dr) < a.cutoff) {
+				double wx[4], wy[4];
+				int ax0, by0;
+				axis_weights(kn, n, scol, h, wx, ax0);
+				axis_weights(kny, n, srow, hy, wy, by0);
+				int ax = ax0 + 9 * j, by = by0 + 9 * i;
+				ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
+				by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
+				v = h2 * prf_pixel(C, n, ax, by, wx, wy);
+			}
+			if (s == ti) at = v; else others += v * mean[s];
+		}
+		acc += others * at;
+	}
+	red[tid] = acc;
+	__syncthreads();
+	if (tid == 0) {
+		double tot = 0.0;
+		for (int l = 0; l < (int)blockDim.x; ++l) tot += red[l];
+		const double cont = tot / mean[ti];
+		fa.contamination[target] = cont;
+		fa.status[target] = (cont > 0.1) ? TP_STATUS_WARNING : TP_STATUS_OK;
+		if (fa.fluxes_mean) for (int u = 0; u < ns; ++u) fa.fluxes_mean[s0 + u] = mean[u];
+	}
+}
+
 } // namespace
 
 extern "C" int tp_linpsf_prf(tp_ctx* ctx, int32_t n_targets, int32_t n_samples, int32_t n_coef,
@@ -800,7 +973,7 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	TP_REQUIRE(ctx, pos_pitch >= desc->n_cad && out_pitch >= desc->n_cad, "tp_linpsf_fit: pitch < n_cad");
 	TP_REQUIRE(ctx, d_subtract == nullptr || subtract_pitch >= desc->n_cad, "tp_linpsf_fit: bad subtract pitch");
 	TP_REQUIRE(ctx, n_coef_axis >= 32 && n_coef_axis <= 140, "tp_linpsf_fit: coefficient table must be 32..140 per axis (LDS resident)");
-	TP_REQUIRE(ctx, max_stars >= 1 && max_stars <= kMaxStars, "tp_linpsf_fit: at most 8 stars fitted per target");
+	TP_REQUIRE(ctx, max_stars >= 1 && max_stars <= kMaxManyStars, "tp_linpsf_fit: at most 64 stars fitted per target");
 	TP_REQUIRE(ctx, cutoff_radius > 0 && cutoff_radius <= 5.25, "tp_linpsf_fit: cutoff_radius must be in (0, 5.25] (uniform-knot region of the PRF spline)");
 	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
 
@@ -848,6 +1021,40 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	if (max_stars > 2) TP_LINPSF_LAUNCH(4, 3);
 	if (max_stars > 4) TP_LINPSF_LAUNCH(8, 5);
 #undef TP_LINPSF_LAUNCH
+	if (max_stars > kMaxStars) {
+		// targets with more than 8 fitted stars (rare: crowded fields): listed on the host from the star offsets, fitted by
+		// the run-time sized kernel out of an HBM scratch
+		std::vector<int64_t> off((size_t)desc->n_targets + 1);
+		TP_HIP(ctx, hipMemcpyAsync(off.data(), d_star_offsets, off.size() * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+		TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		std::vector<int32_t> big;
+		int smax = 0;
+		for (int t = 0; t < desc->n_targets; ++t) {
+			const int ns = (int)(off[t + 1] - off[t]);
+			TP_REQUIRE(ctx, ns <= kMaxManyStars, "tp_linpsf_fit: a target has more than 64 fitted stars");
+			if (ns > kMaxStars) { big.push_back(t); if (ns > smax) smax = ns; }
+		}
+		if (!big.empty()) {
+			const int threads = 256, nblk_m = (desc->n_cad + threads - 1) / threads;
+			const size_t per_thread = (size_t)(2 * smax * smax + 15 * smax) * sizeof(double);
+			const size_t list_bytes = (big.size() * sizeof(int32_t) + 255) & ~(size_t)255;
+			const size_t need = todo_bytes + list_bytes + per_thread * big.size() * nblk_m * threads + 256;
+			// the scratch also holds d_todo at its start: grow it BEFORE the class kernels' flags could be lost -- they are done
+			TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			TP_REQUIRE(ctx, tp_ctx_scratch(ctx, need) != nullptr, "tp_linpsf_fit: out of device memory for the many-star scratch");
+			char* base = static_cast<char*>(ctx->scratch) + ((todo_bytes + 255) & ~(size_t)255);
+			int32_t* d_big = reinterpret_cast<int32_t*>(base);
+			double* d_scr = reinterpret_cast<double*>(base + list_bytes);
+			TP_HIP(ctx, hipMemcpyAsync(d_big, big.data(), big.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+			TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_many_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+			TP_LAUNCH(ctx, TPK_LINPSF_FIT_DIRECT, tp_linpsf_fit_many_kernel, dim3((unsigned)big.size(), (unsigned)nblk_m), dim3(threads), shmem, a, (const int32_t*)d_big, smax, d_scr);
+			TP_LAUNCH_CHECK(ctx, "tp_linpsf_fit_many_kernel");
+			const size_t shmem_fin_m = shmem_fin + kMaxManyStars * sizeof(double);
+			TP_LAUNCH(ctx, TPK_LINPSF_FIN, tp_linpsf_finalize_many_kernel, dim3((unsigned)big.size()), dim3(256), shmem_fin_m, fa, (const int32_t*)d_big);
+			TP_LAUNCH_CHECK(ctx, "tp_linpsf_finalize_many_kernel");
+			TP_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `big` (host) must outlive the copy
+		}
+	}
 	return TP_OK;
 	TP_API_END(ctx)
 }

@@ -1,0 +1,61 @@
+// linpsf_dev.h -- the pixel-integrated PRF (P2: PSF.integrate_to_image, photometry/psf.py:122-148) as device functions shared by
+// the linear (linpsf.hip) and the non-linear (psfphot.hip) PSF photometry kernels.  See linpsf.hip for the derivation: on the
+// uniform 9-samples-per-pixel PRF grid the FITPACK box integral of a pixel is separable and its 13 non-zero basis integrals per
+// axis are [1-M(phi+3..phi), 1,1,1,1,1, M(phi+3..phi)] * h with M the cumulative cardinal cubic B-spline.
+#pragma once
+#include <cmath>
+
+namespace tp_prf {
+
+// cumulative cardinal cubic B-spline M(z) = int_0^z N(t) dt, N supported on [0, 4]
+__device__ __forceinline__ double cumspline01(double w) { const double w2 = w * w; return w2 * w2 / 24.0; }               // z in [0,1], w = z
+__device__ __forceinline__ double cumspline12(double w) { return 1.0 / 24.0 + (w + 1.5 * w * w + w * w * w - 0.75 * (w * w) * (w * w)) / 6.0; } // z in [1,2], w = z-1
+
+// pixel-edge weights of one axis for a star at stamp coordinate `pos`: m[k] = M(phi + k), k = 0..3,
+// and `first` such that pixel j uses table rows first + 9*j .. first + 9*j + 12.
+// phi is the same for every pixel (pixels are 9 knot intervals apart); it is measured at the pixel
+// nearest to the star, whose lower edge is guaranteed to lie inside the uniform part of the knot vector.
+__device__ __forceinline__ void axis_weights(const double* kn, int n, double pos, double h, double (&m)[4], int& first)
+{
+	if (!(fabs(pos) < 1e6)) { m[0] = m[1] = m[2] = m[3] = 0.0; first = 4; return; } // NaN / absurd position: never inside the cut-off (psf.py:142)
+	const int jstar = (int)rint(pos);
+	const double x0 = ((double)jstar - pos) - 0.5;   // lower edge of pixel jstar relative to the star, in [-1, 0]
+	// knot interval l with kn[l] <= x0 < kn[l+1]  (uniform interior knots, spacing h)
+	int l = 4 + (int)floor((x0 - kn[4]) / h);
+	if (l < 4) l = 4;
+	if (l > n - 2) l = n - 2;
+	if (x0 < kn[l] && l > 4) --l;
+	else if (x0 >= kn[l + 1] && l < n - 2) ++l;
+	const double phi = (x0 - kn[l]) / (kn[l + 1] - kn[l]);
+	m[0] = cumspline01(phi);
+	m[1] = cumspline12(phi);
+	m[2] = 1.0 - cumspline12(1.0 - phi);  // M(2+phi) = 1 - M(2-phi), 2-phi in (1,2]
+	m[3] = 1.0 - cumspline01(1.0 - phi);  // M(3+phi) = 1 - M(1-phi)
+	first = (l - 3) - 9 * jstar;           // table index of weight p = 0 for pixel 0
+}
+
+// value of the pixel-integrated unit PRF of one star at pixel (i, j): h^2 * sum_pq wx[p] wy[q] C[ax+p][by+q]
+__device__ __forceinline__ double prf_pixel(const double* __restrict__ C, int n, int ax, int by,
+	const double (&mx)[4], const double (&my)[4])
+{
+	const double* c0 = C + (int64_t)ax * n + by;
+	double acc = 0.0;
+#pragma unroll
+	for (int p = 0; p < 13; ++p) {
+		const double* r = c0 + p * n;
+		// inner contraction over q with weights [1-m3, 1-m2, 1-m1, 1-m0, 1,1,1,1,1, m3, m2, m1, m0]
+		double t = ((r[4] + r[5]) + (r[6] + r[7])) + r[8];
+		t += (r[0] + my[3] * (r[9] - r[0]));
+		t += (r[1] + my[2] * (r[10] - r[1]));
+		t += (r[2] + my[1] * (r[11] - r[2]));
+		t += (r[3] + my[0] * (r[12] - r[3]));
+		double wx;
+		if (p < 4) wx = 1.0 - mx[3 - p];
+		else if (p < 9) wx = 1.0;
+		else wx = mx[12 - p];
+		acc += wx * t;
+	}
+	return acc;
+}
+
+} // namespace tp_prf

@@ -1,0 +1,306 @@
+// psfphot.hip -- non-linear PSF photometry: PSFPhotometry.do_photometry for a batch.
+//
+// Replaces photometry/psf_photometry.py:52-108 (_lhood, Gaussian_d statistic with background) and :143-196 (the per-cadence
+// scipy Nelder-Mead fit of (row, column, flux) of up to five stars, warm-started from the previous cadence, plus the
+// aperture correction on the residuals), on top of the pixel-integrated PRF of psf.py:122-148 (linpsf_dev.h).
+//
+// Mapping (gfx950).  The cadences of a target form a CHAIN (the fit of cadence k starts from the solution of k-1), so the
+// parallelism is across targets and inside one likelihood evaluation: one 256-thread workgroup per target, the target's 117x117
+// float64 PRF coefficient table resident in LDS (110 KB: one workgroup per CU), the simplex and the cadence's image / weight
+// map beside it.  Every thread runs the same Nelder-Mead control flow on the LDS-resident simplex (uniform branches: all
+// decisions are taken on values read back from LDS), thread 0 alone mutates it; a likelihood evaluation spreads the pixels over
+// the threads (each sums flux_s * PRF_s over the stars whose cut-off disc holds the pixel: 169 LDS table reads + ~230 flops per
+// star-pixel) and reduces chi^2 by a fixed shuffle / LDS tree (deterministic).
+// The simplex search is scipy 1.7.3's `_minimize_neldermead` step for step (non-adaptive coefficients 1, 2, 0.5, 0.5; initial
+// simplex 5 % / 0.00025; termination xatol = fatol = 1e-4; `success` = finished before maxiter; stable ordering of ties).
+// FP64 compute-bound: per target and cadence ~100-300 evaluations x (stars x ~79 pixels x 182 FMA).
+#include "common.h"
+#include "linpsf_dev.h"
+#include <cmath>
+
+namespace {
+
+using namespace tp_prf;
+
+constexpr int kMaxPsfStars = 5;                  // psf_photometry.py:127-128
+constexpr int kMaxDim = 3 * kMaxPsfStars;
+constexpr int kThreads = 256;
+
+struct PsfArgs {
+	const float* images; const float* backgrounds;
+	int n_cad, height, width; int64_t t_pitch;
+	const double* coef; const double* knots_x; const double* knots_y; int n;
+	const int64_t* star_offsets; const double* params0; const uint8_t* mini_aperture;
+	float var_floor; double cutoff; int maxiter_first, maxiter;
+	double* flux; double* flux_err; double* cen_row; double* cen_col; int64_t out_pitch;
+	double* params_out; int32_t* nit; int32_t* status;
+};
+
+struct StarW { double row, col, flux, mx[4], my[4]; int ax0, by0; };
+
+// chi^2 of the parameter vector x (psf_photometry.py:52-90); all threads call it, all get the same value
+__device__ double likelihood(const double* x, int ns, const double* C, const double* kn, const double* kny, int n, double h, double hy,
+	const double* img, const double* wgt, int H, int W, double cutoff, StarW* sw, double* red)
+{
+	const int tid = threadIdx.x;
+	if (tid < ns) {
+		StarW& s = sw[tid];
+		s.row = x[3 * tid]; s.col = x[3 * tid + 1]; s.flux = x[3 * tid + 2];
+		axis_weights(kn, n, s.col, h, s.mx, s.ax0);     // x <-> column (first spline axis), y <-> row (psf.py:146)
+		axis_weights(kny, n, s.row, hy, s.my, s.by0);
+	}
+	__syncthreads();
+	const double h2 = h * hy;
+	double acc = 0.0;
+	for (int p = tid; p < H * W; p += kThreads) {
+		const int i = p / W, j = p - i * W;
+		double mdl = 0.0;
+		for (int s = 0; s < ns; ++s) {
+			const double dc = (double)j - sw[s].col, dr = (double)i - sw[s].row;
+			if (sqrt(dc * dc + dr * dr) < cutoff) {     // psf.py:142 (a NaN position is never inside)
+				int ax = sw[s].ax0 + 9 * j, by = sw[s].by0 + 9 * i;
+				ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
+				by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
+				mdl += sw[s].flux * (h2 * prf_pixel(C, n, ax, by, sw[s].mx, sw[s].my));
+			}
+		}
+		const double r = img[p] - mdl;
+		const double term = wgt[p] * (r * r);
+		if (term == term) acc += term;                  // nansum
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+	if ((tid & 63) == 0) red[tid >> 6] = acc;
+	__syncthreads();
+	const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+	__syncthreads();   // red and sw are reused by the next evaluation
+	return tot;
+}
+
+__global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a)
+{
+	extern __shared__ __align__(16) double lds[];
+	const int target = blockIdx.x;
+	const int tid = threadIdx.x;
+	const int n = a.n, H = a.height, W = a.width, P = H * W;
+	double* C = lds;
+	double* kn = C + (size_t)n * n;
+	double* kny = kn + n + 4;
+	double* img = kny + n + 4;                // [P]
+	double* wgt = img + P;                    // [P]
+	double* sim = wgt + P;                    // [(D+1)][kMaxDim]
+	double* fsim = sim + (kMaxDim + 1) * kMaxDim;   // [D+1]
+	double* xt = fsim + (kMaxDim + 1);        // trial points: xbar, xr, xe / xc [3][kMaxDim]
+	double* x0 = xt + 3 * kMaxDim;            // warm start [kMaxDim]
+	double* red = x0 + kMaxDim;               // [4]
+	StarW* sw = reinterpret_cast<StarW*>(red + 4);
+	const double* cg = a.coef + (int64_t)target * n * n;
+	for (int i = tid; i < n * n; i += kThreads) C[i] = cg[i];
+	for (int i = tid; i < n + 4; i += kThreads) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
+	const int64_t s0 = a.star_offsets[target];
+	int ns = (int)(a.star_offsets[target + 1] - s0);
+	if (ns > kMaxPsfStars) ns = kMaxPsfStars;
+	const int D = 3 * ns;
+	if (tid < D) x0[tid] = a.params0[s0 * 3 + tid];
+	__syncthreads();
+	const double h = kn[5] - kn[4], hy = kny[5] - kny[4];
+	const double nan = __builtin_nan("");
+	const uint8_t* mini = a.mini_aperture + (int64_t)target * P;
+	const int64_t ob = (int64_t)target * a.out_pitch;
+	if (ns == 0) { // nothing to fit: every minimisation of an empty vector "succeeds" at once; flux = aperture correction of the image
+		for (int k = tid; k < a.n_cad; k += kThreads) { a.flux[ob + k] = nan; a.flux_err[ob + k] = nan; a.cen_row[ob + k] = nan; a.cen_col[ob + k] = nan; }
+		if (tid == 0) a.status[target] = TP_STATUS_ERROR;
+		return;
+	}
+#define EVAL(xp) likelihood((xp), ns, C, kn, kny, n, h, hy, img, wgt, H, W, a.cutoff, sw, red)
+	for (int k = 0; k < a.n_cad; ++k) {
+		// ---- the cadence's image and weight map (float32 arithmetic of psf_photometry.py:75-86)
+		const float* ip = a.images + (int64_t)target * P * a.t_pitch + k;
+		const float* bp = a.backgrounds ? (a.backgrounds + (int64_t)target * P * a.t_pitch + k) : nullptr;
+		for (int p = tid; p < P; p += kThreads) {
+			const float im = ip[(int64_t)p * a.t_pitch];
+			const float bk = bp ? bp[(int64_t)p * a.t_pitch] : 0.f;
+			float var = fabsf(im + bk) + a.var_floor;
+			if (var < 1e-9f) var = 1e-9f;
+			float w = 1.0f / var;
+			if (w < 1e-9f) w = 1e-9f;
+			img[p] = (double)im;
+			wgt[p] = (double)w;
+		}
+		__syncthreads();
+		// ---- Nelder-Mead (scipy _minimize_neldermead)
+		const int maxiter = (k > 0) ? a.maxiter : a.maxiter_first;
+		if (tid == 0) {
+			for (int d = 0; d < D; ++d) sim[d] = x0[d];
+			for (int v = 0; v < D; ++v) {
+				for (int d = 0; d < D; ++d) sim[(v + 1) * kMaxDim + d] = x0[d];
+				const double y = x0[v];
+				sim[(v + 1) * kMaxDim + v] = (y != 0.0) ? (1.0 + 0.05) * y : 0.00025;
+			}
+		}
+		__syncthreads();
+		for (int v = 0; v <= D; ++v) {
+			const double f = EVAL(sim + v * kMaxDim);
+			if (tid == 0) fsim[v] = f;
+		}
+		__syncthreads();
+		auto sort_simplex = [&]() { // stable insertion sort by fsim (numpy argsort of <= 16 values), thread 0
+			if (tid == 0) {
+				for (int i = 1; i <= D; ++i) {
+					const double fv = fsim[i];
+					double tmp[kMaxDim];
+					for (int d = 0; d < D; ++d) tmp[d] = sim[i * kMaxDim + d];
+					int j = i - 1;
+					while (j >= 0 && fsim[j] > fv) {
+						fsim[j + 1] = fsim[j];
+						for (int d = 0; d < D; ++d) sim[(j + 1) * kMaxDim + d] = sim[j * kMaxDim + d];
+						--j;
+					}
+					fsim[j + 1] = fv;
+					for (int d = 0; d < D; ++d) sim[(j + 1) * kMaxDim + d] = tmp[d];
+				}
+			}
+			__syncthreads();
+		};
+		sort_simplex();
+		int iterations = 1;
+		while (iterations < maxiter) {
+			double dx = 0.0, df = 0.0;
+			for (int v = 1; v <= D; ++v) {
+				for (int d = 0; d < D; ++d) { const double e = fabs(sim[v * kMaxDim + d] - sim[d]); if (e > dx || e != e) dx = e; }
+				const double e = fabs(fsim[0] - fsim[v]); if (e > df || e != e) df = e;
+			}
+			if (dx <= 1e-4 && df <= 1e-4) break;
+			double* xbar = xt; double* xr = xt + kMaxDim; double* xn = xt + 2 * kMaxDim;
+			if (tid == 0) {
+				for (int d = 0; d < D; ++d) {
+					double sacc = 0.0;
+					for (int v = 0; v < D; ++v) sacc += sim[v * kMaxDim + d];   // np.add.reduce(sim[:-1], 0)
+					xbar[d] = sacc / (double)D;
+					xr[d] = 2.0 * xbar[d] - sim[D * kMaxDim + d];
+				}
+			}
+			__syncthreads();
+			const double fxr = EVAL(xr);
+			bool doshrink = false;
+			const double* take = nullptr; double ftake = 0.0;
+			if (fxr < fsim[0]) {
+				if (tid == 0) for (int d = 0; d < D; ++d) xn[d] = 3.0 * xbar[d] - 2.0 * sim[D * kMaxDim + d];
+				__syncthreads();
+				const double fxe = EVAL(xn);
+				if (fxe < fxr) { take = xn; ftake = fxe; } else { take = xr; ftake = fxr; }
+			} else if (fxr < fsim[D - 1]) {
+				take = xr; ftake = fxr;
+			} else if (fxr < fsim[D]) {
+				if (tid == 0) for (int d = 0; d < D; ++d) xn[d] = 1.5 * xbar[d] - 0.5 * sim[D * kMaxDim + d];
+				__syncthreads();
+				const double fxc = EVAL(xn);
+				if (fxc <= fxr) { take = xn; ftake = fxc; } else doshrink = true;
+			} else {
+				if (tid == 0) for (int d = 0; d < D; ++d) xn[d] = 0.5 * xbar[d] + 0.5 * sim[D * kMaxDim + d];
+				__syncthreads();
+				const double fxcc = EVAL(xn);
+				if (fxcc < fsim[D]) { take = xn; ftake = fxcc; } else doshrink = true;
+			}
+			if (doshrink) {
+				for (int v = 1; v <= D; ++v) {
+					if (tid == 0) for (int d = 0; d < D; ++d) sim[v * kMaxDim + d] = sim[d] + 0.5 * (sim[v * kMaxDim + d] - sim[d]);
+					__syncthreads();
+					const double f = EVAL(sim + v * kMaxDim);
+					if (tid == 0) fsim[v] = f;
+				}
+				__syncthreads();
+			} else {
+				if (tid == 0) { for (int d = 0; d < D; ++d) sim[D * kMaxDim + d] = take[d]; fsim[D] = ftake; }
+				__syncthreads();
+			}
+			sort_simplex();
+			++iterations;
+		}
+		const bool success = iterations < maxiter;
+		// ---- result of the cadence (psf_photometry.py:157-196)
+		double flux_ap = 0.0;
+		if (success) {
+			// residuals in the mini aperture: one more model evaluation at the solution
+			if (tid < ns) {
+				StarW& s = sw[tid];
+				s.row = sim[3 * tid]; s.col = sim[3 * tid + 1]; s.flux = sim[3 * tid + 2];
+				axis_weights(kn, n, s.col, h, s.mx, s.ax0);
+				axis_weights(kny, n, s.row, hy, s.my, s.by0);
+			}
+			__syncthreads();
+			double acc = 0.0;
+			for (int p = tid; p < P; p += kThreads) {
+				if (!mini[p]) continue;
+				const int i = p / W, j = p - i * W;
+				double mdl = 0.0;
+				for (int s = 0; s < ns; ++s) {
+					const double dc = (double)j - sw[s].col, dr = (double)i - sw[s].row;
+					if (sqrt(dc * dc + dr * dr) < a.cutoff) {
+						int ax = sw[s].ax0 + 9 * j, by = sw[s].by0 + 9 * i;
+						ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
+						by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
+						mdl += sw[s].flux * ((h * hy) * prf_pixel(C, n, ax, by, sw[s].mx, sw[s].my));
+					}
+				}
+				const double r = img[p] - mdl;
+				if (r == r) acc += r;
+			}
+#pragma unroll
+			for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+			if ((tid & 63) == 0) red[tid >> 6] = acc;
+			__syncthreads();
+			flux_ap = (red[0] + red[1]) + (red[2] + red[3]);
+		}
+		if (tid == 0) {
+			a.flux[ob + k] = success ? (sim[2] + flux_ap) : nan;
+			a.flux_err[ob + k] = nan;
+			a.cen_row[ob + k] = success ? sim[0] : nan;     // pos_centroid[k] = result[0, 0:2] = (row_stamp, column_stamp), as upstream
+			a.cen_col[ob + k] = success ? sim[1] : nan;
+			if (a.nit) a.nit[(int64_t)target * a.out_pitch + k] = iterations;
+			if (success) for (int d = 0; d < D; ++d) x0[d] = sim[d];     // the next cadence starts from this solution
+		}
+		if (a.params_out && tid < D) a.params_out[((s0 * 3) + tid) * a.out_pitch + k] = success ? sim[tid] : nan;
+		__syncthreads();
+	}
+#undef EVAL
+	if (tid == 0) a.status[target] = TP_STATUS_OK; // psf_photometry.py:196
+}
+
+} // namespace
+
+extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images, const float* d_backgrounds,
+	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis,
+	const int64_t* d_star_offsets, const double* d_params0, const uint8_t* d_mini_aperture,
+	double variance_floor, double cutoff_radius, int32_t maxiter_first, int32_t maxiter,
+	double* d_flux, double* d_flux_err, double* d_centroid_row, double* d_centroid_col, int64_t out_pitch,
+	double* d_params_out, int32_t* d_nit, int32_t* d_status)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, tp_desc_ok(desc), "tp_psf_fit: bad cube descriptor");
+	TP_REQUIRE(ctx, d_images && d_coef && d_knots_x && d_knots_y && d_star_offsets && d_params0 && d_mini_aperture, "tp_psf_fit: null input pointer");
+	TP_REQUIRE(ctx, d_flux && d_flux_err && d_centroid_row && d_centroid_col && d_status, "tp_psf_fit: null output pointer");
+	TP_REQUIRE(ctx, out_pitch >= desc->n_cad, "tp_psf_fit: out_pitch < n_cad");
+	TP_REQUIRE(ctx, n_coef_axis >= 32 && n_coef_axis <= 140, "tp_psf_fit: coefficient table must be 32..140 per axis (LDS resident)");
+	TP_REQUIRE(ctx, cutoff_radius > 0 && cutoff_radius <= 5.25, "tp_psf_fit: cutoff_radius must be in (0, 5.25] (uniform-knot region of the PRF spline)");
+	TP_REQUIRE(ctx, maxiter_first >= 1 && maxiter >= 1, "tp_psf_fit: bad iteration limits");
+	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
+	const size_t P = (size_t)desc->height * desc->width;
+	const size_t doubles = (size_t)n_coef_axis * n_coef_axis + 2 * ((size_t)n_coef_axis + 4) + 2 * P + (kMaxDim + 1) * kMaxDim + (kMaxDim + 1)
+		+ 3 * kMaxDim + kMaxDim + 4;
+	const size_t shmem = doubles * sizeof(double) + kMaxPsfStars * sizeof(StarW) + 16;
+	TP_REQUIRE(ctx, shmem <= 160 * 1024, "tp_psf_fit: stamp too large for the LDS-resident image and weight map");
+	PsfArgs a;
+	a.images = d_images; a.backgrounds = d_backgrounds; a.n_cad = desc->n_cad; a.height = desc->height; a.width = desc->width; a.t_pitch = desc->t_pitch;
+	a.coef = d_coef; a.knots_x = d_knots_x; a.knots_y = d_knots_y; a.n = n_coef_axis;
+	a.star_offsets = d_star_offsets; a.params0 = d_params0; a.mini_aperture = d_mini_aperture;
+	a.var_floor = (float)variance_floor; a.cutoff = cutoff_radius; a.maxiter_first = maxiter_first; a.maxiter = maxiter;
+	a.flux = d_flux; a.flux_err = d_flux_err; a.cen_row = d_centroid_row; a.cen_col = d_centroid_col; a.out_pitch = out_pitch;
+	a.params_out = d_params_out; a.nit = d_nit; a.status = d_status;
+	TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_psf_fit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+	TP_LAUNCH(ctx, TPK_PSF_FIT, tp_psf_fit_kernel, dim3((unsigned)desc->n_targets), dim3(kThreads), shmem, a);
+	TP_LAUNCH_CHECK(ctx, "tp_psf_fit_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}

@@ -278,3 +278,25 @@ def linpsf_fit(ctx, images, coef, knots_x, knots_y, star_offsets, target_index, 
 		pos_row.ptr, pos_col.ptr, pos_row.shape[1], float(cutoff_radius),
 		out.flux.ptr, out.flux_err.ptr, out.fluxes_all.ptr, out.n_cad, out.contamination.ptr, out.status.ptr, out.fluxes_mean.ptr))
 	return out
+
+
+
+def psf_fit(ctx, images, backgrounds, coef, knots_x, knots_y, star_offsets, params0, mini_aperture, variance_floor=9.0,
+	cutoff_radius=5.0, maxiter_first=1500, maxiter=500):
+	"""
+	Non-linear PSF photometry of a batch (psf_photometry.py:111-196, ``tp_psf_fit``).  Returns a dict of DeviceArrays:
+	``flux, flux_err, centroid_row, centroid_col`` float64 ``(Nt, T)``, ``params`` float64 ``(n_fit * 3, T)``, ``nit`` int32
+	``(Nt, T)``, ``status`` int32 ``(Nt,)``.
+	"""
+	Nt, T = images.n_targets, images.n_cad
+	n = knots_x.shape[0] - 4
+	out = {k: ctx.zeros((Nt, T), 'float64') for k in ('flux', 'flux_err', 'centroid_row', 'centroid_col')}
+	out['params'] = ctx.zeros((max(params0.shape[0], 1) * 3, T), 'float64')
+	out['nit'] = ctx.zeros((Nt, T), 'int32')
+	out['status'] = ctx.zeros((Nt,), 'int32')
+	desc = images.desc
+	ctx._check(ctx.lib.tp_psf_fit(ctx.handle, ctypes.byref(desc), images.ptr, _ptr(backgrounds), coef.ptr, knots_x.ptr, knots_y.ptr, n,
+		star_offsets.ptr, params0.ptr, mini_aperture.ptr, float(variance_floor), float(cutoff_radius), int(maxiter_first), int(maxiter),
+		out['flux'].ptr, out['flux_err'].ptr, out['centroid_row'].ptr, out['centroid_col'].ptr, T, out['params'].ptr, out['nit'].ptr,
+		out['status'].ptr))
+	return out

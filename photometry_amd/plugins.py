@@ -722,12 +722,58 @@ class LinPSFPhotometry(BasePhotometry):
 		return STATUS.OK
 
 
+def psf_star_selection(row_stamp, column_stamp, tmag, target_row_stamp, target_column_stamp, target_tmag):
+	"""
+	The stars PSFPhotometry fits (psf_photometry.py:117-130): closer than 5 pixels to the target position and not more than
+	5 magnitudes fainter, the five closest, nearest first.  Returns their indices into the catalogue arrays.
+	"""
+	dist = np.sqrt((target_row_stamp - np.asarray(row_stamp))**2 + (target_column_stamp - np.asarray(column_stamp))**2)
+	near = np.flatnonzero((dist < 5) & (target_tmag - np.asarray(tmag) > -5))
+	return near[np.argsort(dist[near], kind='stable')][:5]
+
+
 class PSFPhotometry(BasePhotometry):
-	"""Non-linear PSF photometry (psf_photometry.py) -- not part of this engine."""
-	available = False
+	"""
+	Non-linear PSF photometry (psf_photometry.py:19-196): per cadence a Nelder-Mead fit of position and flux of the target and
+	its up to four nearest neighbours against the pixel-integrated PRF, on the device (``tp_psf_fit``; the cadences of a target
+	form a warm-start chain, a batch of targets runs side by side).
+	"""
+	available = True
+
+	def __init__(self, *args, **kwargs):
+		super().__init__(*args, **kwargs)
+		self.cutoff_radius = 5
+		# statistics of the read noise term of the likelihood (BasePhotometry.py:267-270: header values or these defaults)
+		self.readnoise = getattr(self.source, 'readnoise', 10)
+		self.gain = getattr(self.source, 'gain', 100)
+
+	def _minimum_aperture(self):
+		"""psf_photometry.py:29-41"""
+		cols, rows = self.get_pixel_grid()
+		near = (np.abs(cols - self.target_pos_column - 1) <= 1) & (np.abs(rows - self.target_pos_row - 1) <= 1)
+		return near & (self.aperture & 1 != 0)
 
 	def do_photometry(self):
-		raise NotImplementedError("PSFPhotometry is outside the hot path implemented by photometry_amd")
+		from .device import DeviceCube
+		ctx = self.ctx
+		model = self.psf
+		cat = self.catalog
+		sel = psf_star_selection(cat['row_stamp'], cat['column_stamp'], cat['tmag'], self.target_pos_row_stamp,
+			self.target_pos_column_stamp, self.target['tmag'])
+		params0 = np.column_stack((np.asarray(cat['row_stamp'][sel], dtype='float64'), np.asarray(cat['column_stamp'][sel], dtype='float64'),
+			mag2flux(np.asarray(cat['tmag'][sel], dtype='float64'))))
+		coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(model.weights(np.asarray([self._stamp]))))
+		res = engine.psf_fit(ctx, DeviceCube.from_host(ctx, self.images_cube), DeviceCube.from_host(ctx, self.backgrounds_cube), coef,
+			ctx.array(model.tx), ctx.array(model.ty), ctx.array(np.array([0, len(sel)], dtype='int64')), ctx.array(params0),
+			ctx.array(self._minimum_aperture().astype('uint8')[None]), variance_floor=self.n_readout * self.readnoise**2 / self.gain**2,
+			cutoff_radius=self.cutoff_radius)
+		lc = self.lightcurve
+		lc['flux'] = res['flux'].to_host()[0]
+		lc['flux_err'] = res['flux_err'].to_host()[0]
+		lc['pos_centroid'] = np.column_stack((res['centroid_row'].to_host()[0], res['centroid_col'].to_host()[0]))   # (row, column) as upstream (:176)
+		if np.any(np.isnan(lc['flux'])):
+			logging.getLogger(__name__).warning("We should flag that this has not gone well.")
+		return STATUS.OK
 
 
 class HaloPhotometry(BasePhotometry):

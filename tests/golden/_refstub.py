@@ -166,10 +166,17 @@ class FakeCatalog(object):
 			return self.cols[key]
 		if isinstance(key, (int, np.integer)):
 			return {k: v[key] for k, v in self.cols.items()}
+		if isinstance(key, slice):
+			return FakeCatalog(**{k: v[key] for k, v in self.cols.items()})
 		key = np.asarray(key)
 		if key.size == 0:
 			key = key.astype('int64')
 		return FakeCatalog(**{k: v[key] for k, v in self.cols.items()})
+
+	def sort(self, key):
+		"""astropy ``Table.sort(key)``: in place, ascending (psf_photometry.py:126)."""
+		order = np.argsort(self.cols[key])
+		self.cols = {k: v[order] for k, v in self.cols.items()}
 
 	def __setitem__(self, key, value):
 		self.cols[key] = np.asarray(value)

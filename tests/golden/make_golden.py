@@ -22,6 +22,8 @@ Fixtures:
 * ``golden_psf.npz``      ``PSF.integrate_to_image`` (psf.py:122-148) on a synthetic spline
 * ``golden_linpsf.npz``   ``lsfit`` and ``LinPSFPhotometry.do_photometry``
                           (linpsf_photometry.py:22-34, 79-219)
+* ``golden_psfphot.npz``  ``PSFPhotometry.do_photometry`` (psf_photometry.py:111-196): Nelder-Mead fits of (row, column, flux)
+                          with the real ``scipy.optimize.minimize``, warm-started cadence by cadence
 * ``golden_cutout.npz``   ``BasePhotometry._load_cube`` FFI branch (BasePhotometry.py:720-742) on a small frame stack
 * ``golden_background.npz`` the background smoothing loop and the subtraction / manual-exclude block of
                           ``prepare_photometry`` (prepare.py:317-335, 412-425): those statements live inside a 600-line
@@ -624,8 +626,44 @@ def golden_background():
 	out['b3_raw'], out['b3_raw_err'], out['b3_flags'] = raw, err, flags
 	np.savez_compressed(os.path.join(HERE, 'golden_background.npz'), **out)
 
+def golden_psfphot():
+	"""The reference's own PSFPhotometry.do_photometry on two small targets (a few cadences: every cadence is a Nelder-Mead run)."""
+	from photometry.psf_photometry import PSFPhotometry
+	x, img, spline = _synthetic_spline()
+	out = {'prf_x': x, 'prf_img': img}
+	H, W, T = 11, 11, 4
+	scene = simulate.make_scene(3, T, H, W, seed=23, max_neighbours=2, neighbour_tmag_range=(9.0, 15.0))
+	simulate.fill_cubes(scene, nan_fraction=0.004)
+	n = 0
+	for i in range(3):
+		f = make_fake(PSFPhotometry, scene, i, None)
+		f.cutoff_radius = 5
+		f.n_readout, f.readnoise, f.gain = 900, 10, 100   # FFI defaults (BasePhotometry.py:267-270)
+		f.sector = 1
+		p = PSF.__new__(PSF)
+		p.shape = (H, W)
+		p.stamp = f._stamp
+		p.splineInterpolation = spline
+		f._psf = p
+		with warnings.catch_warnings():
+			warnings.simplefilter('ignore')
+			status = PSFPhotometry.do_photometry(f)
+		out[f'pp{n}_target'] = i
+		out[f'pp{n}_status'] = status.value
+		out[f'pp{n}_flux'] = np.asarray(f.lightcurve['flux'])
+		out[f'pp{n}_flux_err'] = np.asarray(f.lightcurve['flux_err'])
+		out[f'pp{n}_pos_centroid'] = np.asarray(f.lightcurve['pos_centroid'])
+		print('psfphot case', n, status, f.lightcurve['flux'], 'true', scene.star_params[i, 0, 2])
+		n += 1
+	out['n_psfphot'] = n
+	for key in ('images', 'backgrounds', 'stamps', 'aperture', 'target_pos_row', 'target_pos_column', 'target_tmag', 'target_starid', 'cat_offsets'):
+		out[key] = getattr(scene, key)
+	for k, v in scene.catalog.items():
+		out['cat_' + k] = v
+	np.savez_compressed(os.path.join(HERE, 'golden_psfphot.npz'), **out)
+
 
 if __name__ == '__main__':
-	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics', 'cutout', 'background']
+	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics', 'cutout', 'background', 'psfphot']
 	for w in which:
 		globals()['golden_' + w]()

@@ -48,7 +48,8 @@ def test_prf_blend_matches_reference_construction(ctx):
 # 6: sigma 0.12 px (dozens of origins: the K buffer forces column chunks); 30: sigma 0.6 px (more origins than the
 # buffer holds: the target is flagged and redone by the general direct kernel); 1300+ cadences: several passes
 @pytest.mark.parametrize("max_neigh,T,H,W,jit", [(3, 40, 11, 11, 1), (1, 70, 15, 15, 1), (6, 16, 13, 12, 1),
-	(3, 40, 11, 11, 6), (2, 33, 15, 15, 30), (1, 1301, 9, 9, 1), (3, 1100, 9, 9, 2)])
+	(3, 40, 11, 11, 6), (2, 33, 15, 15, 30), (1, 1301, 9, 9, 1), (3, 1100, 9, 9, 2),
+	(13, 12, 11, 11, 1)])     # more than 8 fitted stars: the run-time sized kernel
 def test_linpsf_matches_oracle(ctx, max_neigh, T, H, W, jit):
 	from photometry_amd import simulate, engine, psf as hpsf
 	from photometry_amd.device import DeviceCube
@@ -63,6 +64,7 @@ def test_linpsf_matches_oracle(ctx, max_neigh, T, H, W, jit):
 	sel, star_offsets, target_index = hpsf.select_stars(s.catalog, s.cat_offsets, s.target_starid)
 	pos_row, pos_col = _positions(s, sel, T)
 	max_stars = int(np.diff(star_offsets).max())
+	assert max_stars > 8 or max_neigh < 13
 	coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(model.weights(s.stamps)))
 	res = engine.linpsf_fit(ctx, DeviceCube.from_host(ctx, s.images), coef, ctx.array(model.tx), ctx.array(model.ty),
 		ctx.array(star_offsets), ctx.array(target_index), ctx.array(pos_row), ctx.array(pos_col), max_stars).to_host()

@@ -166,3 +166,26 @@ def test_cutout_golden(golden_dir):
 	for st, ref in zip(g['stamps'], g['cubes']):
 		got = cutout.load_cube(g['frames'], tuple(st), *g['offsets'])
 		np.testing.assert_array_equal(got, ref)
+
+
+def test_psf_photometry_golden(golden_dir):
+	"""oracle.psf_photometry vs the reference's own PSFPhotometry.do_photometry (psf_photometry.py:111-196, real scipy
+	Nelder-Mead); and the oracle's restatement of scipy's Nelder-Mead gives the same fits as scipy itself."""
+	from oracle import psf_photometry as opp
+	g = _load(golden_dir, 'golden_psfphot.npz')
+	x = g['prf_x']
+	spline = RectBivariateSpline(x, x, g['prf_img'])
+	H, W = g['images'].shape[1:3]
+	for n in range(int(g['n_psfphot'])):
+		i = int(g[f'pp{n}_target'])
+		cat = _catalog(g, i)
+		p = opsf.PSF.from_spline(spline, (H, W))
+		for use_scipy in (True, False):
+			res = opp.do_photometry(g['images'][i], g['backgrounds'][i], p, cat, tuple(g['stamps'][i]), g['target_pos_row'][i],
+				g['target_pos_column'][i], g['target_tmag'][i], g['aperture'][i], use_scipy=use_scipy)
+			assert res['status'] == int(g[f'pp{n}_status'])
+			# the simplex search is a chain of comparisons: last-bit differences of the PRF integral (own FITPACK restatement vs
+			# scipy's) may change single steps, both runs end within the optimiser's own tolerances (xatol = fatol = 1e-4)
+			np.testing.assert_allclose(res['flux'], g[f'pp{n}_flux'], rtol=2e-5)
+			np.testing.assert_allclose(res['pos_centroid'], g[f'pp{n}_pos_centroid'], atol=2e-4)
+			assert np.all(np.isnan(res['flux_err']))
