@@ -234,6 +234,34 @@ int tp_subtract_background(tp_ctx* ctx, const tp_cube_desc* desc, const float* d
 	const float* d_bkg, int64_t bkg_pitch, const uint8_t* d_pixel_flags, uint32_t flag_mask,
 	float* d_images, float* d_images_err);
 
+/* ---- B1 + full-frame B2 / B3 / A1: the prepare stage on a frame stack ----------------------------------------
+ * Frames: float32 [n_frames][frame_rows][row_pitch] resident in HBM (frame k at + k * frame_stride), as for tp_cut_stamps.
+ * tp_background_mesh (B1, first half): the low-resolution mesh of backgrounds.fit_background for a plain image
+ *   (photometry/backgrounds.py:89-97 pixel mask; :200-206 photutils Background2D on box_size x box_size cells with
+ *   SigmaClip(3, maxiters = 5) and the SExtractor estimator): d_mesh float64 [n_frames][ny][nx] (NaN for a cell without an
+ *   unmasked pixel), d_nmasked int32 [n_frames][ny][nx] (masked or padded pixels of the cell), ny = ceil(rows / box_size).
+ *   d_exclude: optional uint8 manual-exclude image(s) [frame_rows][frame_cols] (exclude_frame_stride 0 = one for all frames).
+ * tp_background_zoom (B1, second half): the full-resolution background from the cubic-spline coefficients of the finished
+ *   mesh (after the exclusion of mostly-masked cells, their IDW fill, the 3 x 3 median filter and the spline prefilter --
+ *   host work on ny x nx values per frame, photometry_amd/prepare.py), i.e. scipy.ndimage.zoom(order 3, mode 'reflect',
+ *   grid_mode) as photutils' BkgZoomInterpolator calls it, clipped to [d_vmin[k], d_vmax[k]]; float32 output (what the
+ *   reference's smoothing block stores, prepare.py:327).
+ * tp_frames_smooth_time (B2, prepare.py:317-335), tp_frames_subtract (B3, prepare.py:419-425; flags uint8 per value) and
+ *   tp_frames_sumimage (A1, prepare.py:450-453, 459) are the image-layout versions of tp_smooth_time,
+ *   tp_subtract_background and tp_sumimage.                                                                          */
+int tp_background_mesh(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+	int64_t row_pitch, int64_t frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride,
+	double flux_cutoff, int32_t box_size, double* d_mesh, int32_t* d_nmasked);
+int tp_background_zoom(tp_ctx* ctx, const double* d_coef, const double* d_vmin, const double* d_vmax, int32_t n_frames,
+	int32_t mesh_rows, int32_t mesh_cols, int32_t box_size, int32_t frame_rows, int32_t frame_cols, int64_t row_pitch, int64_t frame_stride,
+	float* d_background);
+int tp_frames_smooth_time(tp_ctx* ctx, int32_t n_frames, int64_t n_pixels, int64_t frame_stride, int32_t time_smooth,
+	const float* d_in, float* d_out);
+int tp_frames_subtract(tp_ctx* ctx, int64_t n_values, const float* d_raw, const float* d_raw_err, const float* d_bkg,
+	const uint8_t* d_pixel_flags, uint32_t flag_mask, float* d_images, float* d_images_err);
+int tp_frames_sumimage(tp_ctx* ctx, int32_t n_frames, int64_t n_pixels, int64_t frame_stride, const float* d_images,
+	const int32_t* d_quality, uint32_t bitmask, double* d_sumimage);
+
 /* ---- P1..P4: linear PSF photometry ----------------------------------------------------------------
  * tp_linpsf_prf (P1) replaces the per-target PRF construction of PSF.__init__ (photometry/psf.py:
  *   101-119).  The interpolating-spline fit is linear in the data, so the coefficient table of the

@@ -141,3 +141,75 @@ def subtract_background(raw, raw_err, bkg, pixel_flags=None, backapp=False):
 		img[excl] = np.nan
 		err[excl] = np.nan
 	return img, err
+
+
+#--------------------------------------------------------------------------------------------------
+# B1: the full-frame estimator (backgrounds.py:52-211), branch taken for a plain ndarray image
+#--------------------------------------------------------------------------------------------------
+def mesh_statistics(img, mask, box=64, sigma=3.0, maxiters=5):
+	"""
+	The low-resolution mesh of ``photutils.Background2D(img, (box, box), sigma_clip=SigmaClip(3, maxiters=5),
+	bkg_estimator=SExtractorBackground, mask=mask)`` (backgrounds.py:200-206), photutils 1.3.0 as published: the image is cut
+	into ``box x box`` cells (the reference's 2048 x 2048 frames divide evenly; other sizes are padded with masked pixels,
+	``edge_method='pad'``), the unmasked pixels of every cell are sigma-clipped ONCE (``Background2D`` applies its own
+	``sigma_clip`` and switches the estimator's off) and reduced by the SExtractor estimate.  Returns ``(mesh float64
+	(ny, nx), nmasked int (ny, nx))``; a cell without any unmasked pixel is NaN.
+	"""
+	img = np.asarray(img)
+	R, C = img.shape
+	ny, nx = -(-R // box), -(-C // box)
+	mesh = np.full((ny, nx), np.nan)
+	nmasked = np.zeros((ny, nx), dtype='int64')
+	for j in range(ny):
+		for i in range(nx):
+			cell = img[j*box:(j+1)*box, i*box:(i+1)*box]
+			m = mask[j*box:(j+1)*box, i*box:(i+1)*box]
+			nmasked[j, i] = box*box - int(np.sum(~m))     # padded pixels count as masked
+			data = sigma_clip(cell[~m], sigma, maxiters)
+			mesh[j, i] = sextractor_background(data)
+	return mesh, nmasked
+
+
+def mesh_to_background(mesh, nmasked, shape, box=64, exclude_percentile=50.0, filter_size=3):
+	"""
+	From the mesh to the full-resolution background, photutils 1.3.0 as published: cells with more than
+	``exclude_percentile`` % masked pixels are dropped and filled by inverse-distance weighting from the 10 nearest kept
+	cells (``ShepardIDWInterpolator``, power 1); 3 x 3 median filter (``generic_filter(nanmedian, mode='constant',
+	cval=nan)``); ``BkgZoomInterpolator``: cubic-spline ``scipy.ndimage.zoom(mesh, box, order=3, mode='reflect',
+	grid_mode=True)``, clipped to the range of the mesh.  scipy is called directly, as photutils does.
+	"""
+	from scipy import ndimage
+	mesh = np.array(mesh, dtype='float64', copy=True)
+	good = (nmasked <= exclude_percentile / 100.0 * box * box) & np.isfinite(mesh)
+	if not np.any(good):
+		raise ValueError("All meshes contain > %s masked pixels" % exclude_percentile)
+	if not np.all(good):
+		yy, xx = np.nonzero(good)
+		vals = mesh[good]
+		for (y, x) in zip(*np.nonzero(~good)):
+			d = np.hypot(yy - y, xx - x)
+			near = np.argsort(d, kind='stable')[:10]
+			w = 1.0 / d[near]
+			mesh[y, x] = np.sum(w * vals[near]) / np.sum(w)
+	if filter_size > 1:
+		mesh = ndimage.generic_filter(mesh, np.nanmedian, size=filter_size, mode='constant', cval=np.nan)
+	if mesh.shape == (1, 1):
+		return np.full(shape, mesh[0, 0])
+	bkg = ndimage.zoom(mesh, box, order=3, mode='reflect', cval=0.0, grid_mode=True)
+	bkg = np.clip(bkg, np.min(mesh), np.max(mesh))
+	return bkg[:shape[0], :shape[1]]
+
+
+def fit_background(image, flux_cutoff=8e4, exclude=None):
+	"""
+	``fit_background(image)`` for a plain 2-D array (backgrounds.py:52-211): not a TESS FFIImage, so ``bkgiters = 1`` and no
+	radial component (:156-157).  Returns ``(background float64, mask bool)``.  **Parity unpinned** against photutils /
+	astropy (not installable here) except for the reference's own known answer: a constant image comes back as that
+	constant with nothing masked (tests/test_background.py:36-54).
+	"""
+	img = np.asarray(image)
+	mask = stamp_mask(img, flux_cutoff, exclude)          # backgrounds.py:89-97
+	if np.all(mask):
+		return np.full(img.shape, np.nan), mask
+	mesh, nmasked = mesh_statistics(img, mask)
+	return mesh_to_background(mesh, nmasked, img.shape), mask

@@ -21,6 +21,8 @@ static const char* const kKernelNames[TPK_COUNT] = {
 	"tp_diagnostics_kernel",
 	"tp_cut_stamps_kernel",
 	"tp_psf_fit_kernel",
+	"tp_bkg_mesh_kernel",
+	"tp_bkg_zoom_kernel",
 	"tp_synth_kernel",
 };
 

@@ -26,6 +26,8 @@ enum tp_kernel_id {
 	TPK_DIAGNOSTICS,
 	TPK_CUTOUT,
 	TPK_PSF_FIT,
+	TPK_BKG_MESH,
+	TPK_BKG_ZOOM,
 	TPK_SYNTH,
 	TPK_COUNT
 };

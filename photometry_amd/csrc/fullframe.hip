@@ -1,0 +1,341 @@
+// fullframe.hip -- the full-frame (prepare stage) background path on a frame stack [T][R][C] resident in HBM.
+//
+// B1  tp_background_mesh + tp_background_zoom: backgrounds.fit_background for a plain image (photometry/backgrounds.py:52-211, the
+//     branch without the radial component: bkgiters = 1, :156-157): pixel mask (:89-97), photutils Background2D on 64 x 64 boxes
+//     with SigmaClip(3, maxiters = 5) and the SExtractor estimator (:200-206), cubic-spline zoom of the filtered mesh.
+//     The mesh statistics (every pixel of every frame: the heavy part) and the zoom back to full resolution run here; the
+//     32 x 32 mesh in between (exclusion of mostly-masked boxes, IDW fill, 3 x 3 median filter, spline prefilter) is host
+//     work on a few KB per frame (photometry_amd/prepare.py).
+// B2  tp_frames_smooth_time: prepare.py:317-335 for per-pixel background images (nanmean over +-w frames, float32).
+// B3  tp_frames_subtract:    prepare.py:419-425 (image -= background, manual-exclude pixels -> NaN).
+// A1  tp_frames_sumimage:    prepare.py:450-453, 459 (mean over the good-quality frames, NaN pixels skipped).
+//
+// tp_background_mesh, gfx950: one 256-thread workgroup per (box, frame).  The box (64 rows of 256 contiguous bytes) is loaded
+// coalesced, masked pixels become +inf, and the 4096 values are sorted in LDS by a bitonic network in which every thread keeps
+// 16 consecutive keys: the strides 8..1 of every merge level run in registers (v_min / v_max on compile-time indices), only the
+// 36 stages with stride >= 16 exchange through LDS (36 + 9 barriers instead of 78).  On the sorted keys the kept set of the
+// sigma clipping is a rank range: median by index, float64 two-pass mean / std by block reductions, bounds by counting.
+// LDS-exchange bound (not HBM): the median of 4096 keys needs their order.
+#include "common.h"
+#include <cmath>
+
+namespace {
+
+constexpr int kMeshThreads = 256;
+constexpr int kKeysPerThread = 16;
+constexpr int kMeshKeys = kMeshThreads * kKeysPerThread;   // 4096 = 64 x 64
+
+__device__ __forceinline__ double mesh_block_sum(double v, double* red) {
+	const int tid = threadIdx.x;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+	__syncthreads();
+	if ((tid & 63) == 0) red[tid >> 6] = v;
+	__syncthreads();
+	return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ascending / descending compare-exchange network on 16 registers for strides 8, 4, 2, 1 (one merge tail)
+template <int STRIDE>
+__device__ __forceinline__ void local_tail(float (&v)[kKeysPerThread], bool up) {
+#pragma unroll
+	for (int t = 0; t < kKeysPerThread / 2; ++t) {
+		const int lo = (t / STRIDE) * (STRIDE * 2) + (t % STRIDE), hi = lo + STRIDE;
+		const float a = v[lo], b = v[hi];
+		const float mn = fminf(a, b), mx = fmaxf(a, b);
+		v[lo] = up ? mn : mx;
+		v[hi] = up ? mx : mn;
+	}
+	if constexpr (STRIDE > 1) local_tail<STRIDE / 2>(v, up);
+}
+
+struct MeshArgs {
+	const float* frames; int n_rows, n_cols; int64_t row_pitch, frame_stride;
+	const uint8_t* exclude; int64_t exclude_frame_stride;     // optional manual-exclude image(s), [R][C] per frame (stride 0 = shared)
+	float flux_cutoff; int box; int nx, ny;
+	double* mesh; int32_t* nmasked;
+};
+
+__global__ __launch_bounds__(kMeshThreads) void tp_bkg_mesh_kernel(MeshArgs a)
+{
+	__shared__ __align__(16) float keys[kMeshKeys];
+	__shared__ double red[4];
+	const int bx = blockIdx.x, by = blockIdx.y, frame = blockIdx.z;
+	const int tid = threadIdx.x;
+	const int box = a.box, npix = box * box;
+	const float inf = __builtin_inff();
+	const float* img = a.frames + (int64_t)frame * a.frame_stride;
+	const uint8_t* excl = a.exclude ? (a.exclude + (int64_t)frame * a.exclude_frame_stride) : nullptr;
+	// ---- load + mask (backgrounds.py:89-97); pixels beyond the frame (padding of the last boxes) are masked
+	int nvalid = 0;
+	for (int e = tid; e < kMeshKeys; e += kMeshThreads) {
+		float x = inf;
+		if (e < npix) {
+			const int r = by * box + e / box, c = bx * box + e % box;
+			if (r < a.n_rows && c < a.n_cols) {
+				x = img[(int64_t)r * a.row_pitch + c];
+				bool ok = (x >= 0.f) && (x <= a.flux_cutoff);
+				if (excl && excl[(int64_t)r * a.n_cols + c]) ok = false;
+				nvalid += ok ? 1 : 0;
+				x = ok ? x : inf;
+			}
+		}
+		keys[e] = x;
+	}
+	const int n = (int)mesh_block_sum((double)nvalid, red);
+	__syncthreads();
+	// ---- bitonic sort of the 4096 keys, ascending; thread t owns keys[16 t .. 16 t + 15]
+	float v[kKeysPerThread];
+	{
+		const float4* k4 = reinterpret_cast<const float4*>(keys + tid * kKeysPerThread);
+#pragma unroll
+		for (int q = 0; q < 4; ++q) { const float4 t = k4[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+		// sizes 2, 4, 8 inside the thread: direction from the local index; size 16: from the thread index
+#pragma unroll
+		for (int size = 2; size <= 8; size <<= 1) {
+#pragma unroll
+			for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+				for (int t = 0; t < kKeysPerThread / 2; ++t) {
+					const int lo = (t / stride) * (stride * 2) + (t % stride), hi = lo + stride;
+					const bool up = ((lo & size) == 0);
+					const float x = v[lo], y = v[hi];
+					const float mn = fminf(x, y), mx = fmaxf(x, y);
+					v[lo] = up ? mn : mx;
+					v[hi] = up ? mx : mn;
+				}
+			}
+		}
+		local_tail<8>(v, (tid & 1) == 0);     // size 16: up iff bit 4 of the global index is clear
+		float4* o4 = reinterpret_cast<float4*>(keys + tid * kKeysPerThread);
+#pragma unroll
+		for (int q = 0; q < 4; ++q) o4[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+	}
+	__syncthreads();
+	for (int size = 32; size <= kMeshKeys; size <<= 1) {
+		for (int stride = size >> 1; stride >= kKeysPerThread; stride >>= 1) {
+			for (int t = tid; t < kMeshKeys / 2; t += kMeshThreads) {
+				const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)), hi = lo + stride;
+				const bool up = ((lo & size) == 0) || size == kMeshKeys;
+				const float x = keys[lo], y = keys[hi];
+				if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+			}
+			__syncthreads();
+		}
+		const float4* k4 = reinterpret_cast<const float4*>(keys + tid * kKeysPerThread);
+#pragma unroll
+		for (int q = 0; q < 4; ++q) { const float4 t = k4[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+		local_tail<8>(v, ((tid * kKeysPerThread) & size) == 0 || size == kMeshKeys);
+		float4* o4 = reinterpret_cast<float4*>(keys + tid * kKeysPerThread);
+#pragma unroll
+		for (int q = 0; q < 4; ++q) o4[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+		__syncthreads();
+	}
+	// ---- SigmaClip(3, maxiters = 5) on the rank range [lo, hi), then the SExtractor estimate
+	double result = __builtin_nan("");
+	if (n > 0) {
+		int lo = 0, hi = n;
+		double med = 0.0, mean = 0.0, sd = 0.0;
+		for (int it = 0; it <= 5; ++it) {
+			const int m = hi - lo;
+			const int m1 = lo + (m >> 1), m0 = (m & 1) ? m1 : (m1 - 1);
+			med = ((double)keys[m0] + (double)keys[m1]) / 2.0;
+			double s = 0.0;
+			for (int i = lo + tid; i < hi; i += kMeshThreads) s += (double)keys[i];
+			mean = mesh_block_sum(s, red) / (double)m;
+			double q = 0.0;
+			for (int i = lo + tid; i < hi; i += kMeshThreads) { const double d = (double)keys[i] - mean; q += d * d; }
+			sd = sqrt(mesh_block_sum(q, red) / (double)m);      // np.std: population, two-pass
+			if (it == 5) break;
+			const double tlo = med - 3.0 * sd, thi = med + 3.0 * sd;
+			int below = 0, above = 0;
+			for (int i = lo + tid; i < hi; i += kMeshThreads) { const double x = (double)keys[i]; below += (x < tlo); above += (x > thi); }
+			const int nb = (int)mesh_block_sum((double)below, red), na = (int)mesh_block_sum((double)above, red);
+			if (nb == 0 && na == 0) break;
+			lo += nb; hi -= na;
+		}
+		if (sd == 0.0) result = mean;
+		else if (fabs(mean - med) / sd < 0.3) result = 2.5 * med - 1.5 * mean;
+		else result = med;
+	}
+	if (tid == 0) {
+		const int64_t o = ((int64_t)frame * a.ny + by) * a.nx + bx;
+		a.mesh[o] = result;
+		a.nmasked[o] = npix - n;
+	}
+}
+
+// cubic B-spline zoom of the prefiltered mesh coefficients (scipy.ndimage.zoom order 3, mode 'reflect', grid_mode = True) with
+// the clipping of photutils' BkgZoomInterpolator; one thread per output pixel, the frame's coefficients in LDS
+__global__ __launch_bounds__(256) void tp_bkg_zoom_kernel(const double* __restrict__ coef, const double* __restrict__ vmin, const double* __restrict__ vmax,
+	int ny, int nx, int box, int n_rows, int n_cols, int64_t out_row_pitch, int64_t out_frame_stride, float* __restrict__ out)
+{
+	extern __shared__ double c[];   // [ny][nx]
+	const int frame = blockIdx.z;
+	for (int i = threadIdx.x; i < ny * nx; i += blockDim.x) c[i] = coef[(int64_t)frame * ny * nx + i];
+	__syncthreads();
+	const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+	if (col >= n_cols || row >= n_rows) return;
+	auto weights = [](double x, double (&w)[4], int& start) {
+		const double fl = floor(x);
+		start = (int)fl - 1;
+		const double y = x - fl, z = 1.0 - y;
+		w[1] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0;
+		w[2] = (z * z * (z - 2.0) * 3.0 + 4.0) / 6.0;
+		w[0] = z * z * z / 6.0;
+		w[3] = 1.0 - w[0] - w[1] - w[2];
+	};
+	auto reflect = [](int i, int n) { // (d c b a | a b c d | d c b a)
+		if (n == 1) return 0;
+		const int p = 2 * n;
+		i = ((i % p) + p) % p;
+		return (i < n) ? i : (p - 1 - i);
+	};
+	double wy[4], wx[4];
+	int sy, sx;
+	weights(((double)row + 0.5) / (double)box - 0.5, wy, sy);
+	weights(((double)col + 0.5) / (double)box - 0.5, wx, sx);
+	double acc = 0.0;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const double* r = c + reflect(sy + j, ny) * nx;
+		double t = 0.0;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) t += wx[i] * r[reflect(sx + i, nx)];
+		acc += wy[j] * t;
+	}
+	const double lo = vmin[frame], hi = vmax[frame];
+	acc = (acc < lo) ? lo : ((acc > hi) ? hi : acc);
+	out[(int64_t)frame * out_frame_stride + (int64_t)row * out_row_pitch + col] = (float)acc;
+}
+
+// B2 on images: out[k][p] = nanmean(in[k-w .. k+w][p]), sequential float32 accumulation like bottleneck.nanmean
+__global__ __launch_bounds__(256) void tp_frames_smooth_kernel(const float* __restrict__ in, float* __restrict__ out, int n_frames, int64_t n_pix,
+	int64_t frame_stride, int w)
+{
+	const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const int k = blockIdx.y;
+	if (p >= n_pix) return;
+	const int i1 = (k - w > 0) ? (k - w) : 0, i2 = (k + w + 1 < n_frames) ? (k + w + 1) : n_frames;
+	float asum = 0.f;
+	int cnt = 0;
+	for (int i = i1; i < i2; ++i) { const float v = in[(int64_t)i * frame_stride + p]; if (v == v) { asum += v; cnt++; } }
+	out[(int64_t)k * frame_stride + p] = (cnt > 0) ? (asum / (float)cnt) : __builtin_nanf("");
+}
+
+// B3 on images (prepare.py:419-425)
+__global__ __launch_bounds__(256) void tp_frames_subtract_kernel(const float* __restrict__ raw, const float* __restrict__ raw_err, const float* __restrict__ bkg,
+	const uint8_t* __restrict__ flags, uint32_t flag_mask, float* __restrict__ img, float* __restrict__ err, int64_t n)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const bool excl = flags && (flags[i] & flag_mask) != 0;
+	const float r = raw[i] - bkg[i];
+	img[i] = excl ? __builtin_nanf("") : r;
+	if (raw_err && err) err[i] = excl ? __builtin_nanf("") : raw_err[i];
+}
+
+// A1 on images (prepare.py:450-453, 459): SumImage = sum over good frames of the finite pixels / their count (0 / 0 = NaN)
+__global__ __launch_bounds__(256) void tp_frames_sumimage_kernel(const float* __restrict__ images, const int32_t* __restrict__ quality, uint32_t bitmask,
+	int n_frames, int64_t n_pix, int64_t frame_stride, double* __restrict__ out)
+{
+	const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n_pix) return;
+	double s = 0.0;
+	int cnt = 0;
+	for (int k = 0; k < n_frames; ++k) {
+		if ((quality[k] & bitmask) != 0) continue;
+		const float v = images[(int64_t)k * frame_stride + p];
+		if (fabsf(v) <= 3.402823466e+38f) { s += (double)v; cnt++; }
+	}
+	out[p] = (cnt > 0) ? s / (double)cnt : __builtin_nan("");
+}
+
+} // namespace
+
+extern "C" int tp_background_mesh(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+	int64_t row_pitch, int64_t frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride,
+	double flux_cutoff, int32_t box_size, double* d_mesh, int32_t* d_nmasked)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_frames && d_mesh && d_nmasked, "tp_background_mesh: null pointer");
+	TP_REQUIRE(ctx, n_frames >= 0 && frame_rows > 0 && frame_cols > 0 && row_pitch >= frame_cols && frame_stride >= (int64_t)frame_rows * row_pitch, "tp_background_mesh: bad frame geometry");
+	TP_REQUIRE(ctx, box_size >= 1 && box_size * box_size <= kMeshKeys, "tp_background_mesh: box_size must be 1..64");
+	if (n_frames == 0) return TP_OK;
+	MeshArgs a;
+	a.frames = d_frames; a.n_rows = frame_rows; a.n_cols = frame_cols; a.row_pitch = row_pitch; a.frame_stride = frame_stride;
+	a.exclude = d_exclude; a.exclude_frame_stride = exclude_frame_stride;
+	a.flux_cutoff = (float)flux_cutoff; a.box = box_size;
+	a.nx = (frame_cols + box_size - 1) / box_size; a.ny = (frame_rows + box_size - 1) / box_size;
+	a.mesh = d_mesh; a.nmasked = d_nmasked;
+	TP_REQUIRE(ctx, a.ny <= 65535 && n_frames <= 65535, "tp_background_mesh: too many boxes / frames for one launch");
+	TP_LAUNCH(ctx, TPK_BKG_MESH, tp_bkg_mesh_kernel, dim3((unsigned)a.nx, (unsigned)a.ny, (unsigned)n_frames), dim3(kMeshThreads), 0, a);
+	TP_LAUNCH_CHECK(ctx, "tp_bkg_mesh_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_background_zoom(tp_ctx* ctx, const double* d_coef, const double* d_vmin, const double* d_vmax, int32_t n_frames,
+	int32_t mesh_rows, int32_t mesh_cols, int32_t box_size, int32_t frame_rows, int32_t frame_cols, int64_t row_pitch, int64_t frame_stride,
+	float* d_background)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_coef && d_vmin && d_vmax && d_background, "tp_background_zoom: null pointer");
+	TP_REQUIRE(ctx, mesh_rows > 0 && mesh_cols > 0 && box_size > 0 && frame_rows > 0 && frame_cols > 0 && row_pitch >= frame_cols, "tp_background_zoom: bad geometry");
+	TP_REQUIRE(ctx, (size_t)mesh_rows * mesh_cols * sizeof(double) <= 64 * 1024, "tp_background_zoom: mesh too large for LDS");
+	TP_REQUIRE(ctx, frame_rows <= 65535 && n_frames <= 65535, "tp_background_zoom: too many rows / frames for one launch");
+	if (n_frames == 0) return TP_OK;
+	dim3 grid((unsigned)((frame_cols + 255) / 256), (unsigned)frame_rows, (unsigned)n_frames);
+	TP_LAUNCH(ctx, TPK_BKG_ZOOM, tp_bkg_zoom_kernel, grid, dim3(256), (size_t)mesh_rows * mesh_cols * sizeof(double), d_coef, d_vmin, d_vmax,
+		(int)mesh_rows, (int)mesh_cols, (int)box_size, (int)frame_rows, (int)frame_cols, row_pitch, frame_stride, d_background);
+	TP_LAUNCH_CHECK(ctx, "tp_bkg_zoom_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_frames_smooth_time(tp_ctx* ctx, int32_t n_frames, int64_t n_pixels, int64_t frame_stride, int32_t time_smooth,
+	const float* d_in, float* d_out)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_in && d_out && d_in != d_out, "tp_frames_smooth_time: null or aliased pointers");
+	TP_REQUIRE(ctx, n_frames >= 0 && n_frames <= 65535 && n_pixels >= 0 && frame_stride >= n_pixels && time_smooth >= 1, "tp_frames_smooth_time: bad geometry");
+	if (n_frames == 0 || n_pixels == 0) return TP_OK;
+	dim3 grid((unsigned)((n_pixels + 255) / 256), (unsigned)n_frames);
+	TP_LAUNCH(ctx, TPK_BKG_SMOOTH, tp_frames_smooth_kernel, grid, dim3(256), 0, d_in, d_out, (int)n_frames, n_pixels, frame_stride, (int)(time_smooth / 2));
+	TP_LAUNCH_CHECK(ctx, "tp_frames_smooth_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_frames_subtract(tp_ctx* ctx, int64_t n_values, const float* d_raw, const float* d_raw_err, const float* d_bkg,
+	const uint8_t* d_pixel_flags, uint32_t flag_mask, float* d_images, float* d_images_err)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_raw && d_bkg && d_images, "tp_frames_subtract: null pointer");
+	if (n_values <= 0) return TP_OK;
+	TP_REQUIRE(ctx, (n_values + 255) / 256 <= 2147483647ll, "tp_frames_subtract: too many values for one launch");
+	TP_LAUNCH(ctx, TPK_BKG_SUBTRACT, tp_frames_subtract_kernel, dim3((unsigned)((n_values + 255) / 256)), dim3(256), 0, d_raw, d_raw_err, d_bkg,
+		d_pixel_flags, flag_mask, d_images, d_images_err, n_values);
+	TP_LAUNCH_CHECK(ctx, "tp_frames_subtract_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_frames_sumimage(tp_ctx* ctx, int32_t n_frames, int64_t n_pixels, int64_t frame_stride, const float* d_images,
+	const int32_t* d_quality, uint32_t bitmask, double* d_sumimage)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_images && d_quality && d_sumimage, "tp_frames_sumimage: null pointer");
+	TP_REQUIRE(ctx, n_frames >= 0 && n_pixels >= 0 && frame_stride >= n_pixels, "tp_frames_sumimage: bad geometry");
+	if (n_pixels == 0) return TP_OK;
+	TP_LAUNCH(ctx, TPK_SUMIMAGE, tp_frames_sumimage_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, d_images, d_quality, bitmask,
+		(int)n_frames, n_pixels, frame_stride, d_sumimage);
+	TP_LAUNCH_CHECK(ctx, "tp_frames_sumimage_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}
