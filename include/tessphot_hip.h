@@ -103,6 +103,7 @@ int tp_event_create(tp_ctx* ctx, void** event);
 int tp_event_destroy(tp_ctx* ctx, void* event);
 int tp_event_record(tp_ctx* ctx, void* event);           /* on ctx's stream */
 int tp_stream_wait_event(tp_ctx* ctx, void* event);      /* ctx's stream waits for the event */
+int tp_event_sync(tp_ctx* ctx, void* event);             /* the HOST waits for the event (reuse of a pinned staging buffer) */
 
 /* HIP-event stopwatch on the ctx stream; slot in [0, 16). */
 int tp_timer_start(tp_ctx* ctx, int slot);

@@ -64,6 +64,7 @@ SIGNATURES = {
 	'tp_event_destroy': (c_int, [c_void_p, c_void_p]),
 	'tp_event_record': (c_int, [c_void_p, c_void_p]),
 	'tp_stream_wait_event': (c_int, [c_void_p, c_void_p]),
+	'tp_event_sync': (c_int, [c_void_p, c_void_p]),
 	'tp_timer_start': (c_int, [c_void_p, c_int]),
 	'tp_timer_stop': (c_int, [c_void_p, c_int]),
 	'tp_timer_elapsed_ms': (c_int, [c_void_p, c_int, POINTER(c_float)]),

@@ -282,6 +282,13 @@ int tp_event_record(tp_ctx* ctx, void* event) {
 	return TP_OK;
 }
 
+int tp_event_sync(tp_ctx* ctx, void* event) {
+	TP_CHECK_CTX(ctx);
+	TP_REQUIRE(ctx, event != nullptr, "tp_event_sync: null event");
+	TP_HIP(ctx, hipEventSynchronize((hipEvent_t)event));
+	return TP_OK;
+}
+
 int tp_stream_wait_event(tp_ctx* ctx, void* event) {
 	TP_CHECK_CTX(ctx);
 	TP_REQUIRE(ctx, event != nullptr, "tp_stream_wait_event: null event");

@@ -255,6 +255,10 @@ class Context(object):
 	def wait_event(self, event):
 		self._check(self.lib.tp_stream_wait_event(self.handle, event))
 
+	def event_sync(self, event):
+		"""Block the host until ``event`` has happened."""
+		self._check(self.lib.tp_event_sync(self.handle, event))
+
 	def timer_start(self, slot=0):
 		self._check(self.lib.tp_timer_start(self.handle, slot))
 

@@ -268,10 +268,12 @@ class FrameStack(object):
 	"""
 
 	def __init__(self, ctx, frames, row0, col0):
+		"""``frames``: host arrays (uploaded) or float32 DeviceArrays ``(T, R, C)`` already in HBM (e.g. from ``frameio.load_stack``)."""
+		from .device import DeviceArray
 		self.ctx = ctx
 		self.row0, self.col0 = int(row0), int(col0)
 		self.names = ('images', 'images_err', 'backgrounds')
-		self.dev = {k: ctx.array(np.ascontiguousarray(frames[k], dtype='float32')) for k in self.names}
+		self.dev = {k: (frames[k] if isinstance(frames[k], DeviceArray) else ctx.array(np.ascontiguousarray(frames[k], dtype='float32'))) for k in self.names}
 		self.n_cad, self.n_rows, self.n_cols = self.dev['images'].shape
 		self.limits = (self.row0, self.row0 + self.n_rows, self.col0, self.col0 + self.n_cols)
 

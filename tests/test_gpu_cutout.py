@@ -71,3 +71,27 @@ def test_cut_then_photometry_equals_uploaded_cubes(ctx):
 	got = pipeline.run_aperture(ctx, s, cubes=cubes)
 	for k in ('sumimage', 'mask', 'status', 'flux', 'flux_err', 'flux_background', 'diagnostics'):
 		np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
+def test_cutout_from_a_stack_file(tmp_path):
+	"""File -> HBM -> stamp cutter: the golden frames written to a .tpstack file, streamed in through the pinned double buffer
+	(several chunks), cut on the device == the reference's _load_cube on the same frames (golden_cutout.npz)."""
+	import os
+	from photometry_amd import engine, frameio
+	from photometry_amd.device import Context
+	g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'golden_cutout.npz'))
+	frames = np.ascontiguousarray(g['frames'])           # (T, R, C)
+	path = str(tmp_path / 'golden.tpstack')
+	frameio.write_stack(path, {'images': frames.astype('float32')}, row_offset=int(g['offsets'][0]), col_offset=int(g['offsets'][1]))
+	ctx = Context(0)
+	meta = frameio.read_header(path)
+	dev = frameio.upload_group(ctx, frameio.open_group(path, 'images', meta), frames_per_chunk=9)
+	np.testing.assert_array_equal(dev.to_host(), frames.astype('float32'))
+	stamps = np.asarray(g['stamps'], dtype='int32')
+	shapes = {(s[1] - s[0], s[3] - s[2]) for s in stamps}
+	for (H, W) in shapes:
+		idx = [i for i, s in enumerate(stamps) if (s[1] - s[0], s[3] - s[2]) == (H, W)]
+		cube = engine.cut_stamps(ctx, dev, ctx.array(stamps[idx]), H, W, meta['row_offset'], meta['col_offset']).to_host()
+		for j, i in enumerate(idx):
+			np.testing.assert_array_equal(cube[j], g['cubes'][i])
+	ctx.close()

@@ -132,6 +132,30 @@ def test_linpsf_plugin(ctx, tmp_path):
 		np.testing.assert_allclose(pho.lightcurve['flux'], ref['flux'], rtol=1e-8, atol=1e-9*np.nanmax(np.abs(ref['flux'])))
 
 
+def test_psf_plugin(ctx, tmp_path):
+	"""tessphot('psf'): the non-linear PSF plugin end to end; like LinPSF its flux_err is all NaN upstream (psf_photometry.py:175),
+	which BasePhotometry.photometry() rejects (BasePhotometry.py:1348-1349) -> STATUS.ERROR, with the light curve filled in."""
+	from photometry_amd import psf as hpsf
+	from oracle import psf as opsf, psf_photometry as opp
+	s = simulate.make_scene(2, 3, 11, 11, seed=71, max_neighbours=1, neighbour_tmag_range=(9.0, 14.0))
+	simulate.fill_cubes(s, nan_fraction=0.003)
+	prf = opsf.synthetic_prf(seed=4)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	for i in range(2):
+		src = source_from_scene(s, i)
+		src.prf = model
+		pho = tessphot('psf', int(s.target_starid[i]), src, str(tmp_path), ctx=ctx)
+		assert pho.method == 'psf' and pho.status == STATUS.ERROR and any('errors are all NaNs' in e for e in pho._details['errors'])
+		p = opsf.PSF(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'], pho.stamp)
+		cat = pho.catalog
+		ref = opp.do_photometry(s.images[i], s.backgrounds[i], p, {k: cat[k] for k in ('row_stamp', 'column_stamp', 'tmag')}, pho.stamp,
+			pho.target_pos_row, pho.target_pos_column, pho.target['tmag'], pho.aperture, n_readout=pho.n_readout)
+		ok = ref['success'] & ~np.isnan(pho.lightcurve['flux'])
+		assert ok.sum() >= 2
+		np.testing.assert_allclose(pho.lightcurve['flux'][ok], ref['flux'][ok], rtol=2e-5)
+		np.testing.assert_allclose(pho.lightcurve['pos_centroid'][ok], ref['pos_centroid'][ok], atol=2e-4)
+
+
 def test_batch_api(ctx):
 	s = _scene(n=12, T=30, seed=9)
 	res = tessphot_batch(ctx, s)
