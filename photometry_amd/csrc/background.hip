@@ -34,7 +34,8 @@
 // (16-byte loads, two barriers: 6.2 ms against 5.9 -- the load phase alone got faster, 2.1 against 2.9 ms, the kernel
 // did not, it is not waiting for memory); prefetching the next 32-cadence block into 32 more registers while sorting
 // (5.8 -> 6.2 ms at 4 or 5 waves per SIMD: nothing left to hide); a bitonic instead of Batcher's network for the
-// per-lane sort (5.9 ms); cross-lane exchanges in groups of 4 / 8 independent DPP moves (no change).
+// per-lane sort (5.9 ms); cross-lane exchanges in groups of 4 / 8 independent DPP moves (no change); four lanes per frame
+// instead of eight (half the redundant clipping work, but 109 VGPRs and twice the LDS per wavefront: 6.4 ms).
 #include "common.h"
 #include <cmath>
 #include <utility>
@@ -69,30 +70,30 @@ struct BitonicStage<N, SIZE, 0> {
 	static __device__ __forceinline__ void run(float (&)[N]) {}
 };
 
-// Batcher's odd-even merge sort of 32 values as a compile-time list of compare-exchanges (Knuth 5.2.2 algorithm M)
-struct Oem32 { unsigned char a[256], b[256]; int n; };
-constexpr Oem32 make_oem32() {
-	Oem32 r{};
-	const int n = 32;
+// Batcher's odd-even merge sort of N values as a compile-time list of compare-exchanges (Knuth 5.2.2 algorithm M)
+template <int N> struct OemNet { unsigned char a[N * 12], b[N * 12]; int n; };
+template <int N>
+constexpr OemNet<N> make_oem() {
+	OemNet<N> r{};
 	int c = 0;
-	for (int p = 1; p < n; p *= 2)
+	for (int p = 1; p < N; p *= 2)
 		for (int k = p; k >= 1; k /= 2)
-			for (int j = k % p; j <= n - 1 - k; j += 2 * k)
-				for (int i = 0; i <= ((k - 1 < n - j - k - 1) ? (k - 1) : (n - j - k - 1)); ++i)
+			for (int j = k % p; j <= N - 1 - k; j += 2 * k)
+				for (int i = 0; i <= ((k - 1 < N - j - k - 1) ? (k - 1) : (N - j - k - 1)); ++i)
 					if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) { r.a[c] = (unsigned char)(i + j); r.b[c] = (unsigned char)(i + j + k); ++c; }
 	r.n = c;
 	return r;
 }
-constexpr Oem32 kOem32 = make_oem32();
-static_assert(kOem32.n == 191, "Batcher network of 32 keys");
-template <size_t I>
-__device__ __forceinline__ void oem_exchange(float (&v)[32]) {
-	const float x = v[kOem32.a[I]], y = v[kOem32.b[I]];
-	v[kOem32.a[I]] = tp_min(x, y);
-	v[kOem32.b[I]] = tp_max(x, y);
+template <int N> struct Oem { static constexpr OemNet<N> net = make_oem<N>(); };
+static_assert(Oem<32>::net.n == 191 && Oem<64>::net.n == 543, "Batcher networks of 32 / 64 keys");
+template <int N, size_t I>
+__device__ __forceinline__ void oem_exchange(float (&v)[N]) {
+	const float x = v[Oem<N>::net.a[I]], y = v[Oem<N>::net.b[I]];
+	v[Oem<N>::net.a[I]] = tp_min(x, y);
+	v[Oem<N>::net.b[I]] = tp_max(x, y);
 }
-template <size_t... I>
-__device__ __forceinline__ void oem_sort32(float (&v)[32], std::index_sequence<I...>) { (oem_exchange<I>(v), ...); }
+template <int N, size_t... I>
+__device__ __forceinline__ void oem_sort(float (&v)[N], std::index_sequence<I...>) { (oem_exchange<N, I>(v), ...); }
 
 struct BkgArgs {
 	const float* raw; float* out; int n_cad; int n_pix; int64_t t_pitch; int64_t out_pitch;
@@ -108,13 +109,9 @@ __device__ __forceinline__ float sextractor_mode(double med, double mean, double
 	return (float)bkg;
 }
 
-constexpr int kLanesPerFrame = 8;
-constexpr int kValsPerLane = 32;
-constexpr int kFramesPerWave = 64 / kLanesPerFrame;
-constexpr int kBkgThreads = 256;
-constexpr int kFramesPerBlock = kFramesPerWave * (kBkgThreads / 64);
+constexpr int kFramesPerBlock = 32;   // cadences per workgroup = one 128-byte line of every pixel's time series
 
-// DPP lane permutations inside the 8 lanes of a frame
+// DPP lane permutations inside the lanes of a frame
 constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
 constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
 constexpr int kDppQuadRev = 0x1B;     // quad_perm [3,2,1,0]        (lane ^ 3)
@@ -125,101 +122,117 @@ template <int CTRL> __device__ __forceinline__ double dpp_d(double x) {
 	const int lo = dpp_i<CTRL>(__double2loint(x)), hi = dpp_i<CTRL>(__double2hiint(x));
 	return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ int frame_sum(int x) { x += dpp_i<kDppXor1>(x); x += dpp_i<kDppXor2>(x); x += dpp_i<kDppHalfMirror>(x); return x; }
-__device__ __forceinline__ double frame_sum(double x) { x += dpp_d<kDppXor1>(x); x += dpp_d<kDppXor2>(x); x += dpp_d<kDppHalfMirror>(x); return x; }
+template <int G> __device__ __forceinline__ int frame_sum(int x) {
+	x += dpp_i<kDppXor1>(x); x += dpp_i<kDppXor2>(x);
+	if (G == 8) x += dpp_i<kDppHalfMirror>(x);
+	return x;
+}
+template <int G> __device__ __forceinline__ double frame_sum(double x) {
+	x += dpp_d<kDppXor1>(x); x += dpp_d<kDppXor2>(x);
+	if (G == 8) x += dpp_d<kDppHalfMirror>(x);
+	return x;
+}
 
-// Cross-lane compare-exchange stage: register j against register j (MIRROR: 31 - j) of the partner lane; sel = -inf
+// Cross-lane compare-exchange stage: register j against register j (MIRROR: R-1 - j) of the partner lane; sel = -inf
 // keeps the minimum (v_med3_f32(a, b, -inf) = min), sel = +inf the maximum.
-template <int CTRL, bool MIRROR>
-__device__ __forceinline__ void cross_stage(float (&v)[kValsPerLane], float sel) {
+template <int CTRL, bool MIRROR, int R>
+__device__ __forceinline__ void cross_stage(float (&v)[R], float sel) {
 	if (MIRROR) {
 #pragma unroll
-		for (int j = 0; j < kValsPerLane / 2; ++j) {
-			const float a = v[j], b = v[kValsPerLane - 1 - j];
+		for (int j = 0; j < R / 2; ++j) {
+			const float a = v[j], b = v[R - 1 - j];
 			const float pa = dpp_f<CTRL>(b), pb = dpp_f<CTRL>(a);
 			v[j] = __builtin_amdgcn_fmed3f(a, pa, sel);
-			v[kValsPerLane - 1 - j] = __builtin_amdgcn_fmed3f(b, pb, sel);
+			v[R - 1 - j] = __builtin_amdgcn_fmed3f(b, pb, sel);
 		}
 	} else {
 #pragma unroll
-		for (int j = 0; j < kValsPerLane; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], dpp_f<CTRL>(v[j]), sel);
+		for (int j = 0; j < R; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], dpp_f<CTRL>(v[j]), sel);
 	}
 }
-// ascending bitonic MERGE of a lane's 32 values (strides 16..1)
-__device__ __forceinline__ void local_merge(float (&v)[kValsPerLane]) { BitonicStage<kValsPerLane, kValsPerLane, kValsPerLane / 2>::run(v); }
+// ascending bitonic MERGE of a lane's R values (strides R/2..1)
+template <int R> __device__ __forceinline__ void local_merge(float (&v)[R]) { BitonicStage<R, R, R / 2>::run(v); }
 
-// LDS index of rank r of a staged frame: every lane's run of 32 ranks is followed by 4 pad words, so that the eight
-// 16-byte stores of a staging instruction fall into different banks
+// LDS index of rank r of a staged frame: every run of 32 ranks is followed by 4 pad words, so that the 16-byte stores of the
+// lanes of a frame fall into different banks
 __device__ __forceinline__ int rank_idx(int r) { return r + ((r >> 5) << 2); }
 
-// JFULL: number of complete 8-pixel rows (n_pix / 8) when known at compile time (the pixel-count test is then only made
-// for the last rows), -1 = test every slot.
-template <int JFULL>
-__global__ __launch_bounds__(kBkgThreads) void tp_bkg_stamp_kernel(BkgArgs a, int frame_stride)
+// G: lanes per frame (8: 32 values per lane, 8 frames per wavefront; 4: 64 values per lane, 16 frames per wavefront).
+// JFULL: number of complete G-pixel rows (n_pix / G) when known at compile time (the pixel-count test is then only made for the
+// last rows), -1 = test every slot.
+template <int G, int JFULL>
+__global__ __launch_bounds__(kFramesPerBlock * G) void tp_bkg_stamp_kernel(BkgArgs a, int frame_stride)
 {
+	constexpr int R = 256 / G;             // values per lane
+	constexpr int FPW = 64 / G;            // frames per wavefront
+	constexpr int SHIFT = (G == 8) ? 3 : 2;
 	extern __shared__ __align__(16) float s_sorted[]; // [kFramesPerBlock][frame_stride]
 	const int target = blockIdx.x;
 	const int tid = threadIdx.x;
 	const int wave = tid >> 6, lane = tid & 63;
-	const int f = lane >> 3, g = lane & 7;   // frame within the wavefront, lane within the frame
-	const int k = blockIdx.y * kFramesPerBlock + wave * kFramesPerWave + f;
+	const int f = lane >> SHIFT, g = lane & (G - 1);   // frame within the wavefront, lane within the frame
+	const int k = blockIdx.y * kFramesPerBlock + wave * FPW + f;
 	const bool active = k < a.n_cad;
 	const float inf = __builtin_inff();
-	float* fr = s_sorted + (size_t)(wave * kFramesPerWave + f) * frame_stride;
+	float* fr = s_sorted + (size_t)(wave * FPW + f) * frame_stride;
 
-	// --- loads: pixel i = 8 j + g of cadence k; the descriptor covers this target's cube, the row offset is scalar
+	// --- loads: pixel i = G j + g of cadence k; the descriptor covers this target's cube, the row offset is scalar
 	const int pitch_b = (int)a.t_pitch * 4;
 	const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
 		const_cast<float*>(a.raw + (int64_t)target * a.n_pix * a.t_pitch), 0, a.n_pix * pitch_b, 0x00020000);
 	const int voff = g * pitch_b + (active ? k : (a.n_cad - 1)) * 4;
-	float v[kValsPerLane];
+	float v[R];
 #pragma unroll
-	for (int j = 0; j < kValsPerLane; ++j) // all 32 loads in flight before the first use
-		v[j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, j * kLanesPerFrame * pitch_b, 0));
+	for (int j = 0; j < R; ++j) // all loads in flight before the first use
+		v[j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, j * G * pitch_b, 0));
 	int n = 0;
 	double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-	for (int j = 0; j < kValsPerLane; ++j) {
+	for (int j = 0; j < R; ++j) {
 		const float x = v[j];
 		// backgrounds.py:91-94: mask = ~isfinite | > flux_cutoff | < 0; slots past the last pixel are masked too
 		bool ok = (x >= 0.f) && (x <= a.flux_cutoff);
-		if (JFULL < 0 || j >= JFULL) ok = ok && (j * kLanesPerFrame + g < a.n_pix);
+		if (JFULL < 0 || j >= JFULL) ok = ok && (j * G + g < a.n_pix);
 		n += ok ? 1 : 0;
 		v[j] = ok ? x : inf;
 		float z = ok ? x : 0.f;
-		asm("" : "+v"(z));   // keep the conversion in the loop (else 32 doubles stay live)
+		asm("" : "+v"(z));   // keep the conversion in the loop (else R doubles stay live)
 		const double zd = (double)z;
 		s1 += zd;
 		s2 = __builtin_fma(zd, zd, s2);
 	}
-	n = frame_sum(n);
-	s1 = frame_sum(s1);
-	s2 = frame_sum(s2);
+	n = frame_sum<G>(n);
+	s1 = frame_sum<G>(s1);
+	s2 = frame_sum<G>(s2);
 
-	// --- distributed bitonic sort of the 256 values of the frame: rank = 32 g + j
+	// --- distributed sort of the 256 values of the frame: rank = R g + j
 	const float sel1 = (g & 1) ? inf : -inf, sel2 = (g & 2) ? inf : -inf, sel4 = (g & 4) ? inf : -inf;
-	oem_sort32(v, std::make_index_sequence<kOem32.n>());      // every lane ascending (Batcher: 191 instead of 240 exchanges)
-	cross_stage<kDppXor1, true>(v, sel1);                        // size 64: mirror against lane^1,
-	local_merge(v);                                              //          then ascending merges
-	cross_stage<kDppQuadRev, true>(v, sel2);                     // size 128: mirror against lane^3,
-	cross_stage<kDppXor1, false>(v, sel1);                       //           stride 32 against lane^1,
-	local_merge(v);                                              //           strides 16..1
-	cross_stage<kDppHalfMirror, true>(v, sel4);                  // size 256: mirror against lane^7,
-	cross_stage<kDppXor2, false>(v, sel2);                       //           stride 64 against lane^2,
-	cross_stage<kDppXor1, false>(v, sel1);                       //           stride 32 against lane^1,
-	local_merge(v);                                              //           strides 16..1
+	oem_sort<R>(v, std::make_index_sequence<Oem<R>::net.n>());   // every lane ascending (Batcher: 191 / 543 exchanges for 32 / 64 keys)
+	cross_stage<kDppXor1, true, R>(v, sel1);                     // runs of 2 lanes: mirror against lane^1,
+	local_merge<R>(v);                                           //                  then ascending merges
+	cross_stage<kDppQuadRev, true, R>(v, sel2);                  // runs of 4 lanes: mirror against lane^3,
+	cross_stage<kDppXor1, false, R>(v, sel1);                    //                  stride R against lane^1,
+	local_merge<R>(v);                                           //                  strides R/2..1
+	if (G == 8) {
+		cross_stage<kDppHalfMirror, true, R>(v, sel4);           // runs of 8 lanes: mirror against lane^7,
+		cross_stage<kDppXor2, false, R>(v, sel2);                //                  stride 2R against lane^2,
+		cross_stage<kDppXor1, false, R>(v, sel1);                //                  stride R against lane^1,
+		local_merge<R>(v);                                       //                  strides R/2..1
+	}
 
 	// --- stage the sorted frame (only the ranks that can hold a pixel; ranks >= n are +inf sentinels nobody reads)
 #pragma unroll
-	for (int j = 0; j < kValsPerLane; j += 4)
-		if (g * kValsPerLane + j < a.n_pix) *reinterpret_cast<float4*>(fr + g * (kValsPerLane + 4) + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+	for (int j = 0; j < R; j += 4)
+		if (g * R + j < a.n_pix) *reinterpret_cast<float4*>(fr + rank_idx(g * R + j)) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
 	__builtin_amdgcn_wave_barrier();
 
-	// --- sigma clipping on the staged ranks; the eight lanes of a frame carry the same scalars
+	// --- sigma clipping on the staged ranks; the lanes of a frame carry the same scalars
 	const int nmasked = a.n_pix - n;
 	const bool usable = active && (n > 0) && !((float)nmasked > a.exclude_fraction * (float)a.n_pix);
 	int lo_i = 0, hi_i = usable ? n : 1;
 	double med = 0.0;
+	const int bshift = lane & (64 - G);
+	constexpr unsigned BMASK = (1u << G) - 1u;
 #pragma unroll 1
 	for (int it = 0; ; ++it) {
 		const int m = hi_i - lo_i;
@@ -234,24 +247,24 @@ __global__ __launch_bounds__(kBkgThreads) void tp_bkg_stamp_kernel(BkgArgs a, in
 		double r1 = 0.0, r2 = 0.0;
 		bool more_t = usable, more_b = usable;
 #pragma unroll 1
-		for (int base = 0; ; base += kLanesPerFrame) {
+		for (int base = 0; ; base += G) {
 			const int rt = hi_i - 1 - g - base, rb = lo_i + g + base;
 			const bool vt = more_t && (rt >= lo_i), vb = more_b && (rb < hi_i);
 			const float xt = fr[rank_idx(vt ? rt : lo_i)], xb = fr[rank_idx(vb ? rb : lo_i)];
 			const double dt = ((double)xt - med) * mm, db = ((double)xb - med) * mm;
 			const bool ot = vt && (dt > 0.0) && (dt * dt > q9), ob = vb && (db < 0.0) && (db * db > q9);
-			// number of consecutive clipped ranks from the end of the range, among this step's eight
-			const unsigned bt = (unsigned)(__ballot(ot) >> (lane & 56)) & 0xFFu, bb = (unsigned)(__ballot(ob) >> (lane & 56)) & 0xFFu;
+			// number of consecutive clipped ranks from the end of the range, among this step's G
+			const unsigned bt = (unsigned)(__ballot(ot) >> bshift) & BMASK, bb = (unsigned)(__ballot(ob) >> bshift) & BMASK;
 			const int ct = __builtin_ctz(~bt), cb = __builtin_ctz(~bb);
 			if (g < ct) { const double x = (double)xt; r1 += x; r2 = __builtin_fma(x, x, r2); }
 			if (g < cb) { const double x = (double)xb; r1 += x; r2 = __builtin_fma(x, x, r2); }
 			top += ct; bot += cb;
-			more_t = (ct == kLanesPerFrame); more_b = (cb == kLanesPerFrame);
+			more_t = (ct == G); more_b = (cb == G);
 			if (!__any(more_t || more_b)) break;
 		}
 		if (!__any((top | bot) != 0)) break;       // nchanged == 0 in every frame of the wavefront: the statistics are final
-		s1 -= frame_sum(r1);
-		s2 -= frame_sum(r2);
+		s1 -= frame_sum<G>(r1);
+		s2 -= frame_sum<G>(r2);
 		lo_i += bot;
 		hi_i -= top;
 	}
@@ -418,11 +431,13 @@ extern "C" int tp_background_stamp(tp_ctx* ctx, const tp_cube_desc* desc, const 
 		const int frame_stride = ((last + ((last >> 5) << 2) + 1) + 3) & ~3;
 		const size_t shmem = (size_t)kFramesPerBlock * frame_stride * sizeof(float);
 		TP_REQUIRE(ctx, (int64_t)a.n_pix * a.t_pitch * 4 < 2147483647ll, "tp_background_stamp: stamp cube too large");
-		dim3 block(kBkgThreads), grid((unsigned)desc->n_targets, (unsigned)((desc->n_cad + kFramesPerBlock - 1) / kFramesPerBlock));
-		const int jfull = a.n_pix / kLanesPerFrame;
-		if (jfull == 28) TP_LAUNCH(ctx, TPK_BKG_STAMP, tp_bkg_stamp_kernel<28>, grid, block, shmem, a, frame_stride);        // 15 x 15
-		else if (jfull == 15) TP_LAUNCH(ctx, TPK_BKG_STAMP, tp_bkg_stamp_kernel<15>, grid, block, shmem, a, frame_stride);   // 11 x 11
-		else TP_LAUNCH(ctx, TPK_BKG_STAMP, tp_bkg_stamp_kernel<-1>, grid, block, shmem, a, frame_stride);
+		dim3 grid((unsigned)desc->n_targets, (unsigned)((desc->n_cad + kFramesPerBlock - 1) / kFramesPerBlock));
+		constexpr int G = 8;   // lanes per frame; 4 (16 frames per wavefront, 64 values per lane, 109 VGPRs, 16 KB of LDS per wavefront) measured 6.4 ms against 5.6
+		dim3 block(kFramesPerBlock * G);
+		const int jfull = a.n_pix / G;
+		if (jfull == 225 / G) TP_LAUNCH(ctx, TPK_BKG_STAMP, (tp_bkg_stamp_kernel<G, 225 / G>), grid, block, shmem, a, frame_stride);        // 15 x 15
+		else if (jfull == 121 / G) TP_LAUNCH(ctx, TPK_BKG_STAMP, (tp_bkg_stamp_kernel<G, 121 / G>), grid, block, shmem, a, frame_stride);   // 11 x 11
+		else TP_LAUNCH(ctx, TPK_BKG_STAMP, (tp_bkg_stamp_kernel<G, -1>), grid, block, shmem, a, frame_stride);
 	} else {
 		int np2 = 1;
 		while (np2 < a.n_pix) np2 <<= 1;
