@@ -263,6 +263,22 @@ int tp_frames_subtract(tp_ctx* ctx, int64_t n_values, const float* d_raw, const 
 int tp_frames_sumimage(tp_ctx* ctx, int32_t n_frames, int64_t n_pixels, int64_t frame_stride, const float* d_images,
 	const int32_t* d_quality, uint32_t bitmask, double* d_sumimage);
 
+/* ---- pixel flags: "background shenanigans"  -------------------------------------------------
+ * tp_frames_median_filter replaces pixel_flags.pixel_background_shenanigans (photometry/pixel_flags.py:61-79):
+ *   scipy.ndimage.median_filter(img - SumImage, size) with the default 'reflect' boundary, for every frame of a stack;
+ *   d_reference: float64 [frame_rows][frame_cols] (the sum image) or NULL; size odd, <= 15 (the reference uses 15);
+ *   float32 output (what prepare.py:533-537 stores); non-finite input values sort to the end of a window.
+ * tp_frames_block_median_accumulate: one block of the "mean shenanigans" (prepare.py:558-575): acc += nanmedian over the
+ *   n_block <= 32 frames listed in d_frame_index (per pixel, NaN result -> 0); the caller divides by the number of blocks.
+ * tp_frames_threshold_flags: prepare.py:594-607: clears flag_bit in every pixel flag and sets it where
+ *   |indicator - mean| > threshold (PixelQualityFlags.BackgroundShenanigans, bkgshe_threshold = 40).              */
+int tp_frames_median_filter(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+	int64_t row_pitch, int64_t frame_stride, const double* d_reference, int32_t size, float* d_out);
+int tp_frames_block_median_accumulate(tp_ctx* ctx, const float* d_frames, int64_t n_pixels, int64_t frame_stride,
+	const int32_t* d_frame_index, int32_t n_block, double* d_accumulator);
+int tp_frames_threshold_flags(tp_ctx* ctx, const float* d_indicator, const double* d_mean, double threshold, uint32_t flag_bit,
+	int64_t n_pixels, int32_t n_frames, uint8_t* d_pixel_flags);
+
 /* ---- P1..P4: linear PSF photometry ----------------------------------------------------------------
  * tp_linpsf_prf (P1) replaces the per-target PRF construction of PSF.__init__ (photometry/psf.py:
  *   101-119).  The interpolating-spline fit is linear in the data, so the coefficient table of the

@@ -213,3 +213,45 @@ def fit_background(image, flux_cutoff=8e4, exclude=None):
 		return np.full(img.shape, np.nan), mask
 	mesh, nmasked = mesh_statistics(img, mask)
 	return mesh_to_background(mesh, nmasked, img.shape), mask
+
+
+#--------------------------------------------------------------------------------------------------
+# Pixel flags: "background shenanigans" (pixel_flags.py:61-79, prepare.py:515-622)
+#--------------------------------------------------------------------------------------------------
+def pixel_background_shenanigans(img, SumImage=None):
+	"""pixel_flags.py:61-79"""
+	from scipy.ndimage import median_filter
+	flux0 = (img - SumImage) if SumImage is not None else img
+	return median_filter(flux0, size=15)
+
+
+def background_shenanigans_flags(images, SumImage, pixel_flags, bkgshe_threshold=40, block=25, flag=4):
+	"""
+	prepare.py:515-622 on in-memory arrays: ``images`` float32 ``(T, R, C)``, ``pixel_flags`` integer ``(T, R, C)`` (a
+	modified copy is returned together with the float32 indicator stack and the float64 mean image).
+	"""
+	images = np.asarray(images)
+	numfiles = images.shape[0]
+	pixel_flags_ind = np.empty(images.shape[1:] + (numfiles,), dtype='float32')
+	for k in range(numfiles):
+		pixel_flags_ind[:, :, k] = pixel_background_shenanigans(images[k], SumImage=SumImage)
+	mean_shenanigans = np.zeros_like(SumImage, dtype='float64')
+	indicies = list(range(numfiles))
+	np.random.seed(0)
+	np.random.shuffle(indicies)
+	for k in range(0, numfiles, block):
+		# (the reference reuses one (R, C, 25) float64 buffer; a short last block would see stale frames of the previous block
+		# there -- prepare.py:562-571 -- which is why numfiles is a multiple of 25 in the tests: the intended result)
+		blockdata = np.stack([pixel_flags_ind[:, :, i].astype('float64') for i in indicies[k:k+block]], axis=2)
+		with np.errstate(all='ignore'):
+			bckshe = np.nanmedian(blockdata, axis=2)
+		bckshe[np.isnan(bckshe)] = 0
+		mean_shenanigans += bckshe
+	mean_shenanigans /= np.ceil(numfiles/block)
+	flags = np.array(pixel_flags, copy=True)
+	for k in range(numfiles):
+		bckshe = np.abs(pixel_flags_ind[:, :, k] - mean_shenanigans) > bkgshe_threshold
+		indx = (flags[k] & flag != 0)
+		flags[k][indx] -= flag
+		flags[k][bckshe] |= flag
+	return flags, np.moveaxis(pixel_flags_ind, 2, 0), mean_shenanigans

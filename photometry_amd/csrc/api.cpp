@@ -23,6 +23,7 @@ static const char* const kKernelNames[TPK_COUNT] = {
 	"tp_psf_fit_kernel",
 	"tp_bkg_mesh_kernel",
 	"tp_bkg_zoom_kernel",
+	"tp_median_filter_kernel",
 	"tp_synth_kernel",
 };
 

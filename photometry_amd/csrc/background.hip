@@ -279,6 +279,105 @@ __global__ __launch_bounds__(kFramesPerBlock * G) void tp_bkg_stamp_kernel(BkgAr
 	if (g == 0 && active) a.out[(int64_t)target * a.out_pitch + k] = result;
 }
 
+// Median filter of full-frame images (pixel_flags.pixel_background_shenanigans, photometry/pixel_flags.py:61-79:
+// scipy.ndimage.median_filter(img - SumImage, size = 15), default boundary 'reflect'), with the sorting machinery of the
+// stamp kernel above: a size x size window (<= 256 values) is one "frame" of eight lanes, a wavefront filters 8 consecutive
+// pixels of an image row, a 256-thread workgroup 32.  The window values are float32((double) img - reference): rounding to
+// float32 is monotone, so the median of the rounded values IS the rounded median of the float64 differences the reference
+// sorts (the count is odd).  Non-finite values sort to the end (scipy's result for NaN input is unspecified); a window whose
+// median is non-finite gives NaN.
+struct MedianArgs {
+	const float* frames; const double* reference; float* out;
+	int n_rows, n_cols; int64_t row_pitch, frame_stride; int size;
+};
+
+__device__ __forceinline__ int reflect_index(int i, int n) { // (d c b a | a b c d | d c b a)
+	if (n == 1) return 0;
+	const int p = 2 * n;
+	i %= p;
+	if (i < 0) i += p;
+	return (i < n) ? i : (p - 1 - i);
+}
+
+__global__ __launch_bounds__(256) void tp_median_filter_kernel(MedianArgs a)
+{
+	constexpr int G = 8, R = 32;
+	__shared__ __align__(16) float s_win[32 * 288];
+	const int tid = threadIdx.x;
+	const int wave = tid >> 6, lane = tid & 63;
+	const int f = lane >> 3, g = lane & 7;
+	const int row = blockIdx.y, frame = blockIdx.z;
+	int col = blockIdx.x * 32 + wave * 8 + f;
+	const bool active = col < a.n_cols;
+	if (!active) col = a.n_cols - 1;
+	const int size = a.size, half = size / 2, npix = size * size;
+	const float inf = __builtin_inff();
+	const float* img = a.frames + (int64_t)frame * a.frame_stride;
+	float v[R];
+#pragma unroll
+	for (int j = 0; j < R; ++j) {
+		const int i = j * G + g;
+		float x = inf;
+		if (i < npix) {
+			const int dy = i / size - half, dx = i % size - half;
+			const int rr = reflect_index(row + dy, a.n_rows), cc = reflect_index(col + dx, a.n_cols);
+			const float raw = img[(int64_t)rr * a.row_pitch + cc];
+			x = a.reference ? (float)((double)raw - a.reference[(int64_t)rr * a.n_cols + cc]) : raw;
+			if (!(fabsf(x) <= 3.402823466e+38f)) x = inf;
+		}
+		v[j] = x;
+	}
+	const float sel1 = (g & 1) ? inf : -inf, sel2 = (g & 2) ? inf : -inf, sel4 = (g & 4) ? inf : -inf;
+	oem_sort<R>(v, std::make_index_sequence<Oem<R>::net.n>());
+	cross_stage<kDppXor1, true, R>(v, sel1);
+	local_merge<R>(v);
+	cross_stage<kDppQuadRev, true, R>(v, sel2);
+	cross_stage<kDppXor1, false, R>(v, sel1);
+	local_merge<R>(v);
+	cross_stage<kDppHalfMirror, true, R>(v, sel4);
+	cross_stage<kDppXor2, false, R>(v, sel2);
+	cross_stage<kDppXor1, false, R>(v, sel1);
+	local_merge<R>(v);
+	float* fr = s_win + (wave * 8 + f) * 288;
+#pragma unroll
+	for (int j = 0; j < R; j += 4) *reinterpret_cast<float4*>(fr + rank_idx(g * R + j)) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+	__builtin_amdgcn_wave_barrier();
+	const float med = fr[rank_idx((npix - 1) >> 1)];
+	if (g == 0 && active)
+		a.out[(int64_t)frame * a.frame_stride + (int64_t)row * a.row_pitch + col] = (med <= 3.402823466e+38f) ? med : __builtin_nanf("");
+}
+
+// nanmedian over <= 32 frames per pixel (the "mean shenanigans" blocks of prepare.py:563-575): out[p] += NaN -> 0 of the median
+__global__ __launch_bounds__(256) void tp_block_median_accumulate_kernel(const float* __restrict__ frames, const int32_t* __restrict__ index, int n_block,
+	int64_t n_pix, int64_t frame_stride, double* __restrict__ acc)
+{
+	const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n_pix) return;
+	float v[32];
+	int n = 0;
+	for (int j = 0; j < n_block; ++j) {
+		const float x = frames[(int64_t)index[j] * frame_stride + p];
+		if (x == x) { // insertion keeps v[0..n) sorted
+			int k = n++;
+#pragma unroll 1
+			while (k > 0 && v[k - 1] > x) { v[k] = v[k - 1]; --k; }
+			v[k] = x;
+		}
+	}
+	if (n > 0) acc[p] += (n & 1) ? (double)v[n >> 1] : ((double)v[(n >> 1) - 1] + (double)v[n >> 1]) / 2.0;   // float64 block like the reference
+}
+
+// flags |= bit where |indicator - mean| > threshold, bit cleared elsewhere (prepare.py:594-607)
+__global__ __launch_bounds__(256) void tp_threshold_flags_kernel(const float* __restrict__ ind, const double* __restrict__ mean, double threshold,
+	uint32_t bit, int64_t n_pix, int64_t n_values, uint8_t* __restrict__ flags)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_values) return;
+	const double d = fabs((double)ind[i] - mean[i % n_pix]);
+	const uint8_t fl = flags[i] & (uint8_t)~bit;
+	flags[i] = (d > threshold) ? (uint8_t)(fl | bit) : fl;
+}
+
 // Generic fallback for stamps with more than 256 pixels: one wavefront per (target, cadence), values
 // sorted in LDS.  Correct for any size that fits LDS; not tuned (large stamps are the bright-star tail).
 __global__ __launch_bounds__(64) void tp_bkg_stamp_generic_kernel(BkgArgs a, int np2)
@@ -497,6 +596,58 @@ extern "C" int tp_subtract_background(tp_ctx* ctx, const tp_cube_desc* desc, con
 			d_pixel_flags, flag_mask, d_images, d_images_err, desc->n_cad, n_pix, desc->t_pitch);
 	}
 	TP_LAUNCH_CHECK(ctx, "tp_bkg_subtract_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_frames_median_filter(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+	int64_t row_pitch, int64_t frame_stride, const double* d_reference, int32_t size, float* d_out)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_frames && d_out && d_frames != d_out, "tp_frames_median_filter: null or aliased pointers");
+	TP_REQUIRE(ctx, n_frames >= 0 && n_frames <= 65535 && frame_rows > 0 && frame_rows <= 65535 && frame_cols > 0 && row_pitch >= frame_cols
+		&& frame_stride >= (int64_t)frame_rows * row_pitch, "tp_frames_median_filter: bad frame geometry");
+	TP_REQUIRE(ctx, size >= 1 && (size & 1) == 1 && size * size <= 256, "tp_frames_median_filter: size must be odd, at most 15");
+	if (n_frames == 0) return TP_OK;
+	MedianArgs a;
+	a.frames = d_frames; a.reference = d_reference; a.out = d_out; a.n_rows = frame_rows; a.n_cols = frame_cols;
+	a.row_pitch = row_pitch; a.frame_stride = frame_stride; a.size = size;
+	dim3 grid((unsigned)((frame_cols + 31) / 32), (unsigned)frame_rows, (unsigned)n_frames);
+	TP_LAUNCH(ctx, TPK_MEDIAN_FILTER, tp_median_filter_kernel, grid, dim3(256), 0, a);
+	TP_LAUNCH_CHECK(ctx, "tp_median_filter_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_frames_block_median_accumulate(tp_ctx* ctx, const float* d_frames, int64_t n_pixels, int64_t frame_stride,
+	const int32_t* d_frame_index, int32_t n_block, double* d_accumulator)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_frames && d_frame_index && d_accumulator, "tp_frames_block_median_accumulate: null pointer");
+	TP_REQUIRE(ctx, n_block >= 1 && n_block <= 32 && n_pixels >= 0 && frame_stride >= n_pixels, "tp_frames_block_median_accumulate: at most 32 frames per block");
+	if (n_pixels == 0) return TP_OK;
+	TP_LAUNCH(ctx, TPK_MEDIAN_FILTER, tp_block_median_accumulate_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, d_frames, d_frame_index,
+		(int)n_block, n_pixels, frame_stride, d_accumulator);
+	TP_LAUNCH_CHECK(ctx, "tp_block_median_accumulate_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_frames_threshold_flags(tp_ctx* ctx, const float* d_indicator, const double* d_mean, double threshold, uint32_t flag_bit,
+	int64_t n_pixels, int32_t n_frames, uint8_t* d_pixel_flags)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_indicator && d_mean && d_pixel_flags, "tp_frames_threshold_flags: null pointer");
+	TP_REQUIRE(ctx, n_pixels > 0 && n_frames >= 0 && flag_bit != 0 && flag_bit < 256, "tp_frames_threshold_flags: bad arguments");
+	const int64_t nv = n_pixels * n_frames;
+	if (nv == 0) return TP_OK;
+	TP_REQUIRE(ctx, (nv + 255) / 256 <= 2147483647ll, "tp_frames_threshold_flags: too many values for one launch");
+	TP_LAUNCH(ctx, TPK_MEDIAN_FILTER, tp_threshold_flags_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, d_indicator, d_mean, threshold, flag_bit,
+		n_pixels, nv, d_pixel_flags);
+	TP_LAUNCH_CHECK(ctx, "tp_threshold_flags_kernel");
 	return TP_OK;
 	TP_API_END(ctx)
 }

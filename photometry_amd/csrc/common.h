@@ -28,6 +28,7 @@ enum tp_kernel_id {
 	TPK_PSF_FIT,
 	TPK_BKG_MESH,
 	TPK_BKG_ZOOM,
+	TPK_MEDIAN_FILTER,
 	TPK_SYNTH,
 	TPK_COUNT
 };

@@ -17,9 +17,10 @@ import numpy as np
 from scipy import ndimage
 from .engine import TESS_DEFAULT_BITMASK
 
-#: photometry/quality.py:73-80
-PIXEL_NOT_USED_FOR_BACKGROUND = 4
+#: PixelQualityFlags (photometry/quality.py:157-166)
+PIXEL_NOT_USED_FOR_BACKGROUND = 1
 PIXEL_MANUAL_EXCLUDE = 2
+PIXEL_BACKGROUND_SHENANIGANS = 4
 
 
 def finish_mesh(mesh, nmasked, box=64, exclude_percentile=50.0, filter_size=3):
@@ -113,3 +114,42 @@ def prepare_frames(ctx, raw, raw_err, quality, cadence=1800, flux_cutoff=8e4, pi
 	ctx._check(ctx.lib.tp_frames_sumimage(ctx.handle, T, R * C, R * C, images.ptr, q.ptr, int(TESS_DEFAULT_BITMASK), sumimage.ptr))
 	ctx.sync()
 	return {'backgrounds': bkg, 'images': images, 'images_err': images_err, 'sumimage': sumimage}
+
+
+def background_shenanigans(ctx, images, sumimage, pixel_flags, threshold=40.0, size=15, block=25, indicator=None):
+	"""
+	The "background shenanigans" pass of the prepare stage (prepare.py:515-622) on device-resident stacks:
+
+	1. per frame the indicator image ``median_filter(img - SumImage, size=15)`` (``pixel_flags.pixel_background_shenanigans``,
+	   pixel_flags.py:61-79) -- ``tp_frames_median_filter``;
+	2. its robust mean over time: the frames are shuffled with ``np.random.seed(0); np.random.shuffle`` exactly like the
+	   reference (:566-568), cut into blocks of 25, the per-pixel nanmedian of every block (NaN -> 0) is averaged over
+	   ``ceil(T / 25)`` blocks (:569-577) -- ``tp_frames_block_median_accumulate``;
+	3. ``|indicator - mean| > bkgshe_threshold`` sets ``PixelQualityFlags.BackgroundShenanigans`` in the pixel flags of that
+	   frame, an old flag is cleared (:594-607) -- ``tp_frames_threshold_flags``.
+
+	``images``: float32 DeviceArray ``(T, R, C)``; ``sumimage``: float64 DeviceArray ``(R, C)``; ``pixel_flags``: uint8 DeviceArray
+	``(T, R, C)``, updated in place.  Returns ``(indicator float32 (T, R, C), mean float64 (R, C))`` as DeviceArrays.
+	"""
+	T, R, C = images.shape
+	if indicator is None:
+		indicator = ctx.empty((T, R, C), 'float32')
+	ctx._check(ctx.lib.tp_frames_median_filter(ctx.handle, images.ptr, T, R, C, C, R * C, None if sumimage is None else sumimage.ptr, int(size),
+		indicator.ptr))
+	indices = list(range(T))
+	np.random.seed(0)              # the reference's own seed and (legacy) generator: the blocks must be the same frames
+	np.random.shuffle(indices)
+	mean = ctx.zeros((R, C), 'float64')
+	keep = []
+	for k in range(0, T, block):
+		idx = ctx.array(np.asarray(indices[k:k + block], dtype='int32'))
+		keep.append(idx)
+		ctx._check(ctx.lib.tp_frames_block_median_accumulate(ctx.handle, indicator.ptr, R * C, R * C, idx.ptr, len(indices[k:k + block]), mean.ptr))
+	ctx.sync()
+	nblocks = int(np.ceil(T / block))
+	m = mean.to_host() / nblocks
+	mean = ctx.array(m)
+	ctx._check(ctx.lib.tp_frames_threshold_flags(ctx.handle, indicator.ptr, mean.ptr, float(threshold), PIXEL_BACKGROUND_SHENANIGANS, R * C, T,
+		pixel_flags.ptr))
+	ctx.sync()
+	return indicator, mean

@@ -90,3 +90,35 @@ def test_prepare_frames_matches_oracle(ctx):
 	np.testing.assert_array_equal(out['images_err'].to_host(), ref_err)
 	ref_sum = osum.sumimage(np.moveaxis(ref_img, 0, -1), quality)
 	np.testing.assert_array_equal(out['sumimage'].to_host(), ref_sum)
+
+
+def test_background_shenanigans(ctx):
+	"""The pixel-flag pass of the prepare stage (pixel_flags.py:61-79, prepare.py:515-622): 15 x 15 median filter of img - SumImage
+	(scipy itself is the check: bit-exact), block-median mean over the reference's own frame shuffle, thresholded flags."""
+	from scipy.ndimage import median_filter
+	from photometry_amd import prepare
+	from oracle import backgrounds as ob
+	rng = np.random.default_rng(8)
+	T, R, C = 50, 40, 70
+	sky = rng.normal(0, 3, (T, R, C)).astype('float32')
+	sky[20:30, 10:30, 20:60] += 90.0          # a scattered-light patch in ten frames: flagged there
+	sky[:, 5, 5] += 5000.0                     # a star: removed by the median filter
+	sumimage = np.median(sky.astype('float64'), axis=0)
+	flags0 = np.zeros((T, R, C), dtype='uint8'); flags0[0, 1, 1] = 4; flags0[3, 2, 2] = 1 | 4
+	d_flags = ctx.array(flags0)
+	ind, mean = prepare.background_shenanigans(ctx, ctx.array(sky), ctx.array(sumimage), d_flags)
+	got_ind = ind.to_host()
+	for k in (0, 7, 25):
+		ref = median_filter(sky[k] - sumimage, size=15)            # float64, as the reference computes it
+		np.testing.assert_array_equal(got_ind[k], ref.astype('float32'))
+	rflags, rind, rmean = ob.background_shenanigans_flags(sky, sumimage, flags0)
+	np.testing.assert_array_equal(got_ind, rind)
+	np.testing.assert_allclose(mean.to_host(), rmean, rtol=1e-13, atol=1e-13)
+	got = d_flags.to_host()
+	np.testing.assert_array_equal(got, rflags)
+	assert (got[22] & 4).sum() > 500 and (got[40] & 4).sum() == 0 and got[3, 2, 2] == 1
+	# small windows / no reference image
+	small = prepare.ctypes  # noqa: F841 (keep the import used)
+	out = ctx.empty((3, R, C), 'float32')
+	ctx._check(ctx.lib.tp_frames_median_filter(ctx.handle, ctx.array(sky[:3]).ptr, 3, R, C, C, R * C, None, 5, out.ptr))
+	np.testing.assert_array_equal(out.to_host()[1], median_filter(sky[1], size=5))
