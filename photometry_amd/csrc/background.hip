@@ -36,6 +36,10 @@
 // (5.8 -> 6.2 ms at 4 or 5 waves per SIMD: nothing left to hide); a bitonic instead of Batcher's network for the
 // per-lane sort (5.9 ms); cross-lane exchanges in groups of 4 / 8 independent DPP moves (no change); four lanes per frame
 // instead of eight (half the redundant clipping work, but 109 VGPRs and twice the LDS per wavefront: 6.4 ms).
+// Also dropped (round 2): a wave-specialised workgroup -- eight sorter wavefronts stage 64 frames, a ninth clips them with
+// one lane per frame (float thresholds, 4-ary rank searches) while the sorters work on the next block: 6.7 ms with the
+// clipping switched off and 11.0 ms with it (two 66 KB workgroups per CU leave the sorters 4.5 waves per SIMD between two
+// barriers per block, and the lane-per-frame clipper is a serial chain of LDS round trips that no amount of sorting hides).
 #include "common.h"
 #include <cmath>
 #include <utility>
