@@ -242,6 +242,8 @@ int tp_subtract_background(tp_ctx* ctx, const tp_cube_desc* desc, const float* d
  *   SigmaClip(3, maxiters = 5) and the SExtractor estimator): d_mesh float64 [n_frames][ny][nx] (NaN for a cell without an
  *   unmasked pixel), d_nmasked int32 [n_frames][ny][nx] (masked or padded pixels of the cell), ny = ceil(rows / box_size).
  *   d_exclude: optional uint8 manual-exclude image(s) [frame_rows][frame_cols] (exclude_frame_stride 0 = one for all frames).
+ *   d_subtract: optional float32 image(s) [frame_rows][frame_cols] taken off the pixel values after the masking (the radial
+ *   component of a TESS image, :200: Background2D(img0 - img_bkg_radial, mask = mask)).
  * tp_background_zoom (B1, second half): the full-resolution background from the cubic-spline coefficients of the finished
  *   mesh (after the exclusion of mostly-masked cells, their IDW fill, the 3 x 3 median filter and the spline prefilter --
  *   host work on ny x nx values per frame, photometry_amd/prepare.py), i.e. scipy.ndimage.zoom(order 3, mode 'reflect',
@@ -252,6 +254,7 @@ int tp_subtract_background(tp_ctx* ctx, const tp_cube_desc* desc, const float* d
  *   tp_subtract_background and tp_sumimage.                                                                          */
 int tp_background_mesh(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
 	int64_t row_pitch, int64_t frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride,
+	const float* d_subtract, int64_t subtract_frame_stride,
 	double flux_cutoff, int32_t box_size, double* d_mesh, int32_t* d_nmasked);
 int tp_background_zoom(tp_ctx* ctx, const double* d_coef, const double* d_vmin, const double* d_vmax, int32_t n_frames,
 	int32_t mesh_rows, int32_t mesh_cols, int32_t box_size, int32_t frame_rows, int32_t frame_cols, int64_t row_pitch, int64_t frame_stride,
@@ -278,6 +281,34 @@ int tp_frames_block_median_accumulate(tp_ctx* ctx, const float* d_frames, int64_
 	const int32_t* d_frame_index, int32_t n_block, double* d_accumulator);
 int tp_frames_threshold_flags(tp_ctx* ctx, const float* d_indicator, const double* d_mean, double threshold, uint32_t flag_bit,
 	int64_t n_pixels, int32_t n_frames, uint8_t* d_pixel_flags);
+
+/* ---- B1, TESS branch: the radial component of fit_background (photometry/backgrounds.py:104-197) ---------------
+ * Frames: float32 [n_frames][n_pixels] contiguous images (row_pitch == frame_cols), frame k at + k * frame_stride.  The
+ * pixel mask (:89-97) is evaluated on d_frames; values are d_frames - d_square (float64) once a square (mesh) component of
+ * a previous iteration exists, d_frames alone (float32 arithmetic, as numpy does it) when d_square is NULL.
+ * tp_radial_zeropoint: d_zeropoint[k] = -min(values over the unmasked pixels) + 1.0 (:166-168); NaN when everything is
+ *   masked.  d_partial: float64 scratch [n_frames][n_partial].
+ * tp_radial_ring_modes: _reduce_mode (:20-32) of log10(values + zeropoint) over the pixels of every ring (the callable
+ *   statistic of scipy.stats.binned_statistic, :171-176): d_ring_pixels int32 [n_ring_pixels] lists the pixels of ring 0,
+ *   ring 1, ... (row-major inside a ring), ring j = d_ring_pixels[d_ring_offsets[j] .. d_ring_offsets[j + 1]).
+ *   statsmodels KDEUnivariate(x).fit(gridsize = 2000): Gaussian kernel, FFT on 2048 grid points, cut = 3, bandwidth
+ *   bandwidth_constant * min(std, IQR / 1.349) * n^(-1/5) (bw = 'normal_reference'); zero bandwidth -> median; the mode is
+ *   support[argmax(density)].  d_modes float64 [n_frames][n_rings] (NaN: fewer than 2 pixels), d_counts optional int32
+ *   [n_frames][n_rings], d_scratch float64 [n_frames][n_ring_pixels].
+ * tp_radial_evaluate: d_out = float32(10**s(r) - zeropoint + d_add) with r = hypot(col + col_offset - xcen, row - ycen)
+ *   and s the cubic spline of frame k in FITPACK form (knots d_knots[k][0..n), coefficients d_coefs[k][..], n =
+ *   d_n_knots[k] <= max_knots; evaluated with ext = 3, :186-188); n == 0: no radial component (d_out = d_add or 0).
+ *   d_add optional float32 images (the square component: the total background of :209).                            */
+int tp_radial_zeropoint(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride,
+	const float* d_square, int64_t square_frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride, double flux_cutoff,
+	double* d_partial, int32_t n_partial, double* d_zeropoint);
+int tp_radial_ring_modes(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride,
+	const float* d_square, int64_t square_frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride, double flux_cutoff,
+	const double* d_zeropoint, const int32_t* d_ring_pixels, const int32_t* d_ring_offsets, int32_t n_rings, int32_t n_ring_pixels,
+	double bandwidth_constant, double* d_scratch, double* d_modes, int32_t* d_counts);
+int tp_radial_evaluate(tp_ctx* ctx, int32_t n_frames, int32_t frame_rows, int32_t frame_cols, int64_t frame_stride,
+	double col_offset, double xcen, double ycen, const double* d_knots, const double* d_coefs, const int32_t* d_n_knots, int32_t max_knots,
+	const double* d_zeropoint, const float* d_add, int64_t add_frame_stride, float* d_out);
 
 /* ---- P1..P4: linear PSF photometry ----------------------------------------------------------------
  * tp_linpsf_prf (P1) replaces the per-target PRF construction of PSF.__init__ (photometry/psf.py:

@@ -216,6 +216,132 @@ def fit_background(image, flux_cutoff=8e4, exclude=None):
 
 
 #--------------------------------------------------------------------------------------------------
+# TESS branch of fit_background: the radial component (backgrounds.py:104-197)
+#--------------------------------------------------------------------------------------------------
+#: pixel coordinates of the camera centre relative to every CCD (backgrounds.py:118-135: averages of the Sector 1 WCS)
+CAMERA_CENTRE = {
+	(1, 1): (2158.222313, 2099.523364), (1, 2): (-5.653058, 2098.018608), (1, 3): (2141.511437, 2099.868226), (1, 4): (-22.406442, 2100.116443),
+	(2, 1): (2148.588316, 2094.033024), (2, 2): (-16.806140, 2095.810070), (2, 3): (2151.351646, 2105.747100), (2, 4): (-13.118570, 2105.982211),
+	(3, 1): (2152.175481, 2092.337442), (3, 2): (-10.494413, 2093.108135), (3, 3): (2145.029218, 2107.883573), (3, 4): (-17.374782, 2105.296746),
+	(4, 1): (2149.259760, 2091.433315), (4, 2): (-12.906931, 2093.350054), (4, 3): (2148.906766, 2110.730620), (4, 4): (-14.629676, 2111.341670),
+}
+
+
+def reduce_mode(x):
+	"""``_reduce_mode`` (backgrounds.py:20-32): mode of the KDE (statsmodels default bandwidth, 2000 -> 2048 grid points)."""
+	from .kde import KDE
+	if len(x) == 0:
+		return np.nan
+	x = np.asarray(x, dtype='float64')
+	kde = KDE(x)
+	try:
+		with np.errstate(all='ignore'):
+			kde.fit(gridsize=2000)
+	except RuntimeError as err:
+		if str(err).startswith('Selected KDE bandwidth is 0.'):
+			return np.median(x)
+		raise
+	return kde.support[np.argmax(kde.density)]
+
+
+def binned_callable(x, values, statistic, bins):
+	"""
+	``scipy.stats.binned_statistic(x, values, statistic=<callable>, bins=<edges>)`` (scipy 1.7.3, _binned_statistic.py):
+	``np.digitize`` bin numbers, samples within rounding (``decimal = int(-log10(min edge step)) + 6``) of the last edge moved
+	into the last bin, the callable applied to the values of every occupied bin in input order, ``statistic([])`` elsewhere.
+	"""
+	bins = np.asarray(bins, dtype='float64')
+	nbin = len(bins) - 1
+	number = np.digitize(x, bins)
+	decimal = int(-np.log10(np.diff(bins).min())) + 6
+	on_edge = np.where(np.around(x, decimal) == np.around(bins[-1], decimal))[0]
+	number[on_edge] -= 1
+	try:
+		null = statistic([])
+	except Exception:
+		null = np.nan
+	result = np.full(nbin + 2, null, dtype='float64')
+	for i in np.unique(number):
+		result[i] = statistic(values[number == i])
+	return result[1:-1]
+
+
+def move_median_central(x, width_points):
+	"""utilities.move_median_central (utilities.py:52-62): the restatement in ``oracle/utilities.py`` (pinned by ``golden_misc.npz``)."""
+	from .utilities import move_median_central as mmc
+	import warnings
+	with warnings.catch_warnings():
+		warnings.simplefilter('ignore', RuntimeWarning)    # all-NaN windows
+		with np.errstate(all='ignore'):
+			return mmc(np.asarray(x, dtype='float64'), width_points)
+
+
+def radial_geometry(shape, camera, ccd, radial_cutoff=2400, radial_pixel_step=15):
+	"""backgrounds.py:137-149: distance image (float64), ring edges and ring centres."""
+	xycen = CAMERA_CENTRE[(camera, ccd)]
+	xx, yy = np.meshgrid(np.arange(44, shape[1]+44, 1), np.arange(0, shape[0], 1))
+	r = np.sqrt((xx - xycen[0])**2 + (yy - xycen[1])**2)
+	radial_max = np.max(r) + radial_pixel_step
+	bins = np.arange(radial_cutoff, radial_max, radial_pixel_step)
+	bin_center = bins[1:] - radial_pixel_step/2
+	return r, bins, bin_center
+
+
+def fit_background_tess(image, camera, ccd, flux_cutoff=8e4, exclude=None, bkgiters=3, radial_cutoff=2400, radial_pixel_step=15,
+	radial_smooth=3, full=False):
+	"""
+	``fit_background`` for a TESS FFIImage (backgrounds.py:52-211 with ``is_tess``): ``bkgiters`` rounds of the radial
+	component (ring modes of log10(img - square + zeropoint), 3-point median, interpolating cubic spline, :162-197) and the
+	Background2D mesh of ``img0 - img_bkg_radial`` (:199-206).  ``image``: float32 ``(R, C)`` = ``FFIImage.data`` (the 2048
+	science columns; the distance image starts at column 44, :144).  The numpy 1.21 type promotion the reference runs under
+	is written out: in the first round ``img0 - 0`` is float32, so ``zeropoint = -min + 1.0`` is a float64 made from a float32
+	minimum, ``pix + zeropoint`` and ``log10`` are float32; from the second round on everything is float64.
+	Returns ``(background float64, mask)`` (+ a dict of intermediates with ``full``).  **Parity unpinned** against statsmodels /
+	photutils (not installable here); the scipy parts (binned statistic, spline, zoom) are the real scipy.
+	"""
+	from scipy.interpolate import InterpolatedUnivariateSpline
+	img0 = np.asarray(image, dtype='float32')
+	mask = stamp_mask(img0, flux_cutoff, exclude)
+	if np.all(mask):
+		return (np.full(img0.shape, np.nan), mask, {}) if full else (np.full(img0.shape, np.nan), mask)
+	r, bins, bin_center = radial_geometry(img0.shape, camera, ccd, radial_cutoff, radial_pixel_step)
+	img_bkg_radial = np.asarray(0)
+	img_bkg_square = None
+	inter = {'s2': [], 'zeropoint': [], 'radial': []}
+	for iters in range(bkgiters):
+		if img_bkg_square is None:
+			pix = img0[~mask].flatten()                                # float32
+			zeropoint = -np.float64(np.min(pix)) + 1.0                  # numpy 1.x: float32 scalar + Python float -> float64
+			logpix = np.log10(pix + np.float32(zeropoint))              # float32 array + scalar stays float32
+		else:
+			img = img0.astype('float64') - img_bkg_square
+			pix = img[~mask].flatten()
+			zeropoint = -np.min(pix) + 1.0
+			logpix = np.log10(pix + zeropoint)
+		s2 = binned_callable(r[~mask].flatten(), logpix, reduce_mode, bins)
+		inter['s2'].append(s2.copy())
+		inter['zeropoint'].append(float(zeropoint))
+		if radial_smooth:
+			s2 = move_median_central(s2, radial_smooth)
+		indx = ~np.isnan(s2)
+		Ngood = np.sum(indx)
+		if Ngood >= 3:
+			try:
+				intp = InterpolatedUnivariateSpline(bin_center[indx], s2[indx], k=3, ext=3)
+				img_bkg_radial = 10**intp(r) - zeropoint
+			except ValueError:
+				img_bkg_radial = 0
+		else:
+			img_bkg_radial = 0
+		inter['radial'].append(np.array(img_bkg_radial, dtype='float64', copy=True))
+		work = img0.astype('float64') - img_bkg_radial
+		mesh, nmasked = mesh_statistics(work, mask)
+		img_bkg_square = mesh_to_background(mesh, nmasked, img0.shape)
+	img_bkg = img_bkg_radial + img_bkg_square
+	return (img_bkg, mask, inter) if full else (img_bkg, mask)
+
+
+#--------------------------------------------------------------------------------------------------
 # Pixel flags: "background shenanigans" (pixel_flags.py:61-79, prepare.py:515-622)
 #--------------------------------------------------------------------------------------------------
 def pixel_background_shenanigans(img, SumImage=None):

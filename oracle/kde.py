@@ -43,11 +43,28 @@ def bw_scott(x):
 	return 1.059 * A * n ** (-0.2)
 
 
+def normal_reference_constant():
+	"""
+	kernels.CustomKernel.normal_reference_constant for ``kernels.Gaussian`` (order 2, L2Norm = 1/(2 sqrt(pi)), second moment 1):
+	``C = sqrt(pi) * 2!**3 * L2Norm / (2 * 2 * 4! * 1**2); C = 2 * C**(1/5)`` = 1.0592238...
+	"""
+	C = np.pi**(.5) * 2.0**3 * (1.0/(2.0*np.sqrt(np.pi)))
+	C /= (2 * 2 * 24.0 * 1.0**2)
+	return 2*C**(1.0/(2*2+1))
+
+
+def bw_normal_reference(x):
+	"""bandwidths.bw_normal_reference (the default of ``KDEUnivariate.fit``): C * A * n**(-1/5)."""
+	A = select_sigma(x)
+	n = len(x)
+	return normal_reference_constant() * A * n ** (-0.2)
+
+
 def select_bandwidth(x, bw='scott', kernel='gau'):
 	"""bandwidths.select_bandwidth (raises RuntimeError on zero bandwidth)."""
-	if bw.lower() != 'scott':
-		raise ValueError("only 'scott' is restated")
-	bandwidth = bw_scott(np.asarray(x))
+	if bw.lower() not in ('scott', 'normal_reference'):
+		raise ValueError("only 'scott' and 'normal_reference' are restated")
+	bandwidth = bw_scott(np.asarray(x)) if bw.lower() == 'scott' else bw_normal_reference(np.asarray(x))
 	if np.any(bandwidth == 0):
 		raise RuntimeError("Selected KDE bandwidth is 0. Cannot estimate density. "
 			"Either provide the bandwidth during initialization or use an alternative method.")
@@ -69,6 +86,23 @@ def fast_linbin(X, a, b, M):
 			gcnts[li_i+1] = gcnts[li_i+1] + rem[i]
 		# (statsmodels' ``if li_i > M: gcnts[M] += 1`` branch cannot trigger: b = max + cut*bw)
 	return gcnts
+
+
+def fast_linbin_vec(X, a, b, M):
+	"""``fast_linbin`` without the Python loop (``np.add.at`` accumulates in input order too: same sums, same rounding)."""
+	M = int(M)
+	gcnts = np.zeros(M + 1, dtype='float64')
+	delta = (b - a) / (M - 1)
+	lxi = (np.asarray(X, dtype='float64') - a) / delta
+	li = lxi.astype(int)
+	rem = lxi - li
+	ok = (li > 1) & (li < M)
+	idx = np.empty(2 * int(np.sum(ok)), dtype=int)
+	w = np.empty(idx.size)
+	idx[0::2] = li[ok]; idx[1::2] = li[ok] + 1
+	w[0::2] = 1 - rem[ok]; w[1::2] = rem[ok]
+	np.add.at(gcnts, idx, w)
+	return gcnts[:M]
 
 
 def forrt(X, m=None):
@@ -109,7 +143,7 @@ def kdensityfft(x, bw, gridsize=100, cut=3):
 	b = np.max(x) + cut * bw
 	grid, delta = np.linspace(a, b, int(gridsize), retstep=True)
 	RANGE = b - a
-	binned = fast_linbin(x, a, b, gridsize) / (delta * nobs)
+	binned = (fast_linbin if nobs < 2000 else fast_linbin_vec)(x, a, b, gridsize) / (delta * nobs)
 	y = forrt(binned)
 	zstar = silverman_transform(bw, gridsize, RANGE) * y
 	f = revrt(zstar)
@@ -125,8 +159,10 @@ class KDE(object):
 	def fit(self, kernel='gau', bw=None, fft=True, gridsize=None, cut=3):
 		if kernel != 'gau' or not fft:
 			raise NotImplementedError
-		if bw is None or isinstance(bw, str):
-			bw = select_bandwidth(self.endog, 'scott')
+		if bw is None:
+			bw = 'normal_reference'     # the default of KDEUnivariate.fit
+		if isinstance(bw, str):
+			bw = select_bandwidth(self.endog, bw)
 		if gridsize is None:
 			gridsize = max(len(self.endog), 512.0)
 		self.density, self.support, self.bw = kdensityfft(self.endog, bw, gridsize=gridsize, cut=cut)

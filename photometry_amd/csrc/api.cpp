@@ -24,6 +24,7 @@ static const char* const kKernelNames[TPK_COUNT] = {
 	"tp_bkg_mesh_kernel",
 	"tp_bkg_zoom_kernel",
 	"tp_median_filter_kernel",
+	"tp_radial_kernels",
 	"tp_synth_kernel",
 };
 

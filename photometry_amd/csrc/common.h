@@ -29,6 +29,7 @@ enum tp_kernel_id {
 	TPK_BKG_MESH,
 	TPK_BKG_ZOOM,
 	TPK_MEDIAN_FILTER,
+	TPK_BKG_RADIAL,
 	TPK_SYNTH,
 	TPK_COUNT
 };

@@ -1,8 +1,9 @@
 // fullframe.hip -- the full-frame (prepare stage) background path on a frame stack [T][R][C] resident in HBM.
 //
-// B1  tp_background_mesh + tp_background_zoom: backgrounds.fit_background for a plain image (photometry/backgrounds.py:52-211, the
-//     branch without the radial component: bkgiters = 1, :156-157): pixel mask (:89-97), photutils Background2D on 64 x 64 boxes
-//     with SigmaClip(3, maxiters = 5) and the SExtractor estimator (:200-206), cubic-spline zoom of the filtered mesh.
+// B1  tp_background_mesh + tp_background_zoom: the square component of backgrounds.fit_background (photometry/backgrounds.py:52-211):
+//     pixel mask (:89-97), photutils Background2D on 64 x 64 boxes with SigmaClip(3, maxiters = 5) and the SExtractor estimator
+//     (:200-206), cubic-spline zoom of the filtered mesh.  Alone it is the plain-image branch (bkgiters = 1, :156-157); for TESS
+//     frames it alternates with the radial component of csrc/radial.hip, whose image comes in as d_subtract.
 //     The mesh statistics (every pixel of every frame: the heavy part) and the zoom back to full resolution run here; the
 //     32 x 32 mesh in between (exclusion of mostly-masked boxes, IDW fill, 3 x 3 median filter, spline prefilter) is host
 //     work on a few KB per frame (photometry_amd/prepare.py).
@@ -52,6 +53,7 @@ __device__ __forceinline__ void local_tail(float (&v)[kKeysPerThread], bool up) 
 struct MeshArgs {
 	const float* frames; int n_rows, n_cols; int64_t row_pitch, frame_stride;
 	const uint8_t* exclude; int64_t exclude_frame_stride;     // optional manual-exclude image(s), [R][C] per frame (stride 0 = shared)
+	const float* subtract; int64_t subtract_frame_stride;     // optional image(s) [R][C] taken off the values AFTER the masking (the radial component)
 	float flux_cutoff; int box; int nx, ny;
 	double* mesh; int32_t* nmasked;
 };
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(kMeshThreads) void tp_bkg_mesh_kernel(MeshArgs a)
 	const float inf = __builtin_inff();
 	const float* img = a.frames + (int64_t)frame * a.frame_stride;
 	const uint8_t* excl = a.exclude ? (a.exclude + (int64_t)frame * a.exclude_frame_stride) : nullptr;
+	const float* minus = a.subtract ? (a.subtract + (int64_t)frame * a.subtract_frame_stride) : nullptr;
 	// ---- load + mask (backgrounds.py:89-97); pixels beyond the frame (padding of the last boxes) are masked
 	int nvalid = 0;
 	for (int e = tid; e < kMeshKeys; e += kMeshThreads) {
@@ -77,6 +80,7 @@ __global__ __launch_bounds__(kMeshThreads) void tp_bkg_mesh_kernel(MeshArgs a)
 				bool ok = (x >= 0.f) && (x <= a.flux_cutoff);
 				if (excl && excl[(int64_t)r * a.n_cols + c]) ok = false;
 				nvalid += ok ? 1 : 0;
+				if (minus) x = (float)((double)x - (double)minus[(int64_t)r * a.n_cols + c]);   // backgrounds.py:200 (img0 - img_bkg_radial)
 				x = ok ? x : inf;
 			}
 		}
@@ -255,6 +259,7 @@ __global__ __launch_bounds__(256) void tp_frames_sumimage_kernel(const float* __
 
 extern "C" int tp_background_mesh(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
 	int64_t row_pitch, int64_t frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride,
+	const float* d_subtract, int64_t subtract_frame_stride,
 	double flux_cutoff, int32_t box_size, double* d_mesh, int32_t* d_nmasked)
 {
 	TP_CHECK_CTX(ctx);
@@ -266,6 +271,7 @@ extern "C" int tp_background_mesh(tp_ctx* ctx, const float* d_frames, int32_t n_
 	MeshArgs a;
 	a.frames = d_frames; a.n_rows = frame_rows; a.n_cols = frame_cols; a.row_pitch = row_pitch; a.frame_stride = frame_stride;
 	a.exclude = d_exclude; a.exclude_frame_stride = exclude_frame_stride;
+	a.subtract = d_subtract; a.subtract_frame_stride = subtract_frame_stride;
 	a.flux_cutoff = (float)flux_cutoff; a.box = box_size;
 	a.nx = (frame_cols + box_size - 1) / box_size; a.ny = (frame_rows + box_size - 1) / box_size;
 	a.mesh = d_mesh; a.nmasked = d_nmasked;

@@ -1,0 +1,425 @@
+// radial.hip -- the radial ("corner glow") component of backgrounds.fit_background for TESS full-frame images
+// (photometry/backgrounds.py:104-197) on a frame stack resident in HBM.  Per iteration of its bkgiters loop:
+//
+//   tp_radial_zeropoint   zeropoint = -min(img - square over the unmasked pixels) + 1                       (:166-168)
+//   tp_radial_ring_modes  per ring of 15 pixels beyond 2400 pixels from the camera centre: the mode of log10(img - square +
+//                         zeropoint) -- argmax of statsmodels' FFT Gaussian KDE on 2048 grid points with the
+//                         normal-reference bandwidth (_reduce_mode :20-32, binned_statistic :171-176)
+//   (host, photometry_amd/prepare.py: 3-point median of the ~40 ring modes and the interpolating cubic spline, :179-187)
+//   tp_radial_evaluate    img_bkg_radial = 10**spline(r) - zeropoint for every pixel (ext = 3: constant beyond the end knots), :188
+//
+// The geometry (distance of every pixel from the camera centre, ring membership) does not depend on the frame: the host
+// lists the pixels of every ring once (row-major inside a ring, like r[~mask] in the reference) and the ring kernel walks
+// its list.  One 256-thread workgroup per (ring, frame):
+//   1. gather the unmasked pixels of the ring into an HBM scratch row (<= ~25 000 float64), with their count, sum, min, max;
+//   2. standard deviation (two-pass, ddof = 1), quartiles by radix selection on the order-preserving 64-bit keys
+//      (scipy.stats.scoreatpercentile's linear interpolation between the two neighbouring order statistics);
+//   3. bandwidth C min(std, IQR / 1.349) n^-1/5; linear binning on 2048 grid points over [min - 3 bw, max + 3 bw] with LDS
+//      float64 atomics (the sums differ from a serial loop by rounding only);
+//   4. forward FFT (radix 2, LDS, twiddles from sincospi), multiplication by Silverman's transform of the Gaussian, second
+//      forward FFT of the conjugate = the inverse transform of a Hermitian spectrum; first index of the maximum -> grid value.
+// Bound by LDS/latency (18 passes over an L2-resident row, two 2048-point FFTs); a frame has ~40 rings, so the whole
+// component is a few hundred microseconds per frame and iteration next to the 64 x 64 mesh statistics.
+#include "common.h"
+#include <cmath>
+
+namespace {
+
+constexpr int kRadThreads = 256;
+constexpr int kKdeGrid = 2048;
+constexpr int kKdeLog2 = 11;
+
+struct RadialImage {
+	const float* frames; int64_t frame_stride;
+	const float* square; int64_t square_stride;           // previous iteration's mesh background, or null (first iteration)
+	const uint8_t* exclude; int64_t exclude_stride;       // manual-exclude image(s), stride 0 = shared
+	float flux_cutoff;
+};
+
+// backgrounds.py:89-97 on the RAW image; value = img - square (float64 once a square component exists, float32 before)
+__device__ __forceinline__ bool radial_pixel(const RadialImage& a, int frame, int64_t p, double& value) {
+	const float x = a.frames[(int64_t)frame * a.frame_stride + p];
+	bool ok = (x >= 0.f) && (x <= a.flux_cutoff);
+	if (a.exclude && a.exclude[(int64_t)frame * a.exclude_stride + p]) ok = false;
+	value = a.square ? ((double)x - (double)a.square[(int64_t)frame * a.square_stride + p]) : (double)x;
+	return ok;
+}
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+	return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+	return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+	return v;
+}
+
+// block-wide reductions through a 4-entry LDS array; every thread gets the result
+template <int OP>
+__device__ __forceinline__ double block_reduce(double v, double* red) {
+	v = (OP == 0) ? wave_sum(v) : (OP == 1) ? wave_min(v) : wave_max(v);
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+	__syncthreads();
+	if (OP == 0) return (red[0] + red[1]) + (red[2] + red[3]);
+	if (OP == 1) return fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+	return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(kRadThreads) void tp_radial_min_partial_kernel(RadialImage a, int64_t n_pix, double* __restrict__ partial)
+{
+	__shared__ double red[4];
+	const int frame = blockIdx.y;
+	double mn = __builtin_inf();
+	for (int64_t p = (int64_t)blockIdx.x * kRadThreads + threadIdx.x; p < n_pix; p += (int64_t)gridDim.x * kRadThreads) {
+		double v;
+		if (radial_pixel(a, frame, p, v)) mn = fmin(mn, v);
+	}
+	mn = block_reduce<1>(mn, red);
+	if (threadIdx.x == 0) partial[(int64_t)frame * gridDim.x + blockIdx.x] = mn;
+}
+
+// zeropoint = -min + 1.0 (float64; with numpy 1.21 the float32 minimum of the first iteration is promoted by the Python
+// float); +inf partials (nothing unmasked) -> NaN
+__global__ __launch_bounds__(kRadThreads) void tp_radial_min_final_kernel(const double* __restrict__ partial, int n_partial, double* __restrict__ zeropoint)
+{
+	__shared__ double red[4];
+	const int frame = blockIdx.x;
+	double mn = __builtin_inf();
+	for (int i = threadIdx.x; i < n_partial; i += kRadThreads) mn = fmin(mn, partial[(int64_t)frame * n_partial + i]);
+	mn = block_reduce<1>(mn, red);
+	if (threadIdx.x == 0) zeropoint[frame] = (mn == __builtin_inf()) ? __builtin_nan("") : (-mn + 1.0);
+}
+
+__device__ __forceinline__ uint64_t order_key(double v) {
+	const uint64_t b = (uint64_t)__double_as_longlong(v);
+	return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_value(uint64_t k) {
+	const uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+	return __longlong_as_double((long long)b);
+}
+
+// k-th and (k+1)-th smallest of vals[0..n) (k + 1 clamped to n - 1): MSB-first radix selection, 8 bits per pass
+__device__ void select_pair(const double* __restrict__ vals, int n, int k, int* hist, int* sh, double* red, double& v0, double& v1)
+{
+	const int tid = threadIdx.x;
+	uint64_t prefix = 0, pmask = 0;
+	int rank = k;
+	for (int shift = 56; shift >= 0; shift -= 8) {
+		hist[tid] = 0;
+		__syncthreads();
+		for (int i = tid; i < n; i += kRadThreads) {
+			const uint64_t key = order_key(vals[i]);
+			if ((key & pmask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255u)], 1);
+		}
+		__syncthreads();
+		if (tid == 0) {
+			int acc = 0, d = 0;
+			for (; d < 255; ++d) { if (acc + hist[d] > rank) break; acc += hist[d]; }
+			sh[0] = d; sh[1] = rank - acc;
+		}
+		__syncthreads();
+		prefix |= (uint64_t)sh[0] << shift;
+		pmask |= 255ull << shift;
+		rank = sh[1];
+		__syncthreads();
+	}
+	v0 = key_value(prefix);
+	// the next order statistic: the same value if enough copies of it exist, else the smallest larger one
+	int le = 0;
+	double nxt = __builtin_inf();
+	for (int i = tid; i < n; i += kRadThreads) {
+		const double x = vals[i];
+		le += (x <= v0) ? 1 : 0;
+		if (x > v0) nxt = fmin(nxt, x);
+	}
+	const int n_le = (int)block_reduce<0>((double)le, red);
+	nxt = block_reduce<1>(nxt, red);
+	v1 = (n_le > k + 1 || nxt == __builtin_inf()) ? v0 : nxt;
+}
+
+// scipy.stats.scoreatpercentile(x, per) (interpolation_method = 'fraction') from the two neighbouring order statistics
+__device__ __forceinline__ double percentile_from_pair(int n, double per, double s0, double s1) {
+	const double idx = per / 100.0 * (double)(n - 1);
+	const int i = (int)idx;
+	if ((double)i == idx) return s0;
+	const double w0 = (double)(i + 1) - idx, w1 = idx - (double)i;
+	return (s0 * w0 + s1 * w1) / (w0 + w1);
+}
+
+struct RingArgs {
+	RadialImage img;
+	const double* zeropoint;
+	const int32_t* ring_pixels; const int32_t* ring_offsets; int n_rings;
+	double* scratch; int64_t scratch_stride;     // per frame: one row of ring_offsets[n_rings] float64
+	double bw_constant;                          // the kernel's normal-reference constant 2 (1/24)^(1/5)
+	double* modes; int32_t* counts;              // [frame][ring]
+};
+
+__global__ __launch_bounds__(kRadThreads) void tp_radial_ring_kernel(RingArgs a)
+{
+	__shared__ double re[kKdeGrid], im[kKdeGrid];
+	__shared__ double tw_re[kKdeGrid / 2], tw_im[kKdeGrid / 2];
+	__shared__ double red[4];
+	__shared__ int hist[256];
+	__shared__ int sh[2];
+	const int ring = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+	const int p0 = a.ring_offsets[ring], p1 = a.ring_offsets[ring + 1];
+	double* vals = a.scratch + (int64_t)frame * a.scratch_stride + p0;
+	const double zp = a.zeropoint[frame];
+	const bool single = (a.img.square == nullptr);   // first iteration: float32 arithmetic (numpy: float32 array + scalar, log10 of float32)
+	const float zp32 = (float)zp;
+	double* mode_out = a.modes + (int64_t)frame * a.n_rings + ring;
+
+	// ---- 1. gather
+	if (tid == 0) sh[0] = 0;
+	__syncthreads();
+	double sum = 0.0, mn = __builtin_inf(), mx = -__builtin_inf();
+	for (int i = p0 + tid; i < p1; i += kRadThreads) {
+		double v;
+		if (radial_pixel(a.img, frame, a.ring_pixels[i], v)) {
+			double lg;
+			if (single) lg = (double)(float)log10((double)((float)v + zp32));
+			else lg = log10(v + zp);
+			vals[atomicAdd(&sh[0], 1)] = lg;
+			sum += lg; mn = fmin(mn, lg); mx = fmax(mx, lg);
+		}
+	}
+	__syncthreads();
+	const int n = sh[0];
+	__threadfence_block();
+	if (a.counts && tid == 0) a.counts[(int64_t)frame * a.n_rings + ring] = n;
+	if (n < 2 || !(zp == zp)) {
+		// an empty ring is NaN (_reduce_mode :21-22); one value gives a NaN bandwidth (std with ddof = 1), a NaN grid and support[0] = NaN
+		if (tid == 0) *mode_out = __builtin_nan("");
+		return;
+	}
+	sum = block_reduce<0>(sum, red);
+	mn = block_reduce<1>(mn, red);
+	mx = block_reduce<2>(mx, red);
+	__syncthreads();   // the scratch row is complete and visible
+
+	// ---- 2. spread: std (ddof = 1) and inter-quartile range
+	const double mean = sum / (double)n;
+	double ss = 0.0;
+	for (int i = tid; i < n; i += kRadThreads) { const double d = vals[i] - mean; ss += d * d; }
+	ss = block_reduce<0>(ss, red);
+	const double sd = sqrt(ss / (double)(n - 1));
+	double a0, a1, b0, b1;
+	select_pair(vals, n, (int)(0.25 * (double)(n - 1)), hist, sh, red, a0, a1);
+	select_pair(vals, n, (int)(0.75 * (double)(n - 1)), hist, sh, red, b0, b1);
+	const double q25 = percentile_from_pair(n, 25.0, a0, a1), q75 = percentile_from_pair(n, 75.0, b0, b1);
+	const double iqr = (q75 - q25) / 1.349;
+	const double sigma = (iqr > 0.0) ? fmin(sd, iqr) : sd;
+	const double bw = a.bw_constant * sigma * pow((double)n, -0.2);
+	if (bw == 0.0) {
+		// "Selected KDE bandwidth is 0" -> the median (:27-31)
+		double m0, m1;
+		select_pair(vals, n, (n - 1) / 2, hist, sh, red, m0, m1);
+		if (tid == 0) *mode_out = (n & 1) ? m0 : 0.5 * (m0 + m1);
+		return;
+	}
+
+	// ---- 3. linear binning (statsmodels fast_linbin, with its "li > 1" guard)
+	const double lo = mn - 3.0 * bw, hi = mx + 3.0 * bw;
+	const double delta = (hi - lo) / (double)(kKdeGrid - 1);
+	for (int i = tid; i < kKdeGrid; i += kRadThreads) { re[i] = 0.0; im[i] = 0.0; }
+	for (int i = tid; i < kKdeGrid / 2; i += kRadThreads) {
+		double s, c;
+		sincospi(-2.0 * (double)i / (double)kKdeGrid, &s, &c);
+		tw_re[i] = c; tw_im[i] = s;
+	}
+	__syncthreads();
+	for (int i = tid; i < n; i += kRadThreads) {
+		const double lx = (vals[i] - lo) / delta;
+		const int li = (int)lx;
+		const double rem = lx - (double)li;
+		if (li > 1 && li < kKdeGrid) {
+			// bit-reversed positions: the FFT below is decimation in time
+			atomicAdd(&re[__brev((unsigned)li) >> (32 - kKdeLog2)], 1.0 - rem);
+			if (li + 1 < kKdeGrid) atomicAdd(&re[__brev((unsigned)(li + 1)) >> (32 - kKdeLog2)], rem);
+		}
+	}
+	__syncthreads();
+
+	// ---- 4. density = IFFT(FFT(binned) * Silverman transform); only its argmax is used (positive scale factors dropped)
+	const double range = hi - lo;
+	const double fac1 = 2.0 * (M_PI * bw / range) * (M_PI * bw / range);
+	for (int pass = 0; pass < 2; ++pass) {
+		for (int s = 1; s <= kKdeLog2; ++s) {
+			const int half = 1 << (s - 1), tstep = kKdeGrid >> s;
+			for (int b = tid; b < kKdeGrid / 2; b += kRadThreads) {
+				const int j = b & (half - 1), base = ((b >> (s - 1)) << s) + j;
+				const double wr = tw_re[j * tstep], wi = tw_im[j * tstep];
+				const double xr = re[base + half], xi = im[base + half];
+				const double tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
+				const double ur = re[base], ui = im[base];
+				re[base] = ur + tr; im[base] = ui + ti;
+				re[base + half] = ur - tr; im[base + half] = ui - ti;
+			}
+			__syncthreads();
+		}
+		if (pass == 0) {
+			// multiply by the kernel transform, conjugate, and put back in bit-reversed order for the second transform
+			double zr[kKdeGrid / kRadThreads], zi[kKdeGrid / kRadThreads];
+#pragma unroll
+			for (int q = 0; q < kKdeGrid / kRadThreads; ++q) {
+				const int J = tid + q * kRadThreads;
+				const double jj = (double)((J <= kKdeGrid / 2) ? J : (kKdeGrid - J));
+				const double t = jj / (double)kKdeGrid * M_PI;
+				const double fac = exp(-(jj * jj) * fac1) / (1.0 - 1.0 / 3.0 * (t * t));
+				zr[q] = re[J] * fac; zi[q] = -im[J] * fac;
+			}
+			__syncthreads();
+#pragma unroll
+			for (int q = 0; q < kKdeGrid / kRadThreads; ++q) {
+				const int J = tid + q * kRadThreads;
+				const int r = (int)(__brev((unsigned)J) >> (32 - kKdeLog2));
+				re[r] = zr[q]; im[r] = zi[q];
+			}
+			__syncthreads();
+		}
+	}
+	// first index of the maximum (np.argmax)
+	double best = -__builtin_inf();
+	int best_i = kKdeGrid;
+	for (int i = tid; i < kKdeGrid; i += kRadThreads) {
+		const double f = re[i];
+		if (f > best) { best = f; best_i = i; }
+	}
+	const double wmax = block_reduce<2>(best, red);
+	const int cand = (best == wmax) ? best_i : kKdeGrid;
+	const int arg = (int)block_reduce<1>((double)cand, red);
+	if (tid == 0) {
+		// np.linspace(lo, hi, 2048): arange * step + lo, last point = hi
+		*mode_out = (arg == kKdeGrid - 1) ? hi : ((double)arg * delta + lo);
+	}
+}
+
+struct EvalArgs {
+	int n_rows, n_cols; int64_t frame_stride;
+	double col_offset, xcen, ycen;
+	const double* knots; const double* coefs; const int32_t* n_knots; int max_knots;   // per frame: FITPACK knots t[0..n), coefficients c[0..n-4)
+	const double* zeropoint;
+	const float* add; int64_t add_stride;
+	float* out;
+};
+
+// out = float32(10**spline(r) - zeropoint [+ add]); a frame with n_knots == 0 has no radial component (out = add or 0)
+__global__ __launch_bounds__(256) void tp_radial_eval_kernel(EvalArgs a)
+{
+	extern __shared__ double sp[];   // knots, then coefficients
+	const int frame = blockIdx.z, row = blockIdx.y;
+	const int n = a.n_knots[frame];
+	for (int i = threadIdx.x; i < n; i += 256) {
+		sp[i] = a.knots[(int64_t)frame * a.max_knots + i];
+		sp[a.max_knots + i] = a.coefs[(int64_t)frame * a.max_knots + i];
+	}
+	__syncthreads();
+	const int col = blockIdx.x * 256 + threadIdx.x;
+	if (col >= a.n_cols) return;
+	const int64_t p = (int64_t)row * a.n_cols + col;
+	double radial = 0.0;
+	if (n >= 8) {
+		const double* t = sp;
+		const double* c = sp + a.max_knots;
+		const double dx = ((double)col + a.col_offset) - a.xcen, dy = (double)row - a.ycen;
+		double x = sqrt(dx * dx + dy * dy);
+		// ext = 3: the boundary value outside [t[3], t[n - 4]]
+		x = fmin(fmax(x, t[3]), t[n - 4]);
+		// interval t[l] <= x < t[l + 1], 3 <= l <= n - 5
+		int l = 3, h = n - 4;
+		while (h - l > 1) { const int m = (l + h) >> 1; if (x >= t[m]) l = m; else h = m; }
+		// de Boor, cubic
+		double d0 = c[l - 3], d1 = c[l - 2], d2 = c[l - 1], d3 = c[l];
+		double al;
+		al = (x - t[l]) / (t[l + 3] - t[l]);         d3 = (1.0 - al) * d2 + al * d3;
+		al = (x - t[l - 1]) / (t[l + 2] - t[l - 1]); d2 = (1.0 - al) * d1 + al * d2;
+		al = (x - t[l - 2]) / (t[l + 1] - t[l - 2]); d1 = (1.0 - al) * d0 + al * d1;
+		al = (x - t[l]) / (t[l + 2] - t[l]);         d3 = (1.0 - al) * d2 + al * d3;
+		al = (x - t[l - 1]) / (t[l + 1] - t[l - 1]); d2 = (1.0 - al) * d1 + al * d2;
+		al = (x - t[l]) / (t[l + 1] - t[l]);         d3 = (1.0 - al) * d2 + al * d3;
+		radial = pow(10.0, d3) - a.zeropoint[frame];
+	}
+	const double base = a.add ? (double)a.add[(int64_t)frame * a.add_stride + p] : 0.0;
+	a.out[(int64_t)frame * a.frame_stride + p] = (float)(radial + base);
+}
+
+} // namespace
+
+static bool radial_image_ok(int32_t n_frames, int64_t n_pixels, int64_t frame_stride) {
+	return n_frames >= 0 && n_frames <= 65535 && n_pixels > 0 && n_pixels <= 0x7fffffff && frame_stride >= n_pixels;
+}
+
+extern "C" int tp_radial_zeropoint(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride,
+	const float* d_square, int64_t square_frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride, double flux_cutoff,
+	double* d_partial, int32_t n_partial, double* d_zeropoint)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_frames && d_partial && d_zeropoint, "tp_radial_zeropoint: null pointer");
+	TP_REQUIRE(ctx, radial_image_ok(n_frames, n_pixels, frame_stride), "tp_radial_zeropoint: bad frame geometry");
+	TP_REQUIRE(ctx, n_partial >= 1 && n_partial <= 65535, "tp_radial_zeropoint: n_partial must be 1..65535");
+	if (n_frames == 0) return TP_OK;
+	RadialImage img{d_frames, frame_stride, d_square, square_frame_stride, d_exclude, exclude_frame_stride, (float)flux_cutoff};
+	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_min_partial_kernel, dim3((unsigned)n_partial, (unsigned)n_frames), dim3(kRadThreads), 0, img, n_pixels, d_partial);
+	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_min_final_kernel, dim3((unsigned)n_frames), dim3(kRadThreads), 0, d_partial, (int)n_partial, d_zeropoint);
+	TP_LAUNCH_CHECK(ctx, "tp_radial_min kernels");
+	return TP_OK;
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_radial_ring_modes(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride,
+	const float* d_square, int64_t square_frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride, double flux_cutoff,
+	const double* d_zeropoint, const int32_t* d_ring_pixels, const int32_t* d_ring_offsets, int32_t n_rings, int32_t n_ring_pixels,
+	double bandwidth_constant, double* d_scratch, double* d_modes, int32_t* d_counts)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_frames && d_zeropoint && d_ring_pixels && d_ring_offsets && d_scratch && d_modes, "tp_radial_ring_modes: null pointer");
+	TP_REQUIRE(ctx, radial_image_ok(n_frames, n_pixels, frame_stride), "tp_radial_ring_modes: bad frame geometry");
+	TP_REQUIRE(ctx, n_rings >= 0 && n_rings <= 65535 && n_ring_pixels >= 0, "tp_radial_ring_modes: bad ring list");
+	if (n_frames == 0 || n_rings == 0) return TP_OK;
+	RingArgs a;
+	a.img = RadialImage{d_frames, frame_stride, d_square, square_frame_stride, d_exclude, exclude_frame_stride, (float)flux_cutoff};
+	a.zeropoint = d_zeropoint;
+	a.ring_pixels = d_ring_pixels; a.ring_offsets = d_ring_offsets; a.n_rings = n_rings;
+	a.scratch = d_scratch; a.scratch_stride = n_ring_pixels;
+	a.bw_constant = bandwidth_constant;
+	a.modes = d_modes; a.counts = d_counts;
+	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_ring_kernel, dim3((unsigned)n_rings, (unsigned)n_frames), dim3(kRadThreads), 0, a);
+	TP_LAUNCH_CHECK(ctx, "tp_radial_ring_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_radial_evaluate(tp_ctx* ctx, int32_t n_frames, int32_t frame_rows, int32_t frame_cols, int64_t frame_stride,
+	double col_offset, double xcen, double ycen, const double* d_knots, const double* d_coefs, const int32_t* d_n_knots, int32_t max_knots,
+	const double* d_zeropoint, const float* d_add, int64_t add_frame_stride, float* d_out)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_knots && d_coefs && d_n_knots && d_zeropoint && d_out, "tp_radial_evaluate: null pointer");
+	TP_REQUIRE(ctx, n_frames >= 0 && n_frames <= 65535 && frame_rows > 0 && frame_rows <= 65535 && frame_cols > 0
+		&& frame_stride >= (int64_t)frame_rows * frame_cols, "tp_radial_evaluate: bad frame geometry");
+	TP_REQUIRE(ctx, max_knots >= 8 && max_knots <= 2048, "tp_radial_evaluate: max_knots must be 8..2048");
+	if (n_frames == 0) return TP_OK;
+	EvalArgs a;
+	a.n_rows = frame_rows; a.n_cols = frame_cols; a.frame_stride = frame_stride;
+	a.col_offset = col_offset; a.xcen = xcen; a.ycen = ycen;
+	a.knots = d_knots; a.coefs = d_coefs; a.n_knots = d_n_knots; a.max_knots = max_knots;
+	a.zeropoint = d_zeropoint; a.add = d_add; a.add_stride = add_frame_stride; a.out = d_out;
+	dim3 grid((unsigned)((frame_cols + 255) / 256), (unsigned)frame_rows, (unsigned)n_frames);
+	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_eval_kernel, grid, dim3(256), (size_t)max_knots * 2 * sizeof(double), a);
+	TP_LAUNCH_CHECK(ctx, "tp_radial_eval_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}

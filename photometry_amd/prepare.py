@@ -7,14 +7,19 @@ manual-exclude masking, the pixel flags and the sum image -- everything ``BasePh
 What runs where: every pixel-sized operation is a device kernel (``csrc/fullframe.hip``); the background mesh of a frame
 (32 x 32 numbers for a 2048 x 2048 image) goes through its few small steps -- drop the mostly-masked cells, fill them from
 their neighbours, 3 x 3 median filter, cubic-spline prefilter -- on the host with the same scipy calls photutils makes.
-HDF5 / FITS I/O, WCS and the TESS-specific radial component of ``fit_background`` (backgrounds.py:110-154, 162-197: needs the
-camera geometry of an ``FFIImage``) are not part of this module: ``fit_background_frames`` is the branch the reference takes
-for a plain image (``bkgiters = 1``, :156-157), which is also what its own test exercises (tests/test_background.py:36-54).
+``fit_background_frames`` is both branches of the reference's ``fit_background``: without ``camera`` / ``ccd`` the one it takes
+for a plain image (``bkgiters = 1``, backgrounds.py:156-157 -- what its own test exercises, tests/test_background.py:36-54),
+with them the TESS one: ``bkgiters`` rounds of the radial corner-glow component (ring modes on the device,
+``csrc/radial.hip``; the 3-point median and the interpolating spline of ~40 ring values on the host with the reference's own
+scipy call) and the mesh of ``img0 - img_bkg_radial``.  HDF5 / FITS I/O and WCS are not part of this module.
 """
 
 import ctypes
+import logging
+import warnings
 import numpy as np
 from scipy import ndimage
+from scipy.interpolate import InterpolatedUnivariateSpline
 from .engine import TESS_DEFAULT_BITMASK
 
 #: PixelQualityFlags (photometry/quality.py:157-166)
@@ -42,26 +47,111 @@ def finish_mesh(mesh, nmasked, box=64, exclude_percentile=50.0, filter_size=3):
 			w = 1.0 / dist[nearest]
 			mesh[y, x] = np.sum(w * kv[nearest]) / np.sum(w)
 	if filter_size > 1:
-		mesh = ndimage.generic_filter(mesh, np.nanmedian, size=filter_size, mode='constant', cval=np.nan)
+		# generic_filter(mesh, nanmedian, size, mode='constant', cval=nan) as photutils calls it: the NaN-ignoring median of
+		# every window, windows running off the mesh padded with NaN -- as one nanmedian over the stack of shifted copies
+		h = filter_size // 2
+		ny, nx = mesh.shape
+		pad = np.pad(mesh, ((h, filter_size - 1 - h), (h, filter_size - 1 - h)), constant_values=np.nan)
+		stack = np.stack([pad[dy:dy + ny, dx:dx + nx] for dy in range(filter_size) for dx in range(filter_size)])
+		with warnings.catch_warnings():
+			warnings.simplefilter('ignore', RuntimeWarning)     # a window without any finite value is NaN, as there
+			mesh = np.nanmedian(stack, axis=0)
 	return mesh
 
 
-def fit_background_frames(ctx, frames, flux_cutoff=8e4, box=64, exclude=None, out=None, return_mask=False):
-	"""
-	``fit_background`` (backgrounds.py:52-211, plain-image branch) for every frame of a stack.
+#: pixel coordinates of the camera centre relative to every CCD (backgrounds.py:118-135)
+CAMERA_CENTRE = {
+	(1, 1): (2158.222313, 2099.523364), (1, 2): (-5.653058, 2098.018608), (1, 3): (2141.511437, 2099.868226), (1, 4): (-22.406442, 2100.116443),
+	(2, 1): (2148.588316, 2094.033024), (2, 2): (-16.806140, 2095.810070), (2, 3): (2151.351646, 2105.747100), (2, 4): (-13.118570, 2105.982211),
+	(3, 1): (2152.175481, 2092.337442), (3, 2): (-10.494413, 2093.108135), (3, 3): (2145.029218, 2107.883573), (3, 4): (-17.374782, 2105.296746),
+	(4, 1): (2149.259760, 2091.433315), (4, 2): (-12.906931, 2093.350054), (4, 3): (2148.906766, 2110.730620), (4, 4): (-14.629676, 2111.341670),
+}
+#: first science column of a TESS FFI: the distance image is in the coordinates of the full 2136-column frame (backgrounds.py:144)
+TESS_SCIENCE_COLUMN = 44
 
-	``frames``: float32 DeviceArray ``(T, R, C)``; ``exclude``: optional uint8 DeviceArray ``(R, C)`` or ``(T, R, C)`` of
-	manually excluded pixels (backgrounds.py:96-97).  Returns the background as a float32 DeviceArray ``(T, R, C)`` (and, with
-	``return_mask``, the host bool array ``(T, ny, nx)`` of dropped cells and the masked-pixel counts).  A frame without any
-	usable cell comes back NaN (the reference returns a NaN image when everything is masked, :99-102).
+
+class RadialGeometry(object):
 	"""
+	What the radial component needs to know about a CCD and never changes between frames (backgrounds.py:110-154): the ring
+	edges, their centres, and for every ring the list of its pixels in row-major order (the order ``r[~mask]`` hands them to
+	``binned_statistic``: samples on an edge go to the ring on its right, samples within rounding of the LAST edge into the last
+	ring -- scipy 1.7.3 ``_bin_numbers``).
+	"""
+	def __init__(self, shape, camera, ccd, radial_cutoff=2400, radial_pixel_step=15):
+		if (camera, ccd) not in CAMERA_CENTRE:
+			raise ValueError(f"Invalid CAMERA or CCD in header: CAMERA={camera}, CCD={ccd}")
+		self.xcen, self.ycen = CAMERA_CENTRE[(camera, ccd)]
+		R, C = shape
+		xx, yy = np.meshgrid(np.arange(TESS_SCIENCE_COLUMN, C + TESS_SCIENCE_COLUMN, 1), np.arange(0, R, 1))
+		r = np.sqrt((xx - self.xcen)**2 + (yy - self.ycen)**2)
+		self.bins = np.arange(radial_cutoff, np.max(r) + radial_pixel_step, radial_pixel_step)
+		if len(self.bins) < 2:
+			raise ValueError("no pixel beyond the radial cutoff: the radial component has no rings")
+		self.bin_center = self.bins[1:] - radial_pixel_step / 2
+		self.n_rings = len(self.bins) - 1
+		r = r.ravel()
+		number = np.digitize(r, self.bins)
+		decimal = int(-np.log10(np.diff(self.bins).min())) + 6
+		number[np.around(r, decimal) == np.around(self.bins[-1], decimal)] -= 1
+		inside = np.nonzero((number >= 1) & (number <= self.n_rings))[0]
+		order = np.argsort(number[inside], kind='stable')
+		self.ring_pixels = inside[order].astype('int32')
+		self.ring_offsets = np.concatenate(([0], np.cumsum(np.bincount(number[inside] - 1, minlength=self.n_rings)))).astype('int32')
+
+
+def _move_median_central(x, width):
+	"""utilities.move_median_central (utilities.py:52-62) on a short 1-D array: NaN-ignoring centred moving median with the
+	ends redone over the first / last ``k + 2`` points."""
+	n = len(x)
+	y = np.full(n, np.nan)
+	def med(v):
+		v = v[~np.isnan(v)]
+		return np.median(v) if len(v) else np.nan
+	trail = np.array([med(x[max(i - width + 1, 0):i + 1]) for i in range(n)])
+	y = np.roll(trail, -width // 2 + 1)
+	for k in range(width // 2 + 1):
+		y[k] = med(x[:k + 2])
+		y[-(k + 1)] = med(x[-(k + 2):])
+	return y
+
+
+def radial_profiles(s2, bin_center, radial_smooth=3, max_knots=None):
+	"""
+	backgrounds.py:178-195 for the ring modes ``s2 (T, n_rings)`` of a batch of frames: smoothing, then the interpolating cubic
+	spline through the finite values (``InterpolatedUnivariateSpline(k=3, ext=3)``: the reference's own scipy call) in FITPACK
+	form.  Returns ``(knots (T, K), coefs (T, K), n_knots int32 (T,))``; ``n_knots == 0`` where the reference falls back to no
+	radial component (fewer than 3 points, or a ``ValueError`` from the fit).
+	"""
+	logger = logging.getLogger(__name__)
+	T, nr = s2.shape
+	K = max(nr + 4, 8) if max_knots is None else int(max_knots)
+	knots, coefs, n_knots = np.zeros((T, K)), np.zeros((T, K)), np.zeros(T, dtype='int32')
+	for k in range(T):
+		prof = _move_median_central(s2[k], radial_smooth) if radial_smooth else s2[k]
+		good = ~np.isnan(prof)
+		ngood = int(np.sum(good))
+		if ngood < 3: # "The required number of points for qubic spline" (:183)
+			logger.warning("Not enough points for radial interpolation (N=%d).", ngood)
+			continue
+		try:
+			t, c, _ = InterpolatedUnivariateSpline(bin_center[good], prof[good], k=3, ext=3)._eval_args
+		except ValueError:
+			logger.exception("Background interpolation failed (N=%d).", ngood)
+			continue
+		n_knots[k] = len(t)
+		knots[k, :len(t)] = t
+		coefs[k, :len(c)] = c
+	return knots, coefs, n_knots
+
+
+def _square_component(ctx, frames, flux_cutoff, box, exclude, estride, subtract, out):
+	"""Background2D of ``frames - subtract`` (backgrounds.py:199-206): mesh statistics and zoom on the device, the mesh itself on the host."""
 	T, R, C = frames.shape
 	ny, nx = -(-R // box), -(-C // box)
 	mesh = ctx.empty((T, ny, nx), 'float64')
 	nmasked = ctx.empty((T, ny, nx), 'int32')
-	estride = 0 if exclude is None or len(exclude.shape) == 2 else R * C
 	ctx._check(ctx.lib.tp_background_mesh(ctx.handle, frames.ptr, T, R, C, C, R * C, None if exclude is None else exclude.ptr, estride,
-		float(flux_cutoff), int(box), mesh.ptr, nmasked.ptr))
+		None if subtract is None else subtract.ptr, R * C, float(flux_cutoff), int(box), mesh.ptr, nmasked.ptr))
 	mesh_h, nm_h = mesh.to_host(), nmasked.to_host()
 	coef = np.empty((T, ny, nx))
 	vmin, vmax = np.empty(T), np.empty(T)
@@ -73,8 +163,6 @@ def fit_background_frames(ctx, frames, flux_cutoff=8e4, box=64, exclude=None, ou
 		vmin[k], vmax[k] = np.min(m), np.max(m)
 		# the cubic-spline coefficients scipy.ndimage.zoom(order=3, mode='reflect') interpolates from
 		coef[k] = ndimage.spline_filter(m, order=3, mode='reflect') if min(ny, nx) > 1 else m
-	if out is None:
-		out = ctx.empty((T, R, C), 'float32')
 	if min(ny, nx) > 1:
 		d_coef, d_vmin, d_vmax = ctx.array(coef), ctx.array(vmin), ctx.array(vmax)   # kept alive until the kernel has run
 		ctx._check(ctx.lib.tp_background_zoom(ctx.handle, d_coef.ptr, d_vmin.ptr, d_vmax.ptr, T, ny, nx, int(box), R, C, C, R * C, out.ptr))
@@ -83,22 +171,85 @@ def fit_background_frames(ctx, frames, flux_cutoff=8e4, box=64, exclude=None, ou
 		host = np.empty((T, R, C), dtype='float32')
 		host[:] = coef[:, :1, :1]
 		ctx._check(ctx.lib.tp_memcpy_h2d(ctx.handle, out.ptr, host.ctypes.data, host.nbytes))
-	if return_mask:
-		return out, mesh_h, nm_h
-	return out
+	return mesh_h, nm_h
 
 
-def prepare_frames(ctx, raw, raw_err, quality, cadence=1800, flux_cutoff=8e4, pixel_flags=None, backapp=False):
+def fit_background_frames(ctx, frames, flux_cutoff=8e4, box=64, exclude=None, out=None, return_mask=False,
+	camera=None, ccd=None, bkgiters=3, radial_cutoff=2400, radial_pixel_step=15, radial_smooth=3, geometry=None, details=None):
+	"""
+	``fit_background`` (backgrounds.py:52-211) for every frame of a stack.
+
+	``frames``: float32 DeviceArray ``(T, R, C)``; ``exclude``: optional uint8 DeviceArray ``(R, C)`` or ``(T, R, C)`` of
+	manually excluded pixels (backgrounds.py:96-97).  Returns the background as a float32 DeviceArray ``(T, R, C)`` (and, with
+	``return_mask``, the host arrays of the last mesh and its masked-pixel counts).  A frame without any usable cell comes
+	back NaN (the reference returns a NaN image when everything is masked, :99-102).
+
+	With ``camera`` and ``ccd`` (the FFI header cards of a TESS image, :116-117) the frames are the 2048 science columns of TESS
+	full-frame images and the radial component is fitted as well, ``bkgiters`` times alternating with the mesh (:162-206); a
+	``RadialGeometry`` can be passed in ``geometry`` to reuse it between calls.  ``details``: optional dict that receives the
+	ring modes, zero points and spline arrays of every round (host arrays).
+	"""
+	T, R, C = frames.shape
+	estride = 0 if exclude is None or len(exclude.shape) == 2 else R * C
+	if out is None:
+		out = ctx.empty((T, R, C), 'float32')
+	if camera is None and ccd is None and geometry is None:
+		mesh_h, nm_h = _square_component(ctx, frames, flux_cutoff, box, exclude, estride, None, out)
+		return (out, mesh_h, nm_h) if return_mask else out
+
+	geo = geometry if geometry is not None else RadialGeometry((R, C), camera, ccd, radial_cutoff, radial_pixel_step)
+	d_pixels, d_offsets = ctx.array(geo.ring_pixels), ctx.array(geo.ring_offsets)
+	n_ring_pixels = int(geo.ring_offsets[-1])
+	n_partial = 256
+	d_partial = ctx.empty((T, n_partial), 'float64')
+	d_zp = ctx.empty((T,), 'float64')
+	d_scratch = ctx.empty((T, max(n_ring_pixels, 1)), 'float64')
+	d_modes = ctx.empty((T, geo.n_rings), 'float64')
+	d_counts = ctx.empty((T, geo.n_rings), 'int32')
+	radial = ctx.empty((T, R, C), 'float32')
+	square = None
+	# kernels.Gaussian().normal_reference_constant of statsmodels (order 2, L2 norm 1 / (2 sqrt(pi)), unit variance)
+	bw_constant = np.pi**0.5 * 2.0**3 * (1.0 / (2.0 * np.sqrt(np.pi)))
+	bw_constant /= (2 * 2 * 24.0 * 1.0**2)
+	bw_constant = 2 * bw_constant**(1.0 / 5)
+	ex_ptr = None if exclude is None else exclude.ptr
+	for it in range(int(bkgiters)):
+		sq_ptr = None if square is None else square.ptr
+		ctx._check(ctx.lib.tp_radial_zeropoint(ctx.handle, frames.ptr, T, R * C, R * C, sq_ptr, R * C, ex_ptr, estride, float(flux_cutoff),
+			d_partial.ptr, n_partial, d_zp.ptr))
+		ctx._check(ctx.lib.tp_radial_ring_modes(ctx.handle, frames.ptr, T, R * C, R * C, sq_ptr, R * C, ex_ptr, estride, float(flux_cutoff),
+			d_zp.ptr, d_pixels.ptr, d_offsets.ptr, geo.n_rings, n_ring_pixels, float(bw_constant), d_scratch.ptr, d_modes.ptr, d_counts.ptr))
+		s2 = d_modes.to_host()
+		knots, coefs, n_knots = radial_profiles(s2, geo.bin_center, radial_smooth)
+		d_knots, d_coefs, d_nk = ctx.array(knots), ctx.array(coefs), ctx.array(n_knots)
+		ctx._check(ctx.lib.tp_radial_evaluate(ctx.handle, T, R, C, R * C, float(TESS_SCIENCE_COLUMN), float(geo.xcen), float(geo.ycen),
+			d_knots.ptr, d_coefs.ptr, d_nk.ptr, knots.shape[1], d_zp.ptr, None, 0, radial.ptr))
+		if square is None:
+			square = ctx.empty((T, R, C), 'float32')
+		mesh_h, nm_h = _square_component(ctx, frames, flux_cutoff, box, exclude, estride, radial, square)
+		if details is not None:
+			details.setdefault('s2', []).append(s2)
+			details.setdefault('zeropoint', []).append(d_zp.to_host())
+			details.setdefault('n_knots', []).append(n_knots)
+			details.setdefault('counts', []).append(d_counts.to_host())
+	# total background (:209); a frame in which everything is masked is NaN (:99-102)
+	ctx._check(ctx.lib.tp_radial_evaluate(ctx.handle, T, R, C, R * C, float(TESS_SCIENCE_COLUMN), float(geo.xcen), float(geo.ycen),
+		d_knots.ptr, d_coefs.ptr, d_nk.ptr, knots.shape[1], d_zp.ptr, square.ptr, R * C, out.ptr))
+	ctx.sync()
+	return (out, mesh_h, nm_h) if return_mask else out
+
+
+def prepare_frames(ctx, raw, raw_err, quality, cadence=1800, flux_cutoff=8e4, pixel_flags=None, backapp=False, camera=None, ccd=None):
 	"""
 	The image arithmetic of ``prepare_photometry`` for one CCD (prepare.py:265-459) on device-resident stacks ``(T, R, C)``:
 	backgrounds (B1), their smoothing over ``time_smooth`` frames (B2, :258, :317-335), ``images = raw - background`` with
 	manually excluded pixels set to NaN in image and error (B3, :419-425), the sum image over the good-quality frames
 	(A1, :450-453, :459).  Returns a dict of DeviceArrays: ``backgrounds, images, images_err`` float32 ``(T, R, C)``,
-	``sumimage`` float64 ``(R, C)``.
+	``sumimage`` float64 ``(R, C)``.  ``camera`` / ``ccd``: the header cards of TESS full-frame images (see ``fit_background_frames``).
 	"""
 	T, R, C = raw.shape
 	time_smooth = {1800: 3, 600: 9}[int(cadence)]
-	bkg_us = fit_background_frames(ctx, raw, flux_cutoff=flux_cutoff)
+	bkg_us = fit_background_frames(ctx, raw, flux_cutoff=flux_cutoff, camera=camera, ccd=ccd)   # TESS frames: with the radial component
 	bkg = ctx.empty((T, R, C), 'float32')
 	ctx._check(ctx.lib.tp_frames_smooth_time(ctx.handle, T, R * C, R * C, time_smooth, bkg_us.ptr, bkg.ptr))
 	bkg_us.free()

@@ -10,6 +10,7 @@ scikit-image 0.19.2): every check below holds them to something that is NOT the 
 * hand-derived label images for the priority-flood watershed and hand-derived peak lists for ``peak_local_max``
   (k2p2v2.py:141, 227) -- the expected arrays are written out below, not computed.
 """
+import os
 import numpy as np
 import pytest
 from scipy import stats
@@ -186,3 +187,64 @@ def test_peak_local_max_hand_cases():
 	img = -np.ones((3, 3))
 	img[1, 1] = -0.5
 	assert len(k2p2.peak_local_max(img, footprint=fp)) == 0
+
+
+#--------------------------------------------------------------------------------------------------
+# The radial component of fit_background (oracle/backgrounds.py: TESS branch)
+#--------------------------------------------------------------------------------------------------
+def test_binned_callable_is_scipy_binned_statistic():
+	"""The restated ``binned_statistic`` with a callable against scipy's own (which the reference calls, backgrounds.py:171-176)."""
+	from scipy.stats import binned_statistic
+	from oracle import backgrounds as ob
+	rng = np.random.default_rng(3)
+	x = rng.uniform(2300, 3000, 5000)
+	bins = np.arange(2400, x.max() + 15, 15)
+	x[:3] = [bins[-1], bins[0], bins[5]]             # on the last edge, the first edge, an inner edge
+	v = rng.normal(0, 1, x.size).astype('float32')
+	stat = lambda a: np.nan if len(a) == 0 else float(np.sum(np.asarray(a, dtype='float64') * np.arange(1, len(a) + 1)))   # order sensitive
+	ref, _, _ = binned_statistic(x, v, statistic=stat, bins=bins)
+	got = ob.binned_callable(x, v, stat, bins)
+	assert np.array_equal(np.isnan(ref), np.isnan(got))
+	np.testing.assert_array_equal(ref[~np.isnan(ref)], got[~np.isnan(ref)])
+	# an empty ring is NaN
+	x2 = x[(x < 2500) | (x > 2530)]
+	ref2, _, _ = binned_statistic(x2, v[:x2.size], statistic=stat, bins=bins)
+	got2 = ob.binned_callable(x2, v[:x2.size], stat, bins)
+	assert np.isnan(got2).sum() == np.isnan(ref2).sum() >= 1
+
+
+def test_normal_reference_bandwidth_and_linbin():
+	from oracle import kde
+	# the constant of the Gaussian kernel in closed form: 2 (1/24)^(1/5) = (4/3)^(1/5)
+	assert abs(kde.normal_reference_constant() - (4.0 / 3.0)**0.2) < 1e-15
+	rng = np.random.default_rng(0)
+	x = rng.normal(2.0, 0.1, 5000)
+	np.testing.assert_allclose(kde.fast_linbin_vec(x, 1.5, 2.6, 2048), kde.fast_linbin(x, 1.5, 2.6, 2048), rtol=0, atol=0)
+	# mode of a KDE of a unimodal sample sits at its centre; all-equal input falls back to the median
+	from oracle import backgrounds as ob
+	mode = ob.reduce_mode(x)
+	assert abs(mode - 2.0) < 0.04
+	# ... and where the direct Gaussian sum with the same bandwidth has its maximum on the same 2048-point grid (one step)
+	bw = kde.bw_normal_reference(x)
+	grid = np.linspace(x.min() - 3 * bw, x.max() + 3 * bw, 2048)
+	direct = np.exp(-0.5 * ((grid[:, None] - x[None, :]) / bw)**2).sum(axis=1)
+	assert abs(mode - grid[np.argmax(direct)]) <= (grid[1] - grid[0]) * 1.01
+	assert ob.reduce_mode(np.full(10, 1.25)) == 1.25
+	assert np.isnan(ob.reduce_mode(np.array([])))
+	assert np.isnan(ob.reduce_mode(np.array([3.0])))
+
+
+def test_move_median_central_by_hand():
+	from oracle import backgrounds as ob
+	x = np.array([1.0, np.nan, 3.0, 10.0, 2.0, np.nan, np.nan, 5.0])
+	# interior: nanmedian of (x[i-1], x[i], x[i+1]); ends: utilities.py:56-58
+	expect = [1.0, 2.0, 6.5, 3.0, 6.0, 2.0, 5.0, 5.0]
+	np.testing.assert_array_equal(ob.move_median_central(x, 3), expect)
+	y = ob.move_median_central(np.array([np.nan, np.nan, np.nan, 4.0]), 3)
+	assert np.isnan(y[0]) and np.isnan(y[1]) and y[2] == 4.0 and y[3] == 4.0
+	# the product's host-side version (photometry_amd/prepare.py) on the same inputs and on the reference's own output
+	from photometry_amd import prepare
+	np.testing.assert_array_equal(prepare._move_median_central(x, 3), expect)
+	g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'golden_misc.npz'))
+	np.testing.assert_array_equal(prepare._move_median_central(g['mmc_in'], 3), g['mmc_out'])
+	np.testing.assert_array_equal(ob.move_median_central(g['mmc_in'], 3), g['mmc_out'])
