@@ -30,33 +30,41 @@ PIXEL_BACKGROUND_SHENANIGANS = 4
 
 def finish_mesh(mesh, nmasked, box=64, exclude_percentile=50.0, filter_size=3):
 	"""
-	The low-resolution part of photutils ``Background2D`` (1.3.0) for one frame, after the per-cell statistics: cells with more
-	than ``exclude_percentile`` % masked pixels are replaced by the inverse-distance weighted mean of the 10 nearest kept
-	cells, then the 3 x 3 median filter.  Returns the filtered mesh (float64); raises ``ValueError`` when no cell is usable.
+	The low-resolution part of photutils ``Background2D`` (1.3.0) after the per-cell statistics, for one frame ``(ny, nx)`` or
+	a batch ``(T, ny, nx)``: cells with more than ``exclude_percentile`` % masked pixels are replaced by the inverse-distance
+	weighted mean of the 10 nearest kept cells, then the 3 x 3 median filter.  Returns the filtered mesh (float64).  A single
+	frame without any usable cell raises ``ValueError`` like photutils; in a batch such a frame comes back NaN.
 	"""
 	mesh = np.array(mesh, dtype='float64', copy=True)
+	single = (mesh.ndim == 2)
+	if single:
+		mesh = mesh[None]
+		nmasked = np.asarray(nmasked)[None]
+	T, ny, nx = mesh.shape
 	keep = (np.asarray(nmasked) <= exclude_percentile / 100.0 * box * box) & np.isfinite(mesh)
-	if not keep.any():
-		raise ValueError(f"All meshes contain > {exclude_percentile} percent masked pixels")
-	if not keep.all():
-		ky, kx = np.nonzero(keep)
-		kv = mesh[keep]
-		for y, x in zip(*np.nonzero(~keep)):
+	for k in np.nonzero(~keep.all(axis=(1, 2)))[0]:
+		if not keep[k].any():
+			if single:
+				raise ValueError(f"All meshes contain > {exclude_percentile} percent masked pixels")
+			mesh[k] = np.nan
+			continue
+		ky, kx = np.nonzero(keep[k])
+		kv = mesh[k][keep[k]]
+		for y, x in zip(*np.nonzero(~keep[k])):
 			dist = np.hypot(ky - y, kx - x)
 			nearest = np.argsort(dist, kind='stable')[:10]
 			w = 1.0 / dist[nearest]
-			mesh[y, x] = np.sum(w * kv[nearest]) / np.sum(w)
+			mesh[k, y, x] = np.sum(w * kv[nearest]) / np.sum(w)
 	if filter_size > 1:
 		# generic_filter(mesh, nanmedian, size, mode='constant', cval=nan) as photutils calls it: the NaN-ignoring median of
 		# every window, windows running off the mesh padded with NaN -- as one nanmedian over the stack of shifted copies
 		h = filter_size // 2
-		ny, nx = mesh.shape
-		pad = np.pad(mesh, ((h, filter_size - 1 - h), (h, filter_size - 1 - h)), constant_values=np.nan)
-		stack = np.stack([pad[dy:dy + ny, dx:dx + nx] for dy in range(filter_size) for dx in range(filter_size)])
+		pad = np.pad(mesh, ((0, 0), (h, filter_size - 1 - h), (h, filter_size - 1 - h)), constant_values=np.nan)
+		stack = np.stack([pad[:, dy:dy + ny, dx:dx + nx] for dy in range(filter_size) for dx in range(filter_size)])
 		with warnings.catch_warnings():
 			warnings.simplefilter('ignore', RuntimeWarning)     # a window without any finite value is NaN, as there
 			mesh = np.nanmedian(stack, axis=0)
-	return mesh
+	return mesh[0] if single else mesh
 
 
 #: pixel coordinates of the camera centre relative to every CCD (backgrounds.py:118-135)
@@ -153,16 +161,12 @@ def _square_component(ctx, frames, flux_cutoff, box, exclude, estride, subtract,
 	ctx._check(ctx.lib.tp_background_mesh(ctx.handle, frames.ptr, T, R, C, C, R * C, None if exclude is None else exclude.ptr, estride,
 		None if subtract is None else subtract.ptr, R * C, float(flux_cutoff), int(box), mesh.ptr, nmasked.ptr))
 	mesh_h, nm_h = mesh.to_host(), nmasked.to_host()
-	coef = np.empty((T, ny, nx))
-	vmin, vmax = np.empty(T), np.empty(T)
-	for k in range(T):
-		try:
-			m = finish_mesh(mesh_h[k], nm_h[k], box)
-		except ValueError:
-			m = np.full((ny, nx), np.nan)
-		vmin[k], vmax[k] = np.min(m), np.max(m)
-		# the cubic-spline coefficients scipy.ndimage.zoom(order=3, mode='reflect') interpolates from
-		coef[k] = ndimage.spline_filter(m, order=3, mode='reflect') if min(ny, nx) > 1 else m
+	m = finish_mesh(mesh_h, nm_h, box)
+	vmin, vmax = np.min(m, axis=(1, 2)), np.max(m, axis=(1, 2))
+	# the cubic-spline coefficients scipy.ndimage.zoom(order=3, mode='reflect') interpolates from (separable: one pass per axis)
+	coef = m
+	if min(ny, nx) > 1:
+		coef = ndimage.spline_filter1d(ndimage.spline_filter1d(m, order=3, axis=1, mode='reflect'), order=3, axis=2, mode='reflect')
 	if min(ny, nx) > 1:
 		d_coef, d_vmin, d_vmax = ctx.array(coef), ctx.array(vmin), ctx.array(vmax)   # kept alive until the kernel has run
 		ctx._check(ctx.lib.tp_background_zoom(ctx.handle, d_coef.ptr, d_vmin.ptr, d_vmax.ptr, T, ny, nx, int(box), R, C, C, R * C, out.ptr))
