@@ -275,6 +275,19 @@ int tp_frames_sumimage(tp_ctx* ctx, int32_t n_frames, int64_t n_pixels, int64_t 
  *   n_block <= 32 frames listed in d_frame_index (per pixel, NaN result -> 0); the caller divides by the number of blocks.
  * tp_frames_threshold_flags: prepare.py:594-607: clears flag_bit in every pixel flag and sets it where
  *   |indicator - mean| > threshold (PixelQualityFlags.BackgroundShenanigans, bkgshe_threshold = 40).              */
+/* tp_frames_pixel_flags: the per-frame pixel flags of the prepare stage (prepare.py:296-297, 406-408): bit_background
+ *   (PixelQualityFlags.NotUsedForBackground) where fit_background masks the pixel (backgrounds.py:89-97: not finite, above
+ *   flux_cutoff, negative, manually excluded), bit_manual (ManualExclude) where pixel_flags.pixel_manual_exclude (:13-58) does:
+ *   columns >= d_first_excluded_column[k] (the host evaluates the header rules; NULL = no rule fires), and the whole frame when
+ *   every pixel of it is zero and zero_is_excluded (TESS data).  d_all_zero int32 [n_frames] (out): the zero test per frame.
+ *   d_pixel_flags uint8 [n_frames][rows][cols]; passed as d_exclude to tp_background_mesh / tp_radial_* it is exactly the mask.
+ * tp_frames_used_in_background: backgrounds_pixels_used (prepare.py:435, 464-466): d_used uint8 [n_pixels] = the pixel's
+ *   bit_background is clear in more than threshold of the frames.                                                    */
+int tp_frames_pixel_flags(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+	int64_t row_pitch, int64_t frame_stride, const int32_t* d_first_excluded_column, int32_t zero_is_excluded, double flux_cutoff,
+	uint32_t bit_background, uint32_t bit_manual, int32_t* d_all_zero, uint8_t* d_pixel_flags);
+int tp_frames_used_in_background(tp_ctx* ctx, const uint8_t* d_pixel_flags, int32_t n_frames, int64_t n_pixels, uint32_t bit_background,
+	double threshold, uint8_t* d_used);
 int tp_frames_median_filter(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
 	int64_t row_pitch, int64_t frame_stride, const double* d_reference, int32_t size, float* d_out);
 int tp_frames_block_median_accumulate(tp_ctx* ctx, const float* d_frames, int64_t n_pixels, int64_t frame_stride,

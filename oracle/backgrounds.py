@@ -344,6 +344,41 @@ def fit_background_tess(image, camera, ccd, flux_cutoff=8e4, exclude=None, bkgit
 #--------------------------------------------------------------------------------------------------
 # Pixel flags: "background shenanigans" (pixel_flags.py:61-79, prepare.py:515-622)
 #--------------------------------------------------------------------------------------------------
+def pixel_manual_exclude(data, is_tess=False, camera=None, ccd=None, cadenceno=None, tstart=np.nan, tstop=np.nan):
+	"""
+	pixel_flags.pixel_manual_exclude (pixel_flags.py:13-58) with the header cards as arguments (``cadenceno`` = FFIINDEX, None
+	when the card is missing): Mars in camera 1 CCD 4 (columns >= 1536), Earth-shine in camera 1 (everything), a TESS image
+	that is zero everywhere (everything).  Returns the bool mask.
+	"""
+	data = np.asarray(data)
+	mask = np.zeros(data.shape, dtype='bool')
+	if is_tess:
+		time = 0.5*(tstart + tstop)
+		cadenceno = np.inf if cadenceno is None else cadenceno
+	else:
+		time = np.nan
+		cadenceno = np.inf
+	if is_tess and camera == 1 and ccd == 4 and (cadenceno <= 4724 or tstart <= 1325.881282301840):
+		mask[:, 1536:] = True
+	elif is_tess and camera == 1 and (11354 <= cadenceno <= 11366 or 1464.0158778 <= time <= 1464.265871):
+		mask[:, :] = True
+	if is_tess and np.all(data == 0):
+		mask[:, :] = True
+	return mask
+
+
+def prepare_pixel_flags(raw, masks, manexcl):
+	"""
+	The pixel flags the prepare stage stores per frame (prepare.py:296-297, 406-408): NotUsedForBackground (1) where
+	``fit_background`` masked the pixel, ManualExclude (2) where ``pixel_manual_exclude`` did; and ``backgrounds_pixels_used``
+	(:435, :464-466): the pixel was used for the background in more than half of the frames.
+	"""
+	flags = np.where(masks, 1, 0).astype('uint8')
+	flags[manexcl] |= 2
+	used = np.sum((flags & 1) == 0, axis=0, dtype='int32')
+	return flags, (used / flags.shape[0] > 0.5)
+
+
 def pixel_background_shenanigans(img, SumImage=None):
 	"""pixel_flags.py:61-79"""
 	from scipy.ndimage import median_filter

@@ -97,6 +97,8 @@ SIGNATURES = {
 	'tp_radial_ring_modes': (c_int, [c_void_p, _p, c_int32, c_int64, c_int64, _p, c_int64, _p, c_int64, c_double, _p, _p, _p, c_int32, c_int32,
 		c_double, _p, _p, _p]),
 	'tp_radial_evaluate': (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int64, c_double, c_double, c_double, _p, _p, _p, c_int32, _p, _p, c_int64, _p]),
+	'tp_frames_pixel_flags': (c_int, [c_void_p, _p, c_int32, c_int32, c_int32, c_int64, c_int64, _p, c_int32, c_double, c_uint32, c_uint32, _p, _p]),
+	'tp_frames_used_in_background': (c_int, [c_void_p, _p, c_int32, c_int64, c_uint32, c_double, _p]),
 	'tp_frames_median_filter': (c_int, [c_void_p, _p, c_int32, c_int32, c_int32, c_int64, c_int64, _p, c_int32, _p]),
 	'tp_frames_block_median_accumulate': (c_int, [c_void_p, _p, c_int64, c_int64, _p, c_int32, _p]),
 	'tp_frames_threshold_flags': (c_int, [c_void_p, _p, _p, c_double, c_uint32, c_int64, c_int32, _p]),

@@ -255,7 +255,84 @@ __global__ __launch_bounds__(256) void tp_frames_sumimage_kernel(const float* __
 	out[p] = (cnt > 0) ? s / (double)cnt : __builtin_nan("");
 }
 
+// pixel_flags.py:54-56: is the whole frame zero?  flags[k] starts at 1 and any block that sees a non-zero (or NaN) pixel clears it
+__global__ __launch_bounds__(256) void tp_frames_all_zero_kernel(const float* __restrict__ frames, int64_t n_pix, int64_t frame_stride, int32_t* __restrict__ all_zero)
+{
+	const int frame = blockIdx.y;
+	const float* img = frames + (int64_t)frame * frame_stride;
+	bool nonzero = false;
+	for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_pix; p += (int64_t)gridDim.x * 256) nonzero |= !(img[p] == 0.f);
+	if (__any(nonzero) && (threadIdx.x & 63) == 0) all_zero[frame] = 0;
+}
+
+// prepare.py:296-297, 406-408: NotUsedForBackground where fit_background masked the pixel (backgrounds.py:89-97: not finite,
+// above the cut-off, negative, manually excluded), ManualExclude where pixel_manual_exclude did: columns >= first_excluded[k],
+// or the whole frame when it is zero everywhere and zero_is_excluded (TESS data)
+__global__ __launch_bounds__(256) void tp_frames_pixel_flags_kernel(const float* __restrict__ frames, int n_rows, int n_cols, int64_t row_pitch,
+	int64_t frame_stride, const int32_t* __restrict__ first_excluded, const int32_t* __restrict__ all_zero, int zero_is_excluded,
+	float flux_cutoff, uint8_t bit_background, uint8_t bit_manual, uint8_t* __restrict__ flags)
+{
+	const int frame = blockIdx.z, row = blockIdx.y, col = blockIdx.x * 256 + threadIdx.x;
+	if (col >= n_cols) return;
+	const float x = frames[(int64_t)frame * frame_stride + (int64_t)row * row_pitch + col];
+	int first = first_excluded ? first_excluded[frame] : n_cols;
+	if (zero_is_excluded && all_zero && all_zero[frame]) first = 0;
+	const bool manual = col >= first;
+	const bool masked = !((x >= 0.f) && (x <= flux_cutoff)) || manual;
+	flags[((int64_t)frame * n_rows + row) * n_cols + col] = (uint8_t)((masked ? bit_background : 0) | (manual ? bit_manual : 0));
+}
+
+// prepare.py:435, 464-466: used[p] = (number of frames in which bit_background is clear) / n_frames > threshold
+__global__ __launch_bounds__(256) void tp_frames_used_kernel(const uint8_t* __restrict__ flags, int n_frames, int64_t n_pix, uint8_t bit_background,
+	double threshold, uint8_t* __restrict__ used)
+{
+	const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (p >= n_pix) return;
+	int cnt = 0;
+	for (int k = 0; k < n_frames; ++k) cnt += ((flags[(int64_t)k * n_pix + p] & bit_background) == 0) ? 1 : 0;
+	used[p] = ((double)cnt / (double)n_frames > threshold) ? 1 : 0;
+}
+
 } // namespace
+
+extern "C" int tp_frames_pixel_flags(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+	int64_t row_pitch, int64_t frame_stride, const int32_t* d_first_excluded_column, int32_t zero_is_excluded, double flux_cutoff,
+	uint32_t bit_background, uint32_t bit_manual, int32_t* d_all_zero, uint8_t* d_pixel_flags)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_frames && d_all_zero && d_pixel_flags, "tp_frames_pixel_flags: null pointer");
+	TP_REQUIRE(ctx, n_frames >= 0 && n_frames <= 65535 && frame_rows > 0 && frame_rows <= 65535 && frame_cols > 0 && row_pitch >= frame_cols
+		&& frame_stride >= (int64_t)frame_rows * row_pitch, "tp_frames_pixel_flags: bad frame geometry");
+	TP_REQUIRE(ctx, bit_background < 256 && bit_manual < 256, "tp_frames_pixel_flags: the flags are uint8");
+	TP_REQUIRE(ctx, row_pitch == frame_cols, "tp_frames_pixel_flags: frames must be contiguous images");
+	if (n_frames == 0) return TP_OK;
+	std::vector<int32_t> ones((size_t)n_frames, 1);
+	TP_HIP(ctx, hipMemcpyAsync(d_all_zero, ones.data(), ones.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host vector goes out of scope
+	const int64_t n_pix = (int64_t)frame_rows * frame_cols;
+	TP_LAUNCH(ctx, TPK_BKG_SUBTRACT, tp_frames_all_zero_kernel, dim3(256, (unsigned)n_frames), dim3(256), 0, d_frames, n_pix, frame_stride, d_all_zero);
+	TP_LAUNCH(ctx, TPK_BKG_SUBTRACT, tp_frames_pixel_flags_kernel, dim3((unsigned)((frame_cols + 255) / 256), (unsigned)frame_rows, (unsigned)n_frames), dim3(256), 0,
+		d_frames, (int)frame_rows, (int)frame_cols, row_pitch, frame_stride, d_first_excluded_column, (const int32_t*)d_all_zero, (int)zero_is_excluded,
+		(float)flux_cutoff, (uint8_t)bit_background, (uint8_t)bit_manual, d_pixel_flags);
+	TP_LAUNCH_CHECK(ctx, "tp_frames_pixel_flags kernels");
+	return TP_OK;
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_frames_used_in_background(tp_ctx* ctx, const uint8_t* d_pixel_flags, int32_t n_frames, int64_t n_pixels, uint32_t bit_background,
+	double threshold, uint8_t* d_used)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_pixel_flags && d_used, "tp_frames_used_in_background: null pointer");
+	TP_REQUIRE(ctx, n_frames > 0 && n_pixels > 0 && bit_background < 256, "tp_frames_used_in_background: bad arguments");
+	TP_LAUNCH(ctx, TPK_BKG_SUBTRACT, tp_frames_used_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, d_pixel_flags, (int)n_frames, n_pixels,
+		(uint8_t)bit_background, threshold, d_used);
+	TP_LAUNCH_CHECK(ctx, "tp_frames_used_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}
 
 extern "C" int tp_background_mesh(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
 	int64_t row_pitch, int64_t frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride,

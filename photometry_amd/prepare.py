@@ -243,17 +243,76 @@ def fit_background_frames(ctx, frames, flux_cutoff=8e4, box=64, exclude=None, ou
 	return (out, mesh_h, nm_h) if return_mask else out
 
 
-def prepare_frames(ctx, raw, raw_err, quality, cadence=1800, flux_cutoff=8e4, pixel_flags=None, backapp=False, camera=None, ccd=None):
+def manual_exclude_columns(n_frames, n_cols, is_tess=False, camera=None, ccd=None, cadenceno=None, tstart=None, tstop=None):
 	"""
-	The image arithmetic of ``prepare_photometry`` for one CCD (prepare.py:265-459) on device-resident stacks ``(T, R, C)``:
-	backgrounds (B1), their smoothing over ``time_smooth`` frames (B2, :258, :317-335), ``images = raw - background`` with
-	manually excluded pixels set to NaN in image and error (B3, :419-425), the sum image over the good-quality frames
-	(A1, :450-453, :459).  Returns a dict of DeviceArrays: ``backgrounds, images, images_err`` float32 ``(T, R, C)``,
-	``sumimage`` float64 ``(R, C)``.  ``camera`` / ``ccd``: the header cards of TESS full-frame images (see ``fit_background_frames``).
+	The header rules of ``pixel_flags.pixel_manual_exclude`` (pixel_flags.py:13-52) for a stack of frames: what they exclude is
+	always a suffix of the columns, so the result is the first excluded column per frame (``n_cols`` = nothing, int32).
+	``cadenceno``: FFIINDEX per frame (None or a negative entry = card missing), ``tstart`` / ``tstop``: TSTART / TSTOP.
+	The third rule -- a TESS image that is zero everywhere (:54-56) -- needs the pixels: ``tp_frames_pixel_flags`` applies it.
+	"""
+	first = np.full(n_frames, n_cols, dtype='int32')
+	if not is_tess:
+		return first
+	tstart = np.asarray(tstart, dtype='float64')
+	time = 0.5 * (tstart + np.asarray(tstop, dtype='float64'))
+	cad = np.full(n_frames, np.inf) if cadenceno is None else np.asarray(cadenceno, dtype='float64').copy()
+	cad[cad < 0] = np.inf
+	if camera == 1 and ccd == 4:
+		# Mars floods the registers of output channel D in the beginning of Sector 1
+		mars = (cad <= 4724) | (tstart <= 1325.881282301840)
+		first[mars] = min(1536, n_cols)
+	else:
+		mars = np.zeros(n_frames, dtype=bool)
+	if camera == 1:
+		# excessive Earth-shine (an elif of the Mars rule)
+		earth = ((11354 <= cad) & (cad <= 11366)) | ((1464.0158778 <= time) & (time <= 1464.265871))
+		first[earth & ~mars] = 0
+	return first
+
+
+def pixel_flags_frames(ctx, raw, first_excluded=None, is_tess=False, flux_cutoff=8e4):
+	"""
+	The pixel flags the prepare stage stores with every frame (prepare.py:296-297: NotUsedForBackground from the mask of
+	``fit_background``; :406-408: ManualExclude).  ``raw``: float32 DeviceArray ``(T, R, C)``; ``first_excluded``: the result of
+	:func:`manual_exclude_columns` (or None).  Returns ``(flags uint8 DeviceArray (T, R, C), all_zero bool (T,))``.
+	"""
+	T, R, C = raw.shape
+	flags = ctx.empty((T, R, C), 'uint8')
+	d_zero = ctx.empty((T,), 'int32')
+	d_first = None if first_excluded is None else ctx.array(np.asarray(first_excluded, dtype='int32'))
+	ctx._check(ctx.lib.tp_frames_pixel_flags(ctx.handle, raw.ptr, T, R, C, C, R * C, None if d_first is None else d_first.ptr, 1 if is_tess else 0,
+		float(flux_cutoff), PIXEL_NOT_USED_FOR_BACKGROUND, PIXEL_MANUAL_EXCLUDE, d_zero.ptr, flags.ptr))
+	return flags, d_zero.to_host().astype(bool)
+
+
+def prepare_frames(ctx, raw, raw_err, quality, cadence=1800, flux_cutoff=8e4, pixel_flags=None, backapp=False, camera=None, ccd=None,
+	headers=None, backgrounds_pixels_threshold=0.5):
+	"""
+	The image arithmetic of ``prepare_photometry`` for one CCD (prepare.py:265-470) on device-resident stacks ``(T, R, C)``:
+	pixel flags (manual excludes and the background mask, :296-297, :406-408), backgrounds (B1), their smoothing over
+	``time_smooth`` frames (B2, :258, :317-335), ``images = raw - background`` with manually excluded pixels set to NaN in
+	image and error (B3, :419-425), the sum image over the good-quality frames (A1, :450-453, :459) and the
+	``backgrounds_pixels_used`` image (:435, :464-466).
+
+	``headers``: dict of the FFI header cards the stage reads -- ``is_tess`` (real TESS frames: ``FFIImage.is_tess``), ``CAMERA``,
+	``CCD``, and per frame ``FFIINDEX`` (optional), ``TSTART``, ``TSTOP``.  With it the pixel flags are built here; TESS frames get
+	the radial background component.  Without it ``pixel_flags`` (uint8 ``(T, R, C)``, ManualExclude / NotUsedForBackground bits
+	only, as at this point of the reference) is used as given, and ``camera`` / ``ccd`` select the TESS background branch.
+
+	Returns a dict of DeviceArrays: ``backgrounds, images, images_err`` float32 ``(T, R, C)``, ``sumimage`` float64 ``(R, C)``,
+	and, when flags exist, ``pixel_flags`` uint8 ``(T, R, C)`` and ``backgrounds_pixels_used`` uint8 ``(R, C)``.
 	"""
 	T, R, C = raw.shape
 	time_smooth = {1800: 3, 600: 9}[int(cadence)]
-	bkg_us = fit_background_frames(ctx, raw, flux_cutoff=flux_cutoff, camera=camera, ccd=ccd)   # TESS frames: with the radial component
+	if headers is not None:
+		is_tess = bool(headers.get('is_tess', False))
+		first = manual_exclude_columns(T, C, is_tess, headers.get('CAMERA'), headers.get('CCD'), headers.get('FFIINDEX'),
+			headers.get('TSTART'), headers.get('TSTOP'))
+		pixel_flags, _ = pixel_flags_frames(ctx, raw, first, is_tess, flux_cutoff)
+		if is_tess:
+			camera, ccd = headers.get('CAMERA'), headers.get('CCD')
+	# the flags are the mask of backgrounds.py:89-97 (any set bit = masked) as long as only these two bits exist
+	bkg_us = fit_background_frames(ctx, raw, flux_cutoff=flux_cutoff, exclude=pixel_flags, camera=camera, ccd=ccd)   # TESS frames: with the radial component
 	bkg = ctx.empty((T, R, C), 'float32')
 	ctx._check(ctx.lib.tp_frames_smooth_time(ctx.handle, T, R * C, R * C, time_smooth, bkg_us.ptr, bkg.ptr))
 	bkg_us.free()
@@ -267,8 +326,15 @@ def prepare_frames(ctx, raw, raw_err, quality, cadence=1800, flux_cutoff=8e4, pi
 	sumimage = ctx.empty((R, C), 'float64')
 	q = ctx.array(np.asarray(quality, dtype='int32'))
 	ctx._check(ctx.lib.tp_frames_sumimage(ctx.handle, T, R * C, R * C, images.ptr, q.ptr, int(TESS_DEFAULT_BITMASK), sumimage.ptr))
+	out = {'backgrounds': bkg, 'images': images, 'images_err': images_err, 'sumimage': sumimage}
+	if pixel_flags is not None:
+		used = ctx.empty((R, C), 'uint8')
+		ctx._check(ctx.lib.tp_frames_used_in_background(ctx.handle, pixel_flags.ptr, T, R * C, PIXEL_NOT_USED_FOR_BACKGROUND,
+			float(backgrounds_pixels_threshold), used.ptr))
+		out['pixel_flags'] = pixel_flags
+		out['backgrounds_pixels_used'] = used
 	ctx.sync()
-	return {'backgrounds': bkg, 'images': images, 'images_err': images_err, 'sumimage': sumimage}
+	return out
 
 
 def background_shenanigans(ctx, images, sumimage, pixel_flags, threshold=40.0, size=15, block=25, indicator=None):

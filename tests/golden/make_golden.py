@@ -22,6 +22,7 @@ Fixtures:
 * ``golden_psf.npz``      ``PSF.integrate_to_image`` (psf.py:122-148) on a synthetic spline
 * ``golden_linpsf.npz``   ``lsfit`` and ``LinPSFPhotometry.do_photometry``
                           (linpsf_photometry.py:22-34, 79-219)
+* ``golden_pixelflags.npz`` ``pixel_flags.pixel_manual_exclude`` (pixel_flags.py:13-58) on header / data cases
 * ``golden_psfphot.npz``  ``PSFPhotometry.do_photometry`` (psf_photometry.py:111-196): Nelder-Mead fits of (row, column, flux)
                           with the real ``scipy.optimize.minimize``, warm-started cadence by cadence
 * ``golden_cutout.npz``   ``BasePhotometry._load_cube`` FFI branch (BasePhotometry.py:720-742) on a small frame stack
@@ -626,6 +627,65 @@ def golden_background():
 	out['b3_raw'], out['b3_raw_err'], out['b3_flags'] = raw, err, flags
 	np.savez_compressed(os.path.join(HERE, 'golden_background.npz'), **out)
 
+def golden_pixelflags():
+	"""
+	``pixel_flags.pixel_manual_exclude`` (pixel_flags.py:13-58) executed on stand-in images carrying what the function reads
+	(``header``, ``is_tess``, ``data``, array conversion).  The cases are those of the reference's own tests
+	(tests/test_pixel_flags.py: Mars by FFIINDEX, all-zero image, Earth-shine by FFIINDEX) plus the time-based triggers, the
+	boundaries of every range and the non-TESS / unaffected cases.  Stored: the header values and the first excluded column
+	(the function only ever excludes nothing, the columns >= 1536, or everything -- asserted here).
+	"""
+	from photometry import pixel_flags as refpxf
+
+	class Img(object):
+		def __init__(self, shape, hdr, is_tess, zero):
+			self._d = np.zeros(shape, dtype='float32') if zero else np.ones(shape, dtype='float32')
+			self.header, self.is_tess, self.data, self.shape, self.dtype = hdr, is_tess, self._d, self._d.shape, self._d.dtype
+
+		def __array__(self, dtype=None):
+			return self._d if dtype is None else self._d.astype(dtype)
+
+	shape = (8, 2048)
+	cases = []
+
+	def add(camera, ccd, ffiindex, tstart, tstop, is_tess=True, zero=False):
+		cases.append((camera, ccd, ffiindex, tstart, tstop, is_tess, zero))
+	add(1, 4, 4724, 1330.0, 1330.02)                # Mars by cadence number (the reference's test)
+	add(1, 4, 4725, 1330.0, 1330.02)                # one cadence later: clean
+	add(1, 4, 9999, 1325.881282301840, 1325.9)      # Mars by TSTART (boundary, inclusive)
+	add(1, 4, 9999, 1325.8812824, 1325.9)           # just after
+	add(1, 3, 4000, 1325.5, 1325.52)                # other CCD: clean
+	add(2, 4, 4000, 1325.5, 1325.52)                # other camera: clean
+	add(1, 1, 11354, 1500.0, 1500.02)               # Earth-shine by cadence number (first)
+	add(1, 2, 11366, 1500.0, 1500.02)               # (last)
+	add(1, 2, 11367, 1500.0, 1500.02)               # after
+	add(1, 2, 11353, 1500.0, 1500.02)               # before
+	add(1, 3, 20000, 1464.0158778 - 0.01, 1464.0158778 + 0.01)   # Earth-shine by mid-time, at the lower boundary
+	add(1, 3, 20000, 1464.265871 - 0.01, 1464.265871 + 0.01)     # at the upper boundary
+	add(1, 3, 20000, 1464.3, 1464.32)               # after
+	add(2, 3, 11360, 1464.1, 1464.12)               # other camera: clean
+	add(1, 4, 11360, 1464.1, 1464.12)               # camera 1 CCD 4 late in the sector: the Mars branch does not fire, Earth does
+	add(3, 2, 30000, 1600.0, 1600.02, zero=True)    # whole image zero
+	add(3, 2, 30000, 1600.0, 1600.02, is_tess=False, zero=True)   # ... but not TESS data: clean
+	add(1, 4, 4000, 1325.5, 1325.52, is_tess=False) # not TESS: clean
+	add(1, 4, None, 1330.0, 1330.02)                # no FFIINDEX card: cadenceno = inf
+	out = {k: [] for k in ('camera', 'ccd', 'ffiindex', 'tstart', 'tstop', 'is_tess', 'zero', 'first_excluded_column')}
+	for camera, ccd, ffi, t0, t1, is_tess, zero in cases:
+		hdr = {'CAMERA': camera, 'CCD': ccd, 'TSTART': t0, 'TSTOP': t1}
+		if ffi is not None:
+			hdr['FFIINDEX'] = ffi
+		mask = refpxf.pixel_manual_exclude(Img(shape, hdr, is_tess, zero))
+		assert mask.shape == shape and mask.dtype == bool
+		cols = mask.all(axis=0)
+		assert np.array_equal(mask, np.broadcast_to(cols, shape)), "exclusions are whole columns"
+		first = int(np.argmax(cols)) if cols.any() else shape[1]
+		assert np.array_equal(cols, np.arange(shape[1]) >= first), "exclusions are a column suffix"
+		for k, v in zip(out.keys(), (camera, ccd, -1 if ffi is None else ffi, t0, t1, is_tess, zero, first)):
+			out[k].append(v)
+	np.savez_compressed(os.path.join(HERE, 'golden_pixelflags.npz'), **{k: np.asarray(v) for k, v in out.items()})
+	print('golden_pixelflags', len(cases), 'cases, first excluded columns', out['first_excluded_column'])
+
+
 def golden_psfphot():
 	"""The reference's own PSFPhotometry.do_photometry on two small targets (a few cadences: every cadence is a Nelder-Mead run)."""
 	from photometry.psf_photometry import PSFPhotometry
@@ -664,6 +724,6 @@ def golden_psfphot():
 
 
 if __name__ == '__main__':
-	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics', 'cutout', 'background', 'psfphot']
+	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics', 'cutout', 'background', 'psfphot', 'pixelflags']
 	for w in which:
 		globals()['golden_' + w]()

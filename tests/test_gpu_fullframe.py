@@ -82,7 +82,7 @@ def test_prepare_frames_matches_oracle(ctx):
 	bkg = out['backgrounds'].to_host()
 	# B2 / B3 / A1 from the device's own unsmoothed backgrounds would need them: recompute the chain with the oracle on the
 	# device backgrounds instead (B1 is compared above)
-	us = prepare.fit_background_frames(ctx, ctx.array(f)).to_host()
+	us = prepare.fit_background_frames(ctx, ctx.array(f), exclude=ctx.array(flags)).to_host()   # flagged pixels are masked (backgrounds.py:96-97)
 	ref_bkg = np.moveaxis(ob.smooth_time(np.moveaxis(us, 0, -1), 3), -1, 0)
 	np.testing.assert_array_equal(bkg, ref_bkg)
 	ref_img, ref_err = ob.subtract_background(f, err, bkg, flags)
@@ -214,3 +214,58 @@ def test_radial_pieces(ctx):
 	good = ~np.isnan(y)
 	ref = 10**InterpolatedUnivariateSpline(x[good], y[good], k=3, ext=3)(r) - 7.5
 	np.testing.assert_allclose(out.to_host()[0], ref, rtol=2e-7, atol=1e-5)
+
+
+def test_prepare_pixel_flags_and_headers(ctx):
+	"""
+	prepare_frames with the FFI header cards: manual excludes (pixel_flags.py:13-58: Mars columns, Earth-shine frames, an
+	all-zero frame), the background mask as NotUsedForBackground, backgrounds_pixels_used, and the masked pixels staying out
+	of the background fit -- against the oracle's restatement of the same lines (rules pinned by golden_pixelflags.npz).
+	"""
+	from photometry_amd import prepare
+	from oracle import backgrounds as ob
+	T, R, C = 6, 128, 1600
+	rng = np.random.default_rng(11)
+	f = (100 + rng.normal(0, 3, (T, R, C))).astype('float32')
+	f[0, 3:9, 10:20] = np.nan
+	f[1, 20:30, 1540:1550] = 2e5
+	f[2, 40, 50] = -1.0
+	f[:, 100:110, 200:210] = np.inf              # never usable: backgrounds_pixels_used False there
+	f[4] = 0.0                                   # whole image zero
+	err = np.ones_like(f)
+	headers = {'is_tess': True, 'CAMERA': 1, 'CCD': 4, 'FFIINDEX': [4723, 4724, 4725, 11360, 5000, 5001],
+		'TSTART': [1330.0, 1330.02, 1330.04, 1330.06, 1330.08, 1330.10], 'TSTOP': [1330.02, 1330.04, 1330.06, 1330.08, 1330.10, 1330.12]}
+	quality = np.zeros(T, dtype='int32')
+	first = prepare.manual_exclude_columns(T, C, True, 1, 4, headers['FFIINDEX'], headers['TSTART'], headers['TSTOP'])
+	assert list(first) == [1536, 1536, C, 0, C, C]
+	flags, allzero = prepare.pixel_flags_frames(ctx, ctx.array(f), first, True)
+	assert list(allzero) == [False, False, False, False, True, False]
+	manexcl = np.stack([ob.pixel_manual_exclude(f[k], True, 1, 4, headers['FFIINDEX'][k], headers['TSTART'][k], headers['TSTOP'][k]) for k in range(T)])
+	masks = np.stack([ob.stamp_mask(f[k], 8e4, manexcl[k]) for k in range(T)])
+	ref_flags, ref_used = ob.prepare_pixel_flags(f, masks, manexcl)
+	np.testing.assert_array_equal(flags.to_host(), ref_flags)
+	assert ref_flags[0, 0, 1536] == 3 and ref_flags[0, 0, 1535] == 0 and np.all(ref_flags[3] == 3) and np.all(ref_flags[4] == 3) and ref_flags[2, 40, 50] == 1
+
+	# the whole stage, flags given (plain background branch)
+	res = prepare.prepare_frames(ctx, ctx.array(f), ctx.array(err), quality, pixel_flags=flags)
+	np.testing.assert_array_equal(res['backgrounds_pixels_used'].to_host().astype(bool), ref_used)
+	assert not ref_used[105, 205] and ref_used[0, 0] and not ref_used[0, 1540]      # columns >= 1536: used in 2 of 6 frames only
+	img = res['images'].to_host()
+	assert np.all(np.isnan(img[0][:, 1536:])) and np.all(np.isnan(img[3])) and np.all(np.isnan(img[4])) and np.isfinite(img[2, 40, 51])
+	# excluded pixels did not take part in the background: frame 1's bright block sits in excluded columns, frames 3 / 4 have no background
+	us = prepare.fit_background_frames(ctx, ctx.array(f), exclude=flags).to_host()
+	assert np.all(np.isnan(us[3])) and np.all(np.isnan(us[4]))
+	for k in (0, 1, 2, 5):
+		ref_bkg, _ = ob.fit_background(f[k], exclude=manexcl[k])
+		np.testing.assert_allclose(us[k], ref_bkg, rtol=1e-6)
+
+	# ... and from the header cards (TESS branch: radial component with the excluded columns masked)
+	res_h = prepare.prepare_frames(ctx, ctx.array(f), ctx.array(err), quality, headers=headers)
+	np.testing.assert_array_equal(res_h['pixel_flags'].to_host(), ref_flags)
+	np.testing.assert_array_equal(res_h['backgrounds_pixels_used'].to_host().astype(bool), ref_used)
+	us_t = prepare.fit_background_frames(ctx, ctx.array(f), exclude=flags, camera=1, ccd=4).to_host()
+	for k in (0, 5):
+		ref_bkg, _ = ob.fit_background_tess(f[k], 1, 4, exclude=manexcl[k])
+		np.testing.assert_allclose(us_t[k], ref_bkg, rtol=2e-3)
+	smooth = np.moveaxis(ob.smooth_time(np.moveaxis(us_t, 0, -1), 3), -1, 0)
+	np.testing.assert_array_equal(res_h['backgrounds'].to_host(), smooth)

@@ -189,3 +189,26 @@ def test_psf_photometry_golden(golden_dir):
 			np.testing.assert_allclose(res['flux'], g[f'pp{n}_flux'], rtol=2e-5)
 			np.testing.assert_allclose(res['pos_centroid'], g[f'pp{n}_pos_centroid'], atol=2e-4)
 			assert np.all(np.isnan(res['flux_err']))
+
+
+def test_pixel_manual_exclude_golden(golden_dir):
+	"""pixel_flags.pixel_manual_exclude (pixel_flags.py:13-58): the oracle's restatement and the product's host rule against the
+	reference's own function on 19 header / data cases (golden_pixelflags.npz)."""
+	from oracle import backgrounds as ob
+	from photometry_amd import prepare
+	g = _load(golden_dir, 'golden_pixelflags.npz')
+	assert len(g['camera']) == 19 and set(g['first_excluded_column']) == {0, 1536, 2048}
+	for i in range(len(g['camera'])):
+		is_tess, zero = bool(g['is_tess'][i]), bool(g['zero'][i])
+		ffi = None if g['ffiindex'][i] < 0 else int(g['ffiindex'][i])
+		data = np.zeros((4, 2048), dtype='float32') if zero else np.ones((4, 2048), dtype='float32')
+		m = ob.pixel_manual_exclude(data, is_tess, int(g['camera'][i]), int(g['ccd'][i]), ffi, float(g['tstart'][i]), float(g['tstop'][i]))
+		cols = m.all(axis=0)
+		assert np.array_equal(m, np.broadcast_to(cols, m.shape))
+		first = int(np.argmax(cols)) if cols.any() else 2048
+		assert first == g['first_excluded_column'][i], i
+		rule = prepare.manual_exclude_columns(1, 2048, is_tess, int(g['camera'][i]), int(g['ccd'][i]), None if ffi is None else [ffi],
+			[float(g['tstart'][i])], [float(g['tstop'][i])])[0]
+		if zero and is_tess: # the zero-image rule is applied on the device (tp_frames_pixel_flags)
+			rule = 0
+		assert rule == g['first_excluded_column'][i], i
