@@ -28,6 +28,9 @@ DEFAULT_SETTINGS = {'todolist': {'faint_limit': '15.0'}, 'fixes': {'time_offset'
 	'haloswitch': {'tmag_limit': '6.0', 'flux_limit': '0.01'}}
 
 TESS_DEFAULT_BITMASK = engine.TESS_DEFAULT_BITMASK
+#: PixelQualityFlags.BackgroundShenanigans / CorrectorQualityFlags.BackgroundShenanigans (photometry/quality.py:163, :85)
+PIXEL_BACKGROUND_SHENANIGANS = 4
+CORRECTOR_BACKGROUND_SHENANIGANS = 256
 
 
 def load_settings(path=None):
@@ -279,6 +282,19 @@ class BasePhotometry(object):
 		return self._load()['backgrounds']
 
 	@property
+	def pixelflags_cube(self):
+		"""BasePhotometry.py:832-877: uint8 ``(rows, cols, times)``; zeros when the source carries no pixel flags (:868-870)."""
+		c = self._load()
+		if 'pixel_flags' not in c:
+			c['pixel_flags'] = np.zeros(c['images'].shape, dtype='uint8')
+		return c['pixel_flags']
+
+	@property
+	def pixelflags(self):
+		for k in range(self.Ntimes):
+			yield self.pixelflags_cube[:, :, k]
+
+	@property
 	def images(self):
 		for k in range(self.Ntimes):
 			yield self.images_cube[:, :, k]
@@ -315,6 +331,10 @@ class BasePhotometry(object):
 			ap[(557 <= cols) & (cols <= 1068)] |= 64
 			ap[(1069 <= cols) & (cols <= 1580)] |= 128
 			ap[(1581 <= cols) & (cols <= 2092)] |= 256
+			bpu = getattr(self.source, 'backgrounds_pixels_used', None)
+			if bpu is not None: # pixels used for the background calculation (:1052-1061)
+				r0, c0 = self.source.max_stamp[0], self.source.max_stamp[2]
+				ap[bpu[self._stamp[0] - r0:self._stamp[1] - r0, self._stamp[2] - c0:self._stamp[3] - c0]] |= 4
 			self._aperture = ap
 		return self._aperture
 
@@ -448,7 +468,11 @@ class BasePhotometry(object):
 		data_rel = int(getattr(self, 'data_rel', 0) or 0)
 		SumImage = np.asarray(self.sumimage, dtype='float64')
 		lc = self.lightcurve
+		# Background Shenanigans anywhere in the stamp at a timestamp -> CorrectorQualityFlags.BackgroundShenanigans (:1445-1449)
+		quality = np.zeros(len(lc['time']), dtype='int32')
+		quality[np.any(self.pixelflags_cube & PIXEL_BACKGROUND_SHENANIGANS != 0, axis=(0, 1))] |= CORRECTOR_BACKGROUND_SHENANIGANS
 		indx = np.isfinite(lc['time']) # :1451-1452
+		quality = quality[indx]
 		col = {k: np.asarray(lc[k])[indx] for k in lc.keys()}
 		tgt = self.target
 		undef = fitsio.Undefined()
@@ -499,7 +523,7 @@ class BasePhotometry(object):
 			column('FLUX_BKG', 'D', col['flux_background'], 'e-/s', 'E26.17', 'column title: photometric background flux', 'column units: electrons per second'),
 			column('FLUX_CORR', 'D', nan, 'ppm', 'E26.17', 'column title: corrected photometric flux', 'column units: rel. flux in parts-per-million'),
 			column('FLUX_CORR_ERR', 'D', nan, 'ppm', 'E26.17', 'column title: corrected photometric flux error', 'column units: parts-per-million'),
-			column('QUALITY', 'J', np.zeros(n, dtype='int32'), None, 'B16.16', 'column title: photometry quality flags'),
+			column('QUALITY', 'J', quality, None, 'B16.16', 'column title: photometry quality flags'),
 			column('PIXEL_QUALITY', 'J', col['quality'], None, 'B16.16', 'column title: pixel quality flags'),
 			column('MOM_CENTR1', 'D', col['pos_centroid'][:, 0], 'pixels', 'F10.5', 'column title: moment-derived column centroid', 'column units: pixels'),
 			column('MOM_CENTR2', 'D', col['pos_centroid'][:, 1], 'pixels', 'F10.5', 'column title: moment-derived row centroid', 'column units: pixels'),

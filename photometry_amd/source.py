@@ -32,11 +32,14 @@ class MemoryStampSource(object):
 		time, timecorr, cadenceno, quality: light-curve base arrays ``(T,)``.
 		catalog: dict of arrays ``starid, tmag, row, column`` (CCD coordinates) of ALL stars of the region.
 		jitter: optional ``(T, 2)`` per-cadence (column, row) shift used by ``catalog_attime``.
+		frames may also hold ``pixel_flags`` (uint8 ``(R, C, T)``: the ``pixel_flags/%04d`` images of the prepare stage).
+		backgrounds_pixels_used: optional bool ``(R, C)`` image of the prepare stage (BasePhotometry.py:1052-1061).
 	"""
 
 	def __init__(self, frames, row0, col0, time, timecorr, cadenceno, quality, catalog, sector=1, camera=1, ccd=1,
-		cadence=1800, n_readout=720, jitter=None, prf=None, targets=None):
-		self.frames = {k: np.asarray(v, dtype='float32') for k, v in frames.items()}
+		cadence=1800, n_readout=720, jitter=None, prf=None, targets=None, backgrounds_pixels_used=None):
+		self.frames = {k: np.asarray(v, dtype='uint8' if k == 'pixel_flags' else 'float32') for k, v in frames.items()}
+		self.backgrounds_pixels_used = None if backgrounds_pixels_used is None else np.asarray(backgrounds_pixels_used, dtype=bool)
 		R, C, T = self.frames['images'].shape
 		self.row0, self.col0 = int(row0), int(col0)
 		self.max_stamp = (self.row0, self.row0 + R, self.col0, self.col0 + C)

@@ -175,3 +175,45 @@ def test_batch_api(ctx):
 				for key in ('variance', 'rms_hour', 'variability'):
 					np.testing.assert_allclose(r._details[key], pho._details[key], rtol=1e-9, err_msg=key)
 				np.testing.assert_array_equal(r._details['pos_centroid'], pho._details['pos_centroid'])
+
+
+def test_pixel_flags_reach_the_saved_file(ctx, tmp_path):
+	"""Background Shenanigans flags inside the stamp become QUALITY bit 256 of that timestamp (BasePhotometry.py:1445-1449);
+	``backgrounds_pixels_used`` becomes bit 4 of the aperture image (:1052-1061)."""
+	from photometry_amd import fitsio
+	R = C = 41
+	T = 30
+	s = simulate.make_scene(1, T, R, C, seed=12, tmag_range=(10.0, 10.1), max_neighbours=0)
+	simulate.fill_cubes(s, nan_fraction=0.0)
+	st = s.stamps[0]
+	flags = np.zeros((R, C, T), dtype='uint8')
+	bpu = np.ones((R, C), dtype=bool)
+	cat = s.catalog_of(0)
+	frames = {'images': s.images[0], 'images_err': s.images_err[0], 'backgrounds': s.backgrounds[0], 'pixel_flags': flags}
+	src = MemoryStampSource(frames, st[0], st[2], s.time, s.timecorr, np.arange(T), s.quality,
+		{'starid': cat['starid'], 'tmag': cat['tmag'], 'row': cat['row'], 'column': cat['column']},
+		targets={'starid': s.target_starid, 'tmag': s.target_tmag, 'row': s.target_pos_row, 'column': s.target_pos_column},
+		backgrounds_pixels_used=bpu)
+	with AperturePhotometry(int(s.target_starid[0]), src, str(tmp_path), ctx=ctx) as pho:
+		r1, r2, c1, c2 = pho.stamp
+		assert (r2 - r1) < R and (c2 - c1) < C, "the default stamp must be smaller than the frame for this test"
+		# inside the stamp at cadences 3 and 17, outside it at cadence 9; other bits alone do not count
+		flags[r1 - st[0] + 2, c1 - st[2] + 3, 3] = 4
+		flags[r2 - st[0] - 1, c2 - st[2] - 1, 17] = 4 | 1
+		flags[r1 - st[0] + 1, c1 - st[2] + 1, 20] = 2 | 1
+		outside = (r1 - st[0] - 1) if r1 > st[0] else (r2 - st[0])
+		flags[outside, c1 - st[2], 9] = 4
+		bpu[r1 - st[0]:r1 - st[0] + 3, c1 - st[2]:c2 - st[2]] = False
+		src.frames['pixel_flags'] = flags
+		pho.photometry()
+		assert pho.status in (STATUS.OK, STATUS.WARNING)
+		assert pho.stamp == (r1, r2, c1, c2)
+		fname = pho.save_lightcurve()
+		ap = pho.aperture
+	hdus = fitsio.read(fname)
+	q = hdus[1][1]['QUALITY']
+	expect = np.zeros(T, dtype='int32'); expect[[3, 17]] = 256
+	np.testing.assert_array_equal(q, expect)
+	aper = hdus[3][1]
+	assert np.all(aper[:3] & 4 == 0) and np.all(aper[3:] & 4 != 0)
+	np.testing.assert_array_equal(ap & 4, aper & 4)
