@@ -25,6 +25,8 @@ static const char* const kKernelNames[TPK_COUNT] = {
 	"tp_bkg_zoom_kernel",
 	"tp_median_filter_kernel",
 	"tp_radial_kernels",
+	"tp_linpsf_plan_kernel",
+	"tp_linpsf_coef_kernel",
 	"tp_synth_kernel",
 };
 
@@ -114,6 +116,7 @@ int tp_ctx_destroy(tp_ctx* ctx) {
 	(void)tp_comm_destroy(ctx);
 	if (ctx->twiddle) (void)hipFree(ctx->twiddle);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
+	if (ctx->store) (void)hipFree(ctx->store);
 	for (int k = 0; k < TPK_COUNT; k++)
 		for (auto& p : ctx->pending[k]) {
 			(void)hipEventDestroy(p.first);

@@ -30,6 +30,8 @@ enum tp_kernel_id {
 	TPK_BKG_ZOOM,
 	TPK_MEDIAN_FILTER,
 	TPK_BKG_RADIAL,
+	TPK_LINPSF_PLAN,
+	TPK_LINPSF_COEF,
 	TPK_SYNTH,
 	TPK_COUNT
 };
@@ -49,6 +51,8 @@ struct tp_ctx {
 	void* twiddle = nullptr;    // device table of the K2P2 128-point DFT (k2p2.hip)
 	void* scratch = nullptr;    // grow-only device scratch owned by the context (linpsf.hip)
 	size_t scratch_bytes = 0;
+	void* store = nullptr;      // second grow-only buffer: the polynomial coefficient store of tp_linpsf_fit
+	size_t store_bytes = 0;
 	void* comm = nullptr;       // ncclComm_t (comm.cpp)
 	int comm_rank = 0, comm_size = 1;
 

@@ -604,6 +604,358 @@ __global__ __launch_bounds__(U > 1 ? 768 : 512) void tp_linpsf_fit_kernel(FitArg
 	} // pass
 }
 
+//--------------------------------------------------------------------------------------------------
+// The polynomial path WITHOUT the LDS-resident table: three kernels.
+//   plan  per target the boxes of its stars over ALL cadences (table origins visited, pixels that can be inside the
+//         cut-off), the number of (pixel, origin) items and their place in the coefficient store (one atomic per target);
+//   coef  the 25 biquartic coefficients of every item, contracted from the coefficient table in HBM / L2 (the same
+//         arithmetic as phase A of tp_linpsf_fit_kernel), written to the store: item = (pixel of the star's box, origin);
+//   fit   one thread per cadence in 256-thread workgroups that use NO LDS: the coefficients of a (star, pixel, origin) are
+//         the same for every cadence of a wavefront that sees that origin (all of them unless the jitter crosses a knot),
+//         so the 25 loads of a Horner evaluation are single-address vector loads served by the L1 as broadcasts -- no LDS
+//         read, no barrier, and the occupancy is set by the registers (the 110 KB table pinned one workgroup per CU).
+// Same arithmetic and accumulation order (pixels row-major) as tp_linpsf_fit_kernel: bit-identical results.
+//--------------------------------------------------------------------------------------------------
+struct StarPlan { int axmin, bymin, nby, nc, jmin, jmax, imin, imax; long long item_off; };
+
+// a * b + c with c in scalar registers: one VOP3 instruction (left alone the compiler copies a uniform addend into vector
+// registers and accumulates with v_fmac)
+__device__ __forceinline__ double fma_sgpr_addend(double a, double b, double c) {
+	double r;
+	asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+	return r;
+}
+
+__global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan* __restrict__ plans, int32_t* __restrict__ todo,
+	unsigned long long* __restrict__ total_items, int max_origins, int32_t* __restrict__ order, int sort_n)
+{
+	extern __shared__ unsigned long long skeys[];   // [sort_n] (key of the cadence's origins) * 8192 + cadence, or nothing
+	__shared__ StarBox sbox[kMaxStars];
+	__shared__ StarPlan spl[kMaxStars];
+	__shared__ int s_ok;
+	__shared__ double kn[160], kny[160];
+	const int target = blockIdx.x, tid = threadIdx.x;
+	const int n = a.n;
+	const int64_t s0 = a.star_offsets[target];
+	const int ns = (int)(a.star_offsets[target + 1] - s0);
+	int32_t* ord = order + (int64_t)target * a.n_cad;
+	if (ns > kMaxStars) return;   // the many-star kernel's targets
+	if (tid == 0) s_ok = 0;
+	for (int i = tid; i < n + 4; i += 256) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
+	if (tid < kMaxStars) {
+		sbox[tid].axmin = sbox[tid].bymin = sbox[tid].jmin = sbox[tid].imin = 0x7fffffff;
+		sbox[tid].axmax = sbox[tid].bymax = sbox[tid].jmax = sbox[tid].imax = -0x7fffffff;
+	}
+	__syncthreads();
+	const double h = kn[5] - kn[4], hy = kny[5] - kny[4];
+	const double cutoff = a.cutoff;
+	for (int s = 0; s < ns; ++s) {
+		const int big = 0x7fffffff;
+		int lo[4] = {big, big, big, big}, hi[4] = {-big, -big, -big, -big};
+		for (int k = tid; k < a.n_cad; k += 256) {
+			const double srow = a.pos_row[(s0 + s) * a.pos_pitch + k], scol = a.pos_col[(s0 + s) * a.pos_pitch + k];
+			double phx, phy; int ax0, by0;
+			const bool vx = axis_phase(kn, n, scol, h, phx, ax0);
+			const bool vy = axis_phase(kny, n, srow, hy, phy, by0);
+			if (vx && vy) {
+				const int v0[4] = {ax0, by0, (int)floor(scol - cutoff), (int)floor(srow - cutoff)};
+				const int v1[4] = {ax0, by0, (int)ceil(scol + cutoff), (int)ceil(srow + cutoff)};
+#pragma unroll
+				for (int e = 0; e < 4; ++e) { lo[e] = (v0[e] < lo[e]) ? v0[e] : lo[e]; hi[e] = (v1[e] > hi[e]) ? v1[e] : hi[e]; }
+			}
+		}
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				const int l2 = __shfl_xor(lo[e], off, 64), h2 = __shfl_xor(hi[e], off, 64);
+				lo[e] = (l2 < lo[e]) ? l2 : lo[e];
+				hi[e] = (h2 > hi[e]) ? h2 : hi[e];
+			}
+		}
+		if ((tid & 63) == 0 && hi[0] >= lo[0]) {
+			atomicMin(&sbox[s].axmin, lo[0]); atomicMax(&sbox[s].axmax, hi[0]);
+			atomicMin(&sbox[s].bymin, lo[1]); atomicMax(&sbox[s].bymax, hi[1]);
+			atomicMin(&sbox[s].jmin, lo[2]); atomicMax(&sbox[s].jmax, hi[2]);
+			atomicMin(&sbox[s].imin, lo[3]); atomicMax(&sbox[s].imax, hi[3]);
+		}
+	}
+	__syncthreads();
+	if (tid == 0) {
+		long long items = 0;
+		bool too_many = false;
+		StarPlan pl[kMaxStars];
+		for (int s = 0; s < ns; ++s) {
+			StarBox b = sbox[s];
+			StarPlan& q = pl[s];
+			q.axmin = q.bymin = 0; q.nby = 1; q.nc = 0; q.jmin = q.imin = 0; q.jmax = q.imax = -1; q.item_off = 0;
+			if (b.axmax < b.axmin) continue;   // never a valid position: an all-zero column
+			if (b.jmin < 0) b.jmin = 0;
+			if (b.jmax > a.width - 1) b.jmax = a.width - 1;
+			if (b.imin < 0) b.imin = 0;
+			if (b.imax > a.height - 1) b.imax = a.height - 1;
+			if (b.jmax < b.jmin || b.imax < b.imin) continue;   // never on the stamp
+			q.axmin = b.axmin; q.bymin = b.bymin; q.nby = b.bymax - b.bymin + 1; q.nc = (b.axmax - b.axmin + 1) * q.nby;
+			q.jmin = b.jmin; q.jmax = b.jmax; q.imin = b.imin; q.imax = b.imax;
+			if (q.nc > max_origins) too_many = true;
+			q.item_off = items;
+			items += (long long)q.nc * (b.jmax - b.jmin + 1) * (b.imax - b.imin + 1);
+		}
+		if (too_many) todo[target] = 1;   // pointing excursions over many knots: the general kernel
+		else {
+			const long long base = (long long)atomicAdd(total_items, (unsigned long long)items);
+			for (int s = 0; s < ns; ++s) { pl[s].item_off += base; plans[(int64_t)target * kMaxStars + s] = pl[s]; spl[s] = pl[s]; }
+			s_ok = 1;
+		}
+	}
+	__syncthreads();
+	if (!s_ok) return;
+	// the order in which the fit kernel walks the cadences: sorted by the origins of all stars, so that the 64 cadences of a
+	// wavefront share their polynomial coefficients (the jitter straddles a knot boundary in most targets)
+	if (sort_n <= 0) { for (int k = tid; k < a.n_cad; k += 256) ord[k] = k; return; }
+	for (int k = tid; k < sort_n; k += 256) {
+		unsigned long long key = ~0ull;
+		if (k < a.n_cad) {
+			key = 0;
+			for (int s = 0; s < ns; ++s) {
+				const StarPlan q = spl[s];
+				double phx, phy; int ax0, by0;
+				const bool vx = axis_phase(kn, n, a.pos_col[(s0 + s) * a.pos_pitch + k], h, phx, ax0);
+				const bool vy = axis_phase(kny, n, a.pos_row[(s0 + s) * a.pos_pitch + k], hy, phy, by0);
+				const int cc = (vx && vy && q.nc > 0) ? ((ax0 - q.axmin) * q.nby + (by0 - q.bymin)) : 0;
+				key = key * (unsigned long long)(max_origins + 1) + (unsigned long long)cc;
+			}
+			key = key * 8192ull + (unsigned long long)k;
+		}
+		skeys[k] = key;
+	}
+	__syncthreads();
+	for (int size = 2; size <= sort_n; size <<= 1) {
+		for (int stride = size >> 1; stride > 0; stride >>= 1) {
+			for (int t = tid; t < sort_n / 2; t += 256) {
+				const int lo = ((t / stride) * (stride << 1)) + (t % stride), hi = lo + stride;
+				const bool up = ((lo & size) == 0);
+				const unsigned long long x = skeys[lo], y = skeys[hi];
+				if ((x > y) == up) { skeys[lo] = y; skeys[hi] = x; }
+			}
+			__syncthreads();
+		}
+	}
+	for (int k = tid; k < a.n_cad; k += 256) ord[k] = (int)(skeys[k] & 8191ull);
+}
+
+__global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const StarPlan* __restrict__ plans, const int32_t* __restrict__ todo,
+	double* __restrict__ store)
+{
+	extern __shared__ __align__(16) double ctab[];   // the target's coefficient table [n*n]: every patch is read ~5 times over
+	const int target = blockIdx.x, tid = threadIdx.x;
+	if (todo[target]) return;
+	const int ns = (int)(a.star_offsets[target + 1] - a.star_offsets[target]);
+	if (ns > kMaxStars) return;
+	const int n = a.n;
+	const double h2 = (a.knots_x[5] - a.knots_x[4]) * (a.knots_y[5] - a.knots_y[4]);
+	{
+		const double* cg = a.coef + (int64_t)target * n * n;
+		for (int i0 = 0; i0 < n * n; i0 += 8 * 512) {
+			double tmp[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) { const int i = i0 + u * 512 + tid; tmp[u] = (i < n * n) ? cg[i] : 0.0; }
+#pragma unroll
+			for (int u = 0; u < 8; ++u) { const int i = i0 + u * 512 + tid; if (i < n * n) ctab[i] = tmp[u]; }
+		}
+	}
+	__syncthreads();
+	const double* C = ctab;
+	for (int s = 0; s < ns; ++s) {
+		const StarPlan p = plans[(int64_t)target * kMaxStars + s];
+		const int ncols = p.jmax - p.jmin + 1, nrows = p.imax - p.imin + 1;
+		if (p.nc <= 0 || ncols <= 0 || nrows <= 0) continue;
+		const int nitems = p.nc * ncols * nrows;
+		// one thread per item: the 13 x 13 patch of the table is read once and contracted into all 25 coefficients (the sums
+		// run in the order of tp_linpsf_fit_kernel's phase A: over q inside, over p outside)
+		for (int item = tid; item < nitems; item += 512) {
+			const int pix = item / p.nc, co = item - pix * p.nc;
+			const int ii = pix / ncols, jj = pix - ii * ncols;
+			const int cx = co / p.nby, cy = co - cx * p.nby;
+			int ax = (p.axmin + cx) + 9 * (p.jmin + jj), by = (p.bymin + cy) + 9 * (p.imin + ii);
+			ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
+			by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
+			double kk[5][5];
+#pragma unroll
+			for (int e = 0; e < 5; ++e)
+#pragma unroll
+				for (int bcol = 0; bcol < 5; ++bcol) kk[e][bcol] = 0.0;
+			const double* c0 = C + (int64_t)ax * n + by;
+#pragma unroll 1
+			for (int pp = 0; pp < 13; ++pp) {
+				const double* r = c0 + pp * n;
+				double rv[13];
+#pragma unroll
+				for (int q = 0; q < 13; ++q) rv[q] = r[q];
+				const double e0 = kEdgePoly[pp][0], e1 = kEdgePoly[pp][1], e2 = kEdgePoly[pp][2], e3 = kEdgePoly[pp][3], e4 = kEdgePoly[pp][4];
+#pragma unroll
+				for (int bcol = 0; bcol < 5; ++bcol) {
+					double t = 0.0;
+#pragma unroll
+					for (int q = 0; q < 13; ++q) t = __builtin_fma(kEdgePoly[q][bcol], rv[q], t);
+					kk[0][bcol] = __builtin_fma(e0, t, kk[0][bcol]);
+					kk[1][bcol] = __builtin_fma(e1, t, kk[1][bcol]);
+					kk[2][bcol] = __builtin_fma(e2, t, kk[2][bcol]);
+					kk[3][bcol] = __builtin_fma(e3, t, kk[3][bcol]);
+					kk[4][bcol] = __builtin_fma(e4, t, kk[4][bcol]);
+				}
+			}
+			double* dst = store + (p.item_off + item) * 25;
+#pragma unroll
+			for (int e = 0; e < 5; ++e)
+#pragma unroll
+				for (int bcol = 0; bcol < 5; ++bcol) dst[e * 5 + bcol] = h2 * kk[e][bcol];
+		}
+	}
+}
+
+template <int S, int SLO>
+__global__ __launch_bounds__(256) void tp_linpsf_fit2_kernel(FitArgs a, const StarPlan* __restrict__ plans, const int32_t* __restrict__ todo,
+	const double* __restrict__ store, const int32_t* __restrict__ order)
+{
+	const int target = blockIdx.x;
+	const int64_t s0 = a.star_offsets[target];
+	int ns = (int)(a.star_offsets[target + 1] - s0);
+	if (ns < SLO || ns > S) return;   // another instantiation's targets
+	if (todo[target]) return;         // the general kernel's
+	const int tid = threadIdx.x;
+	const int slot = blockIdx.y * blockDim.x + tid;   // position in the origin-sorted order of the target's cadences
+	const bool active = slot < a.n_cad;
+	const int kreal = order[(int64_t)target * a.n_cad + (active ? slot : (a.n_cad - 1))];
+	const int k = kreal;
+	const int n = a.n;
+	const int H = a.height, W = a.width;
+	const double h = a.knots_x[5] - a.knots_x[4], hy = a.knots_y[5] - a.knots_y[4];
+	const double cutoff = a.cutoff, c2 = cutoff * cutoff;
+
+	double phx[S], phy[S], srow[S], scol[S];
+	int cc[S];
+	bool valid[S];
+	int ncs[S], ncols[S], jmin[S], jmax[S], imin[S], imax[S];
+	long long ioff[S];
+	int ui0 = H, ui1 = -1, uj0 = W, uj1 = -1;
+#pragma unroll
+	for (int s = 0; s < S; ++s) {
+		valid[s] = false; phx[s] = phy[s] = 0.0; srow[s] = scol[s] = 0.0; cc[s] = 0;
+		ncs[s] = 0; ncols[s] = 0; jmin[s] = imin[s] = 0; jmax[s] = imax[s] = -1; ioff[s] = 0;
+		if (s < ns) {
+			const StarPlan p = plans[(int64_t)target * kMaxStars + s];
+			ncs[s] = p.nc; ncols[s] = p.jmax - p.jmin + 1; jmin[s] = p.jmin; jmax[s] = p.jmax; imin[s] = p.imin; imax[s] = p.imax; ioff[s] = p.item_off;
+			srow[s] = a.pos_row[(s0 + s) * a.pos_pitch + k];
+			scol[s] = a.pos_col[(s0 + s) * a.pos_pitch + k];
+			int ax0, by0;
+			// x <-> column (first spline axis), y <-> row  (psf.py:146)
+			const bool vx = axis_phase(a.knots_x, n, scol[s], h, phx[s], ax0);
+			const bool vy = axis_phase(a.knots_y, n, srow[s], hy, phy[s], by0);
+			valid[s] = vx && vy && (p.nc > 0);
+			cc[s] = valid[s] ? ((ax0 - p.axmin) * p.nby + (by0 - p.bymin)) : 0;
+			if (p.nc > 0 && p.jmax >= p.jmin && p.imax >= p.imin) {
+				ui0 = (p.imin < ui0) ? p.imin : ui0; ui1 = (p.imax > ui1) ? p.imax : ui1;
+				uj0 = (p.jmin < uj0) ? p.jmin : uj0; uj1 = (p.jmax > uj1) ? p.jmax : uj1;
+			}
+		}
+	}
+	double G[S][S], g[S];
+#pragma unroll
+	for (int s = 0; s < S; ++s) { g[s] = 0.0;
+#pragma unroll
+		for (int t = 0; t < S; ++t) G[s][t] = 0.0; }
+	const float* img = a.images + (int64_t)target * H * W * a.t_pitch + k;
+	const float sub = a.subtract ? a.subtract[(int64_t)target * a.subtract_pitch + k] : 0.f;
+
+	for (int i = ui0; i <= ui1; ++i) {
+		// the columns some star can reach in this row; the other pixels have an all-zero design row
+		int jfirst = W, jend = 0;
+#pragma unroll
+		for (int s = 0; s < S; ++s)
+			if (i >= imin[s] && i <= imax[s] && jmax[s] >= jmin[s]) { jfirst = (jmin[s] < jfirst) ? jmin[s] : jfirst; jend = (jmax[s] + 1 > jend) ? (jmax[s] + 1) : jend; }
+		if (jend <= jfirst) continue;
+		double dr2[S];
+#pragma unroll
+		for (int s = 0; s < S; ++s) { const double dr = (double)i - srow[s]; dr2[s] = dr * dr; }
+		auto pix_load = [&](int j) { j = (j < jend) ? j : (jend - 1); return img[((int64_t)(i * W) + j) * a.t_pitch]; };
+		float pnext = pix_load(jfirst);
+#pragma unroll 1
+		for (int j = jfirst; j < jend; ++j) {
+			{
+				const float pv = pnext;
+				pnext = pix_load(j + 1);
+				float bf = pv;
+				if (a.subtract) bf = bf - sub;
+				const bool fin = active && (fabsf(bf) <= 3.402823466e+38f);   // good_pixels = isfinite(img) (linpsf_photometry.py:123)
+				const double b = (double)bf;
+				double av[S];
+#pragma unroll
+				for (int s = 0; s < S; ++s) {
+					av[s] = 0.0;
+					if (s < ns && i >= imin[s] && i <= imax[s] && j >= jmin[s] && j <= jmax[s]) {   // uniform
+						const double dc = (double)j - scol[s];
+						// psf.py:142  sqrt((j-col)^2 + (i-row)^2) < cutoff_radius; the squares decide unless they are within
+						// rounding of each other (then, for the whole wavefront, the reference's own expression does)
+						const double d2 = dc * dc + dr2[s];
+						bool inside = d2 < c2;
+						if (__any(fabs(d2 - c2) <= 1e-9 * c2)) inside = (fabs(d2 - c2) > 1e-9 * c2) ? (d2 < c2) : (sqrt(d2) < cutoff);
+						const bool want = fin && valid[s] && inside;
+						const long long ibase = ioff[s] + (long long)((i - imin[s]) * ncols[s] + (j - jmin[s])) * ncs[s];
+						unsigned long long mask = __ballot(want);
+						while (mask) {
+							const int leader = __builtin_ctzll(mask);
+							const int ccu = __builtin_amdgcn_readlane(cc[s], leader);
+							const bool mine = want && (cc[s] == ccu);
+							// wave-uniform address: scalar loads; the coefficients are the SGPR addends of the Horner FMAs
+							const double* __restrict__ kp = store + (ibase + ccu) * 25;
+							double kc[25];
+#pragma unroll
+							for (int q = 0; q < 25; ++q) kc[q] = kp[q];
+							double val = 0.0;
+#pragma unroll
+							for (int e = 4; e >= 0; --e) {
+								double inner = kc[e * 5 + 4];
+#pragma unroll
+								for (int d = 3; d >= 0; --d) inner = fma_sgpr_addend(inner, phy[s], kc[e * 5 + d]);
+								val = __builtin_fma(val, phx[s], inner);
+							}
+							if (mine) av[s] = val;
+							mask &= ~__ballot(mine);
+						}
+					}
+				}
+				if (fin) {
+#pragma unroll
+					for (int s = 0; s < S; ++s) {
+						g[s] += av[s] * b;
+#pragma unroll
+						for (int t = 0; t < S; ++t) if (t >= s) G[s][t] += av[s] * av[t];
+					}
+				}
+			}
+		}
+	}
+	if (!active) return;
+#pragma unroll
+	for (int s = 0; s < S; ++s)
+#pragma unroll
+		for (int t = 0; t < S; ++t) if (t < s) G[s][t] = G[t][s];
+	double x[S];
+	pinv_solve<S>(G, g, ns, x);
+	const int ti = a.target_index[target];
+	double tf = __builtin_nan("");
+#pragma unroll
+	for (int s = 0; s < S; ++s) {
+		if (s < ns) {
+			a.fluxes_all[(s0 + s) * a.out_pitch + kreal] = x[s];
+			if (s == ti) tf = x[s];
+		}
+	}
+	a.flux[(int64_t)target * a.out_pitch + kreal] = tf;
+	a.flux_err[(int64_t)target * a.out_pitch + kreal] = __builtin_nan("");
+}
+
 // Finalise (linpsf_photometry.py:197-219): mean fitted fluxes over the cadences with a valid target
 // flux, contamination from the design matrix of the LAST cadence, status.
 struct FinArgs {
@@ -991,25 +1343,45 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	dim3 grid((unsigned)desc->n_targets, (unsigned)nblk), block((unsigned)threads);
 	const size_t shmem_fin = (2 * ((size_t)n_coef_axis + 4) + 256) * sizeof(double);
 	FinArgs fa; fa.f = a; fa.contamination = d_contamination; fa.status = d_status; fa.fluxes_mean = d_fluxes_mean;
-	// fast path: whatever LDS the table leaves holds the K buffer (25 doubles per item); (target, block) pairs whose
-	// stars visit more table origins than fit are flagged and redone by the general kernel
-	const size_t tail = kMaxStars * sizeof(StarBox) + 64;
-	int kcap = (int)(((size_t)160 * 1024 - shmem - tail) / (25 * sizeof(double)));
-	if (kcap > 1024) kcap = 1024;
-	TP_REQUIRE(ctx, kcap >= 16, "tp_linpsf_fit: coefficient table leaves no LDS for the polynomial buffer");
-	const size_t shmem_fast = shmem + (size_t)kcap * 25 * sizeof(double) + tail;
-	const size_t todo_bytes = (size_t)desc->n_targets * sizeof(int32_t);
-	// fast kernel: U cadences per thread (2 for the classes up to 4 stars: one pass over 1 300 cadences with 11
-	// wavefronts), up to 768 / 512 threads, the passes balanced
-	auto fast_block = [&](int slots) { const int per = (slots > 1 ? 768 : 512) * slots; const int np = (desc->n_cad + per - 1) / per;
-		return dim3((unsigned)((((desc->n_cad + np * slots - 1) / (np * slots)) + 63) / 64 * 64)); };
-	TP_REQUIRE(ctx, tp_ctx_scratch(ctx, todo_bytes) != nullptr, "tp_linpsf_fit: out of device memory for the class flags");
+	// polynomial path: plan (boxes, item counts) -> coefficient store -> fit; targets whose stars visit more table origins than
+	// max_origins are flagged and redone by the general kernel
+	const int max_origins = 36;
+	const size_t todo_bytes = ((size_t)desc->n_targets * sizeof(int32_t) + 255) & ~(size_t)255;
+	const size_t plan_bytes = ((size_t)desc->n_targets * kMaxStars * sizeof(StarPlan) + 255) & ~(size_t)255;
+	const size_t order_bytes = ((size_t)desc->n_targets * desc->n_cad * sizeof(int32_t) + 255) & ~(size_t)255;
+	TP_REQUIRE(ctx, tp_ctx_scratch(ctx, todo_bytes + plan_bytes + 256 + order_bytes) != nullptr, "tp_linpsf_fit: out of device memory for the plan");
 	int32_t* d_todo = static_cast<int32_t*>(ctx->scratch);
+	StarPlan* d_plans = reinterpret_cast<StarPlan*>(static_cast<char*>(ctx->scratch) + todo_bytes);
+	unsigned long long* d_total = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->scratch) + todo_bytes + plan_bytes);
+	int32_t* d_order = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->scratch) + todo_bytes + plan_bytes + 256);
+	// cadences sorted by origin in LDS (8 bytes per slot, next power of two); beyond 8192 cadences the order stays natural
+	int sort_n = 64;
+	while (sort_n < desc->n_cad) sort_n <<= 1;
+	if (sort_n > 8192) sort_n = 0;
 	TP_HIP(ctx, hipMemsetAsync(d_todo, 0, todo_bytes, ctx->stream));
+	TP_HIP(ctx, hipMemsetAsync(d_total, 0, sizeof(unsigned long long), ctx->stream));
+	if (sort_n > 4096) TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sort_n * sizeof(unsigned long long))));
+	TP_LAUNCH(ctx, TPK_LINPSF_PLAN, tp_linpsf_plan_kernel, dim3((unsigned)desc->n_targets), dim3(256), (size_t)sort_n * sizeof(unsigned long long), a, d_plans, d_todo, d_total, max_origins, d_order, sort_n);
+	TP_LAUNCH_CHECK(ctx, "tp_linpsf_plan_kernel");
+	unsigned long long total_items = 0;
+	TP_HIP(ctx, hipMemcpyAsync(&total_items, d_total, sizeof(total_items), hipMemcpyDeviceToHost, ctx->stream));
+	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const size_t store_need = ((size_t)total_items * 25 + 32) * sizeof(double);
+	if (ctx->store_bytes < store_need) {
+		if (ctx->store) (void)hipFree(ctx->store);
+		ctx->store = nullptr; ctx->store_bytes = 0;
+		TP_HIP(ctx, hipMalloc(&ctx->store, store_need));
+		ctx->store_bytes = store_need;
+	}
+	double* d_store = static_cast<double*>(ctx->store);
+	TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_coef_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)n_coef_axis * n_coef_axis * sizeof(double))));
+	TP_LAUNCH(ctx, TPK_LINPSF_COEF, tp_linpsf_coef_kernel, dim3((unsigned)desc->n_targets), dim3(512), (size_t)n_coef_axis * n_coef_axis * sizeof(double), a, (const StarPlan*)d_plans, (const int32_t*)d_todo, d_store);
+	TP_LAUNCH_CHECK(ctx, "tp_linpsf_coef_kernel");
+	const int nblk2 = (desc->n_cad + 255) / 256;
+	const int threads2 = (((desc->n_cad + nblk2 - 1) / nblk2) + 63) / 64 * 64;
 #define TP_LINPSF_LAUNCH(SS, SL) do { \
-		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_kernel<SS, SL, (SS <= 4 ? 2 : 1)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_fast)); \
-		TP_LAUNCH(ctx, TPK_LINPSF_FIT, (tp_linpsf_fit_kernel<SS, SL, (SS <= 4 ? 2 : 1)>), dim3((unsigned)desc->n_targets), fast_block(SS <= 4 ? 2 : 1), shmem_fast, a, kcap, d_todo); \
-		TP_LAUNCH_CHECK(ctx, "tp_linpsf_fit_kernel"); \
+		TP_LAUNCH(ctx, TPK_LINPSF_FIT, (tp_linpsf_fit2_kernel<SS, SL>), dim3((unsigned)desc->n_targets, (unsigned)nblk2), dim3((unsigned)threads2), 0, a, (const StarPlan*)d_plans, (const int32_t*)d_todo, (const double*)d_store, (const int32_t*)d_order); \
+		TP_LAUNCH_CHECK(ctx, "tp_linpsf_fit2_kernel"); \
 		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_direct_kernel<SS, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
 		TP_LAUNCH(ctx, TPK_LINPSF_FIT_DIRECT, (tp_linpsf_fit_direct_kernel<SS, SL>), grid, block, shmem, a, (const int32_t*)d_todo); \
 		TP_LAUNCH_CHECK(ctx, "tp_linpsf_fit_direct_kernel"); \
@@ -1038,11 +1410,12 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 			const int threads = 256, nblk_m = (desc->n_cad + threads - 1) / threads;
 			const size_t per_thread = (size_t)(2 * smax * smax + 15 * smax) * sizeof(double);
 			const size_t list_bytes = (big.size() * sizeof(int32_t) + 255) & ~(size_t)255;
-			const size_t need = todo_bytes + list_bytes + per_thread * big.size() * nblk_m * threads + 256;
+			const size_t head = todo_bytes + plan_bytes + 256 + order_bytes;
+			const size_t need = head + list_bytes + per_thread * big.size() * nblk_m * threads + 256;
 			// the scratch also holds d_todo at its start: grow it BEFORE the class kernels' flags could be lost -- they are done
 			TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 			TP_REQUIRE(ctx, tp_ctx_scratch(ctx, need) != nullptr, "tp_linpsf_fit: out of device memory for the many-star scratch");
-			char* base = static_cast<char*>(ctx->scratch) + ((todo_bytes + 255) & ~(size_t)255);
+			char* base = static_cast<char*>(ctx->scratch) + head;
 			int32_t* d_big = reinterpret_cast<int32_t*>(base);
 			double* d_scr = reinterpret_cast<double*>(base + list_bytes);
 			TP_HIP(ctx, hipMemcpyAsync(d_big, big.data(), big.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
