@@ -11,23 +11,23 @@
 // register-stationary AXPY: each thread keeps one coefficient of all samples in VGPRs and streams
 // over the targets, so the base tables are read once and only the per-target table is written.
 //
-// P2..P4 (tp_linpsf_fit).  One THREAD per cadence of a target, the target's 117x117 float64
-// coefficient table (110 KB) resident in LDS for the whole workgroup.  The FITPACK box integral of
+// P2..P4 (tp_linpsf_fit).  One THREAD per cadence of a target.  The FITPACK box integral of
 // the bicubic spline over a pixel is separable (psf.py:146 -> dblint/fpintb):
 //     integral = sum_ab wx[a] C[a][b] wy[b],  w = integrals of the B-spline basis over the pixel edge.
 // The PRF grid is uniform (9 samples per pixel) and a pixel is exactly 9 knot intervals wide, so
 // for a pixel whose lower edge sits at fraction phi of knot interval l the 13 non-zero weights are
 //     [1-M(phi+3), 1-M(phi+2), 1-M(phi+1), 1-M(phi), 1, 1, 1, 1, 1, M(phi+3), M(phi+2), M(phi+1), M(phi)] * h
 // with M the cumulative cardinal cubic B-spline: 4 numbers per axis per star, the same for every pixel
-// of the stamp (pixels are whole multiples of 9 knots apart).  All 64 lanes of a wavefront work on the
-// same star and pixel of 64 consecutive cadences, so the 169 table reads per pixel are LDS *broadcast*
-// reads (one address, +-1 knot between lanes): one ds_read_b64 feeds 64 float64 FMAs.
+// of the stamp (pixels are whole multiples of 9 knots apart).  The general kernel evaluates that 13 x 13 contraction
+// per star, pixel and cadence from the table in LDS; the polynomial path (below) turns it into a biquartic in the
+// two phases whose 25 coefficients are shared by all cadences with the same knot intervals.
 // The normal equations (A^T A, A^T b) are accumulated on the fly; x = pinv(A^T A) A^T b via a cyclic
 // Jacobi eigen-decomposition with numpy's pinv cutoff (rcond = 1e-15 * largest singular value).
 //
-// Roofline: FP64 vector FMA (about 13.5 k FMA per star-cadence inside the 5-pixel cut-off), not HBM:
-// the image cube is read once (P*T*4 bytes per target).  MFMA is not used: the design matrix product is
-// banded (13 of 117), the dense GEMM form would do 13x the flops.
+// Roofline: FP64 vector FMA, not HBM: the image cube is read once (P*T*4 bytes per target).  MFMA is not used: on the
+// MI355X the FP64 matrix rate equals the FP64 vector rate (78.6 TFLOP/s both), the monomial-basis GEMM form of the
+// polynomial ([cadences x 25] x [25 x pixels]) would also compute the pixels outside the cut-off circle, and the dense
+// form of the direct contraction does 13x the flops of the banded one.
 #include "common.h"
 #include "linpsf_dev.h"
 #include <cmath>
@@ -155,7 +155,7 @@ __device__ __forceinline__ void pinv_solve(double (&G)[S][S], const double (&g)[
 }
 
 // General path: direct evaluation of the 13x13 contraction per star, pixel and cadence.  Runs only for the
-// targets that tp_linpsf_fit_kernel could not take (`todo` flag set, or todo == nullptr).
+// targets that the polynomial path could not take (`todo` flag set, or todo == nullptr).
 template <int S, int SLO>
 __global__ __launch_bounds__(512) void tp_linpsf_fit_direct_kernel(FitArgs a, const int32_t* __restrict__ todo)
 {
@@ -260,17 +260,16 @@ __global__ __launch_bounds__(512) void tp_linpsf_fit_direct_kernel(FitArgs a, co
 }
 
 //--------------------------------------------------------------------------------------------------
-// Fast path.  For a fixed table origin (ax0, by0) -- i.e. fixed knot intervals of the star's sub-pixel phase --
+// Polynomial path.  For a fixed table origin (ax0, by0) -- i.e. fixed knot intervals of the star's sub-pixel phase --
 // the pixel-integrated PRF of a pixel is a BIQUARTIC polynomial of the two phases (phi_x, phi_y): the 13 edge
-// weights of an axis are the quartics below.  So per workgroup (one target, <= 512 cadences) the kernel
-//   A. finds, per fitted star, the rectangle of origins (ax0, by0) its cadences visit (jitter spans a few knot
-//      intervals) and, stamp row by stamp row, contracts the LDS-resident coefficient table into the 25
-//      polynomial coefficients K[a][b] of every (star, origin, pixel) of the row (separable: 13x13 + 5x13 FMAs
-//      per column b, one thread per (item, b));
-//   B. lets every thread (= cadence) evaluate its stars' PRF values of the row by Horner (24 FMAs and 25 LDS reads
-//      per star and pixel instead of 169 LDS reads and ~230 flops) and accumulate the normal equations.
-// The arithmetic differs from the direct contraction only by rounding (1e-15 relative).  A workgroup whose stars
-// visit more origins than the LDS buffer holds flags its target for the general kernel.
+// weights of an axis are the quartics below.  So
+//   A. per fitted star the rectangle of origins (ax0, by0) its cadences visit is found (jitter spans a few knot intervals)
+//      and the coefficient table is contracted into the 25 polynomial coefficients K[a][b] of every (star, origin, pixel)
+//      item (separable: 13x13 + 5x13 FMAs per column b);
+//   B. every cadence evaluates its stars' PRF values by Horner (24 FMAs per star and pixel instead of 169 table reads and
+//      ~230 flops) and accumulates the normal equations.
+// The arithmetic differs from the direct contraction only by rounding (1e-15 relative).  A target whose stars visit more
+// origins than max_origins (pointing excursions) is flagged for the general kernel.
 //--------------------------------------------------------------------------------------------------
 // coefficients (powers 0..4 of phi) of the 13 pixel-edge weights [1-m3, 1-m2, 1-m1, 1-m0, 1,1,1,1,1, m3, m2, m1, m0]
 __constant__ double kEdgePoly[13][5] = {
@@ -304,317 +303,26 @@ __device__ __forceinline__ bool axis_phase(const double* kn, int n, double pos, 
 
 struct StarBox { int axmin, axmax, bymin, bymax, jmin, jmax, imin, imax; };
 
-// one cadence of the target held by a thread (a thread holds U of them: see the kernel)
-template <int S>
-struct CadSlot {
-	double phx[S], phy[S], srow[S], scol[S], dr2[S];
-	double G[S][S], g[S];
-	int ax0[S], by0[S], cc[S];
-	bool valid[S];
-	int k; bool active; float sub; const float* img;
-	float ring[4]; // the next pixels of the current stamp row
-};
-
-// U cadences per thread ("slots", cadences tid, tid + blockDim, ...): the polynomial coefficients of a stamp row are
-// built once for all of them (one pass instead of U over the same table), the U Horner / normal-equation chains of a
-// pixel are independent instruction streams for the scheduler, and the barriers are shared.
-template <int S, int SLO, int U>
-__global__ __launch_bounds__(U > 1 ? 768 : 512) void tp_linpsf_fit_kernel(FitArgs a, int kcap, int32_t* __restrict__ todo)
-{
-	{ const int nst = (int)(a.star_offsets[blockIdx.x + 1] - a.star_offsets[blockIdx.x]); if (nst < SLO || nst > S) return; } // another instantiation's targets
-	extern __shared__ __align__(16) double lds[]; // table [n*n], knots 2 x [n+4], K buffer [kcap*25], then ints
-	const int target = blockIdx.x;
-	const int tid = threadIdx.x;
-	const int nthreads = blockDim.x;
-	const int n = a.n;
-	double* C = lds;
-	double* kn = lds + (size_t)n * n;
-	double* kny = kn + n + 4;
-	double* Kbuf = kny + n + 4;
-	StarBox* sbox = reinterpret_cast<StarBox*>(Kbuf + (size_t)kcap * 25);
-	int* s_flag = reinterpret_cast<int*>(sbox + kMaxStars); // [0] general-kernel flag, [1] chunk width
-	const double* cg = a.coef + (int64_t)target * n * n;
-	for (int i0 = 0; i0 < n * n; i0 += 8 * nthreads) {
-		double tmp[8];
-#pragma unroll
-		for (int u = 0; u < 8; ++u) { const int i = i0 + u * nthreads + tid; tmp[u] = (i < n * n) ? cg[i] : 0.0; }
-#pragma unroll
-		for (int u = 0; u < 8; ++u) { const int i = i0 + u * nthreads + tid; if (i < n * n) C[i] = tmp[u]; }
-	}
-	for (int i = tid; i < n + 4; i += nthreads) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
-	// the table is loaded once; the workgroup then walks the cadences in passes of U * blockDim.x
-	const int per_pass = nthreads * U;
-	const int npass = (a.n_cad + per_pass - 1) / per_pass;
-	const int64_t s0 = a.star_offsets[target];
-	int ns = (int)(a.star_offsets[target + 1] - s0);
-	if (ns > S) ns = S; // host guarantees ns <= S for this instantiation
-	const int H = a.height, W = a.width;
-	for (int pass = 0; pass < npass; ++pass) {
-	__syncthreads(); // table / knots visible; previous pass done with the star boxes and the K buffer
-	if (tid < kMaxStars) {
-		sbox[tid].axmin = sbox[tid].bymin = sbox[tid].jmin = sbox[tid].imin = 0x7fffffff;
-		sbox[tid].axmax = sbox[tid].bymax = sbox[tid].jmax = sbox[tid].imax = -0x7fffffff;
-	}
-	if (tid == 0) *s_flag = 0;
-	__syncthreads();
-
-	const double h = kn[5] - kn[4], hy = kny[5] - kny[4];
-	const double cutoff = a.cutoff;
-	CadSlot<S> c[U];
-#pragma unroll
-	for (int u = 0; u < U; ++u) {
-		c[u].k = pass * per_pass + u * nthreads + tid;
-		c[u].active = c[u].k < a.n_cad;
-#pragma unroll
-		for (int s = 0; s < S; ++s) {
-			c[u].valid[s] = false; c[u].phx[s] = c[u].phy[s] = 0.0; c[u].srow[s] = c[u].scol[s] = 0.0; c[u].ax0[s] = c[u].by0[s] = 4;
-			if (s < ns && c[u].active) {
-				c[u].srow[s] = a.pos_row[(s0 + s) * a.pos_pitch + c[u].k];
-				c[u].scol[s] = a.pos_col[(s0 + s) * a.pos_pitch + c[u].k];
-				// x <-> column (first spline axis), y <-> row  (psf.py:146)
-				const bool vx = axis_phase(kn, n, c[u].scol[s], h, c[u].phx[s], c[u].ax0[s]);
-				const bool vy = axis_phase(kny, n, c[u].srow[s], hy, c[u].phy[s], c[u].by0[s]);
-				c[u].valid[s] = vx && vy;
-			}
-		}
-	}
-	// box of every star over the workgroup's cadences: the thread's slots, a shuffle tree inside the wavefront, then ONE
-	// LDS atomic per wavefront and bound (64 lanes hitting the same LDS word serialise)
-#pragma unroll
-	for (int s = 0; s < S; ++s) {
-		if (s < ns) {
-			const int big = 0x7fffffff;
-			int lo[4] = {big, big, big, big}, hi[4] = {-big, -big, -big, -big};
-#pragma unroll
-			for (int u = 0; u < U; ++u) {
-				if (c[u].valid[s]) {
-					const int v0[4] = {c[u].ax0[s], c[u].by0[s], (int)floor(c[u].scol[s] - cutoff), (int)floor(c[u].srow[s] - cutoff)};
-					const int v1[4] = {c[u].ax0[s], c[u].by0[s], (int)ceil(c[u].scol[s] + cutoff), (int)ceil(c[u].srow[s] + cutoff)};
-#pragma unroll
-					for (int e = 0; e < 4; ++e) { lo[e] = (v0[e] < lo[e]) ? v0[e] : lo[e]; hi[e] = (v1[e] > hi[e]) ? v1[e] : hi[e]; }
-				}
-			}
-#pragma unroll
-			for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-				for (int e = 0; e < 4; ++e) {
-					const int l2 = __shfl_xor(lo[e], off, 64), h2 = __shfl_xor(hi[e], off, 64);
-					lo[e] = (l2 < lo[e]) ? l2 : lo[e];
-					hi[e] = (h2 > hi[e]) ? h2 : hi[e];
-				}
-			}
-			if ((tid & 63) == 0 && hi[0] >= lo[0]) {
-				atomicMin(&sbox[s].axmin, lo[0]); atomicMax(&sbox[s].axmax, hi[0]);
-				atomicMin(&sbox[s].bymin, lo[1]); atomicMax(&sbox[s].bymax, hi[1]);
-				// pixels that can be inside the cut-off of some cadence (strict test below): a conservative box
-				atomicMin(&sbox[s].jmin, lo[2]); atomicMax(&sbox[s].jmax, hi[2]);
-				atomicMin(&sbox[s].imin, lo[3]); atomicMax(&sbox[s].imax, hi[3]);
-			}
-		}
-	}
-	__syncthreads();
-	if (tid == 0) {
-		int tot = 0;
-		for (int s = 0; s < kMaxStars; ++s) {
-			StarBox& b = sbox[s];
-			if (s >= ns || b.axmax < b.axmin) { b.axmax = b.axmin - 1; b.bymax = b.bymin - 1; b.jmax = b.jmin - 1; b.imax = b.imin - 1; continue; }
-			if (b.jmin < 0) b.jmin = 0;
-			if (b.jmax > W - 1) b.jmax = W - 1;
-			if (b.imin < 0) b.imin = 0;
-			if (b.imax > H - 1) b.imax = H - 1;
-			tot += (b.axmax - b.axmin + 1) * (b.bymax - b.bymin + 1);
-		}
-		if (tot > kcap) *s_flag = 1; // even one stamp column of K does not fit: general kernel
-		// widest column chunk whose items fit the buffer whatever the row (uniform for the whole workgroup)
-		int wc = W;
-		for (; wc > 1; --wc) {
-			int items = 0;
-			for (int s = 0; s < kMaxStars; ++s) {
-				const StarBox& b = sbox[s];
-				const int ncols = b.jmax - b.jmin + 1;
-				items += (b.axmax - b.axmin + 1) * (b.bymax - b.bymin + 1) * (ncols < wc ? ncols : wc);
-			}
-			if (items <= kcap) break;
-		}
-		s_flag[1] = wc;
-	}
-	__syncthreads();
-	if (*s_flag) { // the general kernel redoes the whole target
-		if (tid == 0) todo[target] = 1;
-		return;
-	}
-	// per star: number of origins; per slot: the cadence's origin index, normal equations, image pointer
-	int nc[S], nby[S];
-	int bjmin[S], bjmax[S], bimin[S], bimax[S], baxmin[S], bbymin[S];
-#pragma unroll
-	for (int s = 0; s < S; ++s) {
-		const StarBox b = sbox[s];
-		nby[s] = b.bymax - b.bymin + 1;
-		nc[s] = (b.axmax - b.axmin + 1) * nby[s];
-		bjmin[s] = b.jmin; bjmax[s] = b.jmax; bimin[s] = b.imin; bimax[s] = b.imax; baxmin[s] = b.axmin; bbymin[s] = b.bymin;
-	}
-#pragma unroll
-	for (int u = 0; u < U; ++u) {
-#pragma unroll
-		for (int s = 0; s < S; ++s) {
-			c[u].cc[s] = c[u].valid[s] ? ((c[u].ax0[s] - baxmin[s]) * nby[s] + (c[u].by0[s] - bbymin[s])) : 0;
-			c[u].g[s] = 0.0;
-#pragma unroll
-			for (int j = 0; j < S; ++j) c[u].G[s][j] = 0.0;
-		}
-		c[u].img = a.images + (int64_t)target * H * W * a.t_pitch + (c[u].active ? c[u].k : 0);
-		c[u].sub = (a.subtract && c[u].active) ? a.subtract[(int64_t)target * a.subtract_pitch + c[u].k] : 0.f;
-	}
-	const double h2 = h * hy;
-	const int wc = s_flag[1];
-	for (int i = 0; i < H; ++i) {
-		for (int j0 = 0; j0 < W; j0 += wc) {
-			// ---- plan of the chunk = columns [j0, j1) of row i, computed identically by every thread (no serial step):
-			// per star the columns of its box inside the chunk and the offset of its items in the K buffer
-			const int j1 = (j0 + wc < W) ? (j0 + wc) : W;
-			int off[S], jlo[S], jhi[S];
-			int nitems = 0;
-#pragma unroll
-			for (int s = 0; s < S; ++s) {
-				const bool rowin = (i >= bimin[s]) && (i <= bimax[s]);
-				jlo[s] = (bjmin[s] > j0) ? bjmin[s] : j0;
-				jhi[s] = (bjmax[s] < j1 - 1) ? bjmax[s] : (j1 - 1);
-				if (!rowin) { jlo[s] = 0; jhi[s] = -1; }
-				off[s] = nitems;
-				if (jhi[s] >= jlo[s]) nitems += (jhi[s] - jlo[s] + 1) * nc[s];
-			}
-			if (nitems == 0) continue; // no star near this chunk: its pixels do not enter the normal equations
-			int jfirst = j1, jlast = j0 - 1; // union of the stars' columns: the other pixels have an all-zero design row
-#pragma unroll
-			for (int s = 0; s < S; ++s)
-				if (jhi[s] >= jlo[s]) { jfirst = (jlo[s] < jfirst) ? jlo[s] : jfirst; jlast = (jhi[s] > jlast) ? jhi[s] : jlast; }
-			const int jend = jlast + 1;
-			// the chunk's pixels of the thread's cadences: a ring of four loads per slot stays in flight (issued here, before
-			// the coefficient phase, and refilled as the pixels are consumed); indices clamp instead of branching
-			auto pix_load = [&](const CadSlot<S>& cs, int j) { j = (j < jend) ? j : (jend - 1); return cs.img[((int64_t)(i * W) + j) * a.t_pitch]; };
-#pragma unroll
-			for (int u = 0; u < U; ++u) {
-#pragma unroll
-				for (int s = 0; s < S; ++s) { const double dr = (double)i - c[u].srow[s]; c[u].dr2[s] = dr * dr; }
-#pragma unroll
-				for (int r = 0; r < 4; ++r) c[u].ring[r] = pix_load(c[u], jfirst + r);
-			}
-			// ---- A: polynomial coefficients of every (star, column, origin) item of this row chunk
-			for (int w = tid; w < nitems * 5; w += nthreads) {
-				int item = w / 5;
-				const int bcol = w - item * 5;
-				int offs = 0, jlos = 0, ncs = 1, nbys = 1, axm = 0, bym = 0;
-#pragma unroll
-				for (int u = 0; u < S; ++u) if (jhi[u] >= jlo[u] && item >= off[u]) { offs = off[u]; jlos = jlo[u]; ncs = nc[u]; nbys = nby[u]; axm = baxmin[u]; bym = bbymin[u]; }
-				const int rel = item - offs;
-				const int jj = rel / ncs, co = rel - jj * ncs;
-				const int cx = co / nbys, cy = co - cx * nbys;
-				const int j = jlos + jj;
-				int ax = (axm + cx) + 9 * j, by = (bym + cy) + 9 * i;
-				ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
-				by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
-				double yb[13];
-#pragma unroll
-				for (int q = 0; q < 13; ++q) yb[q] = kEdgePoly[q][bcol];
-				double kk[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-				const double* c0 = C + (int64_t)ax * n + by;
-#pragma unroll
-				for (int p = 0; p < 13; ++p) {
-					const double* r = c0 + p * n;
-					double t = 0.0;
-#pragma unroll
-					for (int q = 0; q < 13; ++q) t = __builtin_fma(yb[q], r[q], t);
-#pragma unroll
-					for (int e = 0; e < 5; ++e) kk[e] = __builtin_fma(kEdgePoly[p][e], t, kk[e]);
-				}
-				double* dst = Kbuf + (size_t)item * 25 + bcol;
-#pragma unroll
-				for (int e = 0; e < 5; ++e) dst[e * 5] = h2 * kk[e];
-			}
-			__syncthreads();
-			// ---- B: the cadences' design-matrix row values of the chunk's pixels, normal equations
-			auto consume = [&](CadSlot<S>& cs, float pv, int j) {
-				if (!cs.active || j >= jend) return;
-				float bf = pv;
-				if (a.subtract) bf = bf - cs.sub;
-				if (!(fabsf(bf) <= 3.402823466e+38f)) return; // good_pixels = isfinite(img) (linpsf_photometry.py:123)
-				const double b = (double)bf;
-				double av[S];
-#pragma unroll
-				for (int s = 0; s < S; ++s) {
-					av[s] = 0.0;
-					if (s < ns && cs.valid[s] && j >= jlo[s] && j <= jhi[s]) {
-						const double dc = (double)j - cs.scol[s];
-						// psf.py:142  sqrt((j-col)^2 + (i-row)^2) < cutoff_radius; the squares decide unless they are within
-						// rounding of each other, then the reference's own expression does
-						const double d2 = dc * dc + cs.dr2[s], c2 = cutoff * cutoff;
-						const bool inside = (fabs(d2 - c2) > 1e-9 * c2) ? (d2 < c2) : (sqrt(d2) < cutoff);
-						if (inside) {
-							const double* kp = Kbuf + (size_t)(off[s] + (j - jlo[s]) * nc[s] + cs.cc[s]) * 25;
-							double val = 0.0;
-#pragma unroll
-							for (int e = 4; e >= 0; --e) {
-								double inner = kp[e * 5 + 4];
-#pragma unroll
-								for (int d = 3; d >= 0; --d) inner = __builtin_fma(inner, cs.phy[s], kp[e * 5 + d]);
-								val = __builtin_fma(val, cs.phx[s], inner);
-							}
-							av[s] = val;
-						}
-					}
-				}
-#pragma unroll
-				for (int s = 0; s < S; ++s) {
-					cs.g[s] += av[s] * b;
-#pragma unroll
-					for (int t = 0; t < S; ++t) if (t >= s) cs.G[s][t] += av[s] * av[t];
-				}
-			};
-			for (int jb = jfirst; jb < jend; jb += 4) {
-#pragma unroll
-				for (int r = 0; r < 4; ++r) {
-#pragma unroll
-					for (int u = 0; u < U; ++u) { consume(c[u], c[u].ring[r], jb + r); c[u].ring[r] = pix_load(c[u], jb + r + 4); }
-				}
-			}
-			__syncthreads();
-		}
-	}
-#pragma unroll
-	for (int u = 0; u < U; ++u) {
-		if (!c[u].active) continue;
-#pragma unroll
-		for (int s = 0; s < S; ++s)
-#pragma unroll
-			for (int t = 0; t < S; ++t) if (t < s) c[u].G[s][t] = c[u].G[t][s];
-		double x[S];
-		pinv_solve<S>(c[u].G, c[u].g, ns, x);
-		const int ti = a.target_index[target];
-		double tf = __builtin_nan("");
-#pragma unroll
-		for (int s = 0; s < S; ++s) {
-			if (s < ns) {
-				a.fluxes_all[(s0 + s) * a.out_pitch + c[u].k] = x[s];
-				if (s == ti) tf = x[s];
-			}
-		}
-		a.flux[(int64_t)target * a.out_pitch + c[u].k] = tf;
-		a.flux_err[(int64_t)target * a.out_pitch + c[u].k] = __builtin_nan("");
-	}
-	} // pass
-}
-
 //--------------------------------------------------------------------------------------------------
-// The polynomial path WITHOUT the LDS-resident table: three kernels.
+// Three kernels (round 2; the round-1 kernel kept the 110 KB table in LDS, one 768-thread workgroup per CU, and read the 25
+// coefficients of every Horner evaluation from LDS in every lane: 4 SIMDs share one LDS, so the coefficient reads, not the
+// FMAs, set its pace -- 24 ms for the C3 batch):
 //   plan  per target the boxes of its stars over ALL cadences (table origins visited, pixels that can be inside the
-//         cut-off), the number of (pixel, origin) items and their place in the coefficient store (one atomic per target);
-//   coef  the 25 biquartic coefficients of every item, contracted from the coefficient table in HBM / L2 (the same
-//         arithmetic as phase A of tp_linpsf_fit_kernel), written to the store: item = (pixel of the star's box, origin);
+//         cut-off), the number of (pixel, origin) items and their place in the coefficient store (one atomic per target),
+//         and the ORDER in which the fit walks the cadences: sorted by the origins of all stars (bitonic sort in LDS), because
+//         the jitter straddles a knot boundary in most targets and a wavefront should see one origin per star;
+//   coef  the 25 biquartic coefficients of every item, contracted from the target's table staged in LDS (one thread per
+//         item, the 13 x 13 patch read once), written to the store: item = (pixel of the star's box, origin);
 //   fit   one thread per cadence in 256-thread workgroups that use NO LDS: the coefficients of a (star, pixel, origin) are
-//         the same for every cadence of a wavefront that sees that origin (all of them unless the jitter crosses a knot),
-//         so the 25 loads of a Horner evaluation are single-address vector loads served by the L1 as broadcasts -- no LDS
-//         read, no barrier, and the occupancy is set by the registers (the 110 KB table pinned one workgroup per CU).
-// Same arithmetic and accumulation order (pixels row-major) as tp_linpsf_fit_kernel: bit-identical results.
+//         the same for every cadence of a wavefront that sees that origin, so they are fetched by SCALAR loads from a
+//         wave-uniform address (3 x s_load_dwordx16 + 1) and enter the Horner FMAs as SGPR addends (v_fma_f64 with a scalar
+//         source) -- no LDS read, no barrier, and the occupancy is set by the registers.  Lanes of a wavefront that still
+//         differ in origin are served in turn (ballot loop).  One instantiation per star count (1, 2, 3, 4, 5-8).
+// The coefficient arithmetic and the accumulation order (pixels row-major) are those of the round-1 kernel: same results.
+// Measured (C3: 10 000 targets, 18 057 fitted stars): plan 0.65 ms, coef 1.23 ms, fit 10.9 ms (24.2 ms in round 1's kernel).
+// Also measured: the coefficients by per-lane vector loads of one address instead of scalar loads (17.7 ms: the texture
+// addresser handles 64 lanes whatever they read); natural cadence order (18.6 ms: three origins per wavefront on average);
+// the cadence's pixels fetched a row ahead through LDS (13.6 against 12.5: the loop is not waiting for its pixels).
 //--------------------------------------------------------------------------------------------------
 struct StarPlan { int axmin, bymin, nby, nc, jmin, jmax, imin, imax; long long item_off; };
 
@@ -772,7 +480,7 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 		if (p.nc <= 0 || ncols <= 0 || nrows <= 0) continue;
 		const int nitems = p.nc * ncols * nrows;
 		// one thread per item: the 13 x 13 patch of the table is read once and contracted into all 25 coefficients (the sums
-		// run in the order of tp_linpsf_fit_kernel's phase A: over q inside, over p outside)
+		// run over q inside, over p outside)
 		for (int item = tid; item < nitems; item += 512) {
 			const int pix = item / p.nc, co = item - pix * p.nc;
 			const int ii = pix / ncols, jj = pix - ii * ncols;
@@ -868,70 +576,96 @@ __global__ __launch_bounds__(256) void tp_linpsf_fit2_kernel(FitArgs a, const St
 	const float* img = a.images + (int64_t)target * H * W * a.t_pitch + k;
 	const float sub = a.subtract ? a.subtract[(int64_t)target * a.subtract_pitch + k] : 0.f;
 
+	// item indices relative to the target's first item: 32-bit scalar arithmetic in the pixel loop
+	const double* __restrict__ tstore = store + ioff[0] * 25;
+	int rel[S];
+#pragma unroll
+	for (int s = 0; s < S; ++s) rel[s] = (int)(ioff[s] - ioff[0]);
 	for (int i = ui0; i <= ui1; ++i) {
-		// the columns some star can reach in this row; the other pixels have an all-zero design row
+		// per star the columns of this row that are inside the cut-off for SOME cadence of the wavefront (a float bound with a
+		// margin; the exact test of psf.py:142 stays in the loop), and where the row's items start in the store
+		int ja[S], jb[S], rowoff[S];
+		double dr2[S];
 		int jfirst = W, jend = 0;
 #pragma unroll
-		for (int s = 0; s < S; ++s)
-			if (i >= imin[s] && i <= imax[s] && jmax[s] >= jmin[s]) { jfirst = (jmin[s] < jfirst) ? jmin[s] : jfirst; jend = (jmax[s] + 1 > jend) ? (jmax[s] + 1) : jend; }
-		if (jend <= jfirst) continue;
-		double dr2[S];
+		for (int s = 0; s < S; ++s) {
+			ja[s] = 0; jb[s] = -1; rowoff[s] = 0;
+			const double dr = (double)i - srow[s];
+			dr2[s] = dr * dr;
+			if (s < ns && i >= imin[s] && i <= imax[s] && jmax[s] >= jmin[s]) {   // uniform
+				const float w2 = (float)(c2 - dr2[s]);
+				int jl = 0x3fffffff, jh = -0x3fffffff;
+				if (valid[s] && w2 > -1e-3f) {
+					const float w = sqrtf(fmaxf(w2, 0.f)) * 1.0001f + 1e-3f;
+					jl = (int)floorf((float)scol[s] - w);
+					jh = (int)ceilf((float)scol[s] + w);
+				}
 #pragma unroll
-		for (int s = 0; s < S; ++s) { const double dr = (double)i - srow[s]; dr2[s] = dr * dr; }
+				for (int off = 32; off > 0; off >>= 1) {
+					const int l2 = __shfl_xor(jl, off, 64), h2 = __shfl_xor(jh, off, 64);
+					jl = (l2 < jl) ? l2 : jl;
+					jh = (h2 > jh) ? h2 : jh;
+				}
+				jl = __builtin_amdgcn_readfirstlane(jl); jh = __builtin_amdgcn_readfirstlane(jh);
+				ja[s] = (jl > jmin[s]) ? jl : jmin[s];
+				jb[s] = (jh < jmax[s]) ? jh : jmax[s];
+				rowoff[s] = rel[s] + ((i - imin[s]) * ncols[s] - jmin[s]) * ncs[s];
+				if (jb[s] >= ja[s]) { jfirst = (ja[s] < jfirst) ? ja[s] : jfirst; jend = (jb[s] + 1 > jend) ? (jb[s] + 1) : jend; }
+			}
+		}
+		if (jend <= jfirst) continue;
 		auto pix_load = [&](int j) { j = (j < jend) ? j : (jend - 1); return img[((int64_t)(i * W) + j) * a.t_pitch]; };
 		float pnext = pix_load(jfirst);
 #pragma unroll 1
 		for (int j = jfirst; j < jend; ++j) {
-			{
-				const float pv = pnext;
-				pnext = pix_load(j + 1);
-				float bf = pv;
-				if (a.subtract) bf = bf - sub;
-				const bool fin = active && (fabsf(bf) <= 3.402823466e+38f);   // good_pixels = isfinite(img) (linpsf_photometry.py:123)
-				const double b = (double)bf;
-				double av[S];
+			const float pv = pnext;
+			pnext = pix_load(j + 1);
+			float bf = pv;
+			if (a.subtract) bf = bf - sub;
+			const bool fin = active && (fabsf(bf) <= 3.402823466e+38f);   // good_pixels = isfinite(img) (linpsf_photometry.py:123)
+			const double b = (double)bf;
+			double av[S];
 #pragma unroll
-				for (int s = 0; s < S; ++s) {
-					av[s] = 0.0;
-					if (s < ns && i >= imin[s] && i <= imax[s] && j >= jmin[s] && j <= jmax[s]) {   // uniform
-						const double dc = (double)j - scol[s];
-						// psf.py:142  sqrt((j-col)^2 + (i-row)^2) < cutoff_radius; the squares decide unless they are within
-						// rounding of each other (then, for the whole wavefront, the reference's own expression does)
-						const double d2 = dc * dc + dr2[s];
-						bool inside = d2 < c2;
-						if (__any(fabs(d2 - c2) <= 1e-9 * c2)) inside = (fabs(d2 - c2) > 1e-9 * c2) ? (d2 < c2) : (sqrt(d2) < cutoff);
-						const bool want = fin && valid[s] && inside;
-						const long long ibase = ioff[s] + (long long)((i - imin[s]) * ncols[s] + (j - jmin[s])) * ncs[s];
-						unsigned long long mask = __ballot(want);
-						while (mask) {
-							const int leader = __builtin_ctzll(mask);
-							const int ccu = __builtin_amdgcn_readlane(cc[s], leader);
-							const bool mine = want && (cc[s] == ccu);
-							// wave-uniform address: scalar loads; the coefficients are the SGPR addends of the Horner FMAs
-							const double* __restrict__ kp = store + (ibase + ccu) * 25;
-							double kc[25];
+			for (int s = 0; s < S; ++s) {
+				av[s] = 0.0;
+				if (j >= ja[s] && j <= jb[s]) {   // uniform
+					const double dc = (double)j - scol[s];
+					// psf.py:142  sqrt((j-col)^2 + (i-row)^2) < cutoff_radius; the squares decide unless they are within
+					// rounding of each other (then, for the whole wavefront, the reference's own expression does)
+					const double d2 = dc * dc + dr2[s];
+					bool inside = d2 < c2;
+					if (__any(fabs(d2 - c2) <= 1e-9 * c2)) inside = (fabs(d2 - c2) > 1e-9 * c2) ? (d2 < c2) : (sqrt(d2) < cutoff);
+					const bool want = fin && valid[s] && inside;
+					const int ibase = rowoff[s] + j * ncs[s];
+					unsigned long long mask = __ballot(want);
+					while (mask) {
+						const int leader = __builtin_ctzll(mask);
+						const int ccu = __builtin_amdgcn_readlane(cc[s], leader);
+						const bool mine = want && (cc[s] == ccu);
+						// wave-uniform address: scalar loads; the coefficients are the SGPR addends of the Horner FMAs
+						const double* __restrict__ kp = tstore + (unsigned)(ibase + ccu) * 25u;
+						double kc[25];
 #pragma unroll
-							for (int q = 0; q < 25; ++q) kc[q] = kp[q];
-							double val = 0.0;
+						for (int q = 0; q < 25; ++q) kc[q] = kp[q];
+						double val = 0.0;
 #pragma unroll
-							for (int e = 4; e >= 0; --e) {
-								double inner = kc[e * 5 + 4];
+						for (int e = 4; e >= 0; --e) {
+							double inner = kc[e * 5 + 4];
 #pragma unroll
-								for (int d = 3; d >= 0; --d) inner = fma_sgpr_addend(inner, phy[s], kc[e * 5 + d]);
-								val = __builtin_fma(val, phx[s], inner);
-							}
-							if (mine) av[s] = val;
-							mask &= ~__ballot(mine);
+							for (int d = 3; d >= 0; --d) inner = fma_sgpr_addend(inner, phy[s], kc[e * 5 + d]);
+							val = __builtin_fma(val, phx[s], inner);
 						}
+						if (mine) av[s] = val;
+						mask &= ~__ballot(mine);
 					}
 				}
-				if (fin) {
+			}
+			if (fin) {
 #pragma unroll
-					for (int s = 0; s < S; ++s) {
-						g[s] += av[s] * b;
+				for (int s = 0; s < S; ++s) {
+					g[s] += av[s] * b;
 #pragma unroll
-						for (int t = 0; t < S; ++t) if (t >= s) G[s][t] += av[s] * av[t];
-					}
+					for (int t = 0; t < S; ++t) if (t >= s) G[s][t] += av[s] * av[t];
 				}
 			}
 		}
@@ -1379,19 +1113,29 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	TP_LAUNCH_CHECK(ctx, "tp_linpsf_coef_kernel");
 	const int nblk2 = (desc->n_cad + 255) / 256;
 	const int threads2 = (((desc->n_cad + nblk2 - 1) / nblk2) + 63) / 64 * 64;
-#define TP_LINPSF_LAUNCH(SS, SL) do { \
+#define TP_LINPSF_FIT2(SS, SL) do { \
 		TP_LAUNCH(ctx, TPK_LINPSF_FIT, (tp_linpsf_fit2_kernel<SS, SL>), dim3((unsigned)desc->n_targets, (unsigned)nblk2), dim3((unsigned)threads2), 0, a, (const StarPlan*)d_plans, (const int32_t*)d_todo, (const double*)d_store, (const int32_t*)d_order); \
 		TP_LAUNCH_CHECK(ctx, "tp_linpsf_fit2_kernel"); \
+	} while (0)
+#define TP_LINPSF_LAUNCH(SS, SL) do { \
 		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_direct_kernel<SS, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
 		TP_LAUNCH(ctx, TPK_LINPSF_FIT_DIRECT, (tp_linpsf_fit_direct_kernel<SS, SL>), grid, block, shmem, a, (const int32_t*)d_todo); \
 		TP_LAUNCH_CHECK(ctx, "tp_linpsf_fit_direct_kernel"); \
 		TP_LAUNCH(ctx, TPK_LINPSF_FIN, (tp_linpsf_finalize_kernel<SS, SL>), dim3((unsigned)desc->n_targets), dim3(256), shmem_fin, fa); \
 		TP_LAUNCH_CHECK(ctx, "tp_linpsf_finalize_kernel"); \
 	} while (0)
-	// one instantiation per star-count class; a workgroup whose target belongs to another class exits at once
+	// one instantiation per star count (the normal equations and the registers of a 1-star target are not those of a 4-star
+	// one); a workgroup whose target belongs to another class exits at once
+	TP_LINPSF_FIT2(1, 0);
+	if (max_stars > 1) TP_LINPSF_FIT2(2, 2);
+	if (max_stars > 2) TP_LINPSF_FIT2(3, 3);
+	if (max_stars > 3) TP_LINPSF_FIT2(4, 4);
+	if (max_stars > 4) TP_LINPSF_FIT2(8, 5);
+	// the general kernel (flagged targets) and the finalisation, by coarser classes
 	TP_LINPSF_LAUNCH(2, 0);
 	if (max_stars > 2) TP_LINPSF_LAUNCH(4, 3);
 	if (max_stars > 4) TP_LINPSF_LAUNCH(8, 5);
+#undef TP_LINPSF_FIT2
 #undef TP_LINPSF_LAUNCH
 	if (max_stars > kMaxStars) {
 		// targets with more than 8 fitted stars (rare: crowded fields): listed on the host from the star offsets, fitted by

@@ -44,11 +44,12 @@ def test_prf_blend_matches_reference_construction(ctx):
 		np.testing.assert_array_equal(model.tx, ref.tx)
 
 
-# jitter scale 1: sigma 0.02 px (a few table origins per star: polynomial fast path, whole rows per chunk);
-# 6: sigma 0.12 px (dozens of origins: the K buffer forces column chunks); 30: sigma 0.6 px (more origins than the
-# buffer holds: the target is flagged and redone by the general direct kernel); 1300+ cadences: several passes
+# jitter scale 1: sigma 0.02 px (a few table origins per star: the polynomial path, cadences sorted by origin);
+# 6: sigma 0.12 px (dozens of origins per star, several per wavefront even after sorting); 30: sigma 0.6 px (more origins
+# than the plan allows: the target is flagged and redone by the general direct kernel); 1300+ cadences: several workgroups per
+# target; 8300 cadences: beyond the LDS sort of the plan kernel (natural cadence order)
 @pytest.mark.parametrize("max_neigh,T,H,W,jit", [(3, 40, 11, 11, 1), (1, 70, 15, 15, 1), (6, 16, 13, 12, 1),
-	(3, 40, 11, 11, 6), (2, 33, 15, 15, 30), (1, 1301, 9, 9, 1), (3, 1100, 9, 9, 2),
+	(3, 40, 11, 11, 6), (2, 33, 15, 15, 30), (1, 1301, 9, 9, 1), (3, 1100, 9, 9, 2), (1, 8300, 7, 7, 1),
 	(13, 12, 11, 11, 1)])     # more than 8 fitted stars: the run-time sized kernel
 def test_linpsf_matches_oracle(ctx, max_neigh, T, H, W, jit):
 	from photometry_amd import simulate, engine, psf as hpsf
