@@ -322,7 +322,9 @@ struct StarBox { int axmin, axmax, bymin, bymax, jmin, jmax, imin, imax; };
 // Measured (C3: 10 000 targets, 18 057 fitted stars): plan 0.65 ms, coef 1.23 ms, fit 10.9 ms (24.2 ms in round 1's kernel).
 // Also measured: the coefficients by per-lane vector loads of one address instead of scalar loads (17.7 ms: the texture
 // addresser handles 64 lanes whatever they read); natural cadence order (18.6 ms: three origins per wavefront on average);
-// the cadence's pixels fetched a row ahead through LDS (13.6 against 12.5: the loop is not waiting for its pixels).
+// the cadence's pixels fetched a row ahead through LDS (13.6 against 12.5: the loop is not waiting for its pixels); two or four
+// cadences per lane sharing the scalar loads and the uniform tests (10.9 - 11.9 ms for the combinations tried: no gain, the
+// extra registers cost what the shared work saves).
 //--------------------------------------------------------------------------------------------------
 struct StarPlan { int axmin, bymin, nby, nc, jmin, jmax, imin, imax; long long item_off; };
 

@@ -2,6 +2,9 @@
 """Diagnostic: per-kernel time of the LinPSF fit on the C3 workload (NT targets)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get('TP_LAB_LIB'):
+	from photometry_amd import _lib
+	_lib.LIB_PATH = os.environ['TP_LAB_LIB']
 import bench
 from photometry_amd import simulate, engine, pipeline
 from photometry_amd.device import Context
