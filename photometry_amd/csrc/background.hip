@@ -40,6 +40,11 @@
 // one lane per frame (float thresholds, 4-ary rank searches) while the sorters work on the next block: 6.7 ms with the
 // clipping switched off and 11.0 ms with it (two 66 KB workgroups per CU leave the sorters 4.5 waves per SIMD between two
 // barriers per block, and the lane-per-frame clipper is a serial chain of LDS round trips that no amount of sorting hides).
+// Shared staging areas (512-thread workgroups whose 8 wavefronts take one of 4-6 areas with an LDS atomic when their sort is
+// done: 8 wavefronts per SIMD instead of 5): 5.62-5.66 ms against 5.53 -- occupancy is not what limits it.  The instruction
+// rates do (tools/lab/valu_rate.hip): v_min / v_max / v_med3, DPP moves, v_cmp, v_cndmask and every FP64 instruction issue
+// at one wave64 instruction per 4 cycles on this chip (only plain FP32 / integer add, mul, fma, logic and moves at 2), so the
+// ~2 500 vector instructions of a wavefront are ~9 500 cycles and the batch ~6 ms of vector-ALU time: the kernel runs at it.
 #include "common.h"
 #include <cmath>
 #include <utility>
