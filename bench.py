@@ -442,7 +442,9 @@ def main():
 		dom = max(hbm_kernels, key=lambda k: rows[k]['avg_ms'])
 		notes = {
 			'tp_bkg_stamp_kernel': 'B*: streams the raw cube once, but is bound by the vector ALUs (a 256-key sorting network per frame '
-				'for the sigma-clipped median), not by HBM; traffic = bytes (profiles/)',
+				'for the sigma-clipped median), not by HBM; traffic = bytes (profiles/).  Its instructions (v_min / v_max / v_med3, DPP '
+				'moves, FP64) issue at one wave64 instruction per 4 cycles on gfx950 (tools/lab/valu_rate.hip): ~9 500 cycles per '
+				'wavefront of 8 frames, i.e. the vector-ALU time of this launch is ~%.1f ms at 2.4 GHz on 1 024 SIMDs' % (Nt * ((T + 7) // 8) * 9500.0 / 1024 / 2.4e9 * 1e3),
 			'tp_aperture_fused_kernel': 'the aperture-sum kernel north_star names (A1 + K2P2 + A6 fused, one wavefront per target)',
 		}
 		rooflines = [roofline_of(k, rows, traffic, notes.get(k)) for k in sorted(hbm_kernels, key=lambda k: -rows[k]['avg_ms'])]
