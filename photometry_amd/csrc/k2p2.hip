@@ -72,9 +72,11 @@ extern "C" int tp_k2p2_masks(tp_ctx* ctx, int32_t n_targets, int32_t height, int
 	a.target_starid = d_target_starid; a.stamps = d_stamps; a.aperture = d_aperture; a.cut_override = d_cut_override;
 	a.mask = d_mask; a.status = d_status; a.flags = d_flags; a.contamination = d_contamination; a.diag = d_diag;
 	a.cat_in_mask = d_cat_in_mask;
-	// diagnostics: TP_K2P2_TIMING=1 makes d_diag (which must then hold 16 doubles per target) receive per-phase cycle counts
 	a.timing = nullptr;
-	if (const char* e = getenv("TP_K2P2_TIMING")) { if (e[0] == '1' && d_diag) { a.timing = d_diag; a.diag = nullptr; } }
+#ifdef TP_LAB_K2P2_TIMING
+	// lab builds only (tools/k2p2_phases.py): d_diag, 16 doubles per target, receives per-phase cycle counts instead
+	if (d_diag) { a.timing = d_diag; a.diag = nullptr; }
+#endif
 	TP_LAUNCH(ctx, TPK_K2P2, tp_k2p2_kernel, dim3((unsigned)n_targets), dim3(64), shmem, a, prm, (const double*)ctx->twiddle);
 	TP_LAUNCH_CHECK(ctx, "tp_k2p2_kernel");
 	return TP_OK;
