@@ -43,6 +43,13 @@ __device__ double likelihood(const double* x, int ns, const double* C, const dou
 	const double* img, const double* wgt, int H, int W, double cutoff, StarW* sw, double* red)
 {
 	const int tid = threadIdx.x;
+#ifdef TP_LAB_PSF_NOEVAL
+	{ // lab: a cheap stand-in for chi^2, to time the simplex bookkeeping alone (tools/psf_time.py)
+		double t = 0.0;
+		for (int d = 0; d < 3 * ns; ++d) t += (x[d] - (d % 3 == 2 ? 1000.0 : 7.0)) * (x[d] - (d % 3 == 2 ? 1000.0 : 7.0)) * (d + 1);
+		return t;
+	}
+#endif
 	if (tid < ns) {
 		StarW& s = sw[tid];
 		s.row = x[3 * tid]; s.col = x[3 * tid + 1]; s.flux = x[3 * tid + 2];
@@ -92,8 +99,8 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a)
 	double* fsim = sim + (kMaxDim + 1) * kMaxDim;   // [D+1]
 	double* xt = fsim + (kMaxDim + 1);        // trial points: xbar, xr, xe / xc [3][kMaxDim]
 	double* x0 = xt + 3 * kMaxDim;            // warm start [kMaxDim]
-	double* red = x0 + kMaxDim;               // [4]
-	StarW* sw = reinterpret_cast<StarW*>(red + 4);
+	double* red = x0 + kMaxDim;               // [8]
+	StarW* sw = reinterpret_cast<StarW*>(red + 8);
 	const double* cg = a.coef + (int64_t)target * n * n;
 	for (int i = tid; i < n * n; i += kThreads) C[i] = cg[i];
 	for (int i = tid; i < n + 4; i += kThreads) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
@@ -130,13 +137,13 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a)
 		__syncthreads();
 		// ---- Nelder-Mead (scipy _minimize_neldermead)
 		const int maxiter = (k > 0) ? a.maxiter : a.maxiter_first;
-		if (tid == 0) {
-			for (int d = 0; d < D; ++d) sim[d] = x0[d];
-			for (int v = 0; v < D; ++v) {
-				for (int d = 0; d < D; ++d) sim[(v + 1) * kMaxDim + d] = x0[d];
-				const double y = x0[v];
-				sim[(v + 1) * kMaxDim + v] = (y != 0.0) ? (1.0 + 0.05) * y : 0.00025;
-			}
+		// the simplex bookkeeping below is spread over the threads (vertex v = tid / 16, component d = tid % 16): every component
+		// is computed by the same expression, in the same order, as scipy's vectorised numpy statements (a serial thread spent
+		// two thirds of an iteration walking the 16 x 15 simplex through LDS)
+		const int tv = tid >> 4, td = tid & 15;
+		if (tv <= D && td < D) {
+			const double y = x0[td];
+			sim[tv * kMaxDim + td] = (tv >= 1 && td == tv - 1) ? ((y != 0.0) ? (1.0 + 0.05) * y : 0.00025) : y;
 		}
 		__syncthreads();
 		for (int v = 0; v <= D; ++v) {
@@ -144,74 +151,111 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a)
 			if (tid == 0) fsim[v] = f;
 		}
 		__syncthreads();
-		auto sort_simplex = [&]() { // stable insertion sort by fsim (numpy argsort of <= 16 values), thread 0
-			if (tid == 0) {
-				for (int i = 1; i <= D; ++i) {
-					const double fv = fsim[i];
-					double tmp[kMaxDim];
-					for (int d = 0; d < D; ++d) tmp[d] = sim[i * kMaxDim + d];
-					int j = i - 1;
-					while (j >= 0 && fsim[j] > fv) {
-						fsim[j + 1] = fsim[j];
-						for (int d = 0; d < D; ++d) sim[(j + 1) * kMaxDim + d] = sim[j * kMaxDim + d];
-						--j;
+		auto sort_simplex = [&]() { // stable sort by fsim (numpy argsort of <= 16 values is an insertion sort)
+			bool anynan = false;
+			for (int v = 0; v <= D; ++v) anynan = anynan || (fsim[v] != fsim[v]);
+			if (anynan) {
+				// NaN does not order: replay the insertion sort itself, one thread
+				if (tid == 0) {
+					for (int i = 1; i <= D; ++i) {
+						const double fv = fsim[i];
+						double tmp[kMaxDim];
+						for (int d = 0; d < D; ++d) tmp[d] = sim[i * kMaxDim + d];
+						int j = i - 1;
+						while (j >= 0 && fsim[j] > fv) {
+							fsim[j + 1] = fsim[j];
+							for (int d = 0; d < D; ++d) sim[(j + 1) * kMaxDim + d] = sim[j * kMaxDim + d];
+							--j;
+						}
+						fsim[j + 1] = fv;
+						for (int d = 0; d < D; ++d) sim[(j + 1) * kMaxDim + d] = tmp[d];
 					}
-					fsim[j + 1] = fv;
-					for (int d = 0; d < D; ++d) sim[(j + 1) * kMaxDim + d] = tmp[d];
 				}
+				__syncthreads();
+				return;
+			}
+			// the stable order as ranks: vertex v goes to the number of vertices that sort before it
+			int rank = 0;
+			double mine = 0.0, fmine = 0.0;
+			if (tv <= D) {
+				fmine = fsim[tv];
+				for (int u = 0; u <= D; ++u) { const double fu = fsim[u]; rank += (fu < fmine || (fu == fmine && u < tv)) ? 1 : 0; }
+				if (td < D) mine = sim[tv * kMaxDim + td];
+			}
+			__syncthreads();
+			if (tv <= D) {
+				if (td < D) sim[rank * kMaxDim + td] = mine;
+				if (td == 15) fsim[rank] = fmine;
 			}
 			__syncthreads();
 		};
 		sort_simplex();
 		int iterations = 1;
 		while (iterations < maxiter) {
+			// max |sim[1:] - sim[0]| and max |fsim[0] - fsim[1:]| (a NaN makes the maximum NaN, as numpy's does)
 			double dx = 0.0, df = 0.0;
-			for (int v = 1; v <= D; ++v) {
-				for (int d = 0; d < D; ++d) { const double e = fabs(sim[v * kMaxDim + d] - sim[d]); if (e > dx || e != e) dx = e; }
-				const double e = fabs(fsim[0] - fsim[v]); if (e > df || e != e) df = e;
+			if (tv >= 1 && tv <= D) {
+				if (td < D) dx = fabs(sim[tv * kMaxDim + td] - sim[td]);
+				if (td == 15) df = fabs(fsim[0] - fsim[tv]);
 			}
+#pragma unroll
+			for (int off = 32; off > 0; off >>= 1) {
+				const double ox = __shfl_xor(dx, off, 64), of = __shfl_xor(df, off, 64);
+				if (ox > dx || ox != ox) dx = ox;
+				if (of > df || of != of) df = of;
+			}
+			__syncthreads();   // red is free (the last evaluation has returned everywhere)
+			if ((tid & 63) == 0) { red[tid >> 6] = dx; red[4 + (tid >> 6)] = df; }
+			__syncthreads();
+			dx = red[0]; df = red[4];
+#pragma unroll
+			for (int w = 1; w < 4; ++w) {
+				const double ox = red[w], of = red[4 + w];
+				if (ox > dx || ox != ox) dx = ox;
+				if (of > df || of != of) df = of;
+			}
+			__syncthreads();   // red is reused by the evaluations
 			if (dx <= 1e-4 && df <= 1e-4) break;
 			double* xbar = xt; double* xr = xt + kMaxDim; double* xn = xt + 2 * kMaxDim;
-			if (tid == 0) {
-				for (int d = 0; d < D; ++d) {
-					double sacc = 0.0;
-					for (int v = 0; v < D; ++v) sacc += sim[v * kMaxDim + d];   // np.add.reduce(sim[:-1], 0)
-					xbar[d] = sacc / (double)D;
-					xr[d] = 2.0 * xbar[d] - sim[D * kMaxDim + d];
-				}
+			if (tid < D) {
+				double sacc = 0.0;
+				for (int v = 0; v < D; ++v) sacc += sim[v * kMaxDim + tid];   // np.add.reduce(sim[:-1], 0)
+				xbar[tid] = sacc / (double)D;
+				xr[tid] = 2.0 * xbar[tid] - sim[D * kMaxDim + tid];
 			}
 			__syncthreads();
 			const double fxr = EVAL(xr);
 			bool doshrink = false;
 			const double* take = nullptr; double ftake = 0.0;
 			if (fxr < fsim[0]) {
-				if (tid == 0) for (int d = 0; d < D; ++d) xn[d] = 3.0 * xbar[d] - 2.0 * sim[D * kMaxDim + d];
+				if (tid < D) xn[tid] = 3.0 * xbar[tid] - 2.0 * sim[D * kMaxDim + tid];
 				__syncthreads();
 				const double fxe = EVAL(xn);
 				if (fxe < fxr) { take = xn; ftake = fxe; } else { take = xr; ftake = fxr; }
 			} else if (fxr < fsim[D - 1]) {
 				take = xr; ftake = fxr;
 			} else if (fxr < fsim[D]) {
-				if (tid == 0) for (int d = 0; d < D; ++d) xn[d] = 1.5 * xbar[d] - 0.5 * sim[D * kMaxDim + d];
+				if (tid < D) xn[tid] = 1.5 * xbar[tid] - 0.5 * sim[D * kMaxDim + tid];
 				__syncthreads();
 				const double fxc = EVAL(xn);
 				if (fxc <= fxr) { take = xn; ftake = fxc; } else doshrink = true;
 			} else {
-				if (tid == 0) for (int d = 0; d < D; ++d) xn[d] = 0.5 * xbar[d] + 0.5 * sim[D * kMaxDim + d];
+				if (tid < D) xn[tid] = 0.5 * xbar[tid] + 0.5 * sim[D * kMaxDim + tid];
 				__syncthreads();
 				const double fxcc = EVAL(xn);
 				if (fxcc < fsim[D]) { take = xn; ftake = fxcc; } else doshrink = true;
 			}
 			if (doshrink) {
+				if (tv >= 1 && tv <= D && td < D) sim[tv * kMaxDim + td] = sim[td] + 0.5 * (sim[tv * kMaxDim + td] - sim[td]);
+				__syncthreads();
 				for (int v = 1; v <= D; ++v) {
-					if (tid == 0) for (int d = 0; d < D; ++d) sim[v * kMaxDim + d] = sim[d] + 0.5 * (sim[v * kMaxDim + d] - sim[d]);
-					__syncthreads();
 					const double f = EVAL(sim + v * kMaxDim);
 					if (tid == 0) fsim[v] = f;
 				}
 				__syncthreads();
 			} else {
-				if (tid == 0) { for (int d = 0; d < D; ++d) sim[D * kMaxDim + d] = take[d]; fsim[D] = ftake; }
+				if (tid < D) sim[D * kMaxDim + tid] = take[tid];
+				if (tid == 0) fsim[D] = ftake;
 				__syncthreads();
 			}
 			sort_simplex();
@@ -288,7 +332,7 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
 	const size_t P = (size_t)desc->height * desc->width;
 	const size_t doubles = (size_t)n_coef_axis * n_coef_axis + 2 * ((size_t)n_coef_axis + 4) + 2 * P + (kMaxDim + 1) * kMaxDim + (kMaxDim + 1)
-		+ 3 * kMaxDim + kMaxDim + 4;
+		+ 3 * kMaxDim + kMaxDim + 8;
 	const size_t shmem = doubles * sizeof(double) + kMaxPsfStars * sizeof(StarW) + 16;
 	TP_REQUIRE(ctx, shmem <= 160 * 1024, "tp_psf_fit: stamp too large for the LDS-resident image and weight map");
 	PsfArgs a;

@@ -3,6 +3,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+if os.environ.get('TP_LAB_LIB'):
+	from photometry_amd import _lib
+	_lib.LIB_PATH = os.environ['TP_LAB_LIB']
 from photometry_amd import simulate, engine, psf as hpsf
 from photometry_amd.device import Context, DeviceCube
 from photometry_amd.plugins import psf_star_selection, mag2flux
