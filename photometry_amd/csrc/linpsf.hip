@@ -271,35 +271,7 @@ __global__ __launch_bounds__(512) void tp_linpsf_fit_direct_kernel(FitArgs a, co
 // The arithmetic differs from the direct contraction only by rounding (1e-15 relative).  A target whose stars visit more
 // origins than max_origins (pointing excursions) is flagged for the general kernel.
 //--------------------------------------------------------------------------------------------------
-// coefficients (powers 0..4 of phi) of the 13 pixel-edge weights [1-m3, 1-m2, 1-m1, 1-m0, 1,1,1,1,1, m3, m2, m1, m0]
-__constant__ double kEdgePoly[13][5] = {
-	{1.0 / 24.0, -1.0 / 6.0, 0.25, -1.0 / 6.0, 1.0 / 24.0},
-	{0.5, -2.0 / 3.0, 0.0, 1.0 / 3.0, -0.125},
-	{23.0 / 24.0, -1.0 / 6.0, -0.25, -1.0 / 6.0, 0.125},
-	{1.0, 0.0, 0.0, 0.0, -1.0 / 24.0},
-	{1.0, 0.0, 0.0, 0.0, 0.0}, {1.0, 0.0, 0.0, 0.0, 0.0}, {1.0, 0.0, 0.0, 0.0, 0.0}, {1.0, 0.0, 0.0, 0.0, 0.0}, {1.0, 0.0, 0.0, 0.0, 0.0},
-	{23.0 / 24.0, 1.0 / 6.0, -0.25, 1.0 / 6.0, -1.0 / 24.0},
-	{0.5, 2.0 / 3.0, 0.0, -1.0 / 3.0, 0.125},
-	{1.0 / 24.0, 1.0 / 6.0, 0.25, 1.0 / 6.0, -0.125},
-	{0.0, 0.0, 0.0, 0.0, 1.0 / 24.0},
-};
-
-// phase and table origin of one axis (same arithmetic as axis_weights); false for a NaN / absurd position
-__device__ __forceinline__ bool axis_phase(const double* kn, int n, double pos, double h, double& phi, int& first)
-{
-	phi = 0.0; first = 4;
-	if (!(fabs(pos) < 1e6)) return false;
-	const int jstar = (int)rint(pos);
-	const double x0 = ((double)jstar - pos) - 0.5;
-	int l = 4 + (int)floor((x0 - kn[4]) / h);
-	if (l < 4) l = 4;
-	if (l > n - 2) l = n - 2;
-	if (x0 < kn[l] && l > 4) --l;
-	else if (x0 >= kn[l + 1] && l < n - 2) ++l;
-	phi = (x0 - kn[l]) / (kn[l + 1] - kn[l]);
-	first = (l - 3) - 9 * jstar;
-	return true;
-}
+// (kEdgePoly and axis_phase live in linpsf_dev.h: the non-linear PSF kernel uses the same polynomial form)
 
 struct StarBox { int axmin, axmax, bymin, bymax, jmin, jmax, imin, imax; };
 

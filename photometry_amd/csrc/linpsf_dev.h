@@ -58,4 +58,84 @@ __device__ __forceinline__ double prf_pixel(const double* __restrict__ C, int n,
 	return acc;
 }
 
+// ---- polynomial form (see linpsf.hip): for fixed knot intervals of a star's sub-pixel phases the pixel-integrated PRF of a
+// pixel is a biquartic in the two phases; these are the quartics of the 13 pixel-edge weights
+// coefficients (powers 0..4 of phi) of the 13 pixel-edge weights [1-m3, 1-m2, 1-m1, 1-m0, 1,1,1,1,1, m3, m2, m1, m0]
+static __constant__ double kEdgePoly[13][5] = {
+	{1.0 / 24.0, -1.0 / 6.0, 0.25, -1.0 / 6.0, 1.0 / 24.0},
+	{0.5, -2.0 / 3.0, 0.0, 1.0 / 3.0, -0.125},
+	{23.0 / 24.0, -1.0 / 6.0, -0.25, -1.0 / 6.0, 0.125},
+	{1.0, 0.0, 0.0, 0.0, -1.0 / 24.0},
+	{1.0, 0.0, 0.0, 0.0, 0.0}, {1.0, 0.0, 0.0, 0.0, 0.0}, {1.0, 0.0, 0.0, 0.0, 0.0}, {1.0, 0.0, 0.0, 0.0, 0.0}, {1.0, 0.0, 0.0, 0.0, 0.0},
+	{23.0 / 24.0, 1.0 / 6.0, -0.25, 1.0 / 6.0, -1.0 / 24.0},
+	{0.5, 2.0 / 3.0, 0.0, -1.0 / 3.0, 0.125},
+	{1.0 / 24.0, 1.0 / 6.0, 0.25, 1.0 / 6.0, -0.125},
+	{0.0, 0.0, 0.0, 0.0, 1.0 / 24.0},
+};
+
+// phase and table origin of one axis (same arithmetic as axis_weights); false for a NaN / absurd position
+__device__ __forceinline__ bool axis_phase(const double* kn, int n, double pos, double h, double& phi, int& first)
+{
+	phi = 0.0; first = 4;
+	if (!(fabs(pos) < 1e6)) return false;
+	const int jstar = (int)rint(pos);
+	const double x0 = ((double)jstar - pos) - 0.5;
+	int l = 4 + (int)floor((x0 - kn[4]) / h);
+	if (l < 4) l = 4;
+	if (l > n - 2) l = n - 2;
+	if (x0 < kn[l] && l > 4) --l;
+	else if (x0 >= kn[l + 1] && l < n - 2) ++l;
+	phi = (x0 - kn[l]) / (kn[l + 1] - kn[l]);
+	first = (l - 3) - 9 * jstar;
+	return true;
+}
+
+
+// the 25 coefficients K[e][b] (e: power of phi_x, b: power of phi_y), scaled by h2, of the patch C[ax .. ax+12][by .. by+12];
+// one call computes column b (the sums run over q inside, over p outside: the order of tp_linpsf_coef_kernel)
+__device__ __forceinline__ void poly_column(const double* __restrict__ C, int n, int ax, int by, int bcol, double h2, double (&out)[5])
+{
+	double kk[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+	const double* c0 = C + (int64_t)ax * n + by;
+	// four table rows (52 loads) in flight at a time: the table is read from L2 at low occupancy, a row at a time would be 13
+	// dependent round trips
+#pragma unroll 1
+	for (int p0 = 0; p0 < 13; p0 += 4) {
+		double rv[4][13];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int pp = (p0 + u < 13) ? (p0 + u) : 12;
+			const double* r = c0 + pp * n;
+#pragma unroll
+			for (int q = 0; q < 13; ++q) rv[u][q] = r[q];
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			if (p0 + u < 13) {
+				double t = 0.0;
+#pragma unroll
+				for (int q = 0; q < 13; ++q) t = __builtin_fma(kEdgePoly[q][bcol], rv[u][q], t);
+#pragma unroll
+				for (int e = 0; e < 5; ++e) kk[e] = __builtin_fma(kEdgePoly[p0 + u][e], t, kk[e]);
+			}
+		}
+	}
+#pragma unroll
+	for (int e = 0; e < 5; ++e) out[e] = h2 * kk[e];
+}
+
+// Horner evaluation of the biquartic with coefficients kp[e * 5 + d]
+__device__ __forceinline__ double poly_eval(const double* kp, double phx, double phy)
+{
+	double val = 0.0;
+#pragma unroll
+	for (int e = 4; e >= 0; --e) {
+		double inner = kp[e * 5 + 4];
+#pragma unroll
+		for (int d = 3; d >= 0; --d) inner = __builtin_fma(inner, phy, kp[e * 5 + d]);
+		val = __builtin_fma(val, phx, inner);
+	}
+	return val;
+}
+
 } // namespace tp_prf

@@ -5,15 +5,21 @@
 // aperture correction on the residuals), on top of the pixel-integrated PRF of psf.py:122-148 (linpsf_dev.h).
 //
 // Mapping (gfx950).  The cadences of a target form a CHAIN (the fit of cadence k starts from the solution of k-1), so the
-// parallelism is across targets and inside one likelihood evaluation: one 256-thread workgroup per target, the target's 117x117
-// float64 PRF coefficient table resident in LDS (110 KB: one workgroup per CU), the simplex and the cadence's image / weight
-// map beside it.  Every thread runs the same Nelder-Mead control flow on the LDS-resident simplex (uniform branches: all
-// decisions are taken on values read back from LDS), thread 0 alone mutates it; a likelihood evaluation spreads the pixels over
-// the threads (each sums flux_s * PRF_s over the stars whose cut-off disc holds the pixel: 169 LDS table reads + ~230 flops per
-// star-pixel) and reduces chi^2 by a fixed shuffle / LDS tree (deterministic).
+// parallelism is across targets and inside one likelihood evaluation: one 256-thread workgroup per target, the simplex and the
+// cadence's image / weight map in LDS.  Every thread runs the same Nelder-Mead control flow on the LDS-resident simplex (uniform
+// branches: all decisions are taken on values read back from LDS); the bookkeeping (centroid, ordering, convergence test) is
+// spread over vertex x component threads.  A likelihood evaluation spreads the pixels over the threads, each sums
+// flux_s * PRF_s over the stars whose cut-off disc holds the pixel, chi^2 is reduced by a fixed shuffle / LDS tree.
+// PRF_s of a pixel is evaluated in the POLYNOMIAL form of linpsf.hip: for fixed knot intervals of the star's sub-pixel phases
+// it is a biquartic in the two phases.  The 25 coefficients of the 11 x 11 pixels around a star are cached in LDS per pair of
+// knot intervals (24 KB a set, a pool of six sets shared by the target's stars, oldest replaced); an evaluation whose star sits
+// in intervals that are not cached builds that set from the coefficient table in HBM / L2 first (121 x 5 contractions of a
+// 13 x 13 patch over the 256 threads).
+// Late in a fit the simplex is far smaller than a knot interval (1/9 pixel) and nothing is rebuilt: 24 FMAs and 25 LDS reads
+// per star and pixel instead of the 169 table reads + ~230 flops of the direct contraction (round 2's first version, which
+// was LDS-bandwidth bound with the 110 KB table resident).
 // The simplex search is scipy 1.7.3's `_minimize_neldermead` step for step (non-adaptive coefficients 1, 2, 0.5, 0.5; initial
 // simplex 5 % / 0.00025; termination xatol = fatol = 1e-4; `success` = finished before maxiter; stable ordering of ties).
-// FP64 compute-bound: per target and cadence ~100-300 evaluations x (stars x ~79 pixels x 182 FMA).
 #include "common.h"
 #include "linpsf_dev.h"
 #include <cmath>
@@ -36,50 +42,113 @@ struct PsfArgs {
 	double* params_out; int32_t* nit; int32_t* status;
 };
 
-struct StarW { double row, col, flux, mx[4], my[4]; int ax0, by0; };
+constexpr int kHalfBox = 5;                      // pixels inside the cut-off (<= 5.25) lie within +-5 of the pixel nearest to the star
+constexpr int kBox = 2 * kHalfBox + 1;
+constexpr int kItems = kBox * kBox;              // cached (pixel offset) items per star, 25 coefficients each
+
+constexpr int kPool = 6;                         // cached coefficient sets (24 KB each) shared by the stars of a target: kPool / ns per star
+
+struct StarW { double row, col, flux, phx, phy; int jstar, istar, ax0, by0, valid, rebuild, slot, next; };
+
+// everything an evaluation needs besides the parameter vector
+struct EvalCtx {
+	int ns, n, H, W; double h, hy, cutoff;
+	const double* Cg;            // the target's coefficient table in HBM
+	const double* kn; const double* kny; const double* img; const double* wgt;
+	StarW* sw; double* Kc; double* red; int* keys;   // keys[kPool][2]: the knot intervals of every cached set
+};
+
+// star parameters of x (every thread gets them through LDS); a star whose knot intervals differ from its cached ones gets
+// its polynomial coefficients rebuilt
+__device__ void prepare_stars(const double* x, const EvalCtx& c)
+{
+	const int tid = threadIdx.x;
+	if (tid < c.ns) {
+		StarW& s = c.sw[tid];
+		s.row = x[3 * tid]; s.col = x[3 * tid + 1]; s.flux = x[3 * tid + 2];
+		const bool vx = axis_phase(c.kn, c.n, s.col, c.h, s.phx, s.ax0);     // x <-> column (first spline axis), y <-> row (psf.py:146)
+		const bool vy = axis_phase(c.kny, c.n, s.row, c.hy, s.phy, s.by0);
+		s.valid = (vx && vy) ? 1 : 0;
+		s.jstar = s.valid ? (int)rint(s.col) : 0;
+		s.istar = s.valid ? (int)rint(s.row) : 0;
+		// the knot intervals, free of the pixel the star sits in: first = (l - 3) - 9 * jstar
+		const int kx = s.ax0 + 9 * s.jstar, ky = s.by0 + 9 * s.istar;
+		// the star's share of the pool: sets [tid * per, (tid + 1) * per); a hit anywhere in it, else the oldest is replaced
+		const int per = kPool / c.ns;
+		s.rebuild = 0;
+		if (s.valid) {
+			int hit = -1;
+			for (int e = 0; e < per; ++e) { const int* k2 = c.keys + 2 * (tid * per + e); if (k2[0] == kx && k2[1] == ky) hit = tid * per + e; }
+			if (hit < 0) {
+				hit = tid * per + s.next;
+				s.next = (s.next + 1 == per) ? 0 : (s.next + 1);
+				c.keys[2 * hit] = kx; c.keys[2 * hit + 1] = ky;
+				s.rebuild = 1;
+			}
+			s.slot = hit;
+		}
+	}
+	__syncthreads();
+	const double h2 = c.h * c.hy;
+	for (int s = 0; s < c.ns; ++s) {
+		if (!c.sw[s].rebuild) continue;   // uniform
+		const int kx = c.keys[2 * c.sw[s].slot], ky = c.keys[2 * c.sw[s].slot + 1];
+		double* K = c.Kc + (size_t)c.sw[s].slot * kItems * 25;
+		for (int w = tid; w < kItems * 5; w += kThreads) {
+			const int item = w / 5, bcol = w - item * 5;
+			const int di = item / kBox - kHalfBox, dj = item - (item / kBox) * kBox - kHalfBox;
+			int ax = kx + 9 * dj, by = ky + 9 * di;
+			ax = ax < 0 ? 0 : (ax > c.n - 13 ? c.n - 13 : ax);
+			by = by < 0 ? 0 : (by > c.n - 13 ? c.n - 13 : by);
+			double col5[5];
+			poly_column(c.Cg, c.n, ax, by, bcol, h2, col5);
+#pragma unroll
+			for (int e = 0; e < 5; ++e) K[item * 25 + e * 5 + bcol] = col5[e];
+		}
+	}
+	__syncthreads();
+}
+
+// sum over the stars of flux * pixel-integrated PRF at pixel (i, j)
+__device__ __forceinline__ double model_pixel(int i, int j, const EvalCtx& c)
+{
+	double mdl = 0.0;
+	for (int s = 0; s < c.ns; ++s) {
+		const StarW& st = c.sw[s];
+		if (!st.valid) continue;
+		const int di = i - st.istar, dj = j - st.jstar;
+		if (di < -kHalfBox || di > kHalfBox || dj < -kHalfBox || dj > kHalfBox) continue;
+		const double dc = (double)j - st.col, dr = (double)i - st.row;
+		if (sqrt(dc * dc + dr * dr) < c.cutoff)     // psf.py:142 (a NaN position is never inside)
+			mdl += st.flux * poly_eval(c.Kc + ((size_t)st.slot * kItems + (di + kHalfBox) * kBox + (dj + kHalfBox)) * 25, st.phx, st.phy);
+	}
+	return mdl;
+}
 
 // chi^2 of the parameter vector x (psf_photometry.py:52-90); all threads call it, all get the same value
-__device__ double likelihood(const double* x, int ns, const double* C, const double* kn, const double* kny, int n, double h, double hy,
-	const double* img, const double* wgt, int H, int W, double cutoff, StarW* sw, double* red)
+__device__ double likelihood(const double* x, const EvalCtx& c)
 {
 	const int tid = threadIdx.x;
 #ifdef TP_LAB_PSF_NOEVAL
 	{ // lab: a cheap stand-in for chi^2, to time the simplex bookkeeping alone (tools/psf_time.py)
 		double t = 0.0;
-		for (int d = 0; d < 3 * ns; ++d) t += (x[d] - (d % 3 == 2 ? 1000.0 : 7.0)) * (x[d] - (d % 3 == 2 ? 1000.0 : 7.0)) * (d + 1);
+		for (int d = 0; d < 3 * c.ns; ++d) t += (x[d] - (d % 3 == 2 ? 1000.0 : 7.0)) * (x[d] - (d % 3 == 2 ? 1000.0 : 7.0)) * (d + 1);
 		return t;
 	}
 #endif
-	if (tid < ns) {
-		StarW& s = sw[tid];
-		s.row = x[3 * tid]; s.col = x[3 * tid + 1]; s.flux = x[3 * tid + 2];
-		axis_weights(kn, n, s.col, h, s.mx, s.ax0);     // x <-> column (first spline axis), y <-> row (psf.py:146)
-		axis_weights(kny, n, s.row, hy, s.my, s.by0);
-	}
-	__syncthreads();
-	const double h2 = h * hy;
+	prepare_stars(x, c);
 	double acc = 0.0;
-	for (int p = tid; p < H * W; p += kThreads) {
-		const int i = p / W, j = p - i * W;
-		double mdl = 0.0;
-		for (int s = 0; s < ns; ++s) {
-			const double dc = (double)j - sw[s].col, dr = (double)i - sw[s].row;
-			if (sqrt(dc * dc + dr * dr) < cutoff) {     // psf.py:142 (a NaN position is never inside)
-				int ax = sw[s].ax0 + 9 * j, by = sw[s].by0 + 9 * i;
-				ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
-				by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
-				mdl += sw[s].flux * (h2 * prf_pixel(C, n, ax, by, sw[s].mx, sw[s].my));
-			}
-		}
-		const double r = img[p] - mdl;
-		const double term = wgt[p] * (r * r);
+	for (int p = tid; p < c.H * c.W; p += kThreads) {
+		const int i = p / c.W, j = p - i * c.W;
+		const double r = c.img[p] - model_pixel(i, j, c);
+		const double term = c.wgt[p] * (r * r);
 		if (term == term) acc += term;                  // nansum
 	}
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-	if ((tid & 63) == 0) red[tid >> 6] = acc;
+	if ((tid & 63) == 0) c.red[tid >> 6] = acc;
 	__syncthreads();
-	const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+	const double tot = (c.red[0] + c.red[1]) + (c.red[2] + c.red[3]);
 	__syncthreads();   // red and sw are reused by the next evaluation
 	return tot;
 }
@@ -90,8 +159,7 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a)
 	const int target = blockIdx.x;
 	const int tid = threadIdx.x;
 	const int n = a.n, H = a.height, W = a.width, P = H * W;
-	double* C = lds;
-	double* kn = C + (size_t)n * n;
+	double* kn = lds;
 	double* kny = kn + n + 4;
 	double* img = kny + n + 4;                // [P]
 	double* wgt = img + P;                    // [P]
@@ -100,10 +168,12 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a)
 	double* xt = fsim + (kMaxDim + 1);        // trial points: xbar, xr, xe / xc [3][kMaxDim]
 	double* x0 = xt + 3 * kMaxDim;            // warm start [kMaxDim]
 	double* red = x0 + kMaxDim;               // [8]
-	StarW* sw = reinterpret_cast<StarW*>(red + 8);
-	const double* cg = a.coef + (int64_t)target * n * n;
-	for (int i = tid; i < n * n; i += kThreads) C[i] = cg[i];
+	double* Kc = red + 8;                     // [kPool][kItems][25] cached polynomial coefficients
+	StarW* sw = reinterpret_cast<StarW*>(Kc + (size_t)kPool * kItems * 25);
+	int* keys = reinterpret_cast<int*>(sw + kMaxPsfStars);   // [kPool][2]
 	for (int i = tid; i < n + 4; i += kThreads) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
+	if (tid < kMaxPsfStars) { sw[tid].rebuild = 0; sw[tid].valid = 0; sw[tid].slot = 0; sw[tid].next = 0; }
+	if (tid < 2 * kPool) keys[tid] = -0x7fffffff;
 	const int64_t s0 = a.star_offsets[target];
 	int ns = (int)(a.star_offsets[target + 1] - s0);
 	if (ns > kMaxPsfStars) ns = kMaxPsfStars;
@@ -119,7 +189,10 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a)
 		if (tid == 0) a.status[target] = TP_STATUS_ERROR;
 		return;
 	}
-#define EVAL(xp) likelihood((xp), ns, C, kn, kny, n, h, hy, img, wgt, H, W, a.cutoff, sw, red)
+	EvalCtx ec;
+	ec.ns = ns; ec.n = n; ec.H = H; ec.W = W; ec.h = h; ec.hy = hy; ec.cutoff = a.cutoff;
+	ec.Cg = a.coef + (int64_t)target * n * n; ec.kn = kn; ec.kny = kny; ec.img = img; ec.wgt = wgt; ec.sw = sw; ec.Kc = Kc; ec.red = red; ec.keys = keys;
+#define EVAL(xp) likelihood((xp), ec)
 	for (int k = 0; k < a.n_cad; ++k) {
 		// ---- the cadence's image and weight map (float32 arithmetic of psf_photometry.py:75-86)
 		const float* ip = a.images + (int64_t)target * P * a.t_pitch + k;
@@ -266,28 +339,12 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a)
 		double flux_ap = 0.0;
 		if (success) {
 			// residuals in the mini aperture: one more model evaluation at the solution
-			if (tid < ns) {
-				StarW& s = sw[tid];
-				s.row = sim[3 * tid]; s.col = sim[3 * tid + 1]; s.flux = sim[3 * tid + 2];
-				axis_weights(kn, n, s.col, h, s.mx, s.ax0);
-				axis_weights(kny, n, s.row, hy, s.my, s.by0);
-			}
-			__syncthreads();
+			prepare_stars(sim, ec);
 			double acc = 0.0;
 			for (int p = tid; p < P; p += kThreads) {
 				if (!mini[p]) continue;
 				const int i = p / W, j = p - i * W;
-				double mdl = 0.0;
-				for (int s = 0; s < ns; ++s) {
-					const double dc = (double)j - sw[s].col, dr = (double)i - sw[s].row;
-					if (sqrt(dc * dc + dr * dr) < a.cutoff) {
-						int ax = sw[s].ax0 + 9 * j, by = sw[s].by0 + 9 * i;
-						ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
-						by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
-						mdl += sw[s].flux * ((h * hy) * prf_pixel(C, n, ax, by, sw[s].mx, sw[s].my));
-					}
-				}
-				const double r = img[p] - mdl;
+				const double r = img[p] - model_pixel(i, j, ec);
 				if (r == r) acc += r;
 			}
 #pragma unroll
@@ -326,14 +383,14 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 	TP_REQUIRE(ctx, d_images && d_coef && d_knots_x && d_knots_y && d_star_offsets && d_params0 && d_mini_aperture, "tp_psf_fit: null input pointer");
 	TP_REQUIRE(ctx, d_flux && d_flux_err && d_centroid_row && d_centroid_col && d_status, "tp_psf_fit: null output pointer");
 	TP_REQUIRE(ctx, out_pitch >= desc->n_cad, "tp_psf_fit: out_pitch < n_cad");
-	TP_REQUIRE(ctx, n_coef_axis >= 32 && n_coef_axis <= 140, "tp_psf_fit: coefficient table must be 32..140 per axis (LDS resident)");
+	TP_REQUIRE(ctx, n_coef_axis >= 32 && n_coef_axis <= 140, "tp_psf_fit: coefficient table must be 32..140 per axis");
 	TP_REQUIRE(ctx, cutoff_radius > 0 && cutoff_radius <= 5.25, "tp_psf_fit: cutoff_radius must be in (0, 5.25] (uniform-knot region of the PRF spline)");
 	TP_REQUIRE(ctx, maxiter_first >= 1 && maxiter >= 1, "tp_psf_fit: bad iteration limits");
 	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
 	const size_t P = (size_t)desc->height * desc->width;
-	const size_t doubles = (size_t)n_coef_axis * n_coef_axis + 2 * ((size_t)n_coef_axis + 4) + 2 * P + (kMaxDim + 1) * kMaxDim + (kMaxDim + 1)
-		+ 3 * kMaxDim + kMaxDim + 8;
-	const size_t shmem = doubles * sizeof(double) + kMaxPsfStars * sizeof(StarW) + 16;
+	const size_t doubles = 2 * ((size_t)n_coef_axis + 4) + 2 * P + (kMaxDim + 1) * kMaxDim + (kMaxDim + 1)
+		+ 3 * kMaxDim + kMaxDim + 8 + (size_t)kPool * kItems * 25;
+	const size_t shmem = doubles * sizeof(double) + kMaxPsfStars * sizeof(StarW) + 2 * kPool * sizeof(int) + 16;
 	TP_REQUIRE(ctx, shmem <= 160 * 1024, "tp_psf_fit: stamp too large for the LDS-resident image and weight map");
 	PsfArgs a;
 	a.images = d_images; a.backgrounds = d_backgrounds; a.n_cad = desc->n_cad; a.height = desc->height; a.width = desc->width; a.t_pitch = desc->t_pitch;
