@@ -37,34 +37,47 @@ def assemble_gathered(blocks, sizes, n_columns=5):
 	return np.concatenate(parts, axis=1) if parts else np.zeros((n_columns, 0, 0))
 
 
-def replay_skip_targets(starids, tmags, skip_lists, statuses):
+def replay_skip_targets(starids, tmags, skip_lists, statuses, priorities=None, return_ran=False):
 	"""
-	The one cross-target dependency of the reference: ``skip_targets`` bookkeeping done by the
-	master on gathered results (AperturePhotometry/photometry.py:244-250 ->
-	taskmanager.py:460-532).  Results are replayed in priority order (ascending Tmag,
-	todolist.py:584): a target that is named in the skip list of an already accepted brighter
-	target is marked SKIPPED (5); if the *other* star is the brighter one, the current target is.
+	The one cross-target dependency of the reference: the ``skip_targets`` bookkeeping the master does on the results it
+	receives (AperturePhotometry/photometry.py:269-272 -> taskmanager.py:460-532), replayed for one gathered batch (one
+	sector / camera / CCD / cadence / datasource group) in the order the reference's task loop would have run it
+	(``get_task``: lowest priority whose status is still NULL, taskmanager.py:402; priority = ascending Tmag, todolist.py:584).
 
-	Simplified restatement of TaskManager.save_result's resolution for one batch: returns the new
-	int32 status array.
+	For the target being saved, the rows of the todo-list named in its skip list are looked up (names that are no targets
+	are ignored).  If there are any and the target is strictly brighter than ALL of them, every one of them becomes
+	SKIPPED (whatever it was before); otherwise the target itself becomes SKIPPED and the others are left alone.  A target
+	that is SKIPPED before its turn is never run, so its own skip list never takes effect.
+
+	``priorities`` defaults to the stable ascending-Tmag order.  Returns the int32 status array; with ``return_ran`` also the
+	indices of the targets that ran, in that order.
+	Pinned by ``tests/golden/golden_skiptargets.npz`` (the reference's own TaskManager on sqlite todo-lists).
 	"""
-	order = np.argsort(np.asarray(tmags), kind='stable')
-	status = np.array(statuses, dtype='int32', copy=True)
-	index_of = {int(s): i for i, s in enumerate(starids)}
-	tm = np.asarray(tmags)
+	tm = np.asarray(tmags, dtype='float64')
+	n = len(tm)
+	if priorities is None:
+		order = np.argsort(tm, kind='stable')
+	else:
+		order = np.argsort(np.asarray(priorities), kind='stable')
+	rows_of = {}
+	for i, s in enumerate(starids):
+		rows_of.setdefault(int(s), []).append(i)
+	SKIPPED = 5
+	final = np.zeros(n, dtype='int32') # 0 = status IS NULL
+	ran = []
 	for i in order:
-		if status[i] not in (1, 3):
-			continue
-		for other in skip_lists[i]:
-			j = index_of.get(int(other))
-			if j is None or status[j] == 5:
-				continue
-			if tm[j] >= tm[i]:
-				status[j] = 5 # the fainter star inside our mask is skipped
+		if final[i] != 0:
+			continue # marked by an earlier result: get_task no longer hands it out
+		ran.append(int(i))
+		mine = int(statuses[i])
+		rows = [j for s in set(int(x) for x in skip_lists[i]) for j in rows_of.get(s, ())]
+		if rows:
+			if np.all(tm[i] < tm[rows]):
+				final[rows] = SKIPPED
 			else:
-				status[i] = 5 # we sit inside the mask of a brighter star
-				break
-	return status
+				mine = SKIPPED
+		final[i] = mine
+	return (final, ran) if return_ran else final
 
 
 # ---- RCCL ------------------------------------------------------------------------------------

@@ -24,6 +24,8 @@ Fixtures:
                           (linpsf_photometry.py:22-34, 79-219)
 * ``golden_pixelflags.npz`` ``pixel_flags.pixel_manual_exclude`` (pixel_flags.py:13-58) on header / data cases
 * ``golden_timeoffset.npz`` ``fixes.time_offset`` (fixes/time_offset.py:64-180) on header cases
+* ``golden_skiptargets.npz`` ``TaskManager.get_task / start_task / save_result`` (taskmanager.py:391-532) on sqlite todo-lists with
+                          prescribed outcomes: the master-side skip-target resolution
 * ``golden_psfphot.npz``  ``PSFPhotometry.do_photometry`` (psf_photometry.py:111-196): Nelder-Mead fits of (row, column, flux)
                           with the real ``scipy.optimize.minimize``, warm-started cadence by cadence
 * ``golden_cutout.npz``   ``BasePhotometry._load_cube`` FFI branch (BasePhotometry.py:720-742) on a small frame stack
@@ -753,7 +755,73 @@ def golden_psfphot():
 	np.savez_compressed(os.path.join(HERE, 'golden_psfphot.npz'), **out)
 
 
+#--------------------------------------------------------------------------------------------------
+def golden_skiptargets():
+	"""The master-side skip-target bookkeeping: the reference's own TaskManager (get_task -> start_task -> save_result,
+	taskmanager.py:391-532) driven as run_tessphot.py:139-166 drives it, on sqlite todo-lists with prescribed photometry outcomes."""
+	import sqlite3
+	import tempfile
+	import logging
+	from photometry.taskmanager import TaskManager
+	logging.getLogger('photometry.taskmanager').setLevel(logging.ERROR)
+	rng = np.random.default_rng(77)
+	out = {}
+	n_cases = 60
+	for c in range(n_cases):
+		n = int(rng.integers(2, 13))
+		starids = rng.choice(np.arange(1000, 1100), size=n, replace=False).astype('int64')
+		tmags = np.round(rng.uniform(6.0, 9.0, size=n), 1 if c % 3 else 2)   # one decimal: ties are common
+		# priority = ascending Tmag as todolist.py:584 makes it (stable), or (every fourth case) an arbitrary order
+		order = np.argsort(tmags, kind='stable') if c % 4 else rng.permutation(n)
+		priority = np.empty(n, dtype='int64')
+		priority[order] = np.arange(1, n + 1)
+		statuses = rng.choice([1, 1, 1, 3, 2], size=n).astype('int32')
+		skip_lists = []
+		for i in range(n):
+			k = int(rng.integers(0, 4)) if rng.random() < 0.6 else 0
+			pool = np.concatenate([starids[np.arange(n) != i], [999999]]) if c % 5 else np.concatenate([starids, [999999]])
+			skip_lists.append(sorted(int(x) for x in rng.choice(pool, size=min(k, len(pool)), replace=False)))
+		with tempfile.TemporaryDirectory() as tmp:
+			todo = os.path.join(tmp, 'todo.sqlite')
+			conn = sqlite3.connect(todo)
+			# the table of todolist.py:605-617
+			conn.execute("""CREATE TABLE todolist (priority INTEGER PRIMARY KEY ASC NOT NULL, starid INTEGER NOT NULL, sector INTEGER NOT NULL,
+				datasource TEXT NOT NULL DEFAULT 'ffi', camera INTEGER NOT NULL, ccd INTEGER NOT NULL, cadence INTEGER NOT NULL,
+				method TEXT DEFAULT NULL, tmag REAL, status INTEGER DEFAULT NULL, cbv_area INTEGER NOT NULL);""")
+			for i in range(n):
+				conn.execute("INSERT INTO todolist (priority,starid,sector,datasource,camera,ccd,cadence,tmag,cbv_area) VALUES (?,?,?,?,?,?,?,?,?);",
+					(int(priority[i]), int(starids[i]), 1, 'ffi', 1, 1, 1800, float(tmags[i]), 111))
+			conn.commit()
+			conn.close()
+			ran = []
+			with TaskManager(todo, overwrite=False, cleanup=False, summary=None, backup_interval=None) as tm:
+				while True:
+					task = tm.get_task()
+					if task is None:
+						break
+					tm.start_task(task['priority'])
+					i = int(np.flatnonzero(priority == task['priority'])[0])
+					ran.append(i)
+					result = dict(task)
+					result.update({'status': STATUS(int(statuses[i])), 'method_used': 'aperture', 'time': 1.0,
+						'details': {'skip_targets': list(skip_lists[i])} if skip_lists[i] else {}})
+					tm.save_result(result)
+				tm.cursor.execute("SELECT priority,status FROM todolist ORDER BY priority;")
+				final = {int(r['priority']): r['status'] for r in tm.cursor.fetchall()}
+		out[f's{c}_starid'] = starids
+		out[f's{c}_tmag'] = tmags
+		out[f's{c}_priority'] = priority
+		out[f's{c}_status_in'] = statuses
+		out[f's{c}_skip_offsets'] = np.cumsum([0] + [len(s) for s in skip_lists]).astype('int64')
+		out[f's{c}_skip_flat'] = np.array([x for s in skip_lists for x in s], dtype='int64')
+		out[f's{c}_status_out'] = np.array([final[int(p)] for p in priority], dtype='int32')
+		out[f's{c}_ran'] = np.array(ran, dtype='int64')
+	out['n_cases'] = n_cases
+	np.savez_compressed(os.path.join(HERE, 'golden_skiptargets.npz'), **out)
+	print('skiptargets:', n_cases, 'todo-lists')
+
+
 if __name__ == '__main__':
-	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics', 'cutout', 'background', 'psfphot', 'pixelflags', 'timeoffset']
+	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics', 'cutout', 'background', 'psfphot', 'pixelflags', 'timeoffset', 'skiptargets']
 	for w in which:
 		globals()['golden_' + w]()

@@ -147,6 +147,24 @@ def test_replay_skip_targets():
 	assert list(st) == [1, 5, 2, 1] # 11 lies in the mask of the brighter 10 -> 11 is skipped
 
 
+def test_replay_skip_targets_golden():
+	"""The replay against the reference's own TaskManager (get_task / start_task / save_result on sqlite todo-lists,
+	tests/golden/make_golden.py:golden_skiptargets): final statuses and the order in which targets ran, 60 todo-lists with
+	Tmag ties, arbitrary priorities, self-references and names that are no targets."""
+	import os
+	g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'golden_skiptargets.npz'))
+	n_skipped = 0
+	for c in range(int(g['n_cases'])):
+		off, flat = g[f's{c}_skip_offsets'], g[f's{c}_skip_flat']
+		skip = [list(flat[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+		st, ran = tpcomm.replay_skip_targets(g[f's{c}_starid'], g[f's{c}_tmag'], skip, g[f's{c}_status_in'],
+			priorities=g[f's{c}_priority'], return_ran=True)
+		np.testing.assert_array_equal(st, g[f's{c}_status_out'], err_msg=f'case {c}')
+		assert ran == list(g[f's{c}_ran']), c
+		n_skipped += int((st == 5).sum())
+	assert n_skipped > 100
+
+
 def test_time_offset_applied_from_source_header(tmp_path):
 	"""A source that carries the file header gets the early-release timestamp fix (BasePhotometry.py:244) -- no GPU needed."""
 	from photometry_amd import simulate
