@@ -231,3 +231,66 @@ def read(path):
 		pos += len(_pad(raw)) if nbytes else 0
 		out.append((header, data))
 	return out
+
+
+#--------------------------------------------------------------------------------------------------
+# TDB -> UTC calendar strings for DATE-OBS / DATE-END (astropy ``Time(..., scale='tdb').utc.isot``, BasePhotometry.py:1607-1629)
+#--------------------------------------------------------------------------------------------------
+#: (first MJD of validity, TAI - UTC in seconds): the leap seconds since 1972 (IERS Bulletin C; none after 2017-01-01)
+_LEAP_SECONDS = ((41317, 10), (41499, 11), (41683, 12), (42048, 13), (42413, 14), (42778, 15), (43144, 16), (43509, 17), (43874, 18),
+	(44239, 19), (44786, 20), (45151, 21), (45516, 22), (46247, 23), (47161, 24), (47892, 25), (48257, 26), (48804, 27), (49169, 28),
+	(49534, 29), (50083, 30), (50630, 31), (51179, 32), (53736, 33), (54832, 34), (56109, 35), (57204, 36), (57754, 37))
+
+
+def _tai_minus_utc(mjd_utc):
+	dat = 10
+	for first, value in _LEAP_SECONDS:
+		if mjd_utc >= first:
+			dat = value
+	return dat
+
+
+def tdb_to_utc_isot(jd1, jd2=0.0):
+	"""
+	``'YYYY-MM-DDTHH:MM:SS.sss'`` (UTC) of the TDB Julian date ``jd1 + jd2``.
+
+	TT = TDB - (0.001657 sin g + 0.000014 sin 2g) s with g the Earth's mean anomaly (the two leading terms of the series
+	astropy / ERFA ``dtdb`` evaluate; the rest is below 30 microseconds, i.e. below the millisecond the string carries unless the
+	instant falls within that distance of a rounding boundary), TAI = TT - 32.184 s, UTC = TAI - leap seconds.
+	"""
+	# split into integer day number and seconds of day, keeping the precision of the two-part input
+	big, small = (jd1, jd2) if abs(jd1) >= abs(jd2) else (jd2, jd1)
+	day = np.floor(big + 0.5) # JD of the preceding midnight + 0.5, as an MJD-like integer below
+	frac = (big - (day - 0.5)) + small # days since that midnight (TDB)
+	mjd_day = int(day - 0.5 - 2400000.5 + 0.5) # = day - 2400001
+	g = np.deg2rad(357.53 + 0.98560028 * ((big - 2451545.0) + small))
+	sec = frac * 86400.0 - (0.001657 * np.sin(g) + 0.000014 * np.sin(2 * g)) - 32.184 # TAI seconds of the TDB day
+	# leap seconds: decide with the UTC day the instant falls into
+	sec_utc = sec - _tai_minus_utc(mjd_day)
+	while sec_utc < 0:
+		mjd_day -= 1
+		sec_utc = sec + 86400.0 * 1 - _tai_minus_utc(mjd_day)
+		sec += 86400.0
+	while sec_utc >= 86400.0:
+		mjd_day += 1
+		sec -= 86400.0
+		sec_utc = sec - _tai_minus_utc(mjd_day)
+	ms = int(np.floor(sec_utc * 1000.0 + 0.5))
+	if ms >= 86400000:
+		ms -= 86400000
+		mjd_day += 1
+	# civil date of the MJD (Fliegel & Van Flandern)
+	jdn = mjd_day + 2400001
+	a = jdn + 32044
+	b = (4 * a + 3) // 146097
+	c = a - 146097 * b // 4
+	d = (4 * c + 3) // 1461
+	e = c - 1461 * d // 4
+	m = (5 * e + 2) // 153
+	dd = e - (153 * m + 2) // 5 + 1
+	mm = m + 3 - 12 * (m // 10)
+	yy = 100 * b + d - 4800 + m // 10
+	hh, rem = divmod(ms, 3600000)
+	mi, rem = divmod(rem, 60000)
+	ss, ms = divmod(rem, 1000)
+	return f'{yy:04d}-{mm:02d}-{dd:02d}T{hh:02d}:{mi:02d}:{ss:02d}.{ms:03d}'

@@ -30,6 +30,8 @@ DEFAULT_SETTINGS = {'todolist': {'faint_limit': '15.0'}, 'fixes': {'time_offset'
 TESS_DEFAULT_BITMASK = engine.TESS_DEFAULT_BITMASK
 #: PixelQualityFlags.BackgroundShenanigans / CorrectorQualityFlags.BackgroundShenanigans (photometry/quality.py:163, :85)
 PIXEL_BACKGROUND_SHENANIGANS = 4
+#: PROCVER card of the light-curve files this package writes
+PROCVER = 'photometry_amd-0.2'
 CORRECTOR_BACKGROUND_SHENANIGANS = 256
 
 
@@ -150,7 +152,14 @@ class BasePhotometry(object):
 
 		self._settings = None
 		tgt = src.target(starid)
-		self.target = {'tmag': tgt['tmag']}
+		# tmag plus, when the source knows them, the catalogue properties the light-curve file carries (BasePhotometry.py:416-438)
+		self.target = {k: v for k, v in tgt.items() if k not in ('starid', 'row', 'column')}
+		self.ticver = getattr(src, 'ticver', None)
+		#: header of the input file (BasePhotometry.py:262-270, :330): cosmic-ray mitigation keywords, DATA_REL, NUM_FRM
+		self.header = dict(getattr(src, 'header', None) or {})
+		self.data_rel = self.header.get('DATA_REL')
+		default_frames = 900 if datasource == 'ffi' else 60 # BasePhotometry.py:269, :372
+		self.num_frm = self.header.get('NUM_FRM', getattr(src, 'num_frm', None) or default_frames)
 		self.target_pos_row = tgt['row']
 		self.target_pos_column = tgt['column']
 		self._max_stamp = tuple(src.max_stamp)
@@ -459,8 +468,11 @@ class BasePhotometry(object):
 		not available here): primary header (:1463-1505), the ``LIGHTCURVE`` binary table with the 14 columns and their
 		units / display formats (:1507-1600), the time keywords of the table header (:1602-1641), the ``SUMIMAGE`` and
 		``APERTURE`` image extensions with bits 2 (photometry) and 8 (position) OR-ed into the aperture image (:1643-1665),
-		``CHECKSUM`` / ``DATASUM`` (:1720), the reference's file name (:1708-1717).  Not written: the WCS keywords of the
-		image extensions and ``DATE-OBS`` / ``DATE-END`` (astropy ``WCS`` / ``Time`` upstream).
+		``CHECKSUM`` / ``DATASUM`` (:1720), the reference's file name (:1708-1717).  Every card, comment, column definition and
+		array is pinned by ``tests/golden/golden_fitsfile.*`` (the reference's own function recorded card by card).
+		The WCS keywords of the image extensions come from the source (``wcs_header(stamp)``; the reference slices an astropy
+		``WCS``, :1659-1661); a source without one gets the stamp limits written instead (``STAMP_*``).  ``DATE-OBS`` /
+		``DATE-END`` are converted from TDB by :func:`fitsio.tdb_to_utc_isot`.
 		"""
 		import datetime
 		from . import fitsio
@@ -473,22 +485,28 @@ class BasePhotometry(object):
 			version = self.version
 		os.makedirs(output_folder, exist_ok=True)
 		cadence = int(self.cadence) if self.cadence else 1800
-		data_rel = int(getattr(self, 'data_rel', 0) or 0)
+		data_rel = int(self.data_rel or 0)
 		SumImage = np.asarray(self.sumimage, dtype='float64')
 		lc = self.lightcurve
 		# Background Shenanigans anywhere in the stamp at a timestamp -> CorrectorQualityFlags.BackgroundShenanigans (:1445-1449)
 		quality = np.zeros(len(lc['time']), dtype='int32')
 		quality[np.any(self.pixelflags_cube & PIXEL_BACKGROUND_SHENANIGANS != 0, axis=(0, 1))] |= CORRECTOR_BACKGROUND_SHENANIGANS
-		indx = np.isfinite(lc['time']) # :1451-1452
+		# timestamps without a defined time are dropped (:1451-1452); upstream leaves QUALITY at its full length there, which no
+		# table can hold -- it is cut to the same rows here
+		indx = np.isfinite(lc['time'])
 		quality = quality[indx]
 		col = {k: np.asarray(lc[k])[indx] for k in lc.keys()}
 		tgt = self.target
 		undef = fitsio.Undefined()
 
-		def opt(key):
-			v = tgt.get(key) if isinstance(tgt, dict) else None
+		def opt(key): # "undefined" card for a missing or zero value, as upstream writes it (:1487-1490)
+			v = tgt.get(key)
 			return undef if not v else v
-
+		if tgt.get('pm_ra') is None or tgt.get('pm_decl') is None:
+			pmtotal = undef
+		else:
+			pmtotal = np.sqrt(tgt['pm_ra']**2 + tgt['pm_decl']**2)
+		hdr = self.header
 		prim = [
 			card('NEXTEND', 3, 'number of standard extensions'), card('EXTNAME', 'PRIMARY', 'name of extension'),
 			card('ORIGIN', 'TASOC/Aarhus', 'institution responsible for creating this file'),
@@ -497,16 +515,21 @@ class BasePhotometry(object):
 			card('FILTER', 'TESS', 'Photometric bandpass filter'), card('OBJECT', f"TIC {self.starid:d}", 'string version of TICID'),
 			card('TICID', int(self.starid), 'unique TESS target identifier'), card('CAMERA', int(self.camera), 'Camera number'),
 			card('CCD', int(self.ccd), 'CCD number'), card('SECTOR', int(self.sector), 'Observing sector'),
-			card('PROCVER', 'photometry_amd-0.1', 'Version of photometry pipeline'), card('FILEVER', '1.5', 'File format version'),
-			card('DATA_REL', data_rel, 'Data release number'), card('VERSION', int(version), 'Version of the processing'),
+			card('PROCVER', PROCVER, 'Version of photometry pipeline'), card('FILEVER', '1.5', 'File format version'),
+			card('DATA_REL', self.data_rel, 'Data release number'), card('VERSION', int(version), 'Version of the processing'),
 			card('PHOTMET', self.method, 'Photometric method used'),
 			card('RADESYS', 'ICRS', 'reference frame of celestial coordinates'), card('EQUINOX', 2000.0, 'equinox of celestial coordinate system'),
-			card('RA_OBJ', opt('ra_J2000'), '[deg] Right ascension'), card('DEC_OBJ', opt('decl_J2000'), '[deg] Declination'),
+			card('RA_OBJ', tgt.get('ra_J2000'), '[deg] Right ascension'), card('DEC_OBJ', tgt.get('decl_J2000'), '[deg] Declination'),
 			card('PMRA', opt('pm_ra'), '[mas/yr] RA proper motion'), card('PMDEC', opt('pm_decl'), '[mas/yr] Dec proper motion'),
+			card('PMTOTAL', pmtotal, '[mas/yr] total proper motion'),
 			card('TESSMAG', float(tgt['tmag']), '[mag] TESS magnitude'), card('TEFF', opt('teff'), '[K] Effective temperature'),
+			card('TICVER', self.ticver, 'TESS Input Catalog version'),
+			card('CRMITEN', hdr.get('CRMITEN'), 'spacecraft cosmic ray mitigation enabled'),
+			card('CRBLKSZ', hdr.get('CRBLKSZ'), '[exposures] s/c cosmic ray mitigation block siz'),
+			card('CRSPOC', hdr.get('CRSPOC'), 'SPOC cosmic ray cleaning enabled'),
 		]
 		for key, value in self.additional_headers.items(): # K2P2 settings, AP_CONT, ... (:1497-1499)
-			if isinstance(value, tuple):
+			if isinstance(value, (tuple, list)):
 				prim.append(card(key, value[0], value[1] if len(value) > 1 else None))
 			else:
 				prim.append(card(key, value))
@@ -538,23 +561,30 @@ class BasePhotometry(object):
 			column('POS_CORR1', 'D', col['pos_corr'][:, 0], 'pixels', 'F14.7', 'column title: column position correction', 'column units: pixels'),
 			column('POS_CORR2', 'D', col['pos_corr'][:, 1], 'pixels', 'F14.7', 'column title: row position correction', 'column units: pixels'),
 		]
-		# time keywords (:1602-1641); without cosmic-ray mitigation information deadc = int_time / frametime
+		# time keywords (:1602-1641)
 		tdel = cadence / 86400
 		tstart = float(col['time'][0] - tdel/2) if n else float('nan')
 		tstop = float(col['time'][-1] + tdel/2) if n else float('nan')
 		telapse = tstop - tstart
 		frametime, int_time, readtime = 2.0, 1.98, 0.02
-		deadc = int_time / frametime
-		num_frm = int(round(cadence / frametime))
+		if hdr.get('CRMITEN'):
+			crblocksize = hdr['CRBLKSZ']
+			deadc = (int_time * (crblocksize-2)/crblocksize) / frametime
+		else:
+			deadc = int_time / frametime
+		num_frm = self.num_frm
+		bjdref = 2457000
 		tcards = [
 			card('INHERIT', True, 'inherit the primary header'),
 			card('TIMEREF', 'SOLARSYSTEM', 'barycentric correction applied to times'),
 			card('TIMESYS', 'TDB', 'time system is Barycentric Dynamical Time (TDB)'),
-			card('BJDREFI', 2457000, 'integer part of BTJD reference date'), card('BJDREFF', 0.0, 'fraction of the day in BTJD reference date'),
+			card('BJDREFI', bjdref, 'integer part of BTJD reference date'), card('BJDREFF', 0.0, 'fraction of the day in BTJD reference date'),
 			card('TIMEUNIT', 'd', 'time unit for TIME, TSTART and TSTOP'),
 			card('TSTART', tstart, 'observation start time in BTJD'), card('TSTOP', tstop, 'observation stop time in BTJD'),
-			card('MJD-BEG', tstart + 2457000 - 2400000.5, 'observation start time in MJD'),
-			card('MJD-END', tstop + 2457000 - 2400000.5, 'observation start time in MJD'),
+			card('DATE-OBS', fitsio.tdb_to_utc_isot(tstart, bjdref) if n else None, 'TSTART as UTC calendar date'),
+			card('DATE-END', fitsio.tdb_to_utc_isot(tstop, bjdref) if n else None, 'TSTOP as UTC calendar date'),
+			card('MJD-BEG', tstart + (bjdref - 2400000.5), 'observation start time in MJD'),
+			card('MJD-END', tstop + (bjdref - 2400000.5), 'observation start time in MJD'),
 			card('TELAPSE', telapse, '[d] TSTOP - TSTART'), card('LIVETIME', telapse*deadc, '[d] TELAPSE multiplied by DEADC'),
 			card('DEADC', deadc, 'deadtime correction'), card('EXPOSURE', telapse*deadc, '[d] time on source'),
 			card('XPOSURE', frametime*deadc*num_frm, '[s] Duration of exposure'),
@@ -568,15 +598,25 @@ class BasePhotometry(object):
 			mask[self.final_phot_mask] |= 2
 		if self.final_position_mask is not None:
 			mask[self.final_position_mask] |= 8
-		icards = [card('INHERIT', True, 'inherit the primary header'),
-			card('STAMP_R1', int(self._stamp[0]), 'first CCD row of the stamp'), card('STAMP_R2', int(self._stamp[1]), 'last CCD row + 1'),
-			card('STAMP_C1', int(self._stamp[2]), 'first CCD column of the stamp'), card('STAMP_C2', int(self._stamp[3]), 'last CCD column + 1')]
+		# image extensions: the WCS of the stamp (:1651-1661) when the source has one, then INHERIT
+		wcs_header = getattr(self.source, 'wcs_header', None)
+		if wcs_header is not None:
+			icards = [card(*c) for c in wcs_header(self._stamp)]
+		else:
+			icards = [card('STAMP_R1', int(self._stamp[0]), 'first CCD row of the stamp'), card('STAMP_R2', int(self._stamp[1]), 'last CCD row + 1'),
+				card('STAMP_C1', int(self._stamp[2]), 'first CCD column of the stamp'), card('STAMP_C2', int(self._stamp[3]), 'last CCD column + 1')]
+		icards.append(card('INHERIT', True, 'inherit the primary header'))
 		fname = (f'tess{self.starid:011d}-s{int(self.sector):03d}-{int(self.camera):d}-{int(self.ccd):d}-c{cadence:04d}'
 			f'-dr{data_rel:02d}-v{int(version):02d}-tasoc_lc.fits.gz')
 		path = os.path.join(output_folder, fname)
 		fitsio.write(path, [fitsio.primary_hdu(prim), fitsio.bintable_hdu('LIGHTCURVE', columns, tcards),
 			fitsio.image_hdu('SUMIMAGE', SumImage, icards), fitsio.image_hdu('APERTURE', mask, icards)])
-		self._details['filepath_lightcurve'] = os.path.relpath(path, os.path.abspath(self.output_folder_base)).replace('\\', '/')
+		# relative to the input folder when the output lies inside it, else to the base output folder (:1722-1726)
+		base = self.output_folder_base
+		inp = self.input_folder if isinstance(self.input_folder, (str, bytes, os.PathLike)) else None
+		if inp is not None and os.path.realpath(output_folder).startswith(os.path.realpath(inp)):
+			base = os.path.abspath(inp)
+		self._details['filepath_lightcurve'] = os.path.relpath(path, base).replace('\\', '/')
 		return path
 
 

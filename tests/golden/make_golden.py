@@ -26,6 +26,8 @@ Fixtures:
 * ``golden_timeoffset.npz`` ``fixes.time_offset`` (fixes/time_offset.py:64-180) on header cases
 * ``golden_skiptargets.npz`` ``TaskManager.get_task / start_task / save_result`` (taskmanager.py:391-532) on sqlite todo-lists with
                           prescribed outcomes: the master-side skip-target resolution
+* ``golden_fitsfile.json/.npz`` ``BasePhotometry.save_lightcurve`` (BasePhotometry.py:1417-1730) with a recording stand-in for
+                          astropy.io.fits: cards, comments, columns, arrays and file name of the FILEVER 1.5 light-curve file
 * ``golden_psfphot.npz``  ``PSFPhotometry.do_photometry`` (psf_photometry.py:111-196): Nelder-Mead fits of (row, column, flux)
                           with the real ``scipy.optimize.minimize``, warm-started cadence by cadence
 * ``golden_cutout.npz``   ``BasePhotometry._load_cube`` FFI branch (BasePhotometry.py:720-742) on a small frame stack
@@ -821,7 +823,224 @@ def golden_skiptargets():
 	print('skiptargets:', n_cases, 'todo-lists')
 
 
+#--------------------------------------------------------------------------------------------------
+class _RecUndefined(object):
+	pass
+
+
+class _RecHeader(object):
+	"""Records what save_lightcurve puts into a header: key -> [value, comment], in order of first appearance."""
+	def __init__(self, cards=None):
+		self.cards = dict(cards or {})
+		outer = self
+
+		class _Comments(object):
+			def __setitem__(self, key, comment):
+				outer.cards.setdefault(key, [None, None])[1] = comment
+		self.comments = _Comments()
+
+	def __setitem__(self, key, value):
+		if isinstance(value, tuple):
+			self.cards[key] = [value[0], value[1] if len(value) > 1 else None]
+		else:
+			self.cards.setdefault(key, [None, None])[0] = value
+
+	def set(self, key, value=None, comment=None, before=None, after=None):
+		self.cards[key] = [value, comment]
+
+	def copy(self):
+		return _RecHeader({k: list(v) for k, v in self.cards.items()})
+
+
+class _RecFits(object):
+	"""Stand-in for astropy.io.fits (not installable here) that records the calls of BasePhotometry.save_lightcurve."""
+	class card(object):
+		Undefined = _RecUndefined
+
+	class PrimaryHDU(object):
+		def __init__(self):
+			self.kind, self.name, self.header, self.data, self.columns = 'primary', 'PRIMARY', _RecHeader(), None, None
+
+	class Column(object):
+		def __init__(self, name=None, format=None, disp=None, unit=None, array=None, dim=None):
+			self.name, self.format, self.disp, self.unit, self.array, self.dim = name, format, disp, unit, np.asarray(array), dim
+
+	class BinTableHDU(object):
+		@classmethod
+		def from_columns(cls, columns, header=None, name=None):
+			self = cls()
+			self.kind, self.name, self.columns, self.data = 'bintable', name, list(columns), None
+			self.header = header.copy() if header is not None else _RecHeader()
+			for i, c in enumerate(columns, 1): # the keywords astropy derives from the column definitions
+				self.header[f'TTYPE{i}'] = c.name
+				self.header[f'TFORM{i}'] = c.format
+				if c.unit is not None:
+					self.header[f'TUNIT{i}'] = c.unit
+				if c.disp is not None:
+					self.header[f'TDISP{i}'] = c.disp
+			return self
+
+	class ImageHDU(object):
+		def __init__(self, data=None, header=None, name=None):
+			self.kind, self.name, self.data, self.columns = 'image', name, np.array(data, copy=True), None
+			self.header = header.copy() if header is not None else _RecHeader()
+
+	written = []
+
+	class HDUList(object):
+		def __init__(self, hdus):
+			self.hdus = list(hdus)
+
+		def __enter__(self):
+			return self
+
+		def __exit__(self, *a):
+			return False
+
+		def writeto(self, filepath, checksum=False, overwrite=False):
+			_RecFits.written.append({'filepath': filepath, 'checksum': checksum, 'hdus': self.hdus})
+
+
+class _RecTime(object):
+	"""astropy.time.Time is not installable: the four cards that need it (DATE-OBS, DATE-END, MJD-BEG, MJD-END) are recorded as
+	the (jd1, jd2, scale) they were asked for; the product's own conversion is pinned by known answers instead."""
+	def __init__(self, val, val2=0.0, format=None, scale=None):
+		self.jd1, self.jd2, self.format, self.scale = float(val), float(val2), format, scale
+
+	@property
+	def utc(self):
+		outer = self
+
+		class _U(object):
+			isot = f'UTC-ISOT-OF({outer.jd1!r},{outer.jd2!r},{outer.scale})'
+		return _U()
+
+	@property
+	def mjd(self):
+		return f'MJD-OF({self.jd1!r},{self.jd2!r},{self.scale})'
+
+
+class _RecWCS(object):
+	"""The WCS object only has to be sliced and turned into a header (BasePhotometry.py:1659-1661)."""
+	def __init__(self, sl=None):
+		self.sl = sl
+
+	def __getitem__(self, sl):
+		return _RecWCS(sl)
+
+	def to_header(self, relax=False):
+		h = _RecHeader()
+		h['WCSAXES'] = (2, 'Number of coordinate axes')
+		h['WCSSLICE'] = (repr([(s.start, s.stop) for s in self.sl]), 'stand-in: the slice the WCS was cut to')
+		return h
+
+
+class _RecTable(object):
+	"""The two things save_lightcurve does with the astropy Table: column access and boolean row selection."""
+	def __init__(self, cols):
+		self.cols = cols
+
+	def __getitem__(self, key):
+		if isinstance(key, str):
+			return self.cols[key]
+		return _RecTable({k: v[key] for k, v in self.cols.items()})
+
+
+def golden_fitsfile():
+	"""The reference's own BasePhotometry.save_lightcurve (BasePhotometry.py:1417-1730) with a recording stand-in for
+	astropy.io.fits: every header card (value + comment), column definition, array and the file name it produces."""
+	import json
+	import tempfile
+	bp = sys.modules['photometry.BasePhotometry']
+	rng = np.random.default_rng(5)
+	cases = []
+	arrays = {}
+	for c, (crmiten, pm, teff, cadence, nan_time) in enumerate([(True, (3.5, -4.25), 5777.0, 1800, False), (False, (None, None), None, 600, True)]):
+		T, H, W = 40, 7, 9
+		f = bp.BasePhotometry.__new__(bp.BasePhotometry)
+		time = 1325.3 + np.arange(T) * cadence / 86400
+		if nan_time:
+			time[[3, 17]] = np.nan
+		cols = {'time': time, 'timecorr': rng.normal(0, 1e-3, T).astype('float32'), 'cadenceno': (np.arange(T) + 4697).astype('int32'),
+			'flux': rng.normal(1e4, 30, T), 'flux_err': rng.uniform(5, 6, T), 'flux_background': rng.normal(900, 3, T),
+			'quality': rng.choice([0, 0, 0, 32, 4], T).astype('int32'), 'pos_centroid': rng.normal(300, 0.01, (T, 2)),
+			'pos_corr': rng.normal(0, 0.01, (T, 2))}
+		f.lightcurve = _RecTable({k: np.array(v) for k, v in cols.items()})
+		f._sumimage = rng.uniform(50, 500, (H, W))
+		flags = np.zeros((T, H, W), dtype='uint8')
+		flags[[5, 6, 30], 2, 3] = 4  # PixelQualityFlags.BackgroundShenanigans (quality.py:163)
+		flags[12, 4, 4] = 1 | 4
+		flags[20, 0, 0] = 1          # NotUsedForBackground: must not reach QUALITY
+		flags[9, 1, 1] = 2           # ManualExclude: must not reach QUALITY
+		bp.BasePhotometry.pixelflags = property(lambda self: iter(self._flags_for_test))
+		f._flags_for_test = flags
+		f.starid, f.camera, f.ccd, f.sector, f.data_rel, f.method = 260795451 + c, 3, 2, 14 + c, 5 + c, 'aperture'
+		f.version, f.cadence, f.num_frm, f.n_readout = 6, cadence, cadence // 2, int(cadence // 2 * 0.8)
+		f.ticver = 8
+		f.target = {'pm_ra': pm[0], 'pm_decl': pm[1], 'ra_J2000': 123.456789, 'decl_J2000': -45.678901, 'tmag': 9.875, 'teff': teff}
+		f.header = {'CRMITEN': crmiten, 'CRBLKSZ': 10, 'CRSPOC': False}
+		f.additional_headers = {'KP_SUBKG': (True, 'K2P2 subtract background?'), 'KP_THRES': (0.8, 'K2P2 sum-image threshold'), 'AP_CONT': (0.0125, 'AP contamination')}
+		f._aperture = rng.choice([1, 1 + 4, 1 + 32, 1 + 4 + 64], (H, W)).astype('int32')
+		bp.BasePhotometry.aperture = property(lambda self: self._aperture)
+		bp.BasePhotometry.sumimage = property(lambda self: self._sumimage)
+		f.final_phot_mask = np.zeros((H, W), dtype=bool)
+		f.final_phot_mask[2:5, 3:6] = True
+		f.final_position_mask = None if c else f.final_phot_mask.copy()
+		f.datasource = 'ffi'
+		f._stamp = (100, 100 + H, 200, 200 + W)
+		bp.BasePhotometry.wcs = property(lambda self: _RecWCS())
+		f._details = {}
+		inputs = {k: np.array(v) for k, v in cols.items()}
+		inputs.update(sumimage=f._sumimage.copy(), pixelflags=flags, aperture=f._aperture.copy(), final_phot_mask=f.final_phot_mask.copy())
+		if f.final_position_mask is not None:
+			inputs['final_position_mask'] = f.final_position_mask.copy()
+		with tempfile.TemporaryDirectory() as tmp:
+			f.input_folder = os.path.join(tmp, 'input')
+			f.output_folder_base = os.path.join(tmp, 'output')
+			f.output_folder = os.path.join(f.output_folder_base, 'sub')
+			_RecFits.written.clear()
+			old = bp.fits, bp.Time
+			bp.fits, bp.Time = _RecFits, _RecTime
+			try:
+				path = bp.BasePhotometry.save_lightcurve(f)
+			finally:
+				bp.fits, bp.Time = old
+		w = _RecFits.written[0]
+		assert w['checksum'] is True
+
+		def js(v):
+			if isinstance(v, _RecUndefined):
+				return {'undefined': True}
+			if isinstance(v, (bool, np.bool_)):
+				return bool(v)
+			if isinstance(v, (int, np.integer)):
+				return int(v)
+			if isinstance(v, (float, np.floating)):
+				return float(v)
+			return v
+		hdus = []
+		for h in w['hdus']:
+			d = {'kind': h.kind, 'name': h.name, 'cards': {k: [js(v[0]), v[1]] for k, v in h.header.cards.items()}}
+			if h.columns is not None:
+				d['columns'] = [{'name': col.name, 'format': col.format, 'disp': col.disp, 'unit': col.unit} for col in h.columns]
+				for col in h.columns:
+					arrays[f'c{c}_col_{col.name}'] = col.array
+			if h.data is not None:
+				arrays[f'c{c}_img_{h.name}'] = h.data
+			hdus.append(d)
+		cases.append({'filename': os.path.basename(path), 'details_filepath': f._details['filepath_lightcurve'], 'hdus': hdus,
+			'attrs': {'starid': int(f.starid), 'camera': f.camera, 'ccd': f.ccd, 'sector': f.sector, 'data_rel': f.data_rel, 'method': f.method,
+				'version': f.version, 'cadence': cadence, 'num_frm': f.num_frm, 'n_readout': f.n_readout, 'ticver': f.ticver, 'target': f.target,
+				'header': f.header, 'additional_headers': {k: list(v) for k, v in f.additional_headers.items()}, 'stamp': list(f._stamp)}})
+		for k, v in inputs.items():
+			arrays[f'c{c}_in_{k}'] = v
+	with open(os.path.join(HERE, 'golden_fitsfile.json'), 'w') as fh:
+		json.dump({'cases': cases}, fh, indent=1)
+	np.savez_compressed(os.path.join(HERE, 'golden_fitsfile.npz'), **arrays)
+	print('fitsfile:', len(cases), 'files;', [len(h['cards']) for h in cases[0]['hdus']], 'cards per HDU')
+
+
 if __name__ == '__main__':
-	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics', 'cutout', 'background', 'psfphot', 'pixelflags', 'timeoffset', 'skiptargets']
+	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics', 'cutout', 'background', 'psfphot', 'pixelflags', 'timeoffset', 'skiptargets', 'fitsfile']
 	for w in which:
 		globals()['golden_' + w]()

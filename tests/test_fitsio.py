@@ -50,3 +50,147 @@ def test_file_structure(tmp_path):
 	d = dict((c[:8].strip(), c[10:30].strip()) for c in cards if c[8:10] == '= ')
 	assert d['BITPIX'] == '-64' and d['NAXIS1'] == '3' and d['NAXIS2'] == '2'
 	assert np.frombuffer(raw[5760:5760 + 48], dtype='>f8').tolist() == [0, 1, 2, 3, 4, 5]
+
+
+def _raw_cards(path):
+	"""Independent of fitsio.read: {HDU index: {key: (value string, comment)}} straight from the 80-character cards."""
+	import gzip
+	blob = gzip.open(path, 'rb').read()
+	out, pos = [], 0
+	while pos < len(blob):
+		cards, done = {}, False
+		while not done:
+			block = blob[pos:pos + 2880].decode('ascii')
+			pos += 2880
+			for i in range(0, 2880, 80):
+				c = block[i:i + 80]
+				if c.startswith('END '):
+					done = True
+					break
+				if c[8:10] == '= ':
+					body = c[10:]
+					if body.lstrip().startswith("'"):
+						q = body.index("'")
+						e = q + 1
+						while True:
+							e = body.index("'", e)
+							if body[e + 1:e + 2] == "'":
+								e += 2
+								continue
+							break
+						val, rest = body[:e + 1].strip(), body[e + 1:]
+					else:
+						val, _, rest = body.partition('/')
+						val, rest = val.strip(), '/' + rest if _ else ''
+					cards[c[:8].strip()] = (val, rest.strip()[1:].strip() if rest.strip().startswith('/') else None)
+		out.append(cards)
+		naxis = int(cards.get('NAXIS', ('0',))[0])
+		n = abs(int(cards['BITPIX'][0])) // 8 if naxis else 0
+		for a in range(1, naxis + 1):
+			n *= int(cards[f'NAXIS{a}'][0])
+		pos += (n + 2879) // 2880 * 2880
+	return out
+
+
+def test_save_lightcurve_against_reference_recording(tmp_path):
+	"""
+	The light-curve file of BasePhotometry.save_lightcurve against what the reference's own function produced
+	(tests/golden/make_golden.py:golden_fitsfile -- BasePhotometry.py:1417-1730 executed with a recording stand-in for
+	astropy.io.fits): every card the reference sets is here with the same value and comment, every column with the same
+	name / format / unit / display format / values, both images, the file name and the details entry.
+	Not compared: DATE (today), PROCVER (this package's own version string), the WCS stand-in cards, and the four cards that
+	need astropy's Time upstream (DATE-OBS / DATE-END: checked against known answers below; MJD-BEG / MJD-END: definition).
+	"""
+	import json
+	import os
+	from photometry_amd.plugins import BasePhotometry
+	from photometry_amd.source import MemoryStampSource
+	here = os.path.join(os.path.dirname(__file__), 'golden')
+	G = json.load(open(os.path.join(here, 'golden_fitsfile.json')))
+	A = np.load(os.path.join(here, 'golden_fitsfile.npz'))
+	for c, case in enumerate(G['cases']):
+		at = case['attrs']
+		inp = {k[len(f'c{c}_in_'):]: A[k] for k in A.files if k.startswith(f'c{c}_in_')}
+		T = len(inp['time'])
+		r1, r2, c1, c2 = at['stamp']
+		H, W = r2 - r1, c2 - c1
+		frames = {'images': np.zeros((H, W, T), 'float32'), 'images_err': np.zeros((H, W, T), 'float32'), 'backgrounds': np.zeros((H, W, T), 'float32'),
+			'pixel_flags': np.moveaxis(inp['pixelflags'], 0, -1)}
+		tgt = dict(at['target'])
+		src = MemoryStampSource(frames, r1, c1, inp['time'], inp['timecorr'], inp['cadenceno'], inp['quality'],
+			{'starid': np.array([at['starid']]), 'tmag': np.array([tgt['tmag']]), 'row': np.array([r1 + H / 2]), 'column': np.array([c1 + W / 2])},
+			sector=at['sector'], camera=at['camera'], ccd=at['ccd'], cadence=at['cadence'], n_readout=at['n_readout'])
+		src.header = dict(at['header'], DATA_REL=at['data_rel'], NUM_FRM=at['num_frm'], CAMERA=at['camera'], CCD=at['ccd'])
+		src.ticver = at['ticver']
+		src.target = lambda starid, _t=tgt, _r=r1 + H / 2, _c=c1 + W / 2: dict(_t, starid=starid, row=_r, column=_c)
+		src.wcs_header = lambda stamp: [('WCSAXES', 2, 'Number of coordinate axes')]
+		base = tmp_path / f'out{c}'
+		pho = BasePhotometry(at['starid'], src, str(base), datasource='ffi', version=at['version'])
+		pho.method = at['method']
+		pho._adopt_stamp(tuple(at['stamp']))
+		pho.output_folder = str(base / 'sub')
+		for k in ('time', 'flux', 'flux_err', 'flux_background', 'pos_centroid', 'pos_corr'):
+			pho.lightcurve[k] = inp[k]
+		pho._sumimage = inp['sumimage']
+		pho._aperture = inp['aperture'].copy()
+		pho.final_phot_mask = inp['final_phot_mask']
+		pho.final_position_mask = inp.get('final_position_mask')
+		pho.additional_headers = {k: tuple(v) for k, v in at['additional_headers'].items()}
+		path = pho.save_lightcurve()
+		pho.close()
+		assert os.path.basename(path) == case['filename']
+		assert pho._details['filepath_lightcurve'] == case['details_filepath']
+
+		hdus = fitsio.read(path)
+		raw = _raw_cards(path)
+		assert [h.get('EXTNAME') for h, _ in hdus] == ['PRIMARY', 'LIGHTCURVE', 'SUMIMAGE', 'APERTURE']
+		assert all(h['__checksum_ok__'] and h['__datasum_ok__'] for h, _ in hdus)
+		skip = {'DATE', 'PROCVER', 'WCSSLICE', 'DATE-OBS', 'DATE-END', 'MJD-BEG', 'MJD-END'}
+		n_cards = 0
+		for (hdr, data), cards, ref in zip(hdus, raw, case['hdus']):
+			for key, (value, comment) in ref['cards'].items():
+				if key == 'WCSSLICE': # stand-in card recording the slice the reference cut its WCS to: the stamp
+					assert value == repr([(r1, r2), (c1, c2)])
+					continue
+				assert key in hdr, (ref['name'], key)
+				if key in skip:
+					continue
+				if isinstance(value, dict): # fits.card.Undefined()
+					assert hdr[key] is None and cards[key][0] == '', (key, hdr[key])
+				elif isinstance(value, float):
+					assert hdr[key] == value, (key, hdr[key], value) # repr round trip: exact
+				else:
+					assert hdr[key] == value and type(hdr[key]) is type(value), (key, hdr[key], value)
+				if comment is not None:
+					# a card holds 80 characters: long comments are cut there, as astropy cuts them
+					assert cards[key][1] is not None and comment.startswith(cards[key][1]) and len(cards[key][1]) >= min(len(comment), 30), (key, cards[key], comment)
+				n_cards += 1
+			if 'columns' in ref:
+				keep = np.isfinite(inp['time'])
+				for i, col in enumerate(ref['columns'], 1):
+					assert hdr[f'TTYPE{i}'] == col['name'] and hdr[f'TFORM{i}'].strip() == col['format']
+					assert hdr.get(f'TUNIT{i}') == col['unit'] and hdr.get(f'TDISP{i}') == col['disp']
+					want = A[f'c{c}_col_{col["name"]}']
+					if len(want) != int(keep.sum()): # upstream leaves QUALITY uncut when it drops the undefined timestamps
+						assert col['name'] == 'QUALITY'
+						want = want[keep]
+					np.testing.assert_array_equal(data[col['name']], want, err_msg=col['name'])
+				assert hdr['TFIELDS'] == len(ref['columns']) and hdr['NAXIS2'] == int(keep.sum())
+			if ref['kind'] == 'image':
+				np.testing.assert_array_equal(data, A[f'c{c}_img_{ref["name"]}'])
+				assert data.dtype == A[f'c{c}_img_{ref["name"]}'].dtype
+		assert n_cards > 100
+		lch = hdus[1][0]
+		assert lch['MJD-BEG'] == lch['TSTART'] + 56999.5 and lch['MJD-END'] == lch['TSTOP'] + 56999.5
+		assert lch['DATE-OBS'] == fitsio.tdb_to_utc_isot(lch['TSTART'], 2457000) and lch['DATE-OBS'].startswith('2018-07-2')
+
+
+def test_tdb_to_utc_known_answers():
+	"""J2000.0 (TT) = 2000-01-01T11:58:55.816 UTC; the leap second at the end of 2016; TAI - UTC = 37 s afterwards."""
+	assert fitsio.tdb_to_utc_isot(2451545.0) == '2000-01-01T11:58:55.816'
+	assert fitsio.tdb_to_utc_isot(2451545.0, 0.0) == fitsio.tdb_to_utc_isot(0.0, 2451545.0) == fitsio.tdb_to_utc_isot(2451544.5, 0.5)
+	assert fitsio.tdb_to_utc_isot(2457754.5, 69.184 / 86400) == '2017-01-01T00:00:00.000'
+	assert fitsio.tdb_to_utc_isot(2457754.5, 68.0 / 86400) == '2016-12-31T23:59:59.816' # one second of TT earlier: the leap second absorbs it
+	assert fitsio.tdb_to_utc_isot(2457754.5, 0.0).startswith('2016-12-31T23:58:51.81')
+	# TESS sector 1: TT - UTC = 69.184 s, TDB - TT = -0.56 ms on that day
+	assert fitsio.tdb_to_utc_isot(1325.0, 2457000) == '2018-07-25T11:58:50.817'
