@@ -576,10 +576,17 @@ def leg_stages(ctx, scene, cubes, batch, work, args, Nt, T, H, W, np, engine, pi
 			engine.cut_stamps(ctx, frames, cst, H, W, 0, 44, out=scratch)
 		ctx.sync()
 		r = ctx.profile_report()['tp_cut_stamps_kernel']
-		nb = Nt * 2*P*T*4
+		# necessary bytes: every frame pixel that lies in some stamp read once + every cube element written once (stamps overlap:
+		# SURVEY 8d's 2 P T 4 per target counts a shared pixel once per stamp and is kept as the side figure)
+		covered = np.zeros((FR, FR), dtype=bool)
+		for a, b in zip(r0, c0):
+			covered[a:a + H, b:b + W] = True
+		nb = int(covered.sum()) * T * 4 + Nt * P*T*4
 		out['cutout'] = {'what': f'stamp cutter: {Nt} stamps cut from a {FR} x {FR} x {T} float32 frame stack resident in HBM '
-			'(BasePhotometry._load_cube for the batch), one cube', 'kernel': 'tp_cut_stamps_kernel', 'avg_ms': r[1] / r[0],
-			'necessary_bytes_per_launch': nb, 'necessary_GBps': nb / (r[1] / r[0] * 1e-3) / 1e9, 'frac_of_hbm_peak': nb / (r[1] / r[0] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+			'(BasePhotometry._load_cube for the batch), one cube; frame-tile-major: tiles of 2 x 64 pixels x 64 frames through LDS, '
+			'stamps served from the tile', 'kernel': 'tp_cut_stamps_kernel (binning passes + tp_cut_tiles_kernel)', 'avg_ms': r[1] / r[0],
+			'necessary_bytes_per_launch': nb, 'necessary_GBps': nb / (r[1] / r[0] * 1e-3) / 1e9, 'frac_of_hbm_peak': nb / (r[1] / r[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+			'distinct_frame_pixels_in_stamps': int(covered.sum()), 'survey_8d_bytes_per_launch': Nt * 2*P*T*4}
 		frames.free()
 	ctx.profile(False)
 	return out

@@ -16,7 +16,19 @@
 // HBM-bound: algorithmic bytes per target = 2 * P * T * 4 (read + write); the reads are 60-byte segments of 8 KiB
 // frame rows, so the real fetch traffic is about twice the algorithmic one (whole 128-byte lines).
 // Pixels outside the frame (the reference never produces such stamps: it clips them, BasePhotometry.py:643-679) are NaN.
+//
+// Dense batches (round 2): the FRAME-TILE-MAJOR path.  With thousands of stamps per CCD the per-stamp gather above fetches
+// every 60-byte row piece as one or two whole 128-byte lines -- 36 GB for the 11.7 GB of a 10 k-stamp cube on a 2048 x 2048
+// stack, more than the stack itself (21.8 GB) -- and on crowded fields the same pixels many times over.  The tile-major
+// path turns the transposition around: the frame is cut into tiles of 2 rows x 64 columns; a binning pre-pass (three small
+// kernels: count, scan, fill; no host round trip) lists the stamps that touch each tile; one 256-thread workgroup per (tile,
+// block of 64 cadences) loads the tile of those 64 frames with fully coalesced 256-byte row segments into LDS
+// ([cadence][pixel], stride 129 floats) and then serves every stamp of its list from LDS: one wavefront instruction stores the
+// 64 cadences of one stamp pixel (256 B contiguous in the cube).  Every frame pixel is read from HBM once, whatever the
+// number of stamps that contain it, and never as a partial line.  Tiles without stamps exit at once.
 #include "common.h"
+
+void* tp_ctx_scratch(tp_ctx* ctx, size_t bytes); // aperture.hip
 
 namespace {
 
@@ -88,6 +100,142 @@ __global__ __launch_bounds__(256) void tp_cut_stamps_kernel(CutArgs a, int band_
 	}
 }
 
+
+//--------------------------------------------------------------------------------------------------
+// frame-tile-major path
+//--------------------------------------------------------------------------------------------------
+constexpr int kTileRows = 2, kTileCols = 64, kTilePix = kTileRows * kTileCols;
+constexpr int kTileLd = kTilePix + 1;   // LDS stride of one cadence: odd, so that the transposed reads are conflict-free
+
+struct TileGeom { int tiles_x, tiles_y; };
+
+// range of tiles a stamp touches (clipped to the frame); empty if the stamp lies outside
+__device__ __forceinline__ bool stamp_tiles(const CutArgs& a, int target, int& ty0, int& ty1, int& tx0, int& tx1)
+{
+	const int r0 = a.stamps[target * 4 + 0] - a.row_offset, c0 = a.stamps[target * 4 + 2] - a.col_offset;
+	const int ra = r0 > 0 ? r0 : 0, rb = (r0 + a.height < a.frame_rows) ? (r0 + a.height) : a.frame_rows;
+	const int ca = c0 > 0 ? c0 : 0, cb = (c0 + a.width < a.frame_cols) ? (c0 + a.width) : a.frame_cols;
+	if (ra >= rb || ca >= cb) return false;
+	ty0 = ra / kTileRows; ty1 = (rb - 1) / kTileRows; tx0 = ca / kTileCols; tx1 = (cb - 1) / kTileCols;
+	return true;
+}
+
+// pass 1 (FILL = false): count the stamps per tile; pass 3 (FILL = true): write the stamp indices at the scanned offsets.
+// Stamps that reach outside the frame get their cube filled with NaN first (count pass; the tiles only write what exists).
+template <bool FILL>
+__global__ __launch_bounds__(256) void tp_cut_bin_kernel(CutArgs a, TileGeom tg, int n_targets, int* __restrict__ count_or_cursor,
+	const int* __restrict__ offsets, int* __restrict__ items, int* __restrict__ outside)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n_targets) return;
+	int ty0, ty1, tx0, tx1;
+	const bool any = stamp_tiles(a, t, ty0, ty1, tx0, tx1);
+	if (!FILL) {
+		const int r0 = a.stamps[t * 4 + 0] - a.row_offset, c0 = a.stamps[t * 4 + 2] - a.col_offset;
+		outside[t] = (r0 < 0 || c0 < 0 || r0 + a.height > a.frame_rows || c0 + a.width > a.frame_cols) ? 1 : 0;
+	}
+	if (!any) return;
+	for (int ty = ty0; ty <= ty1; ++ty)
+		for (int tx = tx0; tx <= tx1; ++tx) {
+			const int tile = ty * tg.tiles_x + tx;
+			const int pos = atomicAdd(&count_or_cursor[tile], 1);
+			if (FILL) items[offsets[tile] + pos] = t;
+		}
+}
+
+// pass 2: exclusive scan of the per-tile counts (one workgroup; n + 1 outputs), cursors reset for the fill pass
+__global__ __launch_bounds__(1024) void tp_cut_scan_kernel(int* __restrict__ count, int* __restrict__ offsets, int n)
+{
+	__shared__ int part[1024];
+	const int tid = threadIdx.x;
+	const int per = (n + 1023) / 1024;
+	const int lo = tid * per, hi = (lo + per < n) ? (lo + per) : n;
+	int s = 0;
+	for (int i = lo; i < hi; ++i) s += count[i];
+	part[tid] = s;
+	__syncthreads();
+	for (int d = 1; d < 1024; d <<= 1) {
+		const int v = (tid >= d) ? part[tid - d] : 0;
+		__syncthreads();
+		part[tid] += v;
+		__syncthreads();
+	}
+	int run = part[tid] - s;
+	for (int i = lo; i < hi; ++i) { const int c = count[i]; offsets[i] = run; run += c; count[i] = 0; }
+	if (tid == 1023) offsets[n] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void tp_cut_nanfill_kernel(CutArgs a, const int* __restrict__ outside)
+{
+	const int target = blockIdx.x;
+	if (!outside[target]) return;
+	float* out = a.cube + (int64_t)target * a.height * a.width * a.t_pitch;
+	const int64_t n = (int64_t)a.height * a.width * a.t_pitch;
+	const float nan = __builtin_nanf("");
+	for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
+		if ((int)(i % a.t_pitch) < a.n_frames) out[i] = nan;
+}
+
+__global__ __launch_bounds__(256) void tp_cut_tiles_kernel(CutArgs a, TileGeom tg, const int* __restrict__ offsets, const int* __restrict__ items)
+{
+	__shared__ float tile[kCadBlock * kTileLd];
+	const int tile_id = blockIdx.x;
+	const int first = offsets[tile_id], last = offsets[tile_id + 1];
+	if (first == last) return;                       // no stamp touches this tile
+	const int k0 = blockIdx.y * kCadBlock;
+	const int tid = threadIdx.x;
+	const int lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int ty = tile_id / tg.tiles_x, tx = tile_id - ty * tg.tiles_x;
+	const int tr0 = ty * kTileRows, tc0 = tx * kTileCols;
+	// ---- load: segment = (cadence, tile row), one 256-byte row segment per wavefront instruction, all 32 of a wavefront in flight
+	const int col = tc0 + lane;
+	const bool col_ok = col < a.frame_cols;
+	constexpr int SEG = kCadBlock * kTileRows;       // 128 segments, 32 per wavefront
+	constexpr int U = SEG / 4;
+	{
+		float v[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int sidx = wave + 4 * u;
+			const int kk = sidx / kTileRows, rr = sidx % kTileRows;
+			const bool ok = col_ok && (k0 + kk < a.n_frames) && (tr0 + rr < a.frame_rows);
+			const int64_t off = ok ? ((int64_t)(k0 + kk) * a.frame_stride + (int64_t)(tr0 + rr) * a.row_pitch + col) : 0;
+			v[u] = a.frames[off];
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int sidx = wave + 4 * u;
+			const int kk = sidx / kTileRows, rr = sidx % kTileRows;
+			tile[kk * kTileLd + rr * kTileCols + lane] = v[u];
+		}
+	}
+	__syncthreads();
+	// ---- serve the stamps of this tile: a wavefront stores the 64 cadences of one stamp pixel per instruction
+	const bool k_ok = k0 + lane < a.n_frames;
+	const int P = a.height * a.width;
+	for (int it = first; it < last; ++it) {
+		const int target = __builtin_amdgcn_readfirstlane(items[it]);
+		const int r0 = a.stamps[target * 4 + 0] - a.row_offset, c0 = a.stamps[target * 4 + 2] - a.col_offset;
+		// overlap of the stamp with this tile (and the frame), in tile coordinates
+		int ra = r0 - tr0, rb = r0 + a.height - tr0, ca = c0 - tc0, cb = c0 + a.width - tc0;
+		ra = ra > 0 ? ra : 0; ca = ca > 0 ? ca : 0;
+		const int rmax = (a.frame_rows - tr0 < kTileRows) ? (a.frame_rows - tr0) : kTileRows;
+		const int cmax = (a.frame_cols - tc0 < kTileCols) ? (a.frame_cols - tc0) : kTileCols;
+		rb = rb < rmax ? rb : rmax; cb = cb < cmax ? cb : cmax;
+		float* out = a.cube + (int64_t)target * P * a.t_pitch + k0 + lane;
+		for (int rr = ra; rr < rb; ++rr) {
+			const int prow = (tr0 + rr - r0) * a.width + (tc0 - c0);
+			const float* src = tile + lane * kTileLd + rr * kTileCols;
+#pragma unroll 4
+			for (int cc = ca + wave; cc < cb; cc += 4) {
+				const float x = src[cc];
+				if (k_ok) out[(int64_t)(prow + cc) * a.t_pitch] = x;
+			}
+		}
+	}
+}
+
 } // namespace
 
 extern "C" int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
@@ -113,6 +261,35 @@ extern "C" int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frame
 	a.frames = d_frames; a.n_frames = n_frames; a.frame_rows = frame_rows; a.frame_cols = frame_cols;
 	a.row_pitch = row_pitch; a.frame_stride = frame_stride; a.row_offset = row_offset; a.col_offset = col_offset;
 	a.stamps = d_stamps; a.height = desc->height; a.width = desc->width; a.t_pitch = desc->t_pitch; a.cube = d_cube;
+	// dense batch (the stamps cover at least an eighth of the frame): frame-tile-major, every frame pixel fetched once
+	const int64_t stamp_pixels = (int64_t)desc->n_targets * desc->height * desc->width;
+	TileGeom tg;
+	tg.tiles_x = (frame_cols + kTileCols - 1) / kTileCols;
+	tg.tiles_y = (frame_rows + kTileRows - 1) / kTileRows;
+	const int64_t n_tiles = (int64_t)tg.tiles_x * tg.tiles_y;
+	const int64_t max_per_stamp = (int64_t)((desc->height - 1) / kTileRows + 2) * ((desc->width - 1) / kTileCols + 2);
+	if (stamp_pixels * 8 >= (int64_t)frame_rows * frame_cols && n_tiles <= 16 * 1024 * 1024 && desc->n_targets * max_per_stamp < 2147483647ll) {
+		const size_t n_int = (size_t)(2 * n_tiles + 2 + desc->n_targets * max_per_stamp + desc->n_targets);
+		int* base = static_cast<int*>(tp_ctx_scratch(ctx, n_int * sizeof(int)));
+		TP_REQUIRE(ctx, base != nullptr, "tp_cut_stamps: out of device memory (tile lists)");
+		int* count = base;                       // [n_tiles]      counts, then cursors
+		int* offsets = count + n_tiles;          // [n_tiles + 1]
+		int* outside = offsets + n_tiles + 1;    // [n_targets]
+		int* items = outside + desc->n_targets;  // [sum of counts]
+		TP_HIP(ctx, hipMemsetAsync(count, 0, (size_t)n_tiles * sizeof(int), ctx->stream));
+		const dim3 bgrid((unsigned)((desc->n_targets + 255) / 256));
+		{
+			tp_prof_scope _ps(ctx, TPK_CUTOUT); // the whole path is one profile entry
+			hipLaunchKernelGGL(tp_cut_bin_kernel<false>, bgrid, dim3(256), 0, ctx->stream, a, tg, (int)desc->n_targets, count, (const int*)offsets, items, outside);
+			hipLaunchKernelGGL(tp_cut_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, offsets, (int)n_tiles);
+			hipLaunchKernelGGL(tp_cut_bin_kernel<true>, bgrid, dim3(256), 0, ctx->stream, a, tg, (int)desc->n_targets, count, (const int*)offsets, items, outside);
+			hipLaunchKernelGGL(tp_cut_nanfill_kernel, dim3((unsigned)desc->n_targets), dim3(256), 0, ctx->stream, a, (const int*)outside);
+			dim3 grid((unsigned)n_tiles, (unsigned)((desc->n_cad + kCadBlock - 1) / kCadBlock));
+			hipLaunchKernelGGL(tp_cut_tiles_kernel, grid, dim3(256), 0, ctx->stream, a, tg, (const int*)offsets, (const int*)items);
+		}
+		TP_LAUNCH_CHECK(ctx, "tp_cut_tiles_kernel");
+		return TP_OK;
+	}
 	if (shmem > 64 * 1024)
 		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_cut_stamps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
 	dim3 grid((unsigned)desc->n_targets, (unsigned)((desc->n_cad + kCadBlock - 1) / kCadBlock), (unsigned)n_bands);

@@ -28,14 +28,17 @@ def test_golden_reference_load_cube(ctx, golden_dir):
 	np.testing.assert_array_equal(cube.to_host(), g['cubes'])
 
 
-@pytest.mark.parametrize('T,R,C,H,W', [(64, 30, 30, 15, 15), (129, 50, 70, 11, 17), (200, 64, 64, 21, 16), (7, 20, 20, 5, 3)])
-def test_against_oracle(ctx, T, R, C, H, W):
+# the library cuts dense batches (stamps covering at least an eighth of the frame) tile by tile from LDS and sparse ones stamp by
+# stamp: the first four and the sixth case take the tile-major path (tile edges at column 64 / 128 and every second row, a
+# last tile cut by the frame), the fifth and the last the per-stamp gather
+@pytest.mark.parametrize('T,R,C,H,W,n', [(64, 30, 30, 15, 15, 25), (129, 50, 70, 11, 17, 25), (200, 64, 64, 21, 16, 25), (7, 20, 20, 5, 3, 25),
+	(70, 200, 300, 15, 15, 5), (131, 97, 203, 15, 15, 400), (65, 31, 400, 9, 70, 2)])
+def test_against_oracle(ctx, T, R, C, H, W, n):
 	from photometry_amd import engine
 	from oracle import cutout
 	rng = np.random.default_rng(T + W)
 	frames = rng.normal(0, 1, (T, R, C)).astype('float32')
 	frames[rng.random((T, R, C)) < 0.02] = np.nan
-	n = 25
 	r0 = rng.integers(-3, R - H + 4, n)
 	c0 = rng.integers(-3 + 44, C - W + 4 + 44, n)
 	stamps = np.stack((r0, r0 + H, c0, c0 + W), axis=1).astype('int32')

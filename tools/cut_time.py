@@ -9,7 +9,7 @@ from photometry_amd.device import Context, DeviceCube
 ctx = Context(0)
 Nt, T, H, W = 10000, 1300, 15, 15
 out = DeviceCube(ctx, Nt, T, H, W)
-for FR in (1024, 2048):
+for FR in (512, 1024, 2048):
 	frames = ctx.zeros((T, FR, FR), 'float32')
 	rng = np.random.default_rng(1)
 	r0 = rng.integers(0, FR - H, Nt); c0 = rng.integers(0, FR - W, Nt)
