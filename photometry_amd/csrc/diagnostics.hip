@@ -299,7 +299,11 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 			else {
 				const double ts = a.timescale;
 				const double nbd = ceil((tmax - tmin) / ts); // len(np.arange(tmin, tmax, ts))
-				if (!(nbd <= (double)TP2)) flags |= F_TOO_MANY_BINS;
+				// more bins than the bin array holds (a sparse series: 100 points over 27 days in the reference's own test): the
+				// empty bins are NaN and nanmedian ignores them, so for a time-ordered series the means of the non-empty bins are
+				// kept at the position of the first sample of their run instead
+				const bool many = !(nbd <= (double)TP2);
+				if (many && !(nbd <= 2.0e9)) flags |= F_TOO_MANY_BINS;
 				else {
 					const int nb = (int)nbd;
 					// numpy's arange fills start + i*delta with delta = (start + step) - start, rounded: NOT i*step
@@ -322,6 +326,26 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 					for (int g = tid; g + 1 < Ng; g += kThreads) if (bt[g] < 0 || bt[g + 1] < bt[g]) mono = 0;
 					if (Ng > 0 && tid == 0 && bt[Ng - 1] < 0) mono = 0;
 					const bool sorted = block_min((double)mono, red) > 0.0;
+					if (many) {
+						if (!sorted) flags |= F_TOO_MANY_BINS;
+						else {
+							for (int g = tid; g < Ng; g += kThreads) {
+								double v = nan;
+								if (g == 0 || bt[g] != bt[g - 1]) {
+									const int b = bt[g];
+									double sacc = 0.0; int c = 0;
+									for (int q = g; q < Ng && bt[q] == b; ++q) { const double y = gflux[q]; if (!is_nan(y) && is_finite(y)) { sacc += y; c++; } }
+									v = c ? (0.0 + sacc) / (double)c : nan;
+								}
+								fb[g] = v;
+							}
+							__syncthreads();
+							const double med1 = block_median(fb, Ng, red, hist);
+							for (int g = tid; g < Ng; g += kThreads) srt[g] = fabs(fb[g] - med1);
+							const double med2 = block_median(srt, Ng, red, hist);
+							rms_hour = 1.482602218505602 * med2;
+						}
+					} else {
 					// nanmean per bin, samples added in time-series order (numpy's order inside binned_statistic).  Time-ordered
 					// series (the normal case): the samples of a bin are a contiguous run found by two binary searches.
 					for (int b = tid; b < nb; b += kThreads) {
@@ -342,6 +366,7 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 					for (int b = tid; b < nb; b += kThreads) srt[b] = fabs(fb[b] - med1);
 					const double med2 = block_median(srt, nb, red, hist);
 					rms_hour = 1.482602218505602 * med2; // utilities.mad_to_sigma (:25)
+					}
 				}
 			}
 		}

@@ -105,3 +105,56 @@ def test_against_oracle(ctx, T):
 			continue
 		ref = odiag.diagnostics(time, quality, flux[i], ferr[i], cen[i], sumimage=S[i], mask=mask[i])
 		_check(got[i], ref, tag=f'T{T} target{i}')
+
+
+def test_reference_rms_timescale_known_answers(ctx):
+	"""The known answers of the reference's own tests/test_utilities.py:75-116 (rms_timescale), through the device kernel:
+	zero flux -> 0, all-NaN flux -> NaN, a timescale longer than the time span -> 0, and the three invalid time vectors
+	(+inf, -inf, all timestamps equal) that raise ValueError upstream -> the BAD_TIME flag (4)."""
+	from photometry_amd import engine
+	from photometry_amd.engine import DIAGNOSTICS_COLUMNS as COLS
+	jr, jf = COLS.index('rms_hour'), COLS.index('flags')
+
+	def rms(time, flux, timescale=3600 / 86400):
+		T = len(time)
+		lc = engine.LightCurves(ctx, 1, T)
+		block = np.zeros((5, 1, T))
+		block[0, 0] = flux
+		block[1, 0] = 1.0
+		ctx._check(ctx.lib.tp_memcpy_h2d(ctx.handle, lc.block.ptr, np.ascontiguousarray(block).ctypes.data, block.nbytes))
+		out = engine.lightcurve_diagnostics(ctx, lc, ctx.array(np.asarray(time, dtype='float64')), ctx.array(np.zeros(T, dtype='int32')),
+			timescale=timescale)
+		ctx.sync()
+		row = out.to_host()[0]
+		return row[jr], int(row[jf]) if np.isfinite(row[jf]) else 0
+
+	# the kernel works on rel = flux / median - 1: a constant light curve is the reference's all-zero series
+	time = np.linspace(0, 27, 100)
+	r, f = rms(time, np.full(100, 7.5))
+	assert r == 0 and (f & 4) == 0
+	r, f = rms(time, np.full(100, np.nan))
+	assert np.isnan(r)
+	rng = np.random.default_rng(0)
+	flux = 1000 + rng.standard_normal(1000)
+	time = np.linspace(0, 27, 1000)
+	r, f = rms(time, flux, timescale=30.0)
+	assert r == 0 and (f & 4) == 0
+	for bad in (np.inf, -np.inf):
+		t2 = time.copy()
+		t2[1] = bad
+		r, f = rms(t2, flux)
+		assert (f & 4) == 4 and np.isnan(r), bad
+	r, f = rms(np.full(1000, 1.2), flux)
+	assert (f & 4) == 4 and np.isnan(r)
+	r, f = rms(time * np.nan, flux)
+	assert (f & 4) == 4 and np.isnan(r)
+	# a sparse series (more one-hour bins than samples) with real scatter: against the oracle
+	from oracle.utilities import rms_timescale
+	time = np.sort(rng.uniform(0, 27, 100))
+	flux = 1000 + rng.standard_normal(100)
+	flux[7] = np.nan
+	r, f = rms(time, flux)
+	keep = np.isfinite(flux)
+	rel = flux / np.nanmedian(flux) - 1
+	np.testing.assert_allclose(r, rms_timescale(time, rel), rtol=1e-12)
+	assert f == 0
