@@ -147,6 +147,18 @@ def test_replay_skip_targets():
 	assert list(st) == [1, 5, 2, 1] # 11 lies in the mask of the brighter 10 -> 11 is skipped
 
 
+def test_replay_skip_targets_reference_known_answers():
+	"""tests/test_taskmanager.py:304-400 of the reference (FFI cases): the bright star (Tmag 2.216) with the faint one (14.574)
+	in its skip list keeps OK and the faint one is SKIPPED; the faint one saved first with the bright one in its list is
+	SKIPPED itself and the bright one stays to be processed."""
+	starids, tmags = [267211065, 261522674], [2.216, 14.574]
+	st, ran = tpcomm.replay_skip_targets(starids, tmags, [[261522674], []], [1, 1], return_ran=True)
+	assert list(st) == [1, 5] and ran == [0]
+	# the reference's second test saves the faint star first (it asked for that task explicitly): priorities reversed
+	st, ran = tpcomm.replay_skip_targets(starids, tmags, [[], [267211065]], [1, 1], priorities=[2, 1], return_ran=True)
+	assert list(st) == [1, 5] and ran == [1, 0]
+
+
 def test_replay_skip_targets_golden():
 	"""The replay against the reference's own TaskManager (get_task / start_task / save_result on sqlite todo-lists,
 	tests/golden/make_golden.py:golden_skiptargets): final statuses and the order in which targets ran, 60 todo-lists with
