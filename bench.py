@@ -584,7 +584,7 @@ def leg_stages(ctx, scene, cubes, batch, work, args, Nt, T, H, W, np, engine, pi
 		nb = int(covered.sum()) * T * 4 + Nt * P*T*4
 		out['cutout'] = {'what': f'stamp cutter: {Nt} stamps cut from a {FR} x {FR} x {T} float32 frame stack resident in HBM '
 			'(BasePhotometry._load_cube for the batch), one cube; frame-tile-major: tiles of 2 x 64 pixels x 64 frames through LDS, '
-			'stamps served from the tile', 'kernel': 'tp_cut_stamps_kernel (binning passes + tp_cut_tiles_kernel)', 'avg_ms': r[1] / r[0],
+			'stamps served from the tile', 'kernel': 'tp_cut_tiles_kernel', 'timed': 'the three binning passes + the NaN pre-fill + tp_cut_tiles_kernel (profile entry tp_cut_stamps_kernel)', 'avg_ms': r[1] / r[0],
 			'necessary_bytes_per_launch': nb, 'necessary_GBps': nb / (r[1] / r[0] * 1e-3) / 1e9, 'frac_of_hbm_peak': nb / (r[1] / r[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
 			'distinct_frame_pixels_in_stamps': int(covered.sum()), 'survey_8d_bytes_per_launch': Nt * 2*P*T*4}
 		frames.free()
