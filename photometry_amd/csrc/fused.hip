@@ -183,7 +183,18 @@ extern "C" int tp_aperture_photometry(tp_ctx* ctx, const tp_cube_desc* desc,
 	size_t shmem = lay.total;
 	const size_t a1_bytes = lay.off_region + (size_t)((desc->n_cad + 3) & ~3) + 16; // flags live in the shared region
 	if (a1_bytes > shmem) shmem = a1_bytes;
-	TP_REQUIRE(ctx, shmem <= 160 * 1024, "tp_aperture_photometry: stamp / cadence count too large for the LDS-resident per-target state");
+	if (shmem > 160 * 1024) {
+		// a stamp (or light curve) beyond the LDS-resident per-target state: the three stages one after the other, same results
+		// (tp_k2p2_masks keeps its work arrays in HBM for such stamps)
+		int rc = tp_sumimage(ctx, desc, d_images, d_quality, quality_target_stride, bitmask, d_subtract, subtract_pitch, d_sumimage);
+		if (rc != TP_OK) return rc;
+		rc = tp_k2p2_masks(ctx, desc->n_targets, desc->height, desc->width, d_sumimage, d_cat_offsets, d_cat_column_stamp, d_cat_row_stamp,
+			d_cat_tmag, d_cat_column, d_cat_row, d_cat_starid, d_target_pos_row, d_target_pos_column, d_target_tmag, d_target_starid,
+			d_stamps, d_aperture, nullptr, params, d_mask, d_status, d_flags, d_contamination, d_diag, d_cat_in_mask);
+		if (rc != TP_OK) return rc;
+		return tp_aperture_extract(ctx, desc, d_images, d_images_err, d_backgrounds, (bkg_mode == 2) ? 0 : bkg_mode, bkg_series_pitch,
+			d_subtract, subtract_pitch, d_mask, d_stamps, d_status, d_flux, d_flux_err, d_flux_background, d_centroid_col, d_centroid_row, out_pitch);
+	}
 
 	if (!ctx->twiddle) {
 		double h[2 * k2p2::kGrid];

@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdlib>
 
+void* tp_ctx_scratch(tp_ctx* ctx, size_t bytes); // aperture.hip
+
 namespace {
 
 __global__ __launch_bounds__(64, 2) void tp_k2p2_kernel(k2p2::BatchArgs a, k2p2::Params prm, const double* __restrict__ twid)
@@ -16,6 +18,22 @@ __global__ __launch_bounds__(64, 2) void tp_k2p2_kernel(k2p2::BatchArgs a, k2p2:
 	const int target = blockIdx.x;
 	k2p2::Shared k;
 	k2p2::shared_carve(k, smem, a.H, a.W, (int)threadIdx.x, twid);
+	k2p2::Target t;
+	k2p2::make_target(a, target, t);
+	k2p2::run_target(k, prm, t);
+}
+
+// Stamps whose work arrays do not fit the LDS (beyond about 54 x 54 pixels: the default stamps of stars brighter than
+// Tmag ~ 3.5, BasePhotometry.py:541-564, and what the resize loop grows around Tmag 4-5 stars): the same code on work arrays in
+// a context-owned HBM scratch, one wavefront per target.  A workgroup barrier orders its global accesses like its LDS accesses
+// (one wavefront, s_waitcnt vmcnt(0) before the barrier), so nothing else changes; it is slow (every array access is an L2 round
+// trip), which is acceptable for the few such stars of a CCD -- upstream they are the slowest targets too.
+__global__ __launch_bounds__(64) void tp_k2p2_global_kernel(k2p2::BatchArgs a, k2p2::Params prm, const double* __restrict__ twid,
+	unsigned char* __restrict__ scratch, size_t bytes_per_target)
+{
+	const int target = blockIdx.x;
+	k2p2::Shared k;
+	k2p2::shared_carve(k, scratch + (size_t)target * bytes_per_target, a.H, a.W, (int)threadIdx.x, twid);
 	k2p2::Target t;
 	k2p2::make_target(a, target, t);
 	k2p2::run_target(k, prm, t);
@@ -39,7 +57,8 @@ extern "C" int tp_k2p2_masks(tp_ctx* ctx, int32_t n_targets, int32_t height, int
 	TP_REQUIRE(ctx, d_mask && d_status && d_flags && d_contamination, "tp_k2p2_masks: null output pointer");
 	if (n_targets == 0) return TP_OK;
 	const size_t shmem = k2p2::shared_bytes(height * width);
-	TP_REQUIRE(ctx, shmem <= 160 * 1024, "tp_k2p2_masks: stamp too large for the LDS-resident mask builder (about 54x54 pixels)");
+	const bool in_lds = shmem <= 160 * 1024;
+	TP_REQUIRE(ctx, (int64_t)height * width <= 65535, "tp_k2p2_masks: more than 65535 pixels per stamp (16-bit labels)");
 
 	k2p2::Params prm = k2p2::default_params();
 	if (params) {
@@ -60,7 +79,7 @@ extern "C" int tp_k2p2_masks(tp_ctx* ctx, int32_t n_targets, int32_t height, int
 		TP_HIP(ctx, hipMalloc(&ctx->twiddle, sizeof(h)));
 		TP_HIP(ctx, hipMemcpy(ctx->twiddle, h, sizeof(h), hipMemcpyHostToDevice));
 	}
-	if (shmem > 64 * 1024) {
+	if (in_lds && shmem > 64 * 1024) {
 		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_k2p2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
 	}
 
@@ -77,7 +96,13 @@ extern "C" int tp_k2p2_masks(tp_ctx* ctx, int32_t n_targets, int32_t height, int
 	// lab builds only (tools/k2p2_phases.py): d_diag, 16 doubles per target, receives per-phase cycle counts instead
 	if (d_diag) { a.timing = d_diag; a.diag = nullptr; }
 #endif
-	TP_LAUNCH(ctx, TPK_K2P2, tp_k2p2_kernel, dim3((unsigned)n_targets), dim3(64), shmem, a, prm, (const double*)ctx->twiddle);
+	if (in_lds) TP_LAUNCH(ctx, TPK_K2P2, tp_k2p2_kernel, dim3((unsigned)n_targets), dim3(64), shmem, a, prm, (const double*)ctx->twiddle);
+	else {
+		const size_t per = (shmem + 255) & ~(size_t)255;
+		unsigned char* scratch = static_cast<unsigned char*>(tp_ctx_scratch(ctx, per * (size_t)n_targets));
+		TP_REQUIRE(ctx, scratch != nullptr, "tp_k2p2_masks: out of device memory for the work arrays of a large stamp");
+		TP_LAUNCH(ctx, TPK_K2P2, tp_k2p2_global_kernel, dim3((unsigned)n_targets), dim3(64), 0, a, prm, (const double*)ctx->twiddle, scratch, per);
+	}
 	TP_LAUNCH_CHECK(ctx, "tp_k2p2_kernel");
 	return TP_OK;
 	TP_API_END(ctx)

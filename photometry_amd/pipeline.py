@@ -383,7 +383,7 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 				aperture_diagnostics(ctx, batch, work)
 				ctx.sync()
 			except TessphotError as e:
-				# e.g. a stamp beyond the LDS-resident mask kernel (54 x 54): the bright-star tail, Halo territory upstream
+				# e.g. a stamp beyond 65 535 pixels (the mask builder's 16-bit labels): Halo territory upstream
 				for i in idx:
 					log[i].error('Device pass failed for a %dx%d stamp: %s', H, W, str(e))
 					finish(i, 2)

@@ -51,6 +51,32 @@ def test_k2p2_matches_oracle(ctx, kind, seed):
 	assert stats['n_exact'] >= s.n_targets // 2 and stats['n_razor'] == 0
 
 
+def test_k2p2_large_stamp_work_arrays_in_hbm(ctx):
+	"""62 x 58 stamps (bright stars, BasePhotometry.py:541-564): the same mask builder on work arrays in HBM; then the whole
+	aperture pass through tp_aperture_photometry, which runs its three stages in turn for such stamps."""
+	from photometry_amd import pipeline
+	from oracle import aperture as oap
+	s, S = make_cases('large', 21)
+	got = run_device(ctx, s, S)
+	ref = oracle_batch(s, S)
+	stats = compare(s, S, got, ref)
+	print('large', stats)
+	assert stats['n_exact'] == s.n_targets and stats['n_razor'] == 0
+	res = pipeline.run_aperture(ctx, s, cubes='host')
+	np.testing.assert_allclose(res['sumimage'], S, rtol=1e-12, equal_nan=True)
+	n = 0
+	for i in range(s.n_targets):
+		r = oap.do_photometry(S[i], s.images[i], s.images_err[i], s.backgrounds[i], tuple(s.stamps[i]), s.target_pos_row[i],
+			s.target_pos_column[i], s.target_tmag[i], s.target_starid[i], s.catalog_of(i), s.aperture[i])
+		assert int(res['status'][i]) == r['status']
+		if 'mask' in r:
+			np.testing.assert_array_equal(res['mask'][i].astype(bool), r['mask'])
+			for key in ('flux', 'flux_err', 'flux_background'):
+				np.testing.assert_array_equal(res[key][i], r[key], err_msg=key)
+			n += 1
+	assert n >= 3
+
+
 def test_k2p2_given_oracle_cut(ctx):
 	from oracle import k2p2 as ok2p2
 	s, S = make_cases('crowded', 11)
@@ -94,10 +120,11 @@ def test_full_aperture_pipeline(ctx):
 
 
 def test_k2p2_stamp_too_large_is_an_error(ctx):
+	"""The labels are 16-bit: beyond 65 535 pixels per stamp the call is refused (no fallback, no truncation)."""
 	from photometry_amd._lib import TessphotError
 	from photometry_amd import simulate
-	s = simulate.make_scene(1, 4, 64, 64, seed=1)
-	s.aperture = np.ones((1, 64, 64), dtype='int32')
+	s = simulate.make_scene(1, 2, 300, 300, seed=1)
+	s.aperture = np.ones((1, 300, 300), dtype='int32')
 	with pytest.raises(TessphotError) as e:
-		run_device(ctx, s, np.ones((1, 64, 64)))
-	assert 'too large' in str(e.value)
+		run_device(ctx, s, np.ones((1, 300, 300)))
+	assert '65535 pixels' in str(e.value)
