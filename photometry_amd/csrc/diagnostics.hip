@@ -149,6 +149,29 @@ __device__ double pairwise_leaf(const double* a, int n) {
 	return res;
 }
 
+// numpy's pairwise add.reduce for any n: pw(n) = leaf if n <= 128, else pw(n2) + pw(n - n2) with n2 = n / 2 rounded down to a
+// multiple of 8.  Run by one thread; the recursion is an explicit stack in the workgroup's scratch (left sums in dstack,
+// offset / length / state triples in istack; 16 levels cover 128 * 2^16 values).
+__device__ double pairwise_sum(const double* a, int n, double* dstack, int* istack) {
+	int sp = 0;
+	istack[0] = 0; istack[1] = n; istack[2] = 0;
+	double ret = 0.0;
+	while (true) {
+		int* f = istack + 3 * sp;
+		const int off = f[0], len = f[1];
+		int n2 = len / 2; n2 -= n2 % 8;
+		if (f[2] == 0) {
+			if (len > 128 && sp < 15) { f[2] = 1; ++sp; istack[3 * sp] = off; istack[3 * sp + 1] = n2; istack[3 * sp + 2] = 0; continue; }
+			ret = pairwise_leaf(a + off, len);
+		} else if (f[2] == 1) {
+			dstack[sp] = ret; f[2] = 2; ++sp; istack[3 * sp] = off + n2; istack[3 * sp + 1] = len - n2; istack[3 * sp + 2] = 0; continue;
+		} else ret = dstack[sp] + ret;
+		if (sp == 0) break;
+		--sp;
+	}
+	return ret;
+}
+
 __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 {
 	extern __shared__ __align__(16) double lds[];
@@ -218,10 +241,7 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 		}
 		if (tid == 0) { // numpy pairwise sum of the gathered values
 			const int n = ired[0];
-			double tot;
-			if (n <= 128) tot = pairwise_leaf(srt, n);
-			else { int n2 = n / 2; n2 -= n2 % 8; tot = pairwise_leaf(srt, n2) + pairwise_leaf(srt + n2, n - n2); }
-			red[0] = tot;
+			red[0] = pairwise_sum(srt, n, red + 16, ired + 16);
 		}
 		__syncthreads();
 		edge_flux = red[0];
@@ -467,10 +487,12 @@ extern "C" int tp_lightcurve_diagnostics(tp_ctx* ctx, int32_t n_targets, int32_t
 	TP_REQUIRE(ctx, lc_pitch >= n_cad, "tp_lightcurve_diagnostics: lc_pitch < n_cad");
 	TP_REQUIRE(ctx, quality_target_stride == 0 || quality_target_stride >= n_cad, "tp_lightcurve_diagnostics: bad quality stride");
 	TP_REQUIRE(ctx, (d_mask == nullptr) == (d_sumimage == nullptr), "tp_lightcurve_diagnostics: mask and sum image go together");
-	TP_REQUIRE(ctx, d_mask == nullptr || (height > 0 && width > 0 && 2 * (height + width) <= 256), "tp_lightcurve_diagnostics: bad stamp geometry");
+	TP_REQUIRE(ctx, d_mask == nullptr || (height > 0 && width > 0 && (int64_t)height * width <= 2147483647ll), "tp_lightcurve_diagnostics: bad stamp geometry");
 	TP_REQUIRE(ctx, timescale_days > 0, "tp_lightcurve_diagnostics: timescale must be positive");
 	if (n_targets == 0) return TP_OK;
-	const int tp2 = (n_cad > 256) ? n_cad : 256; // scratch length: the series, the time bins (capped) and the <= 256 edge pixels
+	// scratch length: the series, the time bins (capped) and the in-mask pixels of the stamp edge (at most its perimeter)
+	int tp2 = (n_cad > 256) ? n_cad : 256;
+	if (d_mask && 2 * (height + width) > tp2) tp2 = 2 * (height + width);
 	const size_t small_bytes = kThreads * sizeof(double) + ((size_t)kThreads + 1 + 260 + 1) * sizeof(int);
 	const size_t series_bytes = (((size_t)2 * tp2 + 3 * (size_t)n_cad) * sizeof(double) + 2 * (size_t)n_cad * sizeof(int) + 15) & ~(size_t)15;
 	size_t shmem = small_bytes + series_bytes + 16;

@@ -158,3 +158,27 @@ def test_reference_rms_timescale_known_answers(ctx):
 	rel = flux / np.nanmedian(flux) - 1
 	np.testing.assert_allclose(r, rms_timescale(time, rel), rtol=1e-12)
 	assert f == 0
+
+
+def test_edge_flux_of_large_stamps(ctx):
+	"""Stamps of bright stars (BasePhotometry.py:541-564: 163 x 69 at Tmag 2): more in-mask edge pixels than one pairwise leaf
+	or two -- numpy's recursive pairwise sum (edge_flux, :1400-1403) at any length, exact."""
+	from oracle import diagnostics as odiag
+	rng = np.random.default_rng(5)
+	T = 30
+	time = 1400.0 + np.arange(T) * (1800.0 / 86400.0)
+	quality = np.zeros(T, dtype='int32')
+	for (H, W) in ((90, 70), (163, 69), (40, 30)):
+		Nt = 3
+		flux = 1e4 * (1 + 1e-3 * rng.standard_normal((Nt, T)))
+		ferr = np.sqrt(flux)
+		cen = np.stack((100 + 0.01 * rng.standard_normal((Nt, T)), 200 + 0.01 * rng.standard_normal((Nt, T))), axis=-1)
+		S = rng.uniform(1, 500, (Nt, H, W))
+		S[rng.random((Nt, H, W)) < 0.02] = np.nan
+		mask = np.ones((Nt, H, W), dtype=bool)
+		mask[1] = rng.random((H, W)) < 0.7
+		mask[2, 1:-1, :] = False # the two edge rows only
+		got = _run(ctx, time, quality, flux, ferr, cen, status=np.ones(Nt, dtype='int32'), sumimage=S, mask=mask)
+		for i in range(Nt):
+			ref = odiag.diagnostics(time, quality, flux[i], ferr[i], cen[i], sumimage=S[i], mask=mask[i])
+			_check(got[i], ref, tag=f'{H}x{W} target{i}')
