@@ -108,3 +108,71 @@ def test_batched_resize_equals_plugin_equals_oracle(tmp_path):
 	assert 'WARNING: Could not resize stamp any further.' in seen
 	assert 'ERROR: Stamp resize hit limit. Haloswitch quick break.' in seen or 'ERROR: Too many stamp resizes.' in seen
 	ctx.close()
+
+
+def test_bright_star_large_stamp_three_way():
+	"""A Tmag 3.2 star: default stamp 67 x 45 (BasePhotometry.py:541-564), beyond the LDS-resident mask builder -- cutter, the
+	mask builder on HBM work arrays, extraction and diagnostics of a 3 000-pixel stamp in the batched loop, the per-target plugin
+	and the oracle's restatement of the loop: same statuses, stamps, masks and float32 sums."""
+	from photometry_amd import pipeline, tessphot_frames, STATUS
+	from photometry_amd.device import Context
+	from photometry_amd.plugins import AperturePhotometry
+	from photometry_amd.tessphot import run_plugin
+	from photometry_amd.source import MemoryStampSource
+	from oracle import aperture as oap
+	rng = np.random.default_rng(11)
+	R, C, T = 150, 120, 12
+	row0, col0 = 400, 500
+	stars = [(row0 + 75.4, col0 + 60.7, 3.2), (row0 + 20.2, col0 + 20.9, 10.5), (row0 + 120.6, col0 + 95.1, 9.0), (row0 + 70.8, col0 + 75.3, 8.5)]
+	rr, cc = np.arange(R) + row0, np.arange(C) + col0
+	img = np.zeros((R, C))
+	for (r, c, tmag) in stars:
+		flux = 10**(-0.4 * (tmag - 20.451))
+		sig = 1.4 if tmag < 5 else 0.9
+		pr = 0.5 * (erf((rr + 0.5 - r) / (np.sqrt(2) * sig)) - erf((rr - 0.5 - r) / (np.sqrt(2) * sig)))
+		pc = 0.5 * (erf((cc + 0.5 - c) / (np.sqrt(2) * sig)) - erf((cc - 0.5 - c) / (np.sqrt(2) * sig)))
+		img += flux * np.outer(pr, pc)
+	cube = img[:, :, None] * (1 + 1e-3 * rng.normal(size=T))[None, None, :]
+	noise = np.sqrt(np.abs(cube) + 200.0)
+	images = (cube + 30.0 + rng.normal(size=cube.shape) * noise).astype('float32')
+	frames = {'images': images, 'images_err': noise.astype('float32'), 'backgrounds': np.full(images.shape, 100.0, dtype='float32')}
+	time = 1500.0 + np.arange(T) * 1800.0 / 86400.0
+	quality = np.zeros(T, dtype='int32')
+	cat = {'starid': np.arange(len(stars), dtype='int64') + 201, 'tmag': np.array([s[2] for s in stars], dtype='float32'),
+		'row': np.array([s[0] for s in stars], dtype='float32'), 'column': np.array([s[1] for s in stars], dtype='float32')}
+	targets = {k: np.array(v[:2], dtype=v.dtype if k == 'starid' else 'float64') for k, v in cat.items()}
+	targets['row'] = np.array([s[0] for s in stars[:2]])
+	targets['column'] = np.array([s[1] for s in stars[:2]])
+	targets['tmag'] = np.array([s[2] for s in stars[:2]])
+	ctx = Context(0)
+	stack = pipeline.FrameStack(ctx, {k: np.moveaxis(v, 2, 0) for k, v in frames.items()}, row0, col0)
+	batch = tessphot_frames(ctx, stack, targets, cat, time, quality)
+	src = MemoryStampSource(frames, row0, col0, time, np.zeros(T), np.arange(T), quality, cat, targets=targets)
+	import tempfile
+	with tempfile.TemporaryDirectory() as tmp:
+		for i in range(2):
+			b = batch[i]
+			o = oap.photometry_on_frames(oap.FrameTarget(frames, row0, col0, quality, cat, int(targets['starid'][i]), float(targets['tmag'][i]),
+				float(targets['row'][i]), float(targets['column'][i])))
+			assert b.status.value == o['status'], (i, b.status, o['status'], b._details.get('errors'), o['errors'])
+			assert tuple(b._details['stamp']) == tuple(o['stamp'])
+			assert b._details['stamp_resizes'] == o['stamp_resizes']
+			if i == 0:
+				st = b._details['stamp']
+				assert (st[1] - st[0]) * (st[3] - st[2]) > 54 * 54 # really the HBM path
+			if 'mask' in o:
+				np.testing.assert_array_equal(b.final_phot_mask, o['mask'])
+				np.testing.assert_array_equal(b.lightcurve['flux'], o['flux'])
+				np.testing.assert_array_equal(b.lightcurve['flux_err'], o['flux_err'])
+				np.testing.assert_array_equal(b.lightcurve['flux_background'], o['flux_background'])
+				assert b._details.get('skip_targets', []) == o['skip_targets']
+			p = run_plugin(AperturePhotometry, int(targets['starid'][i]), src, tmp, ctx=ctx)
+			assert p.status == b.status, (i, p.status, b.status, p._details.get('errors'))
+			assert tuple(p._details['stamp']) == tuple(b._details['stamp'])
+			if b.final_phot_mask is not None and p.status != STATUS.ERROR:
+				np.testing.assert_array_equal(p.final_phot_mask, b.final_phot_mask)
+				np.testing.assert_array_equal(p.lightcurve['flux'], b.lightcurve['flux'])
+				for key in ('mean_flux', 'variance', 'rms_hour', 'ptp', 'edge_flux', 'mask_size'):
+					assert p._details[key] == b._details[key], key
+	assert batch[0].status in (STATUS.OK, STATUS.WARNING)
+	ctx.close()
