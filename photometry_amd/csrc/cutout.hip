@@ -22,9 +22,11 @@
 // stack, more than the stack itself (21.8 GB) -- and on crowded fields the same pixels many times over.  The tile-major
 // path turns the transposition around: the frame is cut into tiles of 2 rows x 64 columns; a binning pre-pass (three small
 // kernels: count, scan, fill; no host round trip) lists the stamps that touch each tile; one 256-thread workgroup per (tile,
-// block of 64 cadences) loads the tile of those 64 frames with fully coalesced 256-byte row segments into LDS
-// ([cadence][pixel], stride 129 floats) and then serves every stamp of its list from LDS: one wavefront instruction stores the
-// 64 cadences of one stamp pixel (256 B contiguous in the cube).  Every frame pixel is read from HBM once, whatever the
+// block of 32 cadences) loads the tile of those 32 frames with fully coalesced 256-byte row segments into LDS
+// ([cadence][pixel], stride 129 floats, 16.5 KB) and then serves every stamp of its list from LDS: half a wavefront stores the
+// 32 cadences of one stamp pixel (one 128-byte line of the cube).  Measured tile shapes (rows x columns x frames, 10 k stamps on
+// a 512^2 / 1024^2 / 2048^2 stack, ms): 2x64x32 2.8 / 3.2 / 5.8 (chosen), 2x64x64 3.0 / 3.6 / 6.7, 4x64x32 3.0 / 3.5 / 6.0,
+// 2x128x32 3.4 / 3.4 / 5.7, 1x64x32 3.3 / 3.6 / 6.3, 2x32x32 3.4 / 4.0 / 6.0, 2x64x16 5.8 / 5.0 / 8.4 (64-byte stores).  Every frame pixel is read from HBM once, whatever the
 // number of stamps that contain it, and never as a partial line.  Tiles without stamps exit at once.
 #include "common.h"
 
@@ -104,7 +106,13 @@ __global__ __launch_bounds__(256) void tp_cut_stamps_kernel(CutArgs a, int band_
 //--------------------------------------------------------------------------------------------------
 // frame-tile-major path
 //--------------------------------------------------------------------------------------------------
-constexpr int kTileRows = 2, kTileCols = 64, kTilePix = kTileRows * kTileCols;
+#ifndef TP_CUT_TILE_ROWS   // lab builds vary the tile (tools/lab/cut_variants.py); the product uses the defaults
+#define TP_CUT_TILE_ROWS 2
+#define TP_CUT_TILE_COLS 64
+#define TP_CUT_TILE_CAD 32
+#endif
+constexpr int kTileRows = TP_CUT_TILE_ROWS, kTileCols = TP_CUT_TILE_COLS, kTilePix = kTileRows * kTileCols;
+constexpr int kTileCad = TP_CUT_TILE_CAD;   // frames per tile = lanes per stored pixel run
 constexpr int kTileLd = kTilePix + 1;   // LDS stride of one cadence: odd, so that the transposed reads are conflict-free
 
 struct TileGeom { int tiles_x, tiles_y; };
@@ -178,26 +186,29 @@ __global__ __launch_bounds__(256) void tp_cut_nanfill_kernel(CutArgs a, const in
 
 __global__ __launch_bounds__(256) void tp_cut_tiles_kernel(CutArgs a, TileGeom tg, const int* __restrict__ offsets, const int* __restrict__ items)
 {
-	__shared__ float tile[kCadBlock * kTileLd];
+	__shared__ float tile[kTileCad * kTileLd];
 	const int tile_id = blockIdx.x;
 	const int first = offsets[tile_id], last = offsets[tile_id + 1];
 	if (first == last) return;                       // no stamp touches this tile
-	const int k0 = blockIdx.y * kCadBlock;
+	const int k0 = blockIdx.y * kTileCad;
 	const int tid = threadIdx.x;
-	const int lane = tid & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int ty = tile_id / tg.tiles_x, tx = tile_id - ty * tg.tiles_x;
 	const int tr0 = ty * kTileRows, tc0 = tx * kTileCols;
-	// ---- load: segment = (cadence, tile row), one 256-byte row segment per wavefront instruction, all 32 of a wavefront in flight
-	const int col = tc0 + lane;
+	// ---- load: segment = (frame, tile row); a group of kTileCols lanes takes one row segment (256 bytes for 64 columns), all
+	// loads of a thread in flight
+	constexpr int GRP = 256 / kTileCols;             // row segments per pass of the workgroup
+	int grp = tid / kTileCols;
+	if (kTileCols % 64 == 0) grp = __builtin_amdgcn_readfirstlane(grp);   // wave-uniform: scalar address arithmetic
+	const int lcol = tid % kTileCols;
+	const int col = tc0 + lcol;
 	const bool col_ok = col < a.frame_cols;
-	constexpr int SEG = kCadBlock * kTileRows;       // 128 segments, 32 per wavefront
-	constexpr int U = SEG / 4;
+	constexpr int SEG = kTileCad * kTileRows;
+	constexpr int U = SEG / GRP;
 	{
 		float v[U];
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
-			const int sidx = wave + 4 * u;
+			const int sidx = grp + GRP * u;
 			const int kk = sidx / kTileRows, rr = sidx % kTileRows;
 			const bool ok = col_ok && (k0 + kk < a.n_frames) && (tr0 + rr < a.frame_rows);
 			const int64_t off = ok ? ((int64_t)(k0 + kk) * a.frame_stride + (int64_t)(tr0 + rr) * a.row_pitch + col) : 0;
@@ -205,13 +216,17 @@ __global__ __launch_bounds__(256) void tp_cut_tiles_kernel(CutArgs a, TileGeom t
 		}
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
-			const int sidx = wave + 4 * u;
+			const int sidx = grp + GRP * u;
 			const int kk = sidx / kTileRows, rr = sidx % kTileRows;
-			tile[kk * kTileLd + rr * kTileCols + lane] = v[u];
+			tile[kk * kTileLd + rr * kTileCols + lcol] = v[u];
 		}
 	}
 	__syncthreads();
-	// ---- serve the stamps of this tile: a wavefront stores the 64 cadences of one stamp pixel per instruction
+	// ---- serve the stamps of this tile: kTileCad lanes store the frames of one stamp pixel (256 contiguous bytes for 64)
+	constexpr int RUNS = 256 / kTileCad;             // pixel runs stored per pass of the workgroup
+	const int lane = tid % kTileCad;
+	int run = tid / kTileCad;
+	if (kTileCad % 64 == 0) run = __builtin_amdgcn_readfirstlane(run);
 	const bool k_ok = k0 + lane < a.n_frames;
 	const int P = a.height * a.width;
 	for (int it = first; it < last; ++it) {
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(256) void tp_cut_tiles_kernel(CutArgs a, TileGeom t
 			const int prow = (tr0 + rr - r0) * a.width + (tc0 - c0);
 			const float* src = tile + lane * kTileLd + rr * kTileCols;
 #pragma unroll 4
-			for (int cc = ca + wave; cc < cb; cc += 4) {
+			for (int cc = ca + run; cc < cb; cc += RUNS) {
 				const float x = src[cc];
 				if (k_ok) out[(int64_t)(prow + cc) * a.t_pitch] = x;
 			}
@@ -284,7 +299,7 @@ extern "C" int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frame
 			hipLaunchKernelGGL(tp_cut_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, offsets, (int)n_tiles);
 			hipLaunchKernelGGL(tp_cut_bin_kernel<true>, bgrid, dim3(256), 0, ctx->stream, a, tg, (int)desc->n_targets, count, (const int*)offsets, items, outside);
 			hipLaunchKernelGGL(tp_cut_nanfill_kernel, dim3((unsigned)desc->n_targets), dim3(256), 0, ctx->stream, a, (const int*)outside);
-			dim3 grid((unsigned)n_tiles, (unsigned)((desc->n_cad + kCadBlock - 1) / kCadBlock));
+			dim3 grid((unsigned)n_tiles, (unsigned)((desc->n_cad + kTileCad - 1) / kTileCad));
 			hipLaunchKernelGGL(tp_cut_tiles_kernel, grid, dim3(256), 0, ctx->stream, a, tg, (const int*)offsets, (const int*)items);
 		}
 		TP_LAUNCH_CHECK(ctx, "tp_cut_tiles_kernel");
