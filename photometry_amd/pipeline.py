@@ -309,17 +309,53 @@ def _catalog_of_stamp(catalog, stamp, buffer_size=5):
 		'column_stamp': (col64 - c1).astype('float32'), 'row_stamp': (row64 - r1).astype('float32')}
 
 
+class _CatalogIndex(object):
+	"""The catalogue of a CCD region sorted by row, for :func:`_catalogs_of_stamps`."""
+	def __init__(self, catalog):
+		self.catalog = catalog
+		self.order = np.argsort(catalog['row'], kind='stable')
+		self.rows_sorted = np.asarray(catalog['row'])[self.order]
+
+
+def _catalogs_of_stamps(index, stamps, buffer_size=5):
+	"""
+	:func:`_catalog_of_stamp` for all stamps of a group at once, in CSR form: ``(offsets int64 [n + 1], dict of concatenated
+	arrays)``; the stars of a stamp keep their catalogue order.  Candidate stars come from a binary search on the row-sorted
+	catalogue (a stamp spans a few percent of the rows), the column test and the float32 stamp coordinates are the same
+	expressions evaluated on arrays.
+	"""
+	cat = index.catalog
+	st = np.asarray(stamps, dtype='int64').reshape(-1, 4)
+	n = len(st)
+	lo = np.searchsorted(index.rows_sorted, st[:, 0] - 0.5 - buffer_size, side='left')    # row >= r1 - 0.5 - buffer
+	hi = np.searchsorted(index.rows_sorted, st[:, 1] - 0.5 + buffer_size, side='left')    # row <  r2 - 0.5 + buffer
+	cnt = hi - lo
+	which = np.repeat(np.arange(n), cnt)
+	pos = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt) + np.repeat(lo, cnt)
+	star = index.order[pos]
+	col = np.asarray(cat['column'])[star]
+	keep = (col >= (st[which, 2] - 0.5 - buffer_size)) & (col < (st[which, 3] - 0.5 + buffer_size))
+	which, star = which[keep], star[keep]
+	o = np.lexsort((star, which))   # catalogue order inside every stamp
+	which, star = which[o], star[o]
+	offsets = np.concatenate(([0], np.cumsum(np.bincount(which, minlength=n)))).astype('int64')
+	col64, row64 = np.asarray(cat['column'], dtype='float64')[star], np.asarray(cat['row'], dtype='float64')[star]
+	arrays = {'starid': np.asarray(cat['starid'], dtype='int64')[star], 'tmag': np.asarray(cat['tmag'], dtype='float32')[star],
+		'column': col64.astype('float32'), 'row': row64.astype('float32'),
+		'column_stamp': (col64 - st[which, 2]).astype('float32'), 'row_stamp': (row64 - st[which, 0]).astype('float32')}
+	return offsets, arrays
+
+
 class _GroupScene(object):
 	"""The metadata of a group of same-sized stamps in the form ``ApertureBatch`` takes (no host cubes)."""
-	def __init__(self, stack, time, quality, cadence_s, stamps_list, cats, targets, idx):
+	def __init__(self, stack, time, quality, cadence_s, stamps_list, cat_offsets, cat_arrays, targets, idx):
 		self.n_targets = len(idx)
 		self.n_cad = stack.n_cad
 		self.height, self.width = stamps_list[0][1] - stamps_list[0][0], stamps_list[0][3] - stamps_list[0][2]
 		self.time, self.quality, self.cadence_s = time, quality, cadence_s
 		self.stamps = np.asarray(stamps_list, dtype='int32')
-		counts = [len(c['starid']) for c in cats]
-		self.cat_offsets = np.concatenate(([0], np.cumsum(counts))).astype('int64')
-		self.catalog = {k: (np.concatenate([c[k] for c in cats]) if cats else np.zeros(0)) for k in ('starid', 'tmag', 'row', 'column', 'row_stamp', 'column_stamp')}
+		self.cat_offsets = cat_offsets
+		self.catalog = cat_arrays
 		self.target_pos_row = np.asarray(targets['row'], dtype='float64')[idx]
 		self.target_pos_column = np.asarray(targets['column'], dtype='float64')[idx]
 		self.target_tmag = np.asarray(targets['tmag'], dtype='float64')[idx]
@@ -352,13 +388,11 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 	quality = np.asarray(quality, dtype='int32')
 	out = [{'status': 0, 'errors': [], 'stamp_resizes': 0} for _ in range(n)]
 	log = [_Messages() for _ in range(n)]
-	cur = []
-	for i in range(n):
-		try:
-			cur.append(st.default_stamp(targets['row'][i], targets['column'][i], targets['tmag'][i], stack.limits))
-		except ValueError as e: # BasePhotometry.py:671-672: the constructor raises -> STATUS.ERROR through tessphot
-			cur.append(None)
-			out[i].update(status=2, errors=['ValueError: ' + str(e)])
+	first, valid = st.default_stamps(targets['row'], targets['column'], targets['tmag'], stack.limits)
+	cur = [tuple(s) if ok else None for s, ok in zip(first.tolist(), valid.tolist())]
+	for i in np.flatnonzero(~valid): # BasePhotometry.py:671-672: the constructor raises -> STATUS.ERROR through tessphot
+		out[i].update(status=2, errors=['ValueError: Invalid stamp selected'])
+	cat_index = _CatalogIndex(catalog)
 	attempts_left = [st.retry_limit(targets['tmag'][i]) for i in range(n)]
 	active = [i for i in range(n) if cur[i] is not None]
 
@@ -373,8 +407,8 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 			groups.setdefault((cur[i][1] - cur[i][0], cur[i][3] - cur[i][2]), []).append(i)
 		still = []
 		for (H, W), idx in sorted(groups.items()):
-			cats = [_catalog_of_stamp(catalog, cur[i]) for i in idx]
-			scene = _GroupScene(stack, time, quality, cadence_s, [cur[i] for i in idx], cats, targets, np.asarray(idx))
+			cat_offsets, cat_arrays = _catalogs_of_stamps(cat_index, [cur[i] for i in idx])
+			scene = _GroupScene(stack, time, quality, cadence_s, [cur[i] for i in idx], cat_offsets, cat_arrays, targets, np.asarray(idx))
 			try:
 				cubes = stack.cut(ctx.array(scene.stamps), H, W)
 				batch = ApertureBatch(ctx, scene, cubes=cubes)
@@ -433,7 +467,7 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 				out[i].update(mask=mask, sumimage=res['sumimage'][j], flux=lc['flux'][j], flux_err=lc['flux_err'][j],
 					flux_background=lc['flux_background'][j], pos_centroid=lc['pos_centroid'][j],
 					contamination=float(res['contamination'][j]),
-					skip_targets=[int(s) for s in cats[j]['starid'][inside] if s != targets['starid'][i]],
+					skip_targets=[int(s) for s in cat_arrays['starid'][a:b][inside] if s != targets['starid'][i]],
 					diagnostics=dict(zip(engine.DIAGNOSTICS_COLUMNS, res['diagnostics'][j])))
 				finish(i, status)
 		active = still

@@ -61,6 +61,24 @@ def default_stamp(pos_row, pos_column, tmag, limits):
 	return clip_stamp(centred_stamp(pos_row, pos_column, n_rows, n_columns), limits)
 
 
+def default_stamps(pos_rows, pos_columns, tmags, limits):
+	"""
+	:func:`default_stamp` for a whole batch: int64 ``(n, 4)`` stamps and a bool vector that is False where the clipped stamp is
+	empty (``default_stamp`` raises ``ValueError`` there).  Same arithmetic, vectorised.
+	"""
+	t = _TMAG_HEIGHT_WIDTH
+	tm = np.asarray(tmags, dtype='float64')
+	n_rows = np.maximum(np.ceil(np.interp(tm, t[:, 0], t[:, 1])), MIN_STAMP)
+	n_cols = np.maximum(np.ceil(np.interp(tm, t[:, 0], t[:, 2])), MIN_STAMP)
+	r = np.round(np.asarray(pos_rows, dtype='float64')).astype('int64')
+	c = np.round(np.asarray(pos_columns, dtype='float64')).astype('int64')
+	hr, hc = (n_rows // 2).astype('int64'), (n_cols // 2).astype('int64')
+	st = np.stack((np.maximum(r - hr, limits[0]), np.minimum(r + hr + 1, limits[1]),
+		np.maximum(c - hc, limits[2]), np.minimum(c + hc + 1, limits[3])), axis=1)
+	valid = (st[:, 0] <= st[:, 1]) & (st[:, 2] <= st[:, 3])
+	return st, valid
+
+
 def moved(stamp, limits, pos_row=None, pos_column=None, down=None, up=None, left=None, right=None, width=None, height=None):
 	"""The stamp after a ``resize_stamp(...)`` request (BasePhotometry.py:567-613), clipped; may equal ``stamp``."""
 	st = list(stamp)

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Diagnostic: where the time of the batched drop-in path goes -- tessphot_frames on a synthetic CCD region (N targets on an
+FR x FR x T frame stack resident in HBM): device passes against host-side bookkeeping."""
+import os, sys, time, cProfile, pstats, io
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from photometry_amd import pipeline, tessphot_frames
+from photometry_amd.device import Context
+
+N, FR, T = int(os.environ.get('N', 5000)), int(os.environ.get('FR', 1024)), int(os.environ.get('T', 100))
+rng = np.random.default_rng(2)
+row0, col0 = 0, 44
+img = np.zeros((FR, FR))
+rows = rng.uniform(12, FR - 12, N); cols = rng.uniform(12, FR - 12, N); tmag = rng.uniform(8.5, 14.0, N)
+yy, xx = np.mgrid[-4:5, -4:5]
+for r, c, m in zip(rows, cols, tmag):
+	ri, ci = int(round(r)), int(round(c))
+	img[ri - 4:ri + 5, ci - 4:ci + 5] += 10**(-0.4 * (m - 20.451)) * np.exp(-0.5 * ((yy + ri - r)**2 + (xx + ci - c)**2) / 0.9**2) / (2 * np.pi * 0.81)
+frames = {}
+cube = (img[None] * (1 + 1e-3 * rng.normal(size=T))[:, None, None]).astype('float32')
+noise = np.sqrt(np.abs(cube) + 200.0).astype('float32')
+frames['images'] = (cube + 30.0 + rng.standard_normal(cube.shape).astype('float32') * noise).astype('float32')
+frames['images_err'] = noise
+frames['backgrounds'] = np.full(cube.shape, 100.0, dtype='float32')
+tstamp = 1500.0 + np.arange(T) * 1800.0 / 86400.0
+quality = np.zeros(T, dtype='int32')
+cat = {'starid': np.arange(N, dtype='int64') + 1, 'tmag': tmag.astype('float32'), 'row': (rows + row0).astype('float32'), 'column': (cols + col0).astype('float32')}
+targets = {'starid': cat['starid'].copy(), 'tmag': tmag, 'row': rows + row0, 'column': cols + col0}
+ctx = Context(0)
+stack = pipeline.FrameStack(ctx, frames, row0, col0)
+ctx.sync()
+tessphot_frames(ctx, stack, {k: v[:64] for k, v in targets.items()}, cat, tstamp, quality) # warm up
+for rep in range(2):
+	t0 = time.perf_counter()
+	pr = cProfile.Profile()
+	pr.enable()
+	out = tessphot_frames(ctx, stack, targets, cat, tstamp, quality)
+	pr.disable()
+	dt = time.perf_counter() - t0
+	ok = sum(1 for b in out if b.status.value in (1, 3))
+	print(f'tessphot_frames: {N} targets, {T} cadences, {FR}^2 frames: {dt:.3f} s = {N / dt:.0f} targets/s; OK/WARNING {ok}', flush=True)
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(22)
+print(s.getvalue()[:4500])
