@@ -194,3 +194,40 @@ def test_time_offset_applied_from_source_header(tmp_path):
 	pho = BasePhotometry(int(s.target_starid[0]), src, str(tmp_path), datasource='ffi')
 	np.testing.assert_array_equal(pho.lightcurve['time'], t0)
 	pho.close()
+
+
+def test_batch_helpers_equal_per_target_helpers():
+	"""The vectorised host helpers of the batched path (stamps.default_stamps, pipeline._catalogs_of_stamps) against the
+	per-target functions the plugin uses, on random regions: half-integer positions (rounding mode), stars exactly on the
+	half-pixel limits of the 5-pixel catalogue buffer, stamps clipped by the frame, invalid stamps."""
+	from photometry_amd import stamps as st, pipeline as pl
+	rng = np.random.default_rng(0)
+	n_stamps = 0
+	for trial in range(25):
+		n = int(rng.integers(5, 300))
+		R, C = int(rng.integers(30, 400)), int(rng.integers(30, 400))
+		limits = (100, 100 + R, 200, 200 + C)
+		rows, cols, tm = rng.uniform(90, 110 + R, n), rng.uniform(190, 210 + C, n), rng.uniform(1.5, 15, n)
+		rows[:3] = np.round(rows[:3]) + 0.5
+		S, valid = st.default_stamps(rows, cols, tm, limits)
+		for i in range(n):
+			try:
+				ref = st.default_stamp(rows[i], cols[i], tm[i], limits)
+				assert valid[i] and tuple(S[i]) == ref
+			except ValueError:
+				assert not valid[i]
+		cat = {'starid': np.arange(n) + 7, 'tmag': tm.astype('float32'), 'row': rows.astype('float32'), 'column': cols.astype('float32')}
+		cat['row'][:5] = np.array([S[0][0] - 5.5, S[0][1] + 4.5, S[0][0] - 5.5, S[0][1] + 4.49, S[0][0]], dtype='float32')
+		cat['column'][:2] = np.array([S[0][2] - 5.5, S[0][3] + 4.5], dtype='float32')
+		sel = [tuple(s) for s, v in zip(S.tolist(), valid) if v]
+		if not sel:
+			continue
+		off, arr = pl._catalogs_of_stamps(pl._CatalogIndex(cat), sel)
+		for j, s in enumerate(sel):
+			ref = pl._catalog_of_stamp(cat, s)
+			for k in ref:
+				a = arr[k][off[j]:off[j + 1]]
+				assert a.dtype == ref[k].dtype
+				np.testing.assert_array_equal(a, ref[k], err_msg=f'{trial} {j} {k}')
+		n_stamps += len(sel)
+	assert n_stamps > 1000
