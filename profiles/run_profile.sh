@@ -9,10 +9,10 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export TP_BENCH_NO_TORCH=1
-ARGS="--steps 5 --warmup 2 --cpu-sample 0 --e2e-targets 0 --frame 512"
+ARGS="--steps 5 --warmup 2 --cpu-sample 0 --e2e-targets 0 --frames-targets 0 --frame 512"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --e2e-targets 0 --frame 512 > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --e2e-targets 0 --frame 512 > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --e2e-targets 0 --frames-targets 0 --frame 512 > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --e2e-targets 0 --frames-targets 0 --frame 512 > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log
 cd $REPO
 python3 profiles/summarize.py $OUT $OUT/traffic.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
