@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic: does the VALU-bound B* of step s+1 overlap with the HBM-bound fused kernel of step s on two streams?"""
+"""Diagnostic: does the vector-ALU-bound B* overlap with the bandwidth-bound fused kernel on two streams?
+(a) across steps: step s+1's B* under step s's fused kernel (double-buffered background series);
+(b) inside one step: the batch in CH chunks of targets, B*(chunk c+1) under fused(chunk c)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from photometry_amd import simulate, engine, pipeline
@@ -36,8 +38,31 @@ def pipelined(n):
 		ctx2.record(ev_used[b])
 	ctx.sync(); ctx2.sync()
 
-for name, fn in (('sequential', sequential), ('pipelined', pipelined), ('sequential', sequential), ('pipelined', pipelined)):
-	fn(3)
+def chunked(n, ch):
+	per = (Nt + ch - 1) // ch
+	parts = [(a, min(per, Nt - a)) for a in range(0, Nt, per)]
+	bs = [batch.chunk(a, c) for a, c in parts]
+	ws = [works[0].chunk(a, c) for a, c in parts]
+	evs = [ctx.event() for _ in parts]
+	ev_done = ctx2.event()
+	for s in range(n):
+		if s:
+			ctx.wait_event(ev_done) # the step before has read its background series
+		for i in range(len(parts)):
+			engine.background_stamp(ctx, bs[i].images, out=ws[i].bkg_raw)
+			engine.smooth_time(ctx, ws[i].bkg_raw, batch.n_cad, batch.time_smooth, out=ws[i].bkg)
+			ctx.record(evs[i])
+			ctx2.wait_event(evs[i])
+			engine.aperture_photometry(ctx2, bs[i], ws[i], subtract=ws[i].bkg, backgrounds=ws[i].bkg)
+		ctx2.record(ev_done)
+	ctx.sync(); ctx2.sync()
+
+def timeit(fn, *a):
+	fn(3, *a)
 	t0 = time.perf_counter()
-	fn(10)
-	print(name, 'ms/step', round((time.perf_counter() - t0) / 10 * 1e3, 3), flush=True)
+	fn(10, *a)
+	return round((time.perf_counter() - t0) / 10 * 1e3, 3)
+
+for rep in range(2):
+	print('sequential', timeit(sequential), ' across steps', timeit(pipelined), ' chunks of one step:',
+		{ch: timeit(chunked, ch) for ch in (2, 3, 4, 6, 8)}, flush=True)
