@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round check on the GPU box: smoke, GPU suite, default bench, profile passes (run through gpurun: bash tools/r2c.sh)
+# Round check on the GPU box: smoke, GPU suite, default bench, profile passes (run through gpurun: bash tools/gpu_round_check.sh)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r2c
