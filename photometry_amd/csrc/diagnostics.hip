@@ -186,11 +186,11 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 	double* series = a.gscratch ? reinterpret_cast<double*>(a.gscratch + (size_t)blockIdx.x * a.gscratch_per_target)
 		: reinterpret_cast<double*>(hist + 260 + ((kThreads + 1 + 260) & 1)); // keep 8-byte alignment
 	double* srt = series;              // [TP2] scratch series (TP2 = max(T, 256))
-	double* fb = srt + TP2;            // [TP2] binned flux
-	double* gflux = fb + TP2;          // [T] relative flux of the good cadences
-	double* gerr = gflux + T;          // [T]
-	double* gtime = gerr + T;          // [T]
-	int* gk = reinterpret_cast<int*>(gtime + T); // [T] original index of the g-th good cadence
+	double* fb = srt;                  // the binned flux of the rms section lives in the same scratch (its deviations replace it in place)
+	double* gflux = srt + TP2;         // [T] relative flux of the good cadences
+	// the relative error and the time of a good cadence are not kept in the series scratch: they are one multiplication / one
+	// load away from arrays that stay in L2 (with the bin array sharing the scratch series: 31 instead of 62 KB of LDS per 1300-cadence target, four workgroups per CU)
+	int* gk = reinterpret_cast<int*>(gflux + T); // [T] original index of the g-th good cadence
 	int* bt = gk + T;                  // [T] time bin of every good cadence
 	double* o = a.out + (int64_t)target * 10;
 	const double nan = __builtin_nan("");
@@ -280,13 +280,11 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 	for (int g = tid; g < Ng; g += kThreads) srt[g] = flux[gk[g]];
 	const double mean_flux = block_median(srt, Ng, red, hist);
 	const double ainv = fabs(1.0 / mean_flux);
-	for (int g = tid; g < Ng; g += kThreads) {
-		const int k = gk[g];
-		gflux[g] = (flux[k] / mean_flux) - 1.0;
-		gerr[g] = ainv * ferr[k];
-		gtime[g] = a.time[k];
-	}
+	for (int g = tid; g < Ng; g += kThreads) gflux[g] = (flux[gk[g]] / mean_flux) - 1.0;
 	__syncthreads();
+	const double* tptr = a.time;
+	auto gtime_at = [&](int g) { return tptr[gk[g]]; };
+	auto gerr_at = [&](int g) { return ainv * ferr[gk[g]]; };
 
 	// ---- variance = nanvar(rel, ddof=1) (:1364): two passes
 	double variance;
@@ -309,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 		double tmn = __builtin_inf(), tmx = -__builtin_inf();
 		for (int g = tid; g < Ng; g += kThreads) {
 			cf += !is_nan(gflux[g]);
-			const double t = gtime[g];
+			const double t = gtime_at(g);
 			if (!is_nan(t)) { ct++; if (t < tmn) tmn = t; if (t > tmx) tmx = t; }
 		}
 		const double nfl = block_sum((double)cf, red), nt = block_sum((double)ct, red);
@@ -332,7 +330,7 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 					int mono = 1;
 					for (int g = tid; g < Ng; g += kThreads) {
 						int b = -1;
-						const double x = gtime[g];
+						const double x = gtime_at(g);
 						if (!is_nan(x)) {
 							b = (int)floor((x - tmin) / delta);
 							if (b < 0) b = 0;
@@ -361,7 +359,7 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 							}
 							__syncthreads();
 							const double med1 = block_median(fb, Ng, red, hist);
-							for (int g = tid; g < Ng; g += kThreads) srt[g] = fabs(fb[g] - med1);
+							for (int g = tid; g < Ng; g += kThreads) srt[g] = fabs(fb[g] - med1);   // in place: fb IS srt
 							const double med2 = block_median(srt, Ng, red, hist);
 							rms_hour = 1.482602218505602 * med2;
 						}
@@ -383,7 +381,7 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 					}
 					__syncthreads();
 					const double med1 = block_median(fb, nb, red, hist);
-					for (int b = tid; b < nb; b += kThreads) srt[b] = fabs(fb[b] - med1);
+					for (int b = tid; b < nb; b += kThreads) srt[b] = fabs(fb[b] - med1);   // in place: fb IS srt
 					const double med2 = block_median(srt, nb, red, hist);
 					rms_hour = 1.482602218505602 * med2; // utilities.mad_to_sigma (:25)
 					}
@@ -408,8 +406,9 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 		int c = 0;
 		double tmn = __builtin_inf(), tmx = -__builtin_inf();
 		for (int g = tid; g < Ng; g += kThreads) {
-			const bool ok = is_finite(gtime[g]) && is_finite(gflux[g]) && is_finite(gerr[g]);
-			if (ok) { c++; const double t = gtime[g]; if (t < tmn) tmn = t; if (t > tmx) tmx = t; }
+			const double t = gtime_at(g);
+			const bool ok = is_finite(t) && is_finite(gflux[g]) && is_finite(gerr_at(g));
+			if (ok) { c++; if (t < tmn) tmn = t; if (t > tmx) tmx = t; }
 		}
 		const double nfit = block_sum((double)c, red);
 		const double t0 = block_min(tmn, red), t1 = block_max(tmx, red);
@@ -420,9 +419,10 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 			// moments of the weighted normal equations: M[k] = sum w^2 u^k (k = 0..6), R[k] = sum w^2 u^k y (k = 0..3)
 			double mloc[7] = {0, 0, 0, 0, 0, 0, 0}, rloc[4] = {0, 0, 0, 0};
 			for (int g = tid; g < Ng; g += kThreads) {
-				const bool ok = is_finite(gtime[g]) && is_finite(gflux[g]) && is_finite(gerr[g]);
+				const double t = gtime_at(g), ge = gerr_at(g);
+				const bool ok = is_finite(t) && is_finite(gflux[g]) && is_finite(ge);
 				if (!ok) continue;
-				const double u = (gtime[g] - mid) / half, w = 1.0 / gerr[g], w2 = w * w, y = gflux[g];
+				const double u = (t - mid) / half, w = 1.0 / ge, w2 = w * w, y = gflux[g];
 				double p = w2;
 				for (int k = 0; k < 7; ++k) { mloc[k] += p; if (k < 4) rloc[k] += p * y; p *= u; }
 			}
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 		double s = 0.0; int cn = 0;
 		for (int g = tid; g < Ng; g += kThreads) {
 			double d = gflux[g];
-			if (have_fit) { const double u = (gtime[g] - mid) / half; d -= ((pc[3] * u + pc[2]) * u + pc[1]) * u + pc[0]; }
+			if (have_fit) { const double u = (gtime_at(g) - mid) / half; d -= ((pc[3] * u + pc[2]) * u + pc[1]) * u + pc[0]; }
 			srt[g] = d;
 			if (!is_nan(d)) { s += d; cn++; }
 		}
@@ -462,7 +462,8 @@ __global__ __launch_bounds__(kThreads) void tp_diagnostics_kernel(DiagArgs a)
 		for (int g = tid; g < Ng; g += kThreads) { const double d = srt[g]; if (!is_nan(d)) { const double e = d - avg; s2 += e * e; } }
 		const double tot2 = block_sum(s2, red);
 		const double sd = (cnt > 0.0) ? sqrt(tot2 / cnt) : nan;
-		const double med_err = block_median(gerr, Ng, red, hist);
+		for (int g = tid; g < Ng; g += kThreads) srt[g] = gerr_at(g);   // the residuals in srt have been consumed (barriers of the sums above)
+		const double med_err = block_median(srt, Ng, red, hist);
 		variability = sd / med_err;
 	}
 
@@ -494,7 +495,7 @@ extern "C" int tp_lightcurve_diagnostics(tp_ctx* ctx, int32_t n_targets, int32_t
 	int tp2 = (n_cad > 256) ? n_cad : 256;
 	if (d_mask && 2 * (height + width) > tp2) tp2 = 2 * (height + width);
 	const size_t small_bytes = kThreads * sizeof(double) + ((size_t)kThreads + 1 + 260 + 1) * sizeof(int);
-	const size_t series_bytes = (((size_t)2 * tp2 + 3 * (size_t)n_cad) * sizeof(double) + 2 * (size_t)n_cad * sizeof(int) + 15) & ~(size_t)15;
+	const size_t series_bytes = (((size_t)tp2 + (size_t)n_cad) * sizeof(double) + 2 * (size_t)n_cad * sizeof(int) + 15) & ~(size_t)15;
 	size_t shmem = small_bytes + series_bytes + 16;
 	unsigned char* gscratch = nullptr;
 	if (shmem > 160 * 1024) { // long light curves: the series arrays move to HBM scratch, one slice per target
