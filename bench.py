@@ -722,7 +722,7 @@ def leg_linpsf(ctx, scene, cubes, work, args, Nt, T, H, W, np, engine, pipeline)
 	prof = ctx.profile_report()
 	kernels = {name: {'launches': c, 'avg_ms': t / c, 'ms_per_step': t / n} for name, (c, t) in prof.items()}
 	# the fit = plan + coefficient store + one fit launch per star count: the step's fit time is their sum
-	fit_ms = sum(kernels[k]['ms_per_step'] for k in ('tp_linpsf_fit_kernel', 'tp_linpsf_plan_kernel', 'tp_linpsf_coef_kernel') if k in kernels)
+	fit_ms = sum(kernels[k]['ms_per_step'] for k in ('tp_linpsf_fit_kernel', 'tp_linpsf_fitm_kernel', 'tp_linpsf_plan_kernel', 'tp_linpsf_coef_kernel') if k in kernels)
 	nfit = batch.n_fit_stars
 	counts = np.diff(batch.star_offsets_h)
 	# flops the polynomial path EXECUTES (estimate): per star-cadence ~79 pixels inside the 5 px cut-off x 24 Horner FMAs; per

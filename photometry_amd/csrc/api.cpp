@@ -28,6 +28,7 @@ static const char* const kKernelNames[TPK_COUNT] = {
 	"tp_linpsf_plan_kernel",
 	"tp_linpsf_coef_kernel",
 	"tp_synth_kernel",
+	"tp_linpsf_fitm_kernel",
 };
 
 extern "C" {

@@ -33,6 +33,7 @@ enum tp_kernel_id {
 	TPK_LINPSF_PLAN,
 	TPK_LINPSF_COEF,
 	TPK_SYNTH,
+	TPK_LINPSF_FIT_MFMA,
 	TPK_COUNT
 };
 
@@ -53,6 +54,7 @@ struct tp_ctx {
 	size_t scratch_bytes = 0;
 	void* store = nullptr;      // second grow-only buffer: the polynomial coefficient store of tp_linpsf_fit
 	size_t store_bytes = 0;
+	int linpsf_path = 0;        // tp_linpsf_set_path: 0 = matrix-core fit where a target qualifies, 1 = vector-ALU kernels only
 	void* comm = nullptr;       // ncclComm_t (comm.cpp)
 	int comm_rank = 0, comm_size = 1;
 

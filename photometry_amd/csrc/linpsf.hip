@@ -28,17 +28,15 @@
 // MI355X the FP64 matrix rate equals the FP64 vector rate (78.6 TFLOP/s both), the monomial-basis GEMM form of the
 // polynomial ([cadences x 25] x [25 x pixels]) would also compute the pixels outside the cut-off circle, and the dense
 // form of the direct contraction does 13x the flops of the banded one.
-#include "common.h"
-#include "linpsf_dev.h"
-#include <cmath>
+#include "linpsf_common.h"
 
 void* tp_ctx_scratch(tp_ctx* ctx, size_t bytes); // aperture.hip
 
 namespace {
 
 using namespace tp_prf;
+using namespace tp_linpsf;
 
-constexpr int kMaxStars = 8;
 constexpr int kMaxSamples = 32;
 
 //--------------------------------------------------------------------------------------------------
@@ -61,99 +59,6 @@ __global__ __launch_bounds__(256) void tp_linpsf_prf_kernel(const double* __rest
 	}
 }
 
-//--------------------------------------------------------------------------------------------------
-// P2..P4
-//--------------------------------------------------------------------------------------------------
-struct FitArgs {
-	const float* images; const float* subtract; int64_t subtract_pitch;
-	int n_cad, height, width; int64_t t_pitch;
-	const double* coef;          // [n_targets][n*n]
-	const double* knots_x;       // [n+4] knots along the first spline axis (columns)
-	const double* knots_y;       // [n+4] knots along the second spline axis (rows)
-	int n;                       // coefficients per axis (117)
-	const int64_t* star_offsets; // [n_targets+1] into the fitted-star arrays
-	const int32_t* target_index; // [n_targets] index of the main target inside its fitted stars
-	const double* pos_row;       // [n_fit_stars][pos_pitch] row_stamp per cadence
-	const double* pos_col;       // [n_fit_stars][pos_pitch]
-	int64_t pos_pitch;
-	double cutoff;
-	double* flux;                // [n_targets][out_pitch]  lightcurve flux (target star)
-	double* flux_err;            // [n_targets][out_pitch]  NaN (linpsf_photometry.py:169)
-	double* fluxes_all;          // [n_fit_stars][out_pitch] fitted flux of every star (for the mean fluxes)
-	int64_t out_pitch;
-};
-
-// Cyclic Jacobi eigen-decomposition based pseudo-inverse solve:  x = pinv(G) g,  G symmetric S x S.
-template <int S>
-__device__ __forceinline__ void pinv_solve(double (&G)[S][S], const double (&g)[S], int ns, double (&x)[S])
-{
-	double V[S][S];
-#pragma unroll
-	for (int i = 0; i < S; ++i)
-#pragma unroll
-		for (int j = 0; j < S; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
-	for (int sweep = 0; sweep < 30; ++sweep) {
-		double off = 0.0;
-#pragma unroll
-		for (int p = 0; p < S; ++p)
-#pragma unroll
-			for (int q = p + 1; q < S; ++q) if (q < ns) off += G[p][q] * G[p][q];
-		double d2 = 0.0;
-#pragma unroll
-		for (int p = 0; p < S; ++p) if (p < ns) d2 += G[p][p] * G[p][p];
-		if (!(off > 1e-34 * d2)) break; // off-diagonal below 1e-17 relative: converged (or NaN)
-#pragma unroll
-		for (int p = 0; p < S; ++p) {
-#pragma unroll
-			for (int q = p + 1; q < S; ++q) {
-				if (q >= ns) continue;
-				const double apq = G[p][q];
-				if (apq == 0.0) continue;
-				const double theta = (G[q][q] - G[p][p]) / (2.0 * apq);
-				const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-				const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-#pragma unroll
-				for (int k = 0; k < S; ++k) {
-					const double gkp = G[k][p], gkq = G[k][q];
-					G[k][p] = c * gkp - s * gkq;
-					G[k][q] = s * gkp + c * gkq;
-				}
-#pragma unroll
-				for (int k = 0; k < S; ++k) {
-					const double gpk = G[p][k], gqk = G[q][k];
-					G[p][k] = c * gpk - s * gqk;
-					G[q][k] = s * gpk + c * gqk;
-				}
-#pragma unroll
-				for (int k = 0; k < S; ++k) {
-					const double vkp = V[k][p], vkq = V[k][q];
-					V[k][p] = c * vkp - s * vkq;
-					V[k][q] = s * vkp + c * vkq;
-				}
-			}
-		}
-	}
-	// numpy.linalg.pinv: singular values (= |eigenvalues|) <= 1e-15 * max are treated as zero
-	double smax = 0.0;
-#pragma unroll
-	for (int i = 0; i < S; ++i) if (i < ns) { const double a = fabs(G[i][i]); if (a > smax || a != a) smax = a; }
-	const double cut = 1e-15 * smax;
-#pragma unroll
-	for (int i = 0; i < S; ++i) x[i] = 0.0;
-#pragma unroll
-	for (int e = 0; e < S; ++e) {
-		if (e >= ns) continue;
-		const double lam = G[e][e];
-		double proj = 0.0;
-#pragma unroll
-		for (int k = 0; k < S; ++k) if (k < ns) proj += V[k][e] * g[k];
-		const double inv = (fabs(lam) > cut) ? (1.0 / lam) : ((lam != lam) ? lam : 0.0);
-		const double coef = proj * inv;
-#pragma unroll
-		for (int k = 0; k < S; ++k) if (k < ns) x[k] += V[k][e] * coef;
-	}
-}
-
 // General path: direct evaluation of the 13x13 contraction per star, pixel and cadence.  Runs only for the
 // targets that the polynomial path could not take (`todo` flag set, or todo == nullptr).
 template <int S, int SLO>
@@ -161,7 +66,7 @@ __global__ __launch_bounds__(512) void tp_linpsf_fit_direct_kernel(FitArgs a, co
 {
 	extern __shared__ __align__(16) double lds[]; // [n*n] coefficient table + 2 x [n+4] knots
 	const int target = blockIdx.x;
-	if (todo && !todo[target]) return;
+	if (todo && todo[target] != kPathDirect) return;
 	{ const int nst = (int)(a.star_offsets[target + 1] - a.star_offsets[target]); if (nst < SLO || nst > S) return; } // another instantiation's targets
 	const int tid = threadIdx.x;
 	const int n = a.n;
@@ -298,8 +203,6 @@ struct StarBox { int axmin, axmax, bymin, bymax, jmin, jmax, imin, imax; };
 // cadences per lane sharing the scalar loads and the uniform tests (10.9 - 11.9 ms for the combinations tried: no gain, the
 // extra registers cost what the shared work saves).
 //--------------------------------------------------------------------------------------------------
-struct StarPlan { int axmin, bymin, nby, nc, jmin, jmax, imin, imax; long long item_off; };
-
 // a * b + c with c in scalar registers: one VOP3 instruction (left alone the compiler copies a uniform addend into vector
 // registers and accumulates with v_fmac)
 __device__ __forceinline__ double fma_sgpr_addend(double a, double b, double c) {
@@ -308,13 +211,22 @@ __device__ __forceinline__ double fma_sgpr_addend(double a, double b, double c) 
 	return r;
 }
 
+// inverse of the reflected Gray code n ^ (n >> 1) on 4 bits: the place of a membership pattern in the order 1,3,2,6,7,5,4,12,...
+__device__ __forceinline__ unsigned gray_rank4(unsigned g) { g ^= g >> 2; g ^= g >> 1; return g & 15u; }
+
+// totals[0]: items (25 doubles each) of the polynomial store; totals[1]: doubles of the matrix-core store (laid behind it)
 __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan* __restrict__ plans, int32_t* __restrict__ todo,
-	unsigned long long* __restrict__ total_items, int max_origins, int32_t* __restrict__ order, int sort_n)
+	unsigned long long* __restrict__ totals, int max_origins, int32_t* __restrict__ order, int sort_n,
+	MPlan* __restrict__ mplans, uint16_t* __restrict__ ulist, uint8_t* __restrict__ usig, int use_mfma)
 {
 	extern __shared__ unsigned long long skeys[];   // [sort_n] (key of the cadence's origins) * 8192 + cadence, or nothing
 	__shared__ StarBox sbox[kMaxStars];
 	__shared__ StarPlan spl[kMaxStars];
-	__shared__ int s_ok;
+	__shared__ double spos[4][kMfmaStars][4];      // per wavefront and star: min / max of the row and column position
+	__shared__ double srange[kMfmaStars][4];
+	__shared__ unsigned pkeys[kMfmaPixels];
+	__shared__ unsigned s_tiles[kMfmaStars];
+	__shared__ int s_ok, s_nkeys, s_path;
 	__shared__ double kn[160], kny[160];
 	const int target = blockIdx.x, tid = threadIdx.x;
 	const int n = a.n;
@@ -322,18 +234,20 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 	const int ns = (int)(a.star_offsets[target + 1] - s0);
 	int32_t* ord = order + (int64_t)target * a.n_cad;
 	if (ns > kMaxStars) return;   // the many-star kernel's targets
-	if (tid == 0) s_ok = 0;
+	if (tid == 0) { s_ok = 0; s_nkeys = 0; s_path = kPathPoly; }
 	for (int i = tid; i < n + 4; i += 256) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
 	if (tid < kMaxStars) {
 		sbox[tid].axmin = sbox[tid].bymin = sbox[tid].jmin = sbox[tid].imin = 0x7fffffff;
 		sbox[tid].axmax = sbox[tid].bymax = sbox[tid].jmax = sbox[tid].imax = -0x7fffffff;
 	}
+	if (tid < kMfmaStars) s_tiles[tid] = 0u;
 	__syncthreads();
 	const double h = kn[5] - kn[4], hy = kny[5] - kny[4];
 	const double cutoff = a.cutoff;
 	for (int s = 0; s < ns; ++s) {
 		const int big = 0x7fffffff;
 		int lo[4] = {big, big, big, big}, hi[4] = {-big, -big, -big, -big};
+		double pr[4] = {1e300, -1e300, 1e300, -1e300};   // row min, row max, column min, column max over the valid cadences
 		for (int k = tid; k < a.n_cad; k += 256) {
 			const double srow = a.pos_row[(s0 + s) * a.pos_pitch + k], scol = a.pos_col[(s0 + s) * a.pos_pitch + k];
 			double phx, phy; int ax0, by0;
@@ -344,6 +258,7 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 				const int v1[4] = {ax0, by0, (int)ceil(scol + cutoff), (int)ceil(srow + cutoff)};
 #pragma unroll
 				for (int e = 0; e < 4; ++e) { lo[e] = (v0[e] < lo[e]) ? v0[e] : lo[e]; hi[e] = (v1[e] > hi[e]) ? v1[e] : hi[e]; }
+				pr[0] = fmin(pr[0], srow); pr[1] = fmax(pr[1], srow); pr[2] = fmin(pr[2], scol); pr[3] = fmax(pr[3], scol);
 			}
 		}
 #pragma unroll
@@ -354,22 +269,28 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 				lo[e] = (l2 < lo[e]) ? l2 : lo[e];
 				hi[e] = (h2 > hi[e]) ? h2 : hi[e];
 			}
+			pr[0] = fmin(pr[0], __shfl_xor(pr[0], off, 64)); pr[1] = fmax(pr[1], __shfl_xor(pr[1], off, 64));
+			pr[2] = fmin(pr[2], __shfl_xor(pr[2], off, 64)); pr[3] = fmax(pr[3], __shfl_xor(pr[3], off, 64));
 		}
-		if ((tid & 63) == 0 && hi[0] >= lo[0]) {
-			atomicMin(&sbox[s].axmin, lo[0]); atomicMax(&sbox[s].axmax, hi[0]);
-			atomicMin(&sbox[s].bymin, lo[1]); atomicMax(&sbox[s].bymax, hi[1]);
-			atomicMin(&sbox[s].jmin, lo[2]); atomicMax(&sbox[s].jmax, hi[2]);
-			atomicMin(&sbox[s].imin, lo[3]); atomicMax(&sbox[s].imax, hi[3]);
+		if ((tid & 63) == 0) {
+			if (hi[0] >= lo[0]) {
+				atomicMin(&sbox[s].axmin, lo[0]); atomicMax(&sbox[s].axmax, hi[0]);
+				atomicMin(&sbox[s].bymin, lo[1]); atomicMax(&sbox[s].bymax, hi[1]);
+				atomicMin(&sbox[s].jmin, lo[2]); atomicMax(&sbox[s].jmax, hi[2]);
+				atomicMin(&sbox[s].imin, lo[3]); atomicMax(&sbox[s].imax, hi[3]);
+			}
+			if (s < kMfmaStars) {
+#pragma unroll
+				for (int e = 0; e < 4; ++e) spos[tid >> 6][s][e] = pr[e];
+			}
 		}
 	}
 	__syncthreads();
 	if (tid == 0) {
-		long long items = 0;
 		bool too_many = false;
-		StarPlan pl[kMaxStars];
 		for (int s = 0; s < ns; ++s) {
 			StarBox b = sbox[s];
-			StarPlan& q = pl[s];
+			StarPlan& q = spl[s];
 			q.axmin = q.bymin = 0; q.nby = 1; q.nc = 0; q.jmin = q.imin = 0; q.jmax = q.imax = -1; q.item_off = 0;
 			if (b.axmax < b.axmin) continue;   // never a valid position: an all-zero column
 			if (b.jmin < 0) b.jmin = 0;
@@ -380,13 +301,79 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 			q.axmin = b.axmin; q.bymin = b.bymin; q.nby = b.bymax - b.bymin + 1; q.nc = (b.axmax - b.axmin + 1) * q.nby;
 			q.jmin = b.jmin; q.jmax = b.jmax; q.imin = b.imin; q.imax = b.imax;
 			if (q.nc > max_origins) too_many = true;
-			q.item_off = items;
-			items += (long long)q.nc * (b.jmax - b.jmin + 1) * (b.imax - b.imin + 1);
 		}
-		if (too_many) todo[target] = 1;   // pointing excursions over many knots: the general kernel
+		for (int s = 0; s < ns && s < kMfmaStars; ++s) {
+			srange[s][0] = fmin(fmin(spos[0][s][0], spos[1][s][0]), fmin(spos[2][s][0], spos[3][s][0]));
+			srange[s][1] = fmax(fmax(spos[0][s][1], spos[1][s][1]), fmax(spos[2][s][1], spos[3][s][1]));
+			srange[s][2] = fmin(fmin(spos[0][s][2], spos[1][s][2]), fmin(spos[2][s][2], spos[3][s][2]));
+			srange[s][3] = fmax(fmax(spos[0][s][3], spos[1][s][3]), fmax(spos[2][s][3], spos[3][s][3]));
+		}
+		if (too_many) s_path = kPathDirect;   // pointing excursions over many knots: the general kernel
+		else if (use_mfma && ns <= kMfmaStars && a.height * a.width <= 65535) s_path = kPathMfma;
+	}
+	__syncthreads();
+	if (s_path == kPathMfma) {
+		// the pixels some star can reach at some cadence: nearer than the cut-off to the rectangle its position sweeps
+		const int npix = a.height * a.width;
+		const double reach = (cutoff + 1e-6) * (cutoff + 1e-6);
+		for (int p = tid; p < npix; p += 256) {
+			const int i = p / a.width, j = p - i * a.width;
+			unsigned sig = 0u;
+			for (int s = 0; s < ns; ++s) {
+				if (spl[s].nc <= 0) continue;
+				const double dr = fmax(0.0, fmax(srange[s][0] - (double)i, (double)i - srange[s][1]));
+				const double dc = fmax(0.0, fmax(srange[s][2] - (double)j, (double)j - srange[s][3]));
+				if (dr * dr + dc * dc < reach) sig |= 1u << s;
+			}
+			if (sig) {
+				const int idx = atomicAdd(&s_nkeys, 1);
+				if (idx < kMfmaPixels) pkeys[idx] = (gray_rank4(sig) << 20) | (sig << 16) | (unsigned)p;
+			}
+		}
+		__syncthreads();
+		const int nk = s_nkeys;
+		if (nk > kMfmaPixels) { if (tid == 0) s_path = kPathPoly; }   // a large stamp: the vector-ALU kernels
 		else {
-			const long long base = (long long)atomicAdd(total_items, (unsigned long long)items);
-			for (int s = 0; s < ns; ++s) { pl[s].item_off += base; plans[(int64_t)target * kMaxStars + s] = pl[s]; spl[s] = pl[s]; }
+			uint16_t* ul = ulist + (int64_t)target * kMfmaPixels;
+			uint8_t* us = usig + (int64_t)target * kMfmaPixels;
+			if (tid < nk) {
+				const unsigned key = pkeys[tid];
+				int r = 0;
+				for (int q = 0; q < nk; ++q) r += (pkeys[q] < key) ? 1 : 0;
+				const unsigned sig = (key >> 16) & 15u;
+				ul[r] = (uint16_t)(key & 0xffffu);
+				us[r] = (uint8_t)sig;
+				for (int s = 0; s < ns; ++s) if (sig & (1u << s)) atomicOr(&s_tiles[s], 1u << (r >> 4));
+			} else if (tid < kMfmaPixels) { ul[tid] = (uint16_t)0xffffu; us[tid] = (uint8_t)0; }
+		}
+		__syncthreads();
+	}
+	const int path = s_path;
+	if (tid == 0) {
+		if (path == kPathDirect) todo[target] = kPathDirect;
+		else if (path == kPathMfma) {
+			MPlan mp;
+			mp.n_pix = s_nkeys; mp.n_tiles = (s_nkeys + 15) >> 4;
+			long long need = 0;
+			for (int s = 0; s < kMfmaStars; ++s) {
+				mp.tiles[s] = (s < ns) ? s_tiles[s] : 0u;
+				mp.koff[s] = need;
+				if (s < ns) need += (long long)spl[s].nc * __popc(mp.tiles[s]) * (7 * 64);
+			}
+			const long long base = (long long)atomicAdd(&totals[1], (unsigned long long)need);
+			for (int s = 0; s < kMfmaStars; ++s) mp.koff[s] += base;
+			mplans[target] = mp;
+			for (int s = 0; s < ns; ++s) plans[(int64_t)target * kMaxStars + s] = spl[s];
+			todo[target] = kPathMfma;
+		} else {
+			long long items = 0;
+			for (int s = 0; s < ns; ++s) {
+				StarPlan& q = spl[s];
+				q.item_off = items;
+				if (q.nc > 0) items += (long long)q.nc * (q.jmax - q.jmin + 1) * (q.imax - q.imin + 1);
+			}
+			const long long base = (long long)atomicAdd(&totals[0], (unsigned long long)items);
+			for (int s = 0; s < ns; ++s) { spl[s].item_off += base; plans[(int64_t)target * kMaxStars + s] = spl[s]; }
 			s_ok = 1;
 		}
 	}
@@ -426,12 +413,47 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 	for (int k = tid; k < a.n_cad; k += 256) ord[k] = (int)(skeys[k] & 8191ull);
 }
 
+// the 25 coefficients (times h2) of the 13 x 13 table patch at (ax, by): kk[e][b], e = power of phi_x, b = power of phi_y
+__device__ __forceinline__ void patch_coefficients(const double* __restrict__ C, int n, int ax, int by, double h2, double (&kk)[5][5])
+{
+#pragma unroll
+	for (int e = 0; e < 5; ++e)
+#pragma unroll
+		for (int bcol = 0; bcol < 5; ++bcol) kk[e][bcol] = 0.0;
+	const double* c0 = C + (int64_t)ax * n + by;
+#pragma unroll 1
+	for (int pp = 0; pp < 13; ++pp) {
+		const double* r = c0 + pp * n;
+		double rv[13];
+#pragma unroll
+		for (int q = 0; q < 13; ++q) rv[q] = r[q];
+		const double e0 = kEdgePoly[pp][0], e1 = kEdgePoly[pp][1], e2 = kEdgePoly[pp][2], e3 = kEdgePoly[pp][3], e4 = kEdgePoly[pp][4];
+#pragma unroll
+		for (int bcol = 0; bcol < 5; ++bcol) {
+			double t = 0.0;
+#pragma unroll
+			for (int q = 0; q < 13; ++q) t = __builtin_fma(kEdgePoly[q][bcol], rv[q], t);
+			kk[0][bcol] = __builtin_fma(e0, t, kk[0][bcol]);
+			kk[1][bcol] = __builtin_fma(e1, t, kk[1][bcol]);
+			kk[2][bcol] = __builtin_fma(e2, t, kk[2][bcol]);
+			kk[3][bcol] = __builtin_fma(e3, t, kk[3][bcol]);
+			kk[4][bcol] = __builtin_fma(e4, t, kk[4][bcol]);
+		}
+	}
+#pragma unroll
+	for (int e = 0; e < 5; ++e)
+#pragma unroll
+		for (int bcol = 0; bcol < 5; ++bcol) kk[e][bcol] *= h2;
+}
+
 __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const StarPlan* __restrict__ plans, const int32_t* __restrict__ todo,
-	double* __restrict__ store)
+	double* __restrict__ store, const MPlan* __restrict__ mplans, const uint16_t* __restrict__ ulist, const uint8_t* __restrict__ usig,
+	double* __restrict__ kstore)
 {
 	extern __shared__ __align__(16) double ctab[];   // the target's coefficient table [n*n]: every patch is read ~5 times over
 	const int target = blockIdx.x, tid = threadIdx.x;
-	if (todo[target]) return;
+	const int path = todo[target];
+	if (path == kPathDirect) return;
 	const int ns = (int)(a.star_offsets[target + 1] - a.star_offsets[target]);
 	if (ns > kMaxStars) return;
 	const int n = a.n;
@@ -448,6 +470,54 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 	}
 	__syncthreads();
 	const double* C = ctab;
+	if (path == kPathMfma) {
+		// matrix-core layout: per (star, origin, tile of the star) the A operands of the 7 MFMA steps, lane = (monomial group g,
+		// pixel u of the tile); monomial of (step j, group g): j < 5: phi_x^j phi_y^g; j = 5: phi_x^g phi_y^4; j = 6: g = 0:
+		// phi_x^4 phi_y^4, else a zero pad.  Pixels of the tile the star never reaches get zeros.
+		const MPlan mp = mplans[target];
+		const uint16_t* ul = ulist + (int64_t)target * kMfmaPixels;
+		const uint8_t* us = usig + (int64_t)target * kMfmaPixels;
+		for (int s = 0; s < ns; ++s) {
+			const StarPlan p = plans[(int64_t)target * kMaxStars + s];
+			const unsigned tiles = mp.tiles[s];
+			const int nt = __popc(tiles);
+			const int nitems = p.nc * nt * 16;
+			for (int item = tid; item < nitems; item += 512) {
+				const int co = item / (nt * 16), rem = item - co * (nt * 16);
+				const int r = rem >> 4, u = rem & 15;
+				unsigned m = tiles;
+				for (int q = 0; q < r; ++q) m &= m - 1;          // drop the r lowest set bits
+				const int tile = __ffs(m) - 1;
+				const int slot = tile * 16 + u;
+				const unsigned pix = ul[slot];
+				double kk[5][5];
+				if (pix != 0xffffu && ((us[slot] >> s) & 1)) {
+					const int i = (int)pix / a.width, j = (int)pix - i * a.width;
+					const int cx = co / p.nby, cy = co - cx * p.nby;
+					int ax = (p.axmin + cx) + 9 * j, by = (p.bymin + cy) + 9 * i;
+					ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
+					by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
+					patch_coefficients(C, n, ax, by, h2, kk);
+				} else {
+#pragma unroll
+					for (int e = 0; e < 5; ++e)
+#pragma unroll
+						for (int d = 0; d < 5; ++d) kk[e][d] = 0.0;
+				}
+				double* dst = kstore + mp.koff[s] + ((int64_t)(co * nt + r) * 7) * 64 + u;
+#pragma unroll
+				for (int j = 0; j < 5; ++j)
+#pragma unroll
+					for (int g = 0; g < 4; ++g) dst[j * 64 + g * 16] = kk[j][g];
+#pragma unroll
+				for (int g = 0; g < 4; ++g) dst[5 * 64 + g * 16] = kk[g][4];
+				dst[6 * 64] = kk[4][4];
+#pragma unroll
+				for (int g = 1; g < 4; ++g) dst[6 * 64 + g * 16] = 0.0;
+			}
+		}
+		return;
+	}
 	for (int s = 0; s < ns; ++s) {
 		const StarPlan p = plans[(int64_t)target * kMaxStars + s];
 		const int ncols = p.jmax - p.jmin + 1, nrows = p.imax - p.imin + 1;
@@ -463,35 +533,12 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 			ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
 			by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
 			double kk[5][5];
-#pragma unroll
-			for (int e = 0; e < 5; ++e)
-#pragma unroll
-				for (int bcol = 0; bcol < 5; ++bcol) kk[e][bcol] = 0.0;
-			const double* c0 = C + (int64_t)ax * n + by;
-#pragma unroll 1
-			for (int pp = 0; pp < 13; ++pp) {
-				const double* r = c0 + pp * n;
-				double rv[13];
-#pragma unroll
-				for (int q = 0; q < 13; ++q) rv[q] = r[q];
-				const double e0 = kEdgePoly[pp][0], e1 = kEdgePoly[pp][1], e2 = kEdgePoly[pp][2], e3 = kEdgePoly[pp][3], e4 = kEdgePoly[pp][4];
-#pragma unroll
-				for (int bcol = 0; bcol < 5; ++bcol) {
-					double t = 0.0;
-#pragma unroll
-					for (int q = 0; q < 13; ++q) t = __builtin_fma(kEdgePoly[q][bcol], rv[q], t);
-					kk[0][bcol] = __builtin_fma(e0, t, kk[0][bcol]);
-					kk[1][bcol] = __builtin_fma(e1, t, kk[1][bcol]);
-					kk[2][bcol] = __builtin_fma(e2, t, kk[2][bcol]);
-					kk[3][bcol] = __builtin_fma(e3, t, kk[3][bcol]);
-					kk[4][bcol] = __builtin_fma(e4, t, kk[4][bcol]);
-				}
-			}
+			patch_coefficients(C, n, ax, by, h2, kk);
 			double* dst = store + (p.item_off + item) * 25;
 #pragma unroll
 			for (int e = 0; e < 5; ++e)
 #pragma unroll
-				for (int bcol = 0; bcol < 5; ++bcol) dst[e * 5 + bcol] = h2 * kk[e][bcol];
+				for (int bcol = 0; bcol < 5; ++bcol) dst[e * 5 + bcol] = kk[e][bcol];
 		}
 	}
 }
@@ -504,7 +551,7 @@ __global__ __launch_bounds__(256) void tp_linpsf_fit2_kernel(FitArgs a, const St
 	const int64_t s0 = a.star_offsets[target];
 	int ns = (int)(a.star_offsets[target + 1] - s0);
 	if (ns < SLO || ns > S) return;   // another instantiation's targets
-	if (todo[target]) return;         // the general kernel's
+	if (todo[target] != kPathPoly) return;   // the general / the matrix-core kernel's
 	const int tid = threadIdx.x;
 	const int slot = blockIdx.y * blockDim.x + tid;   // position in the origin-sorted order of the target's cadences
 	const bool active = slot < a.n_cad;
@@ -1017,6 +1064,14 @@ extern "C" int tp_linpsf_prf(tp_ctx* ctx, int32_t n_targets, int32_t n_samples, 
 	TP_API_END(ctx)
 }
 
+extern "C" int tp_linpsf_set_path(tp_ctx* ctx, int32_t path)
+{
+	TP_CHECK_CTX(ctx);
+	TP_REQUIRE(ctx, path == 0 || path == 1, "tp_linpsf_set_path: 0 (matrix-core fit where a target qualifies) or 1 (vector-ALU kernels only)");
+	ctx->linpsf_path = path;
+	return TP_OK;
+}
+
 extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
 	const float* d_subtract, int64_t subtract_pitch,
 	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis, int32_t max_stars,
@@ -1057,24 +1112,35 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	const size_t todo_bytes = ((size_t)desc->n_targets * sizeof(int32_t) + 255) & ~(size_t)255;
 	const size_t plan_bytes = ((size_t)desc->n_targets * kMaxStars * sizeof(StarPlan) + 255) & ~(size_t)255;
 	const size_t order_bytes = ((size_t)desc->n_targets * desc->n_cad * sizeof(int32_t) + 255) & ~(size_t)255;
-	TP_REQUIRE(ctx, tp_ctx_scratch(ctx, todo_bytes + plan_bytes + 256 + order_bytes) != nullptr, "tp_linpsf_fit: out of device memory for the plan");
-	int32_t* d_todo = static_cast<int32_t*>(ctx->scratch);
-	StarPlan* d_plans = reinterpret_cast<StarPlan*>(static_cast<char*>(ctx->scratch) + todo_bytes);
-	unsigned long long* d_total = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->scratch) + todo_bytes + plan_bytes);
-	int32_t* d_order = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->scratch) + todo_bytes + plan_bytes + 256);
+	const size_t mplan_bytes = ((size_t)desc->n_targets * sizeof(MPlan) + 255) & ~(size_t)255;
+	const size_t ulist_bytes = ((size_t)desc->n_targets * kMfmaPixels * sizeof(uint16_t) + 255) & ~(size_t)255;
+	const size_t usig_bytes = ((size_t)desc->n_targets * kMfmaPixels * sizeof(uint8_t) + 255) & ~(size_t)255;
+	const size_t head_bytes = todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes + usig_bytes;
+	TP_REQUIRE(ctx, tp_ctx_scratch(ctx, head_bytes) != nullptr, "tp_linpsf_fit: out of device memory for the plan");
+	char* sbase = static_cast<char*>(ctx->scratch);
+	int32_t* d_todo = reinterpret_cast<int32_t*>(sbase);
+	StarPlan* d_plans = reinterpret_cast<StarPlan*>(sbase + todo_bytes);
+	unsigned long long* d_total = reinterpret_cast<unsigned long long*>(sbase + todo_bytes + plan_bytes);
+	int32_t* d_order = reinterpret_cast<int32_t*>(sbase + todo_bytes + plan_bytes + 256);
+	MPlan* d_mplans = reinterpret_cast<MPlan*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes);
+	uint16_t* d_ulist = reinterpret_cast<uint16_t*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes);
+	uint8_t* d_usig = reinterpret_cast<uint8_t*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes);
 	// cadences sorted by origin in LDS (8 bytes per slot, next power of two); beyond 8192 cadences the order stays natural
 	int sort_n = 64;
 	while (sort_n < desc->n_cad) sort_n <<= 1;
 	if (sort_n > 8192) sort_n = 0;
+	const int use_mfma = (ctx->linpsf_path == 0) ? 1 : 0;
 	TP_HIP(ctx, hipMemsetAsync(d_todo, 0, todo_bytes, ctx->stream));
-	TP_HIP(ctx, hipMemsetAsync(d_total, 0, sizeof(unsigned long long), ctx->stream));
+	TP_HIP(ctx, hipMemsetAsync(d_total, 0, 2 * sizeof(unsigned long long), ctx->stream));
 	if (sort_n > 4096) TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sort_n * sizeof(unsigned long long))));
-	TP_LAUNCH(ctx, TPK_LINPSF_PLAN, tp_linpsf_plan_kernel, dim3((unsigned)desc->n_targets), dim3(256), (size_t)sort_n * sizeof(unsigned long long), a, d_plans, d_todo, d_total, max_origins, d_order, sort_n);
+	TP_LAUNCH(ctx, TPK_LINPSF_PLAN, tp_linpsf_plan_kernel, dim3((unsigned)desc->n_targets), dim3(256), (size_t)sort_n * sizeof(unsigned long long), a, d_plans, d_todo, d_total, max_origins, d_order, sort_n,
+		d_mplans, d_ulist, d_usig, use_mfma);
 	TP_LAUNCH_CHECK(ctx, "tp_linpsf_plan_kernel");
-	unsigned long long total_items = 0;
-	TP_HIP(ctx, hipMemcpyAsync(&total_items, d_total, sizeof(total_items), hipMemcpyDeviceToHost, ctx->stream));
+	unsigned long long totals[2] = {0, 0};   // items of the polynomial store, doubles of the matrix-core store behind it
+	TP_HIP(ctx, hipMemcpyAsync(totals, d_total, sizeof(totals), hipMemcpyDeviceToHost, ctx->stream));
 	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	const size_t store_need = ((size_t)total_items * 25 + 32) * sizeof(double);
+	const size_t poly_doubles = ((size_t)totals[0] * 25 + 32 + 63) & ~(size_t)63;
+	const size_t store_need = (poly_doubles + (size_t)totals[1] + 64) * sizeof(double);
 	if (ctx->store_bytes < store_need) {
 		if (ctx->store) (void)hipFree(ctx->store);
 		ctx->store = nullptr; ctx->store_bytes = 0;
@@ -1082,9 +1148,16 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 		ctx->store_bytes = store_need;
 	}
 	double* d_store = static_cast<double*>(ctx->store);
+	double* d_kstore = d_store + poly_doubles;
 	TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_coef_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)n_coef_axis * n_coef_axis * sizeof(double))));
-	TP_LAUNCH(ctx, TPK_LINPSF_COEF, tp_linpsf_coef_kernel, dim3((unsigned)desc->n_targets), dim3(512), (size_t)n_coef_axis * n_coef_axis * sizeof(double), a, (const StarPlan*)d_plans, (const int32_t*)d_todo, d_store);
+	TP_LAUNCH(ctx, TPK_LINPSF_COEF, tp_linpsf_coef_kernel, dim3((unsigned)desc->n_targets), dim3(512), (size_t)n_coef_axis * n_coef_axis * sizeof(double), a, (const StarPlan*)d_plans, (const int32_t*)d_todo, d_store,
+		(const MPlan*)d_mplans, (const uint16_t*)d_ulist, (const uint8_t*)d_usig, d_kstore);
 	TP_LAUNCH_CHECK(ctx, "tp_linpsf_coef_kernel");
+	// the matrix-core fit of the targets marked for it (up to 4 stars, up to 256 reachable pixels)
+	if (use_mfma) {
+		const int rc = fit_mfma_launch(ctx, a, desc->n_targets, max_stars, d_plans, d_todo, d_mplans, d_ulist, d_kstore);
+		if (rc != TP_OK) return rc;
+	}
 	const int nblk2 = (desc->n_cad + 255) / 256;
 	const int threads2 = (((desc->n_cad + nblk2 - 1) / nblk2) + 63) / 64 * 64;
 #define TP_LINPSF_FIT2(SS, SL) do { \
@@ -1128,7 +1201,7 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 			const int threads = 256, nblk_m = (desc->n_cad + threads - 1) / threads;
 			const size_t per_thread = (size_t)(2 * smax * smax + 15 * smax) * sizeof(double);
 			const size_t list_bytes = (big.size() * sizeof(int32_t) + 255) & ~(size_t)255;
-			const size_t head = todo_bytes + plan_bytes + 256 + order_bytes;
+			const size_t head = head_bytes;
 			const size_t need = head + list_bytes + per_thread * big.size() * nblk_m * threads + 256;
 			// the scratch also holds d_todo at its start: grow it BEFORE the class kernels' flags could be lost -- they are done
 			TP_HIP(ctx, hipStreamSynchronize(ctx->stream));

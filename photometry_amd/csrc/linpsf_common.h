@@ -1,0 +1,130 @@
+// linpsf_common.h -- definitions shared by the LinPSF translation units (linpsf.hip: plan / coefficient store / vector-ALU
+// fit kernels and the C entry; linpsf_mfma.hip: the matrix-core fit kernel).
+#pragma once
+#include "common.h"
+#include "linpsf_dev.h"
+#include <cmath>
+
+namespace tp_linpsf {
+
+using namespace tp_prf;
+
+constexpr int kMaxStars = 8;      // register-resident vector-ALU kernels (fit2 / direct)
+constexpr int kMfmaStars = 4;     // matrix-core kernel (linpsf_mfma.hip)
+constexpr int kMfmaPixels = 256;  // pixels of a target's union list U (16 tiles of 16)
+
+//--------------------------------------------------------------------------------------------------
+// P2..P4
+//--------------------------------------------------------------------------------------------------
+struct FitArgs {
+	const float* images; const float* subtract; int64_t subtract_pitch;
+	int n_cad, height, width; int64_t t_pitch;
+	const double* coef;          // [n_targets][n*n]
+	const double* knots_x;       // [n+4] knots along the first spline axis (columns)
+	const double* knots_y;       // [n+4] knots along the second spline axis (rows)
+	int n;                       // coefficients per axis (117)
+	const int64_t* star_offsets; // [n_targets+1] into the fitted-star arrays
+	const int32_t* target_index; // [n_targets] index of the main target inside its fitted stars
+	const double* pos_row;       // [n_fit_stars][pos_pitch] row_stamp per cadence
+	const double* pos_col;       // [n_fit_stars][pos_pitch]
+	int64_t pos_pitch;
+	double cutoff;
+	double* flux;                // [n_targets][out_pitch]  lightcurve flux (target star)
+	double* flux_err;            // [n_targets][out_pitch]  NaN (linpsf_photometry.py:169)
+	double* fluxes_all;          // [n_fit_stars][out_pitch] fitted flux of every star (for the mean fluxes)
+	int64_t out_pitch;
+};
+
+// Cyclic Jacobi eigen-decomposition based pseudo-inverse solve:  x = pinv(G) g,  G symmetric S x S.
+template <int S>
+__device__ __forceinline__ void pinv_solve(double (&G)[S][S], const double (&g)[S], int ns, double (&x)[S])
+{
+	double V[S][S];
+#pragma unroll
+	for (int i = 0; i < S; ++i)
+#pragma unroll
+		for (int j = 0; j < S; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+	for (int sweep = 0; sweep < 30; ++sweep) {
+		double off = 0.0;
+#pragma unroll
+		for (int p = 0; p < S; ++p)
+#pragma unroll
+			for (int q = p + 1; q < S; ++q) if (q < ns) off += G[p][q] * G[p][q];
+		double d2 = 0.0;
+#pragma unroll
+		for (int p = 0; p < S; ++p) if (p < ns) d2 += G[p][p] * G[p][p];
+		if (!(off > 1e-34 * d2)) break; // off-diagonal below 1e-17 relative: converged (or NaN)
+#pragma unroll
+		for (int p = 0; p < S; ++p) {
+#pragma unroll
+			for (int q = p + 1; q < S; ++q) {
+				if (q >= ns) continue;
+				const double apq = G[p][q];
+				if (apq == 0.0) continue;
+				const double theta = (G[q][q] - G[p][p]) / (2.0 * apq);
+				const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+				const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+				for (int k = 0; k < S; ++k) {
+					const double gkp = G[k][p], gkq = G[k][q];
+					G[k][p] = c * gkp - s * gkq;
+					G[k][q] = s * gkp + c * gkq;
+				}
+#pragma unroll
+				for (int k = 0; k < S; ++k) {
+					const double gpk = G[p][k], gqk = G[q][k];
+					G[p][k] = c * gpk - s * gqk;
+					G[q][k] = s * gpk + c * gqk;
+				}
+#pragma unroll
+				for (int k = 0; k < S; ++k) {
+					const double vkp = V[k][p], vkq = V[k][q];
+					V[k][p] = c * vkp - s * vkq;
+					V[k][q] = s * vkp + c * vkq;
+				}
+			}
+		}
+	}
+	// numpy.linalg.pinv: singular values (= |eigenvalues|) <= 1e-15 * max are treated as zero
+	double smax = 0.0;
+#pragma unroll
+	for (int i = 0; i < S; ++i) if (i < ns) { const double a = fabs(G[i][i]); if (a > smax || a != a) smax = a; }
+	const double cut = 1e-15 * smax;
+#pragma unroll
+	for (int i = 0; i < S; ++i) x[i] = 0.0;
+#pragma unroll
+	for (int e = 0; e < S; ++e) {
+		if (e >= ns) continue;
+		const double lam = G[e][e];
+		double proj = 0.0;
+#pragma unroll
+		for (int k = 0; k < S; ++k) if (k < ns) proj += V[k][e] * g[k];
+		const double inv = (fabs(lam) > cut) ? (1.0 / lam) : ((lam != lam) ? lam : 0.0);
+		const double coef = proj * inv;
+#pragma unroll
+		for (int k = 0; k < S; ++k) if (k < ns) x[k] += V[k][e] * coef;
+	}
+}
+
+
+// plan of one fitted star: the table origins its cadences visit and the pixels its cut-off circle can reach
+struct StarPlan { int axmin, bymin, nby, nc, jmin, jmax, imin, imax; long long item_off; };
+
+// matrix-core path, per target: the pixels inside the cut-off of ANY fitted star at ANY cadence form the list U (ordered by
+// which stars reach them -- Gray-code order of the membership bits, then raster -- so that the pixels of one star are
+// contiguous), cut into tiles of 16; star s touches the tiles of `tiles[s]`; its coefficient block in the store is
+// [origin][rank of the tile among its tiles][7 MFMA steps][64 lanes] doubles from `koff[s]`.
+struct MPlan {
+	int32_t n_pix, n_tiles;
+	uint32_t tiles[kMfmaStars];
+	int64_t koff[kMfmaStars];
+};
+
+// `todo` flag of a target (written by the plan kernel): which kernel fits it
+enum { kPathPoly = 0, kPathDirect = 1, kPathMfma = 2 };
+
+// linpsf_mfma.hip
+int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, int max_stars, const StarPlan* d_plans, const int32_t* d_todo,
+	const MPlan* d_mplans, const uint16_t* d_ulist, const double* d_kstore);
+
+} // namespace tp_linpsf

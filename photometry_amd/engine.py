@@ -265,6 +265,11 @@ def linpsf_prf(ctx, base_coef, weights, out=None):
 	return out
 
 
+def linpsf_set_path(ctx, path):
+	"""``tp_linpsf_set_path``: 0 = matrix-core fit where a target qualifies (default), 1 = vector-ALU kernels only."""
+	ctx._check(ctx.lib.tp_linpsf_set_path(ctx.handle, int(path)))
+
+
 def linpsf_fit(ctx, images, coef, knots_x, knots_y, star_offsets, target_index, pos_row, pos_col, max_stars,
 	cutoff_radius=5.0, subtract=None, out=None):
 	"""P2-P4 (psf.py:122-148, linpsf_photometry.py:22-34, 79-219)."""

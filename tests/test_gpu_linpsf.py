@@ -51,7 +51,8 @@ def test_prf_blend_matches_reference_construction(ctx):
 @pytest.mark.parametrize("max_neigh,T,H,W,jit", [(3, 40, 11, 11, 1), (1, 70, 15, 15, 1), (6, 16, 13, 12, 1),
 	(3, 40, 11, 11, 6), (2, 33, 15, 15, 30), (1, 1301, 9, 9, 1), (3, 1100, 9, 9, 2), (1, 8300, 7, 7, 1),
 	(13, 12, 11, 11, 1)])     # more than 8 fitted stars: the run-time sized kernel
-def test_linpsf_matches_oracle(ctx, max_neigh, T, H, W, jit):
+@pytest.mark.parametrize("path", [0, 1])   # 0: matrix-core fit where the target qualifies; 1: vector-ALU kernels for every target
+def test_linpsf_matches_oracle(ctx, path, max_neigh, T, H, W, jit):
 	from photometry_amd import simulate, engine, psf as hpsf
 	from photometry_amd.device import DeviceCube
 	from oracle import psf as opsf, linpsf as olin
@@ -67,8 +68,12 @@ def test_linpsf_matches_oracle(ctx, max_neigh, T, H, W, jit):
 	max_stars = int(np.diff(star_offsets).max())
 	assert max_stars > 8 or max_neigh < 13
 	coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(model.weights(s.stamps)))
-	res = engine.linpsf_fit(ctx, DeviceCube.from_host(ctx, s.images), coef, ctx.array(model.tx), ctx.array(model.ty),
-		ctx.array(star_offsets), ctx.array(target_index), ctx.array(pos_row), ctx.array(pos_col), max_stars).to_host()
+	engine.linpsf_set_path(ctx, path)
+	try:
+		res = engine.linpsf_fit(ctx, DeviceCube.from_host(ctx, s.images), coef, ctx.array(model.tx), ctx.array(model.ty),
+			ctx.array(star_offsets), ctx.array(target_index), ctx.array(pos_row), ctx.array(pos_col), max_stars).to_host()
+	finally:
+		engine.linpsf_set_path(ctx, 0)
 	for i in range(s.n_targets):
 		cat = s.catalog_of(i)
 		ncat = len(cat['starid'])
@@ -88,8 +93,9 @@ def test_linpsf_matches_oracle(ctx, max_neigh, T, H, W, jit):
 	assert res['flux'][0, 3] == 0.0
 
 
-def test_linpsf_golden(ctx, golden_dir):
-	"""The reference's own LinPSFPhotometry.do_photometry (golden) through the device kernels."""
+@pytest.mark.parametrize("path", [0, 1])
+def test_linpsf_golden(ctx, golden_dir, path):
+	"""The reference's own LinPSFPhotometry.do_photometry (golden) through the device kernels (both mappings of the fit)."""
 	from photometry_amd import engine, psf as hpsf
 	from photometry_amd.device import DeviceCube
 	from scipy.interpolate import RectBivariateSpline
@@ -102,9 +108,13 @@ def test_linpsf_golden(ctx, golden_dir):
 	pos_row = np.concatenate([g[f'lp{i}_positions'][:, :, 0].T for i in range(Nt)])[sel]
 	pos_col = np.concatenate([g[f'lp{i}_positions'][:, :, 1].T for i in range(Nt)])[sel]
 	coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(model.weights(g['stamps'])))
-	res = engine.linpsf_fit(ctx, DeviceCube.from_host(ctx, g['images']), coef, ctx.array(model.tx), ctx.array(model.ty),
-		ctx.array(star_offsets), ctx.array(target_index), ctx.array(np.ascontiguousarray(pos_row)), ctx.array(np.ascontiguousarray(pos_col)),
-		int(np.diff(star_offsets).max())).to_host()
+	engine.linpsf_set_path(ctx, path)
+	try:
+		res = engine.linpsf_fit(ctx, DeviceCube.from_host(ctx, g['images']), coef, ctx.array(model.tx), ctx.array(model.ty),
+			ctx.array(star_offsets), ctx.array(target_index), ctx.array(np.ascontiguousarray(pos_row)), ctx.array(np.ascontiguousarray(pos_col)),
+			int(np.diff(star_offsets).max())).to_host()
+	finally:
+		engine.linpsf_set_path(ctx, 0)
 	for i in range(int(g['n_linpsf'])):
 		ref = g[f'lp{i}_flux']
 		np.testing.assert_allclose(res['flux'][i], ref, rtol=1e-8, atol=1e-9*np.abs(ref).max())
