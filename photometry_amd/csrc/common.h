@@ -54,7 +54,7 @@ struct tp_ctx {
 	size_t scratch_bytes = 0;
 	void* store = nullptr;      // second grow-only buffer: the polynomial coefficient store of tp_linpsf_fit
 	size_t store_bytes = 0;
-	int linpsf_path = 0;        // tp_linpsf_set_path: 0 = matrix-core fit where a target qualifies, 1 = vector-ALU kernels only
+	int linpsf_path = 0;        // tp_linpsf_set_path: 0 = vector-ALU fit kernels, 1 = matrix-core fit where a target qualifies
 	void* comm = nullptr;       // ncclComm_t (comm.cpp)
 	int comm_rank = 0, comm_size = 1;
 

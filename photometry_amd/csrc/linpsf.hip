@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 	__shared__ double spos[4][kMfmaStars][4];      // per wavefront and star: min / max of the row and column position
 	__shared__ double srange[kMfmaStars][4];
 	__shared__ unsigned pkeys[kMfmaPixels];
-	__shared__ unsigned s_tiles[kMfmaStars];
+	__shared__ unsigned s_tiles[kMfmaStars], s_etiles[kMfmaStars];
 	__shared__ int s_ok, s_nkeys, s_path;
 	__shared__ double kn[160], kny[160];
 	const int target = blockIdx.x, tid = threadIdx.x;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 		sbox[tid].axmin = sbox[tid].bymin = sbox[tid].jmin = sbox[tid].imin = 0x7fffffff;
 		sbox[tid].axmax = sbox[tid].bymax = sbox[tid].jmax = sbox[tid].imax = -0x7fffffff;
 	}
-	if (tid < kMfmaStars) s_tiles[tid] = 0u;
+	if (tid < kMfmaStars) { s_tiles[tid] = 0u; s_etiles[tid] = 0u; }
 	__syncthreads();
 	const double h = kn[5] - kn[4], hy = kny[5] - kny[4];
 	const double cutoff = a.cutoff;
@@ -315,19 +315,27 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 	if (s_path == kPathMfma) {
 		// the pixels some star can reach at some cadence: nearer than the cut-off to the rectangle its position sweeps
 		const int npix = a.height * a.width;
-		const double reach = (cutoff + 1e-6) * (cutoff + 1e-6);
+		const double reach = (cutoff + 1e-6) * (cutoff + 1e-6), always = (cutoff - 1e-6) * (cutoff - 1e-6);
 		for (int p = tid; p < npix; p += 256) {
 			const int i = p / a.width, j = p - i * a.width;
-			unsigned sig = 0u;
+			unsigned sig = 0u, edge = 0u;
 			for (int s = 0; s < ns; ++s) {
 				if (spl[s].nc <= 0) continue;
 				const double dr = fmax(0.0, fmax(srange[s][0] - (double)i, (double)i - srange[s][1]));
 				const double dc = fmax(0.0, fmax(srange[s][2] - (double)j, (double)j - srange[s][3]));
-				if (dr * dr + dc * dc < reach) sig |= 1u << s;
+				if (dr * dr + dc * dc < reach) {
+					sig |= 1u << s;
+					// an "edge" pixel is inside the cut-off at some positions of the star and outside at others: the farthest
+					// corner of the rectangle the position sweeps is not inside
+					const double fr = fmax(fabs((double)i - srange[s][0]), fabs((double)i - srange[s][1]));
+					const double fc = fmax(fabs((double)j - srange[s][2]), fabs((double)j - srange[s][3]));
+					if (!(fr * fr + fc * fc < always)) edge |= 1u << s;
+				}
 			}
 			if (sig) {
 				const int idx = atomicAdd(&s_nkeys, 1);
-				if (idx < kMfmaPixels) pkeys[idx] = (gray_rank4(sig) << 20) | (sig << 16) | (unsigned)p;
+				// order: membership pattern (Gray rank), interior pixels before edge pixels, raster
+				if (idx < kMfmaPixels) pkeys[idx] = (gray_rank4(sig) << 25) | ((edge ? 1u : 0u) << 24) | (edge << 20) | (sig << 16) | (unsigned)p;
 			}
 		}
 		__syncthreads();
@@ -340,10 +348,13 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 				const unsigned key = pkeys[tid];
 				int r = 0;
 				for (int q = 0; q < nk; ++q) r += (pkeys[q] < key) ? 1 : 0;
-				const unsigned sig = (key >> 16) & 15u;
+				const unsigned sig = (key >> 16) & 15u, edge = (key >> 20) & 15u;
 				ul[r] = (uint16_t)(key & 0xffffu);
-				us[r] = (uint8_t)sig;
-				for (int s = 0; s < ns; ++s) if (sig & (1u << s)) atomicOr(&s_tiles[s], 1u << (r >> 4));
+				us[r] = (uint8_t)(sig | (edge << 4));
+				for (int s = 0; s < ns; ++s) {
+					if (sig & (1u << s)) atomicOr(&s_tiles[s], 1u << (r >> 4));
+					if (edge & (1u << s)) atomicOr(&s_etiles[s], 1u << (r >> 4));
+				}
 			} else if (tid < kMfmaPixels) { ul[tid] = (uint16_t)0xffffu; us[tid] = (uint8_t)0; }
 		}
 		__syncthreads();
@@ -357,6 +368,7 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 			long long need = 0;
 			for (int s = 0; s < kMfmaStars; ++s) {
 				mp.tiles[s] = (s < ns) ? s_tiles[s] : 0u;
+				mp.edge_tiles[s] = (s < ns) ? s_etiles[s] : 0u;
 				mp.koff[s] = need;
 				if (s < ns) need += (long long)spl[s].nc * __popc(mp.tiles[s]) * (7 * 64);
 			}
@@ -1067,7 +1079,7 @@ extern "C" int tp_linpsf_prf(tp_ctx* ctx, int32_t n_targets, int32_t n_samples, 
 extern "C" int tp_linpsf_set_path(tp_ctx* ctx, int32_t path)
 {
 	TP_CHECK_CTX(ctx);
-	TP_REQUIRE(ctx, path == 0 || path == 1, "tp_linpsf_set_path: 0 (matrix-core fit where a target qualifies) or 1 (vector-ALU kernels only)");
+	TP_REQUIRE(ctx, path == 0 || path == 1, "tp_linpsf_set_path: 0 (vector-ALU kernels) or 1 (matrix-core fit where a target qualifies)");
 	ctx->linpsf_path = path;
 	return TP_OK;
 }
@@ -1129,7 +1141,7 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	int sort_n = 64;
 	while (sort_n < desc->n_cad) sort_n <<= 1;
 	if (sort_n > 8192) sort_n = 0;
-	const int use_mfma = (ctx->linpsf_path == 0) ? 1 : 0;
+	const int use_mfma = (ctx->linpsf_path == 1) ? 1 : 0;
 	TP_HIP(ctx, hipMemsetAsync(d_todo, 0, todo_bytes, ctx->stream));
 	TP_HIP(ctx, hipMemsetAsync(d_total, 0, 2 * sizeof(unsigned long long), ctx->stream));
 	if (sort_n > 4096) TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sort_n * sizeof(unsigned long long))));

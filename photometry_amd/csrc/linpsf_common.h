@@ -117,6 +117,7 @@ struct StarPlan { int axmin, bymin, nby, nc, jmin, jmax, imin, imax; long long i
 struct MPlan {
 	int32_t n_pix, n_tiles;
 	uint32_t tiles[kMfmaStars];
+	uint32_t edge_tiles[kMfmaStars];   // tiles with a pixel that is inside the star's cut-off at some cadences only
 	int64_t koff[kMfmaStars];
 };
 

@@ -51,7 +51,7 @@ def test_prf_blend_matches_reference_construction(ctx):
 @pytest.mark.parametrize("max_neigh,T,H,W,jit", [(3, 40, 11, 11, 1), (1, 70, 15, 15, 1), (6, 16, 13, 12, 1),
 	(3, 40, 11, 11, 6), (2, 33, 15, 15, 30), (1, 1301, 9, 9, 1), (3, 1100, 9, 9, 2), (1, 8300, 7, 7, 1),
 	(13, 12, 11, 11, 1)])     # more than 8 fitted stars: the run-time sized kernel
-@pytest.mark.parametrize("path", [0, 1])   # 0: matrix-core fit where the target qualifies; 1: vector-ALU kernels for every target
+@pytest.mark.parametrize("path", [0, 1])   # 0: vector-ALU kernels for every target; 1: matrix-core fit where the target qualifies
 def test_linpsf_matches_oracle(ctx, path, max_neigh, T, H, W, jit):
 	from photometry_amd import simulate, engine, psf as hpsf
 	from photometry_amd.device import DeviceCube

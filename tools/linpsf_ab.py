@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: the LinPSF step on the C3 workload with the matrix-core fit (path 0) and with the vector-ALU kernels (path 1)."""
+"""Diagnostic: the LinPSF step on the C3 workload with the vector-ALU kernels (path 0) and with the matrix-core fit (path 1)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if os.environ.get('TP_LAB_LIB'):
@@ -23,7 +23,13 @@ engine.background_stamp(ctx, batch.images, out=work.bkg_raw)
 engine.smooth_time(ctx, work.bkg_raw, batch.n_cad, batch.time_smooth, out=work.bkg)
 ctx.sync()
 outs = {}
-for path in [int(x) for x in os.environ.get('PATHS', '1,0,1,0').split(',')]:
+if os.environ.get('MAXS'):
+	_step = pipeline.linpsf_step
+	def _limited(ctx, batch, *a, **k):
+		batch.max_stars = int(os.environ['MAXS'])
+		return _step(ctx, batch, *a, **k)
+	pipeline.linpsf_step = _limited
+for path in [int(x) for x in os.environ.get('PATHS', '0,1,0,1').split(',')]:
 	engine.linpsf_set_path(ctx, path)
 	res = bench.leg_linpsf(ctx, scene, cubes, work, args, Nt, T, H, W, np, engine, pipeline)
 	print('path', path, res['value'], 'targets/s', res['ms_per_step'], 'ms/step', flush=True)
