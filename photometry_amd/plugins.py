@@ -56,6 +56,8 @@ def mag2flux(mag, zp=20.451):
 	return np.clip(10**(-0.4*(mag - zp)), 0, None)
 
 
+_PRF_CACHE = {} #: (psf_dir, sector, camera, ccd) -> PRFModel: the spline fits of a CCD are done once per process
+
 class Table(object):
 	"""Minimal column table (stand-in for the astropy Table used for ``catalog`` / ``lightcurve``)."""
 
@@ -393,7 +395,16 @@ class BasePhotometry(object):
 		if self._psf is None:
 			self._psf = getattr(self.source, 'prf', None)
 			if self._psf is None:
-				raise FileNotFoundError("the stamp source provides no PRF model")
+				# like psf.py:66-72: the SPOC PRF file of (sector, camera, CCD) from the data directory (TESSPHOT_PSF_DIR, or
+				# the source's psf_dir; upstream it is photometry/data/psf inside the package)
+				from . import psf as hpsf
+				psf_dir = getattr(self.source, 'psf_dir', None) or os.environ.get('TESSPHOT_PSF_DIR')
+				if not psf_dir:
+					raise FileNotFoundError("the stamp source provides no PRF model and no PRF directory is configured (TESSPHOT_PSF_DIR)")
+				key = (os.path.abspath(psf_dir), int(self.sector), int(self.camera), int(self.ccd))
+				if key not in _PRF_CACHE:
+					_PRF_CACHE[key] = hpsf.PRFModel.for_ccd(psf_dir, self.sector, self.camera, self.ccd)
+				self._psf = _PRF_CACHE[key]
 		return self._psf
 
 	def delete_plots(self):

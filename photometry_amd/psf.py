@@ -16,10 +16,31 @@ so this class fits the samples ONCE (with the same scipy call) and the per-targe
 25-term weighted sum done on the device (``tp_linpsf_prf``).
 """
 
+import glob
+import os
 import numpy as np
 from scipy.interpolate import RectBivariateSpline
 
 MINIMUM_PRF_WEIGHT = 1e-6 #: psf.py:74
+
+
+def prf_file(psf_dir, sector, camera, ccd):
+	"""
+	The SPOC PRF file the reference opens for (sector, camera, CCD), psf.py:47-72: sectors 1-3 use the characterisation
+	that starts at sector 1, later sectors the one that starts at sector 4; same input checks and messages.
+	``psf_dir`` is the directory that holds ``start_s0001`` / ``start_s0004`` (upstream: ``photometry/data/psf``).
+	"""
+	if sector < 1:
+		raise ValueError("Sector number must be greater than zero")
+	if camera not in (1, 2, 3, 4):
+		raise ValueError("Camera must be 1, 2, 3 or 4.")
+	if ccd not in (1, 2, 3, 4):
+		raise ValueError("CCD must be 1, 2, 3 or 4.")
+	sector_dir = 'start_s0004' if sector >= 4 else 'start_s0001'
+	found = glob.glob(os.path.join(psf_dir, sector_dir, f'tess*-{camera:d}-{ccd:d}-characterized-prf.mat'))
+	if not found:
+		raise FileNotFoundError(f"no PRF file for camera {camera}, CCD {ccd} under {os.path.join(psf_dir, sector_dir)}")
+	return found[0]
 
 
 class PRFModel(object):
@@ -58,6 +79,30 @@ class PRFModel(object):
 		self.tx, self.ty = np.asarray(tx, dtype='float64'), np.asarray(ty, dtype='float64')
 		self.n = len(self.tx) - 4
 		self.base_coef = np.ascontiguousarray(np.stack(coefs)) # (n_hdu, n*n)
+
+	@classmethod
+	def from_mat(cls, path):
+		"""
+		A SPOC ``*-characterized-prf.mat`` file, unpacked like psf.py:81-104: ``prfStruct`` with one entry per PRF sample;
+		``prfColumn`` / ``prfRow`` are taken from the first entry ("assuming they are all the same"), ``values`` /
+		``ccdColumn`` / ``ccdRow`` from every entry.
+		"""
+		from scipy.io import loadmat
+		mat = loadmat(path)['prfStruct']
+		prf_x = np.asarray(mat['prfColumn'][0][0], dtype='float64').flatten()
+		prf_y = np.asarray(mat['prfRow'][0][0], dtype='float64').flatten()
+		n_hdu = len(mat['values'][0])
+		values = np.stack([np.asarray(mat['values'][0][i], dtype='float64') for i in range(n_hdu)])
+		ccd_column = np.array([float(np.asarray(mat['ccdColumn'][0][i]).ravel()[0]) for i in range(n_hdu)])
+		ccd_row = np.array([float(np.asarray(mat['ccdRow'][0][i]).ravel()[0]) for i in range(n_hdu)])
+		self = cls(values, ccd_column, ccd_row, prf_x, prf_y)
+		self.path = path
+		return self
+
+	@classmethod
+	def for_ccd(cls, psf_dir, sector, camera, ccd):
+		"""The model of a CCD from the reference's data directory layout (psf.py:66-72)."""
+		return cls.from_mat(prf_file(psf_dir, sector, camera, ccd))
 
 	@classmethod
 	def from_spline(cls, spline):

@@ -4,6 +4,7 @@ CPU tests of the host-side plugin API: stamp geometry (known answers of the refe
 tests/test_basephotometry.py), dispatch and error conventions (tessphot.py), table helpers,
 target sharding and skip-target replay.  No GPU needed: numerics run only in the gpu tests.
 """
+import os
 import numpy as np
 import pytest
 import photometry_amd
@@ -231,3 +232,70 @@ def test_batch_helpers_equal_per_target_helpers():
 				np.testing.assert_array_equal(a, ref[k], err_msg=f'{trial} {j} {k}')
 		n_stamps += len(sel)
 	assert n_stamps > 1000
+
+
+def _write_prf_mat(path, prf):
+	"""A MATLAB file with the structure of the SPOC PRF files (prfStruct: one struct entry per PRF sample)."""
+	from scipy.io import savemat
+	n = len(prf['ccdRow'])
+	dt = [('values', 'O'), ('ccdRow', 'O'), ('ccdColumn', 'O'), ('prfRow', 'O'), ('prfColumn', 'O')]
+	st = np.empty((1, n), dtype=dt)
+	for i in range(n):
+		st[0, i] = (prf['values'][i], np.array([[prf['ccdRow'][i]]]), np.array([[prf['ccdColumn'][i]]]),
+			prf['prfRow'][None, :], prf['prfColumn'][None, :])
+	savemat(path, {'prfStruct': st})
+
+
+def test_prf_mat_loader_and_file_rule(tmp_path):
+	"""PRFModel.from_mat / for_ccd: the file rule of psf.py:66-72 and the prfStruct unpacking of :81-104, on a file written
+	with scipy.io.savemat from the synthetic PRF; the loaded model equals the one built from the arrays."""
+	from photometry_amd import simulate, psf as hpsf
+	prf = simulate.synthetic_prf(seed=4, n_side=3)
+	for d, cam, ccd in (('start_s0001', 2, 3), ('start_s0004', 2, 3)):
+		os.makedirs(tmp_path / d, exist_ok=True)
+		# the two characterisations differ, so that the sector rule is visible in the result
+		p2 = dict(prf)
+		p2['values'] = prf['values'] * (1.0 if d == 'start_s0001' else 2.0)
+		_write_prf_mat(str(tmp_path / d / f'tess2018243163600-prf-{cam}-{ccd}-characterized-prf.mat'), p2)
+	assert 'start_s0001' in hpsf.prf_file(str(tmp_path), 3, 2, 3) and 'start_s0004' in hpsf.prf_file(str(tmp_path), 4, 2, 3)
+	with pytest.raises(ValueError):
+		hpsf.prf_file(str(tmp_path), 0, 2, 3)
+	with pytest.raises(ValueError):
+		hpsf.prf_file(str(tmp_path), 1, 5, 3)
+	with pytest.raises(ValueError):
+		hpsf.prf_file(str(tmp_path), 1, 2, 0)
+	with pytest.raises(FileNotFoundError):
+		hpsf.prf_file(str(tmp_path), 1, 1, 1)
+	ref = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	m1 = hpsf.PRFModel.for_ccd(str(tmp_path), 2, 2, 3)
+	m4 = hpsf.PRFModel.for_ccd(str(tmp_path), 11, 2, 3)
+	np.testing.assert_array_equal(m1.base_coef, ref.base_coef)
+	np.testing.assert_array_equal(m1.ccd_column, ref.ccd_column)
+	np.testing.assert_array_equal(m1.ccd_row, ref.ccd_row)
+	np.testing.assert_array_equal(m1.tx, ref.tx)
+	np.testing.assert_allclose(m4.sums, 2.0 * ref.sums, rtol=1e-15)
+	stamps = np.array([[100, 115, 300, 315]])
+	np.testing.assert_allclose(m1.weights(stamps), ref.weights(stamps), rtol=1e-15)
+	# the normalised blend does not care about the scale of the file: same coefficient table
+	np.testing.assert_allclose(m4.weights(stamps) @ m4.base_coef, m1.weights(stamps) @ m1.base_coef, rtol=1e-12, atol=1e-18)
+
+
+def test_plugin_psf_from_the_prf_directory(tmp_path, monkeypatch):
+	"""BasePhotometry.psf without a model on the source: the CCD's PRF file from TESSPHOT_PSF_DIR (psf.py:66-72)."""
+	from photometry_amd import simulate, plugins, psf as hpsf
+	prf = simulate.synthetic_prf(seed=5, n_side=2)
+	os.makedirs(tmp_path / 'start_s0001')
+	_write_prf_mat(str(tmp_path / 'start_s0001' / 'tess2018243163600-prf-1-1-characterized-prf.mat'), prf)
+
+	class Src: prf = None; psf_dir = None
+	pho = plugins.BasePhotometry.__new__(plugins.BasePhotometry)
+	pho.source, pho._psf, pho.sector, pho.camera, pho.ccd = Src(), None, 1, 1, 1
+	monkeypatch.delenv('TESSPHOT_PSF_DIR', raising=False)
+	with pytest.raises(FileNotFoundError):
+		pho.psf
+	monkeypatch.setenv('TESSPHOT_PSF_DIR', str(tmp_path))
+	model = pho.psf
+	assert isinstance(model, hpsf.PRFModel) and model.n_hdu == 4
+	pho2 = plugins.BasePhotometry.__new__(plugins.BasePhotometry)
+	pho2.source, pho2._psf, pho2.sector, pho2.camera, pho2.ccd = Src(), None, 1, 1, 1
+	assert pho2.psf is model   # fitted once per process
