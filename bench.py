@@ -52,7 +52,10 @@ def parse_args(argv=None):
 	p.add_argument('--gpus', type=int, default=1)
 	p.add_argument('--steps', type=int, default=10)
 	p.add_argument('--warmup', type=int, default=3)
-	p.add_argument('--targets', type=int, default=10000, help='targets per GPU')
+	p.add_argument('--targets', type=int, default=0, help='targets per GPU (0: 10 000 for workload c2, 12 500 for c4 weak, 100 000 / N for c4 strong)')
+	p.add_argument('--workload', choices=('c2', 'c4'), default=None, help='c2: aperture + background (BASELINE configs[2]; default at N = 1); '
+		'c4: aperture + PSF, the LinPSF fit in the step and in the gathered block (BASELINE configs[4]; default at N > 1)')
+	p.add_argument('--scaling', choices=('weak', 'strong'), default='weak', help='c4: weak = 12 500 targets per GPU, strong = 100 000 targets over the N GPUs')
 	p.add_argument('--cadences', type=int, default=1300)
 	p.add_argument('--stamp', type=int, default=15)
 	p.add_argument('--cpu-sample', type=int, default=4, help='targets per worker process of the CPU baseline (0 = skip)')
@@ -277,28 +280,23 @@ def main():
 	world = int(os.environ.get('WORLD_SIZE', '1'))
 	args.gpus = world
 
-	# torch is plumbing only (rendezvous, barrier, device sync); imported BEFORE the HIP library so that one HIP runtime is shared
+	# torch is plumbing only, and only for N > 1 (gloo rendezvous, barrier, max over ranks); imported BEFORE the HIP library so
+	# that one HIP runtime is shared.  A single-GPU run never loads it.
 	dist = None
 	torch = None
-	if world > 1 or not os.environ.get('TP_BENCH_NO_TORCH'):
+	if world > 1:
+		import torch
+		import torch.distributed as dist
+		os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+		# gloo announces its connections on stdout (C level): keep stdout for the ONE JSON line
+		sys.stdout.flush()
+		saved = os.dup(1)
+		os.dup2(2, 1)
 		try:
-			import torch
-			if world > 1:
-				import torch.distributed as dist
-				os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-				# gloo announces its connections on stdout (C level): keep stdout for the ONE JSON line
-				sys.stdout.flush()
-				saved = os.dup(1)
-				os.dup2(2, 1)
-				try:
-					dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-				finally:
-					os.dup2(saved, 1)
-					os.close(saved)
-		except ImportError:
-			torch = None
-			if world > 1:
-				raise
+			dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+		finally:
+			os.dup2(saved, 1)
+			os.close(saved)
 
 	import numpy as np
 	from photometry_amd import simulate, engine, pipeline, _lib
@@ -314,7 +312,7 @@ def main():
 	shared_device = world > ndev.value
 	device = local_rank % ndev.value
 	ctx = Context(device)
-	use_torch_cuda = torch is not None and torch.cuda.is_available()
+	use_torch_cuda = torch is not None and torch.cuda.is_available()   # N > 1 only
 	if use_torch_cuda:
 		torch.cuda.set_device(device)
 
@@ -328,21 +326,40 @@ def main():
 		if dist is not None:
 			dist.barrier()
 
-	Nt, T, H = args.targets, args.cadences, args.stamp
+	workload = args.workload or ('c4' if world > 1 else 'c2')
+	psf = workload == 'c4'
+	T, H = args.cadences, args.stamp
+	if args.targets > 0:
+		Nt = args.targets
+	elif workload == 'c2':
+		Nt = 10000
+	elif args.scaling == 'weak':
+		Nt = 12500                                            # BASELINE configs[4]: 100 000 targets over 8 GPUs
+	else:
+		Nt = -(-100000 // world)                              # strong scaling: the 100 000 targets over the N GPUs there are
 	W = H
 	P = H * W
 	scene = simulate.make_scene(Nt, T, H, W, seed=args.seed * 1000 + rank)
 	scene.aperture = None
-	extras = (world == 1) and not args.no_extra
+	extras = (world == 1) and (workload == 'c2') and not args.no_extra
 	# resident inputs: raw flux + error cubes (2 x 11.8 GB at the default size); the premade-cube leg adds the
 	# background-subtracted images and the background cube of the reference's per-target stage
 	cubes = engine.synth_fill(ctx, scene, images=extras, images_err=True, backgrounds=extras, raw=True)
 	cubes['raw_err'] = cubes['images_err']
 	batch = pipeline.ApertureBatch(ctx, scene, cubes={'raw': cubes['raw'], 'raw_err': cubes['raw_err']})
 	nbuf = 2 if world > 1 else 1
-	works = [pipeline.ApertureWork(ctx, batch, packed=True) for _ in range(nbuf)]
+	works = [pipeline.ApertureWork(ctx, batch, packed=True, psf=psf) for _ in range(nbuf)]
 	for w in works[1:]: # the background series are scratch of the step, not outputs: shared
 		w.bkg_raw, w.bkg = works[0].bkg_raw, works[0].bkg
+	lin = lin_out = None
+	if psf:
+		# configs[4] "aperture + PSF": the LinPSF fit of every target on the same raw cube, the step's background series subtracted
+		# on the fly; its light curve / contamination / status are part of the gathered block
+		from photometry_amd import psf as hpsf
+		prf = simulate.synthetic_prf(seed=1) # synthetic stand-in for the SPOC PRF file (git-LFS object upstream)
+		lin = pipeline.LinPSFBatch(ctx, scene, hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow']),
+			images=cubes['raw'], subtract=works[0].bkg, work=works[0])
+		lin_out = [lin.out] + [lin.result_for(w) for w in works[1:]]
 
 	# ---- the per-step gather (world > 1): RCCL on a second stream, double-buffered ------------------------------
 	do_gather = world > 1 and not args.no_gather
@@ -395,6 +412,8 @@ def main():
 					gather_ms.append(comm_ctx.timer_ms(b)) # waits for gather s - nbuf (long finished)
 				ctx.wait_event(ev_free[b]) # block b has left for rank 0: it may be overwritten
 			pipeline.aperture_step(ctx, batch, works[b])
+			if psf:
+				pipeline.linpsf_step(ctx, lin, out=lin_out[b])
 			if do_gather:
 				ctx.record(ev_done[b])
 				gather_block(b)
@@ -420,6 +439,20 @@ def main():
 		elapsed = float(t[0])
 	prof = ctx.profile_report()
 	work = works[(args.steps - 1) % nbuf] if args.steps > 0 else works[0]
+	# the same step without the gather (N > 1): what the overlap has to hide the gather under
+	step_alone_ms = None
+	if do_gather:
+		nalone = max(1, min(args.steps, 5))
+		device_sync(comm_ctx)
+		barrier()
+		t1 = time.perf_counter()
+		for _ in range(nalone):
+			pipeline.aperture_step(ctx, batch, works[0])
+			if psf:
+				pipeline.linpsf_step(ctx, lin, out=lin_out[0])
+		device_sync()
+		step_alone_ms = (time.perf_counter() - t1) / nalone * 1e3
+		barrier()
 
 	result = None
 	if rank == 0:
@@ -452,16 +485,29 @@ def main():
 		}
 		rooflines = [roofline_of(k, rows, traffic, notes.get(k)) for k in sorted(hbm_kernels, key=lambda k: -rows[k]['avg_ms'])]
 		step_bytes = sum(necessary[k] for k in rows if k in necessary)
-		result = {
-			'metric': 'targets/sec (whole node), 10k targets x 1300 cad x 15x15, aperture + background',
-			'value': Nt * world * args.steps / elapsed, 'unit': 'targets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-			'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-			'dtype': 'f32', 'data': 'synthetic',
-			'config': {'workload': f'{Nt} targets/GPU x {T} cadences x {H}x{W} stamps, aperture + background (BASELINE configs[2]): raw flux and '
+		n_total = Nt * world if not (psf and args.scaling == 'strong' and args.targets == 0) else min(100000, Nt * world)
+		if psf:
+			nfit = lin.n_fit_stars
+			metric = 'targets/sec (whole node), 100k targets x 1300 cad x 15x15, aperture + PSF, target-sharded'
+			wl = (f'{Nt} targets/GPU x {T} cadences x {H}x{W} stamps, aperture + PSF (BASELINE configs[4]: 100 000 targets over 8 GPUs = 12 500 per GPU): '
+				'raw flux and error cubes resident in HBM; per step the stamp background of every cadence (B*), its time smoothing (B2), '
+				'AperturePhotometry.do_photometry of every target with the background subtracted on the fly (B3), and the LinPSF fit of every '
+				f'target (linpsf_photometry: P1 table blend + P2-P4, {nfit} fitted stars on this rank) on the same cube; light curves of both '
+				'methods in the gathered block')
+		else:
+			metric = 'targets/sec (whole node), 10k targets x 1300 cad x 15x15, aperture + background'
+			wl = (f'{Nt} targets/GPU x {T} cadences x {H}x{W} stamps, aperture + background (BASELINE configs[2]): raw flux and '
 				'error cubes resident in HBM; per step the stamp background of every cadence (B*), its time smoothing (B2), and '
 				'AperturePhotometry.do_photometry of every target (sum image, K2P2 mask, extraction of flux / error / centroid / '
-				'background) with the background subtracted on the fly (B3)',
-				'targets_per_gpu': Nt, 'cadences': T, 'stamp': [H, W], 'parallelism': f'targets sharded over {world} GPU(s), one process per GPU'},
+				'background) with the background subtracted on the fly (B3)')
+		result = {
+			'metric': metric,
+			'value': n_total * args.steps / elapsed, 'unit': 'targets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+			'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling if psf else 'weak', 'vs_baseline': None,
+			'dtype': 'f32 (aperture, background) + f64 (PSF fit)' if psf else 'f32', 'data': 'synthetic',
+			'config': {'workload': wl, 'baseline_config': 'configs[4]' if psf else 'configs[2]',
+				'targets_per_gpu': Nt, 'targets_total': n_total, 'cadences': T, 'stamp': [H, W],
+				'parallelism': f'targets sharded over {world} GPU(s), one process per GPU, no data-path collective but the gather of the output block'},
 			'roofline': next(r for r in rooflines if r['kernel'] == dom),
 			'rooflines': rooflines,
 			'step_hbm': {'necessary_bytes_per_step': step_bytes, 'GBps_over_whole_step': step_bytes / (elapsed / args.steps) / 1e9,
@@ -471,8 +517,20 @@ def main():
 				'block': 'light curves [5][Nt][T] f64 + contamination f64 + status, flags i32 + mask u8 per target, one message per rank',
 				'issued': 'every step, second stream, double-buffered output block' if do_gather else None,
 				'mean_ms': (sum(gather_ms) / len(gather_ms)) if gather_ms else None,
-				'ideal_ms_one_xgmi_link': block_bytes / (XGMI_LINK_GBS * 1e9) * 1e3 if world > 1 else None},
+				'step_ms_without_gather': step_alone_ms,
+				'ideal_ms_one_xgmi_link': block_bytes / (XGMI_LINK_GBS * 1e9) * 1e3 if world > 1 else None,
+				'xgmi_rate_assumed': f'{XGMI_LINK_GBS} GB/s one way per link: the root receives from its N - 1 peers on N - 1 links at once (direct '
+					'send / recv pairs in one RCCL group), so the gather is bound by ONE inbound link per peer; if the 153 GB/s of the guide is the '
+					'bidirectional figure the ideal doubles -- mean_ms beside step_ms_without_gather is the measurement that decides'},
 		}
+		if psf:
+			# the LinPSF fit is the longest part of the configs[4] step: its own roofline (FP64 vector ALU, executed flops)
+			fit_ms = sum(prof[k][1] for k in ('tp_linpsf_fit_kernel', 'tp_linpsf_fitm_kernel', 'tp_linpsf_plan_kernel', 'tp_linpsf_coef_kernel') if k in prof) / max(args.steps, 1)
+			counts = np.diff(lin.star_offsets_h)
+			fma = nfit * T * 79 * 24 + float(np.sum(counts * (counts + 1) / 2 + counts)) * T * H * W + nfit * 3 * 79 * 1170
+			result['linpsf_roofline'] = {'kernel': 'tp_linpsf_plan_kernel + tp_linpsf_coef_kernel + tp_linpsf_fit2_kernel', 'bound': 'fp64 vector ALU',
+				'achieved': 2 * fma / (fit_ms * 1e-3) / 1e12, 'peak': FP64_VALU_TFLOPS, 'unit': 'TFLOP/s', 'frac': 2 * fma / (fit_ms * 1e-3) / 1e12 / FP64_VALU_TFLOPS,
+				'kernel_ms_per_step': fit_ms, 'fitted_stars': int(nfit)}
 		if shared_device:
 			result['warning'] = f'{world} ranks shared {ndev.value} GPU(s): a control-flow run, not a scaling measurement'
 
@@ -480,7 +538,7 @@ def main():
 	if rank == 0 and extras:
 		result['aperture_premade_cubes'] = leg_premade(ctx, scene, cubes, args, Nt, T, H, W, np, engine, pipeline)
 		result['stages'] = leg_stages(ctx, scene, cubes, batch, work, args, Nt, T, H, W, np, engine, pipeline)
-	if rank == 0 and world == 1 and args.cpu_sample > 0:
+	if rank == 0 and world == 1 and workload == 'c2' and args.cpu_sample > 0:
 		cb, parity = cpu_baseline(ctx, scene, cubes, work, args, T, H, W, batch.time_smooth)
 		result['cpu_baseline'] = cb
 		result['parity_sample'] = parity

@@ -25,6 +25,52 @@ def shard_sizes(n_items, world):
 	return [shard_range(n_items, world, r)[1] - shard_range(n_items, world, r)[0] for r in range(world)]
 
 
+def packed_block_layout(n_targets, n_cad, height, width, psf=False, align=256):
+	"""
+	Layout of the per-step output block of a rank: ONE allocation, so that the gather is one
+	message per rank.  Returns ``(layout, nbytes)`` with ``layout[name] = (offset, shape, dtype)``:
+
+	* ``lc`` float64 ``(5, Nt, T)``: flux, flux_err, flux_background, centroid column / row (the plugin's columns,
+	  BasePhotometry.py:425-429); ``contamination`` float64, ``status`` / ``flags`` int32, ``mask`` uint8 ``(Nt, H, W)``;
+	* with ``psf`` (BASELINE configs[4], aperture + PSF): ``psf_flux`` float64 ``(Nt, T)`` (the LinPSF light curve,
+	  linpsf_photometry.py:168), ``psf_contamination`` float64 (PSF_CONT, :203-211), ``psf_status`` int32.
+	"""
+	Nt, T, H, W = int(n_targets), int(n_cad), int(height), int(width)
+	fields = [('lc', (5, Nt, T), 'float64'), ('contamination', (Nt,), 'float64'), ('status', (Nt,), 'int32'), ('flags', (Nt,), 'int32'),
+		('mask', (Nt, H, W), 'uint8')]
+	if psf:
+		fields += [('psf_flux', (Nt, T), 'float64'), ('psf_contamination', (Nt,), 'float64'), ('psf_status', (Nt,), 'int32')]
+	layout, off = {}, 0
+	for name, shape, dtype in fields:
+		layout[name] = (off, shape, dtype)
+		off = -(-(off + int(np.prod(shape)) * np.dtype(dtype).itemsize) // align) * align
+	return layout, off
+
+
+def unpack_block(block, layout):
+	"""Views of the arrays inside one rank's block (a uint8 array of the size ``packed_block_layout`` returned)."""
+	block = np.asarray(block, dtype='uint8').ravel()
+	out = {}
+	for name, (off, shape, dtype) in layout.items():
+		n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+		out[name] = block[off:off + n].view(dtype).reshape(shape)
+	return out
+
+
+def assemble_blocks(blocks, layout, sizes):
+	"""
+	Reassembly on rank 0 of the gathered per-rank blocks (every rank sends the same padded capacity; ``sizes`` = real number
+	of targets per rank) into arrays in global target order: ``{name: array}``, the target axis is axis 1 of ``lc`` and
+	axis 0 of everything else.
+	"""
+	parts = [unpack_block(b, layout) for b in blocks]
+	out = {}
+	for name in layout:
+		ax = 1 if name == 'lc' else 0
+		out[name] = np.concatenate([np.take(p[name], np.arange(n), axis=ax) for p, n in zip(parts, sizes)], axis=ax)
+	return out
+
+
 def assemble_gathered(blocks, sizes, n_columns=5):
 	"""
 	Host-side reassembly of gathered light-curve blocks.

@@ -106,13 +106,9 @@ __global__ __launch_bounds__(256) void tp_cut_stamps_kernel(CutArgs a, int band_
 //--------------------------------------------------------------------------------------------------
 // frame-tile-major path
 //--------------------------------------------------------------------------------------------------
-#ifndef TP_CUT_TILE_ROWS   // lab builds vary the tile (tools/lab/cut_variants.py); the product uses the defaults
-#define TP_CUT_TILE_ROWS 2
-#define TP_CUT_TILE_COLS 64
-#define TP_CUT_TILE_CAD 32
-#endif
-constexpr int kTileRows = TP_CUT_TILE_ROWS, kTileCols = TP_CUT_TILE_COLS, kTilePix = kTileRows * kTileCols;
-constexpr int kTileCad = TP_CUT_TILE_CAD;   // frames per tile = lanes per stored pixel run
+// tile shape: 2 rows x 64 columns x 32 frames (measured against 2x64x64, 4x64x32, 2x128x32, 1x64x32, 2x64x16: DESIGN.md section 3)
+constexpr int kTileRows = 2, kTileCols = 64, kTilePix = kTileRows * kTileCols;
+constexpr int kTileCad = 32;   // frames per tile = lanes per stored pixel run
 constexpr int kTileLd = kTilePix + 1;   // LDS stride of one cadence: odd, so that the transposed reads are conflict-free
 
 struct TileGeom { int tiles_x, tiles_y; };

@@ -222,7 +222,7 @@ extern "C" int tp_aperture_photometry(tp_ctx* ctx, const tp_cube_desc* desc,
 	ka.target_pos_row = d_target_pos_row; ka.target_pos_column = d_target_pos_column; ka.target_tmag = d_target_tmag;
 	ka.target_starid = d_target_starid; ka.stamps = d_stamps; ka.aperture = d_aperture; ka.cut_override = nullptr;
 	ka.mask = d_mask; ka.status = d_status; ka.flags = d_flags; ka.contamination = d_contamination; ka.diag = d_diag;
-	ka.cat_in_mask = d_cat_in_mask; ka.timing = nullptr;
+	ka.cat_in_mask = d_cat_in_mask;
 
 	tp_ap::Args a;
 	a.images = d_images; a.images_err = d_images_err; a.backgrounds = d_backgrounds;

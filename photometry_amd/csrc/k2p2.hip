@@ -91,11 +91,6 @@ extern "C" int tp_k2p2_masks(tp_ctx* ctx, int32_t n_targets, int32_t height, int
 	a.target_starid = d_target_starid; a.stamps = d_stamps; a.aperture = d_aperture; a.cut_override = d_cut_override;
 	a.mask = d_mask; a.status = d_status; a.flags = d_flags; a.contamination = d_contamination; a.diag = d_diag;
 	a.cat_in_mask = d_cat_in_mask;
-	a.timing = nullptr;
-#ifdef TP_LAB_K2P2_TIMING
-	// lab builds only (tools/k2p2_phases.py): d_diag, 16 doubles per target, receives per-phase cycle counts instead
-	if (d_diag) { a.timing = d_diag; a.diag = nullptr; }
-#endif
 	if (in_lds) TP_LAUNCH(ctx, TPK_K2P2, tp_k2p2_kernel, dim3((unsigned)n_targets), dim3(64), shmem, a, prm, (const double*)ctx->twiddle);
 	else {
 		const size_t per = (shmem + 255) & ~(size_t)255;

@@ -16,7 +16,6 @@ struct BatchArgs {
 	const int32_t* aperture;           // [Nt][P]
 	const double* cut_override;        // [Nt] or null
 	uint8_t* mask; int32_t* status; int32_t* flags; double* contamination; double* diag; uint8_t* cat_in_mask;
-	double* timing;                    // optional [Nt][16] per-phase cycles (diagnostics), normally null
 };
 
 inline TP_DEV void make_target(const BatchArgs& a, int i, Target& t) {
@@ -45,7 +44,6 @@ inline TP_DEV void make_target(const BatchArgs& a, int i, Target& t) {
 	t.contamination = a.contamination + i;
 	t.diag = a.diag ? (a.diag + (int64_t)i * 8) : nullptr;
 	t.cat_in_mask = a.cat_in_mask ? (a.cat_in_mask + c0) : nullptr;
-	t.timing = a.timing ? (a.timing + (int64_t)i * 16) : nullptr;
 }
 
 // photometry.py:54-64 + the normalised taps of scipy.ndimage.gaussian_filter(sigma=0.5, truncate=4)

@@ -18,36 +18,22 @@
 // redundantly and identically by all 64 lanes.  Reductions are "per-lane partials, then every lane
 // sums the 64 partials in lane order" so that the arithmetic is order-deterministic.
 //
-// The same source compiles for the host with TP_HOSTSIM (lanes become loops) -- used ONLY by the
-// CPU unit tests to debug the logic where no GPU is available; the product never runs it.
+// The CPU unit tests compile the same phases with loops over the lanes (tests/hostsim) to check the logic where no GPU
+// is available; the product never runs that build.
 // Built with -ffp-contract=off on both sides; exp() is an own implementation, so host-sim and
 // device results are bit-identical.
 #pragma once
 #include <stdint.h>
 #include <math.h>
 
-#ifdef TP_HOSTSIM
-#define TP_DEV
-#define TP_HD
-#define TP_LANE_LOOP(l) for (int l = 0; l < 64; ++l)
-#define TP_PAR_FOR(i, n) for (int i = 0; i < (n); ++i)
-#define TP_SYNC() do {} while (0)
-#define TP_SERIAL if (true)
-#define TP_ATOMIC_INC(ptr) ((*(ptr))++)
-#define TP_ATOMIC_OR(ptr, v) (*(ptr) |= (v))
-#define TP_STAMP(id) do {} while (0)
-#else
-#define TP_DEV __device__
-#define TP_HD __host__ __device__
-#define TP_LANE_LOOP(l) for (int l = k.lane, _once = 0; _once < 1; ++_once)
-#define TP_PAR_FOR(i, n) for (int i = k.lane; i < (n); i += 64)
-#define TP_SYNC() __syncthreads()
-#define TP_SERIAL if (k.lane == 0)
-#define TP_ATOMIC_INC(ptr) atomicAdd((ptr), 1)
-#define TP_ATOMIC_OR(ptr, v) atomicOr((ptr), (v))
-// optional per-phase cycle accounting (diagnostic builds / runs only: t.timing == nullptr in production)
-#define TP_STAMP(id) do { if (t.timing && k.lane == 0) { const long long _now = clock64(); t.timing[id] += (double)(_now - _tlast); _tlast = _now; } } while (0)
+// The lane layer (how a "phase" runs over the 64 lanes, the reductions) comes from a separate header: k2p2_lanes.h for the
+// device; the CPU unit tests of the logic substitute their own (tests/hostsim), the product never does.
+#ifndef K2P2_LANES_HEADER
+#define K2P2_LANES_HEADER "k2p2_lanes.h"
 #endif
+#define K2P2_LANES_SECTION 1
+#include K2P2_LANES_HEADER
+#undef K2P2_LANES_SECTION
 
 namespace k2p2 {
 
@@ -105,7 +91,6 @@ struct Target {
 	double* contamination;
 	double* diag;             // [8]: CUT, MODE, MAD1, bandwidth, max_guess, nflux, margin, nmasks
 	uint8_t* cat_in_mask;     // [ncat] 1 if the catalog star falls in the final mask (skip_targets source)
-	double* timing;           // optional [16] per-phase cycle counters (diagnostics)
 };
 
 // Labels, pixel indices and counters bounded by P (<= 54*54, the LDS limit) are 16-bit: LDS footprint decides how many targets
@@ -259,49 +244,9 @@ inline TP_DEV double tp_exp(double x) {
 // Reductions over the 64 per-lane partials in k.red / k.ired (written by a TP_LANE_LOOP, followed by
 // TP_SYNC).  Fixed binary-tree association: a[l] (op)= a[l+32], then +16, ... so that the host
 // simulation and the device (DPP / permute shuffles, result broadcast from lane 0) agree bit for bit.
-#ifdef TP_HOSTSIM
-#define TP_TREE(T, arr, OP) T a_[64]; for (int l = 0; l < 64; ++l) a_[l] = (arr)[l]; \
-	for (int off = 32; off > 0; off >>= 1) for (int l = 0; l < off; ++l) { const T x_ = a_[l], y_ = a_[l + off]; a_[l] = OP; } return a_[0];
-inline double sum_red(const Shared& k) { TP_TREE(double, k.red, x_ + y_) }
-inline int sum_ired(const Shared& k) { TP_TREE(int, k.ired, x_ + y_) }
-inline int or_ired(const Shared& k) { TP_TREE(int, k.ired, x_ | y_) }
-inline int and_ired(const Shared& k) { TP_TREE(int, k.ired, x_ & y_) }
-inline int max_ired(const Shared& k) { TP_TREE(int, k.ired, (y_ > x_) ? y_ : x_) }
-inline double min_arr(const Shared&, const double* arr) { TP_TREE(double, arr, (y_ < x_) ? y_ : x_) }
-inline double max_arr(const Shared&, const double* arr) { TP_TREE(double, arr, (y_ > x_) ? y_ : x_) }
-#undef TP_TREE
-#else
-// lane l <- lane l + OFF: the two top steps go through the LDS crossbar (ds_bpermute), the four steps inside a row of 16
-// lanes are DPP row shifts (a few cycles instead of ~60 each); the result leaves lane 0 through v_readfirstlane.
-// Same pairs, same order as __shfl_down: the tree association is unchanged.
-template <int OFF> inline TP_DEV int tp_down(int x) {
-	if (OFF >= 16) return __shfl_down(x, OFF, 64);
-	return __builtin_amdgcn_update_dpp(0, x, 0x100 + OFF, 0xF, 0xF, true); // row_shl:OFF
-}
-template <int OFF> inline TP_DEV double tp_down(double x) {
-	const long long b = __double_as_longlong(x);
-	const int lo = tp_down<OFF>((int)(b & 0xffffffffll)), hi = tp_down<OFF>((int)(b >> 32));
-	return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-inline TP_DEV int tp_first(int x) { return __builtin_amdgcn_readfirstlane(x); }
-inline TP_DEV double tp_first(double x) {
-	const long long b = __double_as_longlong(x);
-	const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
-	return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-#define TP_TREE_STEP(T, OFF, OP) { const T y_ = tp_down<OFF>(x_); x_ = OP; }
-#define TP_TREE(T, arr, OP) T x_ = (arr)[k.lane]; \
-	TP_TREE_STEP(T, 32, OP) TP_TREE_STEP(T, 16, OP) TP_TREE_STEP(T, 8, OP) TP_TREE_STEP(T, 4, OP) TP_TREE_STEP(T, 2, OP) TP_TREE_STEP(T, 1, OP) \
-	return tp_first(x_);
-inline TP_DEV double sum_red(const Shared& k) { TP_TREE(double, k.red, x_ + y_) }
-inline TP_DEV int sum_ired(const Shared& k) { TP_TREE(int, k.ired, x_ + y_) }
-inline TP_DEV int or_ired(const Shared& k) { TP_TREE(int, k.ired, x_ | y_) }
-inline TP_DEV int and_ired(const Shared& k) { TP_TREE(int, k.ired, x_ & y_) }
-inline TP_DEV int max_ired(const Shared& k) { TP_TREE(int, k.ired, (y_ > x_) ? y_ : x_) }
-inline TP_DEV double min_arr(const Shared& k, const double* arr) { TP_TREE(double, arr, (y_ < x_) ? y_ : x_) }
-inline TP_DEV double max_arr(const Shared& k, const double* arr) { TP_TREE(double, arr, (y_ > x_) ? y_ : x_) }
-#undef TP_TREE
-#endif
+#define K2P2_LANES_SECTION 2
+#include K2P2_LANES_HEADER
+#undef K2P2_LANES_SECTION
 
 //--------------------------------------------------------------------------------------------------
 // A2: threshold
@@ -333,22 +278,6 @@ inline TP_DEV double score_at_percentile(const double* sorted, int n, double per
 	return (sorted[i] * w0 + sorted[i + 1] * w1) / sumval;
 }
 
-// Tree sum (same association as sum_red) of per-lane partials produced by f(lane), without touching LDS
-// on the device: the partial stays in a register and goes straight into the shuffle tree.
-template <class F>
-inline TP_DEV double wave_sum_f(const Shared& k, const F& f) {
-#ifdef TP_HOSTSIM
-	double a_[64];
-	for (int l = 0; l < 64; ++l) a_[l] = f(l);
-	for (int off = 32; off > 0; off >>= 1) for (int l = 0; l < off; ++l) a_[l] = a_[l] + a_[l + off];
-	return a_[0];
-#else
-	double x_ = f(k.lane);
-	x_ = x_ + tp_down<32>(x_); x_ = x_ + tp_down<16>(x_); x_ = x_ + tp_down<8>(x_);
-	x_ = x_ + tp_down<4>(x_); x_ = x_ + tp_down<2>(x_); x_ = x_ + tp_down<1>(x_);
-	return tp_first(x_);
-#endif
-}
 
 // -KDE(x): direct Gaussian sum over the nc values k.srt[0..nc) with bandwidth h
 // (statsmodels kernels.Gaussian: 0.3989422804014327*exp(-z**2/2); density = 1/(h n) * sum)
@@ -1030,9 +959,6 @@ inline TP_DEV float mags_total_f32(const float* tmag, const uint8_t* sel, int n)
 // Returns the STATUS integer; on return k.res holds the final mask (what was written to t.mask).
 inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 	const int P = k.P, H = k.H, W = k.W;
-#ifndef TP_HOSTSIM
-	long long _tlast = clock64();
-#endif
 	TP_PAR_FOR(p, P) { k.S[p] = t.S[p]; k.res[p] = 0; }
 	TP_SYNC();
 	int flags = 0;
@@ -1045,7 +971,6 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 	double CUT = tp_nan();
 	if (t.cut_override) { CUT = *t.cut_override; if (t.diag) { TP_SERIAL { t.diag[0] = CUT; } } }
 	else err = threshold(k, prm, t, &CUT);
-	TP_STAMP(1);
 
 	// target pixel (photometry.py:107): Python round() = round-half-even; negative indices wrap
 	int tr = (int)rint(t.tpos_row - (double)t.stamp_row0);
@@ -1088,7 +1013,6 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 			}
 			TP_SYNC();
 			const int nclusters = label_components(k, k.core, k.mark, true);
-			TP_STAMP(2);
 			// lab: -2 outside idx, -1 noise, cluster id (0-based) for core; border = min neighbouring cluster
 			TP_PAR_FOR(p, P) {
 				int v = -2;
@@ -1122,7 +1046,6 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 				TP_PAR_FOR(p, P) k.msk[p] = (k.lab[p] == lab) ? 1 : 0;
 				TP_SYNC();
 				const int nsat = saturated_one(k);
-				TP_STAMP(3);
 				// Z = flux on the core pixels of this cluster
 				TP_PAR_FOR(p, P) k.Z[p] = (k.lab2[p] == lab) ? k.S[p] : 0.0;
 				TP_SYNC();
@@ -1169,7 +1092,6 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 				TP_SYNC();
 				const int npeaks = sum_ired(k);
 				TP_SYNC();
-				TP_STAMP(4);
 				// peaks matched to catalog stars (k2p2v2.py:144-153); candidates stay in lmax, selection in sat? no:
 				// selection goes to k.core-independent temp: reuse wsout as "selected" flags
 				TP_PAR_FOR(p, P) k.wsout[p] = 0;
@@ -1213,7 +1135,6 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 				TP_SYNC();
 				TP_PAR_FOR(p, P) k.lmax[p] = k.wsout[p] ? 1 : 0; // local_maxi
 				TP_SYNC();
-				TP_STAMP(5);
 				// de-duplicate maxima inside saturated patches (k2p2v2.py:193-212)
 				if (nsat > 0) {
 					const int ncomp = label_components(k, k.sat, k.mark, false);
@@ -1244,14 +1165,12 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 				}
 				// markers = ndimage.label(local_maxi) (4-connectivity)
 				const int nmark = label_components(k, k.lmax, k.mark, false);
-				TP_STAMP(6);
 				if (nmark == 0) {
 					// "No maxima were found": the cluster is rejected (k2p2v2.py:218-223)
 					TP_PAR_FOR(p, P) if (k.lab2[p] == lab) k.lab2[p] = -1;
 					TP_SYNC();
 				} else {
 					watershed(k, nmark); // k.mark -> k.wsout
-					TP_STAMP(7);
 					// no_labels = number of distinct values in labels_ws, zero included (k2p2v2.py:230)
 					TP_PAR_FOR(m, nmark + 1) k.hage[m] = 0;
 					TP_SYNC();
@@ -1275,7 +1194,6 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 					}
 					TP_SYNC();
 					if (no_labels - 2 > 0) max_label += (no_labels - 2);
-					TP_STAMP(8);
 				}
 			}
 
@@ -1286,7 +1204,6 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 					TP_SYNC();
 					const int npx = sum_ired(k);
 					TP_SYNC();
-					TP_STAMP(9);
 					if (npx < prm.min_no_pixels_in_mask) continue;
 					nmasks_total++;
 					have_masks = true;
@@ -1303,7 +1220,6 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 					TP_SYNC();
 					TP_PAR_FOR(p, P) if (k.lmax[p]) k.msk[p] = 1;
 					TP_SYNC();
-					TP_STAMP(10);
 					// extend overflow columns (k2p2v2.py:579-623)
 					if (prm.extend_overflow) {
 						const int nsat = saturated_one(k);
@@ -1331,7 +1247,6 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 							TP_SYNC();
 						}
 					}
-					TP_STAMP(11);
 					// does this mask contain the target pixel?  (photometry.py:107)
 					if (!target_inside) { err = ERR_TARGET_OUTSIDE; break; }
 					if (k.msk[tr * W + tc]) {
@@ -1424,7 +1339,6 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 	} else if (flags & FLAG_MIN_APERTURE) status = 3; // STATUS.WARNING
 	flags |= (err << ERR_SHIFT);
 
-	TP_STAMP(12);
 	const bool keep_mask = (status != 2) || (err == ERR_NO_TARGETS_IN_MASK); // photometry.py:204 ran before :227
 	TP_PAR_FOR(p, P) { const uint8_t v = keep_mask ? k.res[p] : 0; k.res[p] = v; t.mask[p] = v; }
 	TP_SERIAL {

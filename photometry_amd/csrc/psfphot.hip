@@ -129,13 +129,6 @@ __device__ __forceinline__ double model_pixel(int i, int j, const EvalCtx& c)
 __device__ double likelihood(const double* x, const EvalCtx& c)
 {
 	const int tid = threadIdx.x;
-#ifdef TP_LAB_PSF_NOEVAL
-	{ // lab: a cheap stand-in for chi^2, to time the simplex bookkeeping alone (tools/psf_time.py)
-		double t = 0.0;
-		for (int d = 0; d < 3 * c.ns; ++d) t += (x[d] - (d % 3 == 2 ? 1000.0 : 7.0)) * (x[d] - (d % 3 == 2 ? 1000.0 : 7.0)) * (d + 1);
-		return t;
-	}
-#endif
 	prepare_stars(x, c);
 	double acc = 0.0;
 	for (int p = tid; p < c.H * c.W; p += kThreads) {

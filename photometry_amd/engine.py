@@ -241,13 +241,14 @@ def lightcurve_diagnostics(ctx, lc, time, quality, status=None, sumimage=None, m
 
 class LinPSFResult(object):
 	"""Device-resident outputs of the LinPSF pipeline."""
-	def __init__(self, ctx, n_targets, n_fit_stars, n_cad):
+	def __init__(self, ctx, n_targets, n_fit_stars, n_cad, flux=None, contamination=None, status=None):
+		"""``flux`` / ``contamination`` / ``status``: optional caller-owned arrays (pieces of a packed output block)."""
 		self.n_cad = int(n_cad)
-		self.flux = ctx.zeros((n_targets, n_cad), 'float64')
+		self.flux = ctx.zeros((n_targets, n_cad), 'float64') if flux is None else flux
 		self.flux_err = ctx.zeros((n_targets, n_cad), 'float64')
 		self.fluxes_all = ctx.zeros((max(n_fit_stars, 1), n_cad), 'float64')
-		self.contamination = ctx.zeros((n_targets,), 'float64')
-		self.status = ctx.zeros((n_targets,), 'int32')
+		self.contamination = ctx.zeros((n_targets,), 'float64') if contamination is None else contamination
+		self.status = ctx.zeros((n_targets,), 'int32') if status is None else status
 		self.fluxes_mean = ctx.zeros((max(n_fit_stars, 1),), 'float64')
 
 	def to_host(self):

@@ -91,27 +91,26 @@ class ApertureWork(object):
 
 	``packed=True`` carves the per-target results a scheduler consumes -- the light-curve block ``[5][Nt][T]`` float64,
 	``contamination`` float64, ``status`` / ``flags`` int32 and the ``mask`` uint8 (the output
-	block of a rank) -- out of ONE allocation (``self.block``), so that the per-step gather of a multi-GPU run is a
-	single message.
+	block of a rank), with ``psf=True`` also the LinPSF light curve, contamination and status -- out of ONE allocation
+	(``self.block``, layout: ``comm.packed_block_layout``), so that the per-step gather of a multi-GPU run is a single message.
 	"""
 
-	def __init__(self, ctx, batch, packed=False):
+	def __init__(self, ctx, batch, packed=False, psf=False):
+		from . import comm as tpcomm
 		Nt, T, H, W = batch.n_targets, batch.n_cad, batch.height, batch.width
 		self.sumimage = ctx.empty((Nt, H, W), 'float64')
 		self.block = None
+		self.psf_flux = self.psf_contamination = self.psf_status = None
 		if packed:
-			sizes = [5 * Nt * T * 8, Nt * 8, Nt * 4, Nt * 4, Nt * H * W]
-			offs = [0]
-			for n in sizes:
-				offs.append(round_up(offs[-1] + n, 256))
-			self.block = ctx.zeros((offs[-1],), 'uint8')
+			layout, nbytes = tpcomm.packed_block_layout(Nt, T, H, W, psf=psf)
+			self.block = ctx.zeros((nbytes,), 'uint8')
 			b = self.block
-			self.lc = engine.LightCurves(ctx, Nt, T, block=device_view(ctx, b.ptr + offs[0], (5, Nt, T), 'float64', base=b))
-			self.contamination = device_view(ctx, b.ptr + offs[1], (Nt,), 'float64', base=b)
-			self.status = device_view(ctx, b.ptr + offs[2], (Nt,), 'int32', base=b)
-			self.flags = device_view(ctx, b.ptr + offs[3], (Nt,), 'int32', base=b)
-			self.mask = device_view(ctx, b.ptr + offs[4], (Nt, H, W), 'uint8', base=b)
-			self.block_layout = dict(zip(('lc', 'contamination', 'status', 'flags', 'mask'), offs[:5]))
+			view = lambda name: device_view(ctx, b.ptr + layout[name][0], layout[name][1], layout[name][2], base=b) # noqa: E731
+			self.lc = engine.LightCurves(ctx, Nt, T, block=view('lc'))
+			self.contamination, self.status, self.flags, self.mask = view('contamination'), view('status'), view('flags'), view('mask')
+			if psf:
+				self.psf_flux, self.psf_contamination, self.psf_status = view('psf_flux'), view('psf_contamination'), view('psf_status')
+			self.block_layout = layout
 		else:
 			self.mask = ctx.zeros((Nt, H, W), 'uint8')
 			self.status = ctx.zeros((Nt,), 'int32')
@@ -222,7 +221,8 @@ class LinPSFBatch(object):
 	(``catalog_attime``: reference position + jitter, host geometry).
 	"""
 
-	def __init__(self, ctx, scene, prf_model, images=None, subtract=None):
+	def __init__(self, ctx, scene, prf_model, images=None, subtract=None, work=None):
+		"""``work``: an ``ApertureWork(packed=True, psf=True)`` whose block receives the light curve, contamination and status."""
 		from . import psf as hpsf
 		self.ctx, self.scene, self.model = ctx, scene, prf_model
 		self.images = DeviceCube.from_host(ctx, scene.images) if images is None else images
@@ -244,16 +244,25 @@ class LinPSFBatch(object):
 		self.weights = ctx.array(prf_model.weights(scene.stamps))
 		self.tx, self.ty = ctx.array(prf_model.tx), ctx.array(prf_model.ty)
 		self.coef = ctx.empty((scene.n_targets, prf_model.base_coef.shape[1]), 'float64')
-		self.out = engine.LinPSFResult(ctx, scene.n_targets, len(rs), T)
+		self.out = self.result_for(work)
 		self.n_fit_stars = len(rs)
 
+	def result_for(self, work=None):
+		"""Output arrays of the fit; the per-target results inside ``work``'s packed block when given."""
+		n_fit = int(self.star_offsets_h[-1])
+		if work is None or work.psf_flux is None:
+			return engine.LinPSFResult(self.ctx, self.scene.n_targets, n_fit, self.scene.n_cad)
+		return engine.LinPSFResult(self.ctx, self.scene.n_targets, n_fit, self.scene.n_cad, flux=work.psf_flux,
+			contamination=work.psf_contamination, status=work.psf_status)
 
-def linpsf_step(ctx, batch, cutoff_radius=5.0):
+
+def linpsf_step(ctx, batch, cutoff_radius=5.0, out=None, subtract=None):
 	"""One pass of the LinPSF hot path: P1 table blend, P2-P4 fit + contamination."""
+	out = batch.out if out is None else out
 	engine.linpsf_prf(ctx, batch.base_coef, batch.weights, out=batch.coef)
 	engine.linpsf_fit(ctx, batch.images, batch.coef, batch.tx, batch.ty, batch.star_offsets, batch.target_index,
-		batch.pos_row, batch.pos_col, batch.max_stars, cutoff_radius=cutoff_radius, subtract=batch.subtract, out=batch.out)
-	return batch.out
+		batch.pos_row, batch.pos_col, batch.max_stars, cutoff_radius=cutoff_radius, subtract=batch.subtract if subtract is None else subtract, out=out)
+	return out
 
 
 #--------------------------------------------------------------------------------------------------

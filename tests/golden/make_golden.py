@@ -23,7 +23,6 @@ Fixtures:
 * ``golden_linpsf.npz``   ``lsfit`` and ``LinPSFPhotometry.do_photometry``
                           (linpsf_photometry.py:22-34, 79-219)
 * ``golden_pixelflags.npz`` ``pixel_flags.pixel_manual_exclude`` (pixel_flags.py:13-58) on header / data cases
-* ``golden_timeoffset.npz`` ``fixes.time_offset`` (fixes/time_offset.py:64-180) on header cases
 * ``golden_skiptargets.npz`` ``TaskManager.get_task / start_task / save_result`` (taskmanager.py:391-532) on sqlite todo-lists with
                           prescribed outcomes: the master-side skip-target resolution
 * ``golden_fitsfile.json/.npz`` ``BasePhotometry.save_lightcurve`` (BasePhotometry.py:1417-1730) with a recording stand-in for
@@ -691,35 +690,6 @@ def golden_pixelflags():
 	print('golden_pixelflags', len(cases), 'cases, first excluded columns', out['first_excluded_column'])
 
 
-def golden_timeoffset():
-	"""
-	``fixes.time_offset`` itself on every branch of its decision table: data releases 1, 26, 27 (both deliveries), 29 (both), 30,
-	FFI and TPF, the three time positions, every camera and CCD, the already-corrected card.  (The reference's own vectors,
-	tests/input/time_offset/*.ecsv, are git-LFS pointers here.)
-	"""
-	from photometry import fixes as reffixes
-	time = np.array([1325.3, 1500.25, 1842.5123456, 1870.0])
-	rows = []
-	for datarel, procver in [(1, None), (26, 'spoc-x'), (27, 'spoc-4.0.14-20200108'), (27, 'spoc-4.0.26-20200323'), (29, 'spoc-4.0.20-20200220'),
-		(29, 'spoc-4.0.28-20200407'), (30, 'spoc-y'), (99, None)]:
-		for datatype in ('ffi', 'tpf'):
-			for timepos in ('start', 'mid', 'end'):
-				for camera, ccd in [(1, 1), (2, 3), (3, 2), (4, 4)]:
-					for corrected in (False, True):
-						hdr = {'DATA_REL': datarel, 'CAMERA': camera, 'CCD': ccd}
-						if procver is not None:
-							hdr['PROCVER'] = procver
-						if corrected:
-							hdr['TIME_OFFSET_CORRECTED'] = True
-						out, flag = reffixes.time_offset(time, hdr, datatype=datatype, timepos=timepos, return_flag=True)
-						rows.append((datarel, procver or '', datatype, timepos, camera, ccd, corrected, flag, out))
-	np.savez_compressed(os.path.join(HERE, 'golden_timeoffset.npz'), time=time,
-		datarel=np.array([r[0] for r in rows]), procver=np.array([r[1] for r in rows]), datatype=np.array([r[2] for r in rows]),
-		timepos=np.array([r[3] for r in rows]), camera=np.array([r[4] for r in rows]), ccd=np.array([r[5] for r in rows]),
-		corrected=np.array([r[6] for r in rows]), applied=np.array([r[7] for r in rows]), out=np.stack([r[8] for r in rows]))
-	print('golden_timeoffset', len(rows), 'cases,', int(np.sum([r[7] for r in rows])), 'corrected')
-
-
 def golden_psfphot():
 	"""The reference's own PSFPhotometry.do_photometry on two small targets (a few cadences: every cadence is a Nelder-Mead run)."""
 	from photometry.psf_photometry import PSFPhotometry
@@ -1041,6 +1011,6 @@ def golden_fitsfile():
 
 
 if __name__ == '__main__':
-	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics', 'cutout', 'background', 'psfphot', 'pixelflags', 'timeoffset', 'skiptargets', 'fitsfile']
+	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics', 'cutout', 'background', 'psfphot', 'pixelflags', 'skiptargets', 'fitsfile']
 	for w in which:
 		globals()['golden_' + w]()

@@ -1,7 +1,7 @@
-// k2p2_hostsim.cpp -- TEST-ONLY host build of photometry_amd/csrc/k2p2_core.h (TP_HOSTSIM: the 64
+// k2p2_hostsim.cpp -- TEST-ONLY host build of photometry_amd/csrc/k2p2_core.h (lane layer k2p2_lanes_host.h: the 64
 // lanes of the wavefront become loops).  It exists to debug the K2P2 kernel logic on machines
 // without a GPU; nothing in the product loads it.  Built by tests/test_k2p2_hostsim.py with g++.
-#define TP_HOSTSIM 1
+#define K2P2_LANES_HEADER "k2p2_lanes_host.h"
 #include "../../photometry_amd/csrc/k2p2_args.h"
 #include <vector>
 #include <cmath>
@@ -20,7 +20,7 @@ extern "C" int hostsim_k2p2(int n_targets, int H, int W, const double* sumimage,
 	a.cat_column = cat_column; a.cat_row = cat_row; a.cat_starid = cat_starid;
 	a.target_pos_row = target_pos_row; a.target_pos_column = target_pos_column; a.target_tmag = target_tmag;
 	a.target_starid = target_starid; a.stamps = stamps; a.aperture = aperture; a.cut_override = cut_override;
-	a.mask = mask; a.status = status; a.flags = flags; a.contamination = contamination; a.diag = diag; a.cat_in_mask = cat_in_mask; a.timing = nullptr;
+	a.mask = mask; a.status = status; a.flags = flags; a.contamination = contamination; a.diag = diag; a.cat_in_mask = cat_in_mask;
 	k2p2::Params prm = k2p2::default_params();
 	prm.thresh = thresh;
 	std::vector<double> twid(2 * k2p2::kGrid);

@@ -1,7 +1,7 @@
 # -*- coding: utf-8 -*-
 """
 CPU check of the K2P2 KERNEL LOGIC: photometry_amd/csrc/k2p2_core.h compiled for the host
-(TP_HOSTSIM: lanes become loops; test-only, see tests/hostsim/k2p2_hostsim.cpp) against the
+(lane layer tests/hostsim/k2p2_lanes_host.h: lanes become loops; test-only, see tests/hostsim/k2p2_hostsim.cpp) against the
 oracle.  The real parity test of the HIP kernel is tests/test_gpu_k2p2.py.
 """
 import os
@@ -20,7 +20,7 @@ OUT = os.path.join(OUT_DIR, 'k2p2_hostsim.so')
 @pytest.fixture(scope='module')
 def hostsim():
 	os.makedirs(OUT_DIR, exist_ok=True)
-	subprocess.run(['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-o', OUT, SRC], check=True)
+	subprocess.run(['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-I' + os.path.dirname(SRC), '-o', OUT, SRC], check=True)
 	lib = ctypes.CDLL(OUT)
 	lib.hostsim_k2p2.restype = ctypes.c_int
 	return lib

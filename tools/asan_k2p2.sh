@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p /tmp/tp_asan
-g++ -O1 -g -std=c++17 -ffp-contract=off -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -o /tmp/tp_asan/k2p2_hostsim_asan.so tests/hostsim/k2p2_hostsim.cpp
+g++ -O1 -g -std=c++17 -ffp-contract=off -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -Itests/hostsim -o /tmp/tp_asan/k2p2_hostsim_asan.so tests/hostsim/k2p2_hostsim.cpp
 cat > /tmp/tp_asan/run.py <<'PY'
 import sys, os, ctypes
 root = os.getcwd()
