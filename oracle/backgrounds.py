@@ -227,7 +227,7 @@ CAMERA_CENTRE = {
 }
 
 
-def reduce_mode(x):
+def reduce_mode(x, binning='float'):
 	"""``_reduce_mode`` (backgrounds.py:20-32): mode of the KDE (statsmodels default bandwidth, 2000 -> 2048 grid points)."""
 	from .kde import KDE
 	if len(x) == 0:
@@ -236,7 +236,7 @@ def reduce_mode(x):
 	kde = KDE(x)
 	try:
 		with np.errstate(all='ignore'):
-			kde.fit(gridsize=2000)
+			kde.fit(gridsize=2000, binning=binning)
 	except RuntimeError as err:
 		if str(err).startswith('Selected KDE bandwidth is 0.'):
 			return np.median(x)
@@ -288,7 +288,7 @@ def radial_geometry(shape, camera, ccd, radial_cutoff=2400, radial_pixel_step=15
 
 
 def fit_background_tess(image, camera, ccd, flux_cutoff=8e4, exclude=None, bkgiters=3, radial_cutoff=2400, radial_pixel_step=15,
-	radial_smooth=3, full=False):
+	radial_smooth=3, full=False, device_arithmetic=False):
 	"""
 	``fit_background`` for a TESS FFIImage (backgrounds.py:52-211 with ``is_tess``): ``bkgiters`` rounds of the radial
 	component (ring modes of log10(img - square + zeropoint), 3-point median, interpolating cubic spline, :162-197) and the
@@ -298,6 +298,14 @@ def fit_background_tess(image, camera, ccd, flux_cutoff=8e4, exclude=None, bkgit
 	minimum, ``pix + zeropoint`` and ``log10`` are float32; from the second round on everything is float64.
 	Returns ``(background float64, mask)`` (+ a dict of intermediates with ``full``).  **Parity unpinned** against statsmodels /
 	photutils (not installable here); the scipy parts (binned statistic, spline, zoom) are the real scipy.
+
+	``device_arithmetic``: the same algorithm with the three roundings the device makes, for a comparison that is not decided by
+	them (a ring mode is the argmax over a KDE grid: where two grid points tie within rounding, ANY last-bit difference moves the
+	mode by a whole grid step).  (1) First round: the float32 ``log10`` is the correctly rounded one -- numpy's float32
+	``log10`` is a libm / SVML routine with 1-ulp errors on ~40 % of its arguments, different between numpy builds and CPUs, so
+	the reference's own ring modes are not reproducible across machines at exactly these ties; (2) the two background components
+	are stored as float32 images between the rounds and added in float32 storage at the end (the reference keeps float64);
+	(3) the linear binning accumulates fixed-point integers (:func:`oracle.kde.fast_linbin_fixed`).
 	"""
 	from scipy.interpolate import InterpolatedUnivariateSpline
 	img0 = np.asarray(image, dtype='float32')
@@ -313,12 +321,14 @@ def fit_background_tess(image, camera, ccd, flux_cutoff=8e4, exclude=None, bkgit
 			pix = img0[~mask].flatten()                                # float32
 			zeropoint = -np.float64(np.min(pix)) + 1.0                  # numpy 1.x: float32 scalar + Python float -> float64
 			logpix = np.log10(pix + np.float32(zeropoint))              # float32 array + scalar stays float32
+			if device_arithmetic:
+				logpix = np.log10((pix + np.float32(zeropoint)).astype('float64')).astype('float32')
 		else:
-			img = img0.astype('float64') - img_bkg_square
+			img = img0.astype('float64') - (img_bkg_square.astype('float32').astype('float64') if device_arithmetic else img_bkg_square)
 			pix = img[~mask].flatten()
 			zeropoint = -np.min(pix) + 1.0
 			logpix = np.log10(pix + zeropoint)
-		s2 = binned_callable(r[~mask].flatten(), logpix, reduce_mode, bins)
+		s2 = binned_callable(r[~mask].flatten(), logpix, (lambda v: reduce_mode(v, binning='fixed')) if device_arithmetic else reduce_mode, bins)
 		inter['s2'].append(s2.copy())
 		inter['zeropoint'].append(float(zeropoint))
 		if radial_smooth:
@@ -334,10 +344,13 @@ def fit_background_tess(image, camera, ccd, flux_cutoff=8e4, exclude=None, bkgit
 		else:
 			img_bkg_radial = 0
 		inter['radial'].append(np.array(img_bkg_radial, dtype='float64', copy=True))
-		work = img0.astype('float64') - img_bkg_radial
+		work = img0.astype('float64') - (np.asarray(img_bkg_radial, dtype='float32').astype('float64') if device_arithmetic else img_bkg_radial)
 		mesh, nmasked = mesh_statistics(work, mask)
 		img_bkg_square = mesh_to_background(mesh, nmasked, img0.shape)
-	img_bkg = img_bkg_radial + img_bkg_square
+	if device_arithmetic:
+		img_bkg = (img_bkg_radial + img_bkg_square.astype('float32').astype('float64')).astype('float32').astype('float64')
+	else:
+		img_bkg = img_bkg_radial + img_bkg_square
 	return (img_bkg, mask, inter) if full else (img_bkg, mask)
 
 

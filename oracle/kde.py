@@ -105,6 +105,26 @@ def fast_linbin_vec(X, a, b, M):
 	return gcnts[:M]
 
 
+def fast_linbin_fixed(X, a, b, M, bits=40):
+	"""
+	``fast_linbin`` with the weights accumulated as ``bits``-bit fixed-point integers: ``q = rint(rem * 2**bits)`` goes to the
+	upper grid point, ``2**bits - q`` to the lower one.  Integer sums do not depend on the order of the samples -- this is the
+	arithmetic of the device kernel (``csrc/radial.hip``), whose parallel accumulation must be reproducible; it deviates from
+	the float accumulation by at most ``n * 2**-(bits + 1)`` per grid point.
+	"""
+	M = int(M)
+	delta = (b - a) / (M - 1)
+	lxi = (np.asarray(X, dtype='float64') - a) / delta
+	li = lxi.astype(int)
+	rem = lxi - li
+	ok = (li > 1) & (li < M)
+	q = np.rint(rem[ok] * 2.0**bits).astype(np.uint64)
+	g = np.zeros(M + 1, dtype=np.uint64)
+	np.add.at(g, li[ok], np.uint64(2**bits) - q)
+	np.add.at(g, li[ok] + 1, q)
+	return g[:M].astype('float64') * (1.0 / 2.0**bits)
+
+
 def forrt(X, m=None):
 	"""kdetools.forrt: RFFT in Munro (1976) FORRT ordering."""
 	if m is None:
@@ -133,8 +153,8 @@ def silverman_transform(bw, M, RANGE):
 	return kern_est
 
 
-def kdensityfft(x, bw, gridsize=100, cut=3):
-	"""kde.kdensityfft for a user-given bandwidth.  Returns ``(density, grid, bw)``."""
+def kdensityfft(x, bw, gridsize=100, cut=3, binning='float'):
+	"""kde.kdensityfft for a user-given bandwidth.  Returns ``(density, grid, bw)``.  ``binning='fixed'``: :func:`fast_linbin_fixed`."""
 	x = np.asarray(x, dtype='float64')
 	bw = float(bw)
 	nobs = len(x)
@@ -143,7 +163,10 @@ def kdensityfft(x, bw, gridsize=100, cut=3):
 	b = np.max(x) + cut * bw
 	grid, delta = np.linspace(a, b, int(gridsize), retstep=True)
 	RANGE = b - a
-	binned = (fast_linbin if nobs < 2000 else fast_linbin_vec)(x, a, b, gridsize) / (delta * nobs)
+	if binning == 'fixed':
+		binned = fast_linbin_fixed(x, a, b, gridsize) / (delta * nobs)
+	else:
+		binned = (fast_linbin if nobs < 2000 else fast_linbin_vec)(x, a, b, gridsize) / (delta * nobs)
 	y = forrt(binned)
 	zstar = silverman_transform(bw, gridsize, RANGE) * y
 	f = revrt(zstar)
@@ -156,7 +179,7 @@ class KDE(object):
 	def __init__(self, endog):
 		self.endog = np.ascontiguousarray(endog, dtype='float64')
 
-	def fit(self, kernel='gau', bw=None, fft=True, gridsize=None, cut=3):
+	def fit(self, kernel='gau', bw=None, fft=True, gridsize=None, cut=3, binning='float'):
 		if kernel != 'gau' or not fft:
 			raise NotImplementedError
 		if bw is None:
@@ -165,7 +188,7 @@ class KDE(object):
 			bw = select_bandwidth(self.endog, bw)
 		if gridsize is None:
 			gridsize = max(len(self.endog), 512.0)
-		self.density, self.support, self.bw = kdensityfft(self.endog, bw, gridsize=gridsize, cut=cut)
+		self.density, self.support, self.bw = kdensityfft(self.endog, bw, gridsize=gridsize, cut=cut, binning=binning)
 		return self
 
 	def evaluate(self, point):

@@ -11,11 +11,12 @@
 // The geometry (distance of every pixel from the camera centre, ring membership) does not depend on the frame: the host
 // lists the pixels of every ring once (row-major inside a ring, like r[~mask] in the reference) and the ring kernel walks
 // its list.  One 256-thread workgroup per (ring, frame):
-//   1. gather the unmasked pixels of the ring into an HBM scratch row (<= ~25 000 float64), with their count, sum, min, max;
+//   1. gather the unmasked pixels of the ring into an HBM scratch row (<= ~25 000 float64) by an ORDERED compaction (the
+//      order of the pixel list), with their count, sum, min, max: nothing in the kernel depends on the order of arrival;
 //   2. standard deviation (two-pass, ddof = 1), quartiles by radix selection on the order-preserving 64-bit keys
 //      (scipy.stats.scoreatpercentile's linear interpolation between the two neighbouring order statistics);
-//   3. bandwidth C min(std, IQR / 1.349) n^-1/5; linear binning on 2048 grid points over [min - 3 bw, max + 3 bw] with LDS
-//      float64 atomics (the sums differ from a serial loop by rounding only);
+//   3. bandwidth C min(std, IQR / 1.349) n^-1/5; linear binning on 2048 grid points over [min - 3 bw, max + 3 bw], the
+//      weights accumulated as 40-bit fixed-point integers (LDS integer atomics: independent of the order of arrival);
 //   4. forward FFT (radix 2, LDS, twiddles from sincospi), multiplication by Silverman's transform of the Gaussian, second
 //      forward FFT of the conjugate = the inverse transform of a Hermitian spectrum; first index of the maximum -> grid value.
 // Bound by LDS/latency (18 passes over an L2-resident row, two 2048-point FFTs); a frame has ~40 rings, so the whole
@@ -179,22 +180,34 @@ __global__ __launch_bounds__(kRadThreads) void tp_radial_ring_kernel(RingArgs a)
 	const float zp32 = (float)zp;
 	double* mode_out = a.modes + (int64_t)frame * a.n_rings + ring;
 
-	// ---- 1. gather
-	if (tid == 0) sh[0] = 0;
-	__syncthreads();
+	// ---- 1. gather, in the order of the ring's pixel list (row-major, like values[binnumber == j] in the reference): an
+	// ordered compaction -- per block of 256 list entries the kept ones are ranked by ballot / popcount inside a wavefront
+	// and by a four-entry count across the wavefronts.  Same order, same sums, same result in every run.
+	const int lane = tid & 63, wave = tid >> 6;
+	int base = 0;
 	double sum = 0.0, mn = __builtin_inf(), mx = -__builtin_inf();
-	for (int i = p0 + tid; i < p1; i += kRadThreads) {
-		double v;
-		if (radial_pixel(a.img, frame, a.ring_pixels[i], v)) {
-			double lg;
+	for (int i0 = p0; i0 < p1; i0 += kRadThreads) {
+		const int i = i0 + tid;
+		double v = 0.0, lg = 0.0;
+		const bool keep = (i < p1) && radial_pixel(a.img, frame, a.ring_pixels[i], v);
+		if (keep) {
 			if (single) lg = (double)(float)log10((double)((float)v + zp32));
 			else lg = log10(v + zp);
-			vals[atomicAdd(&sh[0], 1)] = lg;
+		}
+		const unsigned long long bal = __ballot(keep);
+		if (lane == 0) hist[wave] = __popcll(bal);
+		__syncthreads();
+		int before = 0, total = 0;
+#pragma unroll
+		for (int w = 0; w < 4; ++w) { const int c = hist[w]; before += (w < wave) ? c : 0; total += c; }
+		if (keep) {
+			vals[base + before + __popcll(bal & ((1ull << lane) - 1ull))] = lg;
 			sum += lg; mn = fmin(mn, lg); mx = fmax(mx, lg);
 		}
+		base += total;
+		__syncthreads();
 	}
-	__syncthreads();
-	const int n = sh[0];
+	const int n = base;
 	__threadfence_block();
 	if (a.counts && tid == 0) a.counts[(int64_t)frame * a.n_rings + ring] = n;
 	if (n < 2 || !(zp == zp)) {
@@ -231,23 +244,31 @@ __global__ __launch_bounds__(kRadThreads) void tp_radial_ring_kernel(RingArgs a)
 	// ---- 3. linear binning (statsmodels fast_linbin, with its "li > 1" guard)
 	const double lo = mn - 3.0 * bw, hi = mx + 3.0 * bw;
 	const double delta = (hi - lo) / (double)(kKdeGrid - 1);
-	for (int i = tid; i < kKdeGrid; i += kRadThreads) { re[i] = 0.0; im[i] = 0.0; }
+	// The weights (1 - rem, rem) are accumulated as 40-bit fixed-point integers with LDS integer atomics: the sum of integers
+	// does not depend on the order of arrival, so the binned grid is the same in every run (float atomics are not); the
+	// quantisation (2^-41 per sample) is far below the rounding of the float32 logarithm the samples come from.
+	unsigned long long* bins = reinterpret_cast<unsigned long long*>(re);
+	for (int i = tid; i < kKdeGrid; i += kRadThreads) { bins[i] = 0ull; im[i] = 0.0; }
 	for (int i = tid; i < kKdeGrid / 2; i += kRadThreads) {
 		double s, c;
 		sincospi(-2.0 * (double)i / (double)kKdeGrid, &s, &c);
 		tw_re[i] = c; tw_im[i] = s;
 	}
 	__syncthreads();
+	constexpr double kFix = 1099511627776.0;   // 2^40
 	for (int i = tid; i < n; i += kRadThreads) {
 		const double lx = (vals[i] - lo) / delta;
 		const int li = (int)lx;
 		const double rem = lx - (double)li;
 		if (li > 1 && li < kKdeGrid) {
+			const unsigned long long q = (unsigned long long)rint(rem * kFix);
 			// bit-reversed positions: the FFT below is decimation in time
-			atomicAdd(&re[__brev((unsigned)li) >> (32 - kKdeLog2)], 1.0 - rem);
-			if (li + 1 < kKdeGrid) atomicAdd(&re[__brev((unsigned)(li + 1)) >> (32 - kKdeLog2)], rem);
+			atomicAdd(&bins[__brev((unsigned)li) >> (32 - kKdeLog2)], (unsigned long long)kFix - q);
+			if (li + 1 < kKdeGrid) atomicAdd(&bins[__brev((unsigned)(li + 1)) >> (32 - kKdeLog2)], q);
 		}
 	}
+	__syncthreads();
+	for (int i = tid; i < kKdeGrid; i += kRadThreads) re[i] = (double)bins[i] * (1.0 / kFix);
 	__syncthreads();
 
 	// ---- 4. density = IFFT(FFT(binned) * Silverman transform); only its argmax is used (positive scale factors dropped)

@@ -147,19 +147,45 @@ def _tess_frames(T, R, C, seed):
 @pytest.mark.parametrize("T,R,C", [(2, 384, 448)])
 def test_fit_background_tess_matches_oracle(ctx, T, R, C):
 	"""
-	The TESS branch (radial rings + mesh, three rounds).  The ring modes are grid points of a 2048-point KDE: device and oracle
-	must pick the same grid point (the value then agrees to the rounding of the grid's end points: float32 log10 in the first
-	round, float64 plus the float32 square component later) in all but a few rings per round, where two neighbouring grid
-	points tie and the different summation order decides -- there the values differ by one grid step (~5e-4 in log10).  The final background is compared at 2e-3 relative for that reason; typical agreement is printed.
+	The TESS branch (radial rings + mesh, three rounds).  A ring mode is the argmax over a 2048-point KDE grid: where two
+	neighbouring grid points tie within rounding, ANY last-bit difference in the samples moves the mode by a whole grid step
+	(~5e-4 in log10, ~1e-3 in the background).  The reference's own samples carry such differences from machine to machine:
+	its first round takes numpy's float32 log10, a libm / SVML routine that is off by one ulp on ~40 % of its arguments.
+
+	* Against the oracle with the device's three roundings written out (``device_arithmetic``: correctly rounded float32
+	  log10, float32 storage of the two components between the rounds, fixed-point binning) every ring mode must be the same
+	  grid point and the background agree to 1e-5 (north_star's tolerance).
+	* Against the literal oracle (numpy's float32 log10, float64 components) the same holds except in the rings whose mode
+	  sits on such a tie: at most 3 per round may differ, by one grid step.
+	* The device result is reproducible bit for bit (ordered compaction, integer binning: nothing depends on arrival order).
 	"""
 	from photometry_amd import prepare
 	from oracle import backgrounds as ob
 	f = _tess_frames(T, R, C, seed=5)
 	details = {}
-	bkg = prepare.fit_background_frames(ctx, ctx.array(f), camera=1, ccd=1, details=details)
+	d_f = ctx.array(f)
+	bkg = prepare.fit_background_frames(ctx, d_f, camera=1, ccd=1, details=details)
 	b = bkg.to_host()
-	worst = 0.0
+	details2 = {}
+	b2 = prepare.fit_background_frames(ctx, d_f, camera=1, ccd=1, details=details2).to_host()
+	assert np.array_equal(b, b2, equal_nan=True)
+	for it in range(3):
+		assert np.array_equal(details['s2'][it], details2['s2'][it], equal_nan=True)
+	worst = worst_dev = 0.0
 	for k in range(T):
+		# --- the device's arithmetic restated: no tie is decided by a rounding the two sides do differently
+		refd, _, interd = ob.fit_background_tess(f[k], 1, 1, full=True, device_arithmetic=True)
+		for it in range(3):
+			s_dev, s_ref = details['s2'][it][k], interd['s2'][it]
+			assert np.array_equal(np.isnan(s_dev), np.isnan(s_ref))
+			ok = ~np.isnan(s_ref)
+			d = np.abs(s_dev[ok] - s_ref[ok])
+			print('frame', k, 'round', it, '[device arithmetic] max ring-mode diff', float(d.max()))
+			assert d.max() < 2e-5, (k, it, d)
+		errd = np.abs(b[k] - refd) / np.abs(refd)
+		worst_dev = max(worst_dev, float(errd.max()))
+		assert errd.max() < 1e-5, (k, float(errd.max()))
+		# --- the literal restatement of the reference
 		flipped = 0
 		ref, mask, inter = ob.fit_background_tess(f[k], 1, 1, full=True)
 		for it in range(3):
@@ -169,10 +195,8 @@ def test_fit_background_tess_matches_oracle(ctx, T, R, C):
 			assert ok.sum() >= 30
 			np.testing.assert_allclose(details['zeropoint'][it][k], inter['zeropoint'][it], rtol=1e-6)
 			d = np.abs(s_dev[ok] - s_ref[ok])
-			# first round: float32 log10 (one ulp = 1e-7 moves the ends of the grid); later rounds: the square component is a
-			# float32 image here and float64 in the oracle (1e-5 absolute on values of 1..100 under the logarithm)
 			exact = d < 2e-5
-			print('frame', k, 'round', it, 'rings on the same grid point:', int(exact.sum()), 'of', int(ok.sum()), 'max diff', float(d.max()),
+			print('frame', k, 'round', it, '[literal] rings on the same grid point:', int(exact.sum()), 'of', int(ok.sum()), 'max diff', float(d.max()),
 				'median diff', float(np.median(d)))
 			assert exact.sum() >= ok.sum() - 3, (k, it, d)
 			assert d.max() < 2e-3, (k, it, d.max())
@@ -183,7 +207,35 @@ def test_fit_background_tess_matches_oracle(ctx, T, R, C):
 		# the radial component matters here: without it the corner is off by far more than the tolerance
 		plain = ob.fit_background(f[k])[0]
 		assert np.max(np.abs(plain - ref) / ref) > 0.01
-	print('TESS background: worst relative deviation', worst)
+	print('TESS background: worst relative deviation', worst_dev, '(device arithmetic restated)', worst, '(literal)')
+
+
+def test_fit_background_tess_full_frames(ctx):
+	"""The TESS branch on full 2048 x 2048 frames (the size the reference runs it on: 39 rings of ~10 000 pixels, a 32 x 32 mesh):
+	every ring mode on the oracle's grid point and the background within 1e-5 against the oracle with the device's roundings
+	written out; against the literal oracle the tie allowance of the small-frame test."""
+	from photometry_amd import prepare
+	from oracle import backgrounds as ob
+	T, R, C = 2, 2048, 2048
+	f = _tess_frames(T, R, C, seed=11)
+	details = {}
+	b = prepare.fit_background_frames(ctx, ctx.array(f), camera=1, ccd=1, details=details).to_host()
+	for k in range(T):
+		refd, _, interd = ob.fit_background_tess(f[k], 1, 1, full=True, device_arithmetic=True)
+		for it in range(3):
+			s_dev, s_ref = details['s2'][it][k], interd['s2'][it]
+			assert np.array_equal(np.isnan(s_dev), np.isnan(s_ref)) and np.sum(~np.isnan(s_ref)) >= 30
+			d = np.abs(s_dev - s_ref)[~np.isnan(s_ref)]
+			print('frame', k, 'round', it, 'max ring-mode diff', float(d.max()))
+			assert d.max() < 2e-5, (k, it, d)
+		errd = np.abs(b[k] - refd) / np.abs(refd)
+		print('frame', k, 'max relative background deviation', float(errd.max()))
+		assert errd.max() < 1e-5
+	ref, _, inter = ob.fit_background_tess(f[0], 1, 1, full=True)
+	flipped = sum(int(np.sum(np.abs(details['s2'][it][0] - inter['s2'][it]) >= 2e-5)) for it in range(3))
+	err = np.abs(b[0] - ref) / np.abs(ref)
+	print('literal oracle: rings off their grid point', flipped, 'max relative deviation', float(err.max()))
+	assert flipped <= 9 and err.max() < (2e-3 if flipped else 1e-5)
 
 
 def test_radial_pieces(ctx):
@@ -265,7 +317,9 @@ def test_prepare_pixel_flags_and_headers(ctx):
 	np.testing.assert_array_equal(res_h['backgrounds_pixels_used'].to_host().astype(bool), ref_used)
 	us_t = prepare.fit_background_frames(ctx, ctx.array(f), exclude=flags, camera=1, ccd=4).to_host()
 	for k in (0, 5):
-		ref_bkg, _ = ob.fit_background_tess(f[k], 1, 4, exclude=manexcl[k])
-		np.testing.assert_allclose(us_t[k], ref_bkg, rtol=2e-3)
+		ref_bkg, _ = ob.fit_background_tess(f[k], 1, 4, exclude=manexcl[k], device_arithmetic=True)
+		np.testing.assert_allclose(us_t[k], ref_bkg, rtol=1e-5)
+		ref_lit, _ = ob.fit_background_tess(f[k], 1, 4, exclude=manexcl[k])
+		np.testing.assert_allclose(us_t[k], ref_lit, rtol=2e-3)   # literal float32 log10 of numpy: ties of the KDE argmax may flip
 	smooth = np.moveaxis(ob.smooth_time(np.moveaxis(us_t, 0, -1), 3), -1, 0)
 	np.testing.assert_array_equal(res_h['backgrounds'].to_host(), smooth)

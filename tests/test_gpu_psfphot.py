@@ -4,9 +4,13 @@ GPU parity of the non-linear PSF photometry (``tp_psf_fit``; psf_photometry.py:5
 against the golden vectors produced by the reference's own ``PSFPhotometry.do_photometry`` (real scipy Nelder-Mead).
 
 A Nelder-Mead run is a chain of comparisons of chi^2 values: last-bit differences in the summation order can change single
-steps, after which two runs walk different simplices to the same minimum.  Both stop on the optimiser's own tolerances
-(xatol = fatol = 1e-4), so fluxes are compared at 2e-5 relative and positions at 2e-4 pixels; the number of iterations is
-compared loosely.  The device's own Nelder-Mead is additionally pinned step for step: with the likelihood of a one-star target
+steps, after which two runs walk different simplices to the same minimum.  The minimum itself is pinned far tighter than the
+stopping tolerances suggest (fatol = 1e-4 on chi^2 forces a simplex of ~1e-8): the oracle run with its chi^2 summed in another
+order reproduces its own fluxes to 7e-9 although the iteration counts change (measured), and the device
+agrees with the oracle to 1e-7 and with the reference's golden to 7e-9.  Fluxes are compared at 1e-6 relative (north_star:
+1e-5), positions at 2e-6 pixels; the number of iterations is compared loosely, and a cadence may be finite on one side and
+NaN on the other only when the walk reaches three quarters of its iteration limit on both (psf_photometry.py:190-194: "success" is
+"finished before maxiter", a property of the walk, not of the minimum).  The device's own Nelder-Mead is additionally pinned step for step: with the likelihood of a one-star target
 the iteration counts match scipy's exactly until the first such flip in a target's warm-start chain.
 """
 import os
@@ -14,6 +18,9 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+FLUX_RTOL = 1e-6   # north_star: light-curve flux within 1e-5 relative; measured: <= 1e-7 (oracle), <= 7e-9 (reference golden)
+POS_ATOL = 2e-6    # pixels; measured <= 2e-7
 
 
 @pytest.fixture(scope='module')
@@ -58,8 +65,12 @@ def test_psf_photometry_golden(ctx, golden_dir):
 		g['target_tmag'], g['aperture'])
 	for n in range(int(g['n_psfphot'])):
 		i = int(g[f'pp{n}_target'])
-		np.testing.assert_allclose(res['flux'][i], g[f'pp{n}_flux'], rtol=2e-5)
-		np.testing.assert_allclose(np.column_stack((res['centroid_row'][i], res['centroid_col'][i])), g[f'pp{n}_pos_centroid'], atol=2e-4)
+		ref = g[f'pp{n}_flux']
+		ok = np.isfinite(ref)
+		print('golden target', i, 'max rel flux diff', np.max(np.abs(res['flux'][i][ok] / ref[ok] - 1)), 'max pos diff',
+			np.nanmax(np.abs(np.column_stack((res['centroid_row'][i], res['centroid_col'][i])) - g[f'pp{n}_pos_centroid'])))
+		np.testing.assert_allclose(res['flux'][i], ref, rtol=FLUX_RTOL)
+		np.testing.assert_allclose(np.column_stack((res['centroid_row'][i], res['centroid_col'][i])), g[f'pp{n}_pos_centroid'], atol=POS_ATOL)
 		assert np.all(np.isnan(res['flux_err'][i])) and int(res['status'][i]) == int(g[f'pp{n}_status'])
 
 
@@ -82,14 +93,22 @@ def test_psf_photometry_matches_oracle(ctx):
 		# a run that needs about as many iterations as its limit (500) can finish on one side and not on the other: such a
 		# cadence is NaN on that side only (psf_photometry.py:190-194); compared are the cadences both sides finished
 		ok = ref['success'] & ~np.isnan(res['flux'][i])
-		n_flag_diff += int(np.sum(ref['success'] != ~np.isnan(res['flux'][i])))
+		differ = np.flatnonzero(ref['success'] != ~np.isnan(res['flux'][i]))
+		n_flag_diff += len(differ)
+		for k in differ:
+			# only a fit that runs into its iteration limit on one side may be finite on the other: both walks are long
+			limit = 1500 if k == 0 else 500
+			assert min(int(res['nit'][i][k]), int(ref['nit'][k])) >= 0.75 * limit, (i, k, res['nit'][i][k], ref['nit'][k])
 		print(i, 'nit device', res['nit'][i], 'oracle', ref['nit'], 'success', ref['success'])
-		np.testing.assert_allclose(res['flux'][i][ok], ref['flux'][ok], rtol=2e-5, atol=1e-3)
-		np.testing.assert_allclose(res['centroid_row'][i][ok], ref['pos_centroid'][ok, 0], atol=2e-4)
-		np.testing.assert_allclose(res['centroid_col'][i][ok], ref['pos_centroid'][ok, 1], atol=2e-4)
+		if ok.any():
+			print('   max rel flux diff', np.max(np.abs(res['flux'][i][ok] / ref['flux'][ok] - 1)), 'max pos diff',
+				max(np.max(np.abs(res['centroid_row'][i][ok] - ref['pos_centroid'][ok, 0])), np.max(np.abs(res['centroid_col'][i][ok] - ref['pos_centroid'][ok, 1]))))
+		np.testing.assert_allclose(res['flux'][i][ok], ref['flux'][ok], rtol=FLUX_RTOL)
+		np.testing.assert_allclose(res['centroid_row'][i][ok], ref['pos_centroid'][ok, 0], atol=POS_ATOL)
+		np.testing.assert_allclose(res['centroid_col'][i][ok], ref['pos_centroid'][ok, 1], atol=POS_ATOL)
 		n_same_nit += int(np.sum(res['nit'][i] == ref['nit']))
 		n_cad += T
-	assert n_flag_diff <= 2
+	assert n_flag_diff <= 1
 	# the device walks scipy's simplex: until the first last-bit flip in a target's warm-start chain the iteration counts are scipy's
 	print(f"identical iteration counts on {n_same_nit} of {n_cad} cadences")
 	assert n_same_nit >= n_cad // 4
