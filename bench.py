@@ -65,6 +65,8 @@ def parse_args(argv=None):
 	p.add_argument('--no-extra', action='store_true', help='skip the extra legs (premade cubes, LinPSF, end to end, stages)')
 	p.add_argument('--e2e-targets', type=int, default=2048, help='targets of the end-to-end (H2D included) leg (0 = skip)')
 	p.add_argument('--frame', type=int, default=1024, help='side of the frame stack of the stamp-cutter stage (0 = skip)')
+	p.add_argument('--psf-targets', type=int, default=4096, help='targets of the non-linear PSF photometry leg (0 = skip)')
+	p.add_argument('--fullframe-frames', type=int, default=16, help='2048 x 2048 frames of the full-frame background / pixel-flag leg (0 = skip)')
 	p.add_argument('--frames-targets', type=int, default=2500, help='targets of the frames-to-results leg on a 512 x 512 stack (0 = skip)')
 	return p.parse_args(argv)
 
@@ -552,6 +554,12 @@ def main():
 		result['linpsf'] = leg_linpsf(ctx, scene, cubes, work, args, Nt, T, H, W, np, engine, pipeline)
 		if args.frames_targets > 0 and (T, H) == (1300, 15):
 			result['frames_to_results'] = leg_frames(ctx, args, T, np, pipeline)
+		for k in ('raw', 'images_err'):
+			cubes[k].free()
+		if args.psf_targets > 0:
+			result['psf_fit'] = leg_psf_fit(ctx, args, np, engine)
+		if args.fullframe_frames > 0:
+			result['fit_background_frames'] = leg_fullframe(ctx, args, np)
 
 	if rank == 0:
 		print(json.dumps(result))
@@ -751,13 +759,18 @@ def leg_frames(ctx, args, T, np, pipeline):
 	tessphot_frames(ctx, stack, {k: v[:128] for k, v in targets.items()}, cat, tstamp, quality)
 	t0 = time.perf_counter()
 	out = tessphot_frames(ctx, stack, targets, cat, tstamp, quality)
+	good = int(np.sum((out.status == 1) | (out.status == 3)))
+	resized = int(np.sum(out.stamp_resizes > 0))
 	dt = time.perf_counter() - t0
-	good = sum(1 for b in out if b.status.value in (1, 3))
-	resized = sum(1 for b in out if b._details.get('stamp_resizes', 0) > 0)
-	return {'what': f'tessphot_frames: {N} targets on a {FR} x {FR} x {T} region resident in HBM (three frame stacks) -> per-target results '
-		'(status, details, diagnostics, light curve, mask): stamp cuts, fused pass, stamp-resize rounds and diagnostics on the device, '
-		'default stamps / catalogue selection / result objects on the host (one Python process)',
-		'targets_per_s': N / dt, 'seconds': dt, 'ok_or_warning': good, 'targets_resized': resized}
+	# every per-target object as well (what the list-based entry of round 2 built unconditionally)
+	t1 = time.perf_counter()
+	n_obj = sum(1 for b in out if b.status.value in (1, 3))
+	dobj = time.perf_counter() - t1
+	return {'what': f'tessphot_frames: {N} targets on a {FR} x {FR} x {T} region resident in HBM (three frame stacks) -> columnar results '
+		'(status, stamp, resizes, diagnostics, light curves, masks in arrays; per-target objects on demand): stamp cuts, fused pass, '
+		'stamp-resize rounds and diagnostics on the device, default stamps / catalogue selection / decisions on the host (one Python process)',
+		'targets_per_s': N / dt, 'seconds': dt, 'ok_or_warning': good, 'targets_resized': resized,
+		'with_every_per_target_object': {'targets_per_s': N / (dt + dobj), 'seconds_for_the_objects': dobj, 'ok_or_warning': n_obj}}
 
 
 def leg_linpsf(ctx, scene, cubes, work, args, Nt, T, H, W, np, engine, pipeline):
@@ -831,6 +844,163 @@ def leg_linpsf(ctx, scene, cubes, work, args, Nt, T, H, W, np, engine, pipeline)
 				'reference itself would run about 1.24 x this rate'}
 		res['parity_sample'] = {'targets': ns, 'cadences': tsub, 'mismatches': int(bad), 'rtol': 1e-7}
 	return res
+
+
+def tess_like_frames(np, n, R, C, seed):
+	"""Synthetic full-frame images: smooth gradient + the corner glow the radial component models + noise + stars."""
+	rng = np.random.default_rng(seed)
+	yy, xx = np.mgrid[0:R, 0:C]
+	r = np.hypot(xx + 44 - 31.0, yy - 2047.0)   # distance from the camera centre of (camera 1, CCD 1)-like geometry
+	f = np.empty((n, R, C), dtype='float32')
+	for k in range(n):
+		img = 120 + 0.02 * xx + 40 * np.exp((r - 2400) / 250.0) + rng.normal(0, 4, r.shape)
+		ys, xs = rng.integers(0, R, 400), rng.integers(0, C, 400)
+		img[ys, xs] += rng.uniform(500, 60000, 400)
+		f[k] = img
+	return f
+
+
+def leg_psf_fit(ctx, args, np, engine):
+	"""PSFPhotometry.do_photometry (psf_photometry.py:111-196) for a batch -- per target and cadence a
+	Nelder-Mead fit of (row, column, flux) of up to five stars, warm-started along the cadences (tp_psf_fit)."""
+	from photometry_amd import simulate, psf as hpsf
+	from photometry_amd.device import DeviceCube
+	from photometry_amd.plugins import psf_star_selection, mag2flux
+	Nt, T, H, W = args.psf_targets, 50, 15, 15
+	s = simulate.make_scene(Nt, T, H, W, seed=args.seed * 1000 + 7)
+	simulate.fill_cubes(s, nan_fraction=0.001)
+	prf = simulate.synthetic_prf(seed=1)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	offs, params, mini = [0], [], []
+	for i in range(Nt):
+		c = s.catalog_of(i)
+		sel = psf_star_selection(c['row_stamp'], c['column_stamp'], c['tmag'], s.target_pos_row[i] - s.stamps[i][0], s.target_pos_column[i] - s.stamps[i][2], s.target_tmag[i])
+		params.append(np.column_stack((c['row_stamp'][sel].astype('float64'), c['column_stamp'][sel].astype('float64'), mag2flux(c['tmag'][sel].astype('float64')))))
+		offs.append(offs[-1] + len(sel))
+		# psf_photometry.py:29-41: the pixels within one pixel of the target position (all pixels collected here)
+		jj, ii = np.meshgrid(np.arange(W), np.arange(H))
+		mini.append(((np.abs(jj - (s.target_pos_column[i] - s.stamps[i][2])) <= 1) & (np.abs(ii - (s.target_pos_row[i] - s.stamps[i][0])) <= 1)).astype('uint8'))
+	coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(model.weights(s.stamps)))
+	a = (DeviceCube.from_host(ctx, s.images), DeviceCube.from_host(ctx, s.backgrounds), coef, ctx.array(model.tx), ctx.array(model.ty),
+		ctx.array(np.asarray(offs, dtype='int64')), ctx.array(np.concatenate(params)), ctx.array(np.stack(mini)))
+	engine.psf_fit(ctx, *a)
+	ctx.sync()
+	ctx.profile(True)
+	ctx.profile_reset()
+	t0 = time.perf_counter()
+	res = engine.psf_fit(ctx, *a)
+	ctx.sync()
+	dt = time.perf_counter() - t0
+	ctx.profile(False)
+	kern = ctx.profile_report().get('tp_psf_fit_kernel', (1, dt * 1e3))
+	kms = kern[1] / kern[0]
+	nit = res['nit'].to_host().astype('float64')
+	flux = res['flux'].to_host()
+	nstars = offs[-1] / Nt
+	# executed FP64 work of one simplex iteration (estimate): ~1.6 chi^2 evaluations x stars x 121 pixels of the cached set x
+	# (24 Horner FMAs + ~6 for the weights / residual)
+	fma = float(nit.sum()) * 1.6 * nstars * 121 * 30
+	out = {'what': f'PSFPhotometry.do_photometry for {Nt} targets x {T} cadences x {H}x{W} ({offs[-1]} fitted stars): Nelder-Mead fit of (row, column, flux) '
+		'per star and cadence, warm-started from the previous cadence, aperture correction (psf_photometry.py:111-196)',
+		'kernel': 'tp_psf_fit_kernel', 'kernel_ms': kms, 'wall_ms': dt * 1e3, 'targets_per_s_at_50_cadences': Nt / dt,
+		'targets_per_s_at_1300_cadences': Nt / dt * T / 1300.0, 'mean_simplex_iterations_per_cadence': float(nit.mean()),
+		'ns_per_simplex_iteration_chipwide': kms * 1e6 / max(nit.sum(), 1.0), 'finite_fraction': float(np.mean(np.isfinite(flux))),
+		'roofline': {'kernel': 'tp_psf_fit_kernel', 'bound': 'latency (a serial chain per target: one workgroup walks the simplex of one target; barriers, '
+			'ordering, coefficient rebuilds) -- priced against the FP64 vector peak', 'achieved': 2 * fma / (kms * 1e-3) / 1e12, 'peak': FP64_VALU_TFLOPS,
+			'unit': 'TFLOP/s', 'frac': 2 * fma / (kms * 1e-3) / 1e12 / FP64_VALU_TFLOPS, 'traffic': None,
+			'flops': 'estimate of the executed FP64 FMAs (see bench.py:leg_psf_fit)'}}
+	if args.cpu_sample > 0:
+		from oracle import psf as opsf, psf_photometry as opp
+		ns, tsub = 2, 3
+		t1 = time.perf_counter()
+		bad = 0
+		for i in range(ns):
+			p = opsf.PSF(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'], tuple(s.stamps[i]))
+			ref = opp.do_photometry(s.images[i][:, :, :tsub], s.backgrounds[i][:, :, :tsub], p, s.catalog_of(i), tuple(s.stamps[i]),
+				s.target_pos_row[i], s.target_pos_column[i], s.target_tmag[i], np.ones((H, W), dtype='int32'))
+			ok = ref['success'] & np.isfinite(flux[i][:tsub])
+			bad += int(np.sum(~np.isclose(flux[i][:tsub][ok], ref['flux'][ok], rtol=1e-5, atol=0)))
+		dc = time.perf_counter() - t1
+		out['cpu_baseline'] = {'value': ns / (dc * 1300.0 / tsub), 'unit': 'targets/s', 'cores': 1, 'kind': 'port',
+			'sample': f'{ns} targets x first {tsub} cadences (scipy Nelder-Mead on the FITPACK pixel integral, like the reference), extrapolated linearly to 1300 cadences'}
+		out['parity_sample'] = {'targets': ns, 'cadences': tsub, 'mismatches': bad, 'rtol': 1e-5}
+	return out
+
+
+def leg_fullframe(ctx, args, np):
+	"""backgrounds.fit_background (backgrounds.py:52-211) on full 2048 x 2048 frames, plain and TESS
+	branch, and the "background shenanigans" pixel-flag pass (pixel_flags.py:61-79, prepare.py:515-622)."""
+	from photometry_amd import prepare
+	nf, R, C = args.fullframe_frames, 2048, 2048
+	f = tess_like_frames(np, nf, R, C, args.seed + 3)
+	d = ctx.array(f)
+	geo = prepare.RadialGeometry((R, C), 1, 1)
+	out = {'what': f'{nf} frames of {R} x {C} float32 resident in HBM'}
+	results = {}
+	for name, kw in (('plain', {}), ('tess', dict(geometry=geo))):
+		prepare.fit_background_frames(ctx, d, **kw).free()
+		ctx.sync()
+		ctx.profile(True)
+		ctx.profile_reset()
+		t0 = time.perf_counter()
+		bkg = prepare.fit_background_frames(ctx, d, **kw)
+		ctx.sync()
+		dt = time.perf_counter() - t0
+		ctx.profile(False)
+		rep = ctx.profile_report()
+		kms = sum(ms for _, ms in rep.values())
+		results[name] = bkg.to_host()[0]
+		bkg.free()
+		passes = 1 if name == 'plain' else 3
+		# necessary bytes per frame: the image read once per mesh pass (+ once per ring-mode pass), the background written once
+		nb = R * C * 4 * (passes * (2 if name == 'tess' else 1) + 1)
+		out[name] = {'wall_ms_per_frame': dt / nf * 1e3, 'kernel_ms_per_frame': kms / nf, 'frames_per_s': nf / dt,
+			'kernels_ms_per_frame': {k: ms / nf for k, (_, ms) in rep.items()},
+			'roofline': {'kernel': 'tp_bkg_mesh_kernel + tp_bkg_zoom_kernel' + (' + tp_radial_kernels' if name == 'tess' else ''), 'bound': 'hbm',
+				'achieved': nb / (kms / nf * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': nb / (kms / nf * 1e-3) / 1e9 / HBM_PEAK_GBS,
+				'bytes_per_frame': nb, 'bytes': 'R*C*4 per pass over the image (mesh statistics, ring modes) + the background written once', 'traffic': None}}
+	# shenanigans: indicator (15 x 15 median filter of img - SumImage), its robust mean over time, thresholded flags
+	ns = min(nf, 25)
+	img = ctx.array(f[:ns])
+	sumimage = ctx.array(f[:ns].astype('float64').mean(axis=0))
+	flags = ctx.zeros((ns, R, C), 'uint8')
+	prepare.background_shenanigans(ctx, img, sumimage, flags)
+	ctx.sync()
+	ctx.profile(True)
+	ctx.profile_reset()
+	t0 = time.perf_counter()
+	prepare.background_shenanigans(ctx, img, sumimage, flags)
+	ctx.sync()
+	dt = time.perf_counter() - t0
+	ctx.profile(False)
+	rep = ctx.profile_report()
+	kms = sum(ms for _, ms in rep.values())
+	nb = R * C * (4 + 4 + 1)   # image read, indicator written (and read back for mean and threshold), flags written
+	out['shenanigans'] = {'frames': ns, 'wall_ms_per_frame': dt / ns * 1e3, 'kernel_ms_per_frame': kms / ns,
+		'kernels_ms_per_frame': {k: ms / ns for k, (_, ms) in rep.items()},
+		'roofline': {'kernel': 'tp_median_filter_kernel', 'bound': 'vector ALU (a 225-key sorting network per pixel), priced against HBM',
+			'achieved': nb / (kms / ns * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': nb / (kms / ns * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None}}
+	if args.cpu_sample > 0:
+		from oracle import backgrounds as ob
+		t1 = time.perf_counter()
+		ref_plain = ob.fit_background(f[0])[0]
+		t2 = time.perf_counter()
+		ref_tess = ob.fit_background_tess(f[0], 1, 1, device_arithmetic=True)[0]
+		t3 = time.perf_counter()
+		sub = 512
+		ob.pixel_background_shenanigans(f[0][:sub, :sub], f[:ns, :sub, :sub].astype('float64').mean(axis=0))
+		t4 = time.perf_counter()
+		out['plain']['cpu_baseline'] = {'value': 1.0 / (t2 - t1), 'unit': 'frames/s', 'cores': 1, 'kind': 'port', 'sample': 'one 2048 x 2048 frame'}
+		out['tess']['cpu_baseline'] = {'value': 1.0 / (t3 - t2), 'unit': 'frames/s', 'cores': 1, 'kind': 'port', 'sample': 'one 2048 x 2048 frame, three rounds'}
+		out['shenanigans']['cpu_baseline'] = {'value': 1.0 / ((t4 - t3) * (R * C) / (sub * sub)), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+			'sample': f'the indicator image (scipy.ndimage.median_filter, size 15) of a {sub} x {sub} corner of one frame, scaled to 2048 x 2048'}
+		with np.errstate(invalid='ignore', divide='ignore'):
+			out['parity_sample'] = {'frames': 1, 'plain_max_rel_err': float(np.nanmax(np.abs(results['plain'] / ref_plain - 1))),
+				'tess_max_rel_err': float(np.nanmax(np.abs(results['tess'] / ref_tess - 1))),
+				'what': 'device background of frame 0 against the oracle (TESS branch: the oracle with the device\'s roundings written out)'}
+	for a in (d, img, sumimage, flags):
+		a.free()
+	return out
 
 
 if __name__ == '__main__':

@@ -118,6 +118,9 @@ int tp_ctx_destroy(tp_ctx* ctx) {
 	if (ctx->twiddle) (void)hipFree(ctx->twiddle);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
 	if (ctx->store) (void)hipFree(ctx->store);
+	for (auto& kv : ctx->cache) (void)hipFree(kv.second);
+	ctx->cache.clear();
+	if (ctx->stage) (void)hipHostFree(ctx->stage);
 	for (int k = 0; k < TPK_COUNT; k++)
 		for (auto& p : ctx->pending[k]) {
 			(void)hipEventDestroy(p.first);
@@ -149,20 +152,60 @@ int tp_device_info(tp_ctx* ctx, char* name, int name_len, int32_t* n_cu, uint64_
 	return TP_OK;
 }
 
+// capacity classes of the allocation cache: 256-byte multiples up to 64 KiB, then steps of 1/8 of the power of two below
+static size_t tp_alloc_class(size_t n) {
+	if (n <= 65536) return (n + 255) & ~(size_t)255;
+	size_t p = 65536;
+	while (p * 2 <= n) p *= 2;
+	const size_t step = p / 8;
+	return (n + step - 1) / step * step;
+}
+
 int tp_malloc(tp_ctx* ctx, uint64_t nbytes, void** d_ptr) {
 	TP_CHECK_CTX(ctx);
 	TP_REQUIRE(ctx, d_ptr != nullptr, "tp_malloc: null output pointer");
 	*d_ptr = nullptr;
 	if (nbytes == 0) nbytes = 16;
-	hipError_t e = hipMalloc(d_ptr, (size_t)nbytes);
+	const size_t cap = tp_alloc_class((size_t)nbytes);
+	auto it = ctx->cache.find(cap);
+	if (it != ctx->cache.end()) {
+		*d_ptr = it->second;
+		ctx->cache.erase(it);
+		ctx->cache_bytes -= cap;
+		ctx->live[*d_ptr] = cap;
+		return TP_OK;
+	}
+	hipError_t e = hipMalloc(d_ptr, cap);
+	if (e == hipErrorOutOfMemory && !ctx->cache.empty()) {
+		// give the cached blocks back to the driver and try once more
+		(void)hipStreamSynchronize(ctx->stream);
+		for (auto& kv : ctx->cache) (void)hipFree(kv.second);
+		ctx->cache.clear();
+		ctx->cache_bytes = 0;
+		(void)hipGetLastError();
+		e = hipMalloc(d_ptr, cap);
+	}
 	if (e == hipErrorOutOfMemory) return ctx->fail(TP_ERR_NOMEM, "tp_malloc: out of device memory");
 	if (e != hipSuccess) return ctx->fail(TP_ERR_HIP, "hipMalloc", e);
+	ctx->live[*d_ptr] = cap;
 	return TP_OK;
 }
 
 int tp_free(tp_ctx* ctx, void* d_ptr) {
 	TP_CHECK_CTX(ctx);
 	if (!d_ptr) return TP_OK;
+	auto it = ctx->live.find(d_ptr);
+	if (it != ctx->live.end()) {
+		const size_t cap = it->second;
+		ctx->live.erase(it);
+		if (cap <= ((size_t)1 << 30) && ctx->cache_bytes + cap <= ctx->cache_limit) {
+			// kept for the next tp_malloc of this capacity; whatever is queued on the stream for the block runs before any
+			// later use of it (one in-order stream per context)
+			ctx->cache.emplace(cap, d_ptr);
+			ctx->cache_bytes += cap;
+			return TP_OK;
+		}
+	}
 	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	TP_HIP(ctx, hipFree(d_ptr));
 	return TP_OK;
@@ -176,13 +219,46 @@ int tp_memset(tp_ctx* ctx, void* d_ptr, int value, uint64_t nbytes) {
 	return TP_OK;
 }
 
+// the pinned staging area of the synchronous copies (two halves of 16 MiB: one is being filled / drained by the host while the
+// other is in flight)
+static int tp_stage(tp_ctx* ctx) {
+	constexpr size_t kStage = (size_t)32 << 20;
+	if (!ctx->stage) {
+		TP_HIP(ctx, hipHostMalloc(&ctx->stage, kStage, hipHostMallocDefault));
+		ctx->stage_bytes = kStage;
+	}
+	return TP_OK;
+}
+
 int tp_memcpy_h2d(tp_ctx* ctx, void* d_dst, const void* h_src, uint64_t nbytes) {
 	TP_CHECK_CTX(ctx);
 	if (nbytes == 0) return TP_OK;
 	TP_REQUIRE(ctx, d_dst && h_src, "tp_memcpy_h2d: null pointer");
-	// pageable host memory: the async copy is staged, the call returns once h_src is consumed
-	TP_HIP(ctx, hipMemcpyAsync(d_dst, h_src, (size_t)nbytes, hipMemcpyHostToDevice, ctx->stream));
-	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	// pageable host memory goes through the pinned staging area in pieces: the host copy of piece i + 1 overlaps the DMA of
+	// piece i, and the call returns once h_src is consumed (the last DMA may still be in flight: it is ordered on the stream)
+	int rc = tp_stage(ctx);
+	if (rc != TP_OK) return rc;
+	const size_t half = ctx->stage_bytes / 2;
+	hipEvent_t ev[2] = {ctx->get_event(), ctx->get_event()};
+	bool used[2] = {false, false};
+	size_t off = 0;
+	int b = 0;
+	while (off < nbytes) {
+		const size_t n = ((size_t)nbytes - off < half) ? ((size_t)nbytes - off) : half;
+		char* buf = static_cast<char*>(ctx->stage) + b * half;
+		if (used[b]) TP_HIP(ctx, hipEventSynchronize(ev[b]));
+		memcpy(buf, static_cast<const char*>(h_src) + off, n);
+		TP_HIP(ctx, hipMemcpyAsync(static_cast<char*>(d_dst) + off, buf, n, hipMemcpyHostToDevice, ctx->stream));
+		TP_HIP(ctx, hipEventRecord(ev[b], ctx->stream));
+		used[b] = true;
+		off += n;
+		b ^= 1;
+	}
+	// the staging halves are reused by the next call: wait for the DMAs that read them (not for the rest of the stream's
+	// work ahead of them -- events, not a stream synchronisation, would be enough, but the copies ARE the tail of the stream)
+	for (int i = 0; i < 2; i++) if (used[i]) TP_HIP(ctx, hipEventSynchronize(ev[i]));
+	ctx->pool.push_back(ev[0]);
+	ctx->pool.push_back(ev[1]);
 	return TP_OK;
 }
 
@@ -190,8 +266,31 @@ int tp_memcpy_d2h(tp_ctx* ctx, void* h_dst, const void* d_src, uint64_t nbytes) 
 	TP_CHECK_CTX(ctx);
 	if (nbytes == 0) return TP_OK;
 	TP_REQUIRE(ctx, h_dst && d_src, "tp_memcpy_d2h: null pointer");
-	TP_HIP(ctx, hipMemcpyAsync(h_dst, d_src, (size_t)nbytes, hipMemcpyDeviceToHost, ctx->stream));
-	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	int rc = tp_stage(ctx);
+	if (rc != TP_OK) return rc;
+	const size_t half = ctx->stage_bytes / 2;
+	hipEvent_t ev[2] = {ctx->get_event(), ctx->get_event()};
+	// piece i + 1 is on its way into one half of the pinned area while the host copies piece i out of the other
+	size_t issued = 0, drained = 0;
+	size_t len[2] = {0, 0};
+	int bi = 0, bd = 0;
+	while (drained < nbytes) {
+		while (issued < nbytes && len[bi] == 0) {
+			const size_t n = ((size_t)nbytes - issued < half) ? ((size_t)nbytes - issued) : half;
+			TP_HIP(ctx, hipMemcpyAsync(static_cast<char*>(ctx->stage) + bi * half, static_cast<const char*>(d_src) + issued, n, hipMemcpyDeviceToHost, ctx->stream));
+			TP_HIP(ctx, hipEventRecord(ev[bi], ctx->stream));
+			len[bi] = n;
+			issued += n;
+			bi ^= 1;
+		}
+		TP_HIP(ctx, hipEventSynchronize(ev[bd]));
+		memcpy(static_cast<char*>(h_dst) + drained, static_cast<char*>(ctx->stage) + bd * half, len[bd]);
+		drained += len[bd];
+		len[bd] = 0;
+		bd ^= 1;
+	}
+	ctx->pool.push_back(ev[0]);
+	ctx->pool.push_back(ev[1]);
 	return TP_OK;
 }
 

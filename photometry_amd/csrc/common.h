@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <utility>
+#include <map>
 #include "../../include/tessphot_hip.h"
 
 // Dense kernel ids for the per-kernel profile (tp_kernel_name / tp_profile_get).
@@ -54,6 +55,14 @@ struct tp_ctx {
 	size_t scratch_bytes = 0;
 	void* store = nullptr;      // second grow-only buffer: the polynomial coefficient store of tp_linpsf_fit
 	size_t store_bytes = 0;
+	// tp_malloc / tp_free: blocks a caller frees go to a size-keyed cache instead of back to the driver (hipFree synchronises the
+	// whole device, hipMalloc costs tens of microseconds); reuse is ordered by the context's stream.  Bounded by cache_limit.
+	std::multimap<size_t, void*> cache;
+	std::map<void*, size_t> live;   // blocks handed out by tp_malloc -> capacity
+	size_t cache_bytes = 0, cache_limit = (size_t)8 << 30;
+	// pinned staging area of the synchronous copy entries (tp_memcpy_h2d / _d2h): pageable transfers go through it in pieces
+	void* stage = nullptr;
+	size_t stage_bytes = 0;
 	int linpsf_path = 0;        // tp_linpsf_set_path: 0 = vector-ALU fit kernels, 1 = matrix-core fit where a target qualifies
 	void* comm = nullptr;       // ncclComm_t (comm.cpp)
 	int comm_rank = 0, comm_size = 1;

@@ -372,6 +372,72 @@ class _GroupScene(object):
 		self.aperture = None
 
 
+class FramesResult(object):
+	"""
+	Columnar result of :func:`aperture_frames`: one entry per target in arrays (``status``, ``stamp``, ``stamp_resizes``, ``has_result``),
+	the rare per-target extras (log messages, ``edge_flux``) in sparse dicts, and the arrays the device passes returned kept group by
+	group (a group = the targets of one pass that share a stamp size): target ``i`` is row ``pos[i]`` of group ``group[i]``.  Nothing is
+	allocated per target until a per-target view is asked for: ``result[i]`` builds the dict the list-based API used to return.
+	"""
+
+	def __init__(self, n):
+		self.n = int(n)
+		self.status = np.zeros(n, dtype='int32')
+		self.stamp = np.full((n, 4), -1, dtype='int64')
+		self.stamp_resizes = np.zeros(n, dtype='int32')
+		self.has_result = np.zeros(n, dtype=bool)
+		self.group = np.full(n, -1, dtype='int32')
+		self.pos = np.zeros(n, dtype='int32')
+		self.errors = {}       # target -> list of "LEVEL: message" strings (targets without messages have no entry)
+		self.edge_flux = {}    # target -> flux on the stuck edges (haloswitch quick break)
+		self.groups = []       # per device pass: dict of host arrays
+
+	def __len__(self):
+		return self.n
+
+	def column(self, name, fill=np.nan):
+		"""A per-target column gathered from the groups (``contamination``, ``mask_size``, or a ``DIAGNOSTICS_COLUMNS`` name)."""
+		out = np.full(self.n, fill, dtype='float64')
+		for g, grp in enumerate(self.groups):
+			sel = np.flatnonzero(self.has_result & (self.group == g))
+			if len(sel) == 0:
+				continue
+			rows = self.pos[sel]
+			if name == 'contamination':
+				out[sel] = grp['contamination'][rows]
+			elif name == 'mask_size':
+				out[sel] = grp['mask'][rows].reshape(len(rows), -1).sum(axis=1)
+			else:
+				out[sel] = grp['diagnostics'][rows, engine.DIAGNOSTICS_COLUMNS.index(name)]
+		return out
+
+	def __getitem__(self, i):
+		i = int(i)
+		if i < 0:
+			i += self.n
+		if not 0 <= i < self.n:
+			raise IndexError(i)
+		d = {'status': int(self.status[i]), 'errors': list(self.errors.get(i, ())), 'stamp_resizes': int(self.stamp_resizes[i])}
+		if self.stamp[i, 1] >= 0:
+			d['stamp'] = tuple(int(v) for v in self.stamp[i])
+		if i in self.edge_flux:
+			d['edge_flux'] = self.edge_flux[i]
+		if self.has_result[i]:
+			grp, j = self.groups[self.group[i]], int(self.pos[i])
+			a, b = grp['cat_offsets'][j], grp['cat_offsets'][j + 1]
+			inside = grp['cat_in_mask'][a:b].astype(bool)
+			lc = grp['lc']   # the light-curve block (5, m, T): flux, flux_err, flux_background, centroid column, centroid row
+			d.update(mask=grp['mask'][j].astype(bool), sumimage=grp['sumimage'][j], flux=lc[0][j], flux_err=lc[1][j],
+				flux_background=lc[2][j], pos_centroid=np.stack((lc[3][j], lc[4][j]), axis=-1),   # (T, 2): column then row (BasePhotometry.py:428)
+				contamination=float(grp['contamination'][j]),
+				skip_targets=[int(s) for s in grp['cat_starid'][a:b][inside] if s != grp['target_starid'][j]],
+				diagnostics=dict(zip(engine.DIAGNOSTICS_COLUMNS, grp['diagnostics'][j])))
+		return d
+
+	def __iter__(self):
+		return (self[i] for i in range(self.n))
+
+
 def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, cadence_s=1800, datasource='ffi'):
 	"""
 	``AperturePhotometry.do_photometry`` INCLUDING its stamp-resize loop (photometry.py:75-170) for every target of a CCD region
@@ -381,9 +447,11 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 	gives up ("Too many stamp resizes." / "Stamp resize hit limit. Haloswitch quick break.").
 
 	``targets``: dict of arrays ``starid, tmag, row, column`` (CCD positions, float64); ``catalog``: the same columns for every
-	star of the region.  Returns one dict per target (``status, stamp, stamp_resizes, errors`` and, unless it ended in an
-	error before the extraction, ``mask, sumimage, flux, flux_err, flux_background, pos_centroid, contamination,
-	skip_targets, diagnostics``).
+	star of the region.  Returns a :class:`FramesResult` (columnar; ``result[i]`` is the per-target dict: ``status, stamp,
+	stamp_resizes, errors`` and, unless the target ended in an error before the extraction, ``mask, sumimage, flux, flux_err,
+	flux_background, pos_centroid, contamination, skip_targets, diagnostics``).  The common case -- the mask does not touch an
+	edge and nothing is logged -- is decided for a whole group with array operations; only the targets that resize, warn or fail
+	take the per-target path.
 	"""
 	from . import stamps as st
 	from .plugins import load_settings, mag2flux, mask_outcome
@@ -395,30 +463,44 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 	catalog = {k: np.asarray(v) for k, v in catalog.items()}
 	time = np.asarray(time, dtype='float64')
 	quality = np.asarray(quality, dtype='int32')
-	out = [{'status': 0, 'errors': [], 'stamp_resizes': 0} for _ in range(n)]
-	log = [_Messages() for _ in range(n)]
+	tmags = np.asarray(targets['tmag'], dtype='float64')
+	out = FramesResult(n)
+	log = {}
+	def logger_of(i):
+		if i not in log:
+			log[i] = _Messages()
+		return log[i]
 	first, valid = st.default_stamps(targets['row'], targets['column'], targets['tmag'], stack.limits)
-	cur = [tuple(s) if ok else None for s, ok in zip(first.tolist(), valid.tolist())]
+	cur = np.asarray(first, dtype='int64').copy()
 	for i in np.flatnonzero(~valid): # BasePhotometry.py:671-672: the constructor raises -> STATUS.ERROR through tessphot
-		out[i].update(status=2, errors=['ValueError: Invalid stamp selected'])
+		out.status[i] = 2
+		out.errors[int(i)] = ['ValueError: Invalid stamp selected']
+		out.stamp[i] = (-1, -2, -1, -2)
 	cat_index = _CatalogIndex(catalog)
-	attempts_left = [st.retry_limit(targets['tmag'][i]) for i in range(n)]
-	active = [i for i in range(n) if cur[i] is not None]
+	attempts_left = np.where(tmags < 6, 10, 5).astype('int64')   # photometry.py:70-73 (stamps.retry_limit)
+	active = np.flatnonzero(valid)
+	edge_bits = sum(bit for _name, bit, _idx, _sign in st.SIDES)
 
 	def finish(i, status):
-		out[i]['status'] = int(status)
-		out[i]['stamp'] = cur[i]
-		out[i]['errors'] = out[i]['errors'] + log[i].items
+		out.status[i] = int(status)
+		out.stamp[i] = cur[i]
+		if i in log and log[i].items:
+			out.errors[i] = out.errors.get(i, []) + log[i].items
+			log[i].items = []
 
-	while active:
-		groups = {}
-		for i in active:
-			groups.setdefault((cur[i][1] - cur[i][0], cur[i][3] - cur[i][2]), []).append(i)
+	while len(active):
+		heights, widths = cur[active, 1] - cur[active, 0], cur[active, 3] - cur[active, 2]
+		keys = heights * 100000 + widths
 		still = []
-		for (H, W), idx in sorted(groups.items()):
-			cat_offsets, cat_arrays = _catalogs_of_stamps(cat_index, [cur[i] for i in idx])
-			scene = _GroupScene(stack, time, quality, cadence_s, [cur[i] for i in idx], cat_offsets, cat_arrays, targets, np.asarray(idx))
+		for key in np.unique(keys):
+			idx = active[keys == key]
+			H, W = int(key // 100000), int(key % 100000)
+			cat_offsets, cat_arrays = _catalogs_of_stamps(cat_index, cur[idx])
+			scene = _GroupScene(stack, time, quality, cadence_s, cur[idx], cat_offsets, cat_arrays, targets, idx)
+			cubes = None
 			try:
+				if H * W > 65535:
+					raise TessphotError(1, f'a {H}x{W} stamp is beyond the 65 535 pixels of the mask builder')
 				cubes = stack.cut(ctx.array(scene.stamps), H, W)
 				batch = ApertureBatch(ctx, scene, cubes=cubes)
 				work = ApertureWork(ctx, batch)
@@ -428,56 +510,70 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 			except TessphotError as e:
 				# e.g. a stamp beyond 65 535 pixels (the mask builder's 16-bit labels): Halo territory upstream
 				for i in idx:
-					log[i].error('Device pass failed for a %dx%d stamp: %s', H, W, str(e))
-					finish(i, 2)
+					logger_of(int(i)).error('Device pass failed for a %dx%d stamp: %s', H, W, str(e))
+					finish(int(i), 2)
 				continue
+			finally:
+				if cubes is not None:
+					try:
+						ctx.sync()
+					finally:
+						for c in cubes.values():
+							c.free()
 			res = {k: getattr(work, k).to_host() for k in ('sumimage', 'mask', 'status', 'flags', 'contamination', 'cat_in_mask', 'diagnostics')}
-			lc = work.lc.to_host()
-			for c in cubes.values():
-				c.free()
-			for j, i in enumerate(idx):
-				attempts_left[i] -= 1
-				flags = int(res['flags'][j])
+			grp = dict(res, lc=work.lc.block.to_host(), cat_offsets=cat_offsets, cat_starid=cat_arrays['starid'], target_starid=scene.target_starid)
+			gid = len(out.groups)
+			out.groups.append(grp)
+			attempts_left[idx] -= 1
+			flags = res['flags'].astype('int64')
+			kind = flags >> 8
+			# ---- the common case, for the whole group at once: nothing to log, no edge touched -> the attempt stands
+			simple = ((flags & (1 | 32 | edge_bits)) == 0) & (kind == 0)
+			done = idx[simple]
+			out.status[done] = res['status'][simple]
+			out.stamp[done] = cur[done]
+			out.has_result[done] = True
+			out.group[done] = gid
+			out.pos[done] = np.flatnonzero(simple)
+			# ---- the others, one by one with the plugin's rules
+			for j in np.flatnonzero(~simple):
+				i = int(idx[j])
+				fl = int(flags[j])
 				try:
-					if mask_outcome(flags, log[i]) == 'error':
+					if mask_outcome(fl, logger_of(i)) == 'error':
 						finish(i, 2)
 						continue
 				except RuntimeError as e: # an uncaught exception of the reference's plugin -> STATUS.ERROR (tessphot.py:37-49)
-					out[i]['errors'].append('RuntimeError: ' + str(e))
+					out.errors[i] = out.errors.get(i, []) + ['RuntimeError: ' + str(e)]
 					finish(i, 2)
 					continue
-				mask = res['mask'][j].astype(bool)
-				wanted = st.edge_requests(flags)
+				wanted = st.edge_requests(fl)
 				if wanted:
-					new = st.moved(cur[i], stack.limits, **wanted)
-					if new == cur[i]:
-						log[i].warning("Could not resize stamp any further.")
+					before = tuple(int(v) for v in cur[i])
+					new = st.moved(before, stack.limits, **wanted)
+					if new == before:
+						logger_of(i).warning("Could not resize stamp any further.")
 					else:
-						out[i]['stamp_resizes'] += 1
-						before, cur[i] = cur[i], new
-						bright = targets['tmag'][i] <= tmag_limit and not datasource.startswith('tpf:')
+						out.stamp_resizes[i] += 1
+						cur[i] = new
+						mask = res['mask'][j].astype(bool)
+						bright = tmags[i] <= tmag_limit and not datasource.startswith('tpf:')
 						stuck = st.quick_break_flux(res['sumimage'][j], mask, before, new, wanted) if bright else None
-						if stuck is not None and stuck > flux_limit * mag2flux(targets['tmag'][i]):
-							log[i].error('Stamp resize hit limit. Haloswitch quick break.')
-							out[i]['edge_flux'] = stuck
+						if stuck is not None and stuck > flux_limit * mag2flux(tmags[i]):
+							logger_of(i).error('Stamp resize hit limit. Haloswitch quick break.')
+							out.edge_flux[i] = stuck
 							finish(i, 2)
 						elif attempts_left[i] == 0:
-							log[i].error('Too many stamp resizes.')
+							logger_of(i).error('Too many stamp resizes.')
 							finish(i, 2)
 						else:
 							still.append(i)
 						continue
 				# this attempt stands
-				a, b = scene.cat_offsets[j], scene.cat_offsets[j + 1]
-				inside = res['cat_in_mask'][a:b].astype(bool)
-				status = int(res['status'][j])
-				if flags >> 8 == 6:
-					log[i].error("No targets in mask.")
-				out[i].update(mask=mask, sumimage=res['sumimage'][j], flux=lc['flux'][j], flux_err=lc['flux_err'][j],
-					flux_background=lc['flux_background'][j], pos_centroid=lc['pos_centroid'][j],
-					contamination=float(res['contamination'][j]),
-					skip_targets=[int(s) for s in cat_arrays['starid'][a:b][inside] if s != targets['starid'][i]],
-					diagnostics=dict(zip(engine.DIAGNOSTICS_COLUMNS, res['diagnostics'][j])))
-				finish(i, status)
-		active = still
+				if fl >> 8 == 6:
+					logger_of(i).error("No targets in mask.")
+				out.has_result[i] = True
+				out.group[i], out.pos[i] = gid, j
+				finish(i, int(res['status'][j]))
+		active = np.asarray(sorted(still), dtype='int64')
 	return out

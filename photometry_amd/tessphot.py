@@ -139,19 +139,50 @@ def _diagnostics_into(details, d, status):
 	details['pos_centroid'] = np.array([d['pos_centroid_col'], d['pos_centroid_row']])
 	if problems & 8:
 		details.setdefault('errors', []).append('WARNING: Could not detrend lightcurve for variability calculation.')
+	if problems & 16:
+		# the device's hourly binning gave up (unsorted or extremely sparse time axis): rms_hour is NaN -- say so
+		details.setdefault('errors', []).append('WARNING: rms_hour not computed: the time axis could not be binned on the device.')
 	return status
 
 
-def tessphot_frames(ctx, stack, targets, catalog, time, quality, settings=None, cadence_s=1800):
+class BatchResults(object):
 	"""
-	Aperture photometry of every target of a CCD region resident in HBM (:class:`photometry_amd.pipeline.FrameStack`), stamp
-	resizes included: what ``tessphot('aperture', ...)`` returns per target, for the whole batch in a few device passes.
-	Returns one :class:`BatchResult` per target, in order.
+	What :func:`tessphot_frames` returns: the results of a whole batch in columns (``status`` int32 with the reference's STATUS
+	integers -- what ``todolist.status`` stores, taskmanager.py:538-541 --, ``starid``, ``stamp``, ``stamp_resizes`` and, through
+	:meth:`column`, ``mask_size`` / ``contamination`` / the diagnostics), and the per-target objects a scheduler's ``save_result``
+	takes only when asked for: ``results[i]`` (or iteration) builds the :class:`BatchResult` of target ``i``.
 	"""
-	from . import pipeline
-	res = pipeline.aperture_frames(ctx, stack, targets, catalog, time, quality, settings=settings, cadence_s=cadence_s)
-	out = []
-	for i, r in enumerate(res):
+
+	def __init__(self, frames_result, starid):
+		self.frames = frames_result
+		self.starid = np.asarray(starid, dtype='int64')
+		fr = frames_result
+		status = fr.status.copy()
+		# BasePhotometry.photometry (BasePhotometry.py:1343-1407): the diagnostics' ValueErrors turn OK / WARNING into ERROR
+		self._problems = np.zeros(len(fr), dtype='int64')
+		sel = np.flatnonzero(fr.has_result & ((status == STATUS.OK.value) | (status == STATUS.WARNING.value)))
+		if len(sel):
+			self._problems[sel] = fr.column('flags', fill=0)[sel].astype('int64')
+			status[sel[(self._problems[sel] & 7) != 0]] = STATUS.ERROR.value
+		self.status = status
+
+	def __len__(self):
+		return len(self.frames)
+
+	def column(self, name):
+		"""Per-target float64 column: ``mask_size``, ``contamination`` or one of ``engine.DIAGNOSTICS_COLUMNS``; NaN without a result."""
+		return self.frames.column(name)
+
+	@property
+	def stamp(self):
+		return self.frames.stamp
+
+	@property
+	def stamp_resizes(self):
+		return self.frames.stamp_resizes
+
+	def __getitem__(self, i):
+		r = self.frames[i]
 		status = STATUS(r['status'])
 		details = {'stamp': r.get('stamp'), 'stamp_resizes': r['stamp_resizes']}
 		if r['errors']:
@@ -169,8 +200,21 @@ def tessphot_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 			lc = {k: r[k] for k in ('flux', 'flux_err', 'flux_background', 'pos_centroid')}
 			if status in (STATUS.OK, STATUS.WARNING):
 				status = _diagnostics_into(details, r['diagnostics'], status)
-		out.append(BatchResult(int(targets['starid'][i]), status, 'aperture', details, lc, mask))
-	return out
+		return BatchResult(int(self.starid[int(i)]), status, 'aperture', details, lc, mask)
+
+	def __iter__(self):
+		return (self[i] for i in range(len(self)))
+
+
+def tessphot_frames(ctx, stack, targets, catalog, time, quality, settings=None, cadence_s=1800):
+	"""
+	Aperture photometry of every target of a CCD region resident in HBM (:class:`photometry_amd.pipeline.FrameStack`), stamp
+	resizes included: what ``tessphot('aperture', ...)`` returns per target, for the whole batch in a few device passes.
+	Returns a :class:`BatchResults`: columns for the whole batch, one :class:`BatchResult` per target on demand (``results[i]``).
+	"""
+	from . import pipeline
+	res = pipeline.aperture_frames(ctx, stack, targets, catalog, time, quality, settings=settings, cadence_s=cadence_s)
+	return BatchResults(res, targets['starid'])
 
 
 def tessphot_batch(ctx, scene, cubes='host'):
