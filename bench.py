@@ -473,7 +473,7 @@ def main():
 		}
 		rows = kernel_rows(prof, Nt, alg, necessary)
 		traffic = None
-		tfile = os.path.join(ROOT, 'profiles', 'r2_traffic.json')
+		tfile = os.path.join(ROOT, 'profiles', 'r3_traffic.json')
 		if os.path.exists(tfile) and (Nt, T, H) == (10000, 1300, 15):
 			traffic = json.load(open(tfile)).get('traffic_bytes_per_launch')
 		hbm_kernels = [k for k in rows if k in necessary and k != 'tp_bkg_smooth_kernel']
@@ -595,7 +595,7 @@ def leg_premade(ctx, scene, cubes, args, Nt, T, H, W, np, engine, pipeline):
 	necessary = {'tp_aperture_fused_kernel': Nt * (P*T*4 + T*4 + P*8) + 3 * n_mask * T * 4 + Nt * (P + 5*T*8)}
 	alg = {'tp_aperture_fused_kernel': (P*T*4 + T*4 + P*8) + (3*P*T*4 + P + 5*T*8)}
 	rows = kernel_rows(prof, Nt, alg, necessary)
-	tfile = os.path.join(ROOT, 'profiles', 'r2_traffic.json')
+	tfile = os.path.join(ROOT, 'profiles', 'r3_traffic.json')
 	traffic = json.load(open(tfile)).get('traffic_bytes_per_launch_premade') if os.path.exists(tfile) and (Nt, T, H) == (10000, 1300, 15) else None
 	# three stand-alone kernels (A1, K2P2, A6), per-stage durations when a stage owns the GPU
 	pipeline.aperture_step(ctx, batch, work, fused=False)
@@ -773,6 +773,14 @@ def leg_frames(ctx, args, T, np, pipeline):
 		'with_every_per_target_object': {'targets_per_s': N / (dt + dobj), 'seconds_for_the_objects': dobj, 'ok_or_warning': n_obj}}
 
 
+def linpsf_traffic(Nt, T, H):
+	"""HBM bytes per step of the LinPSF fit from the committed PMC passes (profiles/r3_traffic.json), for the default size only."""
+	tfile = os.path.join(ROOT, 'profiles', 'r3_traffic.json')
+	if os.path.exists(tfile) and (Nt, T, H) == (10000, 1300, 15):
+		return json.load(open(tfile)).get('traffic_bytes_per_launch', {}).get('tp_linpsf_fit')
+	return None
+
+
 def leg_linpsf(ctx, scene, cubes, work, args, Nt, T, H, W, np, engine, pipeline):
 	"""BASELINE configs[3]: linpsf_photometry PSF-fit path over the same cube (raw cube + on-the-fly background subtraction)."""
 	from photometry_amd import simulate, psf as hpsf
@@ -812,7 +820,7 @@ def leg_linpsf(ctx, scene, cubes, work, args, Nt, T, H, W, np, engine, pipeline)
 			'achieved': flops / (fit_ms * 1e-3) / 1e12, 'peak': FP64_VALU_TFLOPS, 'unit': 'TFLOP/s', 'frac': flops / (fit_ms * 1e-3) / 1e12 / FP64_VALU_TFLOPS,
 			'flops': 'executed FP64 flops of the polynomial path (estimate, see bench.py:leg_linpsf)', 'kernel_ms_per_step': fit_ms,
 			'hbm': {'necessary_bytes_per_step': nbytes, 'GBps': nbytes / (fit_ms * 1e-3) / 1e9, 'frac_of_hbm_peak': nbytes / (fit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-			'traffic': None},
+			'traffic': linpsf_traffic(Nt, T, H)},
 		'kernels': kernels,
 	}
 	if args.cpu_sample > 0:

@@ -399,6 +399,20 @@ def pixel_background_shenanigans(img, SumImage=None):
 	return median_filter(flux0, size=15)
 
 
+def shenanigans_block_frames(indicies, k, block=25):
+	"""
+	The frames whose median makes up the block that starts at position ``k`` of the shuffled list (prepare.py:562-571).  The
+	reference fills ONE ``(R, C, block)`` buffer block after block and takes ``nanmedian`` over ALL its slots: a short last block
+	overwrites only its first ``L`` slots, the others still hold frames ``L .. block-1`` of the previous block -- they take part.
+	(With fewer than ``block`` frames in total the untouched slots are uninitialised memory upstream: undefined; here they are
+	left out.)  Pinned by ``tests/golden/golden_shenanigans.npz`` (those statements executed).
+	"""
+	own = list(indicies[k:k + block])
+	if len(own) < block and k >= block:
+		own += list(indicies[k - block + len(own):k])
+	return own
+
+
 def background_shenanigans_flags(images, SumImage, pixel_flags, bkgshe_threshold=40, block=25, flag=4):
 	"""
 	prepare.py:515-622 on in-memory arrays: ``images`` float32 ``(T, R, C)``, ``pixel_flags`` integer ``(T, R, C)`` (a
@@ -414,9 +428,7 @@ def background_shenanigans_flags(images, SumImage, pixel_flags, bkgshe_threshold
 	np.random.seed(0)
 	np.random.shuffle(indicies)
 	for k in range(0, numfiles, block):
-		# (the reference reuses one (R, C, 25) float64 buffer; a short last block would see stale frames of the previous block
-		# there -- prepare.py:562-571 -- which is why numfiles is a multiple of 25 in the tests: the intended result)
-		blockdata = np.stack([pixel_flags_ind[:, :, i].astype('float64') for i in indicies[k:k+block]], axis=2)
+		blockdata = np.stack([pixel_flags_ind[:, :, i].astype('float64') for i in shenanigans_block_frames(indicies, k, block)], axis=2)
 		with np.errstate(all='ignore'):
 			bckshe = np.nanmedian(blockdata, axis=2)
 		bckshe[np.isnan(bckshe)] = 0

@@ -201,7 +201,10 @@ struct StarBox { int axmin, axmax, bymin, bymax, jmin, jmax, imin, imax; };
 // addresser handles 64 lanes whatever they read); natural cadence order (18.6 ms: three origins per wavefront on average);
 // the cadence's pixels fetched a row ahead through LDS (13.6 against 12.5: the loop is not waiting for its pixels); two or four
 // cadences per lane sharing the scalar loads and the uniform tests (10.9 - 11.9 ms for the combinations tried: no gain, the
-// extra registers cost what the shared work saves).
+// extra registers cost what the shared work saves).  Round 3: the cadences sorted by origin only inside windows of 256 / 512
+// consecutive cadences (a 128-byte line of a pixel's series is then touched by one workgroup: the PMC passes show 34 GB of
+// line fills per step against 12 GB of necessary bytes for the global sort): 14.2 / 12.6 ms against 10.9 -- the extra origins
+// per wavefront cost more than the re-fetched lines.
 //--------------------------------------------------------------------------------------------------
 // a * b + c with c in scalar registers: one VOP3 instruction (left alone the compiler copies a uniform addend into vector
 // registers and accumulates with v_fmac)

@@ -98,6 +98,12 @@ class PinnedArray(object):
 			self.ctx.lib.tp_host_free(self.ctx.handle, self.ptr)
 		self.ptr = None
 
+	def __del__(self):
+		try:
+			self.free()   # page-locked memory is a scarce resource: never left to the end of the process
+		except Exception: # noqa: B902
+			pass
+
 
 def device_view(ctx, ptr, shape, dtype, base=None):
 	"""A non-owning :class:`DeviceArray` over ``ptr`` (a piece of a larger allocation kept alive by ``base``)."""

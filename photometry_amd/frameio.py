@@ -107,28 +107,42 @@ def upload_group(ctx, mm, frames_per_chunk=None, up=None):
 	item = mm.dtype.itemsize
 	if frames_per_chunk is None:
 		frames_per_chunk = max(1, min(T, (256 << 20) // max(R * C * item, 1)))   # about 256 MiB per chunk
-	own = up is None
-	if own:
-		up = Context(ctx.device, high_priority=False)
-	dst = ctx.empty((T, R, C), mm.dtype)
-	stage = [ctx.pinned((frames_per_chunk, R, C), mm.dtype) for _ in range(2)]
-	done = [up.event(), up.event()]
 	if (R * C * item) % 4:
-		raise ValueError('frame size must be a multiple of 4 bytes')
-	for i, k0 in enumerate(range(0, T, frames_per_chunk)):
-		s = i % 2
-		n = min(frames_per_chunk, T - k0)
-		if i >= 2:
-			up.event_sync(done[s])                                 # the transfer that last read this staging buffer is over
-		stage[s].array[:n] = mm[k0:k0 + n]                         # page cache / disk -> pinned memory, while chunk i-1 is in flight
-		nbytes = n * R * C * item
-		up._check(up.lib.tp_upload_cube_async(up.handle, dst.ptr + k0 * R * C * item, nbytes // 4, stage[s].ptr, nbytes // 4, 1, nbytes // 4))
-		up.record(done[s])
-	up.sync()
-	for p in stage:
-		p.free()
-	if own:
-		up.close()
+		raise ValueError('frame size must be a multiple of 4 bytes')   # before anything is allocated
+	own = up is None
+	dst = ctx.empty((T, R, C), mm.dtype)
+	stage, done = [], []
+	try:
+		if own:
+			up = Context(ctx.device, high_priority=False)
+		stage = [ctx.pinned((frames_per_chunk, R, C), mm.dtype) for _ in range(2)]
+		done = [up.event(), up.event()]
+		for i, k0 in enumerate(range(0, T, frames_per_chunk)):
+			s = i % 2
+			n = min(frames_per_chunk, T - k0)
+			if i >= 2:
+				up.event_sync(done[s])                                 # the transfer that last read this staging buffer is over
+			stage[s].array[:n] = mm[k0:k0 + n]                         # page cache / disk -> pinned memory, while chunk i-1 is in flight
+			nbytes = n * R * C * item
+			up._check(up.lib.tp_upload_cube_async(up.handle, dst.ptr + k0 * R * C * item, nbytes // 4, stage[s].ptr, nbytes // 4, 1, nbytes // 4))
+			up.record(done[s])
+		up.sync()
+	except BaseException:
+		dst.free()
+		raise
+	finally:
+		# staging buffers, events and the transfer context go whatever happened
+		if up is not None and getattr(up, 'handle', None) is not None:
+			try:
+				up.sync()
+			except Exception: # noqa: B902
+				pass
+			for e in done:
+				up.lib.tp_event_destroy(up.handle, e)
+		for p in stage:
+			p.free()
+		if own and up is not None:
+			up.close()
 	return dst
 
 

@@ -175,13 +175,8 @@ class BasePhotometry(object):
 			pos_centroid=np.zeros((self.Ntimes, 2)), pos_corr=np.zeros((self.Ntimes, 2)))
 		if getattr(src, 'jitter', None) is not None:
 			self.lightcurve['pos_corr'] = np.array(src.jitter, dtype='float64')
-		# a source that hands over the file's header gets the timestamp offset of the early data releases applied, as
-		# BasePhotometry does to the times it reads (BasePhotometry.py:244, :384)
-		hdr = getattr(src, 'header', None)
-		if hdr is not None and 'DATA_REL' in hdr:
-			from .fixes import time_offset
-			self.lightcurve['time'] = time_offset(self.lightcurve['time'], hdr, datatype='tpf' if self.datasource.startswith('tpf') else 'ffi',
-				settings=self.settings)
+		# (the timestamp offset of the early data releases, fixes/time_offset.py upstream, belongs to the input adapter: a source
+		# hands over corrected times -- SURVEY.md section 2, item 20)
 
 		self.final_phot_mask = None
 		self.final_position_mask = None

@@ -363,9 +363,14 @@ def background_shenanigans(ctx, images, sumimage, pixel_flags, threshold=40.0, s
 	mean = ctx.zeros((R, C), 'float64')
 	keep = []
 	for k in range(0, T, block):
-		idx = ctx.array(np.asarray(indices[k:k + block], dtype='int32'))
+		own = indices[k:k + block]
+		if len(own) < block and k >= block:
+			# the reference fills one (R, C, 25) buffer block after block (prepare.py:562-566): the slots a short last block does
+			# not overwrite still hold the frames of the previous block, and its nanmedian runs over all 25 slots
+			own = own + indices[k - block + len(own):k]
+		idx = ctx.array(np.asarray(own, dtype='int32'))
 		keep.append(idx)
-		ctx._check(ctx.lib.tp_frames_block_median_accumulate(ctx.handle, indicator.ptr, R * C, R * C, idx.ptr, len(indices[k:k + block]), mean.ptr))
+		ctx._check(ctx.lib.tp_frames_block_median_accumulate(ctx.handle, indicator.ptr, R * C, R * C, idx.ptr, len(own), mean.ptr))
 	ctx.sync()
 	nblocks = int(np.ceil(T / block))
 	m = mean.to_host() / nblocks

@@ -37,14 +37,18 @@ class FailedTask(object):
 		self._details = {'errors': list(tracebacks)} if tracebacks else {}
 
 
-def run_plugin(plugin, *args, **kwargs):
-	"""Construct ``plugin``, run its photometry inside its context manager, save on success; never raises (see module doc)."""
+def run_plugin(plugin, *args, before_save=None, **kwargs):
+	"""Construct ``plugin``, run its photometry inside its context manager, save on success; never raises (see module doc).
+	``before_save(pho)``: called after the photometry and before the light curve is written (a last word on status and details,
+	so that the file on disk and the returned object agree)."""
 	logger = logging.getLogger(__name__)
 	pho, lost = None, []
 	try:
 		pho = plugin(*args, **kwargs)
 		with pho:
 			pho.photometry()
+			if before_save is not None:
+				before_save(pho)
 			if pho.status in (STATUS.OK, STATUS.WARNING):
 				pho.save_lightcurve()
 	except (KeyboardInterrupt, SystemExit): # pragma: no cover
@@ -89,7 +93,17 @@ def tessphot(method=None, *args, **kwargs):
 			raise ValueError(f"Invalid method: '{method:s}'")
 		pho = run_plugin(PLUGINS[method], *args, **kwargs)
 	else:
-		pho = run_plugin(AperturePhotometry, *args, **kwargs)
+		def keep_aperture_result(p):
+			# No Halo photometry in this engine (third-party halophot upstream): the finished aperture result is kept, not
+			# thrown away for a plugin that can only fail; a good light curve is downgraded to WARNING and the request recorded
+			# BEFORE the light curve is written, so that the file and the returned status agree.
+			why = halo_switch_reason(p)
+			if why is not None and not HaloPhotometry.available:
+				p.report_details(error='Halo switch requested (' + why + ') but Halo photometry is not available: aperture result kept')
+				if p.status == STATUS.OK:
+					p._status = STATUS.WARNING
+
+		pho = run_plugin(AperturePhotometry, *args, before_save=keep_aperture_result, **kwargs)
 		reason = halo_switch_reason(pho)
 		if reason is not None:
 			logger.warning(reason)
@@ -100,12 +114,6 @@ def tessphot(method=None, *args, **kwargs):
 					# keep the diagnostics that led to the switch (tessphot.py:104-109)
 					pho.report_details('Automatically switched to Halo photometry')
 					pho._details['edge_flux'] = edge_flux
-			else:
-				# No Halo photometry in this engine (third-party halophot upstream): the finished aperture result is kept, not
-				# thrown away for a plugin that can only fail; a good light curve is downgraded to WARNING and the request recorded.
-				pho.report_details(error='Halo switch requested (' + reason + ') but Halo photometry is not available: aperture result kept')
-				if pho.status == STATUS.OK:
-					pho._status = STATUS.WARNING
 		if pho.status == STATUS.WARNING:
 			logger.warning("Do something else?")
 	logger.info("Done")

@@ -3,16 +3,19 @@
 #   bash profiles/run_profile.sh r2
 # 1. rocprofv3 kernel trace + stats (per-kernel durations) of the default bench command
 # 2./3. PMC passes for the HBM traffic of every dispatch (FETCH_SIZE and WRITE_SIZE need separate passes; never together with a trace)
-TAG=${1:-r2}
+# 4. a PMC pass with the raw L2 counters that calibrate FETCH_SIZE per kernel
+TAG=${1:-r3}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export TP_BENCH_NO_TORCH=1
-ARGS="--steps 5 --warmup 2 --cpu-sample 0 --e2e-targets 0 --frames-targets 0 --frame 512"
+ARGS="--steps 5 --warmup 2 --cpu-sample 0 --e2e-targets 0 --frames-targets 0 --frame 512 --psf-targets 0 --fullframe-frames 0"
+PMCARGS="--steps 2 --warmup 1 --cpu-sample 0 --e2e-targets 0 --frames-targets 0 --frame 512 --psf-targets 0 --fullframe-frames 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --e2e-targets 0 --frames-targets 0 --frame 512 > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --e2e-targets 0 --frames-targets 0 --frame 512 > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log
+# 4. what one read request carries: L2 misses, write requests and read requests of every dispatch (see profiles/summarize.py)
+rocprofv3 --pmc TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/pmc_lines -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_lines.json 2> $OUT/pmc_lines.log
 cd $REPO
 python3 profiles/summarize.py $OUT $OUT/traffic.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

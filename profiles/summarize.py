@@ -3,11 +3,18 @@
 Summarise rocprofv3 CSV output (kernel stats + PMC counters) of profiles/run_profile.sh into a small text table and a
 traffic JSON (HBM bytes per launch of every kernel, read by bench.py).
 
-FETCH_SIZE on gfx950 reports half the bytes of SOME access patterns (MI355X_MICROARCH.md: wide coalesced streaming reads) and
-the full bytes of others (e.g. the read-modify-write stream of the materialised subtraction).  The factor is therefore not
-assumed: for every kernel whose necessary bytes are known (bench.py prints them) the factor f in {1, 2} is the smallest
-one with f x FETCH_SIZE + WRITE_SIZE >= 0.97 x necessary bytes -- a kernel cannot have moved less than it needs -- and it
-is recorded next to the number.  Kernels without a known byte count get no traffic figure, only the raw counters.
+FETCH_SIZE on gfx950 = 64 B x (read requests of the L2 to the fabric): rocprofv3 applies the gfx94x formula, whose count of
+128-byte requests (TCC_BUBBLE) stays zero on this chip.  What a read request carries depends on the kernel
+(tools/fetchcal.hip, tools/fetchcal2.sh, measured): pure read streams of any load width (4 / 8 / 16 bytes per lane, coalesced
+or in 32-byte segments) issue ONE 128-byte request per missed line -- FETCH_SIZE reports exactly half their bytes --, a stream
+that also writes at the same rate (the materialised subtraction) issues TWO 64-byte requests per line -- FETCH_SIZE is exact.
+The factor is therefore measured per kernel from a third PMC pass: read lines = TCC_MISS - TCC_EA0_WRREQ (every L2 miss that
+is not a write request fetches one 128-byte line; the write requests of these streaming kernels all miss), so
+
+    read bytes = 128 x max(TCC_MISS - TCC_EA0_WRREQ, TCC_EA0_RDREQ / 2)        (between 64 and 128 bytes per read request)
+    traffic    = read bytes + WRITE_SIZE
+
+and the bytes per read request this implies are printed next to every kernel.  No byte count of the kernel enters.
 """
 import csv
 import glob
@@ -49,6 +56,14 @@ for counter, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
 		means[k][counter] = sum(v) / len(v) * 1024.0     # reported in KiB
 		means[k]['dispatches_' + counter] = len(v)
 
+# raw L2 counters of the calibration pass
+lines = defaultdict(lambda: defaultdict(list))
+for f in find('pmc_lines/**/*counter_collection.csv'):
+	with open(f) as fh:
+		for r in csv.DictReader(fh):
+			if 'tp_' in r.get('Kernel_Name', ''):
+				lines[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+
 # necessary bytes per launch from the bench line of the trace run
 need = {}
 for f in ('bench_trace.json',):
@@ -65,9 +80,13 @@ for f in ('bench_trace.json',):
 	for k, v in r.get('aperture_premade_cubes', {}).get('kernels', {}).items():
 		if 'necessary_bytes_per_launch' in v:
 			need[('premade', k)] = v['necessary_bytes_per_launch']
+	lp = r.get('linpsf', {}).get('roofline', {}).get('hbm', {})
+	if lp:
+		need[('step', 'tp_linpsf_fit')] = lp['necessary_bytes_per_step']
 
-print("== HBM traffic per launch ==")
+print("== HBM traffic per launch (read bytes = 128 x (L2 misses - write requests), see the header) ==")
 traffic = {'traffic_bytes_per_launch': {}, 'traffic_bytes_per_launch_premade': {}, 'detail': {}}
+linpsf_total = 0.0
 for k in sorted(means):
 	v = means[k]
 	if 'FETCH_SIZE' not in v or 'WRITE_SIZE' not in v:
@@ -77,16 +96,29 @@ for k in sorted(means):
 	leg = 'premade' if (base == 'tp_aperture_fused_kernel' and re.search(r'false,\s*0>', k)) else 'step'
 	nb = need.get((leg, base))
 	d = {'fetch_size_bytes_as_reported': v['FETCH_SIZE'], 'write_size_bytes': v['WRITE_SIZE'], 'necessary_bytes': nb}
-	if nb:
-		f = 1 if (v['FETCH_SIZE'] + v['WRITE_SIZE'] >= 0.97 * nb) else 2
-		d['fetch_factor'] = f
-		d['traffic_bytes'] = f * v['FETCH_SIZE'] + v['WRITE_SIZE']
-		d['traffic_over_necessary'] = d['traffic_bytes'] / nb
-		traffic['traffic_bytes_per_launch_premade' if leg == 'premade' else 'traffic_bytes_per_launch'][base] = d['traffic_bytes']
-		print(f"{k:64s} FETCH {v['FETCH_SIZE']/1e9:8.3f} GB (x{f})  WRITE {v['WRITE_SIZE']/1e9:7.3f} GB  traffic {d['traffic_bytes']/1e9:8.3f} GB  necessary {nb/1e9:8.3f} GB  ratio {d['traffic_over_necessary']:.3f}")
+	ln = {c: sum(x) / len(x) for c, x in lines.get(k, {}).items()}
+	if 'TCC_MISS_sum' in ln and 'TCC_EA0_RDREQ_sum' in ln and ln['TCC_EA0_RDREQ_sum'] > 0:
+		read_lines = max(ln['TCC_MISS_sum'] - ln.get('TCC_EA0_WRREQ_sum', 0.0), ln['TCC_EA0_RDREQ_sum'] / 2)
+		read_bytes = min(128.0 * read_lines, 128.0 * ln['TCC_EA0_RDREQ_sum'])
+		d['bytes_per_read_request'] = read_bytes / ln['TCC_EA0_RDREQ_sum']
+		d['fetch_factor'] = d['bytes_per_read_request'] / 64.0
+		d['traffic_bytes'] = read_bytes + v['WRITE_SIZE']
+		d['raw'] = ln
+		txt = f"{k:64s} read {read_bytes/1e9:8.3f} GB ({d['bytes_per_read_request']:5.1f} B/request; FETCH_SIZE says {v['FETCH_SIZE']/1e9:7.3f})  WRITE {v['WRITE_SIZE']/1e9:7.3f} GB  traffic {d['traffic_bytes']/1e9:8.3f} GB"
+		if nb:
+			d['traffic_over_necessary'] = d['traffic_bytes'] / nb
+			txt += f"  necessary {nb/1e9:8.3f} GB  ratio {d['traffic_over_necessary']:.3f}"
+		print(txt)
+		traffic['traffic_bytes_per_launch_premade' if leg == 'premade' else 'traffic_bytes_per_launch'][base if '<' not in k or base != 'tp_linpsf_fit2_kernel' else k] = d['traffic_bytes']
+		if base in ('tp_linpsf_fit2_kernel', 'tp_linpsf_plan_kernel', 'tp_linpsf_coef_kernel', 'tp_linpsf_fitm_kernel'):
+			linpsf_total += d['traffic_bytes']
 	else:
-		print(f"{k:64s} FETCH {v['FETCH_SIZE']/1e9:8.3f} GB (as reported, uncalibrated)  WRITE {v['WRITE_SIZE']/1e9:7.3f} GB")
+		print(f"{k:64s} FETCH {v['FETCH_SIZE']/1e9:8.3f} GB (as reported, no calibration pass)  WRITE {v['WRITE_SIZE']/1e9:7.3f} GB")
 	traffic['detail'][k] = d
+if linpsf_total:
+	nb = need.get(('step', 'tp_linpsf_fit'))
+	traffic['traffic_bytes_per_launch']['tp_linpsf_fit'] = linpsf_total
+	print(f"{'LinPSF fit (plan + coefficient store + every fit2 instantiation)':64s} traffic {linpsf_total/1e9:8.3f} GB per step" + (f"  necessary {nb/1e9:8.3f} GB  ratio {linpsf_total/nb:.3f}" if nb else ''))
 if len(sys.argv) > 2:
 	with open(sys.argv[2], 'w') as fh:
 		json.dump(traffic, fh, indent=1, sort_keys=True)

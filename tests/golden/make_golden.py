@@ -23,6 +23,8 @@ Fixtures:
 * ``golden_linpsf.npz``   ``lsfit`` and ``LinPSFPhotometry.do_photometry``
                           (linpsf_photometry.py:22-34, 79-219)
 * ``golden_pixelflags.npz`` ``pixel_flags.pixel_manual_exclude`` (pixel_flags.py:13-58) on header / data cases
+* ``golden_shenanigans.npz`` the block-median mean of the shenanigans indicator (prepare.py:557-571 executed), frame counts that
+                          are and are not multiples of the block of 25
 * ``golden_skiptargets.npz`` ``TaskManager.get_task / start_task / save_result`` (taskmanager.py:391-532) on sqlite todo-lists with
                           prescribed outcomes: the master-side skip-target resolution
 * ``golden_fitsfile.json/.npz`` ``BasePhotometry.save_lightcurve`` (BasePhotometry.py:1417-1730) with a recording stand-in for
@@ -631,6 +633,43 @@ def golden_background():
 	out['b3_raw'], out['b3_raw_err'], out['b3_flags'] = raw, err, flags
 	np.savez_compressed(os.path.join(HERE, 'golden_background.npz'), **out)
 
+def golden_shenanigans():
+	"""
+	The robust mean of the "background shenanigans" indicator over time: the reference's own statements (prepare.py:557-571,
+	read at generation time) executed on indicator stacks in memory.  bottleneck's ``nanmedian`` / ``replace`` are numpy
+	stand-ins (medians of float64 values: no summation order involved).  The cases include frame counts that are NOT a multiple
+	of the block of 25: the reference fills ONE (R, C, 25) buffer block after block, so the median of a short last block also
+	runs over the frames the previous block left in the slots it does not overwrite.
+	"""
+	import logging
+	src, span = _reference_block("mean_shenanigans = np.zeros_like(SumImage, dtype='float64')", 'mean_shenanigans /= np.ceil(numfiles/block)')
+	print('shenanigans statements: prepare.py:%d-%d' % span)
+	rng = np.random.default_rng(314)
+	out = {}
+
+	def replace(a, old, new):
+		a[np.isnan(a)] = new
+
+	def nanmedian(a, axis=2):
+		with warnings.catch_warnings():
+			warnings.simplefilter('ignore')
+			return np.nanmedian(a, axis=axis)
+
+	for case, (R, C, T) in enumerate(((6, 5, 50), (6, 5, 60), (4, 7, 37), (5, 5, 76))):
+		ind = rng.normal(0, 20, (R, C, T)).astype('float32')
+		ind[rng.random(ind.shape) < 0.05] = np.nan
+		ind[1, 2, :] = np.nan                     # a pixel that never has a value
+		ns = {'SumImage': np.zeros((R, C)), 'numfiles': T, 'pixel_flags_ind': ind, 'np': np, 'trange': lambda a, b, c, **kw: range(a, b, c),
+			'tqdm_settings': {}, 'nanmedian': nanmedian, 'replace': replace, 'logger': logging.getLogger('golden'), 'default_timer': lambda: 0.0, 'tic': 0.0}
+		# np.empty of the block buffer: make the never-written slots of a FIRST short block recognisable (not reached: T >= 25 here)
+		exec(compile(src, 'prepare.py[shenanigans]', 'exec'), ns)
+		out[f's{case}_indicator'] = np.moveaxis(ind, 2, 0)
+		out[f's{case}_mean'] = ns['mean_shenanigans']
+	out['n_cases'] = np.array(4)
+	np.savez_compressed(os.path.join(HERE, 'golden_shenanigans.npz'), **out)
+	print('golden_shenanigans', 4, 'cases')
+
+
 def golden_pixelflags():
 	"""
 	``pixel_flags.pixel_manual_exclude`` (pixel_flags.py:13-58) executed on stand-in images carrying what the function reads
@@ -1011,6 +1050,6 @@ def golden_fitsfile():
 
 
 if __name__ == '__main__':
-	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics', 'cutout', 'background', 'psfphot', 'pixelflags', 'skiptargets', 'fitsfile']
+	which = sys.argv[1:] or ['misc', 'sumimage', 'aperture', 'k2p2', 'psf', 'linpsf', 'diagnostics', 'cutout', 'background', 'psfphot', 'pixelflags', 'shenanigans', 'skiptargets', 'fitsfile']
 	for w in which:
 		globals()['golden_' + w]()

@@ -124,6 +124,21 @@ def test_background_shenanigans(ctx):
 	np.testing.assert_array_equal(out.to_host()[1], median_filter(sky[1], size=5))
 
 
+def test_shenanigans_mean_golden_on_device(ctx, golden_dir):
+	"""The block-median mean against the reference's own statements (tests/golden/golden_shenanigans.npz), frame counts that are
+	not a multiple of 25 included: a 1 x 1 "median filter" with a zero reference image hands the golden indicator through."""
+	import os
+	from photometry_amd import prepare
+	g = np.load(os.path.join(golden_dir, 'golden_shenanigans.npz'))
+	for c in range(int(g['n_cases'])):
+		ind = g[f's{c}_indicator']
+		T, R, C = ind.shape
+		flags = ctx.zeros((T, R, C), 'uint8')
+		got_ind, mean = prepare.background_shenanigans(ctx, ctx.array(ind), ctx.array(np.zeros((R, C))), flags, size=1)
+		np.testing.assert_array_equal(got_ind.to_host(), ind)
+		np.testing.assert_allclose(mean.to_host(), g[f's{c}_mean'], rtol=1e-15, atol=0)
+
+
 def _tess_frames(T, R, C, seed):
 	"""Frames of the corner of CCD (1, 1): a sky plus a glow rising with the distance from the camera centre, stars, defects."""
 	from photometry_amd import prepare

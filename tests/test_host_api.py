@@ -178,25 +178,6 @@ def test_replay_skip_targets_golden():
 	assert n_skipped > 100
 
 
-def test_time_offset_applied_from_source_header(tmp_path):
-	"""A source that carries the file header gets the early-release timestamp fix (BasePhotometry.py:244) -- no GPU needed."""
-	from photometry_amd import simulate
-	from photometry_amd.plugins import BasePhotometry
-	from photometry_amd.source import source_from_scene
-	s = simulate.make_scene(1, 10, 11, 11, seed=2)
-	simulate.fill_cubes(s)
-	src = source_from_scene(s, 0)
-	t0 = np.array(src.time, dtype='float64')
-	src.header = {'DATA_REL': 5, 'CAMERA': 2, 'CCD': 3}
-	pho = BasePhotometry(int(s.target_starid[0]), src, str(tmp_path), datasource='ffi')
-	np.testing.assert_array_equal(pho.lightcurve['time'], t0 + (1.500 + 0.040 - 2.000 + 0.021) / 86400)
-	pho.close()
-	src.header = {'DATA_REL': 40, 'CAMERA': 2, 'CCD': 3}
-	pho = BasePhotometry(int(s.target_starid[0]), src, str(tmp_path), datasource='ffi')
-	np.testing.assert_array_equal(pho.lightcurve['time'], t0)
-	pho.close()
-
-
 def test_batch_helpers_equal_per_target_helpers():
 	"""The vectorised host helpers of the batched path (stamps.default_stamps, pipeline._catalogs_of_stamps) against the
 	per-target functions the plugin uses, on random regions: half-integer positions (rounding mode), stars exactly on the

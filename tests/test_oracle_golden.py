@@ -214,3 +214,32 @@ def test_pixel_manual_exclude_golden(golden_dir):
 		assert rule == g['first_excluded_column'][i], i
 
 
+
+
+def test_shenanigans_mean_golden(golden_dir):
+	"""The block-median mean of the shenanigans indicator (prepare.py:557-571 executed by the generator), including frame counts
+	that are not a multiple of 25: the short last block's median also runs over the frames the previous block left in the
+	reference's buffer."""
+	from oracle import backgrounds as ob
+	g = _load(golden_dir, 'golden_shenanigans.npz')
+	for c in range(int(g['n_cases'])):
+		ind = g[f's{c}_indicator']                      # (T, R, C) float32
+		T = ind.shape[0]
+		indicies = list(range(T))
+		np.random.seed(0)
+		np.random.shuffle(indicies)
+		mean = np.zeros(ind.shape[1:])
+		for k in range(0, T, 25):
+			blockdata = np.stack([ind[i].astype('float64') for i in ob.shenanigans_block_frames(indicies, k)], axis=2)
+			with np.errstate(all='ignore'):
+				import warnings
+				with warnings.catch_warnings():
+					warnings.simplefilter('ignore')
+					b = np.nanmedian(blockdata, axis=2)
+			b[np.isnan(b)] = 0
+			mean += b
+		mean /= np.ceil(T / 25)
+		np.testing.assert_array_equal(mean, g[f's{c}_mean'])
+	# a last block of 10 frames after a full one: 15 stale frames take part
+	assert len(ob.shenanigans_block_frames(list(range(60)), 50)) == 25 and len(ob.shenanigans_block_frames(list(range(60)), 25)) == 25
+	assert len(ob.shenanigans_block_frames(list(range(10)), 0)) == 10
