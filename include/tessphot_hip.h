@@ -258,6 +258,15 @@ int tp_background_mesh(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int
 	int64_t row_pitch, int64_t frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride,
 	const float* d_subtract, int64_t subtract_frame_stride,
 	double flux_cutoff, int32_t box_size, double* d_mesh, int32_t* d_nmasked);
+/* tp_background_mesh_finish: the low-resolution part of photutils Background2D after the cell statistics, per frame on the device:
+ *   cells with more than exclude_percentile % masked pixels (of box_size^2) or a non-finite statistic are replaced by the
+ *   inverse-distance weighted mean of the 10 nearest kept cells, the filter_size x filter_size NaN-ignoring median filter, then
+ *   d_vmin / d_vmax (range of the filtered mesh) and d_coef float64 [n_frames][rows][cols] = the cubic B-spline coefficients
+ *   scipy.ndimage.zoom(order 3, mode 'reflect') interpolates from (spline_filter1d along both axes) -- the inputs of
+ *   tp_background_zoom.  d_filtered optional: the filtered mesh itself.  A frame without a kept cell is NaN.  <= 2048 cells.  */
+int tp_background_mesh_finish(tp_ctx* ctx, const double* d_mesh, const int32_t* d_nmasked, int32_t n_frames, int32_t mesh_rows,
+	int32_t mesh_cols, int32_t box_size, double exclude_percentile, int32_t filter_size, double* d_coef, double* d_vmin, double* d_vmax,
+	double* d_filtered);
 int tp_background_zoom(tp_ctx* ctx, const double* d_coef, const double* d_vmin, const double* d_vmax, int32_t n_frames,
 	int32_t mesh_rows, int32_t mesh_cols, int32_t box_size, int32_t frame_rows, int32_t frame_cols, int64_t row_pitch, int64_t frame_stride,
 	float* d_background);
@@ -321,6 +330,15 @@ int tp_radial_ring_modes(tp_ctx* ctx, const float* d_frames, int32_t n_frames, i
 	const float* d_square, int64_t square_frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride, double flux_cutoff,
 	const double* d_zeropoint, const int32_t* d_ring_pixels, const int32_t* d_ring_offsets, int32_t n_rings, int32_t n_ring_pixels,
 	double bandwidth_constant, double* d_scratch, double* d_modes, int32_t* d_counts);
+/* tp_radial_profiles: the ring profile of every frame on the device (backgrounds.py:178-187): utilities.move_median_central of the
+ *   ring modes (width radial_smooth, 0 = none; NaN-ignoring, ends redone over the first / last k + 2 points) and the interpolating
+ *   cubic spline through the rings that have a mode, in FITPACK form (interior knots on the data points x[2 .. m-3], the m x m
+ *   collocation system solved in the band) -- what InterpolatedUnivariateSpline(k = 3) returns, to rounding.  d_modes float64
+ *   [n_frames][n_rings] (tp_radial_ring_modes), d_bin_center float64 [n_rings]; outputs as tp_radial_evaluate takes them
+ *   (d_knots / d_coefs float64 [n_frames][max_knots], d_n_knots int32; 0 = no radial component: fewer than 4 usable rings --
+ *   the reference logs for fewer than 3 and FITPACK refuses exactly 3).  n_rings <= 64.                           */
+int tp_radial_profiles(tp_ctx* ctx, int32_t n_frames, int32_t n_rings, const double* d_modes, const double* d_bin_center,
+	int32_t radial_smooth, int32_t max_knots, double* d_knots, double* d_coefs, int32_t* d_n_knots);
 int tp_radial_evaluate(tp_ctx* ctx, int32_t n_frames, int32_t frame_rows, int32_t frame_cols, int64_t frame_stride,
 	double col_offset, double xcen, double ycen, const double* d_knots, const double* d_coefs, const int32_t* d_n_knots, int32_t max_knots,
 	const double* d_zeropoint, const float* d_add, int64_t add_frame_stride, float* d_out);

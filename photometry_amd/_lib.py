@@ -89,6 +89,7 @@ SIGNATURES = {
 	'tp_smooth_time': (c_int, [c_void_p, c_int32, c_int32, c_int64, c_int32, _p, _p]),
 	'tp_subtract_background': (c_int, [c_void_p, _desc_p, _p, _p, _p, c_int64, _p, c_uint32, _p, _p]),
 	'tp_background_mesh': (c_int, [c_void_p, _p, c_int32, c_int32, c_int32, c_int64, c_int64, _p, c_int64, _p, c_int64, c_double, c_int32, _p, _p]),
+	'tp_background_mesh_finish': (c_int, [c_void_p, _p, _p, c_int32, c_int32, c_int32, c_int32, c_double, c_int32, _p, _p, _p, _p]),
 	'tp_background_zoom': (c_int, [c_void_p, _p, _p, _p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, _p]),
 	'tp_frames_smooth_time': (c_int, [c_void_p, c_int32, c_int64, c_int64, c_int32, _p, _p]),
 	'tp_frames_subtract': (c_int, [c_void_p, c_int64, _p, _p, _p, _p, c_uint32, _p, _p]),
@@ -96,6 +97,7 @@ SIGNATURES = {
 	'tp_radial_zeropoint': (c_int, [c_void_p, _p, c_int32, c_int64, c_int64, _p, c_int64, _p, c_int64, c_double, _p, c_int32, _p]),
 	'tp_radial_ring_modes': (c_int, [c_void_p, _p, c_int32, c_int64, c_int64, _p, c_int64, _p, c_int64, c_double, _p, _p, _p, c_int32, c_int32,
 		c_double, _p, _p, _p]),
+	'tp_radial_profiles': (c_int, [c_void_p, c_int32, c_int32, _p, _p, c_int32, c_int32, _p, _p, _p]),
 	'tp_radial_evaluate': (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int64, c_double, c_double, c_double, _p, _p, _p, c_int32, _p, _p, c_int64, _p]),
 	'tp_frames_pixel_flags': (c_int, [c_void_p, _p, c_int32, c_int32, c_int32, c_int64, c_int64, _p, c_int32, c_double, c_uint32, c_uint32, _p, _p]),
 	'tp_frames_used_in_background': (c_int, [c_void_p, _p, c_int32, c_int64, c_uint32, c_double, _p]),

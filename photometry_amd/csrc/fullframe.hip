@@ -293,6 +293,148 @@ __global__ __launch_bounds__(256) void tp_frames_used_kernel(const uint8_t* __re
 	used[p] = ((double)cnt / (double)n_frames > threshold) ? 1 : 0;
 }
 
+
+//--------------------------------------------------------------------------------------------------
+// The low-resolution part of photutils Background2D (1.3.0) after the per-cell statistics, and the cubic-spline prefilter of
+// the zoom -- for a few KB per frame, one workgroup per frame with the mesh in LDS (the host did this with numpy / scipy):
+//   1. cells with more than exclude_percentile % masked pixels (or a non-finite statistic) are replaced by the inverse-distance
+//      weighted mean of the 10 nearest kept cells (ties in distance: row-major order of the kept cells, like the stable argsort);
+//   2. 3 x 3 median filter ignoring NaN, windows running off the mesh padded with NaN (generic_filter(nanmedian, mode='constant'));
+//   3. min / max of the filtered mesh (the zoom clips to them) and the B-spline coefficients scipy.ndimage.zoom(order = 3,
+//      mode = 'reflect') interpolates from: spline_filter1d along both axes (pole sqrt(3) - 2, scipy's ni_splines.c
+//      initialisation for the half-sample symmetric boundary).
+// A frame without any kept cell comes back NaN.
+//--------------------------------------------------------------------------------------------------
+constexpr int kMaxMeshCells = 2048;
+
+__device__ inline void prefilter_reflect(double* c, int n, int stride) {
+	if (n < 2) return;
+	const double z = -0.26794919243112270647;   // sqrt(3) - 2
+	const double gain = (1.0 - z) * (1.0 - 1.0 / z);
+	for (int i = 0; i < n; ++i) c[i * stride] *= gain;
+	double z_i = z;
+	double z_n = 1.0;   // z^n (scipy: pow(z, n)); by multiplication: a handful of factors, the same to an ulp or two
+	for (int i = 0; i < n; ++i) z_n *= z;
+	const double c0 = c[0];
+	double acc = c[0] + z_n * c[(n - 1) * stride];
+	// scipy accumulates IN PLACE in c[0]: the last term (i = n - 1) reads the running sum, not the original first sample
+	for (int i = 1; i < n; ++i) { acc += z_i * (c[i * stride] + z_n * ((i == n - 1) ? acc : c[(n - 1 - i) * stride])); z_i *= z; }
+	acc *= z / (1.0 - z_n * z_n);
+	c[0] = acc + c0;
+	for (int i = 1; i < n; ++i) c[i * stride] += z * c[(i - 1) * stride];
+	c[(n - 1) * stride] *= z / (z - 1.0);
+	for (int i = n - 2; i >= 0; --i) c[i * stride] = z * (c[(i + 1) * stride] - c[i * stride]);
+}
+
+__global__ __launch_bounds__(256) void tp_mesh_finish_kernel(const double* __restrict__ mesh, const int32_t* __restrict__ nmasked, int ny, int nx,
+	double max_masked, int filter_size, double* __restrict__ coef, double* __restrict__ vmin, double* __restrict__ vmax, double* __restrict__ filtered)
+{
+	__shared__ double a[kMaxMeshCells], b[kMaxMeshCells];
+	__shared__ unsigned short kept[kMaxMeshCells];
+	__shared__ int n_kept;
+	__shared__ double red[8];
+	const int frame = blockIdx.x, tid = threadIdx.x, nc = ny * nx;
+	const double* m = mesh + (int64_t)frame * nc;
+	const int32_t* nm = nmasked + (int64_t)frame * nc;
+	for (int i = tid; i < nc; i += 256) a[i] = m[i];
+	if (tid == 0) {
+		// the kept cells in row-major order (np.nonzero)
+		int k = 0;
+		for (int i = 0; i < nc; ++i) { const double v = m[i]; if ((double)nm[i] <= max_masked && v - v == 0.0) kept[k++] = (unsigned short)i; }
+		n_kept = k;
+	}
+	__syncthreads();
+	const int nk = n_kept;
+	double* outc = coef + (int64_t)frame * nc;
+	if (nk == 0) {
+		for (int i = tid; i < nc; i += 256) { outc[i] = __builtin_nan(""); if (filtered) filtered[(int64_t)frame * nc + i] = __builtin_nan(""); }
+		if (tid == 0) { vmin[frame] = __builtin_nan(""); vmax[frame] = __builtin_nan(""); }
+		return;
+	}
+	// ---- 1. inverse-distance fill of the excluded cells from the 10 nearest kept ones
+	for (int i = tid; i < nc; i += 256) {
+		const double v = a[i];
+		double r = v;
+		if (!((double)nm[i] <= max_masked && v - v == 0.0)) {
+			const int y = i / nx, x = i - y * nx;
+			double dsel[10], vsel[10];
+			int nsel = 0;
+			double last_d = -1.0; int last_k = -1;
+			for (int s = 0; s < 10 && s < nk; ++s) {
+				// the next (distance, position in the kept list) in lexicographic order
+				double bd = __builtin_inf(); int bk = -1;
+				for (int k = 0; k < nk; ++k) {
+					const int c = kept[k];
+					const int cy = c / nx, cx = c - cy * nx;
+					const double d = hypot((double)(cy - y), (double)(cx - x));
+					if ((d > last_d || (d == last_d && k > last_k)) && d < bd) { bd = d; bk = k; }
+				}
+				if (bk < 0) break;
+				dsel[nsel] = bd; vsel[nsel] = a[kept[bk]]; ++nsel;
+				last_d = bd; last_k = bk;
+			}
+			// np.sum over 10 (or fewer) terms: numpy's pairwise reduction -- eight running sums, then the tail
+			double w[10], wv[10];
+			for (int s = 0; s < nsel; ++s) { w[s] = 1.0 / dsel[s]; wv[s] = w[s] * vsel[s]; }
+			auto npsum = [&](const double* q, int n) {
+				if (n < 8) { double t = 0.0; for (int s = 0; s < n; ++s) t += q[s]; return t; }
+				double t = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+				for (int s = 8; s < n; ++s) t += q[s];
+				return t;
+			};
+			r = npsum(wv, nsel) / npsum(w, nsel);
+		}
+		b[i] = r;
+	}
+	__syncthreads();
+	// ---- 2. nan-median filter
+	if (filter_size > 1) {
+		const int h = filter_size / 2;
+		for (int i = tid; i < nc; i += 256) {
+			const int y = i / nx, x = i - y * nx;
+			double w[25];
+			int n = 0;
+			for (int dy = -h; dy < filter_size - h; ++dy)
+				for (int dx = -h; dx < filter_size - h; ++dx) {
+					const int yy = y + dy, xx = x + dx;
+					if (yy < 0 || yy >= ny || xx < 0 || xx >= nx) continue;
+					const double v = b[yy * nx + xx];
+					if (v == v && n < 25) {
+						int j = n++;
+						while (j > 0 && w[j - 1] > v) { w[j] = w[j - 1]; --j; }
+						w[j] = v;
+					}
+				}
+			a[i] = (n == 0) ? __builtin_nan("") : ((n & 1) ? w[n >> 1] : 0.5 * (w[(n >> 1) - 1] + w[n >> 1]));
+		}
+	} else {
+		for (int i = tid; i < nc; i += 256) a[i] = b[i];
+	}
+	__syncthreads();
+	// ---- 3. range of the mesh (np.min / np.max propagate NaN) and the spline coefficients
+	double lo = __builtin_inf(), hi = -__builtin_inf();
+	bool anynan = false;
+	for (int i = tid; i < nc; i += 256) { const double v = a[i]; anynan = anynan || (v != v); lo = fmin(lo, v); hi = fmax(hi, v); }
+	for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_xor(lo, off, 64)); hi = fmax(hi, __shfl_xor(hi, off, 64)); }
+	const bool wavenan = __any(anynan) != 0;
+	if ((tid & 63) == 0) { red[tid >> 6] = wavenan ? __builtin_nan("") : lo; red[4 + (tid >> 6)] = wavenan ? __builtin_nan("") : hi; }
+	if (filtered) for (int i = tid; i < nc; i += 256) filtered[(int64_t)frame * nc + i] = a[i];
+	__syncthreads();
+	if (tid == 0) {
+		double l = red[0], hmax = red[4];
+		for (int w = 1; w < 4; ++w) { l = (red[w] != red[w] || l != l) ? __builtin_nan("") : fmin(l, red[w]); hmax = (red[4 + w] != red[4 + w] || hmax != hmax) ? __builtin_nan("") : fmax(hmax, red[4 + w]); }
+		vmin[frame] = l; vmax[frame] = hmax;
+	}
+	if (ny > 1 && nx > 1) {
+		// spline_filter1d(axis = 1 of (T, ny, nx)) = along the rows' index y, for every column; then along x for every row
+		for (int x = tid; x < nx; x += 256) prefilter_reflect(a + x, ny, nx);
+		__syncthreads();
+		for (int y = tid; y < ny; y += 256) prefilter_reflect(a + y * nx, nx, 1);
+		__syncthreads();
+	}
+	for (int i = tid; i < nc; i += 256) outc[i] = a[i];
+}
+
 } // namespace
 
 extern "C" int tp_frames_pixel_flags(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
@@ -355,6 +497,23 @@ extern "C" int tp_background_mesh(tp_ctx* ctx, const float* d_frames, int32_t n_
 	TP_REQUIRE(ctx, a.ny <= 65535 && n_frames <= 65535, "tp_background_mesh: too many boxes / frames for one launch");
 	TP_LAUNCH(ctx, TPK_BKG_MESH, tp_bkg_mesh_kernel, dim3((unsigned)a.nx, (unsigned)a.ny, (unsigned)n_frames), dim3(kMeshThreads), 0, a);
 	TP_LAUNCH_CHECK(ctx, "tp_bkg_mesh_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_background_mesh_finish(tp_ctx* ctx, const double* d_mesh, const int32_t* d_nmasked, int32_t n_frames, int32_t mesh_rows,
+	int32_t mesh_cols, int32_t box_size, double exclude_percentile, int32_t filter_size, double* d_coef, double* d_vmin, double* d_vmax,
+	double* d_filtered)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_mesh && d_nmasked && d_coef && d_vmin && d_vmax, "tp_background_mesh_finish: null pointer");
+	TP_REQUIRE(ctx, n_frames >= 0 && mesh_rows > 0 && mesh_cols > 0 && mesh_rows * mesh_cols <= kMaxMeshCells, "tp_background_mesh_finish: at most 2048 cells per frame");
+	TP_REQUIRE(ctx, box_size > 0 && filter_size >= 1 && filter_size <= 5 && (filter_size & 1), "tp_background_mesh_finish: filter_size must be 1, 3 or 5");
+	if (n_frames == 0) return TP_OK;
+	TP_LAUNCH(ctx, TPK_BKG_MESH, tp_mesh_finish_kernel, dim3((unsigned)n_frames), dim3(256), 0, d_mesh, d_nmasked, (int)mesh_rows, (int)mesh_cols,
+		exclude_percentile / 100.0 * (double)box_size * (double)box_size, (int)filter_size, d_coef, d_vmin, d_vmax, d_filtered);
+	TP_LAUNCH_CHECK(ctx, "tp_mesh_finish_kernel");
 	return TP_OK;
 	TP_API_END(ctx)
 }

@@ -325,6 +325,120 @@ __global__ __launch_bounds__(kRadThreads) void tp_radial_ring_kernel(RingArgs a)
 	}
 }
 
+
+//--------------------------------------------------------------------------------------------------
+// The ring profile of a frame: 3-point moving median of the ring modes (utilities.move_median_central, utilities.py:52-62,
+// backgrounds.py:178-179) and the interpolating cubic spline through the rings that have a mode
+// (InterpolatedUnivariateSpline(k = 3), backgrounds.py:186: FITPACK's interpolating spline puts its interior knots on the data
+// points x[2 .. m-3] -- "not a knot" at the second and the second-to-last point -- and solves the m x m collocation system).
+// A few dozen points per frame: one lane per frame does it, the collocation matrix (four non-zeros per row) in LDS.
+//--------------------------------------------------------------------------------------------------
+constexpr int kMaxRings = 64;
+
+__device__ inline double nan_median(const double* v, int n) {
+	double w[8];
+	int m = 0;
+	for (int i = 0; i < n && i < 8; ++i) if (v[i] == v[i]) w[m++] = v[i];
+	if (m == 0) return __builtin_nan("");
+	for (int i = 1; i < m; ++i) { const double x = w[i]; int j = i; while (j > 0 && w[j - 1] > x) { w[j] = w[j - 1]; --j; } w[j] = x; }
+	return (m & 1) ? w[m >> 1] : 0.5 * (w[(m >> 1) - 1] + w[m >> 1]);
+}
+
+__global__ __launch_bounds__(64) void tp_radial_profile_kernel(const double* __restrict__ modes, const double* __restrict__ bin_center, int n_rings,
+	int width, int n_frames, int max_knots, double* __restrict__ knots, double* __restrict__ coefs, int32_t* __restrict__ n_knots)
+{
+	__shared__ double A[kMaxRings][8];      // banded rows after elimination: columns j0 .. j0 + 6 of the row
+	__shared__ double prof[kMaxRings], x[kMaxRings], y[kMaxRings], trail[kMaxRings], t[kMaxRings + 8];
+	__shared__ int j0[kMaxRings];
+	const int frame = blockIdx.x;
+	if (frame >= n_frames || threadIdx.x != 0) return;
+	const double* s2 = modes + (int64_t)frame * n_rings;
+	double* kt = knots + (int64_t)frame * max_knots;
+	double* kc = coefs + (int64_t)frame * max_knots;
+	const int n = n_rings;
+	// ---- move_median_central: trailing nan-median over `width` points (bottleneck.move_median, min_count = 1), shifted to the
+	// centre, the ends redone over the first / last k + 2 points
+	if (width > 1) {
+		for (int i = 0; i < n; ++i) {
+			const int a0 = (i - width + 1 > 0) ? (i - width + 1) : 0;
+			trail[i] = nan_median(s2 + a0, i + 1 - a0);
+		}
+		// np.roll(trail, -width // 2 + 1): Python floor division of the NEGATED width
+		const int shift = -((width + 1) / 2) + 1;
+		for (int i = 0; i < n; ++i) prof[i] = trail[((i - shift) % n + n) % n];
+		for (int k = 0; k < width / 2 + 1 && k < n; ++k) {
+			const int c0 = (k + 2 < n) ? (k + 2) : n;
+			prof[k] = nan_median(s2, c0);
+			prof[n - 1 - k] = nan_median(s2 + n - c0, c0);
+		}
+	} else {
+		for (int i = 0; i < n; ++i) prof[i] = s2[i];
+	}
+	int m = 0;
+	for (int i = 0; i < n; ++i) if (prof[i] == prof[i]) { x[m] = bin_center[i]; y[m] = prof[i]; ++m; }
+	// fewer than 3 points: "The required number of points for qubic spline" (:183); exactly 3: FITPACK refuses (m > k)
+	if (m < 4 || m + 4 > max_knots) { n_knots[frame] = 0; return; }
+	// ---- knots
+	for (int i = 0; i < 4; ++i) { t[i] = x[0]; t[m + i] = x[m - 1]; }
+	for (int i = 4; i < m; ++i) t[i] = x[i - 2];
+	// ---- collocation rows: the four cubic B-splines that are non-zero at x[i] (de Boor's recurrence)
+	for (int i = 0; i < m; ++i) {
+		int l = 3;
+		while (l < m - 1 && x[i] >= t[l + 1]) ++l;     // t[l] <= x < t[l + 1]; the last point stays in the last interval
+		double h[4] = {1.0, 0.0, 0.0, 0.0}, hh[4];
+		for (int j = 1; j <= 3; ++j) {
+			for (int q = 0; q < j; ++q) hh[q] = h[q];
+			h[0] = 0.0;
+			for (int q = 0; q < j; ++q) {
+				const int li = l + q + 1, lj = li - j;
+				const double f = hh[q] / (t[li] - t[lj]);
+				h[q] += f * (t[li] - x[i]);
+				h[q + 1] = f * (x[i] - t[lj]);
+			}
+		}
+		// row i: columns l - 3 .. l; stored relative to the first column the elimination can still touch (i - 3 clipped)
+		j0[i] = (i - 3 > 0) ? (i - 3) : 0;
+		for (int q = 0; q < 8; ++q) A[i][q] = 0.0;
+		for (int q = 0; q < 4; ++q) { const int col = l - 3 + q - j0[i]; if (col >= 0 && col < 8) A[i][col] = h[q]; }
+	}
+	// ---- Gaussian elimination with partial pivoting inside the band (row i has non-zeros in columns i - 3 .. i + 3 at most)
+	for (int c = 0; c < m; ++c) {
+		// the rows that can have an entry in column c are c .. c + 3; left of column c they are already zero: re-base them to c
+		for (int r = c; r < m && r <= c + 3; ++r) {
+			const int sh = c - j0[r];
+			if (sh > 0) {
+				for (int q = 0; q < 8; ++q) A[r][q] = (q + sh < 8) ? A[r][q + sh] : 0.0;
+				j0[r] = c;
+			}
+		}
+		int piv = c;
+		double best = 0.0;
+		for (int r = c; r < m && r <= c + 3; ++r) {
+			const double v = fabs(A[r][0]);
+			if (v > best) { best = v; piv = r; }
+		}
+		if (piv != c) {
+			for (int q = 0; q < 8; ++q) { const double tmp = A[c][q]; A[c][q] = A[piv][q]; A[piv][q] = tmp; }
+			const double ty = y[c]; y[c] = y[piv]; y[piv] = ty;
+		}
+		const double d = A[c][0];
+		for (int r = c + 1; r < m && r <= c + 3; ++r) {
+			if (A[r][0] == 0.0) continue;
+			const double f = A[r][0] / d;
+			for (int q = 0; q < 7; ++q) A[r][q] -= f * A[c][q];   // after the exchanges a row reaches at most column c + 6
+			y[r] -= f * y[c];
+		}
+	}
+	for (int c = m - 1; c >= 0; --c) {   // row c is stored from column c on
+		double acc = y[c];
+		for (int q = 1; q < 7 && c + q < m; ++q) acc -= A[c][q] * y[c + q];
+		y[c] = acc / A[c][0];
+	}
+	for (int i = 0; i < m + 4; ++i) kt[i] = t[i];
+	for (int i = 0; i < m; ++i) kc[i] = y[i];
+	n_knots[frame] = m + 4;
+}
+
 struct EvalArgs {
 	int n_rows, n_cols; int64_t frame_stride;
 	double col_offset, xcen, ycen;
@@ -441,6 +555,22 @@ extern "C" int tp_radial_evaluate(tp_ctx* ctx, int32_t n_frames, int32_t frame_r
 	dim3 grid((unsigned)((frame_cols + 255) / 256), (unsigned)frame_rows, (unsigned)n_frames);
 	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_eval_kernel, grid, dim3(256), (size_t)max_knots * 2 * sizeof(double), a);
 	TP_LAUNCH_CHECK(ctx, "tp_radial_eval_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_radial_profiles(tp_ctx* ctx, int32_t n_frames, int32_t n_rings, const double* d_modes, const double* d_bin_center,
+	int32_t radial_smooth, int32_t max_knots, double* d_knots, double* d_coefs, int32_t* d_n_knots)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_modes && d_bin_center && d_knots && d_coefs && d_n_knots, "tp_radial_profiles: null pointer");
+	TP_REQUIRE(ctx, n_frames >= 0 && n_rings >= 1 && n_rings <= kMaxRings, "tp_radial_profiles: at most 64 rings");
+	TP_REQUIRE(ctx, radial_smooth >= 0 && radial_smooth <= 8 && max_knots >= n_rings + 4, "tp_radial_profiles: radial_smooth must be 0..8, max_knots >= n_rings + 4");
+	if (n_frames == 0) return TP_OK;
+	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_profile_kernel, dim3((unsigned)n_frames), dim3(64), 0, d_modes, d_bin_center, (int)n_rings,
+		(int)radial_smooth, (int)n_frames, (int)max_knots, d_knots, d_coefs, d_n_knots);
+	TP_LAUNCH_CHECK(ctx, "tp_radial_profile_kernel");
 	return TP_OK;
 	TP_API_END(ctx)
 }

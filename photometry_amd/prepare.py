@@ -152,30 +152,44 @@ def radial_profiles(s2, bin_center, radial_smooth=3, max_knots=None):
 	return knots, coefs, n_knots
 
 
-def _square_component(ctx, frames, flux_cutoff, box, exclude, estride, subtract, out):
-	"""Background2D of ``frames - subtract`` (backgrounds.py:199-206): mesh statistics and zoom on the device, the mesh itself on the host."""
+def _square_component(ctx, frames, flux_cutoff, box, exclude, estride, subtract, out, want_host=False, work=None):
+	"""
+	Background2D of ``frames - subtract`` (backgrounds.py:199-206), everything on the device: per-cell statistics
+	(``tp_background_mesh``), the low-resolution finishing -- excluded cells filled, 3 x 3 median filter, spline prefilter
+	(``tp_background_mesh_finish``) -- and the cubic-spline zoom (``tp_background_zoom``); no host round trip.  ``want_host``:
+	also return the host copies of the cell statistics and masked-pixel counts.  ``work``: dict that keeps the small device
+	arrays between calls of one ``fit_background_frames``.
+	"""
 	T, R, C = frames.shape
 	ny, nx = -(-R // box), -(-C // box)
-	mesh = ctx.empty((T, ny, nx), 'float64')
-	nmasked = ctx.empty((T, ny, nx), 'int32')
+	work = {} if work is None else work
+	if 'mesh' not in work:
+		work.update(mesh=ctx.empty((T, ny, nx), 'float64'), nmasked=ctx.empty((T, ny, nx), 'int32'), coef=ctx.empty((T, ny, nx), 'float64'),
+			vmin=ctx.empty((T,), 'float64'), vmax=ctx.empty((T,), 'float64'))
+	mesh, nmasked, coef, vmin, vmax = (work[k] for k in ('mesh', 'nmasked', 'coef', 'vmin', 'vmax'))
 	ctx._check(ctx.lib.tp_background_mesh(ctx.handle, frames.ptr, T, R, C, C, R * C, None if exclude is None else exclude.ptr, estride,
 		None if subtract is None else subtract.ptr, R * C, float(flux_cutoff), int(box), mesh.ptr, nmasked.ptr))
-	mesh_h, nm_h = mesh.to_host(), nmasked.to_host()
-	m = finish_mesh(mesh_h, nm_h, box)
-	vmin, vmax = np.min(m, axis=(1, 2)), np.max(m, axis=(1, 2))
-	# the cubic-spline coefficients scipy.ndimage.zoom(order=3, mode='reflect') interpolates from (separable: one pass per axis)
-	coef = m
-	if min(ny, nx) > 1:
-		coef = ndimage.spline_filter1d(ndimage.spline_filter1d(m, order=3, axis=1, mode='reflect'), order=3, axis=2, mode='reflect')
-	if min(ny, nx) > 1:
-		d_coef, d_vmin, d_vmax = ctx.array(coef), ctx.array(vmin), ctx.array(vmax)   # kept alive until the kernel has run
-		ctx._check(ctx.lib.tp_background_zoom(ctx.handle, d_coef.ptr, d_vmin.ptr, d_vmax.ptr, T, ny, nx, int(box), R, C, C, R * C, out.ptr))
-		ctx.sync()
+	if ny * nx <= 2048:
+		ctx._check(ctx.lib.tp_background_mesh_finish(ctx.handle, mesh.ptr, nmasked.ptr, T, ny, nx, int(box), 50.0, 3, coef.ptr, vmin.ptr, vmax.ptr, None))
 	else:
+		# a mesh beyond the LDS-resident kernel (frames above ~2900 pixels a side): finished on the host like round 2
+		m = finish_mesh(mesh.to_host(), nmasked.to_host(), box)
+		c = m
+		if min(ny, nx) > 1:
+			c = ndimage.spline_filter1d(ndimage.spline_filter1d(m, order=3, axis=1, mode='reflect'), order=3, axis=2, mode='reflect')
+		for dst, src in ((coef, c), (vmin, np.min(m, axis=(1, 2))), (vmax, np.max(m, axis=(1, 2)))):
+			a = np.ascontiguousarray(src, dtype='float64')
+			ctx._check(ctx.lib.tp_memcpy_h2d(ctx.handle, dst.ptr, a.ctypes.data, a.nbytes))
+	if min(ny, nx) > 1:
+		ctx._check(ctx.lib.tp_background_zoom(ctx.handle, coef.ptr, vmin.ptr, vmax.ptr, T, ny, nx, int(box), R, C, C, R * C, out.ptr))
+	else:
+		# a single row / column of cells: ndimage.zoom of a length-1 axis is constant along it; photutils' answer is the cell value
 		host = np.empty((T, R, C), dtype='float32')
-		host[:] = coef[:, :1, :1]
+		host[:] = coef.to_host()[:, :1, :1]
 		ctx._check(ctx.lib.tp_memcpy_h2d(ctx.handle, out.ptr, host.ctypes.data, host.nbytes))
-	return mesh_h, nm_h
+	if want_host:
+		return mesh.to_host(), nmasked.to_host()
+	return None, None
 
 
 def fit_background_frames(ctx, frames, flux_cutoff=8e4, box=64, exclude=None, out=None, return_mask=False,
@@ -197,8 +211,10 @@ def fit_background_frames(ctx, frames, flux_cutoff=8e4, box=64, exclude=None, ou
 	estride = 0 if exclude is None or len(exclude.shape) == 2 else R * C
 	if out is None:
 		out = ctx.empty((T, R, C), 'float32')
+	work = {}
 	if camera is None and ccd is None and geometry is None:
-		mesh_h, nm_h = _square_component(ctx, frames, flux_cutoff, box, exclude, estride, None, out)
+		mesh_h, nm_h = _square_component(ctx, frames, flux_cutoff, box, exclude, estride, None, out, want_host=return_mask, work=work)
+		ctx.sync()   # the small work arrays go out of scope with this call
 		return (out, mesh_h, nm_h) if return_mask else out
 
 	geo = geometry if geometry is not None else RadialGeometry((R, C), camera, ccd, radial_cutoff, radial_pixel_step)
@@ -217,28 +233,40 @@ def fit_background_frames(ctx, frames, flux_cutoff=8e4, box=64, exclude=None, ou
 	bw_constant /= (2 * 2 * 24.0 * 1.0**2)
 	bw_constant = 2 * bw_constant**(1.0 / 5)
 	ex_ptr = None if exclude is None else exclude.ptr
+	# the ring profile (3-point median, interpolating spline through the rings that have a mode) on the device when it fits the
+	# kernel (<= 64 rings: a 2048 x 2048 CCD has 39); otherwise on the host with the reference's own scipy call
+	on_device = geo.n_rings <= 64 and (radial_smooth or 0) <= 8
+	K = max(geo.n_rings + 4, 8)
+	d_bin_center = ctx.array(np.asarray(geo.bin_center, dtype='float64'))
+	d_knots, d_coefs, d_nk = ctx.zeros((T, K), 'float64'), ctx.zeros((T, K), 'float64'), ctx.zeros((T,), 'int32')
+	mesh_h = nm_h = None
 	for it in range(int(bkgiters)):
 		sq_ptr = None if square is None else square.ptr
 		ctx._check(ctx.lib.tp_radial_zeropoint(ctx.handle, frames.ptr, T, R * C, R * C, sq_ptr, R * C, ex_ptr, estride, float(flux_cutoff),
 			d_partial.ptr, n_partial, d_zp.ptr))
 		ctx._check(ctx.lib.tp_radial_ring_modes(ctx.handle, frames.ptr, T, R * C, R * C, sq_ptr, R * C, ex_ptr, estride, float(flux_cutoff),
 			d_zp.ptr, d_pixels.ptr, d_offsets.ptr, geo.n_rings, n_ring_pixels, float(bw_constant), d_scratch.ptr, d_modes.ptr, d_counts.ptr))
-		s2 = d_modes.to_host()
-		knots, coefs, n_knots = radial_profiles(s2, geo.bin_center, radial_smooth)
-		d_knots, d_coefs, d_nk = ctx.array(knots), ctx.array(coefs), ctx.array(n_knots)
+		if on_device:
+			ctx._check(ctx.lib.tp_radial_profiles(ctx.handle, T, geo.n_rings, d_modes.ptr, d_bin_center.ptr, int(radial_smooth or 0), K,
+				d_knots.ptr, d_coefs.ptr, d_nk.ptr))
+		else:
+			knots, coefs, n_knots = radial_profiles(d_modes.to_host(), geo.bin_center, radial_smooth, max_knots=K)
+			for dst, src in ((d_knots, knots), (d_coefs, coefs), (d_nk, n_knots)):
+				ctx._check(ctx.lib.tp_memcpy_h2d(ctx.handle, dst.ptr, src.ctypes.data, src.nbytes))
 		ctx._check(ctx.lib.tp_radial_evaluate(ctx.handle, T, R, C, R * C, float(TESS_SCIENCE_COLUMN), float(geo.xcen), float(geo.ycen),
-			d_knots.ptr, d_coefs.ptr, d_nk.ptr, knots.shape[1], d_zp.ptr, None, 0, radial.ptr))
+			d_knots.ptr, d_coefs.ptr, d_nk.ptr, K, d_zp.ptr, None, 0, radial.ptr))
 		if square is None:
 			square = ctx.empty((T, R, C), 'float32')
-		mesh_h, nm_h = _square_component(ctx, frames, flux_cutoff, box, exclude, estride, radial, square)
+		last = it == int(bkgiters) - 1
+		mesh_h, nm_h = _square_component(ctx, frames, flux_cutoff, box, exclude, estride, radial, square, want_host=return_mask and last, work=work)
 		if details is not None:
-			details.setdefault('s2', []).append(s2)
+			details.setdefault('s2', []).append(d_modes.to_host())
 			details.setdefault('zeropoint', []).append(d_zp.to_host())
-			details.setdefault('n_knots', []).append(n_knots)
+			details.setdefault('n_knots', []).append(d_nk.to_host())
 			details.setdefault('counts', []).append(d_counts.to_host())
 	# total background (:209); a frame in which everything is masked is NaN (:99-102)
 	ctx._check(ctx.lib.tp_radial_evaluate(ctx.handle, T, R, C, R * C, float(TESS_SCIENCE_COLUMN), float(geo.xcen), float(geo.ycen),
-		d_knots.ptr, d_coefs.ptr, d_nk.ptr, knots.shape[1], d_zp.ptr, square.ptr, R * C, out.ptr))
+		d_knots.ptr, d_coefs.ptr, d_nk.ptr, K, d_zp.ptr, square.ptr, R * C, out.ptr))
 	ctx.sync()
 	return (out, mesh_h, nm_h) if return_mask else out
 

@@ -253,6 +253,71 @@ def test_fit_background_tess_full_frames(ctx):
 	assert flipped <= 9 and err.max() < (2e-3 if flipped else 1e-5)
 
 
+def test_mesh_finish_and_ring_profiles_on_device(ctx):
+	"""The two small device passes that replaced host numpy / scipy work in the full-frame background: the finishing of the
+	low-resolution mesh (excluded cells, 3 x 3 nan-median, scipy.ndimage spline prefilter) and the ring profile (moving median,
+	interpolating cubic spline in FITPACK form) -- each against the host functions that call numpy / scipy themselves."""
+	from scipy import ndimage
+	from scipy.interpolate import InterpolatedUnivariateSpline
+	from photometry_amd import prepare
+	rng = np.random.default_rng(21)
+	T, ny, nx, box = 7, 32, 32, 64
+	mesh = rng.normal(150, 5, (T, ny, nx))
+	nm = rng.integers(0, 1000, (T, ny, nx)).astype('int32')
+	nm[0, 3:9, 4:20] = 3000                       # a block of excluded cells
+	nm[1, :, :] = 4096; nm[1, 10, 11] = 5         # one kept cell
+	nm[2, :, :] = 4000                            # nothing kept
+	mesh[3, 5, 5] = np.nan; mesh[3, 0, 0] = np.nan # non-finite statistics count as excluded
+	nm[4, ::2, :] = 2500                          # every other row excluded
+	nm[5, 0, :] = 2049; nm[5, :, -1] = 2049       # edges excluded (2048 = exactly 50 % is still kept)
+	nm[6, 7, 7] = 2048
+	coef, vmin, vmax, filt = ctx.empty((T, ny, nx), 'float64'), ctx.empty((T,), 'float64'), ctx.empty((T,), 'float64'), ctx.empty((T, ny, nx), 'float64')
+	ctx._check(ctx.lib.tp_background_mesh_finish(ctx.handle, ctx.array(mesh).ptr, ctx.array(nm).ptr, T, ny, nx, box, 50.0, 3, coef.ptr, vmin.ptr, vmax.ptr, filt.ptr))
+	ref = prepare.finish_mesh(mesh, nm, box)
+	got = filt.to_host()
+	assert np.all(np.isnan(got[2])) and np.all(np.isnan(ref[2]))
+	np.testing.assert_allclose(got, ref, rtol=1e-14, equal_nan=True)
+	c = ndimage.spline_filter1d(ndimage.spline_filter1d(ref, order=3, axis=1, mode='reflect'), order=3, axis=2, mode='reflect')
+	np.testing.assert_allclose(coef.to_host(), c, rtol=1e-12, atol=1e-10, equal_nan=True)
+	np.testing.assert_array_equal(vmin.to_host(), np.min(ref, axis=(1, 2)))
+	np.testing.assert_array_equal(vmax.to_host(), np.max(ref, axis=(1, 2)))
+	# a non-square mesh and no filter
+	mesh2 = rng.normal(10, 1, (2, 5, 9)); nm2 = np.zeros((2, 5, 9), dtype='int32'); nm2[0, 2, 3:6] = 4096
+	coef2, f2 = ctx.empty((2, 5, 9), 'float64'), ctx.empty((2, 5, 9), 'float64')
+	ctx._check(ctx.lib.tp_background_mesh_finish(ctx.handle, ctx.array(mesh2).ptr, ctx.array(nm2).ptr, 2, 5, 9, box, 50.0, 1, coef2.ptr, vmin.ptr, vmax.ptr, f2.ptr))
+	ref2 = prepare.finish_mesh(mesh2, nm2, box, filter_size=1)
+	np.testing.assert_allclose(f2.to_host(), ref2, rtol=1e-14)
+	# short axes: the causal initialisation of scipy's prefilter (accumulated in place) matters most here
+	c2 = ndimage.spline_filter1d(ndimage.spline_filter1d(ref2, order=3, axis=1, mode='reflect'), order=3, axis=2, mode='reflect')
+	np.testing.assert_allclose(coef2.to_host(), c2, rtol=1e-13)
+
+	# ---- ring profiles
+	nr = 39
+	bc = 2400.0 + 15.0 * np.arange(nr) + 7.5
+	s2 = 2.0 + 0.004 * np.arange(nr)[None, :] + rng.normal(0, 2e-3, (9, nr))
+	s2[1, 0] = np.nan; s2[1, 17:20] = np.nan; s2[1, -1] = np.nan
+	s2[2, :] = np.nan; s2[2, 5] = 2.0; s2[2, 6] = 2.1                      # two usable rings: no radial component
+	s2[3, :] = np.nan; s2[3, 3:8] = [2.0, 2.1, 2.05, 2.2, 2.15]           # a short run
+	s2[4, ::2] = np.nan                                                    # every other ring missing: medians fill them
+	s2[5, :] = np.nan; s2[5, [4, 20, 30]] = 2.0                            # isolated rings
+	for smooth in (3, 0, 5):
+		K = nr + 4
+		knots, coefs, nk = ctx.zeros((9, K), 'float64'), ctx.zeros((9, K), 'float64'), ctx.zeros((9,), 'int32')
+		ctx._check(ctx.lib.tp_radial_profiles(ctx.handle, 9, nr, ctx.array(s2).ptr, ctx.array(bc).ptr, smooth, K, knots.ptr, coefs.ptr, nk.ptr))
+		kn, co, n = knots.to_host(), coefs.to_host(), nk.to_host()
+		for k in range(9):
+			prof = prepare._move_median_central(s2[k], smooth) if smooth else s2[k]
+			good = ~np.isnan(prof)
+			if good.sum() < 4:
+				assert n[k] == 0
+				continue
+			t, c, _ = InterpolatedUnivariateSpline(bc[good], prof[good], k=3, ext=3)._eval_args
+			assert n[k] == len(t)
+			np.testing.assert_array_equal(kn[k, :len(t)], t)
+			m = int(good.sum())
+			np.testing.assert_allclose(co[k, :m], c[:m], rtol=1e-11, atol=1e-12)
+
+
 def test_radial_pieces(ctx):
 	"""Zero point, ring counts and the spline evaluation, each against numpy / scipy directly."""
 	from photometry_amd import prepare
