@@ -145,7 +145,30 @@ __global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a,
 		if (lane == 0 && a.big_list) a.big_list[1 + atomicAdd(&a.big_list[0], 1)] = target;
 		return;
 	}
-	tp_ap::extract_small_stream<VEC, HAS_SUB, BKG>(a, target, s_list, M, lane, 64);
+	// the series a lane needs in every pixel group (subtracted series, background series: the same array in the background-in-
+	// the-step configuration) are staged once in the part of the LDS the mask builder no longer needs: [smem, s_list)
+	const float* lds_sub = nullptr;
+	const float* lds_ser = nullptr;
+	{
+		constexpr bool SER = (BKG == 1);
+		const float* gsub = HAS_SUB ? (a.subtract + (int64_t)target * a.subtract_pitch) : nullptr;
+		const float* gser = SER ? (a.backgrounds + (int64_t)target * a.bkg_series_pitch) : nullptr;
+		const int nflt = (a.n_cad + VEC - 1) / VEC * VEC;                       // what the VEC-wide reads touch
+		const int room = (int)((reinterpret_cast<unsigned char*>(s_list) - smem) / sizeof(float));
+		float* stage = reinterpret_cast<float*>(smem);
+		const bool same = HAS_SUB && SER && (gsub == gser);
+		const int need = ((HAS_SUB ? 1 : 0) + ((SER && !same) ? 1 : 0)) * nflt;
+		if ((HAS_SUB || SER) && need > 0 && need <= room) {
+			if (HAS_SUB) { for (int i = lane; i < nflt; i += 64) stage[i] = gsub[(i < a.n_cad) ? i : (a.n_cad - 1)]; lds_sub = stage; }
+			if (SER) {
+				if (same) lds_ser = stage;
+				else { float* st2 = stage + (HAS_SUB ? nflt : 0); for (int i = lane; i < nflt; i += 64) st2[i] = gser[(i < a.n_cad) ? i : (a.n_cad - 1)]; lds_ser = st2; }
+			}
+			__syncthreads();
+		}
+	}
+	if ((HAS_SUB && lds_sub) || (BKG == 1 && lds_ser)) tp_ap::extract_small_stream<VEC, HAS_SUB, BKG, true>(a, target, s_list, M, lane, 64, lds_sub, lds_ser);
+	else tp_ap::extract_small_stream<VEC, HAS_SUB, BKG, false>(a, target, s_list, M, lane, 64);
 }
 
 } // namespace
