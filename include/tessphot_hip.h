@@ -369,11 +369,12 @@ int tp_radial_evaluate(tp_ctx* ctx, int32_t n_frames, int32_t frame_rows, int32_
  *   d_fluxes_all float64 [n_fit_stars][out_pitch] every fitted flux; d_contamination float64 (PSF_CONT,
  *   :203-211); d_status int32 (OK, WARNING if contamination > 0.1, ERROR if all fluxes are NaN);
  *   d_fluxes_mean optional float64 [n_fit_stars].
- * tp_linpsf_set_path chooses between the two mappings of the fit that exist for targets with up to 4 fitted stars and up
- *   to 256 pixels within reach of their cut-off circles: 0 (default) the vector-ALU kernels (one cadence per lane, scalar-
- *   loaded polynomial coefficients), 1 the matrix-core kernel (v_mfma_f64_16x16x4_f64 on the monomial form of the
- *   pixel-integrated PRF, operands staged by LDS DMA).  Same results to rounding (1e-13); on the measured workloads the
- *   vector-ALU kernels are the faster ones, which is why they are the default.   */
+ * tp_linpsf_set_path chooses between the two mappings of the fit that exist for targets with up to 4 fitted stars, up to 256
+ *   pixels within reach of their cut-off circles and stars that visit at most 3 x 3 knot intervals of the PRF grid: 1 (default)
+ *   the matrix-core kernel (v_mfma_f64_16x16x4_f64 on ONE tensor-product quartic spline per star and pixel, cadences in
+ *   their natural order, the target's coefficients resident in LDS); 0 the vector-ALU kernels (one cadence per lane, cadences
+ *   sorted by table origin, scalar-loaded polynomial coefficients) for every target.  Targets that do not qualify take the
+ *   vector-ALU kernels either way.  Same results to rounding (1e-13).   */
 int tp_linpsf_prf(tp_ctx* ctx, int32_t n_targets, int32_t n_samples, int32_t n_coef,
 	const double* d_base_coef, const double* d_weights, double* d_coef);
 int tp_linpsf_set_path(tp_ctx* ctx, int32_t path);

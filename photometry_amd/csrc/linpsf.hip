@@ -217,10 +217,11 @@ __device__ __forceinline__ double fma_sgpr_addend(double a, double b, double c) 
 // inverse of the reflected Gray code n ^ (n >> 1) on 4 bits: the place of a membership pattern in the order 1,3,2,6,7,5,4,12,...
 __device__ __forceinline__ unsigned gray_rank4(unsigned g) { g ^= g >> 2; g ^= g >> 1; return g & 15u; }
 
-// totals[0]: items (25 doubles each) of the polynomial store; totals[1]: doubles of the matrix-core store (laid behind it)
+// totals: kTotPolyItems items (25 doubles each) of the polynomial store; kTotKDoubles doubles of the matrix-core store (laid behind
+// it); kTotPolyTargets targets left to the vector-ALU fit; kTotClass0 + c targets of class c of the matrix-core fit (class_lists[c][..])
 __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan* __restrict__ plans, int32_t* __restrict__ todo,
 	unsigned long long* __restrict__ totals, int max_origins, int32_t* __restrict__ order, int sort_n,
-	MPlan* __restrict__ mplans, uint16_t* __restrict__ ulist, uint8_t* __restrict__ usig, int use_mfma)
+	MPlan* __restrict__ mplans, uint16_t* __restrict__ ulist, uint8_t* __restrict__ usig, int use_mfma, int32_t* __restrict__ class_lists, int n_targets)
 {
 	extern __shared__ unsigned long long skeys[];   // [sort_n] (key of the cadence's origins) * 8192 + cadence, or nothing
 	__shared__ StarBox sbox[kMaxStars];
@@ -362,32 +363,48 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 		}
 		__syncthreads();
 	}
-	const int path = s_path;
 	if (tid == 0) {
-		if (path == kPathDirect) todo[target] = kPathDirect;
-		else if (path == kPathMfma) {
+		int path = s_path;
+		if (path == kPathMfma) {
+			// one spline per star over the knot intervals it visits (at most 3 x 3), the target's coefficient image within the LDS
+			// of its class; otherwise the vector-ALU kernels take the target
 			MPlan mp;
 			mp.n_pix = s_nkeys; mp.n_tiles = (s_nkeys + 15) >> 4;
-			long long need = 0;
+			long long blocks = 0;
+			bool fits = true;
 			for (int s = 0; s < kMfmaStars; ++s) {
 				mp.tiles[s] = (s < ns) ? s_tiles[s] : 0u;
 				mp.edge_tiles[s] = (s < ns) ? s_etiles[s] : 0u;
-				mp.koff[s] = need;
-				if (s < ns) need += (long long)spl[s].nc * __popc(mp.tiles[s]) * (7 * 64);
+				mp.ksub[s] = (uint16_t)blocks;
+				int na = 0, nb = 0;
+				if (s < ns && spl[s].nc > 0) { nb = spl[s].nby; na = spl[s].nc / nb; }
+				if (na > kMfmaSpan || nb > kMfmaSpan) fits = false;
+				mp.na[s] = (uint8_t)na; mp.nb[s] = (uint8_t)nb;
+				if (na > 0) blocks += (long long)__popc(mp.tiles[s]) * mfma_steps(na, nb);
 			}
-			const long long base = (long long)atomicAdd(&totals[1], (unsigned long long)need);
-			for (int s = 0; s < kMfmaStars; ++s) mp.koff[s] += base;
-			mplans[target] = mp;
-			for (int s = 0; s < ns; ++s) plans[(int64_t)target * kMaxStars + s] = spl[s];
-			todo[target] = kPathMfma;
-		} else {
+			const bool large = blocks * 512 > kMfmaLdsSmall;
+			if (blocks * 512 > ((ns <= 1) ? kMfmaLdsSmall : kMfmaLdsLarge)) fits = false;
+			if (fits) {
+				mp.kdoubles = (int32_t)(blocks * 64);
+				mp.koff = (long long)atomicAdd(&totals[kTotKDoubles], (unsigned long long)(blocks * 64));
+				mplans[target] = mp;
+				for (int s = 0; s < ns; ++s) plans[(int64_t)target * kMaxStars + s] = spl[s];
+				todo[target] = kPathMfma;
+				const int cls = (ns - 1) * 2 + (large ? 1 : 0);
+				const unsigned long long at = atomicAdd(&totals[kTotClass0 + cls], 1ull);
+				class_lists[(int64_t)cls * n_targets + (int64_t)at] = target;
+			} else path = kPathPoly;
+		}
+		if (path == kPathDirect) todo[target] = kPathDirect;
+		else if (path == kPathPoly) {
 			long long items = 0;
 			for (int s = 0; s < ns; ++s) {
 				StarPlan& q = spl[s];
 				q.item_off = items;
 				if (q.nc > 0) items += (long long)q.nc * (q.jmax - q.jmin + 1) * (q.imax - q.imin + 1);
 			}
-			const long long base = (long long)atomicAdd(&totals[0], (unsigned long long)items);
+			const long long base = (long long)atomicAdd(&totals[kTotPolyItems], (unsigned long long)items);
+			atomicAdd(&totals[kTotPolyTargets], 1ull);
 			for (int s = 0; s < ns; ++s) { spl[s].item_off += base; plans[(int64_t)target * kMaxStars + s] = spl[s]; }
 			s_ok = 1;
 		}
@@ -486,9 +503,13 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 	__syncthreads();
 	const double* C = ctab;
 	if (path == kPathMfma) {
-		// matrix-core layout: per (star, origin, tile of the star) the A operands of the 7 MFMA steps, lane = (monomial group g,
-		// pixel u of the tile); monomial of (step j, group g): j < 5: phi_x^j phi_y^g; j = 5: phi_x^g phi_y^4; j = 6: g = 0:
-		// phi_x^4 phi_y^4, else a zero pad.  Pixels of the tile the star never reaches get zeros.
+		// matrix-core layout (linpsf_mfma.hip): per (star, tile of the star) the A operands of the MFMA steps, lane = (group g,
+		// pixel u of the tile).  The coefficients are those of the tensor-product quartic spline over the na x nb knot intervals
+		// the star visits, in the basis {1, X, X^2, X^3, X^4, (X-1)+^4, (X-2)+^4} x {the same in Y}: ce[e][d] (e, d <= 4) is the
+		// biquartic of interval (0, 0); a quartic spline changes only its leading coefficient at a knot, so the coefficient of
+		// (X-a)+^4 Y^d is K(a,0)[4][d] - K(a-1,0)[4][d], of X^e (Y-b)+^4 it is K(0,b)[e][4] - K(0,b-1)[e][4], and of (X-a)+^4 (Y-b)+^4
+		// the second difference of K[4][4] -- every interval's 13 x 13 patch is contracted as for the vector-ALU path.
+		// Pixels of the tile the star never reaches get zeros.
 		const MPlan mp = mplans[target];
 		const uint16_t* ul = ulist + (int64_t)target * kMfmaPixels;
 		const uint8_t* us = usig + (int64_t)target * kMfmaPixels;
@@ -496,39 +517,81 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 			const StarPlan p = plans[(int64_t)target * kMaxStars + s];
 			const unsigned tiles = mp.tiles[s];
 			const int nt = __popc(tiles);
-			const int nitems = p.nc * nt * 16;
-			for (int item = tid; item < nitems; item += 512) {
-				const int co = item / (nt * 16), rem = item - co * (nt * 16);
-				const int r = rem >> 4, u = rem & 15;
+			const int na = mp.na[s], nb = mp.nb[s];
+			if (na == 0) continue;
+			const int nk = mfma_steps(na, nb);
+			for (int item = tid; item < nt * 16; item += 512) {
+				const int r = item >> 4, u = item & 15;
 				unsigned m = tiles;
 				for (int q = 0; q < r; ++q) m &= m - 1;          // drop the r lowest set bits
 				const int tile = __ffs(m) - 1;
 				const int slot = tile * 16 + u;
 				const unsigned pix = ul[slot];
-				double kk[5][5];
+				double ce[7][7];
+#pragma unroll
+				for (int e = 0; e < 7; ++e)
+#pragma unroll
+					for (int d = 0; d < 7; ++d) ce[e][d] = 0.0;
 				if (pix != 0xffffu && ((us[slot] >> s) & 1)) {
 					const int i = (int)pix / a.width, j = (int)pix - i * a.width;
-					const int cx = co / p.nby, cy = co - cx * p.nby;
-					int ax = (p.axmin + cx) + 9 * j, by = (p.bymin + cy) + 9 * i;
-					ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
-					by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
-					patch_coefficients(C, n, ax, by, h2, kk);
-				} else {
 #pragma unroll
-					for (int e = 0; e < 5; ++e)
+					for (int ca = 0; ca < kMfmaSpan; ++ca) {
 #pragma unroll
-						for (int d = 0; d < 5; ++d) kk[e][d] = 0.0;
+						for (int cb = 0; cb < kMfmaSpan; ++cb) {
+							if (ca >= na || cb >= nb) continue;
+							int ax = (p.axmin + ca) + 9 * j, by = (p.bymin + cb) + 9 * i;
+							ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
+							by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
+							double kk[5][5];
+							patch_coefficients(C, n, ax, by, h2, kk);
+							if (ca == 0 && cb == 0) {
+#pragma unroll
+								for (int e = 0; e < 4; ++e)
+#pragma unroll
+									for (int d = 0; d < 4; ++d) ce[e][d] = kk[e][d];
+							}
+							if (cb == 0) {
+#pragma unroll
+								for (int d = 0; d < 4; ++d) { ce[4 + ca][d] += kk[4][d]; if (ca + 1 < kMfmaSpan && ca + 1 < na) ce[5 + ca][d] -= kk[4][d]; }
+							}
+							if (ca == 0) {
+#pragma unroll
+								for (int e = 0; e < 4; ++e) { ce[e][4 + cb] += kk[e][4]; if (cb + 1 < kMfmaSpan && cb + 1 < nb) ce[e][5 + cb] -= kk[e][4]; }
+							}
+							const double k44 = kk[4][4];
+							ce[4 + ca][4 + cb] += k44;
+							if (ca + 1 < kMfmaSpan && ca + 1 < na) ce[5 + ca][4 + cb] -= k44;
+							if (cb + 1 < kMfmaSpan && cb + 1 < nb) ce[4 + ca][5 + cb] -= k44;
+							if (ca + 1 < kMfmaSpan && cb + 1 < kMfmaSpan && ca + 1 < na && cb + 1 < nb) ce[5 + ca][5 + cb] += k44;
+						}
+					}
 				}
-				double* dst = kstore + mp.koff[s] + ((int64_t)(co * nt + r) * 7) * 64 + u;
+				// steps: E = 0..4 (x basis E, y basis g); y basis 4 with x basis g, then 4 + g; x basis 5, 6 where visited; y basis 5, 6
+				double* dst = kstore + mp.koff + ((int64_t)mp.ksub[s] + (int64_t)r * nk) * 64 + u;
+				int idx = 0;
 #pragma unroll
-				for (int j = 0; j < 5; ++j)
+				for (int e = 0; e < 5; ++e, ++idx)
 #pragma unroll
-					for (int g = 0; g < 4; ++g) dst[j * 64 + g * 16] = kk[j][g];
+					for (int g = 0; g < 4; ++g) dst[idx * 64 + g * 16] = ce[e][g];
 #pragma unroll
-				for (int g = 0; g < 4; ++g) dst[5 * 64 + g * 16] = kk[g][4];
-				dst[6 * 64] = kk[4][4];
+				for (int g = 0; g < 4; ++g) { dst[idx * 64 + g * 16] = ce[g][4]; dst[(idx + 1) * 64 + g * 16] = (g < 3) ? ce[4 + g][4] : 0.0; }
+				idx += 2;
 #pragma unroll
-				for (int g = 1; g < 4; ++g) dst[6 * 64 + g * 16] = 0.0;
+				for (int ea = 1; ea < kMfmaSpan; ++ea) {
+					if (ea < na) {
+#pragma unroll
+						for (int g = 0; g < 4; ++g) dst[idx * 64 + g * 16] = ce[4 + ea][g];
+						++idx;
+					}
+				}
+#pragma unroll
+				for (int db = 1; db < kMfmaSpan; ++db) {
+					if (db < nb) {
+#pragma unroll
+						for (int g = 0; g < 4; ++g) { dst[idx * 64 + g * 16] = ce[g][4 + db]; dst[(idx + 1) * 64 + g * 16] = (g < 3) ? ce[4 + g][4 + db] : 0.0; }
+						idx += 2;
+					}
+				}
 			}
 		}
 		return;
@@ -1082,7 +1145,7 @@ extern "C" int tp_linpsf_prf(tp_ctx* ctx, int32_t n_targets, int32_t n_samples, 
 extern "C" int tp_linpsf_set_path(tp_ctx* ctx, int32_t path)
 {
 	TP_CHECK_CTX(ctx);
-	TP_REQUIRE(ctx, path == 0 || path == 1, "tp_linpsf_set_path: 0 (vector-ALU kernels) or 1 (matrix-core fit where a target qualifies)");
+	TP_REQUIRE(ctx, path == 0 || path == 1, "tp_linpsf_set_path: 1 (matrix-core fit where a target qualifies) or 0 (vector-ALU kernels only)");
 	ctx->linpsf_path = path;
 	return TP_OK;
 }
@@ -1130,7 +1193,8 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	const size_t mplan_bytes = ((size_t)desc->n_targets * sizeof(MPlan) + 255) & ~(size_t)255;
 	const size_t ulist_bytes = ((size_t)desc->n_targets * kMfmaPixels * sizeof(uint16_t) + 255) & ~(size_t)255;
 	const size_t usig_bytes = ((size_t)desc->n_targets * kMfmaPixels * sizeof(uint8_t) + 255) & ~(size_t)255;
-	const size_t head_bytes = todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes + usig_bytes;
+	const size_t lists_bytes = ((size_t)desc->n_targets * kMfmaClasses * sizeof(int32_t) + 255) & ~(size_t)255;
+	const size_t head_bytes = todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes + usig_bytes + lists_bytes;
 	TP_REQUIRE(ctx, tp_ctx_scratch(ctx, head_bytes) != nullptr, "tp_linpsf_fit: out of device memory for the plan");
 	char* sbase = static_cast<char*>(ctx->scratch);
 	int32_t* d_todo = reinterpret_cast<int32_t*>(sbase);
@@ -1140,22 +1204,23 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	MPlan* d_mplans = reinterpret_cast<MPlan*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes);
 	uint16_t* d_ulist = reinterpret_cast<uint16_t*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes);
 	uint8_t* d_usig = reinterpret_cast<uint8_t*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes);
+	int32_t* d_lists = reinterpret_cast<int32_t*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes + usig_bytes);
 	// cadences sorted by origin in LDS (8 bytes per slot, next power of two); beyond 8192 cadences the order stays natural
 	int sort_n = 64;
 	while (sort_n < desc->n_cad) sort_n <<= 1;
 	if (sort_n > 8192) sort_n = 0;
 	const int use_mfma = (ctx->linpsf_path == 1) ? 1 : 0;
 	TP_HIP(ctx, hipMemsetAsync(d_todo, 0, todo_bytes, ctx->stream));
-	TP_HIP(ctx, hipMemsetAsync(d_total, 0, 2 * sizeof(unsigned long long), ctx->stream));
+	TP_HIP(ctx, hipMemsetAsync(d_total, 0, 256, ctx->stream));
 	if (sort_n > 4096) TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sort_n * sizeof(unsigned long long))));
 	TP_LAUNCH(ctx, TPK_LINPSF_PLAN, tp_linpsf_plan_kernel, dim3((unsigned)desc->n_targets), dim3(256), (size_t)sort_n * sizeof(unsigned long long), a, d_plans, d_todo, d_total, max_origins, d_order, sort_n,
-		d_mplans, d_ulist, d_usig, use_mfma);
+		d_mplans, d_ulist, d_usig, use_mfma, d_lists, (int)desc->n_targets);
 	TP_LAUNCH_CHECK(ctx, "tp_linpsf_plan_kernel");
-	unsigned long long totals[2] = {0, 0};   // items of the polynomial store, doubles of the matrix-core store behind it
+	unsigned long long totals[kTotClass0 + kMfmaClasses] = {};   // items of the polynomial store, doubles of the matrix-core store behind it, class sizes
 	TP_HIP(ctx, hipMemcpyAsync(totals, d_total, sizeof(totals), hipMemcpyDeviceToHost, ctx->stream));
 	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	const size_t poly_doubles = ((size_t)totals[0] * 25 + 32 + 63) & ~(size_t)63;
-	const size_t store_need = (poly_doubles + (size_t)totals[1] + 64) * sizeof(double);
+	const size_t poly_doubles = ((size_t)totals[kTotPolyItems] * 25 + 32 + 63) & ~(size_t)63;
+	const size_t store_need = (poly_doubles + (size_t)totals[kTotKDoubles] + 64) * sizeof(double);
 	if (ctx->store_bytes < store_need) {
 		if (ctx->store) (void)hipFree(ctx->store);
 		ctx->store = nullptr; ctx->store_bytes = 0;
@@ -1170,7 +1235,7 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	TP_LAUNCH_CHECK(ctx, "tp_linpsf_coef_kernel");
 	// the matrix-core fit of the targets marked for it (up to 4 stars, up to 256 reachable pixels)
 	if (use_mfma) {
-		const int rc = fit_mfma_launch(ctx, a, desc->n_targets, max_stars, d_plans, d_todo, d_mplans, d_ulist, d_kstore);
+		const int rc = fit_mfma_launch(ctx, a, desc->n_targets, totals + kTotClass0, d_plans, d_lists, d_mplans, d_ulist, d_kstore);
 		if (rc != TP_OK) return rc;
 	}
 	const int nblk2 = (desc->n_cad + 255) / 256;
@@ -1188,11 +1253,13 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	} while (0)
 	// one instantiation per star count (the normal equations and the registers of a 1-star target are not those of a 4-star
 	// one); a workgroup whose target belongs to another class exits at once
-	TP_LINPSF_FIT2(1, 0);
-	if (max_stars > 1) TP_LINPSF_FIT2(2, 2);
-	if (max_stars > 2) TP_LINPSF_FIT2(3, 3);
-	if (max_stars > 3) TP_LINPSF_FIT2(4, 4);
-	if (max_stars > 4) TP_LINPSF_FIT2(8, 5);
+	if (totals[kTotPolyTargets] > 0) {   // none when the matrix-core fit has taken every target
+		TP_LINPSF_FIT2(1, 0);
+		if (max_stars > 1) TP_LINPSF_FIT2(2, 2);
+		if (max_stars > 2) TP_LINPSF_FIT2(3, 3);
+		if (max_stars > 3) TP_LINPSF_FIT2(4, 4);
+		if (max_stars > 4) TP_LINPSF_FIT2(8, 5);
+	}
 	// the general kernel (flagged targets) and the finalisation, by coarser classes
 	TP_LINPSF_LAUNCH(2, 0);
 	if (max_stars > 2) TP_LINPSF_LAUNCH(4, 3);

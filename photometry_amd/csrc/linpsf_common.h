@@ -112,20 +112,36 @@ struct StarPlan { int axmin, bymin, nby, nc, jmin, jmax, imin, imax; long long i
 
 // matrix-core path, per target: the pixels inside the cut-off of ANY fitted star at ANY cadence form the list U (ordered by
 // which stars reach them -- Gray-code order of the membership bits, then raster -- so that the pixels of one star are
-// contiguous), cut into tiles of 16; star s touches the tiles of `tiles[s]`; its coefficient block in the store is
-// [origin][rank of the tile among its tiles][7 MFMA steps][64 lanes] doubles from `koff[s]`.
+// contiguous), cut into tiles of 16; star s touches the tiles of `tiles[s]`.  Its coefficients are those of ONE tensor-product
+// quartic spline over the na x nb knot intervals its phases visit (linpsf_mfma.hip), laid out as the A operands of the matrix
+// instruction: [star][rank of the tile among its tiles][step][64 lanes] doubles, the whole target contiguous from `koff`
+// (that image is copied to LDS as it is), star s from `koff + 64 * ksub[s]`, `mfma_steps(na, nb)` steps per tile.
 struct MPlan {
 	int32_t n_pix, n_tiles;
 	uint32_t tiles[kMfmaStars];
 	uint32_t edge_tiles[kMfmaStars];   // tiles with a pixel that is inside the star's cut-off at some cadences only
-	int64_t koff[kMfmaStars];
+	int64_t koff;                      // doubles from the start of the matrix-core store
+	int32_t kdoubles;                  // size of the target's image (a multiple of 64)
+	uint16_t ksub[kMfmaStars];         // in blocks of 64 doubles
+	uint8_t na[kMfmaStars], nb[kMfmaStars];   // knot intervals visited along x / y (1..3; 0: the star is never on the stamp)
 };
+constexpr int kMfmaSpan = 3;          // knot intervals per axis a star may visit on this path
+// steps of v_mfma_f64_16x16x4_f64 per (star, pixel tile): (4 + na) basis functions of x times the first four of y, then two steps
+// for each of the nb remaining basis functions of y
+__host__ __device__ constexpr int mfma_steps(int na, int nb) { return (4 + na) + 2 * nb; }
+// LDS bytes for the coefficient image of a target: "small" leaves room for two workgroups per CU, "large" (three and four
+// stars only: their kernels run one workgroup per CU anyway) takes the LDS of the CU
+constexpr int kMfmaLdsSmall = 75776, kMfmaLdsLarge = 157696;
+// the plan kernel sorts the targets of the matrix-core path into classes, one launch each: (stars - 1) * 2 + (large image)
+constexpr int kMfmaClasses = 2 * kMfmaStars;
+// counters the plan kernel keeps (64-bit words of one 256-byte block)
+enum { kTotPolyItems = 0, kTotKDoubles = 1, kTotPolyTargets = 2, kTotClass0 = 8 };
 
 // `todo` flag of a target (written by the plan kernel): which kernel fits it
 enum { kPathPoly = 0, kPathDirect = 1, kPathMfma = 2 };
 
 // linpsf_mfma.hip
-int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, int max_stars, const StarPlan* d_plans, const int32_t* d_todo,
-	const MPlan* d_mplans, const uint16_t* d_ulist, const double* d_kstore);
+int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned long long* class_counts, const StarPlan* d_plans,
+	const int32_t* d_class_lists, const MPlan* d_mplans, const uint16_t* d_ulist, const double* d_kstore);
 
 } // namespace tp_linpsf

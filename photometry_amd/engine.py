@@ -267,7 +267,7 @@ def linpsf_prf(ctx, base_coef, weights, out=None):
 
 
 def linpsf_set_path(ctx, path):
-	"""``tp_linpsf_set_path``: 0 = vector-ALU fit kernels (default), 1 = matrix-core fit where a target qualifies."""
+	"""``tp_linpsf_set_path``: 1 = matrix-core fit where a target qualifies (default), 0 = vector-ALU fit kernels for every target."""
 	ctx._check(ctx.lib.tp_linpsf_set_path(ctx.handle, int(path)))
 
 

@@ -73,7 +73,7 @@ def test_linpsf_matches_oracle(ctx, path, max_neigh, T, H, W, jit):
 		res = engine.linpsf_fit(ctx, DeviceCube.from_host(ctx, s.images), coef, ctx.array(model.tx), ctx.array(model.ty),
 			ctx.array(star_offsets), ctx.array(target_index), ctx.array(pos_row), ctx.array(pos_col), max_stars).to_host()
 	finally:
-		engine.linpsf_set_path(ctx, 0)
+		engine.linpsf_set_path(ctx, 1)
 	for i in range(s.n_targets):
 		cat = s.catalog_of(i)
 		ncat = len(cat['starid'])
@@ -114,7 +114,7 @@ def test_linpsf_golden(ctx, golden_dir, path):
 			ctx.array(star_offsets), ctx.array(target_index), ctx.array(np.ascontiguousarray(pos_row)), ctx.array(np.ascontiguousarray(pos_col)),
 			int(np.diff(star_offsets).max())).to_host()
 	finally:
-		engine.linpsf_set_path(ctx, 0)
+		engine.linpsf_set_path(ctx, 1)
 	for i in range(int(g['n_linpsf'])):
 		ref = g[f'lp{i}_flux']
 		np.testing.assert_allclose(res['flux'][i], ref, rtol=1e-8, atol=1e-9*np.abs(ref).max())

@@ -21,7 +21,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out, '**/*counter_collection.csv'), recursive=True):
 	with open(f) as fh:
 		for r in csv.DictReader(fh):
-			m = re.search(r'(tp_linpsf_\w+(<\d(, \d)?>)?)', r.get('Kernel_Name', ''))
+			m = re.search(r'(tp_linpsf_\w+(<[\d, ]+>)?)', r.get('Kernel_Name', ''))
 			if m: acc[m.group(1)][r['Counter_Name']].append(float(r['Counter_Value']))
 for k in sorted(acc):
 	print(k)

@@ -64,6 +64,39 @@ __global__ __launch_bounds__(256) void mix_kernel(double* out, int iters)
 	if (s == 12345.678) out[0] = s;
 }
 
+// other instruction kinds beside the MFMAs: 1 v_fma_f32, 2 v_add_u32, 3 v_cvt_f64_f32, 4 v_cndmask_b32, 5 v_mul_f64, 6 v_mov_b32
+template <int KIND, int NV>
+__global__ __launch_bounds__(256) void mixk_kernel(double* out, int iters)
+{
+	f64x4 acc[2];
+	for (int i = 0; i < 2; ++i) acc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
+	double a = (double)(threadIdx.x & 7) * 0.25, b = (double)(threadIdx.x & 3) * 0.5;
+	float f[8]; unsigned u32[8]; double d[8];
+	for (int i = 0; i < 8; ++i) { f[i] = 1.f + threadIdx.x * 1e-6f * i; u32[i] = threadIdx.x + i; d[i] = 1.0 + threadIdx.x * 1e-9 * i; }
+	for (int it = 0; it < iters; ++it) {
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+#pragma unroll
+			for (int i = 0; i < 2; ++i) {
+				acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+				for (int q = 0; q < NV; ++q) {
+					if (KIND == 1) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[q & 7]) : "v"(f[(q + 1) & 7]));
+					if (KIND == 2) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u32[q & 7]) : "v"(u32[(q + 1) & 7]));
+					if (KIND == 3) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[q & 7]) : "v"(f[(q + 1) & 7]));
+					if (KIND == 4) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u32[q & 7]) : "v"(u32[(q + 1) & 7]) : );
+					if (KIND == 5) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[q & 7]) : "v"(d[(q + 1) & 7]));
+					if (KIND == 6) asm volatile("v_mov_b32 %0, %1" : "=v"(u32[q & 7]) : "v"(u32[(q + 1) & 7]));
+				}
+			}
+		}
+	}
+	double s = 0.0;
+	for (int i = 0; i < 2; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+	for (int i = 0; i < 8; ++i) s += f[i] + u32[i] + d[i];
+	if (s == 12345.678) out[0] = s;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 template <typename K>
@@ -119,6 +152,14 @@ int main()
 		const double m0 = time_kernel(mix_kernel<2, 0>, blocks, iters, d_out), m4 = time_kernel(mix_kernel<2, 4>, blocks, iters, d_out),
 			m8 = time_kernel(mix_kernel<2, 8>, blocks, iters, d_out), m16 = time_kernel(mix_kernel<2, 16>, blocks, iters, d_out);
 		printf("waves/SIMD %d  2 chains + {0, 4, 8, 16} v_fma_f64 per MFMA: %.3f %.3f %.3f %.3f ms\n", wps, m0, m4, m8, m16);
+	}
+	{
+		const int blocks = 256 * 2;
+		printf("2 waves/SIMD, 2 chains + {0, 4, 8, 16} instructions of another kind per MFMA (ms):\n");
+#define ROW(K, NAME) printf("  %-14s %.3f %.3f %.3f %.3f\n", NAME, time_kernel(mixk_kernel<K, 0>, blocks, iters, d_out), time_kernel(mixk_kernel<K, 4>, blocks, iters, d_out), \
+			time_kernel(mixk_kernel<K, 8>, blocks, iters, d_out), time_kernel(mixk_kernel<K, 16>, blocks, iters, d_out))
+		ROW(1, "v_fma_f32"); ROW(2, "v_add_u32"); ROW(3, "v_cvt_f64_f32"); ROW(4, "v_cndmask_b32"); ROW(5, "v_mul_f64"); ROW(6, "v_mov_b32");
+#undef ROW
 	}
 	return bad != 0;
 }

@@ -22,6 +22,8 @@ work = pipeline.ApertureWork(ctx, batch, packed=True)
 engine.background_stamp(ctx, batch.images, out=work.bkg_raw)
 engine.smooth_time(ctx, work.bkg_raw, batch.n_cad, batch.time_smooth, out=work.bkg)
 ctx.sync()
+if os.environ.get('LINPSF_PATH'):
+	engine.linpsf_set_path(ctx, int(os.environ['LINPSF_PATH']))
 res = bench.leg_linpsf(ctx, scene, cubes, work, args, Nt, T, H, W, np, engine, pipeline)
 print(res['value'], 'targets/s', res['ms_per_step'], 'ms/step')
 for k, v in res['kernels'].items():
