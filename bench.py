@@ -804,9 +804,11 @@ def leg_linpsf(ctx, scene, cubes, work, args, Nt, T, H, W, np, engine, pipeline)
 	fit_ms = sum(kernels[k]['ms_per_step'] for k in ('tp_linpsf_fit_kernel', 'tp_linpsf_fitm_kernel', 'tp_linpsf_plan_kernel', 'tp_linpsf_coef_kernel') if k in kernels)
 	nfit = batch.n_fit_stars
 	counts = np.diff(batch.star_offsets_h)
-	# flops the polynomial path EXECUTES (estimate): per star-cadence ~79 pixels inside the 5 px cut-off x 24 Horner FMAs; per
-	# cadence and finite pixel the normal equations S(S+1)/2 + S FMAs; per (star, visited table origin, pixel) item the
-	# 13x13 -> 5x5 contraction (~1 170 FMAs), ~3 origins per star
+	# ALGORITHMIC flops (what the path needs, the same count as in rounds 1-2): per star-cadence ~79 pixels inside the 5 px
+	# cut-off x 24 FMAs of a biquartic; per cadence and finite pixel the normal equations S(S+1)/2 + S FMAs; per (star, visited
+	# table origin, pixel) item the 13x13 -> 5x5 contraction (~1 170 FMAs), ~3 origins per star.  The matrix-core fit executes
+	# more than that: dense 16 x 16 tiles, 28-52 basis products instead of 24 nested multiplications (PMC: 91.5 M
+	# v_mfma_f64_16x16x4_f64 per step on this batch = 1.9e14 flops against 1.1e14 algorithmic)
 	fma = nfit * T * 79 * 24 + float(np.sum(counts * (counts + 1) / 2 + counts)) * T * H * W + nfit * 3 * 79 * 1170
 	flops = 2.0 * fma
 	nbytes = Nt * (H*W*T*4 + T*4) + nfit * T * 16 + Nt * T * 8
@@ -815,10 +817,10 @@ def leg_linpsf(ctx, scene, cubes, work, args, Nt, T, H, W, np, engine, pipeline)
 		'value': Nt / (ms * 1e-3), 'unit': 'targets/s', 'ms_per_step': ms, 'steps': n, 'dtype': 'f64', 'fitted_stars': int(nfit),
 		'config': {'workload': f'{Nt} targets x {T} cadences x {H}x{W}, LinPSF fit of {nfit} stars (P1 table blend + P2-P4), raw cube resident, '
 			'background series subtracted on the fly'},
-		'roofline': {'kernel': 'tp_linpsf_plan_kernel + tp_linpsf_coef_kernel + tp_linpsf_fit2_kernel (profile name tp_linpsf_fit_kernel)',
-			'bound': 'fp64 vector ALU (not HBM; not MFMA: FP64 matrix rate = FP64 vector rate on this chip and the cut-off circle is sparse)',
+		'roofline': {'kernel': 'tp_linpsf_plan_kernel + tp_linpsf_coef_kernel + tp_linpsf_fitm_kernel (matrix-core fit; tp_linpsf_fit_kernel = the vector-ALU fit of the targets that do not qualify)',
+			'bound': 'fp64 pipe (not HBM): FP64 matrix and vector instructions share one pipe on this chip and have the same peak',
 			'achieved': flops / (fit_ms * 1e-3) / 1e12, 'peak': FP64_VALU_TFLOPS, 'unit': 'TFLOP/s', 'frac': flops / (fit_ms * 1e-3) / 1e12 / FP64_VALU_TFLOPS,
-			'flops': 'executed FP64 flops of the polynomial path (estimate, see bench.py:leg_linpsf)', 'kernel_ms_per_step': fit_ms,
+			'flops': 'algorithmic FP64 flops of the path (estimate, see bench.py:leg_linpsf); the matrix-core fit executes ~1.7 x that', 'kernel_ms_per_step': fit_ms,
 			'hbm': {'necessary_bytes_per_step': nbytes, 'GBps': nbytes / (fit_ms * 1e-3) / 1e9, 'frac_of_hbm_peak': nbytes / (fit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
 			'traffic': linpsf_traffic(Nt, T, H)},
 		'kernels': kernels,

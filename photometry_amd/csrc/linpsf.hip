@@ -819,27 +819,37 @@ __global__ __launch_bounds__(256) void tp_linpsf_finalize_kernel(FinArgs fa)
 	const int ti = a.target_index[target];
 	const double* ftar = a.flux + (int64_t)target * a.out_pitch;
 
-	// count of valid cadences and per-star flux sums (only over cadences whose fit succeeded)
+	// count of valid cadences and per-star flux sums (only over cadences whose fit succeeded): one pass, every thread its
+	// cadences in order, then a fixed tree (lanes, then the wavefronts in order)
 	double mean[S];
-	double cntd = 0.0;
-	for (int s = -1; s < ns; ++s) {
-		double acc = 0.0;
-		for (int k = tid; k < a.n_cad; k += blockDim.x) {
-			const bool ok = ftar[k] == ftar[k];
-			if (s < 0) acc += ok ? 1.0 : 0.0;
-			else acc += ok ? a.fluxes_all[(s0 + s) * a.out_pitch + k] : 0.0;
-		}
-		red[tid] = acc;
-		__syncthreads();
-		double tot = 0.0;
-		for (int l = 0; l < (int)blockDim.x; ++l) tot += red[l];
-		__syncthreads();
-		if (s < 0) cntd = tot;
-		else {
+	double part[S + 1];
 #pragma unroll
-			for (int u = 0; u < S; ++u) if (u == s) mean[u] = tot / cntd;
+	for (int u = 0; u <= S; ++u) part[u] = 0.0;
+	for (int k = tid; k < a.n_cad; k += blockDim.x) {
+		const bool ok = ftar[k] == ftar[k];
+		part[0] += ok ? 1.0 : 0.0;
+#pragma unroll
+		for (int s = 0; s < S; ++s) if (s < ns) { const double v = a.fluxes_all[(s0 + s) * a.out_pitch + k]; part[1 + s] += ok ? v : 0.0; }
+	}
+#pragma unroll
+	for (int u = 0; u <= S; ++u) {
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) part[u] += __shfl_xor(part[u], off, 64);
+		if ((tid & 63) == 0) red[(tid >> 6) * (S + 1) + u] = part[u];
+	}
+	__syncthreads();
+	double cntd = 0.0;
+	{
+		const int nw = (int)blockDim.x >> 6;
+		for (int w = 0; w < nw; ++w) cntd += red[w * (S + 1)];
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			double tot = 0.0;
+			for (int w = 0; w < nw; ++w) tot += red[w * (S + 1) + 1 + s];
+			mean[s] = tot / cntd;
 		}
 	}
+	__syncthreads();
 	if (cntd == 0.0) { // allnan(flux) -> ERROR (linpsf_photometry.py:198-200)
 		if (tid == 0) { fa.status[target] = TP_STATUS_ERROR; fa.contamination[target] = __builtin_nan(""); }
 		return;
@@ -885,11 +895,13 @@ __global__ __launch_bounds__(256) void tp_linpsf_finalize_kernel(FinArgs fa)
 		}
 		acc += others * at;
 	}
-	red[tid] = acc;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+	if ((tid & 63) == 0) red[tid >> 6] = acc;
 	__syncthreads();
 	if (tid == 0) {
 		double tot = 0.0;
-		for (int l = 0; l < (int)blockDim.x; ++l) tot += red[l];
+		for (int w = 0; w < ((int)blockDim.x >> 6); ++w) tot += red[w];
 		double mt = 0.0;
 #pragma unroll
 		for (int u = 0; u < S; ++u) if (u == ti) mt = mean[u];
@@ -1134,7 +1146,8 @@ extern "C" int tp_linpsf_prf(tp_ctx* ctx, int32_t n_targets, int32_t n_samples, 
 	TP_REQUIRE(ctx, n_targets >= 0 && n_samples > 0 && n_samples <= kMaxSamples && n_coef > 0, "tp_linpsf_prf: bad sizes (at most 32 PRF samples)");
 	TP_REQUIRE(ctx, d_base_coef && d_weights && d_coef, "tp_linpsf_prf: null pointer");
 	if (n_targets == 0) return TP_OK;
-	const unsigned gy = (unsigned)((n_targets < 64) ? n_targets : 64);
+	const unsigned gy = (unsigned)((n_targets < 256) ? n_targets : 256);   // 54 x 256 workgroups: each thread's trip (scalar loads of the weights, 25 FMAs, one store) is a latency chain
+
 	dim3 block(256), grid((unsigned)((n_coef + 255) / 256), gy);
 	TP_LAUNCH(ctx, TPK_LINPSF_PRF, tp_linpsf_prf_kernel, grid, block, 0, d_base_coef, (int)n_samples, (int)n_coef, d_weights, (int)n_targets, d_coef);
 	TP_LAUNCH_CHECK(ctx, "tp_linpsf_prf_kernel");

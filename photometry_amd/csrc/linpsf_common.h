@@ -107,6 +107,49 @@ __device__ __forceinline__ void pinv_solve(double (&G)[S][S], const double (&g)[
 }
 
 
+// The same solve for the well-conditioned case: Cholesky.  Returns false (x untouched) when a pivot is not safely positive
+// -- singular, nearly singular or NaN normal equations -- and the caller takes pinv_solve, whose cut-off then matters
+// (numpy.linalg.pinv, linpsf_photometry.py:22-34).  Where it succeeds the two agree to rounding times the condition number
+// (< 1e4 here: pivots below 1e-4 of their diagonal element are refused).
+template <int S>
+__device__ __forceinline__ bool chol_solve(const double (&G)[S][S], const double (&g)[S], double (&x)[S])
+{
+	double L[S][S], y[S];
+	bool ok = true;
+#pragma unroll
+	for (int j = 0; j < S; ++j) {
+		double d = G[j][j];
+#pragma unroll
+		for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+		ok = ok && (d > 1e-4 * G[j][j]);
+		const double inv = 1.0 / sqrt(d);
+		L[j][j] = inv;   // the reciprocal of the diagonal element
+#pragma unroll
+		for (int i = j + 1; i < S; ++i) {
+			double v = G[i][j];
+#pragma unroll
+			for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+			L[i][j] = v * inv;
+		}
+	}
+	if (!ok) return false;
+#pragma unroll
+	for (int i = 0; i < S; ++i) {
+		double v = g[i];
+#pragma unroll
+		for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
+		y[i] = v * L[i][i];
+	}
+#pragma unroll
+	for (int i = S - 1; i >= 0; --i) {
+		double v = y[i];
+#pragma unroll
+		for (int k = i + 1; k < S; ++k) v -= L[k][i] * x[k];
+		x[i] = v * L[i][i];
+	}
+	return true;
+}
+
 // plan of one fitted star: the table origins its cadences visit and the pixels its cut-off circle can reach
 struct StarPlan { int axmin, bymin, nby, nc, jmin, jmax, imin, imax; long long item_off; };
 

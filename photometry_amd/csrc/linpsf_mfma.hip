@@ -45,8 +45,9 @@ __device__ __forceinline__ void dma_to_lds16(const void* src, void* lds_base)
 }
 
 // S fitted stars (exactly); one workgroup of up to NTHR / 64 wavefronts per target of the class list, at least MINW wavefronts
-// resident per SIMD.
-template <int S, int NTHR, int MINW>
+// resident per SIMD; a wavefront takes GC tiles of 16 cadences at a time (its unit of work: the smaller, the more evenly the
+// series divides over the wavefronts; 16 GC lanes then solve -- with one star that costs nothing, with more it is the price).
+template <int S, int NTHR, int MINW, int GC>
 __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, const StarPlan* __restrict__ plans,
 	const int32_t* __restrict__ targets, const MPlan* __restrict__ mplans, const uint16_t* __restrict__ ulist, const double* __restrict__ kstore)
 {
@@ -101,15 +102,28 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 		axmin[s] = p.axmin; bymin[s] = p.bymin;
 	}
 	const float* img = a.images + (int64_t)target * H * W * a.t_pitch;
-	const int ngroups = (a.n_cad + 63) >> 6;
+	constexpr int GCAD = 16 * GC;   // cadences per group
+	const int ngroups = (a.n_cad + GCAD - 1) / GCAD;
 
+	// positions and subtracted value of the NEXT tile of cadences are loaded a tile ahead (their latency would otherwise stand
+	// in front of every tile: nothing else can start before the basis products)
+	double nprow[S], npcol[S];
+	float nsb = 0.f;
+	auto load_cadence = [&](int k0) {
+		int kq = k0 + (lane & 15);
+		kq = (kq < a.n_cad) ? kq : (a.n_cad - 1);
+#pragma unroll
+		for (int s = 0; s < S; ++s) { nprow[s] = a.pos_row[(s0 + s) * a.pos_pitch + kq]; npcol[s] = a.pos_col[(s0 + s) * a.pos_pitch + kq]; }
+		if (a.subtract) nsb = a.subtract[(int64_t)target * a.subtract_pitch + kq];
+	};
+	load_cadence(wave * GCAD);
 	for (int gi = wave; gi < ngroups; gi += NWV) {
 		double kept[NACC];   // the normal equations of the cadence this lane solves: g[0..S), then G[s][t], t >= s, row-major
 #pragma unroll
 		for (int m = 0; m < NACC; ++m) kept[m] = 0.0;
 #pragma unroll 1
-		for (int mt = 0; mt < 4; ++mt) {
-			const int k0 = gi * 64 + mt * 16;
+		for (int mt = 0; mt < GC; ++mt) {
+			const int k0 = gi * GCAD + mt * 16;
 			if (k0 >= a.n_cad) break;   // uniform
 			const int k = k0 + (lane & 15);
 			const bool act = k < a.n_cad;
@@ -122,7 +136,7 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 			float bv0[4], bv1[4] = {0.f, 0.f, 0.f, 0.f}, bv2[4] = {0.f, 0.f, 0.f, 0.f};
 			load_tile(0, bv0);
 			if (ntiles > 1) load_tile(1, bv1);
-			const float sb = a.subtract ? a.subtract[(int64_t)target * a.subtract_pitch + kk] : 0.f;
+			const float sb = nsb;
 
 			// ---- B operands: the basis products of this lane's cadence.  Steps (the order of the coefficient image): x basis
 			// 0..4 times y basis g; y basis 4 times x basis g, then 4 + g; x basis 5, 6 times y basis g; y basis 5, 6 like 4
@@ -130,7 +144,7 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 			float scf[S], srf[S];
 #pragma unroll
 			for (int s = 0; s < S; ++s) {
-				const double prow = a.pos_row[(s0 + s) * a.pos_pitch + kk], pcol = a.pos_col[(s0 + s) * a.pos_pitch + kk];
+				const double prow = nprow[s], pcol = npcol[s];
 				// x <-> column (first spline axis), y <-> row  (psf.py:146).  Position -> knot interval + phase as in axis_phase
 				// (linpsf_dev.h), in one piece: the lower edge of the nearest pixel, in knot intervals from the first interior knot,
 				// less the origin of the intervals the star visits.  A NaN / absurd position fits nothing (psf.py:142).
@@ -156,6 +170,8 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 				B[s][9] = xlo * y5; B[s][10] = xhi * y5;
 				B[s][11] = xlo * y6; B[s][12] = xhi * y6;
 			}
+
+			load_cadence((mt < GC - 1 && k0 + 16 < a.n_cad) ? (k0 + 16) : ((gi + NWV) * GCAD));
 
 			double acc[NACC];
 #pragma unroll
@@ -262,8 +278,8 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 			}
 		}
 		// ---- every lane solves one cadence
-		const int k = gi * 64 + lane;
-		if (k < a.n_cad) {
+		const int k = gi * GCAD + lane;
+		if (lane < GCAD && k < a.n_cad) {
 			double G[S][S], gv[S], x[S];
 			int m = S;
 #pragma unroll
@@ -272,7 +288,17 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 #pragma unroll
 				for (int t = s; t < S; ++t) { G[s][t] = kept[m]; G[t][s] = kept[m]; ++m; }
 			}
-			pinv_solve<S>(G, gv, S, x);
+			// Cholesky where the normal equations are well conditioned (almost always), the pseudo-inverse otherwise; the branch is
+			// taken per wavefront so that the Jacobi sweeps run only where some cadence needs them
+			const bool easy = (S > 1) && chol_solve<S>(G, gv, x);
+			if (__any(!easy)) {
+				double xp[S];
+				pinv_solve<S>(G, gv, S, xp);
+				if (!easy) {
+#pragma unroll
+					for (int s = 0; s < S; ++s) x[s] = xp[s];
+				}
+			}
 			const int ti = a.target_index[target];
 			double tf = __builtin_nan("");
 #pragma unroll
@@ -291,9 +317,9 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 namespace tp_linpsf {
 
 // the number of wavefronts (at most `most`) that leaves the fewest idle while the others finish their last group of 64 cadences
-static int fit_waves(int n_cad, int most)
+static int fit_waves(int n_cad, int most, int group_cadences)
 {
-	const int groups = (n_cad + 63) / 64;
+	const int groups = (n_cad + group_cadences - 1) / group_cadences;
 	int best = most;
 	double best_par = 0.0;
 	for (int w = most; w >= (most + 1) / 2; --w) {
@@ -307,23 +333,24 @@ static int fit_waves(int n_cad, int most)
 int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned long long* class_counts, const StarPlan* d_plans,
 	const int32_t* d_class_lists, const MPlan* d_mplans, const uint16_t* d_ulist, const double* d_kstore)
 {
-#define TP_FITM(CLS, SS, TT, WW, LDS) do { \
+#define TP_FITM(CLS, SS, TT, WW, GG, LDS) do { \
 		if (class_counts[CLS] > 0) { \
-			TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fitm_kernel<SS, TT, WW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
-			TP_LAUNCH(ctx, TPK_LINPSF_FIT_MFMA, (tp_linpsf_fitm_kernel<SS, TT, WW>), dim3((unsigned)class_counts[CLS]), dim3(64 * fit_waves(a.n_cad, TT / 64)), (size_t)LDS, \
+			TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fitm_kernel<SS, TT, WW, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+			TP_LAUNCH(ctx, TPK_LINPSF_FIT_MFMA, (tp_linpsf_fitm_kernel<SS, TT, WW, GG>), dim3((unsigned)class_counts[CLS]), dim3(64 * fit_waves(a.n_cad, TT / 64, 16 * GG)), (size_t)LDS, \
 				a, d_plans, d_class_lists + (size_t)(CLS) * n_targets, d_mplans, d_ulist, d_kstore); \
 			TP_LAUNCH_CHECK(ctx, "tp_linpsf_fitm_kernel"); \
 		} \
 	} while (0)
-	// registers decide the shape: one star 120 VGPRs, two 128 (with spills): two workgroups of 8 wavefronts per CU; three and
-	// four stars 240 / 256: two wavefronts per SIMD -- two workgroups of 4 where the image is small, one of 8 where it is large
-	TP_FITM(0, 1, 512, 4, kMfmaLdsSmall);
-	TP_FITM(2, 2, 768, 3, kMfmaLdsLarge);
-	TP_FITM(3, 2, 768, 3, kMfmaLdsLarge);
-	TP_FITM(4, 3, 256, 2, kMfmaLdsSmall);
-	TP_FITM(5, 3, 512, 2, kMfmaLdsLarge);
-	TP_FITM(6, 4, 256, 2, kMfmaLdsSmall);
-	TP_FITM(7, 4, 512, 2, kMfmaLdsLarge);
+	// registers decide the shape (measured, C3 batch): one star 124 VGPRs -- two workgroups of 8 wavefronts per CU, units of 16
+	// cadences; two stars 168 -- one workgroup of up to 12 (three per SIMD; 128 registers and two workgroups of 8 spill and lose);
+	// three and four stars 253 / 256 -- two per SIMD: two workgroups of 4 where the image is small, one of 8 where it is large
+	TP_FITM(0, 1, 512, 4, 1, kMfmaLdsSmall);
+	TP_FITM(2, 2, 768, 3, 2, kMfmaLdsLarge);
+	TP_FITM(3, 2, 768, 3, 2, kMfmaLdsLarge);
+	TP_FITM(4, 3, 256, 2, 4, kMfmaLdsSmall);
+	TP_FITM(5, 3, 512, 2, 4, kMfmaLdsLarge);
+	TP_FITM(6, 4, 256, 2, 4, kMfmaLdsSmall);
+	TP_FITM(7, 4, 512, 2, 4, kMfmaLdsLarge);
 #undef TP_FITM
 	return TP_OK;
 }
