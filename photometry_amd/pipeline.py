@@ -577,3 +577,164 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 				finish(i, int(res['status'][j]))
 		active = np.asarray(sorted(still), dtype='int64')
 	return out
+
+
+#--------------------------------------------------------------------------------------------------
+# PSF photometry of many targets of one CCD region (the batched counterparts of the LinPSF / PSF plugins)
+#--------------------------------------------------------------------------------------------------
+class PSFFramesResult(object):
+	"""
+	Columnar results of :func:`linpsf_frames` / :func:`psf_frames`: ``status`` int32 (values of ``STATUS``), ``stamp`` int64
+	``(n, 4)``, ``flux`` / ``flux_err`` float64 ``(n, T)``, ``contamination`` float64 (LinPSF), ``pos_centroid`` float64
+	``(n, T, 2)`` as (row, column) (PSF), ``errors``: target index -> messages.  ``result[i]`` is the per-target dict.
+	"""
+	def __init__(self, n, T, method):
+		self.n, self.method = n, method
+		self.status = np.zeros(n, dtype='int32')
+		self.stamp = np.zeros((n, 4), dtype='int64')
+		self.flux = np.full((n, T), np.nan)
+		self.flux_err = np.full((n, T), np.nan)
+		self.contamination = np.full(n, np.nan)
+		self.pos_centroid = np.full((n, T, 2), np.nan) if method == 'psf' else None
+		self.errors = {}
+
+	def __len__(self):
+		return self.n
+
+	def __getitem__(self, i):
+		i = int(i)
+		r = {'status': int(self.status[i]), 'stamp': tuple(int(v) for v in self.stamp[i]), 'errors': list(self.errors.get(i, [])),
+			'flux': self.flux[i], 'flux_err': self.flux_err[i]}
+		if self.method == 'linpsf':
+			r['contamination'] = float(self.contamination[i])
+		else:
+			r['pos_centroid'] = self.pos_centroid[i]
+		return r
+
+
+def _psf_frame_groups(stack, targets):
+	"""Default stamps of the targets (BasePhotometry.py:541-564, no resizing: neither PSF plugin resizes) grouped by size."""
+	from . import stamps as st
+	first, valid = st.default_stamps(targets['row'], targets['column'], targets['tmag'], stack.limits)
+	cur = np.asarray(first, dtype='int64')
+	active = np.flatnonzero(valid)
+	keys = (cur[active, 1] - cur[active, 0]) * 100000 + (cur[active, 3] - cur[active, 2])
+	groups = [(int(key // 100000), int(key % 100000), active[keys == key]) for key in np.unique(keys)]
+	return cur, valid, groups
+
+
+def _jitter32(jitter, T):
+	"""Per-cadence (column, row) shifts as the plugins apply them (``catalog_attime``: float32 additions)."""
+	if jitter is None:
+		return np.zeros(T, dtype='float32'), np.zeros(T, dtype='float32')
+	j = np.asarray(jitter, dtype='float64')
+	return j[:, 0].astype('float32'), j[:, 1].astype('float32')
+
+
+def linpsf_frames(ctx, stack, targets, catalog, time, quality, prf_model, jitter=None, cutoff_radius=5):
+	"""
+	``LinPSFPhotometry.do_photometry`` (linpsf_photometry.py:79-219) for every target of a CCD region held in a
+	:class:`FrameStack`: default stamps grouped by size and cut on the device, the stars fitted beside each target selected as
+	the plugin does (:93-104), their positions at every cadence = catalogue position + ``jitter[k]`` (``(T, 2)`` column / row
+	shifts: what ``catalog_attime`` returns for a translation), one ``tp_linpsf_prf`` + ``tp_linpsf_fit`` per group.
+	Status and messages follow the plugin: ERROR "All target flux values are NaN.", WARNING "High contamination" above 0.1.
+	Returns a :class:`PSFFramesResult`.
+	"""
+	from . import psf as hpsf
+	n, T = len(targets['starid']), stack.n_cad
+	catalog = {k: np.asarray(v) for k, v in catalog.items()}
+	out = PSFFramesResult(n, T, 'linpsf')
+	cur, valid, groups = _psf_frame_groups(stack, targets)
+	out.stamp[:] = cur
+	for i in np.flatnonzero(~valid):
+		out.status[i] = 2
+		out.errors[int(i)] = ['ValueError: Invalid stamp selected']
+		out.stamp[i] = (-1, -2, -1, -2)
+	cat_index = _CatalogIndex(catalog)
+	jc, jr = _jitter32(jitter, T)
+	base_coef, tx, ty = ctx.array(prf_model.base_coef), ctx.array(prf_model.tx), ctx.array(prf_model.ty)
+	for H, W, idx in groups:
+		cat_offsets, cat = _catalogs_of_stamps(cat_index, cur[idx])
+		sel, star_offsets, target_index = hpsf.select_stars(cat, cat_offsets, np.asarray(targets['starid'], dtype='int64')[idx])
+		pos_row = (cat['row_stamp'][sel][:, None] + jr[None, :]).astype('float64')    # float32 sums, like the plugin's catalogue
+		pos_col = (cat['column_stamp'][sel][:, None] + jc[None, :]).astype('float64')
+		cube = engine.cut_stamps(ctx, stack.dev['images'], ctx.array(cur[idx].astype('int32')), H, W, stack.row0, stack.col0)
+		try:
+			coef = engine.linpsf_prf(ctx, base_coef, ctx.array(prf_model.weights(cur[idx])))
+			res = engine.linpsf_fit(ctx, cube, coef, tx, ty, ctx.array(star_offsets), ctx.array(target_index), ctx.array(pos_row), ctx.array(pos_col),
+				max(int(np.diff(star_offsets).max()), 1), cutoff_radius=cutoff_radius).to_host()
+		finally:
+			ctx.sync()
+			cube.free()
+		out.flux[idx] = res['flux'][:, :T]
+		out.flux_err[idx] = res['flux_err'][:, :T]
+		out.contamination[idx] = res['contamination']
+		for j, i in enumerate(idx):
+			i = int(i)
+			if int(res['status'][j]) == 2:
+				out.status[i] = 2
+				out.errors[i] = ['All target flux values are NaN.']
+			elif res['contamination'][j] > 0.1:
+				out.status[i] = 3
+				out.errors[i] = ['High contamination']
+			else:
+				out.status[i] = 1
+	return out
+
+
+def psf_frames(ctx, stack, targets, catalog, time, quality, prf_model, readnoise=10.0, gain=100.0, n_readout=720, cutoff_radius=5):
+	"""
+	``PSFPhotometry.do_photometry`` (psf_photometry.py:111-196) for every target of a CCD region held in a :class:`FrameStack`:
+	default stamps grouped by size, images and backgrounds cut on the device, per target the up to five stars the plugin fits
+	(:117-130) with their catalogue positions and fluxes as the first guess, the 3 x 3 minimum aperture of the finite sum-image
+	pixels (:29-41), one ``tp_psf_fit`` per group (the cadences of a target are a warm-start chain, the targets run side by side).
+	Returns a :class:`PSFFramesResult` (status OK, as the plugin: NaN fluxes are only logged there, :190-194).
+	"""
+	from .plugins import psf_star_selection, mag2flux
+	n, T = len(targets['starid']), stack.n_cad
+	catalog = {k: np.asarray(v) for k, v in catalog.items()}
+	out = PSFFramesResult(n, T, 'psf')
+	cur, valid, groups = _psf_frame_groups(stack, targets)
+	out.stamp[:] = cur
+	for i in np.flatnonzero(~valid):
+		out.status[i] = 2
+		out.errors[int(i)] = ['ValueError: Invalid stamp selected']
+		out.stamp[i] = (-1, -2, -1, -2)
+	cat_index = _CatalogIndex(catalog)
+	base_coef, tx, ty = ctx.array(prf_model.base_coef), ctx.array(prf_model.tx), ctx.array(prf_model.ty)
+	qual = ctx.array(np.asarray(quality, dtype='int32'))
+	trow, tcol, ttmag = (np.asarray(targets[k], dtype='float64') for k in ('row', 'column', 'tmag'))
+	for H, W, idx in groups:
+		cat_offsets, cat = _catalogs_of_stamps(cat_index, cur[idx])
+		stamps_dev = ctx.array(cur[idx].astype('int32'))
+		images = engine.cut_stamps(ctx, stack.dev['images'], stamps_dev, H, W, stack.row0, stack.col0)
+		backgrounds = engine.cut_stamps(ctx, stack.dev['backgrounds'], stamps_dev, H, W, stack.row0, stack.col0)
+		try:
+			finite = np.isfinite(engine.sumimage(ctx, images, qual).to_host())   # bit 1 of the aperture image (BasePhotometry.py:1033-1074)
+			offsets = [0]
+			params0 = []
+			mini = np.zeros((len(idx), H, W), dtype='uint8')
+			for j, i in enumerate(idx):
+				lo, hi = int(cat_offsets[j]), int(cat_offsets[j + 1])
+				r1, c1 = cur[i, 0], cur[i, 2]
+				sel = psf_star_selection(cat['row_stamp'][lo:hi], cat['column_stamp'][lo:hi], cat['tmag'][lo:hi], trow[i] - r1, tcol[i] - c1, ttmag[i])
+				params0.append(np.column_stack((np.asarray(cat['row_stamp'][lo:hi][sel], dtype='float64'), np.asarray(cat['column_stamp'][lo:hi][sel], dtype='float64'),
+					mag2flux(np.asarray(cat['tmag'][lo:hi][sel], dtype='float64')))))
+				offsets.append(offsets[-1] + len(sel))
+				cols, rows = np.meshgrid(np.arange(c1 + 1, cur[i, 3] + 1, dtype='int32'), np.arange(r1 + 1, cur[i, 1] + 1, dtype='int32'))
+				mini[j] = (np.abs(cols - tcol[i] - 1) <= 1) & (np.abs(rows - trow[i] - 1) <= 1) & finite[j]
+			coef = engine.linpsf_prf(ctx, base_coef, ctx.array(prf_model.weights(cur[idx])))
+			res = engine.psf_fit(ctx, images, backgrounds, coef, tx, ty, ctx.array(np.asarray(offsets, dtype='int64')), ctx.array(np.concatenate(params0, axis=0)),
+				ctx.array(mini), variance_floor=n_readout * readnoise**2 / gain**2, cutoff_radius=cutoff_radius)
+			flux, flux_err = res['flux'].to_host(), res['flux_err'].to_host()
+			crow, ccol = res['centroid_row'].to_host(), res['centroid_col'].to_host()
+		finally:
+			ctx.sync()
+			images.free()
+			backgrounds.free()
+		out.flux[idx] = flux[:, :T]
+		out.flux_err[idx] = flux_err[:, :T]
+		out.pos_centroid[idx, :, 0] = crow[:, :T]
+		out.pos_centroid[idx, :, 1] = ccol[:, :T]
+		out.status[idx] = 1
+	return out
