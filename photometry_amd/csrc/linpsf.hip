@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 				class_lists[(int64_t)cls * n_targets + (int64_t)at] = target;
 			} else path = kPathPoly;
 		}
-		if (path == kPathDirect) todo[target] = kPathDirect;
+		if (path == kPathDirect) { todo[target] = kPathDirect; atomicAdd(&totals[kTotDirectTargets], 1ull); }
 		else if (path == kPathPoly) {
 			long long items = 0;
 			for (int s = 0; s < ns; ++s) {
@@ -794,12 +794,14 @@ __global__ __launch_bounds__(256) void tp_linpsf_fit2_kernel(FitArgs a, const St
 struct FinArgs {
 	FitArgs f;
 	double* contamination; int32_t* status; double* fluxes_mean;
+	const int32_t* todo;   // targets marked kPathMfma are finalised by tp_linpsf_finalize_m_kernel (nullptr: none are)
 };
 
 template <int S, int SLO>
 __global__ __launch_bounds__(256) void tp_linpsf_finalize_kernel(FinArgs fa)
 {
 	{ const int nst = (int)(fa.f.star_offsets[blockIdx.x + 1] - fa.f.star_offsets[blockIdx.x]); if (nst < SLO || nst > S) return; } // another instantiation's targets
+	if (fa.todo && fa.todo[blockIdx.x] == kPathMfma) return;
 	extern __shared__ __align__(16) double lds[];
 	const FitArgs& a = fa.f;
 	const int target = blockIdx.x;
@@ -915,6 +917,81 @@ __global__ __launch_bounds__(256) void tp_linpsf_finalize_kernel(FinArgs fa)
 	}
 }
 
+
+// Finalise for the targets of the matrix-core fit: the same rules, with the design matrix of the last cadence as the fit
+// kernel left it (alast[target][star][pixel of the list U], zero outside the cut-off and where the pixel is not finite) instead
+// of a second evaluation of the PRF.
+template <int S>
+__global__ __launch_bounds__(256) void tp_linpsf_finalize_m_kernel(FinArgs fa, const int32_t* __restrict__ targets, const MPlan* __restrict__ mplans,
+	const double* __restrict__ alast)
+{
+	__shared__ double red[4 * (S + 1)];
+	const FitArgs& a = fa.f;
+	const int target = targets[blockIdx.x];
+	const int tid = threadIdx.x;
+	const int64_t s0 = a.star_offsets[target];
+	const int ti = a.target_index[target];
+	const double* ftar = a.flux + (int64_t)target * a.out_pitch;
+	double mean[S], part[S + 1];
+#pragma unroll
+	for (int u = 0; u <= S; ++u) part[u] = 0.0;
+	for (int k = tid; k < a.n_cad; k += 256) {
+		const bool ok = ftar[k] == ftar[k];
+		part[0] += ok ? 1.0 : 0.0;
+#pragma unroll
+		for (int s = 0; s < S; ++s) { const double v = a.fluxes_all[(s0 + s) * a.out_pitch + k]; part[1 + s] += ok ? v : 0.0; }
+	}
+#pragma unroll
+	for (int u = 0; u <= S; ++u) {
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) part[u] += __shfl_xor(part[u], off, 64);
+		if ((tid & 63) == 0) red[(tid >> 6) * (S + 1) + u] = part[u];
+	}
+	__syncthreads();
+	double cntd = 0.0;
+	for (int w = 0; w < 4; ++w) cntd += red[w * (S + 1)];
+#pragma unroll
+	for (int s = 0; s < S; ++s) {
+		double tot = 0.0;
+		for (int w = 0; w < 4; ++w) tot += red[w * (S + 1) + 1 + s];
+		mean[s] = tot / cntd;
+	}
+	__syncthreads();
+	if (cntd == 0.0) { // allnan(flux) -> ERROR (linpsf_photometry.py:198-200)
+		if (tid == 0) { fa.status[target] = TP_STATUS_ERROR; fa.contamination[target] = __builtin_nan(""); }
+		return;
+	}
+	// contamination = sum_p (A[p, others] . mean[others]) * A[p, target] / mean[target]
+	const int npix = mplans[target].n_tiles * 16;
+	const double* al = alast + (int64_t)target * kMfmaStars * kMfmaPixels;
+	double acc = 0.0;
+	for (int u = tid; u < npix; u += 256) {
+		double others = 0.0, at = 0.0;
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			const double v = al[s * kMfmaPixels + u];
+			if (s == ti) at = v; else others += v * mean[s];
+		}
+		acc += others * at;
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+	if ((tid & 63) == 0) red[tid >> 6] = acc;
+	__syncthreads();
+	if (tid == 0) {
+		const double tot = ((red[0] + red[1]) + red[2]) + red[3];
+		double mt = 0.0;
+#pragma unroll
+		for (int u = 0; u < S; ++u) if (u == ti) mt = mean[u];
+		const double cont = tot / mt;
+		fa.contamination[target] = cont;
+		fa.status[target] = (cont > 0.1) ? TP_STATUS_WARNING : TP_STATUS_OK; // :214-219
+		if (fa.fluxes_mean) {
+#pragma unroll
+			for (int u = 0; u < S; ++u) fa.fluxes_mean[s0 + u] = mean[u];
+		}
+	}
+}
 
 //--------------------------------------------------------------------------------------------------
 // Any number of fitted stars.  select_stars (linpsf_photometry.py:93-104) has no upper limit: a crowded target can bring
@@ -1196,7 +1273,7 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	int threads = (((desc->n_cad + nblk - 1) / nblk) + 63) / 64 * 64;
 	dim3 grid((unsigned)desc->n_targets, (unsigned)nblk), block((unsigned)threads);
 	const size_t shmem_fin = (2 * ((size_t)n_coef_axis + 4) + 256) * sizeof(double);
-	FinArgs fa; fa.f = a; fa.contamination = d_contamination; fa.status = d_status; fa.fluxes_mean = d_fluxes_mean;
+	FinArgs fa; fa.f = a; fa.contamination = d_contamination; fa.status = d_status; fa.fluxes_mean = d_fluxes_mean; fa.todo = nullptr;
 	// polynomial path: plan (boxes, item counts) -> coefficient store -> fit; targets whose stars visit more table origins than
 	// max_origins are flagged and redone by the general kernel
 	const int max_origins = 36;
@@ -1207,7 +1284,8 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	const size_t ulist_bytes = ((size_t)desc->n_targets * kMfmaPixels * sizeof(uint16_t) + 255) & ~(size_t)255;
 	const size_t usig_bytes = ((size_t)desc->n_targets * kMfmaPixels * sizeof(uint8_t) + 255) & ~(size_t)255;
 	const size_t lists_bytes = ((size_t)desc->n_targets * kMfmaClasses * sizeof(int32_t) + 255) & ~(size_t)255;
-	const size_t head_bytes = todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes + usig_bytes + lists_bytes;
+	const size_t alast_bytes = (ctx->linpsf_path == 1) ? (((size_t)desc->n_targets * kMfmaStars * kMfmaPixels * sizeof(double) + 255) & ~(size_t)255) : 0;
+	const size_t head_bytes = todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes + usig_bytes + lists_bytes + alast_bytes;
 	TP_REQUIRE(ctx, tp_ctx_scratch(ctx, head_bytes) != nullptr, "tp_linpsf_fit: out of device memory for the plan");
 	char* sbase = static_cast<char*>(ctx->scratch);
 	int32_t* d_todo = reinterpret_cast<int32_t*>(sbase);
@@ -1218,11 +1296,13 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	uint16_t* d_ulist = reinterpret_cast<uint16_t*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes);
 	uint8_t* d_usig = reinterpret_cast<uint8_t*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes);
 	int32_t* d_lists = reinterpret_cast<int32_t*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes + usig_bytes);
+	double* d_alast = reinterpret_cast<double*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes + usig_bytes + lists_bytes);
 	// cadences sorted by origin in LDS (8 bytes per slot, next power of two); beyond 8192 cadences the order stays natural
 	int sort_n = 64;
 	while (sort_n < desc->n_cad) sort_n <<= 1;
 	if (sort_n > 8192) sort_n = 0;
 	const int use_mfma = (ctx->linpsf_path == 1) ? 1 : 0;
+	fa.todo = use_mfma ? d_todo : nullptr;
 	TP_HIP(ctx, hipMemsetAsync(d_todo, 0, todo_bytes, ctx->stream));
 	TP_HIP(ctx, hipMemsetAsync(d_total, 0, 256, ctx->stream));
 	if (sort_n > 4096) TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sort_n * sizeof(unsigned long long))));
@@ -1248,8 +1328,17 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	TP_LAUNCH_CHECK(ctx, "tp_linpsf_coef_kernel");
 	// the matrix-core fit of the targets marked for it (up to 4 stars, up to 256 reachable pixels)
 	if (use_mfma) {
-		const int rc = fit_mfma_launch(ctx, a, desc->n_targets, totals + kTotClass0, d_plans, d_lists, d_mplans, d_ulist, d_kstore);
+		const int rc = fit_mfma_launch(ctx, a, desc->n_targets, totals + kTotClass0, d_plans, d_lists, d_mplans, d_ulist, d_kstore, d_alast);
 		if (rc != TP_OK) return rc;
+#define TP_LINPSF_FINM(CLS, SS) do { \
+			if (totals[kTotClass0 + CLS] > 0) { \
+				TP_LAUNCH(ctx, TPK_LINPSF_FIN, (tp_linpsf_finalize_m_kernel<SS>), dim3((unsigned)totals[kTotClass0 + CLS]), dim3(256), 0, fa, (const int32_t*)(d_lists + (size_t)(CLS) * desc->n_targets), \
+					(const MPlan*)d_mplans, (const double*)d_alast); \
+				TP_LAUNCH_CHECK(ctx, "tp_linpsf_finalize_m_kernel"); \
+			} \
+		} while (0)
+		TP_LINPSF_FINM(0, 1); TP_LINPSF_FINM(2, 2); TP_LINPSF_FINM(3, 2); TP_LINPSF_FINM(4, 3); TP_LINPSF_FINM(5, 3); TP_LINPSF_FINM(6, 4); TP_LINPSF_FINM(7, 4);
+#undef TP_LINPSF_FINM
 	}
 	const int nblk2 = (desc->n_cad + 255) / 256;
 	const int threads2 = (((desc->n_cad + nblk2 - 1) / nblk2) + 63) / 64 * 64;
@@ -1274,9 +1363,11 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 		if (max_stars > 4) TP_LINPSF_FIT2(8, 5);
 	}
 	// the general kernel (flagged targets) and the finalisation, by coarser classes
-	TP_LINPSF_LAUNCH(2, 0);
-	if (max_stars > 2) TP_LINPSF_LAUNCH(4, 3);
-	if (max_stars > 4) TP_LINPSF_LAUNCH(8, 5);
+	if (totals[kTotPolyTargets] + totals[kTotDirectTargets] > 0) {
+		TP_LINPSF_LAUNCH(2, 0);
+		if (max_stars > 2) TP_LINPSF_LAUNCH(4, 3);
+		if (max_stars > 4) TP_LINPSF_LAUNCH(8, 5);
+	}
 #undef TP_LINPSF_FIT2
 #undef TP_LINPSF_LAUNCH
 	if (max_stars > kMaxStars) {

@@ -178,13 +178,13 @@ constexpr int kMfmaLdsSmall = 75776, kMfmaLdsLarge = 157696;
 // the plan kernel sorts the targets of the matrix-core path into classes, one launch each: (stars - 1) * 2 + (large image)
 constexpr int kMfmaClasses = 2 * kMfmaStars;
 // counters the plan kernel keeps (64-bit words of one 256-byte block)
-enum { kTotPolyItems = 0, kTotKDoubles = 1, kTotPolyTargets = 2, kTotClass0 = 8 };
+enum { kTotPolyItems = 0, kTotKDoubles = 1, kTotPolyTargets = 2, kTotDirectTargets = 3, kTotClass0 = 8 };
 
 // `todo` flag of a target (written by the plan kernel): which kernel fits it
 enum { kPathPoly = 0, kPathDirect = 1, kPathMfma = 2 };
 
 // linpsf_mfma.hip
 int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned long long* class_counts, const StarPlan* d_plans,
-	const int32_t* d_class_lists, const MPlan* d_mplans, const uint16_t* d_ulist, const double* d_kstore);
+	const int32_t* d_class_lists, const MPlan* d_mplans, const uint16_t* d_ulist, const double* d_kstore, double* d_alast);
 
 } // namespace tp_linpsf

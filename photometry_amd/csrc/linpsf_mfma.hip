@@ -49,7 +49,8 @@ __device__ __forceinline__ void dma_to_lds16(const void* src, void* lds_base)
 // series divides over the wavefronts; 16 GC lanes then solve -- with one star that costs nothing, with more it is the price).
 template <int S, int NTHR, int MINW, int GC>
 __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, const StarPlan* __restrict__ plans,
-	const int32_t* __restrict__ targets, const MPlan* __restrict__ mplans, const uint16_t* __restrict__ ulist, const double* __restrict__ kstore)
+	const int32_t* __restrict__ targets, const MPlan* __restrict__ mplans, const uint16_t* __restrict__ ulist, const double* __restrict__ kstore,
+	double* __restrict__ alast)
 {
 	const int NWV = (int)blockDim.x >> 6;   // wavefronts of the workgroup (chosen by the host for the length of the series)
 	constexpr int NACC = S + S * (S + 1) / 2;
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 			if (k0 >= a.n_cad) break;   // uniform
 			const int k = k0 + (lane & 15);
 			const bool act = k < a.n_cad;
+			const bool last_here = (a.n_cad - 1 >= k0) && (a.n_cad - 1 < k0 + 16);   // uniform
 			const int kk = act ? k : (a.n_cad - 1);
 			// the first pixel tiles of this tile of cadences are on their way while the basis products are computed
 			auto load_tile = [&](int P, float (&bv)[4]) {
@@ -244,6 +246,14 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 						}
 					}
 				}
+				// the design matrix of the LAST cadence (pixels outside the cut-off and non-finite pixels zero) is what the
+				// contamination is computed from (linpsf_photometry.py:203-211): the lane that owns that cadence writes it out
+				if (last_here && (lane & 15) == a.n_cad - 1 - k0) {
+#pragma unroll
+					for (int s = 0; s < S; ++s)
+#pragma unroll
+						for (int r = 0; r < 4; ++r) alast[((int64_t)target * kMfmaStars + s) * kMfmaPixels + P * 16 + g + 4 * r] = D[s][r];
+				}
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
 					const double b = (double)bv[r];
@@ -331,13 +341,13 @@ static int fit_waves(int n_cad, int most, int group_cadences)
 
 // launches the matrix-core fit, one launch per class of targets the plan kernel has listed ((stars - 1) * 2 + large image)
 int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned long long* class_counts, const StarPlan* d_plans,
-	const int32_t* d_class_lists, const MPlan* d_mplans, const uint16_t* d_ulist, const double* d_kstore)
+	const int32_t* d_class_lists, const MPlan* d_mplans, const uint16_t* d_ulist, const double* d_kstore, double* d_alast)
 {
 #define TP_FITM(CLS, SS, TT, WW, GG, LDS) do { \
 		if (class_counts[CLS] > 0) { \
 			TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fitm_kernel<SS, TT, WW, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
 			TP_LAUNCH(ctx, TPK_LINPSF_FIT_MFMA, (tp_linpsf_fitm_kernel<SS, TT, WW, GG>), dim3((unsigned)class_counts[CLS]), dim3(64 * fit_waves(a.n_cad, TT / 64, 16 * GG)), (size_t)LDS, \
-				a, d_plans, d_class_lists + (size_t)(CLS) * n_targets, d_mplans, d_ulist, d_kstore); \
+				a, d_plans, d_class_lists + (size_t)(CLS) * n_targets, d_mplans, d_ulist, d_kstore, d_alast); \
 			TP_LAUNCH_CHECK(ctx, "tp_linpsf_fitm_kernel"); \
 		} \
 	} while (0)
