@@ -38,6 +38,7 @@ using namespace tp_prf;
 using namespace tp_linpsf;
 
 constexpr int kMaxSamples = 32;
+constexpr size_t kCoefScratchBytes = 512 * 9 * sizeof(double);   // tp_linpsf_coef_kernel, matrix-core layout: [thread][9]
 
 //--------------------------------------------------------------------------------------------------
 // P1: per-target blend of the per-sample coefficient tables
@@ -491,14 +492,15 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 	const int n = a.n;
 	const double h2 = (a.knots_x[5] - a.knots_x[4]) * (a.knots_y[5] - a.knots_y[4]);
 	{
+		// the whole table in flight at once (up to 39 doubles per thread for the largest table admitted), then into LDS: one round
+		// trip to memory instead of one per slice
 		const double* cg = a.coef + (int64_t)target * n * n;
-		for (int i0 = 0; i0 < n * n; i0 += 8 * 512) {
-			double tmp[8];
+		constexpr int kPer = (140 * 140 + 511) / 512;
+		double tmp[kPer];
 #pragma unroll
-			for (int u = 0; u < 8; ++u) { const int i = i0 + u * 512 + tid; tmp[u] = (i < n * n) ? cg[i] : 0.0; }
+		for (int u = 0; u < kPer; ++u) { const int i = u * 512 + tid; tmp[u] = (i < n * n) ? cg[i] : 0.0; }
 #pragma unroll
-			for (int u = 0; u < 8; ++u) { const int i = i0 + u * 512 + tid; if (i < n * n) ctab[i] = tmp[u]; }
-		}
+		for (int u = 0; u < kPer; ++u) { const int i = u * 512 + tid; if (i < n * n) ctab[i] = tmp[u]; }
 	}
 	__syncthreads();
 	const double* C = ctab;
@@ -513,6 +515,10 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 		const MPlan mp = mplans[target];
 		const uint16_t* ul = ulist + (int64_t)target * kMfmaPixels;
 		const uint8_t* us = usig + (int64_t)target * kMfmaPixels;
+		// One thread per (pixel of a tile, knot interval): the 13 x 13 patch of that interval is contracted into its 25
+		// coefficients; the interval (0, 0) writes the steps that hold C[e][d], e <= 4, d < 4, at once, every interval leaves its
+		// K[4][0..4] and K[0..3][4] in LDS, and one thread per pixel then forms the differences and writes the remaining steps.
+		double* scr = ctab + n * n;   // [512][9]
 		for (int s = 0; s < ns; ++s) {
 			const StarPlan p = plans[(int64_t)target * kMaxStars + s];
 			const unsigned tiles = mp.tiles[s];
@@ -520,78 +526,74 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 			const int na = mp.na[s], nb = mp.nb[s];
 			if (na == 0) continue;
 			const int nk = mfma_steps(na, nb);
-			for (int item = tid; item < nt * 16; item += 512) {
-				const int r = item >> 4, u = item & 15;
-				unsigned m = tiles;
-				for (int q = 0; q < r; ++q) m &= m - 1;          // drop the r lowest set bits
-				const int tile = __ffs(m) - 1;
-				const int slot = tile * 16 + u;
-				const unsigned pix = ul[slot];
-				double ce[7][7];
-#pragma unroll
-				for (int e = 0; e < 7; ++e)
-#pragma unroll
-					for (int d = 0; d < 7; ++d) ce[e][d] = 0.0;
-				if (pix != 0xffffu && ((us[slot] >> s) & 1)) {
-					const int i = (int)pix / a.width, j = (int)pix - i * a.width;
-#pragma unroll
-					for (int ca = 0; ca < kMfmaSpan; ++ca) {
-#pragma unroll
-						for (int cb = 0; cb < kMfmaSpan; ++cb) {
-							if (ca >= na || cb >= nb) continue;
+			const int ncell = na * nb;
+			const int chunk = 512 / ncell;            // pixels per round
+			const int nitems = nt * 16;
+			for (int base = 0; base < nitems; base += chunk) {
+				{
+					const int li = tid / ncell, cell = tid - li * ncell;
+					const int item = base + li;
+					if (li < chunk && item < nitems) {
+						const int r = item >> 4, u = item & 15;
+						unsigned m = tiles;
+						for (int q = 0; q < r; ++q) m &= m - 1;          // drop the r lowest set bits
+						const int slot = (__ffs(m) - 1) * 16 + u;
+						const unsigned pix = ul[slot];
+						const int ca = cell / nb, cb = cell - ca * nb;
+						double kk[5][5];
+						if (pix != 0xffffu && ((us[slot] >> s) & 1)) {
+							const int i = (int)pix / a.width, j = (int)pix - i * a.width;
 							int ax = (p.axmin + ca) + 9 * j, by = (p.bymin + cb) + 9 * i;
 							ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
 							by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
-							double kk[5][5];
 							patch_coefficients(C, n, ax, by, h2, kk);
-							if (ca == 0 && cb == 0) {
+						} else {
 #pragma unroll
-								for (int e = 0; e < 4; ++e)
+							for (int e = 0; e < 5; ++e)
 #pragma unroll
-									for (int d = 0; d < 4; ++d) ce[e][d] = kk[e][d];
-							}
-							if (cb == 0) {
-#pragma unroll
-								for (int d = 0; d < 4; ++d) { ce[4 + ca][d] += kk[4][d]; if (ca + 1 < kMfmaSpan && ca + 1 < na) ce[5 + ca][d] -= kk[4][d]; }
-							}
-							if (ca == 0) {
-#pragma unroll
-								for (int e = 0; e < 4; ++e) { ce[e][4 + cb] += kk[e][4]; if (cb + 1 < kMfmaSpan && cb + 1 < nb) ce[e][5 + cb] -= kk[e][4]; }
-							}
-							const double k44 = kk[4][4];
-							ce[4 + ca][4 + cb] += k44;
-							if (ca + 1 < kMfmaSpan && ca + 1 < na) ce[5 + ca][4 + cb] -= k44;
-							if (cb + 1 < kMfmaSpan && cb + 1 < nb) ce[4 + ca][5 + cb] -= k44;
-							if (ca + 1 < kMfmaSpan && cb + 1 < kMfmaSpan && ca + 1 < na && cb + 1 < nb) ce[5 + ca][5 + cb] += k44;
+								for (int d = 0; d < 5; ++d) kk[e][d] = 0.0;
 						}
+						if (cell == 0) {
+							double* dst = kstore + mp.koff + ((int64_t)mp.ksub[s] + (int64_t)r * nk) * 64 + u;
+#pragma unroll
+							for (int e = 0; e < 5; ++e)
+#pragma unroll
+								for (int g = 0; g < 4; ++g) dst[e * 64 + g * 16] = kk[e][g];
+						}
+						double* sc = scr + tid * 9;
+#pragma unroll
+						for (int d = 0; d < 5; ++d) sc[d] = kk[4][d];
+#pragma unroll
+						for (int e = 0; e < 4; ++e) sc[5 + e] = kk[e][4];
 					}
 				}
-				// steps: E = 0..4 (x basis E, y basis g); y basis 4 with x basis g, then 4 + g; x basis 5, 6 where visited; y basis 5, 6
-				double* dst = kstore + mp.koff + ((int64_t)mp.ksub[s] + (int64_t)r * nk) * 64 + u;
-				int idx = 0;
-#pragma unroll
-				for (int e = 0; e < 5; ++e, ++idx)
-#pragma unroll
-					for (int g = 0; g < 4; ++g) dst[idx * 64 + g * 16] = ce[e][g];
-#pragma unroll
-				for (int g = 0; g < 4; ++g) { dst[idx * 64 + g * 16] = ce[g][4]; dst[(idx + 1) * 64 + g * 16] = (g < 3) ? ce[4 + g][4] : 0.0; }
-				idx += 2;
-#pragma unroll
-				for (int ea = 1; ea < kMfmaSpan; ++ea) {
-					if (ea < na) {
-#pragma unroll
-						for (int g = 0; g < 4; ++g) dst[idx * 64 + g * 16] = ce[4 + ea][g];
-						++idx;
-					}
-				}
-#pragma unroll
-				for (int db = 1; db < kMfmaSpan; ++db) {
-					if (db < nb) {
-#pragma unroll
-						for (int g = 0; g < 4; ++g) { dst[idx * 64 + g * 16] = ce[g][4 + db]; dst[(idx + 1) * 64 + g * 16] = (g < 3) ? ce[4 + g][4 + db] : 0.0; }
+				__syncthreads();
+				if (tid < chunk && base + tid < nitems) {
+					const int item = base + tid;
+					const int r = item >> 4, u = item & 15;
+					auto sc = [&](int ca, int cb, int q) -> double { return (ca < 0 || cb < 0) ? 0.0 : scr[(tid * ncell + ca * nb + cb) * 9 + q]; };
+					// ce[4 + a][d] (d < 4), ce[e][4 + b] (e < 4), ce[4 + a][4 + b]: first differences along the axis that leaves interval 0,
+					// the second difference of K[4][4] off both axes
+					double* dst = kstore + mp.koff + ((int64_t)mp.ksub[s] + (int64_t)r * nk) * 64 + u;
+					int idx = 5;
+					auto corner = [&](int ca, int cb) -> double { return ((sc(ca, cb, 4) - sc(ca - 1, cb, 4)) - sc(ca, cb - 1, 4)) + sc(ca - 1, cb - 1, 4); };
+					for (int cb = 0; cb < nb; ++cb) {
+						if (cb == 1) {   // the steps of the x basis functions 5, 6 come between those of y basis function 4 and 5
+							for (int ca = 1; ca < na; ++ca, ++idx)
+								for (int g = 0; g < 4; ++g) dst[idx * 64 + g * 16] = sc(ca, 0, g) - sc(ca - 1, 0, g);
+						}
+						for (int g = 0; g < 4; ++g) {
+							dst[idx * 64 + g * 16] = sc(0, cb, 5 + g) - sc(0, cb - 1, 5 + g);
+							dst[(idx + 1) * 64 + g * 16] = (g < na) ? corner(g, cb) : 0.0;
+						}
 						idx += 2;
 					}
+					if (nb == 1) {
+						for (int ca = 1; ca < na; ++ca, ++idx)
+							for (int g = 0; g < 4; ++g) dst[idx * 64 + g * 16] = sc(ca, 0, g) - sc(ca - 1, 0, g);
+					}
 				}
+				__syncthreads();
 			}
 		}
 		return;
@@ -1301,7 +1303,10 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	int sort_n = 64;
 	while (sort_n < desc->n_cad) sort_n <<= 1;
 	if (sort_n > 8192) sort_n = 0;
-	const int use_mfma = (ctx->linpsf_path == 1) ? 1 : 0;
+	// the matrix-core path needs the table AND the exchange area of its coefficient kernel in LDS, and 32-bit element offsets
+	// into a target's cube
+	const int use_mfma = (ctx->linpsf_path == 1 && (size_t)n_coef_axis * n_coef_axis * sizeof(double) + kCoefScratchBytes <= 160 * 1024
+		&& (int64_t)desc->height * desc->width * desc->t_pitch < (1ll << 30)) ? 1 : 0;
 	fa.todo = use_mfma ? d_todo : nullptr;
 	TP_HIP(ctx, hipMemsetAsync(d_todo, 0, todo_bytes, ctx->stream));
 	TP_HIP(ctx, hipMemsetAsync(d_total, 0, 256, ctx->stream));
@@ -1322,8 +1327,9 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	}
 	double* d_store = static_cast<double*>(ctx->store);
 	double* d_kstore = d_store + poly_doubles;
-	TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_coef_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)n_coef_axis * n_coef_axis * sizeof(double))));
-	TP_LAUNCH(ctx, TPK_LINPSF_COEF, tp_linpsf_coef_kernel, dim3((unsigned)desc->n_targets), dim3(512), (size_t)n_coef_axis * n_coef_axis * sizeof(double), a, (const StarPlan*)d_plans, (const int32_t*)d_todo, d_store,
+	const size_t coef_lds = (size_t)n_coef_axis * n_coef_axis * sizeof(double) + (use_mfma ? kCoefScratchBytes : 0);
+	TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_coef_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coef_lds));
+	TP_LAUNCH(ctx, TPK_LINPSF_COEF, tp_linpsf_coef_kernel, dim3((unsigned)desc->n_targets), dim3(512), coef_lds, a, (const StarPlan*)d_plans, (const int32_t*)d_todo, d_store,
 		(const MPlan*)d_mplans, (const uint16_t*)d_ulist, (const uint8_t*)d_usig, d_kstore);
 	TP_LAUNCH_CHECK(ctx, "tp_linpsf_coef_kernel");
 	// the matrix-core fit of the targets marked for it (up to 4 stars, up to 256 reachable pixels)
