@@ -530,7 +530,7 @@ def main():
 			fit_ms = sum(prof[k][1] for k in ('tp_linpsf_fit_kernel', 'tp_linpsf_fitm_kernel', 'tp_linpsf_plan_kernel', 'tp_linpsf_coef_kernel') if k in prof) / max(args.steps, 1)
 			counts = np.diff(lin.star_offsets_h)
 			fma = nfit * T * 79 * 24 + float(np.sum(counts * (counts + 1) / 2 + counts)) * T * H * W + nfit * 3 * 79 * 1170
-			result['linpsf_roofline'] = {'kernel': 'tp_linpsf_plan_kernel + tp_linpsf_coef_kernel + tp_linpsf_fit2_kernel', 'bound': 'fp64 vector ALU',
+			result['linpsf_roofline'] = {'kernel': 'tp_linpsf_plan_kernel + tp_linpsf_coef_kernel + tp_linpsf_fitm_kernel', 'bound': 'fp64 pipe (matrix + vector instructions share it)',
 				'achieved': 2 * fma / (fit_ms * 1e-3) / 1e12, 'peak': FP64_VALU_TFLOPS, 'unit': 'TFLOP/s', 'frac': 2 * fma / (fit_ms * 1e-3) / 1e12 / FP64_VALU_TFLOPS,
 				'kernel_ms_per_step': fit_ms, 'fitted_stars': int(nfit)}
 		if shared_device:

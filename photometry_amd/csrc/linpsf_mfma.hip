@@ -117,7 +117,8 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 		for (int s = 0; s < S; ++s) { nprow[s] = a.pos_row[(s0 + s) * a.pos_pitch + kq]; npcol[s] = a.pos_col[(s0 + s) * a.pos_pitch + kq]; }
 		if (a.subtract) nsb = a.subtract[(int64_t)target * a.subtract_pitch + kq];
 	};
-	load_cadence(wave * GCAD);
+	constexpr bool AHEAD = (S == 1);   // with more stars the registers are worth more than the latency (measured)
+	if (AHEAD) load_cadence(wave * GCAD);
 	for (int gi = wave; gi < ngroups; gi += NWV) {
 		double kept[NACC];   // the normal equations of the cadence this lane solves: g[0..S), then G[s][t], t >= s, row-major
 #pragma unroll
@@ -136,8 +137,10 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 				bv[0] = img[o.x + (unsigned)kk]; bv[1] = img[o.y + (unsigned)kk]; bv[2] = img[o.z + (unsigned)kk]; bv[3] = img[o.w + (unsigned)kk];
 			};
 			float bv0[4], bv1[4] = {0.f, 0.f, 0.f, 0.f}, bv2[4] = {0.f, 0.f, 0.f, 0.f};
+			constexpr int RING = (S == 1) ? 3 : 2;   // pixel tiles in flight (registers again)
 			load_tile(0, bv0);
-			if (ntiles > 1) load_tile(1, bv1);
+			if (RING == 3 && ntiles > 1) load_tile(1, bv1);
+			if (!AHEAD) load_cadence(k0);
 			const float sb = nsb;
 
 			// ---- B operands: the basis products of this lane's cadence.  Steps (the order of the coefficient image): x basis
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 				B[s][11] = xlo * y6; B[s][12] = xhi * y6;
 			}
 
-			load_cadence((mt < GC - 1 && k0 + 16 < a.n_cad) ? (k0 + 16) : ((gi + NWV) * GCAD));
+			if (AHEAD) load_cadence((mt < GC - 1 && k0 + 16 < a.n_cad) ? (k0 + 16) : ((gi + NWV) * GCAD));
 
 			double acc[NACC];
 #pragma unroll
@@ -267,16 +270,27 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 				}
 			};
 			// three pixel tiles in flight, the loop unrolled by three so that no loaded register is copied (a copy waits for its load)
+			if (RING == 3) {
 #pragma unroll 1
-			for (int P = 0; P < ntiles; P += 3) {
-				if (P + 2 < ntiles) load_tile(P + 2, bv2);
-				process(P, bv0);
-				if (P + 1 >= ntiles) break;
-				if (P + 3 < ntiles) load_tile(P + 3, bv0);
-				process(P + 1, bv1);
-				if (P + 2 >= ntiles) break;
-				if (P + 4 < ntiles) load_tile(P + 4, bv1);
-				process(P + 2, bv2);
+				for (int P = 0; P < ntiles; P += 3) {
+					if (P + 2 < ntiles) load_tile(P + 2, bv2);
+					process(P, bv0);
+					if (P + 1 >= ntiles) break;
+					if (P + 3 < ntiles) load_tile(P + 3, bv0);
+					process(P + 1, bv1);
+					if (P + 2 >= ntiles) break;
+					if (P + 4 < ntiles) load_tile(P + 4, bv1);
+					process(P + 2, bv2);
+				}
+			} else {
+#pragma unroll 1
+				for (int P = 0; P < ntiles; P += 2) {
+					if (P + 1 < ntiles) load_tile(P + 1, bv1);
+					process(P, bv0);
+					if (P + 1 >= ntiles) break;
+					if (P + 2 < ntiles) load_tile(P + 2, bv0);
+					process(P + 1, bv1);
+				}
 			}
 			// ---- sum over the four lane groups; group mt keeps the sums of this tile of cadences
 #pragma unroll
@@ -351,16 +365,18 @@ int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned
 			TP_LAUNCH_CHECK(ctx, "tp_linpsf_fitm_kernel"); \
 		} \
 	} while (0)
-	// registers decide the shape (measured, C3 batch): one star 124 VGPRs -- two workgroups of 8 wavefronts per CU, units of 16
-	// cadences; two stars 168 -- one workgroup of up to 12 (three per SIMD; 128 registers and two workgroups of 8 spill and lose);
-	// three and four stars 253 / 256 -- two per SIMD: two workgroups of 4 where the image is small, one of 8 where it is large
+	// registers decide the shape (measured, C3 batch): one star 124 VGPRs -- two workgroups of 8 wavefronts per CU; two stars 167 --
+	// one workgroup of up to 12 (three per SIMD; at 128 registers two workgroups of 8 spill and lose: 8.46 against 8.12 ms per
+	// step); three and four stars 226 / 256 -- two per SIMD: two workgroups of 4 where the image is small, one of 8 where it is
+	// large.  Units of 16 cadences everywhere: with the Cholesky solve the sixteen-lane solve costs less than the idle tail of
+	// larger units (three stars: 2.78 -> 2.47 ms)
 	TP_FITM(0, 1, 512, 4, 1, kMfmaLdsSmall);
-	TP_FITM(2, 2, 768, 3, 2, kMfmaLdsLarge);
-	TP_FITM(3, 2, 768, 3, 2, kMfmaLdsLarge);
-	TP_FITM(4, 3, 256, 2, 4, kMfmaLdsSmall);
-	TP_FITM(5, 3, 512, 2, 4, kMfmaLdsLarge);
-	TP_FITM(6, 4, 256, 2, 4, kMfmaLdsSmall);
-	TP_FITM(7, 4, 512, 2, 4, kMfmaLdsLarge);
+	TP_FITM(2, 2, 768, 3, 1, kMfmaLdsLarge);
+	TP_FITM(3, 2, 768, 3, 1, kMfmaLdsLarge);
+	TP_FITM(4, 3, 256, 2, 1, kMfmaLdsSmall);
+	TP_FITM(5, 3, 512, 2, 1, kMfmaLdsLarge);
+	TP_FITM(6, 4, 256, 2, 1, kMfmaLdsSmall);
+	TP_FITM(7, 4, 512, 2, 1, kMfmaLdsLarge);
 #undef TP_FITM
 	return TP_OK;
 }
