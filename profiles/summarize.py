@@ -118,7 +118,7 @@ for k in sorted(means):
 if linpsf_total:
 	nb = need.get(('step', 'tp_linpsf_fit'))
 	traffic['traffic_bytes_per_launch']['tp_linpsf_fit'] = linpsf_total
-	print(f"{'LinPSF fit (plan + coefficient store + every fit2 instantiation)':64s} traffic {linpsf_total/1e9:8.3f} GB per step" + (f"  necessary {nb/1e9:8.3f} GB  ratio {linpsf_total/nb:.3f}" if nb else ''))
+	print(f"{'LinPSF fit (plan + coefficient store + every fit launch)':64s} traffic {linpsf_total/1e9:8.3f} GB per step" + (f"  necessary {nb/1e9:8.3f} GB  ratio {linpsf_total/nb:.3f}" if nb else ''))
 if len(sys.argv) > 2:
 	with open(sys.argv[2], 'w') as fh:
 		json.dump(traffic, fh, indent=1, sort_keys=True)
