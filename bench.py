@@ -516,7 +516,7 @@ def main():
 				'frac_of_hbm_peak': step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 'mean_mask_pixels': n_mask / Nt},
 			'kernels': rows,
 			'gather': {'mode': gather_mode, 'bytes_per_rank_per_step': block_bytes if world > 1 else 0,
-				'block': 'light curves [5][Nt][T] f64 + contamination f64 + status, flags i32 + mask u8 per target, one message per rank',
+				'block': 'light curves [5][Nt][T] f64 + contamination f64 + status, flags i32 + mask u8 per target' + (' + LinPSF light curve [Nt][T] f64, contamination f64, status i32' if psf else '') + ', one message per rank (comm.packed_block_layout)',
 				'issued': 'every step, second stream, double-buffered output block' if do_gather else None,
 				'mean_ms': (sum(gather_ms) / len(gather_ms)) if gather_ms else None,
 				'step_ms_without_gather': step_alone_ms,
