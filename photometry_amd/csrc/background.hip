@@ -26,8 +26,9 @@
 //      goes.  The 3-sigma test is evaluated without division or square root: x is clipped iff
 //      ((x - med) m)^2 > 9 (m s2 - s1^2), with s1, s2 the float64 sums of the m kept values.
 // A wavefront stages and reads only its own 8 frames and its LDS operations execute in order: no workgroup barrier.
-// Measured on the C3 cube (10 000 x 1 300 x 15x15, 13 M frames, 11.75 GB): 5.2 ms = 2.3 TB/s (round 3: the walk runs for the upper end
-// alone when the lowest kept rank is not clipped -- almost always: 5.7 -> 5.2 ms; rounds 1-2: 10.9, 5.4-5.7).  The kernel is bound by the
+// Measured on the C3 cube (10 000 x 1 300 x 15x15, 13 M frames, 11.75 GB): 5.05 ms = 2.3 TB/s (round 3: the walk runs for the upper end
+// alone when the lowest kept rank is not clipped -- almost always: 5.7 -> 5.2 ms; the registers past the last pixel are left out of
+// the loads, the sums and the per-lane network: 5.05; rounds 1-2: 10.9, 5.4-5.7).  The kernel is bound by the
 // vector ALUs, not by HBM: ~2 500 vector instructions per wavefront of 8 frames, 1 340 of them the sorting network
 // (counters: 1.64 M waves, 4.3 G VALU instructions, VALU busy 57 % of the two-waves-per-SIMD issue peak, 15 of 20
 // possible waves per CU resident).  Phases timed by cutting the kernel short: loads + mask + sums 2.1 ms (HBM rate
@@ -96,14 +97,19 @@ constexpr OemNet<N> make_oem() {
 }
 template <int N> struct Oem { static constexpr OemNet<N> net = make_oem<N>(); };
 static_assert(Oem<32>::net.n == 191 && Oem<64>::net.n == 543, "Batcher networks of 32 / 64 keys");
-template <int N, size_t I>
+// NREAL: registers NREAL..N-1 are known to hold the +inf sentinel in every lane (slots past the last pixel): an exchange whose
+// upper register is one of them changes nothing (the upper register of an exchange receives the maximum) and is left out --
+// 20 of the 191 exchanges for the 29 registers a 15 x 15 stamp fills
+template <int N, int NREAL, size_t I>
 __device__ __forceinline__ void oem_exchange(float (&v)[N]) {
-	const float x = v[Oem<N>::net.a[I]], y = v[Oem<N>::net.b[I]];
-	v[Oem<N>::net.a[I]] = tp_min(x, y);
-	v[Oem<N>::net.b[I]] = tp_max(x, y);
+	if constexpr (Oem<N>::net.b[I] < NREAL) {
+		const float x = v[Oem<N>::net.a[I]], y = v[Oem<N>::net.b[I]];
+		v[Oem<N>::net.a[I]] = tp_min(x, y);
+		v[Oem<N>::net.b[I]] = tp_max(x, y);
+	}
 }
-template <int N, size_t... I>
-__device__ __forceinline__ void oem_sort(float (&v)[N], std::index_sequence<I...>) { (oem_exchange<N, I>(v), ...); }
+template <int N, int NREAL = N, size_t... I>
+__device__ __forceinline__ void oem_sort(float (&v)[N], std::index_sequence<I...>) { (oem_exchange<N, NREAL, I>(v), ...); }
 
 struct BkgArgs {
 	const float* raw; float* out; int n_cad; int n_pix; int64_t t_pitch; int64_t out_pitch;
@@ -191,14 +197,15 @@ __global__ __launch_bounds__(kFramesPerBlock * G) void tp_bkg_stamp_kernel(BkgAr
 	const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
 		const_cast<float*>(a.raw + (int64_t)target * a.n_pix * a.t_pitch), 0, a.n_pix * pitch_b, 0x00020000);
 	const int voff = g * pitch_b + (active ? k : (a.n_cad - 1)) * 4;
+	constexpr int NREAL = (JFULL >= 0 && JFULL + 1 < R) ? (JFULL + 1) : R;   // registers 0..NREAL-1 can hold a pixel (JFULL: the first lanes only)
 	float v[R];
 #pragma unroll
-	for (int j = 0; j < R; ++j) // all loads in flight before the first use
-		v[j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, j * G * pitch_b, 0));
+	for (int j = 0; j < R; ++j) // all loads in flight before the first use; registers past the last pixel hold the sentinel
+		v[j] = (j < NREAL) ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, j * G * pitch_b, 0)) : inf;
 	int n = 0;
 	double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-	for (int j = 0; j < R; ++j) {
+	for (int j = 0; j < NREAL; ++j) {
 		const float x = v[j];
 		// backgrounds.py:91-94: mask = ~isfinite | > flux_cutoff | < 0; slots past the last pixel are masked too
 		bool ok = (x >= 0.f) && (x <= a.flux_cutoff);
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(kFramesPerBlock * G) void tp_bkg_stamp_kernel(BkgAr
 
 	// --- distributed sort of the 256 values of the frame: rank = R g + j
 	const float sel1 = (g & 1) ? inf : -inf, sel2 = (g & 2) ? inf : -inf, sel4 = (g & 4) ? inf : -inf;
-	oem_sort<R>(v, std::make_index_sequence<Oem<R>::net.n>());   // every lane ascending (Batcher: 191 / 543 exchanges for 32 / 64 keys)
+	oem_sort<R, NREAL>(v, std::make_index_sequence<Oem<R>::net.n>());   // every lane ascending (Batcher: 191 / 543 exchanges for 32 / 64 keys)
 	cross_stage<kDppXor1, true, R>(v, sel1);                     // runs of 2 lanes: mirror against lane^1,
 	local_merge<R>(v);                                           //                  then ascending merges
 	cross_stage<kDppQuadRev, true, R>(v, sel2);                  // runs of 4 lanes: mirror against lane^3,
