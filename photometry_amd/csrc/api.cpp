@@ -198,7 +198,7 @@ int tp_free(tp_ctx* ctx, void* d_ptr) {
 	if (it != ctx->live.end()) {
 		const size_t cap = it->second;
 		ctx->live.erase(it);
-		if (cap <= ((size_t)1 << 30) && ctx->cache_bytes + cap <= ctx->cache_limit) {
+		if (cap <= ctx->cache_block && ctx->cache_bytes + cap <= ctx->cache_limit) {
 			// kept for the next tp_malloc of this capacity; whatever is queued on the stream for the block runs before any
 			// later use of it (one in-order stream per context)
 			ctx->cache.emplace(cap, d_ptr);

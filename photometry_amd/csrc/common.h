@@ -56,10 +56,12 @@ struct tp_ctx {
 	void* store = nullptr;      // second grow-only buffer: the polynomial coefficient store of tp_linpsf_fit
 	size_t store_bytes = 0;
 	// tp_malloc / tp_free: blocks a caller frees go to a size-keyed cache instead of back to the driver (hipFree synchronises the
-	// whole device, hipMalloc costs tens of microseconds); reuse is ordered by the context's stream.  Bounded by cache_limit.
+	// whole device, hipMalloc costs tens of microseconds -- and ~12 ms for a multi-GB block: the stamp cubes of the batched frames
+	// entry, measured); reuse is ordered by the context's stream.  Blocks up to cache_block (8 GiB), cache_limit (48 GiB) in all:
+	// a sixth of the 288 GB, given back when an allocation fails.
 	std::multimap<size_t, void*> cache;
 	std::map<void*, size_t> live;   // blocks handed out by tp_malloc -> capacity
-	size_t cache_bytes = 0, cache_limit = (size_t)8 << 30;
+	size_t cache_bytes = 0, cache_limit = (size_t)48 << 30, cache_block = (size_t)8 << 30;
 	// pinned staging area of the synchronous copy entries (tp_memcpy_h2d / _d2h): pageable transfers go through it in pieces
 	void* stage = nullptr;
 	size_t stage_bytes = 0;
