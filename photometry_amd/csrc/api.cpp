@@ -122,6 +122,7 @@ int tp_ctx_destroy(tp_ctx* ctx) {
 	for (auto& kv : ctx->cache) (void)hipFree(kv.second);
 	ctx->cache.clear();
 	if (ctx->stage) (void)hipHostFree(ctx->stage);
+	if (ctx->ring) (void)hipHostFree(ctx->ring);
 	for (int k = 0; k < TPK_COUNT; k++)
 		for (auto& p : ctx->pending[k]) {
 			(void)hipEventDestroy(p.first);
@@ -254,6 +255,17 @@ int tp_memcpy_h2d(tp_ctx* ctx, void* d_dst, const void* h_src, uint64_t nbytes) 
 	TP_CHECK_CTX(ctx);
 	if (nbytes == 0) return TP_OK;
 	TP_REQUIRE(ctx, d_dst && h_src, "tp_memcpy_h2d: null pointer");
+	constexpr size_t kRing = (size_t)4 << 20, kSmall = (size_t)256 << 10;
+	if (nbytes <= kSmall) {
+		if (!ctx->ring) { TP_HIP(ctx, hipHostMalloc(&ctx->ring, kRing, hipHostMallocDefault)); ctx->ring_cursor = 0; }
+		const size_t n = ((size_t)nbytes + 63) & ~(size_t)63;
+		if (ctx->ring_cursor + n > kRing) { TP_HIP(ctx, hipStreamSynchronize(ctx->stream)); ctx->ring_cursor = 0; }
+		char* buf = static_cast<char*>(ctx->ring) + ctx->ring_cursor;
+		memcpy(buf, h_src, (size_t)nbytes);
+		TP_HIP(ctx, hipMemcpyAsync(d_dst, buf, (size_t)nbytes, hipMemcpyHostToDevice, ctx->stream));
+		ctx->ring_cursor += n;
+		return TP_OK;
+	}
 	// pageable host memory goes through the pinned staging area in pieces: the host copy of piece i + 1 overlaps the DMA of
 	// piece i, and the call returns once h_src is consumed (the last DMA may still be in flight: it is ordered on the stream)
 	int rc = tp_stage(ctx);

@@ -65,6 +65,10 @@ struct tp_ctx {
 	// pinned staging area of the synchronous copy entries (tp_memcpy_h2d / _d2h): pageable transfers go through it in pieces
 	void* stage = nullptr;
 	size_t stage_bytes = 0;
+	// small uploads (<= 256 KiB) go through a pinned ring and return without waiting for their DMA (the ring is reused only
+	// after the stream has been synchronised): a batched entry makes a hundred of them per call
+	void* ring = nullptr;
+	size_t ring_cursor = 0;
 	int linpsf_path = 1;        // tp_linpsf_set_path: 1 = matrix-core fit where a target qualifies, 0 = vector-ALU fit kernels only
 	void* comm = nullptr;       // ncclComm_t (comm.cpp)
 	int comm_rank = 0, comm_size = 1;
