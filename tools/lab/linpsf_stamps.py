@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""lab: in-kernel s_memtime stamps of the matrix-core LinPSF fit (library built with -DTP_LAB_STAMP), summed per star count."""
+"""lab: in-kernel s_memtime stamps of the matrix-core LinPSF fit (library built with -DTP_LAB_STAMP after
+``git apply tools/lab/linpsf_lab_hooks.patch``: the hooks are not in the product source), summed per star count."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

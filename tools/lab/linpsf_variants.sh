@@ -1,5 +1,8 @@
 #!/bin/bash
-# lab: per-class time of the matrix-core LinPSF fit for the library variants of tools/lab/build_variants.sh (rocprofv3 kernel stats)
+# lab: per-class time of the matrix-core LinPSF fit for the library variants of tools/lab/build_variants.sh (rocprofv3 kernel stats).
+# The variants need the lab hooks, which are NOT in the product source: git apply tools/lab/linpsf_lab_hooks.patch, then e.g.
+#   SRC=linpsf_mfma.hip bash tools/lab/build_variants.sh base: noload:-DTP_LAB_NOLOAD nomfma:-DTP_LAB_NOMFMA noacc:-DTP_LAB_NOACC stamp:-DTP_LAB_STAMP
+# and git checkout photometry_amd/csrc/linpsf_mfma.hip afterwards.
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 for lib in $R/tools/lab/lib_*.so; do
