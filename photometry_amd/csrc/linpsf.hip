@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 				mplans[target] = mp;
 				for (int s = 0; s < ns; ++s) plans[(int64_t)target * kMaxStars + s] = spl[s];
 				todo[target] = kPathMfma;
-				const int cls = (ns - 1) * 2 + (large ? 1 : 0);
+				const int cls = (ns - 1) * 2;   // one launch per star count (the odd classes -- a separate list for large images -- are not in use:
+				(void)large;                    // the same launch configuration serves both, and two launches have two tails)
 				const unsigned long long at = atomicAdd(&totals[kTotClass0 + cls], 1ull);
 				class_lists[(int64_t)cls * n_targets + (int64_t)at] = target;
 			} else path = kPathPoly;
@@ -601,6 +602,17 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 					double* dst = kstore + mp.koff + ((int64_t)mp.ksub[s] + (int64_t)r * nk) * 64 + u;
 					int idx = 5;
 					auto corner = [&](int ca, int cb) -> double { return ((sc(ca, cb, 4) - sc(ca - 1, cb, 4)) - sc(ca, cb - 1, 4)) + sc(ca - 1, cb - 1, 4); };
+					if (mfma_is22(na, nb)) {
+						// 9 steps: y basis 4 with x basis 0..3; {x basis 4, 5 with y basis 4, x basis 0, 1 with y basis 5}; x basis 5 with y
+						// basis 0..3; x basis 2..5 with y basis 5
+						for (int g = 0; g < 4; ++g) {
+							dst[5 * 64 + g * 16] = sc(0, 0, 5 + g);
+							dst[6 * 64 + g * 16] = (g < 2) ? corner(g, 0) : (sc(0, 1, 5 + g - 2) - sc(0, 0, 5 + g - 2));
+							dst[7 * 64 + g * 16] = sc(1, 0, g) - sc(0, 0, g);
+							dst[8 * 64 + g * 16] = (g < 2) ? (sc(0, 1, 5 + 2 + g) - sc(0, 0, 5 + 2 + g)) : corner(g - 2, 1);
+						}
+						idx = 9;
+					} else
 					for (int cb = 0; cb < nb; ++cb) {
 						if (cb == 1) {   // the steps of the x basis functions 5, 6 come between those of y basis function 4 and 5
 							for (int ca = 1; ca < na; ++ca, ++idx)

@@ -170,8 +170,11 @@ struct MPlan {
 };
 constexpr int kMfmaSpan = 3;          // knot intervals per axis a star may visit on this path
 // steps of v_mfma_f64_16x16x4_f64 per (star, pixel tile): (4 + na) basis functions of x times the first four of y, then two steps
-// for each of the nb remaining basis functions of y
-__host__ __device__ constexpr int mfma_steps(int na, int nb) { return (4 + na) + 2 * nb; }
+// for each of the nb remaining basis functions of y -- except for the commonest case, 2 x 2 intervals (36 products), which is
+// packed into 9 steps instead of 10: the half-empty second step of y basis function 4 also carries x basis functions 0, 1 of y
+// basis function 5, and one more step the other four (mfma_is22)
+__host__ __device__ constexpr bool mfma_is22(int na, int nb) { return na == 2 && nb == 2; }
+__host__ __device__ constexpr int mfma_steps(int na, int nb) { return mfma_is22(na, nb) ? 9 : ((4 + na) + 2 * nb); }
 // LDS bytes for the coefficient image of a target: "small" leaves room for two workgroups per CU, "large" (three and four
 // stars only: their kernels run one workgroup per CU anyway) takes the LDS of the CU
 constexpr int kMfmaLdsSmall = 75776, kMfmaLdsLarge = 157696;

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 
 			// ---- B operands: the basis products of this lane's cadence.  Steps (the order of the coefficient image): x basis
 			// 0..4 times y basis g; y basis 4 times x basis g, then 4 + g; x basis 5, 6 times y basis g; y basis 5, 6 like 4
+			// (2 x 2 intervals: 9 steps, see mfma_is22)
 			double B[S][13];
 			float scf[S], srf[S];
 #pragma unroll
@@ -170,9 +171,13 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 				yg = ok ? yg : 0.0;
 				const double y4 = ok ? Y4 : 0.0, y5 = ok ? Y5 : 0.0, y6 = ok ? Y6 : 0.0;
 				B[s][0] = yg; B[s][1] = X * yg; B[s][2] = X2 * yg; B[s][3] = X3 * yg; B[s][4] = X4 * yg;
-				B[s][5] = xlo * y4; B[s][6] = xhi * y4;
+				// 2 x 2 intervals (uniform per star): step 6 = {X^4, (X-1)+^4} y4 and {1, X} y5, step 9 = {X^2, X^3, X^4, (X-1)+^4} y5
+				const bool p22 = mfma_is22(na[s], nb[s]);
+				const double x6 = p22 ? ((g == 2) ? 1.0 : ((g == 3) ? X : xhi)) : xhi;
+				const double x9 = p22 ? ((g == 0) ? X2 : ((g == 1) ? X3 : ((g == 2) ? X4 : X5))) : xlo;
+				B[s][5] = xlo * y4; B[s][6] = x6 * ((p22 && g >= 2) ? y5 : y4);
 				B[s][7] = X5 * yg; B[s][8] = X6 * yg;
-				B[s][9] = xlo * y5; B[s][10] = xhi * y5;
+				B[s][9] = x9 * y5; B[s][10] = xhi * y5;
 				B[s][11] = xlo * y6; B[s][12] = xhi * y6;
 			}
 
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 					if (na[s] >= 3) { D[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(kb[0], B[s][8], D[s], 0, 0, 0); kb += 64; }
 					if (nb[s] >= 2) {
 						D[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(kb[0], B[s][9], D[s], 0, 0, 0);
-						D[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(kb[64], B[s][10], D[s], 0, 0, 0);
+						if (!mfma_is22(na[s], nb[s])) D[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(kb[64], B[s][10], D[s], 0, 0, 0);
 						kb += 128;
 					}
 					if (nb[s] >= 3) {
@@ -367,15 +372,15 @@ int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned
 	} while (0)
 	// registers decide the shape (measured, C3 batch): one star 124 VGPRs -- two workgroups of 8 wavefronts per CU; two stars 167 --
 	// one workgroup of up to 12 (three per SIMD; at 128 registers two workgroups of 8 spill and lose: 8.46 against 8.12 ms per
-	// step); three and four stars 226 / 256 -- two per SIMD: two workgroups of 4 where the image is small, one of 8 where it is
-	// large.  Units of 16 cadences everywhere: with the Cholesky solve the sixteen-lane solve costs less than the idle tail of
-	// larger units (three stars: 2.78 -> 2.47 ms)
+	// step); three and four stars 226 / 256 -- two per SIMD, one workgroup of 8 whatever the size of the image (two workgroups
+	// of 4 for the small images: 0.38 ms for what the large configuration does in 0.1).  Units of 16 cadences everywhere: with the
+	// Cholesky solve the sixteen-lane solve costs less than the idle tail of larger units (three stars: 2.78 -> 2.47 ms)
 	TP_FITM(0, 1, 512, 4, 1, kMfmaLdsSmall);
 	TP_FITM(2, 2, 768, 3, 1, kMfmaLdsLarge);
 	TP_FITM(3, 2, 768, 3, 1, kMfmaLdsLarge);
-	TP_FITM(4, 3, 256, 2, 1, kMfmaLdsSmall);
+	TP_FITM(4, 3, 512, 2, 1, kMfmaLdsLarge);
 	TP_FITM(5, 3, 512, 2, 1, kMfmaLdsLarge);
-	TP_FITM(6, 4, 256, 2, 1, kMfmaLdsSmall);
+	TP_FITM(6, 4, 512, 2, 1, kMfmaLdsLarge);
 	TP_FITM(7, 4, 512, 2, 1, kMfmaLdsLarge);
 #undef TP_FITM
 	return TP_OK;
