@@ -133,6 +133,7 @@ int tp_ctx_destroy(tp_ctx* ctx) {
 		(void)hipEventDestroy(ctx->tstart[i]);
 		(void)hipEventDestroy(ctx->tstop[i]);
 	}
+	for (auto& st : ctx->side) if (st) (void)hipStreamDestroy(st);
 	(void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 	return TP_OK;

@@ -41,6 +41,7 @@ enum tp_kernel_id {
 struct tp_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t side[2] = {nullptr, nullptr};   // created on demand: independent launches of one entry whose tails may overlap (tp_linpsf_fit)
 	std::string err;
 	hipEvent_t tstart[16] = {};
 	hipEvent_t tstop[16] = {};
@@ -103,17 +104,18 @@ extern thread_local std::string tp_global_err;
 struct tp_prof_scope {
 	tp_ctx* ctx;
 	int kid;
+	hipStream_t st;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
-	tp_prof_scope(tp_ctx* c, int k) : ctx(c), kid(k) {
+	tp_prof_scope(tp_ctx* c, int k, hipStream_t s = nullptr) : ctx(c), kid(k), st(s ? s : c->stream) {
 		if (ctx->profile) {
 			e0 = ctx->get_event();
 			e1 = ctx->get_event();
-			(void)hipEventRecord(e0, ctx->stream);
+			(void)hipEventRecord(e0, st);
 		}
 	}
 	~tp_prof_scope() {
 		if (ctx->profile) {
-			(void)hipEventRecord(e1, ctx->stream);
+			(void)hipEventRecord(e1, st);
 			ctx->pending[kid].emplace_back(e0, e1);
 		}
 	}
@@ -122,6 +124,11 @@ struct tp_prof_scope {
 #define TP_LAUNCH(ctx, kid, kernel, grid, block, shmem, ...) do { \
 	tp_prof_scope _ps((ctx), (kid)); \
 	hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__); \
+} while (0)
+// the same on another stream of the context (the caller orders it against ctx->stream with events)
+#define TP_LAUNCH_ON(ctx, st, kid, kernel, grid, block, shmem, ...) do { \
+	tp_prof_scope _ps((ctx), (kid), (st)); \
+	hipLaunchKernelGGL(kernel, grid, block, shmem, (st), __VA_ARGS__); \
 } while (0)
 
 #define TP_LAUNCH_CHECK(ctx, name) do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) return (ctx)->fail(TP_ERR_HIP, name, _e); } while (0)

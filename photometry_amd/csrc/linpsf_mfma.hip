@@ -362,10 +362,24 @@ static int fit_waves(int n_cad, int most, int group_cadences)
 int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned long long* class_counts, const StarPlan* d_plans,
 	const int32_t* d_class_lists, const MPlan* d_mplans, const uint16_t* d_ulist, const double* d_kstore, double* d_alast)
 {
+	// The launches are independent (one per star count): the first runs on the context's stream, the others on two side streams
+	// that wait for what precedes on it (the coefficient store) and are waited for before what follows (the finalisation), so that
+	// the tail of one launch -- its last workgroups on a mostly idle chip -- overlaps the body of another.
+	hipEvent_t before = ctx->get_event();
+	TP_HIP(ctx, hipEventRecord(before, ctx->stream));
+	int used = 0;
+	hipStream_t streams[3] = {ctx->stream, nullptr, nullptr};
+	for (int i = 0; i < 2; ++i) {
+		if (!ctx->side[i]) TP_HIP(ctx, hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+		streams[i + 1] = ctx->side[i];
+	}
+	bool waited[3] = {true, false, false};
 #define TP_FITM(CLS, SS, TT, WW, GG, LDS) do { \
 		if (class_counts[CLS] > 0) { \
+			const int si = used++ % 3; \
+			if (!waited[si]) { TP_HIP(ctx, hipStreamWaitEvent(streams[si], before, 0)); waited[si] = true; } \
 			TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fitm_kernel<SS, TT, WW, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
-			TP_LAUNCH(ctx, TPK_LINPSF_FIT_MFMA, (tp_linpsf_fitm_kernel<SS, TT, WW, GG>), dim3((unsigned)class_counts[CLS]), dim3(64 * fit_waves(a.n_cad, TT / 64, 16 * GG)), (size_t)LDS, \
+			TP_LAUNCH_ON(ctx, streams[si], TPK_LINPSF_FIT_MFMA, (tp_linpsf_fitm_kernel<SS, TT, WW, GG>), dim3((unsigned)class_counts[CLS]), dim3(64 * fit_waves(a.n_cad, TT / 64, 16 * GG)), (size_t)LDS, \
 				a, d_plans, d_class_lists + (size_t)(CLS) * n_targets, d_mplans, d_ulist, d_kstore, d_alast); \
 			TP_LAUNCH_CHECK(ctx, "tp_linpsf_fitm_kernel"); \
 		} \
@@ -383,6 +397,15 @@ int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned
 	TP_FITM(6, 4, 512, 2, 1, kMfmaLdsLarge);
 	TP_FITM(7, 4, 512, 2, 1, kMfmaLdsLarge);
 #undef TP_FITM
+	for (int i = 1; i < 3; ++i) {
+		if (waited[i]) {
+			hipEvent_t done = ctx->get_event();
+			TP_HIP(ctx, hipEventRecord(done, streams[i]));
+			TP_HIP(ctx, hipStreamWaitEvent(ctx->stream, done, 0));
+			ctx->pool.push_back(done);
+		}
+	}
+	ctx->pool.push_back(before);
 	return TP_OK;
 }
 
