@@ -23,6 +23,7 @@
 #include "common.h"
 #include "linpsf_dev.h"
 #include <cmath>
+#include <vector>
 
 namespace {
 
@@ -46,13 +47,19 @@ constexpr int kHalfBox = 5;                      // pixels inside the cut-off (<
 constexpr int kBox = 2 * kHalfBox + 1;
 constexpr int kItems = kBox * kBox;              // cached (pixel offset) items per star, 25 coefficients each
 
-constexpr int kPool = 6;                         // cached coefficient sets (24 KB each) shared by the stars of a target: kPool / ns per star
+constexpr int kPool = 6;                         // most cached coefficient sets (24 KB each) a target gets; it uses psf_pool(ns) of them, pool / ns per star
+
+// Sets cached for a target with ns fitted stars: two for a single star, one per star otherwise.  The kernel is a chain of
+// dependent steps (one workgroup per target), so what counts is how many workgroups a CU holds: with 2 sets (56 KB of LDS) two,
+// and the fit of one- and two-star targets takes 20 / 36 ns per simplex iteration instead of 34 / 49 with the 6 sets (145 KB) of
+// round 2 -- more rebuilds, fewer idle CUs (measured, tools/psf_time.py).
+__host__ __device__ constexpr int psf_pool(int ns) { return ns < 2 ? 2 : (ns > kPool ? kPool : ns); }
 
 struct StarW { double row, col, flux, phx, phy; int jstar, istar, ax0, by0, valid, rebuild, slot, next; };
 
 // everything an evaluation needs besides the parameter vector
 struct EvalCtx {
-	int ns, n, H, W; double h, hy, cutoff;
+	int ns, n, H, W, pool; double h, hy, cutoff;
 	const double* Cg;            // the target's coefficient table in HBM
 	const double* kn; const double* kny; const double* img; const double* wgt;
 	StarW* sw; double* Kc; double* red; int* keys;   // keys[kPool][2]: the knot intervals of every cached set
@@ -74,7 +81,7 @@ __device__ void prepare_stars(const double* x, const EvalCtx& c)
 		// the knot intervals, free of the pixel the star sits in: first = (l - 3) - 9 * jstar
 		const int kx = s.ax0 + 9 * s.jstar, ky = s.by0 + 9 * s.istar;
 		// the star's share of the pool: sets [tid * per, (tid + 1) * per); a hit anywhere in it, else the oldest is replaced
-		const int per = kPool / c.ns;
+		const int per = c.pool / c.ns;
 		s.rebuild = 0;
 		if (s.valid) {
 			int hit = -1;
@@ -146,10 +153,11 @@ __device__ double likelihood(const double* x, const EvalCtx& c)
 	return tot;
 }
 
-__global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a)
+// `targets`: the targets of this launch (all with the same number of fitted stars, so that `pool` sets are what each needs)
+__global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const int32_t* __restrict__ targets, int pool)
 {
 	extern __shared__ __align__(16) double lds[];
-	const int target = blockIdx.x;
+	const int target = targets[blockIdx.x];
 	const int tid = threadIdx.x;
 	const int n = a.n, H = a.height, W = a.width, P = H * W;
 	double* kn = lds;
@@ -162,11 +170,11 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a)
 	double* x0 = xt + 3 * kMaxDim;            // warm start [kMaxDim]
 	double* red = x0 + kMaxDim;               // [8]
 	double* Kc = red + 8;                     // [kPool][kItems][25] cached polynomial coefficients
-	StarW* sw = reinterpret_cast<StarW*>(Kc + (size_t)kPool * kItems * 25);
-	int* keys = reinterpret_cast<int*>(sw + kMaxPsfStars);   // [kPool][2]
+	StarW* sw = reinterpret_cast<StarW*>(Kc + (size_t)pool * kItems * 25);
+	int* keys = reinterpret_cast<int*>(sw + kMaxPsfStars);   // [pool][2]
 	for (int i = tid; i < n + 4; i += kThreads) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
 	if (tid < kMaxPsfStars) { sw[tid].rebuild = 0; sw[tid].valid = 0; sw[tid].slot = 0; sw[tid].next = 0; }
-	if (tid < 2 * kPool) keys[tid] = -0x7fffffff;
+	if (tid < 2 * pool) keys[tid] = -0x7fffffff;
 	const int64_t s0 = a.star_offsets[target];
 	int ns = (int)(a.star_offsets[target + 1] - s0);
 	if (ns > kMaxPsfStars) ns = kMaxPsfStars;
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a)
 		return;
 	}
 	EvalCtx ec;
-	ec.ns = ns; ec.n = n; ec.H = H; ec.W = W; ec.h = h; ec.hy = hy; ec.cutoff = a.cutoff;
+	ec.ns = ns; ec.n = n; ec.H = H; ec.W = W; ec.pool = pool; ec.h = h; ec.hy = hy; ec.cutoff = a.cutoff;
 	ec.Cg = a.coef + (int64_t)target * n * n; ec.kn = kn; ec.kny = kny; ec.img = img; ec.wgt = wgt; ec.sw = sw; ec.Kc = Kc; ec.red = red; ec.keys = keys;
 #define EVAL(xp) likelihood((xp), ec)
 	for (int k = 0; k < a.n_cad; ++k) {
@@ -381,10 +389,24 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 	TP_REQUIRE(ctx, maxiter_first >= 1 && maxiter >= 1, "tp_psf_fit: bad iteration limits");
 	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
 	const size_t P = (size_t)desc->height * desc->width;
-	const size_t doubles = 2 * ((size_t)n_coef_axis + 4) + 2 * P + (kMaxDim + 1) * kMaxDim + (kMaxDim + 1)
-		+ 3 * kMaxDim + kMaxDim + 8 + (size_t)kPool * kItems * 25;
-	const size_t shmem = doubles * sizeof(double) + kMaxPsfStars * sizeof(StarW) + 2 * kPool * sizeof(int) + 16;
-	TP_REQUIRE(ctx, shmem <= 160 * 1024, "tp_psf_fit: stamp too large for the LDS-resident image and weight map");
+	auto lds_bytes = [&](int pool) {
+		const size_t doubles = 2 * ((size_t)n_coef_axis + 4) + 2 * P + (kMaxDim + 1) * kMaxDim + (kMaxDim + 1)
+			+ 3 * kMaxDim + kMaxDim + 8 + (size_t)pool * kItems * 25;
+		return doubles * sizeof(double) + kMaxPsfStars * sizeof(StarW) + 2 * kPool * sizeof(int) + 16;
+	};
+	TP_REQUIRE(ctx, lds_bytes(kPool) <= 160 * 1024, "tp_psf_fit: stamp too large for the LDS-resident image and weight map");
+	// the targets by their number of fitted stars (one launch each, see psf_pool): the star offsets come to the host once
+	std::vector<int64_t> off((size_t)desc->n_targets + 1);
+	TP_HIP(ctx, hipMemcpyAsync(off.data(), d_star_offsets, off.size() * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	std::vector<int32_t> lists[kMaxPsfStars + 1];
+	for (int t = 0; t < desc->n_targets; ++t) {
+		int ns = (int)(off[(size_t)t + 1] - off[(size_t)t]);
+		ns = ns < 0 ? 0 : (ns > kMaxPsfStars ? kMaxPsfStars : ns);
+		lists[ns].push_back(t);
+	}
+	int32_t* d_lists = nullptr;
+	TP_HIP(ctx, hipMalloc(&d_lists, (size_t)desc->n_targets * sizeof(int32_t)));
 	PsfArgs a;
 	a.images = d_images; a.backgrounds = d_backgrounds; a.n_cad = desc->n_cad; a.height = desc->height; a.width = desc->width; a.t_pitch = desc->t_pitch;
 	a.coef = d_coef; a.knots_x = d_knots_x; a.knots_y = d_knots_y; a.n = n_coef_axis;
@@ -392,9 +414,40 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 	a.var_floor = (float)variance_floor; a.cutoff = cutoff_radius; a.maxiter_first = maxiter_first; a.maxiter = maxiter;
 	a.flux = d_flux; a.flux_err = d_flux_err; a.cen_row = d_centroid_row; a.cen_col = d_centroid_col; a.out_pitch = out_pitch;
 	a.params_out = d_params_out; a.nit = d_nit; a.status = d_status;
-	TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_psf_fit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-	TP_LAUNCH(ctx, TPK_PSF_FIT, tp_psf_fit_kernel, dim3((unsigned)desc->n_targets), dim3(kThreads), shmem, a);
-	TP_LAUNCH_CHECK(ctx, "tp_psf_fit_kernel");
+	TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_psf_fit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(kPool)));
+	// the launches are independent: the context's stream and two side streams in turn, so that their tails overlap (every launch
+	// ends with a few long-running workgroups on an otherwise idle chip)
+	hipStream_t streams[3] = {ctx->stream, nullptr, nullptr};
+	for (int i = 0; i < 2; ++i) {
+		if (!ctx->side[i]) TP_HIP(ctx, hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+		streams[i + 1] = ctx->side[i];
+	}
+	size_t at = 0;
+	for (int ns = 0; ns <= kMaxPsfStars; ++ns) {
+		if (lists[ns].empty()) continue;
+		if (hipMemcpyAsync(d_lists + at, lists[ns].data(), lists[ns].size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) break;
+		at += lists[ns].size();
+	}
+	hipEvent_t before = ctx->get_event();
+	hipError_t err = hipEventRecord(before, ctx->stream);
+	at = 0;
+	int used = 0;
+	bool waited[3] = {true, false, false};
+	for (int ns = kMaxPsfStars; ns >= 0 && err == hipSuccess; --ns) {   // the longest fits first
+		if (lists[ns].empty()) continue;
+		size_t first = 0;
+		for (int m = 0; m < ns; ++m) first += lists[m].size();
+		const int pool = psf_pool(ns);
+		const int si = used++ % 3;
+		if (!waited[si]) { err = hipStreamWaitEvent(streams[si], before, 0); waited[si] = true; if (err != hipSuccess) break; }
+		TP_LAUNCH_ON(ctx, streams[si], TPK_PSF_FIT, tp_psf_fit_kernel, dim3((unsigned)lists[ns].size()), dim3(kThreads), lds_bytes(pool), a, (const int32_t*)(d_lists + first), pool);
+		err = hipGetLastError();
+	}
+	// the lists (host vectors, device copy) must outlive the copies and the launches
+	for (int i = 2; i >= 0; --i) if (waited[i]) (void)hipStreamSynchronize(streams[i]);
+	ctx->pool.push_back(before);
+	(void)hipFree(d_lists);
+	if (err != hipSuccess) return ctx->fail(TP_ERR_HIP, "tp_psf_fit_kernel", err);
 	return TP_OK;
 	TP_API_END(ctx)
 }

@@ -20,6 +20,8 @@ offs, params, mini = [0], [], []
 for i in range(Nt):
 	c = s.catalog_of(i)
 	sel = psf_star_selection(c['row_stamp'], c['column_stamp'], c['tmag'], s.target_pos_row[i] - s.stamps[i][0], s.target_pos_column[i] - s.stamps[i][2], s.target_tmag[i])
+	if os.environ.get('MAXSTARS'):
+		sel = sel[:int(os.environ['MAXSTARS'])]
 	params.append(np.column_stack((c['row_stamp'][sel].astype('float64'), c['column_stamp'][sel].astype('float64'), mag2flux(c['tmag'][sel].astype('float64')))))
 	offs.append(offs[-1] + len(sel))
 	m = np.zeros((H, W), dtype='uint8')
