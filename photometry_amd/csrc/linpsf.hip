@@ -1371,7 +1371,7 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	TP_LAUNCH_CHECK(ctx, "tp_linpsf_coef_kernel");
 	// the matrix-core fit of the targets marked for it (up to 4 stars, up to 256 reachable pixels)
 	if (use_mfma) {
-		const int rc = fit_mfma_launch(ctx, a, desc->n_targets, totals + kTotClass0, d_plans, d_lists, d_mplans, d_ulist, d_kstore, d_alast);
+		const int rc = fit_mfma_launch(ctx, a, desc->n_targets, totals + kTotClass0, d_plans, d_lists, d_mplans, d_ulist, d_usig, d_kstore, d_alast);
 		if (rc != TP_OK) return rc;
 #define TP_LINPSF_FINM(CLS, SS) do { \
 			if (totals[kTotClass0 + CLS] > 0) { \

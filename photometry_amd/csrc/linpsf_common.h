@@ -188,6 +188,6 @@ enum { kPathPoly = 0, kPathDirect = 1, kPathMfma = 2 };
 
 // linpsf_mfma.hip
 int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned long long* class_counts, const StarPlan* d_plans,
-	const int32_t* d_class_lists, const MPlan* d_mplans, const uint16_t* d_ulist, const double* d_kstore, double* d_alast);
+	const int32_t* d_class_lists, const MPlan* d_mplans, const uint16_t* d_ulist, const uint8_t* d_usig, const double* d_kstore, double* d_alast);
 
 } // namespace tp_linpsf

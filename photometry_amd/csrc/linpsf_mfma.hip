@@ -49,8 +49,8 @@ __device__ __forceinline__ void dma_to_lds16(const void* src, void* lds_base)
 // series divides over the wavefronts; 16 GC lanes then solve -- with one star that costs nothing, with more it is the price).
 template <int S, int NTHR, int MINW, int GC>
 __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, const StarPlan* __restrict__ plans,
-	const int32_t* __restrict__ targets, const MPlan* __restrict__ mplans, const uint16_t* __restrict__ ulist, const double* __restrict__ kstore,
-	double* __restrict__ alast)
+	const int32_t* __restrict__ targets, const MPlan* __restrict__ mplans, const uint16_t* __restrict__ ulist, const uint8_t* __restrict__ usig,
+	const double* __restrict__ kstore, double* __restrict__ alast)
 {
 	const int NWV = (int)blockDim.x >> 6;   // wavefronts of the workgroup (chosen by the host for the length of the series)
 	constexpr int NACC = S + S * (S + 1) / 2;
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 	// element offset of its series in the target's cube (one 16-byte read gives a lane its four), row and column
 	__shared__ __align__(16) unsigned soff[kMfmaPixels];
 	__shared__ __align__(16) float scrow[kMfmaPixels], sccol[kMfmaPixels];
+	__shared__ unsigned semask[S][16];   // per star and tile: the pixels (bit u of the tile) that are inside the cut-off at some cadences only
 
 	const int target = targets[blockIdx.x];
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,7 +77,12 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 		for (int off = wave * 128; off < mp.kdoubles; off += NWV * 128)
 			if (off + lane * 2 < mp.kdoubles) dma_to_lds16(ksrc + off + lane * 2, sK + off);
 	}
+	if (tid < S * 16) (&semask[0][0])[tid] = 0u;
+	__syncthreads();
 	for (int t = tid; t < kMfmaPixels; t += (int)blockDim.x) {
+		const unsigned edge = (unsigned)usig[(int64_t)target * kMfmaPixels + t] >> 4;
+#pragma unroll
+		for (int s = 0; s < S; ++s) if ((edge >> s) & 1u) atomicOr(&semask[s][t >> 4], 1u << (t & 15));
 		const unsigned px = ulist[(int64_t)target * kMfmaPixels + t];
 		const int slot = (t & ~15) | ((t & 3) << 2) | ((t >> 2) & 3);   // pixel t = 16 tile + g + 4 r  ->  [tile][g][r]
 		soff[slot] = (px == 0xffffu) ? 0u : px * (unsigned)a.t_pitch;    // a pad slot: any valid address (its coefficients are zero)
@@ -224,23 +230,34 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 				// adds its issue time), so only the terms of the stars that reach the tile are formed (uniform branches).
 				const bool fin4 = (fabsf(bv[0]) <= 3.402823466e+38f) && (fabsf(bv[1]) <= 3.402823466e+38f) && (fabsf(bv[2]) <= 3.402823466e+38f)
 					&& (fabsf(bv[3]) <= 3.402823466e+38f);
-				if (anyedge || __any(!fin4)) {
-					const float4 pr = *reinterpret_cast<const float4*>(&scrow[P * 16 + g * 4]), pc = *reinterpret_cast<const float4*>(&sccol[P * 16 + g * 4]);
-					const float prr[4] = {pr.x, pr.y, pr.z, pr.w}, pcr[4] = {pc.x, pc.y, pc.z, pc.w};
+				if (__any(!fin4)) {   // a NaN pixel in the tile (uniform): its row of the design matrix and its value count as zero
 #pragma unroll
 					for (int r = 0; r < 4; ++r) {
 						const bool fin = fabsf(bv[r]) <= 3.402823466e+38f;
 						bv[r] = fin ? bv[r] : 0.f;
 #pragma unroll
-						for (int s = 0; s < S; ++s) {
-							if (!has[s]) continue;
+						for (int s = 0; s < S; ++s) if (has[s]) D[s][r] = fin ? D[s][r] : 0.0;
+					}
+				}
+				if (anyedge) {
+					const float4 pr = *reinterpret_cast<const float4*>(&scrow[P * 16 + g * 4]), pc = *reinterpret_cast<const float4*>(&sccol[P * 16 + g * 4]);
+					const float prr[4] = {pr.x, pr.y, pr.z, pr.w}, pcr[4] = {pc.x, pc.y, pc.z, pc.w};
+#pragma unroll
+					for (int s = 0; s < S; ++s) {
+						if (!has[s] || !((etl[s] >> P) & 1u)) continue;
+						// the pixels of this tile that are inside the star's cut-off at some cadences only: bit u = g + 4 r, so a nibble
+						// per register r -- the edge pixels are the last of their group of the list, a few consecutive u
+						const unsigned em = (unsigned)__builtin_amdgcn_readfirstlane((int)semask[s][P]);
+#pragma unroll
+						for (int r = 0; r < 4; ++r) {
+							if (!((em >> (4 * r)) & 15u)) continue;
 							const float dcf = pcr[r] - scf[s], drf = prr[r] - srf[s];
 							const float d2f = dcf * dcf + drf * drf;
 							bool inside = d2f < c2f;
 							// psf.py:142  sqrt((j-col)^2 + (i-row)^2) < cutoff_radius: FP32 decides unless it is within 1e-4 of the
 							// radius squared (its error is below 1e-5 for stamps up to 256 pixels wide); then the FP64 expression
 							// does, and the reference's own square root when that too is within rounding
-							const bool near = fin && (fabsf(d2f - c2f) <= 1e-4f * c2f);
+							const bool near = fabsf(d2f - c2f) <= 1e-4f * c2f;
 							if (__any(near)) {
 								if (near) {
 									const double dc = (double)pcr[r] - a.pos_col[(s0 + s) * a.pos_pitch + kk];
@@ -250,7 +267,7 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 									inside = (fabs(d2 - c2) > 1e-9 * c2) ? (d2 < c2) : (sqrt(d2) < cutoff);
 								}
 							}
-							D[s][r] = (fin && inside) ? D[s][r] : 0.0;
+							D[s][r] = inside ? D[s][r] : 0.0;
 						}
 					}
 				}
@@ -360,7 +377,7 @@ static int fit_waves(int n_cad, int most, int group_cadences)
 
 // launches the matrix-core fit, one launch per class of targets the plan kernel has listed ((stars - 1) * 2 + large image)
 int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned long long* class_counts, const StarPlan* d_plans,
-	const int32_t* d_class_lists, const MPlan* d_mplans, const uint16_t* d_ulist, const double* d_kstore, double* d_alast)
+	const int32_t* d_class_lists, const MPlan* d_mplans, const uint16_t* d_ulist, const uint8_t* d_usig, const double* d_kstore, double* d_alast)
 {
 	// The launches are independent (one per star count): the first runs on the context's stream, the others on two side streams
 	// that wait for what precedes on it (the coefficient store) and are waited for before what follows (the finalisation), so that
@@ -380,7 +397,7 @@ int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned
 			if (!waited[si]) { TP_HIP(ctx, hipStreamWaitEvent(streams[si], before, 0)); waited[si] = true; } \
 			TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fitm_kernel<SS, TT, WW, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
 			TP_LAUNCH_ON(ctx, streams[si], TPK_LINPSF_FIT_MFMA, (tp_linpsf_fitm_kernel<SS, TT, WW, GG>), dim3((unsigned)class_counts[CLS]), dim3(64 * fit_waves(a.n_cad, TT / 64, 16 * GG)), (size_t)LDS, \
-				a, d_plans, d_class_lists + (size_t)(CLS) * n_targets, d_mplans, d_ulist, d_kstore, d_alast); \
+				a, d_plans, d_class_lists + (size_t)(CLS) * n_targets, d_mplans, d_ulist, d_usig, d_kstore, d_alast); \
 			TP_LAUNCH_CHECK(ctx, "tp_linpsf_fitm_kernel"); \
 		} \
 	} while (0)
