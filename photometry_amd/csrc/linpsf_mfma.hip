@@ -56,7 +56,7 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 	constexpr int NACC = S + S * (S + 1) / 2;
 	extern __shared__ __align__(16) double sK[];    // the target's coefficient image
 	// per pixel of the list, in the order a lane reads them -- [tile][lane group g][register r] = pixel 16 tile + g + 4 r: the
-	// element offset of its series in the target's cube (one 16-byte read gives a lane its four), row and column
+	// byte offset of its series in the target's cube (one 16-byte read gives a lane its four), row and column
 	__shared__ __align__(16) unsigned soff[kMfmaPixels];
 	__shared__ __align__(16) float scrow[kMfmaPixels], sccol[kMfmaPixels];
 	__shared__ unsigned semask[S][16];   // per star and tile: the pixels (bit u of the tile) that are inside the cut-off at some cadences only
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 		for (int s = 0; s < S; ++s) if ((edge >> s) & 1u) atomicOr(&semask[s][t >> 4], 1u << (t & 15));
 		const unsigned px = ulist[(int64_t)target * kMfmaPixels + t];
 		const int slot = (t & ~15) | ((t & 3) << 2) | ((t >> 2) & 3);   // pixel t = 16 tile + g + 4 r  ->  [tile][g][r]
-		soff[slot] = (px == 0xffffu) ? 0u : px * (unsigned)a.t_pitch;    // a pad slot: any valid address (its coefficients are zero)
+		soff[slot] = (px == 0xffffu) ? 0u : (px * (unsigned)a.t_pitch) << 2;    // bytes; a pad slot: any valid address (its coefficients are zero)
 		const int pi = (int)px / W, pj = (int)px - pi * W;
 		scrow[slot] = (px != 0xffffu) ? (float)pi : 1e6f;
 		sccol[slot] = (px != 0xffffu) ? (float)pj : 1e6f;
@@ -137,10 +137,14 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 			const bool act = k < a.n_cad;
 			const bool last_here = (a.n_cad - 1 >= k0) && (a.n_cad - 1 < k0 + 16);   // uniform
 			const int kk = act ? k : (a.n_cad - 1);
+			const unsigned kk4 = (unsigned)kk << 2;
 			// the first pixel tiles of this tile of cadences are on their way while the basis products are computed
 			auto load_tile = [&](int P, float (&bv)[4]) {
+				// byte offsets (the host admits cubes below 2^30 elements per target only): one addition per load
 				const uint4 o = *reinterpret_cast<const uint4*>(&soff[P * 16 + g * 4]);
-				bv[0] = img[o.x + (unsigned)kk]; bv[1] = img[o.y + (unsigned)kk]; bv[2] = img[o.z + (unsigned)kk]; bv[3] = img[o.w + (unsigned)kk];
+				const char* ib = reinterpret_cast<const char*>(img);
+				bv[0] = *reinterpret_cast<const float*>(ib + (o.x + kk4)); bv[1] = *reinterpret_cast<const float*>(ib + (o.y + kk4));
+				bv[2] = *reinterpret_cast<const float*>(ib + (o.z + kk4)); bv[3] = *reinterpret_cast<const float*>(ib + (o.w + kk4));
 			};
 			float bv0[4], bv1[4] = {0.f, 0.f, 0.f, 0.f}, bv2[4] = {0.f, 0.f, 0.f, 0.f};
 			constexpr int RING = (S == 1) ? 3 : 2;   // pixel tiles in flight (registers again)
@@ -228,8 +232,9 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 				// that are inside at some cadences only ("edge") at the end of the list -- the test runs only in tiles that hold one.
 				// Vector instructions do not run beside the matrix instructions on this chip (tools/lab/mfma_f64.hip: every kind
 				// adds its issue time), so only the terms of the stars that reach the tile are formed (uniform branches).
-				const bool fin4 = (fabsf(bv[0]) <= 3.402823466e+38f) && (fabsf(bv[1]) <= 3.402823466e+38f) && (fabsf(bv[2]) <= 3.402823466e+38f)
-					&& (fabsf(bv[3]) <= 3.402823466e+38f);
+				// all four finite <=> their sum is (a NaN or an infinity survives any sum; finite values that overflow it only send
+				// the tile through the exact per-pixel test below)
+				const bool fin4 = fabsf((bv[0] + bv[1]) + (bv[2] + bv[3])) <= 3.402823466e+38f;
 				if (__any(!fin4)) {   // a NaN pixel in the tile (uniform): its row of the design matrix and its value count as zero
 #pragma unroll
 					for (int r = 0; r < 4; ++r) {
