@@ -17,17 +17,20 @@
 // coefficient block per (star, origin, tile): it spent its time staging those blocks).
 //
 // Layout.  One workgroup per target; the target's coefficient image (A operands, [star][tile][step][lane], 20 - 150 KB) is copied
-// to LDS once.  A wavefront takes 64 consecutive cadences at a time, as four tiles of 16.  Result tile D: column = cadence
-// (lane & 15), row = pixel ((lane >> 4) + 4 r in register r): a lane owns one cadence and a quarter of the pixels, so the normal
-// equations G = A^T A, g = A^T b of a cadence are sums INSIDE a lane over registers and pixel tiles, plus one cross-lane sum over
-// the four lane groups per tile of cadences; lane group m keeps the sums of tile m, so that all 64 lanes solve one cadence each.
+// to LDS once.  A wavefront takes GC tiles of 16 consecutive cadences at a time (GC = 1 in every launch now: with the Cholesky
+// solve a sixteen-lane solve costs less than the idle tail of larger units).  Result tile D: column = cadence (lane & 15), row =
+// pixel ((lane >> 4) + 4 r in register r): a lane owns one cadence and a quarter of the pixels, so the normal equations G = A^T A,
+// g = A^T b of a cadence are sums INSIDE a lane over registers and pixel tiles, plus one cross-lane sum over the four lane groups
+// per tile of cadences; with GC > 1 lane group m keeps the sums of tile m, so that 16 GC lanes solve one cadence each.
 // Pixels: the list U of the target (every pixel inside the cut-off of some star at some cadence, ordered so that the pixels of one
 // star are contiguous; plan kernel), cut into tiles of 16, the same for all stars, so products A_s A_t meet in the same register.
 // The B operands (basis products of the lane's cadence) are computed once per star and tile of cadences and stay in registers.
 //
 // FP64 matrix and FP64 vector instructions share one pipe on this chip (tools/lab/mfma_f64.hip: v_fma_f64 beside the MFMAs adds
-// its full issue time), so everything that can is done in FP32 or integer: the cut-off test runs in FP32 with an exact FP64
-// re-test for lanes within 1e-4 of the radius, and only in tiles that hold a pixel which is inside at some cadences only.
+// its full issue time -- and so does every other vector instruction, 2.3 - 5 cycles each beside the 70 of an MFMA), so the
+// vector work per tile is kept small: the cut-off test runs in FP32 with an exact FP64 re-test for lanes within 1e-4 of the
+// radius, and only for the stars and registers that hold a pixel which is inside at some cadences only; a NaN pixel only zeroes
+// its row; the terms of the normal equations are formed only for the stars that reach the tile.
 #include "linpsf_common.h"
 
 namespace {
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 	const double cutoff = a.cutoff, c2 = cutoff * cutoff;
 	const float c2f = (float)c2;
 
-	// ---- the coefficient image by LDS DMA (1 KB per wavefront and instruction), the pixel list, the knots
+	// ---- the coefficient image by LDS DMA (1 KB per wavefront and instruction), the pixel list, the edge masks
 	{
 		const double* ksrc = kstore + mp.koff;
 		for (int off = wave * 128; off < mp.kdoubles; off += NWV * 128)
