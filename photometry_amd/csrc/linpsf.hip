@@ -24,10 +24,12 @@
 // The normal equations (A^T A, A^T b) are accumulated on the fly; x = pinv(A^T A) A^T b via a cyclic
 // Jacobi eigen-decomposition with numpy's pinv cutoff (rcond = 1e-15 * largest singular value).
 //
-// Roofline: FP64 vector FMA, not HBM: the image cube is read once (P*T*4 bytes per target).  MFMA is not used: on the
-// MI355X the FP64 matrix rate equals the FP64 vector rate (78.6 TFLOP/s both), the monomial-basis GEMM form of the
-// polynomial ([cadences x 25] x [25 x pixels]) would also compute the pixels outside the cut-off circle, and the dense
-// form of the direct contraction does 13x the flops of the banded one.
+// Roofline: the FP64 pipe, not HBM: the image cube is read once (P*T*4 bytes per target).  Since round 3 the fit of a target
+// with up to 4 stars runs on the matrix cores (linpsf_mfma.hip: ONE quartic spline per star and pixel over the knot intervals the
+// star visits, cadences in natural order); the kernels of this file plan it (tp_linpsf_plan_kernel), build its coefficients
+// (tp_linpsf_coef_kernel) and finalise it (tp_linpsf_finalize_m_kernel), and fit the targets that do not qualify on the vector
+// ALUs (tp_linpsf_fit2_kernel: a biquartic per pixel and table origin, cadences sorted by origin; tp_linpsf_fit_direct_kernel;
+// tp_linpsf_fit_many_kernel).
 #include "linpsf_common.h"
 
 void* tp_ctx_scratch(tp_ctx* ctx, size_t bytes); // aperture.hip
