@@ -492,6 +492,9 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 		heights, widths = cur[active, 1] - cur[active, 0], cur[active, 3] - cur[active, 2]
 		keys = heights * 100000 + widths
 		still = []
+		# ---- the device passes of all groups of this round are queued first (the host prepares group i + 1 while the device
+		# works on group i), then their results are read and decided group by group
+		launched = []
 		for key in np.unique(keys):
 			idx = active[keys == key]
 			H, W = int(key // 100000), int(key % 100000)
@@ -506,20 +509,32 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 				work = ApertureWork(ctx, batch)
 				aperture_step(ctx, batch, work)
 				aperture_diagnostics(ctx, batch, work)
-				ctx.sync()
+				launched.append((idx, H, W, scene, cat_offsets, cat_arrays, cubes, batch, work))
 			except TessphotError as e:
 				# e.g. a stamp beyond 65 535 pixels (the mask builder's 16-bit labels): Halo territory upstream
+				try:
+					ctx.sync()
+				except TessphotError:
+					pass
+				if cubes is not None:
+					for c in cubes.values():
+						c.free()
 				for i in idx:
 					logger_of(int(i)).error('Device pass failed for a %dx%d stamp: %s', H, W, str(e))
 					finish(int(i), 2)
+		failed = None
+		try:
+			ctx.sync()
+		except TessphotError as e:   # a device error surfaces at the synchronisation: every group of the round is lost
+			failed = e
+		for (idx, H, W, scene, cat_offsets, cat_arrays, cubes, batch, work) in launched:
+			for c in cubes.values():
+				c.free()
+			if failed is not None:
+				for i in idx:
+					logger_of(int(i)).error('Device pass failed for a %dx%d stamp: %s', H, W, str(failed))
+					finish(int(i), 2)
 				continue
-			finally:
-				if cubes is not None:
-					try:
-						ctx.sync()
-					finally:
-						for c in cubes.values():
-							c.free()
 			res = {k: getattr(work, k).to_host() for k in ('sumimage', 'mask', 'status', 'flags', 'contamination', 'cat_in_mask', 'diagnostics')}
 			grp = dict(res, lc=work.lc.block.to_host(), cat_offsets=cat_offsets, cat_starid=cat_arrays['starid'], target_starid=scene.target_starid)
 			gid = len(out.groups)
