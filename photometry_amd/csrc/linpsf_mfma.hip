@@ -112,6 +112,7 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 		axmin[s] = p.axmin; bymin[s] = p.bymin;
 	}
 	const float* img = a.images + (int64_t)target * H * W * a.t_pitch;
+	const int ti = a.target_index[target];   // loaded once: inside the loop its latency would stand in front of every solve
 	constexpr int GCAD = 16 * GC;   // cadences per group
 	const int ngroups = (a.n_cad + GCAD - 1) / GCAD;
 
@@ -353,7 +354,6 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 					for (int s = 0; s < S; ++s) x[s] = xp[s];
 				}
 			}
-			const int ti = a.target_index[target];
 			double tf = __builtin_nan("");
 #pragma unroll
 			for (int s = 0; s < S; ++s) {
