@@ -132,3 +132,46 @@ def test_linpsf_argument_checks(ctx):
 		engine.linpsf_fit(ctx, img, z, ctx.zeros((121,), 'float64'), ctx.zeros((121,), 'float64'), ctx.zeros((2,), 'int64'),
 			ctx.zeros((1,), 'int32'), ctx.zeros((1, 8), 'float64'), ctx.zeros((1, 8), 'float64'), 1, cutoff_radius=7.0)
 	assert 'cutoff_radius' in str(e.value)
+
+
+def test_matrix_core_fit_takes_the_qualifying_targets(ctx):
+	"""With the default mapping a batch of targets with up to four fitted stars and ordinary jitter is fitted by the matrix-core
+	kernel alone (no vector-ALU fit launch); with path 0, and for stars that wander over more than three knot intervals, by the
+	vector-ALU kernels -- same light curves either way."""
+	from photometry_amd import simulate, engine, psf as hpsf
+	from photometry_amd.device import DeviceCube
+	from oracle import psf as opsf
+	prf = opsf.synthetic_prf(seed=7)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	out = {}
+	for jit in (1, 8):
+		s = simulate.make_scene(24, 64, 13, 13, seed=77, max_neighbours=2, neighbour_tmag_range=(9.0, 16.0))
+		s.jitter = s.jitter * jit
+		simulate.fill_cubes(s, nan_fraction=0.002)
+		sel, star_offsets, target_index = hpsf.select_stars(s.catalog, s.cat_offsets, s.target_starid)
+		pos_row, pos_col = _positions(s, sel, 64)
+		coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(model.weights(s.stamps)))
+		cube = DeviceCube.from_host(ctx, s.images)
+		for path in (1, 0):
+			engine.linpsf_set_path(ctx, path)
+			ctx.profile(True)
+			ctx.profile_reset()
+			try:
+				res = engine.linpsf_fit(ctx, cube, coef, ctx.array(model.tx), ctx.array(model.ty), ctx.array(star_offsets), ctx.array(target_index),
+					ctx.array(pos_row), ctx.array(pos_col), int(np.diff(star_offsets).max())).to_host()
+				ctx.sync()
+				rep = ctx.profile_report()
+			finally:
+				ctx.profile(False)
+				engine.linpsf_set_path(ctx, 1)
+			out[(jit, path)] = (res, set(rep))
+	# ordinary jitter: matrix cores only / vector ALUs only
+	assert 'tp_linpsf_fitm_kernel' in out[(1, 1)][1] and 'tp_linpsf_fit_kernel' not in out[(1, 1)][1]
+	assert 'tp_linpsf_fitm_kernel' not in out[(1, 0)][1] and 'tp_linpsf_fit_kernel' in out[(1, 0)][1]
+	# wide jitter: more than 3 x 3 knot intervals -> the plan leaves (most of) the targets to the vector-ALU kernels
+	assert 'tp_linpsf_fit_kernel' in out[(8, 1)][1] or 'tp_linpsf_fit_direct_kernel' in out[(8, 1)][1]
+	for jit in (1, 8):
+		a, b = out[(jit, 1)][0], out[(jit, 0)][0]
+		scale = np.nanmax(np.abs(a['flux']))
+		np.testing.assert_allclose(a['flux'], b['flux'], rtol=1e-9, atol=1e-10 * scale)
+		np.testing.assert_array_equal(a['status'], b['status'])
