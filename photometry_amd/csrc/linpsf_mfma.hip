@@ -156,6 +156,9 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 			if (RING == 3 && ntiles > 1) load_tile(1, bv1);
 			if (!AHEAD) load_cadence(k0);
 			const float sb = nsb;
+			// the short vector phases (basis products here, reduction and solve below) run at raised priority: a wavefront in one of
+			// them would otherwise queue every instruction behind the 70-cycle matrix instructions of the wavefronts in their pixel loops
+			__builtin_amdgcn_s_setprio(3);
 
 			// ---- B operands: the basis products of this lane's cadence.  Steps (the order of the coefficient image): x basis
 			// 0..4 times y basis g; y basis 4 times x basis g, then 4 + g; x basis 5, 6 times y basis g; y basis 5, 6 like 4
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 			}
 
 			if (AHEAD) load_cadence((mt < GC - 1 && k0 + 16 < a.n_cad) ? (k0 + 16) : ((gi + NWV) * GCAD));
+			__builtin_amdgcn_s_setprio(0);
 
 			double acc[NACC];
 #pragma unroll
@@ -323,6 +327,7 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 					process(P + 1, bv1);
 				}
 			}
+			__builtin_amdgcn_s_setprio(3);
 			// ---- sum over the four lane groups; group mt keeps the sums of this tile of cadences
 #pragma unroll
 			for (int m = 0; m < NACC; ++m) {
