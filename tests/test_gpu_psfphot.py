@@ -112,3 +112,41 @@ def test_psf_photometry_matches_oracle(ctx):
 	# the device walks scipy's simplex: until the first last-bit flip in a target's warm-start chain the iteration counts are scipy's
 	print(f"identical iteration counts on {n_same_nit} of {n_cad} cadences")
 	assert n_same_nit >= n_cad // 4
+
+
+def test_psf_fit_batch_equals_target_by_target(ctx):
+	"""The kernel launches the targets of a batch by their number of fitted stars (one to five, a coefficient pool sized for each
+	class, three streams): every target gets exactly what it gets when fitted alone -- fluxes, centroids and iteration counts
+	bit for bit -- and the classes with four and five stars are exercised."""
+	from photometry_amd import simulate, engine, psf as hpsf
+	from photometry_amd.device import DeviceCube
+	from photometry_amd.plugins import psf_star_selection, mag2flux
+	from oracle import psf as opsf
+	Nt, T, H, W = 24, 3, 13, 13
+	s = simulate.make_scene(Nt, T, H, W, seed=123, max_neighbours=6, neighbour_tmag_range=(9.0, 13.5))
+	simulate.fill_cubes(s, nan_fraction=0.002)
+	prf = opsf.synthetic_prf(seed=5)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	offs, params, mini = [0], [], []
+	for i in range(Nt):
+		c = s.catalog_of(i)
+		sel = psf_star_selection(c['row_stamp'], c['column_stamp'], c['tmag'], s.target_pos_row[i] - s.stamps[i][0], s.target_pos_column[i] - s.stamps[i][2], s.target_tmag[i])
+		params.append(np.column_stack((c['row_stamp'][sel].astype('float64'), c['column_stamp'][sel].astype('float64'), mag2flux(c['tmag'][sel].astype('float64')))))
+		offs.append(offs[-1] + len(sel))
+		m = np.zeros((H, W), dtype='uint8')
+		r, cc = int(round(s.target_pos_row[i] - s.stamps[i][0])), int(round(s.target_pos_column[i] - s.stamps[i][2]))
+		m[max(r - 1, 0):r + 2, max(cc - 1, 0):cc + 2] = 1
+		mini.append(m)
+	counts = np.diff(offs)
+	assert counts.max() >= 4 and len(set(counts)) >= 3, counts
+	coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(model.weights(s.stamps)))
+	tx, ty = ctx.array(model.tx), ctx.array(model.ty)
+	whole = engine.psf_fit(ctx, DeviceCube.from_host(ctx, s.images), DeviceCube.from_host(ctx, s.backgrounds), coef, tx, ty,
+		ctx.array(np.asarray(offs, dtype='int64')), ctx.array(np.concatenate(params)), ctx.array(np.stack(mini)))
+	whole = {k: whole[k].to_host() for k in ('flux', 'centroid_row', 'centroid_col', 'nit')}
+	coef_h = coef.to_host()
+	for i in range(0, Nt, 3):
+		one = engine.psf_fit(ctx, DeviceCube.from_host(ctx, s.images[i:i + 1]), DeviceCube.from_host(ctx, s.backgrounds[i:i + 1]), ctx.array(coef_h[i:i + 1]), tx, ty,
+			ctx.array(np.array([0, len(params[i])], dtype='int64')), ctx.array(params[i]), ctx.array(mini[i][None]))
+		for k in ('flux', 'centroid_row', 'centroid_col', 'nit'):
+			np.testing.assert_array_equal(one[k].to_host()[0][:T], whole[k][i][:T], err_msg=f'target {i} ({counts[i]} stars) {k}')
