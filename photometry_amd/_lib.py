@@ -50,6 +50,7 @@ SIGNATURES = {
 	'tp_device_info': (c_int, [c_void_p, c_char_p, c_int, POINTER(c_int32), POINTER(c_uint64)]),
 	'tp_malloc': (c_int, [c_void_p, c_uint64, POINTER(c_void_p)]),
 	'tp_free': (c_int, [c_void_p, _p]),
+	'tp_cache_trim': (c_int, [c_void_p]),
 	'tp_memset': (c_int, [c_void_p, _p, c_int, c_uint64]),
 	'tp_memcpy_h2d': (c_int, [c_void_p, _p, _p, c_uint64]),
 	'tp_memcpy_d2h': (c_int, [c_void_p, _p, _p, c_uint64]),

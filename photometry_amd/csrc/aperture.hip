@@ -250,7 +250,7 @@ void* tp_ctx_scratch(tp_ctx* ctx, size_t bytes)
 	if (ctx->scratch_bytes < bytes) {
 		if (ctx->scratch) (void)hipFree(ctx->scratch);
 		ctx->scratch = nullptr; ctx->scratch_bytes = 0;
-		if (hipMalloc(&ctx->scratch, bytes) != hipSuccess) { ctx->scratch = nullptr; return nullptr; }
+		if (tp_device_alloc(ctx, &ctx->scratch, bytes) != hipSuccess) { ctx->scratch = nullptr; return nullptr; }
 		ctx->scratch_bytes = bytes;
 	}
 	return ctx->scratch;

@@ -102,6 +102,7 @@ static int tp_ctx_create_impl(int device, int high_priority, tp_ctx** out) {
 }
 
 int tp_comm_destroy(tp_ctx* ctx);
+static void tp_cache_release(tp_ctx* ctx);
 
 int tp_ctx_create(int device, tp_ctx** out) {
 	return tp_ctx_create_impl(device, 0, out);
@@ -119,8 +120,7 @@ int tp_ctx_destroy(tp_ctx* ctx) {
 	if (ctx->twiddle) (void)hipFree(ctx->twiddle);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
 	if (ctx->store) (void)hipFree(ctx->store);
-	for (auto& kv : ctx->cache) (void)hipFree(kv.second);
-	ctx->cache.clear();
+	tp_cache_release(ctx);
 	if (ctx->stage) (void)hipHostFree(ctx->stage);
 	if (ctx->ring) (void)hipHostFree(ctx->ring);
 	for (int k = 0; k < TPK_COUNT; k++)
@@ -164,30 +164,60 @@ static size_t tp_alloc_class(size_t n) {
 	return (n + step - 1) / step * step;
 }
 
+// every cached block back to the driver (their freeing events have to have completed: the stream is synchronised first)
+static void tp_cache_release(tp_ctx* ctx) {
+	if (ctx->cache.empty()) return;
+	(void)hipStreamSynchronize(ctx->stream);
+	for (auto& kv : ctx->cache) {
+		(void)hipFree(kv.second.ptr);
+		if (kv.second.freed) ctx->pool.push_back(kv.second.freed);
+	}
+	ctx->cache.clear();
+	ctx->cache_bytes = 0;
+}
+
+} // extern "C"
+hipError_t tp_device_alloc(tp_ctx* ctx, void** ptr, size_t bytes) {
+	hipError_t e = hipMalloc(ptr, bytes);
+	if (e == hipErrorOutOfMemory && !ctx->cache.empty()) {
+		tp_cache_release(ctx);
+		(void)hipGetLastError();
+		e = hipMalloc(ptr, bytes);
+	}
+	return e;
+}
+extern "C" {
+
+int tp_cache_trim(tp_ctx* ctx) {
+	TP_CHECK_CTX(ctx);
+	tp_cache_release(ctx);
+	return TP_OK;
+}
+
 int tp_malloc(tp_ctx* ctx, uint64_t nbytes, void** d_ptr) {
 	TP_CHECK_CTX(ctx);
 	TP_REQUIRE(ctx, d_ptr != nullptr, "tp_malloc: null output pointer");
 	*d_ptr = nullptr;
 	if (nbytes == 0) nbytes = 16;
 	const size_t cap = tp_alloc_class((size_t)nbytes);
-	auto it = ctx->cache.find(cap);
-	if (it != ctx->cache.end()) {
-		*d_ptr = it->second;
-		ctx->cache.erase(it);
+	auto range = ctx->cache.equal_range(cap);
+	if (range.first != range.second) {
+		// a block whose freeing event has completed is idle for every stream; if none is, wait for the oldest (what was queued on
+		// the context's stream when it was freed: the wait the old hipFree paid at once, paid only when it is still due)
+		auto pick = range.first;
+		bool idle = false;
+		for (auto it = range.first; it != range.second; ++it)
+			if (!it->second.freed || hipEventQuery(it->second.freed) == hipSuccess) { pick = it; idle = true; break; }
+		(void)hipGetLastError();   // hipErrorNotReady of the queries
+		if (!idle) TP_HIP(ctx, hipEventSynchronize(pick->second.freed));
+		*d_ptr = pick->second.ptr;
+		if (pick->second.freed) ctx->pool.push_back(pick->second.freed);
+		ctx->cache.erase(pick);
 		ctx->cache_bytes -= cap;
 		ctx->live[*d_ptr] = cap;
 		return TP_OK;
 	}
-	hipError_t e = hipMalloc(d_ptr, cap);
-	if (e == hipErrorOutOfMemory && !ctx->cache.empty()) {
-		// give the cached blocks back to the driver and try once more
-		(void)hipStreamSynchronize(ctx->stream);
-		for (auto& kv : ctx->cache) (void)hipFree(kv.second);
-		ctx->cache.clear();
-		ctx->cache_bytes = 0;
-		(void)hipGetLastError();
-		e = hipMalloc(d_ptr, cap);
-	}
+	const hipError_t e = tp_device_alloc(ctx, d_ptr, cap);
 	if (e == hipErrorOutOfMemory) return ctx->fail(TP_ERR_NOMEM, "tp_malloc: out of device memory");
 	if (e != hipSuccess) return ctx->fail(TP_ERR_HIP, "hipMalloc", e);
 	ctx->live[*d_ptr] = cap;
@@ -202,9 +232,11 @@ int tp_free(tp_ctx* ctx, void* d_ptr) {
 		const size_t cap = it->second;
 		ctx->live.erase(it);
 		if (cap <= ctx->cache_block && ctx->cache_bytes + cap <= ctx->cache_limit) {
-			// kept for the next tp_malloc of this capacity; whatever is queued on the stream for the block runs before any
-			// later use of it (one in-order stream per context)
-			ctx->cache.emplace(cap, d_ptr);
+			// kept for the next tp_malloc of this capacity; the event marks the end of what is queued on the context's stream for
+			// the block (tp_malloc hands it out again once that has run)
+			hipEvent_t ev = ctx->get_event();
+			if (ev) (void)hipEventRecord(ev, ctx->stream);
+			ctx->cache.emplace(cap, tp_ctx::cached_block{d_ptr, ev});
 			ctx->cache_bytes += cap;
 			return TP_OK;
 		}

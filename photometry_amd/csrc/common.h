@@ -60,9 +60,14 @@ struct tp_ctx {
 	// whole device, hipMalloc costs tens of microseconds -- and ~12 ms for a multi-GB block: the stamp cubes of the batched frames
 	// entry, measured); reuse is ordered by the context's stream.  Blocks up to cache_block (8 GiB), cache_limit (48 GiB) in all:
 	// a sixth of the 288 GB, given back when an allocation fails.
-	std::multimap<size_t, void*> cache;
+	// A cached block carries an event recorded on the context's stream when it was freed; tp_malloc hands it out again only once
+	// that event has completed (it prefers a block whose event already has, and waits otherwise), so a recycled block is idle
+	// whichever stream or context writes to it next.  tp_device_alloc (scratch, stores, work lists) and tp_malloc give the cache
+	// back to the driver when an allocation fails; tp_cache_trim does so on request.
+	struct cached_block { void* ptr; hipEvent_t freed; };
+	std::multimap<size_t, cached_block> cache;
 	std::map<void*, size_t> live;   // blocks handed out by tp_malloc -> capacity
-	size_t cache_bytes = 0, cache_limit = (size_t)48 << 30, cache_block = (size_t)8 << 30;
+	size_t cache_bytes = 0, cache_limit = (size_t)24 << 30, cache_block = (size_t)8 << 30;
 	// pinned staging area of the synchronous copy entries (tp_memcpy_h2d / _d2h): pageable transfers go through it in pieces
 	void* stage = nullptr;
 	size_t stage_bytes = 0;
@@ -95,6 +100,10 @@ struct tp_ctx {
 };
 
 extern thread_local std::string tp_global_err;
+
+// hipMalloc for the library's own buffers (context scratch, coefficient store, work lists): when the driver is out of memory
+// the blocks idling in the tp_malloc cache are given back first (api.cpp)
+hipError_t tp_device_alloc(tp_ctx* ctx, void** ptr, size_t bytes);
 
 #define TP_HIP(ctx, call) do { hipError_t _e = (call); if (_e != hipSuccess) return (ctx)->fail(TP_ERR_HIP, #call, _e); } while (0)
 #define TP_REQUIRE(ctx, cond, msg) do { if (!(cond)) return (ctx)->fail(TP_ERR_INVALID, msg); } while (0)

@@ -340,7 +340,9 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 			srange[s][3] = fmax(fmax(spos[0][s][3], spos[1][s][3]), fmax(spos[2][s][3], spos[3][s][3]));
 		}
 		if (too_many) s_path = kPathDirect;   // pointing excursions over many knots: the general kernel
-		else if (use_mfma && ns <= kMfmaStars && a.height * a.width <= 65535) s_path = kPathMfma;
+		// (a target without a fitted star -- its own catalogue entry dropped for a NaN magnitude or position -- has no class list:
+		// the polynomial path finalises it as 'All target flux values are NaN')
+		else if (use_mfma && ns >= 1 && ns <= kMfmaStars && a.height * a.width <= 65535) s_path = kPathMfma;
 	}
 	__syncthreads();
 	if (s_path == kPathMfma) {
@@ -1361,7 +1363,7 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	if (ctx->store_bytes < store_need) {
 		if (ctx->store) (void)hipFree(ctx->store);
 		ctx->store = nullptr; ctx->store_bytes = 0;
-		TP_HIP(ctx, hipMalloc(&ctx->store, store_need));
+		TP_HIP(ctx, tp_device_alloc(ctx, &ctx->store, store_need));
 		ctx->store_bytes = store_need;
 	}
 	double* d_store = static_cast<double*>(ctx->store);

@@ -25,6 +25,8 @@
 #include <cmath>
 #include <vector>
 
+void* tp_ctx_scratch(tp_ctx* ctx, size_t bytes); // aperture.hip
+
 namespace {
 
 using namespace tp_prf;
@@ -405,8 +407,8 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 		ns = ns < 0 ? 0 : (ns > kMaxPsfStars ? kMaxPsfStars : ns);
 		lists[ns].push_back(t);
 	}
-	int32_t* d_lists = nullptr;
-	TP_HIP(ctx, hipMalloc(&d_lists, (size_t)desc->n_targets * sizeof(int32_t)));
+	int32_t* d_lists = static_cast<int32_t*>(tp_ctx_scratch(ctx, (size_t)desc->n_targets * sizeof(int32_t)));
+	TP_REQUIRE(ctx, d_lists != nullptr, "tp_psf_fit: out of device memory for the target lists");
 	PsfArgs a;
 	a.images = d_images; a.backgrounds = d_backgrounds; a.n_cad = desc->n_cad; a.height = desc->height; a.width = desc->width; a.t_pitch = desc->t_pitch;
 	a.coef = d_coef; a.knots_x = d_knots_x; a.knots_y = d_knots_y; a.n = n_coef_axis;
@@ -425,7 +427,10 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 	size_t at = 0;
 	for (int ns = 0; ns <= kMaxPsfStars; ++ns) {
 		if (lists[ns].empty()) continue;
-		if (hipMemcpyAsync(d_lists + at, lists[ns].data(), lists[ns].size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) break;
+		// (a failed copy must not be followed by launches on half-written lists; the copies already queued read host vectors
+		// that die with this frame: wait for them)
+		const hipError_t ce = hipMemcpyAsync(d_lists + at, lists[ns].data(), lists[ns].size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+		if (ce != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); return ctx->fail(TP_ERR_HIP, "tp_psf_fit: target list copy", ce); }
 		at += lists[ns].size();
 	}
 	hipEvent_t before = ctx->get_event();
@@ -446,7 +451,6 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 	// the lists (host vectors, device copy) must outlive the copies and the launches
 	for (int i = 2; i >= 0; --i) if (waited[i]) (void)hipStreamSynchronize(streams[i]);
 	ctx->pool.push_back(before);
-	(void)hipFree(d_lists);
 	if (err != hipSuccess) return ctx->fail(TP_ERR_HIP, "tp_psf_fit_kernel", err);
 	return TP_OK;
 	TP_API_END(ctx)
