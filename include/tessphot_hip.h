@@ -221,6 +221,21 @@ int tp_aperture_photometry(tp_ctx* ctx, const tp_cube_desc* desc,
 	double* d_sumimage, uint8_t* d_mask, int32_t* d_status, int32_t* d_flags, double* d_contamination, double* d_diag,
 	uint8_t* d_cat_in_mask,
 	double* d_flux, double* d_flux_err, double* d_flux_background, double* d_centroid_col, double* d_centroid_row, int64_t out_pitch);
+/* The same from a sum image the caller already holds (d_sumimage is an INPUT: float64 [n_targets][height*width], e.g. from
+ * tp_background_sumimage, which forms it while it streams the raw cube for the background): the kernel starts at the K2P2 mask
+ * (k2p2v2.py:388-623) and reads only the in-mask pixel rows of the cubes.  d_quality / bitmask are not used (the sum image
+ * carries them) and may be NULL / 0.  Everything else as above; outputs bit-identical to tp_k2p2_masks + tp_aperture_extract. */
+int tp_aperture_photometry_from_sumimage(tp_ctx* ctx, const tp_cube_desc* desc,
+	const float* d_images, const float* d_images_err, const float* d_backgrounds, int32_t bkg_mode, int64_t bkg_series_pitch,
+	const float* d_subtract, int64_t subtract_pitch,
+	const int32_t* d_quality, int64_t quality_target_stride, uint32_t bitmask,
+	const int64_t* d_cat_offsets, const float* d_cat_column_stamp, const float* d_cat_row_stamp, const float* d_cat_tmag,
+	const float* d_cat_column, const float* d_cat_row, const int64_t* d_cat_starid,
+	const double* d_target_pos_row, const double* d_target_pos_column, const double* d_target_tmag, const int64_t* d_target_starid,
+	const int32_t* d_stamps, const int32_t* d_aperture, const tp_k2p2_params* params,
+	const double* d_sumimage, uint8_t* d_mask, int32_t* d_status, int32_t* d_flags, double* d_contamination, double* d_diag,
+	uint8_t* d_cat_in_mask,
+	double* d_flux, double* d_flux_err, double* d_flux_background, double* d_centroid_col, double* d_centroid_row, int64_t out_pitch);
 
 /* ---- B*, B2, B3: background on stamps -----------------------------------------------------------
  * tp_background_stamp (B*): build-defined stamp analogue of backgrounds.fit_background
@@ -241,6 +256,16 @@ int tp_smooth_time(tp_ctx* ctx, int32_t n_targets, int32_t n_cad, int64_t pitch,
 int tp_subtract_background(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_raw, const float* d_raw_err,
 	const float* d_bkg, int64_t bkg_pitch, const uint8_t* d_pixel_flags, uint32_t flag_mask,
 	float* d_images, float* d_images_err);
+/* B* + B2 + A1 in ONE pass over the raw cube: d_bkg_raw = tp_background_stamp(d_raw), d_bkg = tp_smooth_time(d_bkg_raw)
+ * (prepare.py:258, 317-335), d_sumimage = tp_sumimage(d_raw, d_subtract = d_bkg), i.e. the good-cadence mean of
+ * float32(raw - smoothed background) per pixel (prepare.py:419-421, 450-459; BasePhotometry.py:1008-1019).  Both series
+ * float32 [n_targets][bkg_pitch] and bit-identical to the two stand-alone entries; the sum image float64
+ * [n_targets][height*width], equal to tp_sumimage's to rounding (another order of the float64 additions).  Stamps up to
+ * 256 pixels and time_smooth <= 17 read the cube once; anything else runs the three entries in turn.                    */
+int tp_background_sumimage(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_raw,
+	double flux_cutoff, double exclude_percentile, int32_t time_smooth,
+	const int32_t* d_quality, int64_t quality_target_stride, uint32_t bitmask,
+	float* d_bkg_raw, float* d_bkg, int64_t bkg_pitch, double* d_sumimage);
 
 /* ---- B1 + full-frame B2 / B3 / A1: the prepare stage on a frame stack ----------------------------------------
  * Frames: float32 [n_frames][frame_rows][row_pitch] resident in HBM (frame k at + k * frame_stride), as for tp_cut_stamps.

@@ -86,7 +86,15 @@ SIGNATURES = {
 		_p, _p, POINTER(tp_k2p2_params),
 		_p, _p, _p, _p, _p, _p, _p,
 		_p, _p, _p, _p, _p, c_int64]),
+	'tp_aperture_photometry_from_sumimage': (c_int, [c_void_p, _desc_p, _p, _p, _p, c_int32, c_int64, _p, c_int64,
+		_p, c_int64, c_uint32,
+		_p, _p, _p, _p, _p, _p, _p,
+		_p, _p, _p, _p,
+		_p, _p, POINTER(tp_k2p2_params),
+		_p, _p, _p, _p, _p, _p, _p,
+		_p, _p, _p, _p, _p, c_int64]),
 	'tp_background_stamp': (c_int, [c_void_p, _desc_p, _p, c_double, c_double, _p, c_int64]),
+	'tp_background_sumimage': (c_int, [c_void_p, _desc_p, _p, c_double, c_double, c_int32, _p, c_int64, c_uint32, _p, _p, c_int64, _p]),
 	'tp_smooth_time': (c_int, [c_void_p, c_int32, c_int32, c_int64, c_int32, _p, _p]),
 	'tp_subtract_background': (c_int, [c_void_p, _desc_p, _p, _p, _p, c_int64, _p, c_uint32, _p, _p]),
 	'tp_background_mesh': (c_int, [c_void_p, _p, c_int32, c_int32, c_int32, c_int64, c_int64, _p, c_int64, _p, c_int64, c_double, c_int32, _p, _p]),

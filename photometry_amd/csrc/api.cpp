@@ -30,6 +30,7 @@ static const char* const kKernelNames[TPK_COUNT] = {
 	"tp_linpsf_coef_kernel",
 	"tp_synth_kernel",
 	"tp_linpsf_fitm_kernel",
+	"tp_bkg_stamp_sum_kernel",
 };
 
 extern "C" {

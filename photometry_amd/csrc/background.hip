@@ -173,35 +173,19 @@ template <int R> __device__ __forceinline__ void local_merge(float (&v)[R]) { Bi
 // lanes of a frame fall into different banks
 __device__ __forceinline__ int rank_idx(int r) { return r + ((r >> 5) << 2); }
 
+// One frame (cadence) per G lanes, from the loaded values to the background estimate: mask + float64 sums, distributed sort,
+// rank-staged sigma clipping, SExtractor mode.  `v` holds the lane's loaded pixel values (pixel i = G j + g in register j; the
+// registers NREAL.. hold +inf) and is consumed; `fr` is the frame's staging area in LDS.  Every lane of the frame returns the
+// same value (NaN: no estimate).
 // G: lanes per frame (8: 32 values per lane, 8 frames per wavefront; 4: 64 values per lane, 16 frames per wavefront).
 // JFULL: number of complete G-pixel rows (n_pix / G) when known at compile time (the pixel-count test is then only made for the
 // last rows), -1 = test every slot.
 template <int G, int JFULL>
-__global__ __launch_bounds__(kFramesPerBlock * G) void tp_bkg_stamp_kernel(BkgArgs a, int frame_stride)
+__device__ __forceinline__ float bkg_frame(const BkgArgs& a, float (&v)[256 / G], float* fr, int g, int lane, bool active, bool* all_kept = nullptr)
 {
 	constexpr int R = 256 / G;             // values per lane
-	constexpr int FPW = 64 / G;            // frames per wavefront
-	constexpr int SHIFT = (G == 8) ? 3 : 2;
-	extern __shared__ __align__(16) float s_sorted[]; // [kFramesPerBlock][frame_stride]
-	const int target = blockIdx.x;
-	const int tid = threadIdx.x;
-	const int wave = tid >> 6, lane = tid & 63;
-	const int f = lane >> SHIFT, g = lane & (G - 1);   // frame within the wavefront, lane within the frame
-	const int k = blockIdx.y * kFramesPerBlock + wave * FPW + f;
-	const bool active = k < a.n_cad;
-	const float inf = __builtin_inff();
-	float* fr = s_sorted + (size_t)(wave * FPW + f) * frame_stride;
-
-	// --- loads: pixel i = G j + g of cadence k; the descriptor covers this target's cube, the row offset is scalar
-	const int pitch_b = (int)a.t_pitch * 4;
-	const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
-		const_cast<float*>(a.raw + (int64_t)target * a.n_pix * a.t_pitch), 0, a.n_pix * pitch_b, 0x00020000);
-	const int voff = g * pitch_b + (active ? k : (a.n_cad - 1)) * 4;
 	constexpr int NREAL = (JFULL >= 0 && JFULL + 1 < R) ? (JFULL + 1) : R;   // registers 0..NREAL-1 can hold a pixel (JFULL: the first lanes only)
-	float v[R];
-#pragma unroll
-	for (int j = 0; j < R; ++j) // all loads in flight before the first use; registers past the last pixel hold the sentinel
-		v[j] = (j < NREAL) ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, j * G * pitch_b, 0)) : inf;
+	const float inf = __builtin_inff();
 	int n = 0;
 	double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -221,6 +205,7 @@ __global__ __launch_bounds__(kFramesPerBlock * G) void tp_bkg_stamp_kernel(BkgAr
 	n = frame_sum<G>(n);
 	s1 = frame_sum<G>(s1);
 	s2 = frame_sum<G>(s2);
+	if (all_kept) *all_kept = (n == a.n_pix);   // no pixel masked: in particular every value is finite
 
 	// --- distributed sort of the 256 values of the frame: rank = R g + j
 	const float sel1 = (g & 1) ? inf : -inf, sel2 = (g & 2) ? inf : -inf, sel4 = (g & 4) ? inf : -inf;
@@ -319,7 +304,250 @@ __global__ __launch_bounds__(kFramesPerBlock * G) void tp_bkg_stamp_kernel(BkgAr
 		if (var < 0.0) var = 0.0;
 		result = sextractor_mode(med, mean, sqrt(var));
 	}
+	return result;
+}
+
+template <int G, int JFULL>
+__global__ __launch_bounds__(kFramesPerBlock * G) void tp_bkg_stamp_kernel(BkgArgs a, int frame_stride)
+{
+	constexpr int R = 256 / G;             // values per lane
+	constexpr int FPW = 64 / G;            // frames per wavefront
+	constexpr int SHIFT = (G == 8) ? 3 : 2;
+	extern __shared__ __align__(16) float s_sorted[]; // [kFramesPerBlock][frame_stride]
+	const int target = blockIdx.x;
+	const int tid = threadIdx.x;
+	const int wave = tid >> 6, lane = tid & 63;
+	const int f = lane >> SHIFT, g = lane & (G - 1);   // frame within the wavefront, lane within the frame
+	const int k = blockIdx.y * kFramesPerBlock + wave * FPW + f;
+	const bool active = k < a.n_cad;
+	const float inf = __builtin_inff();
+	float* fr = s_sorted + (size_t)(wave * FPW + f) * frame_stride;
+
+	// --- loads: pixel i = G j + g of cadence k; the descriptor covers this target's cube, the row offset is scalar
+	const int pitch_b = (int)a.t_pitch * 4;
+	const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+		const_cast<float*>(a.raw + (int64_t)target * a.n_pix * a.t_pitch), 0, a.n_pix * pitch_b, 0x00020000);
+	const int voff = g * pitch_b + (active ? k : (a.n_cad - 1)) * 4;
+	constexpr int NREAL = (JFULL >= 0 && JFULL + 1 < R) ? (JFULL + 1) : R;
+	float v[R];
+#pragma unroll
+	for (int j = 0; j < R; ++j) // all loads in flight before the first use; registers past the last pixel hold the sentinel
+		v[j] = (j < NREAL) ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, j * G * pitch_b, 0)) : inf;
+	const float result = bkg_frame<G, JFULL>(a, v, fr, g, lane, active);
 	if (g == 0 && active) a.out[(int64_t)target * a.out_pitch + k] = result;
+}
+
+// B* + B2 + A1 in ONE pass over the raw cube (round 4).  The step of the raw-cube pipeline used to stream the cube twice: B*
+// above, then the sum image of `raw - smoothed background` inside the fused aperture kernel (prepare.py:317-335 smoothing,
+// :419-425 subtraction, :450-459 / BasePhotometry.py:1008-1019 sum image).  B* holds every pixel of every frame in registers, so
+// the sum image is formed here and the cube is read once per step.
+//   One 256-thread workgroup per TARGET walks its cadence blocks (32 cadences, frames as in the kernel above) in order.  A
+//   lane keeps its loaded values (`u`, +29 VGPRs) beside the copy the sort consumes.  After the clipping the frame's staging
+//   area is free and takes the RAW values [frame][pixel]; the frame's estimate goes to a ring of the last 128 cadences in LDS.
+//   One workgroup barrier per block makes the ring entries of the block visible.  Then every wavefront smooths with ONE LANE PER
+//   CADENCE (lane L: cadence 32 b - 32 + L, i.e. the previous block and this one): the 2 w + 1 taps of the two windows the
+//   reference uses (w = 1, 4; prepare.py:258) come from wave-shift DPP moves of one register and are added in series order
+//   (nanmean in float32: tp_bkg_smooth_kernel's expression); other windows loop over the ring.  The summing phase gives a lane 4
+//   pixels (one 16-byte LDS read per cadence) and walks the wavefront's eight cadences: the smoothed value of a cadence is
+//   read out of its lane into a scalar register, a cadence that does not count (bad quality, no background, window not
+//   complete yet) is skipped by a scalar branch, fl32(raw - smooth) is widened and added to the lane's float64 sums in
+//   cadence order -- fixed order, no atomics.  A frame that passed B*'s pixel mask whole holds finite values only: no test
+//   and a per-wavefront count; other frames test every difference (BasePhotometry.py:1011-1015).  The last w cadences of a
+//   block need the first w estimates of the next one: their raw values wait in a small LDS buffer (owned by the last
+//   wavefront) and are added one block later.  The loads of block b + 1 are issued before the barrier of block b.  At the
+//   end the four wavefront sums of a pixel are added in wavefront order and divided by the count (0 -> NaN).
+//   The phase after the barrier is ~200 vector instructions per wavefront and block beside the ~2 100 of B* (measured: every
+//   instruction counts, the kernel runs on the vector-ALU floor like B*; the first version -- smoothing by the frames' lanes
+//   through LDS, per-element finiteness tests everywhere -- had ~400 and took 6.4 ms against B*'s 5.1-5.2).
+struct BkgSumArgs {
+	BkgArgs b;
+	float* smooth;                    // [n_targets][out_pitch]: the smoothed series (what the aperture kernel subtracts)
+	const int32_t* quality; int64_t quality_stride; uint32_t bitmask;
+	double* sumimage;                 // [n_targets][n_pix]
+	int w;                            // time_smooth / 2, at most 8
+};
+constexpr int kRing = 128;
+constexpr int kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138;   // lane L <- lane L + 1 / lane L - 1; lanes without a source keep `old`
+
+// W: half width of the smoothing window when known at compile time (1, 4), -1: run-time (s.w)
+template <int JFULL, int W>
+__global__ __launch_bounds__(256, 4) void tp_bkg_stamp_sum_kernel(BkgSumArgs s, int frame_stride)
+{
+	constexpr int G = 8, R = 32, FPW = 8;
+	constexpr int NREAL = (JFULL >= 0 && JFULL + 1 < R) ? (JFULL + 1) : R;
+	const BkgArgs& a = s.b;
+	extern __shared__ __align__(16) float s_lds[];
+	float* s_sorted = s_lds;                                              // [32][frame_stride]: sorted ranks, then raw pixels
+	float* s_ring = s_lds + (size_t)kFramesPerBlock * frame_stride;       // [kRing] unsmoothed estimates by cadence & 127
+	float* s_pend = s_ring + kRing;                                       // [w][n_pix4]: raw values of a block's last w cadences
+	const int n_pix4 = (a.n_pix + 3) & ~3;
+	const int w = (W >= 0) ? W : s.w;
+	unsigned char* s_good = reinterpret_cast<unsigned char*>(s_pend + (size_t)w * n_pix4);   // [n_cad]: good-quality flags (a load
+	                                                                      // behind the next block's pixel loads would wait for all of them)
+	const int target = blockIdx.x;
+	const int tid = threadIdx.x;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+	const int f = lane >> 3, g = lane & 7;
+	const float inf = __builtin_inff(), qnan = __builtin_nanf("");
+	float* fr = s_sorted + (size_t)(wave * FPW + f) * frame_stride;
+	float* my_frames = s_sorted + (size_t)(wave * FPW) * frame_stride;
+	const int n_cad = a.n_cad;
+	const int nblocks = (n_cad + kFramesPerBlock - 1) / kFramesPerBlock;
+	{
+		const int32_t* q = s.quality + (int64_t)target * s.quality_stride;
+		for (int i = tid; i < n_cad; i += 256) s_good[i] = (((uint32_t)q[i] & s.bitmask) == 0u) ? 1 : 0;   // BasePhotometry.py:1010
+	}
+	float* out_raw = a.out + (int64_t)target * a.out_pitch;
+	float* out_smooth = s.smooth + (int64_t)target * a.out_pitch;
+
+	const int pitch_b = (int)a.t_pitch * 4;
+	const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+		const_cast<float*>(a.raw + (int64_t)target * a.n_pix * a.t_pitch), 0, a.n_pix * pitch_b, 0x00020000);
+	float u[NREAL];
+	{
+		const int k0 = wave * FPW + f;
+		const int voff = g * pitch_b + ((k0 < n_cad) ? k0 : (n_cad - 1)) * 4;
+#pragma unroll
+		for (int j = 0; j < NREAL; ++j) u[j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, j * G * pitch_b, 0));
+	}
+	// a lane's pixels in the summing phase: 4 lane .. 4 lane + 3
+	double acc[4] = {0.0, 0.0, 0.0, 0.0};
+	int cnt[4] = {0, 0, 0, 0};
+	int n_clean = 0;                  // cadences added without a test: they count for every pixel (wave-uniform)
+	unsigned held_clean = 0u;         // the held-back cadences' frames passed the pixel mask whole (bit per cadence, wave-uniform)
+	const int p0 = 4 * lane;
+	// One cadence's four pixels; `bs` finite.  `clean`: every value is finite and every difference counts.
+	auto add4 = [&](const float4 x, const float bs, const bool clean) {
+		float d[4] = {x.x - bs, x.y - bs, x.z - bs, x.w - bs};   // prepare.py:421 in float32
+		if (clean) n_clean++;
+		else {
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const bool ok = fabsf(d[c]) <= 3.402823466e+38f;      // BasePhotometry.py:1011-1015
+				d[c] = ok ? d[c] : 0.f;
+				cnt[c] += ok ? 1 : 0;
+			}
+		}
+#pragma unroll
+		for (int c = 0; c < 4; ++c) acc[c] += (double)d[c];
+	};
+	// nanmean of the ring over [k - w, k + w] clipped to the series (tp_bkg_smooth_kernel's expression)
+	auto smooth_at = [&](int k) {
+		const int i1 = (k - w > 0) ? (k - w) : 0;
+		const int i2 = (k + w + 1 < n_cad) ? (k + w + 1) : n_cad;
+		float asum = 0.f;
+		int c = 0;
+		for (int i = i1; i < i2; ++i) {
+			const float x = s_ring[i & (kRing - 1)];
+			if (x == x) { asum += x; c++; }
+		}
+		return (c > 0) ? (asum / (float)c) : qnan;
+	};
+
+#pragma unroll 1
+	for (int b = 0; b < nblocks; ++b) {
+		const int kb = b * kFramesPerBlock;
+		const int k = kb + wave * FPW + f;
+		const bool active = k < n_cad;
+		float v[R];
+#pragma unroll
+		for (int j = 0; j < R; ++j) v[j] = (j < NREAL) ? u[j] : inf;
+		bool all_kept;
+		const float result = bkg_frame<G, JFULL>(a, v, fr, g, lane, active, &all_kept);
+		__builtin_amdgcn_wave_barrier();   // the clipping's reads of the staged ranks come before the raw values take their place
+		if (g == 0 && active) { out_raw[k] = result; s_ring[k & (kRing - 1)] = result; }
+#pragma unroll
+		for (int j = 0; j < NREAL; ++j)
+			if (JFULL >= 0 ? (j < JFULL || j * G + g < a.n_pix) : (j * G + g < a.n_pix)) fr[j * G + g] = u[j];
+		// the loads of the next block fly during the barrier and the summing phase
+		if (b + 1 < nblocks) {
+			const int kn = k + kFramesPerBlock;
+			const int voff = g * pitch_b + ((kn < n_cad) ? kn : (n_cad - 1)) * 4;
+#pragma unroll
+			for (int j = 0; j < NREAL; ++j) u[j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, j * G * pitch_b, 0));
+		}
+		const uint64_t clean_mask = __ballot(all_kept);   // bit 8 ff: frame ff of this wavefront
+		__syncthreads();                    // every estimate of block b is in the ring
+		const int kmax = (kb + kFramesPerBlock - 1 < n_cad - 1) ? (kb + kFramesPerBlock - 1) : (n_cad - 1);
+		const bool last = (b + 1 == nblocks);
+		const int n_held = (wave == 3 && b > 0) ? w : 0;   // cadences of the previous block this wavefront held back
+		// --- B2, one lane per cadence: lane L <-> cadence kb - 32 + L
+		const int c = kb - kFramesPerBlock + lane;
+		const bool mine = (lane >= 32 + wave * FPW) && (lane < 40 + wave * FPW) && (c < n_cad) && (last || c + w <= kmax);
+		const bool held = (lane >= 32 - n_held) && (lane < 32);
+		float bs;
+		if constexpr (W > 0) {
+			const float rv = (c >= 0 && c < n_cad) ? s_ring[c & (kRing - 1)] : qnan;   // outside the series: not in any window
+			float dn[W], up[W];
+			int t = __float_as_int(rv);
+#pragma unroll
+			for (int i = 0; i < W; ++i) { t = __builtin_amdgcn_update_dpp(__float_as_int(qnan), t, kDppWaveShr1, 0xF, 0xF, false); dn[i] = __int_as_float(t); }
+			t = __float_as_int(rv);
+#pragma unroll
+			for (int i = 0; i < W; ++i) { t = __builtin_amdgcn_update_dpp(__float_as_int(qnan), t, kDppWaveShl1, 0xF, 0xF, false); up[i] = __int_as_float(t); }
+			float asum = 0.f;
+			int cn = 0;
+#pragma unroll
+			for (int j = -W; j <= W; ++j) {
+				const float x = (j < 0) ? dn[-j - 1] : ((j == 0) ? rv : up[j - 1]);
+				const bool ok = (x == x);
+				asum += ok ? x : 0.f;
+				cn += ok ? 1 : 0;
+			}
+			bs = (cn > 0) ? (asum / (float)cn) : qnan;
+		} else {
+			bs = (mine || held) ? smooth_at(c) : qnan;
+		}
+		float eff = qnan;
+		if (mine || held) {
+			out_smooth[c] = bs;
+			eff = s_good[c] ? bs : qnan;        // good-quality cadences only (BasePhotometry.py:1010)
+		}
+		const uint64_t valid_mask = __ballot(eff == eff);
+		// --- A1: the held-back cadences first (they are earlier in the series), then this block's
+		if (p0 < a.n_pix) {
+			for (int sl = 0; sl < n_held; ++sl) {
+				const int L = 32 - n_held + sl;
+				if ((valid_mask >> L) & 1ull)
+					add4(*reinterpret_cast<const float4*>(s_pend + sl * n_pix4 + p0), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eff), L)), ((held_clean >> sl) & 1u) != 0u);
+			}
+			// everything the eight cadences need is read first (one LDS round trip, not one per cadence)
+			float4 x[FPW];
+#pragma unroll
+			for (int ff = 0; ff < FPW; ++ff) x[ff] = *reinterpret_cast<const float4*>(my_frames + (size_t)ff * frame_stride + p0);
+#pragma unroll
+			for (int ff = 0; ff < FPW; ++ff) asm volatile("" : "+v"(x[ff].x), "+v"(x[ff].y), "+v"(x[ff].z), "+v"(x[ff].w));
+#pragma unroll
+			for (int ff = 0; ff < FPW; ++ff) {
+				const int L = 32 + wave * FPW + ff;
+				if ((valid_mask >> L) & 1ull)
+					add4(x[ff], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eff), L)), ((clean_mask >> (8 * ff)) & 1ull) != 0ull);
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+		if (wave == 3 && !last) {
+			// the block's last w cadences wait for the next block's estimates
+			for (int sl = 0; sl < w; ++sl)
+				if (p0 < a.n_pix) *reinterpret_cast<float4*>(s_pend + sl * n_pix4 + p0) = *reinterpret_cast<const float4*>(my_frames + (size_t)(FPW - w + sl) * frame_stride + p0);
+			held_clean = 0u;
+			for (int sl = 0; sl < w; ++sl) held_clean |= (unsigned)((clean_mask >> (8 * (FPW - w + sl))) & 1ull) << sl;
+		}
+		__builtin_amdgcn_wave_barrier();   // ... before the next block's sorted ranks overwrite them
+	}
+	// --- the four wavefront sums of a pixel, in wavefront order
+	__syncthreads();
+	double* s_acc = reinterpret_cast<double*>(s_lds);             // [4][n_pix4]
+	int* s_cnt = reinterpret_cast<int*>(s_acc + 4 * n_pix4);      // [4][n_pix4]
+	if (p0 < a.n_pix) {
+#pragma unroll
+		for (int c = 0; c < 4; ++c) { s_acc[wave * n_pix4 + p0 + c] = acc[c]; s_cnt[wave * n_pix4 + p0 + c] = cnt[c] + n_clean; }
+	}
+	__syncthreads();
+	for (int p = tid; p < a.n_pix; p += 256) {
+		const double t = ((s_acc[p] + s_acc[n_pix4 + p]) + s_acc[2 * n_pix4 + p]) + s_acc[3 * n_pix4 + p];
+		const int c = s_cnt[p] + s_cnt[n_pix4 + p] + s_cnt[2 * n_pix4 + p] + s_cnt[3 * n_pix4 + p];
+		s.sumimage[(int64_t)target * a.n_pix + p] = (c > 0) ? t / (double)c : __builtin_nan("");
+	}
 }
 
 // Median filter of full-frame images (pixel_flags.pixel_background_shenanigans, photometry/pixel_flags.py:61-79:
@@ -636,6 +864,60 @@ extern "C" int tp_background_stamp(tp_ctx* ctx, const tp_cube_desc* desc, const 
 		TP_LAUNCH(ctx, TPK_BKG_STAMP, tp_bkg_stamp_generic_kernel, grid, block, shmem, a, np2);
 	}
 	TP_LAUNCH_CHECK(ctx, "tp_bkg_stamp_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_background_sumimage(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_raw,
+	double flux_cutoff, double exclude_percentile, int32_t time_smooth,
+	const int32_t* d_quality, int64_t quality_target_stride, uint32_t bitmask,
+	float* d_bkg_raw, float* d_bkg, int64_t bkg_pitch, double* d_sumimage)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, tp_desc_ok(desc), "tp_background_sumimage: bad cube descriptor");
+	TP_REQUIRE(ctx, d_raw && d_quality && d_bkg_raw && d_bkg && d_sumimage && d_bkg_raw != d_bkg, "tp_background_sumimage: null or aliased pointers");
+	TP_REQUIRE(ctx, bkg_pitch >= desc->n_cad && time_smooth >= 1, "tp_background_sumimage: bkg_pitch < n_cad or time_smooth < 1");
+	TP_REQUIRE(ctx, quality_target_stride == 0 || quality_target_stride >= desc->n_cad, "tp_background_sumimage: bad quality stride");
+	if (desc->n_targets == 0) return TP_OK;
+	const int n_pix = desc->height * desc->width;
+	const int w = time_smooth / 2;
+	// a frame's area holds its sorted ranks (rank_idx of the last 16-byte store + 1), then its raw pixels; an area stride that is
+	// a multiple of 32 words would put the eight frames of a wavefront on the same banks when the raw values are written
+	const int last = (n_pix - 1) | 3;
+	int frame_stride = ((last + ((last >> 5) << 2) + 1) + 3) & ~3;
+	if (frame_stride % 32 == 0) frame_stride += 8;
+	const int n_pix4 = (n_pix + 3) & ~3;
+	const size_t shmem = ((size_t)kFramesPerBlock * frame_stride + kRing + (size_t)(w <= 8 ? w : 0) * n_pix4) * sizeof(float) + (((size_t)desc->n_cad + 15) & ~(size_t)15);
+	if (n_pix > 256 || w > 8 || desc->n_cad == 0 || shmem > 160 * 1024 || (int64_t)n_pix * desc->t_pitch * 4 >= 2147483647ll) {
+		// stamps above 256 pixels (the bright-star tail), windows beyond the reference's two (prepare.py:258), series whose quality
+		// flags do not fit the LDS: the three stages one after the other -- same series, the sum image to rounding (another
+		// order of the float64 additions)
+		int rc = tp_background_stamp(ctx, desc, d_raw, flux_cutoff, exclude_percentile, d_bkg_raw, bkg_pitch);
+		if (rc != TP_OK) return rc;
+		rc = tp_smooth_time(ctx, desc->n_targets, desc->n_cad, bkg_pitch, time_smooth, d_bkg_raw, d_bkg);
+		if (rc != TP_OK) return rc;
+		return tp_sumimage(ctx, desc, d_raw, d_quality, quality_target_stride, bitmask, d_bkg, bkg_pitch, d_sumimage);
+	}
+	BkgSumArgs s;
+	s.b.raw = d_raw; s.b.out = d_bkg_raw; s.b.n_cad = desc->n_cad; s.b.n_pix = n_pix;
+	s.b.t_pitch = desc->t_pitch; s.b.out_pitch = bkg_pitch;
+	s.b.flux_cutoff = (float)flux_cutoff; s.b.exclude_fraction = (float)(exclude_percentile / 100.0);
+	s.smooth = d_bkg; s.quality = d_quality; s.quality_stride = quality_target_stride; s.bitmask = bitmask; s.sumimage = d_sumimage; s.w = w;
+	const dim3 grid((unsigned)desc->n_targets), block(256);
+	const int jfull = n_pix / 8;
+#define TP_BKG_SUM_LAUNCH(JF, WW) do { \
+		auto kern = tp_bkg_stamp_sum_kernel<JF, WW>; \
+		if (shmem > 64 * 1024) TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+		TP_LAUNCH(ctx, TPK_BKG_STAMP_SUM, kern, grid, block, shmem, s, frame_stride); \
+	} while (0)
+#define TP_BKG_SUM_W(JF) do { if (w == 1) TP_BKG_SUM_LAUNCH(JF, 1); else if (w == 4) TP_BKG_SUM_LAUNCH(JF, 4); else TP_BKG_SUM_LAUNCH(JF, -1); } while (0)
+	if (jfull == 225 / 8) TP_BKG_SUM_W(225 / 8);        // 15 x 15
+	else if (jfull == 121 / 8) TP_BKG_SUM_W(121 / 8);   // 11 x 11
+	else TP_BKG_SUM_W(-1);
+#undef TP_BKG_SUM_W
+#undef TP_BKG_SUM_LAUNCH
+	TP_LAUNCH_CHECK(ctx, "tp_bkg_stamp_sum_kernel");
 	return TP_OK;
 	TP_API_END(ctx)
 }

@@ -35,6 +35,7 @@ enum tp_kernel_id {
 	TPK_LINPSF_COEF,
 	TPK_SYNTH,
 	TPK_LINPSF_FIT_MFMA,
+	TPK_BKG_STAMP_SUM,
 	TPK_COUNT
 };
 

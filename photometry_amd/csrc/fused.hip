@@ -24,7 +24,9 @@ namespace {
 constexpr int kRows = 8; // pixel rows per A1 step: 8 x 1 KiB loads in flight per lane
 
 // BKG: 0 = background cube, 1 = one background series per target, 2 = no background (aperture-only)
-template <int VEC, bool VEC4, bool HAS_SUB, int BKG>
+// A1: the sum image is formed here (streams the whole images cube); false: it is an input (tp_background_sumimage formed it
+// while it streamed the raw cube for the background) and the kernel reads in-mask pixel rows only
+template <int VEC, bool VEC4, bool HAS_SUB, int BKG, bool A1>
 __global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a, k2p2::BatchArgs ka, k2p2::Params prm,
 	const double* __restrict__ twid, const int32_t* __restrict__ quality, int64_t quality_stride, uint32_t bitmask,
 	double* __restrict__ sumimage_out)
@@ -37,6 +39,10 @@ __global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a,
 	const int P = ka.H * ka.W;
 
 	// ---------------- A1: sum image into LDS (k.S) and HBM ----------------
+	if constexpr (!A1) {
+		const double* in = sumimage_out + (int64_t)target * P;
+		for (int p = lane; p < P; p += 64) k.S[p] = in[p];
+	} else {
 	unsigned char* good = reinterpret_cast<unsigned char*>(k.srt);
 	tp_sum::stage_good(good, quality + (int64_t)target * quality_stride, bitmask, a.n_cad, lane, 64);
 	__syncthreads();
@@ -127,6 +133,7 @@ __global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a,
 			}
 		}
 	}
+	}
 	__syncthreads();
 
 	// ---------------- A2..A5b, A7: the mask, from the LDS-resident sum image ----------------
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a,
 
 } // namespace
 
-extern "C" int tp_aperture_photometry(tp_ctx* ctx, const tp_cube_desc* desc,
+static int aperture_photometry_impl(tp_ctx* ctx, const tp_cube_desc* desc, bool given_sumimage,
 	const float* d_images, const float* d_images_err, const float* d_backgrounds, int32_t bkg_mode, int64_t bkg_series_pitch,
 	const float* d_subtract, int64_t subtract_pitch,
 	const int32_t* d_quality, int64_t quality_target_stride, uint32_t bitmask,
@@ -188,7 +195,7 @@ extern "C" int tp_aperture_photometry(tp_ctx* ctx, const tp_cube_desc* desc,
 	TP_CHECK_CTX(ctx);
 	TP_API_BEGIN
 	TP_REQUIRE(ctx, tp_desc_ok(desc), "tp_aperture_photometry: bad cube descriptor");
-	TP_REQUIRE(ctx, d_images && d_images_err && d_quality && d_stamps && d_aperture && d_cat_offsets
+	TP_REQUIRE(ctx, d_images && d_images_err && (d_quality || given_sumimage) && d_stamps && d_aperture && d_cat_offsets
 		&& d_target_pos_row && d_target_pos_column && d_target_tmag && d_target_starid, "tp_aperture_photometry: null input pointer");
 	TP_REQUIRE(ctx, d_sumimage && d_mask && d_status && d_flags && d_contamination, "tp_aperture_photometry: null output pointer");
 	TP_REQUIRE(ctx, d_flux && d_flux_err && d_centroid_col && d_centroid_row, "tp_aperture_photometry: null output pointer");
@@ -205,11 +212,11 @@ extern "C" int tp_aperture_photometry(tp_ctx* ctx, const tp_cube_desc* desc,
 	const k2p2::SharedLayout lay = k2p2::shared_layout(P);
 	size_t shmem = lay.total;
 	const size_t a1_bytes = lay.off_region + (size_t)((desc->n_cad + 3) & ~3) + 16; // flags live in the shared region
-	if (a1_bytes > shmem) shmem = a1_bytes;
+	if (!given_sumimage && a1_bytes > shmem) shmem = a1_bytes;
 	if (shmem > 160 * 1024) {
 		// a stamp (or light curve) beyond the LDS-resident per-target state: the three stages one after the other, same results
 		// (tp_k2p2_masks keeps its work arrays in HBM for such stamps)
-		int rc = tp_sumimage(ctx, desc, d_images, d_quality, quality_target_stride, bitmask, d_subtract, subtract_pitch, d_sumimage);
+		int rc = given_sumimage ? TP_OK : tp_sumimage(ctx, desc, d_images, d_quality, quality_target_stride, bitmask, d_subtract, subtract_pitch, d_sumimage);
 		if (rc != TP_OK) return rc;
 		rc = tp_k2p2_masks(ctx, desc->n_targets, desc->height, desc->width, d_sumimage, d_cat_offsets, d_cat_column_stamp, d_cat_row_stamp,
 			d_cat_tmag, d_cat_column, d_cat_row, d_cat_starid, d_target_pos_row, d_target_pos_column, d_target_tmag, d_target_starid,
@@ -267,11 +274,12 @@ extern "C" int tp_aperture_photometry(tp_ctx* ctx, const tp_cube_desc* desc,
 	if (d_subtract) vec4 = vec4 && tp_vec4_ok(d_subtract, subtract_pitch);
 
 	const dim3 grid((unsigned)desc->n_targets), block(64);
-#define TP_FUSED_LAUNCH(V, V4, HS, BK) do { \
-		auto kern = tp_aperture_fused_kernel<V, V4, HS, BK>; \
+#define TP_FUSED_LAUNCH_A(V, V4, HS, BK, A1) do { \
+		auto kern = tp_aperture_fused_kernel<V, V4, HS, BK, A1>; \
 		if (shmem > 64 * 1024) TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
 		TP_LAUNCH(ctx, TPK_FUSED, kern, grid, block, shmem, a, ka, prm, (const double*)ctx->twiddle, d_quality, quality_target_stride, bitmask, d_sumimage); \
 	} while (0)
+#define TP_FUSED_LAUNCH(V, V4, HS, BK) do { if (given_sumimage) TP_FUSED_LAUNCH_A(V, V4, HS, BK, false); else TP_FUSED_LAUNCH_A(V, V4, HS, BK, true); } while (0)
 #define TP_FUSED_BKG(V, V4, HS) do { \
 		if (bkg_mode == 0) TP_FUSED_LAUNCH(V, V4, HS, 0); else if (bkg_mode == 1) TP_FUSED_LAUNCH(V, V4, HS, 1); else TP_FUSED_LAUNCH(V, V4, HS, 2); \
 	} while (0)
@@ -281,8 +289,46 @@ extern "C" int tp_aperture_photometry(tp_ctx* ctx, const tp_cube_desc* desc,
 	else { if (d_subtract) TP_FUSED_BKG(1, false, true); else TP_FUSED_BKG(1, false, false); }
 #undef TP_FUSED_BKG
 #undef TP_FUSED_LAUNCH
+#undef TP_FUSED_LAUNCH_A
 	TP_LAUNCH_CHECK(ctx, "tp_aperture_fused_kernel");
 	// masks above 128 pixels: the recursive pairwise tree kernel picks them from the mask / status in HBM
 	return tp_aperture_extract_big(ctx, a, vec4);
 	TP_API_END(ctx)
+}
+
+extern "C" int tp_aperture_photometry(tp_ctx* ctx, const tp_cube_desc* desc,
+	const float* d_images, const float* d_images_err, const float* d_backgrounds, int32_t bkg_mode, int64_t bkg_series_pitch,
+	const float* d_subtract, int64_t subtract_pitch,
+	const int32_t* d_quality, int64_t quality_target_stride, uint32_t bitmask,
+	const int64_t* d_cat_offsets, const float* d_cat_column_stamp, const float* d_cat_row_stamp, const float* d_cat_tmag,
+	const float* d_cat_column, const float* d_cat_row, const int64_t* d_cat_starid,
+	const double* d_target_pos_row, const double* d_target_pos_column, const double* d_target_tmag, const int64_t* d_target_starid,
+	const int32_t* d_stamps, const int32_t* d_aperture, const tp_k2p2_params* params,
+	double* d_sumimage, uint8_t* d_mask, int32_t* d_status, int32_t* d_flags, double* d_contamination, double* d_diag,
+	uint8_t* d_cat_in_mask,
+	double* d_flux, double* d_flux_err, double* d_flux_background, double* d_centroid_col, double* d_centroid_row, int64_t out_pitch)
+{
+	return aperture_photometry_impl(ctx, desc, false, d_images, d_images_err, d_backgrounds, bkg_mode, bkg_series_pitch, d_subtract, subtract_pitch,
+		d_quality, quality_target_stride, bitmask, d_cat_offsets, d_cat_column_stamp, d_cat_row_stamp, d_cat_tmag, d_cat_column, d_cat_row, d_cat_starid,
+		d_target_pos_row, d_target_pos_column, d_target_tmag, d_target_starid, d_stamps, d_aperture, params, d_sumimage, d_mask, d_status, d_flags,
+		d_contamination, d_diag, d_cat_in_mask, d_flux, d_flux_err, d_flux_background, d_centroid_col, d_centroid_row, out_pitch);
+}
+
+extern "C" int tp_aperture_photometry_from_sumimage(tp_ctx* ctx, const tp_cube_desc* desc,
+	const float* d_images, const float* d_images_err, const float* d_backgrounds, int32_t bkg_mode, int64_t bkg_series_pitch,
+	const float* d_subtract, int64_t subtract_pitch,
+	const int32_t* d_quality, int64_t quality_target_stride, uint32_t bitmask,
+	const int64_t* d_cat_offsets, const float* d_cat_column_stamp, const float* d_cat_row_stamp, const float* d_cat_tmag,
+	const float* d_cat_column, const float* d_cat_row, const int64_t* d_cat_starid,
+	const double* d_target_pos_row, const double* d_target_pos_column, const double* d_target_tmag, const int64_t* d_target_starid,
+	const int32_t* d_stamps, const int32_t* d_aperture, const tp_k2p2_params* params,
+	const double* d_sumimage, uint8_t* d_mask, int32_t* d_status, int32_t* d_flags, double* d_contamination, double* d_diag,
+	uint8_t* d_cat_in_mask,
+	double* d_flux, double* d_flux_err, double* d_flux_background, double* d_centroid_col, double* d_centroid_row, int64_t out_pitch)
+{
+	// (the kernel only reads the sum image on this path)
+	return aperture_photometry_impl(ctx, desc, true, d_images, d_images_err, d_backgrounds, bkg_mode, bkg_series_pitch, d_subtract, subtract_pitch,
+		d_quality, quality_target_stride, bitmask, d_cat_offsets, d_cat_column_stamp, d_cat_row_stamp, d_cat_tmag, d_cat_column, d_cat_row, d_cat_starid,
+		d_target_pos_row, d_target_pos_column, d_target_tmag, d_target_starid, d_stamps, d_aperture, params, const_cast<double*>(d_sumimage), d_mask, d_status, d_flags,
+		d_contamination, d_diag, d_cat_in_mask, d_flux, d_flux_err, d_flux_background, d_centroid_col, d_centroid_row, out_pitch);
 }

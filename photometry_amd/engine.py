@@ -133,6 +133,33 @@ def background_stamp(ctx, raw, flux_cutoff=8e4, exclude_percentile=50.0, out=Non
 	return out
 
 
+def _quality_stride(quality, images):
+	if len(quality.shape) == 1:
+		assert quality.shape[0] >= images.n_cad
+		return 0
+	assert quality.shape[0] == images.n_targets and quality.shape[1] >= images.n_cad
+	return quality.shape[1]
+
+
+def background_sumimage(ctx, raw, quality, time_smooth=3, bitmask=TESS_DEFAULT_BITMASK, flux_cutoff=8e4, exclude_percentile=50.0,
+	bkg_raw=None, bkg=None, sumimage=None):
+	"""
+	B* + B2 + A1 in one pass over the raw cube (``tp_background_sumimage``): the unsmoothed and the smoothed background series
+	(float32 ``(Nt, t_pitch)``) and the sum image of ``raw - smoothed background`` (float64 ``(Nt, H, W)``).
+	"""
+	if bkg_raw is None:
+		bkg_raw = ctx.zeros((raw.n_targets, raw.t_pitch), 'float32')
+	if bkg is None:
+		bkg = ctx.zeros((raw.n_targets, raw.t_pitch), 'float32')
+	if sumimage is None:
+		sumimage = ctx.empty((raw.n_targets, raw.height, raw.width), 'float64')
+	assert bkg_raw.shape[1] == bkg.shape[1]
+	desc = raw.desc
+	ctx._check(ctx.lib.tp_background_sumimage(ctx.handle, ctypes.byref(desc), raw.ptr, float(flux_cutoff), float(exclude_percentile), int(time_smooth),
+		quality.ptr, _quality_stride(quality, raw), int(bitmask), bkg_raw.ptr, bkg.ptr, bkg.shape[1], sumimage.ptr))
+	return bkg_raw, bkg, sumimage
+
+
 def smooth_time(ctx, series, n_cad, time_smooth=3, out=None):
 	"""B2 (prepare.py:317-335) on float32 series ``(Nt, pitch)``."""
 	if out is None:
@@ -166,11 +193,12 @@ def k2p2_masks(ctx, batch, work, cut_override=None, params=None):
 	return work
 
 
-def aperture_photometry(ctx, batch, work, bitmask=TESS_DEFAULT_BITMASK, subtract=None, backgrounds=None, params=None):
+def aperture_photometry(ctx, batch, work, bitmask=TESS_DEFAULT_BITMASK, subtract=None, backgrounds=None, params=None, sumimage_given=False):
 	"""
 	A1 + A2..A5b + A7 + A6 in one launch (photometry.py:75-257 for every target of the batch): fills
 	``work.sumimage, mask, status, flags, contamination, diag, cat_in_mask, lc``.
 	``backgrounds`` / ``subtract`` as in :func:`aperture_extract` (default: ``batch.backgrounds``).
+	``sumimage_given``: ``work.sumimage`` is an input (:func:`background_sumimage` formed it) and the launch starts at the mask.
 	"""
 	images, images_err = batch.images, batch.images_err
 	backgrounds = batch.backgrounds if backgrounds is None else backgrounds
@@ -178,14 +206,10 @@ def aperture_photometry(ctx, batch, work, bitmask=TESS_DEFAULT_BITMASK, subtract
 	assert images_err.t_pitch == images.t_pitch and images_err.data.shape == images.data.shape
 	bkg_mode, bpitch = _background_mode(images, backgrounds)
 	quality = batch.quality
-	if len(quality.shape) == 1:
-		assert quality.shape[0] >= images.n_cad
-		qstride = 0
-	else:
-		assert quality.shape[0] == images.n_targets and quality.shape[1] >= images.n_cad
-		qstride = quality.shape[1]
+	qstride = _quality_stride(quality, images)
 	lc = work.lc
-	ctx._check(ctx.lib.tp_aperture_photometry(ctx.handle, ctypes.byref(desc), images.ptr, images_err.ptr, _ptr(backgrounds), bkg_mode, bpitch,
+	entry = ctx.lib.tp_aperture_photometry_from_sumimage if sumimage_given else ctx.lib.tp_aperture_photometry
+	ctx._check(entry(ctx.handle, ctypes.byref(desc), images.ptr, images_err.ptr, _ptr(backgrounds), bkg_mode, bpitch,
 		_ptr(subtract), 0 if subtract is None else subtract.shape[1],
 		quality.ptr, qstride, int(bitmask),
 		batch.cat_offsets.ptr, batch.cat_column_stamp.ptr, batch.cat_row_stamp.ptr, batch.cat_tmag.ptr,

@@ -146,6 +146,12 @@ def aperture_step(ctx, batch, work, masks_from=None, fused=True):
 	on-device K2P2 (used by tests that inject the oracle's masks; implies the stand-alone kernels).
 	"""
 	subtract, backgrounds = None, batch.backgrounds
+	if batch.raw_mode and fused and masks_from is None:
+		# the raw cube is read ONCE: B*, B2 and the sum image of raw - background (A1 with B3 on the fly) in one pass,
+		# then the mask and the extraction, which read in-mask pixel rows only
+		engine.background_sumimage(ctx, batch.images, batch.quality, batch.time_smooth, bkg_raw=work.bkg_raw, bkg=work.bkg, sumimage=work.sumimage)
+		engine.aperture_photometry(ctx, batch, work, subtract=work.bkg, backgrounds=work.bkg, sumimage_given=True)   # A2..A7
+		return work
 	if batch.raw_mode:
 		engine.background_stamp(ctx, batch.images, out=work.bkg_raw)                           # B*
 		engine.smooth_time(ctx, work.bkg_raw, batch.n_cad, batch.time_smooth, out=work.bkg)    # B2

@@ -51,6 +51,41 @@ def test_background_stamp_parity(ctx, nt, T, H, W):
 		assert np.nanmedian(np.abs(bkg[ok] / truth[ok] - 1)) < 0.03
 
 
+@pytest.mark.parametrize("nt,T,H,W", [(6, 70, 15, 15), (5, 33, 11, 11), (3, 9, 16, 16), (4, 40, 6, 5), (3, 32, 15, 15), (2, 64, 13, 9), (2, 200, 17, 17)])
+@pytest.mark.parametrize("time_smooth", [1, 3, 9, 17, 19])
+def test_background_sumimage_one_pass(ctx, nt, T, H, W, time_smooth):
+	"""tp_background_sumimage: the two series bit for bit those of tp_background_stamp + tp_smooth_time (series shorter than the
+	window, one-block series, blocks whose last cadences wait for the next block, stamps above 256 pixels and windows above 17
+	through the three-entry route), the sum image within rounding of tp_sumimage and 1e-12 of the oracle."""
+	from photometry_amd import engine
+	from photometry_amd.device import DeviceCube
+	from oracle import sumimage as osum, backgrounds as ob
+	s = _scene(nt, T, H, W, seed=300 + H + T)
+	raw = s.raw.copy()
+	raw[0, :, :, 1] = np.nan                       # a cadence without estimate inside the windows of its neighbours
+	if T > 40:
+		raw[1, :, :, 30:34] = np.nan               # ... across a block boundary
+	q = s.quality.astype('int32').copy()
+	q[T // 2] |= 32
+	q[T - 1] |= 4
+	cube = DeviceCube.from_host(ctx, raw)
+	dq = ctx.array(q)
+	b_raw, b_smooth, S = engine.background_sumimage(ctx, cube, dq, time_smooth)
+	ref_raw = engine.background_stamp(ctx, cube)
+	ref_smooth = engine.smooth_time(ctx, ref_raw, T, time_smooth)
+	ref_S = engine.sumimage(ctx, cube, dq, subtract=ref_smooth)
+	np.testing.assert_array_equal(b_raw.to_host()[:, :T], ref_raw.to_host()[:, :T])
+	np.testing.assert_array_equal(b_smooth.to_host()[:, :T], ref_smooth.to_host()[:, :T])
+	np.testing.assert_array_equal(ref_smooth.to_host()[:, :T], ob.smooth_time(ref_raw.to_host()[:, :T], time_smooth))
+	got = S.to_host()
+	np.testing.assert_allclose(got, ref_S.to_host(), rtol=1e-13, atol=0, equal_nan=True)
+	diff = raw - b_smooth.to_host()[:, None, None, :T]
+	np.testing.assert_allclose(got, osum.sumimage_batch(diff, q), rtol=1e-12, atol=0, equal_nan=True)
+	# run to run: fixed summation order, no atomics
+	_, _, S2 = engine.background_sumimage(ctx, cube, dq, time_smooth)
+	np.testing.assert_array_equal(S2.to_host(), got)
+
+
 def test_smooth_and_subtract(ctx):
 	from photometry_amd import engine
 	from photometry_amd.device import DeviceCube

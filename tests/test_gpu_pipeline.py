@@ -82,14 +82,13 @@ def test_fused_against_oracle(ctx):
 
 
 @pytest.mark.parametrize('shape', [(41, 203, 15, 15), (9, 64, 11, 13), (5, 37, 7, 7), (3, 1301, 21, 19)])
-@pytest.mark.parametrize('mode', ['cubes', 'raw'])
-def test_fused_equals_three_kernels(ctx, shape, mode):
+def test_fused_equals_three_kernels(ctx, shape):
 	"""tp_aperture_photometry (one wavefront per target) against tp_sumimage + tp_k2p2_masks + tp_aperture_extract."""
 	n, T, H, W = shape
 	s = simulate.make_scene(n, T, H, W, seed=n + T)
-	simulate.fill_cubes(s, with_raw=(mode == 'raw'))
+	simulate.fill_cubes(s)
 	s.aperture = None
-	batch = pipeline.ApertureBatch(ctx, s, cubes='host' if mode == 'cubes' else 'host_raw')
+	batch = pipeline.ApertureBatch(ctx, s, cubes='host')
 	ref_work = pipeline.ApertureWork(ctx, batch)
 	pipeline.aperture_step(ctx, batch, ref_work, fused=False)
 	ctx.sync()
@@ -98,6 +97,46 @@ def test_fused_equals_three_kernels(ctx, shape, mode):
 	pipeline.aperture_step(ctx, batch, work, fused=True)
 	ctx.sync()
 	got = _collect(work)
+	assert (ref['status'] != 2).any()
+	for k in KEYS:
+		np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
+@pytest.mark.parametrize('shape', [(41, 203, 15, 15), (9, 64, 11, 13), (5, 37, 7, 7), (3, 1301, 21, 19), (6, 97, 11, 11), (4, 1300, 15, 15)])
+@pytest.mark.parametrize('time_smooth', [3, 9])
+def test_raw_step_reads_the_cube_once(ctx, shape, time_smooth):
+	"""The step on RAW cubes: tp_background_sumimage (B* + B2 + A1 in one pass) + tp_aperture_photometry_from_sumimage against
+	the stand-alone entries.  The two background series are bit-identical to tp_background_stamp / tp_smooth_time; the sum image
+	equals tp_sumimage's to rounding (another order of the float64 additions) and the oracle's to 1e-12; and from THAT sum image
+	the fused launch is bit-identical to tp_k2p2_masks + tp_aperture_extract."""
+	from photometry_amd import engine
+	from oracle import sumimage as osum
+	n, T, H, W = shape
+	s = simulate.make_scene(n, T, H, W, seed=n + T)
+	simulate.fill_cubes(s, with_raw=True)
+	s.aperture = None
+	s.cadence_s = {3: 1800, 9: 600}[time_smooth]
+	batch = pipeline.ApertureBatch(ctx, s, cubes='host_raw')
+	assert batch.time_smooth == time_smooth
+	ref_work = pipeline.ApertureWork(ctx, batch)
+	pipeline.aperture_step(ctx, batch, ref_work, fused=False)     # B*, B2, A1, K2P2, A6: five launches, the cube read twice
+	ctx.sync()
+	ref = _collect(ref_work)
+	work = pipeline.ApertureWork(ctx, batch)
+	pipeline.aperture_step(ctx, batch, work, fused=True)
+	ctx.sync()
+	got = _collect(work)
+	np.testing.assert_array_equal(work.bkg_raw.to_host()[:, :T], ref_work.bkg_raw.to_host()[:, :T])
+	np.testing.assert_array_equal(work.bkg.to_host()[:, :T], ref_work.bkg.to_host()[:, :T])
+	np.testing.assert_allclose(got['sumimage'], ref['sumimage'], rtol=1e-13, atol=0, equal_nan=True)
+	diff = s.raw - work.bkg.to_host()[:, None, None, :T]           # float32, prepare.py:421
+	np.testing.assert_allclose(got['sumimage'], osum.sumimage_batch(diff, s.quality), rtol=1e-12, atol=0, equal_nan=True)
+	# the rest of the step from the one-pass sum image, stage by stage
+	ref_work.sumimage = work.sumimage
+	engine.k2p2_masks(ctx, batch, ref_work)
+	engine.aperture_extract(ctx, batch.images, batch.images_err, work.bkg, ref_work.mask, batch.stamps, status=ref_work.status, out=ref_work.lc, subtract=work.bkg)
+	ctx.sync()
+	ref = _collect(ref_work)
 	assert (ref['status'] != 2).any()
 	for k in KEYS:
 		np.testing.assert_array_equal(got[k], ref[k], err_msg=k)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""lab: time B* variants (each in its own process: one library per process)."""
+"""lab: time tp_background_sumimage variants (each in its own process: one library per process)."""
 import os, sys, subprocess, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1:
@@ -12,15 +12,16 @@ if len(sys.argv) > 1:
 	Nt = int(os.environ.get("NT", 10000))
 	scene = simulate.make_scene(Nt, 1300, 15, 15, seed=1000)
 	raw = engine.synth_fill(ctx, scene, images=False, images_err=False, backgrounds=False, raw=True)['raw']
-	out = ctx.zeros((Nt, raw.t_pitch), 'float32')
+	q = ctx.array(scene.quality.astype('int32'))
+	outs = engine.background_sumimage(ctx, raw, q, 3)
 	for _ in range(2):
-		engine.background_stamp(ctx, raw, out=out)
+		engine.background_sumimage(ctx, raw, q, 3, bkg_raw=outs[0], bkg=outs[1], sumimage=outs[2])
 	ctx.sync()
 	t0 = time.perf_counter()
 	for _ in range(5):
-		engine.background_stamp(ctx, raw, out=out)
+		engine.background_sumimage(ctx, raw, q, 3, bkg_raw=outs[0], bkg=outs[1], sumimage=outs[2])
 	ctx.sync()
-	print(sys.argv[1], 'B* ms', round((time.perf_counter() - t0) / 5 * 1e3, 3), flush=True)
+	print(sys.argv[1], 'B*+B2+A1 ms', round((time.perf_counter() - t0) / 5 * 1e3, 3), flush=True)
 else:
 	import glob
 	for v in sorted(os.path.basename(p)[4:-3] for p in glob.glob(os.path.join(ROOT, 'tools', 'lab', 'lib_*.so'))):

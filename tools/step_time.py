@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Diagnostic: the configs[2] step on the C3 raw + error cubes: per-kernel HIP-event times and the step's wall time."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from photometry_amd import simulate, engine, pipeline
+from photometry_amd.device import Context
+
+ctx = Context(0)
+Nt = int(os.environ.get('NT', 10000))
+T = int(os.environ.get('T', 1300))
+scene = simulate.make_scene(Nt, T, 15, 15, seed=1000)
+scene.aperture = None
+if 'CADENCE' in os.environ:
+	scene.cadence_s = int(os.environ['CADENCE'])
+cubes = engine.synth_fill(ctx, scene, images=False, images_err=True, backgrounds=False, raw=True)
+batch = pipeline.ApertureBatch(ctx, scene, cubes={'raw': cubes['raw'], 'raw_err': cubes['images_err']})
+work = pipeline.ApertureWork(ctx, batch)
+for _ in range(2):
+	pipeline.aperture_step(ctx, batch, work)
+ctx.sync()
+ctx.profile(True)
+ctx.profile_reset()
+n = int(os.environ.get('STEPS', 8))
+t0 = time.perf_counter()
+for _ in range(n):
+	pipeline.aperture_step(ctx, batch, work)
+ctx.sync()
+wall = (time.perf_counter() - t0) / n * 1e3
+ctx.profile(False)
+rep = ctx.profile_report()
+print('step ms', round(wall, 3), {k: round(v[1] / max(v[0], 1), 3) for k, v in rep.items() if v[0]})
