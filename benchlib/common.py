@@ -1,0 +1,51 @@
+# -*- coding: utf-8 -*-
+"""Shared pieces of the bench legs: hardware peaks, per-kernel rows from the library's HIP-event profile, roofline objects and the
+PMC traffic committed under profiles/ (the line names the file it read)."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak (MI355X_MICROARCH.md)
+FP64_VALU_TFLOPS = 78.6  # MI355X FP64 vector peak
+XGMI_LINK_GBS = 153.0
+TRAFFIC_FILE = os.path.join('profiles', 'r4_traffic.json')
+
+
+def committed_traffic(key='traffic_bytes_per_launch', default_size=True):
+	"""HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/run_profile.sh -> profiles/r4_traffic.json): they are
+	NOT measured in this run (a PMC pass serialises the kernels), they belong to the default problem size only, and every
+	roofline object that carries them names this file as its source."""
+	path = os.path.join(ROOT, TRAFFIC_FILE)
+	if not default_size or not os.path.exists(path):
+		return None
+	return json.load(open(path)).get(key)
+
+
+def kernel_rows(report, n_launch_units, alg=None, necessary=None):
+	out = {}
+	for name, (n, ms) in report.items():
+		avg = ms / n
+		k = {'launches': n, 'avg_ms': avg}
+		if necessary and name in necessary:
+			k['necessary_bytes_per_launch'] = necessary[name]
+			k['necessary_GBps'] = necessary[name] / (avg * 1e-3) / 1e9
+			k['frac_of_hbm_peak'] = k['necessary_GBps'] / HBM_PEAK_GBS
+		if alg and name in alg:
+			k['survey_8d_bytes_per_launch'] = alg[name] * n_launch_units
+		out[name] = k
+	return out
+
+
+def roofline_of(name, rows, traffic, note=None):
+	k = rows[name]
+	r = {'kernel': name, 'bound': 'hbm', 'achieved': k['necessary_GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+		'frac': k['necessary_GBps'] / HBM_PEAK_GBS, 'traffic': (traffic or {}).get(name),
+		'avg_kernel_ms': k['avg_ms'], 'bytes_per_launch': k['necessary_bytes_per_launch'],
+		'bytes': 'necessary bytes per launch (what the kernel cannot avoid reading / writing) = SURVEY 8d per-target figure x targets '
+			'per launch, with A6 charged only for the rows of in-mask pixels it needs'}
+	if 'survey_8d_bytes_per_launch' in k:
+		r['survey_8d_bytes_per_launch_all_rows'] = k['survey_8d_bytes_per_launch']
+	r['traffic_source'] = (TRAFFIC_FILE + ' (committed rocprofv3 PMC passes of this command, calibrated per kernel; not measured in this run)') if r['traffic'] is not None else None
+	if note:
+		r['note'] = note
+	return r

@@ -1,0 +1,153 @@
+# -*- coding: utf-8 -*-
+"""cpu_baseline of the headline workload: the oracle (reference-equivalent numpy restatement, per-cadence Python loops like the
+reference) on a bounded sample of the same device-generated cubes, and the parity of that sample while it is there."""
+import os
+import time
+
+_CPU_JOBS = None
+
+
+def _cpu_worker(job):
+	"""
+	One step on a list of targets, as the reference would run it per target: B* per-cadence stamp background (oracle of the
+	build-defined estimator), B2 smoothing, B3 subtraction, A1 sum image, K2P2 masks, A6 extraction, A7.
+	The downstream stages use the DEVICE's background series so that their results can be compared bit for bit; the
+	oracle's own background is compared with it at 1e-6 and its time is counted.  Returns (seconds, results).
+	"""
+	import numpy as np
+	try:
+		from threadpoolctl import threadpool_limits
+		threadpool_limits(1)
+	except Exception: # noqa: B902
+		pass
+	from oracle import sumimage as osum, aperture as oap, backgrounds as ob
+	t0 = time.perf_counter()
+	out = []
+	for i in range(job.n_targets):
+		raw = job.raw[i]
+		bkg_raw = ob.background_series(raw)                                   # B*
+		bkg = ob.smooth_time(job.dev_bkg_raw[i], job.time_smooth)              # B2 (on the device's series: bit-exact check)
+		ob.smooth_time(bkg_raw, job.time_smooth)                               # B2 of the oracle's own series (timed)
+		series = job.dev_bkg[i][None, None, :]
+		img, err = ob.subtract_background(raw, job.raw_err[i], series)         # B3
+		S = osum.sumimage(img, job.quality)                                    # A1
+		bcube = np.broadcast_to(series.astype('float32'), img.shape)
+		try:
+			r = oap.do_photometry(S, img, err, bcube, tuple(job.stamps[i]), job.target_pos_row[i], job.target_pos_column[i],
+				job.target_tmag[i], job.target_starid[i], job.catalog_of(i), job.aperture[i])
+		except Exception: # noqa: B902 -- tessphot.py:37-49: any exception is STATUS.ERROR
+			r = {'status': 2}
+		d = {k: r.get(k) for k in ('status', 'flux', 'flux_err', 'flux_background', 'mask')}
+		with np.errstate(invalid='ignore', divide='ignore'):
+			both = np.isfinite(bkg_raw) & np.isfinite(job.dev_bkg_raw[i])
+			d['bkg_nan_equal'] = bool(np.array_equal(np.isnan(bkg_raw), np.isnan(job.dev_bkg_raw[i])))
+			d['bkg_max_rel'] = float(np.max(np.abs(bkg_raw[both] / job.dev_bkg_raw[i][both] - 1))) if both.any() else 0.0
+		d['smooth_equal'] = bool(np.array_equal(bkg, job.dev_bkg[i], equal_nan=True))
+		out.append(d)
+	return time.perf_counter() - t0, out
+
+
+def _cpu_worker_indexed(c):
+	return _cpu_worker(_CPU_JOBS[c])
+
+
+def cgroup_cpu_quota():
+	"""CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
+	try:
+		q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+		return None if q == 'max' else float(q) / float(p)
+	except Exception: # noqa: B902
+		pass
+	try:
+		q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+		p = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+		return None if q <= 0 else q / p
+	except Exception: # noqa: B902
+		return None
+
+
+def physical_cores():
+	avail = len(os.sched_getaffinity(0))
+	try:
+		import psutil
+		phys = psutil.cpu_count(logical=False) or avail
+	except Exception: # noqa: B902
+		phys = avail
+	return max(1, min(avail, phys)), avail
+
+
+def cpu_baseline(ctx, scene, cubes, work, args, T, H, W, time_smooth):
+	"""Oracle on a bounded sample of the same device-generated cubes: one core, 16 processes, all physical cores."""
+	import numpy as np
+	import multiprocessing as mp
+	global _CPU_JOBS
+	phys, avail = physical_cores()
+	nproc = args.cpu_procs if args.cpu_procs > 0 else phys
+	per = max(1, args.cpu_sample)
+	ns = min(scene.n_targets, nproc * per)
+	nproc = max(1, ns // per)
+	ns = nproc * per
+	sub = scene.subset(slice(0, ns))
+	for name, key in (('raw', 'raw'), ('raw_err', 'raw_err')):
+		cube = cubes[key]
+		host = np.empty((ns, H, W, cube.t_pitch), dtype='float32')
+		ctx._check(ctx.lib.tp_memcpy_d2h(ctx.handle, host.ctypes.data, cube.ptr, host.nbytes))
+		setattr(sub, name, np.ascontiguousarray(host[..., :T]))
+		del host
+	sub.dev_bkg_raw = work.bkg_raw.slice0(0, ns).to_host()[:, :T]
+	sub.dev_bkg = work.bkg.slice0(0, ns).to_host()[:, :T]
+	sub.time_smooth = time_smooth
+	sub.aperture = np.ones((ns, H, W), dtype='int32')
+
+	def part(s, sl):
+		p = s.subset(sl)
+		for k in ('dev_bkg_raw', 'dev_bkg'):
+			setattr(p, k, getattr(s, k)[sl])
+		p.time_smooth = s.time_smooth
+		return p
+
+	# (a) one process, one core: the analogue of one MPI worker of run_tessphot_mpi.py
+	n1 = min(ns, max(2, per))
+	t1, _ = _cpu_worker(part(sub, slice(0, n1)))
+	# (b) worker processes (forked: the sample is shared copy-on-write, nothing is pickled in); rate = targets / slowest
+	#     worker's compute time.  All physical cores, and 16 processes as the round-1 reference point.
+	rates = {}
+	rr_all = None
+	for n in sorted({min(16, nproc), nproc}):
+		_CPU_JOBS = [part(sub, slice(c, n * per, n)) for c in range(n)]
+		with mp.get_context('fork').Pool(n) as pool:
+			rr = pool.map(_cpu_worker_indexed, range(n))
+		rates[n] = n * per / max(r[0] for r in rr)
+		if n == nproc:
+			rr_all = rr
+	# parity of the sample while we are here
+	lc = work.lc.to_host()
+	masks = work.mask.to_host()
+	status = work.status.to_host()
+	bad = bad_bkg = 0
+	max_rel = 0.0
+	for c, (_, out) in enumerate(rr_all):
+		for j, r in enumerate(out):
+			i = c + j * nproc
+			ok = int(status[i]) == r['status']
+			if ok and r.get('mask') is not None:
+				ok = np.array_equal(masks[i].astype(bool), r['mask']) and np.array_equal(lc['flux'][i], r['flux'], equal_nan=True) \
+					and np.array_equal(lc['flux_err'][i], r['flux_err'], equal_nan=True) \
+					and np.array_equal(lc['flux_background'][i], r['flux_background'], equal_nan=True)
+			bad += (not ok)
+			bad_bkg += (not r['bkg_nan_equal']) or (r['bkg_max_rel'] > 1e-6) or (not r['smooth_equal'])
+			max_rel = max(max_rel, r['bkg_max_rel'])
+	best = max(rates.values())
+	return {
+		'value': best, 'unit': 'targets/s', 'cores': max(rates, key=rates.get), 'kind': 'port',
+		'sample': f'{ns} of the {scene.n_targets} targets of the same device-generated raw cubes ({per} per worker process); oracle = numpy '
+			'restatement of the reference per-cadence loops: stamp background (B*, B2, B3) + sum image + K2P2 + extraction; rate = '
+			'targets / slowest worker compute time; BLAS / OpenMP threads pinned to 1',
+		'rates_by_process_count': {str(k): v for k, v in rates.items()},
+		'single_core_targets_per_s': n1 / t1,
+		'calibration': 'dev-container timing of the reference\'s own AperturePhotometry.do_photometry loop (mask given, 15x15x1300) beside this '
+			'restatement on the same core (tests/golden/time_reference.py): 0.0916 s/target against 0.0889 -- the port takes 0.97 x the reference\'s time',
+		'host_cores': {'physical': phys, 'usable_logical': avail, 'cgroup_cpu_quota': cgroup_cpu_quota()},
+	}, {'targets': ns, 'mismatches': int(bad), 'background_mismatches': int(bad_bkg), 'background_max_rel_err': max_rel,
+		'what': 'status / mask / flux / flux_err / flux_background bit-exact given the device background; B* within 1e-6 of the oracle, '
+			'B2 bit-exact'}

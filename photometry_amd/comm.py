@@ -25,7 +25,7 @@ def shard_sizes(n_items, world):
 	return [shard_range(n_items, world, r)[1] - shard_range(n_items, world, r)[0] for r in range(world)]
 
 
-def packed_block_layout(n_targets, n_cad, height, width, psf=False, align=256):
+def packed_block_layout(n_targets, n_cad, height, width, psf=False, align=256, n_cat=0):
 	"""
 	Layout of the per-step output block of a rank: ONE allocation, so that the gather is one
 	message per rank.  Returns ``(layout, nbytes)`` with ``layout[name] = (offset, shape, dtype)``:
@@ -33,13 +33,18 @@ def packed_block_layout(n_targets, n_cad, height, width, psf=False, align=256):
 	* ``lc`` float64 ``(5, Nt, T)``: flux, flux_err, flux_background, centroid column / row (the plugin's columns,
 	  BasePhotometry.py:425-429); ``contamination`` float64, ``status`` / ``flags`` int32, ``mask`` uint8 ``(Nt, H, W)``;
 	* with ``psf`` (BASELINE configs[4], aperture + PSF): ``psf_flux`` float64 ``(Nt, T)`` (the LinPSF light curve,
-	  linpsf_photometry.py:168), ``psf_contamination`` float64 (PSF_CONT, :203-211), ``psf_status`` int32.
+	  linpsf_photometry.py:168), ``psf_contamination`` float64 (PSF_CONT, :203-211), ``psf_status`` int32;
+	* with ``n_cat`` > 0: ``cat_in_mask`` uint8 ``(n_cat,)``, one flag per row of the rank's (ragged) catalogue: the star lies
+	  in the target's mask -- what the master's skip-target bookkeeping needs (photometry.py:269-272).  ``n_cat`` is a capacity
+	  like ``n_targets``: the same on every rank.
 	"""
 	Nt, T, H, W = int(n_targets), int(n_cad), int(height), int(width)
 	fields = [('lc', (5, Nt, T), 'float64'), ('contamination', (Nt,), 'float64'), ('status', (Nt,), 'int32'), ('flags', (Nt,), 'int32'),
 		('mask', (Nt, H, W), 'uint8')]
 	if psf:
 		fields += [('psf_flux', (Nt, T), 'float64'), ('psf_contamination', (Nt,), 'float64'), ('psf_status', (Nt,), 'int32')]
+	if n_cat:
+		fields += [('cat_in_mask', (int(n_cat),), 'uint8')]
 	layout, off = {}, 0
 	for name, shape, dtype in fields:
 		layout[name] = (off, shape, dtype)
@@ -57,17 +62,23 @@ def unpack_block(block, layout):
 	return out
 
 
-def assemble_blocks(blocks, layout, sizes):
+def assemble_blocks(blocks, layout, sizes, cat_sizes=None):
 	"""
 	Reassembly on rank 0 of the gathered per-rank blocks (every rank sends the same padded capacity; ``sizes`` = real number
-	of targets per rank) into arrays in global target order: ``{name: array}``, the target axis is axis 1 of ``lc`` and
-	axis 0 of everything else.
+	of targets per rank, ``cat_sizes`` = real number of catalogue rows per rank when the block carries ``cat_in_mask``) into
+	arrays in global target order: ``{name: array}``, the target axis is axis 1 of ``lc`` and axis 0 of everything else;
+	``cat_in_mask`` is the concatenation of the ranks' catalogue flags (global catalogue row = rank's first row + local row).
 	"""
 	parts = [unpack_block(b, layout) for b in blocks]
 	out = {}
 	for name in layout:
 		ax = 1 if name == 'lc' else 0
-		out[name] = np.concatenate([np.take(p[name], np.arange(n), axis=ax) for p, n in zip(parts, sizes)], axis=ax)
+		counts = sizes
+		if name == 'cat_in_mask':
+			if cat_sizes is None:
+				raise ValueError('the blocks carry cat_in_mask: the catalogue rows per rank (cat_sizes) are needed to trim them')
+			counts = cat_sizes
+		out[name] = np.concatenate([np.take(p[name], np.arange(n), axis=ax) for p, n in zip(parts, counts)], axis=ax)
 	return out
 
 

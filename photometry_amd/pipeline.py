@@ -95,14 +95,22 @@ class ApertureWork(object):
 	(``self.block``, layout: ``comm.packed_block_layout``), so that the per-step gather of a multi-GPU run is a single message.
 	"""
 
-	def __init__(self, ctx, batch, packed=False, psf=False):
+	def __init__(self, ctx, batch, packed=False, psf=False, capacity=None, cat_capacity=0):
+		"""``capacity`` >= the batch's targets lays the packed block out for that many (the padded shard size every rank of a
+		sharded run sends); ``cat_capacity`` > 0 puts the catalogue flags ``cat_in_mask`` into the block as well."""
 		from . import comm as tpcomm
 		Nt, T, H, W = batch.n_targets, batch.n_cad, batch.height, batch.width
 		self.sumimage = ctx.empty((Nt, H, W), 'float64')
 		self.block = None
 		self.psf_flux = self.psf_contamination = self.psf_status = None
+		n_cat = max(int(batch.scene.cat_offsets[-1]), 1)
+		self.cat_in_mask = None
 		if packed:
-			layout, nbytes = tpcomm.packed_block_layout(Nt, T, H, W, psf=psf)
+			cap = Nt if capacity is None else int(capacity)
+			if cap < Nt or (cat_capacity and cat_capacity < n_cat):
+				raise ValueError('block capacity below the size of the batch')
+			layout, nbytes = tpcomm.packed_block_layout(cap, T, H, W, psf=psf, n_cat=int(cat_capacity))
+			Nt = cap
 			self.block = ctx.zeros((nbytes,), 'uint8')
 			b = self.block
 			view = lambda name: device_view(ctx, b.ptr + layout[name][0], layout[name][1], layout[name][2], base=b) # noqa: E731
@@ -110,7 +118,10 @@ class ApertureWork(object):
 			self.contamination, self.status, self.flags, self.mask = view('contamination'), view('status'), view('flags'), view('mask')
 			if psf:
 				self.psf_flux, self.psf_contamination, self.psf_status = view('psf_flux'), view('psf_contamination'), view('psf_status')
+			if cat_capacity:
+				self.cat_in_mask = view('cat_in_mask')
 			self.block_layout = layout
+			Nt = batch.n_targets
 		else:
 			self.mask = ctx.zeros((Nt, H, W), 'uint8')
 			self.status = ctx.zeros((Nt,), 'int32')
@@ -118,7 +129,8 @@ class ApertureWork(object):
 			self.contamination = ctx.zeros((Nt,), 'float64')
 			self.lc = engine.LightCurves(ctx, Nt, T)
 		self.diag = ctx.zeros((Nt, 8), 'float64')
-		self.cat_in_mask = ctx.zeros((max(int(batch.scene.cat_offsets[-1]), 1),), 'uint8')
+		if self.cat_in_mask is None:
+			self.cat_in_mask = ctx.zeros((n_cat,), 'uint8')
 		self.diagnostics = ctx.zeros((Nt, 10), 'float64')
 		self.bkg_raw = self.bkg = None
 		if batch.raw_mode:

@@ -77,6 +77,125 @@ def _block_worker(rank, world, port, outfile):
 	dist.destroy_process_group()
 
 
+class _NumpyWorker(object):
+	"""A rank's share of a made-up batch, computed with numpy from the GLOBAL target index, so that any division of the targets
+	over ranks must reproduce the single-rank result: light curves, masks, statuses, and a ragged catalogue whose in-mask flags
+	give the skip lists.  Follows the ``sharded.ShardWorker`` protocol with a host block (``ctx`` is None)."""
+	ctx = None
+	nbuf = 2
+	T, H, W = 3, 2, 2
+
+	def __init__(self, n_total, world, rank):
+		from photometry_amd import comm as tpcomm
+		self.a, self.b = tpcomm.shard_range(n_total, world, rank)
+		self.n_local = self.b - self.a
+		self.capacity = max(tpcomm.shard_sizes(n_total, world))
+		g = self.global_fields(n_total)
+		self.cat_offsets_local = g['cat_offsets'][self.a:self.b + 1] - g['cat_offsets'][self.a]
+		self.n_cat_local = int(self.cat_offsets_local[-1])
+		cat_cap = int(max(g['cat_offsets'][tpcomm.shard_range(n_total, world, r)[1]] - g['cat_offsets'][tpcomm.shard_range(n_total, world, r)[0]] for r in range(world)))
+		self.layout, self.block_nbytes = tpcomm.packed_block_layout(self.capacity, self.T, self.H, self.W, psf=True, n_cat=max(cat_cap, 1))
+		self.blocks = [np.zeros(self.block_nbytes, dtype='uint8') for _ in range(self.nbuf)]
+		self.g = g
+		self.n_steps = 0
+
+	@classmethod
+	def global_fields(cls, n):
+		i = np.arange(n)
+		ncat = 1 + (i % 3)                                              # 1..3 catalogue rows per target: itself + neighbours
+		off = np.concatenate(([0], np.cumsum(ncat)))
+		starid = 1000 + i
+		tmag = 6.0 + ((i * 7919) % 1000) / 100.0
+		cat_starid = np.concatenate([[starid[j]] + [starid[(j + k) % n] for k in range(1, ncat[j])] for j in range(n)]) if n < 5000 else None
+		if cat_starid is None:                                          # vectorised for the large case
+			rows = np.repeat(i, ncat)
+			k = np.arange(off[-1]) - off[rows]
+			cat_starid = starid[(rows + k) % n]
+		return {'cat_offsets': off, 'starid': starid, 'tmag': tmag, 'cat_starid': cat_starid, 'ncat': ncat}
+
+	def step(self, b):
+		from photometry_amd import comm as tpcomm
+		self.n_steps += 1
+		v = tpcomm.unpack_block(self.blocks[b], self.layout)
+		i = np.arange(self.a, self.b)
+		n = self.n_local
+		v['lc'][:, :n, :] = (i[None, :, None] * 0.5 + np.arange(5)[:, None, None] * 1e3 + np.arange(self.T)[None, None, :] + self.n_steps * 1e-3)
+		v['contamination'][:n] = (i % 17) / 17.0
+		v['status'][:n] = 1 + (i % 3 == 0) * 2                            # OK / WARNING
+		v['flags'][:n] = i % 5
+		v['mask'][:n] = ((i[:, None, None] + np.arange(self.H)[None, :, None] + np.arange(self.W)[None, None, :]) % 2).astype('uint8')
+		v['psf_flux'][:n] = i[:, None] * 2.0 + np.arange(self.T)[None, :]
+		v['psf_contamination'][:n] = (i % 11) / 11.0
+		v['psf_status'][:n] = 1 + (i % 4 == 0)
+		# catalogue flags: the target itself always, its first neighbour when the target index is a multiple of 5
+		rows = np.repeat(np.arange(n), np.diff(self.cat_offsets_local))
+		k = np.arange(self.n_cat_local) - self.cat_offsets_local[rows]
+		v['cat_in_mask'][:self.n_cat_local] = ((k == 0) | ((k == 1) & (i[rows] % 5 == 0))).astype('uint8')
+
+	def block(self, b):
+		return self.blocks[b]
+
+	def sync(self):
+		pass
+
+
+def _sharded_run(n_total, world, rank, dist=None, torch=None, steps=3):
+	from photometry_amd import sharded
+	w = _NumpyWorker(n_total, world, rank)
+	run = sharded.ShardedRun(w, n_total, rank=rank, world=world, dist=dist, torch=torch, gather='auto')
+	run.run_steps(steps, collect=True)
+	run.barrier()
+	res = run.collect()
+	out = None
+	if rank == 0:
+		g = w.g
+		skip = run.skip_lists(res['cat_in_mask'], g['cat_offsets'], g['cat_starid'], g['starid'])
+		res['final_status'] = run.replay(res, g['starid'], g['tmag'], skip)
+		res['n_skip'] = np.array([sum(len(s) for s in skip)])
+		res['mode'] = run.mode
+		out = res
+	run.close()
+	return out
+
+
+def _sharded_worker(rank, world, port, n_total, outfile):
+	sys.path.insert(0, ROOT)
+	os.environ['MASTER_ADDR'] = '127.0.0.1'
+	os.environ['MASTER_PORT'] = str(port)
+	os.environ['RANK'], os.environ['LOCAL_RANK'], os.environ['WORLD_SIZE'] = str(rank), str(rank), str(world)
+	from photometry_amd import sharded
+	assert sharded.rank_environment() == (rank, rank, world)
+	torch, dist = sharded.init_host_group(rank, world)
+	res = _sharded_run(n_total, world, rank, dist=dist, torch=torch)
+	if rank == 0:
+		mode = res.pop('mode')
+		assert mode == 'host (gloo)', mode
+		np.savez(outfile, **res)
+	dist.barrier()
+	dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_total,world', [(100003, 3), (11, 2)])
+def test_sharded_run_uneven_shards_equals_single_process(tmp_path, n_total, world):
+	"""The package's sharded entry (photometry_amd.sharded.ShardedRun) on CPU ranks: 100 003 targets over 3 ranks (shards of
+	33 335 / 33 335 / 33 333 behind a padded capacity, ragged catalogues of different lengths), three double-buffered steps
+	with a gather each, reassembly, skip lists and the master's skip-target replay -- against the same run in ONE process."""
+	pytest.importorskip('torch')
+	import torch.multiprocessing as mp
+	out = str(tmp_path / 'sharded.npz')
+	port = 33500 + (os.getpid() % 2000)
+	mp.spawn(_sharded_worker, args=(world, port, n_total, out), nprocs=world, join=True)
+	got = dict(np.load(out))
+	ref = _sharded_run(n_total, 1, 0)
+	assert ref.pop('mode') == 'none (single rank)'
+	assert set(got) == set(ref)
+	for k in ref:
+		np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+		assert got[k].dtype == ref[k].dtype, k
+	assert got['lc'].shape == (5, n_total, _NumpyWorker.T) and int(got['n_skip'][0]) > 0
+	assert (got['final_status'] == 5).any() and (got['final_status'] != ref['status']).any()   # the replay did something
+
+
 def test_packed_block_with_psf_outputs_two_ranks(tmp_path):
 	torch = pytest.importorskip('torch')
 	import torch.multiprocessing as mp
