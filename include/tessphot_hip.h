@@ -408,6 +408,12 @@ int tp_radial_evaluate(tp_ctx* ctx, int32_t n_frames, int32_t frame_rows, int32_
 int tp_linpsf_prf(tp_ctx* ctx, int32_t n_targets, int32_t n_samples, int32_t n_coef,
 	const double* d_base_coef, const double* d_weights, double* d_coef);
 int tp_linpsf_set_path(tp_ctx* ctx, int32_t path);
+/* Which kernels fitted the targets of the LAST tp_linpsf_fit call of this context (the plan kernel decides per target):
+ * counts[0] targets on the matrix cores, [1] the segments their series were cut into (a star that drifts over more than three
+ * knot intervals gets one spline per stretch of the series; without drift one segment per target), [2] targets on the
+ * vector-ALU polynomial kernels, [3] on the general kernel (wide excursions inside 16 cadences), [4] with more than 8 fitted
+ * stars, [5..8] matrix-core targets with 1..4 fitted stars, [9..12] their segments.  n <= 16 counters are copied. */
+int tp_linpsf_last_counts(tp_ctx* ctx, int64_t* counts, int32_t n);
 int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
 	const float* d_subtract, int64_t subtract_pitch,
 	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis, int32_t max_stars,

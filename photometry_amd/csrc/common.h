@@ -77,6 +77,7 @@ struct tp_ctx {
 	void* ring = nullptr;
 	size_t ring_cursor = 0;
 	int linpsf_path = 1;        // tp_linpsf_set_path: 1 = matrix-core fit where a target qualifies, 0 = vector-ALU fit kernels only
+	int64_t linpsf_counts[16] = {};   // tp_linpsf_last_counts: which kernels fitted the targets of the last tp_linpsf_fit call
 	void* comm = nullptr;       // ncclComm_t (comm.cpp)
 	int comm_rank = 0, comm_size = 1;
 

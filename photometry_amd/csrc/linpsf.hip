@@ -244,13 +244,32 @@ __device__ __forceinline__ double fma_sgpr_addend(double a, double b, double c) 
 // inverse of the reflected Gray code n ^ (n >> 1) on 4 bits: the place of a membership pattern in the order 1,3,2,6,7,5,4,12,...
 __device__ __forceinline__ unsigned gray_rank4(unsigned g) { g ^= g >> 2; g ^= g >> 1; return g & 15u; }
 
+// one segment of a target's series: the knot intervals every star visits in it (lo / hi per star and axis; hi < lo: never valid)
+__device__ __forceinline__ void emit_segment(SegPlan& g, int target, int t0, int t1, const int (&lo)[kMfmaStars][2], const int (&hi)[kMfmaStars][2],
+	int ns, const StarPlan* spl)
+{
+	g.target = target; g.tile0 = t0; g.tile1 = t1; g.kdoubles = 0; g.koff = 0;
+	for (int s = 0; s < kMfmaStars; ++s) {
+		const bool any = (s < ns) && (hi[s][0] >= lo[s][0]) && (hi[s][1] >= lo[s][1]) && (spl[s].nc > 0);
+		g.axmin[s] = any ? lo[s][0] : 0; g.bymin[s] = any ? lo[s][1] : 0;
+		g.na[s] = (uint8_t)(any ? (hi[s][0] - lo[s][0] + 1) : 0); g.nb[s] = (uint8_t)(any ? (hi[s][1] - lo[s][1] + 1) : 0);
+		g.ksub[s] = 0;
+	}
+}
+
 // totals: kTotPolyItems items (25 doubles each) of the polynomial store; kTotKDoubles doubles of the matrix-core store (laid behind
 // it); kTotPolyTargets targets left to the vector-ALU fit; kTotClass0 + c targets of class c of the matrix-core fit (class_lists[c][..])
 __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan* __restrict__ plans, int32_t* __restrict__ todo,
 	unsigned long long* __restrict__ totals, int max_origins, int32_t* __restrict__ order, int sort_n,
-	MPlan* __restrict__ mplans, uint16_t* __restrict__ ulist, uint8_t* __restrict__ usig, int use_mfma, int32_t* __restrict__ class_lists, int n_targets)
+	MPlan* __restrict__ mplans, uint16_t* __restrict__ ulist, uint8_t* __restrict__ usig, int use_mfma, int32_t* __restrict__ class_lists, int n_targets,
+	SegPlan* __restrict__ segs, int32_t* __restrict__ seg_lists)
 {
 	extern __shared__ unsigned long long skeys[];   // [sort_n] (key of the cadence's origins) * 8192 + cadence, or nothing
+	// matrix-core path: the knot intervals every star visits per 16-cadence tile (x lowest / highest, y lowest / highest; the
+	// sentinel 32767 / -32768: no valid position in the tile), and the segments the series is cut into
+	__shared__ __align__(8) short s_tr[kMfmaStars][kMfmaCadTiles][4];
+	__shared__ SegPlan s_seg[kMfmaSegs];
+	__shared__ int s_nseg, s_walk, s_too_many;
 	__shared__ StarBox sbox[kMaxStars];
 	__shared__ StarPlan spl[kMaxStars];
 	__shared__ double spos[4][kMfmaStars][4];      // per wavefront and star: min / max of the row and column position
@@ -265,7 +284,8 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 	const int ns = (int)(a.star_offsets[target + 1] - s0);
 	int32_t* ord = order + (int64_t)target * a.n_cad;
 	if (ns > kMaxStars) return;   // the many-star kernel's targets
-	if (tid == 0) { s_ok = 0; s_nkeys = 0; s_path = kPathPoly; }
+	if (tid == 0) { s_ok = 0; s_nkeys = 0; s_path = kPathPoly; s_nseg = 0; }
+	const bool want_segments = use_mfma && ns >= 1 && ns <= kMfmaStars;
 	for (int i = tid; i < n + 4; i += 256) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
 	if (tid < kMaxStars) {
 		sbox[tid].axmin = sbox[tid].bymin = sbox[tid].jmin = sbox[tid].imin = 0x7fffffff;
@@ -279,11 +299,30 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 		const int big = 0x7fffffff;
 		int lo[4] = {big, big, big, big}, hi[4] = {-big, -big, -big, -big};
 		double pr[4] = {1e300, -1e300, 1e300, -1e300};   // row min, row max, column min, column max over the valid cadences
-		for (int k = tid; k < a.n_cad; k += 256) {
-			const double srow = a.pos_row[(s0 + s) * a.pos_pitch + k], scol = a.pos_col[(s0 + s) * a.pos_pitch + k];
+		// (whole rounds of 256 cadences, so that the 16 lanes of a tile of cadences reduce together)
+		for (int k = tid; k < ((a.n_cad + 255) & ~255); k += 256) {
+			const bool in_series = k < a.n_cad;
+			const double srow = in_series ? a.pos_row[(s0 + s) * a.pos_pitch + k] : __builtin_nan(""), scol = in_series ? a.pos_col[(s0 + s) * a.pos_pitch + k] : __builtin_nan("");
 			double phx, phy; int ax0, by0;
 			const bool vx = axis_phase(kn, n, scol, h, phx, ax0);
 			const bool vy = axis_phase(kny, n, srow, hy, phy, by0);
+			if (want_segments && s < kMfmaStars) {
+				// consecutive lanes hold consecutive cadences: 16 of them are one tile
+				int t0 = (vx && vy) ? ax0 : 32767, t1 = (vx && vy) ? ax0 : -32768, t2 = (vx && vy) ? by0 : 32767, t3 = (vx && vy) ? by0 : -32768;
+#pragma unroll
+				for (int off = 1; off < 16; off <<= 1) {
+					const int o0 = __shfl_xor(t0, off, 64), o1 = __shfl_xor(t1, off, 64), o2 = __shfl_xor(t2, off, 64), o3 = __shfl_xor(t3, off, 64);
+					t0 = (o0 < t0) ? o0 : t0; t1 = (o1 > t1) ? o1 : t1; t2 = (o2 < t2) ? o2 : t2; t3 = (o3 > t3) ? o3 : t3;
+				}
+				if ((tid & 15) == 0 && in_series && (k >> 4) < kMfmaCadTiles) {
+					// (an interval index beyond 16 bits -- a position thousands of pixels off -- can only come with others that are
+					// not: the span test below then refuses the target; clamping keeps the order)
+					auto cl = [](int v) { return (short)((v < -32767) ? -32767 : ((v > 32766) ? 32766 : v)); };
+					const bool any = t1 >= t0;
+					s_tr[s][k >> 4][0] = any ? cl(t0) : (short)32767; s_tr[s][k >> 4][1] = any ? cl(t1) : (short)-32768;
+					s_tr[s][k >> 4][2] = any ? cl(t2) : (short)32767; s_tr[s][k >> 4][3] = any ? cl(t3) : (short)-32768;
+				}
+			}
 			if (vx && vy) {
 				const int v0[4] = {ax0, by0, (int)floor(scol - cutoff), (int)floor(srow - cutoff)};
 				const int v1[4] = {ax0, by0, (int)ceil(scol + cutoff), (int)ceil(srow + cutoff)};
@@ -339,10 +378,101 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 			srange[s][2] = fmin(fmin(spos[0][s][2], spos[1][s][2]), fmin(spos[2][s][2], spos[3][s][2]));
 			srange[s][3] = fmax(fmax(spos[0][s][3], spos[1][s][3]), fmax(spos[2][s][3], spos[3][s][3]));
 		}
-		if (too_many) s_path = kPathDirect;   // pointing excursions over many knots: the general kernel
+		// The matrix-core path: the series cut into segments of 16-cadence tiles inside which no star visits more than kMfmaSpan knot
+		// intervals per axis (greedy: a segment ends before the tile that would take a star beyond that).  A star that does so inside
+		// ONE tile (jitter of a third of a pixel within 16 cadences), more than kMfmaSegs segments, or a series beyond
+		// 16 * kMfmaCadTiles cadences leave the target to the vector-ALU kernels.
 		// (a target without a fitted star -- its own catalogue entry dropped for a NaN magnitude or position -- has no class list:
 		// the polynomial path finalises it as 'All target flux values are NaN')
-		else if (use_mfma && ns >= 1 && ns <= kMfmaStars && a.height * a.width <= 65535) s_path = kPathMfma;
+		bool seg_ok = want_segments && a.height * a.width <= 65535 && a.n_cad <= 16 * kMfmaCadTiles;
+		int nseg = 0;
+		s_walk = 0;
+		if (seg_ok) {
+			// the common case needs no walk: no star leaves its three intervals during the whole series (no drift) -- one segment with
+			// the boxes found above
+			int lo[kMfmaStars][2], hi[kMfmaStars][2];
+			for (int s = 0; s < kMfmaStars; ++s) { lo[s][0] = lo[s][1] = 32767; hi[s][0] = hi[s][1] = -32768; }
+			bool whole = true;
+			for (int s = 0; s < ns; ++s) {
+				const StarBox b = sbox[s];
+				if (b.axmax < b.axmin) continue;
+				if (b.axmax - b.axmin + 1 > kMfmaSpan || b.bymax - b.bymin + 1 > kMfmaSpan || b.axmin < -32000 || b.axmax > 32000 || b.bymin < -32000 || b.bymax > 32000) whole = false;
+				lo[s][0] = b.axmin; hi[s][0] = b.axmax; lo[s][1] = b.bymin; hi[s][1] = b.bymax;
+			}
+			if (whole) { emit_segment(s_seg[0], target, 0, (a.n_cad + 15) >> 4, lo, hi, ns, spl); nseg = 1; }
+			else s_walk = 1;   // the first wavefront walks the tiles (below)
+		}
+		s_nseg = seg_ok ? nseg : 0;
+		s_too_many = too_many ? 1 : 0;
+	}
+	__syncthreads();
+	if (s_walk && tid < 64) {
+		// Greedy segmentation by one wavefront, a window of 64 tiles at a time: lane j holds the knot intervals of tile pos + j,
+		// an inclusive min / max scan gives every lane the range of [segment start, its tile], the first lane whose range goes
+		// beyond the span ends the segment before its tile.  (One thread walking the tiles through LDS took 40 us per target.)
+		const int ntile = (a.n_cad + 15) >> 4;
+		const int lane = tid;
+		int nseg = 0, seg_start = 0, pos = 0;
+		bool ok = true;
+		int clo[kMfmaStars][2], chi[kMfmaStars][2];   // the range of the open segment up to the window (wave-uniform)
+#pragma unroll
+		for (int s = 0; s < kMfmaStars; ++s) { clo[s][0] = clo[s][1] = 32767; chi[s][0] = chi[s][1] = -32768; }
+		while (pos < ntile && ok) {
+			const int t = pos + lane;
+			const bool valid = t < ntile;
+			int pl[kMfmaStars][2], pu[kMfmaStars][2];
+			bool fits = true;
+#pragma unroll
+			for (int s = 0; s < kMfmaStars; ++s) {
+#pragma unroll
+				for (int e = 0; e < 2; ++e) {
+					int l = (valid && s < ns) ? (int)s_tr[s][valid ? t : 0][2 * e] : 32767, u = (valid && s < ns) ? (int)s_tr[s][valid ? t : 0][2 * e + 1] : -32768;
+					if (lane == 0) { l = (clo[s][e] < l) ? clo[s][e] : l; u = (chi[s][e] > u) ? chi[s][e] : u; }
+#pragma unroll
+					for (int off = 1; off < 64; off <<= 1) {
+						const int ol = __shfl_up(l, off, 64), ou = __shfl_up(u, off, 64);
+						if (lane >= off) { l = (ol < l) ? ol : l; u = (ou > u) ? ou : u; }
+					}
+					pl[s][e] = l; pu[s][e] = u;
+					if (u >= l && u - l + 1 > kMfmaSpan) fits = false;
+				}
+			}
+			const unsigned long long bad = __ballot(valid && !fits);
+			if (bad == 0ull) {
+				const int lastl = (ntile - 1 - pos < 63) ? (ntile - 1 - pos) : 63;
+#pragma unroll
+				for (int s = 0; s < kMfmaStars; ++s)
+#pragma unroll
+					for (int e = 0; e < 2; ++e) { clo[s][e] = __shfl(pl[s][e], lastl, 64); chi[s][e] = __shfl(pu[s][e], lastl, 64); }
+				pos += 64;
+				continue;
+			}
+			const int c = __builtin_ctzll(bad);
+			if (c == 0 && pos == seg_start) { ok = false; break; }   // one tile of cadences alone goes beyond the span
+			int lo[kMfmaStars][2], hi[kMfmaStars][2];
+#pragma unroll
+			for (int s = 0; s < kMfmaStars; ++s)
+#pragma unroll
+				for (int e = 0; e < 2; ++e) {
+					const int sl = __shfl(pl[s][e], (c > 0) ? (c - 1) : 0, 64), su = __shfl(pu[s][e], (c > 0) ? (c - 1) : 0, 64);
+					lo[s][e] = (c > 0) ? sl : clo[s][e]; hi[s][e] = (c > 0) ? su : chi[s][e];
+					clo[s][e] = 32767; chi[s][e] = -32768;
+				}
+			if (nseg >= kMfmaSegs) { ok = false; break; }
+			if (lane == 0) emit_segment(s_seg[nseg], target, seg_start, pos + c, lo, hi, ns, spl);
+			++nseg;
+			seg_start = pos = pos + c;
+		}
+		if (ok) {
+			if (nseg >= kMfmaSegs) ok = false;
+			else { if (lane == 0) emit_segment(s_seg[nseg], target, seg_start, ntile, clo, chi, ns, spl); ++nseg; }
+		}
+		if (lane == 0) s_nseg = ok ? nseg : 0;
+	}
+	__syncthreads();
+	if (tid == 0) {
+		if (s_nseg > 0) s_path = kPathMfma;
+		else if (s_too_many) s_path = kPathDirect;   // pointing excursions over many knots: the general kernel
 	}
 	__syncthreads();
 	if (s_path == kPathMfma) {
@@ -373,7 +503,9 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 		}
 		__syncthreads();
 		const int nk = s_nkeys;
-		if (nk > kMfmaPixels) { if (tid == 0) s_path = kPathPoly; }   // a large stamp: the vector-ALU kernels
+		if (nk > kMfmaPixels) {   // a large stamp: the vector-ALU kernels
+			if (tid == 0) { bool tm = false; for (int s = 0; s < ns; ++s) if (spl[s].nc > max_origins) tm = true; s_path = tm ? kPathDirect : kPathPoly; }
+		}
 		else {
 			uint16_t* ul = ulist + (int64_t)target * kMfmaPixels;
 			uint8_t* us = usig + (int64_t)target * kMfmaPixels;
@@ -395,35 +527,47 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 	if (tid == 0) {
 		int path = s_path;
 		if (path == kPathMfma) {
-			// one spline per star over the knot intervals it visits (at most 3 x 3), the target's coefficient image within the LDS
-			// of its class; otherwise the vector-ALU kernels take the target
+			// per segment one spline per star over the knot intervals it visits there (at most 3 x 3), the segment's coefficient image
+			// within the LDS of its class; otherwise the vector-ALU kernels take the target
 			MPlan mp;
-			mp.n_pix = s_nkeys; mp.n_tiles = (s_nkeys + 15) >> 4;
-			long long blocks = 0;
-			bool fits = true;
+			mp.n_pix = s_nkeys; mp.n_tiles = (s_nkeys + 15) >> 4; mp.n_seg = s_nseg;
 			for (int s = 0; s < kMfmaStars; ++s) {
 				mp.tiles[s] = (s < ns) ? s_tiles[s] : 0u;
 				mp.edge_tiles[s] = (s < ns) ? s_etiles[s] : 0u;
-				mp.ksub[s] = (uint16_t)blocks;
-				int na = 0, nb = 0;
-				if (s < ns && spl[s].nc > 0) { nb = spl[s].nby; na = spl[s].nc / nb; }
-				if (na > kMfmaSpan || nb > kMfmaSpan) fits = false;
-				mp.na[s] = (uint8_t)na; mp.nb[s] = (uint8_t)nb;
-				if (na > 0) blocks += (long long)__popc(mp.tiles[s]) * mfma_steps(na, nb);
 			}
-			const bool large = blocks * 512 > kMfmaLdsSmall;
-			if (blocks * 512 > ((ns <= 1) ? kMfmaLdsSmall : kMfmaLdsLarge)) fits = false;
+			bool fits = true;
+			long long total = 0;
+			for (int i = 0; i < s_nseg; ++i) {
+				SegPlan& g = s_seg[i];
+				long long blocks = 0;
+				for (int s = 0; s < kMfmaStars; ++s) {
+					g.ksub[s] = (uint16_t)blocks;
+					if (g.na[s] > 0) blocks += (long long)__popc(mp.tiles[s]) * mfma_steps(g.na[s], g.nb[s]);
+				}
+				if (blocks * 512 > ((ns <= 1) ? kMfmaLdsSmall : kMfmaLdsLarge)) fits = false;
+				g.kdoubles = (int32_t)(blocks * 64);
+				g.koff = total;
+				total += blocks * 64;
+			}
 			if (fits) {
-				mp.kdoubles = (int32_t)(blocks * 64);
-				mp.koff = (long long)atomicAdd(&totals[kTotKDoubles], (unsigned long long)(blocks * 64));
+				const long long base = (long long)atomicAdd(&totals[kTotKDoubles], (unsigned long long)total);
 				mplans[target] = mp;
+				const int cls = ns - 1;   // one launch per star count
+				const unsigned long long sat = atomicAdd(&totals[kTotSeg0 + cls], (unsigned long long)s_nseg);
+				for (int i = 0; i < s_nseg; ++i) {
+					s_seg[i].koff += base;
+					segs[(int64_t)target * kMfmaSegs + i] = s_seg[i];
+					seg_lists[(int64_t)cls * n_targets * kMfmaSegs + (int64_t)sat + i] = target * kMfmaSegs + i;
+				}
 				for (int s = 0; s < ns; ++s) plans[(int64_t)target * kMaxStars + s] = spl[s];
 				todo[target] = kPathMfma;
-				const int cls = (ns - 1) * 2;   // one launch per star count (the odd classes -- a separate list for large images -- are not in use:
-				(void)large;                    // the same launch configuration serves both, and two launches have two tails)
 				const unsigned long long at = atomicAdd(&totals[kTotClass0 + cls], 1ull);
 				class_lists[(int64_t)cls * n_targets + (int64_t)at] = target;
-			} else path = kPathPoly;
+			} else {
+				bool too_many = false;
+				for (int s = 0; s < ns; ++s) if (spl[s].nc > max_origins) too_many = true;
+				path = too_many ? kPathDirect : kPathPoly;
+			}
 		}
 		if (path == kPathDirect) { todo[target] = kPathDirect; atomicAdd(&totals[kTotDirectTargets], 1ull); }
 		else if (path == kPathPoly) {
@@ -510,7 +654,7 @@ __device__ __forceinline__ void patch_coefficients(const double* __restrict__ C,
 
 __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const StarPlan* __restrict__ plans, const int32_t* __restrict__ todo,
 	double* __restrict__ store, const MPlan* __restrict__ mplans, const uint16_t* __restrict__ ulist, const uint8_t* __restrict__ usig,
-	double* __restrict__ kstore)
+	double* __restrict__ kstore, const SegPlan* __restrict__ segs)
 {
 	extern __shared__ __align__(16) double ctab[];   // the target's coefficient table [n*n]: every patch is read ~5 times over
 	const int target = blockIdx.x, tid = threadIdx.x;
@@ -548,11 +692,13 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 		// coefficients; the interval (0, 0) writes the steps that hold C[e][d], e <= 4, d < 4, at once, every interval leaves its
 		// K[4][0..4] and K[0..3][4] in LDS, and one thread per pixel then forms the differences and writes the remaining steps.
 		double* scr = ctab + n * n;   // [512][9]
+		// (the table is staged once for all segments of the series: a drifting star costs its extra intervals, not extra table loads)
+		for (int sgi = 0; sgi < mp.n_seg; ++sgi) {
+		const SegPlan sg = segs[(int64_t)target * kMfmaSegs + sgi];
 		for (int s = 0; s < ns; ++s) {
-			const StarPlan p = plans[(int64_t)target * kMaxStars + s];
 			const unsigned tiles = mp.tiles[s];
 			const int nt = __popc(tiles);
-			const int na = mp.na[s], nb = mp.nb[s];
+			const int na = sg.na[s], nb = sg.nb[s];
 			if (na == 0) continue;
 			const int nk = mfma_steps(na, nb);
 			const int ncell = na * nb;
@@ -572,7 +718,7 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 						double kk[5][5];
 						if (pix != 0xffffu && ((us[slot] >> s) & 1)) {
 							const int i = (int)pix / a.width, j = (int)pix - i * a.width;
-							int ax = (p.axmin + ca) + 9 * j, by = (p.bymin + cb) + 9 * i;
+							int ax = (sg.axmin[s] + ca) + 9 * j, by = (sg.bymin[s] + cb) + 9 * i;
 							ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
 							by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
 							patch_coefficients(C, n, ax, by, h2, kk);
@@ -583,7 +729,7 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 								for (int d = 0; d < 5; ++d) kk[e][d] = 0.0;
 						}
 						if (cell == 0) {
-							double* dst = kstore + mp.koff + ((int64_t)mp.ksub[s] + (int64_t)r * nk) * 64 + u;
+							double* dst = kstore + sg.koff + ((int64_t)sg.ksub[s] + (int64_t)r * nk) * 64 + u;
 #pragma unroll
 							for (int e = 0; e < 5; ++e)
 #pragma unroll
@@ -603,7 +749,7 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 					auto sc = [&](int ca, int cb, int q) -> double { return (ca < 0 || cb < 0) ? 0.0 : scr[(tid * ncell + ca * nb + cb) * 9 + q]; };
 					// ce[4 + a][d] (d < 4), ce[e][4 + b] (e < 4), ce[4 + a][4 + b]: first differences along the axis that leaves interval 0,
 					// the second difference of K[4][4] off both axes
-					double* dst = kstore + mp.koff + ((int64_t)mp.ksub[s] + (int64_t)r * nk) * 64 + u;
+					double* dst = kstore + sg.koff + ((int64_t)sg.ksub[s] + (int64_t)r * nk) * 64 + u;
 					int idx = 5;
 					auto corner = [&](int ca, int cb) -> double { return ((sc(ca, cb, 4) - sc(ca - 1, cb, 4)) - sc(ca, cb - 1, 4)) + sc(ca - 1, cb - 1, 4); };
 					if (mfma_is22(na, nb)) {
@@ -635,6 +781,7 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 				}
 				__syncthreads();
 			}
+		}
 		}
 		return;
 	}
@@ -1283,6 +1430,14 @@ extern "C" int tp_linpsf_set_path(tp_ctx* ctx, int32_t path)
 	return TP_OK;
 }
 
+extern "C" int tp_linpsf_last_counts(tp_ctx* ctx, int64_t* counts, int32_t n)
+{
+	TP_CHECK_CTX(ctx);
+	TP_REQUIRE(ctx, counts != nullptr && n >= 1 && n <= 16, "tp_linpsf_last_counts: 1..16 counters");
+	for (int i = 0; i < n; ++i) counts[i] = ctx->linpsf_counts[i];
+	return TP_OK;
+}
+
 extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
 	const float* d_subtract, int64_t subtract_pitch,
 	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis, int32_t max_stars,
@@ -1327,8 +1482,11 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	const size_t ulist_bytes = ((size_t)desc->n_targets * kMfmaPixels * sizeof(uint16_t) + 255) & ~(size_t)255;
 	const size_t usig_bytes = ((size_t)desc->n_targets * kMfmaPixels * sizeof(uint8_t) + 255) & ~(size_t)255;
 	const size_t lists_bytes = ((size_t)desc->n_targets * kMfmaClasses * sizeof(int32_t) + 255) & ~(size_t)255;
+	const size_t segs_bytes = ((size_t)desc->n_targets * kMfmaSegs * sizeof(SegPlan) + 255) & ~(size_t)255;
+	const size_t seglists_bytes = ((size_t)desc->n_targets * kMfmaSegs * kMfmaClasses * sizeof(int32_t) + 255) & ~(size_t)255;
 	const size_t alast_bytes = (ctx->linpsf_path == 1) ? (((size_t)desc->n_targets * kMfmaStars * kMfmaPixels * sizeof(double) + 255) & ~(size_t)255) : 0;
-	const size_t head_bytes = todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes + usig_bytes + lists_bytes + alast_bytes;
+	const size_t head_bytes = todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes + usig_bytes + lists_bytes + segs_bytes + seglists_bytes + alast_bytes;
+	static_assert(kTotCount * sizeof(unsigned long long) <= 256, "the counters fit their block");
 	TP_REQUIRE(ctx, tp_ctx_scratch(ctx, head_bytes) != nullptr, "tp_linpsf_fit: out of device memory for the plan");
 	char* sbase = static_cast<char*>(ctx->scratch);
 	int32_t* d_todo = reinterpret_cast<int32_t*>(sbase);
@@ -1339,7 +1497,9 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	uint16_t* d_ulist = reinterpret_cast<uint16_t*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes);
 	uint8_t* d_usig = reinterpret_cast<uint8_t*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes);
 	int32_t* d_lists = reinterpret_cast<int32_t*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes + usig_bytes);
-	double* d_alast = reinterpret_cast<double*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes + usig_bytes + lists_bytes);
+	SegPlan* d_segs = reinterpret_cast<SegPlan*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes + usig_bytes + lists_bytes);
+	int32_t* d_seglists = reinterpret_cast<int32_t*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes + usig_bytes + lists_bytes + segs_bytes);
+	double* d_alast = reinterpret_cast<double*>(sbase + todo_bytes + plan_bytes + 256 + order_bytes + mplan_bytes + ulist_bytes + usig_bytes + lists_bytes + segs_bytes + seglists_bytes);
 	// cadences sorted by origin in LDS (8 bytes per slot, next power of two); beyond 8192 cadences the order stays natural
 	int sort_n = 64;
 	while (sort_n < desc->n_cad) sort_n <<= 1;
@@ -1353,11 +1513,23 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	TP_HIP(ctx, hipMemsetAsync(d_total, 0, 256, ctx->stream));
 	if (sort_n > 4096) TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sort_n * sizeof(unsigned long long))));
 	TP_LAUNCH(ctx, TPK_LINPSF_PLAN, tp_linpsf_plan_kernel, dim3((unsigned)desc->n_targets), dim3(256), (size_t)sort_n * sizeof(unsigned long long), a, d_plans, d_todo, d_total, max_origins, d_order, sort_n,
-		d_mplans, d_ulist, d_usig, use_mfma, d_lists, (int)desc->n_targets);
+		d_mplans, d_ulist, d_usig, use_mfma, d_lists, (int)desc->n_targets, d_segs, d_seglists);
 	TP_LAUNCH_CHECK(ctx, "tp_linpsf_plan_kernel");
-	unsigned long long totals[kTotClass0 + kMfmaClasses] = {};   // items of the polynomial store, doubles of the matrix-core store behind it, class sizes
+	// items of the polynomial store, doubles of the matrix-core store behind it, targets and segments per class.  The host needs
+	// them to size the store and the launches: one round trip in the middle of the call (measured: the plan kernel's 0.2 ms and
+	// the launch of the coefficient kernel hide it -- the step's wall time equals the sum of its kernels to 0.05 ms)
+	unsigned long long totals[kTotCount] = {};
 	TP_HIP(ctx, hipMemcpyAsync(totals, d_total, sizeof(totals), hipMemcpyDeviceToHost, ctx->stream));
 	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	{
+		int64_t* c = ctx->linpsf_counts;
+		for (int i = 0; i < 16; ++i) c[i] = 0;
+		for (int k = 0; k < kMfmaClasses; ++k) {
+			c[0] += (int64_t)totals[kTotClass0 + k]; c[1] += (int64_t)totals[kTotSeg0 + k];
+			c[5 + k] = (int64_t)totals[kTotClass0 + k]; c[9 + k] = (int64_t)totals[kTotSeg0 + k];
+		}
+		c[2] = (int64_t)totals[kTotPolyTargets]; c[3] = (int64_t)totals[kTotDirectTargets];
+	}
 	const size_t poly_doubles = ((size_t)totals[kTotPolyItems] * 25 + 32 + 63) & ~(size_t)63;
 	const size_t store_need = (poly_doubles + (size_t)totals[kTotKDoubles] + 64) * sizeof(double);
 	if (ctx->store_bytes < store_need) {
@@ -1371,11 +1543,11 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	const size_t coef_lds = (size_t)n_coef_axis * n_coef_axis * sizeof(double) + (use_mfma ? kCoefScratchBytes : 0);
 	TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_coef_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coef_lds));
 	TP_LAUNCH(ctx, TPK_LINPSF_COEF, tp_linpsf_coef_kernel, dim3((unsigned)desc->n_targets), dim3(512), coef_lds, a, (const StarPlan*)d_plans, (const int32_t*)d_todo, d_store,
-		(const MPlan*)d_mplans, (const uint16_t*)d_ulist, (const uint8_t*)d_usig, d_kstore);
+		(const MPlan*)d_mplans, (const uint16_t*)d_ulist, (const uint8_t*)d_usig, d_kstore, (const SegPlan*)d_segs);
 	TP_LAUNCH_CHECK(ctx, "tp_linpsf_coef_kernel");
 	// the matrix-core fit of the targets marked for it (up to 4 stars, up to 256 reachable pixels)
 	if (use_mfma) {
-		const int rc = fit_mfma_launch(ctx, a, desc->n_targets, totals + kTotClass0, d_plans, d_lists, d_mplans, d_ulist, d_usig, d_kstore, d_alast);
+		const int rc = fit_mfma_launch(ctx, a, desc->n_targets, totals + kTotSeg0, totals + kTotClass0, d_segs, d_seglists, d_mplans, d_ulist, d_usig, d_kstore, d_alast);
 		if (rc != TP_OK) return rc;
 #define TP_LINPSF_FINM(CLS, SS) do { \
 			if (totals[kTotClass0 + CLS] > 0) { \
@@ -1384,7 +1556,7 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 				TP_LAUNCH_CHECK(ctx, "tp_linpsf_finalize_m_kernel"); \
 			} \
 		} while (0)
-		TP_LINPSF_FINM(0, 1); TP_LINPSF_FINM(2, 2); TP_LINPSF_FINM(3, 2); TP_LINPSF_FINM(4, 3); TP_LINPSF_FINM(5, 3); TP_LINPSF_FINM(6, 4); TP_LINPSF_FINM(7, 4);
+		TP_LINPSF_FINM(0, 1); TP_LINPSF_FINM(1, 2); TP_LINPSF_FINM(2, 3); TP_LINPSF_FINM(3, 4);
 #undef TP_LINPSF_FINM
 	}
 	const int nblk2 = (desc->n_cad + 255) / 256;
@@ -1430,6 +1602,7 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 			TP_REQUIRE(ctx, ns <= kMaxManyStars, "tp_linpsf_fit: a target has more than 64 fitted stars");
 			if (ns > kMaxStars) { big.push_back(t); if (ns > smax) smax = ns; }
 		}
+		ctx->linpsf_counts[4] = (int64_t)big.size();
 		if (!big.empty()) {
 			const int threads = 256, nblk_m = (desc->n_cad + threads - 1) / threads;
 			const size_t per_thread = (size_t)(2 * smax * smax + 15 * smax) * sizeof(double);

@@ -155,39 +155,52 @@ struct StarPlan { int axmin, bymin, nby, nc, jmin, jmax, imin, imax; long long i
 
 // matrix-core path, per target: the pixels inside the cut-off of ANY fitted star at ANY cadence form the list U (ordered by
 // which stars reach them -- Gray-code order of the membership bits, then raster -- so that the pixels of one star are
-// contiguous), cut into tiles of 16; star s touches the tiles of `tiles[s]`.  Its coefficients are those of ONE tensor-product
-// quartic spline over the na x nb knot intervals its phases visit (linpsf_mfma.hip), laid out as the A operands of the matrix
-// instruction: [star][rank of the tile among its tiles][step][64 lanes] doubles, the whole target contiguous from `koff`
-// (that image is copied to LDS as it is), star s from `koff + 64 * ksub[s]`, `mfma_steps(na, nb)` steps per tile.
+// contiguous), cut into tiles of 16; star s touches the tiles of `tiles[s]`.
 struct MPlan {
 	int32_t n_pix, n_tiles;
 	uint32_t tiles[kMfmaStars];
 	uint32_t edge_tiles[kMfmaStars];   // tiles with a pixel that is inside the star's cut-off at some cadences only
+	int32_t n_seg;                     // segments of the series (records target * kMfmaSegs .. + n_seg of the segment array)
+};
+// The series of a target is cut into SEGMENTS of consecutive 16-cadence tiles inside which every fitted star visits at most
+// kMfmaSpan knot intervals per axis: a star that drifts across the pixel during the series (pointing drift, velocity aberration:
+// half a pixel is 4.5 knot intervals) stays on the matrix cores, each stretch of the series with the spline of the intervals it
+// visits THEN (round 3 sent such a target to the vector-ALU kernels).  Without drift the jitter gives one segment.
+// Per (target, segment): the coefficients of ONE tensor-product quartic spline per star over its na x nb intervals
+// (linpsf_mfma.hip), laid out as the A operands of the matrix instruction: [star][rank of the tile among its tiles][step][64
+// lanes] doubles, the whole segment contiguous from `koff` (that image is copied to LDS as it is), star s from
+// `koff + 64 * ksub[s]`, `mfma_steps(na, nb)` steps per tile.  One workgroup of the fit kernel per segment.
+struct SegPlan {
+	int32_t target;
+	int32_t tile0, tile1;              // 16-cadence tiles [tile0, tile1) of the series
+	int32_t kdoubles;                  // size of the segment's image (a multiple of 64)
 	int64_t koff;                      // doubles from the start of the matrix-core store
-	int32_t kdoubles;                  // size of the target's image (a multiple of 64)
+	int32_t axmin[kMfmaStars], bymin[kMfmaStars];   // first knot interval the star visits in this segment, per axis
 	uint16_t ksub[kMfmaStars];         // in blocks of 64 doubles
 	uint8_t na[kMfmaStars], nb[kMfmaStars];   // knot intervals visited along x / y (1..3; 0: the star is never on the stamp)
 };
-constexpr int kMfmaSpan = 3;          // knot intervals per axis a star may visit on this path
+constexpr int kMfmaSpan = 3;          // knot intervals per axis a star may visit inside a segment
+constexpr int kMfmaSegs = 8;          // segments per target (more: the vector-ALU kernels take the target)
+constexpr int kMfmaCadTiles = 256;    // 16-cadence tiles of a series the plan kernel can cut into segments (4096 cadences: a sector at 600 s)
 // steps of v_mfma_f64_16x16x4_f64 per (star, pixel tile): (4 + na) basis functions of x times the first four of y, then two steps
 // for each of the nb remaining basis functions of y -- except for the commonest case, 2 x 2 intervals (36 products), which is
 // packed into 9 steps instead of 10: the half-empty second step of y basis function 4 also carries x basis functions 0, 1 of y
 // basis function 5, and one more step the other four (mfma_is22)
 __host__ __device__ constexpr bool mfma_is22(int na, int nb) { return na == 2 && nb == 2; }
 __host__ __device__ constexpr int mfma_steps(int na, int nb) { return mfma_is22(na, nb) ? 9 : ((4 + na) + 2 * nb); }
-// LDS bytes for the coefficient image of a target: "small" leaves room for two workgroups per CU, "large" (three and four
+// LDS bytes for the coefficient image of a segment: "small" leaves room for two workgroups per CU, "large" (three and four
 // stars only: their kernels run one workgroup per CU anyway) takes the LDS of the CU
 constexpr int kMfmaLdsSmall = 75776, kMfmaLdsLarge = 157696;
-// the plan kernel sorts the targets of the matrix-core path into classes, one launch each: (stars - 1) * 2 + (large image)
-constexpr int kMfmaClasses = 2 * kMfmaStars;
-// counters the plan kernel keeps (64-bit words of one 256-byte block)
-enum { kTotPolyItems = 0, kTotKDoubles = 1, kTotPolyTargets = 2, kTotDirectTargets = 3, kTotClass0 = 8 };
+// the plan kernel lists the targets and the segments of the matrix-core path by their number of fitted stars: class = stars - 1
+constexpr int kMfmaClasses = kMfmaStars;
+// counters the plan kernel keeps (64-bit words of one 256-byte block): kTotClass0 + c targets, kTotSeg0 + c segments of class c
+enum { kTotPolyItems = 0, kTotKDoubles = 1, kTotPolyTargets = 2, kTotDirectTargets = 3, kTotClass0 = 8, kTotSeg0 = 16, kTotCount = 24 };
 
 // `todo` flag of a target (written by the plan kernel): which kernel fits it
 enum { kPathPoly = 0, kPathDirect = 1, kPathMfma = 2 };
 
 // linpsf_mfma.hip
-int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned long long* class_counts, const StarPlan* d_plans,
-	const int32_t* d_class_lists, const MPlan* d_mplans, const uint16_t* d_ulist, const uint8_t* d_usig, const double* d_kstore, double* d_alast);
+int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned long long* seg_counts, const unsigned long long* class_counts, const SegPlan* d_segs,
+	const int32_t* d_seg_lists, const MPlan* d_mplans, const uint16_t* d_ulist, const uint8_t* d_usig, const double* d_kstore, double* d_alast);
 
 } // namespace tp_linpsf

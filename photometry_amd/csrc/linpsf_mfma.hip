@@ -16,12 +16,13 @@
 // natural order (round 3's first version sorted every window of cadences by origin and ran one masked pass per origin with a
 // coefficient block per (star, origin, tile): it spent its time staging those blocks).
 //
-// Layout.  One workgroup per target; the target's coefficient image (A operands, [star][tile][step][lane], 20 - 150 KB) is copied
-// to LDS once.  A wavefront takes GC tiles of 16 consecutive cadences at a time (GC = 1 in every launch now: with the Cholesky
-// solve a sixteen-lane solve costs less than the idle tail of larger units).  Result tile D: column = cadence (lane & 15), row =
-// pixel ((lane >> 4) + 4 r in register r): a lane owns one cadence and a quarter of the pixels, so the normal equations G = A^T A,
-// g = A^T b of a cadence are sums INSIDE a lane over registers and pixel tiles, plus one cross-lane sum over the four lane groups
-// per tile of cadences; with GC > 1 lane group m keeps the sums of tile m, so that 16 GC lanes solve one cadence each.
+// Layout.  One workgroup per SEGMENT of a target's series (linpsf_common.h: a stretch of 16-cadence tiles inside which every star
+// visits at most 3 x 3 knot intervals; one segment per target unless a star drifts); the segment's coefficient image (A operands,
+// [star][tile][step][lane], 20 - 150 KB) is copied to LDS once.  A wavefront takes one tile of 16 consecutive cadences at a time
+// (with the Cholesky solve a sixteen-lane solve costs less than the idle tail of larger units).  Result tile D: column = cadence
+// (lane & 15), row = pixel ((lane >> 4) + 4 r in register r): a lane owns one cadence and a quarter of the pixels, so the normal
+// equations G = A^T A, g = A^T b of a cadence are sums INSIDE a lane over registers and pixel tiles, plus one cross-lane sum
+// over the four lane groups per tile of cadences.
 // Pixels: the list U of the target (every pixel inside the cut-off of some star at some cadence, ordered so that the pixels of one
 // star are contiguous; plan kernel), cut into tiles of 16, the same for all stars, so products A_s A_t meet in the same register.
 // The B operands (basis products of the lane's cadence) are computed once per star and tile of cadences and stay in registers.
@@ -47,12 +48,12 @@ __device__ __forceinline__ void dma_to_lds16(const void* src, void* lds_base)
 	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
-// S fitted stars (exactly); one workgroup of up to NTHR / 64 wavefronts per target of the class list, at least MINW wavefronts
-// resident per SIMD; a wavefront takes GC tiles of 16 cadences at a time (its unit of work: the smaller, the more evenly the
-// series divides over the wavefronts; 16 GC lanes then solve -- with one star that costs nothing, with more it is the price).
-template <int S, int NTHR, int MINW, int GC>
-__global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, const StarPlan* __restrict__ plans,
-	const int32_t* __restrict__ targets, const MPlan* __restrict__ mplans, const uint16_t* __restrict__ ulist, const uint8_t* __restrict__ usig,
+// S fitted stars (exactly); one workgroup of up to NTHR / 64 wavefronts per segment of the class list, at least MINW wavefronts
+// resident per SIMD; a wavefront takes a tile of 16 cadences at a time (its unit of work: the smaller, the more evenly the
+// segment divides over the wavefronts; 16 lanes then solve).
+template <int S, int NTHR, int MINW>
+__global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, const SegPlan* __restrict__ segs,
+	const int32_t* __restrict__ seg_list, const MPlan* __restrict__ mplans, const uint16_t* __restrict__ ulist, const uint8_t* __restrict__ usig,
 	const double* __restrict__ kstore, double* __restrict__ alast)
 {
 	const int NWV = (int)blockDim.x >> 6;   // wavefronts of the workgroup (chosen by the host for the length of the series)
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 	__shared__ __align__(16) float scrow[kMfmaPixels], sccol[kMfmaPixels];
 	__shared__ unsigned semask[S][16];   // per star and tile: the pixels (bit u of the tile) that are inside the cut-off at some cadences only
 
-	const int target = targets[blockIdx.x];
+	const SegPlan sg = segs[seg_list[blockIdx.x]];
+	const int target = sg.target;
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int g = lane >> 4;
 	const int64_t s0 = a.star_offsets[target];
@@ -76,9 +78,9 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 
 	// ---- the coefficient image by LDS DMA (1 KB per wavefront and instruction), the pixel list, the edge masks
 	{
-		const double* ksrc = kstore + mp.koff;
-		for (int off = wave * 128; off < mp.kdoubles; off += NWV * 128)
-			if (off + lane * 2 < mp.kdoubles) dma_to_lds16(ksrc + off + lane * 2, sK + off);
+		const double* ksrc = kstore + sg.koff;
+		for (int off = wave * 128; off < sg.kdoubles; off += NWV * 128)
+			if (off + lane * 2 < sg.kdoubles) dma_to_lds16(ksrc + off + lane * 2, sK + off);
 	}
 	if (tid < S * 16) (&semask[0][0])[tid] = 0u;
 	__syncthreads();
@@ -104,17 +106,15 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 	int na[S], nb[S], nk[S], kbase[S], axmin[S], bymin[S];
 #pragma unroll
 	for (int s = 0; s < S; ++s) {
-		const StarPlan p = plans[(int64_t)target * kMaxStars + s];
 		tl[s] = mp.tiles[s]; etl[s] = mp.edge_tiles[s];
-		na[s] = mp.na[s]; nb[s] = mp.nb[s];
+		na[s] = sg.na[s]; nb[s] = sg.nb[s];
 		nk[s] = mfma_steps(na[s], nb[s]);
-		kbase[s] = (int)mp.ksub[s] * 64;
-		axmin[s] = p.axmin; bymin[s] = p.bymin;
+		kbase[s] = (int)sg.ksub[s] * 64;
+		axmin[s] = sg.axmin[s]; bymin[s] = sg.bymin[s];
 	}
 	const float* img = a.images + (int64_t)target * H * W * a.t_pitch;
 	const int ti = a.target_index[target];   // loaded once: inside the loop its latency would stand in front of every solve
-	constexpr int GCAD = 16 * GC;   // cadences per group
-	const int ngroups = (a.n_cad + GCAD - 1) / GCAD;
+	constexpr int GCAD = 16;        // cadences per unit
 
 	// positions and subtracted value of the NEXT tile of cadences are loaded a tile ahead (their latency would otherwise stand
 	// in front of every tile: nothing else can start before the basis products)
@@ -128,15 +128,13 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 		if (a.subtract) nsb = a.subtract[(int64_t)target * a.subtract_pitch + kq];
 	};
 	constexpr bool AHEAD = (S == 1);   // with more stars the registers are worth more than the latency (measured)
-	if (AHEAD) load_cadence(wave * GCAD);
-	for (int gi = wave; gi < ngroups; gi += NWV) {
+	if (AHEAD) load_cadence((sg.tile0 + wave) * GCAD);
+	for (int gi = sg.tile0 + wave; gi < sg.tile1; gi += NWV) {
 		double kept[NACC];   // the normal equations of the cadence this lane solves: g[0..S), then G[s][t], t >= s, row-major
 #pragma unroll
 		for (int m = 0; m < NACC; ++m) kept[m] = 0.0;
-#pragma unroll 1
-		for (int mt = 0; mt < GC; ++mt) {
-			const int k0 = gi * GCAD + mt * 16;
-			if (k0 >= a.n_cad) break;   // uniform
+		{
+			const int k0 = gi * GCAD;
 			const int k = k0 + (lane & 15);
 			const bool act = k < a.n_cad;
 			const bool last_here = (a.n_cad - 1 >= k0) && (a.n_cad - 1 < k0 + 16);   // uniform
@@ -198,7 +196,7 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 				B[s][11] = xlo * y6; B[s][12] = xhi * y6;
 			}
 
-			if (AHEAD) load_cadence((mt < GC - 1 && k0 + 16 < a.n_cad) ? (k0 + 16) : ((gi + NWV) * GCAD));
+			if (AHEAD) load_cadence((gi + NWV) * GCAD);
 			__builtin_amdgcn_s_setprio(0);
 
 			double acc[NACC];
@@ -328,13 +326,13 @@ __global__ __launch_bounds__(NTHR, MINW) void tp_linpsf_fitm_kernel(FitArgs a, c
 				}
 			}
 			__builtin_amdgcn_s_setprio(3);
-			// ---- sum over the four lane groups; group mt keeps the sums of this tile of cadences
+			// ---- sum over the four lane groups
 #pragma unroll
 			for (int m = 0; m < NACC; ++m) {
 				double v = acc[m];
 				v += __shfl_xor(v, 16, 64);
 				v += __shfl_xor(v, 32, 64);
-				if (g == mt) kept[m] = v;
+				kept[m] = v;
 			}
 		}
 		// ---- every lane solves one cadence
@@ -388,9 +386,9 @@ static int fit_waves(int n_cad, int most, int group_cadences)
 	return best;
 }
 
-// launches the matrix-core fit, one launch per class of targets the plan kernel has listed ((stars - 1) * 2 + large image)
-int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned long long* class_counts, const StarPlan* d_plans,
-	const int32_t* d_class_lists, const MPlan* d_mplans, const uint16_t* d_ulist, const uint8_t* d_usig, const double* d_kstore, double* d_alast)
+// launches the matrix-core fit, one launch per star count over the segments the plan kernel has listed for it
+int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned long long* seg_counts, const unsigned long long* class_counts, const SegPlan* d_segs,
+	const int32_t* d_seg_lists, const MPlan* d_mplans, const uint16_t* d_ulist, const uint8_t* d_usig, const double* d_kstore, double* d_alast)
 {
 	// The launches are independent (one per star count): the first runs on the context's stream, the others on two side streams
 	// that wait for what precedes on it (the coefficient store) and are waited for before what follows (the finalisation), so that
@@ -404,13 +402,17 @@ int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned
 		streams[i + 1] = ctx->side[i];
 	}
 	bool waited[3] = {true, false, false};
-#define TP_FITM(CLS, SS, TT, WW, GG, LDS) do { \
-		if (class_counts[CLS] > 0) { \
+	// (the workgroup is sized for the whole series also where the class has several segments per target: sizing it for the mean
+	// segment -- fewer wavefronts, a fuller last round -- measured slower, 7.5 against 6.9 ms on the drift scene: the classes with
+	// two and more stars hold one workgroup per CU, and its wavefronts are the CU's occupancy)
+	(void)class_counts;
+#define TP_FITM(CLS, SS, TT, WW, LDS) do { \
+		if (seg_counts[CLS] > 0) { \
 			const int si = used++ % 3; \
 			if (!waited[si]) { TP_HIP(ctx, hipStreamWaitEvent(streams[si], before, 0)); waited[si] = true; } \
-			TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fitm_kernel<SS, TT, WW, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
-			TP_LAUNCH_ON(ctx, streams[si], TPK_LINPSF_FIT_MFMA, (tp_linpsf_fitm_kernel<SS, TT, WW, GG>), dim3((unsigned)class_counts[CLS]), dim3(64 * fit_waves(a.n_cad, TT / 64, 16 * GG)), (size_t)LDS, \
-				a, d_plans, d_class_lists + (size_t)(CLS) * n_targets, d_mplans, d_ulist, d_usig, d_kstore, d_alast); \
+			TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fitm_kernel<SS, TT, WW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+			TP_LAUNCH_ON(ctx, streams[si], TPK_LINPSF_FIT_MFMA, (tp_linpsf_fitm_kernel<SS, TT, WW>), dim3((unsigned)seg_counts[CLS]), dim3(64 * fit_waves(a.n_cad, TT / 64, 16)), (size_t)LDS, \
+				a, d_segs, d_seg_lists + (size_t)(CLS) * n_targets * kMfmaSegs, d_mplans, d_ulist, d_usig, d_kstore, d_alast); \
 			TP_LAUNCH_CHECK(ctx, "tp_linpsf_fitm_kernel"); \
 		} \
 	} while (0)
@@ -419,13 +421,10 @@ int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned
 	// step); three and four stars 226 / 256 -- two per SIMD, one workgroup of 8 whatever the size of the image (two workgroups
 	// of 4 for the small images: 0.38 ms for what the large configuration does in 0.1).  Units of 16 cadences everywhere: with the
 	// Cholesky solve the sixteen-lane solve costs less than the idle tail of larger units (three stars: 2.78 -> 2.47 ms)
-	TP_FITM(0, 1, 512, 4, 1, kMfmaLdsSmall);
-	TP_FITM(2, 2, 768, 3, 1, kMfmaLdsLarge);
-	TP_FITM(3, 2, 768, 3, 1, kMfmaLdsLarge);
-	TP_FITM(4, 3, 512, 2, 1, kMfmaLdsLarge);
-	TP_FITM(5, 3, 512, 2, 1, kMfmaLdsLarge);
-	TP_FITM(6, 4, 512, 2, 1, kMfmaLdsLarge);
-	TP_FITM(7, 4, 512, 2, 1, kMfmaLdsLarge);
+	TP_FITM(0, 1, 512, 4, kMfmaLdsSmall);
+	TP_FITM(1, 2, 768, 3, kMfmaLdsLarge);
+	TP_FITM(2, 3, 512, 2, kMfmaLdsLarge);
+	TP_FITM(3, 4, 512, 2, kMfmaLdsLarge);
 #undef TP_FITM
 	for (int i = 1; i < 3; ++i) {
 		if (waited[i]) {

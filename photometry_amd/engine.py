@@ -295,6 +295,15 @@ def linpsf_set_path(ctx, path):
 	ctx._check(ctx.lib.tp_linpsf_set_path(ctx.handle, int(path)))
 
 
+def linpsf_last_counts(ctx):
+	"""Which kernels fitted the targets of the last :func:`linpsf_fit` call (``tp_linpsf_last_counts``), as a dict."""
+	c = (ctypes.c_int64 * 13)()
+	ctx._check(ctx.lib.tp_linpsf_last_counts(ctx.handle, c, 13))
+	return {'matrix_core_targets': int(c[0]), 'matrix_core_segments': int(c[1]), 'vector_alu_polynomial_targets': int(c[2]),
+		'vector_alu_general_targets': int(c[3]), 'many_star_targets': int(c[4]),
+		'matrix_core_targets_by_stars': [int(c[5 + i]) for i in range(4)], 'matrix_core_segments_by_stars': [int(c[9 + i]) for i in range(4)]}
+
+
 def linpsf_fit(ctx, images, coef, knots_x, knots_y, star_offsets, target_index, pos_row, pos_col, max_stars,
 	cutoff_radius=5.0, subtract=None, out=None):
 	"""P2-P4 (psf.py:122-148, linpsf_photometry.py:22-34, 79-219)."""

@@ -124,3 +124,36 @@ def compare(s, S, got, ref, check_cut=True):
 			n_exact += 1
 	return {'n_exact': n_exact, 'n_razor': n_razor, 'min_margin': float(np.min(margins)) if margins else np.nan,
 		'max_dcut': float(np.max(dcuts)) if dcuts else 0.0}
+
+
+def own_chain_check(S_dev, images, images_err, backgrounds, quality, stamp, pos_row, pos_col, tmag, starid, catalog, aperture, got_mask, got_status,
+	got_flux=None, got_flux_err=None, got_flux_background=None):
+	"""
+	The parity chain closed at one target: the ORACLE's own sum image (its restatement of prepare.py:450-459 /
+	BasePhotometry.py:1008-1019 on the same cube) -> the oracle's own mask and light curve, against the device's mask (built from
+	the device's sum image).  The two sum images agree to ~1e-16 relative (float64 sums of float32 values in another order), so
+	the masks can differ only where a pixel of the sum image sits within that distance (times the K2P2 threshold's sensitivity,
+	see :func:`compare`) of the threshold: such a target is reported as a razor case, anything else must be equal.
+	Returns ``'exact'``, ``'razor'`` or raises.
+	"""
+	S_or = osum.sumimage(images, quality)
+	with np.errstate(invalid='ignore'):
+		np.testing.assert_allclose(S_dev, S_or, rtol=1e-12, atol=0, equal_nan=True)
+	try:
+		ref = oap.do_photometry(S_or, images, images_err, backgrounds, stamp, pos_row, pos_col, tmag, starid, catalog, aperture)
+	except Exception as e: # noqa: B902 -- any exception in the plugin is STATUS.ERROR upstream (tessphot.py:37-49)
+		ref = {'status': oap.STATUS_ERROR, 'exception': repr(e)}
+	same = int(got_status) == ref['status'] and (ref['status'] == oap.STATUS_ERROR or 'mask' not in ref or np.array_equal(np.asarray(got_mask).astype(bool), ref['mask']))
+	if not same:
+		# razor: a pixel of the sum image within the reach of the threshold's own uncertainty (2e-6 relative, see compare())
+		thr = ok2p2.threshold(S_or, 0.8, full_output=True)
+		with np.errstate(invalid='ignore'):
+			margin = np.nanmin(np.abs(S_or - thr['CUT']))
+		assert margin <= 8e-6 * max(1.0, abs(thr['CUT'])), f"masks differ off the razor's edge: margin {margin}, CUT {thr['CUT']}, status {got_status} vs {ref['status']}"
+		return 'razor'
+	if ref['status'] != oap.STATUS_ERROR and 'mask' in ref and got_flux is not None:
+		np.testing.assert_array_equal(got_flux, ref['flux'])
+		np.testing.assert_array_equal(got_flux_err, ref['flux_err'])
+		if got_flux_background is not None and backgrounds is not None:
+			np.testing.assert_array_equal(got_flux_background, ref['flux_background'])
+	return 'exact'

@@ -21,6 +21,7 @@ def test_config1_aperture_only_every_target():
 	from photometry_amd import simulate, pipeline
 	from photometry_amd.device import Context
 	from oracle import aperture as oap
+	from k2p2_common import own_chain_check
 	ctx = Context(0)
 	Nt, T, H, W = 1000, 200, 11, 11
 	s = simulate.make_scene(Nt, T, H, W, seed=0)           # seed 0 for this configuration
@@ -48,6 +49,12 @@ def test_config1_aperture_only_every_target():
 		n_ok += 1
 	print(f"configs[1]: {n_ok} targets bit-exact, {n_err} ERROR targets agree")
 	assert n_ok >= 0.9 * Nt
+	# the chain closed for EVERY target: the oracle's own sum image -> the oracle's own mask and light curve against the device's
+	verdicts = [own_chain_check(res['sumimage'][i], s.images[i], s.images_err[i], None, s.quality, tuple(s.stamps[i]), s.target_pos_row[i],
+		s.target_pos_column[i], s.target_tmag[i], s.target_starid[i], s.catalog_of(i), s.aperture[i], res['mask'][i], res['status'][i],
+		res['flux'][i], res['flux_err'][i]) for i in range(Nt)]
+	print('configs[1], own-sum-image chain:', verdicts.count('exact'), 'exact,', verdicts.count('razor'), 'razor of', Nt)
+	assert verdicts.count('razor') <= 2
 	ctx.close()
 
 

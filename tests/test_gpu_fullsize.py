@@ -7,7 +7,8 @@ through size-independent properties, because the oracle needs ~40 ms per target:
 * running the batch as two unequal chunks (views of the same cubes) gives the same bits as one launch
   (targets are independent: no cross-target state, no launch-geometry dependence);
 * a second run reproduces the first bit for bit (fixed-shape reductions, no atomics on the data path);
-* a seeded sample of targets spread over the whole batch equals the oracle bit for bit;
+* a seeded sample of targets spread over the whole batch equals the oracle bit for bit -- fed the device's sum image, AND from
+  the oracle's own sum image of the same cube (the chain closed: oracle sum image -> oracle mask against the device mask);
 * an exact power-of-two rescaling of the inputs (medium size, host cubes) leaves masks unchanged and scales the fluxes exactly.
 """
 import numpy as np
@@ -34,6 +35,7 @@ def _checksum(out):
 def test_full_size_properties():
 	from photometry_amd.device import Context
 	from oracle import aperture as oap
+	from k2p2_common import own_chain_check
 	ctx = Context(0)
 	hbm = ctx.info()['hbm_bytes']
 	if hbm < 60e9:
@@ -74,6 +76,7 @@ def test_full_size_properties():
 	rng = np.random.default_rng(7)
 	sample = np.sort(rng.choice(Nt, 24, replace=False))
 	ap = np.ones((H, W), dtype='int32')
+	verdicts = []
 	for i in sample:
 		host = {}
 		for name in ('images', 'images_err', 'backgrounds'):
@@ -87,6 +90,12 @@ def test_full_size_properties():
 			np.testing.assert_array_equal(a['flux'][i], ref['flux'])
 			np.testing.assert_array_equal(a['flux_err'][i], ref['flux_err'])
 			np.testing.assert_array_equal(a['flux_background'][i], ref['flux_background'])
+		# ... and the chain closed: nothing of the device enters the oracle's side
+		verdicts.append(own_chain_check(a['sumimage'][i], host['images'], host['images_err'], host['backgrounds'], scene.quality, tuple(scene.stamps[i]),
+			scene.target_pos_row[i], scene.target_pos_column[i], scene.target_tmag[i], scene.target_starid[i], scene.catalog_of(int(i)), ap,
+			a['mask'][i], a['status'][i], a['flux'][i], a['flux_err'][i], a['flux_background'][i]))
+	print('own-sum-image chain:', verdicts.count('exact'), 'exact,', verdicts.count('razor'), 'razor of', len(verdicts))
+	assert verdicts.count('razor') <= 1
 	ctx.close()
 
 

@@ -168,10 +168,113 @@ def test_matrix_core_fit_takes_the_qualifying_targets(ctx):
 	# ordinary jitter: matrix cores only / vector ALUs only
 	assert 'tp_linpsf_fitm_kernel' in out[(1, 1)][1] and 'tp_linpsf_fit_kernel' not in out[(1, 1)][1]
 	assert 'tp_linpsf_fitm_kernel' not in out[(1, 0)][1] and 'tp_linpsf_fit_kernel' in out[(1, 0)][1]
-	# wide jitter: more than 3 x 3 knot intervals -> the plan leaves (most of) the targets to the vector-ALU kernels
+	# wide jitter: more than 3 x 3 knot intervals inside 16 cadences -> the plan leaves (most of) the targets to the vector-ALU kernels
 	assert 'tp_linpsf_fit_kernel' in out[(8, 1)][1] or 'tp_linpsf_fit_direct_kernel' in out[(8, 1)][1]
 	for jit in (1, 8):
 		a, b = out[(jit, 1)][0], out[(jit, 0)][0]
 		scale = np.nanmax(np.abs(a['flux']))
 		np.testing.assert_allclose(a['flux'], b['flux'], rtol=1e-9, atol=1e-10 * scale)
 		np.testing.assert_array_equal(a['status'], b['status'])
+
+
+def _oracle_linpsf(s, prf, i, pos_row_of, pos_col_of, T):
+	"""Oracle light curve of target i with per-star position series given by index into the catalogue of the target."""
+	from oracle import psf as opsf, linpsf as olin
+	cat = s.catalog_of(i)
+	ncat = len(cat['starid'])
+	positions = np.empty((T, ncat, 2))
+	positions[:, :, 0] = pos_row_of(i, cat)
+	positions[:, :, 1] = pos_col_of(i, cat)
+	p = opsf.PSF(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'], tuple(s.stamps[i]))
+	return olin.do_photometry(s.images[i], p, cat, s.target_starid[i], positions, tuple(s.stamps[i]),
+		s.target_pos_row[i], s.target_pos_column[i], s.aperture[i])
+
+
+@pytest.mark.parametrize("T,drift", [(200, 0.5), (1300, 0.8), (333, -0.9)])
+def test_drifting_stars_stay_on_the_matrix_cores(ctx, T, drift):
+	"""A pointing drift over the series (half a pixel and more = 4.5+ knot intervals of the PRF grid, linear in time, on top of
+	the jitter): the series is cut into segments, each with the spline of the intervals visited THEN, and every target is fitted
+	by the matrix-core kernel -- no vector-ALU fit launch -- within 1e-8 of the oracle and of the vector-ALU mapping."""
+	from photometry_amd import simulate, engine, psf as hpsf
+	from photometry_amd.device import DeviceCube
+	from oracle import psf as opsf
+	nt = 8 if T < 1000 else 3
+	s = simulate.make_scene(nt, T, 13, 13, seed=91, max_neighbours=2, neighbour_tmag_range=(9.0, 16.0))
+	ramp = np.linspace(0.0, 1.0, T)
+	s.jitter = s.jitter + np.stack((drift * ramp, -0.7 * drift * ramp), axis=1)     # (column, row) drift
+	simulate.fill_cubes(s, nan_fraction=0.003)
+	prf = opsf.synthetic_prf(seed=7)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	sel, star_offsets, target_index = hpsf.select_stars(s.catalog, s.cat_offsets, s.target_starid)
+	pos_row, pos_col = _positions(s, sel, T)
+	coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(model.weights(s.stamps)))
+	cube = DeviceCube.from_host(ctx, s.images)
+	res, counts, kernels = {}, {}, {}
+	for path in (1, 0):
+		engine.linpsf_set_path(ctx, path)
+		ctx.profile(True)
+		ctx.profile_reset()
+		try:
+			res[path] = engine.linpsf_fit(ctx, cube, coef, ctx.array(model.tx), ctx.array(model.ty), ctx.array(star_offsets), ctx.array(target_index),
+				ctx.array(pos_row), ctx.array(pos_col), int(np.diff(star_offsets).max())).to_host()
+			ctx.sync()
+			kernels[path] = set(ctx.profile_report())
+			counts[path] = engine.linpsf_last_counts(ctx)
+		finally:
+			ctx.profile(False)
+			engine.linpsf_set_path(ctx, 1)
+	c = counts[1]
+	assert c['matrix_core_targets'] == nt and c['vector_alu_polynomial_targets'] == 0 and c['vector_alu_general_targets'] == 0, c
+	assert c['matrix_core_segments'] > nt, c                        # the drift needs more than one spline per star
+	assert 'tp_linpsf_fitm_kernel' in kernels[1] and 'tp_linpsf_fit_kernel' not in kernels[1] and 'tp_linpsf_fit_direct_kernel' not in kernels[1]
+	assert counts[0]['matrix_core_targets'] == 0
+	scale = np.nanmax(np.abs(res[1]['flux']))
+	np.testing.assert_allclose(res[1]['flux'], res[0]['flux'], rtol=1e-9, atol=1e-10 * scale)
+	np.testing.assert_array_equal(res[1]['status'], res[0]['status'])
+	np.testing.assert_allclose(res[1]['contamination'], res[0]['contamination'], rtol=1e-7, atol=1e-11)
+	for i in range(min(nt, 3)):
+		ref = _oracle_linpsf(s, prf, i, lambda i, cat: cat['row_stamp'][None, :] + s.jitter[:, 1][:, None],
+			lambda i, cat: cat['column_stamp'][None, :] + s.jitter[:, 0][:, None], T)
+		sc = np.nanmax(np.abs(ref['flux']))
+		np.testing.assert_allclose(res[1]['flux'][i], ref['flux'], rtol=1e-8, atol=1e-9 * sc)
+		assert int(res[1]['status'][i]) == ref['status']
+		np.testing.assert_allclose(res[1]['contamination'][i], ref['contamination'], rtol=1e-7, atol=1e-11)
+
+
+@pytest.mark.parametrize("path", [0, 1])
+def test_target_without_a_fitted_star(ctx, path):
+	"""A target whose own catalogue entry has a NaN magnitude loses it in the star selection (linpsf_photometry.py:93-101) and is
+	left with no fitted star: its flux is all NaN and the plugin's status ERROR ('All target flux values are NaN'), and the
+	targets beside it are fitted exactly as without it (round 3's plan kernel wrote such a target's list entry before the lists)."""
+	from photometry_amd import simulate, engine, psf as hpsf
+	from photometry_amd.device import DeviceCube
+	from oracle import psf as opsf
+	T = 48
+	s = simulate.make_scene(5, T, 11, 11, seed=23, max_neighbours=0)
+	simulate.fill_cubes(s, nan_fraction=0.002)
+	prf = opsf.synthetic_prf(seed=7)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	sel, star_offsets, target_index = hpsf.select_stars(s.catalog, s.cat_offsets, s.target_starid)
+	pos_row, pos_col = _positions(s, sel, T)
+	coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(model.weights(s.stamps)))
+	cube = DeviceCube.from_host(ctx, s.images)
+
+	def fit(offsets, pr, pc, tidx):
+		engine.linpsf_set_path(ctx, path)
+		try:
+			return engine.linpsf_fit(ctx, cube, coef, ctx.array(model.tx), ctx.array(model.ty), ctx.array(offsets), ctx.array(tidx),
+				ctx.array(np.ascontiguousarray(pr)), ctx.array(np.ascontiguousarray(pc)), 1).to_host()
+		finally:
+			engine.linpsf_set_path(ctx, 1)
+	full = fit(star_offsets, pos_row, pos_col, target_index)
+	assert np.all(np.diff(star_offsets) == 1)
+	# drop the star of target 2: offsets 0 1 2 2 3 4
+	keep = np.ones(len(pos_row), dtype=bool)
+	keep[star_offsets[2]] = False
+	offs = np.concatenate(([0], np.cumsum(np.diff(star_offsets) - (np.arange(5) == 2)))).astype('int64')
+	got = fit(offs, pos_row[keep], pos_col[keep], target_index)
+	assert int(got['status'][2]) == 2 and np.all(np.isnan(got['flux'][2][:T]))          # STATUS.ERROR
+	for i in (0, 1, 3, 4):
+		np.testing.assert_array_equal(got['flux'][i][:T], full['flux'][i][:T])
+		assert int(got['status'][i]) == int(full['status'][i])
+		np.testing.assert_array_equal(got['contamination'][i], full['contamination'][i])
