@@ -108,8 +108,22 @@ def leg_linpsf_drift(ctx, scene, model, prf, work, args, Nt, T, H, W, np, engine
 	ms = (time.perf_counter() - t0) / n * 1e3
 	ctx.profile(False)
 	kernels = {name: {'launches': c, 'ms_per_step': t / n} for name, (c, t) in ctx.profile_report().items()}
+	# the same scene on the vector-ALU kernels (where round 3 sent every target whose stars leave their three knot intervals)
+	engine.linpsf_set_path(ctx, 0)
+	try:
+		pipeline.linpsf_step(ctx, batch)
+		ctx.sync()
+		t1 = time.perf_counter()
+		for _ in range(2):
+			pipeline.linpsf_step(ctx, batch)
+		ctx.sync()
+		ms_valu = (time.perf_counter() - t1) / 2 * 1e3
+	finally:
+		engine.linpsf_set_path(ctx, 1)
+	pipeline.linpsf_step(ctx, batch)   # (the results compared below are the matrix-core ones)
+	ctx.sync()
 	out = {'what': 'linear drift of 0.5 px (column) and -0.35 px (row) over the series added to every star\'s positions (and to the synthetic cube), jitter as before',
-		'value': Nt / (ms * 1e-3), 'unit': 'targets/s', 'ms_per_step': ms, 'ratio_to_no_drift': ms / ms_no_drift, 'targets_by_path': engine.linpsf_last_counts(ctx), 'kernels': kernels}
+		'value': Nt / (ms * 1e-3), 'unit': 'targets/s', 'ms_per_step': ms, 'ratio_to_no_drift': ms / ms_no_drift, 'ms_per_step_on_the_vector_alu_kernels': ms_valu, 'targets_by_path': engine.linpsf_last_counts(ctx), 'kernels': kernels}
 	if args.cpu_sample > 0:
 		from oracle import linpsf as olin, psf as opsf
 		ns, tsub = 2, min(T, 60)
