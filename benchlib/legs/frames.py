@@ -31,7 +31,9 @@ def leg_frames(ctx, args, T, np, pipeline):
 	stack = pipeline.FrameStack(ctx, frames, 0, 44)
 	del frames
 	ctx.sync()
-	tessphot_frames(ctx, stack, {k: v[:128] for k, v in targets.items()}, cat, tstamp, quality)
+	# the steady state of a scheduler that calls the entry CCD after CCD: the page-locked result buffers and the device blocks of
+	# the first call are in the context's pools when the timed one runs
+	tessphot_frames(ctx, stack, targets, cat, tstamp, quality)
 	t0 = time.perf_counter()
 	out = tessphot_frames(ctx, stack, targets, cat, tstamp, quality)
 	good = int(np.sum((out.status == 1) | (out.status == 3)))

@@ -25,7 +25,7 @@ def shard_sizes(n_items, world):
 	return [shard_range(n_items, world, r)[1] - shard_range(n_items, world, r)[0] for r in range(world)]
 
 
-def packed_block_layout(n_targets, n_cad, height, width, psf=False, align=256, n_cat=0):
+def packed_block_layout(n_targets, n_cad, height, width, psf=False, align=256, n_cat=0, extras=False):
 	"""
 	Layout of the per-step output block of a rank: ONE allocation, so that the gather is one
 	message per rank.  Returns ``(layout, nbytes)`` with ``layout[name] = (offset, shape, dtype)``:
@@ -36,7 +36,8 @@ def packed_block_layout(n_targets, n_cad, height, width, psf=False, align=256, n
 	  linpsf_photometry.py:168), ``psf_contamination`` float64 (PSF_CONT, :203-211), ``psf_status`` int32;
 	* with ``n_cat`` > 0: ``cat_in_mask`` uint8 ``(n_cat,)``, one flag per row of the rank's (ragged) catalogue: the star lies
 	  in the target's mask -- what the master's skip-target bookkeeping needs (photometry.py:269-272).  ``n_cat`` is a capacity
-	  like ``n_targets``: the same on every rank.
+	  like ``n_targets``: the same on every rank;
+	* with ``extras``: ``sumimage`` float64 ``(Nt, H, W)`` and ``diagnostics`` float64 ``(Nt, 10)`` (``engine.DIAGNOSTICS_COLUMNS``).
 	"""
 	Nt, T, H, W = int(n_targets), int(n_cad), int(height), int(width)
 	fields = [('lc', (5, Nt, T), 'float64'), ('contamination', (Nt,), 'float64'), ('status', (Nt,), 'int32'), ('flags', (Nt,), 'int32'),
@@ -45,6 +46,8 @@ def packed_block_layout(n_targets, n_cad, height, width, psf=False, align=256, n
 		fields += [('psf_flux', (Nt, T), 'float64'), ('psf_contamination', (Nt,), 'float64'), ('psf_status', (Nt,), 'int32')]
 	if n_cat:
 		fields += [('cat_in_mask', (int(n_cat),), 'uint8')]
+	if extras:   # what the batched drop-in entry returns besides: the sum image and the light-curve diagnostics (one download per group)
+		fields += [('sumimage', (Nt, H, W), 'float64'), ('diagnostics', (Nt, 10), 'float64')]
 	layout, off = {}, 0
 	for name, shape, dtype in fields:
 		layout[name] = (off, shape, dtype)

@@ -156,9 +156,11 @@ int tp_device_info(tp_ctx* ctx, char* name, int name_len, int32_t* n_cu, uint64_
 	return TP_OK;
 }
 
-// capacity classes of the allocation cache: 256-byte multiples up to 64 KiB, then steps of 1/8 of the power of two below
+// capacity classes of the allocation cache: powers of two from 4 KiB up to 64 KiB (the metadata blocks of a batched entry differ
+// by a few bytes from group to group: with finer classes every one of them went to the driver, and a hipMalloc that has to map a
+// new chunk takes milliseconds), then steps of 1/8 of the power of two below
 static size_t tp_alloc_class(size_t n) {
-	if (n <= 65536) return (n + 255) & ~(size_t)255;
+	if (n <= 65536) { size_t p = 4096; while (p < n) p *= 2; return p; }
 	size_t p = 65536;
 	while (p * 2 <= n) p *= 2;
 	const size_t step = p / 8;
@@ -203,20 +205,24 @@ int tp_malloc(tp_ctx* ctx, uint64_t nbytes, void** d_ptr) {
 	const size_t cap = tp_alloc_class((size_t)nbytes);
 	auto range = ctx->cache.equal_range(cap);
 	if (range.first != range.second) {
-		// a block whose freeing event has completed is idle for every stream; if none is, wait for the oldest (what was queued on
-		// the context's stream when it was freed: the wait the old hipFree paid at once, paid only when it is still due)
+		// a block whose freeing event has completed is idle for every stream.  If none is: a small block is cheaper to get from
+		// the driver than to wait for (tens of microseconds against the kernels still queued on the freed one); a large one waits
+		// for the oldest (what was queued on the context's stream when it was freed: the wait the old hipFree paid at once)
 		auto pick = range.first;
 		bool idle = false;
 		for (auto it = range.first; it != range.second; ++it)
 			if (!it->second.freed || hipEventQuery(it->second.freed) == hipSuccess) { pick = it; idle = true; break; }
 		(void)hipGetLastError();   // hipErrorNotReady of the queries
-		if (!idle) TP_HIP(ctx, hipEventSynchronize(pick->second.freed));
-		*d_ptr = pick->second.ptr;
-		if (pick->second.freed) ctx->pool.push_back(pick->second.freed);
-		ctx->cache.erase(pick);
-		ctx->cache_bytes -= cap;
-		ctx->live[*d_ptr] = cap;
-		return TP_OK;
+		constexpr size_t kWaitAbove = (size_t)16 << 20;
+		if (idle || cap >= kWaitAbove) {
+			if (!idle) TP_HIP(ctx, hipEventSynchronize(pick->second.freed));
+			*d_ptr = pick->second.ptr;
+			if (pick->second.freed) ctx->pool.push_back(pick->second.freed);
+			ctx->cache.erase(pick);
+			ctx->cache_bytes -= cap;
+			ctx->live[*d_ptr] = cap;
+			return TP_OK;
+		}
 	}
 	const hipError_t e = tp_device_alloc(ctx, d_ptr, cap);
 	if (e == hipErrorOutOfMemory) return ctx->fail(TP_ERR_NOMEM, "tp_malloc: out of device memory");

@@ -204,6 +204,10 @@ class Context(object):
 
 	def close(self):
 		if getattr(self, 'handle', None) is not None:
+			self.pinned_trim()
+			for c in self.__dict__.get('_side', []):
+				c.close()
+			self.__dict__['_side'] = []
 			self.lib.tp_ctx_destroy(self.handle)
 			self.handle = None
 
@@ -242,6 +246,38 @@ class Context(object):
 
 	def pinned(self, shape, dtype):
 		return PinnedArray(self, shape, dtype)
+
+	# Page-locked buffers for results that are handed to the caller where the DMA left them (no staging copy): locking pages costs
+	# milliseconds per 100 MB, so the buffers a result has released are kept for the next one (size classes of 1 MiB and
+	# powers of two above; `pinned_trim` gives them back).
+	def pinned_block(self, nbytes):
+		"""A :class:`PinnedArray` of at least ``nbytes`` bytes (uint8) from the context's pool."""
+		cap = 1 << 20
+		while cap < nbytes:
+			cap <<= 1
+		pool = self.__dict__.setdefault('_pinned_pool', {})
+		free = pool.get(cap)
+		if free:
+			return free.pop()
+		return PinnedArray(self, (cap,), 'uint8')
+
+	def pinned_release(self, block):
+		if block is None or block.ptr is None or self.handle is None:
+			return
+		self.__dict__.setdefault('_pinned_pool', {}).setdefault(block.nbytes, []).append(block)
+
+	def pinned_trim(self):
+		for free in self.__dict__.get('_pinned_pool', {}).values():
+			while free:
+				free.pop().free()
+
+	def side_contexts(self, n):
+		"""``n`` further contexts (= HIP streams) on this device, created once: independent passes of a batched entry (the groups
+		of stamp sizes of a round) run on them side by side."""
+		side = self.__dict__.setdefault('_side', [])
+		while len(side) < n:
+			side.append(Context(self.device, high_priority=False))
+		return side[:n]
 
 	def download_async(self, pinned, device_array, nbytes=None, host_offset=0):
 		"""Enqueue a device -> pinned-host copy on this context's stream (returns at once)."""

@@ -41,30 +41,65 @@ class ApertureBatch(object):
 		else:
 			self.images, self.images_err, self.backgrounds = cubes['images'], cubes.get('images_err'), cubes.get('backgrounds')
 		self.time_smooth = {1800: 3, 600: 9}.get(int(round(getattr(scene, 'cadence_s', 1800))), 3) # prepare.py:258
-		q = np.asarray(scene.quality, dtype='int32')
-		self.quality = ctx.array(q)
-		self.time = ctx.array(np.asarray(scene.time, dtype='float64'))
-		self.stamps = ctx.array(np.asarray(scene.stamps, dtype='int32'))
 		self.n_targets = self.images.n_targets
 		self.n_cad = self.images.n_cad
 		self.height, self.width = self.images.height, self.images.width
-		# catalog (ragged) and target metadata for the mask kernel
+		# the per-batch metadata -- quality flags, time stamps, stamps, the ragged catalogue and the target columns -- travel as ONE
+		# host block and one upload (a batched entry builds a batch per stamp-size group and round: fifteen small uploads each were
+		# a fifth of its time); the arrays below are views into that block
 		c = scene.catalog
-		self.cat_offsets = ctx.array(np.asarray(scene.cat_offsets, dtype='int64'))
-		self.cat_starid = ctx.array(np.asarray(c['starid'], dtype='int64'))
-		self.cat_tmag = ctx.array(np.asarray(c['tmag'], dtype='float32'))
-		self.cat_row = ctx.array(np.asarray(c['row'], dtype='float32'))
-		self.cat_column = ctx.array(np.asarray(c['column'], dtype='float32'))
-		self.cat_row_stamp = ctx.array(np.asarray(c['row_stamp'], dtype='float32'))
-		self.cat_column_stamp = ctx.array(np.asarray(c['column_stamp'], dtype='float32'))
-		self.target_pos_row = ctx.array(np.asarray(scene.target_pos_row, dtype='float64'))
-		self.target_pos_column = ctx.array(np.asarray(scene.target_pos_column, dtype='float64'))
-		self.target_tmag = ctx.array(np.asarray(scene.target_tmag, dtype='float64'))
-		self.target_starid = ctx.array(np.asarray(scene.target_starid, dtype='int64'))
+		fields = [('quality', np.asarray(scene.quality, dtype='int32')), ('time', np.asarray(scene.time, dtype='float64')),
+			('stamps', np.asarray(scene.stamps, dtype='int32')), ('cat_offsets', np.asarray(scene.cat_offsets, dtype='int64')),
+			('cat_starid', np.asarray(c['starid'], dtype='int64')), ('cat_tmag', np.asarray(c['tmag'], dtype='float32')),
+			('cat_row', np.asarray(c['row'], dtype='float32')), ('cat_column', np.asarray(c['column'], dtype='float32')),
+			('cat_row_stamp', np.asarray(c['row_stamp'], dtype='float32')), ('cat_column_stamp', np.asarray(c['column_stamp'], dtype='float32')),
+			('target_pos_row', np.asarray(scene.target_pos_row, dtype='float64')), ('target_pos_column', np.asarray(scene.target_pos_column, dtype='float64')),
+			('target_tmag', np.asarray(scene.target_tmag, dtype='float64')), ('target_starid', np.asarray(scene.target_starid, dtype='int64'))]
+		offs, total = [], 0
+		for _name, a in fields:
+			offs.append(total)
+			total = -(-(total + max(a.nbytes, 16)) // 256) * 256
+		total = -(-total // 4) * 4
+		if total <= (256 << 10):
+			# small blocks: the library's ring of page-locked memory (tp_memcpy_h2d returns once the copy is queued)
+			blob = np.zeros(total, dtype='uint8')
+			for (_name, a), o in zip(fields, offs):
+				blob[o:o + a.nbytes] = np.ascontiguousarray(a).view('uint8').ravel()
+			self._meta = ctx.array(blob)
+		else:
+			# (page-locked, from the context's pool: the copy is queued and the host goes on -- a pageable block above 256 KB would wait for its DMA)
+			self._meta_host = ctx.pinned_block(total)
+			blob = self._meta_host.array
+			for (_name, a), o in zip(fields, offs):
+				blob[o:o + a.nbytes] = np.ascontiguousarray(a).view('uint8').ravel()
+			self._meta = ctx.empty((total,), 'uint8')
+			ctx._check(ctx.lib.tp_upload_cube_async(ctx.handle, self._meta.ptr, total // 4, self._meta_host.ptr, total // 4, 1, total // 4))
+		for (name, a), o in zip(fields, offs):
+			setattr(self, name, device_view(ctx, self._meta.ptr + o, a.shape, a.dtype, base=self._meta))
 		ap = getattr(scene, 'aperture', None)
 		if ap is None:
-			ap = np.ones((self.n_targets, self.height, self.width), dtype='int32')
-		self.aperture = ctx.array(np.asarray(ap, dtype='int32'))
+			# every pixel collected (bit 1 of BasePhotometry.aperture, BasePhotometry.py:1043; the kernels require a finite sum-image
+			# pixel themselves): set on the device, 0x01010101 per pixel -- bit 1 is what the mask builder reads
+			self.aperture = ctx.empty((self.n_targets, self.height, self.width), 'int32')
+			self.aperture.fill_bytes(1)
+		else:
+			self.aperture = ctx.array(np.asarray(ap, dtype='int32'))
+
+	def release_host(self):
+		"""The page-locked block the metadata were uploaded from goes back to the context's pool (call after a synchronisation)."""
+		h = self.__dict__.pop('_meta_host', None)
+		if h is not None:
+			self.ctx.pinned_release(h)
+
+	def __del__(self):
+		# not returned to the pool here: the upload may still be in flight when the last reference goes; the block is freed instead
+		h = self.__dict__.pop('_meta_host', None)
+		if h is not None:
+			try:
+				self.ctx.sync()
+				self.ctx.pinned_release(h)
+			except Exception: # noqa: B902
+				pass
 
 	#: per-target arrays (sliced by :meth:`chunk`); the flat catalogue arrays are shared because the
 	#: CSR offsets are absolute
@@ -75,6 +110,7 @@ class ApertureBatch(object):
 		"""Non-owning view of the targets ``[start, start+count)`` (same HBM)."""
 		v = ApertureBatch.__new__(ApertureBatch)
 		v.__dict__.update(self.__dict__)
+		v.__dict__.pop('_meta_host', None)   # the view does not own the upload's host block
 		for name in self._PER_TARGET:
 			a = getattr(self, name)
 			setattr(v, name, None if a is None else a.slice0(start, count))
@@ -95,12 +131,12 @@ class ApertureWork(object):
 	(``self.block``, layout: ``comm.packed_block_layout``), so that the per-step gather of a multi-GPU run is a single message.
 	"""
 
-	def __init__(self, ctx, batch, packed=False, psf=False, capacity=None, cat_capacity=0):
+	def __init__(self, ctx, batch, packed=False, psf=False, capacity=None, cat_capacity=0, extras=False):
 		"""``capacity`` >= the batch's targets lays the packed block out for that many (the padded shard size every rank of a
 		sharded run sends); ``cat_capacity`` > 0 puts the catalogue flags ``cat_in_mask`` into the block as well."""
 		from . import comm as tpcomm
 		Nt, T, H, W = batch.n_targets, batch.n_cad, batch.height, batch.width
-		self.sumimage = ctx.empty((Nt, H, W), 'float64')
+		self.sumimage = self.diagnostics = None
 		self.block = None
 		self.psf_flux = self.psf_contamination = self.psf_status = None
 		n_cat = max(int(batch.scene.cat_offsets[-1]), 1)
@@ -109,7 +145,7 @@ class ApertureWork(object):
 			cap = Nt if capacity is None else int(capacity)
 			if cap < Nt or (cat_capacity and cat_capacity < n_cat):
 				raise ValueError('block capacity below the size of the batch')
-			layout, nbytes = tpcomm.packed_block_layout(cap, T, H, W, psf=psf, n_cat=int(cat_capacity))
+			layout, nbytes = tpcomm.packed_block_layout(cap, T, H, W, psf=psf, n_cat=int(cat_capacity), extras=extras)
 			Nt = cap
 			self.block = ctx.zeros((nbytes,), 'uint8')
 			b = self.block
@@ -120,6 +156,8 @@ class ApertureWork(object):
 				self.psf_flux, self.psf_contamination, self.psf_status = view('psf_flux'), view('psf_contamination'), view('psf_status')
 			if cat_capacity:
 				self.cat_in_mask = view('cat_in_mask')
+			if extras:   # (with a capacity above the batch the views cover the capacity: the kernels address the first Nt entries)
+				self.sumimage, self.diagnostics = view('sumimage'), view('diagnostics')
 			self.block_layout = layout
 			Nt = batch.n_targets
 		else:
@@ -131,7 +169,10 @@ class ApertureWork(object):
 		self.diag = ctx.zeros((Nt, 8), 'float64')
 		if self.cat_in_mask is None:
 			self.cat_in_mask = ctx.zeros((n_cat,), 'uint8')
-		self.diagnostics = ctx.zeros((Nt, 10), 'float64')
+		if self.sumimage is None:
+			self.sumimage = ctx.empty((Nt, H, W), 'float64')
+		if self.diagnostics is None:
+			self.diagnostics = ctx.zeros((Nt, 10), 'float64')
 		self.bkg_raw = self.bkg = None
 		if batch.raw_mode:
 			pitch = batch.images.t_pitch
@@ -304,9 +345,17 @@ class FrameStack(object):
 		self.n_cad, self.n_rows, self.n_cols = self.dev['images'].shape
 		self.limits = (self.row0, self.row0 + self.n_rows, self.col0, self.col0 + self.n_cols)
 
-	def cut(self, stamps_dev, height, width):
-		"""The three stamp cubes of a group of same-sized stamps (``tp_cut_stamps``)."""
-		return {k: engine.cut_stamps(self.ctx, self.dev[k], stamps_dev, height, width, self.row0, self.col0) for k in self.names}
+	def cut_lazy(self, ctx, stamps, height, width):
+		"""The cut cubes of a group on ``ctx``'s stream, the stamp list uploaded there too."""
+		d = ctx.array(np.asarray(stamps, dtype='int32'))
+		cubes = self.cut(d, height, width, ctx=ctx)
+		cubes['_stamps'] = d   # alive until the cut has run
+		return cubes
+
+	def cut(self, stamps_dev, height, width, ctx=None):
+		"""The three stamp cubes of a group of same-sized stamps (``tp_cut_stamps``), on ``ctx``'s stream (default: the stack's)."""
+		ctx = self.ctx if ctx is None else ctx
+		return {k: engine.cut_stamps(ctx, self.dev[k], stamps_dev, height, width, self.row0, self.col0) for k in self.names}
 
 
 class _Messages(object):
@@ -408,7 +457,21 @@ class FramesResult(object):
 		self.pos = np.zeros(n, dtype='int32')
 		self.errors = {}       # target -> list of "LEVEL: message" strings (targets without messages have no entry)
 		self.edge_flux = {}    # target -> flux on the stuck edges (haloswitch quick break)
-		self.groups = []       # per device pass: dict of host arrays
+		self.groups = []       # per device pass: dict of host arrays (views of the page-locked block the pass was downloaded into)
+		self._pinned = []      # (context, block): returned to the context's pool when the result goes
+
+	def release(self):
+		"""Give the page-locked blocks behind the group arrays back to their context's pool (the arrays must not be used afterwards)."""
+		for ctx, blk in self._pinned:
+			ctx.pinned_release(blk)
+		self._pinned = []
+		self.groups = []
+
+	def __del__(self):
+		try:
+			self.release()
+		except Exception: # noqa: B902
+			pass
 
 	def __len__(self):
 		return self.n
@@ -445,8 +508,9 @@ class FramesResult(object):
 			a, b = grp['cat_offsets'][j], grp['cat_offsets'][j + 1]
 			inside = grp['cat_in_mask'][a:b].astype(bool)
 			lc = grp['lc']   # the light-curve block (5, m, T): flux, flux_err, flux_background, centroid column, centroid row
-			d.update(mask=grp['mask'][j].astype(bool), sumimage=grp['sumimage'][j], flux=lc[0][j], flux_err=lc[1][j],
-				flux_background=lc[2][j], pos_centroid=np.stack((lc[3][j], lc[4][j]), axis=-1),   # (T, 2): column then row (BasePhotometry.py:428)
+			# (copies: the group arrays live in page-locked memory that goes back to the context's pool with this result)
+			d.update(mask=grp['mask'][j].astype(bool), sumimage=np.array(grp['sumimage'][j]), flux=np.array(lc[0][j]), flux_err=np.array(lc[1][j]),
+				flux_background=np.array(lc[2][j]), pos_centroid=np.stack((lc[3][j], lc[4][j]), axis=-1),   # (T, 2): column then row (BasePhotometry.py:428)
 				contamination=float(grp['contamination'][j]),
 				skip_targets=[int(s) for s in grp['cat_starid'][a:b][inside] if s != grp['target_starid'][j]],
 				diagnostics=dict(zip(engine.DIAGNOSTICS_COLUMNS, grp['diagnostics'][j])))
@@ -506,55 +570,76 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 			out.errors[i] = out.errors.get(i, []) + log[i].items
 			log[i].items = []
 
+	events, pending = [], []
 	while len(active):
 		heights, widths = cur[active, 1] - cur[active, 0], cur[active, 3] - cur[active, 2]
 		keys = heights * 100000 + widths
 		still = []
-		# ---- the device passes of all groups of this round are queued first (the host prepares group i + 1 while the device
-		# works on group i), then their results are read and decided group by group
+		# ---- the device passes of all groups of this round are queued first, round-robin on a few streams (a group of a few large
+		# stamps is a latency-bound pass of ~1 ms that hides under the pass of the 15 x 15 group), each pass ending with ONE
+		# download of its packed output block into page-locked memory; then the results are decided group by group
 		launched = []
-		for key in np.unique(keys):
+		streams = [ctx] + ctx.side_contexts(2)
+		for gi, key in enumerate(np.unique(keys)):
 			idx = active[keys == key]
 			H, W = int(key // 100000), int(key % 100000)
-			cat_offsets, cat_arrays = _catalogs_of_stamps(cat_index, cur[idx])
-			scene = _GroupScene(stack, time, quality, cadence_s, cur[idx], cat_offsets, cat_arrays, targets, idx)
-			cubes = None
+			g = streams[gi % len(streams)] if len(idx) < 256 or gi == 0 else ctx
+			cubes = host = None
 			try:
 				if H * W > 65535:
 					raise TessphotError(1, f'a {H}x{W} stamp is beyond the 65 535 pixels of the mask builder')
-				cubes = stack.cut(ctx.array(scene.stamps), H, W)
-				batch = ApertureBatch(ctx, scene, cubes=cubes)
-				work = ApertureWork(ctx, batch)
-				aperture_step(ctx, batch, work)
-				aperture_diagnostics(ctx, batch, work)
-				launched.append((idx, H, W, scene, cat_offsets, cat_arrays, cubes, batch, work))
+				# the stamps are cut while the host selects the catalogue stars of the group
+				cut = stack.cut_lazy(g, cur[idx], H, W)
+				cubes = {k: cut[k] for k in stack.names}
+				cat_offsets, cat_arrays = _catalogs_of_stamps(cat_index, cur[idx])
+				scene = _GroupScene(stack, time, quality, cadence_s, cur[idx], cat_offsets, cat_arrays, targets, idx)
+				batch = ApertureBatch(g, scene, cubes=cut)
+				work = ApertureWork(g, batch, packed=True, cat_capacity=max(int(cat_offsets[-1]), 1), extras=True)
+				aperture_step(g, batch, work)
+				aperture_diagnostics(g, batch, work)
+				host = g.pinned_block(work.block.nbytes)
+				# two copies: what the decisions of this round read (flags, masks, sum images ...: everything behind the light curves in
+				# the block) first, with an event; the light curves (97 % of the bytes) travel while the next round is decided and queued
+				lc_bytes = work.block_layout['contamination'][0]
+				g.download_async(host, device_view(g, work.block.ptr + lc_bytes, (work.block.nbytes - lc_bytes,), 'uint8'), host_offset=lc_bytes)
+				ev = events.pop() if events else g.event()
+				g.record(ev)
+				g.download_async(host, device_view(g, work.block.ptr, (lc_bytes,), 'uint8'))
+				launched.append((g, idx, H, W, scene, cat_offsets, cat_arrays, cubes, batch, work, host, ev))
 			except TessphotError as e:
 				# e.g. a stamp beyond 65 535 pixels (the mask builder's 16-bit labels): Halo territory upstream
 				try:
-					ctx.sync()
+					g.sync()
 				except TessphotError:
 					pass
 				if cubes is not None:
 					for c in cubes.values():
 						c.free()
+				if host is not None:
+					g.pinned_release(host)
 				for i in idx:
 					logger_of(int(i)).error('Device pass failed for a %dx%d stamp: %s', H, W, str(e))
 					finish(int(i), 2)
 		failed = None
-		try:
-			ctx.sync()
-		except TessphotError as e:   # a device error surfaces at the synchronisation: every group of the round is lost
-			failed = e
-		for (idx, H, W, scene, cat_offsets, cat_arrays, cubes, batch, work) in launched:
+		from . import comm as tpcomm
+		for (g, idx, H, W, scene, cat_offsets, cat_arrays, cubes, batch, work, host, ev) in launched:
+			try:
+				g.event_sync(ev)      # the small part of the group's block is on the host (its light curves may still be on their way)
+			except TessphotError as e:   # a device error surfaces here: every group of the round is lost
+				failed = e
+			events.append(ev)
 			for c in cubes.values():
 				c.free()
+			pending.append((g, batch, work))   # alive until the light curves have arrived
 			if failed is not None:
+				g.pinned_release(host)
 				for i in idx:
 					logger_of(int(i)).error('Device pass failed for a %dx%d stamp: %s', H, W, str(failed))
 					finish(int(i), 2)
 				continue
-			res = {k: getattr(work, k).to_host() for k in ('sumimage', 'mask', 'status', 'flags', 'contamination', 'cat_in_mask', 'diagnostics')}
-			grp = dict(res, lc=work.lc.block.to_host(), cat_offsets=cat_offsets, cat_starid=cat_arrays['starid'], target_starid=scene.target_starid)
+			res = tpcomm.unpack_block(host.array[:work.block.nbytes], work.block_layout)
+			out._pinned.append((g, host))
+			grp = dict(res, cat_offsets=cat_offsets, cat_starid=cat_arrays['starid'], target_starid=scene.target_starid)
 			gid = len(out.groups)
 			out.groups.append(grp)
 			attempts_left[idx] -= 1
@@ -609,6 +694,17 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 				out.group[i], out.pos[i] = gid, j
 				finish(i, int(res['status'][j]))
 		active = np.asarray(sorted(still), dtype='int64')
+	# the light curves of every round have arrived
+	for g in [ctx] + ctx.side_contexts(2):
+		try:
+			g.sync()
+		except TessphotError as e:   # a copy of light curves failed: nothing that was extracted can be trusted
+			for i in np.flatnonzero(out.has_result):
+				out.has_result[i] = False
+				out.errors[int(i)] = out.errors.get(int(i), []) + ['ERROR: Device pass failed while the light curves were copied: ' + str(e)]
+				out.status[i] = 2
+	for g, batch, _work in pending:
+		batch.release_host()
 	return out
 
 
