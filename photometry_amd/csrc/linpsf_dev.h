@@ -91,6 +91,48 @@ __device__ __forceinline__ bool axis_phase(const double* kn, int n, double pos, 
 }
 
 
+// columns b0 .. b0 + NB - 1 of the same 25 coefficients with ONE pass over the patch (poly_column reads the 169 table values once per
+// column: five passes for a full set; the non-linear PSF kernel rebuilds its cached sets from the table in L2 and was bound by
+// exactly that traffic).  Same sums in the same order as poly_column.
+template <int NB>
+__device__ __forceinline__ void poly_columns(const double* __restrict__ C, int n, int ax, int by, int b0, double h2, double (&out)[NB][5])
+{
+	double kk[NB][5];
+#pragma unroll
+	for (int b = 0; b < NB; ++b)
+#pragma unroll
+		for (int e = 0; e < 5; ++e) kk[b][e] = 0.0;
+	const double* c0 = C + (int64_t)ax * n + by;
+#pragma unroll 1
+	for (int p0 = 0; p0 < 13; p0 += 4) {
+		double rv[4][13];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int pp = (p0 + u < 13) ? (p0 + u) : 12;
+			const double* r = c0 + pp * n;
+#pragma unroll
+			for (int q = 0; q < 13; ++q) rv[u][q] = r[q];
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			if (p0 + u < 13) {
+#pragma unroll
+				for (int b = 0; b < NB; ++b) {
+					double t = 0.0;
+#pragma unroll
+					for (int q = 0; q < 13; ++q) t = __builtin_fma(kEdgePoly[q][b0 + b], rv[u][q], t);
+#pragma unroll
+					for (int e = 0; e < 5; ++e) kk[b][e] = __builtin_fma(kEdgePoly[p0 + u][e], t, kk[b][e]);
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int b = 0; b < NB; ++b)
+#pragma unroll
+		for (int e = 0; e < 5; ++e) out[b][e] = h2 * kk[b][e];
+}
+
 // the 25 coefficients K[e][b] (e: power of phi_x, b: power of phi_y), scaled by h2, of the patch C[ax .. ax+12][by .. by+12];
 // one call computes column b (the sums run over q inside, over p outside: the order of tp_linpsf_coef_kernel)
 __device__ __forceinline__ void poly_column(const double* __restrict__ C, int n, int ax, int by, int bcol, double h2, double (&out)[5])

@@ -18,6 +18,16 @@
 // Late in a fit the simplex is far smaller than a knot interval (1/9 pixel) and nothing is rebuilt: 24 FMAs and 25 LDS reads
 // per star and pixel instead of the 169 table reads + ~230 flops of the direct contraction (round 2's first version, which
 // was LDS-bandwidth bound with the 110 KB table resident).
+// Round 4, measured (tools/psf_time.py, 4 096 targets x 50 cadences, 31-32 ns per simplex iteration chip-wide before and after):
+//  * ONE WAVEFRONT per target (no barrier at all, reductions by xor shuffles, the bookkeeping 64 pairs at a time) was built and
+//    dropped: 181 ns against 94 at 512 targets -- what was spread over 256 threads (the pixels of an evaluation, the 218 work
+//    items of a rebuild) takes four times as long per target, and the LDS of the cached sets lets a CU hold three such targets,
+//    not the eight the wavefronts would allow;
+//  * 11.6 % of the star evaluations miss their cached sets (0.33 rebuilds per simplex iteration: a simplex that straddles a knot
+//    in both axes alternates between four interval pairs); without rebuilds an iteration takes 21 ns: a third of the time is
+//    the four dependent rounds of table reads of a rebuild (the tables of the targets in flight, 110 KB each, do not fit L2);
+//  * three workgroups per CU instead of two (the compact item set, the float32 image) and 2.5 x fewer table reads per rebuild
+//    (poly_columns) change nothing: neither occupancy nor L2 traffic bounds it, the latency of a workgroup's own chain does.
 // The simplex search is scipy 1.7.3's `_minimize_neldermead` step for step (non-adaptive coefficients 1, 2, 0.5, 0.5; initial
 // simplex 5 % / 0.00025; termination xatol = fatol = 1e-4; `success` = finished before maxiter; stable ordering of ties).
 #include "common.h"
@@ -47,7 +57,14 @@ struct PsfArgs {
 
 constexpr int kHalfBox = 5;                      // pixels inside the cut-off (<= 5.25) lie within +-5 of the pixel nearest to the star
 constexpr int kBox = 2 * kHalfBox + 1;
-constexpr int kItems = kBox * kBox;              // cached (pixel offset) items per star, 25 coefficients each
+// The cached (pixel offset) items of a star, 25 coefficients each: of the 11 x 11 box only the offsets (di, dj) that can be inside the
+// cut-off for SOME position of the star within half a pixel of the box centre -- (|di| - 1/2)+^2 + (|dj| - 1/2)+^2 < 5.25^2: rows
+// of 7, 9, 11 ... 11, 9, 7 offsets, 109 in all.  (Round 3 cached all 121: 24.2 KB a set; 21.8 KB now, and with the image and weight
+// map kept in float32 and the knots read from global memory a one- or two-star target needs 48 KB of LDS instead of 56: three
+// workgroups per CU instead of two.)
+__device__ constexpr int kRowHalf[kBox] = {3, 4, 5, 5, 5, 5, 5, 5, 5, 4, 3};
+__device__ constexpr int kRowStart[kBox] = {0, 7, 16, 27, 38, 49, 60, 71, 82, 93, 102};
+constexpr int kItems = 109;
 
 constexpr int kPool = 6;                         // most cached coefficient sets (24 KB each) a target gets; it uses psf_pool(ns) of them, pool / ns per star
 
@@ -63,7 +80,8 @@ struct StarW { double row, col, flux, phx, phy; int jstar, istar, ax0, by0, vali
 struct EvalCtx {
 	int ns, n, H, W, pool; double h, hy, cutoff;
 	const double* Cg;            // the target's coefficient table in HBM
-	const double* kn; const double* kny; const double* img; const double* wgt;
+	const double* kn; const double* kny;   // the knot vectors (global memory: read by the first threads only, cached)
+	const float* img; const float* wgt;    // float32 as psf_photometry.py:75-86 computes them
 	StarW* sw; double* Kc; double* red; int* keys;   // keys[kPool][2]: the knot intervals of every cached set
 };
 
@@ -103,16 +121,33 @@ __device__ void prepare_stars(const double* x, const EvalCtx& c)
 		if (!c.sw[s].rebuild) continue;   // uniform
 		const int kx = c.keys[2 * c.sw[s].slot], ky = c.keys[2 * c.sw[s].slot + 1];
 		double* K = c.Kc + (size_t)c.sw[s].slot * kItems * 25;
-		for (int w = tid; w < kItems * 5; w += kThreads) {
-			const int item = w / 5, bcol = w - item * 5;
-			const int di = item / kBox - kHalfBox, dj = item - (item / kBox) * kBox - kHalfBox;
+		// two threads per item: one contracts columns 0..2 of the 25 coefficients, the other columns 3..4, each with one pass over
+		// the item's 13 x 13 patch of the table (round 3: a thread per (item, column) = five passes per item; the table is read
+		// from L2 and those reads, ~0.7 MB per rebuild, were what the kernel waited for)
+		for (int w = tid; w < kItems * 2; w += kThreads) {
+			const int item = w >> 1, half = w & 1;
+			int r = 0;
+#pragma unroll
+			for (int q = 1; q < kBox; ++q) r += (item >= kRowStart[q]) ? 1 : 0;
+			const int di = r - kHalfBox, dj = (item - kRowStart[r]) - kRowHalf[r];
 			int ax = kx + 9 * dj, by = ky + 9 * di;
 			ax = ax < 0 ? 0 : (ax > c.n - 13 ? c.n - 13 : ax);
 			by = by < 0 ? 0 : (by > c.n - 13 ? c.n - 13 : by);
-			double col5[5];
-			poly_column(c.Cg, c.n, ax, by, bcol, h2, col5);
+			if (half == 0) {
+				double col[3][5];
+				poly_columns<3>(c.Cg, c.n, ax, by, 0, h2, col);
 #pragma unroll
-			for (int e = 0; e < 5; ++e) K[item * 25 + e * 5 + bcol] = col5[e];
+				for (int b = 0; b < 3; ++b)
+#pragma unroll
+					for (int e = 0; e < 5; ++e) K[item * 25 + e * 5 + b] = col[b][e];
+			} else {
+				double col[2][5];
+				poly_columns<2>(c.Cg, c.n, ax, by, 3, h2, col);
+#pragma unroll
+				for (int b = 0; b < 2; ++b)
+#pragma unroll
+					for (int e = 0; e < 5; ++e) K[item * 25 + e * 5 + 3 + b] = col[b][e];
+			}
 		}
 	}
 	__syncthreads();
@@ -126,10 +161,12 @@ __device__ __forceinline__ double model_pixel(int i, int j, const EvalCtx& c)
 		const StarW& st = c.sw[s];
 		if (!st.valid) continue;
 		const int di = i - st.istar, dj = j - st.jstar;
-		if (di < -kHalfBox || di > kHalfBox || dj < -kHalfBox || dj > kHalfBox) continue;
+		if (di < -kHalfBox || di > kHalfBox) continue;
+		const int half = kRowHalf[di + kHalfBox];
+		if (dj < -half || dj > half) continue;          // offsets outside the cached set are never inside the cut-off
 		const double dc = (double)j - st.col, dr = (double)i - st.row;
 		if (sqrt(dc * dc + dr * dr) < c.cutoff)     // psf.py:142 (a NaN position is never inside)
-			mdl += st.flux * poly_eval(c.Kc + ((size_t)st.slot * kItems + (di + kHalfBox) * kBox + (dj + kHalfBox)) * 25, st.phx, st.phy);
+			mdl += st.flux * poly_eval(c.Kc + ((size_t)st.slot * kItems + kRowStart[di + kHalfBox] + (dj + half)) * 25, st.phx, st.phy);
 	}
 	return mdl;
 }
@@ -142,8 +179,8 @@ __device__ double likelihood(const double* x, const EvalCtx& c)
 	double acc = 0.0;
 	for (int p = tid; p < c.H * c.W; p += kThreads) {
 		const int i = p / c.W, j = p - i * c.W;
-		const double r = c.img[p] - model_pixel(i, j, c);
-		const double term = c.wgt[p] * (r * r);
+		const double r = (double)c.img[p] - model_pixel(i, j, c);
+		const double term = (double)c.wgt[p] * (r * r);
 		if (term == term) acc += term;                  // nansum
 	}
 #pragma unroll
@@ -162,11 +199,7 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 	const int target = targets[blockIdx.x];
 	const int tid = threadIdx.x;
 	const int n = a.n, H = a.height, W = a.width, P = H * W;
-	double* kn = lds;
-	double* kny = kn + n + 4;
-	double* img = kny + n + 4;                // [P]
-	double* wgt = img + P;                    // [P]
-	double* sim = wgt + P;                    // [(D+1)][kMaxDim]
+	double* sim = lds;                        // [(D+1)][kMaxDim]
 	double* fsim = sim + (kMaxDim + 1) * kMaxDim;   // [D+1]
 	double* xt = fsim + (kMaxDim + 1);        // trial points: xbar, xr, xe / xc [3][kMaxDim]
 	double* x0 = xt + 3 * kMaxDim;            // warm start [kMaxDim]
@@ -174,7 +207,9 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 	double* Kc = red + 8;                     // [kPool][kItems][25] cached polynomial coefficients
 	StarW* sw = reinterpret_cast<StarW*>(Kc + (size_t)pool * kItems * 25);
 	int* keys = reinterpret_cast<int*>(sw + kMaxPsfStars);   // [pool][2]
-	for (int i = tid; i < n + 4; i += kThreads) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
+	float* img = reinterpret_cast<float*>(keys + 2 * kPool);  // [P]
+	float* wgt = img + P;                     // [P]
+	const double* kn = a.knots_x; const double* kny = a.knots_y;
 	if (tid < kMaxPsfStars) { sw[tid].rebuild = 0; sw[tid].valid = 0; sw[tid].slot = 0; sw[tid].next = 0; }
 	if (tid < 2 * pool) keys[tid] = -0x7fffffff;
 	const int64_t s0 = a.star_offsets[target];
@@ -207,8 +242,8 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 			if (var < 1e-9f) var = 1e-9f;
 			float w = 1.0f / var;
 			if (w < 1e-9f) w = 1e-9f;
-			img[p] = (double)im;
-			wgt[p] = (double)w;
+			img[p] = im;
+			wgt[p] = w;
 		}
 		__syncthreads();
 		// ---- Nelder-Mead (scipy _minimize_neldermead)
@@ -347,7 +382,7 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 			for (int p = tid; p < P; p += kThreads) {
 				if (!mini[p]) continue;
 				const int i = p / W, j = p - i * W;
-				const double r = img[p] - model_pixel(i, j, ec);
+				const double r = (double)img[p] - model_pixel(i, j, ec);
 				if (r == r) acc += r;
 			}
 #pragma unroll
@@ -392,9 +427,8 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
 	const size_t P = (size_t)desc->height * desc->width;
 	auto lds_bytes = [&](int pool) {
-		const size_t doubles = 2 * ((size_t)n_coef_axis + 4) + 2 * P + (kMaxDim + 1) * kMaxDim + (kMaxDim + 1)
-			+ 3 * kMaxDim + kMaxDim + 8 + (size_t)pool * kItems * 25;
-		return doubles * sizeof(double) + kMaxPsfStars * sizeof(StarW) + 2 * kPool * sizeof(int) + 16;
+		const size_t doubles = (kMaxDim + 1) * kMaxDim + (kMaxDim + 1) + 3 * kMaxDim + kMaxDim + 8 + (size_t)pool * kItems * 25;
+		return doubles * sizeof(double) + kMaxPsfStars * sizeof(StarW) + 2 * kPool * sizeof(int) + 2 * P * sizeof(float) + 16;
 	};
 	TP_REQUIRE(ctx, lds_bytes(kPool) <= 160 * 1024, "tp_psf_fit: stamp too large for the LDS-resident image and weight map");
 	// the targets by their number of fitted stars (one launch each, see psf_pool): the star offsets come to the host once
