@@ -1,6 +1,6 @@
 # -*- coding: utf-8 -*-
 import time
-from ..common import HBM_PEAK_GBS
+from ..common import HBM_PEAK_GBS, TRAFFIC_FILE, committed_traffic
 
 
 def tess_like_frames(np, n, R, C, seed):
@@ -26,6 +26,15 @@ def leg_fullframe(ctx, args, np):
 	d = ctx.array(f)
 	geo = prepare.RadialGeometry((R, C), 1, 1)
 	out = {'what': f'{nf} frames of {R} x {C} float32 resident in HBM'}
+	# HBM bytes per frame from the committed PMC passes (profiles/run_profile.sh runs this leg on a few frames): the mean over a kernel's
+	# dispatches divided by the frames of a dispatch; the mesh / zoom / radial kernels run once per round (3 in the TESS branch)
+	tj = committed_traffic('traffic_bytes_per_launch', (R, C) == (2048, 2048)) or {}
+	ff = committed_traffic('fullframe_frames', (R, C) == (2048, 2048)) or 0
+	per_frame = {k: v / ff for k, v in tj.items() if ff and k.startswith(('tp_bkg_mesh', 'tp_mesh_finish', 'tp_bkg_zoom', 'tp_radial', 'tp_median_filter', 'tp_block_median', 'tp_threshold'))}
+	def leg_traffic(names, rounds):
+		got = [per_frame[k] for k in per_frame if k.startswith(names)]
+		return rounds * sum(got) if got else None
+	src = (TRAFFIC_FILE + ' (committed rocprofv3 PMC passes of this leg on %d frames, per-kernel means; not measured in this run)' % ff) if per_frame else None
 	results = {}
 	for name, kw in (('plain', {}), ('tess', dict(geometry=geo))):
 		prepare.fit_background_frames(ctx, d, **kw).free()
@@ -48,7 +57,8 @@ def leg_fullframe(ctx, args, np):
 			'kernels_ms_per_frame': {k: ms / nf for k, (_, ms) in rep.items()},
 			'roofline': {'kernel': 'tp_bkg_mesh_kernel + tp_bkg_zoom_kernel' + (' + tp_radial_kernels' if name == 'tess' else ''), 'bound': 'hbm',
 				'achieved': nb / (kms / nf * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': nb / (kms / nf * 1e-3) / 1e9 / HBM_PEAK_GBS,
-				'bytes_per_frame': nb, 'bytes': 'R*C*4 per pass over the image (mesh statistics, ring modes) + the background written once', 'traffic': None}}
+				'bytes_per_frame': nb, 'bytes': 'R*C*4 per pass over the image (mesh statistics, ring modes) + the background written once',
+				'traffic': leg_traffic(('tp_bkg_mesh', 'tp_mesh_finish', 'tp_bkg_zoom') + (('tp_radial',) if name == 'tess' else ()), passes), 'traffic_unit': 'bytes per frame', 'traffic_source': src}}
 	# shenanigans: indicator (15 x 15 median filter of img - SumImage), its robust mean over time, thresholded flags
 	ns = min(nf, 25)
 	img = ctx.array(f[:ns])
@@ -69,7 +79,8 @@ def leg_fullframe(ctx, args, np):
 	out['shenanigans'] = {'frames': ns, 'wall_ms_per_frame': dt / ns * 1e3, 'kernel_ms_per_frame': kms / ns,
 		'kernels_ms_per_frame': {k: ms / ns for k, (_, ms) in rep.items()},
 		'roofline': {'kernel': 'tp_median_filter_kernel', 'bound': 'vector ALU (a 225-key sorting network per pixel), priced against HBM',
-			'achieved': nb / (kms / ns * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': nb / (kms / ns * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None}}
+			'achieved': nb / (kms / ns * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': nb / (kms / ns * 1e-3) / 1e9 / HBM_PEAK_GBS,
+			'traffic': leg_traffic(('tp_median_filter', 'tp_block_median', 'tp_threshold'), 1), 'traffic_unit': 'bytes per frame', 'traffic_source': src}}
 	if args.cpu_sample > 0:
 		from oracle import backgrounds as ob
 		t1 = time.perf_counter()

@@ -1,23 +1,26 @@
 #!/bin/bash
 # Profiles of the default bench (run on the GPU box through gpurun):
-#   bash profiles/run_profile.sh r2
+#   bash profiles/run_profile.sh r4
 # 1. rocprofv3 kernel trace + stats (per-kernel durations) of the default bench command
 # 2./3. PMC passes for the HBM traffic of every dispatch (FETCH_SIZE and WRITE_SIZE need separate passes; never together with a trace)
 # 4. a PMC pass with the raw L2 counters that calibrate FETCH_SIZE per kernel
-TAG=${1:-r3}
+TAG=${1:-r4}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 5 --warmup 2 --cpu-sample 0 --e2e-targets 0 --frames-targets 0 --frame 512 --psf-targets 0 --fullframe-frames 0"
-PMCARGS="--steps 2 --warmup 1 --cpu-sample 0 --e2e-targets 0 --frames-targets 0 --frame 512 --psf-targets 0 --fullframe-frames 0"
+# (the PMC passes include FF full frames of the full-frame background / pixel-flag leg, so that its kernels -- mesh, zoom, radial,
+# median filter -- get their traffic too; summarize.py divides by FF)
+FF=4
+PMCARGS="--steps 2 --warmup 1 --cpu-sample 0 --e2e-targets 0 --frames-targets 0 --frame 512 --psf-targets 0 --fullframe-frames $FF"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log
 # 4. what one read request carries: L2 misses, write requests and read requests of every dispatch (see profiles/summarize.py)
 rocprofv3 --pmc TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/pmc_lines -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_lines.json 2> $OUT/pmc_lines.log
 cd $REPO
-python3 profiles/summarize.py $OUT $OUT/traffic.json > $OUT/summary.txt 2>&1
+FULLFRAME_FRAMES=$FF python3 profiles/summarize.py $OUT $OUT/traffic.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # keep only small files in the merged output
 find $OUT -name "*.csv" -size +8M -delete

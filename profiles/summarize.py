@@ -85,7 +85,7 @@ for f in ('bench_trace.json',):
 		need[('step', 'tp_linpsf_fit')] = lp['necessary_bytes_per_step']
 
 print("== HBM traffic per launch (read bytes = 128 x (L2 misses - write requests), see the header) ==")
-traffic = {'traffic_bytes_per_launch': {}, 'traffic_bytes_per_launch_premade': {}, 'detail': {}}
+traffic = {'traffic_bytes_per_launch': {}, 'traffic_bytes_per_launch_premade': {}, 'detail': {}, 'fullframe_frames': int(os.environ.get('FULLFRAME_FRAMES', '0'))}
 linpsf_total = 0.0
 for k in sorted(means):
 	v = means[k]
@@ -93,7 +93,8 @@ for k in sorted(means):
 		continue
 	base = re.sub(r'<.*', '', k)
 	# the fused kernel: <.., HAS_SUB = true, BKG = 1> is the timed step (raw cubes), <.., false, 0> the premade-cube leg
-	leg = 'premade' if (base == 'tp_aperture_fused_kernel' and re.search(r'false,\s*0>', k)) else 'step'
+	# the fused kernel <VEC, VEC4, HAS_SUB, BKG, A1>: <.., true, 1, false> is the timed step (raw cubes, the sum image given), <.., false, 0, true> the premade-cube leg
+	leg = 'premade' if (base == 'tp_aperture_fused_kernel' and re.search(r'false,\s*0,\s*true>', k)) else 'step'
 	nb = need.get((leg, base))
 	d = {'fetch_size_bytes_as_reported': v['FETCH_SIZE'], 'write_size_bytes': v['WRITE_SIZE'], 'necessary_bytes': nb}
 	ln = {c: sum(x) / len(x) for c, x in lines.get(k, {}).items()}

@@ -218,7 +218,7 @@ def test_fit_background_tess_matches_oracle(ctx, T, R, C):
 			flipped += int(ok.sum() - exact.sum())
 		err = np.abs(b[k] - ref) / np.abs(ref)
 		worst = max(worst, float(err.max()))
-		assert err.max() < (2e-3 if flipped else 1e-5), (k, flipped, float(err.max()))
+		assert err.max() < (5e-4 if flipped else 1e-5), (k, flipped, float(err.max()))   # measured on 32 full frames (profiles/r4_tess_flip_stats.txt): 1.3e-4 at worst with a flipped ring
 		# the radial component matters here: without it the corner is off by far more than the tolerance
 		plain = ob.fit_background(f[k])[0]
 		assert np.max(np.abs(plain - ref) / ref) > 0.01
@@ -250,7 +250,7 @@ def test_fit_background_tess_full_frames(ctx):
 	flipped = sum(int(np.sum(np.abs(details['s2'][it][0] - inter['s2'][it]) >= 2e-5)) for it in range(3))
 	err = np.abs(b[0] - ref) / np.abs(ref)
 	print('literal oracle: rings off their grid point', flipped, 'max relative deviation', float(err.max()))
-	assert flipped <= 9 and err.max() < (2e-3 if flipped else 1e-5)
+	assert flipped <= 9 and err.max() < (5e-4 if flipped else 1e-5)
 
 
 def test_mesh_finish_and_ring_profiles_on_device(ctx):
