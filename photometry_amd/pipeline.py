@@ -7,6 +7,7 @@ i.e. ``AperturePhotometry.do_photometry`` (photometry/AperturePhotometry/photome
 for every target of the batch at once.
 """
 
+import os
 import numpy as np
 from . import engine
 from .device import DeviceCube, device_view, round_up
@@ -571,128 +572,148 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 			log[i].items = []
 
 	events, pending = [], []
+	if '_hbm_bytes' not in ctx.__dict__:
+		ctx.__dict__['_hbm_bytes'] = ctx.info()['hbm_bytes']
+	budget = float(os.environ.get('TESSPHOT_FRAMES_BUDGET_GB', 0)) * 1e9 or ctx.__dict__['_hbm_bytes'] / 4.0
 	while len(active):
 		heights, widths = cur[active, 1] - cur[active, 0], cur[active, 3] - cur[active, 2]
 		keys = heights * 100000 + widths
 		still = []
-		# ---- the device passes of all groups of this round are queued first, round-robin on a few streams (a group of a few large
-		# stamps is a latency-bound pass of ~1 ms that hides under the pass of the 15 x 15 group), each pass ending with ONE
-		# download of its packed output block into page-locked memory; then the results are decided group by group
-		launched = []
-		streams = [ctx] + ctx.side_contexts(2)
-		for gi, key in enumerate(np.unique(keys)):
-			idx = active[keys == key]
+		# the groups of this round (targets that share a stamp size), cut into parts whose cubes and output blocks fit a budget of
+		# device memory: a full CCD has tens of thousands of targets beside 65 GB of resident frame stacks, and an out-of-memory
+		# error would cost every target of the part its result (a quarter of the HBM by default, TESSPHOT_FRAMES_BUDGET_GB)
+		jobs = []
+		for key in np.unique(keys):
+			idx_all = active[keys == key]
 			H, W = int(key // 100000), int(key % 100000)
-			g = streams[gi % len(streams)] if len(idx) < 256 or gi == 0 else ctx
-			cubes = host = None
-			try:
-				if H * W > 65535:
-					raise TessphotError(1, f'a {H}x{W} stamp is beyond the 65 535 pixels of the mask builder')
-				# the stamps are cut while the host selects the catalogue stars of the group
-				cut = stack.cut_lazy(g, cur[idx], H, W)
-				cubes = {k: cut[k] for k in stack.names}
-				cat_offsets, cat_arrays = _catalogs_of_stamps(cat_index, cur[idx])
-				scene = _GroupScene(stack, time, quality, cadence_s, cur[idx], cat_offsets, cat_arrays, targets, idx)
-				batch = ApertureBatch(g, scene, cubes=cut)
-				work = ApertureWork(g, batch, packed=True, cat_capacity=max(int(cat_offsets[-1]), 1), extras=True)
-				aperture_step(g, batch, work)
-				aperture_diagnostics(g, batch, work)
-				host = g.pinned_block(work.block.nbytes)
-				# two copies: what the decisions of this round read (flags, masks, sum images ...: everything behind the light curves in
-				# the block) first, with an event; the light curves (97 % of the bytes) travel while the next round is decided and queued
-				lc_bytes = work.block_layout['contamination'][0]
-				g.download_async(host, device_view(g, work.block.ptr + lc_bytes, (work.block.nbytes - lc_bytes,), 'uint8'), host_offset=lc_bytes)
-				ev = events.pop() if events else g.event()
-				g.record(ev)
-				g.download_async(host, device_view(g, work.block.ptr, (lc_bytes,), 'uint8'))
-				launched.append((g, idx, H, W, scene, cat_offsets, cat_arrays, cubes, batch, work, host, ev))
-			except TessphotError as e:
-				# e.g. a stamp beyond 65 535 pixels (the mask builder's 16-bit labels): Halo territory upstream
+			per_target = 3 * H * W * round_up(stack.n_cad, 32) * 4 + 5 * stack.n_cad * 8 + H * W * 9 + 256
+			nmax = max(1, int(budget // per_target))
+			for a0 in range(0, len(idx_all), nmax):
+				jobs.append((idx_all[a0:a0 + nmax], H, W, per_target * len(idx_all[a0:a0 + nmax])))
+		parts, acc = [[]], 0
+		for idx_j, H, W, nbytes_j in jobs:
+			if parts[-1] and acc + nbytes_j > budget:
+				parts.append([])
+				acc = 0
+			parts[-1].append((idx_j, H, W))
+			acc += nbytes_j
+		for part in parts:
+			# ---- the device passes of all groups of this round are queued first, round-robin on a few streams (a group of a few large
+			# stamps is a latency-bound pass of ~1 ms that hides under the pass of the 15 x 15 group), each pass ending with ONE
+			# download of its packed output block into page-locked memory; then the results are decided group by group
+			launched = []
+			streams = [ctx] + ctx.side_contexts(2)
+			for gi, (idx, H, W) in enumerate(part):
+				g = streams[gi % len(streams)] if len(idx) < 256 or gi == 0 else ctx
+				cubes = host = None
 				try:
-					g.sync()
-				except TessphotError:
-					pass
-				if cubes is not None:
-					for c in cubes.values():
-						c.free()
-				if host is not None:
+					if H * W > 65535:
+						raise TessphotError(1, f'a {H}x{W} stamp is beyond the 65 535 pixels of the mask builder')
+					# the stamps are cut while the host selects the catalogue stars of the group
+					cut = stack.cut_lazy(g, cur[idx], H, W)
+					cubes = {k: cut[k] for k in stack.names}
+					cat_offsets, cat_arrays = _catalogs_of_stamps(cat_index, cur[idx])
+					scene = _GroupScene(stack, time, quality, cadence_s, cur[idx], cat_offsets, cat_arrays, targets, idx)
+					batch = ApertureBatch(g, scene, cubes=cut)
+					work = ApertureWork(g, batch, packed=True, cat_capacity=max(int(cat_offsets[-1]), 1), extras=True)
+					aperture_step(g, batch, work)
+					aperture_diagnostics(g, batch, work)
+					host = g.pinned_block(work.block.nbytes)
+					# two copies: what the decisions of this round read (flags, masks, sum images ...: everything behind the light curves in
+					# the block) first, with an event; the light curves (97 % of the bytes) travel while the next round is decided and queued
+					lc_bytes = work.block_layout['contamination'][0]
+					g.download_async(host, device_view(g, work.block.ptr + lc_bytes, (work.block.nbytes - lc_bytes,), 'uint8'), host_offset=lc_bytes)
+					ev = events.pop() if events else g.event()
+					g.record(ev)
+					g.download_async(host, device_view(g, work.block.ptr, (lc_bytes,), 'uint8'))
+					launched.append((g, idx, H, W, scene, cat_offsets, cat_arrays, cubes, batch, work, host, ev))
+				except TessphotError as e:
+					# e.g. a stamp beyond 65 535 pixels (the mask builder's 16-bit labels): Halo territory upstream
+					try:
+						g.sync()
+					except TessphotError:
+						pass
+					if cubes is not None:
+						for c in cubes.values():
+							c.free()
+					if host is not None:
+						g.pinned_release(host)
+					for i in idx:
+						logger_of(int(i)).error('Device pass failed for a %dx%d stamp: %s', H, W, str(e))
+						finish(int(i), 2)
+			failed = None
+			from . import comm as tpcomm
+			for (g, idx, H, W, scene, cat_offsets, cat_arrays, cubes, batch, work, host, ev) in launched:
+				try:
+					g.event_sync(ev)      # the small part of the group's block is on the host (its light curves may still be on their way)
+				except TessphotError as e:   # a device error surfaces here: every group of the round is lost
+					failed = e
+				events.append(ev)
+				for c in cubes.values():
+					c.free()
+				pending.append((g, batch, work))   # alive until the light curves have arrived
+				if failed is not None:
 					g.pinned_release(host)
-				for i in idx:
-					logger_of(int(i)).error('Device pass failed for a %dx%d stamp: %s', H, W, str(e))
-					finish(int(i), 2)
-		failed = None
-		from . import comm as tpcomm
-		for (g, idx, H, W, scene, cat_offsets, cat_arrays, cubes, batch, work, host, ev) in launched:
-			try:
-				g.event_sync(ev)      # the small part of the group's block is on the host (its light curves may still be on their way)
-			except TessphotError as e:   # a device error surfaces here: every group of the round is lost
-				failed = e
-			events.append(ev)
-			for c in cubes.values():
-				c.free()
-			pending.append((g, batch, work))   # alive until the light curves have arrived
-			if failed is not None:
-				g.pinned_release(host)
-				for i in idx:
-					logger_of(int(i)).error('Device pass failed for a %dx%d stamp: %s', H, W, str(failed))
-					finish(int(i), 2)
-				continue
-			res = tpcomm.unpack_block(host.array[:work.block.nbytes], work.block_layout)
-			out._pinned.append((g, host))
-			grp = dict(res, cat_offsets=cat_offsets, cat_starid=cat_arrays['starid'], target_starid=scene.target_starid)
-			gid = len(out.groups)
-			out.groups.append(grp)
-			attempts_left[idx] -= 1
-			flags = res['flags'].astype('int64')
-			kind = flags >> 8
-			# ---- the common case, for the whole group at once: nothing to log, no edge touched -> the attempt stands
-			simple = ((flags & (1 | 32 | edge_bits)) == 0) & (kind == 0)
-			done = idx[simple]
-			out.status[done] = res['status'][simple]
-			out.stamp[done] = cur[done]
-			out.has_result[done] = True
-			out.group[done] = gid
-			out.pos[done] = np.flatnonzero(simple)
-			# ---- the others, one by one with the plugin's rules
-			for j in np.flatnonzero(~simple):
-				i = int(idx[j])
-				fl = int(flags[j])
-				try:
-					if mask_outcome(fl, logger_of(i)) == 'error':
+					for i in idx:
+						logger_of(int(i)).error('Device pass failed for a %dx%d stamp: %s', H, W, str(failed))
+						finish(int(i), 2)
+					continue
+				res = tpcomm.unpack_block(host.array[:work.block.nbytes], work.block_layout)
+				out._pinned.append((g, host))
+				grp = dict(res, cat_offsets=cat_offsets, cat_starid=cat_arrays['starid'], target_starid=scene.target_starid)
+				gid = len(out.groups)
+				out.groups.append(grp)
+				attempts_left[idx] -= 1
+				flags = res['flags'].astype('int64')
+				kind = flags >> 8
+				# ---- the common case, for the whole group at once: nothing to log, no edge touched -> the attempt stands
+				simple = ((flags & (1 | 32 | edge_bits)) == 0) & (kind == 0)
+				done = idx[simple]
+				out.status[done] = res['status'][simple]
+				out.stamp[done] = cur[done]
+				out.has_result[done] = True
+				out.group[done] = gid
+				out.pos[done] = np.flatnonzero(simple)
+				# ---- the others, one by one with the plugin's rules
+				for j in np.flatnonzero(~simple):
+					i = int(idx[j])
+					fl = int(flags[j])
+					try:
+						if mask_outcome(fl, logger_of(i)) == 'error':
+							finish(i, 2)
+							continue
+					except RuntimeError as e: # an uncaught exception of the reference's plugin -> STATUS.ERROR (tessphot.py:37-49)
+						out.errors[i] = out.errors.get(i, []) + ['RuntimeError: ' + str(e)]
 						finish(i, 2)
 						continue
-				except RuntimeError as e: # an uncaught exception of the reference's plugin -> STATUS.ERROR (tessphot.py:37-49)
-					out.errors[i] = out.errors.get(i, []) + ['RuntimeError: ' + str(e)]
-					finish(i, 2)
-					continue
-				wanted = st.edge_requests(fl)
-				if wanted:
-					before = tuple(int(v) for v in cur[i])
-					new = st.moved(before, stack.limits, **wanted)
-					if new == before:
-						logger_of(i).warning("Could not resize stamp any further.")
-					else:
-						out.stamp_resizes[i] += 1
-						cur[i] = new
-						mask = res['mask'][j].astype(bool)
-						bright = tmags[i] <= tmag_limit and not datasource.startswith('tpf:')
-						stuck = st.quick_break_flux(res['sumimage'][j], mask, before, new, wanted) if bright else None
-						if stuck is not None and stuck > flux_limit * mag2flux(tmags[i]):
-							logger_of(i).error('Stamp resize hit limit. Haloswitch quick break.')
-							out.edge_flux[i] = stuck
-							finish(i, 2)
-						elif attempts_left[i] == 0:
-							logger_of(i).error('Too many stamp resizes.')
-							finish(i, 2)
+					wanted = st.edge_requests(fl)
+					if wanted:
+						before = tuple(int(v) for v in cur[i])
+						new = st.moved(before, stack.limits, **wanted)
+						if new == before:
+							logger_of(i).warning("Could not resize stamp any further.")
 						else:
-							still.append(i)
-						continue
-				# this attempt stands
-				if fl >> 8 == 6:
-					logger_of(i).error("No targets in mask.")
-				out.has_result[i] = True
-				out.group[i], out.pos[i] = gid, j
-				finish(i, int(res['status'][j]))
+							out.stamp_resizes[i] += 1
+							cur[i] = new
+							mask = res['mask'][j].astype(bool)
+							bright = tmags[i] <= tmag_limit and not datasource.startswith('tpf:')
+							stuck = st.quick_break_flux(res['sumimage'][j], mask, before, new, wanted) if bright else None
+							if stuck is not None and stuck > flux_limit * mag2flux(tmags[i]):
+								logger_of(i).error('Stamp resize hit limit. Haloswitch quick break.')
+								out.edge_flux[i] = stuck
+								finish(i, 2)
+							elif attempts_left[i] == 0:
+								logger_of(i).error('Too many stamp resizes.')
+								finish(i, 2)
+							else:
+								still.append(i)
+							continue
+					# this attempt stands
+					if fl >> 8 == 6:
+						logger_of(i).error("No targets in mask.")
+					out.has_result[i] = True
+					out.group[i], out.pos[i] = gid, j
+					finish(i, int(res['status'][j]))
 		active = np.asarray(sorted(still), dtype='int64')
 	# the light curves of every round have arrived
 	for g in [ctx] + ctx.side_contexts(2):

@@ -24,8 +24,9 @@ from .status import STATUS
 from . import engine, pipeline, stamps
 
 #: the values of the reference's photometry/data/settings.ini, used when no settings file is given
-DEFAULT_SETTINGS = {'todolist': {'faint_limit': '15.0'}, 'fixes': {'time_offset': 'True'},
-	'haloswitch': {'tmag_limit': '6.0', 'flux_limit': '0.01'}}
+# ([fixes] time_offset of the reference's file is not among them: the timestamp correction of the early data releases is the
+# input adapter's job here -- see the warning in BasePhotometry.__init__ -- and a switch that switches nothing would mislead)
+DEFAULT_SETTINGS = {'todolist': {'faint_limit': '15.0'}, 'haloswitch': {'tmag_limit': '6.0', 'flux_limit': '0.01'}}
 
 TESS_DEFAULT_BITMASK = engine.TESS_DEFAULT_BITMASK
 #: PixelQualityFlags.BackgroundShenanigans / CorrectorQualityFlags.BackgroundShenanigans (photometry/quality.py:163, :85)
@@ -175,8 +176,12 @@ class BasePhotometry(object):
 			pos_centroid=np.zeros((self.Ntimes, 2)), pos_corr=np.zeros((self.Ntimes, 2)))
 		if getattr(src, 'jitter', None) is not None:
 			self.lightcurve['pos_corr'] = np.array(src.jitter, dtype='float64')
-		# (the timestamp offset of the early data releases, fixes/time_offset.py upstream, belongs to the input adapter: a source
-		# hands over corrected times -- SURVEY.md section 2, item 20)
+		# The timestamp offset of the early data releases (fixes/time_offset.py upstream, applied at BasePhotometry.py:244 / :384 for
+		# sectors 1-21) belongs to the input adapter: a source hands over corrected times.  A source
+		# that passes a header with DATA_REL but does not say that it did so gets a WARNING in the details instead of silence.
+		if self.data_rel is not None and not (self.header.get('TIME_OFFSET_CORRECTED') or getattr(src, 'time_offset_corrected', False)):
+			logger.warning("Timestamps used as the source delivered them (DATA_REL = %s, no TIME_OFFSET_CORRECTED in its header): the "
+				"time-offset correction of the early data releases is the input adapter's job.", self.data_rel)
 
 		self.final_phot_mask = None
 		self.final_position_mask = None

@@ -176,3 +176,43 @@ def test_bright_star_large_stamp_three_way():
 					assert p._details[key] == b._details[key], key
 	assert batch[0].status in (STATUS.OK, STATUS.WARNING)
 	ctx.close()
+
+
+def test_aperture_frames_in_parts_under_a_memory_budget(monkeypatch):
+	"""A budget of device memory far below the batch cuts the groups of a round into parts (and a group into chunks of targets)
+	that are processed one after the other: same results as in one piece."""
+	from photometry_amd import pipeline, tessphot_frames
+	from photometry_amd.device import Context
+	rng = np.random.default_rng(12)
+	N, FR, T = 150, 128, 40
+	rows, cols, tmag = rng.uniform(12, FR - 12, N), rng.uniform(12, FR - 12, N), rng.uniform(8.0, 13.5, N)
+	img = np.zeros((FR, FR))
+	yy, xx = np.mgrid[-4:5, -4:5]
+	for r, c, m in zip(rows, cols, tmag):
+		ri, ci = int(round(r)), int(round(c))
+		img[ri - 4:ri + 5, ci - 4:ci + 5] += 10**(-0.4 * (m - 20.451)) * np.exp(-0.5 * ((yy + ri - r)**2 + (xx + ci - c)**2) / 0.81) / (2 * np.pi * 0.81)
+	base = (img[None] * (1 + 1e-3 * rng.normal(size=T))[:, None, None]).astype('float32')
+	noise = np.sqrt(np.abs(base) + 200.0).astype('float32')
+	frames = {'images': (base + 30.0 + rng.standard_normal(base.shape).astype('float32') * noise).astype('float32'), 'images_err': noise,
+		'backgrounds': np.full((T, FR, FR), 100.0, dtype='float32')}
+	tstamp = 1500.0 + np.arange(T) * 1800.0 / 86400.0
+	quality = np.zeros(T, dtype='int32')
+	cat = {'starid': np.arange(N, dtype='int64') + 1, 'tmag': tmag.astype('float32'), 'row': rows.astype('float32'), 'column': (cols + 44).astype('float32')}
+	targets = {'starid': cat['starid'].copy(), 'tmag': tmag, 'row': rows, 'column': cols + 44}
+	ctx = Context(0)
+	stack = pipeline.FrameStack(ctx, frames, 0, 44)
+	whole = tessphot_frames(ctx, stack, targets, cat, tstamp, quality)
+	monkeypatch.setenv('TESSPHOT_FRAMES_BUDGET_GB', '0.004')     # 4 MB: a dozen 15 x 15 x 40 targets per chunk
+	parts = tessphot_frames(ctx, stack, targets, cat, tstamp, quality)
+	assert len(parts.frames.groups) > len(whole.frames.groups) + 3
+	np.testing.assert_array_equal(parts.status, whole.status)
+	np.testing.assert_array_equal(parts.stamp, whole.stamp)
+	for name in ('mask_size', 'contamination', 'mean_flux', 'variance'):
+		np.testing.assert_array_equal(parts.column(name), whole.column(name))
+	for i in (0, 7, 77, N - 1):
+		a, b = whole[i], parts[i]
+		assert a.status == b.status
+		if a.lightcurve is not None:
+			np.testing.assert_array_equal(a.lightcurve['flux'], b.lightcurve['flux'])
+			np.testing.assert_array_equal(a.final_phot_mask, b.final_phot_mask)
+	ctx.close()
