@@ -65,6 +65,7 @@ def parse_args(argv=None):
 	p.add_argument('--frame', type=int, default=1024, help='side of the frame stack of the stamp-cutter stage (0 = skip)')
 	p.add_argument('--psf-targets', type=int, default=4096, help='targets of the non-linear PSF photometry leg (0 = skip)')
 	p.add_argument('--fullframe-frames', type=int, default=16, help='2048 x 2048 frames of the full-frame background / pixel-flag leg (0 = skip)')
+	p.add_argument('--linpsf-drift', type=int, default=1, help='1: the LinPSF leg also runs the scene with a pointing drift (0 = skip: the profiling passes, whose per-kernel means it would mix)')
 	p.add_argument('--frames-targets', type=int, default=2500, help='targets of the frames-to-results leg on a 512 x 512 stack (0 = skip)')
 	return p.parse_args(argv)
 

@@ -83,7 +83,8 @@ def leg_linpsf(ctx, scene, cubes, work, args, Nt, T, H, W, np, engine, pipeline)
 				'(tests/golden/time_reference.py): 3.77 ms/cadence against 4.68 -- the port takes 1.24 x the reference\'s time, i.e. the '
 				'reference itself would run about 1.24 x this rate'}
 		res['parity_sample'] = {'targets': ns, 'cadences': tsub, 'mismatches': int(bad), 'rtol': 1e-7}
-	res['drift'] = leg_linpsf_drift(ctx, scene, model, prf, work, args, Nt, T, H, W, np, engine, pipeline, ms)
+	if getattr(args, 'linpsf_drift', 1):
+		res['drift'] = leg_linpsf_drift(ctx, scene, model, prf, work, args, Nt, T, H, W, np, engine, pipeline, ms)
 	return res
 
 

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Derived PMC metrics of the default bench, one rocprofv3 pass per metric (run on the GPU box through gpurun):
-#   bash profiles/run_counters.sh r1
-TAG=${1:-r1}
+#   bash profiles/run_counters.sh r4
+TAG=${1:-r4}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/counters_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for M in MeanOccupancyPerCU VALUBusy SALUBusy LdsBankConflict MemUnitStalled VALUUtilization; do
-	rocprofv3 --pmc $M --output-format csv -d $OUT/$M -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --e2e-targets 0 --frames-targets 0 --frame 512 --psf-targets 0 --fullframe-frames 0 > $OUT/$M.json 2> $OUT/$M.log
+	rocprofv3 --pmc $M --output-format csv -d $OUT/$M -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --e2e-targets 0 --frames-targets 0 --frame 512 --psf-targets 0 --fullframe-frames 0 --linpsf-drift 0 > $OUT/$M.json 2> $OUT/$M.log
 done
 cd $REPO
 python3 - "$OUT" <<'PY' > $OUT/summary.txt 2>&1
