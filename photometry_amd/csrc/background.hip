@@ -180,8 +180,11 @@ __device__ __forceinline__ int rank_idx(int r) { return r + ((r >> 5) << 2); }
 // G: lanes per frame (8: 32 values per lane, 8 frames per wavefront; 4: 64 values per lane, 16 frames per wavefront).
 // JFULL: number of complete G-pixel rows (n_pix / G) when known at compile time (the pixel-count test is then only made for the
 // last rows), -1 = test every slot.
+// (the two halves of bkg_frame: the kernel that forms the sum image in the same pass does other work between them)
+struct FrameSums { int n; double s1, s2; };
+
 template <int G, int JFULL>
-__device__ __forceinline__ float bkg_frame(const BkgArgs& a, float (&v)[256 / G], float* fr, int g, int lane, bool active, bool* all_kept = nullptr)
+__device__ __forceinline__ FrameSums bkg_frame_sort(const BkgArgs& a, float (&v)[256 / G], int g)
 {
 	constexpr int R = 256 / G;             // values per lane
 	constexpr int NREAL = (JFULL >= 0 && JFULL + 1 < R) ? (JFULL + 1) : R;   // registers 0..NREAL-1 can hold a pixel (JFULL: the first lanes only)
@@ -205,7 +208,6 @@ __device__ __forceinline__ float bkg_frame(const BkgArgs& a, float (&v)[256 / G]
 	n = frame_sum<G>(n);
 	s1 = frame_sum<G>(s1);
 	s2 = frame_sum<G>(s2);
-	if (all_kept) *all_kept = (n == a.n_pix);   // no pixel masked: in particular every value is finite
 
 	// --- distributed sort of the 256 values of the frame: rank = R g + j
 	const float sel1 = (g & 1) ? inf : -inf, sel2 = (g & 2) ? inf : -inf, sel4 = (g & 4) ? inf : -inf;
@@ -221,7 +223,15 @@ __device__ __forceinline__ float bkg_frame(const BkgArgs& a, float (&v)[256 / G]
 		cross_stage<kDppXor1, false, R>(v, sel1);                //                  stride R against lane^1,
 		local_merge<R>(v);                                       //                  strides R/2..1
 	}
+	return FrameSums{n, s1, s2};
+}
 
+template <int G, int JFULL>
+__device__ __forceinline__ float bkg_frame_clip(const BkgArgs& a, float (&v)[256 / G], FrameSums fs, float* fr, int g, int lane, bool active)
+{
+	constexpr int R = 256 / G;
+	int n = fs.n;
+	double s1 = fs.s1, s2 = fs.s2;
 	// --- stage the sorted frame (only the ranks that can hold a pixel; ranks >= n are +inf sentinels nobody reads)
 #pragma unroll
 	for (int j = 0; j < R; j += 4)
@@ -308,6 +318,13 @@ __device__ __forceinline__ float bkg_frame(const BkgArgs& a, float (&v)[256 / G]
 }
 
 template <int G, int JFULL>
+__device__ __forceinline__ float bkg_frame(const BkgArgs& a, float (&v)[256 / G], float* fr, int g, int lane, bool active)
+{
+	const FrameSums fs = bkg_frame_sort<G, JFULL>(a, v, g);
+	return bkg_frame_clip<G, JFULL>(a, v, fs, fr, g, lane, active);
+}
+
+template <int G, int JFULL>
 __global__ __launch_bounds__(kFramesPerBlock * G) void tp_bkg_stamp_kernel(BkgArgs a, int frame_stride)
 {
 	constexpr int R = 256 / G;             // values per lane
@@ -344,7 +361,8 @@ __global__ __launch_bounds__(kFramesPerBlock * G) void tp_bkg_stamp_kernel(BkgAr
 //   One 256-thread workgroup per TARGET walks its cadence blocks (32 cadences, frames as in the kernel above) in order.  A
 //   lane keeps its loaded values (`u`, +29 VGPRs) beside the copy the sort consumes.  After the clipping the frame's staging
 //   area is free and takes the RAW values [frame][pixel]; the frame's estimate goes to a ring of the last 128 cadences in LDS.
-//   One workgroup barrier per block makes the ring entries of the block visible.  Then every wavefront smooths with ONE LANE PER
+//   A split workgroup barrier per block (signal after the clipping, wait one block later: see the kernel) makes the ring entries
+//   of the block visible.  Then every wavefront smooths with ONE LANE PER
 //   CADENCE (lane L: cadence 32 b - 32 + L, i.e. the previous block and this one): the 2 w + 1 taps of the two windows the
 //   reference uses (w = 1, 4; prepare.py:258) come from wave-shift DPP moves of one register and are added in series order
 //   (nanmean in float32: tp_bkg_smooth_kernel's expression); other windows loop over the ring.  The summing phase gives a lane 4
@@ -444,33 +462,24 @@ __global__ __launch_bounds__(256, 4) void tp_bkg_stamp_sum_kernel(BkgSumArgs s, 
 		return (c > 0) ? (asum / (float)c) : qnan;
 	};
 
-#pragma unroll 1
-	for (int b = 0; b < nblocks; ++b) {
-		const int kb = b * kFramesPerBlock;
-		const int k = kb + wave * FPW + f;
-		const bool active = k < n_cad;
-		float v[R];
-#pragma unroll
-		for (int j = 0; j < R; ++j) v[j] = (j < NREAL) ? u[j] : inf;
-		bool all_kept;
-		const float result = bkg_frame<G, JFULL>(a, v, fr, g, lane, active, &all_kept);
-		__builtin_amdgcn_wave_barrier();   // the clipping's reads of the staged ranks come before the raw values take their place
-		if (g == 0 && active) { out_raw[k] = result; s_ring[k & (kRing - 1)] = result; }
-#pragma unroll
-		for (int j = 0; j < NREAL; ++j)
-			if (JFULL >= 0 ? (j < JFULL || j * G + g < a.n_pix) : (j * G + g < a.n_pix)) fr[j * G + g] = u[j];
-		// the loads of the next block fly during the barrier and the summing phase
-		if (b + 1 < nblocks) {
-			const int kn = k + kFramesPerBlock;
-			const int voff = g * pitch_b + ((kn < n_cad) ? kn : (n_cad - 1)) * 4;
-#pragma unroll
-			for (int j = 0; j < NREAL; ++j) u[j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, j * G * pitch_b, 0));
-		}
-		const uint64_t clean_mask = __ballot(all_kept);   // bit 8 ff: frame ff of this wavefront
-		__syncthreads();                    // every estimate of block b is in the ring
+	// The phase that smooths and sums a block needs every wavefront's estimates of that block.  A workgroup barrier right after the
+	// clipping made the four wavefronts wait for the slowest at every block (their clipping loops run for different numbers of
+	// passes, their SIMDs are shared with other workgroups): 0.2 ms of the launch.  Instead the barrier is SPLIT: a wavefront
+	// signals (an LDS counter) once its estimates of block b are in the ring, and waits for the four signals of block b only after
+	// it has sorted block b + 1 -- by then they are almost always there.  The summing of block b therefore runs one block late,
+	// between the sort and the staging of block b + 1 (the sort works in registers: block b's raw values are still in the
+	// staging area), and once more after the loop for the last block.
+	unsigned* s_sig = reinterpret_cast<unsigned*>(s_good + ((n_cad + 15) & ~15));
+	if (tid == 0) *s_sig = 0u;
+	__syncthreads();
+	uint64_t clean_prev = 0ull;       // bit 8 ff: frame ff of this wavefront's previous block passed the pixel mask whole
+	auto post_phase = [&](const int pb, const uint64_t clean_mask) {
+		// wait for the estimates of block pb of all four wavefronts
+		while (__hip_atomic_load(s_sig, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * (unsigned)(pb + 1)) __builtin_amdgcn_s_sleep(1);
+		const int kb = pb * kFramesPerBlock;
 		const int kmax = (kb + kFramesPerBlock - 1 < n_cad - 1) ? (kb + kFramesPerBlock - 1) : (n_cad - 1);
-		const bool last = (b + 1 == nblocks);
-		const int n_held = (wave == 3 && b > 0) ? w : 0;   // cadences of the previous block this wavefront held back
+		const bool last = (pb + 1 == nblocks);
+		const int n_held = (wave == 3 && pb > 0) ? w : 0;   // cadences of the block before that this wavefront held back
 		// --- B2, one lane per cadence: lane L <-> cadence kb - 32 + L
 		const int c = kb - kFramesPerBlock + lane;
 		const bool mine = (lane >= 32 + wave * FPW) && (lane < 40 + wave * FPW) && (c < n_cad) && (last || c + w <= kmax);
@@ -504,24 +513,27 @@ __global__ __launch_bounds__(256, 4) void tp_bkg_stamp_sum_kernel(BkgSumArgs s, 
 			eff = s_good[c] ? bs : qnan;        // good-quality cadences only (BasePhotometry.py:1010)
 		}
 		const uint64_t valid_mask = __ballot(eff == eff);
-		// --- A1: the held-back cadences first (they are earlier in the series), then this block's
+		// --- A1: the held-back cadences first (they are earlier in the series), then the block's
 		if (p0 < a.n_pix) {
 			for (int sl = 0; sl < n_held; ++sl) {
 				const int L = 32 - n_held + sl;
 				if ((valid_mask >> L) & 1ull)
 					add4(*reinterpret_cast<const float4*>(s_pend + sl * n_pix4 + p0), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eff), L)), ((held_clean >> sl) & 1u) != 0u);
 			}
-			// everything the eight cadences need is read first (one LDS round trip, not one per cadence)
-			float4 x[FPW];
+			// four cadences' pixels are read at a time (the sorted values of the next block and its raw values are live in registers here)
 #pragma unroll
-			for (int ff = 0; ff < FPW; ++ff) x[ff] = *reinterpret_cast<const float4*>(my_frames + (size_t)ff * frame_stride + p0);
+			for (int h4 = 0; h4 < FPW; h4 += 4) {
+				float4 x[4];
 #pragma unroll
-			for (int ff = 0; ff < FPW; ++ff) asm volatile("" : "+v"(x[ff].x), "+v"(x[ff].y), "+v"(x[ff].z), "+v"(x[ff].w));
+				for (int ff = 0; ff < 4; ++ff) x[ff] = *reinterpret_cast<const float4*>(my_frames + (size_t)(h4 + ff) * frame_stride + p0);
 #pragma unroll
-			for (int ff = 0; ff < FPW; ++ff) {
-				const int L = 32 + wave * FPW + ff;
-				if ((valid_mask >> L) & 1ull)
-					add4(x[ff], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eff), L)), ((clean_mask >> (8 * ff)) & 1ull) != 0ull);
+				for (int ff = 0; ff < 4; ++ff) asm volatile("" : "+v"(x[ff].x), "+v"(x[ff].y), "+v"(x[ff].z), "+v"(x[ff].w));
+#pragma unroll
+				for (int ff = 0; ff < 4; ++ff) {
+					const int L = 32 + wave * FPW + h4 + ff;
+					if ((valid_mask >> L) & 1ull)
+						add4(x[ff], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(eff), L)), ((clean_mask >> (8 * (h4 + ff))) & 1ull) != 0ull);
+				}
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
@@ -532,8 +544,37 @@ __global__ __launch_bounds__(256, 4) void tp_bkg_stamp_sum_kernel(BkgSumArgs s, 
 			held_clean = 0u;
 			for (int sl = 0; sl < w; ++sl) held_clean |= (unsigned)((clean_mask >> (8 * (FPW - w + sl))) & 1ull) << sl;
 		}
-		__builtin_amdgcn_wave_barrier();   // ... before the next block's sorted ranks overwrite them
+		__builtin_amdgcn_wave_barrier();   // ... before the sorted ranks of the next block overwrite the staging area
+	};
+
+#pragma unroll 1
+	for (int b = 0; b < nblocks; ++b) {
+		const int kb = b * kFramesPerBlock;
+		const int k = kb + wave * FPW + f;
+		const bool active = k < n_cad;
+		float v[R];
+#pragma unroll
+		for (int j = 0; j < R; ++j) v[j] = (j < NREAL) ? u[j] : inf;
+		const FrameSums fs = bkg_frame_sort<G, JFULL>(a, v, g);
+		if (b > 0) post_phase(b - 1, clean_prev);      // block b - 1: its raw values are still in the staging area
+		const float result = bkg_frame_clip<G, JFULL>(a, v, fs, fr, g, lane, active);
+		__builtin_amdgcn_wave_barrier();   // the clipping's reads of the staged ranks come before the raw values take their place
+		if (g == 0 && active) { out_raw[k] = result; s_ring[k & (kRing - 1)] = result; }
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		if (lane == 0) atomicAdd(s_sig, 1u);   // this wavefront's estimates of block b are in the ring (its LDS operations execute in order)
+#pragma unroll
+		for (int j = 0; j < NREAL; ++j)
+			if (JFULL >= 0 ? (j < JFULL || j * G + g < a.n_pix) : (j * G + g < a.n_pix)) fr[j * G + g] = u[j];
+		clean_prev = __ballot(fs.n == a.n_pix);   // no pixel masked: in particular every value is finite
+		// the loads of the next block fly during its predecessor's summing phase
+		if (b + 1 < nblocks) {
+			const int kn = k + kFramesPerBlock;
+			const int voff = g * pitch_b + ((kn < n_cad) ? kn : (n_cad - 1)) * 4;
+#pragma unroll
+			for (int j = 0; j < NREAL; ++j) u[j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, j * G * pitch_b, 0));
+		}
 	}
+	post_phase(nblocks - 1, clean_prev);
 	// --- the four wavefront sums of a pixel, in wavefront order
 	__syncthreads();
 	double* s_acc = reinterpret_cast<double*>(s_lds);             // [4][n_pix4]
@@ -888,7 +929,7 @@ extern "C" int tp_background_sumimage(tp_ctx* ctx, const tp_cube_desc* desc, con
 	int frame_stride = ((last + ((last >> 5) << 2) + 1) + 3) & ~3;
 	if (frame_stride % 32 == 0) frame_stride += 8;
 	const int n_pix4 = (n_pix + 3) & ~3;
-	const size_t shmem = ((size_t)kFramesPerBlock * frame_stride + kRing + (size_t)(w <= 8 ? w : 0) * n_pix4) * sizeof(float) + (((size_t)desc->n_cad + 15) & ~(size_t)15);
+	const size_t shmem = ((size_t)kFramesPerBlock * frame_stride + kRing + (size_t)(w <= 8 ? w : 0) * n_pix4) * sizeof(float) + (((size_t)desc->n_cad + 15) & ~(size_t)15) + 16;
 	if (n_pix > 256 || w > 8 || desc->n_cad == 0 || shmem > 160 * 1024 || (int64_t)n_pix * desc->t_pitch * 4 >= 2147483647ll) {
 		// stamps above 256 pixels (the bright-star tail), windows beyond the reference's two (prepare.py:258), series whose quality
 		// flags do not fit the LDS: the three stages one after the other -- same series, the sum image to rounding (another
