@@ -258,7 +258,7 @@ def main():
 	if rank == 0 and extras:
 		from benchlib.legs.end_to_end import leg_end_to_end
 		from benchlib.legs.linpsf import leg_linpsf
-		from benchlib.legs.frames import leg_frames
+		from benchlib.legs.frames import leg_frames, leg_psf_frames
 		from benchlib.legs.psf_fit import leg_psf_fit
 		from benchlib.legs.fullframe import leg_fullframe
 		if args.e2e_targets > 0:
@@ -268,6 +268,7 @@ def main():
 		result['linpsf'] = leg_linpsf(ctx, scene, cubes, work, args, Nt, T, H, W, np, engine, pipeline)
 		if args.frames_targets > 0 and (T, H) == (1300, 15):
 			result['frames_to_results'] = leg_frames(ctx, args, T, np, pipeline)
+			result['psf_frames_to_results'] = leg_psf_frames(ctx, args, T, np, pipeline)
 		for k in ('raw', 'images_err'):
 			cubes[k].free()
 		if args.psf_targets > 0:

@@ -2,15 +2,10 @@
 import time
 
 
-def leg_frames(ctx, args, T, np, pipeline):
-	"""
-	The batched drop-in entry as a scheduler would call it: a CCD region's frame stacks (images, errors, backgrounds) resident
-	in HBM, ``tessphot_frames`` from target list to per-target results -- default stamps, catalogue selection, stamp cuts on
-	the device, the fused pass, the stamp-resize rounds, diagnostics, download and the host-side bookkeeping per target.
-	"""
-	from photometry_amd import tessphot_frames
-	N, FR, Tn = args.frames_targets, 512, 100
-	rng = np.random.default_rng(args.seed + 7)
+def synthetic_region(np, N, FR, T, seed):
+	"""A CCD region of FR x FR pixels with N stars (Gaussian PRF, sigma 0.9 px), T frames: frame stacks, time, quality, catalogue, targets."""
+	Tn = 100
+	rng = np.random.default_rng(seed)
 	rows, cols, tmag = rng.uniform(12, FR - 12, N), rng.uniform(12, FR - 12, N), rng.uniform(9.0, 14.0, N)
 	img = np.zeros((FR, FR))
 	yy, xx = np.mgrid[-4:5, -4:5]
@@ -23,11 +18,22 @@ def leg_frames(ctx, args, T, np, pipeline):
 	images = (base + 30.0 + rng.standard_normal(base.shape).astype('float32') * noise).astype('float32')
 	frames = {'images': np.tile(images, (reps, 1, 1))[:T], 'images_err': np.tile(noise, (reps, 1, 1))[:T],
 		'backgrounds': np.full((T, FR, FR), 100.0, dtype='float32')}
-	del base, noise, images
 	tstamp = 1500.0 + np.arange(T) * 1800.0 / 86400.0
 	quality = np.zeros(T, dtype='int32')
 	cat = {'starid': np.arange(N, dtype='int64') + 1, 'tmag': tmag.astype('float32'), 'row': rows.astype('float32'), 'column': (cols + 44).astype('float32')}
 	targets = {'starid': cat['starid'].copy(), 'tmag': tmag, 'row': rows, 'column': cols + 44}
+	return frames, tstamp, quality, cat, targets
+
+
+def leg_frames(ctx, args, T, np, pipeline):
+	"""
+	The batched drop-in entry as a scheduler would call it: a CCD region's frame stacks (images, errors, backgrounds) resident
+	in HBM, ``tessphot_frames`` from target list to per-target results -- default stamps, catalogue selection, stamp cuts on
+	the device, the fused pass, the stamp-resize rounds, diagnostics, download and the host-side bookkeeping per target.
+	"""
+	from photometry_amd import tessphot_frames
+	N, FR = args.frames_targets, 512
+	frames, tstamp, quality, cat, targets = synthetic_region(np, N, FR, T, args.seed + 7)
 	stack = pipeline.FrameStack(ctx, frames, 0, 44)
 	del frames
 	ctx.sync()
@@ -48,3 +54,59 @@ def leg_frames(ctx, args, T, np, pipeline):
 		'stamp-resize rounds and diagnostics on the device, default stamps / catalogue selection / decisions on the host (one Python process)',
 		'targets_per_s': N / dt, 'seconds': dt, 'ok_or_warning': good, 'targets_resized': resized,
 		'with_every_per_target_object': {'targets_per_s': N / (dt + dobj), 'seconds_for_the_objects': dobj, 'ok_or_warning': n_obj}}
+
+
+def leg_psf_frames(ctx, args, T, np, pipeline):
+	"""
+	The batched PSF entries: ``pipeline.linpsf_frames`` (LinPSFPhotometry for every target of a region resident in HBM) and
+	``pipeline.psf_frames`` (PSFPhotometry), from the target list to columnar results -- default stamps, catalogue and star
+	selection, stamp cuts on the device, P1 blend + fit, download.  cpu_baseline / parity: the oracle on the host copy of two targets'
+	stamps, first cadences.
+	"""
+	from photometry_amd import simulate, psf as hpsf
+	from oracle import psf as opsf, linpsf as olin
+	N, FR = min(args.frames_targets, 2000), 512
+	frames, tstamp, quality, cat, targets = synthetic_region(np, N, FR, T, args.seed + 11)
+	prf = simulate.synthetic_prf(seed=1)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	stack = pipeline.FrameStack(ctx, frames, 0, 44)
+	ctx.sync()
+	out = {}
+	pipeline.linpsf_frames(ctx, stack, targets, cat, tstamp, quality, model)
+	t0 = time.perf_counter()
+	lin = pipeline.linpsf_frames(ctx, stack, targets, cat, tstamp, quality, model)
+	dt = time.perf_counter() - t0
+	out['linpsf_frames'] = {'what': f'pipeline.linpsf_frames: {N} targets on a {FR} x {FR} x {T} region resident in HBM -> columnar results',
+		'targets_per_s': N / dt, 'seconds': dt, 'ok_or_warning': int(np.sum((lin.status == 1) | (lin.status == 3)))}
+	if args.cpu_sample > 0:
+		ns, tsub = 2, min(T, 40)
+		t1 = time.perf_counter()
+		bad = 0
+		for i in range(ns):
+			b = lin[i]
+			r1, r2, c1, c2 = b['stamp']
+			img = frames['images'][:tsub, r1:r2, c1 - 44:c2 - 44].transpose(1, 2, 0)
+			c = pipeline._catalog_of_stamp(cat, b['stamp'])
+			positions = np.empty((tsub, len(c['starid']), 2))
+			positions[:, :, 0] = c['row_stamp'][None, :]
+			positions[:, :, 1] = c['column_stamp'][None, :]
+			p = opsf.PSF(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'], b['stamp'])
+			ref = olin.do_photometry(img, p, c, targets['starid'][i], positions, b['stamp'], targets['row'][i], targets['column'][i],
+				np.ones((r2 - r1, c2 - c1), dtype='int32'))
+			bad += not np.allclose(b['flux'][:tsub], ref['flux'], rtol=1e-7, atol=1e-8 * np.nanmax(np.abs(ref['flux'])))
+		dc = time.perf_counter() - t1
+		out['linpsf_frames']['cpu_baseline'] = {'value': ns / (dc * T / tsub), 'unit': 'targets/s', 'cores': 1, 'kind': 'port',
+			'sample': f'{ns} targets x first {tsub} cadences (oracle restatement of LinPSFPhotometry.do_photometry on the host copy of their stamps), extrapolated to {T} cadences'}
+		out['linpsf_frames']['parity_sample'] = {'targets': ns, 'cadences': tsub, 'mismatches': int(bad), 'rtol': 1e-7}
+	# PSFPhotometry: a serial chain per target (tp_psf_fit); fewer targets
+	n2 = min(N, 256)
+	sub = {k: v[:n2] for k, v in targets.items()}
+	pipeline.psf_frames(ctx, stack, {k: v[:16] for k, v in targets.items()}, cat, tstamp, quality, model)
+	t0 = time.perf_counter()
+	ps = pipeline.psf_frames(ctx, stack, sub, cat, tstamp, quality, model)
+	dt = time.perf_counter() - t0
+	out['psf_frames'] = {'what': f'pipeline.psf_frames: {n2} targets x {T} cadences of the same region (Nelder-Mead fit per star and cadence, warm-started)',
+		'targets_per_s': n2 / dt, 'seconds': dt, 'finite_fraction': float(np.mean(np.isfinite(ps.flux)))}
+	for a in stack.dev.values():
+		a.free()
+	return out

@@ -387,33 +387,61 @@ def _catalog_of_stamp(catalog, stamp, buffer_size=5):
 
 
 class _CatalogIndex(object):
-	"""The catalogue of a CCD region sorted by row, for :func:`_catalogs_of_stamps`."""
-	def __init__(self, catalog):
+	"""The catalogue of a CCD region binned into cells of ``cell`` x ``cell`` pixels (stars sorted by cell), for
+	:func:`_catalogs_of_stamps`: the candidates of a stamp are the stars of the few cells it overlaps -- a row-sorted catalogue
+	alone hands every stamp all the stars of its band of rows, hundreds of candidates for the handful that are kept."""
+	def __init__(self, catalog, cell=16):
 		self.catalog = catalog
-		self.order = np.argsort(catalog['row'], kind='stable')
-		self.rows_sorted = np.asarray(catalog['row'])[self.order]
+		self.cell = int(cell)
+		row = np.asarray(catalog['row'], dtype='float64')
+		col = np.asarray(catalog['column'], dtype='float64')
+		if len(row):
+			self.r0 = int(np.floor(np.nanmin(row))) if np.isfinite(row).any() else 0
+			self.c0 = int(np.floor(np.nanmin(col))) if np.isfinite(col).any() else 0
+			finite = np.isfinite(row) & np.isfinite(col)
+			cr = np.where(finite, np.floor((row - self.r0) / self.cell), 0).astype('int64')
+			cc = np.where(finite, np.floor((col - self.c0) / self.cell), 0).astype('int64')
+			self.n_cr, self.n_cc = int(cr.max()) + 1, int(cc.max()) + 1
+			cid = np.where(finite, cr * self.n_cc + cc, self.n_cr * self.n_cc)   # stars without a position: a cell no stamp asks for
+		else:
+			self.r0 = self.c0 = 0
+			self.n_cr = self.n_cc = 1
+			cid = np.zeros(0, dtype='int64')
+		self.order = np.argsort(cid, kind='stable')
+		self.cell_start = np.searchsorted(cid[self.order], np.arange(self.n_cr * self.n_cc + 1), side='left')
 
 
 def _catalogs_of_stamps(index, stamps, buffer_size=5):
 	"""
 	:func:`_catalog_of_stamp` for all stamps of a group at once, in CSR form: ``(offsets int64 [n + 1], dict of concatenated
-	arrays)``; the stars of a stamp keep their catalogue order.  Candidate stars come from a binary search on the row-sorted
-	catalogue (a stamp spans a few percent of the rows), the column test and the float32 stamp coordinates are the same
-	expressions evaluated on arrays.
+	arrays)``; the stars of a stamp keep their catalogue order.  Candidate stars come from the cells of the binned catalogue the
+	stamp (plus its buffer) overlaps, one contiguous run of the cell-sorted catalogue per row of cells; the row / column tests and the
+	float32 stamp coordinates are the expressions of the per-stamp function evaluated on arrays.
 	"""
 	cat = index.catalog
 	st = np.asarray(stamps, dtype='int64').reshape(-1, 4)
 	n = len(st)
-	lo = np.searchsorted(index.rows_sorted, st[:, 0] - 0.5 - buffer_size, side='left')    # row >= r1 - 0.5 - buffer
-	hi = np.searchsorted(index.rows_sorted, st[:, 1] - 0.5 + buffer_size, side='left')    # row <  r2 - 0.5 + buffer
-	cnt = hi - lo
-	which = np.repeat(np.arange(n), cnt)
-	pos = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt) + np.repeat(lo, cnt)
+	B = index.cell
+	rlo, rhi = st[:, 0] - 0.5 - buffer_size, st[:, 1] - 0.5 + buffer_size      # row >= rlo, row < rhi
+	clo, chi = st[:, 2] - 0.5 - buffer_size, st[:, 3] - 0.5 + buffer_size
+	cr0 = np.clip(np.floor((rlo - index.r0) / B).astype('int64'), 0, index.n_cr - 1)
+	cr1 = np.clip(np.floor((rhi - index.r0) / B).astype('int64'), -1, index.n_cr - 1)
+	cc0 = np.clip(np.floor((clo - index.c0) / B).astype('int64'), 0, index.n_cc - 1)
+	cc1 = np.clip(np.floor((chi - index.c0) / B).astype('int64'), -1, index.n_cc - 1)
+	# one run [cell_start[first cell], cell_start[last cell + 1]) per (stamp, row of cells)
+	nrows = np.maximum(cr1 - cr0 + 1, 0) * (cc1 >= cc0)
+	run_stamp = np.repeat(np.arange(n), nrows)
+	run_row = np.arange(int(nrows.sum())) - np.repeat(np.cumsum(nrows) - nrows, nrows) + np.repeat(cr0, nrows)
+	a = index.cell_start[run_row * index.n_cc + cc0[run_stamp]]
+	b = index.cell_start[run_row * index.n_cc + cc1[run_stamp] + 1]
+	cnt = b - a
+	which = np.repeat(run_stamp, cnt)
+	pos = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt) + np.repeat(a, cnt)
 	star = index.order[pos]
-	col = np.asarray(cat['column'])[star]
-	keep = (col >= (st[which, 2] - 0.5 - buffer_size)) & (col < (st[which, 3] - 0.5 + buffer_size))
+	col, row = np.asarray(cat['column'])[star], np.asarray(cat['row'])[star]
+	keep = (row >= rlo[which]) & (row < rhi[which]) & (col >= clo[which]) & (col < chi[which])
 	which, star = which[keep], star[keep]
-	o = np.lexsort((star, which))   # catalogue order inside every stamp
+	o = np.argsort(which * (len(index.order) + 1) + star, kind='stable')   # catalogue order inside every stamp
 	which, star = which[o], star[o]
 	offsets = np.concatenate(([0], np.cumsum(np.bincount(which, minlength=n)))).astype('int64')
 	col64, row64 = np.asarray(cat['column'], dtype='float64')[star], np.asarray(cat['row'], dtype='float64')[star]

@@ -280,3 +280,35 @@ def test_plugin_psf_from_the_prf_directory(tmp_path, monkeypatch):
 	pho2 = plugins.BasePhotometry.__new__(plugins.BasePhotometry)
 	pho2.source, pho2._psf, pho2.sector, pho2.camera, pho2.ccd = Src(), None, 1, 1, 1
 	assert pho2.psf is model   # fitted once per process
+
+
+def test_binned_catalogue_selection_equals_the_per_stamp_function():
+	"""pipeline._catalogs_of_stamps (all stamps of a group at once, candidates from the cells of a binned catalogue) against
+	pipeline._catalog_of_stamp (the reference's selection, BasePhotometry.py:1094-1181, one stamp at a time): same stars in the same
+	(catalogue) order with the same float32 stamp coordinates -- stamps of every size, stars on the stamp's buffer limits, stars
+	without a position."""
+	from photometry_amd import pipeline as pl
+	rng = np.random.default_rng(3)
+	N = 3000
+	cat = {'starid': np.arange(N) + 1, 'tmag': rng.uniform(8, 15, N).astype('float32'), 'row': rng.uniform(-3, 520, N).astype('float32'),
+		'column': rng.uniform(40, 560, N).astype('float32')}
+	cat['row'][5] = np.nan
+	cat['row'][6], cat['column'][6] = 94.5, 139.5          # exactly on the lower limits of the first stamp's buffer
+	cat['row'][7], cat['column'][7] = 119.5, 169.5         # exactly on the (excluded) upper limits
+	st = [(100, 115, 145, 165)]
+	for _ in range(600):
+		r, c, h, w = rng.integers(0, 500), rng.integers(44, 540), rng.integers(5, 40), rng.integers(5, 40)
+		st.append((r, r + h, c, c + w))
+	st = np.array(st)
+	off, arr = pl._catalogs_of_stamps(pl._CatalogIndex(cat), st)
+	assert off[0] == 0 and len(off) == len(st) + 1
+	for i in range(len(st)):
+		ref = pl._catalog_of_stamp(cat, tuple(st[i]))
+		for k in ref:
+			np.testing.assert_array_equal(arr[k][off[i]:off[i + 1]], ref[k], err_msg=f'stamp {i} {k}')
+	first = set(arr['starid'][off[0]:off[1]])
+	assert 7 in first and 8 not in first
+	# an empty catalogue and an empty group
+	e = {k: v[:0] for k, v in cat.items()}
+	off0, arr0 = pl._catalogs_of_stamps(pl._CatalogIndex(e), st[:3])
+	assert list(off0) == [0, 0, 0, 0] and len(arr0['starid']) == 0
