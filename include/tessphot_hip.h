@@ -75,10 +75,11 @@ int tp_ctx_destroy(tp_ctx* ctx);
 const char* tp_last_error(tp_ctx* ctx);      /* ctx may be NULL: last tp_ctx_create failure */
 int tp_device_info(tp_ctx* ctx, char* name, int name_len, int32_t* n_cu, uint64_t* hbm_bytes);
 
-/* Device memory.  tp_free keeps a block for the next tp_malloc of its size class (up to 24 GiB per context; hipMalloc / hipFree
- * of multi-GB blocks cost milliseconds and synchronise the device); a recycled block is handed out only after everything that
- * was queued on the context's stream when it was freed has run, so it is idle for whichever stream writes it next.
- * tp_cache_trim gives the cached blocks back to the driver (the library does so itself when an allocation fails). */
+/* Device memory.  tp_free keeps a block for the next tp_malloc of its size class (blocks up to 32 GiB, 64 GiB per context;
+ * hipMalloc / hipFree of multi-GB blocks cost milliseconds and synchronise the device); a recycled block is handed out only
+ * after everything that was queued on the context's stream when it was freed has run, so it is idle for whichever stream writes
+ * it next.  tp_cache_trim gives the cached blocks back to the driver; when an allocation fails the library does so itself, for
+ * this context first and then for every other context of the device. */
 int tp_malloc(tp_ctx* ctx, uint64_t nbytes, void** d_ptr);
 int tp_free(tp_ctx* ctx, void* d_ptr);
 int tp_cache_trim(tp_ctx* ctx);

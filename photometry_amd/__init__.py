@@ -10,4 +10,4 @@ from .status import STATUS  # noqa: F401
 
 __version__ = '0.1.0'
 from .plugins import BasePhotometry, AperturePhotometry, LinPSFPhotometry, PSFPhotometry, HaloPhotometry  # noqa: F401,E402
-from .tessphot import tessphot, tessphot_batch, tessphot_frames  # noqa: F401,E402
+from .tessphot import tessphot, tessphot_batch, tessphot_frames, tessphot_frames_pipelined  # noqa: F401,E402

@@ -1,8 +1,14 @@
 // api.cpp -- context, memory, timers and the per-kernel profile of libtessphot_hip.so.
 #include "common.h"
+#include <algorithm>
+#include <mutex>
 #include <thread>
 #include <cstring>
 #include <exception>
+
+// every live context, so that an allocation that fails can ask the others of its device for their cached blocks
+static std::mutex tp_registry_mutex;
+static std::vector<tp_ctx*> tp_registry;
 
 thread_local std::string tp_global_err;
 
@@ -97,13 +103,18 @@ static int tp_ctx_create_impl(int device, int high_priority, tp_ctx** out) {
 		(void)hipEventCreate(&ctx->tstart[i]);
 		(void)hipEventCreate(&ctx->tstop[i]);
 	}
+	{
+		std::lock_guard<std::mutex> lk(tp_registry_mutex);
+		tp_registry.push_back(ctx);
+	}
 	*out = ctx;
 	return TP_OK;
 	TP_API_END((tp_ctx*)nullptr)
 }
 
 int tp_comm_destroy(tp_ctx* ctx);
-static void tp_cache_release(tp_ctx* ctx);
+static void tp_cache_release(tp_ctx* ctx, bool own = true);
+
 
 int tp_ctx_create(int device, tp_ctx** out) {
 	return tp_ctx_create_impl(device, 0, out);
@@ -115,6 +126,10 @@ int tp_ctx_create_stream(int device, int high_priority, tp_ctx** out) {
 
 int tp_ctx_destroy(tp_ctx* ctx) {
 	if (!ctx) return TP_OK;
+	{
+		std::lock_guard<std::mutex> lk(tp_registry_mutex);
+		tp_registry.erase(std::remove(tp_registry.begin(), tp_registry.end(), ctx), tp_registry.end());
+	}
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
 	(void)tp_comm_destroy(ctx);
@@ -168,15 +183,35 @@ static size_t tp_alloc_class(size_t n) {
 }
 
 // every cached block back to the driver (their freeing events have to have completed: the stream is synchronised first)
-static void tp_cache_release(tp_ctx* ctx) {
+static void tp_cache_release(tp_ctx* ctx, bool own) {
+	std::lock_guard<std::recursive_mutex> lk(ctx->cache_mutex);
 	if (ctx->cache.empty()) return;
 	(void)hipStreamSynchronize(ctx->stream);
 	for (auto& kv : ctx->cache) {
 		(void)hipFree(kv.second.ptr);
-		if (kv.second.freed) ctx->pool.push_back(kv.second.freed);
+		if (kv.second.freed) {
+			// (a visitor does not touch the owner's event pool: that one is not behind the mutex)
+			if (own) ctx->pool.push_back(kv.second.freed);
+			else (void)hipEventDestroy(kv.second.freed);
+		}
 	}
 	ctx->cache.clear();
 	ctx->cache_bytes = 0;
+}
+
+// the cached blocks of the OTHER contexts of ctx's device back to the driver; a context whose cache is in use right now
+// (another thread inside tp_malloc / tp_free on it) is passed over rather than waited for
+static bool tp_cache_release_others(tp_ctx* ctx) {
+	bool any = false;
+	std::lock_guard<std::mutex> lk(tp_registry_mutex);
+	for (tp_ctx* other : tp_registry) {
+		if (other == ctx || other->device != ctx->device) continue;
+		std::unique_lock<std::recursive_mutex> ol(other->cache_mutex, std::try_to_lock);
+		if (!ol.owns_lock() || other->cache.empty()) continue;
+		tp_cache_release(other, false);
+		any = true;
+	}
+	return any;
 }
 
 } // extern "C"
@@ -184,6 +219,10 @@ hipError_t tp_device_alloc(tp_ctx* ctx, void** ptr, size_t bytes) {
 	hipError_t e = hipMalloc(ptr, bytes);
 	if (e == hipErrorOutOfMemory && !ctx->cache.empty()) {
 		tp_cache_release(ctx);
+		(void)hipGetLastError();
+		e = hipMalloc(ptr, bytes);
+	}
+	if (e == hipErrorOutOfMemory && tp_cache_release_others(ctx)) {
 		(void)hipGetLastError();
 		e = hipMalloc(ptr, bytes);
 	}
@@ -203,6 +242,7 @@ int tp_malloc(tp_ctx* ctx, uint64_t nbytes, void** d_ptr) {
 	*d_ptr = nullptr;
 	if (nbytes == 0) nbytes = 16;
 	const size_t cap = tp_alloc_class((size_t)nbytes);
+	std::lock_guard<std::recursive_mutex> lk(ctx->cache_mutex);
 	auto range = ctx->cache.equal_range(cap);
 	if (range.first != range.second) {
 		// a block whose freeing event has completed is idle for every stream.  If none is: a small block is cheaper to get from
@@ -234,6 +274,7 @@ int tp_malloc(tp_ctx* ctx, uint64_t nbytes, void** d_ptr) {
 int tp_free(tp_ctx* ctx, void* d_ptr) {
 	TP_CHECK_CTX(ctx);
 	if (!d_ptr) return TP_OK;
+	std::lock_guard<std::recursive_mutex> lk(ctx->cache_mutex);
 	auto it = ctx->live.find(d_ptr);
 	if (it != ctx->live.end()) {
 		const size_t cap = it->second;

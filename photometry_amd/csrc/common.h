@@ -8,6 +8,7 @@
 #include <vector>
 #include <utility>
 #include <map>
+#include <mutex>
 #include "../../include/tessphot_hip.h"
 
 // Dense kernel ids for the per-kernel profile (tp_kernel_name / tp_profile_get).
@@ -59,8 +60,10 @@ struct tp_ctx {
 	size_t store_bytes = 0;
 	// tp_malloc / tp_free: blocks a caller frees go to a size-keyed cache instead of back to the driver (hipFree synchronises the
 	// whole device, hipMalloc costs tens of microseconds -- and ~12 ms for a multi-GB block: the stamp cubes of the batched frames
-	// entry, measured); reuse is ordered by the context's stream.  Blocks up to cache_block (8 GiB), cache_limit (48 GiB) in all:
-	// a sixth of the 288 GB, given back when an allocation fails.
+	// entry, measured -- a batch of 10 000 stamps of 15 x 15 is three blocks of 11.8 GB, and outside the cache every call paid 1.2 s
+	// for them); reuse is ordered by the context's stream.  Blocks up to cache_block (32 GiB), cache_limit (64 GiB) per context.
+	// When an allocation fails the context's own cache goes back to the driver first, then the caches of every other context of
+	// the device (api.cpp keeps a registry; cache_mutex serialises a context's cache against such a visit from another thread).
 	// A cached block carries an event recorded on the context's stream when it was freed; tp_malloc hands it out again only once
 	// that event has completed (it prefers a block whose event already has, and waits otherwise), so a recycled block is idle
 	// whichever stream or context writes to it next.  tp_device_alloc (scratch, stores, work lists) and tp_malloc give the cache
@@ -68,7 +71,8 @@ struct tp_ctx {
 	struct cached_block { void* ptr; hipEvent_t freed; };
 	std::multimap<size_t, cached_block> cache;
 	std::map<void*, size_t> live;   // blocks handed out by tp_malloc -> capacity
-	size_t cache_bytes = 0, cache_limit = (size_t)24 << 30, cache_block = (size_t)8 << 30;
+	size_t cache_bytes = 0, cache_limit = (size_t)64 << 30, cache_block = (size_t)32 << 30;
+	std::recursive_mutex cache_mutex;
 	// pinned staging area of the synchronous copy entries (tp_memcpy_h2d / _d2h): pageable transfers go through it in pieces
 	void* stage = nullptr;
 	size_t stage_bytes = 0;

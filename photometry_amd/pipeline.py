@@ -564,6 +564,67 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 	edge and nothing is logged -- is decided for a whole group with array operations; only the targets that resize, warn or fail
 	take the per-target path.
 	"""
+	job = _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s, datasource, [ctx] + ctx.side_contexts(2))
+	while True:
+		try:
+			next(job)
+		except StopIteration as done:
+			return done.value
+
+
+def aperture_frames_pipelined(ctx, stack, batches, catalog, time, quality, settings=None, cadence_s=1800, datasource='ffi', in_flight=2):
+	"""
+	:func:`aperture_frames` over consecutive batches of targets of one CCD region (``batches``: an iterable of ``targets`` dicts),
+	``in_flight`` of them at a time, each on its own streams: the rounds of a batch are a strict chain -- queue the passes, wait,
+	decide, queue the next round -- whose later links are a few latency-bound passes over the resized stamps that leave most of
+	the chip idle, so the first round of the next batch runs under them and the host decides one batch while the device works on
+	the other.  Yields one :class:`FramesResult` per batch, in order; every batch gives what a call of its own would.
+	"""
+	catalog = {k: np.asarray(v) for k, v in catalog.items()}
+	cat_index = _CatalogIndex(catalog)
+	every = [ctx] + ctx.side_contexts(3 * in_flight - 1)
+	free_slots = list(range(in_flight))[::-1]
+	source = iter(batches)
+	running, finished, order, exhausted = [], {}, 0, False   # running: [serial, slot, generator]
+	next_out = 0
+	while True:
+		while not exhausted and free_slots:
+			try:
+				targets = next(source)
+			except StopIteration:
+				exhausted = True
+				break
+			slot = free_slots.pop()
+			job = _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s, datasource, every[3 * slot:3 * slot + 3], cat_index)
+			running.append([order, slot, job])
+			order += 1
+			try:
+				next(job)   # the first round of the new batch is queued before the older ones are waited for
+			except StopIteration as done:
+				serial, slot, _ = running.pop()
+				finished[serial] = done.value
+				free_slots.append(slot)
+		if not running and exhausted:
+			break
+		for entry in list(running):
+			try:
+				next(entry[2])
+			except StopIteration as done:
+				running.remove(entry)
+				finished[entry[0]] = done.value
+				free_slots.append(entry[1])
+		while next_out in finished:
+			yield finished.pop(next_out)
+			next_out += 1
+	while next_out in finished:
+		yield finished.pop(next_out)
+		next_out += 1
+
+
+def _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s, datasource, streams, cat_index=None):
+	"""The rounds of :func:`aperture_frames` as a generator: it yields wherever the host would wait for the device (after the
+	passes of a round are queued; before the last light curves have arrived) and returns the :class:`FramesResult`.  ``streams``:
+	the contexts of this job (the first one takes the large groups); ``cat_index``: a prebuilt index of ``catalog``."""
 	from . import stamps as st
 	from .plugins import load_settings, mag2flux, mask_outcome
 	from ._lib import TessphotError
@@ -587,7 +648,7 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 		out.status[i] = 2
 		out.errors[int(i)] = ['ValueError: Invalid stamp selected']
 		out.stamp[i] = (-1, -2, -1, -2)
-	cat_index = _CatalogIndex(catalog)
+	cat_index = _CatalogIndex(catalog) if cat_index is None else cat_index
 	attempts_left = np.where(tmags < 6, 10, 5).astype('int64')   # photometry.py:70-73 (stamps.retry_limit)
 	active = np.flatnonzero(valid)
 	edge_bits = sum(bit for _name, bit, _idx, _sign in st.SIDES)
@@ -599,6 +660,7 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 			out.errors[i] = out.errors.get(i, []) + log[i].items
 			log[i].items = []
 
+	from . import comm as tpcomm
 	events, pending = [], []
 	if '_hbm_bytes' not in ctx.__dict__:
 		ctx.__dict__['_hbm_bytes'] = ctx.info()['hbm_bytes']
@@ -630,9 +692,8 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 			# stamps is a latency-bound pass of ~1 ms that hides under the pass of the 15 x 15 group), each pass ending with ONE
 			# download of its packed output block into page-locked memory; then the results are decided group by group
 			launched = []
-			streams = [ctx] + ctx.side_contexts(2)
 			for gi, (idx, H, W) in enumerate(part):
-				g = streams[gi % len(streams)] if len(idx) < 256 or gi == 0 else ctx
+				g = streams[gi % len(streams)] if len(idx) < 256 or gi == 0 else streams[0]
 				cubes = host = None
 				try:
 					if H * W > 65535:
@@ -644,7 +705,9 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 					scene = _GroupScene(stack, time, quality, cadence_s, cur[idx], cat_offsets, cat_arrays, targets, idx)
 					batch = ApertureBatch(g, scene, cubes=cut)
 					work = ApertureWork(g, batch, packed=True, cat_capacity=max(int(cat_offsets[-1]), 1), extras=True)
-					aperture_step(g, batch, work)
+					# a small group is a latency-bound pass: the three stand-alone kernels spread A1 and A6 over the chip where the fused launch
+					# gives each target one wavefront (8 targets of 25 x 25: 1.03 against 1.47 ms; bit-identical outputs)
+					aperture_step(g, batch, work, fused=len(idx) >= 1024)
 					aperture_diagnostics(g, batch, work)
 					host = g.pinned_block(work.block.nbytes)
 					# two copies: what the decisions of this round read (flags, masks, sum images ...: everything behind the light curves in
@@ -669,8 +732,8 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 					for i in idx:
 						logger_of(int(i)).error('Device pass failed for a %dx%d stamp: %s', H, W, str(e))
 						finish(int(i), 2)
+			yield   # the passes of this part run: the caller may serve another job meanwhile
 			failed = None
-			from . import comm as tpcomm
 			for (g, idx, H, W, scene, cat_offsets, cat_arrays, cubes, batch, work, host, ev) in launched:
 				try:
 					g.event_sync(ev)      # the small part of the group's block is on the host (its light curves may still be on their way)
@@ -744,9 +807,15 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 					finish(i, int(res['status'][j]))
 		active = np.asarray(sorted(still), dtype='int64')
 	# the light curves of every round have arrived
-	for g in [ctx] + ctx.side_contexts(2):
+	marks = []
+	for g in streams:
+		ev = events.pop() if events else g.event()
+		g.record(ev)
+		marks.append((g, ev))
+	yield
+	for g, ev in marks:
 		try:
-			g.sync()
+			g.event_sync(ev)
 		except TessphotError as e:   # a copy of light curves failed: nothing that was extracted can be trusted
 			for i in np.flatnonzero(out.has_result):
 				out.has_result[i] = False

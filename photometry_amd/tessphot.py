@@ -225,6 +225,25 @@ def tessphot_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 	return BatchResults(res, targets['starid'])
 
 
+def tessphot_frames_pipelined(ctx, stack, batches, catalog, time, quality, settings=None, cadence_s=1800, in_flight=2):
+	"""
+	:func:`tessphot_frames` over consecutive batches of targets of one CCD region -- what a run over a whole CCD does, a few
+	thousand targets per call -- with ``in_flight`` batches on the device at a time (``pipeline.aperture_frames_pipelined``: the
+	first round of a batch runs under the latency-bound resize rounds of the one before it).  ``batches``: an iterable of
+	``targets`` dicts; yields one :class:`BatchResults` per batch, in order, equal to what a call of its own returns.
+	"""
+	from . import pipeline
+	batches = list(batches) if not hasattr(batches, '__next__') else batches
+	ids = []
+	def feed():
+		for t in batches:
+			ids.append(t['starid'])
+			yield t
+	for k, res in enumerate(pipeline.aperture_frames_pipelined(ctx, stack, feed(), catalog, time, quality, settings=settings,
+			cadence_s=cadence_s, in_flight=in_flight)):
+		yield BatchResults(res, ids[k])
+
+
 def tessphot_batch(ctx, scene, cubes='host'):
 	"""
 	Aperture photometry of a whole batch of FIXED-size stamp cubes in one pass over the device

@@ -124,3 +124,23 @@ def test_two_minute_cadence_length(ctx):
 			assert d[i][0] == o['mean_flux'] and d[i][3] == o['ptp']
 			np.testing.assert_allclose(d[i][[1, 2]], [o['variance'], o['rms_hour']], rtol=1e-12)
 			np.testing.assert_allclose(d[i][6], o['variability'], rtol=1e-9)
+
+
+def test_allocation_takes_back_the_blocks_other_contexts_have_cached():
+	"""Blocks a context has freed stay in ITS cache; an allocation on another context of the device that would fail for them
+	gets them back to the driver and succeeds (the batched frames entry runs several contexts side by side)."""
+	from photometry_amd.device import Context
+	a, b = Context(0), Context(0)
+	total = a.info()['hbm_bytes']
+	if total < 200e9:
+		pytest.skip("sized for the 288 GB device")
+	gb = 1 << 30
+	blocks = [a.empty((28 * gb,), 'uint8') for _ in range(2)]
+	for blk in blocks:
+		blk.free()                      # 56 GiB idle in a's cache
+	big = b.empty((int(total) - 40 * gb,), 'uint8')   # more than what is left beside them
+	big.free()
+	again = a.empty((28 * gb,), 'uint8')              # a's cache is empty now: from the driver
+	again.free()
+	a.close()
+	b.close()

@@ -216,3 +216,34 @@ def test_aperture_frames_in_parts_under_a_memory_budget(monkeypatch):
 			np.testing.assert_array_equal(a.lightcurve['flux'], b.lightcurve['flux'])
 			np.testing.assert_array_equal(a.final_phot_mask, b.final_phot_mask)
 	ctx.close()
+
+
+def test_pipelined_batches_equal_separate_calls():
+	"""Consecutive batches of one region with two (and three) of them on the device at a time: every batch gives exactly what a
+	call of its own gives -- statuses, stamps, resize counts, messages, masks, light curves -- in order."""
+	from photometry_amd import pipeline, tessphot_frames, tessphot_frames_pipelined
+	from photometry_amd.device import Context
+	frames, row0, col0, time, quality, cat, targets = _region()
+	rng = np.random.default_rng(5)
+	order = rng.permutation(len(targets['starid']))
+	cuts = [order[:3], order[3:4], order[4:], order[:0], order[::2]]   # ragged batches, an empty one, a repeated target
+	batches = [{k: np.asarray(v)[sel] for k, v in targets.items()} for sel in cuts]
+	ctx = Context(0)
+	stack = pipeline.FrameStack(ctx, {k: np.moveaxis(v, 2, 0) for k, v in frames.items()}, row0, col0)
+	alone = [tessphot_frames(ctx, stack, b, cat, time, quality) for b in batches]
+	for in_flight in (2, 3):
+		together = list(tessphot_frames_pipelined(ctx, stack, iter(batches), cat, time, quality, in_flight=in_flight))
+		assert len(together) == len(batches)
+		for a, b in zip(alone, together):
+			assert len(a) == len(b)
+			np.testing.assert_array_equal(a.status, b.status)
+			np.testing.assert_array_equal(a.stamp, b.stamp)
+			np.testing.assert_array_equal(a.frames.stamp_resizes, b.frames.stamp_resizes)
+			for i in range(len(a)):
+				x, y = a[i], b[i]
+				assert x.status == y.status and x._details.get("errors") == y._details.get("errors") and x.starid == y.starid
+				if x.lightcurve is not None:
+					for key in ('flux', 'flux_err', 'flux_background', 'pos_centroid'):
+						np.testing.assert_array_equal(x.lightcurve[key], y.lightcurve[key])
+					np.testing.assert_array_equal(x.final_phot_mask, y.final_phot_mask)
+	ctx.close()

@@ -41,6 +41,44 @@ for rep in range(2):
 	dt = time.perf_counter() - t0
 	ok = int(np.sum((out.status == 1) | (out.status == 3)))
 	print(f'tessphot_frames: {N} targets, {T} cadences, {FR}^2 frames: {dt:.3f} s = {N / dt:.0f} targets/s; OK/WARNING {ok}', flush=True)
+NB = int(os.environ.get('BATCHES', 0))
+if NB:
+	# consecutive batches of N targets each (other positions on the same region), two on the device at a time
+	from photometry_amd import tessphot_frames_pipelined
+	batches = []
+	for b in range(NB):
+		sel = rng.permutation(N)   # the same stars in another order: the same work per batch
+		batches.append({k: np.asarray(v)[sel] for k, v in targets.items()})
+	for fl in (1, 2, 3):
+		for rep in range(2):
+			prp = cProfile.Profile()
+			if rep == 1 and os.environ.get('PROFILE_PIPE'):
+				prp.enable()
+			t0 = time.perf_counter()
+			okc = 0
+			for res in tessphot_frames_pipelined(ctx, stack, iter(batches), cat, tstamp, quality, in_flight=fl):
+				okc += int(np.sum((res.status == 1) | (res.status == 3)))   # the consumer takes what it needs and lets the batch go
+				res = None
+			dt = time.perf_counter() - t0
+			prp.disable()
+		if os.environ.get('PROFILE_PIPE') and fl == 3:
+			sp = io.StringIO()
+			pstats.Stats(prp, stream=sp).sort_stats('tottime').print_stats(22)
+			print(sp.getvalue()[:5000])
+		print(f'pipelined, {NB} batches of {N}, {fl} in flight: {dt * 1e3:.1f} ms = {NB * N / dt:.0f} targets/s; OK/WARNING {okc}', flush=True)
+if os.environ.get('KERNELS'):
+	# the device side of one call: per-kernel totals from the library's HIP events (every stream the call used)
+	allc = [ctx] + ctx.side_contexts(2)
+	for c in allc:
+		c.profile(True); c.profile_reset()
+	t0 = time.perf_counter()
+	out = tessphot_frames(ctx, stack, targets, cat, tstamp, quality)
+	dt = time.perf_counter() - t0
+	print(f'with the event profile on: {dt * 1e3:.2f} ms')
+	for ci, c in enumerate(allc):
+		for name, (cnt, ms) in sorted(c.profile_report().items(), key=lambda kv: -kv[1][1]):
+			print(f'  stream {ci}: {name:34s} {cnt:4d} launches {ms:8.3f} ms')
+		c.profile(False)
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(28)
 print(s.getvalue()[:6500])
