@@ -78,7 +78,7 @@ def leg_fullframe(ctx, args, np):
 	nb = R * C * (4 + 4 + 1)   # image read, indicator written (and read back for mean and threshold), flags written
 	out['shenanigans'] = {'frames': ns, 'wall_ms_per_frame': dt / ns * 1e3, 'kernel_ms_per_frame': kms / ns,
 		'kernels_ms_per_frame': {k: ms / ns for k, (_, ms) in rep.items()},
-		'roofline': {'kernel': 'tp_median_filter_kernel', 'bound': 'vector ALU (a 225-key sorting network per pixel), priced against HBM',
+		'roofline': {'kernel': 'tp_median_filter_kernel', 'bound': 'vector ALU (tp_median15_quad_kernel: per four adjacent pixels one sort of the 180 values their windows share + four sorts of 45 + a rank selection from the two sorted lists), priced against HBM',
 			'achieved': nb / (kms / ns * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': nb / (kms / ns * 1e-3) / 1e9 / HBM_PEAK_GBS,
 			'traffic': leg_traffic(('tp_median_filter', 'tp_block_median', 'tp_threshold'), 1), 'traffic_unit': 'bytes per frame', 'traffic_source': src}}
 	if args.cpu_sample > 0:

@@ -690,6 +690,138 @@ __global__ __launch_bounds__(256) void tp_median_filter_kernel(MedianArgs a)
 		a.out[(int64_t)frame * a.frame_stride + (int64_t)row * a.row_pitch + col] = (med <= 3.402823466e+38f) ? med : __builtin_nanf("");
 }
 
+// The 15 x 15 window the reference uses, four output pixels at a time.  The windows of four horizontally adjacent pixels
+// c0 .. c0+3 share twelve of their fifteen columns (c0-4 .. c0+7: 180 values); each has three columns of its own (45 values).
+// The eight lanes of a group sort the shared 180 ONCE (23 registers per lane), then the 45 own values of each of the four
+// pixels (6 registers per lane: a network a fifth the size), and the median of a window is the rank-112 element of the union
+// of two sorted lists -- no merge is needed for that:
+//     rank k of A u B  =  min over i of max(A[k - i], B[i - 1]),   i = how many of the k + 1 smallest come from B (0 .. 45),
+// 46 candidates, six per lane, one cross-lane minimum.  Of the shared list only ranks 67 .. 112 can be asked for: lanes 2 and 3 of
+// the group stage theirs (ranks 64 .. 127) in LDS, the others nothing.  The window values come from an LDS tile of the workgroup
+// (15 rows x 128 + 14 columns of float32(img - reference), reflected at the image edges, non-finite -> +inf): the index
+// arithmetic of the reflection is paid once per tile element, not once per window element.
+// Per pixel ~75 vector instructions against ~260 of the kernel above (one full 256-key sort per pixel).
+__global__ __launch_bounds__(256) void tp_median15_quad_kernel(MedianArgs a)
+{
+	constexpr int TW = 144;                       // tile row pitch: 128 output columns + 14 + 2 pad
+	__shared__ float s_tile[15 * TW];
+	__shared__ __align__(16) float s_a[32 * 72];  // per group: ranks 64 .. 127 of the shared list (two runs of 32 + 4 pad words each)
+	__shared__ __align__(16) float s_b[32 * 72];  // per group: the sorted own values of the pixel in work (64 slots)
+	const int tid = threadIdx.x;
+	const int wave = tid >> 6, lane = tid & 63;
+	const int f = lane >> 3, g = lane & 7;
+	const int q = wave * 8 + f;                   // group of the workgroup: output columns col0 + 4 q .. + 3
+	const int row = blockIdx.y, frame = blockIdx.z;
+	const int col0 = blockIdx.x * 128;
+	const float inf = __builtin_inff();
+	const float* img = a.frames + (int64_t)frame * a.frame_stride;
+
+	// ---- the tile: rows row-7 .. row+7, columns col0-7 .. col0+134 (both dimensions are at least 15: one reflection suffices)
+	for (int e = tid; e < 15 * 142; e += 256) {
+		const int dy = e / 142, t = e - dy * 142;
+		int rr = row - 7 + dy, cc = col0 - 7 + t;
+		float x = inf;
+		if (cc < a.n_cols + 7) {                  // (columns further out belong to outputs beyond the image only)
+			rr = (rr < 0) ? (-rr - 1) : rr; rr = (rr >= a.n_rows) ? (2 * a.n_rows - 1 - rr) : rr;
+			cc = (cc < 0) ? (-cc - 1) : cc; cc = (cc >= a.n_cols) ? (2 * a.n_cols - 1 - cc) : cc;
+			const float raw = img[(int64_t)rr * a.row_pitch + cc];
+			x = a.reference ? (float)((double)raw - a.reference[(int64_t)rr * a.n_cols + cc]) : raw;
+			if (!(fabsf(x) <= 3.402823466e+38f)) x = inf;
+		}
+		s_tile[dy * TW + t] = x;
+	}
+	__syncthreads();
+
+	const float sel1 = (g & 1) ? inf : -inf, sel2 = (g & 2) ? inf : -inf, sel4 = (g & 4) ? inf : -inf;
+	// ---- the shared columns: value i = 8 j + g of the 15 x 12 block in raster order, tile column 4 q + 3 + dx
+	float* sa = s_a + q * 72;
+	{
+		constexpr int R = 32;
+		float v[R];
+		int dy = 0, dx = g;
+		const float* base = s_tile + 4 * q + 3;
+#pragma unroll
+		for (int j = 0; j < R; ++j) {
+			float x = inf;
+			if (j < 23) {
+				if (j < 22 || g < 4) x = base[dy * TW + dx];
+				dx += 8;
+				if (dx >= 12) { dx -= 12; dy += 1; }
+			}
+			v[j] = x;
+		}
+		oem_sort<R, 23>(v, std::make_index_sequence<Oem<R>::net.n>());
+		cross_stage<kDppXor1, true, R>(v, sel1);
+		local_merge<R>(v);
+		cross_stage<kDppQuadRev, true, R>(v, sel2);
+		cross_stage<kDppXor1, false, R>(v, sel1);
+		local_merge<R>(v);
+		cross_stage<kDppHalfMirror, true, R>(v, sel4);
+		cross_stage<kDppXor2, false, R>(v, sel2);
+		cross_stage<kDppXor1, false, R>(v, sel1);
+		local_merge<R>(v);
+		if (g == 2 || g == 3) {
+			float* dst = sa + (g - 2) * 36;
+#pragma unroll
+			for (int j = 0; j < R; j += 4) *reinterpret_cast<float4*>(dst + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+		}
+	}
+	// ---- the four pixels: their own three columns (tile columns 4 q + k .. 4 q + 2, then 4 q + 15 .. 4 q + 14 + k), 15 x 3 in
+	// raster order, value i = 8 j + g
+	float* sb = s_b + q * 72;
+	float med4 = 0.f;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		constexpr int R = 8;
+		float v[R];
+#pragma unroll
+		for (int j = 0; j < R; ++j) {
+			const int i = 8 * j + g;
+			float x = inf;
+			if (j < 6 && i < 45) {
+				const int dy = i / 3, e = i - 3 * dy;
+				const int off = (k + e <= 2) ? (k + e) : (12 + k + e);
+				x = s_tile[dy * TW + 4 * q + off];
+			}
+			v[j] = x;
+		}
+		oem_sort<R, 6>(v, std::make_index_sequence<Oem<R>::net.n>());
+		cross_stage<kDppXor1, true, R>(v, sel1);
+		local_merge<R>(v);
+		cross_stage<kDppQuadRev, true, R>(v, sel2);
+		cross_stage<kDppXor1, false, R>(v, sel1);
+		local_merge<R>(v);
+		cross_stage<kDppHalfMirror, true, R>(v, sel4);
+		cross_stage<kDppXor2, false, R>(v, sel2);
+		cross_stage<kDppXor1, false, R>(v, sel1);
+		local_merge<R>(v);
+		__builtin_amdgcn_wave_barrier();          // (the reads of the pixel before are done: LDS operations of a wavefront run in order)
+		*reinterpret_cast<float4*>(sb + 4 + g * 8) = make_float4(v[0], v[1], v[2], v[3]);      // B[r] at sb[4 + r], B[-1] = -inf at sb[3]
+		*reinterpret_cast<float4*>(sb + 8 + g * 8) = make_float4(v[4], v[5], v[6], v[7]);
+		if (g == 0) sb[3] = -inf;
+		__builtin_amdgcn_wave_barrier();
+		// rank 112 of the union: candidates i = 6 g + t
+		float best = inf;
+#pragma unroll
+		for (int t = 0; t < 6; ++t) {
+			const int i = 6 * g + t;
+			if (i <= 45) {
+				const int ra = 112 - i - 64;          // 3 .. 48: rank of the shared list, less the 64 that are not staged
+				const float xa = sa[ra + ((ra >> 5) << 2)];
+				const float xb = sb[3 + i];           // B[i - 1]
+				best = tp_min(best, tp_max(xa, xb));
+			}
+		}
+		best = tp_min(best, dpp_f<kDppXor1>(best));
+		best = tp_min(best, dpp_f<kDppXor2>(best));
+		best = tp_min(best, dpp_f<kDppHalfMirror>(best));
+		med4 = (g == k) ? best : med4;
+	}
+	const int col = col0 + 4 * q + g;
+	if (g < 4 && col < a.n_cols)
+		a.out[(int64_t)frame * a.frame_stride + (int64_t)row * a.row_pitch + col] = (med4 <= 3.402823466e+38f) ? med4 : __builtin_nanf("");
+}
+
 // nanmedian over <= 32 frames per pixel (the "mean shenanigans" blocks of prepare.py:563-575): out[p] += NaN -> 0 of the median.
 // The values of a pixel sit in registers (NaN -> +inf, which sorts last), Batcher's network orders them, and the one or two middle
 // ranks of the n finite ones are picked by a chain of selects: no array is indexed at run time (an insertion sort into a
@@ -1023,7 +1155,10 @@ extern "C" int tp_frames_median_filter(tp_ctx* ctx, const float* d_frames, int32
 	a.row_pitch = row_pitch; a.frame_stride = frame_stride; a.size = size;
 	dim3 grid((unsigned)((frame_cols + 31) / 32), (unsigned)frame_rows, (unsigned)n_frames);
 	const bool fast = frame_rows >= size && frame_cols >= size && size >= 8;
-	if (size == 15 && fast) TP_LAUNCH(ctx, TPK_MEDIAN_FILTER, (tp_median_filter_kernel<29, true>), grid, dim3(256), 0, a);
+	if (size == 15 && fast && !ctx->median_plain) {
+		dim3 grid4((unsigned)((frame_cols + 127) / 128), (unsigned)frame_rows, (unsigned)n_frames);
+		TP_LAUNCH(ctx, TPK_MEDIAN_FILTER, tp_median15_quad_kernel, grid4, dim3(256), 0, a);
+	} else if (size == 15 && fast) TP_LAUNCH(ctx, TPK_MEDIAN_FILTER, (tp_median_filter_kernel<29, true>), grid, dim3(256), 0, a);
 	else if (fast) TP_LAUNCH(ctx, TPK_MEDIAN_FILTER, (tp_median_filter_kernel<32, true>), grid, dim3(256), 0, a);
 	else TP_LAUNCH(ctx, TPK_MEDIAN_FILTER, (tp_median_filter_kernel<32, false>), grid, dim3(256), 0, a);
 	TP_LAUNCH_CHECK(ctx, "tp_median_filter_kernel");

@@ -403,3 +403,27 @@ def test_prepare_pixel_flags_and_headers(ctx):
 		np.testing.assert_allclose(us_t[k], ref_lit, rtol=2e-3)   # literal float32 log10 of numpy: ties of the KDE argmax may flip
 	smooth = np.moveaxis(ob.smooth_time(np.moveaxis(us_t, 0, -1), 3), -1, 0)
 	np.testing.assert_array_equal(res_h['backgrounds'].to_host(), smooth)
+
+
+def test_median_filter_15_shared_columns(ctx):
+	"""The 15 x 15 median filter, four output pixels per sort of their shared columns: frames wider than one workgroup's 128
+	columns with a ragged last block, image edges (reflection) on all sides, runs of +inf / NaN / -inf pixels -- scipy on the
+	same values is the check (non-finite -> +inf, which sorts last; a window whose median is non-finite gives NaN)."""
+	from scipy.ndimage import median_filter
+	rng = np.random.default_rng(21)
+	for (R, C, with_ref) in ((37, 301, True), (15, 15, False), (16, 128, False), (64, 129, True)):
+		img = rng.normal(0, 3, (2, R, C)).astype('float32')
+		img[0, R // 2:, : C // 3] = rng.integers(-2, 3, (R - R // 2, C // 3)).astype('float32')   # many equal values
+		bad = rng.random((2, R, C)) < 0.02
+		img[bad] = rng.choice(np.array([np.nan, np.inf, -np.inf], dtype='float32'), int(bad.sum()))
+		img[1, 3:14, 5:14] = np.nan                                   # a hole larger than half a window
+		ref = rng.normal(0, 1, (R, C)) if with_ref else None
+		out = ctx.empty((2, R, C), 'float32')
+		ctx._check(ctx.lib.tp_frames_median_filter(ctx.handle, ctx.array(img).ptr, 2, R, C, C, R * C, ctx.array(ref).ptr if with_ref else None, 15, out.ptr))
+		got = out.to_host()
+		for k in range(2):
+			x = (img[k].astype('float64') - ref).astype('float32') if with_ref else img[k].copy()
+			x[~np.isfinite(x)] = np.inf
+			want = median_filter(x, size=15)
+			want[~np.isfinite(want)] = np.nan
+			np.testing.assert_array_equal(got[k], want)
