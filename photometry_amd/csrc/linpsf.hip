@@ -40,7 +40,6 @@ using namespace tp_prf;
 using namespace tp_linpsf;
 
 constexpr int kMaxSamples = 32;
-constexpr size_t kCoefScratchBytes = 512 * 9 * sizeof(double);   // tp_linpsf_coef_kernel, matrix-core layout: [thread][9]
 
 //--------------------------------------------------------------------------------------------------
 // P1: per-target blend of the per-sample coefficient tables
@@ -652,7 +651,58 @@ __device__ __forceinline__ void patch_coefficients(const double* __restrict__ C,
 		for (int bcol = 0; bcol < 5; ++bcol) kk[e][bcol] *= h2;
 }
 
-__global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const StarPlan* __restrict__ plans, const int32_t* __restrict__ todo,
+// The same contraction for the `na` consecutive intervals (ax, by), (ax + 1, by) .. along x at once: their 13 x 13 patches are
+// 13 + na - 1 table rows, and the inner sums t = sum_q E[q][b] C[row][by + q] of a row serve every interval that holds the row
+// (2 340 -> 1 560 multiply-adds for two intervals, 3 510 -> 2 100 for three).  Every kk[ca] gets exactly the operations
+// patch_coefficients gives it, in the same order: bit-identical.  Rows ax .. ax + 12 + na - 1 must lie inside the table.
+__device__ __forceinline__ void patch_coefficients_along_x(const double* __restrict__ C, int n, int ax, int by, double h2, int na, double (&kk)[3][5][5])
+{
+#pragma unroll
+	for (int ca = 0; ca < 3; ++ca)
+#pragma unroll
+		for (int e = 0; e < 5; ++e)
+#pragma unroll
+			for (int bcol = 0; bcol < 5; ++bcol) kk[ca][e][bcol] = 0.0;
+	const double* c0 = C + (int64_t)ax * n + by;
+#pragma unroll 1
+	for (int row = 0; row < 12 + na; ++row) {
+		const double* r = c0 + row * n;
+		double rv[13], t[5];
+#pragma unroll
+		for (int q = 0; q < 13; ++q) rv[q] = r[q];
+#pragma unroll
+		for (int bcol = 0; bcol < 5; ++bcol) {
+			double v = 0.0;
+#pragma unroll
+			for (int q = 0; q < 13; ++q) v = __builtin_fma(kEdgePoly[q][bcol], rv[q], v);
+			t[bcol] = v;
+		}
+#pragma unroll
+		for (int ca = 0; ca < 3; ++ca) {
+			const int pp = row - ca;
+			if (ca < na && pp >= 0 && pp < 13) {   // uniform
+				const double e0 = kEdgePoly[pp][0], e1 = kEdgePoly[pp][1], e2 = kEdgePoly[pp][2], e3 = kEdgePoly[pp][3], e4 = kEdgePoly[pp][4];
+#pragma unroll
+				for (int bcol = 0; bcol < 5; ++bcol) {
+					kk[ca][0][bcol] = __builtin_fma(e0, t[bcol], kk[ca][0][bcol]);
+					kk[ca][1][bcol] = __builtin_fma(e1, t[bcol], kk[ca][1][bcol]);
+					kk[ca][2][bcol] = __builtin_fma(e2, t[bcol], kk[ca][2][bcol]);
+					kk[ca][3][bcol] = __builtin_fma(e3, t[bcol], kk[ca][3][bcol]);
+					kk[ca][4][bcol] = __builtin_fma(e4, t[bcol], kk[ca][4][bcol]);
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int ca = 0; ca < 3; ++ca)
+#pragma unroll
+		for (int e = 0; e < 5; ++e)
+#pragma unroll
+			for (int bcol = 0; bcol < 5; ++bcol) kk[ca][e][bcol] *= h2;
+}
+
+constexpr int kCoefThreads = 512;
+__global__ __launch_bounds__(kCoefThreads) void tp_linpsf_coef_kernel(FitArgs a, const StarPlan* __restrict__ plans, const int32_t* __restrict__ todo,
 	double* __restrict__ store, const MPlan* __restrict__ mplans, const uint16_t* __restrict__ ulist, const uint8_t* __restrict__ usig,
 	double* __restrict__ kstore, const SegPlan* __restrict__ segs)
 {
@@ -666,14 +716,15 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 	const double h2 = (a.knots_x[5] - a.knots_x[4]) * (a.knots_y[5] - a.knots_y[4]);
 	{
 		// the whole table in flight at once (up to 39 doubles per thread for the largest table admitted), then into LDS: one round
-		// trip to memory instead of one per slice
+		// trip to memory instead of one per slice.  (A workgroup per CU that walks the targets with the next table on its way in
+		// registers while this one's patches are contracted: 0.85 against 0.76 ms -- 78 more registers, and the targets' work differs.)
 		const double* cg = a.coef + (int64_t)target * n * n;
-		constexpr int kPer = (140 * 140 + 511) / 512;
+		constexpr int kPer = (140 * 140 + kCoefThreads - 1) / kCoefThreads;
 		double tmp[kPer];
 #pragma unroll
-		for (int u = 0; u < kPer; ++u) { const int i = u * 512 + tid; tmp[u] = (i < n * n) ? cg[i] : 0.0; }
+		for (int u = 0; u < kPer; ++u) { const int i = u * kCoefThreads + tid; tmp[u] = (i < n * n) ? cg[i] : 0.0; }
 #pragma unroll
-		for (int u = 0; u < kPer; ++u) { const int i = u * 512 + tid; if (i < n * n) ctab[i] = tmp[u]; }
+		for (int u = 0; u < kPer; ++u) { const int i = u * kCoefThreads + tid; if (i < n * n) ctab[i] = tmp[u]; }
 	}
 	__syncthreads();
 	const double* C = ctab;
@@ -691,97 +742,140 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 		// One thread per (pixel of a tile, knot interval): the 13 x 13 patch of that interval is contracted into its 25
 		// coefficients; the interval (0, 0) writes the steps that hold C[e][d], e <= 4, d < 4, at once, every interval leaves its
 		// K[4][0..4] and K[0..3][4] in LDS, and one thread per pixel then forms the differences and writes the remaining steps.
-		double* scr = ctab + n * n;   // [512][9]
-		// (the table is staged once for all segments of the series: a drifting star costs its extra intervals, not extra table loads)
-		for (int sgi = 0; sgi < mp.n_seg; ++sgi) {
-		const SegPlan sg = segs[(int64_t)target * kMfmaSegs + sgi];
-		for (int s = 0; s < ns; ++s) {
-			const unsigned tiles = mp.tiles[s];
-			const int nt = __popc(tiles);
-			const int na = sg.na[s], nb = sg.nb[s];
-			if (na == 0) continue;
-			const int nk = mfma_steps(na, nb);
-			const int ncell = na * nb;
-			const int chunk = 512 / ncell;            // pixels per round
-			const int nitems = nt * 16;
-			for (int base = 0; base < nitems; base += chunk) {
-				{
-					const int li = tid / ncell, cell = tid - li * ncell;
-					const int item = base + li;
-					if (li < chunk && item < nitems) {
-						const int r = item >> 4, u = item & 15;
-						unsigned m = tiles;
-						for (int q = 0; q < r; ++q) m &= m - 1;          // drop the r lowest set bits
-						const int slot = (__ffs(m) - 1) * 16 + u;
-						const unsigned pix = ul[slot];
-						const int ca = cell / nb, cb = cell - ca * nb;
-						double kk[5][5];
-						if (pix != 0xffffu && ((us[slot] >> s) & 1)) {
-							const int i = (int)pix / a.width, j = (int)pix - i * a.width;
-							int ax = (sg.axmin[s] + ca) + 9 * j, by = (sg.bymin[s] + cb) + 9 * i;
-							ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
-							by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
-							patch_coefficients(C, n, ax, by, h2, kk);
+		// Jobs: one per (segment, star that is on the stamp in it).  A LANE takes one pixel of the star's tiles and one interval
+		// along y, and all na intervals along x (patch_coefficients_along_x); the nb lanes of a pixel are neighbours, so the
+		// differences across y come from the lane below by one shuffle and those across x are the lane's own -- nothing goes
+		// through LDS, and after the table is staged no wavefront waits for another: each takes every (waves)-th unit of 64 / nb
+		// pixels of the job list.  (One thread per (pixel, interval) with the differences formed through LDS between two barriers
+		// per round of 512 threads, a round per star and segment: 1.09 ms per 10 000 targets, 4.4 ms on the drift scene.)
+		struct Job { int na, nb, nt, axmin, bymin, s; unsigned tiles; long long dst; };
+		__shared__ Job s_job[kMfmaSegs * kMfmaStars];
+		__shared__ int s_njobs;
+		if (tid == 0) {
+			int nj = 0;
+			for (int sgi = 0; sgi < mp.n_seg; ++sgi) {
+				const SegPlan sg = segs[(int64_t)target * kMfmaSegs + sgi];
+				for (int s = 0; s < ns; ++s) {
+					if (sg.na[s] == 0) continue;
+					Job j;
+					j.na = sg.na[s]; j.nb = sg.nb[s]; j.nt = __popc(mp.tiles[s]); j.axmin = sg.axmin[s]; j.bymin = sg.bymin[s]; j.s = s;
+					j.tiles = mp.tiles[s]; j.dst = sg.koff + (long long)sg.ksub[s] * 64;
+					s_job[nj++] = j;
+				}
+			}
+			s_njobs = nj;
+		}
+		__syncthreads();
+		const int njobs = s_njobs;
+		const int lane = tid & 63, wave = tid >> 6, nwaves = (int)blockDim.x >> 6;
+		int unit = 0;                              // units of the job list passed so far (uniform)
+		for (int jb = 0; jb < njobs; ++jb) {
+			const Job jq = s_job[jb];
+			const int na = jq.na, nb = jq.nb, nk = mfma_steps(na, nb);
+			const int per = 64 / nb, nitems = jq.nt * 16;
+			const int nunits = (nitems + per - 1) / per;
+			for (int c = 0; c < nunits; ++c, ++unit) {
+				if (unit % nwaves != wave) continue;
+				const int li = lane / nb, cb = lane - li * nb;
+				const int item = c * per + li;
+				const bool mine = li < per && item < nitems;
+				double kk[3][5][5];
+				int r = 0, u = 0;
+				bool reach = false;
+				int ax = 0, by = 0;
+				if (mine) {
+					r = item >> 4; u = item & 15;
+					unsigned m = jq.tiles;
+					for (int q = 0; q < r; ++q) m &= m - 1;          // drop the r lowest set bits
+					const int slot = (__ffs(m) - 1) * 16 + u;
+					const unsigned pix = ul[slot];
+					if (pix != 0xffffu && ((us[slot] >> jq.s) & 1)) {
+						const int i = (int)pix / a.width, j = (int)pix - i * a.width;
+						ax = jq.axmin + 9 * j; by = (jq.bymin + cb) + 9 * i;
+						by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
+						reach = true;
+					}
+				}
+				if (reach && ax >= 0 && ax + na - 1 <= n - 13) {
+					patch_coefficients_along_x(C, n, ax, by, h2, na, kk);
+				} else {
+#pragma unroll
+					for (int ca = 0; ca < 3; ++ca) {
+						if (reach && ca < na) {                  // an interval beyond the table's edge: clamped one by one
+							int axc = ax + ca;
+							axc = axc < 0 ? 0 : (axc > n - 13 ? n - 13 : axc);
+							patch_coefficients(C, n, axc, by, h2, kk[ca]);
 						} else {
 #pragma unroll
 							for (int e = 0; e < 5; ++e)
 #pragma unroll
-								for (int d = 0; d < 5; ++d) kk[e][d] = 0.0;
+								for (int d = 0; d < 5; ++d) kk[ca][e][d] = 0.0;
 						}
-						if (cell == 0) {
-							double* dst = kstore + sg.koff + ((int64_t)sg.ksub[s] + (int64_t)r * nk) * 64 + u;
-#pragma unroll
-							for (int e = 0; e < 5; ++e)
-#pragma unroll
-								for (int g = 0; g < 4; ++g) dst[e * 64 + g * 16] = kk[e][g];
-						}
-						double* sc = scr + tid * 9;
-#pragma unroll
-						for (int d = 0; d < 5; ++d) sc[d] = kk[4][d];
-#pragma unroll
-						for (int e = 0; e < 4; ++e) sc[5 + e] = kk[e][4];
 					}
 				}
-				__syncthreads();
-				if (tid < chunk && base + tid < nitems) {
-					const int item = base + tid;
-					const int r = item >> 4, u = item & 15;
-					auto sc = [&](int ca, int cb, int q) -> double { return (ca < 0 || cb < 0) ? 0.0 : scr[(tid * ncell + ca * nb + cb) * 9 + q]; };
-					// ce[4 + a][d] (d < 4), ce[e][4 + b] (e < 4), ce[4 + a][4 + b]: first differences along the axis that leaves interval 0,
-					// the second difference of K[4][4] off both axes
-					double* dst = kstore + sg.koff + ((int64_t)sg.ksub[s] + (int64_t)r * nk) * 64 + u;
-					int idx = 5;
-					auto corner = [&](int ca, int cb) -> double { return ((sc(ca, cb, 4) - sc(ca - 1, cb, 4)) - sc(ca, cb - 1, 4)) + sc(ca - 1, cb - 1, 4); };
-					if (mfma_is22(na, nb)) {
-						// 9 steps: y basis 4 with x basis 0..3; {x basis 4, 5 with y basis 4, x basis 0, 1 with y basis 5}; x basis 5 with y
-						// basis 0..3; x basis 2..5 with y basis 5
+				// what the lane below (same pixel, interval cb - 1) holds of K[0][0..3][4] and K[ca][4][4]; zero below interval 0
+				double lo_e4[4], lo_44[3];
+#pragma unroll
+				for (int e = 0; e < 4; ++e) { const double v = __shfl_up(kk[0][e][4], 1, 64); lo_e4[e] = (cb > 0) ? v : 0.0; }
+#pragma unroll
+				for (int ca = 0; ca < 3; ++ca) { const double v = __shfl_up(kk[ca][4][4], 1, 64); lo_44[ca] = (cb > 0) ? v : 0.0; }
+				if (!mine) continue;
+				double* dst = kstore + jq.dst + (int64_t)r * nk * 64 + u;
+				// ce[4 + a][d] (d < 4), ce[e][4 + b] (e < 4), ce[4 + a][4 + b]: first differences along the axis that leaves interval 0,
+				// the second difference of K[4][4] off both axes (operations and their order as in the LDS version)
+				auto corner = [&](int ca) -> double {
+					const double here = kk[ca][4][4], left = (ca > 0) ? kk[ca > 0 ? ca - 1 : 0][4][4] : 0.0;
+					const double below = lo_44[ca], diag = (ca > 0) ? lo_44[ca > 0 ? ca - 1 : 0] : 0.0;
+					return ((here - left) - below) + diag;
+				};
+				if (cb == 0) {
+#pragma unroll
+					for (int e = 0; e < 5; ++e)
+#pragma unroll
+						for (int g = 0; g < 4; ++g) dst[e * 64 + g * 16] = kk[0][e][g];
+				}
+				if (mfma_is22(na, nb)) {
+					// 9 steps: y basis 4 with x basis 0..3; {x basis 4, 5 with y basis 4, x basis 0, 1 with y basis 5}; x basis 5 with y
+					// basis 0..3; x basis 2..5 with y basis 5
+					if (cb == 0) {
+#pragma unroll
 						for (int g = 0; g < 4; ++g) {
-							dst[5 * 64 + g * 16] = sc(0, 0, 5 + g);
-							dst[6 * 64 + g * 16] = (g < 2) ? corner(g, 0) : (sc(0, 1, 5 + g - 2) - sc(0, 0, 5 + g - 2));
-							dst[7 * 64 + g * 16] = sc(1, 0, g) - sc(0, 0, g);
-							dst[8 * 64 + g * 16] = (g < 2) ? (sc(0, 1, 5 + 2 + g) - sc(0, 0, 5 + 2 + g)) : corner(g - 2, 1);
+							dst[5 * 64 + g * 16] = kk[0][g][4] - 0.0;
+							dst[7 * 64 + g * 16] = kk[1][4][g] - kk[0][4][g];
 						}
-						idx = 9;
-					} else
-					for (int cb = 0; cb < nb; ++cb) {
-						if (cb == 1) {   // the steps of the x basis functions 5, 6 come between those of y basis function 4 and 5
-							for (int ca = 1; ca < na; ++ca, ++idx)
-								for (int g = 0; g < 4; ++g) dst[idx * 64 + g * 16] = sc(ca, 0, g) - sc(ca - 1, 0, g);
-						}
-						for (int g = 0; g < 4; ++g) {
-							dst[idx * 64 + g * 16] = sc(0, cb, 5 + g) - sc(0, cb - 1, 5 + g);
-							dst[(idx + 1) * 64 + g * 16] = (g < na) ? corner(g, cb) : 0.0;
-						}
-						idx += 2;
+						dst[6 * 64 + 0 * 16] = corner(0);
+						dst[6 * 64 + 1 * 16] = corner(1);
+					} else {
+						dst[6 * 64 + 2 * 16] = kk[0][0][4] - lo_e4[0];
+						dst[6 * 64 + 3 * 16] = kk[0][1][4] - lo_e4[1];
+						dst[8 * 64 + 0 * 16] = kk[0][2][4] - lo_e4[2];
+						dst[8 * 64 + 1 * 16] = kk[0][3][4] - lo_e4[3];
+						dst[8 * 64 + 2 * 16] = corner(0);
+						dst[8 * 64 + 3 * 16] = corner(1);
 					}
-					if (nb == 1) {
-						for (int ca = 1; ca < na; ++ca, ++idx)
-							for (int g = 0; g < 4; ++g) dst[idx * 64 + g * 16] = sc(ca, 0, g) - sc(ca - 1, 0, g);
+				} else {
+					// steps: 5, 6 for y interval 0; 7 .. for the x basis functions 5, 6; then two per further y interval
+					const int ystep = 5 + 2 * cb + ((cb >= 1) ? (na - 1) : 0);
+#pragma unroll
+					for (int g = 0; g < 4; ++g) {
+						dst[ystep * 64 + g * 16] = kk[0][g][4] - lo_e4[g];
+						double cv = 0.0;
+						if (g == 0) cv = corner(0);
+						else if (g == 1 && na > 1) cv = corner(1);
+						else if (g == 2 && na > 2) cv = corner(2);
+						dst[(ystep + 1) * 64 + g * 16] = cv;
+					}
+					if (cb == 0) {
+#pragma unroll
+						for (int ca = 1; ca < 3; ++ca) {
+							if (ca < na) {
+#pragma unroll
+								for (int g = 0; g < 4; ++g) dst[(6 + ca) * 64 + g * 16] = kk[ca][4][g] - kk[ca - 1][4][g];
+							}
+						}
 					}
 				}
-				__syncthreads();
 			}
-		}
 		}
 		return;
 	}
@@ -792,7 +886,7 @@ __global__ __launch_bounds__(512) void tp_linpsf_coef_kernel(FitArgs a, const St
 		const int nitems = p.nc * ncols * nrows;
 		// one thread per item: the 13 x 13 patch of the table is read once and contracted into all 25 coefficients (the sums
 		// run over q inside, over p outside)
-		for (int item = tid; item < nitems; item += 512) {
+		for (int item = tid; item < nitems; item += kCoefThreads) {
 			const int pix = item / p.nc, co = item - pix * p.nc;
 			const int ii = pix / ncols, jj = pix - ii * ncols;
 			const int cx = co / p.nby, cy = co - cx * p.nby;
@@ -1504,9 +1598,9 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	int sort_n = 64;
 	while (sort_n < desc->n_cad) sort_n <<= 1;
 	if (sort_n > 8192) sort_n = 0;
-	// the matrix-core path needs the table AND the exchange area of its coefficient kernel in LDS, and 32-bit element offsets
+	// the matrix-core path needs the table in LDS (beside the job list of its coefficient kernel), and 32-bit element offsets
 	// into a target's cube
-	const int use_mfma = (ctx->linpsf_path == 1 && (size_t)n_coef_axis * n_coef_axis * sizeof(double) + kCoefScratchBytes <= 160 * 1024
+	const int use_mfma = (ctx->linpsf_path == 1 && (size_t)n_coef_axis * n_coef_axis * sizeof(double) + 2048 <= 160 * 1024   // (2 KB: the kernel's job table)
 		&& (int64_t)desc->height * desc->width * desc->t_pitch < (1ll << 30)) ? 1 : 0;
 	fa.todo = use_mfma ? d_todo : nullptr;
 	TP_HIP(ctx, hipMemsetAsync(d_todo, 0, todo_bytes, ctx->stream));
@@ -1540,9 +1634,9 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	}
 	double* d_store = static_cast<double*>(ctx->store);
 	double* d_kstore = d_store + poly_doubles;
-	const size_t coef_lds = (size_t)n_coef_axis * n_coef_axis * sizeof(double) + (use_mfma ? kCoefScratchBytes : 0);
+	const size_t coef_lds = (size_t)n_coef_axis * n_coef_axis * sizeof(double);
 	TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_coef_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coef_lds));
-	TP_LAUNCH(ctx, TPK_LINPSF_COEF, tp_linpsf_coef_kernel, dim3((unsigned)desc->n_targets), dim3(512), coef_lds, a, (const StarPlan*)d_plans, (const int32_t*)d_todo, d_store,
+	TP_LAUNCH(ctx, TPK_LINPSF_COEF, tp_linpsf_coef_kernel, dim3((unsigned)desc->n_targets), dim3(kCoefThreads), coef_lds, a, (const StarPlan*)d_plans, (const int32_t*)d_todo, d_store,
 		(const MPlan*)d_mplans, (const uint16_t*)d_ulist, (const uint8_t*)d_usig, d_kstore, (const SegPlan*)d_segs);
 	TP_LAUNCH_CHECK(ctx, "tp_linpsf_coef_kernel");
 	// the matrix-core fit of the targets marked for it (up to 4 stars, up to 256 reachable pixels)
