@@ -62,7 +62,7 @@ constexpr int kBox = 2 * kHalfBox + 1;
 // of 7, 9, 11 ... 11, 9, 7 offsets, 109 in all.  (Round 3 cached all 121: 24.2 KB a set; 21.8 KB now, and with the image and weight
 // map kept in float32 and the knots read from global memory a one- or two-star target needs 48 KB of LDS instead of 56: three
 // workgroups per CU instead of two.)
-__device__ constexpr int kRowHalf[kBox] = {3, 4, 5, 5, 5, 5, 5, 5, 5, 4, 3};
+// (row widths 2 * {3, 4, 5, 5, 5, 5, 5, 5, 5, 4, 3} + 1: row_half below)
 __device__ constexpr int kRowStart[kBox] = {0, 7, 16, 27, 38, 49, 60, 71, 82, 93, 102};
 constexpr int kItems = 109;
 
@@ -74,53 +74,87 @@ constexpr int kPool = 6;                         // most cached coefficient sets
 // round 2 -- more rebuilds, fewer idle CUs (measured, tools/psf_time.py).
 __host__ __device__ constexpr int psf_pool(int ns) { return ns < 2 ? 2 : (ns > kPool ? kPool : ns); }
 
-struct StarW { double row, col, flux, phx, phy; int jstar, istar, ax0, by0, valid, rebuild, slot, next; };
+#ifdef TP_LAB_PSF_CLOCK
+// lab build only (tools/lab/build_variants.sh): cycles of the phases of an evaluation / an iteration, summed by thread 0
+__device__ long long g_clk[8];
+#define LAB_T0 long long lab_t0 = clock64()
+#define LAB_ADD(i) do { const long long lab_t1 = clock64(); if (threadIdx.x == 0 && blockIdx.x == 0) g_clk[i] += lab_t1 - lab_t0; lab_t0 = lab_t1; } while (0)
+#else
+#define LAB_T0 do {} while (0)
+#define LAB_ADD(i) do {} while (0)
+#endif
+
+// width and first item of row r = di + 5 of the cached item set (kRowHalf / kRowStart as arithmetic: a table indexed by a
+// lane's own di is a load from memory in front of every pixel)
+__device__ __forceinline__ int row_half(int di) { const int m = (di < 0 ? -di : di) - 3; return 5 - (m > 0 ? m : 0); }
+__device__ __forceinline__ int row_start(int r) { return (r == 0) ? 0 : ((r == 1) ? 7 : ((r == 10) ? 102 : (16 + 11 * (r - 2)))); }
+
+// the parameters of one star as an evaluation needs them: in REGISTERS of every thread (each thread works them out itself from
+// the parameter vector and the knots in LDS -- round 3 had one thread per star do it and publish them through LDS behind a
+// barrier: a quarter of an iteration, tools/lab lab clocks)
+struct StarR { double row, col, flux, phx, phy; int jstar, istar, slot, valid; };
 
 // everything an evaluation needs besides the parameter vector
 struct EvalCtx {
 	int ns, n, H, W, pool; double h, hy, cutoff;
 	const double* Cg;            // the target's coefficient table in HBM
-	const double* kn; const double* kny;   // the knot vectors (global memory: read by the first threads only, cached)
+	const double* kn; const double* kny;   // the knot vectors (LDS)
 	const float* img; const float* wgt;    // float32 as psf_photometry.py:75-86 computes them
-	StarW* sw; double* Kc; double* red; int* keys;   // keys[kPool][2]: the knot intervals of every cached set
+	double* Kc; double* red; int* keys;    // keys[kPool][2]: the knot intervals of every cached set; red[2][4]
+	int* nxt; int* rbs;                    // per star: the set of its share that is replaced next; the set to rebuild now (-1: none)
 };
 
-// star parameters of x (every thread gets them through LDS); a star whose knot intervals differ from its cached ones gets
-// its polynomial coefficients rebuilt
-__device__ void prepare_stars(const double* x, const EvalCtx& c)
+// Star parameters of x for every thread; a star whose knot intervals are in none of its cached sets gets the oldest one rebuilt
+// (the only case with barriers: the cache state changes).  Same arithmetic, same replacement order as before.
+template <int NS>
+__device__ __forceinline__ void prepare_stars(const double* x, const EvalCtx& c, StarR (&st)[NS])
 {
 	const int tid = threadIdx.x;
-	if (tid < c.ns) {
-		StarW& s = c.sw[tid];
-		s.row = x[3 * tid]; s.col = x[3 * tid + 1]; s.flux = x[3 * tid + 2];
-		const bool vx = axis_phase(c.kn, c.n, s.col, c.h, s.phx, s.ax0);     // x <-> column (first spline axis), y <-> row (psf.py:146)
-		const bool vy = axis_phase(c.kny, c.n, s.row, c.hy, s.phy, s.by0);
-		s.valid = (vx && vy) ? 1 : 0;
-		s.jstar = s.valid ? (int)rint(s.col) : 0;
-		s.istar = s.valid ? (int)rint(s.row) : 0;
+	LAB_T0;
+	const int per = c.pool / NS;
+	bool miss = false;
+	int kxs[NS], kys[NS];
+#pragma unroll
+	for (int s = 0; s < NS; ++s) {
+		st[s].row = x[3 * s]; st[s].col = x[3 * s + 1]; st[s].flux = x[3 * s + 2];
+		int ax0, by0;
+		const bool vx = axis_phase(c.kn, c.n, st[s].col, c.h, st[s].phx, ax0);     // x <-> column (first spline axis), y <-> row (psf.py:146)
+		const bool vy = axis_phase(c.kny, c.n, st[s].row, c.hy, st[s].phy, by0);
+		st[s].valid = (vx && vy) ? 1 : 0;
+		st[s].jstar = st[s].valid ? (int)rint(st[s].col) : 0;
+		st[s].istar = st[s].valid ? (int)rint(st[s].row) : 0;
 		// the knot intervals, free of the pixel the star sits in: first = (l - 3) - 9 * jstar
-		const int kx = s.ax0 + 9 * s.jstar, ky = s.by0 + 9 * s.istar;
-		// the star's share of the pool: sets [tid * per, (tid + 1) * per); a hit anywhere in it, else the oldest is replaced
-		const int per = c.pool / c.ns;
-		s.rebuild = 0;
-		if (s.valid) {
-			int hit = -1;
-			for (int e = 0; e < per; ++e) { const int* k2 = c.keys + 2 * (tid * per + e); if (k2[0] == kx && k2[1] == ky) hit = tid * per + e; }
-			if (hit < 0) {
-				hit = tid * per + s.next;
-				s.next = (s.next + 1 == per) ? 0 : (s.next + 1);
-				c.keys[2 * hit] = kx; c.keys[2 * hit + 1] = ky;
-				s.rebuild = 1;
+		kxs[s] = ax0 + 9 * st[s].jstar; kys[s] = by0 + 9 * st[s].istar;
+		// the star's share of the pool: sets [s * per, (s + 1) * per); a hit anywhere in it, else the oldest is replaced
+		int hit = -1;
+		for (int e = 0; e < per; ++e) { const int* k2 = c.keys + 2 * (s * per + e); if (k2[0] == kxs[s] && k2[1] == kys[s]) hit = s * per + e; }
+		st[s].slot = hit;
+		miss = miss || (st[s].valid && hit < 0);
+	}
+	LAB_ADD(0);
+	if (!miss) return;                         // uniform: every thread read the same simplex and the same keys
+	__syncthreads();                           // ... and has read them
+#pragma unroll
+	for (int s = 0; s < NS; ++s) {
+		if (tid == s) {
+			int rb = -1;
+			if (st[s].valid && st[s].slot < 0) {
+				rb = s * per + c.nxt[s];
+				c.nxt[s] = (c.nxt[s] + 1 == per) ? 0 : (c.nxt[s] + 1);
+				c.keys[2 * rb] = kxs[s]; c.keys[2 * rb + 1] = kys[s];
 			}
-			s.slot = hit;
+			c.rbs[s] = rb;
 		}
 	}
 	__syncthreads();
 	const double h2 = c.h * c.hy;
-	for (int s = 0; s < c.ns; ++s) {
-		if (!c.sw[s].rebuild) continue;   // uniform
-		const int kx = c.keys[2 * c.sw[s].slot], ky = c.keys[2 * c.sw[s].slot + 1];
-		double* K = c.Kc + (size_t)c.sw[s].slot * kItems * 25;
+#pragma unroll
+	for (int s = 0; s < NS; ++s) {
+		const int rb = c.rbs[s];
+		if (rb < 0) continue;   // uniform
+		st[s].slot = rb;
+		const int kx = kxs[s], ky = kys[s];
+		double* K = c.Kc + (size_t)rb * kItems * 25;
 		// two threads per item: one contracts columns 0..2 of the 25 coefficients, the other columns 3..4, each with one pass over
 		// the item's 13 x 13 patch of the table (round 3: a thread per (item, column) = five passes per item; the table is read
 		// from L2 and those reads, ~0.7 MB per rebuild, were what the kernel waited for)
@@ -129,7 +163,7 @@ __device__ void prepare_stars(const double* x, const EvalCtx& c)
 			int r = 0;
 #pragma unroll
 			for (int q = 1; q < kBox; ++q) r += (item >= kRowStart[q]) ? 1 : 0;
-			const int di = r - kHalfBox, dj = (item - kRowStart[r]) - kRowHalf[r];
+			const int di = r - kHalfBox, dj = (item - row_start(r)) - row_half(di);
 			int ax = kx + 9 * dj, by = ky + 9 * di;
 			ax = ax < 0 ? 0 : (ax > c.n - 13 ? c.n - 13 : ax);
 			by = by < 0 ? 0 : (by > c.n - 13 ? c.n - 13 : by);
@@ -151,48 +185,60 @@ __device__ void prepare_stars(const double* x, const EvalCtx& c)
 		}
 	}
 	__syncthreads();
+	LAB_ADD(1);
 }
 
 // sum over the stars of flux * pixel-integrated PRF at pixel (i, j)
-__device__ __forceinline__ double model_pixel(int i, int j, const EvalCtx& c)
+template <int NS>
+__device__ __forceinline__ double model_pixel(int i, int j, const EvalCtx& c, const StarR (&st)[NS])
 {
 	double mdl = 0.0;
-	for (int s = 0; s < c.ns; ++s) {
-		const StarW& st = c.sw[s];
-		if (!st.valid) continue;
-		const int di = i - st.istar, dj = j - st.jstar;
+#pragma unroll
+	for (int s = 0; s < NS; ++s) {
+		if (!st[s].valid) continue;
+		const int di = i - st[s].istar, dj = j - st[s].jstar;
 		if (di < -kHalfBox || di > kHalfBox) continue;
-		const int half = kRowHalf[di + kHalfBox];
+		const int half = row_half(di);
 		if (dj < -half || dj > half) continue;          // offsets outside the cached set are never inside the cut-off
-		const double dc = (double)j - st.col, dr = (double)i - st.row;
+		const double dc = (double)j - st[s].col, dr = (double)i - st[s].row;
 		if (sqrt(dc * dc + dr * dr) < c.cutoff)     // psf.py:142 (a NaN position is never inside)
-			mdl += st.flux * poly_eval(c.Kc + ((size_t)st.slot * kItems + kRowStart[di + kHalfBox] + (dj + half)) * 25, st.phx, st.phy);
+			mdl += st[s].flux * poly_eval(c.Kc + ((size_t)st[s].slot * kItems + row_start(di + kHalfBox) + (dj + half)) * 25, st[s].phx, st[s].phy);
 	}
 	return mdl;
 }
 
-// chi^2 of the parameter vector x (psf_photometry.py:52-90); all threads call it, all get the same value
-__device__ double likelihood(const double* x, const EvalCtx& c)
+// chi^2 of the parameter vector x (psf_photometry.py:52-90); all threads call it, all get the same value.  One barrier: the
+// partial sums of the wavefronts alternate between two places (`flip`), so the next evaluation never writes what a slower
+// wavefront still reads.
+template <int NS>
+__device__ double likelihood(const double* x, const EvalCtx& c, int& flip)
 {
 	const int tid = threadIdx.x;
-	prepare_stars(x, c);
+	StarR st[NS];
+	prepare_stars<NS>(x, c, st);
+	LAB_T0;
 	double acc = 0.0;
 	for (int p = tid; p < c.H * c.W; p += kThreads) {
 		const int i = p / c.W, j = p - i * c.W;
-		const double r = (double)c.img[p] - model_pixel(i, j, c);
+		const double r = (double)c.img[p] - model_pixel<NS>(i, j, c, st);
 		const double term = (double)c.wgt[p] * (r * r);
 		if (term == term) acc += term;                  // nansum
 	}
+	LAB_ADD(2);
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-	if ((tid & 63) == 0) c.red[tid >> 6] = acc;
+	double* red = c.red + 4 * flip;
+	flip ^= 1;
+	if ((tid & 63) == 0) red[tid >> 6] = acc;
 	__syncthreads();
-	const double tot = (c.red[0] + c.red[1]) + (c.red[2] + c.red[3]);
-	__syncthreads();   // red and sw are reused by the next evaluation
+	const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+	LAB_ADD(3);
 	return tot;
 }
 
 // `targets`: the targets of this launch (all with the same number of fitted stars, so that `pool` sets are what each needs)
+// NS: the number of fitted stars of the launch's targets (0: the targets without one)
+template <int NS>
 __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const int32_t* __restrict__ targets, int pool)
 {
 	extern __shared__ __align__(16) double lds[];
@@ -203,19 +249,21 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 	double* fsim = sim + (kMaxDim + 1) * kMaxDim;   // [D+1]
 	double* xt = fsim + (kMaxDim + 1);        // trial points: xbar, xr, xe / xc [3][kMaxDim]
 	double* x0 = xt + 3 * kMaxDim;            // warm start [kMaxDim]
-	double* red = x0 + kMaxDim;               // [8]
-	double* Kc = red + 8;                     // [kPool][kItems][25] cached polynomial coefficients
-	StarW* sw = reinterpret_cast<StarW*>(Kc + (size_t)pool * kItems * 25);
-	int* keys = reinterpret_cast<int*>(sw + kMaxPsfStars);   // [pool][2]
-	float* img = reinterpret_cast<float*>(keys + 2 * kPool);  // [P]
+	double* red = x0 + kMaxDim;               // [2][4] partial sums of the evaluations, [8] the convergence test's
+	double* kn = red + 16;                    // [n + 4] knots of the first spline axis (every evaluation reads a few: LDS, not L2)
+	double* kny = kn + (n + 4);               // [n + 4]
+	double* Kc = kny + (n + 4);               // [kPool][kItems][25] cached polynomial coefficients
+	int* keys = reinterpret_cast<int*>(Kc + (size_t)pool * kItems * 25);   // [kPool][2]
+	int* nxt = keys + 2 * kPool;              // [kMaxPsfStars]
+	int* rbs = nxt + kMaxPsfStars;            // [kMaxPsfStars]
+	float* img = reinterpret_cast<float*>(rbs + kMaxPsfStars + 1);  // [P]   (2 kPool + 2 kMaxPsfStars + 1 ints: 4-byte aligned is enough)
 	float* wgt = img + P;                     // [P]
-	const double* kn = a.knots_x; const double* kny = a.knots_y;
-	if (tid < kMaxPsfStars) { sw[tid].rebuild = 0; sw[tid].valid = 0; sw[tid].slot = 0; sw[tid].next = 0; }
+	for (int q = tid; q < n + 4; q += kThreads) { kn[q] = a.knots_x[q]; kny[q] = a.knots_y[q]; }
+	if (tid < kMaxPsfStars) { nxt[tid] = 0; rbs[tid] = -1; }
 	if (tid < 2 * pool) keys[tid] = -0x7fffffff;
 	const int64_t s0 = a.star_offsets[target];
-	int ns = (int)(a.star_offsets[target + 1] - s0);
-	if (ns > kMaxPsfStars) ns = kMaxPsfStars;
-	const int D = 3 * ns;
+	constexpr int ns = NS;   // (the host lists a target with more than five stars with the five-star ones: the first five are fitted)
+	constexpr int D = 3 * ns;
 	if (tid < D) x0[tid] = a.params0[s0 * 3 + tid];
 	__syncthreads();
 	const double h = kn[5] - kn[4], hy = kny[5] - kny[4];
@@ -229,8 +277,9 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 	}
 	EvalCtx ec;
 	ec.ns = ns; ec.n = n; ec.H = H; ec.W = W; ec.pool = pool; ec.h = h; ec.hy = hy; ec.cutoff = a.cutoff;
-	ec.Cg = a.coef + (int64_t)target * n * n; ec.kn = kn; ec.kny = kny; ec.img = img; ec.wgt = wgt; ec.sw = sw; ec.Kc = Kc; ec.red = red; ec.keys = keys;
-#define EVAL(xp) likelihood((xp), ec)
+	ec.Cg = a.coef + (int64_t)target * n * n; ec.kn = kn; ec.kny = kny; ec.img = img; ec.wgt = wgt; ec.Kc = Kc; ec.red = red; ec.keys = keys; ec.nxt = nxt; ec.rbs = rbs;
+	int flip = 0;
+#define EVAL(xp) likelihood<(NS > 0 ? NS : 1)>((xp), ec, flip)
 	for (int k = 0; k < a.n_cad; ++k) {
 		// ---- the cadence's image and weight map (float32 arithmetic of psf_photometry.py:75-86)
 		const float* ip = a.images + (int64_t)target * P * a.t_pitch + k;
@@ -268,18 +317,12 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 			if (anynan) {
 				// NaN does not order: replay the insertion sort itself, one thread
 				if (tid == 0) {
+					// (insertion by adjacent swaps: the same final order as numpy's insertion sort, and no per-thread array)
 					for (int i = 1; i <= D; ++i) {
-						const double fv = fsim[i];
-						double tmp[kMaxDim];
-						for (int d = 0; d < D; ++d) tmp[d] = sim[i * kMaxDim + d];
-						int j = i - 1;
-						while (j >= 0 && fsim[j] > fv) {
-							fsim[j + 1] = fsim[j];
-							for (int d = 0; d < D; ++d) sim[(j + 1) * kMaxDim + d] = sim[j * kMaxDim + d];
-							--j;
+						for (int j = i - 1; j >= 0 && fsim[j] > fsim[j + 1]; --j) {
+							const double f0 = fsim[j]; fsim[j] = fsim[j + 1]; fsim[j + 1] = f0;
+							for (int d = 0; d < D; ++d) { const double v0 = sim[j * kMaxDim + d]; sim[j * kMaxDim + d] = sim[(j + 1) * kMaxDim + d]; sim[(j + 1) * kMaxDim + d] = v0; }
 						}
-						fsim[j + 1] = fv;
-						for (int d = 0; d < D; ++d) sim[(j + 1) * kMaxDim + d] = tmp[d];
 					}
 				}
 				__syncthreads();
@@ -302,6 +345,9 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 		};
 		sort_simplex();
 		int iterations = 1;
+#ifdef TP_LAB_PSF_CLOCK
+		const long long lab_loop0 = clock64();
+#endif
 		while (iterations < maxiter) {
 			// max |sim[1:] - sim[0]| and max |fsim[0] - fsim[1:]| (a NaN makes the maximum NaN, as numpy's does)
 			double dx = 0.0, df = 0.0;
@@ -315,17 +361,17 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 				if (ox > dx || ox != ox) dx = ox;
 				if (of > df || of != of) df = of;
 			}
-			__syncthreads();   // red is free (the last evaluation has returned everywhere)
-			if ((tid & 63) == 0) { red[tid >> 6] = dx; red[4 + (tid >> 6)] = df; }
+			// (its own eight words: the evaluations' partial sums live elsewhere, and between two tests lies at least one barrier)
+			double* red2 = red + 8;
+			if ((tid & 63) == 0) { red2[tid >> 6] = dx; red2[4 + (tid >> 6)] = df; }
 			__syncthreads();
-			dx = red[0]; df = red[4];
+			dx = red2[0]; df = red2[4];
 #pragma unroll
 			for (int w = 1; w < 4; ++w) {
-				const double ox = red[w], of = red[4 + w];
+				const double ox = red2[w], of = red2[4 + w];
 				if (ox > dx || ox != ox) dx = ox;
 				if (of > df || of != of) df = of;
 			}
-			__syncthreads();   // red is reused by the evaluations
 			if (dx <= 1e-4 && df <= 1e-4) break;
 			double* xbar = xt; double* xr = xt + kMaxDim; double* xn = xt + 2 * kMaxDim;
 			if (tid < D) {
@@ -334,18 +380,22 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 				xbar[tid] = sacc / (double)D;
 				xr[tid] = 2.0 * xbar[tid] - sim[D * kMaxDim + tid];
 			}
+			// the values the decisions below compare with are taken NOW: the thread that accepts a point overwrites fsim[D] while
+			// slower wavefronts may still be deciding (fxcc < fsim[D] read after that write sends them into the shrink branch: a race
+			// the barrier that used to end every evaluation hid but did not exclude)
+			const double f_best = fsim[0], f_second_worst = fsim[D - 1], f_worst = fsim[D];
 			__syncthreads();
 			const double fxr = EVAL(xr);
 			bool doshrink = false;
 			const double* take = nullptr; double ftake = 0.0;
-			if (fxr < fsim[0]) {
+			if (fxr < f_best) {
 				if (tid < D) xn[tid] = 3.0 * xbar[tid] - 2.0 * sim[D * kMaxDim + tid];
 				__syncthreads();
 				const double fxe = EVAL(xn);
 				if (fxe < fxr) { take = xn; ftake = fxe; } else { take = xr; ftake = fxr; }
-			} else if (fxr < fsim[D - 1]) {
+			} else if (fxr < f_second_worst) {
 				take = xr; ftake = fxr;
-			} else if (fxr < fsim[D]) {
+			} else if (fxr < f_worst) {
 				if (tid < D) xn[tid] = 1.5 * xbar[tid] - 0.5 * sim[D * kMaxDim + tid];
 				__syncthreads();
 				const double fxc = EVAL(xn);
@@ -354,7 +404,7 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 				if (tid < D) xn[tid] = 0.5 * xbar[tid] + 0.5 * sim[D * kMaxDim + tid];
 				__syncthreads();
 				const double fxcc = EVAL(xn);
-				if (fxcc < fsim[D]) { take = xn; ftake = fxcc; } else doshrink = true;
+				if (fxcc < f_worst) { take = xn; ftake = fxcc; } else doshrink = true;
 			}
 			if (doshrink) {
 				if (tv >= 1 && tv <= D && td < D) sim[tv * kMaxDim + td] = sim[td] + 0.5 * (sim[tv * kMaxDim + td] - sim[td]);
@@ -372,24 +422,30 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 			sort_simplex();
 			++iterations;
 		}
+#ifdef TP_LAB_PSF_CLOCK
+		if (tid == 0 && blockIdx.x == 0) { g_clk[4] += clock64() - lab_loop0; g_clk[5] += iterations; }
+#endif
 		const bool success = iterations < maxiter;
 		// ---- result of the cadence (psf_photometry.py:157-196)
 		double flux_ap = 0.0;
 		if (success) {
 			// residuals in the mini aperture: one more model evaluation at the solution
-			prepare_stars(sim, ec);
+			StarR st[NS > 0 ? NS : 1];
+			prepare_stars<(NS > 0 ? NS : 1)>(sim, ec, st);
 			double acc = 0.0;
 			for (int p = tid; p < P; p += kThreads) {
 				if (!mini[p]) continue;
 				const int i = p / W, j = p - i * W;
-				const double r = (double)img[p] - model_pixel(i, j, ec);
+				const double r = (double)img[p] - model_pixel<(NS > 0 ? NS : 1)>(i, j, ec, st);
 				if (r == r) acc += r;
 			}
 #pragma unroll
 			for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-			if ((tid & 63) == 0) red[tid >> 6] = acc;
+			double* redf = red + 4 * flip;
+			flip ^= 1;
+			if ((tid & 63) == 0) redf[tid >> 6] = acc;
 			__syncthreads();
-			flux_ap = (red[0] + red[1]) + (red[2] + red[3]);
+			flux_ap = (redf[0] + redf[1]) + (redf[2] + redf[3]);
 		}
 		if (tid == 0) {
 			a.flux[ob + k] = success ? (sim[2] + flux_ap) : nan;
@@ -407,6 +463,12 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 }
 
 } // namespace
+
+#ifdef TP_LAB_PSF_CLOCK
+extern "C" int tp_lab_psf_clocks(long long* out) {
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(long long) * 8);
+}
+#endif
 
 extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images, const float* d_backgrounds,
 	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis,
@@ -427,8 +489,8 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
 	const size_t P = (size_t)desc->height * desc->width;
 	auto lds_bytes = [&](int pool) {
-		const size_t doubles = (kMaxDim + 1) * kMaxDim + (kMaxDim + 1) + 3 * kMaxDim + kMaxDim + 8 + (size_t)pool * kItems * 25;
-		return doubles * sizeof(double) + kMaxPsfStars * sizeof(StarW) + 2 * kPool * sizeof(int) + 2 * P * sizeof(float) + 16;
+		const size_t doubles = (kMaxDim + 1) * kMaxDim + (kMaxDim + 1) + 3 * kMaxDim + kMaxDim + 16 + 2 * ((size_t)n_coef_axis + 4) + (size_t)pool * kItems * 25;
+		return doubles * sizeof(double) + (2 * kPool + 2 * kMaxPsfStars + 1) * sizeof(int) + 2 * P * sizeof(float) + 16;
 	};
 	TP_REQUIRE(ctx, lds_bytes(kPool) <= 160 * 1024, "tp_psf_fit: stamp too large for the LDS-resident image and weight map");
 	// the targets by their number of fitted stars (one launch each, see psf_pool): the star offsets come to the host once
@@ -450,7 +512,6 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 	a.var_floor = (float)variance_floor; a.cutoff = cutoff_radius; a.maxiter_first = maxiter_first; a.maxiter = maxiter;
 	a.flux = d_flux; a.flux_err = d_flux_err; a.cen_row = d_centroid_row; a.cen_col = d_centroid_col; a.out_pitch = out_pitch;
 	a.params_out = d_params_out; a.nit = d_nit; a.status = d_status;
-	TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_psf_fit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(kPool)));
 	// the launches are independent: the context's stream and two side streams in turn, so that their tails overlap (every launch
 	// ends with a few long-running workgroups on an otherwise idle chip)
 	hipStream_t streams[3] = {ctx->stream, nullptr, nullptr};
@@ -479,8 +540,22 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 		const int pool = psf_pool(ns);
 		const int si = used++ % 3;
 		if (!waited[si]) { err = hipStreamWaitEvent(streams[si], before, 0); waited[si] = true; if (err != hipSuccess) break; }
-		TP_LAUNCH_ON(ctx, streams[si], TPK_PSF_FIT, tp_psf_fit_kernel, dim3((unsigned)lists[ns].size()), dim3(kThreads), lds_bytes(pool), a, (const int32_t*)(d_lists + first), pool);
-		err = hipGetLastError();
+#define TP_PSF_LAUNCH(NSV) do { \
+			err = hipFuncSetAttribute(reinterpret_cast<const void*>(tp_psf_fit_kernel<NSV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(pool)); \
+			if (err == hipSuccess) { \
+				TP_LAUNCH_ON(ctx, streams[si], TPK_PSF_FIT, tp_psf_fit_kernel<NSV>, dim3((unsigned)lists[ns].size()), dim3(kThreads), lds_bytes(pool), a, (const int32_t*)(d_lists + first), pool); \
+				err = hipGetLastError(); \
+			} \
+		} while (0)
+		switch (ns) {
+			case 0: TP_PSF_LAUNCH(0); break;
+			case 1: TP_PSF_LAUNCH(1); break;
+			case 2: TP_PSF_LAUNCH(2); break;
+			case 3: TP_PSF_LAUNCH(3); break;
+			case 4: TP_PSF_LAUNCH(4); break;
+			default: TP_PSF_LAUNCH(5); break;
+		}
+#undef TP_PSF_LAUNCH
 	}
 	// the lists (host vectors, device copy) must outlive the copies and the launches
 	for (int i = 2; i >= 0; --i) if (waited[i]) (void)hipStreamSynchronize(streams[i]);

@@ -40,3 +40,19 @@ dt = time.perf_counter() - t0
 nit = res['nit'].to_host()
 print(f'{Nt} targets x {T} cadences, {offs[-1]} fitted stars: {dt*1e3:.1f} ms = {Nt/dt:.0f} targets/s; mean iterations {nit.mean():.0f}; '
 	f'{dt / max(nit.sum(), 1) * 1e9:.0f} ns per simplex iteration')
+if os.environ.get('STATS'):
+	ns_of = np.diff(np.asarray(offs))
+	tot = nit[:, :T].sum(axis=1)
+	print('total iterations', int(tot.sum()), '; slots 768 -> ideal share per slot', int(tot.sum() / 768))
+	for k in range(1, 6):
+		sel = ns_of == k
+		if sel.any():
+			print(f'  {k} stars: {int(sel.sum())} targets, iterations per target: mean {tot[sel].mean():.0f}, max {tot[sel].max():.0f}, share of all iterations {tot[sel].sum() / tot.sum():.2f}')
+if os.environ.get('TP_LAB_LIB') and os.environ.get('CLOCKS'):
+	import ctypes
+	buf = (ctypes.c_longlong * 8)()
+	ctx.lib.tp_lab_psf_clocks(buf)
+	c = list(buf)
+	it = max(c[5], 1)
+	print('workgroup 0 of every launch, both calls: iterations', c[5], '; cycles per iteration (100 MHz clock64 ticks x 24 at 2.4 GHz?):')
+	print('  loop total %.0f; prepare %.0f, rebuild %.0f, pixels %.0f, reduce %.0f ticks per iteration' % (c[4] / it, c[0] / it, c[1] / it, c[2] / it, c[3] / it))
