@@ -7,7 +7,7 @@ OUT=$REPO/gpurun_out/counters_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for M in MeanOccupancyPerCU VALUBusy SALUBusy LdsBankConflict MemUnitStalled VALUUtilization; do
-	rocprofv3 --pmc $M --output-format csv -d $OUT/$M -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --e2e-targets 0 --frames-targets 0 --frame 512 --psf-targets 0 --fullframe-frames 0 --linpsf-drift 0 > $OUT/$M.json 2> $OUT/$M.log
+	rocprofv3 --pmc $M --output-format csv -d $OUT/$M -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --e2e-targets 0 --frames-targets 0 --frame 512 --psf-targets 0 --fullframe-frames 4 --linpsf-drift 0 > $OUT/$M.json 2> $OUT/$M.log
 done
 cd $REPO
 python3 - "$OUT" <<'PY' > $OUT/summary.txt 2>&1
