@@ -18,16 +18,29 @@
 // Late in a fit the simplex is far smaller than a knot interval (1/9 pixel) and nothing is rebuilt: 24 FMAs and 25 LDS reads
 // per star and pixel instead of the 169 table reads + ~230 flops of the direct contraction (round 2's first version, which
 // was LDS-bandwidth bound with the 110 KB table resident).
-// Round 4, measured (tools/psf_time.py, 4 096 targets x 50 cadences, 31-32 ns per simplex iteration chip-wide before and after):
-//  * ONE WAVEFRONT per target (no barrier at all, reductions by xor shuffles, the bookkeeping 64 pairs at a time) was built and
-//    dropped: 181 ns against 94 at 512 targets -- what was spread over 256 threads (the pixels of an evaluation, the 218 work
-//    items of a rebuild) takes four times as long per target, and the LDS of the cached sets lets a CU hold three such targets,
-//    not the eight the wavefronts would allow;
+// Round 4, measured (tools/psf_time.py, 4 096 targets x 50 cadences; lab clocks of a workgroup's phases, counters: tools/lab/psf_counters.sh):
+//  * the kernel is a set of CHAINS: a three-star target takes 26 000 iterations (the reference's maxiter is reached at nearly
+//    every cadence: nine parameters do not converge in 500 Nelder-Mead steps), 917 such targets on 512 slots are two rounds of
+//    that chain, and the chip idles around them (0.9 wavefronts per SIMD on average, vector ALUs 14 % busy): what counts is the
+//    latency of ONE iteration of ONE workgroup.  Where that went for a one-star target: 26 % one thread per star deriving the
+//    star parameters (two dependent reads of the knots from L2, the result published through LDS behind a barrier), 24 % set
+//    rebuilds, 15 % the pixels, 9 % the reduction, 27 % simplex bookkeeping.
+//  * now: every thread derives the star parameters itself from the parameter vector and the knots in LDS (registers, no LDS
+//    record, no barrier unless a set has to be rebuilt), the partial sums of an evaluation alternate between two places (one
+//    barrier per evaluation instead of four), one kernel instantiation per star count: 32 -> 29 ns per simplex iteration
+//    chip-wide, one-star targets 23 -> 15, two-star 28 -> 25.
+//  * a RACE this uncovered (and the old kernel had, hidden by the barrier that ended every evaluation): the thread that accepts
+//    a point overwrites fsim[D] while slower wavefronts may still be comparing with it (fxcc < fsim[D]) -- those then shrink
+//    instead of accepting and the workgroup falls apart.  The decisions now compare with copies taken before the evaluation
+//    (tests/test_gpu_psfphot.py::test_psf_fit_is_reproducible; the old kernel gave one target 17 834 iterations where 5 902 are right).
+//  * built and dropped: ONE WAVEFRONT per target (181 ns against 94 at 512 targets: the pixels of an evaluation and the 218 work
+//    items of a rebuild take four times as long, and the LDS of the cached sets lets a CU hold three such targets, not eight);
+//    168 registers for three workgroups per CU (one- and two-star classes alone 10 % faster, the mix 1.82 s against 1.61: the
+//    three-star chains that decide the run share their CUs with more neighbours); wave priority for the three-star class (no
+//    change); three cached sets for a one-star target (+2 %); the accepted point handed to the sort and the convergence test
+//    sharing the centroid's barrier (two barriers fewer per iteration: no gain -- barriers are not what an iteration waits for).
 //  * 11.6 % of the star evaluations miss their cached sets (0.33 rebuilds per simplex iteration: a simplex that straddles a knot
-//    in both axes alternates between four interval pairs); without rebuilds an iteration takes 21 ns: a third of the time is
-//    the four dependent rounds of table reads of a rebuild (the tables of the targets in flight, 110 KB each, do not fit L2);
-//  * three workgroups per CU instead of two (the compact item set, the float32 image) and 2.5 x fewer table reads per rebuild
-//    (poly_columns) change nothing: neither occupancy nor L2 traffic bounds it, the latency of a workgroup's own chain does.
+//    in both axes alternates between four interval pairs); a rebuild is four dependent rounds of table reads from L2.
 // The simplex search is scipy 1.7.3's `_minimize_neldermead` step for step (non-adaptive coefficients 1, 2, 0.5, 0.5; initial
 // simplex 5 % / 0.00025; termination xatol = fatol = 1e-4; `success` = finished before maxiter; stable ordering of ties).
 #include "common.h"

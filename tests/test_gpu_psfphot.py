@@ -150,3 +150,37 @@ def test_psf_fit_batch_equals_target_by_target(ctx):
 			ctx.array(np.array([0, len(params[i])], dtype='int64')), ctx.array(params[i]), ctx.array(mini[i][None]))
 		for k in ('flux', 'centroid_row', 'centroid_col', 'nit'):
 			np.testing.assert_array_equal(one[k].to_host()[0][:T], whole[k][i][:T], err_msg=f'target {i} ({counts[i]} stars) {k}')
+
+
+def test_psf_fit_is_reproducible(ctx):
+	"""Two runs of the same batch give the same bits: iteration counts, fluxes, centroids.  (Until round 4 the thread that accepted a
+	simplex point overwrote fsim[D] while slower wavefronts of the workgroup could still be comparing with it -- a spurious shrink
+	step now and then, different from run to run: 256 targets x 6 cadences showed it in every run once the barrier that ended
+	every likelihood evaluation was gone, and rarely before.)"""
+	from photometry_amd import simulate, engine, psf as hpsf
+	from photometry_amd.device import DeviceCube
+	from photometry_amd.plugins import psf_star_selection, mag2flux
+	Nt, T, H, W = 256, 6, 15, 15
+	s = simulate.make_scene(Nt, T, H, W, seed=7)
+	simulate.fill_cubes(s, nan_fraction=0.001)
+	prf = simulate.synthetic_prf(seed=1)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	offs, params, mini = [0], [], []
+	for i in range(Nt):
+		c = s.catalog_of(i)
+		sel = psf_star_selection(c['row_stamp'], c['column_stamp'], c['tmag'], s.target_pos_row[i] - s.stamps[i][0], s.target_pos_column[i] - s.stamps[i][2], s.target_tmag[i])
+		params.append(np.column_stack((c['row_stamp'][sel].astype('float64'), c['column_stamp'][sel].astype('float64'), mag2flux(c['tmag'][sel].astype('float64')))))
+		offs.append(offs[-1] + len(sel))
+		m = np.zeros((H, W), dtype='uint8'); m[5:10, 5:10] = 1
+		mini.append(m)
+	assert len(set(np.diff(offs))) >= 3
+	coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(model.weights(s.stamps)))
+	args = (DeviceCube.from_host(ctx, s.images), DeviceCube.from_host(ctx, s.backgrounds), coef, ctx.array(model.tx), ctx.array(model.ty),
+		ctx.array(np.asarray(offs, dtype='int64')), ctx.array(np.concatenate(params)), ctx.array(np.stack(mini)))
+	runs = []
+	for _ in range(3):
+		r = engine.psf_fit(ctx, *args)
+		runs.append({k: r[k].to_host()[:, :T].copy() for k in ('flux', 'centroid_row', 'centroid_col', 'nit')})
+	for other in runs[1:]:
+		for k in ('nit', 'flux', 'centroid_row', 'centroid_col'):
+			np.testing.assert_array_equal(other[k], runs[0][k], err_msg=k)
