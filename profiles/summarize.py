@@ -44,6 +44,26 @@ for f in find('trace/**/*kernel_stats.csv'):
 			if 'tp_' in r.get('Name', ''):
 				print(f"{short(r['Name']):64s} calls={r.get('Calls'):>4s} avg_ns={r.get('AverageNs'):>12s} total_ns={r.get('TotalDurationNs'):>14s} pct={r.get('Percentage')}")
 
+# the step kernels dispatch by dispatch (kernel trace): the --stats average above includes the untimed warm-up steps, whose
+# launches are slower (the first ones of the process); bench.py's own HIP events cover the timed steps only -- the same launches
+# as the last `steps` rows here
+print("== the step's kernels, every launch in order (ms; rocprofv3 --kernel-trace), and the mean of the timed steps ==")
+try:
+	timed = int(json.load(open(os.path.join(out, 'bench_trace.json')))['steps'])
+except Exception: # noqa: B902
+	timed = 0
+for f in find('trace/**/*kernel_trace.csv'):
+	per = defaultdict(list)
+	with open(f) as fh:
+		for r in csv.DictReader(fh):
+			n = short(r.get('Kernel_Name', ''))
+			if n.startswith(('tp_bkg_stamp_sum_kernel', 'tp_aperture_fused_kernel<2, true, true, 1, false>')):
+				per[n].append((int(r['Start_Timestamp']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6))
+	for n, v in per.items():
+		d = [x[1] for x in sorted(v)]
+		tail = d[-timed:] if timed and len(d) >= timed else d
+		print(f"{n:64s} {' '.join('%.3f' % x for x in d)}   mean of the last {len(tail)}: {sum(tail) / len(tail):.3f}")
+
 means = defaultdict(dict)
 for counter, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write')):
 	acc = defaultdict(list)
