@@ -50,6 +50,8 @@ __global__ __launch_bounds__(256) void tp_aperture_kernel(Args a)
 	__syncthreads();
 	const int M = s_M;
 	if (M > kMaxList) return; // handled by tp_aperture_big_kernel
+	pack_rows(s_list, M, a.width, tid, (int)blockDim.x);
+	__syncthreads();
 	extract_small<VEC>(a, target, s_list, M, blockIdx.x * blockDim.x + tid, gridDim.x * blockDim.x);
 }
 

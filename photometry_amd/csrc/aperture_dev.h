@@ -140,6 +140,13 @@ __device__ __forceinline__ int compact_mask(const uint8_t* m, int P, int& p_next
 	return n < cap ? n : cap;
 }
 
+// The pixel list of the two small-mask extractions carries a pixel's row beside its index (index in the low, row in the high 16
+// bits; a stamp holds at most 65 535 pixels): the extraction turns every list entry into (row, column) once per cadence block,
+// and a division by the run-time stamp width is ~30 instructions -- a third of the vector work of a pixel (lab clocks, round 4).
+__device__ __forceinline__ void pack_rows(int* list, int M, int width, int lane, int nlanes) {
+	for (int i = lane; i < M; i += nlanes) { const int p = list[i]; list[i] = p | ((p / width) << 16); }
+}
+
 // Extraction of the cadences q_first, q_first + q_stride, ... (VEC cadences each) of one target with a mask of
 // M <= kMaxList pixels listed (raster order) in s_list: a single pairwise leaf.
 template <int VEC>
@@ -165,7 +172,8 @@ __device__ __forceinline__ void extract_small(const Args& a, int target, const i
 		if (a.subtract) Vec<VEC>::load(a.subtract + (int64_t)target * a.subtract_pitch + k0, ssub);
 
 		auto fetch = [&](int idx, float (&v)[VEC], float (&e2)[VEC], float (&y)[VEC]) {
-			const int p = s_list[idx];
+			const int pk = s_list[idx];
+			const int p = pk & 0xffff;
 			const int64_t off = (int64_t)p * a.t_pitch + k0;
 			float ee[VEC], bb[VEC];
 			Vec<VEC>::load(img + off, v);
@@ -179,7 +187,7 @@ __device__ __forceinline__ void extract_small(const Args& a, int target, const i
 #pragma unroll
 				for (int c = 0; c < VEC; c++) bb[c] = (a.bkg_mode == 1) ? bser[c] : 0.f;
 			}
-			const int pr = p / a.width;
+			const int pr = (int)((unsigned)pk >> 16);
 			const int pc = p - pr * a.width;
 #pragma unroll
 			for (int c = 0; c < VEC; c++) e2[c] = ee[c] * ee[c];
@@ -238,7 +246,11 @@ __device__ __forceinline__ void extract_small_stream(const Args& a, int target, 
 	const int P = a.height * a.width;
 	const int col0 = a.stamps[target * 4 + 2] + 1;
 	const int row0 = a.stamps[target * 4 + 0] + 1;
+#ifdef TP_LAB_A6_SAMEROWS
+	const int64_t tb = (int64_t)(target & 63) * P * a.t_pitch;   // lab: 64 targets' cubes serve all (L2-resident): what A6 costs without HBM
+#else
 	const int64_t tb = (int64_t)target * P * a.t_pitch;
+#endif
 	const float* img = a.images + tb;
 	const float* err = a.images_err + tb;
 	constexpr bool BKG_CUBE = (BKG == 0), BKG_SERIES = (BKG == 1), HAS_BKG = (BKG != 2);
@@ -274,7 +286,7 @@ __device__ __forceinline__ void extract_small_stream(const Args& a, int target, 
 		for (int j = 0; j < 8; j++) {
 			int idx = g * 8 + j;
 			idx = (idx < M) ? idx : (M - 1);
-			const int64_t off = (int64_t)s_list[idx] * a.t_pitch + k0;
+			const int64_t off = (int64_t)(s_list[idx] & 0xffff) * a.t_pitch + k0;
 			Vec<VEC>::load(img + off, B.v[j]);
 			Vec<VEC>::load(err + off, B.e[j]);
 			if (BKG_CUBE) Vec<VEC>::load(bkg + off, B.b[j]);
@@ -289,8 +301,9 @@ __device__ __forceinline__ void extract_small_stream(const Args& a, int target, 
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
 			if (j < cnt) {
-				const int p = s_list[g * 8 + j];
-				const int pr = p / a.width;
+				const int pk = s_list[g * 8 + j];
+				const int p = pk & 0xffff;
+				const int pr = (int)((unsigned)pk >> 16);
 				const int pc = p - pr * a.width;
 				float v[VEC], e2[VEC], bb[VEC], y[VEC];
 #pragma unroll

@@ -34,10 +34,23 @@
 #define K2P2_LANES_SECTION 1
 #include K2P2_LANES_HEADER
 #undef K2P2_LANES_SECTION
+#ifndef TP_NO_UNROLL
+#define TP_NO_UNROLL
+#endif
+#ifndef TP_ALWAYS_INLINE
+#define TP_ALWAYS_INLINE inline
+#endif
+#ifndef TP_CLK
+#define TP_CLK_DECL do {} while (0)
+#define TP_CLK_BEGIN do {} while (0)
+#define TP_CLK(i) do {} while (0)
+#define TP_CLK_FLUSH do {} while (0)
+#endif
 
 namespace k2p2 {
 
 constexpr int kGrid = 128;          // KDE FFT grid: gridsize=100 -> next power of two (kde.py kdensityfft)
+static_assert(kGrid == 128, "the bit reversal of the KDE transform is written for seven bits");
 constexpr double kMadToSigma = 1.482602218505602;   // photometry/utilities.py:25
 constexpr double kPi = 3.141592653589793;
 
@@ -101,6 +114,7 @@ typedef int16_t lab_t;
 struct Shared {
 	int lane;
 	int P, Pp, H, W;
+	uint32_t wmagic;  // ceil(2^32 / W): row of a pixel index by one multiplication (exact for indices and widths below 2^16)
 	double* S;        // [P]
 	double* srt;      // [Pp] sorted positive fluxes (+inf padding)
 	double* Z;        // [P]
@@ -108,7 +122,7 @@ struct Shared {
 	double* tmp;      // [P]
 	double* hval;     // [max(64, P/2 + 1)] per-lane scratch / the watershed's rank -> pixel table (int32)
 	double* red;      // [64]
-	double* grid;     // [kGrid + 132]: binned (later dens), Yre[66], Yim[66]
+	double* grid;     // [kGrid + 132]: real parts [kGrid] (the binned counts, in the end the density), imaginary parts [kGrid] of the KDE's transforms
 	lab_t* lab;       // [P] DBSCAN labels
 	lab_t* lab2;      // [P] labels after watershed
 	lab_t* mark;      // [P] markers / component labels
@@ -145,7 +159,7 @@ inline TP_HD SharedLayout shared_layout(int P) {
 	while (L.Pp_sort < P) L.Pp_sort <<= 1;
 	const size_t Pa = (size_t)L.Pa;
 	L.off_region = (2 * Pa + 64) * 8;                                   // S, tmp, red
-	const size_t phase1 = ((size_t)L.Pp + 3 * kGrid + 132) * 8;        // srt, grid (binned = dens [kGrid], Yre[66], Yim[66]), twiddle copy [2*kGrid]
+	const size_t phase1 = ((size_t)L.Pp + 3 * kGrid + 132) * 8;        // srt, grid (real and imaginary parts of the KDE's in-place transforms), twiddle copy [2*kGrid]
 	L.hval_len = (Pa / 2 + 1 > 64) ? (Pa / 2 + 1) : 64;
 	const size_t phase2 = (2 * Pa + (size_t)L.hval_len) * 8 + 4 * Pa * sizeof(lab_t); // Z, dist, hval | lab, lab2, mark, wsout
 	L.region_bytes = ((phase1 > phase2 ? phase1 : phase2) + 15) & ~(size_t)15;
@@ -162,6 +176,7 @@ inline TP_DEV void shared_carve(Shared& k, void* base, int H, int W, int lane, c
 	const SharedLayout L = shared_layout(P);
 	const int Pa = L.Pa;
 	k.lane = lane; k.P = P; k.Pp = L.Pp_sort; k.H = H; k.W = W; k.twid = twid;
+	k.wmagic = (W > 1) ? (uint32_t)((0x100000000ull + (uint64_t)W - 1) / (uint64_t)W) : 0u;
 	unsigned char* b0 = (unsigned char*)base;
 	double* d = (double*)b0;
 	k.S = d; d += Pa;
@@ -204,6 +219,10 @@ inline TP_DEV void shared_carve(Shared& k, void* base, int H, int W, int lane, c
 inline TP_DEV double tp_inf() { return __builtin_inf(); }
 inline TP_DEV double tp_nan() { return __builtin_nan(""); }
 inline TP_DEV bool tp_isnan(double x) { return x != x; }
+// p / W for 0 <= p < 2^16 (stamps hold at most 65 535 pixels): floor(p / W) = (p * ceil(2^32 / W)) >> 32 exactly, because the
+// error term p * (ceil(2^32 / W) * W - 2^32) stays below 2^32.  (A division by a run-time W is ~30 instructions, and every phase
+// of the builder converts pixel indices to rows and columns.)
+inline TP_DEV int row_of(const Shared& k, int p) { return (k.W > 1) ? (int)(((uint64_t)(uint32_t)p * (uint64_t)k.wmagic) >> 32) : p; }
 
 inline TP_DEV double tp_pow2(int e) { // 2^e for -1022 <= e <= 1023
 	union { uint64_t u; double d; } c;
@@ -253,6 +272,9 @@ inline TP_DEV double tp_exp(double x) {
 //--------------------------------------------------------------------------------------------------
 // Bitonic sort of k.srt[0..Pp) ascending (NaN-free input; +inf padding).
 inline TP_DEV void bitonic_sort(Shared& k) {
+#ifdef TP_HAVE_WAVE_SORT
+	if (k.Pp <= 256) { wave_sort_256(k); return; }   // the device's lane layer sorts small stamps in registers
+#endif
 	const int n = k.Pp;
 	for (int size = 2; size <= n; size <<= 1) {
 		for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -466,6 +488,7 @@ inline TP_DEV double powell_mode(Shared& k, int nc, double h, double x0) {
 // Returns 0 ok, or an ERR_* code; fills diag[0..5] and leaves CUT in *cut (may be NaN).
 inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, double* cut) {
 	const int P = k.P;
+	TP_CLK_BEGIN;
 
 	// Flux = S[~isnan(S)]; Flux = Flux[Flux > 0]   (k2p2v2.py:394-395) -> compacted in raster order
 	TP_LANE_LOOP(l) {
@@ -481,6 +504,7 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 	TP_PAR_FOR(p, k.Pp) k.srt[p] = (p < P && k.S[p] > 0.0) ? k.S[p] : tp_inf();
 	TP_SYNC();
 	bitonic_sort(k);
+	TP_CLK(0);
 	// count of finite entries == nflux unless some flux is +inf (kept, as numpy would)
 	// trim1(sorted, 0.15): keep the n - int(0.15 n) smallest (scipy/stats trim1, tail='right')
 	int nc = nflux - (int)(0.15 * (double)nflux);
@@ -517,6 +541,7 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 	}
 	if (nc == 0) bw = tp_nan();
 	if (bw == 0.0) return ERR_BANDWIDTH_ZERO;
+	TP_CLK(1);
 
 	// --- kdensityfft: linear binning on a 128-point grid, Silverman transform, inverse transform
 	double max_guess;
@@ -526,7 +551,7 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 		const double b = ((nc > 0) ? k.srt[nc - 1] : tp_nan()) + 3.0 * bw;
 		const double delta = (b - a) / (double)(M - 1);   // np.linspace retstep
 		const double RANGE = b - a;
-		double* binned = k.grid; double* dens = k.grid; double* Yre = k.grid + M; double* Yim = k.grid + M + 66; // dens overwrites binned (dead after the forward transform)
+		double* binned = k.grid; double* dens = k.grid; double* fre = k.grid; double* fim = k.grid + M; // the transforms work in place: dens overwrites binned
 		// the DFT twiddles next to the grids (LDS) for the two transforms below
 		TP_PAR_FOR(j, 2 * M) k.twl[j] = k.twid[j];
 		// fast_linbin: bin m accumulates, in data order, (1 - rem) from points with li == m and rem from li == m-1.
@@ -563,34 +588,58 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 			}
 		}
 		TP_SYNC();
-		// forward real DFT (Y = rfft(binned)), k = 0..M/2
-		TP_PAR_FOR(kk, M / 2 + 1) {
-			double re = 0.0, im = 0.0;
-			for (int n = 0; n < M; ++n) {
-				const int j = (kk * n) & (M - 1);
-				re += binned[n] * k.twl[j];
-				im -= binned[n] * k.twl[M + j];
+		// zstar = silverman_transform * forrt(binned), density = revrt(zstar): statsmodels' kdensityfft takes numpy's rfft / irfft.
+		// Here: a radix-2 complex FFT of the M real counts in place -- decimation in frequency forward (natural order in,
+		// bit-reversed out), the Silverman factors applied where the coefficients lie, decimation in time back (bit-reversed in,
+		// natural order out): no permutation pass, 2 x 7 stages of 64 butterflies, one per lane.  (The two O(M^2) sums this
+		// replaces were a sixth of the mask builder's time, tools/k2p2_timing.py.)  Only the argmax of the density is read
+		// (k2p2v2.py:420), so the summation order is free.
+		TP_PAR_FOR(j, M) fim[j] = 0.0;
+		TP_SYNC();
+		TP_NO_UNROLL   // (unrolled seven times the stages cost 476 bytes of scratch per lane and the fused kernel its third wavefront per SIMD)
+		for (int lg = 6; lg >= 0; --lg) {   // half-length h = 2^lg of the butterflies: 64 .. 1
+			const int h = 1 << lg;
+			TP_PAR_FOR(bf, M / 2) {
+				const int i = ((bf & ~(h - 1)) << 1) | (bf & (h - 1));
+				const int tw = (bf & (h - 1)) << (6 - lg);
+				const double ar = fre[i], ai = fim[i], br = fre[i + h], bi = fim[i + h];
+				const double wr = k.twl[tw], wi = -k.twl[M + tw];          // e^{-2 pi i tw / M}
+				const double dr = ar - br, di = ai - bi;
+				fre[i] = ar + br; fim[i] = ai + bi;
+				fre[i + h] = dr * wr - di * wi; fim[i + h] = dr * wi + di * wr;
 			}
-			// zstar = silverman_transform * forrt(binned): FAC[k] * Y[k] / M
+			TP_SYNC();
+		}
+		// FAC[k] * Y[k] / M at the bit-reversed position of k; the spectrum of real data is Hermitian (k and M - k), and the
+		// imaginary parts of k = 0 and k = M / 2 do not enter a real inverse transform
+		TP_PAR_FOR(pos, M) {
+			int kk = 0;
+			for (int q = 0; q < 7; ++q) kk = (kk << 1) | ((pos >> q) & 1);   // M = 128: seven bits
+			const int jj = (kk <= M / 2) ? kk : (M - kk);
 			const double FAC1 = 2.0 * ((kPi * bw / RANGE) * (kPi * bw / RANGE));
-			const double J = (double)kk;
+			const double J = (double)jj;
 			const double BC = 1.0 - 1.0 / 3.0 * ((J * 1.0 / (double)M * kPi) * (J * 1.0 / (double)M * kPi));
 			const double FAC = tp_exp(-(J * J * FAC1)) / BC;
-			Yre[kk] = FAC * (re / (double)M);
-			Yim[kk] = FAC * (im / (double)M);
+			fre[pos] = FAC * (fre[pos] / (double)M);
+			fim[pos] = (kk == 0 || kk == M / 2) ? 0.0 : FAC * (fim[pos] / (double)M);
 		}
 		TP_SYNC();
-		// revrt: irfft(Z) * M  ->  f[m] = Z0 + 2 sum_{k=1}^{M/2-1} Re(Z_k e^{+2 pi i k m / M}) + Z_{M/2} (-1)^m
-		TP_PAR_FOR(m, M) {
-			double f = Yre[0];
-			for (int kk = 1; kk < M / 2; ++kk) {
-				const int j = (kk * m) & (M - 1);
-				f += 2.0 * (Yre[kk] * k.twl[j] - Yim[kk] * k.twl[M + j]);
+		TP_NO_UNROLL
+		for (int lg = 0; lg <= 6; ++lg) {
+			const int h = 1 << lg;
+			TP_PAR_FOR(bf, M / 2) {
+				const int i = ((bf & ~(h - 1)) << 1) | (bf & (h - 1));
+				const int tw = (bf & (h - 1)) << (6 - lg);
+				const double wr = k.twl[tw], wi = k.twl[M + tw];           // e^{+2 pi i tw / M}
+				const double br = fre[i + h], bi = fim[i + h];
+				const double tr = br * wr - bi * wi, ti = br * wi + bi * wr;
+				const double ar = fre[i], ai = fim[i];
+				fre[i] = ar + tr; fim[i] = ai + ti;
+				fre[i + h] = ar - tr; fim[i + h] = ai - ti;
 			}
-			f += Yre[M / 2] * ((m & 1) ? -1.0 : 1.0);
-			dens[m] = f;
+			TP_SYNC();
 		}
-		TP_SYNC();
+		// (dens = fre: the real part, in natural order)
 		// support[argmax(density)]: np.argmax returns the first maximum, NaN counts as maximum
 		// (two grid points per lane, then the tree picks the larger value / the smaller index on ties)
 		TP_LANE_LOOP(l) {
@@ -616,7 +665,9 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 		TP_SYNC();
 	}
 
+	TP_CLK(2);
 	const double MODE = powell_mode(k, nc, bw, max_guess);
+	TP_CLK(3);
 
 	// MAD1 = mad_to_sigma * nanmedian(|Flux[Flux < MODE] - MODE|)   (k2p2v2.py:424)
 	// Flux sorted ascending: the selection is the prefix [0, c)
@@ -638,6 +689,7 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 	const double MAD1 = kMadToSigma * med;
 	const double CUT = MODE + prm.thresh * MAD1;
 	*cut = CUT;
+	TP_CLK(4);
 	if (t.diag) {
 		TP_SERIAL { t.diag[0] = CUT; t.diag[1] = MODE; t.diag[2] = MAD1; t.diag[3] = bw; t.diag[4] = max_guess; }
 	}
@@ -660,7 +712,7 @@ inline TP_DEV int label_components(Shared& k, const uint8_t* in, lab_t* out, boo
 			for (int p = l; p < P; p += 64) {
 				int cur = out[p];
 				if (cur < 0) continue;
-				const int r = p / W, c = p - r * W;
+				const int r = row_of(k, p), c = p - r * W;
 				int best = cur;
 				for (int dr = -1; dr <= 1; ++dr) {
 					for (int dc = -1; dc <= 1; ++dc) {
@@ -772,13 +824,13 @@ inline TP_DEV int saturated_one(Shared& k) {
 			// imax = nanargmax(S * mask * column_mask) over the whole image (first maximum in raster order)
 			int imax = -1; double best = 0.0;
 			for (int p = 0; p < P; ++p) {
-				const int pr = p / W, pc = p - pr * W;
+				const int pr = row_of(k, p), pc = p - pr * W;
 				const double v = k.S[p] * (double)(k.msk[p] ? 1 : 0) * (double)(pc == c ? 1 : 0);
 				if (tp_isnan(v)) continue;
 				if (imax < 0 || v > best) { best = v; imax = p; }
 			}
 			if (imax >= 0) {
-				const int ir = imax / W, ic = imax - ir * W;
+				const int ir = row_of(k, imax), ic = imax - ir * W;
 				// add_to_mask = idx & column; keep the 4-connected (vertical) run containing imax
 				if (ic == c && k.idx[imax]) {
 					int r0 = ir, r1 = ir;
@@ -813,7 +865,7 @@ inline TP_DEV void gaussian_blur(Shared& k, const Params& prm, const double* in,
 	const double w0 = prm.gauss_w0, w1 = prm.gauss_w1, w2 = prm.gauss_w2;
 	// axis 0 (rows) -> tmp
 	TP_PAR_FOR(p, P) {
-		const int r = p / W, c = p - r * W;
+		const int r = row_of(k, p), c = p - r * W;
 		double v = in[p] * w0;
 		v += (in[reflect_idx(r - 1, H) * W + c] + in[reflect_idx(r + 1, H) * W + c]) * w1;
 		v += (in[reflect_idx(r - 2, H) * W + c] + in[reflect_idx(r + 2, H) * W + c]) * w2;
@@ -821,7 +873,7 @@ inline TP_DEV void gaussian_blur(Shared& k, const Params& prm, const double* in,
 	}
 	TP_SYNC();
 	TP_PAR_FOR(p, P) {
-		const int r = p / W, c = p - r * W;
+		const int r = row_of(k, p), c = p - r * W;
 		double v = k.tmp[p] * w0;
 		v += (k.tmp[r * W + reflect_idx(c - 1, W)] + k.tmp[r * W + reflect_idx(c + 1, W)]) * w1;
 		v += (k.tmp[r * W + reflect_idx(c - 2, W)] + k.tmp[r * W + reflect_idx(c + 2, W)]) * w2;
@@ -915,7 +967,7 @@ inline TP_DEV void watershed(Shared& k, int nmark) {
 			if (bits == 0u) { if (w < 32) sum0 &= ~(1u << w); else if (w < 64) sum1 &= ~(1u << (w - 32)); else sum2 &= ~(1u << (w - 64)); }
 			const int px = ord[w * 32 + b];
 			const int lbl = k.wsout[px];
-			const int r = px / W, c = px - r * W;
+			const int r = row_of(k, px), c = px - r * W;
 			// the four neighbours: every LDS read first (independent, one latency), then the decisions and the writes.
 			// Two neighbours are never the same pixel, so reading ahead does not change the sequential semantics.
 			const int nbr[4] = {r - 1, r, r, r + 1};
@@ -957,8 +1009,11 @@ inline TP_DEV float mags_total_f32(const float* tmag, const uint8_t* sel, int n)
 }
 
 // Returns the STATUS integer; on return k.res holds the final mask (what was written to t.mask).
-inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
+// (always inlined into its kernels: as a call -- which the inliner chooses once the body passes its size threshold -- it costs a
+// stack frame in scratch memory and the fused kernel its register allocation)
+TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 	const int P = k.P, H = k.H, W = k.W;
+	TP_CLK_DECL;
 	TP_PAR_FOR(p, P) { k.S[p] = t.S[p]; k.res[p] = 0; }
 	TP_SYNC();
 	int flags = 0;
@@ -971,6 +1026,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 	double CUT = tp_nan();
 	if (t.cut_override) { CUT = *t.cut_override; if (t.diag) { TP_SERIAL { t.diag[0] = CUT; } } }
 	else err = threshold(k, prm, t, &CUT);
+	TP_CLK_BEGIN;
 
 	// target pixel (photometry.py:107): Python round() = round-half-even; negative indices wrap
 	int tr = (int)rint(t.tpos_row - (double)t.stamp_row0);
@@ -1003,7 +1059,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 		} else {
 			// ---------------- A3: DBSCAN on the grid ----------------
 			TP_PAR_FOR(p, P) {
-				const int r = p / W, c = p - r * W;
+				const int r = row_of(k, p), c = p - r * W;
 				int cnt = 0;
 				for (int dr = -1; dr <= 1; ++dr) for (int dc = -1; dc <= 1; ++dc) {
 					const int rr = r + dr, cc = c + dc;
@@ -1020,7 +1076,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 					v = -1;
 					if (k.core[p]) v = k.mark[p] - 1;
 					else {
-						const int r = p / W, c = p - r * W;
+						const int r = row_of(k, p), c = p - r * W;
 						int best = 0x7fffffff;
 						for (int dr = -1; dr <= 1; ++dr) for (int dc = -1; dc <= 1; ++dc) {
 							const int rr = r + dr, cc = c + dc;
@@ -1036,6 +1092,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 			}
 			TP_SYNC();
 
+			TP_CLK(5);
 			// ---------------- A4: watershed per cluster (segmentation=True, any cluster) ----------------
 			// Labels after k2p2WS: non-core -> noise (k2p2v2.py:112)
 			TP_PAR_FOR(p, P) k.lab2[p] = (k.idx[p]) ? ((k.core[p]) ? k.lab[p] : -1) : -2;
@@ -1046,6 +1103,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 				TP_PAR_FOR(p, P) k.msk[p] = (k.lab[p] == lab) ? 1 : 0;
 				TP_SYNC();
 				const int nsat = saturated_one(k);
+				TP_CLK(6);
 				// Z = flux on the core pixels of this cluster
 				TP_PAR_FOR(p, P) k.Z[p] = (k.lab2[p] == lab) ? k.S[p] : 0.0;
 				TP_SYNC();
@@ -1064,7 +1122,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 				TP_LANE_LOOP(l) {
 					int allpk = 1;
 					for (int p = l; p < P; p += 64) {
-						const int r = p / W, c = p - r * W;
+						const int r = row_of(k, p), c = p - r * W;
 						double m = 0.0; // mode='constant', cval=0: out-of-image neighbours count as 0
 						bool first = true;
 						for (int dr = -1; dr <= 1; ++dr) for (int dc = -1; dc <= 1; ++dc) {
@@ -1092,6 +1150,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 				TP_SYNC();
 				const int npeaks = sum_ired(k);
 				TP_SYNC();
+				TP_CLK(7);
 				// peaks matched to catalog stars (k2p2v2.py:144-153); candidates stay in lmax, selection in sat? no:
 				// selection goes to k.core-independent temp: reuse wsout as "selected" flags
 				TP_PAR_FOR(p, P) k.wsout[p] = 0;
@@ -1102,12 +1161,13 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 				TP_SYNC();
 				TP_PAR_FOR(p, P) if (k.lmax[p]) { const int slot = TP_ATOMIC_INC(&k.scal[3]); k.hpix[slot] = p; }
 				TP_SYNC();
+				TP_CLK(12);
 				TP_PAR_FOR(s, t.ncat) {
 					const double c0 = (double)t.cat_col[s], c1 = (double)t.cat_row[s];
 					int bi = -1; double bd = 0.0, bint = 0.0;
 					for (int e = 0; e < npeaks; ++e) {
 						const int p = k.hpix[e];
-						const int r = p / W, c = p - r * W;
+						const int r = row_of(k, p), c = p - r * W;
 						const double dx = (double)c - c0, dy = (double)r - c1;
 						const double d = sqrt(dx * dx + dy * dy);
 						// np.argmin over the peaks sorted by decreasing intensity (stable: raster order among equal
@@ -1133,8 +1193,10 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 					}
 				}
 				TP_SYNC();
+				TP_CLK(16);
 				TP_PAR_FOR(p, P) k.lmax[p] = k.wsout[p] ? 1 : 0; // local_maxi
 				TP_SYNC();
+				TP_CLK(13);
 				// de-duplicate maxima inside saturated patches (k2p2v2.py:193-212)
 				if (nsat > 0) {
 					const int ncomp = label_components(k, k.sat, k.mark, false);
@@ -1163,8 +1225,10 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 						}
 					}
 				}
+				TP_CLK(14);
 				// markers = ndimage.label(local_maxi) (4-connectivity)
 				const int nmark = label_components(k, k.lmax, k.mark, false);
+				TP_CLK(8);
 				if (nmark == 0) {
 					// "No maxima were found": the cluster is rejected (k2p2v2.py:218-223)
 					TP_PAR_FOR(p, P) if (k.lab2[p] == lab) k.lab2[p] = -1;
@@ -1195,6 +1259,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 					TP_SYNC();
 					if (no_labels - 2 > 0) max_label += (no_labels - 2);
 				}
+				TP_CLK(9);
 			}
 
 			// ---------------- A5: mask assembly, one candidate mask at a time ----------------
@@ -1211,7 +1276,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 					TP_SYNC();
 					// fill holes: not in mask and all four neighbours in mask (k2p2v2.py:549-554)
 					TP_PAR_FOR(p, P) {
-						const int r = p / W, c = p - r * W;
+						const int r = row_of(k, p), c = p - r * W;
 						uint8_t fill = 0;
 						if (!k.msk[p] && r > 0 && r < H - 1 && c > 0 && c < W - 1)
 							fill = (k.msk[p - W] && k.msk[p + W] && k.msk[p - 1] && k.msk[p + 1]) ? 1 : 0;
@@ -1259,6 +1324,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 		}
 	}
 
+	TP_CLK(10);
 	bool using_min = false;
 	if (!err) {
 		if (!have_masks) { using_min = true; if (!(flags & FLAG_NOSTARS)) flags |= FLAG_NOMASKS; }
@@ -1268,7 +1334,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 	if (!err && using_min) {
 		// _minimum_aperture (photometry.py:31-41)
 		TP_PAR_FOR(p, P) {
-			const int r = p / W, c = p - r * W;
+			const int r = row_of(k, p), c = p - r * W;
 			const double dc = ((double)(t.stamp_col0 + c + 1) - t.tpos_col) - 1.0;
 			const double dr = ((double)(t.stamp_row0 + r + 1) - t.tpos_row) - 1.0;
 			// bit 1 of BasePhotometry.aperture is "pixel collected" = finite sum image (BasePhotometry.py:1043): enforced here as well,
@@ -1287,7 +1353,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 		TP_LANE_LOOP(l) {
 			int e = 0;
 			for (int p = l; p < P; p += 64) if (k.res[p]) {
-				const int r = p / W, c = p - r * W;
+				const int r = row_of(k, p), c = p - r * W;
 				if (r == 0) e |= FLAG_EDGE_DOWN;
 				if (r == H - 1) e |= FLAG_EDGE_UP;
 				if (c == 0) e |= FLAG_EDGE_LEFT;
@@ -1299,6 +1365,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 		flags |= or_ired(k);
 		TP_SYNC();
 
+		TP_CLK(15);
 		// ---------------- A7: contamination (photometry.py:220-238) ----------------
 		TP_PAR_FOR(s, t.ncat) {
 			// rows == np.round(t['row'])+1 with 1-based grid rows: stamp index = round(row) - stamp_row0
@@ -1309,6 +1376,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 			if (t.cat_in_mask) t.cat_in_mask[s] = in;
 		}
 		TP_SYNC();
+		TP_CLK(17);
 		// serial tail on every lane (uniform, reads global cat_in_mask written above)
 		int nin = 0, only = -1;
 		float ssum = 0.f;
@@ -1322,6 +1390,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 			const float v = powf(10.0f, -0.4f * t.cat_tmag[s]);
 			if (v == v) ssum += v;
 		}
+		TP_CLK(18);
 		if (nin == 0) { err = ERR_NO_TARGETS_IN_MASK; }
 		else if (nin == 1 && t.cat_starid[only] == t.target_starid) contamination = 0.0;
 		else {
@@ -1333,6 +1402,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 		}
 	}
 
+	TP_CLK(19);
 	if (err) {
 		status = 2; // STATUS.ERROR
 		if (err == ERR_NO_TARGETS_IN_MASK && (flags & FLAG_MIN_APERTURE)) status = 3; // photometry.py:253-254 overrides
@@ -1341,6 +1411,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 
 	const bool keep_mask = (status != 2) || (err == ERR_NO_TARGETS_IN_MASK); // photometry.py:204 ran before :227
 	TP_PAR_FOR(p, P) { const uint8_t v = keep_mask ? k.res[p] : 0; k.res[p] = v; t.mask[p] = v; }
+	TP_CLK(11);
 	TP_SERIAL {
 		*t.status = status;
 		*t.flags = flags;
@@ -1348,6 +1419,7 @@ inline TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 		if (t.diag) t.diag[7] = (double)nmasks_total;
 	}
 	TP_SYNC();
+	TP_CLK_FLUSH;
 	return status;
 }
 

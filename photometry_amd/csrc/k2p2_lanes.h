@@ -11,6 +11,18 @@
 #define TP_SERIAL if (k.lane == 0)
 #define TP_ATOMIC_INC(ptr) atomicAdd((ptr), 1)
 #define TP_ATOMIC_OR(ptr, v) atomicOr((ptr), (v))
+#define TP_NO_UNROLL _Pragma("unroll 1")
+#define TP_ALWAYS_INLINE __forceinline__
+#ifdef TP_LAB_K2P2_CLOCK
+// lab build only: cycles per phase of the mask builder, summed over the targets of a launch (tools/k2p2_timing.py); a wavefront
+// keeps its sums in LDS (one workgroup = one wavefront in tp_k2p2_kernel) and adds them to the global counters once, at the end
+static __device__ unsigned long long g_k2clk[24];
+__shared__ unsigned long long s_k2clk[24];
+#define TP_CLK_DECL do { if (k.lane < 24) s_k2clk[k.lane] = 0ull; __syncthreads(); } while (0)
+#define TP_CLK_BEGIN long long k2_t0 = clock64()
+#define TP_CLK(i) do { const long long k2_t1 = clock64(); if (k.lane == 0) s_k2clk[i] += (unsigned long long)(k2_t1 - k2_t0); k2_t0 = clock64(); } while (0)
+#define TP_CLK_FLUSH do { __syncthreads(); if (k.lane < 24) atomicAdd(&g_k2clk[k.lane], s_k2clk[k.lane]); } while (0)
+#endif
 #elif K2P2_LANES_SECTION == 2
 // Reductions over the 64 per-lane partials in k.red / k.ired (written by a TP_LANE_LOOP, followed by TP_SYNC).  Fixed
 // binary-tree association: a[l] (op)= a[l+32], then +16, ...
@@ -44,6 +56,36 @@ inline TP_DEV int max_ired(const Shared& k) { TP_TREE(int, k.ired, (y_ > x_) ? y
 inline TP_DEV double min_arr(const Shared& k, const double* arr) { TP_TREE(double, arr, (y_ < x_) ? y_ : x_) }
 inline TP_DEV double max_arr(const Shared& k, const double* arr) { TP_TREE(double, arr, (y_ > x_) ? y_ : x_) }
 #undef TP_TREE
+// Ascending sort of k.srt[0 .. Pp), Pp <= 256 (stamps up to 16 x 16), in REGISTERS: a lane holds four consecutive keys, the
+// bitonic network's strides 1 and 2 are exchanges between its own registers, the strides from 4 up exchanges with the lane
+// l ^ (stride / 4) (21 cross-lane stages of four doubles each).  The LDS version (k2p2_core.h: 36 stages, two dependent LDS round
+// trips and a fence each) took 28 000 cycles of a target's ~360 000; a sorted array is a sorted array: same result.
+#define TP_HAVE_WAVE_SORT 1
+inline TP_DEV void wave_sort_256(Shared& k) {
+	const int l = k.lane, n = k.Pp;
+	const double inf = __builtin_inf();
+	double v[4];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) { const int i = 4 * l + j; v[j] = (i < n) ? k.srt[i] : inf; }
+	auto cx = [](double& a, double& b, bool up) { const double mn = fmin(a, b), mx = fmax(a, b); a = up ? mn : mx; b = up ? mx : mn; };
+	cx(v[0], v[1], true); cx(v[2], v[3], false);                       // size 2: direction from bit 1 of the index
+	{ const bool up = (l & 1) == 0; cx(v[0], v[2], up); cx(v[1], v[3], up); cx(v[0], v[1], up); cx(v[2], v[3], up); }   // size 4: from bit 2
+#pragma unroll
+	for (int size = 8; size <= 256; size <<= 1) {
+		const bool up = ((4 * l) & size) == 0;
+#pragma unroll
+		for (int stride = size >> 1; stride >= 4; stride >>= 1) {
+			const int lx = stride >> 2;
+			const bool keep_min = (((l & lx) == 0) == up);
+#pragma unroll
+			for (int j = 0; j < 4; ++j) { const double o = __shfl_xor(v[j], lx, 64); v[j] = keep_min ? fmin(v[j], o) : fmax(v[j], o); }
+		}
+		cx(v[0], v[2], up); cx(v[1], v[3], up); cx(v[0], v[1], up); cx(v[2], v[3], up);
+	}
+#pragma unroll
+	for (int j = 0; j < 4; ++j) { const int i = 4 * l + j; if (i < n) k.srt[i] = v[j]; }
+	__syncthreads();
+}
 // Tree sum (same association as sum_red) of per-lane partials produced by f(lane), without touching LDS: the partial stays
 // in a register and goes straight into the shuffle tree.
 template <class F>

@@ -120,7 +120,8 @@ def test_background_shenanigans(ctx):
 	# small windows / no reference image
 	small = prepare.ctypes  # noqa: F841 (keep the import used)
 	out = ctx.empty((3, R, C), 'float32')
-	ctx._check(ctx.lib.tp_frames_median_filter(ctx.handle, ctx.array(sky[:3]).ptr, 3, R, C, C, R * C, None, 5, out.ptr))
+	d_sky3 = ctx.array(sky[:3])
+	ctx._check(ctx.lib.tp_frames_median_filter(ctx.handle, d_sky3.ptr, 3, R, C, C, R * C, None, 5, out.ptr))
 	np.testing.assert_array_equal(out.to_host()[1], median_filter(sky[1], size=5))
 
 
@@ -272,7 +273,8 @@ def test_mesh_finish_and_ring_profiles_on_device(ctx):
 	nm[5, 0, :] = 2049; nm[5, :, -1] = 2049       # edges excluded (2048 = exactly 50 % is still kept)
 	nm[6, 7, 7] = 2048
 	coef, vmin, vmax, filt = ctx.empty((T, ny, nx), 'float64'), ctx.empty((T,), 'float64'), ctx.empty((T,), 'float64'), ctx.empty((T, ny, nx), 'float64')
-	ctx._check(ctx.lib.tp_background_mesh_finish(ctx.handle, ctx.array(mesh).ptr, ctx.array(nm).ptr, T, ny, nx, box, 50.0, 3, coef.ptr, vmin.ptr, vmax.ptr, filt.ptr))
+	d_mesh, d_nm = ctx.array(mesh), ctx.array(nm)   # (named: a temporary's block would go back to the allocation cache before the call)
+	ctx._check(ctx.lib.tp_background_mesh_finish(ctx.handle, d_mesh.ptr, d_nm.ptr, T, ny, nx, box, 50.0, 3, coef.ptr, vmin.ptr, vmax.ptr, filt.ptr))
 	ref = prepare.finish_mesh(mesh, nm, box)
 	got = filt.to_host()
 	assert np.all(np.isnan(got[2])) and np.all(np.isnan(ref[2]))
@@ -284,7 +286,8 @@ def test_mesh_finish_and_ring_profiles_on_device(ctx):
 	# a non-square mesh and no filter
 	mesh2 = rng.normal(10, 1, (2, 5, 9)); nm2 = np.zeros((2, 5, 9), dtype='int32'); nm2[0, 2, 3:6] = 4096
 	coef2, f2 = ctx.empty((2, 5, 9), 'float64'), ctx.empty((2, 5, 9), 'float64')
-	ctx._check(ctx.lib.tp_background_mesh_finish(ctx.handle, ctx.array(mesh2).ptr, ctx.array(nm2).ptr, 2, 5, 9, box, 50.0, 1, coef2.ptr, vmin.ptr, vmax.ptr, f2.ptr))
+	d_mesh2, d_nm2 = ctx.array(mesh2), ctx.array(nm2)
+	ctx._check(ctx.lib.tp_background_mesh_finish(ctx.handle, d_mesh2.ptr, d_nm2.ptr, 2, 5, 9, box, 50.0, 1, coef2.ptr, vmin.ptr, vmax.ptr, f2.ptr))
 	ref2 = prepare.finish_mesh(mesh2, nm2, box, filter_size=1)
 	np.testing.assert_allclose(f2.to_host(), ref2, rtol=1e-14)
 	# short axes: the causal initialisation of scipy's prefilter (accumulated in place) matters most here
@@ -303,7 +306,8 @@ def test_mesh_finish_and_ring_profiles_on_device(ctx):
 	for smooth in (3, 0, 5):
 		K = nr + 4
 		knots, coefs, nk = ctx.zeros((9, K), 'float64'), ctx.zeros((9, K), 'float64'), ctx.zeros((9,), 'int32')
-		ctx._check(ctx.lib.tp_radial_profiles(ctx.handle, 9, nr, ctx.array(s2).ptr, ctx.array(bc).ptr, smooth, K, knots.ptr, coefs.ptr, nk.ptr))
+		d_s2, d_bc = ctx.array(s2), ctx.array(bc)
+		ctx._check(ctx.lib.tp_radial_profiles(ctx.handle, 9, nr, d_s2.ptr, d_bc.ptr, smooth, K, knots.ptr, coefs.ptr, nk.ptr))
 		kn, co, n = knots.to_host(), coefs.to_host(), nk.to_host()
 		for k in range(9):
 			prof = prepare._move_median_central(s2[k], smooth) if smooth else s2[k]
@@ -419,7 +423,9 @@ def test_median_filter_15_shared_columns(ctx):
 		img[1, 3:14, 5:14] = np.nan                                   # a hole larger than half a window
 		ref = rng.normal(0, 1, (R, C)) if with_ref else None
 		out = ctx.empty((2, R, C), 'float32')
-		ctx._check(ctx.lib.tp_frames_median_filter(ctx.handle, ctx.array(img).ptr, 2, R, C, C, R * C, ctx.array(ref).ptr if with_ref else None, 15, out.ptr))
+		d_img = ctx.array(img)                       # (kept alive: a temporary's block goes back to the allocation cache at once)
+		d_ref = ctx.array(ref) if with_ref else None
+		ctx._check(ctx.lib.tp_frames_median_filter(ctx.handle, d_img.ptr, 2, R, C, C, R * C, d_ref.ptr if with_ref else None, 15, out.ptr))
 		got = out.to_host()
 		for k in range(2):
 			x = (img[k].astype('float64') - ref).astype('float32') if with_ref else img[k].copy()

@@ -1,21 +1,30 @@
-import sys, os, numpy as np
-os.environ['TP_K2P2_TIMING'] = '1'
-sys.path.insert(0, '.')
+#!/usr/bin/env python3
+"""Diagnostic (lab build with -DTP_LAB_K2P2_CLOCK, TP_LAB_LIB=...): cycles per phase of the mask builder, summed over the 10 000
+targets of the BASELINE batch, in the stand-alone kernel (tp_k2p2_masks)."""
+import sys, os, ctypes, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get('TP_LAB_LIB'):
+	from photometry_amd import _lib
+	_lib.LIB_PATH = os.environ['TP_LAB_LIB']
 from photometry_amd import simulate, engine, pipeline
 from photometry_amd.device import Context
 ctx = Context(0)
-Nt, T, H, W = 10000, 200, 15, 15
+Nt, T, H, W = int(os.environ.get('NT', 10000)), 200, int(os.environ.get('H', 15)), int(os.environ.get('W', 15))
 scene = simulate.make_scene(Nt, T, H, W, seed=1000)
 scene.aperture = None
 cubes = engine.synth_fill(ctx, scene)
 batch = pipeline.ApertureBatch(ctx, scene, cubes=cubes)
 work = pipeline.ApertureWork(ctx, batch)
-work.diag = ctx.zeros((Nt, 16), 'float64')
 engine.sumimage(ctx, batch.images, batch.quality, out=work.sumimage)
 engine.k2p2_masks(ctx, batch, work); ctx.sync()
-t = work.diag.to_host()
-names = ['-', 'threshold', 'idx+core+label', 'sat prepass', 'blur+peaks', 'star match', 'dedupe+markers', 'watershed', 'relabel', 'A5 count', 'hole fill', 'A5 sat', 'target check', 'final']
-tot = t.sum(axis=1).mean()
-for i, n in enumerate(names):
-    if i < 16 and t[:, i].mean() > 0: print('%-16s %9.0f cycles  %5.1f %%' % (n, t[:, i].mean(), 100*t[:, i].mean()/tot))
-print('total per target %.0f cycles' % tot)
+buf = (ctypes.c_ulonglong * 24)()
+ctx.lib.tp_lab_k2p2_clocks(buf, 1)
+engine.k2p2_masks(ctx, batch, work); ctx.sync()
+ctx.lib.tp_lab_k2p2_clocks(buf, 0)
+c = np.array(list(buf), dtype='float64') / Nt
+names = ['sort', 'bandwidth', 'KDE by DFT + argmax', 'Powell / Brent on the Gaussian sum', 'MAD + CUT', 'idx, DBSCAN core, labels', 'saturated pre-pass', 'blur + peaks',
+	'label the markers', 'watershed + relabel', 'mask assembly', 'contamination + outputs', 'peak list', 'copy of the selected peaks', 'dedupe in saturated patches', 'minimum aperture + edges', 'star match loop', 'cat_in_mask', 'contamination: serial star loop', 'contamination: log10f / pow']
+tot = c.sum()
+for n, v in zip(names, c):
+	print('%-40s %9.0f ticks  %5.1f %%' % (n, v, 100 * v / tot))
+print('total per target %.0f ticks' % tot)

@@ -2,6 +2,9 @@
 """Diagnostic: the configs[2] step on the C3 raw + error cubes: per-kernel HIP-event times and the step's wall time."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get('TP_LAB_LIB'):
+	from photometry_amd import _lib
+	_lib.LIB_PATH = os.environ['TP_LAB_LIB']
 from photometry_amd import simulate, engine, pipeline
 from photometry_amd.device import Context
 
@@ -29,3 +32,12 @@ wall = (time.perf_counter() - t0) / n * 1e3
 ctx.profile(False)
 rep = ctx.profile_report()
 print('step ms', round(wall, 3), {k: round(v[1] / max(v[0], 1), 3) for k, v in rep.items() if v[0]})
+if os.environ.get('TP_LAB_LIB') and os.environ.get('FCLK'):
+	import ctypes
+	buf = (ctypes.c_ulonglong * 8)()
+	ctx.lib.tp_lab_fused_clocks(buf, 1)
+	pipeline.aperture_step(ctx, batch, work)
+	ctx.sync()
+	ctx.lib.tp_lab_fused_clocks(buf, 0)
+	c = list(buf)
+	print('fused kernel, per target (cycles): sum image to LDS %.0f, mask builder %.0f, mask list + series staging %.0f, extraction %.0f; wavefronts %d' % (c[0] / Nt, c[1] / Nt, c[2] / Nt, c[3] / Nt, c[4]))
