@@ -53,12 +53,11 @@ struct CadState {
 			const float x = v[c];
 			f_allnan[c] = f_allnan[c] && (x != x);
 			f_allzero[c] = f_allzero[c] && (x == 0.f);
-			if (x > 0.f) {
-				const double w = (double)x;
-				cw[c] += w;
-				ccol[c] += col * w;
-				crow[c] += row * w;
-			}
+			// (branch-free: a value that is not positive enters as +0.0, which changes none of the three sums)
+			const double w = (x > 0.f) ? (double)x : 0.0;
+			cw[c] += w;
+			ccol[c] += col * w;
+			crow[c] += row * w;
 		}
 	}
 	// np.nansum (photometry.py:201) = np.sum of the values with NaN replaced by 0: the term that enters the pairwise tree
@@ -286,10 +285,12 @@ __device__ __forceinline__ void extract_small_stream(const Args& a, int target, 
 		for (int j = 0; j < 8; j++) {
 			int idx = g * 8 + j;
 			idx = (idx < M) ? idx : (M - 1);
-			const int64_t off = (int64_t)(s_list[idx] & 0xffff) * a.t_pitch + k0;
-			Vec<VEC>::load(img + off, B.v[j]);
-			Vec<VEC>::load(err + off, B.e[j]);
-			if (BKG_CUBE) Vec<VEC>::load(bkg + off, B.b[j]);
+			// (the list entry is the same in every lane: taken to a scalar register, the row's base address is scalar arithmetic and
+			// the load gets a scalar base + the lane's cadence offset)
+			const int64_t rowoff = (int64_t)(__builtin_amdgcn_readfirstlane(s_list[idx]) & 0xffff) * a.t_pitch;
+			Vec<VEC>::load(img + rowoff + k0, B.v[j]);
+			Vec<VEC>::load(err + rowoff + k0, B.e[j]);
+			if (BKG_CUBE) Vec<VEC>::load(bkg + rowoff + k0, B.b[j]);
 		}
 	};
 	auto consume = [&](const Buf& B, int step) {
@@ -301,7 +302,7 @@ __device__ __forceinline__ void extract_small_stream(const Args& a, int target, 
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
 			if (j < cnt) {
-				const int pk = s_list[g * 8 + j];
+				const int pk = __builtin_amdgcn_readfirstlane(s_list[g * 8 + j]);
 				const int p = pk & 0xffff;
 				const int pr = (int)((unsigned)pk >> 16);
 				const int pc = p - pr * a.width;
