@@ -81,4 +81,4 @@ def test_hostsim_two_sample_kde_tie(hostsim):
 	aperture, STATUS.WARNING.  `compare` counts it as a tie and still checks the outputs."""
 	s, S = make_cases('bright', 338)
 	stats = compare(s, S, run_hostsim(hostsim, s, S), oracle_batch(s, S))
-	assert stats['n_tie'] == 1 and stats['n_razor'] == 0 and stats['n_exact'] == s.n_targets - 1 - 0 or stats['n_exact'] >= s.n_targets - 2
+	assert stats['n_tie'] == 1 and stats['n_razor'] == 0   # (compare itself asserts status, mask, flags, contamination of every target)
