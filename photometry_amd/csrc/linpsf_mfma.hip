@@ -393,12 +393,13 @@ int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned
 	// The launches are independent (one per star count): the first runs on the context's stream, the others on two side streams
 	// that wait for what precedes on it (the coefficient store) and are waited for before what follows (the finalisation), so that
 	// the tail of one launch -- its last workgroups on a mostly idle chip -- overlaps the body of another.
+	// (one way out: a failure below still joins the side streams and returns the events to the pool)
 	hipEvent_t before = ctx->get_event();
-	TP_HIP(ctx, hipEventRecord(before, ctx->stream));
+	hipError_t err = hipEventRecord(before, ctx->stream);
 	int used = 0;
 	hipStream_t streams[3] = {ctx->stream, nullptr, nullptr};
 	for (int i = 0; i < 2; ++i) {
-		if (!ctx->side[i]) TP_HIP(ctx, hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+		if (!ctx->side[i] && err == hipSuccess) err = hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking);
 		streams[i + 1] = ctx->side[i];
 	}
 	bool waited[3] = {true, false, false};
@@ -407,13 +408,13 @@ int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned
 	// two and more stars hold one workgroup per CU, and its wavefronts are the CU's occupancy)
 	(void)class_counts;
 #define TP_FITM(CLS, SS, TT, WW, LDS) do { \
-		if (seg_counts[CLS] > 0) { \
+		if (seg_counts[CLS] > 0 && err == hipSuccess && streams[used % 3] != nullptr) { \
 			const int si = used++ % 3; \
-			if (!waited[si]) { TP_HIP(ctx, hipStreamWaitEvent(streams[si], before, 0)); waited[si] = true; } \
-			TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fitm_kernel<SS, TT, WW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
-			TP_LAUNCH_ON(ctx, streams[si], TPK_LINPSF_FIT_MFMA, (tp_linpsf_fitm_kernel<SS, TT, WW>), dim3((unsigned)seg_counts[CLS]), dim3(64 * fit_waves(a.n_cad, TT / 64, 16)), (size_t)LDS, \
+			if (!waited[si]) { err = hipStreamWaitEvent(streams[si], before, 0); waited[si] = (err == hipSuccess); } \
+			if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fitm_kernel<SS, TT, WW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+			if (err == hipSuccess) { TP_LAUNCH_ON(ctx, streams[si], TPK_LINPSF_FIT_MFMA, (tp_linpsf_fitm_kernel<SS, TT, WW>), dim3((unsigned)seg_counts[CLS]), dim3(64 * fit_waves(a.n_cad, TT / 64, 16)), (size_t)LDS, \
 				a, d_segs, d_seg_lists + (size_t)(CLS) * n_targets * kMfmaSegs, d_mplans, d_ulist, d_usig, d_kstore, d_alast); \
-			TP_LAUNCH_CHECK(ctx, "tp_linpsf_fitm_kernel"); \
+			err = hipGetLastError(); } \
 		} \
 	} while (0)
 	// registers decide the shape (measured, C3 batch): one star 124 VGPRs -- two workgroups of 8 wavefronts per CU; two stars 167 --
@@ -427,14 +428,17 @@ int fit_mfma_launch(tp_ctx* ctx, const FitArgs& a, int n_targets, const unsigned
 	TP_FITM(3, 4, 512, 2, kMfmaLdsLarge);
 #undef TP_FITM
 	for (int i = 1; i < 3; ++i) {
-		if (waited[i]) {
+		if (waited[i] && streams[i]) {
 			hipEvent_t done = ctx->get_event();
-			TP_HIP(ctx, hipEventRecord(done, streams[i]));
-			TP_HIP(ctx, hipStreamWaitEvent(ctx->stream, done, 0));
+			hipError_t e2 = hipEventRecord(done, streams[i]);
+			if (e2 == hipSuccess) e2 = hipStreamWaitEvent(ctx->stream, done, 0);
+			if (e2 != hipSuccess) (void)hipStreamSynchronize(streams[i]);   // the join of last resort
+			if (err == hipSuccess) err = e2;
 			ctx->pool.push_back(done);
 		}
 	}
 	ctx->pool.push_back(before);
+	if (err != hipSuccess) return ctx->fail(TP_ERR_HIP, "tp_linpsf_fitm_kernel", err);
 	return TP_OK;
 }
 
