@@ -245,11 +245,7 @@ __device__ __forceinline__ void extract_small_stream(const Args& a, int target, 
 	const int P = a.height * a.width;
 	const int col0 = a.stamps[target * 4 + 2] + 1;
 	const int row0 = a.stamps[target * 4 + 0] + 1;
-#ifdef TP_LAB_A6_SAMEROWS
-	const int64_t tb = (int64_t)(target & 63) * P * a.t_pitch;   // lab: 64 targets' cubes serve all (L2-resident): what A6 costs without HBM
-#else
 	const int64_t tb = (int64_t)target * P * a.t_pitch;
-#endif
 	const float* img = a.images + tb;
 	const float* err = a.images_err + tb;
 	constexpr bool BKG_CUBE = (BKG == 0), BKG_SERIES = (BKG == 1), HAS_BKG = (BKG != 2);

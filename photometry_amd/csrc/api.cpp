@@ -88,7 +88,6 @@ static int tp_ctx_create_impl(int device, int high_priority, tp_ctx** out) {
 	}
 	tp_ctx* ctx = new tp_ctx();
 	ctx->device = device;
-	ctx->median_plain = std::getenv("TP_MEDIAN_PLAIN") ? 1 : 0;
 	if (high_priority) {
 		int least = 0, greatest = 0;
 		(void)hipDeviceGetStreamPriorityRange(&least, &greatest);

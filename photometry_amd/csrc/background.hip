@@ -611,7 +611,7 @@ __device__ __forceinline__ int reflect_index(int i, int n) { // (d c b a | a b c
 	return (i < n) ? i : (p - 1 - i);
 }
 
-// NREAL: registers that can hold a window value (29 for the 15 x 15 window the reference uses, else 32).  FAST: both image
+// NREAL: registers that can hold a window value (32; the 15 x 15 window the reference uses has tp_median15_quad_kernel below).  FAST: both image
 // dimensions are at least the window size, so an index leaves the image by less than its length and one reflection is a
 // comparison and a subtraction; the window offset of a lane's next value (8 further in raster order) follows from the last
 // without a division.  (The generic index arithmetic -- two divisions and two modulo reflections per value -- cost as much as
@@ -664,22 +664,6 @@ __global__ __launch_bounds__(256) void tp_median_filter_kernel(MedianArgs a)
 	cross_stage<kDppHalfMirror, true, R>(v, sel4);
 	cross_stage<kDppXor2, false, R>(v, sel2);
 	cross_stage<kDppXor1, false, R>(v, sel1);
-	if constexpr (NREAL == 29) {
-		// 15 x 15 window: the median is rank 112 = register 16 of lane 3 of the frame, and of the last in-lane merge only the
-		// comparisons that lead to register 16 are made -- 31 one-sided ones (maxima over stride 16, then minima over 8, 4, 2, 1)
-		// instead of 80 exchanges -- and nothing is staged
-		float w[16];
-#pragma unroll
-		for (int j = 0; j < 16; ++j) w[j] = tp_max(v[j], v[j + 16]);
-#pragma unroll
-		for (int j = 0; j < 8; ++j) w[j] = tp_min(w[j], w[j + 8]);
-#pragma unroll
-		for (int j = 0; j < 4; ++j) w[j] = tp_min(w[j], w[j + 4]);
-		const float med = tp_min(tp_min(w[0], w[2]), tp_min(w[1], w[3]));
-		if (g == 3 && active)
-			a.out[(int64_t)frame * a.frame_stride + (int64_t)row * a.row_pitch + col] = (med <= 3.402823466e+38f) ? med : __builtin_nanf("");
-		return;
-	}
 	local_merge<R>(v);
 	float* fr = s_win + (wave * 8 + f) * 288;
 #pragma unroll
@@ -1155,10 +1139,10 @@ extern "C" int tp_frames_median_filter(tp_ctx* ctx, const float* d_frames, int32
 	a.row_pitch = row_pitch; a.frame_stride = frame_stride; a.size = size;
 	dim3 grid((unsigned)((frame_cols + 31) / 32), (unsigned)frame_rows, (unsigned)n_frames);
 	const bool fast = frame_rows >= size && frame_cols >= size && size >= 8;
-	if (size == 15 && fast && !ctx->median_plain) {
+	if (size == 15 && fast) {
 		dim3 grid4((unsigned)((frame_cols + 127) / 128), (unsigned)frame_rows, (unsigned)n_frames);
 		TP_LAUNCH(ctx, TPK_MEDIAN_FILTER, tp_median15_quad_kernel, grid4, dim3(256), 0, a);
-	} else if (size == 15 && fast) TP_LAUNCH(ctx, TPK_MEDIAN_FILTER, (tp_median_filter_kernel<29, true>), grid, dim3(256), 0, a);
+	}
 	else if (fast) TP_LAUNCH(ctx, TPK_MEDIAN_FILTER, (tp_median_filter_kernel<32, true>), grid, dim3(256), 0, a);
 	else TP_LAUNCH(ctx, TPK_MEDIAN_FILTER, (tp_median_filter_kernel<32, false>), grid, dim3(256), 0, a);
 	TP_LAUNCH_CHECK(ctx, "tp_median_filter_kernel");

@@ -80,7 +80,6 @@ struct tp_ctx {
 	// after the stream has been synchronised): a batched entry makes a hundred of them per call
 	void* ring = nullptr;
 	size_t ring_cursor = 0;
-	int median_plain = 0;       // lab switch (TP_MEDIAN_PLAIN=1 in the environment at context creation): one full sort per pixel
 	int linpsf_path = 1;        // tp_linpsf_set_path: 1 = matrix-core fit where a target qualifies, 0 = vector-ALU fit kernels only
 	int64_t linpsf_counts[16] = {};   // tp_linpsf_last_counts: which kernels fitted the targets of the last tp_linpsf_fit call
 	void* comm = nullptr;       // ncclComm_t (comm.cpp)

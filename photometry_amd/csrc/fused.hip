@@ -20,15 +20,6 @@
 #include "k2p2_args.h"
 
 namespace {
-#ifdef TP_LAB_FUSED_CLOCK
-// lab build only: cycles of a wavefront's phases, summed over the launch (tools/step_time.py)
-__device__ unsigned long long g_fclk[8];
-#define F_CLK_BEGIN long long f_t0 = clock64()
-#define F_CLK(i) do { const long long t1_ = clock64(); if (threadIdx.x == 0) atomicAdd(&g_fclk[i], (unsigned long long)(t1_ - f_t0)); f_t0 = clock64(); } while (0)
-#else
-#define F_CLK_BEGIN do {} while (0)
-#define F_CLK(i) do {} while (0)
-#endif
 
 constexpr int kRows = 8; // pixel rows per A1 step: 8 x 1 KiB loads in flight per lane
 
@@ -46,7 +37,6 @@ __global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a,
 	k2p2::Shared k;
 	k2p2::shared_carve(k, smem, ka.H, ka.W, lane, twid);
 	const int P = ka.H * ka.W;
-	F_CLK_BEGIN;
 
 	// ---------------- A1: sum image into LDS (k.S) and HBM ----------------
 	if constexpr (!A1) {
@@ -150,9 +140,7 @@ __global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a,
 	k2p2::Target t;
 	k2p2::make_target(ka, target, t);
 	t.S = k.S;
-	F_CLK(0);
 	const int status = k2p2::run_target(k, prm, t);
-	F_CLK(1);
 	if (status == TP_STATUS_ERROR) return; // photometry.py: the plugin stops, nothing is extracted
 
 	// ---------------- A6: extraction over the mask pixels (k.res), all cadences ----------------
@@ -188,10 +176,8 @@ __global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a,
 			__syncthreads();
 		}
 	}
-	F_CLK(2);
 	if ((HAS_SUB && lds_sub) || (BKG == 1 && lds_ser)) tp_ap::extract_small_stream<VEC, HAS_SUB, BKG, true>(a, target, s_list, M, lane, 64, lds_sub, lds_ser);
 	else tp_ap::extract_small_stream<VEC, HAS_SUB, BKG, false>(a, target, s_list, M, lane, 64);
-	F_CLK(3);
 }
 
 } // namespace
@@ -349,10 +335,3 @@ extern "C" int tp_aperture_photometry_from_sumimage(tp_ctx* ctx, const tp_cube_d
 		d_contamination, d_diag, d_cat_in_mask, d_flux, d_flux_err, d_flux_background, d_centroid_col, d_centroid_row, out_pitch);
 }
 
-#ifdef TP_LAB_FUSED_CLOCK
-extern "C" int tp_lab_fused_clocks(unsigned long long* out, int reset) {
-	int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fclk), sizeof(unsigned long long) * 8);
-	if (reset) { unsigned long long z[8] = {}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fclk), z, sizeof(z)); }
-	return rc;
-}
-#endif

@@ -102,11 +102,3 @@ extern "C" int tp_k2p2_masks(tp_ctx* ctx, int32_t n_targets, int32_t height, int
 	return TP_OK;
 	TP_API_END(ctx)
 }
-
-#ifdef TP_LAB_K2P2_CLOCK
-extern "C" int tp_lab_k2p2_clocks(unsigned long long* out, int reset) {
-	int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k2clk), sizeof(unsigned long long) * 24);
-	if (reset) { unsigned long long z[24] = {}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_k2clk), z, sizeof(z)); }
-	return rc;
-}
-#endif

@@ -40,12 +40,6 @@
 #ifndef TP_ALWAYS_INLINE
 #define TP_ALWAYS_INLINE inline
 #endif
-#ifndef TP_CLK
-#define TP_CLK_DECL do {} while (0)
-#define TP_CLK_BEGIN do {} while (0)
-#define TP_CLK(i) do {} while (0)
-#define TP_CLK_FLUSH do {} while (0)
-#endif
 
 namespace k2p2 {
 
@@ -488,7 +482,6 @@ inline TP_DEV double powell_mode(Shared& k, int nc, double h, double x0) {
 // Returns 0 ok, or an ERR_* code; fills diag[0..5] and leaves CUT in *cut (may be NaN).
 inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, double* cut) {
 	const int P = k.P;
-	TP_CLK_BEGIN;
 
 	// Flux = S[~isnan(S)]; Flux = Flux[Flux > 0]   (k2p2v2.py:394-395) -> compacted in raster order
 	TP_LANE_LOOP(l) {
@@ -504,7 +497,6 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 	TP_PAR_FOR(p, k.Pp) k.srt[p] = (p < P && k.S[p] > 0.0) ? k.S[p] : tp_inf();
 	TP_SYNC();
 	bitonic_sort(k);
-	TP_CLK(0);
 	// count of finite entries == nflux unless some flux is +inf (kept, as numpy would)
 	// trim1(sorted, 0.15): keep the n - int(0.15 n) smallest (scipy/stats trim1, tail='right')
 	int nc = nflux - (int)(0.15 * (double)nflux);
@@ -541,7 +533,6 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 	}
 	if (nc == 0) bw = tp_nan();
 	if (bw == 0.0) return ERR_BANDWIDTH_ZERO;
-	TP_CLK(1);
 
 	// --- kdensityfft: linear binning on a 128-point grid, Silverman transform, inverse transform
 	double max_guess;
@@ -664,10 +655,7 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 		max_guess = (am == M - 1) ? b : (a + (double)am * delta);
 		TP_SYNC();
 	}
-
-	TP_CLK(2);
 	const double MODE = powell_mode(k, nc, bw, max_guess);
-	TP_CLK(3);
 
 	// MAD1 = mad_to_sigma * nanmedian(|Flux[Flux < MODE] - MODE|)   (k2p2v2.py:424)
 	// Flux sorted ascending: the selection is the prefix [0, c)
@@ -689,7 +677,6 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 	const double MAD1 = kMadToSigma * med;
 	const double CUT = MODE + prm.thresh * MAD1;
 	*cut = CUT;
-	TP_CLK(4);
 	if (t.diag) {
 		TP_SERIAL { t.diag[0] = CUT; t.diag[1] = MODE; t.diag[2] = MAD1; t.diag[3] = bw; t.diag[4] = max_guess; }
 	}
@@ -1013,7 +1000,6 @@ inline TP_DEV float mags_total_f32(const float* tmag, const uint8_t* sel, int n)
 // stack frame in scratch memory and the fused kernel its register allocation)
 TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 	const int P = k.P, H = k.H, W = k.W;
-	TP_CLK_DECL;
 	TP_PAR_FOR(p, P) { k.S[p] = t.S[p]; k.res[p] = 0; }
 	TP_SYNC();
 	int flags = 0;
@@ -1026,7 +1012,6 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 	double CUT = tp_nan();
 	if (t.cut_override) { CUT = *t.cut_override; if (t.diag) { TP_SERIAL { t.diag[0] = CUT; } } }
 	else err = threshold(k, prm, t, &CUT);
-	TP_CLK_BEGIN;
 
 	// target pixel (photometry.py:107): Python round() = round-half-even; negative indices wrap
 	int tr = (int)rint(t.tpos_row - (double)t.stamp_row0);
@@ -1091,8 +1076,6 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 				k.lab[p] = v;
 			}
 			TP_SYNC();
-
-			TP_CLK(5);
 			// ---------------- A4: watershed per cluster (segmentation=True, any cluster) ----------------
 			// Labels after k2p2WS: non-core -> noise (k2p2v2.py:112)
 			TP_PAR_FOR(p, P) k.lab2[p] = (k.idx[p]) ? ((k.core[p]) ? k.lab[p] : -1) : -2;
@@ -1103,7 +1086,6 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 				TP_PAR_FOR(p, P) k.msk[p] = (k.lab[p] == lab) ? 1 : 0;
 				TP_SYNC();
 				const int nsat = saturated_one(k);
-				TP_CLK(6);
 				// Z = flux on the core pixels of this cluster
 				TP_PAR_FOR(p, P) k.Z[p] = (k.lab2[p] == lab) ? k.S[p] : 0.0;
 				TP_SYNC();
@@ -1150,7 +1132,6 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 				TP_SYNC();
 				const int npeaks = sum_ired(k);
 				TP_SYNC();
-				TP_CLK(7);
 				// peaks matched to catalog stars (k2p2v2.py:144-153); candidates stay in lmax, selection in sat? no:
 				// selection goes to k.core-independent temp: reuse wsout as "selected" flags
 				TP_PAR_FOR(p, P) k.wsout[p] = 0;
@@ -1161,7 +1142,6 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 				TP_SYNC();
 				TP_PAR_FOR(p, P) if (k.lmax[p]) { const int slot = TP_ATOMIC_INC(&k.scal[3]); k.hpix[slot] = p; }
 				TP_SYNC();
-				TP_CLK(12);
 				TP_PAR_FOR(s, t.ncat) {
 					const double c0 = (double)t.cat_col[s], c1 = (double)t.cat_row[s];
 					int bi = -1; double bd = 0.0, bint = 0.0;
@@ -1193,10 +1173,8 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 					}
 				}
 				TP_SYNC();
-				TP_CLK(16);
 				TP_PAR_FOR(p, P) k.lmax[p] = k.wsout[p] ? 1 : 0; // local_maxi
 				TP_SYNC();
-				TP_CLK(13);
 				// de-duplicate maxima inside saturated patches (k2p2v2.py:193-212)
 				if (nsat > 0) {
 					const int ncomp = label_components(k, k.sat, k.mark, false);
@@ -1225,10 +1203,8 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 						}
 					}
 				}
-				TP_CLK(14);
 				// markers = ndimage.label(local_maxi) (4-connectivity)
 				const int nmark = label_components(k, k.lmax, k.mark, false);
-				TP_CLK(8);
 				if (nmark == 0) {
 					// "No maxima were found": the cluster is rejected (k2p2v2.py:218-223)
 					TP_PAR_FOR(p, P) if (k.lab2[p] == lab) k.lab2[p] = -1;
@@ -1259,7 +1235,6 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 					TP_SYNC();
 					if (no_labels - 2 > 0) max_label += (no_labels - 2);
 				}
-				TP_CLK(9);
 			}
 
 			// ---------------- A5: mask assembly, one candidate mask at a time ----------------
@@ -1323,8 +1298,6 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 			}
 		}
 	}
-
-	TP_CLK(10);
 	bool using_min = false;
 	if (!err) {
 		if (!have_masks) { using_min = true; if (!(flags & FLAG_NOSTARS)) flags |= FLAG_NOMASKS; }
@@ -1364,8 +1337,6 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 		TP_SYNC();
 		flags |= or_ired(k);
 		TP_SYNC();
-
-		TP_CLK(15);
 		// ---------------- A7: contamination (photometry.py:220-238) ----------------
 		TP_PAR_FOR(s, t.ncat) {
 			// rows == np.round(t['row'])+1 with 1-based grid rows: stamp index = round(row) - stamp_row0
@@ -1376,7 +1347,6 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 			if (t.cat_in_mask) t.cat_in_mask[s] = in;
 		}
 		TP_SYNC();
-		TP_CLK(17);
 		// serial tail on every lane (uniform, reads global cat_in_mask written above)
 		int nin = 0, only = -1;
 		float ssum = 0.f;
@@ -1390,7 +1360,6 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 			const float v = powf(10.0f, -0.4f * t.cat_tmag[s]);
 			if (v == v) ssum += v;
 		}
-		TP_CLK(18);
 		if (nin == 0) { err = ERR_NO_TARGETS_IN_MASK; }
 		else if (nin == 1 && t.cat_starid[only] == t.target_starid) contamination = 0.0;
 		else {
@@ -1401,8 +1370,6 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 			contamination = cont;
 		}
 	}
-
-	TP_CLK(19);
 	if (err) {
 		status = 2; // STATUS.ERROR
 		if (err == ERR_NO_TARGETS_IN_MASK && (flags & FLAG_MIN_APERTURE)) status = 3; // photometry.py:253-254 overrides
@@ -1411,7 +1378,6 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 
 	const bool keep_mask = (status != 2) || (err == ERR_NO_TARGETS_IN_MASK); // photometry.py:204 ran before :227
 	TP_PAR_FOR(p, P) { const uint8_t v = keep_mask ? k.res[p] : 0; k.res[p] = v; t.mask[p] = v; }
-	TP_CLK(11);
 	TP_SERIAL {
 		*t.status = status;
 		*t.flags = flags;
@@ -1419,7 +1385,6 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 		if (t.diag) t.diag[7] = (double)nmasks_total;
 	}
 	TP_SYNC();
-	TP_CLK_FLUSH;
 	return status;
 }
 

@@ -13,16 +13,6 @@
 #define TP_ATOMIC_OR(ptr, v) atomicOr((ptr), (v))
 #define TP_NO_UNROLL _Pragma("unroll 1")
 #define TP_ALWAYS_INLINE __forceinline__
-#ifdef TP_LAB_K2P2_CLOCK
-// lab build only: cycles per phase of the mask builder, summed over the targets of a launch (tools/k2p2_timing.py); a wavefront
-// keeps its sums in LDS (one workgroup = one wavefront in tp_k2p2_kernel) and adds them to the global counters once, at the end
-static __device__ unsigned long long g_k2clk[24];
-__shared__ unsigned long long s_k2clk[24];
-#define TP_CLK_DECL do { if (k.lane < 24) s_k2clk[k.lane] = 0ull; __syncthreads(); } while (0)
-#define TP_CLK_BEGIN long long k2_t0 = clock64()
-#define TP_CLK(i) do { const long long k2_t1 = clock64(); if (k.lane == 0) s_k2clk[i] += (unsigned long long)(k2_t1 - k2_t0); k2_t0 = clock64(); } while (0)
-#define TP_CLK_FLUSH do { __syncthreads(); if (k.lane < 24) atomicAdd(&g_k2clk[k.lane], s_k2clk[k.lane]); } while (0)
-#endif
 #elif K2P2_LANES_SECTION == 2
 // Reductions over the 64 per-lane partials in k.red / k.ired (written by a TP_LANE_LOOP, followed by TP_SYNC).  Fixed
 // binary-tree association: a[l] (op)= a[l+32], then +16, ...

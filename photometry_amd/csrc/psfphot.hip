@@ -87,15 +87,6 @@ constexpr int kPool = 6;                         // most cached coefficient sets
 // round 2 -- more rebuilds, fewer idle CUs (measured, tools/psf_time.py).
 __host__ __device__ constexpr int psf_pool(int ns) { return ns < 2 ? 2 : (ns > kPool ? kPool : ns); }
 
-#ifdef TP_LAB_PSF_CLOCK
-// lab build only (tools/lab/build_variants.sh): cycles of the phases of an evaluation / an iteration, summed by thread 0
-__device__ long long g_clk[8];
-#define LAB_T0 long long lab_t0 = clock64()
-#define LAB_ADD(i) do { const long long lab_t1 = clock64(); if (threadIdx.x == 0 && blockIdx.x == 0) g_clk[i] += lab_t1 - lab_t0; lab_t0 = lab_t1; } while (0)
-#else
-#define LAB_T0 do {} while (0)
-#define LAB_ADD(i) do {} while (0)
-#endif
 
 // width and first item of row r = di + 5 of the cached item set (kRowHalf / kRowStart as arithmetic: a table indexed by a
 // lane's own di is a load from memory in front of every pixel)
@@ -123,7 +114,6 @@ template <int NS>
 __device__ __forceinline__ void prepare_stars(const double* x, const EvalCtx& c, StarR (&st)[NS])
 {
 	const int tid = threadIdx.x;
-	LAB_T0;
 	const int per = c.pool / NS;
 	bool miss = false;
 	int kxs[NS], kys[NS];
@@ -144,7 +134,6 @@ __device__ __forceinline__ void prepare_stars(const double* x, const EvalCtx& c,
 		st[s].slot = hit;
 		miss = miss || (st[s].valid && hit < 0);
 	}
-	LAB_ADD(0);
 	if (!miss) return;                         // uniform: every thread read the same simplex and the same keys
 	__syncthreads();                           // ... and has read them
 #pragma unroll
@@ -198,7 +187,6 @@ __device__ __forceinline__ void prepare_stars(const double* x, const EvalCtx& c,
 		}
 	}
 	__syncthreads();
-	LAB_ADD(1);
 }
 
 // sum over the stars of flux * pixel-integrated PRF at pixel (i, j)
@@ -229,7 +217,6 @@ __device__ double likelihood(const double* x, const EvalCtx& c, int& flip)
 	const int tid = threadIdx.x;
 	StarR st[NS];
 	prepare_stars<NS>(x, c, st);
-	LAB_T0;
 	double acc = 0.0;
 	for (int p = tid; p < c.H * c.W; p += kThreads) {
 		const int i = p / c.W, j = p - i * c.W;
@@ -237,7 +224,6 @@ __device__ double likelihood(const double* x, const EvalCtx& c, int& flip)
 		const double term = (double)c.wgt[p] * (r * r);
 		if (term == term) acc += term;                  // nansum
 	}
-	LAB_ADD(2);
 #pragma unroll
 	for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
 	double* red = c.red + 4 * flip;
@@ -245,7 +231,6 @@ __device__ double likelihood(const double* x, const EvalCtx& c, int& flip)
 	if ((tid & 63) == 0) red[tid >> 6] = acc;
 	__syncthreads();
 	const double tot = (red[0] + red[1]) + (red[2] + red[3]);
-	LAB_ADD(3);
 	return tot;
 }
 
@@ -358,9 +343,6 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 		};
 		sort_simplex();
 		int iterations = 1;
-#ifdef TP_LAB_PSF_CLOCK
-		const long long lab_loop0 = clock64();
-#endif
 		while (iterations < maxiter) {
 			// max |sim[1:] - sim[0]| and max |fsim[0] - fsim[1:]| (a NaN makes the maximum NaN, as numpy's does)
 			double dx = 0.0, df = 0.0;
@@ -435,9 +417,6 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 			sort_simplex();
 			++iterations;
 		}
-#ifdef TP_LAB_PSF_CLOCK
-		if (tid == 0 && blockIdx.x == 0) { g_clk[4] += clock64() - lab_loop0; g_clk[5] += iterations; }
-#endif
 		const bool success = iterations < maxiter;
 		// ---- result of the cadence (psf_photometry.py:157-196)
 		double flux_ap = 0.0;
@@ -477,11 +456,6 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 
 } // namespace
 
-#ifdef TP_LAB_PSF_CLOCK
-extern "C" int tp_lab_psf_clocks(long long* out) {
-	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(long long) * 8);
-}
-#endif
 
 extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images, const float* d_backgrounds,
 	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis,

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""Diagnostic (lab build with -DTP_LAB_K2P2_CLOCK, TP_LAB_LIB=...): cycles per phase of the mask builder, summed over the 10 000
-targets of the BASELINE batch, in the stand-alone kernel (tp_k2p2_masks)."""
+"""Diagnostic: cycles per phase of the mask builder, summed over the 10 000 targets of the BASELINE batch, in the stand-alone
+kernel (tp_k2p2_masks).  Needs a scratch build with the in-kernel clocks, which are NOT in the product sources:
+    git apply tools/lab/clock_hooks.patch
+    SRC=k2p2.hip bash tools/lab/build_variants.sh "k2clk:-DTP_LAB_K2P2_CLOCK"
+    git apply -R tools/lab/clock_hooks.patch
+    TP_LAB_LIB=tools/lab/lib_k2clk.so python tools/k2p2_timing.py        (on the GPU box)"""
 import sys, os, ctypes, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if os.environ.get('TP_LAB_LIB'):

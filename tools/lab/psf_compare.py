@@ -30,18 +30,6 @@ if len(sys.argv) > 1:
 		ctx.array(np.asarray(offs, dtype='int64')), ctx.array(np.concatenate(params)), ctx.array(np.stack(mini)))
 	res = engine.psf_fit(ctx, *args)
 	ctx.sync()
-	if hasattr(ctx.lib, 'tp_lab_psf_debug') or True:
-		try:
-			import ctypes
-			buf = (ctypes.c_ulonglong * 4)()
-			ctx.lib.tp_lab_psf_debug(buf)
-			print('debug counters:', list(buf), flush=True)
-			d = (ctypes.c_double * 32)()
-			ctx.lib.tp_lab_psf_dump(d)
-			for w in range(4):
-				print('   wave', w, 'need kx ky key0 key1 col row star:', [d[w * 8 + i] for i in range(8)], flush=True)
-		except AttributeError:
-			pass
 	np.savez(sys.argv[2], nit=res['nit'].to_host()[:, :T], flux=res['flux'].to_host()[:, :T], ns=np.diff(offs))
 	sys.exit(0)
 here = os.path.abspath(__file__)
