@@ -178,10 +178,11 @@ def main():
 				'per frame for the sigma-clipped median), not by HBM.  Its instructions (v_min / v_max / v_med3, DPP moves, FP64) issue at one '
 				'wave64 instruction per 4 cycles on gfx950 (tools/lab/valu_rate.hip): ~9 500 cycles per wavefront of 8 frames for B*, i.e. the '
 				'vector-ALU time of the B* part of this launch is ~%.1f ms at 2.4 GHz on 1 024 SIMDs; the smoothing and the sum image add ~200 '
-				'instructions per wavefront and block and one workgroup barrier per block' % (Nt * nblocks * 4 * 9500.0 / 1024 / 2.4e9 * 1e3),
+				'instructions per wavefront and block and one split-phase workgroup barrier per block' % (Nt * nblocks * 4 * 9500.0 / 1024 / 2.4e9 * 1e3),
 			'tp_aperture_fused_kernel': 'the aperture-sum kernel north_star names, from the K2P2 mask on (the sum image comes from the background pass): '
-				'one wavefront per target, in-mask pixel rows only; latency-bound by the mask building (scipy bracket / Brent / Powell replayed, '
-				'DBSCAN, watershed: ~270 us per target) now that it no longer streams the whole cube',
+				'one wavefront per target, in-mask pixel rows only; bound by the vector ALUs, not by HBM: 47 600 vector instructions per target '
+				'(counters: profiles/r4_step_kernel_counters.txt), about half the mask builder (scipy bracket / Brent / Powell replayed, DBSCAN, '
+				'watershed) and half the extraction, which takes the same time with its rows resident in L2 (DESIGN.md section 3)',
 		}
 		rooflines = [roofline_of(k, rows, traffic, notes.get(k)) for k in sorted(hbm_kernels, key=lambda k: -rows[k]['avg_ms'])]
 		step_bytes = sum(necessary[k] for k in rows if k in necessary)
