@@ -415,6 +415,11 @@ int tp_linpsf_set_path(tp_ctx* ctx, int32_t path);
  * vector-ALU polynomial kernels, [3] on the general kernel (wide excursions inside 16 cadences), [4] with more than 8 fitted
  * stars, [5..8] matrix-core targets with 1..4 fitted stars, [9..12] their segments.  n <= 16 counters are copied. */
 int tp_linpsf_last_counts(tp_ctx* ctx, int64_t* counts, int32_t n);
+/* The positions a fit takes, for a field that moves as a whole: d_pos[s][k] = (double)(d_base[s] + d_shift[k]) -- the float32 sum the
+ * plugin's catalogue holds after catalog_attime (BasePhotometry.py:1224-1258) for a translation, widened as
+ * linpsf_photometry.py:116-121 does -- for n_stars stars and n_cad cadences, pos_pitch >= n_cad doubles per star.  (Built on the
+ * host these arrays were most of the batched LinPSF entry's time: 75 MB for 2 000 targets.) */
+int tp_star_positions(tp_ctx* ctx, int64_t n_stars, int32_t n_cad, const float* d_base, const float* d_shift, double* d_pos, int64_t pos_pitch);
 int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
 	const float* d_subtract, int64_t subtract_pitch,
 	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis, int32_t max_stars,

@@ -116,6 +116,7 @@ SIGNATURES = {
 	'tp_linpsf_prf': (c_int, [c_void_p, c_int32, c_int32, c_int32, _p, _p, _p]),
 	'tp_linpsf_set_path': (c_int, [c_void_p, c_int32]),
 	'tp_linpsf_last_counts': (c_int, [c_void_p, POINTER(ctypes.c_int64), c_int32]),
+	'tp_star_positions': (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int64]),
 	'tp_linpsf_fit': (c_int, [c_void_p, _desc_p, _p, _p, c_int64, _p, _p, _p, c_int32, c_int32, _p, _p, _p, _p, c_int64, c_double,
 		_p, _p, _p, c_int64, _p, _p, _p]),
 	'tp_psf_fit': (c_int, [c_void_p, _desc_p, _p, _p, _p, _p, _p, c_int32, _p, _p, _p, c_double, c_double, c_int32, c_int32,

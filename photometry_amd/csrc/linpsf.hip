@@ -1722,3 +1722,29 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	return TP_OK;
 	TP_API_END(ctx)
 }
+
+// positions of the fitted stars of a field that moves as a whole (see tessphot_hip.h)
+namespace {
+__global__ __launch_bounds__(256) void tp_star_positions_kernel(int64_t n_stars, int n_cad, const float* __restrict__ base, const float* __restrict__ shift,
+	double* __restrict__ pos, int64_t pitch)
+{
+	const int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n_cad) return;
+	const float sh = shift[k];
+	for (int64_t s = blockIdx.y; s < n_stars; s += gridDim.y) pos[s * pitch + k] = (double)(base[s] + sh);
+}
+} // namespace
+
+extern "C" int tp_star_positions(tp_ctx* ctx, int64_t n_stars, int32_t n_cad, const float* d_base, const float* d_shift, double* d_pos, int64_t pos_pitch)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, n_stars >= 0 && n_cad >= 0 && pos_pitch >= n_cad, "tp_star_positions: bad sizes");
+	if (n_stars == 0 || n_cad == 0) return TP_OK;
+	TP_REQUIRE(ctx, d_base && d_shift && d_pos, "tp_star_positions: null pointer");
+	const unsigned gy = (unsigned)(n_stars < 65535 ? n_stars : 65535);
+	TP_LAUNCH(ctx, TPK_LINPSF_PLAN, tp_star_positions_kernel, dim3((unsigned)((n_cad + 255) / 256), gy), dim3(256), 0, n_stars, (int)n_cad, d_base, d_shift, d_pos, pos_pitch);
+	TP_LAUNCH_CHECK(ctx, "tp_star_positions_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}

@@ -37,8 +37,12 @@ class DeviceArray(object):
 			ctx._check(ctx.lib.tp_memcpy_h2d(ctx.handle, d.ptr, a.ctypes.data, a.nbytes))
 		return d
 
-	def to_host(self):
-		out = np.empty(self.shape, dtype=self.dtype)
+	def to_host(self, out=None):
+		"""The array on the host; ``out``: a C-contiguous numpy array of this shape and dtype to copy into (no temporary)."""
+		if out is None:
+			out = np.empty(self.shape, dtype=self.dtype)
+		else:
+			assert out.shape == tuple(self.shape) and out.dtype == np.dtype(self.dtype) and out.flags['C_CONTIGUOUS'], (out.shape, out.dtype, self.shape, self.dtype)
 		if self.nbytes:
 			self.ctx._check(self.ctx.lib.tp_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
 		return out

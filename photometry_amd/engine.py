@@ -275,8 +275,9 @@ class LinPSFResult(object):
 		self.status = ctx.zeros((n_targets,), 'int32') if status is None else status
 		self.fluxes_mean = ctx.zeros((max(n_fit_stars, 1),), 'float64')
 
-	def to_host(self):
-		return {k: getattr(self, k).to_host() for k in ('flux', 'flux_err', 'fluxes_all', 'contamination', 'status', 'fluxes_mean')}
+	def to_host(self, keys=('flux', 'flux_err', 'fluxes_all', 'contamination', 'status', 'fluxes_mean')):
+		"""The arrays on the host (all of them by default; ``keys`` picks: the per-star fluxes are the largest piece and few callers want them)."""
+		return {k: getattr(self, k).to_host() for k in keys}
 
 
 def linpsf_prf(ctx, base_coef, weights, out=None):
@@ -302,6 +303,16 @@ def linpsf_last_counts(ctx):
 	return {'matrix_core_targets': int(c[0]), 'matrix_core_segments': int(c[1]), 'vector_alu_polynomial_targets': int(c[2]),
 		'vector_alu_general_targets': int(c[3]), 'many_star_targets': int(c[4]),
 		'matrix_core_targets_by_stars': [int(c[5 + i]) for i in range(4)], 'matrix_core_segments_by_stars': [int(c[9 + i]) for i in range(4)]}
+
+
+def star_positions(ctx, base, shift):
+	"""Positions of ``n_stars`` stars at ``T`` cadences for a field that moves as a whole: ``float64(base[s] + shift[k])`` with the sum
+	in float32 (what ``catalog_attime`` leaves in the plugin's catalogue for a translation), on the device (``tp_star_positions``).
+	``base``, ``shift``: float32 DeviceArrays; returns a float64 DeviceArray ``(n_stars, T)``."""
+	n, T = int(base.shape[0]), int(shift.shape[0])
+	out = ctx.empty((max(n, 1), T), 'float64')
+	ctx._check(ctx.lib.tp_star_positions(ctx.handle, n, T, base.ptr, shift.ptr, out.ptr, T))
+	return out
 
 
 def linpsf_fit(ctx, images, coef, knots_x, knots_y, star_offsets, target_index, pos_row, pos_col, max_stars,

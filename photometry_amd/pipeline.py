@@ -899,33 +899,41 @@ def linpsf_frames(ctx, stack, targets, catalog, time, quality, prf_model, jitter
 		out.stamp[i] = (-1, -2, -1, -2)
 	cat_index = _CatalogIndex(catalog)
 	jc, jr = _jitter32(jitter, T)
+	d_jc, d_jr = ctx.array(jc), ctx.array(jr)
 	base_coef, tx, ty = ctx.array(prf_model.base_coef), ctx.array(prf_model.tx), ctx.array(prf_model.ty)
 	for H, W, idx in groups:
 		cat_offsets, cat = _catalogs_of_stamps(cat_index, cur[idx])
 		sel, star_offsets, target_index = hpsf.select_stars(cat, cat_offsets, np.asarray(targets['starid'], dtype='int64')[idx])
-		pos_row = (cat['row_stamp'][sel][:, None] + jr[None, :]).astype('float64')    # float32 sums, like the plugin's catalogue
-		pos_col = (cat['column_stamp'][sel][:, None] + jc[None, :]).astype('float64')
+		# positions = catalogue position + the cadence's shift, summed in float32 like the plugin's catalogue: formed on the device
+		# (on the host the two arrays -- 75 MB for 2 000 targets -- were most of this entry's time)
+		pos_row = engine.star_positions(ctx, ctx.array(np.ascontiguousarray(cat['row_stamp'][sel], dtype='float32')), d_jr)
+		pos_col = engine.star_positions(ctx, ctx.array(np.ascontiguousarray(cat['column_stamp'][sel], dtype='float32')), d_jc)
 		cube = engine.cut_stamps(ctx, stack.dev['images'], ctx.array(cur[idx].astype('int32')), H, W, stack.row0, stack.col0)
 		try:
 			coef = engine.linpsf_prf(ctx, base_coef, ctx.array(prf_model.weights(cur[idx])))
-			res = engine.linpsf_fit(ctx, cube, coef, tx, ty, ctx.array(star_offsets), ctx.array(target_index), ctx.array(pos_row), ctx.array(pos_col),
-				max(int(np.diff(star_offsets).max()), 1), cutoff_radius=cutoff_radius).to_host()
+			fit = engine.linpsf_fit(ctx, cube, coef, tx, ty, ctx.array(star_offsets), ctx.array(target_index), pos_row, pos_col,
+				max(int(np.diff(star_offsets).max()), 1), cutoff_radius=cutoff_radius)
+			res = fit.to_host(('contamination', 'status'))
+			if len(idx) == n and np.array_equal(idx, np.arange(n)) and fit.flux.shape == out.flux.shape:
+				# one group holds every target in order (the usual case: default stamps of one size): straight into the result arrays
+				fit.flux.to_host(out=out.flux)
+				fit.flux_err.to_host(out=out.flux_err)
+			else:
+				out.flux[idx] = fit.flux.to_host()[:, :T]
+				out.flux_err[idx] = fit.flux_err.to_host()[:, :T]
 		finally:
 			ctx.sync()
 			cube.free()
-		out.flux[idx] = res['flux'][:, :T]
-		out.flux_err[idx] = res['flux_err'][:, :T]
 		out.contamination[idx] = res['contamination']
-		for j, i in enumerate(idx):
-			i = int(i)
-			if int(res['status'][j]) == 2:
-				out.status[i] = 2
-				out.errors[i] = ['All target flux values are NaN.']
-			elif res['contamination'][j] > 0.1:
-				out.status[i] = 3
-				out.errors[i] = ['High contamination']
-			else:
-				out.status[i] = 1
+		# linpsf_photometry.py:198-200, 214-219: ERROR when every flux is NaN, WARNING above 10 % contamination (NaN compares false)
+		failed = res['status'] == 2
+		with np.errstate(invalid='ignore'):
+			high = ~failed & (res['contamination'] > 0.1)
+		out.status[idx] = np.where(failed, 2, np.where(high, 3, 1))
+		for i in idx[failed]:
+			out.errors[int(i)] = ['All target flux values are NaN.']
+		for i in idx[high]:
+			out.errors[int(i)] = ['High contamination']
 	return out
 
 

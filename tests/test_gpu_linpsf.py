@@ -278,3 +278,18 @@ def test_target_without_a_fitted_star(ctx, path):
 		np.testing.assert_array_equal(got['flux'][i][:T], full['flux'][i][:T])
 		assert int(got['status'][i]) == int(full['status'][i])
 		np.testing.assert_array_equal(got['contamination'][i], full['contamination'][i])
+
+
+def test_star_positions_on_the_device():
+	"""tp_star_positions: float64(base[s] + shift[k]) with the sum in float32 -- bit for bit the host expression the batched LinPSF
+	entry used to build (and the plugin's catalogue after catalog_attime for a translation); ragged sizes, a pitch beyond T."""
+	from photometry_amd import engine
+	from photometry_amd.device import Context
+	ctx = Context(0)
+	rng = np.random.default_rng(3)
+	for n, T in ((1, 1), (7, 1300), (70001, 33), (5, 257)):
+		base = rng.uniform(0, 2048, n).astype('float32')
+		shift = rng.normal(0, 0.3, T).astype('float32')
+		got = engine.star_positions(ctx, ctx.array(base), ctx.array(shift)).to_host()
+		np.testing.assert_array_equal(got, (base[:, None] + shift[None, :]).astype('float64'))
+	ctx.close()
