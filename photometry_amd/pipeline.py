@@ -572,7 +572,7 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 			return done.value
 
 
-def aperture_frames_pipelined(ctx, stack, batches, catalog, time, quality, settings=None, cadence_s=1800, datasource='ffi', in_flight=2):
+def aperture_frames_pipelined(ctx, stack, batches, catalog, time, quality, settings=None, cadence_s=1800, datasource='ffi', in_flight=3):
 	"""
 	:func:`aperture_frames` over consecutive batches of targets of one CCD region (``batches``: an iterable of ``targets`` dicts),
 	``in_flight`` of them at a time, each on its own streams: the rounds of a batch are a strict chain -- queue the passes, wait,
