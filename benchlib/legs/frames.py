@@ -49,11 +49,11 @@ def leg_frames(ctx, args, T, np, pipeline):
 	t1 = time.perf_counter()
 	n_obj = sum(1 for b in out if b.status.value in (1, 3))
 	dobj = time.perf_counter() - t1
-	# consecutive batches (what a run over a CCD does): the same stars in another order per batch, three batches on the device at a
+	# consecutive batches (what a run over a CCD does): the same stars in another order per batch, four batches on the device at a
 	# time, each result consumed (its counts read) and let go before the next is taken
 	from photometry_amd import tessphot_frames_pipelined
 	rng = np.random.default_rng(args.seed + 8)
-	NB = 6
+	NB = 8
 	batches = []
 	for _b in range(NB):
 		sel = rng.permutation(N)
@@ -65,14 +65,14 @@ def leg_frames(ctx, args, T, np, pipeline):
 	for rep in range(3):
 		t2 = time.perf_counter()
 		okc = 0
-		for res in tessphot_frames_pipelined(ctx, stack, iter(batches), cat, tstamp, quality, in_flight=3):
+		for res in tessphot_frames_pipelined(ctx, stack, iter(batches), cat, tstamp, quality, in_flight=4):
 			okc += int(np.sum((res.status == 1) | (res.status == 3)))
 			res = None
 		dp = time.perf_counter() - t2
-		piped = {'what': f'tessphot_frames_pipelined: {NB} consecutive batches of {N} targets of the same region, three on the device at a time '
+		piped = {'what': f'tessphot_frames_pipelined: {NB} consecutive batches of {N} targets of the same region, four on the device at a time '
 			'(the first round of a batch runs under the latency-bound stamp-resize rounds of the one before; every batch equals a call of its own: '
 			'tests/test_gpu_resize.py::test_pipelined_batches_equal_separate_calls)',
-			'targets_per_s': NB * N / dp, 'seconds': dp, 'batches': NB, 'in_flight': 3, 'ok_or_warning': okc}
+			'targets_per_s': NB * N / dp, 'seconds': dp, 'batches': NB, 'in_flight': 4, 'ok_or_warning': okc}
 	return {'what': f'tessphot_frames: {N} targets on a {FR} x {FR} x {T} region resident in HBM (three frame stacks) -> columnar results '
 		'(status, stamp, resizes, diagnostics, light curves, masks in arrays; per-target objects on demand): stamp cuts, fused pass, '
 		'stamp-resize rounds and diagnostics on the device, default stamps / catalogue selection / decisions on the host (one Python process)',

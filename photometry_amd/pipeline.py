@@ -572,7 +572,7 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 			return done.value
 
 
-def aperture_frames_pipelined(ctx, stack, batches, catalog, time, quality, settings=None, cadence_s=1800, datasource='ffi', in_flight=3):
+def aperture_frames_pipelined(ctx, stack, batches, catalog, time, quality, settings=None, cadence_s=1800, datasource='ffi', in_flight=4):
 	"""
 	:func:`aperture_frames` over consecutive batches of targets of one CCD region (``batches``: an iterable of ``targets`` dicts),
 	``in_flight`` of them at a time, each on its own streams: the rounds of a batch are a strict chain -- queue the passes, wait,
@@ -595,7 +595,7 @@ def aperture_frames_pipelined(ctx, stack, batches, catalog, time, quality, setti
 				exhausted = True
 				break
 			slot = free_slots.pop()
-			job = _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s, datasource, every[3 * slot:3 * slot + 3], cat_index)
+			job = _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s, datasource, every[3 * slot:3 * slot + 3], cat_index, 1.0 / in_flight)
 			running.append([order, slot, job])
 			order += 1
 			try:
@@ -621,7 +621,7 @@ def aperture_frames_pipelined(ctx, stack, batches, catalog, time, quality, setti
 		next_out += 1
 
 
-def _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s, datasource, streams, cat_index=None):
+def _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s, datasource, streams, cat_index=None, budget_share=1.0):
 	"""The rounds of :func:`aperture_frames` as a generator: it yields wherever the host would wait for the device (after the
 	passes of a round are queued; before the last light curves have arrived) and returns the :class:`FramesResult`.  ``streams``:
 	the contexts of this job (the first one takes the large groups); ``cat_index``: a prebuilt index of ``catalog``."""
@@ -664,7 +664,7 @@ def _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s
 	events, pending = [], []
 	if '_hbm_bytes' not in ctx.__dict__:
 		ctx.__dict__['_hbm_bytes'] = ctx.info()['hbm_bytes']
-	budget = float(os.environ.get('TESSPHOT_FRAMES_BUDGET_GB', 0)) * 1e9 or ctx.__dict__['_hbm_bytes'] / 4.0
+	budget = (float(os.environ.get('TESSPHOT_FRAMES_BUDGET_GB', 0)) * 1e9 or ctx.__dict__['_hbm_bytes'] / 4.0) * budget_share   # (jobs in flight share it)
 	while len(active):
 		heights, widths = cur[active, 1] - cur[active, 0], cur[active, 3] - cur[active, 2]
 		keys = heights * 100000 + widths

@@ -225,7 +225,7 @@ def tessphot_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 	return BatchResults(res, targets['starid'])
 
 
-def tessphot_frames_pipelined(ctx, stack, batches, catalog, time, quality, settings=None, cadence_s=1800, in_flight=3):
+def tessphot_frames_pipelined(ctx, stack, batches, catalog, time, quality, settings=None, cadence_s=1800, in_flight=4):
 	"""
 	:func:`tessphot_frames` over consecutive batches of targets of one CCD region -- what a run over a whole CCD does, a few
 	thousand targets per call -- with ``in_flight`` batches on the device at a time (``pipeline.aperture_frames_pipelined``: the

@@ -49,7 +49,7 @@ if NB:
 	for b in range(NB):
 		sel = rng.permutation(N)   # the same stars in another order: the same work per batch
 		batches.append({k: np.asarray(v)[sel] for k, v in targets.items()})
-	for fl in (1, 2, 3):
+	for fl in [int(x) for x in os.environ.get('INFLIGHT', '1,2,3').split(',')]:
 		for rep in range(2):
 			prp = cProfile.Profile()
 			if rep == 1 and os.environ.get('PROFILE_PIPE'):
