@@ -201,15 +201,18 @@ def main():
 				'error cubes resident in HBM; per step the stamp background of every cadence (B*), its time smoothing (B2) and the sum image '
 				'(A1) in ONE pass over the raw cube, then AperturePhotometry.do_photometry of every target from the mask on (K2P2 mask, '
 				'extraction of flux / error / centroid / background) with the background subtracted on the fly (B3)')
+		wl_short = (f'configs[4]: {Nt} targets/GPU x {T} cad x {H}x{W}, aperture + background + LinPSF' if psf
+			else f'configs[2]: {Nt} targets x {T} cad x {H}x{W}, aperture + background')
 		gms = run.gather_ms
 		result = {
 			'metric': metric,
 			'value': n_total * args.steps / elapsed, 'unit': 'targets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
 			'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling if psf else 'weak', 'vs_baseline': None,
 			'dtype': 'f32 (aperture, background) + f64 (PSF fit)' if psf else 'f32', 'data': 'synthetic',
-			'config': {'workload': wl, 'baseline_config': 'configs[4]' if psf else 'configs[2]',
+			'config': {'workload': wl, 'workload_short': wl_short, 'baseline_config': 'configs[4]' if psf else 'configs[2]',
 				'targets_per_gpu': Nt, 'targets_total': n_total, 'cadences': T, 'stamp': [H, W],
-				'parallelism': f'targets sharded over {world} GPU(s), one process per GPU (photometry_amd.sharded), no data-path collective but the gather of the output block'},
+				'parallelism': f'targets sharded over {world} GPU(s), one process per GPU (photometry_amd.sharded), no data-path collective but the gather of the output block',
+				'parallelism_short': f'targets sharded over {world} GPU(s), 1 process/GPU, output gather only'},
 			'roofline': next(r for r in rooflines if r['kernel'] == dom),
 			'rooflines': rooflines,
 			'step_hbm': {'necessary_bytes_per_step': step_bytes, 'GBps_over_whole_step': step_bytes / (elapsed / args.steps) / 1e9,
@@ -278,7 +281,11 @@ def main():
 			result['fit_background_frames'] = leg_fullframe(ctx, args, np)
 
 	if rank == 0:
-		print(json.dumps(result))
+		# the full result (every leg with its notes) goes to bench_legs.json and stderr; stdout gets ONE short, self-checked line
+		from benchlib.line import emit
+		line = emit(result, ROOT, stream=sys.stderr)
+		sys.stdout.flush()
+		print(line)
 		sys.stdout.flush()
 	if dist is not None:
 		dist.barrier()

@@ -143,6 +143,7 @@ def cpu_baseline(ctx, scene, cubes, work, args, T, H, W, time_smooth):
 		'sample': f'{ns} of the {scene.n_targets} targets of the same device-generated raw cubes ({per} per worker process); oracle = numpy '
 			'restatement of the reference per-cadence loops: stamp background (B*, B2, B3) + sum image + K2P2 + extraction; rate = '
 			'targets / slowest worker compute time; BLAS / OpenMP threads pinned to 1',
+		'sample_short': f'{ns} of {scene.n_targets} targets of the same cubes, {per} per process; numpy oracle',
 		'rates_by_process_count': {str(k): v for k, v in rates.items()},
 		'single_core_targets_per_s': n1 / t1,
 		'calibration': 'dev-container timing of the reference\'s own AperturePhotometry.do_photometry loop (mask given, 15x15x1300) beside this '
