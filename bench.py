@@ -60,6 +60,10 @@ def parse_args(argv=None):
 	p.add_argument('--cpu-procs', type=int, default=0, help='worker processes of the all-core CPU baseline (0 = physical cores)')
 	p.add_argument('--seed', type=int, default=1)
 	p.add_argument('--no-gather', action='store_true')
+	p.add_argument('--gather-when', choices=('auto', 'step', 'final'), default='auto', help='N > 1: gather the output block every step (under the next '
+		"step's compute), once after the last step, or (auto) whichever the warm-up's measurement favours")
+	p.add_argument('--host-group', choices=('socket', 'gloo'), default='socket', help='N > 1: the host-side group (rendezvous, barriers, RCCL id): '
+		'plain TCP sockets (no PyTorch) or torch.distributed gloo')
 	p.add_argument('--no-extra', action='store_true', help='skip the extra legs (premade cubes, LinPSF, end to end, stages)')
 	p.add_argument('--e2e-targets', type=int, default=2048, help='targets of the end-to-end (H2D included) leg (0 = skip)')
 	p.add_argument('--frame', type=int, default=1024, help='side of the frame stack of the stamp-cutter stage (0 = skip)')
@@ -78,11 +82,9 @@ def main():
 		sys.exit(sharded.spawn_ranks(__file__, sys.argv[1:], args.gpus))
 	rank, local_rank, world = sharded.rank_environment()
 	args.gpus = world
-	# torch is plumbing only, and only for N > 1 (gloo rendezvous, barrier, max over ranks); imported BEFORE the HIP library so
-	# that one HIP runtime is shared.  A single-GPU run never loads it.
-	torch = dist = None
-	if world > 1:
-		torch, dist = sharded.init_host_group(rank, world)
+	# the host-side group of a multi-rank run (rendezvous, barrier, max over ranks, the RCCL id): plain TCP sockets by default --
+	# no PyTorch is imported; --host-group gloo takes torch.distributed's gloo group instead (imported BEFORE the HIP library)
+	group = sharded.init_host_group(rank, world, kind=args.host_group)
 
 	import numpy as np
 	from photometry_amd import simulate, engine, pipeline, _lib
@@ -97,8 +99,6 @@ def main():
 	shared_device = world > ndev.value
 	device = local_rank % ndev.value
 	ctx = Context(device)
-	if torch is not None and torch.cuda.is_available():
-		torch.cuda.set_device(device)
 
 	workload = args.workload or ('c4' if world > 1 else 'c2')
 	psf = workload == 'c4'
@@ -117,19 +117,36 @@ def main():
 	scene.aperture = None
 	extras = (world == 1) and (workload == 'c2') and not args.no_extra
 	worker = sharded.DeviceShardWorker(ctx, scene, capacity=Nt, psf=psf, nbuf=2 if world > 1 else 1, extras=extras)
-	run = sharded.ShardedRun(worker, Nt * world, rank=rank, world=world, dist=dist, torch=torch,
-		gather='none' if args.no_gather else 'auto', shared_device=shared_device)
+	run = sharded.ShardedRun(worker, Nt * world, rank=rank, world=world, group=group,
+		gather='none' if args.no_gather else 'auto', when='step', shared_device=shared_device)
 	cubes, batch, lin = worker.cubes, worker.batch, worker.lin
 
 	def device_sync():
 		run.sync()
-		if torch is not None and torch.cuda.is_available():
-			torch.cuda.synchronize(device)
 
-	run.run_steps(args.warmup)
+	# warm-up, with the gather of every step on the second stream: its measured duration beside the step without a gather
+	# decides whether the timed region gathers every step (it hides under the next step) or once at the end
+	run.run_steps(args.warmup, collect=True)
+	step_alone_ms = None
+	if run.gathers:
+		if len(run.gather_ms) < 2:
+			run.run_steps(2 * run.nbuf, collect=True)
+		nalone = max(1, min(args.steps, 5))
+		device_sync()
+		run.barrier()
+		t1 = time.perf_counter()
+		for _ in range(nalone):
+			worker.step(0)
+		device_sync()
+		step_alone_ms = run.max_over_ranks((time.perf_counter() - t1) / nalone * 1e3)
+		if args.gather_when == 'auto':
+			run.choose_when(step_alone_ms)
+		else:
+			run.when = args.gather_when
+	per_step_gather_ms = list(run.gather_ms)
+	del run.gather_ms[:]
 	device_sync()
 	run.barrier()
-	del run.gather_ms[:]
 	ctx.profile(True)
 	ctx.profile_reset()
 	t0 = time.perf_counter()
@@ -140,18 +157,7 @@ def main():
 	ctx.profile(False)
 	prof = ctx.profile_report()
 	work = worker.works[run.last_buffer if run.last_buffer is not None else 0]
-	# the same step without the gather (N > 1): what the overlap has to hide the gather under
-	step_alone_ms = None
-	if run.gathers:
-		nalone = max(1, min(args.steps, 5))
-		device_sync()
-		run.barrier()
-		t1 = time.perf_counter()
-		for _ in range(nalone):
-			worker.step(0)
-		device_sync()
-		step_alone_ms = (time.perf_counter() - t1) / nalone * 1e3
-		run.barrier()
+	per_step_gather_ms = run.gather_ms or per_step_gather_ms
 
 	result = None
 	if rank == 0:
@@ -203,7 +209,7 @@ def main():
 				'extraction of flux / error / centroid / background) with the background subtracted on the fly (B3)')
 		wl_short = (f'configs[4]: {Nt} targets/GPU x {T} cad x {H}x{W}, aperture + background + LinPSF' if psf
 			else f'configs[2]: {Nt} targets x {T} cad x {H}x{W}, aperture + background')
-		gms = run.gather_ms
+		gms = per_step_gather_ms
 		result = {
 			'metric': metric,
 			'value': n_total * args.steps / elapsed, 'unit': 'targets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -219,13 +225,18 @@ def main():
 				'frac_of_hbm_peak': step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 'mean_mask_pixels': n_mask / Nt,
 				'note': 'the raw cube is read once per step (rounds 1-3: twice -- the background kernel, then the sum-image phase of the fused kernel)'},
 			'kernels': rows,
-			'gather': {'mode': run.mode, 'bytes_per_rank_per_step': worker.block_nbytes if world > 1 else 0,
+			'gather': {'mode': run.mode, 'when': run.when if run.gathers else None, 'bytes_per_rank_per_step': worker.block_nbytes if world > 1 else 0,
 				'block': 'light curves [5][Nt][T] f64 + contamination f64 + status, flags i32 + mask u8 per target' + (' + LinPSF light curve [Nt][T] f64, contamination f64, status i32' if psf else '') + ', one message per rank (comm.packed_block_layout)',
-				'issued': 'every step, second stream, double-buffered output block' if run.gathers else None,
+				'issued': ('every step, second stream, double-buffered output block' if run.when == 'step' else 'once, after the last step (inside the timed region)') if run.gathers else None,
+				'issued_short': run.when if run.gathers else None,
 				'mean_ms': (sum(gms) / len(gms)) if gms else None,
+				'mean_ms_from': ('the timed region' if run.gather_ms else 'the warm-up steps (per-step gather, before the timed region chose "final")') if gms else None,
+				'final_ms': (sum(run.final_ms) / len(run.final_ms)) if run.final_ms else None,
 				'step_ms_without_gather': step_alone_ms,
 				'ideal_ms_one_xgmi_link': worker.block_nbytes / (XGMI_LINK_GBS * 1e9) * 1e3 if world > 1 else None,
-				'measured_on': 'never on an 8-GPU node so far (this pool gives one GPU per call): the N > 1 lines come from the driver\'s node, if it has one',
+				'measured_8gpu': False,
+				'measured_on': 'never on an 8-GPU node so far (this pool gives one GPU per call): the N > 1 lines come from the driver\'s node, if it has one; no 8-GPU scaling curve exists',
+				'host_group': type(group).__name__,
 				'xgmi_rate_assumed': f'{XGMI_LINK_GBS} GB/s one way per link: the root receives from its N - 1 peers on N - 1 links at once (direct '
 					'send / recv pairs in one RCCL group), so the gather is bound by ONE inbound link per peer; if the 153 GB/s of the guide is the '
 					'bidirectional figure the ideal doubles -- mean_ms beside step_ms_without_gather is the measurement that decides'},
@@ -287,11 +298,10 @@ def main():
 		sys.stdout.flush()
 		print(line)
 		sys.stdout.flush()
-	if dist is not None:
-		dist.barrier()
-		dist.destroy_process_group()
+	group.barrier()
 	run.close()
 	ctx.close()
+	group.close()
 
 
 if __name__ == '__main__':

@@ -154,6 +154,23 @@ def init(ctx, uid, rank, world):
 	ctx._check(ctx.lib.tp_comm_init(ctx.handle, uid, len(uid), int(rank), int(world)))
 
 
+def init_from_group(ctx, group):
+	"""Distribute the RCCL unique id (128 bytes, made on rank 0) through the host group (``hostgroup.SocketGroup`` /
+	``TorchGroup``) and create the communicator on ``ctx``."""
+	uid, err = b'', None
+	if group.rank == 0:
+		try:
+			uid = unique_id()
+		except Exception as e: # noqa: B902 -- the other ranks are waiting in the broadcast: tell them, then raise
+			err = e
+	uid = group.broadcast_bytes(uid, src=0)
+	if err is not None:
+		raise err
+	if len(uid) != 128:
+		raise RuntimeError('rank 0 could not make the RCCL unique id')
+	init(ctx, uid, group.rank, group.world)
+
+
 def init_from_torch(ctx, dist, rank, world):
 	"""Distribute the RCCL unique id through an already initialised torch.distributed group."""
 	obj = [unique_id() if rank == 0 else None]

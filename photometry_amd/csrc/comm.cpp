@@ -77,15 +77,26 @@ int tp_comm_gather(tp_ctx* ctx, const void* d_send, void* d_recv, uint64_t nbyte
 	}
 	ncclComm_t comm = (ncclComm_t)ctx->comm;
 	TP_NCCL(ctx, ncclGroupStart());
+	// inside the group no early return: a failed call is remembered, the group is ALWAYS closed, then the first error is
+	// reported (a return between ncclGroupStart and ncclGroupEnd would leave the communicator in an open group)
+	ncclResult_t first = ncclSuccess;
+	const char* what = nullptr;
 	if (me == root) {
-		for (int r = 0; r < n; r++) {
+		for (int r = 0; r < n && first == ncclSuccess; r++) {
 			if (r == root) continue;
-			TP_NCCL(ctx, ncclRecv(static_cast<char*>(d_recv) + (size_t)r * nbytes_per_rank, (size_t)nbytes_per_rank, ncclChar, r, comm, ctx->stream));
+			ncclResult_t e = ncclRecv(static_cast<char*>(d_recv) + (size_t)r * nbytes_per_rank, (size_t)nbytes_per_rank, ncclChar, r, comm, ctx->stream);
+			if (e != ncclSuccess) { first = e; what = "ncclRecv"; }
 		}
 	} else {
-		TP_NCCL(ctx, ncclSend(d_send, (size_t)nbytes_per_rank, ncclChar, root, comm, ctx->stream));
+		ncclResult_t e = ncclSend(d_send, (size_t)nbytes_per_rank, ncclChar, root, comm, ctx->stream);
+		if (e != ncclSuccess) { first = e; what = "ncclSend"; }
 	}
-	TP_NCCL(ctx, ncclGroupEnd());
+	ncclResult_t e_end = ncclGroupEnd();
+	if (first == ncclSuccess && e_end != ncclSuccess) { first = e_end; what = "ncclGroupEnd"; }
+	if (first != ncclSuccess) {
+		ctx->err = std::string("tp_comm_gather: ") + what + ": " + ncclGetErrorString(first);
+		return TP_ERR_COMM;
+	}
 	if (me == root) {
 		char* mine = static_cast<char*>(d_recv) + (size_t)root * nbytes_per_rank;
 		if (mine != d_send)

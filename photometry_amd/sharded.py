@@ -24,7 +24,6 @@ CPU ranks with uneven shards):
 """
 
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -35,23 +34,43 @@ from . import comm as tpcomm
 # --------------------------------------------------------------------------------------------------
 # ranks
 # --------------------------------------------------------------------------------------------------
-def spawn_ranks(script, argv, n_ranks):
+def spawn_ranks(script, argv, n_ranks, poll_s=0.2, grace_s=10.0):
 	"""
-	Start one fresh child process per rank (``script argv...`` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) BEFORE
-	anything in this process touches the GPU, relay rank 0's standard output, return the worst exit code.
+	Start one fresh child process per rank (``script argv...`` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR and a rendezvous
+	id of this launch set) BEFORE anything in this process touches the GPU, relay rank 0's standard output, return the worst
+	exit code.  The ranks are watched together: when one fails, the others -- who would wait for it in a rendezvous or a
+	barrier until a timeout -- are terminated and the failure's code is returned.
 	"""
-	with socket.socket() as s:
-		s.bind(('127.0.0.1', 0))
-		port = s.getsockname()[1]
+	import uuid
+	rdzv = uuid.uuid4().hex
 	procs = []
 	for r in range(int(n_ranks)):
 		env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR='127.0.0.1',
-			MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+			TESSPHOT_RDZV_ID=rdzv, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+		env.pop('MASTER_PORT', None)
 		procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env,
 			stdout=None if r == 0 else subprocess.DEVNULL))
 	rc = 0
+	live = list(procs)
+	while live:
+		time.sleep(poll_s)
+		for p in list(live):
+			code = p.poll()
+			if code is None:
+				continue
+			live.remove(p)
+			if code != 0 and rc == 0:
+				rc = abs(code) or 1
+				for q in live:          # exactly the processes started above, by handle -- never by pattern
+					q.terminate()
+				deadline = time.monotonic() + grace_s
+				for q in live:
+					try:
+						q.wait(max(0.0, deadline - time.monotonic()))
+					except subprocess.TimeoutExpired:
+						q.kill()
 	for p in procs:
-		rc = max(rc, abs(p.wait()))
+		p.wait()
 	return rc
 
 
@@ -60,24 +79,14 @@ def rank_environment():
 	return int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
 
 
-def init_host_group(rank, world):
+def init_host_group(rank, world, kind='socket'):
 	"""
-	The gloo process group of a multi-rank run (rendezvous, barriers, max over ranks, the unique id of the RCCL communicator).
-	torch is plumbing only and is imported only here, BEFORE the HIP library, so that one HIP runtime is shared.  gloo announces
-	its connections on stdout (C level): stdout is kept clean for the caller's one result line.  Returns ``(torch, dist)``.
+	The host-side group of a multi-rank run (rendezvous, barriers, max over ranks, the id of the RCCL communicator):
+	``hostgroup.SocketGroup`` by default -- standard library only, **no PyTorch in a multi-GPU run** -- or, with
+	``kind='gloo'``, ``torch.distributed``'s gloo group (torch is then imported here, BEFORE the HIP library).
 	"""
-	import torch
-	import torch.distributed as dist
-	os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-	sys.stdout.flush()
-	saved = os.dup(1)
-	os.dup2(2, 1)
-	try:
-		dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-	finally:
-		os.dup2(saved, 1)
-		os.close(saved)
-	return torch, dist
+	from . import hostgroup
+	return hostgroup.open_group(rank, world, kind)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -153,17 +162,32 @@ class DeviceShardWorker(ShardWorker):
 # --------------------------------------------------------------------------------------------------
 class ShardedRun(object):
 	"""
-	The step loop of one rank with the per-step gather of the output block to rank 0.
+	The step loop of one rank with the gather of the output block to rank 0.
 
 	``gather``: ``'rccl'`` (device blocks, ``tp_comm_gather`` on a second high-priority stream: direct send / recv pairs in one
-	group, so the root receives from its N - 1 peers at once), ``'host'`` (the block goes through host memory and
-	``dist.gather``: CPU workers, and the control-flow fallback when ranks share a device), ``'auto'`` (RCCL when every rank
-	has a device of its own and the communicator comes up on all of them, else host), ``'none'``.
-	With one rank nothing is gathered: the block of the last step is the result.
+	group, so the root receives from its N - 1 peers at once), ``'host'`` (the block goes through host memory and the host
+	group: CPU workers, and the control-flow fallback when ranks share a device), ``'auto'`` (RCCL when every rank has a device
+	of its own and the communicator comes up on all of them, else host), ``'none'``.
+	``when``: ``'step'`` -- the block of EVERY step is gathered, on the second stream from the other half of the double-buffered
+	block, under the next step's compute; ``'final'`` -- one gather after the last step of a ``run_steps`` call (north_star's
+	"final light-curve gather": nothing to hide, nothing in the way of the steps).  :meth:`choose_when` picks between them from
+	what was measured.  With one rank nothing is gathered: the block of the last step is the result.
+
+	``group``: the host-side group (``hostgroup.SocketGroup`` / ``TorchGroup``); ``dist`` + ``torch`` (an initialised
+	``torch.distributed`` group) are still accepted and wrapped.  ``run_steps`` may be called any number of times: which blocks
+	have a gather in flight is kept on the instance.
 	"""
 
-	def __init__(self, worker, n_total, rank=0, world=1, dist=None, torch=None, gather='auto', shared_device=False):
-		self.worker, self.n_total, self.rank, self.world, self.dist, self.torch = worker, int(n_total), int(rank), int(world), dist, torch
+	def __init__(self, worker, n_total, rank=0, world=1, group=None, dist=None, torch=None, gather='auto', when='step', shared_device=False):
+		from . import hostgroup
+		if group is None:
+			group = hostgroup.TorchGroup(dist, torch, rank, world) if (dist is not None and world > 1) else hostgroup.SingleGroup()
+		if world > 1 and group.world != world:
+			raise ValueError(f'the host group has {group.world} ranks, the run {world}')
+		if when not in ('step', 'final'):
+			raise ValueError("when must be 'step' or 'final'")
+		self.worker, self.n_total, self.rank, self.world, self.group = worker, int(n_total), int(rank), int(world), group
+		self.when = when
 		self.sizes = tpcomm.shard_sizes(n_total, world)
 		self.range = tpcomm.shard_range(n_total, world, rank)
 		if worker.n_local != self.sizes[rank]:
@@ -173,14 +197,15 @@ class ShardedRun(object):
 		self.nbuf = worker.nbuf
 		self.cat_sizes = None
 		if 'cat_in_mask' in worker.layout:
-			self.cat_sizes = [int(worker.n_cat_local)]
-			if world > 1:
-				self.cat_sizes = [None] * world
-				dist.all_gather_object(self.cat_sizes, int(worker.n_cat_local))
+			self.cat_sizes = group.allgather_int(worker.n_cat_local) if world > 1 else [int(worker.n_cat_local)]
 		self.comm_ctx = None
 		self.recv = [None] * self.nbuf
-		self.gather_ms = []
+		self.gather_ms = []              # durations of the per-step gathers that were collected
+		self.final_ms = []               # durations of the final gathers that were collected
 		self.last_buffer = None
+		self._gathered_buffer = None     # the block rank 0 last received
+		self._in_flight = [False] * self.nbuf   # a gather of block b has been issued and block b not waited for since
+		self._timer = [None] * self.nbuf        # a started timer of block b that has not been read: the list its duration goes to (or False)
 		self.mode = 'none (single rank)' if world == 1 else 'disabled'
 		if world > 1 and gather != 'none':
 			self.mode = self._open_gather(gather, shared_device)
@@ -196,7 +221,7 @@ class ShardedRun(object):
 	def _open_gather(self, gather, shared_device):
 		w = self.worker
 		if w.ctx is None or gather == 'host':
-			return 'host (gloo)'
+			return 'host'
 		from .device import Context
 		# its copy kernels must not queue behind a grid that fills every CU
 		self.comm_ctx = Context(w.ctx.device, high_priority=True)
@@ -205,59 +230,84 @@ class ShardedRun(object):
 			ok, note = 0, 'ranks share a GPU: RCCL needs one device per rank'
 		else:
 			try:
-				tpcomm.init_from_torch(self.comm_ctx, self.dist, self.rank, self.world)
+				tpcomm.init_from_group(self.comm_ctx, self.group)
 			except Exception as e: # noqa: B902
 				ok, note = 0, f'RCCL communicator not created ({e})'
-		t = self.torch.tensor([ok], dtype=self.torch.int32)
-		self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-		if int(t[0]) == 1:
+		if int(self.group.min(ok)) == 1:
 			if self.rank == 0:
 				self.recv = [w.ctx.empty((self.world, w.block_nbytes), 'uint8') for _ in range(self.nbuf)]
 			return 'rccl'
 		if gather == 'rccl':
 			raise RuntimeError('RCCL gather asked for but not available: ' + (note or 'another rank failed'))
-		# control-flow fallback (never on a real multi-GPU node): the block goes through host memory and gloo
-		return 'host-gloo fallback: ' + (note or 'RCCL unavailable on another rank')
+		# control-flow fallback (never on a real multi-GPU node): the block goes through host memory and the host group
+		return 'host fallback: ' + (note or 'RCCL unavailable on another rank')
 
-	# ---- one step's gather ---------------------------------------------------------------------
-	def _gather(self, b):
+	# ---- one gather ----------------------------------------------------------------------------
+	def _read_timer(self, b):
+		"""The duration of the last timed gather of block ``b`` goes where it was asked for (waits for that gather)."""
+		if self._timer[b] is not None:
+			ms = self.comm_ctx.timer_ms(b)
+			if self._timer[b] is not False:
+				self._timer[b].append(ms)
+			self._timer[b] = None
+
+	def _gather(self, b, into):
+		"""Queue (RCCL) or do (host) the gather of block ``b``; ``into``: the list its duration is appended to, or None."""
 		w = self.worker
+		self._gathered_buffer = b
 		if self.mode == 'rccl':
+			w.ctx.record(self.ev_done[b])
+			self._read_timer(b)
 			self.comm_ctx.wait_event(self.ev_done[b])
 			self.comm_ctx.timer_start(b)
 			tpcomm.gather(self.comm_ctx, w.block(b), self.recv[b], root=0)
 			self.comm_ctx.timer_stop(b)
 			self.comm_ctx.record(self.ev_free[b])
+			self._timer[b] = into if into is not None else False
+			self._in_flight[b] = True
 			return
 		w.sync()
 		t0 = time.perf_counter()
 		blk = w.block(b)
-		h = self.torch.from_numpy(np.ascontiguousarray(blk.to_host() if hasattr(blk, 'to_host') else blk))
-		out = [self.torch.empty_like(h) for _ in range(self.world)] if self.rank == 0 else None
-		self.dist.gather(h, out, dst=0)
+		got = self.group.gather_array(blk.to_host() if hasattr(blk, 'to_host') else blk, dst=0)
 		if self.rank == 0:
-			self._host_recv = [o.numpy() for o in out]
-		self.gather_ms.append((time.perf_counter() - t0) * 1e3)
+			self._host_recv = got
+		if into is not None:
+			into.append((time.perf_counter() - t0) * 1e3)
 
-	def run_steps(self, n, collect=False):
-		"""``n`` steps; with ``collect`` the durations of the gathers are recorded (``gather_ms``)."""
+	def run_steps(self, n, collect=False, when=None):
+		"""``n`` steps; with ``collect`` the durations of the gathers are recorded (``gather_ms`` per step, ``final_ms``)."""
 		w, ctx = self.worker, self.worker.ctx
+		when = when or self.when
 		rccl = self.mode == 'rccl'
+		b = None
 		for s in range(n):
 			b = s % self.nbuf
-			if rccl and s >= self.nbuf:
-				if collect:
-					self.gather_ms.append(self.comm_ctx.timer_ms(b))   # waits for gather s - nbuf (long finished)
-				ctx.wait_event(self.ev_free[b])                        # block b has left for rank 0: it may be overwritten
+			if rccl and self._in_flight[b]:
+				# a gather of block b is (or was) on its way -- whichever call issued it: the block may be overwritten only once
+				# it has left for rank 0
+				self._read_timer(b)
+				ctx.wait_event(self.ev_free[b])
+				self._in_flight[b] = False
 			w.step(b)
 			self.last_buffer = b
-			if self.gathers:
-				if ctx is not None:
-					ctx.record(self.ev_done[b])
-				self._gather(b)
+			if self.gathers and when == 'step':
+				self._gather(b, self.gather_ms if collect else None)
+		if self.gathers and when == 'final' and b is not None:
+			self._gather(b, self.final_ms if collect else None)
 		if rccl and collect:
-			for s in range(max(0, n - self.nbuf), n):
-				self.gather_ms.append(self.comm_ctx.timer_ms(s % self.nbuf))
+			for k in range(self.nbuf):
+				self._read_timer(k)
+
+	def choose_when(self, step_ms_without_gather):
+		"""
+		``'final'`` when the per-step gather cannot hide under a step (its measured mean duration, the slowest rank's, exceeds the
+		step without a gather, the slowest rank's), else ``'step'``; the same answer on every rank.  Sets and returns ``self.when``.
+		"""
+		if self.gathers:
+			mean = (sum(self.gather_ms) / len(self.gather_ms)) if self.gather_ms else 0.0
+			self.when = 'final' if self.group.max(mean) > self.group.max(step_ms_without_gather) else 'step'
+		return self.when
 
 	def sync(self):
 		self.worker.sync()
@@ -265,15 +315,10 @@ class ShardedRun(object):
 			self.comm_ctx.sync()
 
 	def barrier(self):
-		if self.dist is not None:
-			self.dist.barrier()
+		self.group.barrier()
 
 	def max_over_ranks(self, value):
-		if self.dist is None:
-			return float(value)
-		t = self.torch.tensor([float(value)], dtype=self.torch.float64)
-		self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-		return float(t[0])
+		return self.group.max(value)
 
 	# ---- results -------------------------------------------------------------------------------
 	def collect(self):
@@ -285,6 +330,8 @@ class ShardedRun(object):
 		if self.rank != 0 or self.last_buffer is None:
 			return None
 		w, b = self.worker, self.last_buffer
+		if self.gathers and self._gathered_buffer != b:
+			raise RuntimeError('the block of the last step has not been gathered')
 		if not self.gathers:
 			blk = w.block(b)
 			blocks = [blk.to_host() if hasattr(blk, 'to_host') else np.asarray(blk)]

@@ -139,11 +139,12 @@ class _NumpyWorker(object):
 		pass
 
 
-def _sharded_run(n_total, world, rank, dist=None, torch=None, steps=3):
+def _sharded_run(n_total, world, rank, group=None, steps=3, when='step', calls=1):
 	from photometry_amd import sharded
 	w = _NumpyWorker(n_total, world, rank)
-	run = sharded.ShardedRun(w, n_total, rank=rank, world=world, dist=dist, torch=torch, gather='auto')
-	run.run_steps(steps, collect=True)
+	run = sharded.ShardedRun(w, n_total, rank=rank, world=world, group=group, gather='auto', when=when)
+	for _ in range(calls):                     # run_steps is re-entrant: the state of the double buffer lives on the instance
+		run.run_steps(steps, collect=True)
 	run.barrier()
 	res = run.collect()
 	out = None
@@ -153,26 +154,44 @@ def _sharded_run(n_total, world, rank, dist=None, torch=None, steps=3):
 		res['final_status'] = run.replay(res, g['starid'], g['tmag'], skip)
 		res['n_skip'] = np.array([sum(len(s) for s in skip)])
 		res['mode'] = run.mode
+		res['n_gathers'] = np.array([len(run.gather_ms), len(run.final_ms)])
 		out = res
 	run.close()
 	return out
 
 
-def _sharded_worker(rank, world, port, n_total, outfile):
+def _sharded_worker(rank, world, port, n_total, outfile, kind='gloo', when='step', calls=1):
 	sys.path.insert(0, ROOT)
 	os.environ['MASTER_ADDR'] = '127.0.0.1'
 	os.environ['MASTER_PORT'] = str(port)
 	os.environ['RANK'], os.environ['LOCAL_RANK'], os.environ['WORLD_SIZE'] = str(rank), str(rank), str(world)
 	from photometry_amd import sharded
 	assert sharded.rank_environment() == (rank, rank, world)
-	torch, dist = sharded.init_host_group(rank, world)
-	res = _sharded_run(n_total, world, rank, dist=dist, torch=torch)
+	group = sharded.init_host_group(rank, world, kind=kind)
+	assert type(group).__name__ == {'gloo': 'TorchGroup', 'socket': 'SocketGroup'}[kind]
+	if kind == 'socket':
+		assert 'torch' not in sys.modules or os.environ.get('TP_TEST_SPAWNED_BY_TORCH') == '1'
+	res = _sharded_run(n_total, world, rank, group=group, when=when, calls=calls)
 	if rank == 0:
 		mode = res.pop('mode')
-		assert mode == 'host (gloo)', mode
+		assert mode == 'host', mode
 		np.savez(outfile, **res)
-	dist.barrier()
-	dist.destroy_process_group()
+	group.barrier()
+	group.close()
+
+
+def _compare_with_single_process(got, n_total, steps_total=3, when='step'):
+	ref = _sharded_run(n_total, 1, 0, steps=steps_total)
+	assert ref.pop('mode') == 'none (single rank)'
+	ng, nr = got.pop('n_gathers'), ref.pop('n_gathers')
+	assert list(nr) == [0, 0]
+	assert set(got) == set(ref)
+	for k in ref:
+		np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+		assert got[k].dtype == ref[k].dtype, k
+	assert got['lc'].shape == (5, n_total, _NumpyWorker.T) and int(got['n_skip'][0]) > 0
+	assert (got['final_status'] == 5).any() and (got['final_status'] != ref['status']).any()   # the replay did something
+	return list(ng)
 
 
 @pytest.mark.parametrize('n_total,world', [(100003, 3), (11, 2)])
@@ -185,15 +204,115 @@ def test_sharded_run_uneven_shards_equals_single_process(tmp_path, n_total, worl
 	out = str(tmp_path / 'sharded.npz')
 	port = 33500 + (os.getpid() % 2000)
 	mp.spawn(_sharded_worker, args=(world, port, n_total, out), nprocs=world, join=True)
-	got = dict(np.load(out))
-	ref = _sharded_run(n_total, 1, 0)
-	assert ref.pop('mode') == 'none (single rank)'
-	assert set(got) == set(ref)
-	for k in ref:
-		np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
-		assert got[k].dtype == ref[k].dtype, k
-	assert got['lc'].shape == (5, n_total, _NumpyWorker.T) and int(got['n_skip'][0]) > 0
-	assert (got['final_status'] == 5).any() and (got['final_status'] != ref['status']).any()   # the replay did something
+	assert _compare_with_single_process(dict(np.load(out)), n_total) == [3, 0]
+
+
+def _spawn_plain(target, args, world):
+	"""Ranks as plain child processes (multiprocessing 'spawn': fresh interpreters, as on a GPU node), no torch anywhere."""
+	import multiprocessing
+	ctx = multiprocessing.get_context('spawn')
+	procs = [ctx.Process(target=target, args=(r,) + args) for r in range(world)]
+	for p in procs:
+		p.start()
+	for p in procs:
+		p.join(600)
+	assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+@pytest.mark.parametrize('when,calls', [('step', 1), ('final', 1), ('step', 2)])
+def test_sharded_run_over_the_socket_group_without_torch(tmp_path, when, calls):
+	"""The same run with the host group on plain TCP sockets (hostgroup.SocketGroup: rank 0 on an ephemeral port announced in a
+	rendezvous file; no PyTorch imported in any rank), gathering every step, once at the end, and with run_steps called twice
+	back to back (the second call must wait for the first call's gathers before it overwrites their blocks)."""
+	out = str(tmp_path / 'sock.npz')
+	n_total, world = 1003, 3
+	os.environ['TESSPHOT_RDZV_ID'] = 'test_%d_%s_%d' % (os.getpid(), when, calls)
+	try:
+		_spawn_plain(_sharded_worker, (world, 0, n_total, out, 'socket', when, calls), world)
+	finally:
+		del os.environ['TESSPHOT_RDZV_ID']
+	ng = _compare_with_single_process(dict(np.load(out)), n_total, steps_total=3 * calls)
+	assert ng == {('step', 1): [3, 0], ('final', 1): [0, 1], ('step', 2): [6, 0]}[(when, calls)]
+
+
+def test_strong_scaling_100k_targets_over_8_cpu_ranks(tmp_path):
+	"""BASELINE configs[4]'s division in small: 100 000 targets over 8 ranks (12 500 each, tiny cadence count) through
+	sharded.ShardedRun on CPU ranks, final gather, reassembled and replayed == the single-process run."""
+	out = str(tmp_path / 'strong.npz')
+	n_total, world = 100000, 8
+	from photometry_amd import comm as tpcomm
+	assert tpcomm.shard_sizes(n_total, world) == [12500] * 8
+	os.environ['TESSPHOT_RDZV_ID'] = 'test_strong_%d' % os.getpid()
+	try:
+		_spawn_plain(_sharded_worker, (world, 0, n_total, out, 'socket', 'final', 1), world)
+	finally:
+		del os.environ['TESSPHOT_RDZV_ID']
+	assert _compare_with_single_process(dict(np.load(out)), n_total) == [0, 1]
+
+
+def _group_worker(rank, world, outdir):
+	sys.path.insert(0, ROOT)
+	from photometry_amd import hostgroup
+	g = hostgroup.SocketGroup(rank, world, rendezvous_timeout=60)
+	assert g.max(rank * 1.5) == (world - 1) * 1.5 and g.min(rank + 2) == 2
+	assert g.allgather_int(rank * rank) == [r * r for r in range(world)]
+	assert g.broadcast_bytes(b'\x01' * 128 if rank == 0 else b'', src=0) == b'\x01' * 128
+	a = np.full((3, 5), rank, dtype='int32')
+	got = g.gather_array(a)
+	if rank == 0:
+		assert [int(x[0, 0]) for x in got] == list(range(world)) and got[1].dtype == a.dtype and got[1].shape == a.shape
+		assert not os.path.exists(hostgroup.rendezvous_file())       # removed once every rank is connected
+	else:
+		assert got is None
+	g.barrier()
+	g.close()
+	open(os.path.join(outdir, 'ok%d' % rank), 'w').close()
+
+
+def test_socket_group_collectives_and_stale_rendezvous_file(tmp_path):
+	"""hostgroup.SocketGroup on 4 ranks; a stale rendezvous file of an 'earlier launch' (a dead port) is in the way: the ranks
+	must retry until rank 0 has replaced it."""
+	from photometry_amd import hostgroup
+	os.environ['TESSPHOT_RDZV_ID'] = 'test_group_%d' % os.getpid()
+	try:
+		with open(hostgroup.rendezvous_file(), 'w') as fh:
+			fh.write('1 999999\n')                                   # port 1: nobody listens there
+		_spawn_plain(_group_worker, (4, str(tmp_path)), 4)
+	finally:
+		del os.environ['TESSPHOT_RDZV_ID']
+	assert sorted(os.listdir(tmp_path)) == ['ok0', 'ok1', 'ok2', 'ok3']
+
+
+def test_socket_group_under_torch_distributed_run(tmp_path):
+	"""As the driver starts the N > 1 bench: ``python -m torch.distributed.run --master-port P``.  MASTER_PORT belongs to the
+	launcher's own store there; the socket group must come up beside it (rendezvous file named after the launcher's pid), and
+	the ranks themselves import no torch."""
+	pytest.importorskip('torch')
+	import subprocess
+	script = tmp_path / 'rank.py'
+	script.write_text(
+		"import os, sys\nsys.path.insert(0, %r)\nfrom photometry_amd import sharded\n"
+		"rank, lr, world = sharded.rank_environment()\ng = sharded.init_host_group(rank, world)\n"
+		"assert type(g).__name__ == 'SocketGroup' and g.max(rank) == world - 1 and g.allgather_int(rank) == list(range(world))\n"
+		"assert 'torch' not in sys.modules\ng.barrier(); g.close()\nopen(os.path.join(%r, 'ok%%d' %% rank), 'w').close()\n" % (ROOT, str(tmp_path)))
+	port = 27500 + (os.getpid() % 2000)
+	env = {k: v for k, v in os.environ.items() if k != 'TESSPHOT_RDZV_ID'}
+	r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '3', '--master-addr', '127.0.0.1',
+		'--master-port', str(port), str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+	assert r.returncode == 0, r.stdout.decode()[-3000:]
+	assert sorted(f for f in os.listdir(tmp_path) if f.startswith('ok')) == ['ok0', 'ok1', 'ok2']
+
+
+def test_spawn_ranks_ends_the_survivors_when_a_rank_fails(tmp_path):
+	"""sharded.spawn_ranks: rank 1 exits with an error at once, rank 0 would wait for it for ever: the launcher must end it and
+	return the failure."""
+	import time
+	from photometry_amd import sharded
+	script = tmp_path / 'rank.py'
+	script.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\nassert os.environ['TESSPHOT_RDZV_ID']\ntime.sleep(600)\n")
+	t0 = time.time()
+	assert sharded.spawn_ranks(str(script), [], 2, grace_s=5.0) == 7
+	assert time.time() - t0 < 60
 
 
 def test_packed_block_with_psf_outputs_two_ranks(tmp_path):
