@@ -273,7 +273,8 @@ int tp_background_sumimage(tp_ctx* ctx, const tp_cube_desc* desc, const float* d
  * tp_background_mesh (B1, first half): the low-resolution mesh of backgrounds.fit_background for a plain image
  *   (photometry/backgrounds.py:89-97 pixel mask; :200-206 photutils Background2D on box_size x box_size cells with
  *   SigmaClip(3, maxiters = 5) and the SExtractor estimator): d_mesh float64 [n_frames][ny][nx] (NaN for a cell without an
- *   unmasked pixel), d_nmasked int32 [n_frames][ny][nx] (masked or padded pixels of the cell), ny = ceil(rows / box_size).
+ *   unmasked pixel), d_nmasked int32 [n_frames][ny][nx] (masked, padded or sigma-clipped pixels of the cell: photutils' mesh_nmasked, what its
+ *   second mesh selection compares with exclude_percentile), ny = ceil(rows / box_size).
  *   d_exclude: optional uint8 manual-exclude image(s) [frame_rows][frame_cols] (exclude_frame_stride 0 = one for all frames).
  *   d_subtract: optional float32 image(s) [frame_rows][frame_cols] taken off the pixel values after the masking (the radial
  *   component of a TESS image, :200: Background2D(img0 - img_bkg_radial, mask = mask)).

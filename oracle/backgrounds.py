@@ -154,6 +154,11 @@ def mesh_statistics(img, mask, box=64, sigma=3.0, maxiters=5):
 	``edge_method='pad'``), the unmasked pixels of every cell are sigma-clipped ONCE (``Background2D`` applies its own
 	``sigma_clip`` and switches the estimator's off) and reduced by the SExtractor estimate.  Returns ``(mesh float64
 	(ny, nx), nmasked int (ny, nx))``; a cell without any unmasked pixel is NaN.
+
+	``nmasked`` counts what photutils' SECOND mesh selection counts (``Background2D._calc_bkg_bkgrms``: "perform mesh rejection
+	on sigma-clipped data (i.e., for any newly-masked pixels)", ``np.ma.count_masked(data_sigclip, axis=1)``; its
+	``mesh_nmasked`` property is the same number): the input mask, the padding AND the pixels the sigma clip rejected.  The
+	first selection (input mask + padding only) is implied by it: the clip only adds masked pixels.
 	"""
 	img = np.asarray(img)
 	R, C = img.shape
@@ -164,20 +169,14 @@ def mesh_statistics(img, mask, box=64, sigma=3.0, maxiters=5):
 		for i in range(nx):
 			cell = img[j*box:(j+1)*box, i*box:(i+1)*box]
 			m = mask[j*box:(j+1)*box, i*box:(i+1)*box]
-			nmasked[j, i] = box*box - int(np.sum(~m))     # padded pixels count as masked
 			data = sigma_clip(cell[~m], sigma, maxiters)
+			nmasked[j, i] = box*box - data.size           # masked + padded + clipped pixels
 			mesh[j, i] = sextractor_background(data)
 	return mesh, nmasked
 
 
-def mesh_to_background(mesh, nmasked, shape, box=64, exclude_percentile=50.0, filter_size=3):
-	"""
-	From the mesh to the full-resolution background, photutils 1.3.0 as published: cells with more than
-	``exclude_percentile`` % masked pixels are dropped and filled by inverse-distance weighting from the 10 nearest kept
-	cells (``ShepardIDWInterpolator``, power 1); 3 x 3 median filter (``generic_filter(nanmedian, mode='constant',
-	cval=nan)``); ``BkgZoomInterpolator``: cubic-spline ``scipy.ndimage.zoom(mesh, box, order=3, mode='reflect',
-	grid_mode=True)``, clipped to the range of the mesh.  scipy is called directly, as photutils does.
-	"""
+def finish_mesh(mesh, nmasked, box=64, exclude_percentile=50.0, filter_size=3):
+	"""The low-resolution half of :func:`mesh_to_background`: rejected cells filled, then the 3 x 3 NaN-ignoring median filter."""
 	from scipy import ndimage
 	mesh = np.array(mesh, dtype='float64', copy=True)
 	good = (nmasked <= exclude_percentile / 100.0 * box * box) & np.isfinite(mesh)
@@ -193,6 +192,21 @@ def mesh_to_background(mesh, nmasked, shape, box=64, exclude_percentile=50.0, fi
 			mesh[y, x] = np.sum(w * vals[near]) / np.sum(w)
 	if filter_size > 1:
 		mesh = ndimage.generic_filter(mesh, np.nanmedian, size=filter_size, mode='constant', cval=np.nan)
+	return mesh
+
+
+def mesh_to_background(mesh, nmasked, shape, box=64, exclude_percentile=50.0, filter_size=3):
+	"""
+	From the mesh to the full-resolution background, photutils 1.3.0 as published: cells with more than
+	``exclude_percentile`` % masked pixels (``nmasked <= exclude_percentile / 100 * box**2`` keeps a cell, ``_select_meshes``;
+	``nmasked`` after the sigma clip, see :func:`mesh_statistics`) are dropped and filled by inverse-distance weighting from
+	the 10 nearest kept cells (``ShepardIDWInterpolator``, power 1, weights ``1 / distance`` in mesh-index units; which of
+	several EQUIDISTANT cells make the ten is cKDTree's traversal order upstream and index order here: unpinned); 3 x 3 median filter (``generic_filter(nanmedian, mode='constant',
+	cval=nan)``); ``BkgZoomInterpolator``: cubic-spline ``scipy.ndimage.zoom(mesh, box, order=3, mode='reflect',
+	grid_mode=True)``, clipped to the range of the mesh.  scipy is called directly, as photutils does.
+	"""
+	from scipy import ndimage
+	mesh = finish_mesh(mesh, nmasked, box, exclude_percentile, filter_size)
 	if mesh.shape == (1, 1):
 		return np.full(shape, mesh[0, 0])
 	bkg = ndimage.zoom(mesh, box, order=3, mode='reflect', cval=0.0, grid_mode=True)

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(kMeshThreads) void tp_bkg_mesh_kernel(MeshArgs a)
 	}
 	// ---- SigmaClip(3, maxiters = 5) on the rank range [lo, hi), then the SExtractor estimate
 	double result = __builtin_nan("");
+	int nkept = 0;
 	if (n > 0) {
 		int lo = 0, hi = n;
 		double med = 0.0, mean = 0.0, sd = 0.0;
@@ -161,11 +162,14 @@ __global__ __launch_bounds__(kMeshThreads) void tp_bkg_mesh_kernel(MeshArgs a)
 		if (sd == 0.0) result = mean;
 		else if (fabs(mean - med) / sd < 0.3) result = 2.5 * med - 1.5 * mean;
 		else result = med;
+		nkept = hi - lo;
 	}
 	if (tid == 0) {
 		const int64_t o = ((int64_t)frame * a.ny + by) * a.nx + bx;
 		a.mesh[o] = result;
-		a.nmasked[o] = npix - n;
+		// photutils selects the cells a SECOND time on the sigma-clipped data (Background2D._calc_bkg_bkgrms; mesh_nmasked):
+		// masked, padded and clipped pixels all count against exclude_percentile
+		a.nmasked[o] = npix - nkept;
 	}
 }
 
@@ -430,13 +434,12 @@ __global__ __launch_bounds__(256) void tp_mesh_finish_kernel(const double* __res
 		for (int w = 1; w < 4; ++w) { l = (red[w] != red[w] || l != l) ? __builtin_nan("") : fmin(l, red[w]); hmax = (red[4 + w] != red[4 + w] || hmax != hmax) ? __builtin_nan("") : fmax(hmax, red[4 + w]); }
 		vmin[frame] = l; vmax[frame] = hmax;
 	}
-	if (ny > 1 && nx > 1) {
-		// spline_filter1d(axis = 1 of (T, ny, nx)) = along the rows' index y, for every column; then along x for every row
-		for (int x = tid; x < nx; x += 256) prefilter_reflect(a + x, ny, nx);
-		__syncthreads();
-		for (int y = tid; y < ny; y += 256) prefilter_reflect(a + y * nx, nx, 1);
-		__syncthreads();
-	}
+	// spline_filter1d(axis = 1 of (T, ny, nx)) = along the rows' index y, for every column; then along x for every row.  An axis
+	// of length one is left alone (scipy skips it; the zoom is constant along it): a single row or column of cells is the 1-D case.
+	for (int x = tid; x < nx; x += 256) prefilter_reflect(a + x, ny, nx);
+	__syncthreads();
+	for (int y = tid; y < ny; y += 256) prefilter_reflect(a + y * nx, nx, 1);
+	__syncthreads();
 	for (int i = tid; i < nc; i += 256) outc[i] = a[i];
 }
 

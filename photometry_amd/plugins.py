@@ -176,12 +176,23 @@ class BasePhotometry(object):
 			pos_centroid=np.zeros((self.Ntimes, 2)), pos_corr=np.zeros((self.Ntimes, 2)))
 		if getattr(src, 'jitter', None) is not None:
 			self.lightcurve['pos_corr'] = np.array(src.jitter, dtype='float64')
-		# The timestamp offset of the early data releases (fixes/time_offset.py upstream, applied at BasePhotometry.py:244 / :384 for
-		# sectors 1-21) belongs to the input adapter: a source hands over corrected times.  A source
-		# that passes a header with DATA_REL but does not say that it did so gets a WARNING in the details instead of silence.
+		# The timestamp offset of the early data releases (fixes/time_offset.py upstream, applied at BasePhotometry.py:244 / :384)
+		# belongs to the input adapter: a source hands over corrected times.  The reference applies
+		# the correction silently (a DEBUG record, fixes/time_offset.py:125), so nothing may enter details['errors'] here: a source
+		# that passes one of the data releases the reference WOULD correct (DATA_REL <= 26 always, 27 / 29 depending on PROCVER:
+		# fixes/time_offset.py:99-120) without saying that it did is noted at INFO level, once per source.
 		if self.data_rel is not None and not (self.header.get('TIME_OFFSET_CORRECTED') or getattr(src, 'time_offset_corrected', False)):
-			logger.warning("Timestamps used as the source delivered them (DATA_REL = %s, no TIME_OFFSET_CORRECTED in its header): the "
-				"time-offset correction of the early data releases is the input adapter's job.", self.data_rel)
+			try:
+				affected = int(self.data_rel) <= 26 or int(self.data_rel) in (27, 29)
+			except (TypeError, ValueError):
+				affected = False
+			if affected and not getattr(src, '_time_offset_noted', False):
+				logger.info("Timestamps used as the source delivered them (DATA_REL = %s, no TIME_OFFSET_CORRECTED in its header): the "
+					"time-offset correction of the early data releases is the input adapter's job.", self.data_rel)
+				try:
+					src._time_offset_noted = True
+				except AttributeError:
+					pass
 
 		self.final_phot_mask = None
 		self.final_position_mask = None

@@ -18,7 +18,6 @@ import ctypes
 import logging
 import warnings
 import numpy as np
-from scipy import ndimage
 from scipy.interpolate import InterpolatedUnivariateSpline
 from .engine import TESS_DEFAULT_BITMASK
 
@@ -30,6 +29,9 @@ PIXEL_BACKGROUND_SHENANIGANS = 4
 
 def finish_mesh(mesh, nmasked, box=64, exclude_percentile=50.0, filter_size=3):
 	"""
+	(Host statement of what ``tp_background_mesh_finish`` does on the device -- kept for the tests that hold the kernel to numpy;
+	``fit_background_frames`` does not call it.)
+
 	The low-resolution part of photutils ``Background2D`` (1.3.0) after the per-cell statistics, for one frame ``(ny, nx)`` or
 	a batch ``(T, ny, nx)``: cells with more than ``exclude_percentile`` % masked pixels are replaced by the inverse-distance
 	weighted mean of the 10 nearest kept cells, then the 3 x 3 median filter.  Returns the filtered mesh (float64).  A single
@@ -169,24 +171,10 @@ def _square_component(ctx, frames, flux_cutoff, box, exclude, estride, subtract,
 	mesh, nmasked, coef, vmin, vmax = (work[k] for k in ('mesh', 'nmasked', 'coef', 'vmin', 'vmax'))
 	ctx._check(ctx.lib.tp_background_mesh(ctx.handle, frames.ptr, T, R, C, C, R * C, None if exclude is None else exclude.ptr, estride,
 		None if subtract is None else subtract.ptr, R * C, float(flux_cutoff), int(box), mesh.ptr, nmasked.ptr))
-	if ny * nx <= 2048:
-		ctx._check(ctx.lib.tp_background_mesh_finish(ctx.handle, mesh.ptr, nmasked.ptr, T, ny, nx, int(box), 50.0, 3, coef.ptr, vmin.ptr, vmax.ptr, None))
-	else:
-		# a mesh beyond the LDS-resident kernel (frames above ~2900 pixels a side): finished on the host like round 2
-		m = finish_mesh(mesh.to_host(), nmasked.to_host(), box)
-		c = m
-		if min(ny, nx) > 1:
-			c = ndimage.spline_filter1d(ndimage.spline_filter1d(m, order=3, axis=1, mode='reflect'), order=3, axis=2, mode='reflect')
-		for dst, src in ((coef, c), (vmin, np.min(m, axis=(1, 2))), (vmax, np.max(m, axis=(1, 2)))):
-			a = np.ascontiguousarray(src, dtype='float64')
-			ctx._check(ctx.lib.tp_memcpy_h2d(ctx.handle, dst.ptr, a.ctypes.data, a.nbytes))
-	if min(ny, nx) > 1:
-		ctx._check(ctx.lib.tp_background_zoom(ctx.handle, coef.ptr, vmin.ptr, vmax.ptr, T, ny, nx, int(box), R, C, C, R * C, out.ptr))
-	else:
-		# a single row / column of cells: ndimage.zoom of a length-1 axis is constant along it; photutils' answer is the cell value
-		host = np.empty((T, R, C), dtype='float32')
-		host[:] = coef.to_host()[:, :1, :1]
-		ctx._check(ctx.lib.tp_memcpy_h2d(ctx.handle, out.ptr, host.ctypes.data, host.nbytes))
+	if ny * nx > 2048:
+		raise ValueError(f'fit_background_frames: a {R} x {C} frame has {ny} x {nx} cells of {box} pixels; the device finishes meshes of at most 2048 cells')
+	ctx._check(ctx.lib.tp_background_mesh_finish(ctx.handle, mesh.ptr, nmasked.ptr, T, ny, nx, int(box), 50.0, 3, coef.ptr, vmin.ptr, vmax.ptr, None))
+	ctx._check(ctx.lib.tp_background_zoom(ctx.handle, coef.ptr, vmin.ptr, vmax.ptr, T, ny, nx, int(box), R, C, C, R * C, out.ptr))
 	if want_host:
 		return mesh.to_host(), nmasked.to_host()
 	return None, None

@@ -79,6 +79,7 @@ def oracle_batch(s, S, cut_override=None):
 def compare(s, S, got, ref, check_cut=True):
 	"""``got``: dict of arrays mask,status,flags,contamination,diag,cat_in_mask.  Returns stats dict."""
 	n_exact = 0
+	n_error_agree = 0
 	n_razor = 0
 	n_tie = 0
 	margins = []
@@ -130,7 +131,9 @@ def compare(s, S, got, ref, check_cut=True):
 			fl = int(got['flags'][i])
 			assert bool(fl & 2) == ('down' in e) and bool(fl & 4) == ('up' in e) and bool(fl & 8) == ('left' in e) and bool(fl & 16) == ('right' in e)
 			n_exact += 1
-	return {'n_exact': n_exact, 'n_razor': n_razor, 'n_tie': n_tie, 'min_margin': float(np.min(margins)) if margins else np.nan,
+		else:
+			n_error_agree += 1   # no mask on the reference's side (ERROR): the statuses were asserted equal above
+	return {'n_exact': n_exact, 'n_error_agree': n_error_agree, 'n_razor': n_razor, 'n_tie': n_tie, 'min_margin': float(np.min(margins)) if margins else np.nan,
 		'max_dcut': float(np.max(dcuts)) if dcuts else 0.0}
 
 

@@ -404,9 +404,77 @@ def test_prepare_pixel_flags_and_headers(ctx):
 		ref_bkg, _ = ob.fit_background_tess(f[k], 1, 4, exclude=manexcl[k], device_arithmetic=True)
 		np.testing.assert_allclose(us_t[k], ref_bkg, rtol=1e-5)
 		ref_lit, _ = ob.fit_background_tess(f[k], 1, 4, exclude=manexcl[k])
-		np.testing.assert_allclose(us_t[k], ref_lit, rtol=2e-3)   # literal float32 log10 of numpy: ties of the KDE argmax may flip
+		# literal float32 log10 of numpy: a ring whose KDE argmax sits on a tie may land on the neighbouring grid point; measured on 32
+		# full frames (profiles/r4_tess_flip_stats.txt): 1.3e-4 at worst with a flipped ring, asserted at 5e-4 like the tests above
+		np.testing.assert_allclose(us_t[k], ref_lit, rtol=5e-4)
 	smooth = np.moveaxis(ob.smooth_time(np.moveaxis(us_t, 0, -1), 3), -1, 0)
 	np.testing.assert_array_equal(res_h['backgrounds'].to_host(), smooth)
+
+
+def test_mesh_path_hand_cases_on_device(ctx):
+	"""The hand-derived cases of tests/test_oracle_pins.py (photutils Background2D after the cell statistics) through the device
+	entries: tp_background_mesh_finish (IDW fill of a rejected cell from its ten nearest kept cells, 2048 / 2049 masked pixels,
+	fewer kept cells than neighbours, the NaN-ignoring 3 x 3 median at corners and edges), tp_background_zoom (3 x 3 ramp mesh
+	against the hand formula, a 32 x 32 mesh against the tridiagonal solve, frame edges and cropped last cells) and the whole
+	fit_background_frames on a frame that is no multiple of 64 and on one where only the SECOND mesh selection (after the
+	sigma clip) rejects a cell."""
+	import test_oracle_pins as pins
+	from photometry_amd import prepare
+
+	def finish(mesh, nm, filter_size):
+		ny, nx = mesh.shape
+		d_mesh, d_nm = ctx.array(np.ascontiguousarray(mesh[None], dtype='float64')), ctx.array(np.ascontiguousarray(nm[None], dtype='int32'))
+		coef, vmin, vmax, filt = ctx.empty((1, ny, nx), 'float64'), ctx.empty((1,), 'float64'), ctx.empty((1,), 'float64'), ctx.empty((1, ny, nx), 'float64')
+		ctx._check(ctx.lib.tp_background_mesh_finish(ctx.handle, d_mesh.ptr, d_nm.ptr, 1, ny, nx, 64, 50.0, filter_size, coef.ptr, vmin.ptr, vmax.ptr, filt.ptr))
+		return filt.to_host()[0], coef, vmin, vmax
+
+	mesh, nm, expect = pins.mesh_idw_case()
+	got = finish(mesh, nm, 1)[0]
+	assert abs(got[2, 2] - expect) < 1e-13 * expect
+	keep = np.ones((5, 5), bool); keep[2, 2] = False
+	np.testing.assert_array_equal(got[keep], mesh[keep])
+	mesh, nm, expect = pins.mesh_few_cells_case()
+	got = finish(mesh, nm, 1)[0]
+	assert abs(got[0, 0] - expect) < 1e-14 * expect and got[0, 1] == 4.0 and got[1, 0] == 8.0 and got[1, 1] == 16.0
+	np.testing.assert_array_equal(finish(pins.MEDIAN_3X3_IN, np.zeros((3, 3), dtype='int32'), 3)[0], pins.MEDIAN_3X3_OUT)
+	assert np.all(np.isnan(finish(np.ones((2, 2)), np.full((2, 2), 4096, dtype='int32'), 3)[0]))   # nothing kept: NaN (photutils raises)
+
+	def zoom(mesh, box, R, C):
+		ny, nx = mesh.shape
+		_, coef, vmin, vmax = finish(mesh, np.zeros(mesh.shape, dtype='int32'), 1)
+		out = ctx.empty((1, R, C), 'float32')
+		ctx._check(ctx.lib.tp_background_zoom(ctx.handle, coef.ptr, vmin.ptr, vmax.ptr, 1, ny, nx, box, R, C, C, R * C, out.ptr))
+		return out.to_host()[0].astype('float64')
+
+	ramp = 10.0 + np.arange(3)[None, :] + 3.0 * np.arange(3)[:, None]
+	for box, (R, C) in ((64, (192, 192)), (64, (150, 131)), (4, (12, 12))):
+		got = zoom(ramp, box, R, C)
+		# the hand answer within scipy's three-sample prefilter deviation (see test_zoom_of_a_ramp_mesh_by_hand) ...
+		np.testing.assert_allclose(got, pins.zoom_ramp_expected(box, R, C), rtol=0, atol=5e-3)
+		assert got[0, 0] == 10.0 and got[-1, -1] == 18.0
+	m32 = pins.zoom_mesh_32()
+	want = pins.exact_zoom(m32, 4)
+	# ... and exactly (float32 output: 6e-8 relative) where the mesh has the size of a real frame's
+	np.testing.assert_allclose(zoom(m32, 4, 128, 128), want, rtol=1.2e-7)
+	np.testing.assert_allclose(zoom(m32, 4, 126, 125), want[:126, :125], rtol=1.2e-7)
+
+	# a single row / column of cells: the 1-D case (scipy leaves an axis of length one alone, the zoom is constant along it)
+	from scipy import ndimage
+	for shape in ((1, 5), (4, 1), (1, 1)):
+		m1 = np.random.default_rng(3).normal(50, 3, shape)
+		want1 = np.clip(ndimage.zoom(m1, 8, order=3, mode='reflect', grid_mode=True), m1.min(), m1.max())
+		np.testing.assert_allclose(zoom(m1, 8, 8 * shape[0], 8 * shape[1]), want1, rtol=1.2e-7)
+
+	img, expect = pins.make_ragged_frame()
+	bkg, mesh, nmasked = prepare.fit_background_frames(ctx, ctx.array(img[None]), return_mask=True)
+	np.testing.assert_array_equal(nmasked[0], [[0, 3712], [1792, 3880]])
+	np.testing.assert_array_equal(mesh[0], [[5.0, 1234.0], [9.0, 0.5]])
+	np.testing.assert_allclose(bkg.to_host()[0], expect, rtol=1e-7)
+	img, expect = pins.make_second_selection_frame()
+	bkg, mesh, nmasked = prepare.fit_background_frames(ctx, ctx.array(img[None]), return_mask=True)
+	np.testing.assert_array_equal(nmasked[0].ravel(), [2050, 0])          # 2040 masked + the 10 pixels the sigma clip rejected
+	np.testing.assert_array_equal(mesh[0].ravel(), [100.0, 300.0])
+	np.testing.assert_allclose(bkg.to_host()[0], expect, rtol=1e-7)
 
 
 def test_median_filter_15_shared_columns(ctx):

@@ -35,7 +35,7 @@ def test_k2p2_fuzz_forty_scenes():
 	with get_context('fork').Pool(nproc) as pool:
 		refs = dict(pool.map(_oracle_job, jobs, chunksize=1))
 	ctx = Context(0)
-	tot = {'targets': 0, 'n_exact': 0, 'n_razor': 0}
+	tot = {'targets': 0, 'n_exact': 0, 'n_error_agree': 0, 'n_razor': 0}
 	worst = 0.0
 	for job in jobs:
 		s, S = make_cases(*job)
@@ -44,7 +44,8 @@ def test_k2p2_fuzz_forty_scenes():
 		tot['targets'] += s.n_targets
 		tot['n_exact'] += st['n_exact']
 		tot['n_razor'] += st['n_razor']
+		tot['n_error_agree'] += st['n_error_agree']
 		worst = max(worst, st['max_dcut'])
 	ctx.close()
 	print('K2P2 fuzz:', tot, 'largest |dCUT|', worst)
-	assert tot['targets'] >= 1000 and tot['n_razor'] == 0 and tot['n_exact'] > 0.7 * tot['targets']
+	assert tot['targets'] >= 1000 and tot['n_razor'] == 0 and tot['n_exact'] + tot['n_error_agree'] == tot['targets'] and tot['n_exact'] > 0

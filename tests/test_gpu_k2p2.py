@@ -48,7 +48,7 @@ def test_k2p2_matches_oracle(ctx, kind, seed):
 	stats = compare(s, S, got, ref)
 	print(kind, stats)
 	# the razor-edge escape of k2p2_common.compare is for new seeds only: on the committed seeds no target may use it
-	assert stats['n_exact'] >= s.n_targets // 2 and stats['n_razor'] == 0
+	assert stats['n_exact'] + stats['n_error_agree'] == s.n_targets and stats['n_exact'] > 0 and stats['n_razor'] == 0
 
 
 def test_k2p2_large_stamp_work_arrays_in_hbm(ctx):

@@ -248,3 +248,223 @@ def test_move_median_central_by_hand():
 	g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'golden_misc.npz'))
 	np.testing.assert_array_equal(prepare._move_median_central(g['mmc_in'], 3), g['mmc_out'])
 	np.testing.assert_array_equal(ob.move_median_central(g['mmc_in'], 3), g['mmc_out'])
+
+
+#--------------------------------------------------------------------------------------------------
+# The mesh path of fit_background: photutils Background2D (1.3.0) after the cell statistics (backgrounds.py:200-206).
+# Every expected number below is derived by hand in the comments, none is computed by the code under test.  The same cases run
+# through the device entries in tests/test_gpu_fullframe.py::test_mesh_path_hand_cases_on_device.
+#--------------------------------------------------------------------------------------------------
+SQ2 = np.sqrt(2.0)
+
+#: 3 x 3 mesh 1..9: nanmedian of every 3 x 3 window, windows off the mesh padded with NaN (generic_filter(mode='constant', cval=nan)).
+#: corner (0,0): {1,2,4,5} -> 3; edge (0,1): {1..6} -> 3.5; (0,2): {2,3,5,6} -> 4; (1,0): {1,2,4,5,7,8} -> 4.5; centre: 5; ...
+MEDIAN_3X3_IN = np.arange(1.0, 10.0).reshape(3, 3)
+MEDIAN_3X3_OUT = np.array([[3.0, 3.5, 4.0], [4.5, 5.0, 5.5], [6.0, 6.5, 7.0]])
+
+
+def mesh_idw_case():
+	"""5 x 5 mesh, the centre cell (2,2) has 2049 of 4096 pixels masked -> rejected (2048 would be kept); its value must not matter.
+	The ten nearest kept cells: four at distance 1 (values 10, 20, 30, 40), four at sqrt(2) (all 50), and two of the four at
+	distance 2, which all hold 7 (the tie among equidistant cells cannot change the answer).  Shepard weights 1 / d:
+	    (10 + 20 + 30 + 40) / 1 + 4 * 50 / sqrt(2) + 2 * 7 / 2   over   4 + 4 / sqrt(2) + 2 / 2"""
+	mesh = np.full((5, 5), 3.0)
+	mesh[1, 2], mesh[3, 2], mesh[2, 1], mesh[2, 3] = 10.0, 20.0, 30.0, 40.0
+	mesh[1, 1] = mesh[1, 3] = mesh[3, 1] = mesh[3, 3] = 50.0
+	mesh[0, 2] = mesh[4, 2] = mesh[2, 0] = mesh[2, 4] = 7.0
+	mesh[2, 2] = -1e9
+	nm = np.zeros((5, 5), dtype='int32')
+	nm[2, 2] = 2049
+	nm[0, 0] = 2048                                   # exactly 50 %: kept, keeps its 3.0
+	expect = (100.0 + 200.0 / SQ2 + 7.0) / (4.0 + 4.0 / SQ2 + 1.0)
+	return mesh, nm, expect
+
+
+def mesh_few_cells_case():
+	"""2 x 2 mesh with one rejected cell: fewer kept cells than neighbours asked for (10) -- all three are used.
+	(0,0) rejected; kept (0,1) = 4 at d = 1, (1,0) = 8 at d = 1, (1,1) = 16 at d = sqrt(2):  (4 + 8 + 16 / sqrt(2)) / (2 + 1 / sqrt(2))"""
+	mesh = np.array([[np.nan, 4.0], [8.0, 16.0]])     # a NaN statistic (no unmasked pixel) is a rejected cell
+	nm = np.array([[4096, 0], [0, 0]], dtype='int32')
+	return mesh, nm, (12.0 + 16.0 / SQ2) / (2.0 + 1.0 / SQ2)
+
+
+def spline_ramp_1d(x):
+	"""The interpolating cubic spline of the samples [0, 1, 2] with the half-sample symmetric extension (scipy 'reflect':
+	d c b a | a b c d | d c b a) at coordinate x, by hand: the B-spline coefficients c solve (c[k-1] + 4 c[k] + c[k+1]) / 6 = m[k]
+	with c[-1] = c[0], c[3] = c[2]:  5 c0 + c1 = 0,  c0 + 4 c1 + c2 = 6,  c1 + 5 c2 = 12  ->  c = (-1/5, 1, 11/5)."""
+	c = np.array([-0.2, 1.0, 2.2])
+
+	def B3(t):
+		t = abs(t)
+		return (4.0 - 6.0 * t * t + 3.0 * t**3) / 6.0 if t < 1 else ((2.0 - t)**3 / 6.0 if t < 2 else 0.0)
+
+	def refl(k):
+		k = -k - 1 if k < 0 else k
+		return 2 * 3 - 1 - k if k >= 3 else k
+	k0 = int(np.floor(x)) - 1
+	return sum(c[refl(k)] * B3(x - k) for k in range(k0, k0 + 4))
+
+
+def zoom_ramp_expected(box, rows, cols):
+	"""BkgZoomInterpolator on the 3 x 3 mesh m[j, i] = 10 + i + 3 j: scipy.ndimage.zoom(order=3, mode='reflect', grid_mode=True)
+	samples the spline at (p + 1/2) / box - 1/2; the spline of a sum of a function of i and a function of j is the sum of the 1-D
+	splines and the spline of a constant is the constant; then the clip to the range of the mesh [10, 18]."""
+	sx = np.array([spline_ramp_1d((p + 0.5) / box - 0.5) for p in range(cols)])
+	sy = np.array([spline_ramp_1d((p + 0.5) / box - 0.5) for p in range(rows)])
+	return np.clip(10.0 + sx[None, :] + 3.0 * sy[:, None], 10.0, 18.0)
+
+
+def exact_zoom(mesh, box):
+	"""The same interpolation for any mesh WITHOUT scipy's recursive prefilter: the B-spline coefficients from the tridiagonal
+	system (c[k-1] + 4 c[k] + c[k+1]) / 6 = m[k] with the half-sample symmetric ends (c[-1] = c[0], c[n] = c[n-1]) solved by
+	numpy.linalg.solve along both axes, then the tensor-product cubic B-spline at (p + 1/2) / box - 1/2, clipped to the mesh range."""
+	def coefs(m):
+		n = m.shape[0]
+		A = np.zeros((n, n))
+		for k in range(n):
+			A[k, k] += 4.0
+			A[k, max(k - 1, 0)] += 1.0
+			A[k, min(k + 1, n - 1)] += 1.0
+		return np.linalg.solve(A / 6.0, m)
+
+	def basis(n):
+		W = np.zeros((n * box, n))
+		for p in range(n * box):
+			x = (p + 0.5) / box - 0.5
+			k0 = int(np.floor(x)) - 1
+			for k in range(k0, k0 + 4):
+				t = abs(x - k)
+				w = (4.0 - 6.0 * t * t + 3.0 * t**3) / 6.0 if t < 1 else ((2.0 - t)**3 / 6.0 if t < 2 else 0.0)
+				kk = -k - 1 if k < 0 else k
+				kk = 2 * n - 1 - kk if kk >= n else kk
+				W[p, kk] += w
+		return W
+	c = coefs(coefs(mesh).T).T
+	return np.clip(basis(mesh.shape[0]) @ c @ basis(mesh.shape[1]).T, mesh.min(), mesh.max())
+
+
+def test_spline_ramp_by_hand_values():
+	"""The hand evaluation itself at points worked out on paper: at a sample the spline interpolates (s(1) = 1: (c0 + 4 c1 + c2) / 6);
+	half-way, with B3(1/2) = 23/48 and B3(3/2) = 1/48: s(1/2) = (c0 + 23 c0 + 23 c1 + c2) / 48 = (-4.8 + 23 + 2.2) / 48 = 0.425 (a straight
+	line would give 0.5: the reflecting boundary flattens the ends); at the frame edge x = -1/2 the extension is symmetric, the
+	slope is zero and s(-1/2) = (c1 + 23 c0 + 23 c0 + c1) / 48 = (2 - 9.2) / 48 = -0.15."""
+	assert abs(spline_ramp_1d(1.0) - 1.0) < 1e-15 and abs(spline_ramp_1d(0.0)) < 1e-15 and abs(spline_ramp_1d(2.0) - 2.0) < 1e-15
+	assert abs(spline_ramp_1d(0.5) - 0.425) < 1e-15
+	assert abs(spline_ramp_1d(-0.5) + 0.15) < 1e-15
+	assert abs(spline_ramp_1d(-0.5 + 1e-7) - spline_ramp_1d(-0.5 - 1e-7)) < 1e-13      # symmetric about the edge
+	assert abs(spline_ramp_1d(2.5) - 2.15) < 1e-15                                      # the other edge, by the ramp's symmetry
+
+
+@pytest.mark.parametrize('which', ['oracle', 'product'])
+def test_mesh_finish_hand_cases(which):
+	from oracle import backgrounds as ob
+	from photometry_amd import prepare
+
+	def finish(mesh, nm, filter_size):
+		if which == 'product':
+			return prepare.finish_mesh(mesh, nm, 64, filter_size=filter_size)
+		return ob.finish_mesh(mesh, nm, 64, filter_size=filter_size)
+	# IDW fill of a rejected cell from its ten nearest kept cells; 2048 masked pixels are still kept
+	mesh, nm, expect = mesh_idw_case()
+	got = finish(mesh, nm, 1)
+	assert abs(got[2, 2] - expect) < 1e-13 * expect
+	keep = np.ones((5, 5), bool); keep[2, 2] = False
+	np.testing.assert_array_equal(got[keep], mesh[keep])
+	# fewer kept cells than neighbours
+	mesh, nm, expect = mesh_few_cells_case()
+	got = finish(mesh, nm, 1)
+	assert abs(got[0, 0] - expect) < 1e-14 * expect and got[0, 1] == 4.0 and got[1, 0] == 8.0 and got[1, 1] == 16.0
+	# the NaN-ignoring 3 x 3 median at corners and edges
+	np.testing.assert_array_equal(finish(MEDIAN_3X3_IN, np.zeros((3, 3), dtype='int32'), 3), MEDIAN_3X3_OUT)
+	# nothing kept
+	with pytest.raises(ValueError):
+		finish(np.ones((2, 2)), np.full((2, 2), 4096, dtype='int32'), 3)
+
+
+def test_rejection_rule_reaches_the_zoomed_background():
+	"""2048 masked pixels of 4096 keep a cell, 2049 reject it -- seen in the full-resolution output of the oracle."""
+	from oracle import backgrounds as ob
+	mesh = np.array([[1.0, 2.0], [3.0, 4.0]])
+	for n, kept in ((2048, True), (2049, False)):
+		nm = np.zeros((2, 2), dtype='int64'); nm[0, 0] = n
+		out = ob.mesh_to_background(mesh, nm, (128, 128), box=64, filter_size=1)
+		# kept: the zoomed mesh still reaches its minimum 1.0 in the corner cell; rejected: the cell was filled from the others (> 2)
+		assert (out.min() < 1.5) == kept
+
+
+def test_zoom_of_a_ramp_mesh_by_hand():
+	"""3 x 3 ramp mesh against the hand evaluation.  scipy's prefilter starts its causal recursion from a sum over the reflected
+	series accumulated in place (ni_splines.c, _init_causal_reflect): for THREE samples it returns c = (-0.20019, 1.00005, 2.19999)
+	where the exact coefficients are (-1/5, 1, 11/5); the deviation decays like 0.268^n and is below rounding for the 32 x 32
+	meshes of 2048 x 2048 frames.  photutils calls scipy, so the oracle (and the device, which reproduces the recursion) carry it:
+	the hand answer is met within 5e-3 here, and exactly (1e-11) on a 32 x 32 mesh in the next test."""
+	from oracle import backgrounds as ob
+	mesh = 10.0 + np.arange(3)[None, :] + 3.0 * np.arange(3)[:, None]
+	np.testing.assert_allclose(exact_zoom(mesh, 4), zoom_ramp_expected(4, 12, 12), rtol=0, atol=1e-13)   # the general evaluator == the hand formula
+	nm = np.zeros((3, 3), dtype='int64')
+	for box, shape in ((64, (192, 192)), (64, (150, 131)), (4, (12, 12))):      # full frames and one cropped from the padded size
+		got = ob.mesh_to_background(mesh, nm, shape, box=box, filter_size=1)
+		np.testing.assert_allclose(got, zoom_ramp_expected(box, *shape), rtol=0, atol=5e-3)
+	# the corners: the unclipped spline leaves the range of the mesh there (10 + s(-0.49) + 3 s(-0.49) < 10): clipped to it
+	assert got[0, 0] == 10.0 and got[-1, -1] == 18.0
+
+
+def zoom_mesh_32():
+	rng = np.random.default_rng(77)
+	return 100.0 + 0.5 * np.arange(32)[None, :] - 0.25 * np.arange(32)[:, None] + rng.normal(0, 2.0, (32, 32))
+
+
+def test_zoom_of_a_32x32_mesh_without_scipys_prefilter():
+	"""The mesh size of a 2048 x 2048 frame: scipy's zoom (as photutils calls it) against the tridiagonal solve + tensor-product
+	B-spline evaluation written out in this file, including the frame edges and the cropped last cells."""
+	from oracle import backgrounds as ob
+	mesh = zoom_mesh_32()
+	want = exact_zoom(mesh, 4)
+	got = ob.mesh_to_background(mesh, np.zeros((32, 32), dtype='int64'), (128, 128), box=4, filter_size=1)
+	np.testing.assert_allclose(got, want, rtol=0, atol=1e-11)
+	got = ob.mesh_to_background(mesh, np.zeros((32, 32), dtype='int64'), (126, 125), box=4, filter_size=1)
+	np.testing.assert_allclose(got, want[:126, :125], rtol=0, atol=1e-11)
+
+
+def make_ragged_frame():
+	"""100 x 70 frame, 64 x 64 cells -> 2 x 2 mesh padded to 128 x 128.  Real pixels per cell: (0,0) 4096; (0,1) 64 x 6 = 384 (3712
+	padded > 2048: rejected); (1,0) 36 x 64 = 2304 (1792 padded: kept); (1,1) 36 x 6 = 216 (rejected).  Cell (0,0) holds 5
+	everywhere, (1,0) holds 9 (std 0 -> the SExtractor estimate is the mean).  Fill: (0,1) from (0,0) at d = 1 and (1,0) at
+	sqrt(2): (5 + 9 / sqrt(2)) / (1 + 1 / sqrt(2)); (1,1) likewise with 5 and 9 exchanged; the two add up to 14.  On a 2 x 2 mesh every
+	3 x 3 window holds all four cells: nanmedian{5, 6.657, 7.343, 9} = 14 / 2 = 7 in every cell -> the background is 7 everywhere."""
+	img = np.full((100, 70), 5.0, dtype='float32')
+	img[64:, :] = 9.0
+	img[:64, 64:] = 1234.0          # rejected cells: their pixels must not matter
+	img[64:, 64:] = 0.5
+	return img, 7.0
+
+
+def make_second_selection_frame():
+	"""128 x 64 frame = two cells.  Top cell: 2040 pixels masked by the flux cut-off, 10 pixels at 10 000 among 2046 at 100: the sigma
+	clip (median 100, std ~ 690: 3 sigma ~ 2070) rejects the ten, then stops (std 0).  Masked before the clip: 2040 <= 2048, after
+	it 2050 > 2048 -- photutils' second mesh selection (on the sigma-clipped data) drops the cell.  Bottom cell: 300 everywhere.
+	-> the background is 300 everywhere; with the first selection alone the top would sit at 100."""
+	img = np.full((128, 64), 300.0, dtype='float32')
+	top = np.full(4096, 100.0, dtype='float32')
+	top[:2040] = 1e5                # above flux_cutoff = 8e4: masked
+	top[2040:2050] = 1e4
+	img[:64] = top.reshape(64, 64)
+	return img, 300.0
+
+
+def test_fit_background_ragged_frame_and_second_selection():
+	from oracle import backgrounds as ob
+	img, expect = make_ragged_frame()
+	bkg, mask = ob.fit_background(img)
+	assert bkg.shape == img.shape and not mask.any()
+	np.testing.assert_allclose(bkg, expect, rtol=1e-14)
+	mesh, nm = ob.mesh_statistics(img, mask)
+	np.testing.assert_array_equal(nm, [[0, 3712], [1792, 3880]])
+	np.testing.assert_array_equal(mesh, [[5.0, 1234.0], [9.0, 0.5]])
+	img, expect = make_second_selection_frame()
+	bkg, mask = ob.fit_background(img)
+	assert int(mask.sum()) == 2040
+	mesh, nm = ob.mesh_statistics(img, mask)
+	np.testing.assert_array_equal(nm.ravel(), [2050, 0])
+	np.testing.assert_array_equal(mesh.ravel(), [100.0, 300.0])
+	np.testing.assert_allclose(bkg, expect, rtol=1e-14)
