@@ -483,10 +483,70 @@ int tp_lightcurve_diagnostics(tp_ctx* ctx, int32_t n_targets, int32_t n_cad,
  *   row_offset / col_offset: PIXEL_OFFSET_ROW / PIXEL_OFFSET_COLUMN (BasePhotometry.py:724-727; 0 and 44);
  *   d_stamps: int32 [n_targets][4] = (row_min, row_max, col_min, col_max) in CCD coordinates; every stamp must be
  *             desc->height x desc->width; pixels outside the frame become NaN;
- *   d_cube:   float32 cube with the layout of desc (n_cad == n_frames).                                */
+ *   d_cube:   float32 cube with the layout of desc (n_cad == n_frames); the padding of the time axis (cadences n_cad ..
+ *             t_pitch of every pixel) is written as zeros: the caller need not clear the cube.             */
 int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
 	int64_t row_pitch, int64_t frame_stride, int32_t row_offset, int32_t col_offset,
 	const int32_t* d_stamps, const tp_cube_desc* desc, float* d_cube);
+
+/* ---- the batched drop-in entry as a native job engine ----------------------------------------------------
+ * replaces, for every target of a CCD region at once, what run_tessphot(_mpi).py does target by target through
+ * tessphot('aperture', ...): the constructor's stamp cut (BasePhotometry._load_cube, BasePhotometry.py:720-751), the
+ * catalogue of the stamp (BasePhotometry.catalog, :1094-1181), AperturePhotometry.do_photometry WITH its stamp-resize loop
+ * (photometry/AperturePhotometry/photometry.py:75-170; resize_stamp / _set_stamp, BasePhotometry.py:567-693) and the
+ * diagnostics of BasePhotometry.photometry (:1343-1407).  The frame stacks of the region stay in HBM; the host submits a batch
+ * of targets and collects it, a worker thread of the library drives the rounds in between on the job's own three streams
+ * (group by stamp size, catalogue selection, tp_cut_stamps, tp_aperture_photometry / the three stand-alone kernels for small
+ * groups, tp_lightcurve_diagnostics, download, the plugin's decisions), so several jobs -- one per engine slot -- overlap.
+ *
+ *   tp_frames_stack: the three image groups of the region, float32 [n_frames][n_rows][n_cols] in HBM, covering CCD rows
+ *     [row0, row0 + n_rows) and columns [col0, col0 + n_cols) (PIXEL_OFFSET_ROW / _COLUMN); must stay valid until the job
+ *     has been waited for.
+ *   tp_frames_catalog: every star of the region (host arrays, copied), binned once into cells for the per-stamp selection
+ *     (stars in the stamp + its 5-pixel buffer, float32 stamp coordinates as BasePhotometry.catalog); must outlive its jobs.
+ *   tp_frames_submit: host arrays (copied before it returns): targets (starid, tmag, CCD row / column), their default stamps
+ *     int64 [n][4] = (row_min, row_max, col_min, col_max) and h_valid (0: "Invalid stamp selected", BasePhotometry.py:671),
+ *     h_attempts (retry limit, photometry.py:70-73), h_quick_break_budget (flux_limit x expected flux for a target the
+ *     haloswitch quick break applies to, NaN otherwise: photometry.py:146-158), time float64 [n_frames], quality int32
+ *     [n_frames]; budget_bytes: device memory the cubes of one round may take (0: a quarter of the HBM).  Fails when every
+ *     slot of the engine holds a job that has not been waited for.
+ *   tp_frames_wait: joins the job (its slot is free afterwards).  Then: tp_frames_counts / _targets (per target: STATUS,
+ *     final stamp, number of resizes, has_result, and where its arrays are: group, position) / _group (per device pass: its
+ *     size and the page-locked host block with the layout of the packed output block -- light curves [5][n][T] float64,
+ *     contamination, status, flags, mask, catalogue flags, sum image, diagnostics [n][10], each field on a 256-byte boundary)
+ *     / _group_lists (catalogue CSR offsets and star ids, target ids) / _events (what the reference would have logged, as
+ *     codes: 1 "No flux above threshold.", 2 / 3 minimum aperture, 4 "Too many masks.", 5 an uncaught exception of the mask
+ *     stage (a = kind), 6 "Could not resize stamp any further.", 7 haloswitch quick break (value = edge flux), 8 "Too many
+ *     stamp resizes.", 9 "No targets in mask.", 10 / 11 a device failure (text), 12 "Invalid stamp selected").
+ *   tp_frames_release: the job's host blocks go back to the engine's pool; the job is gone.                              */
+typedef struct tp_frames_engine tp_frames_engine;
+typedef struct tp_frames_catalog tp_frames_catalog;
+typedef struct tp_frames_job tp_frames_job;
+typedef struct tp_frames_stack {
+	const float* d_images;
+	const float* d_images_err;
+	const float* d_backgrounds;
+	int32_t n_frames, n_rows, n_cols, row0, col0;
+} tp_frames_stack;
+int tp_frames_engine_create(int device, int32_t n_slots, tp_frames_engine** out);
+int tp_frames_engine_destroy(tp_frames_engine* eng);        /* every job waited for and released first */
+int tp_frames_engine_info(tp_frames_engine* eng, int32_t* n_slots, int32_t* n_free, uint64_t* hbm_bytes);
+int tp_frames_catalog_create(int64_t n_stars, const int64_t* h_starid, const float* h_tmag, const double* h_row, const double* h_column,
+	tp_frames_catalog** out);
+int tp_frames_catalog_destroy(tp_frames_catalog* cat);
+int tp_frames_submit(tp_frames_engine* eng, const tp_frames_stack* stack, const tp_frames_catalog* cat,
+	int32_t n_targets, const int64_t* h_starid, const double* h_tmag, const double* h_row, const double* h_column,
+	const int64_t* h_stamps, const uint8_t* h_valid, const int32_t* h_attempts, const double* h_quick_break_budget,
+	const double* h_time, const int32_t* h_quality, double budget_bytes, tp_frames_job** out);
+int tp_frames_wait(tp_frames_job* job);
+int tp_frames_counts(tp_frames_job* job, int32_t* n_groups, int64_t* n_events);
+int tp_frames_targets(tp_frames_job* job, int32_t* status, int64_t* stamps, int32_t* stamp_resizes, uint8_t* has_result, int32_t* group, int32_t* pos);
+int tp_frames_group(tp_frames_job* job, int32_t g, int32_t* n_targets, int32_t* height, int32_t* width, int64_t* cat_capacity, int64_t* n_cat,
+	void** h_block, uint64_t* block_nbytes);
+int tp_frames_group_lists(tp_frames_job* job, int32_t g, int64_t* cat_offsets, int64_t* cat_starid, int64_t* target_starid);
+int tp_frames_events(tp_frames_job* job, int32_t* target, int32_t* code, int32_t* a, int32_t* b, double* value, int32_t* text);
+const char* tp_frames_text(tp_frames_job* job, int32_t k);
+int tp_frames_release(tp_frames_job* job);
 
 /* ---- multi-GPU: the final light-curve gather (RCCL over xGMI) --------------------------------
  * replaces the pickled result messages of run_tessphot_mpi.py:114-132,163-191: targets are

@@ -31,6 +31,11 @@ class tp_cube_desc(Structure):
 	_fields_ = [('n_targets', c_int32), ('n_cad', c_int32), ('height', c_int32), ('width', c_int32), ('t_pitch', c_int64)]
 
 
+class tp_frames_stack(Structure):
+	_fields_ = [('d_images', c_void_p), ('d_images_err', c_void_p), ('d_backgrounds', c_void_p),
+		('n_frames', c_int32), ('n_rows', c_int32), ('n_cols', c_int32), ('row0', c_int32), ('col0', c_int32)]
+
+
 class tp_k2p2_params(Structure):
 	_fields_ = [('thresh', c_double), ('min_no_pixels_in_mask', c_int32), ('min_for_cluster', c_int32),
 		('extend_overflow', c_int32), ('reserved', c_int32), ('ws_thres', c_double), ('saturation_limit', c_double)]
@@ -130,6 +135,20 @@ SIGNATURES = {
 	'tp_comm_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
 	'tp_comm_gather': (c_int, [c_void_p, _p, _p, c_uint64, c_int]),
 	'tp_comm_allgather': (c_int, [c_void_p, _p, _p, c_uint64]),
+	'tp_frames_engine_create': (c_int, [c_int, c_int32, POINTER(c_void_p)]),
+	'tp_frames_engine_destroy': (c_int, [c_void_p]),
+	'tp_frames_engine_info': (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_uint64)]),
+	'tp_frames_catalog_create': (c_int, [c_int64, _p, _p, _p, _p, POINTER(c_void_p)]),
+	'tp_frames_catalog_destroy': (c_int, [c_void_p]),
+	'tp_frames_submit': (c_int, [c_void_p, POINTER(tp_frames_stack), c_void_p, c_int32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_double, POINTER(c_void_p)]),
+	'tp_frames_wait': (c_int, [c_void_p]),
+	'tp_frames_counts': (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int64)]),
+	'tp_frames_targets': (c_int, [c_void_p, _p, _p, _p, _p, _p, _p]),
+	'tp_frames_group': (c_int, [c_void_p, c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int64), POINTER(c_int64), POINTER(c_void_p), POINTER(c_uint64)]),
+	'tp_frames_group_lists': (c_int, [c_void_p, c_int32, _p, _p, _p]),
+	'tp_frames_events': (c_int, [c_void_p, _p, _p, _p, _p, _p, _p]),
+	'tp_frames_text': (c_char_p, [c_void_p, c_int32]),
+	'tp_frames_release': (c_int, [c_void_p]),
 	'tp_synth_fill': (c_int, [c_void_p, _desc_p, c_int32, _p, _p, _p, _p, _p, c_double, c_double, c_uint64, _p, _p, _p, _p]),
 }
 
@@ -164,5 +183,5 @@ def exported_symbols():
 	return sorted(SIGNATURES.keys())
 
 
-__all__ = ['load', 'TessphotError', 'TessphotLibraryError', 'tp_cube_desc', 'tp_k2p2_params', 'SIGNATURES', 'LIB_PATH',
+__all__ = ['load', 'TessphotError', 'TessphotLibraryError', 'tp_cube_desc', 'tp_k2p2_params', 'tp_frames_stack', 'SIGNATURES', 'LIB_PATH',
 	'byref', 'c_void_p', 'c_int', 'c_int32', 'c_int64', 'c_uint64', 'c_float', 'c_double', 'c_uint8']

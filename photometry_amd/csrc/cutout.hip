@@ -97,8 +97,10 @@ __global__ __launch_bounds__(256) void tp_cut_stamps_kernel(CutArgs a, int band_
 	// ---- store: 64 consecutive cadences of one pixel per wavefront
 	const int lane = tid & 63, wave = tid >> 6;
 	float* out = a.cube + ((int64_t)target * a.height * W + (int64_t)row_first * W) * a.t_pitch;
-	if (k0 + lane < a.n_frames) {
-		for (int p = wave; p < P; p += 4) out[(int64_t)p * a.t_pitch + k0 + lane] = tile[lane * ldp + p];
+	// the padding of the time axis (cadences n_frames .. t_pitch) is written too, as zeros: the caller need not clear the cube
+	if (k0 + lane < a.t_pitch) {
+		const bool real = k0 + lane < a.n_frames;
+		for (int p = wave; p < P; p += 4) out[(int64_t)p * a.t_pitch + k0 + lane] = real ? tile[lane * ldp + p] : 0.f;
 	}
 }
 
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void tp_cut_nanfill_kernel(CutArgs a, const in
 	const int64_t n = (int64_t)a.height * a.width * a.t_pitch;
 	const float nan = __builtin_nanf("");
 	for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
-		if ((int)(i % a.t_pitch) < a.n_frames) out[i] = nan;
+		out[i] = ((int)(i % a.t_pitch) < a.n_frames) ? nan : 0.f;
 }
 
 __global__ __launch_bounds__(256) void tp_cut_tiles_kernel(CutArgs a, TileGeom tg, const int* __restrict__ offsets, const int* __restrict__ items)
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(256) void tp_cut_tiles_kernel(CutArgs a, TileGeom t
 	int run = tid / kTileCad;
 	if (kTileCad % 64 == 0) run = __builtin_amdgcn_readfirstlane(run);
 	const bool k_ok = k0 + lane < a.n_frames;
+	const bool k_store = k0 + lane < a.t_pitch;      // the padding of the time axis is written too (zeros): no memset of the cube
 	const int P = a.height * a.width;
 	for (int it = first; it < last; ++it) {
 		const int target = __builtin_amdgcn_readfirstlane(items[it]);
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void tp_cut_tiles_kernel(CutArgs a, TileGeom t
 #pragma unroll 4
 			for (int cc = ca + run; cc < cb; cc += RUNS) {
 				const float x = src[cc];
-				if (k_ok) out[(int64_t)(prow + cc) * a.t_pitch] = x;
+				if (k_store) out[(int64_t)(prow + cc) * a.t_pitch] = k_ok ? x : 0.f;
 			}
 		}
 	}
@@ -267,7 +270,7 @@ extern "C" int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frame
 	const size_t shmem = (size_t)kCadBlock * ((band_rows * desc->width) | 1) * sizeof(float);
 	TP_REQUIRE(ctx, shmem <= 160 * 1024, "tp_cut_stamps: stamp rows wider than 639 pixels are not supported");
 	const int n_bands = (desc->height + band_rows - 1) / band_rows;
-	TP_REQUIRE(ctx, n_bands <= 65535 && (desc->n_cad + kCadBlock - 1) / kCadBlock <= 65535, "tp_cut_stamps: too many bands / cadence blocks");
+	TP_REQUIRE(ctx, n_bands <= 65535 && (desc->t_pitch + kCadBlock - 1) / kCadBlock <= 65535, "tp_cut_stamps: too many bands / cadence blocks");
 	CutArgs a;
 	a.frames = d_frames; a.n_frames = n_frames; a.frame_rows = frame_rows; a.frame_cols = frame_cols;
 	a.row_pitch = row_pitch; a.frame_stride = frame_stride; a.row_offset = row_offset; a.col_offset = col_offset;
@@ -295,7 +298,7 @@ extern "C" int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frame
 			hipLaunchKernelGGL(tp_cut_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, offsets, (int)n_tiles);
 			hipLaunchKernelGGL(tp_cut_bin_kernel<true>, bgrid, dim3(256), 0, ctx->stream, a, tg, (int)desc->n_targets, count, (const int*)offsets, items, outside);
 			hipLaunchKernelGGL(tp_cut_nanfill_kernel, dim3((unsigned)desc->n_targets), dim3(256), 0, ctx->stream, a, (const int*)outside);
-			dim3 grid((unsigned)n_tiles, (unsigned)((desc->n_cad + kTileCad - 1) / kTileCad));
+			dim3 grid((unsigned)n_tiles, (unsigned)((desc->t_pitch + kTileCad - 1) / kTileCad));   // (blocks cover the padding of the time axis too)
 			hipLaunchKernelGGL(tp_cut_tiles_kernel, grid, dim3(256), 0, ctx->stream, a, tg, (const int*)offsets, (const int*)items);
 		}
 		TP_LAUNCH_CHECK(ctx, "tp_cut_tiles_kernel");
@@ -303,7 +306,7 @@ extern "C" int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frame
 	}
 	if (shmem > 64 * 1024)
 		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_cut_stamps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-	dim3 grid((unsigned)desc->n_targets, (unsigned)((desc->n_cad + kCadBlock - 1) / kCadBlock), (unsigned)n_bands);
+	dim3 grid((unsigned)desc->n_targets, (unsigned)((desc->t_pitch + kCadBlock - 1) / kCadBlock), (unsigned)n_bands);
 	TP_LAUNCH(ctx, TPK_CUTOUT, tp_cut_stamps_kernel, grid, dim3(256), shmem, a, band_rows);
 	TP_LAUNCH_CHECK(ctx, "tp_cut_stamps_kernel");
 	return TP_OK;

@@ -1,0 +1,757 @@
+// frames.cpp -- the batched drop-in entry as a native host engine: AperturePhotometry.do_photometry INCLUDING its stamp-resize loop
+// (photometry/AperturePhotometry/photometry.py:75-170, BasePhotometry.resize_stamp / _set_stamp BasePhotometry.py:567-693) for every
+// target of a CCD region whose frame stacks are resident in HBM, from the target list to columnar results.
+//
+// What the reference does one target at a time in Python -- cut the stamp out of the HDF5 groups, run the plugin, look at the mask,
+// grow the stamp, try again -- is here a JOB: the host submits a batch (tp_frames_submit) and collects it (tp_frames_wait); in
+// between a worker thread of the library drives the rounds on the job's own three streams: group the targets still in play by
+// stamp size, select the catalogue stars of every stamp from a cell-binned index, cut the stamps on the device (tp_cut_stamps), run
+// the fused pass (tp_aperture_photometry; the three stand-alone kernels for a small group) and the light-curve diagnostics,
+// download the packed output block into page-locked memory (the part the decisions read first, with an event; the light curves
+// behind it), decide with the plugin's rules who is finished, who gets a bigger stamp and who gives up.  No Python runs between
+// submit and collect, so several jobs in flight (one per engine slot) keep the device busy: the first round of one batch runs
+// under the latency-bound resize rounds of another.  The rules are those of photometry_amd/stamps.py and plugins.mask_outcome
+// (which stay the per-target plugin's implementation and the reference of tests/test_gpu_resize.py); messages travel as codes
+// that the Python layer turns into the reference's log strings.
+#include "common.h"
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr uint32_t kBitmask = 1 | 2 | 4 | 8 | 32 | 64 | 128 | 4096;   // TESSQualityFlags.DEFAULT_BITMASK (quality.py:123-124)
+constexpr int kStreams = 3;
+constexpr int kResizeStep = 10;          // photometry.py:124-131
+constexpr int kFusedFrom = 1024;         // smaller groups take the three stand-alone kernels (latency-bound passes)
+constexpr int kEdgeBits = 2 | 4 | 8 | 16;
+
+inline int64_t round_up(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
+
+struct Fail : std::runtime_error { using std::runtime_error::runtime_error; };
+inline void ck(tp_ctx* g, int rc) { if (rc != TP_OK) throw Fail(g->err.empty() ? std::string("error ") + std::to_string(rc) : g->err); }
+inline void ckh(hipError_t e, const char* what) { if (e != hipSuccess) throw Fail(std::string(what) + ": " + hipGetErrorString(e)); }
+
+// ---- page-locked host memory, pooled by size class (hipHostMalloc takes milliseconds) ---------------------------------------
+struct PinnedPool {
+	std::mutex m;
+	std::multimap<size_t, void*> free_blocks;
+	static size_t size_class(size_t n) {
+		size_t p = 65536;
+		while (p < n && p < ((size_t)1 << 20)) p *= 2;
+		if (n <= p) return p;
+		p = (size_t)1 << 20;
+		while (p * 2 <= n) p *= 2;
+		const size_t step = p / 8;
+		return (n + step - 1) / step * step;
+	}
+	void* get(size_t n, size_t* cap) {
+		const size_t c = size_class(n ? n : 16);
+		{
+			std::lock_guard<std::mutex> lk(m);
+			auto it = free_blocks.find(c);
+			if (it != free_blocks.end()) { void* p = it->second; free_blocks.erase(it); *cap = c; return p; }
+		}
+		void* p = nullptr;
+		ckh(hipHostMalloc(&p, c, hipHostMallocDefault), "hipHostMalloc");
+		*cap = c;
+		return p;
+	}
+	void put(void* p, size_t cap) {
+		if (!p) return;
+		std::lock_guard<std::mutex> lk(m);
+		free_blocks.emplace(cap, p);
+	}
+	~PinnedPool() { for (auto& kv : free_blocks) (void)hipHostFree(kv.second); }
+};
+
+// numpy's pairwise summation of a contiguous float64 vector (np.add.reduce): what np.nansum does after replacing the NaNs
+double np_pairwise_sum(const double* a, int64_t n) {
+	if (n < 8) { double r = 0.0; for (int64_t i = 0; i < n; ++i) r += a[i]; return r; }
+	if (n <= 128) {
+		double r[8];
+		for (int j = 0; j < 8; ++j) r[j] = a[j];
+		int64_t i = 8;
+		for (; i < n - (n % 8); i += 8) for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+		double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+		for (; i < n; ++i) res += a[i];
+		return res;
+	}
+	int64_t n2 = n / 2;
+	n2 -= n2 % 8;
+	return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+} // namespace
+
+// ---- the catalogue of a region, binned into cells of 16 x 16 pixels (stars sorted by cell) ------------------------------------
+struct tp_frames_catalog {
+	int64_t n = 0;
+	std::vector<int64_t> starid;
+	std::vector<float> tmag;
+	std::vector<double> row, col;
+	int64_t cell = 16, r0 = 0, c0 = 0, n_cr = 1, n_cc = 1;
+	std::vector<int64_t> order, cell_start;
+};
+
+struct tp_frames_engine {
+	int device = 0;
+	int n_slots = 0;
+	std::vector<tp_ctx*> ctxs;          // kStreams per slot
+	std::vector<char> busy;
+	std::mutex m;
+	PinnedPool pinned;
+	uint64_t hbm_bytes = 0;
+};
+
+namespace {
+
+struct Event { int32_t target, code, a, b; double value; int32_t text; };
+
+struct Group {
+	int32_t n = 0, H = 0, W = 0;
+	int64_t n_cat = 0, cat_capacity = 1;
+	std::vector<int64_t> cat_offsets, cat_starid, target_starid;
+	void* h_block = nullptr; size_t h_cap = 0; uint64_t nbytes = 0;
+	// offsets of the fields of the packed block (comm.packed_block_layout(n, T, H, W, n_cat = cat_capacity, extras = True))
+	uint64_t off_lc = 0, off_cont = 0, off_status = 0, off_flags = 0, off_mask = 0, off_cim = 0, off_sum = 0, off_diag = 0;
+};
+
+// a group of one round while its pass is in flight
+struct Launched {
+	tp_ctx* g = nullptr;
+	std::vector<int32_t> idx;
+	Group grp;
+	hipEvent_t ev = nullptr;
+	bool failed = false;
+	std::string error;
+};
+
+} // namespace
+
+struct tp_frames_job {
+	tp_frames_engine* eng = nullptr;
+	int slot = -1;
+	tp_ctx* streams[kStreams] = {};
+	tp_frames_stack stack{};
+	const tp_frames_catalog* cat = nullptr;
+	int32_t n = 0, T = 0;
+	std::vector<int64_t> starid;
+	std::vector<double> tmag, row, col, budget_flux, time;
+	std::vector<int64_t> cur;                 // [n][4]
+	std::vector<uint8_t> valid;
+	std::vector<int32_t> attempts, quality;
+	double budget = 0.0;
+	// results
+	std::vector<int32_t> status, stamp_resizes, group, pos;
+	std::vector<uint8_t> has_result;
+	std::vector<int64_t> stamp;               // [n][4]
+	std::vector<Group> groups;
+	std::vector<Event> events;
+	std::vector<std::string> texts;
+	std::map<int32_t, std::vector<Event>> pending;   // logged, not yet flushed into `events` (plugins._Messages of a target)
+	std::vector<std::pair<void*, size_t>> host_scratch;   // pinned metadata blocks: back to the pool when the job is done
+	std::thread worker;
+	int rc = TP_OK;
+	std::string err;
+	bool joined = false, released = false;
+
+	void log(int32_t i, int32_t code, int32_t a = 0, int32_t b = 0, double v = 0.0, int32_t text = -1) { pending[i].push_back(Event{i, code, a, b, v, text}); }
+	void direct(int32_t i, int32_t code, int32_t a = 0, int32_t b = 0, double v = 0.0, int32_t text = -1) { events.push_back(Event{i, code, a, b, v, text}); }
+	void flush(int32_t i) {
+		auto it = pending.find(i);
+		if (it == pending.end()) return;
+		for (auto& e : it->second) events.push_back(e);
+		pending.erase(it);
+	}
+	void finish(int32_t i, int32_t st) {
+		status[i] = st;
+		for (int k = 0; k < 4; ++k) stamp[(size_t)i * 4 + k] = cur[(size_t)i * 4 + k];
+		flush(i);
+	}
+	int32_t add_text(const std::string& s) { texts.push_back(s); return (int32_t)texts.size() - 1; }
+	void run();
+	void select_catalog(const std::vector<int32_t>& idx, Group& g, std::vector<float>& c_tmag, std::vector<float>& c_row, std::vector<float>& c_col,
+		std::vector<float>& c_row_stamp, std::vector<float>& c_col_stamp) const;
+	void launch(Launched& L, int gi, std::vector<hipEvent_t>& event_pool);
+	void decide(Launched& L, std::vector<int32_t>& still);
+};
+
+// the stars inside every stamp plus its 5-pixel buffer, in catalogue order, with the float32 stamp coordinates of
+// BasePhotometry.catalog (BasePhotometry.py:1094-1181) -- pipeline._catalogs_of_stamps, stamp by stamp
+void tp_frames_job::select_catalog(const std::vector<int32_t>& idx, Group& g, std::vector<float>& c_tmag, std::vector<float>& c_row,
+	std::vector<float>& c_col, std::vector<float>& c_row_stamp, std::vector<float>& c_col_stamp) const
+{
+	const tp_frames_catalog& c = *cat;
+	const double buffer = 5.0;
+	const int64_t B = c.cell;
+	g.cat_offsets.assign(1, 0);
+	g.cat_starid.clear();
+	std::vector<int64_t> found;
+	auto clipi = [](int64_t v, int64_t lo, int64_t hi) { return v < lo ? lo : (v > hi ? hi : v); };
+	for (int32_t i : idx) {
+		const int64_t* st = &cur[(size_t)i * 4];
+		const double rlo = (double)st[0] - 0.5 - buffer, rhi = (double)st[1] - 0.5 + buffer;
+		const double clo = (double)st[2] - 0.5 - buffer, chi = (double)st[3] - 0.5 + buffer;
+		found.clear();
+		if (c.n > 0) {
+			const int64_t cr0 = clipi((int64_t)std::floor((rlo - (double)c.r0) / (double)B), 0, c.n_cr - 1);
+			const int64_t cr1 = clipi((int64_t)std::floor((rhi - (double)c.r0) / (double)B), -1, c.n_cr - 1);
+			const int64_t cc0 = clipi((int64_t)std::floor((clo - (double)c.c0) / (double)B), 0, c.n_cc - 1);
+			const int64_t cc1 = clipi((int64_t)std::floor((chi - (double)c.c0) / (double)B), -1, c.n_cc - 1);
+			if (cc1 >= cc0)
+				for (int64_t cr = cr0; cr <= cr1; ++cr) {
+					const int64_t a = c.cell_start[cr * c.n_cc + cc0], b = c.cell_start[cr * c.n_cc + cc1 + 1];
+					for (int64_t p = a; p < b; ++p) {
+						const int64_t s = c.order[p];
+						if (c.row[s] >= rlo && c.row[s] < rhi && c.col[s] >= clo && c.col[s] < chi) found.push_back(s);
+					}
+				}
+			std::sort(found.begin(), found.end());
+		}
+		for (int64_t s : found) {
+			g.cat_starid.push_back(c.starid[s]);
+			c_tmag.push_back(c.tmag[s]);
+			c_col.push_back((float)c.col[s]);
+			c_row.push_back((float)c.row[s]);
+			c_col_stamp.push_back((float)(c.col[s] - (double)st[2]));
+			c_row_stamp.push_back((float)(c.row[s] - (double)st[0]));
+		}
+		g.cat_offsets.push_back((int64_t)g.cat_starid.size());
+	}
+	g.n_cat = (int64_t)g.cat_starid.size();
+	g.cat_capacity = g.n_cat > 0 ? g.n_cat : 1;
+}
+
+namespace {
+
+struct MetaField { const void* src; size_t nbytes; size_t off; };
+
+} // namespace
+
+// queue everything a group of same-sized stamps needs on stream g: metadata upload, the three cuts, the pass, the diagnostics and
+// the two downloads of the packed block (the light curves last); an event sits between the downloads
+void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_pool)
+{
+	tp_ctx* g = L.g;
+	Group& G = L.grp;
+	const int32_t m = (int32_t)L.idx.size(), H = G.H, W = G.W;
+	std::vector<void*> dev;                      // device blocks of this group: freed (stream-ordered) once everything is queued
+	void* h_meta = nullptr; size_t h_meta_cap = 0;
+	auto dalloc = [&](size_t nbytes) { void* p = nullptr; ck(g, tp_malloc(g, nbytes, &p)); dev.push_back(p); return p; };
+	try {
+		if ((int64_t)H * W > 65535) throw Fail("a " + std::to_string(H) + "x" + std::to_string(W) + " stamp is beyond the 65 535 pixels of the mask builder");
+		G.n = m;
+		G.target_starid.resize(m);
+		std::vector<float> c_tmag, c_row, c_col, c_row_stamp, c_col_stamp;
+		select_catalog(L.idx, G, c_tmag, c_row, c_col, c_row_stamp, c_col_stamp);
+		// ---- the metadata of the group as ONE block: one upload
+		std::vector<int32_t> stamps32((size_t)m * 4);
+		std::vector<double> t_row(m), t_col(m), t_tmag(m);
+		for (int32_t j = 0; j < m; ++j) {
+			const int32_t i = L.idx[j];
+			for (int k = 0; k < 4; ++k) stamps32[(size_t)j * 4 + k] = (int32_t)cur[(size_t)i * 4 + k];
+			t_row[j] = row[i]; t_col[j] = col[i]; t_tmag[j] = tmag[i];
+			G.target_starid[j] = starid[i];
+		}
+		const size_t nc = (size_t)G.n_cat;
+		MetaField f[14] = {
+			{quality.data(), (size_t)T * 4, 0}, {time.data(), (size_t)T * 8, 0}, {stamps32.data(), (size_t)m * 16, 0},
+			{G.cat_offsets.data(), (size_t)(m + 1) * 8, 0}, {G.cat_starid.data(), nc * 8, 0}, {c_tmag.data(), nc * 4, 0},
+			{c_row.data(), nc * 4, 0}, {c_col.data(), nc * 4, 0}, {c_row_stamp.data(), nc * 4, 0}, {c_col_stamp.data(), nc * 4, 0},
+			{t_row.data(), (size_t)m * 8, 0}, {t_col.data(), (size_t)m * 8, 0}, {t_tmag.data(), (size_t)m * 8, 0}, {G.target_starid.data(), (size_t)m * 8, 0}};
+		size_t total = 0;
+		for (auto& x : f) { x.off = total; total = (size_t)round_up((int64_t)(total + std::max(x.nbytes, (size_t)16)), 256); }
+		h_meta = eng->pinned.get(total, &h_meta_cap);
+		host_scratch.emplace_back(h_meta, h_meta_cap);
+		std::memset(h_meta, 0, total);
+		for (auto& x : f) if (x.nbytes) std::memcpy(static_cast<char*>(h_meta) + x.off, x.src, x.nbytes);
+		char* d_meta = static_cast<char*>(dalloc(total));
+		ckh(hipMemcpyAsync(d_meta, h_meta, total, hipMemcpyHostToDevice, g->stream), "hipMemcpyAsync(metadata)");
+		const int32_t* d_quality = reinterpret_cast<const int32_t*>(d_meta + f[0].off);
+		const double* d_time = reinterpret_cast<const double*>(d_meta + f[1].off);
+		const int32_t* d_stamps = reinterpret_cast<const int32_t*>(d_meta + f[2].off);
+		const int64_t* d_cat_offsets = reinterpret_cast<const int64_t*>(d_meta + f[3].off);
+		const int64_t* d_cat_starid = reinterpret_cast<const int64_t*>(d_meta + f[4].off);
+		const float* d_cat_tmag = reinterpret_cast<const float*>(d_meta + f[5].off);
+		const float* d_cat_row = reinterpret_cast<const float*>(d_meta + f[6].off);
+		const float* d_cat_col = reinterpret_cast<const float*>(d_meta + f[7].off);
+		const float* d_cat_row_stamp = reinterpret_cast<const float*>(d_meta + f[8].off);
+		const float* d_cat_col_stamp = reinterpret_cast<const float*>(d_meta + f[9].off);
+		const double* d_t_row = reinterpret_cast<const double*>(d_meta + f[10].off);
+		const double* d_t_col = reinterpret_cast<const double*>(d_meta + f[11].off);
+		const double* d_t_tmag = reinterpret_cast<const double*>(d_meta + f[12].off);
+		const int64_t* d_t_starid = reinterpret_cast<const int64_t*>(d_meta + f[13].off);
+		// ---- the three stamp cubes (BasePhotometry._load_cube for the whole group; the cutter writes the padding of the time axis)
+		tp_cube_desc desc;
+		desc.n_targets = m; desc.n_cad = T; desc.height = H; desc.width = W; desc.t_pitch = round_up(T, 32);
+		const size_t cube_bytes = (size_t)m * H * W * (size_t)desc.t_pitch * 4;
+		const float* frames[3] = {stack.d_images, stack.d_images_err, stack.d_backgrounds};
+		float* cubes[3];
+		for (int k = 0; k < 3; ++k) {
+			cubes[k] = static_cast<float*>(dalloc(cube_bytes));
+			ck(g, tp_cut_stamps(g, frames[k], stack.n_frames, stack.n_rows, stack.n_cols, stack.n_cols, (int64_t)stack.n_rows * stack.n_cols,
+				stack.row0, stack.col0, d_stamps, &desc, cubes[k]));
+		}
+		// ---- the packed output block (comm.packed_block_layout with the catalogue flags, the sum image and the diagnostics)
+		const size_t P = (size_t)H * W;
+		uint64_t off = 0;
+		auto field = [&](uint64_t nbytes) { const uint64_t o = off; off = (uint64_t)round_up((int64_t)(off + nbytes), 256); return o; };
+		G.off_lc = field((uint64_t)5 * m * T * 8);
+		G.off_cont = field((uint64_t)m * 8);
+		G.off_status = field((uint64_t)m * 4);
+		G.off_flags = field((uint64_t)m * 4);
+		G.off_mask = field((uint64_t)m * P);
+		G.off_cim = field((uint64_t)G.cat_capacity);
+		G.off_sum = field((uint64_t)m * P * 8);
+		G.off_diag = field((uint64_t)m * 10 * 8);
+		G.nbytes = off;
+		char* blk = static_cast<char*>(dalloc((size_t)G.nbytes));
+		ckh(hipMemsetAsync(blk, 0, (size_t)G.nbytes, g->stream), "hipMemsetAsync(block)");
+		double* lc[5];
+		for (int k = 0; k < 5; ++k) lc[k] = reinterpret_cast<double*>(blk + G.off_lc) + (size_t)k * m * T;
+		double* d_cont = reinterpret_cast<double*>(blk + G.off_cont);
+		int32_t* d_status = reinterpret_cast<int32_t*>(blk + G.off_status);
+		int32_t* d_flags = reinterpret_cast<int32_t*>(blk + G.off_flags);
+		uint8_t* d_mask = reinterpret_cast<uint8_t*>(blk + G.off_mask);
+		uint8_t* d_cim = reinterpret_cast<uint8_t*>(blk + G.off_cim);
+		double* d_sum = reinterpret_cast<double*>(blk + G.off_sum);
+		double* d_diagn = reinterpret_cast<double*>(blk + G.off_diag);
+		// scratch: the mask builder's diagnostics and the aperture image (bit 1 = collected: every pixel, BasePhotometry.py:1043)
+		double* d_diag8 = static_cast<double*>(dalloc((size_t)m * 8 * 8));
+		ckh(hipMemsetAsync(d_diag8, 0, (size_t)m * 64, g->stream), "hipMemsetAsync(diag)");
+		int32_t* d_aperture = static_cast<int32_t*>(dalloc((size_t)m * P * 4));
+		ckh(hipMemsetAsync(d_aperture, 1, (size_t)m * P * 4, g->stream), "hipMemsetAsync(aperture)");
+		// ---- the pass: fused for a large group; a small one is latency-bound and spreads better as three kernels (bit-identical)
+		if (m >= kFusedFrom) {
+			ck(g, tp_aperture_photometry(g, &desc, cubes[0], cubes[1], cubes[2], 0, 0, nullptr, 0, d_quality, 0, kBitmask,
+				d_cat_offsets, d_cat_col_stamp, d_cat_row_stamp, d_cat_tmag, d_cat_col, d_cat_row, d_cat_starid,
+				d_t_row, d_t_col, d_t_tmag, d_t_starid, d_stamps, d_aperture, nullptr,
+				d_sum, d_mask, d_status, d_flags, d_cont, d_diag8, d_cim, lc[0], lc[1], lc[2], lc[3], lc[4], T));
+		} else {
+			ck(g, tp_sumimage(g, &desc, cubes[0], d_quality, 0, kBitmask, nullptr, 0, d_sum));
+			ck(g, tp_k2p2_masks(g, m, H, W, d_sum, d_cat_offsets, d_cat_col_stamp, d_cat_row_stamp, d_cat_tmag, d_cat_col, d_cat_row, d_cat_starid,
+				d_t_row, d_t_col, d_t_tmag, d_t_starid, d_stamps, d_aperture, nullptr, nullptr, d_mask, d_status, d_flags, d_cont, d_diag8, d_cim));
+			ck(g, tp_aperture_extract(g, &desc, cubes[0], cubes[1], cubes[2], 0, 0, nullptr, 0, d_mask, d_stamps, d_status,
+				lc[0], lc[1], lc[2], lc[3], lc[4], T));
+		}
+		ck(g, tp_lightcurve_diagnostics(g, m, T, lc[0], lc[1], lc[3], lc[4], T, d_time, d_quality, 0, kBitmask, d_status, d_sum, d_mask, H, W,
+			3600.0 / 86400.0, d_diagn));
+		// ---- two downloads: what the decisions read (everything behind the light curves) first, with an event; then the light curves
+		G.h_block = eng->pinned.get((size_t)G.nbytes, &G.h_cap);
+		const uint64_t lc_bytes = G.off_cont;
+		ckh(hipMemcpyAsync(static_cast<char*>(G.h_block) + lc_bytes, blk + lc_bytes, (size_t)(G.nbytes - lc_bytes), hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(results)");
+		if (event_pool.empty()) { hipEvent_t e = nullptr; ckh(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); event_pool.push_back(e); }
+		L.ev = event_pool.back(); event_pool.pop_back();
+		ckh(hipEventRecord(L.ev, g->stream), "hipEventRecord");
+		ckh(hipMemcpyAsync(G.h_block, blk, (size_t)lc_bytes, hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(light curves)");
+		for (void* p : dev) (void)tp_free(g, p);      // stream-ordered: handed out again only after what is queued above has run
+		(void)gi;
+	} catch (const std::exception& e) {
+		L.failed = true;
+		L.error = e.what();
+		(void)hipStreamSynchronize(g->stream);
+		(void)hipGetLastError();
+		for (void* p : dev) (void)tp_free(g, p);
+		if (G.h_block) { eng->pinned.put(G.h_block, G.h_cap); G.h_block = nullptr; }
+		if (L.ev) { event_pool.push_back(L.ev); L.ev = nullptr; }
+	}
+}
+
+// the plugin's rules on the results of one group (photometry.py:93-170; plugins.mask_outcome, stamps.py)
+void tp_frames_job::decide(Launched& L, std::vector<int32_t>& still)
+{
+	Group& G = L.grp;
+	const int32_t m = G.n, H = G.H, W = G.W;
+	const int32_t gid = (int32_t)groups.size();
+	const char* blk = static_cast<const char*>(G.h_block);
+	const int32_t* r_status = reinterpret_cast<const int32_t*>(blk + G.off_status);
+	const int32_t* r_flags = reinterpret_cast<const int32_t*>(blk + G.off_flags);
+	const uint8_t* r_mask = reinterpret_cast<const uint8_t*>(blk + G.off_mask);
+	const double* r_sum = reinterpret_cast<const double*>(blk + G.off_sum);
+	const int64_t limits[4] = {stack.row0, (int64_t)stack.row0 + stack.n_rows, stack.col0, (int64_t)stack.col0 + stack.n_cols};
+	static const int side_bit[4] = {2, 4, 8, 16};      // down, up, left, right (stamps.SIDES)
+	static const int side_sign[4] = {-1, +1, -1, +1};
+	std::vector<double> vals;
+	for (int32_t j = 0; j < m; ++j) {
+		const int32_t i = L.idx[j];
+		attempts[i] -= 1;
+		const int32_t fl = r_flags[j], kind = fl >> 8;
+		auto stands = [&]() {
+			has_result[i] = 1; group[i] = gid; pos[i] = j;
+			finish(i, r_status[j]);
+		};
+		if ((fl & (1 | 32 | kEdgeBits)) == 0 && kind == 0) { stands(); continue; }   // the common case: nothing to log, no edge touched
+		// plugins.mask_outcome
+		if (fl & 32) log(i, 1);
+		if (fl & 1) log(i, (fl & (32 | 64)) ? 2 : 3);
+		if (kind == 5) { log(i, 4); finish(i, TP_STATUS_ERROR); continue; }
+		if (kind >= 1 && kind <= 4) { direct(i, 5, kind); finish(i, TP_STATUS_ERROR); continue; }   // an uncaught exception upstream
+		if (fl & kEdgeBits) {
+			int64_t before[4], after[4];
+			for (int k = 0; k < 4; ++k) before[k] = after[k] = cur[(size_t)i * 4 + k];
+			for (int s = 0; s < 4; ++s) if (fl & side_bit[s]) after[s] += side_sign[s] * kResizeStep;
+			// stamps.clip_stamp (growing a valid stamp cannot empty it)
+			after[0] = std::max(after[0], limits[0]); after[2] = std::max(after[2], limits[2]);
+			after[1] = std::min(after[1], limits[1]); after[3] = std::min(after[3], limits[3]);
+			if (std::equal(before, before + 4, after)) {
+				log(i, 6);                             // "Could not resize stamp any further.": the attempt just made stands
+			} else {
+				stamp_resizes[i] += 1;
+				for (int k = 0; k < 4; ++k) cur[(size_t)i * 4 + k] = after[k];
+				bool quick = false;
+				double stuck = 0.0;
+				if (budget_flux[i] == budget_flux[i]) {     // bright target (not NaN): stamps.quick_break_flux
+					bool side_stuck[4], any = false;
+					for (int s = 0; s < 4; ++s) { side_stuck[s] = (fl & side_bit[s]) && before[s] == after[s]; any = any || side_stuck[s]; }
+					if (any) {
+						vals.clear();
+						const uint8_t* mk = r_mask + (size_t)j * H * W;
+						const double* sm = r_sum + (size_t)j * H * W;
+						for (int r = 0; r < H; ++r)
+							for (int c = 0; c < W; ++c) {
+								const bool edge = (side_stuck[0] && r == 0) || (side_stuck[1] && r == H - 1) || (side_stuck[2] && c == 0) || (side_stuck[3] && c == W - 1);
+								if (edge && mk[r * W + c]) { const double v = sm[r * W + c]; vals.push_back(v == v ? v : 0.0); }
+							}
+						stuck = np_pairwise_sum(vals.data(), (int64_t)vals.size());
+						quick = stuck > budget_flux[i];
+					}
+				}
+				if (quick) { log(i, 7, 0, 0, stuck); finish(i, TP_STATUS_ERROR); }
+				else if (attempts[i] == 0) { log(i, 8); finish(i, TP_STATUS_ERROR); }
+				else still.push_back(i);
+				continue;
+			}
+		}
+		if (kind == 6) log(i, 9);                          // "No targets in mask."
+		stands();
+	}
+	groups.push_back(std::move(G));
+}
+
+void tp_frames_job::run()
+{
+	(void)hipSetDevice(eng->device);
+	std::vector<hipEvent_t> event_pool;
+	try {
+		status.assign(n, 0); stamp_resizes.assign(n, 0); group.assign(n, -1); pos.assign(n, 0); has_result.assign(n, 0);
+		stamp.assign((size_t)n * 4, -1);
+		std::vector<int32_t> active;
+		for (int32_t i = 0; i < n; ++i) {
+			if (valid[i]) { active.push_back(i); continue; }
+			status[i] = TP_STATUS_ERROR;                    // BasePhotometry.py:671-672: the constructor raises
+			direct(i, 12);
+			stamp[(size_t)i * 4] = -1; stamp[(size_t)i * 4 + 1] = -2; stamp[(size_t)i * 4 + 2] = -1; stamp[(size_t)i * 4 + 3] = -2;
+		}
+		const int64_t pitch = round_up(T, 32);
+		while (!active.empty()) {
+			// ---- the groups of this round (targets that share a stamp size), cut into parts that fit the memory budget
+			std::map<int64_t, std::vector<int32_t>> by_size;
+			for (int32_t i : active) {
+				const int64_t h = cur[(size_t)i * 4 + 1] - cur[(size_t)i * 4], w = cur[(size_t)i * 4 + 3] - cur[(size_t)i * 4 + 2];
+				by_size[h * 100000 + w].push_back(i);
+			}
+			struct Piece { std::vector<int32_t> idx; int32_t H, W; double nbytes; };
+			std::vector<std::vector<Piece>> parts(1);
+			double acc = 0.0;
+			for (auto& kv : by_size) {
+				const int32_t H = (int32_t)(kv.first / 100000), W = (int32_t)(kv.first % 100000);
+				const double per_target = 3.0 * H * W * (double)pitch * 4 + 5.0 * T * 8 + (double)H * W * 9 + 256;
+				const int64_t nmax = std::max<int64_t>(1, (int64_t)std::floor(budget / per_target));
+				for (size_t a0 = 0; a0 < kv.second.size(); a0 += (size_t)nmax) {
+					Piece p;
+					p.idx.assign(kv.second.begin() + a0, kv.second.begin() + std::min(kv.second.size(), a0 + (size_t)nmax));
+					p.H = H; p.W = W; p.nbytes = per_target * (double)p.idx.size();
+					if (!parts.back().empty() && acc + p.nbytes > budget) { parts.emplace_back(); acc = 0.0; }
+					acc += p.nbytes;
+					parts.back().push_back(std::move(p));
+				}
+			}
+			std::vector<int32_t> still;
+			for (auto& part : parts) {
+				std::vector<Launched> launched(part.size());
+				for (size_t gi = 0; gi < part.size(); ++gi) {
+					Launched& L = launched[gi];
+					L.idx = std::move(part[gi].idx);
+					L.grp.H = part[gi].H; L.grp.W = part[gi].W;
+					L.g = (L.idx.size() < 256 || gi == 0) ? streams[gi % kStreams] : streams[0];
+					launch(L, (int)gi, event_pool);
+				}
+				std::string lost;                        // a device error that surfaces at an event costs every group of the part
+				for (auto& L : launched) {
+					if (!L.failed && lost.empty()) {
+						const hipError_t e = hipEventSynchronize(L.ev);
+						if (e != hipSuccess) { lost = std::string("hipEventSynchronize: ") + hipGetErrorString(e); (void)hipGetLastError(); }
+					}
+					if (L.ev) { event_pool.push_back(L.ev); L.ev = nullptr; }
+					if (L.failed || !lost.empty()) {
+						if (L.grp.h_block) { eng->pinned.put(L.grp.h_block, L.grp.h_cap); L.grp.h_block = nullptr; }
+						const int32_t t = add_text(L.failed ? L.error : lost);
+						for (int32_t i : L.idx) { log(i, 10, L.grp.H, L.grp.W, 0.0, t); finish(i, TP_STATUS_ERROR); }
+						continue;
+					}
+					decide(L, still);
+				}
+			}
+			std::sort(still.begin(), still.end());
+			active.swap(still);
+		}
+		// ---- the light curves of every round have arrived
+		std::string copy_error;
+		for (int s = 0; s < kStreams; ++s) {
+			const hipError_t e = hipStreamSynchronize(streams[s]->stream);
+			if (e != hipSuccess && copy_error.empty()) { copy_error = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); (void)hipGetLastError(); }
+		}
+		if (!copy_error.empty()) {       // nothing that was extracted can be trusted
+			const int32_t t = add_text(copy_error);
+			for (int32_t i = 0; i < n; ++i) if (has_result[i]) { has_result[i] = 0; direct(i, 11, 0, 0, 0.0, t); status[i] = TP_STATUS_ERROR; }
+		}
+	} catch (const std::exception& e) {
+		rc = TP_ERR_HIP;
+		err = e.what();
+		for (int s = 0; s < kStreams; ++s) (void)hipStreamSynchronize(streams[s]->stream);
+		(void)hipGetLastError();
+	}
+	for (auto e : event_pool) (void)hipEventDestroy(e);
+	for (auto& hs : host_scratch) eng->pinned.put(hs.first, hs.second);
+	host_scratch.clear();
+}
+
+extern "C" {
+
+int tp_frames_engine_create(int device, int32_t n_slots, tp_frames_engine** out)
+{
+	if (!out) { tp_global_err = "tp_frames_engine_create: null output pointer"; return TP_ERR_INVALID; }
+	*out = nullptr;
+	if (n_slots < 1 || n_slots > 64) { tp_global_err = "tp_frames_engine_create: 1 .. 64 slots"; return TP_ERR_INVALID; }
+	TP_API_BEGIN
+	tp_frames_engine* eng = new tp_frames_engine();
+	eng->device = device;
+	eng->n_slots = n_slots;
+	for (int i = 0; i < n_slots * kStreams; ++i) {
+		tp_ctx* c = nullptr;
+		const int rc = tp_ctx_create_stream(device, 0, &c);
+		if (rc != TP_OK) {
+			for (tp_ctx* x : eng->ctxs) (void)tp_ctx_destroy(x);
+			delete eng;
+			return rc;
+		}
+		eng->ctxs.push_back(c);
+	}
+	eng->busy.assign(n_slots, 0);
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) eng->hbm_bytes = (uint64_t)prop.totalGlobalMem;
+	*out = eng;
+	return TP_OK;
+	TP_API_END((tp_ctx*)nullptr)
+}
+
+int tp_frames_engine_destroy(tp_frames_engine* eng)
+{
+	if (!eng) return TP_OK;
+	for (tp_ctx* c : eng->ctxs) (void)tp_ctx_destroy(c);
+	delete eng;
+	return TP_OK;
+}
+
+int tp_frames_engine_info(tp_frames_engine* eng, int32_t* n_slots, int32_t* n_free, uint64_t* hbm_bytes)
+{
+	if (!eng) { tp_global_err = "null engine"; return TP_ERR_INVALID; }
+	std::lock_guard<std::mutex> lk(eng->m);
+	if (n_slots) *n_slots = eng->n_slots;
+	if (n_free) { int f = 0; for (char b : eng->busy) f += b ? 0 : 1; *n_free = f; }
+	if (hbm_bytes) *hbm_bytes = eng->hbm_bytes;
+	return TP_OK;
+}
+
+int tp_frames_catalog_create(int64_t n_stars, const int64_t* h_starid, const float* h_tmag, const double* h_row, const double* h_column,
+	tp_frames_catalog** out)
+{
+	if (!out || n_stars < 0 || (n_stars > 0 && !(h_starid && h_tmag && h_row && h_column))) { tp_global_err = "tp_frames_catalog_create: bad arguments"; return TP_ERR_INVALID; }
+	*out = nullptr;
+	TP_API_BEGIN
+	tp_frames_catalog* c = new tp_frames_catalog();
+	c->n = n_stars;
+	c->starid.assign(h_starid, h_starid + n_stars);
+	c->tmag.assign(h_tmag, h_tmag + n_stars);
+	c->row.assign(h_row, h_row + n_stars);
+	c->col.assign(h_column, h_column + n_stars);
+	// pipeline._CatalogIndex: cells of 16 x 16 pixels from the floor of the smallest row / column; stars without a position go
+	// to a cell no stamp asks for
+	double rmin = INFINITY, cmin = INFINITY;
+	for (int64_t i = 0; i < n_stars; ++i) {
+		if (std::isfinite(c->row[i])) rmin = std::min(rmin, c->row[i]);
+		if (std::isfinite(c->col[i])) cmin = std::min(cmin, c->col[i]);
+	}
+	c->r0 = std::isfinite(rmin) ? (int64_t)std::floor(rmin) : 0;
+	c->c0 = std::isfinite(cmin) ? (int64_t)std::floor(cmin) : 0;
+	std::vector<int64_t> cr(n_stars, 0), cc(n_stars, 0);
+	int64_t crmax = 0, ccmax = 0;
+	for (int64_t i = 0; i < n_stars; ++i) {
+		if (std::isfinite(c->row[i]) && std::isfinite(c->col[i])) {
+			cr[i] = (int64_t)std::floor((c->row[i] - (double)c->r0) / (double)c->cell);
+			cc[i] = (int64_t)std::floor((c->col[i] - (double)c->c0) / (double)c->cell);
+			crmax = std::max(crmax, cr[i]); ccmax = std::max(ccmax, cc[i]);
+		}
+	}
+	c->n_cr = crmax + 1; c->n_cc = ccmax + 1;
+	const int64_t n_cells = c->n_cr * c->n_cc;
+	std::vector<int64_t> cid(n_stars);
+	for (int64_t i = 0; i < n_stars; ++i)
+		cid[i] = (std::isfinite(c->row[i]) && std::isfinite(c->col[i]) && cr[i] >= 0 && cc[i] >= 0) ? cr[i] * c->n_cc + cc[i] : n_cells;
+	c->order.resize(n_stars);
+	for (int64_t i = 0; i < n_stars; ++i) c->order[i] = i;
+	std::stable_sort(c->order.begin(), c->order.end(), [&](int64_t a, int64_t b) { return cid[a] < cid[b]; });
+	c->cell_start.assign(n_cells + 2, 0);
+	for (int64_t i = 0; i < n_stars; ++i) c->cell_start[cid[i] + 1] += 1;
+	for (int64_t k = 0; k <= n_cells; ++k) c->cell_start[k + 1] += c->cell_start[k];
+	*out = c;
+	return TP_OK;
+	TP_API_END((tp_ctx*)nullptr)
+}
+
+int tp_frames_catalog_destroy(tp_frames_catalog* cat)
+{
+	delete cat;
+	return TP_OK;
+}
+
+int tp_frames_submit(tp_frames_engine* eng, const tp_frames_stack* stack, const tp_frames_catalog* cat,
+	int32_t n_targets, const int64_t* h_starid, const double* h_tmag, const double* h_row, const double* h_column,
+	const int64_t* h_stamps, const uint8_t* h_valid, const int32_t* h_attempts, const double* h_quick_break_budget,
+	const double* h_time, const int32_t* h_quality, double budget_bytes, tp_frames_job** out)
+{
+	if (!eng || !out) { tp_global_err = "tp_frames_submit: null engine / output pointer"; return TP_ERR_INVALID; }
+	*out = nullptr;
+	if (!stack || !cat || n_targets < 0 || !stack->d_images || !stack->d_images_err || !stack->d_backgrounds || stack->n_frames <= 0 ||
+		stack->n_rows <= 0 || stack->n_cols <= 0 || !h_time || !h_quality ||
+		(n_targets > 0 && !(h_starid && h_tmag && h_row && h_column && h_stamps && h_valid && h_attempts && h_quick_break_budget))) {
+		tp_global_err = "tp_frames_submit: bad arguments";
+		return TP_ERR_INVALID;
+	}
+	TP_API_BEGIN
+	int slot = -1;
+	{
+		std::lock_guard<std::mutex> lk(eng->m);
+		for (int s = 0; s < eng->n_slots; ++s) if (!eng->busy[s]) { slot = s; eng->busy[s] = 1; break; }
+	}
+	if (slot < 0) { tp_global_err = "tp_frames_submit: every slot of the engine holds a job (wait for and release one first)"; return TP_ERR_INVALID; }
+	tp_frames_job* job = new tp_frames_job();
+	job->eng = eng; job->slot = slot;
+	for (int s = 0; s < kStreams; ++s) job->streams[s] = eng->ctxs[(size_t)slot * kStreams + s];
+	job->stack = *stack; job->cat = cat;
+	job->n = n_targets; job->T = stack->n_frames;
+	job->starid.assign(h_starid, h_starid + n_targets);
+	job->tmag.assign(h_tmag, h_tmag + n_targets);
+	job->row.assign(h_row, h_row + n_targets);
+	job->col.assign(h_column, h_column + n_targets);
+	job->cur.assign(h_stamps, h_stamps + (size_t)n_targets * 4);
+	job->valid.assign(h_valid, h_valid + n_targets);
+	job->attempts.assign(h_attempts, h_attempts + n_targets);
+	job->budget_flux.assign(h_quick_break_budget, h_quick_break_budget + n_targets);
+	job->time.assign(h_time, h_time + job->T);
+	job->quality.assign(h_quality, h_quality + job->T);
+	job->budget = budget_bytes > 0 ? budget_bytes : (double)eng->hbm_bytes / 4.0;
+	job->worker = std::thread([job] { job->run(); });
+	*out = job;
+	return TP_OK;
+	TP_API_END((tp_ctx*)nullptr)
+}
+
+int tp_frames_wait(tp_frames_job* job)
+{
+	if (!job) { tp_global_err = "null job"; return TP_ERR_INVALID; }
+	if (!job->joined) {
+		job->worker.join();
+		job->joined = true;
+		// the job's streams are idle: its slot can take the next job while the caller still holds this one's results
+		std::lock_guard<std::mutex> lk(job->eng->m);
+		job->eng->busy[job->slot] = 0;
+	}
+	if (job->rc != TP_OK) tp_global_err = job->err;
+	return job->rc;
+}
+
+int tp_frames_counts(tp_frames_job* job, int32_t* n_groups, int64_t* n_events)
+{
+	if (!job || !job->joined) { tp_global_err = "tp_frames_counts: wait for the job first"; return TP_ERR_INVALID; }
+	if (n_groups) *n_groups = (int32_t)job->groups.size();
+	if (n_events) *n_events = (int64_t)job->events.size();
+	return TP_OK;
+}
+
+int tp_frames_targets(tp_frames_job* job, int32_t* status, int64_t* stamps, int32_t* stamp_resizes, uint8_t* has_result, int32_t* group, int32_t* pos)
+{
+	if (!job || !job->joined) { tp_global_err = "tp_frames_targets: wait for the job first"; return TP_ERR_INVALID; }
+	const size_t n = (size_t)job->n;
+	if (status) std::memcpy(status, job->status.data(), n * 4);
+	if (stamps) std::memcpy(stamps, job->stamp.data(), n * 32);
+	if (stamp_resizes) std::memcpy(stamp_resizes, job->stamp_resizes.data(), n * 4);
+	if (has_result) std::memcpy(has_result, job->has_result.data(), n);
+	if (group) std::memcpy(group, job->group.data(), n * 4);
+	if (pos) std::memcpy(pos, job->pos.data(), n * 4);
+	return TP_OK;
+}
+
+int tp_frames_group(tp_frames_job* job, int32_t g, int32_t* n_targets, int32_t* height, int32_t* width, int64_t* cat_capacity, int64_t* n_cat,
+	void** h_block, uint64_t* block_nbytes)
+{
+	if (!job || !job->joined || g < 0 || g >= (int32_t)job->groups.size()) { tp_global_err = "tp_frames_group: no such group"; return TP_ERR_INVALID; }
+	const Group& G = job->groups[g];
+	if (n_targets) *n_targets = G.n;
+	if (height) *height = G.H;
+	if (width) *width = G.W;
+	if (cat_capacity) *cat_capacity = G.cat_capacity;
+	if (n_cat) *n_cat = G.n_cat;
+	if (h_block) *h_block = G.h_block;
+	if (block_nbytes) *block_nbytes = G.nbytes;
+	return TP_OK;
+}
+
+int tp_frames_group_lists(tp_frames_job* job, int32_t g, int64_t* cat_offsets, int64_t* cat_starid, int64_t* target_starid)
+{
+	if (!job || !job->joined || g < 0 || g >= (int32_t)job->groups.size()) { tp_global_err = "tp_frames_group_lists: no such group"; return TP_ERR_INVALID; }
+	const Group& G = job->groups[g];
+	if (cat_offsets) std::memcpy(cat_offsets, G.cat_offsets.data(), G.cat_offsets.size() * 8);
+	if (cat_starid && G.n_cat) std::memcpy(cat_starid, G.cat_starid.data(), (size_t)G.n_cat * 8);
+	if (target_starid) std::memcpy(target_starid, G.target_starid.data(), (size_t)G.n * 8);
+	return TP_OK;
+}
+
+int tp_frames_events(tp_frames_job* job, int32_t* target, int32_t* code, int32_t* a, int32_t* b, double* value, int32_t* text)
+{
+	if (!job || !job->joined) { tp_global_err = "tp_frames_events: wait for the job first"; return TP_ERR_INVALID; }
+	for (size_t k = 0; k < job->events.size(); ++k) {
+		const Event& e = job->events[k];
+		if (target) target[k] = e.target;
+		if (code) code[k] = e.code;
+		if (a) a[k] = e.a;
+		if (b) b[k] = e.b;
+		if (value) value[k] = e.value;
+		if (text) text[k] = e.text;
+	}
+	return TP_OK;
+}
+
+const char* tp_frames_text(tp_frames_job* job, int32_t k)
+{
+	if (!job || k < 0 || k >= (int32_t)job->texts.size()) return "";
+	return job->texts[k].c_str();
+}
+
+int tp_frames_release(tp_frames_job* job)
+{
+	if (!job) return TP_OK;
+	(void)tp_frames_wait(job);
+	for (auto& G : job->groups) if (G.h_block) { job->eng->pinned.put(G.h_block, G.h_cap); G.h_block = nullptr; }
+	delete job;
+	return TP_OK;
+}
+
+} // extern "C"

@@ -208,6 +208,9 @@ class Context(object):
 
 	def close(self):
 		if getattr(self, 'handle', None) is not None:
+			eng = self.__dict__.pop('_frames_engine', None)   # pipeline.FramesEngine: its streams and page-locked pool go first
+			if eng is not None:
+				eng.close()
 			self.pinned_trim()
 			for c in self.__dict__.get('_side', []):
 				c.close()

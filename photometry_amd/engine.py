@@ -230,9 +230,7 @@ def cut_stamps(ctx, frames, stamps, height, width, row_offset=0, col_offset=0, o
 	T, R, C = frames.shape
 	Nt = stamps.shape[0]
 	if out is None:
-		out = DeviceCube(ctx, Nt, T, height, width)
-		if out.t_pitch != T:
-			out.data.fill_bytes(0)
+		out = DeviceCube(ctx, Nt, T, height, width)   # (not cleared: the cutter writes the padding of the time axis as zeros itself)
 	desc = out.desc
 	ctx._check(ctx.lib.tp_cut_stamps(ctx.handle, frames.ptr, T, R, C, C, R * C, int(row_offset), int(col_offset), stamps.ptr,
 		ctypes.byref(desc), out.ptr))

@@ -7,9 +7,11 @@ i.e. ``AperturePhotometry.do_photometry`` (photometry/AperturePhotometry/photome
 for every target of the batch at once.
 """
 
+import ctypes
 import os
 import numpy as np
-from . import engine
+from . import engine, _lib
+from ._lib import TessphotError
 from .device import DeviceCube, device_view, round_up
 
 
@@ -486,15 +488,23 @@ class FramesResult(object):
 		self.pos = np.zeros(n, dtype='int32')
 		self.errors = {}       # target -> list of "LEVEL: message" strings (targets without messages have no entry)
 		self.edge_flux = {}    # target -> flux on the stuck edges (haloswitch quick break)
-		self.groups = []       # per device pass: dict of host arrays (views of the page-locked block the pass was downloaded into)
+		#: per device pass: dict of host arrays.  They are READ-ONLY VIEWS of the page-locked block the pass was downloaded into and
+		#: live as long as this result: :meth:`release` (and the result's deletion) hands the blocks to the next job's download.  Copy
+		#: what has to outlive the result (``result[i]`` does: the per-target dict holds copies).
+		self.groups = []
 		self._pinned = []      # (context, block): returned to the context's pool when the result goes
+		self._job = None       # the native job (pipeline.FramesEngine) whose page-locked blocks the group arrays view
 
 	def release(self):
-		"""Give the page-locked blocks behind the group arrays back to their context's pool (the arrays must not be used afterwards)."""
+		"""Give the page-locked blocks behind the group arrays back to their pool: the group arrays must not be used afterwards
+		(they are dropped from ``groups``; a view a caller kept would read the next job's data)."""
 		for ctx, blk in self._pinned:
 			ctx.pinned_release(blk)
 		self._pinned = []
 		self.groups = []
+		job, self._job = self._job, None
+		if job is not None:
+			job.release()
 
 	def __del__(self):
 		try:
@@ -549,7 +559,173 @@ class FramesResult(object):
 		return (self[i] for i in range(self.n))
 
 
-def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, cadence_s=1800, datasource='ffi'):
+#: what the native engine reports as codes (csrc/frames.cpp) in the words of the reference's plugin / of the Python rounds below
+_EVENT_TEXT = {1: 'ERROR: No flux above threshold.', 2: 'WARNING: No masks found. Using minimum aperture.',
+	3: 'WARNING: No mask found for main target. Using minimum aperture.', 4: 'ERROR: Too many masks.',
+	6: 'WARNING: Could not resize stamp any further.', 7: 'ERROR: Stamp resize hit limit. Haloswitch quick break.',
+	8: 'ERROR: Too many stamp resizes.', 9: 'ERROR: No targets in mask.', 12: 'ValueError: Invalid stamp selected'}
+
+
+class _NativeCatalog(object):
+	"""The catalogue of a region inside the library (``tp_frames_catalog``: copied and binned into cells once)."""
+	def __init__(self, lib, catalog):
+		self.lib = lib
+		sid = np.ascontiguousarray(catalog['starid'], dtype='int64')
+		tm = np.ascontiguousarray(catalog['tmag'], dtype='float32')
+		row = np.ascontiguousarray(catalog['row'], dtype='float64')
+		col = np.ascontiguousarray(catalog['column'], dtype='float64')
+		h = ctypes.c_void_p()
+		rc = lib.tp_frames_catalog_create(len(sid), sid.ctypes.data, tm.ctypes.data, row.ctypes.data, col.ctypes.data, ctypes.byref(h))
+		if rc != 0:
+			raise TessphotError(rc, (lib.tp_last_error(None) or b'').decode())
+		self.handle = h.value
+
+	def __del__(self):
+		h, self.handle = getattr(self, 'handle', None), None
+		if h:
+			self.lib.tp_frames_catalog_destroy(h)
+
+
+class FramesJob(object):
+	"""A batch in flight in the native engine: :meth:`collect` waits for it and returns its :class:`FramesResult`."""
+	def __init__(self, engine, handle, n, T, keep):
+		self.engine, self.handle, self.n, self.T = engine, handle, int(n), int(T)
+		self._keep = keep      # the stack and the catalogue: alive while the job runs
+
+	def release(self):
+		h, self.handle = self.handle, None
+		if h and self.engine.handle:
+			self.engine.lib.tp_frames_release(h)
+
+	def __del__(self):
+		try:
+			self.release()
+		except Exception: # noqa: B902
+			pass
+
+	def collect(self):
+		from . import comm as tpcomm
+		lib, h, n, T = self.engine.lib, self.handle, self.n, self.T
+		rc = lib.tp_frames_wait(h)
+		if rc != 0:
+			msg = (lib.tp_last_error(None) or b'').decode()
+			self.release()
+			raise TessphotError(rc, msg)
+		self._keep = None
+		out = FramesResult(n)
+		out._job = self
+		ng, ne = ctypes.c_int32(), ctypes.c_int64()
+		lib.tp_frames_counts(h, ctypes.byref(ng), ctypes.byref(ne))
+		has = np.zeros(n, dtype='uint8')
+		lib.tp_frames_targets(h, out.status.ctypes.data, out.stamp.ctypes.data, out.stamp_resizes.ctypes.data, has.ctypes.data,
+			out.group.ctypes.data, out.pos.ctypes.data)
+		out.has_result = has.astype(bool)
+		for g in range(ng.value):
+			m, H, W, cap, ncat, blk, nb = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_void_p(), ctypes.c_uint64()
+			lib.tp_frames_group(h, g, ctypes.byref(m), ctypes.byref(H), ctypes.byref(W), ctypes.byref(cap), ctypes.byref(ncat), ctypes.byref(blk), ctypes.byref(nb))
+			layout, nbytes = tpcomm.packed_block_layout(m.value, T, H.value, W.value, n_cat=cap.value, extras=True)
+			if nbytes != nb.value:
+				raise RuntimeError('the packed block of the native engine does not have the layout of comm.packed_block_layout')
+			host = np.frombuffer((ctypes.c_uint8 * nbytes).from_address(blk.value), dtype='uint8')
+			host.flags.writeable = False
+			grp = tpcomm.unpack_block(host, layout)
+			offs = np.empty(m.value + 1, dtype='int64')
+			cat_ids = np.empty(max(ncat.value, 0), dtype='int64')
+			tids = np.empty(m.value, dtype='int64')
+			lib.tp_frames_group_lists(h, g, offs.ctypes.data, cat_ids.ctypes.data, tids.ctypes.data)
+			grp.update(cat_offsets=offs, cat_starid=cat_ids, target_starid=tids)
+			out.groups.append(grp)
+		if ne.value:
+			k = ne.value
+			tgt, code, a, b, txt = (np.empty(k, dtype='int32') for _ in range(5))
+			val = np.empty(k, dtype='float64')
+			lib.tp_frames_events(h, tgt.ctypes.data, code.ctypes.data, a.ctypes.data, b.ctypes.data, val.ctypes.data, txt.ctypes.data)
+			from .plugins import _MASK_EXCEPTIONS
+			for e in range(k):
+				i, c = int(tgt[e]), int(code[e])
+				if c == 5:
+					msg = 'RuntimeError: ' + _MASK_EXCEPTIONS[int(a[e])]
+				elif c == 10:
+					msg = 'ERROR: Device pass failed for a %dx%d stamp: %s' % (a[e], b[e], lib.tp_frames_text(h, int(txt[e])).decode())
+				elif c == 11:
+					msg = 'ERROR: Device pass failed while the light curves were copied: ' + lib.tp_frames_text(h, int(txt[e])).decode()
+				else:
+					msg = _EVENT_TEXT[c]
+				out.errors.setdefault(i, []).append(msg)
+				if c == 7:
+					out.edge_flux[i] = float(val[e])
+		return out
+
+
+class FramesEngine(object):
+	"""
+	The native job engine of the batched drop-in entry (``tp_frames_*``, ``csrc/frames.cpp``): ``slots`` jobs in flight, each
+	driven by a worker thread of the library on three streams of its own.  ``submit`` copies the batch's host arrays and
+	returns at once; ``FramesJob.collect`` waits.  One engine per context (:meth:`of`), closed with it.
+	"""
+	def __init__(self, ctx, slots=4):
+		self.ctx, self.lib, self.slots = ctx, ctx.lib, int(slots)
+		h = ctypes.c_void_p()
+		rc = self.lib.tp_frames_engine_create(ctx.device, self.slots, ctypes.byref(h))
+		if rc != 0:
+			raise TessphotError(rc, (self.lib.tp_last_error(None) or b'').decode())
+		self.handle = h.value
+		hbm = ctypes.c_uint64()
+		self.lib.tp_frames_engine_info(self.handle, None, None, ctypes.byref(hbm))
+		self.hbm_bytes = hbm.value
+
+	@classmethod
+	def of(cls, ctx, slots=4):
+		"""The engine of ``ctx`` (made on first use; remade with more slots when asked for more than it has)."""
+		eng = ctx.__dict__.get('_frames_engine')
+		if eng is None or eng.slots < slots or eng.handle is None:
+			if eng is not None:
+				eng.close()
+			eng = ctx.__dict__['_frames_engine'] = cls(ctx, slots=max(int(slots), 4))
+		return eng
+
+	def catalog(self, catalog):
+		"""The catalogue of a region copied into the library and binned (once per run over the region: the pipelined entry)."""
+		return _NativeCatalog(self.lib, catalog)
+
+	def submit(self, stack, targets, catalog, time, quality, settings=None, datasource='ffi', budget_share=1.0):
+		from . import stamps as st
+		from .plugins import load_settings, mag2flux
+		settings = load_settings() if settings is None else settings
+		tmag_limit = settings.getfloat('haloswitch', 'tmag_limit')
+		flux_limit = settings.getfloat('haloswitch', 'flux_limit')
+		sid = np.ascontiguousarray(targets['starid'], dtype='int64')
+		tm = np.ascontiguousarray(targets['tmag'], dtype='float64')
+		row = np.ascontiguousarray(targets['row'], dtype='float64')
+		col = np.ascontiguousarray(targets['column'], dtype='float64')
+		n = len(sid)
+		first, valid = st.default_stamps(row, col, tm, stack.limits)
+		first = np.ascontiguousarray(first, dtype='int64')
+		valid8 = np.ascontiguousarray(valid, dtype='uint8')
+		attempts = np.where(tm < 6, 10, 5).astype('int32')                    # photometry.py:70-73 (stamps.retry_limit)
+		bright = (tm <= tmag_limit) & (not datasource.startswith('tpf:'))      # photometry.py:146
+		budget_flux = np.where(bright, flux_limit * mag2flux(tm), np.nan).astype('float64')
+		t = np.ascontiguousarray(time, dtype='float64')
+		q = np.ascontiguousarray(quality, dtype='int32')
+		if len(t) != stack.n_cad or len(q) != stack.n_cad:
+			raise ValueError('time and quality must have one entry per frame of the stack')
+		sdesc = _lib.tp_frames_stack(stack.dev['images'].ptr, stack.dev['images_err'].ptr, stack.dev['backgrounds'].ptr,
+			stack.n_cad, stack.n_rows, stack.n_cols, stack.row0, stack.col0)
+		budget = float(os.environ.get('TESSPHOT_FRAMES_BUDGET_GB', 0)) * 1e9 or self.hbm_bytes / 4.0
+		h = ctypes.c_void_p()
+		rc = self.lib.tp_frames_submit(self.handle, ctypes.byref(sdesc), catalog.handle, n, sid.ctypes.data, tm.ctypes.data, row.ctypes.data, col.ctypes.data,
+			first.ctypes.data, valid8.ctypes.data, attempts.ctypes.data, budget_flux.ctypes.data, t.ctypes.data, q.ctypes.data, budget * budget_share, ctypes.byref(h))
+		if rc != 0:
+			raise TessphotError(rc, (self.lib.tp_last_error(None) or b'').decode())
+		return FramesJob(self, h.value, n, stack.n_cad, (stack, catalog))
+
+	def close(self):
+		h, self.handle = self.handle, None
+		if h:
+			self.lib.tp_frames_engine_destroy(h)
+
+
+def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, cadence_s=1800, datasource='ffi', engine='native'):
 	"""
 	``AperturePhotometry.do_photometry`` INCLUDING its stamp-resize loop (photometry.py:75-170) for every target of a CCD region
 	held in a :class:`FrameStack`: round after round, the targets still in play are grouped by stamp size, their stamps are cut
@@ -563,23 +739,44 @@ def aperture_frames(ctx, stack, targets, catalog, time, quality, settings=None, 
 	flux_background, pos_centroid, contamination, skip_targets, diagnostics``).  The common case -- the mask does not touch an
 	edge and nothing is logged -- is decided for a whole group with array operations; only the targets that resize, warn or fail
 	take the per-target path.
+
+	``engine``: ``'native'`` (default) -- the rounds are driven by a worker thread of the library (``csrc/frames.cpp``,
+	:class:`FramesEngine`): the host submits the batch and collects it; ``'python'`` -- the same rounds as a Python generator
+	(:func:`_frames_job`, the implementation the native engine is held to in ``tests/test_gpu_resize.py``).
 	"""
-	job = _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s, datasource, [ctx] + ctx.side_contexts(2))
-	while True:
-		try:
-			next(job)
-		except StopIteration as done:
-			return done.value
+	if engine == 'python':
+		job = _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s, datasource, [ctx] + ctx.side_contexts(2))
+		while True:
+			try:
+				next(job)
+			except StopIteration as done:
+				return done.value
+	eng = FramesEngine.of(ctx)
+	return eng.submit(stack, targets, eng.catalog(catalog), time, quality, settings=settings, datasource=datasource).collect()
 
 
-def aperture_frames_pipelined(ctx, stack, batches, catalog, time, quality, settings=None, cadence_s=1800, datasource='ffi', in_flight=4):
+def aperture_frames_pipelined(ctx, stack, batches, catalog, time, quality, settings=None, cadence_s=1800, datasource='ffi', in_flight=4, engine='native'):
 	"""
 	:func:`aperture_frames` over consecutive batches of targets of one CCD region (``batches``: an iterable of ``targets`` dicts),
 	``in_flight`` of them at a time, each on its own streams: the rounds of a batch are a strict chain -- queue the passes, wait,
 	decide, queue the next round -- whose later links are a few latency-bound passes over the resized stamps that leave most of
 	the chip idle, so the first round of the next batch runs under them and the host decides one batch while the device works on
 	the other.  Yields one :class:`FramesResult` per batch, in order; every batch gives what a call of its own would.
+	With the native engine (default) every batch is a job of :class:`FramesEngine`: submitted, driven by its own worker thread of
+	the library, collected in order -- the host touches a batch twice.
 	"""
+	if engine != 'python':
+		from collections import deque
+		eng = FramesEngine.of(ctx, slots=in_flight)
+		cat = eng.catalog(catalog)
+		queue = deque()
+		for targets in batches:
+			while len(queue) >= in_flight:
+				yield queue.popleft().collect()
+			queue.append(eng.submit(stack, targets, cat, time, quality, settings=settings, datasource=datasource, budget_share=1.0 / in_flight))
+		while queue:
+			yield queue.popleft().collect()
+		return
 	catalog = {k: np.asarray(v) for k, v in catalog.items()}
 	cat_index = _CatalogIndex(catalog)
 	every = [ctx] + ctx.side_contexts(3 * in_flight - 1)
@@ -765,6 +962,9 @@ def _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s
 				out.has_result[done] = True
 				out.group[done] = gid
 				out.pos[done] = np.flatnonzero(simple)
+				for i in done:   # what an earlier round logged for the target (it went on with a bigger stamp) stays in its details
+					if int(i) in log and log[int(i)].items:
+						finish(int(i), int(out.status[i]))
 				# ---- the others, one by one with the plugin's rules
 				for j in np.flatnonzero(~simple):
 					i = int(idx[j])

@@ -214,18 +214,18 @@ class BatchResults(object):
 		return (self[i] for i in range(len(self)))
 
 
-def tessphot_frames(ctx, stack, targets, catalog, time, quality, settings=None, cadence_s=1800):
+def tessphot_frames(ctx, stack, targets, catalog, time, quality, settings=None, cadence_s=1800, engine='native'):
 	"""
 	Aperture photometry of every target of a CCD region resident in HBM (:class:`photometry_amd.pipeline.FrameStack`), stamp
 	resizes included: what ``tessphot('aperture', ...)`` returns per target, for the whole batch in a few device passes.
 	Returns a :class:`BatchResults`: columns for the whole batch, one :class:`BatchResult` per target on demand (``results[i]``).
 	"""
 	from . import pipeline
-	res = pipeline.aperture_frames(ctx, stack, targets, catalog, time, quality, settings=settings, cadence_s=cadence_s)
+	res = pipeline.aperture_frames(ctx, stack, targets, catalog, time, quality, settings=settings, cadence_s=cadence_s, engine=engine)
 	return BatchResults(res, targets['starid'])
 
 
-def tessphot_frames_pipelined(ctx, stack, batches, catalog, time, quality, settings=None, cadence_s=1800, in_flight=4):
+def tessphot_frames_pipelined(ctx, stack, batches, catalog, time, quality, settings=None, cadence_s=1800, in_flight=4, engine='native'):
 	"""
 	:func:`tessphot_frames` over consecutive batches of targets of one CCD region -- what a run over a whole CCD does, a few
 	thousand targets per call -- with ``in_flight`` batches on the device at a time (``pipeline.aperture_frames_pipelined``: the
@@ -240,7 +240,7 @@ def tessphot_frames_pipelined(ctx, stack, batches, catalog, time, quality, setti
 			ids.append(t['starid'])
 			yield t
 	for k, res in enumerate(pipeline.aperture_frames_pipelined(ctx, stack, feed(), catalog, time, quality, settings=settings,
-			cadence_s=cadence_s, in_flight=in_flight)):
+			cadence_s=cadence_s, in_flight=in_flight, engine=engine)):
 		yield BatchResults(res, ids[k])
 
 

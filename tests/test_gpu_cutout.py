@@ -44,9 +44,18 @@ def test_against_oracle(ctx, T, R, C, H, W, n):
 	stamps = np.stack((r0, r0 + H, c0, c0 + W), axis=1).astype('int32')
 	stamps[0] = (0, H, 44, 44 + W)
 	stamps[1] = (R - H, R, 44 + C - W, 44 + C)
-	cube = engine.cut_stamps(ctx, ctx.array(frames), ctx.array(stamps), H, W, 0, 44)
+	# the cube is handed over full of 0xFF bytes (NaN): the cutter must write every element, the padding of the time axis (cadences
+	# T .. t_pitch of every pixel) as zeros -- callers do not clear the cube
+	from photometry_amd.device import DeviceCube
+	out = DeviceCube(ctx, n, T, H, W)
+	out.data.fill_bytes(255)
+	d_frames, d_stamps = ctx.array(frames), ctx.array(stamps)
+	cube = engine.cut_stamps(ctx, d_frames, d_stamps, H, W, 0, 44, out=out)
 	ctx.sync()
-	got = cube.to_host()
+	full = cube.data.to_host()
+	assert full.shape == (n, H, W, cube.t_pitch)
+	assert np.all(full[..., T:] == 0)
+	got = full[..., :T]
 	for i in range(n):
 		np.testing.assert_array_equal(got[i], cutout.load_cube(frames, tuple(stamps[i]), 0, 44), err_msg=str(stamps[i]))
 

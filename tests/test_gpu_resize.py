@@ -247,3 +247,93 @@ def test_pipelined_batches_equal_separate_calls():
 						np.testing.assert_array_equal(x.lightcurve[key], y.lightcurve[key])
 					np.testing.assert_array_equal(x.final_phot_mask, y.final_phot_mask)
 	ctx.close()
+
+
+def _compare_frames_results(a, b):
+	"""Two pipeline.FramesResult of the same batch: everything a caller can see, target by target."""
+	assert a.n == b.n
+	np.testing.assert_array_equal(a.status, b.status)
+	np.testing.assert_array_equal(a.stamp, b.stamp)
+	np.testing.assert_array_equal(a.stamp_resizes, b.stamp_resizes)
+	np.testing.assert_array_equal(a.has_result, b.has_result)
+	assert a.errors == b.errors
+	assert a.edge_flux == b.edge_flux                       # (float64 sums in numpy's pairwise order on both sides: equal, not close)
+	assert len(a.groups) == len(b.groups)
+	for i in range(a.n):
+		x, y = a[i], b[i]
+		assert set(x) == set(y), (i, set(x) ^ set(y))
+		for k in x:
+			if isinstance(x[k], np.ndarray):
+				np.testing.assert_array_equal(x[k], y[k], err_msg=f'target {i}: {k}')
+			elif k == 'diagnostics':
+				np.testing.assert_array_equal(np.array(list(x[k].values())), np.array(list(y[k].values())), err_msg=f'target {i}: diagnostics')
+			elif isinstance(x[k], float):
+				assert x[k] == y[k] or (x[k] != x[k] and y[k] != y[k]), (i, k, x[k], y[k])
+			else:
+				assert x[k] == y[k], (i, k, x[k], y[k])
+
+
+def test_native_engine_equals_the_python_rounds():
+	"""The native job engine (csrc/frames.cpp: rounds driven by a worker thread of the library) against the Python generator of the
+	same rounds, on the region with bleed trails / frame limits / the haloswitch quick break, on a crowded region whose targets
+	resize in several size groups, with invalid stamps and an empty batch, and under a memory budget that cuts the rounds in parts."""
+	import os
+	from photometry_amd import pipeline
+	from photometry_amd.device import Context
+	ctx = Context(0)
+	frames, row0, col0, time, quality, cat, targets = _region()
+	stack = pipeline.FrameStack(ctx, {k: np.moveaxis(v, 2, 0) for k, v in frames.items()}, row0, col0)
+	# a target whose default stamp lies outside the region ("Invalid stamp selected") among the others
+	t2 = {k: np.concatenate((np.asarray(v), np.asarray(v)[:1])) for k, v in targets.items()}
+	t2['row'][-1] = row0 - 500.0
+	for tg in (targets, t2, {k: np.asarray(v)[:0] for k, v in targets.items()}):
+		py = pipeline.aperture_frames(ctx, stack, tg, cat, time, quality, engine='python')
+		nat = pipeline.aperture_frames(ctx, stack, tg, cat, time, quality, engine='native')
+		_compare_frames_results(py, nat)
+	assert int(py.n) == 0
+	# crowded region
+	rng = np.random.default_rng(44)
+	N, FR, T = 700, 192, 30
+	rows, cols = rng.uniform(10, FR - 10, N), rng.uniform(10, FR - 10, N)
+	tmag = np.where(rng.random(N) < 0.06, rng.uniform(5.0, 7.5, N), rng.uniform(8.0, 14.0, N))
+	img = np.zeros((FR + 16, FR + 16))
+	yy, xx = np.mgrid[-8:9, -8:9]
+	for r, c, m in zip(rows, cols, tmag):
+		ri, ci = int(round(r)) + 8, int(round(c)) + 8
+		img[ri - 8:ri + 9, ci - 8:ci + 9] += 10**(-0.4 * (m - 20.451)) * np.exp(-0.5 * ((yy + ri - 8 - r)**2 + (xx + ci - 8 - c)**2) / 0.81) / (2 * np.pi * 0.81)
+	img = img[8:-8, 8:-8]
+	base = (img[None] * (1 + 1e-3 * rng.normal(size=T))[:, None, None]).astype('float32')
+	noise = np.sqrt(np.abs(base) + 200.0).astype('float32')
+	fr = {'images': (base + 30.0 + rng.standard_normal(base.shape).astype('float32') * noise).astype('float32'), 'images_err': noise,
+		'backgrounds': np.full((T, FR, FR), 100.0, dtype='float32')}
+	tstamp = 1500.0 + np.arange(T) * 1800.0 / 86400.0
+	q = np.zeros(T, dtype='int32')
+	cat2 = {'starid': np.arange(N, dtype='int64') + 1, 'tmag': tmag.astype('float32'), 'row': rows.astype('float32'), 'column': (cols + 44).astype('float32')}
+	tg2 = {'starid': cat2['starid'].copy(), 'tmag': tmag, 'row': rows, 'column': cols + 44}
+	stack2 = pipeline.FrameStack(ctx, fr, 0, 44)
+	py = pipeline.aperture_frames(ctx, stack2, tg2, cat2, tstamp, q, engine='python')
+	nat = pipeline.aperture_frames(ctx, stack2, tg2, cat2, tstamp, q, engine='native')
+	_compare_frames_results(py, nat)
+	assert int((nat.stamp_resizes > 0).sum()) >= 10 and len(nat.groups) >= 4 and len(nat.errors) >= 1
+	print('crowded region:', int((nat.stamp_resizes > 0).sum()), 'targets resized,', len(nat.groups), 'device passes,', len(nat.errors), 'targets with messages')
+	os.environ['TESSPHOT_FRAMES_BUDGET_GB'] = '0.003'
+	try:
+		parts = pipeline.aperture_frames(ctx, stack2, tg2, cat2, tstamp, q, engine='native')
+		parts_py = pipeline.aperture_frames(ctx, stack2, tg2, cat2, tstamp, q, engine='python')
+	finally:
+		del os.environ['TESSPHOT_FRAMES_BUDGET_GB']
+	assert len(parts.groups) > len(nat.groups) + 3
+	_compare_frames_results(parts_py, parts)
+	# the group arrays are read-only views that go with the result
+	g0 = nat.groups[0]
+	with pytest.raises(ValueError):
+		g0['status'][0] = 7
+	nat.release()
+	assert nat.groups == []
+	# pipelined, more batches than slots, results held by the caller while later batches run
+	batches = [{k: np.asarray(v)[rng.permutation(N)[:200]] for k, v in tg2.items()} for _ in range(7)]
+	alone = [pipeline.aperture_frames(ctx, stack2, b, cat2, tstamp, q, engine='python') for b in batches]
+	held = list(pipeline.aperture_frames_pipelined(ctx, stack2, iter(batches), cat2, tstamp, q, in_flight=3))
+	for a, b in zip(alone, held):
+		_compare_frames_results(a, b)
+	ctx.close()
