@@ -341,15 +341,17 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 			ck(g, tp_aperture_extract(g, &desc, cubes[0], cubes[1], cubes[2], 0, 0, nullptr, 0, d_mask, d_stamps, d_status,
 				lc[0], lc[1], lc[2], lc[3], lc[4], T));
 		}
-		ck(g, tp_lightcurve_diagnostics(g, m, T, lc[0], lc[1], lc[3], lc[4], T, d_time, d_quality, 0, kBitmask, d_status, d_sum, d_mask, H, W,
-			3600.0 / 86400.0, d_diagn));
-		// ---- two downloads: what the decisions read (everything behind the light curves) first, with an event; then the light curves
+		// ---- downloads: what the decisions read (status, flags, mask, catalogue flags, sum image) first, with an event; the
+		// diagnostics are computed behind it (nothing of a round is decided from them) and travel with the light curves
 		G.h_block = eng->pinned.get((size_t)G.nbytes, &G.h_cap);
 		const uint64_t lc_bytes = G.off_cont;
-		ckh(hipMemcpyAsync(static_cast<char*>(G.h_block) + lc_bytes, blk + lc_bytes, (size_t)(G.nbytes - lc_bytes), hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(results)");
+		ckh(hipMemcpyAsync(static_cast<char*>(G.h_block) + lc_bytes, blk + lc_bytes, (size_t)(G.off_diag - lc_bytes), hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(results)");
 		if (event_pool.empty()) { hipEvent_t e = nullptr; ckh(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); event_pool.push_back(e); }
 		L.ev = event_pool.back(); event_pool.pop_back();
 		ckh(hipEventRecord(L.ev, g->stream), "hipEventRecord");
+		ck(g, tp_lightcurve_diagnostics(g, m, T, lc[0], lc[1], lc[3], lc[4], T, d_time, d_quality, 0, kBitmask, d_status, d_sum, d_mask, H, W,
+			3600.0 / 86400.0, d_diagn));
+		ckh(hipMemcpyAsync(static_cast<char*>(G.h_block) + G.off_diag, blk + G.off_diag, (size_t)(G.nbytes - G.off_diag), hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(diagnostics)");
 		ckh(hipMemcpyAsync(G.h_block, blk, (size_t)lc_bytes, hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(light curves)");
 		for (void* p : dev) (void)tp_free(g, p);      // stream-ordered: handed out again only after what is queued above has run
 		(void)gi;

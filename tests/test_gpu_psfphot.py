@@ -9,8 +9,10 @@ stopping tolerances suggest (fatol = 1e-4 on chi^2 forces a simplex of ~1e-8): t
 order reproduces its own fluxes to 7e-9 although the iteration counts change (measured), and the device
 agrees with the oracle to 1e-7 and with the reference's golden to 7e-9.  Fluxes are compared at 1e-6 relative (north_star:
 1e-5), positions at 2e-6 pixels; the number of iterations is compared loosely, and a cadence may be finite on one side and
-NaN on the other only when the walk reaches three quarters of its iteration limit on both (psf_photometry.py:190-194: "success" is
-"finished before maxiter", a property of the walk, not of the minimum).  The device's own Nelder-Mead is additionally pinned step for step: with the likelihood of a one-star target
+NaN on the other only when at least one of the two walks ran into its iteration limit (psf_photometry.py:190-194: "success" is
+"finished before maxiter", a property of the walk, not of the minimum: the other walk may have converged hundreds of iterations
+earlier -- 335 against 500, 815 against 1 500 in the committed distribution).  ``test_psf_parity_by_distribution`` asserts the
+agreement as a distribution over 120 targets x 20 cadences against a committed oracle fixture.  The device's own Nelder-Mead is additionally pinned step for step: with the likelihood of a one-star target
 the iteration counts match scipy's exactly until the first such flip in a target's warm-start chain.
 """
 import os
@@ -96,9 +98,9 @@ def test_psf_photometry_matches_oracle(ctx):
 		differ = np.flatnonzero(ref['success'] != ~np.isnan(res['flux'][i]))
 		n_flag_diff += len(differ)
 		for k in differ:
-			# only a fit that runs into its iteration limit on one side may be finite on the other: both walks are long
+			# only a fit that runs into its iteration limit on one side may be finite on the other
 			limit = 1500 if k == 0 else 500
-			assert min(int(res['nit'][i][k]), int(ref['nit'][k])) >= 0.75 * limit, (i, k, res['nit'][i][k], ref['nit'][k])
+			assert max(int(res['nit'][i][k]), int(ref['nit'][k])) >= limit, (i, k, res['nit'][i][k], ref['nit'][k])
 		print(i, 'nit device', res['nit'][i], 'oracle', ref['nit'], 'success', ref['success'])
 		if ok.any():
 			print('   max rel flux diff', np.max(np.abs(res['flux'][i][ok] / ref['flux'][ok] - 1)), 'max pos diff',
@@ -112,6 +114,54 @@ def test_psf_photometry_matches_oracle(ctx):
 	# the device walks scipy's simplex: until the first last-bit flip in a target's warm-start chain the iteration counts are scipy's
 	print(f"identical iteration counts on {n_same_nit} of {n_cad} cadences")
 	assert n_same_nit >= n_cad // 4
+
+
+def test_psf_parity_by_distribution(ctx, golden_dir):
+	"""
+	PSFPhotometry parity stated and asserted as a distribution: 120 targets x 20 cadences (one to three fitted stars, NaN pixels)
+	against the committed fit of the oracle -- scipy's Nelder-Mead restated step for step on the FITPACK pixel integral, generated by
+	tests/golden/make_psf_distribution.py (21 minutes on 7 processes).  A Nelder-Mead run is a chain of comparisons of chi^2 values:
+	a last-bit difference in a sum sends the two sides along different simplices to the same minimum, so single cadences cannot
+	be pinned tighter than the distribution: median |dflux| / flux <= 1e-8, 99 % <= 1e-6 (north_star: 1e-5), maximum <= 1e-3;
+	finite / NaN pattern different on <= 3 % of the cadences, and ONLY where one of the two walks hit its iteration limit
+	(psf_photometry.py:190-194: `success` is a property of the walk).
+	"""
+	import sys
+	sys.path.insert(0, golden_dir)
+	import make_psf_distribution as mk
+	from photometry_amd import psf as hpsf
+	g = np.load(os.path.join(golden_dir, 'golden_psf_distribution.npz'))
+	Nt, T, H, W = (int(v) for v in g['shape'])
+	assert (mk.NT, mk.T, mk.H, mk.W) == (Nt, T, H, W) and [mk.SCENE_SEED, mk.PRF_SEED] == [int(v) for v in g['seeds']]
+	s, prf = mk.build_scene()
+	assert float(np.nansum(s.images.astype('float64'))) == float(g['images_checksum'][0])      # the scene the oracle fitted
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	cats = [s.catalog_of(i) for i in range(Nt)]
+	res = _run_device(ctx, s.images, s.backgrounds, model, s.stamps, cats, s.target_pos_row, s.target_pos_column, s.target_tmag, s.aperture)
+	flux_d, flux_o = np.asarray(res['flux'])[:, :T], g['flux']
+	nit_d, nit_o = np.asarray(res['nit'])[:, :T], g['nit']
+	cen_d = np.stack((np.asarray(res['centroid_row'])[:, :T], np.asarray(res['centroid_col'])[:, :T]), axis=-1)
+	fin_d, fin_o = np.isfinite(flux_d), np.isfinite(flux_o)
+	limit = np.full((Nt, T), 500)
+	limit[:, 0] = 1500
+	differ = fin_d != fin_o
+	both = fin_d & fin_o
+	rel = np.abs(flux_d[both] / flux_o[both] - 1)
+	dpos = np.abs(cen_d - g['pos_centroid'])[both].max(axis=1)
+	n_cad = Nt * T
+	pct = {q: float(np.percentile(rel, q)) for q in (50, 90, 99, 99.9, 100)}
+	print(f'PSF parity: {int(both.sum())} cadences finite on both sides, {int(differ.sum())} on one side only ({100.0 * differ.sum() / n_cad:.2f} %)')
+	print('   |dflux|/flux percentiles:', {k: f'{v:.2e}' for k, v in pct.items()}, ' |dpos| px: median %.2e, max %.2e' % (np.median(dpos), dpos.max()))
+	print('   identical iteration counts: %.1f %%' % (100.0 * np.mean(nit_d[both] == nit_o[both])))
+	assert both.sum() >= 0.4 * Nt * T      # (the rest: fits that run into maxiter on both sides -- NaN by the reference's rule)
+	assert pct[50] <= 1e-8 and pct[99] <= 1e-6 and pct[100] <= 1e-3
+	assert np.median(dpos) <= 1e-7 and np.percentile(dpos, 99) <= 2e-6
+	assert differ.sum() <= 0.03 * n_cad
+	hit = (nit_d >= limit) | (nit_o >= limit)
+	bad = np.argwhere(differ & ~hit)
+	assert len(bad) == 0, [(int(i), int(k), int(nit_d[i, k]), int(nit_o[i, k])) for i, k in bad]
+	# the side that is NaN is the side that hit its limit
+	assert np.all(nit_d[differ & ~fin_d] >= limit[differ & ~fin_d]) and np.all(nit_o[differ & ~fin_o] >= limit[differ & ~fin_o])
 
 
 def test_psf_fit_batch_equals_target_by_target(ctx):

@@ -243,3 +243,17 @@ def test_shenanigans_mean_golden(golden_dir):
 	# a last block of 10 frames after a full one: 15 stale frames take part
 	assert len(ob.shenanigans_block_frames(list(range(60)), 50)) == 25 and len(ob.shenanigans_block_frames(list(range(60)), 25)) == 25
 	assert len(ob.shenanigans_block_frames(list(range(10)), 0)) == 10
+
+
+def test_psf_distribution_fixture_belongs_to_the_seeded_scene(golden_dir):
+	"""tests/golden/golden_psf_distribution.npz (the oracle's Nelder-Mead fit of 120 targets x 20 cadences, 21 minutes to make) holds
+	outputs only; the GPU test rebuilds the scene from the recorded seeds: the rebuilt scene must be the one that was fitted."""
+	import sys
+	sys.path.insert(0, golden_dir)
+	import make_psf_distribution as mk
+	g = np.load(os.path.join(golden_dir, 'golden_psf_distribution.npz'))
+	assert tuple(int(v) for v in g['shape']) == (mk.NT, mk.T, mk.H, mk.W)
+	s, _prf = mk.build_scene()
+	assert float(np.nansum(s.images.astype('float64'))) == float(g['images_checksum'][0])
+	assert g['flux'].shape == (mk.NT, mk.T) and g['nit'].max() == 1500 and 0.4 < np.isfinite(g['flux']).mean() < 0.9   # two- and three-star fits mostly run into maxiter: NaN by the reference's rule
+	assert (g['status'] == 1).all()      # the plugin returns OK; NaN fluxes are only logged (psf_photometry.py:190-194)
