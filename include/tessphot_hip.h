@@ -355,6 +355,23 @@ int tp_frames_threshold_flags(tp_ctx* ctx, const float* d_indicator, const doubl
  *   and s the cubic spline of frame k in FITPACK form (knots d_knots[k][0..n), coefficients d_coefs[k][..], n =
  *   d_n_knots[k] <= max_knots; evaluated with ext = 3, :186-188); n == 0: no radial component (d_out = d_add or 0).
  *   d_add optional float32 images (the square component: the total background of :209).                            */
+/* Images that are evaluated where they are read instead of stored (round 5: the alternation read and wrote each of them
+ * several times per iteration -- 304 MB of traffic per 2048 x 2048 frame against 117 MB of algorithmic bytes):
+ *   tp_zoom_image   the square component, i.e. what tp_background_zoom would write, from the outputs of
+ *                   tp_background_mesh_finish (d_coef / d_vmin / d_vmax); frame_cols = columns of the frame;
+ *   tp_radial_image the radial component, i.e. what tp_radial_evaluate would write without d_add, from the ring profile
+ *                   (tp_radial_profiles) and the zero point.
+ * The *_zoom / *_radial entries below take them in place of d_square / d_subtract / d_add and give bit-identical results. */
+typedef struct tp_zoom_image {
+	const double* d_coef; const double* d_vmin; const double* d_vmax;
+	int32_t mesh_rows, mesh_cols, box_size, frame_cols;
+} tp_zoom_image;
+typedef struct tp_radial_image {
+	double col_offset, xcen, ycen;
+	const double* d_knots; const double* d_coefs; const int32_t* d_n_knots;
+	const double* d_zeropoint;
+	int32_t max_knots, reserved;
+} tp_radial_image;
 int tp_radial_zeropoint(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride,
 	const float* d_square, int64_t square_frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride, double flux_cutoff,
 	double* d_partial, int32_t n_partial, double* d_zeropoint);
@@ -374,6 +391,20 @@ int tp_radial_profiles(tp_ctx* ctx, int32_t n_frames, int32_t n_rings, const dou
 int tp_radial_evaluate(tp_ctx* ctx, int32_t n_frames, int32_t frame_rows, int32_t frame_cols, int64_t frame_stride,
 	double col_offset, double xcen, double ycen, const double* d_knots, const double* d_coefs, const int32_t* d_n_knots, int32_t max_knots,
 	const double* d_zeropoint, const float* d_add, int64_t add_frame_stride, float* d_out);
+int tp_radial_zeropoint_zoom(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride,
+	const tp_zoom_image* square, const uint8_t* d_exclude, int64_t exclude_frame_stride, double flux_cutoff,
+	double* d_partial, int32_t n_partial, double* d_zeropoint);
+int tp_radial_ring_modes_zoom(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride,
+	const tp_zoom_image* square, const uint8_t* d_exclude, int64_t exclude_frame_stride, double flux_cutoff,
+	const double* d_zeropoint, const int32_t* d_ring_pixels, const int32_t* d_ring_offsets, int32_t n_rings, int32_t n_ring_pixels,
+	double bandwidth_constant, double* d_scratch, double* d_modes, int32_t* d_counts);
+/* d_out = float32(radial + square): the total background of backgrounds.py:209 from the two implicit images */
+int tp_radial_evaluate_zoom(tp_ctx* ctx, int32_t n_frames, int32_t frame_rows, int32_t frame_cols, int64_t frame_stride,
+	const tp_radial_image* radial, const tp_zoom_image* add, float* d_out);
+/* tp_background_mesh with the radial component to subtract (backgrounds.py:200) evaluated from its ring profile; max_knots <= 128 */
+int tp_background_mesh_radial(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+	int64_t row_pitch, int64_t frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride,
+	const tp_radial_image* radial, double flux_cutoff, int32_t box_size, double* d_mesh, int32_t* d_nmasked);
 
 /* ---- P1..P4: linear PSF photometry ----------------------------------------------------------------
  * tp_linpsf_prf (P1) replaces the per-target PRF construction of PSF.__init__ (photometry/psf.py:

@@ -31,6 +31,16 @@ class tp_cube_desc(Structure):
 	_fields_ = [('n_targets', c_int32), ('n_cad', c_int32), ('height', c_int32), ('width', c_int32), ('t_pitch', c_int64)]
 
 
+class tp_zoom_image(Structure):
+	_fields_ = [('d_coef', c_void_p), ('d_vmin', c_void_p), ('d_vmax', c_void_p),
+		('mesh_rows', c_int32), ('mesh_cols', c_int32), ('box_size', c_int32), ('frame_cols', c_int32)]
+
+
+class tp_radial_image(Structure):
+	_fields_ = [('col_offset', c_double), ('xcen', c_double), ('ycen', c_double), ('d_knots', c_void_p), ('d_coefs', c_void_p), ('d_n_knots', c_void_p),
+		('d_zeropoint', c_void_p), ('max_knots', c_int32), ('reserved', c_int32)]
+
+
 class tp_frames_stack(Structure):
 	_fields_ = [('d_images', c_void_p), ('d_images_err', c_void_p), ('d_backgrounds', c_void_p),
 		('n_frames', c_int32), ('n_rows', c_int32), ('n_cols', c_int32), ('row0', c_int32), ('col0', c_int32)]
@@ -135,6 +145,10 @@ SIGNATURES = {
 	'tp_comm_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
 	'tp_comm_gather': (c_int, [c_void_p, _p, _p, c_uint64, c_int]),
 	'tp_comm_allgather': (c_int, [c_void_p, _p, _p, c_uint64]),
+	'tp_radial_zeropoint_zoom': (c_int, [c_void_p, _p, c_int32, c_int64, c_int64, POINTER(tp_zoom_image), _p, c_int64, c_double, _p, c_int32, _p]),
+	'tp_radial_ring_modes_zoom': (c_int, [c_void_p, _p, c_int32, c_int64, c_int64, POINTER(tp_zoom_image), _p, c_int64, c_double, _p, _p, _p, c_int32, c_int32, c_double, _p, _p, _p]),
+	'tp_radial_evaluate_zoom': (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int64, POINTER(tp_radial_image), POINTER(tp_zoom_image), _p]),
+	'tp_background_mesh_radial': (c_int, [c_void_p, _p, c_int32, c_int32, c_int32, c_int64, c_int64, _p, c_int64, POINTER(tp_radial_image), c_double, c_int32, _p, _p]),
 	'tp_frames_engine_create': (c_int, [c_int, c_int32, POINTER(c_void_p)]),
 	'tp_frames_engine_destroy': (c_int, [c_void_p]),
 	'tp_frames_engine_info': (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_uint64)]),
@@ -188,5 +202,5 @@ def exported_symbols():
 	return sorted(SIGNATURES.keys())
 
 
-__all__ = ['load', 'TessphotError', 'TessphotLibraryError', 'tp_cube_desc', 'tp_k2p2_params', 'tp_frames_stack', 'SIGNATURES', 'LIB_PATH',
+__all__ = ['load', 'TessphotError', 'TessphotLibraryError', 'tp_cube_desc', 'tp_k2p2_params', 'tp_frames_stack', 'tp_zoom_image', 'tp_radial_image', 'SIGNATURES', 'LIB_PATH',
 	'byref', 'c_void_p', 'c_int', 'c_int32', 'c_int64', 'c_uint64', 'c_float', 'c_double', 'c_uint8']

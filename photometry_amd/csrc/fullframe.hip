@@ -18,6 +18,7 @@
 // sigma clipping is a rank range: median by index, float64 two-pass mean / std by block reductions, bounds by counting.
 // LDS-exchange bound (not HBM): the median of 4096 keys needs their order.
 #include "common.h"
+#include "fullframe_dev.h"
 #include <cmath>
 
 namespace {
@@ -25,6 +26,7 @@ namespace {
 constexpr int kMeshThreads = 256;
 constexpr int kKeysPerThread = 16;
 constexpr int kMeshKeys = kMeshThreads * kKeysPerThread;   // 4096 = 64 x 64
+constexpr int kMaxFusedKnots = 128;                        // knots + coefficients of a frame's ring profile staged in LDS by the mesh kernel
 
 __device__ __forceinline__ double mesh_block_sum(double v, double* red) {
 	const int tid = threadIdx.x;
@@ -54,6 +56,7 @@ struct MeshArgs {
 	const float* frames; int n_rows, n_cols; int64_t row_pitch, frame_stride;
 	const uint8_t* exclude; int64_t exclude_frame_stride;     // optional manual-exclude image(s), [R][C] per frame (stride 0 = shared)
 	const float* subtract; int64_t subtract_frame_stride;     // optional image(s) [R][C] taken off the values AFTER the masking (the radial component)
+	bool radial_on; RadialSpline radial;                      // ... or the radial component evaluated here from its ring profile (max_knots <= kMaxFusedKnots)
 	float flux_cutoff; int box; int nx, ny;
 	double* mesh; int32_t* nmasked;
 };
@@ -62,9 +65,21 @@ __global__ __launch_bounds__(kMeshThreads) void tp_bkg_mesh_kernel(MeshArgs a)
 {
 	__shared__ __align__(16) float keys[kMeshKeys];
 	__shared__ double red[4];
+	__shared__ double sp[2 * kMaxFusedKnots];
 	const int bx = blockIdx.x, by = blockIdx.y, frame = blockIdx.z;
 	const int tid = threadIdx.x;
 	const int box = a.box, npix = box * box;
+	int rn = 0;
+	double rzp = 0.0;
+	if (a.radial_on) {
+		rn = a.radial.n_knots[frame];
+		rzp = a.radial.zeropoint[frame];
+		for (int i = tid; i < rn; i += kMeshThreads) {
+			sp[i] = a.radial.knots[(int64_t)frame * a.radial.max_knots + i];
+			sp[kMaxFusedKnots + i] = a.radial.coefs[(int64_t)frame * a.radial.max_knots + i];
+		}
+		__syncthreads();
+	}
 	const float inf = __builtin_inff();
 	const float* img = a.frames + (int64_t)frame * a.frame_stride;
 	const uint8_t* excl = a.exclude ? (a.exclude + (int64_t)frame * a.exclude_frame_stride) : nullptr;
@@ -81,6 +96,8 @@ __global__ __launch_bounds__(kMeshThreads) void tp_bkg_mesh_kernel(MeshArgs a)
 				if (excl && excl[(int64_t)r * a.n_cols + c]) ok = false;
 				nvalid += ok ? 1 : 0;
 				if (minus) x = (float)((double)x - (double)minus[(int64_t)r * a.n_cols + c]);   // backgrounds.py:200 (img0 - img_bkg_radial)
+				else if (a.radial_on)   // the same float32 image, evaluated here: (float)(10**s(r) - zeropoint), see tp_radial_evaluate
+					x = (float)((double)x - (double)(float)radial_value(sp, sp + kMaxFusedKnots, rn, rzp, a.radial.col_offset, a.radial.xcen, a.radial.ycen, r, c));
 				x = ok ? x : inf;
 			}
 		}
@@ -182,44 +199,10 @@ __global__ __launch_bounds__(256) void tp_bkg_zoom_kernel(const double* __restri
 	int ny, int nx, int box, int n_rows, int n_cols, int64_t out_row_pitch, int64_t out_frame_stride, float* __restrict__ out)
 {
 	const int frame = blockIdx.z;
-	const double* c = coef + (int64_t)frame * ny * nx;   // [ny][nx]
 	const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
 	if (col >= n_cols || row >= n_rows) return;
-	auto weights = [](double x, double (&w)[4], int& start) {
-		const double fl = floor(x);
-		start = (int)fl - 1;
-		const double y = x - fl, z = 1.0 - y;
-		w[1] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0;
-		w[2] = (z * z * (z - 2.0) * 3.0 + 4.0) / 6.0;
-		w[0] = z * z * z / 6.0;
-		w[3] = 1.0 - w[0] - w[1] - w[2];
-	};
-	// (d c b a | a b c d | d c b a): an index is at most two outside [0, n), so one reflection does unless the mesh has a
-	// single cell along the axis
-	auto reflect = [](int i, int n) {
-		if (n < 2) return 0;
-		i = (i < 0) ? (-i - 1) : i;
-		return (i >= n) ? (2 * n - 1 - i) : i;
-	};
-	double wy[4], wx[4];
-	int sy, sx;
-	weights(((double)row + 0.5) / (double)box - 0.5, wy, sy);
-	weights(((double)col + 0.5) / (double)box - 0.5, wx, sx);
-	int cx[4];
-#pragma unroll
-	for (int i = 0; i < 4; ++i) cx[i] = reflect(sx + i, nx);
-	double acc = 0.0;
-#pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		const double* r = c + reflect(sy + j, ny) * nx;
-		double t = 0.0;
-#pragma unroll
-		for (int i = 0; i < 4; ++i) t += wx[i] * r[cx[i]];
-		acc += wy[j] * t;
-	}
-	const double lo = vmin[frame], hi = vmax[frame];
-	acc = (acc < lo) ? lo : ((acc > hi) ? hi : acc);
-	out[(int64_t)frame * out_frame_stride + (int64_t)row * out_row_pitch + col] = (float)acc;
+	const ZoomImage z{coef, vmin, vmax, ny, nx, box, n_cols};
+	out[(int64_t)frame * out_frame_stride + (int64_t)row * out_row_pitch + col] = zoom_value(z, frame, row, col);
 }
 
 // B2 on images: out[k][p] = nanmean(in[k-w .. k+w][p]), sequential float32 accumulation like bottleneck.nanmean
@@ -484,13 +467,11 @@ extern "C" int tp_frames_used_in_background(tp_ctx* ctx, const uint8_t* d_pixel_
 	TP_API_END(ctx)
 }
 
-extern "C" int tp_background_mesh(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+static int background_mesh_launch(tp_ctx* ctx, const char* who, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
 	int64_t row_pitch, int64_t frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride,
-	const float* d_subtract, int64_t subtract_frame_stride,
+	const float* d_subtract, int64_t subtract_frame_stride, const tp_radial_image* radial,
 	double flux_cutoff, int32_t box_size, double* d_mesh, int32_t* d_nmasked)
 {
-	TP_CHECK_CTX(ctx);
-	TP_API_BEGIN
 	TP_REQUIRE(ctx, d_frames && d_mesh && d_nmasked, "tp_background_mesh: null pointer");
 	TP_REQUIRE(ctx, n_frames >= 0 && frame_rows > 0 && frame_cols > 0 && row_pitch >= frame_cols && frame_stride >= (int64_t)frame_rows * row_pitch, "tp_background_mesh: bad frame geometry");
 	TP_REQUIRE(ctx, box_size >= 1 && box_size * box_size <= kMeshKeys, "tp_background_mesh: box_size must be 1..64");
@@ -499,13 +480,45 @@ extern "C" int tp_background_mesh(tp_ctx* ctx, const float* d_frames, int32_t n_
 	a.frames = d_frames; a.n_rows = frame_rows; a.n_cols = frame_cols; a.row_pitch = row_pitch; a.frame_stride = frame_stride;
 	a.exclude = d_exclude; a.exclude_frame_stride = exclude_frame_stride;
 	a.subtract = d_subtract; a.subtract_frame_stride = subtract_frame_stride;
+	a.radial_on = false;
+	a.radial = RadialSpline{};
+	if (radial) {
+		TP_REQUIRE(ctx, d_subtract == nullptr, "tp_background_mesh_radial: a stored image and a ring profile to subtract");
+		TP_REQUIRE(ctx, radial->d_knots && radial->d_coefs && radial->d_n_knots && radial->d_zeropoint && radial->max_knots >= 8 && radial->max_knots <= kMaxFusedKnots,
+			"tp_background_mesh_radial: bad ring profile (max_knots 8..128)");
+		a.radial_on = true;
+		a.radial = RadialSpline{radial->col_offset, radial->xcen, radial->ycen, radial->d_knots, radial->d_coefs, radial->d_n_knots, radial->max_knots, radial->d_zeropoint};
+	}
 	a.flux_cutoff = (float)flux_cutoff; a.box = box_size;
 	a.nx = (frame_cols + box_size - 1) / box_size; a.ny = (frame_rows + box_size - 1) / box_size;
 	a.mesh = d_mesh; a.nmasked = d_nmasked;
 	TP_REQUIRE(ctx, a.ny <= 65535 && n_frames <= 65535, "tp_background_mesh: too many boxes / frames for one launch");
 	TP_LAUNCH(ctx, TPK_BKG_MESH, tp_bkg_mesh_kernel, dim3((unsigned)a.nx, (unsigned)a.ny, (unsigned)n_frames), dim3(kMeshThreads), 0, a);
-	TP_LAUNCH_CHECK(ctx, "tp_bkg_mesh_kernel");
+	TP_LAUNCH_CHECK(ctx, who);
 	return TP_OK;
+}
+
+extern "C" int tp_background_mesh(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+	int64_t row_pitch, int64_t frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride,
+	const float* d_subtract, int64_t subtract_frame_stride,
+	double flux_cutoff, int32_t box_size, double* d_mesh, int32_t* d_nmasked)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	return background_mesh_launch(ctx, "tp_bkg_mesh_kernel", d_frames, n_frames, frame_rows, frame_cols, row_pitch, frame_stride, d_exclude, exclude_frame_stride,
+		d_subtract, subtract_frame_stride, nullptr, flux_cutoff, box_size, d_mesh, d_nmasked);
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_background_mesh_radial(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+	int64_t row_pitch, int64_t frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride,
+	const tp_radial_image* radial, double flux_cutoff, int32_t box_size, double* d_mesh, int32_t* d_nmasked)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, radial != nullptr, "tp_background_mesh_radial: null ring profile");
+	return background_mesh_launch(ctx, "tp_bkg_mesh_kernel (radial)", d_frames, n_frames, frame_rows, frame_cols, row_pitch, frame_stride, d_exclude, exclude_frame_stride,
+		nullptr, 0, radial, flux_cutoff, box_size, d_mesh, d_nmasked);
 	TP_API_END(ctx)
 }
 

@@ -22,6 +22,7 @@
 // Bound by LDS/latency (18 passes over an L2-resident row, two 2048-point FFTs); a frame has ~40 rings, so the whole
 // component is a few hundred microseconds per frame and iteration next to the 64 x 64 mesh statistics.
 #include "common.h"
+#include "fullframe_dev.h"
 #include <cmath>
 
 namespace {
@@ -32,7 +33,8 @@ constexpr int kKdeLog2 = 11;
 
 struct RadialImage {
 	const float* frames; int64_t frame_stride;
-	const float* square; int64_t square_stride;           // previous iteration's mesh background, or null (first iteration)
+	const float* square; int64_t square_stride;           // previous iteration's mesh background, or null (first iteration) ...
+	bool zoom_on; ZoomImage zoom;                         // ... or the same image evaluated here from the mesh's spline coefficients
 	const uint8_t* exclude; int64_t exclude_stride;       // manual-exclude image(s), stride 0 = shared
 	float flux_cutoff;
 };
@@ -42,7 +44,9 @@ __device__ __forceinline__ bool radial_pixel(const RadialImage& a, int frame, in
 	const float x = a.frames[(int64_t)frame * a.frame_stride + p];
 	bool ok = (x >= 0.f) && (x <= a.flux_cutoff);
 	if (a.exclude && a.exclude[(int64_t)frame * a.exclude_stride + p]) ok = false;
-	value = a.square ? ((double)x - (double)a.square[(int64_t)frame * a.square_stride + p]) : (double)x;
+	if (a.square) value = (double)x - (double)a.square[(int64_t)frame * a.square_stride + p];
+	else if (a.zoom_on) { const int row = (int)(p / a.zoom.n_cols); value = (double)x - (double)zoom_value(a.zoom, frame, row, (int)(p - (int64_t)row * a.zoom.n_cols)); }
+	else value = (double)x;
 	return ok;
 }
 
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(kRadThreads) void tp_radial_ring_kernel(RingArgs a)
 	const int p0 = a.ring_offsets[ring], p1 = a.ring_offsets[ring + 1];
 	double* vals = a.scratch + (int64_t)frame * a.scratch_stride + p0;
 	const double zp = a.zeropoint[frame];
-	const bool single = (a.img.square == nullptr);   // first iteration: float32 arithmetic (numpy: float32 array + scalar, log10 of float32)
+	const bool single = (a.img.square == nullptr) && !a.img.zoom_on;   // first iteration: float32 arithmetic (numpy: float32 array + scalar, log10 of float32)
 	const float zp32 = (float)zp;
 	double* mode_out = a.modes + (int64_t)frame * a.n_rings + ring;
 
@@ -441,10 +445,9 @@ __global__ __launch_bounds__(64) void tp_radial_profile_kernel(const double* __r
 
 struct EvalArgs {
 	int n_rows, n_cols; int64_t frame_stride;
-	double col_offset, xcen, ycen;
-	const double* knots; const double* coefs; const int32_t* n_knots; int max_knots;   // per frame: FITPACK knots t[0..n), coefficients c[0..n-4)
-	const double* zeropoint;
+	RadialSpline sp;
 	const float* add; int64_t add_stride;
+	bool zoom_on; ZoomImage zoom;         // the square component evaluated here instead of read from `add`
 	float* out;
 };
 
@@ -453,38 +456,19 @@ __global__ __launch_bounds__(256) void tp_radial_eval_kernel(EvalArgs a)
 {
 	extern __shared__ double sp[];   // knots, then coefficients
 	const int frame = blockIdx.z, row = blockIdx.y;
-	const int n = a.n_knots[frame];
+	const int n = a.sp.n_knots[frame];
 	for (int i = threadIdx.x; i < n; i += 256) {
-		sp[i] = a.knots[(int64_t)frame * a.max_knots + i];
-		sp[a.max_knots + i] = a.coefs[(int64_t)frame * a.max_knots + i];
+		sp[i] = a.sp.knots[(int64_t)frame * a.sp.max_knots + i];
+		sp[a.sp.max_knots + i] = a.sp.coefs[(int64_t)frame * a.sp.max_knots + i];
 	}
 	__syncthreads();
 	const int col = blockIdx.x * 256 + threadIdx.x;
 	if (col >= a.n_cols) return;
 	const int64_t p = (int64_t)row * a.n_cols + col;
-	double radial = 0.0;
-	if (n >= 8) {
-		const double* t = sp;
-		const double* c = sp + a.max_knots;
-		const double dx = ((double)col + a.col_offset) - a.xcen, dy = (double)row - a.ycen;
-		double x = sqrt(dx * dx + dy * dy);
-		// ext = 3: the boundary value outside [t[3], t[n - 4]]
-		x = fmin(fmax(x, t[3]), t[n - 4]);
-		// interval t[l] <= x < t[l + 1], 3 <= l <= n - 5
-		int l = 3, h = n - 4;
-		while (h - l > 1) { const int m = (l + h) >> 1; if (x >= t[m]) l = m; else h = m; }
-		// de Boor, cubic
-		double d0 = c[l - 3], d1 = c[l - 2], d2 = c[l - 1], d3 = c[l];
-		double al;
-		al = (x - t[l]) / (t[l + 3] - t[l]);         d3 = (1.0 - al) * d2 + al * d3;
-		al = (x - t[l - 1]) / (t[l + 2] - t[l - 1]); d2 = (1.0 - al) * d1 + al * d2;
-		al = (x - t[l - 2]) / (t[l + 1] - t[l - 2]); d1 = (1.0 - al) * d0 + al * d1;
-		al = (x - t[l]) / (t[l + 2] - t[l]);         d3 = (1.0 - al) * d2 + al * d3;
-		al = (x - t[l - 1]) / (t[l + 1] - t[l - 1]); d2 = (1.0 - al) * d1 + al * d2;
-		al = (x - t[l]) / (t[l + 1] - t[l]);         d3 = (1.0 - al) * d2 + al * d3;
-		radial = pow(10.0, d3) - a.zeropoint[frame];
-	}
-	const double base = a.add ? (double)a.add[(int64_t)frame * a.add_stride + p] : 0.0;
+	const double radial = radial_value(sp, sp + a.sp.max_knots, n, a.sp.zeropoint[frame], a.sp.col_offset, a.sp.xcen, a.sp.ycen, row, col);
+	double base = 0.0;
+	if (a.add) base = (double)a.add[(int64_t)frame * a.add_stride + p];
+	else if (a.zoom_on) base = (double)zoom_value(a.zoom, frame, row, col);
 	a.out[(int64_t)frame * a.frame_stride + p] = (float)(radial + base);
 }
 
@@ -494,22 +478,72 @@ static bool radial_image_ok(int32_t n_frames, int64_t n_pixels, int64_t frame_st
 	return n_frames >= 0 && n_frames <= 65535 && n_pixels > 0 && n_pixels <= 0x7fffffff && frame_stride >= n_pixels;
 }
 
+static bool zoom_image_ok(const tp_zoom_image* z) {
+	return z && z->d_coef && z->d_vmin && z->d_vmax && z->mesh_rows > 0 && z->mesh_cols > 0 && z->box_size > 0 && z->frame_cols > 0;
+}
+static ZoomImage zoom_of(const tp_zoom_image* z) {
+	return ZoomImage{z->d_coef, z->d_vmin, z->d_vmax, z->mesh_rows, z->mesh_cols, z->box_size, z->frame_cols};
+}
+
+static int radial_zeropoint_launch(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride,
+	const float* d_square, int64_t square_frame_stride, const tp_zoom_image* zoom, const uint8_t* d_exclude, int64_t exclude_frame_stride, double flux_cutoff,
+	double* d_partial, int32_t n_partial, double* d_zeropoint)
+{
+	TP_REQUIRE(ctx, d_frames && d_partial && d_zeropoint, "tp_radial_zeropoint: null pointer");
+	TP_REQUIRE(ctx, radial_image_ok(n_frames, n_pixels, frame_stride), "tp_radial_zeropoint: bad frame geometry");
+	TP_REQUIRE(ctx, n_partial >= 1 && n_partial <= 65535, "tp_radial_zeropoint: n_partial must be 1..65535");
+	TP_REQUIRE(ctx, zoom == nullptr || (zoom_image_ok(zoom) && d_square == nullptr && n_pixels % zoom->frame_cols == 0), "tp_radial_zeropoint_zoom: bad mesh image");
+	if (n_frames == 0) return TP_OK;
+	RadialImage img{d_frames, frame_stride, d_square, square_frame_stride, zoom != nullptr, zoom ? zoom_of(zoom) : ZoomImage{}, d_exclude, exclude_frame_stride, (float)flux_cutoff};
+	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_min_partial_kernel, dim3((unsigned)n_partial, (unsigned)n_frames), dim3(kRadThreads), 0, img, n_pixels, d_partial);
+	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_min_final_kernel, dim3((unsigned)n_frames), dim3(kRadThreads), 0, d_partial, (int)n_partial, d_zeropoint);
+	TP_LAUNCH_CHECK(ctx, "tp_radial_min kernels");
+	return TP_OK;
+}
+
 extern "C" int tp_radial_zeropoint(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride,
 	const float* d_square, int64_t square_frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride, double flux_cutoff,
 	double* d_partial, int32_t n_partial, double* d_zeropoint)
 {
 	TP_CHECK_CTX(ctx);
 	TP_API_BEGIN
-	TP_REQUIRE(ctx, d_frames && d_partial && d_zeropoint, "tp_radial_zeropoint: null pointer");
-	TP_REQUIRE(ctx, radial_image_ok(n_frames, n_pixels, frame_stride), "tp_radial_zeropoint: bad frame geometry");
-	TP_REQUIRE(ctx, n_partial >= 1 && n_partial <= 65535, "tp_radial_zeropoint: n_partial must be 1..65535");
-	if (n_frames == 0) return TP_OK;
-	RadialImage img{d_frames, frame_stride, d_square, square_frame_stride, d_exclude, exclude_frame_stride, (float)flux_cutoff};
-	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_min_partial_kernel, dim3((unsigned)n_partial, (unsigned)n_frames), dim3(kRadThreads), 0, img, n_pixels, d_partial);
-	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_min_final_kernel, dim3((unsigned)n_frames), dim3(kRadThreads), 0, d_partial, (int)n_partial, d_zeropoint);
-	TP_LAUNCH_CHECK(ctx, "tp_radial_min kernels");
-	return TP_OK;
+	return radial_zeropoint_launch(ctx, d_frames, n_frames, n_pixels, frame_stride, d_square, square_frame_stride, nullptr, d_exclude, exclude_frame_stride,
+		flux_cutoff, d_partial, n_partial, d_zeropoint);
 	TP_API_END(ctx)
+}
+
+extern "C" int tp_radial_zeropoint_zoom(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride,
+	const tp_zoom_image* square, const uint8_t* d_exclude, int64_t exclude_frame_stride, double flux_cutoff,
+	double* d_partial, int32_t n_partial, double* d_zeropoint)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, square != nullptr, "tp_radial_zeropoint_zoom: null mesh image");
+	return radial_zeropoint_launch(ctx, d_frames, n_frames, n_pixels, frame_stride, nullptr, 0, square, d_exclude, exclude_frame_stride,
+		flux_cutoff, d_partial, n_partial, d_zeropoint);
+	TP_API_END(ctx)
+}
+
+static int radial_ring_launch(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride,
+	const float* d_square, int64_t square_frame_stride, const tp_zoom_image* zoom, const uint8_t* d_exclude, int64_t exclude_frame_stride, double flux_cutoff,
+	const double* d_zeropoint, const int32_t* d_ring_pixels, const int32_t* d_ring_offsets, int32_t n_rings, int32_t n_ring_pixels,
+	double bandwidth_constant, double* d_scratch, double* d_modes, int32_t* d_counts)
+{
+	TP_REQUIRE(ctx, d_frames && d_zeropoint && d_ring_pixels && d_ring_offsets && d_scratch && d_modes, "tp_radial_ring_modes: null pointer");
+	TP_REQUIRE(ctx, radial_image_ok(n_frames, n_pixels, frame_stride), "tp_radial_ring_modes: bad frame geometry");
+	TP_REQUIRE(ctx, n_rings >= 0 && n_rings <= 65535 && n_ring_pixels >= 0, "tp_radial_ring_modes: bad ring list");
+	TP_REQUIRE(ctx, zoom == nullptr || (zoom_image_ok(zoom) && d_square == nullptr && n_pixels % zoom->frame_cols == 0), "tp_radial_ring_modes_zoom: bad mesh image");
+	if (n_frames == 0 || n_rings == 0) return TP_OK;
+	RingArgs a;
+	a.img = RadialImage{d_frames, frame_stride, d_square, square_frame_stride, zoom != nullptr, zoom ? zoom_of(zoom) : ZoomImage{}, d_exclude, exclude_frame_stride, (float)flux_cutoff};
+	a.zeropoint = d_zeropoint;
+	a.ring_pixels = d_ring_pixels; a.ring_offsets = d_ring_offsets; a.n_rings = n_rings;
+	a.scratch = d_scratch; a.scratch_stride = n_ring_pixels;
+	a.bw_constant = bandwidth_constant;
+	a.modes = d_modes; a.counts = d_counts;
+	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_ring_kernel, dim3((unsigned)n_rings, (unsigned)n_frames), dim3(kRadThreads), 0, a);
+	TP_LAUNCH_CHECK(ctx, "tp_radial_ring_kernel");
+	return TP_OK;
 }
 
 extern "C" int tp_radial_ring_modes(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride,
@@ -519,21 +553,44 @@ extern "C" int tp_radial_ring_modes(tp_ctx* ctx, const float* d_frames, int32_t 
 {
 	TP_CHECK_CTX(ctx);
 	TP_API_BEGIN
-	TP_REQUIRE(ctx, d_frames && d_zeropoint && d_ring_pixels && d_ring_offsets && d_scratch && d_modes, "tp_radial_ring_modes: null pointer");
-	TP_REQUIRE(ctx, radial_image_ok(n_frames, n_pixels, frame_stride), "tp_radial_ring_modes: bad frame geometry");
-	TP_REQUIRE(ctx, n_rings >= 0 && n_rings <= 65535 && n_ring_pixels >= 0, "tp_radial_ring_modes: bad ring list");
-	if (n_frames == 0 || n_rings == 0) return TP_OK;
-	RingArgs a;
-	a.img = RadialImage{d_frames, frame_stride, d_square, square_frame_stride, d_exclude, exclude_frame_stride, (float)flux_cutoff};
-	a.zeropoint = d_zeropoint;
-	a.ring_pixels = d_ring_pixels; a.ring_offsets = d_ring_offsets; a.n_rings = n_rings;
-	a.scratch = d_scratch; a.scratch_stride = n_ring_pixels;
-	a.bw_constant = bandwidth_constant;
-	a.modes = d_modes; a.counts = d_counts;
-	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_ring_kernel, dim3((unsigned)n_rings, (unsigned)n_frames), dim3(kRadThreads), 0, a);
-	TP_LAUNCH_CHECK(ctx, "tp_radial_ring_kernel");
-	return TP_OK;
+	return radial_ring_launch(ctx, d_frames, n_frames, n_pixels, frame_stride, d_square, square_frame_stride, nullptr, d_exclude, exclude_frame_stride, flux_cutoff,
+		d_zeropoint, d_ring_pixels, d_ring_offsets, n_rings, n_ring_pixels, bandwidth_constant, d_scratch, d_modes, d_counts);
 	TP_API_END(ctx)
+}
+
+extern "C" int tp_radial_ring_modes_zoom(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride,
+	const tp_zoom_image* square, const uint8_t* d_exclude, int64_t exclude_frame_stride, double flux_cutoff,
+	const double* d_zeropoint, const int32_t* d_ring_pixels, const int32_t* d_ring_offsets, int32_t n_rings, int32_t n_ring_pixels,
+	double bandwidth_constant, double* d_scratch, double* d_modes, int32_t* d_counts)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, square != nullptr, "tp_radial_ring_modes_zoom: null mesh image");
+	return radial_ring_launch(ctx, d_frames, n_frames, n_pixels, frame_stride, nullptr, 0, square, d_exclude, exclude_frame_stride, flux_cutoff,
+		d_zeropoint, d_ring_pixels, d_ring_offsets, n_rings, n_ring_pixels, bandwidth_constant, d_scratch, d_modes, d_counts);
+	TP_API_END(ctx)
+}
+
+static int radial_evaluate_launch(tp_ctx* ctx, int32_t n_frames, int32_t frame_rows, int32_t frame_cols, int64_t frame_stride,
+	double col_offset, double xcen, double ycen, const double* d_knots, const double* d_coefs, const int32_t* d_n_knots, int32_t max_knots,
+	const double* d_zeropoint, const float* d_add, int64_t add_frame_stride, const tp_zoom_image* zoom, float* d_out)
+{
+	TP_REQUIRE(ctx, d_knots && d_coefs && d_n_knots && d_zeropoint && d_out, "tp_radial_evaluate: null pointer");
+	TP_REQUIRE(ctx, n_frames >= 0 && n_frames <= 65535 && frame_rows > 0 && frame_rows <= 65535 && frame_cols > 0
+		&& frame_stride >= (int64_t)frame_rows * frame_cols, "tp_radial_evaluate: bad frame geometry");
+	TP_REQUIRE(ctx, max_knots >= 8 && max_knots <= 2048, "tp_radial_evaluate: max_knots must be 8..2048");
+	TP_REQUIRE(ctx, zoom == nullptr || (zoom_image_ok(zoom) && d_add == nullptr && zoom->frame_cols == frame_cols), "tp_radial_evaluate_zoom: bad mesh image");
+	if (n_frames == 0) return TP_OK;
+	EvalArgs a;
+	a.n_rows = frame_rows; a.n_cols = frame_cols; a.frame_stride = frame_stride;
+	a.sp = RadialSpline{col_offset, xcen, ycen, d_knots, d_coefs, d_n_knots, max_knots, d_zeropoint};
+	a.add = d_add; a.add_stride = add_frame_stride;
+	a.zoom_on = zoom != nullptr; a.zoom = zoom ? zoom_of(zoom) : ZoomImage{};
+	a.out = d_out;
+	dim3 grid((unsigned)((frame_cols + 255) / 256), (unsigned)frame_rows, (unsigned)n_frames);
+	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_eval_kernel, grid, dim3(256), (size_t)max_knots * 2 * sizeof(double), a);
+	TP_LAUNCH_CHECK(ctx, "tp_radial_eval_kernel");
+	return TP_OK;
 }
 
 extern "C" int tp_radial_evaluate(tp_ctx* ctx, int32_t n_frames, int32_t frame_rows, int32_t frame_cols, int64_t frame_stride,
@@ -542,20 +599,19 @@ extern "C" int tp_radial_evaluate(tp_ctx* ctx, int32_t n_frames, int32_t frame_r
 {
 	TP_CHECK_CTX(ctx);
 	TP_API_BEGIN
-	TP_REQUIRE(ctx, d_knots && d_coefs && d_n_knots && d_zeropoint && d_out, "tp_radial_evaluate: null pointer");
-	TP_REQUIRE(ctx, n_frames >= 0 && n_frames <= 65535 && frame_rows > 0 && frame_rows <= 65535 && frame_cols > 0
-		&& frame_stride >= (int64_t)frame_rows * frame_cols, "tp_radial_evaluate: bad frame geometry");
-	TP_REQUIRE(ctx, max_knots >= 8 && max_knots <= 2048, "tp_radial_evaluate: max_knots must be 8..2048");
-	if (n_frames == 0) return TP_OK;
-	EvalArgs a;
-	a.n_rows = frame_rows; a.n_cols = frame_cols; a.frame_stride = frame_stride;
-	a.col_offset = col_offset; a.xcen = xcen; a.ycen = ycen;
-	a.knots = d_knots; a.coefs = d_coefs; a.n_knots = d_n_knots; a.max_knots = max_knots;
-	a.zeropoint = d_zeropoint; a.add = d_add; a.add_stride = add_frame_stride; a.out = d_out;
-	dim3 grid((unsigned)((frame_cols + 255) / 256), (unsigned)frame_rows, (unsigned)n_frames);
-	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_eval_kernel, grid, dim3(256), (size_t)max_knots * 2 * sizeof(double), a);
-	TP_LAUNCH_CHECK(ctx, "tp_radial_eval_kernel");
-	return TP_OK;
+	return radial_evaluate_launch(ctx, n_frames, frame_rows, frame_cols, frame_stride, col_offset, xcen, ycen, d_knots, d_coefs, d_n_knots, max_knots,
+		d_zeropoint, d_add, add_frame_stride, nullptr, d_out);
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_radial_evaluate_zoom(tp_ctx* ctx, int32_t n_frames, int32_t frame_rows, int32_t frame_cols, int64_t frame_stride,
+	const tp_radial_image* radial, const tp_zoom_image* add, float* d_out)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, radial != nullptr && add != nullptr, "tp_radial_evaluate_zoom: null ring profile / mesh image");
+	return radial_evaluate_launch(ctx, n_frames, frame_rows, frame_cols, frame_stride, radial->col_offset, radial->xcen, radial->ycen,
+		radial->d_knots, radial->d_coefs, radial->d_n_knots, radial->max_knots, radial->d_zeropoint, nullptr, 0, add, d_out);
 	TP_API_END(ctx)
 }
 

@@ -19,6 +19,7 @@ import logging
 import warnings
 import numpy as np
 from scipy.interpolate import InterpolatedUnivariateSpline
+from . import _lib
 from .engine import TESS_DEFAULT_BITMASK
 
 #: PixelQualityFlags (photometry/quality.py:157-166)
@@ -154,13 +155,17 @@ def radial_profiles(s2, bin_center, radial_smooth=3, max_knots=None):
 	return knots, coefs, n_knots
 
 
-def _square_component(ctx, frames, flux_cutoff, box, exclude, estride, subtract, out, want_host=False, work=None):
+def _square_component(ctx, frames, flux_cutoff, box, exclude, estride, subtract, out, want_host=False, work=None, radial_spec=None):
 	"""
 	Background2D of ``frames - subtract`` (backgrounds.py:199-206), everything on the device: per-cell statistics
 	(``tp_background_mesh``), the low-resolution finishing -- excluded cells filled, 3 x 3 median filter, spline prefilter
 	(``tp_background_mesh_finish``) -- and the cubic-spline zoom (``tp_background_zoom``); no host round trip.  ``want_host``:
 	also return the host copies of the cell statistics and masked-pixel counts.  ``work``: dict that keeps the small device
 	arrays between calls of one ``fit_background_frames``.
+
+	``radial_spec`` (a ``tp_radial_image``) in place of ``subtract``: the radial component is evaluated inside the mesh kernel from
+	its ring profile instead of read from a stored image; ``out`` None: the zoomed mesh is not written (the caller evaluates it
+	where it needs it from ``work['coef' / 'vmin' / 'vmax']``: ``zoom_image``).
 	"""
 	T, R, C = frames.shape
 	ny, nx = -(-R // box), -(-C // box)
@@ -169,19 +174,24 @@ def _square_component(ctx, frames, flux_cutoff, box, exclude, estride, subtract,
 		work.update(mesh=ctx.empty((T, ny, nx), 'float64'), nmasked=ctx.empty((T, ny, nx), 'int32'), coef=ctx.empty((T, ny, nx), 'float64'),
 			vmin=ctx.empty((T,), 'float64'), vmax=ctx.empty((T,), 'float64'))
 	mesh, nmasked, coef, vmin, vmax = (work[k] for k in ('mesh', 'nmasked', 'coef', 'vmin', 'vmax'))
-	ctx._check(ctx.lib.tp_background_mesh(ctx.handle, frames.ptr, T, R, C, C, R * C, None if exclude is None else exclude.ptr, estride,
-		None if subtract is None else subtract.ptr, R * C, float(flux_cutoff), int(box), mesh.ptr, nmasked.ptr))
 	if ny * nx > 2048:
 		raise ValueError(f'fit_background_frames: a {R} x {C} frame has {ny} x {nx} cells of {box} pixels; the device finishes meshes of at most 2048 cells')
+	if radial_spec is not None:
+		ctx._check(ctx.lib.tp_background_mesh_radial(ctx.handle, frames.ptr, T, R, C, C, R * C, None if exclude is None else exclude.ptr, estride,
+			ctypes.byref(radial_spec), float(flux_cutoff), int(box), mesh.ptr, nmasked.ptr))
+	else:
+		ctx._check(ctx.lib.tp_background_mesh(ctx.handle, frames.ptr, T, R, C, C, R * C, None if exclude is None else exclude.ptr, estride,
+			None if subtract is None else subtract.ptr, R * C, float(flux_cutoff), int(box), mesh.ptr, nmasked.ptr))
 	ctx._check(ctx.lib.tp_background_mesh_finish(ctx.handle, mesh.ptr, nmasked.ptr, T, ny, nx, int(box), 50.0, 3, coef.ptr, vmin.ptr, vmax.ptr, None))
-	ctx._check(ctx.lib.tp_background_zoom(ctx.handle, coef.ptr, vmin.ptr, vmax.ptr, T, ny, nx, int(box), R, C, C, R * C, out.ptr))
+	if out is not None:
+		ctx._check(ctx.lib.tp_background_zoom(ctx.handle, coef.ptr, vmin.ptr, vmax.ptr, T, ny, nx, int(box), R, C, C, R * C, out.ptr))
 	if want_host:
 		return mesh.to_host(), nmasked.to_host()
 	return None, None
 
 
 def fit_background_frames(ctx, frames, flux_cutoff=8e4, box=64, exclude=None, out=None, return_mask=False,
-	camera=None, ccd=None, bkgiters=3, radial_cutoff=2400, radial_pixel_step=15, radial_smooth=3, geometry=None, details=None):
+	camera=None, ccd=None, bkgiters=3, radial_cutoff=2400, radial_pixel_step=15, radial_smooth=3, geometry=None, details=None, implicit=True):
 	"""
 	``fit_background`` (backgrounds.py:52-211) for every frame of a stack.
 
@@ -194,6 +204,13 @@ def fit_background_frames(ctx, frames, flux_cutoff=8e4, box=64, exclude=None, ou
 	full-frame images and the radial component is fitted as well, ``bkgiters`` times alternating with the mesh (:162-206); a
 	``RadialGeometry`` can be passed in ``geometry`` to reuse it between calls.  ``details``: optional dict that receives the
 	ring modes, zero points and spline arrays of every round (host arrays).
+
+	``implicit`` (default): inside the alternation neither the radial nor the square component is ever stored as an image -- the
+	mesh kernel evaluates the radial component from its ring profile, the zero-point and ring passes evaluate the zoomed mesh from
+	its spline coefficients, the last pass writes the total: per iteration the frame is read by the zero-point pass, the ring
+	pass (a tenth of it) and the mesh pass, and nothing the size of a frame is written (round 4: 304 MB of traffic per 2048 x
+	2048 frame, now the three reads per iteration and one write).  ``implicit=False`` stores both images like round 4 (bit-identical;
+	kept for the test that says so).
 	"""
 	T, R, C = frames.shape
 	estride = 0 if exclude is None or len(exclude.shape) == 2 else R * C
@@ -214,8 +231,7 @@ def fit_background_frames(ctx, frames, flux_cutoff=8e4, box=64, exclude=None, ou
 	d_scratch = ctx.empty((T, max(n_ring_pixels, 1)), 'float64')
 	d_modes = ctx.empty((T, geo.n_rings), 'float64')
 	d_counts = ctx.empty((T, geo.n_rings), 'int32')
-	radial = ctx.empty((T, R, C), 'float32')
-	square = None
+	radial = square = None
 	# kernels.Gaussian().normal_reference_constant of statsmodels (order 2, L2 norm 1 / (2 sqrt(pi)), unit variance)
 	bw_constant = np.pi**0.5 * 2.0**3 * (1.0 / (2.0 * np.sqrt(np.pi)))
 	bw_constant /= (2 * 2 * 24.0 * 1.0**2)
@@ -225,15 +241,26 @@ def fit_background_frames(ctx, frames, flux_cutoff=8e4, box=64, exclude=None, ou
 	# kernel (<= 64 rings: a 2048 x 2048 CCD has 39); otherwise on the host with the reference's own scipy call
 	on_device = geo.n_rings <= 64 and (radial_smooth or 0) <= 8
 	K = max(geo.n_rings + 4, 8)
+	implicit = bool(implicit) and K <= 128
 	d_bin_center = ctx.array(np.asarray(geo.bin_center, dtype='float64'))
 	d_knots, d_coefs, d_nk = ctx.zeros((T, K), 'float64'), ctx.zeros((T, K), 'float64'), ctx.zeros((T,), 'int32')
+	ny, nx = -(-R // box), -(-C // box)
+	radial_spec = _lib.tp_radial_image(float(TESS_SCIENCE_COLUMN), float(geo.xcen), float(geo.ycen), d_knots.ptr, d_coefs.ptr, d_nk.ptr, d_zp.ptr, K, 0)
+	zoom_spec = None
 	mesh_h = nm_h = None
 	for it in range(int(bkgiters)):
-		sq_ptr = None if square is None else square.ptr
-		ctx._check(ctx.lib.tp_radial_zeropoint(ctx.handle, frames.ptr, T, R * C, R * C, sq_ptr, R * C, ex_ptr, estride, float(flux_cutoff),
-			d_partial.ptr, n_partial, d_zp.ptr))
-		ctx._check(ctx.lib.tp_radial_ring_modes(ctx.handle, frames.ptr, T, R * C, R * C, sq_ptr, R * C, ex_ptr, estride, float(flux_cutoff),
-			d_zp.ptr, d_pixels.ptr, d_offsets.ptr, geo.n_rings, n_ring_pixels, float(bw_constant), d_scratch.ptr, d_modes.ptr, d_counts.ptr))
+		last = it == int(bkgiters) - 1
+		if implicit and zoom_spec is not None:
+			ctx._check(ctx.lib.tp_radial_zeropoint_zoom(ctx.handle, frames.ptr, T, R * C, R * C, ctypes.byref(zoom_spec), ex_ptr, estride, float(flux_cutoff),
+				d_partial.ptr, n_partial, d_zp.ptr))
+			ctx._check(ctx.lib.tp_radial_ring_modes_zoom(ctx.handle, frames.ptr, T, R * C, R * C, ctypes.byref(zoom_spec), ex_ptr, estride, float(flux_cutoff),
+				d_zp.ptr, d_pixels.ptr, d_offsets.ptr, geo.n_rings, n_ring_pixels, float(bw_constant), d_scratch.ptr, d_modes.ptr, d_counts.ptr))
+		else:
+			sq_ptr = None if square is None else square.ptr
+			ctx._check(ctx.lib.tp_radial_zeropoint(ctx.handle, frames.ptr, T, R * C, R * C, sq_ptr, R * C, ex_ptr, estride, float(flux_cutoff),
+				d_partial.ptr, n_partial, d_zp.ptr))
+			ctx._check(ctx.lib.tp_radial_ring_modes(ctx.handle, frames.ptr, T, R * C, R * C, sq_ptr, R * C, ex_ptr, estride, float(flux_cutoff),
+				d_zp.ptr, d_pixels.ptr, d_offsets.ptr, geo.n_rings, n_ring_pixels, float(bw_constant), d_scratch.ptr, d_modes.ptr, d_counts.ptr))
 		if on_device:
 			ctx._check(ctx.lib.tp_radial_profiles(ctx.handle, T, geo.n_rings, d_modes.ptr, d_bin_center.ptr, int(radial_smooth or 0), K,
 				d_knots.ptr, d_coefs.ptr, d_nk.ptr))
@@ -241,20 +268,29 @@ def fit_background_frames(ctx, frames, flux_cutoff=8e4, box=64, exclude=None, ou
 			knots, coefs, n_knots = radial_profiles(d_modes.to_host(), geo.bin_center, radial_smooth, max_knots=K)
 			for dst, src in ((d_knots, knots), (d_coefs, coefs), (d_nk, n_knots)):
 				ctx._check(ctx.lib.tp_memcpy_h2d(ctx.handle, dst.ptr, src.ctypes.data, src.nbytes))
-		ctx._check(ctx.lib.tp_radial_evaluate(ctx.handle, T, R, C, R * C, float(TESS_SCIENCE_COLUMN), float(geo.xcen), float(geo.ycen),
-			d_knots.ptr, d_coefs.ptr, d_nk.ptr, K, d_zp.ptr, None, 0, radial.ptr))
-		if square is None:
-			square = ctx.empty((T, R, C), 'float32')
-		last = it == int(bkgiters) - 1
-		mesh_h, nm_h = _square_component(ctx, frames, flux_cutoff, box, exclude, estride, radial, square, want_host=return_mask and last, work=work)
+		if implicit:
+			mesh_h, nm_h = _square_component(ctx, frames, flux_cutoff, box, exclude, estride, None, None, want_host=return_mask and last, work=work,
+				radial_spec=radial_spec)
+			zoom_spec = _lib.tp_zoom_image(work['coef'].ptr, work['vmin'].ptr, work['vmax'].ptr, ny, nx, int(box), C)
+		else:
+			if radial is None:
+				radial = ctx.empty((T, R, C), 'float32')
+			ctx._check(ctx.lib.tp_radial_evaluate(ctx.handle, T, R, C, R * C, float(TESS_SCIENCE_COLUMN), float(geo.xcen), float(geo.ycen),
+				d_knots.ptr, d_coefs.ptr, d_nk.ptr, K, d_zp.ptr, None, 0, radial.ptr))
+			if square is None:
+				square = ctx.empty((T, R, C), 'float32')
+			mesh_h, nm_h = _square_component(ctx, frames, flux_cutoff, box, exclude, estride, radial, square, want_host=return_mask and last, work=work)
 		if details is not None:
 			details.setdefault('s2', []).append(d_modes.to_host())
 			details.setdefault('zeropoint', []).append(d_zp.to_host())
 			details.setdefault('n_knots', []).append(d_nk.to_host())
 			details.setdefault('counts', []).append(d_counts.to_host())
 	# total background (:209); a frame in which everything is masked is NaN (:99-102)
-	ctx._check(ctx.lib.tp_radial_evaluate(ctx.handle, T, R, C, R * C, float(TESS_SCIENCE_COLUMN), float(geo.xcen), float(geo.ycen),
-		d_knots.ptr, d_coefs.ptr, d_nk.ptr, K, d_zp.ptr, square.ptr, R * C, out.ptr))
+	if implicit:
+		ctx._check(ctx.lib.tp_radial_evaluate_zoom(ctx.handle, T, R, C, R * C, ctypes.byref(radial_spec), ctypes.byref(zoom_spec), out.ptr))
+	else:
+		ctx._check(ctx.lib.tp_radial_evaluate(ctx.handle, T, R, C, R * C, float(TESS_SCIENCE_COLUMN), float(geo.xcen), float(geo.ycen),
+			d_knots.ptr, d_coefs.ptr, d_nk.ptr, K, d_zp.ptr, square.ptr, R * C, out.ptr))
 	ctx.sync()
 	return (out, mesh_h, nm_h) if return_mask else out
 

@@ -411,6 +411,30 @@ def test_prepare_pixel_flags_and_headers(ctx):
 	np.testing.assert_array_equal(res_h['backgrounds'].to_host(), smooth)
 
 
+def test_tess_branch_implicit_images_equal_stored_images(ctx):
+	"""fit_background's TESS branch with the radial and the square component evaluated where they are read (tp_background_mesh_radial,
+	tp_radial_zeropoint_zoom, tp_radial_ring_modes_zoom, tp_radial_evaluate_zoom: the default) against the same alternation with both
+	images stored and re-read (round 4): ring modes, zero points, knots and the background bit for bit -- frames with a manual
+	exclusion, a frame that is no multiple of the box size, a frame without a radial component."""
+	from photometry_amd import prepare
+	for (T, R, C, cam, ccd, excl) in ((2, 512, 512, 1, 1, False), (2, 300, 421, 1, 1, True), (1, 2048, 2048, 3, 2, False)):
+		f = _tess_frames(T, R, C, seed=R + C)
+		exclude = None
+		if excl:
+			ex = np.zeros((T, R, C), dtype='uint8')
+			ex[:, :, C - 37:] = 1
+			ex[1, 100:140, 50:90] = 1
+			exclude = ctx.array(ex)
+		d_f = ctx.array(f)
+		da, db = {}, {}
+		a = prepare.fit_background_frames(ctx, d_f, camera=cam, ccd=ccd, exclude=exclude, details=da, implicit=True).to_host()
+		b = prepare.fit_background_frames(ctx, d_f, camera=cam, ccd=ccd, exclude=exclude, details=db, implicit=False).to_host()
+		for key in ('s2', 'zeropoint', 'n_knots', 'counts'):
+			for it in range(3):
+				np.testing.assert_array_equal(da[key][it], db[key][it], err_msg=f'{key} round {it} of a {R} x {C} frame')
+		np.testing.assert_array_equal(a, b)
+		assert np.isfinite(a).all()
+
 def test_mesh_path_hand_cases_on_device(ctx):
 	"""The hand-derived cases of tests/test_oracle_pins.py (photutils Background2D after the cell statistics) through the device
 	entries: tp_background_mesh_finish (IDW fill of a rejected cell from its ten nearest kept cells, 2048 / 2049 masked pixels,
