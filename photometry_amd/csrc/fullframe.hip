@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kMeshThreads) void tp_bkg_mesh_kernel(MeshArgs a)
 {
 	__shared__ __align__(16) float keys[kMeshKeys];
 	__shared__ double red[4];
-	__shared__ double sp[2 * kMaxFusedKnots];
+	__shared__ double sp[kRadialStageDoubles(kMaxFusedKnots)];
 	const int bx = blockIdx.x, by = blockIdx.y, frame = blockIdx.z;
 	const int tid = threadIdx.x;
 	const int box = a.box, npix = box * box;
@@ -74,11 +74,7 @@ __global__ __launch_bounds__(kMeshThreads) void tp_bkg_mesh_kernel(MeshArgs a)
 	if (a.radial_on) {
 		rn = a.radial.n_knots[frame];
 		rzp = a.radial.zeropoint[frame];
-		for (int i = tid; i < rn; i += kMeshThreads) {
-			sp[i] = a.radial.knots[(int64_t)frame * a.radial.max_knots + i];
-			sp[kMaxFusedKnots + i] = a.radial.coefs[(int64_t)frame * a.radial.max_knots + i];
-		}
-		__syncthreads();
+		stage_radial(sp, kMaxFusedKnots, a.radial, frame, rn, tid, kMeshThreads);
 	}
 	const float inf = __builtin_inff();
 	const float* img = a.frames + (int64_t)frame * a.frame_stride;
@@ -97,7 +93,7 @@ __global__ __launch_bounds__(kMeshThreads) void tp_bkg_mesh_kernel(MeshArgs a)
 				nvalid += ok ? 1 : 0;
 				if (minus) x = (float)((double)x - (double)minus[(int64_t)r * a.n_cols + c]);   // backgrounds.py:200 (img0 - img_bkg_radial)
 				else if (a.radial_on)   // the same float32 image, evaluated here: (float)(10**s(r) - zeropoint), see tp_radial_evaluate
-					x = (float)((double)x - (double)(float)radial_value(sp, sp + kMaxFusedKnots, rn, rzp, a.radial.col_offset, a.radial.xcen, a.radial.ycen, r, c));
+					x = (float)((double)x - (double)(float)radial_value(sp, kMaxFusedKnots, rn, rzp, a.radial.col_offset, a.radial.xcen, a.radial.ycen, r, c));
 				x = ok ? x : inf;
 			}
 		}
@@ -195,14 +191,26 @@ __global__ __launch_bounds__(kMeshThreads) void tp_bkg_mesh_kernel(MeshArgs a)
 // straight from memory: the 64 pixels of a mesh cell along a row share them (one broadcast line), and a row segment of 256 pixels
 // touches 4 x 8 of them -- staging the whole mesh in LDS per workgroup (first version) moved 8 KB and a barrier per 256 pixels
 // and, with two integer modulo reflections per index, took 0.10 ms per 2048 x 2048 frame.
+constexpr int kZoomRows = 16;
 __global__ __launch_bounds__(256) void tp_bkg_zoom_kernel(const double* __restrict__ coef, const double* __restrict__ vmin, const double* __restrict__ vmax,
 	int ny, int nx, int box, int n_rows, int n_cols, int64_t out_row_pitch, int64_t out_frame_stride, float* __restrict__ out)
 {
 	const int frame = blockIdx.z;
-	const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
-	if (col >= n_cols || row >= n_rows) return;
+	const int col = blockIdx.x * blockDim.x + threadIdx.x;
+	if (col >= n_cols) return;
+	// a thread walks down its column of a strip of kZoomRows rows: column weights once, row sums once per mesh cell
 	const ZoomImage z{coef, vmin, vmax, ny, nx, box, n_cols};
-	out[(int64_t)frame * out_frame_stride + (int64_t)row * out_row_pitch + col] = zoom_value(z, frame, row, col);
+	const int r0 = blockIdx.y * kZoomRows, r1 = (r0 + kZoomRows < n_rows) ? (r0 + kZoomRows) : n_rows;
+	ZoomAxis ax, ay;
+	zoom_axis(col, box, nx, ax);
+	const double lo = vmin[frame], hi = vmax[frame];
+	double T[4];
+	int have = -0x7fffffff;
+	for (int row = r0; row < r1; ++row) {
+		zoom_axis(row, box, ny, ay);
+		if (ay.start != have) { zoom_sums(z, frame, ay, ax, T); have = ay.start; }
+		out[(int64_t)frame * out_frame_stride + (int64_t)row * out_row_pitch + col] = zoom_from_sums(ay, T, lo, hi);
+	}
 }
 
 // B2 on images: out[k][p] = nanmean(in[k-w .. k+w][p]), sequential float32 accumulation like bottleneck.nanmean
@@ -329,11 +337,26 @@ __global__ __launch_bounds__(256) void tp_mesh_finish_kernel(const double* __res
 	const double* m = mesh + (int64_t)frame * nc;
 	const int32_t* nm = nmasked + (int64_t)frame * nc;
 	for (int i = tid; i < nc; i += 256) a[i] = m[i];
-	if (tid == 0) {
-		// the kept cells in row-major order (np.nonzero)
-		int k = 0;
-		for (int i = 0; i < nc; ++i) { const double v = m[i]; if ((double)nm[i] <= max_masked && v - v == 0.0) kept[k++] = (unsigned short)i; }
-		n_kept = k;
+	{
+		// the kept cells in row-major order (np.nonzero): an ordered compaction, 256 cells per step (ballot / popcount inside a
+		// wavefront, four counts across them) -- one thread walking the cells was most of this kernel's time
+		__shared__ int wcount[4];
+		const int lane = tid & 63, wave = tid >> 6;
+		int base = 0;
+		for (int i0 = 0; i0 < nc; i0 += 256) {
+			const int i = i0 + tid;
+			bool keep = false;
+			if (i < nc) { const double v = m[i]; keep = ((double)nm[i] <= max_masked) && (v - v == 0.0); }
+			const unsigned long long bal = __ballot(keep);
+			if (lane == 0) wcount[wave] = __popcll(bal);
+			__syncthreads();
+			int before = 0, total = 0;
+			for (int w = 0; w < 4; ++w) { if (w < wave) before += wcount[w]; total += wcount[w]; }
+			if (keep) kept[base + before + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)i;
+			base += total;
+			__syncthreads();
+		}
+		if (tid == 0) n_kept = base;
 	}
 	__syncthreads();
 	const int nk = n_kept;
@@ -549,7 +572,7 @@ extern "C" int tp_background_zoom(tp_ctx* ctx, const double* d_coef, const doubl
 	TP_REQUIRE(ctx, mesh_rows > 0 && mesh_cols > 0 && box_size > 0 && frame_rows > 0 && frame_cols > 0 && row_pitch >= frame_cols, "tp_background_zoom: bad geometry");
 	TP_REQUIRE(ctx, frame_rows <= 65535 && n_frames <= 65535, "tp_background_zoom: too many rows / frames for one launch");
 	if (n_frames == 0) return TP_OK;
-	dim3 grid((unsigned)((frame_cols + 255) / 256), (unsigned)frame_rows, (unsigned)n_frames);
+	dim3 grid((unsigned)((frame_cols + 255) / 256), (unsigned)((frame_rows + kZoomRows - 1) / kZoomRows), (unsigned)n_frames);
 	TP_LAUNCH(ctx, TPK_BKG_ZOOM, tp_bkg_zoom_kernel, grid, dim3(256), 0, d_coef, d_vmin, d_vmax,
 		(int)mesh_rows, (int)mesh_cols, (int)box_size, (int)frame_rows, (int)frame_cols, row_pitch, frame_stride, d_background);
 	TP_LAUNCH_CHECK(ctx, "tp_bkg_zoom_kernel");

@@ -45,7 +45,8 @@ __device__ __forceinline__ bool radial_pixel(const RadialImage& a, int frame, in
 	bool ok = (x >= 0.f) && (x <= a.flux_cutoff);
 	if (a.exclude && a.exclude[(int64_t)frame * a.exclude_stride + p]) ok = false;
 	if (a.square) value = (double)x - (double)a.square[(int64_t)frame * a.square_stride + p];
-	else if (a.zoom_on) { const int row = (int)(p / a.zoom.n_cols); value = (double)x - (double)zoom_value(a.zoom, frame, row, (int)(p - (int64_t)row * a.zoom.n_cols)); }
+	else if (a.zoom_on) { const uint32_t q = (uint32_t)p, row = q / (uint32_t)a.zoom.n_cols;   // (pixel indices fit 31 bits: radial_image_ok)
+		value = (double)x - (double)zoom_value(a.zoom, frame, (int)row, (int)(q - row * (uint32_t)a.zoom.n_cols)); }
 	else value = (double)x;
 	return ok;
 }
@@ -91,6 +92,37 @@ __global__ __launch_bounds__(kRadThreads) void tp_radial_min_partial_kernel(Radi
 	if (threadIdx.x == 0) partial[(int64_t)frame * gridDim.x + blockIdx.x] = mn;
 }
 
+// The same with the square component evaluated from the mesh's spline coefficients: a thread walks down one column of a band of
+// rows, so that the column's weights are formed once and the row sums of the coefficients once per mesh cell (zoom_sums).
+// grid (column blocks, row bands, frames); partial [frame][gridDim.x * gridDim.y]
+__global__ __launch_bounds__(kRadThreads) void tp_radial_min_zoom_kernel(RadialImage a, int n_rows, int n_cols, int rows_per_band, double* __restrict__ partial)
+{
+	__shared__ double red[4];
+	const int frame = blockIdx.z;
+	const int col = blockIdx.x * kRadThreads + threadIdx.x;
+	const int r0 = blockIdx.y * rows_per_band, r1 = (r0 + rows_per_band < n_rows) ? (r0 + rows_per_band) : n_rows;
+	double mn = __builtin_inf();
+	if (col < n_cols) {
+		ZoomAxis ax, ay;
+		zoom_axis(col, a.zoom.box, a.zoom.nx, ax);
+		const double lo = a.zoom.vmin[frame], hi = a.zoom.vmax[frame];
+		double T[4];
+		int have = -0x7fffffff;
+		for (int r = r0; r < r1; ++r) {
+			const int64_t p = (int64_t)r * n_cols + col;
+			const float x = a.frames[(int64_t)frame * a.frame_stride + p];
+			bool ok = (x >= 0.f) && (x <= a.flux_cutoff);
+			if (a.exclude && a.exclude[(int64_t)frame * a.exclude_stride + p]) ok = false;
+			zoom_axis(r, a.zoom.box, a.zoom.ny, ay);
+			if (ay.start != have) { zoom_sums(a.zoom, frame, ay, ax, T); have = ay.start; }
+			const double v = (double)x - (double)zoom_from_sums(ay, T, lo, hi);
+			if (ok) mn = fmin(mn, v);
+		}
+	}
+	mn = block_reduce<1>(mn, red);
+	if (threadIdx.x == 0) partial[((int64_t)frame * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = mn;
+}
+
 // zeropoint = -min + 1.0 (float64; with numpy 1.21 the float32 minimum of the first iteration is promoted by the Python
 // float); +inf partials (nothing unmasked) -> NaN
 __global__ __launch_bounds__(kRadThreads) void tp_radial_min_final_kernel(const double* __restrict__ partial, int n_partial, double* __restrict__ zeropoint)
@@ -126,10 +158,21 @@ __device__ void select_pair(const double* __restrict__ vals, int n, int k, int* 
 			if ((key & pmask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255u)], 1);
 		}
 		__syncthreads();
-		if (tid == 0) {
-			int acc = 0, d = 0;
-			for (; d < 255; ++d) { if (acc + hist[d] > rank) break; acc += hist[d]; }
-			sh[0] = d; sh[1] = rank - acc;
+		{
+			// the digit whose bin holds the rank: the first d with hist[0] + ... + hist[d] > rank -- one bin per thread, an inclusive
+			// scan by shuffles inside the wavefronts and over their four totals (a single thread walking the 256 bins through LDS was
+			// a seventh of the kernel's time: 16 such walks per ring)
+			const int c = hist[tid];
+			int x = c;
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off, 64); if ((tid & 63) >= off) x += y; }
+			int* wtot = reinterpret_cast<int*>(red);           // four wave totals (the reductions that use `red` come later)
+			if ((tid & 63) == 63) wtot[tid >> 6] = x;
+			__syncthreads();
+			int before = 0;
+			for (int w = 0; w < (tid >> 6); ++w) before += wtot[w];
+			const int incl = x + before, excl = incl - c;
+			if (excl <= rank && rank < incl) { sh[0] = tid; sh[1] = rank - excl; }
 		}
 		__syncthreads();
 		prefix |= (uint64_t)sh[0] << shift;
@@ -451,25 +494,36 @@ struct EvalArgs {
 	float* out;
 };
 
-// out = float32(10**spline(r) - zeropoint [+ add]); a frame with n_knots == 0 has no radial component (out = add or 0)
+// out = float32(10**spline(r) - zeropoint [+ add]); a frame with n_knots == 0 has no radial component (out = add or 0).
+// A workgroup takes 256 columns of a strip of kEvalRows rows; a thread walks down its column (the square component from the mesh
+// coefficients: column weights once, row sums once per mesh cell).
+constexpr int kEvalRows = 16;
 __global__ __launch_bounds__(256) void tp_radial_eval_kernel(EvalArgs a)
 {
-	extern __shared__ double sp[];   // knots, then coefficients
-	const int frame = blockIdx.z, row = blockIdx.y;
+	extern __shared__ double sp[];   // knots, coefficients, reciprocal knot differences (stage_radial)
+	const int frame = blockIdx.z;
 	const int n = a.sp.n_knots[frame];
-	for (int i = threadIdx.x; i < n; i += 256) {
-		sp[i] = a.sp.knots[(int64_t)frame * a.sp.max_knots + i];
-		sp[a.sp.max_knots + i] = a.sp.coefs[(int64_t)frame * a.sp.max_knots + i];
-	}
-	__syncthreads();
+	stage_radial(sp, a.sp.max_knots, a.sp, frame, n, threadIdx.x, 256);
 	const int col = blockIdx.x * 256 + threadIdx.x;
 	if (col >= a.n_cols) return;
-	const int64_t p = (int64_t)row * a.n_cols + col;
-	const double radial = radial_value(sp, sp + a.sp.max_knots, n, a.sp.zeropoint[frame], a.sp.col_offset, a.sp.xcen, a.sp.ycen, row, col);
-	double base = 0.0;
-	if (a.add) base = (double)a.add[(int64_t)frame * a.add_stride + p];
-	else if (a.zoom_on) base = (double)zoom_value(a.zoom, frame, row, col);
-	a.out[(int64_t)frame * a.frame_stride + p] = (float)(radial + base);
+	const int r0 = blockIdx.y * kEvalRows, r1 = (r0 + kEvalRows < a.n_rows) ? (r0 + kEvalRows) : a.n_rows;
+	const double zp = a.sp.zeropoint[frame];
+	ZoomAxis ax, ay;
+	double T[4], lo = 0.0, hi = 0.0;
+	int have = -0x7fffffff;
+	if (a.zoom_on) { zoom_axis(col, a.zoom.box, a.zoom.nx, ax); lo = a.zoom.vmin[frame]; hi = a.zoom.vmax[frame]; }
+	for (int row = r0; row < r1; ++row) {
+		const int64_t p = (int64_t)row * a.n_cols + col;
+		const double radial = radial_value(sp, a.sp.max_knots, n, zp, a.sp.col_offset, a.sp.xcen, a.sp.ycen, row, col);
+		double base = 0.0;
+		if (a.add) base = (double)a.add[(int64_t)frame * a.add_stride + p];
+		else if (a.zoom_on) {
+			zoom_axis(row, a.zoom.box, a.zoom.ny, ay);
+			if (ay.start != have) { zoom_sums(a.zoom, frame, ay, ax, T); have = ay.start; }
+			base = (double)zoom_from_sums(ay, T, lo, hi);
+		}
+		a.out[(int64_t)frame * a.frame_stride + p] = (float)(radial + base);
+	}
 }
 
 } // namespace
@@ -495,8 +549,23 @@ static int radial_zeropoint_launch(tp_ctx* ctx, const float* d_frames, int32_t n
 	TP_REQUIRE(ctx, zoom == nullptr || (zoom_image_ok(zoom) && d_square == nullptr && n_pixels % zoom->frame_cols == 0), "tp_radial_zeropoint_zoom: bad mesh image");
 	if (n_frames == 0) return TP_OK;
 	RadialImage img{d_frames, frame_stride, d_square, square_frame_stride, zoom != nullptr, zoom ? zoom_of(zoom) : ZoomImage{}, d_exclude, exclude_frame_stride, (float)flux_cutoff};
-	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_min_partial_kernel, dim3((unsigned)n_partial, (unsigned)n_frames), dim3(kRadThreads), 0, img, n_pixels, d_partial);
-	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_min_final_kernel, dim3((unsigned)n_frames), dim3(kRadThreads), 0, d_partial, (int)n_partial, d_zeropoint);
+	int n_used = n_partial;
+	const int n_cols = zoom ? zoom->frame_cols : 0;
+	const int col_blocks = zoom ? (n_cols + kRadThreads - 1) / kRadThreads : 0;
+	if (zoom && col_blocks <= n_partial) {
+		// column walk: as many row bands as the partial array holds (a minimum does not depend on how the pixels are divided)
+		const int n_rows = (int)(n_pixels / n_cols);
+		int bands = n_partial / col_blocks;
+		if (bands > n_rows) bands = n_rows;
+		const int rows_per_band = (n_rows + bands - 1) / bands;
+		bands = (n_rows + rows_per_band - 1) / rows_per_band;
+		n_used = bands * col_blocks;
+		TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_min_zoom_kernel, dim3((unsigned)col_blocks, (unsigned)bands, (unsigned)n_frames), dim3(kRadThreads), 0,
+			img, n_rows, n_cols, rows_per_band, d_partial);
+	} else {
+		TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_min_partial_kernel, dim3((unsigned)n_partial, (unsigned)n_frames), dim3(kRadThreads), 0, img, n_pixels, d_partial);
+	}
+	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_min_final_kernel, dim3((unsigned)n_frames), dim3(kRadThreads), 0, d_partial, n_used, d_zeropoint);
 	TP_LAUNCH_CHECK(ctx, "tp_radial_min kernels");
 	return TP_OK;
 }
@@ -578,7 +647,7 @@ static int radial_evaluate_launch(tp_ctx* ctx, int32_t n_frames, int32_t frame_r
 	TP_REQUIRE(ctx, d_knots && d_coefs && d_n_knots && d_zeropoint && d_out, "tp_radial_evaluate: null pointer");
 	TP_REQUIRE(ctx, n_frames >= 0 && n_frames <= 65535 && frame_rows > 0 && frame_rows <= 65535 && frame_cols > 0
 		&& frame_stride >= (int64_t)frame_rows * frame_cols, "tp_radial_evaluate: bad frame geometry");
-	TP_REQUIRE(ctx, max_knots >= 8 && max_knots <= 2048, "tp_radial_evaluate: max_knots must be 8..2048");
+	TP_REQUIRE(ctx, max_knots >= 8 && max_knots <= 1024, "tp_radial_evaluate: max_knots must be 8..1024");
 	TP_REQUIRE(ctx, zoom == nullptr || (zoom_image_ok(zoom) && d_add == nullptr && zoom->frame_cols == frame_cols), "tp_radial_evaluate_zoom: bad mesh image");
 	if (n_frames == 0) return TP_OK;
 	EvalArgs a;
@@ -587,8 +656,8 @@ static int radial_evaluate_launch(tp_ctx* ctx, int32_t n_frames, int32_t frame_r
 	a.add = d_add; a.add_stride = add_frame_stride;
 	a.zoom_on = zoom != nullptr; a.zoom = zoom ? zoom_of(zoom) : ZoomImage{};
 	a.out = d_out;
-	dim3 grid((unsigned)((frame_cols + 255) / 256), (unsigned)frame_rows, (unsigned)n_frames);
-	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_eval_kernel, grid, dim3(256), (size_t)max_knots * 2 * sizeof(double), a);
+	dim3 grid((unsigned)((frame_cols + 255) / 256), (unsigned)((frame_rows + kEvalRows - 1) / kEvalRows), (unsigned)n_frames);
+	TP_LAUNCH(ctx, TPK_BKG_RADIAL, tp_radial_eval_kernel, grid, dim3(256), (size_t)kRadialStageDoubles(max_knots) * sizeof(double), a);
 	TP_LAUNCH_CHECK(ctx, "tp_radial_eval_kernel");
 	return TP_OK;
 }
