@@ -60,6 +60,7 @@ def parse_args(argv=None):
 	p.add_argument('--cpu-procs', type=int, default=0, help='worker processes of the all-core CPU baseline (0 = physical cores)')
 	p.add_argument('--seed', type=int, default=1)
 	p.add_argument('--no-gather', action='store_true')
+	p.add_argument('--no-bind', action='store_true', help="leave the CPU affinity alone (default: the process is bound to the cores of its GPU's NUMA node)")
 	p.add_argument('--gather-when', choices=('auto', 'step', 'final'), default='auto', help='N > 1: gather the output block every step (under the next '
 		"step's compute), once after the last step, or (auto) whichever the warm-up's measurement favours")
 	p.add_argument('--host-group', choices=('socket', 'gloo'), default='socket', help='N > 1: the host-side group (rendezvous, barriers, RCCL id): '
@@ -98,6 +99,9 @@ def main():
 		raise RuntimeError("bench.py needs a GPU: " + (_lib.load().tp_last_error(None) or b'').decode())
 	shared_device = world > ndev.value
 	device = local_rank % ndev.value
+	from photometry_amd.device import bind_host_to_device
+	all_cpus = os.sched_getaffinity(0)
+	numa_node = None if args.no_bind else bind_host_to_device(device)   # this rank's threads on the cores next to its GPU
 	ctx = Context(device)
 
 	workload = args.workload or ('c4' if world > 1 else 'c2')
@@ -216,7 +220,7 @@ def main():
 			'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling if psf else 'weak', 'vs_baseline': None,
 			'dtype': 'f32 (aperture, background) + f64 (PSF fit)' if psf else 'f32', 'data': 'synthetic',
 			'config': {'workload': wl, 'workload_short': wl_short, 'baseline_config': 'configs[4]' if psf else 'configs[2]',
-				'targets_per_gpu': Nt, 'targets_total': n_total, 'cadences': T, 'stamp': [H, W],
+				'targets_per_gpu': Nt, 'targets_total': n_total, 'cadences': T, 'stamp': [H, W], 'host_numa_node': numa_node,
 				'parallelism': f'targets sharded over {world} GPU(s), one process per GPU (photometry_amd.sharded), no data-path collective but the gather of the output block',
 				'parallelism_short': f'targets sharded over {world} GPU(s), 1 process/GPU, output gather only'},
 			'roofline': next(r for r in rooflines if r['kernel'] == dom),
@@ -265,7 +269,12 @@ def main():
 		result['stages'] = leg_stages(ctx, scene, cubes, batch, work, args, Nt, T, H, W, np, engine, pipeline)
 	if rank == 0 and world == 1 and workload == 'c2' and args.cpu_sample > 0:
 		from benchlib.cpu import cpu_baseline
-		cb, parity = cpu_baseline(ctx, scene, cubes, work, args, T, H, W, batch.time_smooth)
+		bound = os.sched_getaffinity(0)
+		os.sched_setaffinity(0, all_cpus)     # the CPU baseline gets every core the box gives, not only the GPU's NUMA node
+		try:
+			cb, parity = cpu_baseline(ctx, scene, cubes, work, args, T, H, W, batch.time_smooth)
+		finally:
+			os.sched_setaffinity(0, bound)
 		result['cpu_baseline'] = cb
 		result['parity_sample'] = parity
 		result['speedup_vs_cpu_baseline'] = result['value'] / cb['value']

@@ -74,6 +74,8 @@ int tp_ctx_create_stream(int device, int high_priority, tp_ctx** out);
 int tp_ctx_destroy(tp_ctx* ctx);
 const char* tp_last_error(tp_ctx* ctx);      /* ctx may be NULL: last tp_ctx_create failure */
 int tp_device_info(tp_ctx* ctx, char* name, int name_len, int32_t* n_cu, uint64_t* hbm_bytes);
+/* NUMA node of the device's PCIe slot (-1: unknown), for binding the host threads that feed it (device.bind_host_to_device). */
+int tp_device_numa_node(int device, int* node);
 
 /* Device memory.  tp_free keeps a block for the next tp_malloc of its size class (blocks up to 32 GiB, 64 GiB per context;
  * hipMalloc / hipFree of multi-GB blocks cost milliseconds and synchronise the device); a recycled block is handed out only
@@ -519,6 +521,11 @@ int tp_lightcurve_diagnostics(tp_ctx* ctx, int32_t n_targets, int32_t n_cad,
 int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
 	int64_t row_pitch, int64_t frame_stride, int32_t row_offset, int32_t col_offset,
 	const int32_t* d_stamps, const tp_cube_desc* desc, float* d_cube);
+/* The same for n_stacks (1 .. 4) frame stacks of one geometry at once -- the images / images_err / backgrounds groups of a CCD
+ * share their stamps: one binning of the stamps, one launch.  d_frames / d_cubes: HOST arrays of n_stacks device pointers. */
+int tp_cut_stamps_multi(tp_ctx* ctx, int32_t n_stacks, const float* const* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+	int64_t row_pitch, int64_t frame_stride, int32_t row_offset, int32_t col_offset,
+	const int32_t* d_stamps, const tp_cube_desc* desc, float* const* d_cubes);
 
 /* ---- the batched drop-in entry as a native job engine ----------------------------------------------------
  * replaces, for every target of a CCD region at once, what run_tessphot(_mpi).py does target by target through
@@ -526,7 +533,7 @@ int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t 
  * catalogue of the stamp (BasePhotometry.catalog, :1094-1181), AperturePhotometry.do_photometry WITH its stamp-resize loop
  * (photometry/AperturePhotometry/photometry.py:75-170; resize_stamp / _set_stamp, BasePhotometry.py:567-693) and the
  * diagnostics of BasePhotometry.photometry (:1343-1407).  The frame stacks of the region stay in HBM; the host submits a batch
- * of targets and collects it, a worker thread of the library drives the rounds in between on the job's own three streams
+ * of targets and collects it, a worker thread of the library drives the rounds in between on the job's own four streams
  * (group by stamp size, catalogue selection, tp_cut_stamps, tp_aperture_photometry / the three stand-alone kernels for small
  * groups, tp_lightcurve_diagnostics, download, the plugin's decisions), so several jobs -- one per engine slot -- overlap.
  *

@@ -172,6 +172,28 @@ int tp_device_info(tp_ctx* ctx, char* name, int name_len, int32_t* n_cu, uint64_
 	return TP_OK;
 }
 
+// NUMA node of the device's PCIe slot (sysfs), -1 when unknown: the host threads that feed a GPU and the page-locked buffers it
+// copies into are best kept on that node's cores (a process whose threads float over both sockets of a two-socket host ran the
+// batched frames entry in 20 ms instead of 13, a third of its starts)
+int tp_device_numa_node(int device, int* node) {
+	if (!node) return TP_ERR_INVALID;
+	*node = -1;
+	char bus[64] = {0};
+	hipError_t e = hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device);
+	if (e != hipSuccess) {
+		tp_global_err = std::string("hipDeviceGetPCIBusId: ") + hipGetErrorString(e);
+		return TP_ERR_HIP;
+	}
+	for (char* c = bus; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+	const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+	if (FILE* f = std::fopen(path.c_str(), "r")) {
+		int n = -1;
+		if (std::fscanf(f, "%d", &n) == 1) *node = n;
+		std::fclose(f);
+	}
+	return TP_OK;
+}
+
 // capacity classes of the allocation cache: powers of two from 4 KiB up to 64 KiB (the metadata blocks of a batched entry differ
 // by a few bytes from group to group: with finer classes every one of them went to the driver, and a hipMalloc that has to map a
 // new chunk takes milliseconds), then steps of 1/8 of the power of two below

@@ -171,20 +171,27 @@ __global__ __launch_bounds__(1024) void tp_cut_scan_kernel(int* __restrict__ cou
 	if (tid == 1023) offsets[n] = part[1023];
 }
 
-__global__ __launch_bounds__(256) void tp_cut_nanfill_kernel(CutArgs a, const int* __restrict__ outside)
+// up to kMaxStacks frame stacks cut with ONE binning of the stamps (the three image groups of a CCD share stamps and geometry):
+// blockIdx.z picks the stack
+constexpr int kMaxStacks = 4;
+struct StackPtrs { const float* frames[kMaxStacks]; float* cubes[kMaxStacks]; };
+
+__global__ __launch_bounds__(256) void tp_cut_nanfill_kernel(CutArgs a, StackPtrs sp, const int* __restrict__ outside)
 {
 	const int target = blockIdx.x;
 	if (!outside[target]) return;
-	float* out = a.cube + (int64_t)target * a.height * a.width * a.t_pitch;
+	float* out = sp.cubes[blockIdx.z] + (int64_t)target * a.height * a.width * a.t_pitch;
 	const int64_t n = (int64_t)a.height * a.width * a.t_pitch;
 	const float nan = __builtin_nanf("");
 	for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
 		out[i] = ((int)(i % a.t_pitch) < a.n_frames) ? nan : 0.f;
 }
 
-__global__ __launch_bounds__(256) void tp_cut_tiles_kernel(CutArgs a, TileGeom tg, const int* __restrict__ offsets, const int* __restrict__ items)
+__global__ __launch_bounds__(256) void tp_cut_tiles_kernel(CutArgs a, StackPtrs sp, TileGeom tg, const int* __restrict__ offsets, const int* __restrict__ items)
 {
 	__shared__ float tile[kTileCad * kTileLd];
+	a.frames = sp.frames[blockIdx.z];
+	a.cube = sp.cubes[blockIdx.z];
 	const int tile_id = blockIdx.x;
 	const int first = offsets[tile_id], last = offsets[tile_id + 1];
 	if (first == last) return;                       // no stamp touches this tile
@@ -252,14 +259,13 @@ __global__ __launch_bounds__(256) void tp_cut_tiles_kernel(CutArgs a, TileGeom t
 
 } // namespace
 
-extern "C" int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+static int cut_stamps_launch(tp_ctx* ctx, int n_stacks, const float* const* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
 	int64_t row_pitch, int64_t frame_stride, int32_t row_offset, int32_t col_offset,
-	const int32_t* d_stamps, const tp_cube_desc* desc, float* d_cube)
+	const int32_t* d_stamps, const tp_cube_desc* desc, float* const* d_cubes)
 {
-	TP_CHECK_CTX(ctx);
-	TP_API_BEGIN
 	TP_REQUIRE(ctx, tp_desc_ok(desc), "tp_cut_stamps: bad cube descriptor");
-	TP_REQUIRE(ctx, d_frames && d_stamps && d_cube, "tp_cut_stamps: null pointer");
+	TP_REQUIRE(ctx, n_stacks >= 1 && n_stacks <= kMaxStacks && d_frames && d_stamps && d_cubes, "tp_cut_stamps: null pointer / 1 .. 4 stacks");
+	for (int k = 0; k < n_stacks; ++k) TP_REQUIRE(ctx, d_frames[k] && d_cubes[k], "tp_cut_stamps: null pointer");
 	TP_REQUIRE(ctx, n_frames == desc->n_cad, "tp_cut_stamps: the cube must have one cadence per frame");
 	TP_REQUIRE(ctx, frame_rows > 0 && frame_cols > 0 && row_pitch >= frame_cols && frame_stride >= (int64_t)frame_rows * row_pitch, "tp_cut_stamps: bad frame geometry");
 	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
@@ -272,9 +278,11 @@ extern "C" int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frame
 	const int n_bands = (desc->height + band_rows - 1) / band_rows;
 	TP_REQUIRE(ctx, n_bands <= 65535 && (desc->t_pitch + kCadBlock - 1) / kCadBlock <= 65535, "tp_cut_stamps: too many bands / cadence blocks");
 	CutArgs a;
-	a.frames = d_frames; a.n_frames = n_frames; a.frame_rows = frame_rows; a.frame_cols = frame_cols;
+	a.frames = d_frames[0]; a.n_frames = n_frames; a.frame_rows = frame_rows; a.frame_cols = frame_cols;
 	a.row_pitch = row_pitch; a.frame_stride = frame_stride; a.row_offset = row_offset; a.col_offset = col_offset;
-	a.stamps = d_stamps; a.height = desc->height; a.width = desc->width; a.t_pitch = desc->t_pitch; a.cube = d_cube;
+	a.stamps = d_stamps; a.height = desc->height; a.width = desc->width; a.t_pitch = desc->t_pitch; a.cube = d_cubes[0];
+	StackPtrs sp{};
+	for (int k = 0; k < n_stacks; ++k) { sp.frames[k] = d_frames[k]; sp.cubes[k] = d_cubes[k]; }
 	// dense batch (the stamps cover at least an eighth of the frame): frame-tile-major, every frame pixel fetched once
 	const int64_t stamp_pixels = (int64_t)desc->n_targets * desc->height * desc->width;
 	TileGeom tg;
@@ -297,9 +305,9 @@ extern "C" int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frame
 			hipLaunchKernelGGL(tp_cut_bin_kernel<false>, bgrid, dim3(256), 0, ctx->stream, a, tg, (int)desc->n_targets, count, (const int*)offsets, items, outside);
 			hipLaunchKernelGGL(tp_cut_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, offsets, (int)n_tiles);
 			hipLaunchKernelGGL(tp_cut_bin_kernel<true>, bgrid, dim3(256), 0, ctx->stream, a, tg, (int)desc->n_targets, count, (const int*)offsets, items, outside);
-			hipLaunchKernelGGL(tp_cut_nanfill_kernel, dim3((unsigned)desc->n_targets), dim3(256), 0, ctx->stream, a, (const int*)outside);
-			dim3 grid((unsigned)n_tiles, (unsigned)((desc->t_pitch + kTileCad - 1) / kTileCad));   // (blocks cover the padding of the time axis too)
-			hipLaunchKernelGGL(tp_cut_tiles_kernel, grid, dim3(256), 0, ctx->stream, a, tg, (const int*)offsets, (const int*)items);
+			hipLaunchKernelGGL(tp_cut_nanfill_kernel, dim3((unsigned)desc->n_targets, 1, (unsigned)n_stacks), dim3(256), 0, ctx->stream, a, sp, (const int*)outside);
+			dim3 grid((unsigned)n_tiles, (unsigned)((desc->t_pitch + kTileCad - 1) / kTileCad), (unsigned)n_stacks);   // (blocks cover the padding of the time axis too)
+			hipLaunchKernelGGL(tp_cut_tiles_kernel, grid, dim3(256), 0, ctx->stream, a, sp, tg, (const int*)offsets, (const int*)items);
 		}
 		TP_LAUNCH_CHECK(ctx, "tp_cut_tiles_kernel");
 		return TP_OK;
@@ -307,8 +315,30 @@ extern "C" int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frame
 	if (shmem > 64 * 1024)
 		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_cut_stamps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
 	dim3 grid((unsigned)desc->n_targets, (unsigned)((desc->t_pitch + kCadBlock - 1) / kCadBlock), (unsigned)n_bands);
-	TP_LAUNCH(ctx, TPK_CUTOUT, tp_cut_stamps_kernel, grid, dim3(256), shmem, a, band_rows);
+	for (int k = 0; k < n_stacks; ++k) {
+		a.frames = d_frames[k]; a.cube = d_cubes[k];
+		TP_LAUNCH(ctx, TPK_CUTOUT, tp_cut_stamps_kernel, grid, dim3(256), shmem, a, band_rows);
+	}
 	TP_LAUNCH_CHECK(ctx, "tp_cut_stamps_kernel");
 	return TP_OK;
+}
+
+extern "C" int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+	int64_t row_pitch, int64_t frame_stride, int32_t row_offset, int32_t col_offset,
+	const int32_t* d_stamps, const tp_cube_desc* desc, float* d_cube)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	return cut_stamps_launch(ctx, 1, &d_frames, n_frames, frame_rows, frame_cols, row_pitch, frame_stride, row_offset, col_offset, d_stamps, desc, &d_cube);
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_cut_stamps_multi(tp_ctx* ctx, int32_t n_stacks, const float* const* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+	int64_t row_pitch, int64_t frame_stride, int32_t row_offset, int32_t col_offset,
+	const int32_t* d_stamps, const tp_cube_desc* desc, float* const* d_cubes)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	return cut_stamps_launch(ctx, n_stacks, d_frames, n_frames, frame_rows, frame_cols, row_pitch, frame_stride, row_offset, col_offset, d_stamps, desc, d_cubes);
 	TP_API_END(ctx)
 }

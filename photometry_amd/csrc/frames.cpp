@@ -4,7 +4,7 @@
 //
 // What the reference does one target at a time in Python -- cut the stamp out of the HDF5 groups, run the plugin, look at the mask,
 // grow the stamp, try again -- is here a JOB: the host submits a batch (tp_frames_submit) and collects it (tp_frames_wait); in
-// between a worker thread of the library drives the rounds on the job's own three streams: group the targets still in play by
+// between a worker thread of the library drives the rounds on the job's own four streams: group the targets still in play by
 // stamp size, select the catalogue stars of every stamp from a cell-binned index, cut the stamps on the device (tp_cut_stamps), run
 // the fused pass (tp_aperture_photometry; the three stand-alone kernels for a small group) and the light-curve diagnostics,
 // download the packed output block into page-locked memory (the part the decisions read first, with an event; the light curves
@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -27,7 +28,11 @@
 namespace {
 
 constexpr uint32_t kBitmask = 1 | 2 | 4 | 8 | 32 | 64 | 128 | 4096;   // TESSQualityFlags.DEFAULT_BITMASK (quality.py:123-124)
-constexpr int kStreams = 3;
+// Streams per job: stream 0 for the large groups, three for the small, latency-bound ones.  Four active streams is what a single
+// job runs fastest with (measured, 2 500 targets: 15 / 13 / 20 ms with 2 / 3 / 4 streams for the small groups: beyond four active
+// queues of a process the hardware time-slices them).
+constexpr int kStreams = 4;
+static int g_small_streams = 3;          // (experiment: TESSPHOT_FRAMES_STREAMS = 1 .. 3)
 constexpr int kResizeStep = 10;          // photometry.py:124-131
 constexpr int kFusedFrom = 1024;         // smaller groups take the three stand-alone kernels (latency-bound passes)
 constexpr int kEdgeBits = 2 | 4 | 8 | 16;
@@ -294,11 +299,10 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 		const size_t cube_bytes = (size_t)m * H * W * (size_t)desc.t_pitch * 4;
 		const float* frames[3] = {stack.d_images, stack.d_images_err, stack.d_backgrounds};
 		float* cubes[3];
-		for (int k = 0; k < 3; ++k) {
-			cubes[k] = static_cast<float*>(dalloc(cube_bytes));
-			ck(g, tp_cut_stamps(g, frames[k], stack.n_frames, stack.n_rows, stack.n_cols, stack.n_cols, (int64_t)stack.n_rows * stack.n_cols,
-				stack.row0, stack.col0, d_stamps, &desc, cubes[k]));
-		}
+		for (int k = 0; k < 3; ++k) cubes[k] = static_cast<float*>(dalloc(cube_bytes));
+		// (one binning of the stamps and one launch for the three stacks)
+		ck(g, tp_cut_stamps_multi(g, 3, frames, stack.n_frames, stack.n_rows, stack.n_cols, stack.n_cols, (int64_t)stack.n_rows * stack.n_cols,
+			stack.row0, stack.col0, d_stamps, &desc, cubes));
 		// ---- the packed output block (comm.packed_block_layout with the catalogue flags, the sum image and the diagnostics)
 		const size_t P = (size_t)H * W;
 		uint64_t off = 0;
@@ -478,11 +482,15 @@ void tp_frames_job::run()
 			std::vector<int32_t> still;
 			for (auto& part : parts) {
 				std::vector<Launched> launched(part.size());
+				int n_small = 0;
 				for (size_t gi = 0; gi < part.size(); ++gi) {
 					Launched& L = launched[gi];
 					L.idx = std::move(part[gi].idx);
 					L.grp.H = part[gi].H; L.grp.W = part[gi].W;
-					L.g = (L.idx.size() < 256 || gi == 0) ? streams[gi % kStreams] : streams[0];
+					// a large group is a throughput pass: stream 0.  A small one (the resized stamps of a few targets) is a chain of
+					// latency-bound launches that decides when the job's next round can start: its own high-priority stream, so that its
+					// few workgroups are placed ahead of the thousands another job's large pass has queued
+					L.g = (L.idx.size() < 256) ? streams[1 + (n_small++ % g_small_streams)] : streams[0];
 					launch(L, (int)gi, event_pool);
 				}
 				std::string lost;                        // a device error that surfaces at an event costs every group of the part
@@ -538,7 +546,9 @@ int tp_frames_engine_create(int device, int32_t n_slots, tp_frames_engine** out)
 	eng->n_slots = n_slots;
 	for (int i = 0; i < n_slots * kStreams; ++i) {
 		tp_ctx* c = nullptr;
-		const int rc = tp_ctx_create_stream(device, 0, &c);
+		const char* pe = std::getenv("TESSPHOT_FRAMES_PRIO");
+		if (const char* se = std::getenv("TESSPHOT_FRAMES_STREAMS")) { const int v = std::atoi(se); if (v >= 1 && v <= kStreams - 1) g_small_streams = v; }
+		const int rc = tp_ctx_create_stream(device, (pe && pe[0] == '1' && (i % kStreams) != 0) ? 1 : 0, &c);
 		if (rc != TP_OK) {
 			for (tp_ctx* x : eng->ctxs) (void)tp_ctx_destroy(x);
 			delete eng;

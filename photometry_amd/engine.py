@@ -237,6 +237,23 @@ def cut_stamps(ctx, frames, stamps, height, width, row_offset=0, col_offset=0, o
 	return out
 
 
+def cut_stamps_multi(ctx, frames_list, stamps, height, width, row_offset=0, col_offset=0):
+	"""
+	:func:`cut_stamps` for several frame stacks of one geometry at once (``tp_cut_stamps_multi``: the image groups of a CCD share their
+	stamps, so the stamps are binned into frame tiles once and one launch cuts all stacks).  Returns a list of :class:`DeviceCube`.
+	"""
+	T, R, C = frames_list[0].shape
+	assert all(tuple(f.shape) == (T, R, C) for f in frames_list) and 1 <= len(frames_list) <= 4
+	Nt = stamps.shape[0]
+	outs = [DeviceCube(ctx, Nt, T, height, width) for _ in frames_list]
+	desc = outs[0].desc
+	fp = (ctypes.c_void_p * len(frames_list))(*[f.ptr for f in frames_list])
+	cp = (ctypes.c_void_p * len(outs))(*[o.ptr for o in outs])
+	ctx._check(ctx.lib.tp_cut_stamps_multi(ctx.handle, len(frames_list), fp, T, R, C, C, R * C, int(row_offset), int(col_offset), stamps.ptr,
+		ctypes.byref(desc), cp))
+	return outs
+
+
 #: columns of the diagnostics block (BasePhotometry.py:1357-1403)
 DIAGNOSTICS_COLUMNS = ('mean_flux', 'variance', 'rms_hour', 'ptp', 'pos_centroid_col', 'pos_centroid_row', 'variability',
 	'mask_size', 'edge_flux', 'flags')

@@ -358,7 +358,8 @@ class FrameStack(object):
 	def cut(self, stamps_dev, height, width, ctx=None):
 		"""The three stamp cubes of a group of same-sized stamps (``tp_cut_stamps``), on ``ctx``'s stream (default: the stack's)."""
 		ctx = self.ctx if ctx is None else ctx
-		return {k: engine.cut_stamps(ctx, self.dev[k], stamps_dev, height, width, self.row0, self.col0) for k in self.names}
+		cubes = engine.cut_stamps_multi(ctx, [self.dev[k] for k in self.names], stamps_dev, height, width, self.row0, self.col0)
+		return dict(zip(self.names, cubes))
 
 
 class _Messages(object):

@@ -107,3 +107,21 @@ def test_cutout_from_a_stack_file(tmp_path):
 		for j, i in enumerate(idx):
 			np.testing.assert_array_equal(cube[j], g['cubes'][i])
 	ctx.close()
+
+
+def test_multi_stack_cut_equals_one_stack_at_a_time(ctx):
+	"""tp_cut_stamps_multi (one binning of the stamps, one launch for the three image groups of a CCD) against tp_cut_stamps stack by
+	stack: tile-major path and per-stamp gather, stamps reaching over the frame edge."""
+	from photometry_amd import engine
+	rng = np.random.default_rng(17)
+	for (T, R, C, H, W, n) in ((70, 60, 130, 15, 15, 300), (33, 200, 300, 21, 11, 4)):
+		stacks = [ctx.array(rng.normal(0, 1, (T, R, C)).astype('float32')) for _ in range(3)]
+		r0 = rng.integers(-3, R - H + 4, n)
+		c0 = rng.integers(-3 + 44, C - W + 4 + 44, n)
+		d_stamps = ctx.array(np.stack((r0, r0 + H, c0, c0 + W), axis=1).astype('int32'))
+		together = engine.cut_stamps_multi(ctx, stacks, d_stamps, H, W, 0, 44)
+		ctx.sync()
+		for k in range(3):
+			alone = engine.cut_stamps(ctx, stacks[k], d_stamps, H, W, 0, 44)
+			ctx.sync()
+			np.testing.assert_array_equal(together[k].data.to_host(), alone.data.to_host())

@@ -10,6 +10,9 @@ from benchlib.legs.frames import synthetic_region
 N, FR, T = int(os.environ.get('N', 2500)), int(os.environ.get('FR', 512)), int(os.environ.get('T', 1300))
 NB, FL = int(os.environ.get('BATCHES', 12)), int(os.environ.get('IN_FLIGHT', 4))
 frames, tstamp, quality, cat, targets = synthetic_region(np, N, FR, T, 8)
+if not os.environ.get('NOBIND'):
+	from photometry_amd.device import bind_host_to_device
+	bind_host_to_device(0)
 ctx = Context(0)
 stack = pipeline.FrameStack(ctx, frames, 0, 44)
 del frames

@@ -3,6 +3,9 @@
 FR x FR x T frame stack resident in HBM): device passes against host-side bookkeeping."""
 import os, sys, time, cProfile, pstats, io
 import numpy as np
+if os.environ.get('NODE') is not None:   # experiment: run on the CPUs of one NUMA node (2 x 64 cores, SMT siblings at +128)
+	node = int(os.environ['NODE'])
+	os.sched_setaffinity(0, set(range(64 * node, 64 * node + 64)) | set(range(128 + 64 * node, 128 + 64 * node + 64)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from photometry_amd import pipeline, tessphot_frames
 from photometry_amd.device import Context
@@ -26,6 +29,9 @@ tstamp = 1500.0 + np.arange(T) * 1800.0 / 86400.0
 quality = np.zeros(T, dtype='int32')
 cat = {'starid': np.arange(N, dtype='int64') + 1, 'tmag': tmag.astype('float32'), 'row': (rows + row0).astype('float32'), 'column': (cols + col0).astype('float32')}
 targets = {'starid': cat['starid'].copy(), 'tmag': tmag, 'row': rows + row0, 'column': cols + col0}
+if os.environ.get('NODE') is None and not os.environ.get('NOBIND'):
+	from photometry_amd.device import bind_host_to_device
+	print('bound to NUMA node', bind_host_to_device(0))
 ctx = Context(0)
 stack = pipeline.FrameStack(ctx, frames, row0, col0)
 ctx.sync()
