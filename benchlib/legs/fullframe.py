@@ -31,10 +31,13 @@ def leg_fullframe(ctx, args, np):
 	tj = committed_traffic('traffic_bytes_per_launch', (R, C) == (2048, 2048)) or {}
 	ff = committed_traffic('fullframe_frames', (R, C) == (2048, 2048)) or 0
 	per_frame = {k: v / ff for k, v in tj.items() if ff and k.startswith(('tp_bkg_mesh', 'tp_mesh_finish', 'tp_bkg_zoom', 'tp_radial', 'tp_median_filter', 'tp_block_median', 'tp_threshold'))}
-	def leg_traffic(names, rounds):
+	b1 = committed_traffic('b1_traffic_bytes_per_frame', (R, C) == (2048, 2048)) or {}
+	def leg_traffic(names, rounds, branch=None):
+		if branch in b1:     # every dispatch of the branch summed (profiles/run_profile.sh, tools/radial_time.py MODE=branch)
+			return b1[branch]
 		got = [per_frame[k] for k in per_frame if k.startswith(names)]
 		return rounds * sum(got) if got else None
-	src = (TRAFFIC_FILE + ' (committed rocprofv3 PMC passes of this leg on %d frames, per-kernel means; not measured in this run)' % ff) if per_frame else None
+	src = (TRAFFIC_FILE + ' (committed rocprofv3 PMC passes; not measured in this run)') if (per_frame or b1) else None
 	results = {}
 	for name, kw in (('plain', {}), ('tess', dict(geometry=geo))):
 		prepare.fit_background_frames(ctx, d, **kw).free()
@@ -58,7 +61,7 @@ def leg_fullframe(ctx, args, np):
 			'roofline': {'kernel': 'tp_bkg_mesh_kernel + tp_bkg_zoom_kernel' + (' + tp_radial_kernels' if name == 'tess' else ''), 'bound': 'hbm',
 				'achieved': nb / (kms / nf * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': nb / (kms / nf * 1e-3) / 1e9 / HBM_PEAK_GBS,
 				'bytes_per_frame': nb, 'bytes': 'R*C*4 per pass over the image (mesh statistics, ring modes) + the background written once',
-				'traffic': leg_traffic(('tp_bkg_mesh', 'tp_mesh_finish', 'tp_bkg_zoom') + (('tp_radial',) if name == 'tess' else ()), passes), 'traffic_unit': 'bytes per frame', 'traffic_source': src}}
+				'traffic': leg_traffic(('tp_bkg_mesh', 'tp_mesh_finish', 'tp_bkg_zoom') + (('tp_radial',) if name == 'tess' else ()), passes, name), 'traffic_unit': 'bytes per frame', 'traffic_source': src}}
 	# shenanigans: indicator (15 x 15 median filter of img - SumImage), its robust mean over time, thresholded flags
 	ns = min(nf, 25)
 	img = ctx.array(f[:ns])

@@ -86,10 +86,14 @@ for f in find('pmc_lines/**/*counter_collection.csv'):
 
 # necessary bytes per launch from the bench line of the trace run
 need = {}
-for f in ('bench_trace.json',):
+for f in ('bench_trace_legs.json', 'bench_trace.json'):
+	# the full result of the traced run (bench_legs.json, copied by run_profile.sh); before round 5 the stdout line was the full result
 	try:
-		r = json.loads(open(os.path.join(out, f)).read().strip().splitlines()[-1])
+		txt = open(os.path.join(out, f)).read().strip()
+		r = json.loads(txt) if f.endswith('_legs.json') else json.loads(txt.splitlines()[-1])
 	except Exception: # noqa: B902
+		continue
+	if 'kernels' not in r:
 		continue
 	for k, v in r.get('kernels', {}).items():
 		if 'necessary_bytes_per_launch' in v:
@@ -140,6 +144,32 @@ if linpsf_total:
 	nb = need.get(('step', 'tp_linpsf_fit'))
 	traffic['traffic_bytes_per_launch']['tp_linpsf_fit'] = linpsf_total
 	print(f"{'LinPSF fit (plan + coefficient store + every fit launch)':64s} traffic {linpsf_total/1e9:8.3f} GB per step" + (f"  necessary {nb/1e9:8.3f} GB  ratio {linpsf_total/nb:.3f}" if nb else ''))
+# B1 branch by branch: every dispatch of tools/radial_time.py MODE=plain / tess (two runs of NF frames), summed
+b1_frames = int(os.environ.get('B1_FRAMES', '0'))
+if b1_frames:
+	traffic['b1_traffic_bytes_per_frame'] = {}
+	traffic['b1_frames'] = b1_frames
+	print("== B1 (fit_background) traffic per 2048 x 2048 frame, every dispatch of the branch summed ==")
+	for mode in ('plain', 'tess'):
+		written = 0.0
+		for f in find(f'b1_{mode}_write/**/*counter_collection.csv'):
+			with open(f) as fh:
+				for r in csv.DictReader(fh):
+					if r.get('Counter_Name') == 'WRITE_SIZE' and 'tp_' in r.get('Kernel_Name', ''):
+						written += float(r['Counter_Value']) * 1024.0
+		disp = defaultdict(dict)
+		for f in find(f'b1_{mode}_lines/**/*counter_collection.csv'):
+			with open(f) as fh:
+				for r in csv.DictReader(fh):
+					if 'tp_' in r.get('Kernel_Name', ''):
+						disp[r.get('Dispatch_Id')][r['Counter_Name']] = float(r['Counter_Value'])
+		read = 0.0
+		for c in disp.values():
+			if 'TCC_MISS_sum' in c and 'TCC_EA0_RDREQ_sum' in c:
+				read += min(128.0 * max(c['TCC_MISS_sum'] - c.get('TCC_EA0_WRREQ_sum', 0.0), c['TCC_EA0_RDREQ_sum'] / 2), 128.0 * c['TCC_EA0_RDREQ_sum'])
+		if disp:
+			traffic['b1_traffic_bytes_per_frame'][mode] = (read + written) / b1_frames
+			print(f"{mode:6s} read {read / b1_frames / 1e6:8.1f} MB  written {written / b1_frames / 1e6:8.1f} MB  traffic {(read + written) / b1_frames / 1e6:8.1f} MB per frame ({len(disp)} dispatches)")
 if len(sys.argv) > 2:
 	with open(sys.argv[2], 'w') as fh:
 		json.dump(traffic, fh, indent=1, sort_keys=True)

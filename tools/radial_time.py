@@ -17,7 +17,8 @@ for k in range(T):
 	f[k] = 120 + 0.02 * xx + 40 * np.exp((r - 2400) / 250.0) + rng.normal(0, 4, r.shape)
 d = ctx.array(f)
 geo = prepare.RadialGeometry((2048, 2048), 1, 1)
-for name, kw in (('plain', {}), ('tess', dict(geometry=geo))):
+MODE = os.environ.get('MODE')   # 'plain' / 'tess': that branch only (the PMC passes of profiles/run_profile.sh: every dispatch then belongs to it)
+for name, kw in [(n, k) for n, k in (('plain', {}), ('tess', dict(geometry=geo))) if MODE in (None, n)]:
 	prepare.fit_background_frames(ctx, d, **kw).free()
 	ctx.profile(True)
 	ctx.profile_reset()
