@@ -38,6 +38,7 @@ static const char* const kKernelNames[TPK_COUNT] = {
 	"tp_synth_kernel",
 	"tp_linpsf_fitm_kernel",
 	"tp_bkg_stamp_sum_kernel",
+	"tp_star_positions_kernel",
 };
 
 extern "C" {

@@ -37,6 +37,7 @@ enum tp_kernel_id {
 	TPK_SYNTH,
 	TPK_LINPSF_FIT_MFMA,
 	TPK_BKG_STAMP_SUM,
+	TPK_STAR_POSITIONS,
 	TPK_COUNT
 };
 

@@ -1743,7 +1743,7 @@ extern "C" int tp_star_positions(tp_ctx* ctx, int64_t n_stars, int32_t n_cad, co
 	if (n_stars == 0 || n_cad == 0) return TP_OK;
 	TP_REQUIRE(ctx, d_base && d_shift && d_pos, "tp_star_positions: null pointer");
 	const unsigned gy = (unsigned)(n_stars < 65535 ? n_stars : 65535);
-	TP_LAUNCH(ctx, TPK_LINPSF_PLAN, tp_star_positions_kernel, dim3((unsigned)((n_cad + 255) / 256), gy), dim3(256), 0, n_stars, (int)n_cad, d_base, d_shift, d_pos, pos_pitch);
+	TP_LAUNCH(ctx, TPK_STAR_POSITIONS, tp_star_positions_kernel, dim3((unsigned)((n_cad + 255) / 256), gy), dim3(256), 0, n_stars, (int)n_cad, d_base, d_shift, d_pos, pos_pitch);
 	TP_LAUNCH_CHECK(ctx, "tp_star_positions_kernel");
 	return TP_OK;
 	TP_API_END(ctx)

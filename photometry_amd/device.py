@@ -16,7 +16,14 @@ def round_up(n, m):
 
 
 class DeviceArray(object):
-	"""A typed buffer in HBM.  ``shape`` / ``dtype`` describe the logical contents."""
+	"""
+	A typed buffer in HBM.  ``shape`` / ``dtype`` describe the logical contents.
+
+	Lifetime: when the object goes, its block returns to the context's allocation cache (``tp_free``) and the NEXT allocation of its
+	size class (powers of two from 4 KiB, eighth-steps above 64 KiB) may get the same block -- ordered on the context's stream, so
+	work already queued is safe, but a ``ptr`` handed to a later call is not: keep the array named for as long as a raw pointer to
+	it is in use (``d = ctx.array(x); lib.tp_...(d.ptr)``, never ``lib.tp_...(ctx.array(x).ptr)`` followed by another allocation).
+	"""
 
 	def __init__(self, ctx, shape, dtype, zero=False):
 		self.ctx = ctx

@@ -95,7 +95,7 @@ class ApertureBatch(object):
 			self.ctx.pinned_release(h)
 
 	def __del__(self):
-		# not returned to the pool here: the upload may still be in flight when the last reference goes; the block is freed instead
+		# the upload may still be in flight when the last reference goes: wait for the stream, then the block goes back to the pool
 		h = self.__dict__.pop('_meta_host', None)
 		if h is not None:
 			try:
