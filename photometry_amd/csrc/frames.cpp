@@ -113,6 +113,7 @@ struct tp_frames_engine {
 	std::mutex m;
 	PinnedPool pinned;
 	uint64_t hbm_bytes = 0;
+	std::atomic<int> running{0};         // worker threads inside run(): tp_frames_engine_destroy waits for them
 };
 
 namespace {
@@ -567,6 +568,7 @@ int tp_frames_engine_create(int device, int32_t n_slots, tp_frames_engine** out)
 int tp_frames_engine_destroy(tp_frames_engine* eng)
 {
 	if (!eng) return TP_OK;
+	while (eng->running.load() > 0) std::this_thread::yield();   // (a job still running: its streams go only once it is through)
 	for (tp_ctx* c : eng->ctxs) (void)tp_ctx_destroy(c);
 	delete eng;
 	return TP_OK;
@@ -670,7 +672,8 @@ int tp_frames_submit(tp_frames_engine* eng, const tp_frames_stack* stack, const 
 	job->time.assign(h_time, h_time + job->T);
 	job->quality.assign(h_quality, h_quality + job->T);
 	job->budget = budget_bytes > 0 ? budget_bytes : (double)eng->hbm_bytes / 4.0;
-	job->worker = std::thread([job] { job->run(); });
+	eng->running.fetch_add(1);
+	job->worker = std::thread([job] { job->run(); job->eng->running.fetch_sub(1); });
 	*out = job;
 	return TP_OK;
 	TP_API_END((tp_ctx*)nullptr)
