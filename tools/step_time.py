@@ -12,6 +12,10 @@ ctx = Context(0)
 Nt = int(os.environ.get('NT', 10000))
 T = int(os.environ.get('T', 1300))
 scene = simulate.make_scene(Nt, T, 15, 15, seed=1000)
+if os.environ.get('SORT'):   # experiment: the targets in order of brightness (a proxy for the work of the mask + extraction launch)
+	import numpy as np
+	o = np.argsort(scene.target_tmag, kind='stable')
+	scene = scene.subset(o if os.environ['SORT'] == 'asc' else o[::-1])
 scene.aperture = None
 if 'CADENCE' in os.environ:
 	scene.cadence_s = int(os.environ['CADENCE'])
