@@ -335,7 +335,11 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 		ckh(hipMemsetAsync(d_aperture, 1, (size_t)m * P * 4, g->stream), "hipMemsetAsync(aperture)");
 		// ---- the pass: fused for a large group; a small one is latency-bound and spreads better as three kernels (bit-identical)
 		if (m >= kFusedFrom) {
-			ck(g, tp_aperture_photometry(g, &desc, cubes[0], cubes[1], cubes[2], 0, 0, nullptr, 0, d_quality, 0, kBitmask,
+			// a few thousand targets are less than one round of the chip for the one-wavefront-per-target launch, and the sum image is
+			// most of its bytes: formed by the stand-alone kernel (every CU streams) the pair takes 1.1 ms where the fused launch with the
+			// sum image inside took 1.8 (2 500 targets; bit-identical: tests/test_gpu_pipeline.py)
+			ck(g, tp_sumimage(g, &desc, cubes[0], d_quality, 0, kBitmask, nullptr, 0, d_sum));
+			ck(g, tp_aperture_photometry_from_sumimage(g, &desc, cubes[0], cubes[1], cubes[2], 0, 0, nullptr, 0, d_quality, 0, kBitmask,
 				d_cat_offsets, d_cat_col_stamp, d_cat_row_stamp, d_cat_tmag, d_cat_col, d_cat_row, d_cat_starid,
 				d_t_row, d_t_col, d_t_tmag, d_t_starid, d_stamps, d_aperture, nullptr,
 				d_sum, d_mask, d_status, d_flags, d_cont, d_diag8, d_cim, lc[0], lc[1], lc[2], lc[3], lc[4], T));

@@ -49,3 +49,54 @@ def test_k2p2_fuzz_forty_scenes():
 	ctx.close()
 	print('K2P2 fuzz:', tot, 'largest |dCUT|', worst)
 	assert tot['targets'] >= 1000 and tot['n_razor'] == 0 and tot['n_exact'] + tot['n_error_agree'] == tot['targets'] and tot['n_exact'] > 0
+
+
+def test_frames_engine_fuzz_native_equals_python_rounds():
+	"""The native job engine of the batched drop-in entry against the Python rounds on eight further random regions (crowded
+	fields with bright stars near the frame limits: several resize rounds, size groups, quick breaks, minimum apertures, stamps
+	clipped by the region): every target equal in every field a caller can see."""
+	from photometry_amd import pipeline
+	from photometry_amd.device import Context
+	from test_gpu_resize import _compare_frames_results
+	ctx = Context(0)
+	tot = {'targets': 0, 'resized': 0, 'messages': 0, 'errors': 0, 'passes': 0}
+	for seed in range(201, 209):
+		rng = np.random.default_rng(seed)
+		N, FR, T = int(rng.integers(150, 500)), int(rng.integers(96, 200)), 24
+		rows, cols = rng.uniform(2, FR - 2, N), rng.uniform(2, FR - 2, N)      # (stars right at the limits: clipped default stamps)
+		tmag = np.where(rng.random(N) < 0.08, rng.uniform(4.5, 7.5, N), rng.uniform(8.0, 14.5, N))
+		img = np.zeros((FR + 32, FR + 32))
+		yy, xx = np.mgrid[-8:9, -8:9]
+		for r, c, m in zip(rows, cols, tmag):
+			ri, ci = int(round(r)) + 16, int(round(c)) + 16
+			flux = 10**(-0.4 * (m - 20.451))
+			img[ri - 8:ri + 9, ci - 8:ci + 9] += flux * np.exp(-0.5 * ((yy + ri - 16 - r)**2 + (xx + ci - 16 - c)**2) / 0.81) / (2 * np.pi * 0.81)
+			if m < 7.5:   # a bleed trail along the column, two pixels wide
+				half = int(rng.integers(8, 40))
+				img[max(ri - half, 0):ri + half + 1, ci:ci + 2] += 0.02 * flux
+		img = img[16:-16, 16:-16]
+		base = (img[None] * (1 + 1e-3 * rng.normal(size=T))[:, None, None]).astype('float32')
+		noise = np.sqrt(np.abs(base) + 200.0).astype('float32')
+		images = (base + 30.0 + rng.standard_normal(base.shape).astype('float32') * noise).astype('float32')
+		images[rng.random(images.shape) < 3e-4] = np.nan
+		fr = {'images': images, 'images_err': noise, 'backgrounds': np.full((T, FR, FR), 100.0, dtype='float32')}
+		tstamp = 1500.0 + np.arange(T) * 1800.0 / 86400.0
+		q = np.zeros(T, dtype='int32')
+		q[int(rng.integers(0, T))] = 32
+		row0, col0 = int(rng.integers(0, 300)), 44 + int(rng.integers(0, 300))
+		cat = {'starid': np.arange(N, dtype='int64') + 1, 'tmag': tmag.astype('float32'), 'row': (rows + row0).astype('float32'), 'column': (cols + col0).astype('float32')}
+		sel = rng.permutation(N)[:int(0.8 * N)]
+		tg = {'starid': cat['starid'][sel].copy(), 'tmag': tmag[sel], 'row': rows[sel] + row0, 'column': cols[sel] + col0}
+		stack = pipeline.FrameStack(ctx, fr, row0, col0)
+		py = pipeline.aperture_frames(ctx, stack, tg, cat, tstamp, q, engine='python')
+		nat = pipeline.aperture_frames(ctx, stack, tg, cat, tstamp, q, engine='native')
+		_compare_frames_results(py, nat)
+		tot['targets'] += nat.n
+		tot['resized'] += int((nat.stamp_resizes > 0).sum())
+		tot['messages'] += len(nat.errors)
+		tot['errors'] += int((nat.status == 2).sum())
+		tot['passes'] += len(nat.groups)
+		del py, nat, stack
+	ctx.close()
+	print('frames engine fuzz:', tot)
+	assert tot['targets'] > 1500 and tot['resized'] > 50 and tot['messages'] > 20 and tot['passes'] > 40
