@@ -526,6 +526,12 @@ int tp_cut_stamps(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t 
 int tp_cut_stamps_multi(tp_ctx* ctx, int32_t n_stacks, const float* const* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
 	int64_t row_pitch, int64_t frame_stride, int32_t row_offset, int32_t col_offset,
 	const int32_t* d_stamps, const tp_cube_desc* desc, float* const* d_cubes);
+/* The same, writing only the pixel rows of every stamp's aperture mask (d_mask uint8 [n_targets][height * width], non-zero = write;
+ * e.g. tp_k2p2_masks' output): tp_aperture_extract reads nothing else of the error and background cubes, and a mask is a sixth of
+ * a 15 x 15 stamp on average.  The other rows of d_cubes are left as they were. */
+int tp_cut_stamps_masked(tp_ctx* ctx, int32_t n_stacks, const float* const* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+	int64_t row_pitch, int64_t frame_stride, int32_t row_offset, int32_t col_offset,
+	const int32_t* d_stamps, const tp_cube_desc* desc, const uint8_t* d_mask, float* const* d_cubes);
 
 /* ---- the batched drop-in entry as a native job engine ----------------------------------------------------
  * replaces, for every target of a CCD region at once, what run_tessphot(_mpi).py does target by target through

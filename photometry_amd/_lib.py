@@ -147,6 +147,7 @@ SIGNATURES = {
 	'tp_comm_gather': (c_int, [c_void_p, _p, _p, c_uint64, c_int]),
 	'tp_comm_allgather': (c_int, [c_void_p, _p, _p, c_uint64]),
 	'tp_cut_stamps_multi': (c_int, [c_void_p, c_int32, _p, c_int32, c_int32, c_int32, c_int64, c_int64, c_int32, c_int32, _p, _desc_p, _p]),
+	'tp_cut_stamps_masked': (c_int, [c_void_p, c_int32, _p, c_int32, c_int32, c_int32, c_int64, c_int64, c_int32, c_int32, _p, _desc_p, _p, _p]),
 	'tp_radial_zeropoint_zoom': (c_int, [c_void_p, _p, c_int32, c_int64, c_int64, POINTER(tp_zoom_image), _p, c_int64, c_double, _p, c_int32, _p]),
 	'tp_radial_ring_modes_zoom': (c_int, [c_void_p, _p, c_int32, c_int64, c_int64, POINTER(tp_zoom_image), _p, c_int64, c_double, _p, _p, _p, c_int32, c_int32, c_double, _p, _p, _p]),
 	'tp_radial_evaluate_zoom': (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int64, POINTER(tp_radial_image), POINTER(tp_zoom_image), _p]),

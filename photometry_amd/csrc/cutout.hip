@@ -40,6 +40,7 @@ struct CutArgs {
 	const float* frames; int n_frames; int frame_rows, frame_cols; int64_t row_pitch, frame_stride;
 	int row_offset, col_offset;          // pixel_offset_row / pixel_offset_col (BasePhotometry.py:724-727)
 	const int32_t* stamps; int height, width; int64_t t_pitch; float* cube;
+	const uint8_t* mask;                 // optional [n_targets][height * width]: only the pixels with a non-zero entry are written
 };
 
 __global__ __launch_bounds__(256) void tp_cut_stamps_kernel(CutArgs a, int band_rows)
@@ -100,7 +101,11 @@ __global__ __launch_bounds__(256) void tp_cut_stamps_kernel(CutArgs a, int band_
 	// the padding of the time axis (cadences n_frames .. t_pitch) is written too, as zeros: the caller need not clear the cube
 	if (k0 + lane < a.t_pitch) {
 		const bool real = k0 + lane < a.n_frames;
-		for (int p = wave; p < P; p += 4) out[(int64_t)p * a.t_pitch + k0 + lane] = real ? tile[lane * ldp + p] : 0.f;
+		const uint8_t* mk = a.mask ? (a.mask + (int64_t)target * a.height * W + (int64_t)row_first * W) : nullptr;
+		for (int p = wave; p < P; p += 4) {
+			if (mk && !mk[p]) continue;   // (wave-uniform: p depends on the wavefront only)
+			out[(int64_t)p * a.t_pitch + k0 + lane] = real ? tile[lane * ldp + p] : 0.f;
+		}
 	}
 }
 
@@ -257,11 +262,93 @@ __global__ __launch_bounds__(256) void tp_cut_tiles_kernel(CutArgs a, StackPtrs 
 	}
 }
 
+// ---- masked cut: only the in-mask pixels of every stamp are written.  The tile lists then hold PIXELS, not stamps (an item =
+// target, pixel of its stamp): a mask is a sixth of a 15 x 15 stamp, and a serve loop that walks every stamp pixel to skip five
+// of six is as slow as the unmasked cut (measured: 1.83 ms for two stacks of 2 500 stamps, against 1.88 without a mask).
+// pass 1 / 3: one thread per (target, stamp pixel)
+template <bool FILL>
+__global__ __launch_bounds__(256) void tp_cut_bin_pixels_kernel(CutArgs a, StackPtrs sp, int n_stacks, TileGeom tg, int n_targets, int* __restrict__ count_or_cursor,
+	const int* __restrict__ offsets, uint32_t* __restrict__ items)
+{
+	const int P = a.height * a.width;
+	const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= (int64_t)n_targets * P) return;
+	if (!a.mask[e]) return;
+	const int t = (int)(e / P), p = (int)(e - (int64_t)t * P);
+	const int pi = p / a.width, pj = p - pi * a.width;
+	const int r = a.stamps[t * 4 + 0] - a.row_offset + pi, c = a.stamps[t * 4 + 2] - a.col_offset + pj;
+	if (r < 0 || r >= a.frame_rows || c < 0 || c >= a.frame_cols) {
+		// an in-mask pixel beyond the frame (the reference never cuts such stamps: BasePhotometry.py:643-679): NaN, written here
+		if (!FILL) {
+			const float nan = __builtin_nanf("");
+			for (int k = 0; k < n_stacks; ++k) {
+				float* out = sp.cubes[k] + e * a.t_pitch;
+				for (int q = 0; q < (int)a.t_pitch; ++q) out[q] = (q < a.n_frames) ? nan : 0.f;
+			}
+		}
+		return;
+	}
+	const int tile = (r / kTileRows) * tg.tiles_x + (c / kTileCols);
+	const int pos = atomicAdd(&count_or_cursor[tile], 1);
+	if (FILL) { const int64_t o = 2 * ((int64_t)offsets[tile] + pos); items[o] = (uint32_t)t; items[o + 1] = (uint32_t)p; }
+}
+
+__global__ __launch_bounds__(256) void tp_cut_tiles_pixels_kernel(CutArgs a, StackPtrs sp, TileGeom tg, const int* __restrict__ offsets, const uint32_t* __restrict__ items)
+{
+	__shared__ float tile[kTileCad * kTileLd];
+	a.frames = sp.frames[blockIdx.z];
+	a.cube = sp.cubes[blockIdx.z];
+	const int tile_id = blockIdx.x;
+	const int first = offsets[tile_id], last = offsets[tile_id + 1];
+	if (first == last) return;                       // no in-mask pixel in this tile
+	const int k0 = blockIdx.y * kTileCad;
+	const int tid = threadIdx.x;
+	const int ty = tile_id / tg.tiles_x, tx = tile_id - ty * tg.tiles_x;
+	const int tr0 = ty * kTileRows, tc0 = tx * kTileCols;
+	constexpr int GRP = 256 / kTileCols;
+	const int grp = __builtin_amdgcn_readfirstlane(tid / kTileCols);
+	const int lcol = tid % kTileCols;
+	const int col = tc0 + lcol;
+	const bool col_ok = col < a.frame_cols;
+	constexpr int SEG = kTileCad * kTileRows;
+	constexpr int U = SEG / GRP;
+	{
+		float v[U];
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int sidx = grp + GRP * u;
+			const int kk = sidx / kTileRows, rr = sidx % kTileRows;
+			const bool ok = col_ok && (k0 + kk < a.n_frames) && (tr0 + rr < a.frame_rows);
+			const int64_t off = ok ? ((int64_t)(k0 + kk) * a.frame_stride + (int64_t)(tr0 + rr) * a.row_pitch + col) : 0;
+			v[u] = a.frames[off];
+		}
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int sidx = grp + GRP * u;
+			const int kk = sidx / kTileRows, rr = sidx % kTileRows;
+			tile[kk * kTileLd + rr * kTileCols + lcol] = v[u];
+		}
+	}
+	__syncthreads();
+	// ---- one in-mask pixel per group of kTileCad lanes and step: its frames of this block are one 128-byte line of the cube
+	constexpr int RUNS = 256 / kTileCad;
+	const int lane = tid % kTileCad, run = tid / kTileCad;
+	const bool k_ok = k0 + lane < a.n_frames, k_store = k0 + lane < a.t_pitch;
+	const int P = a.height * a.width;
+	for (int it = first + run; it < last; it += RUNS) {
+		const int target = (int)items[2 * (int64_t)it], p = (int)items[2 * (int64_t)it + 1];
+		const int pi = p / a.width, pj = p - pi * a.width;
+		const int rr = a.stamps[target * 4 + 0] - a.row_offset + pi - tr0, cc = a.stamps[target * 4 + 2] - a.col_offset + pj - tc0;
+		const float x = tile[lane * kTileLd + rr * kTileCols + cc];
+		if (k_store) a.cube[((int64_t)target * P + p) * a.t_pitch + k0 + lane] = k_ok ? x : 0.f;
+	}
+}
+
 } // namespace
 
 static int cut_stamps_launch(tp_ctx* ctx, int n_stacks, const float* const* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
 	int64_t row_pitch, int64_t frame_stride, int32_t row_offset, int32_t col_offset,
-	const int32_t* d_stamps, const tp_cube_desc* desc, float* const* d_cubes)
+	const int32_t* d_stamps, const tp_cube_desc* desc, float* const* d_cubes, const uint8_t* d_mask = nullptr)
 {
 	TP_REQUIRE(ctx, tp_desc_ok(desc), "tp_cut_stamps: bad cube descriptor");
 	TP_REQUIRE(ctx, n_stacks >= 1 && n_stacks <= kMaxStacks && d_frames && d_stamps && d_cubes, "tp_cut_stamps: null pointer / 1 .. 4 stacks");
@@ -281,6 +368,7 @@ static int cut_stamps_launch(tp_ctx* ctx, int n_stacks, const float* const* d_fr
 	a.frames = d_frames[0]; a.n_frames = n_frames; a.frame_rows = frame_rows; a.frame_cols = frame_cols;
 	a.row_pitch = row_pitch; a.frame_stride = frame_stride; a.row_offset = row_offset; a.col_offset = col_offset;
 	a.stamps = d_stamps; a.height = desc->height; a.width = desc->width; a.t_pitch = desc->t_pitch; a.cube = d_cubes[0];
+	a.mask = d_mask;
 	StackPtrs sp{};
 	for (int k = 0; k < n_stacks; ++k) { sp.frames[k] = d_frames[k]; sp.cubes[k] = d_cubes[k]; }
 	// dense batch (the stamps cover at least an eighth of the frame): frame-tile-major, every frame pixel fetched once
@@ -290,6 +378,27 @@ static int cut_stamps_launch(tp_ctx* ctx, int n_stacks, const float* const* d_fr
 	tg.tiles_y = (frame_rows + kTileRows - 1) / kTileRows;
 	const int64_t n_tiles = (int64_t)tg.tiles_x * tg.tiles_y;
 	const int64_t max_per_stamp = (int64_t)((desc->height - 1) / kTileRows + 2) * ((desc->width - 1) / kTileCols + 2);
+	if (d_mask && n_tiles <= 16 * 1024 * 1024 && stamp_pixels < 1073741823ll) {
+		// masked: the tiles serve lists of in-mask pixels (a tile without any exits at once: a sparse batch reads what it needs)
+		const size_t n_int = (size_t)(2 * n_tiles + 2 + 2 * stamp_pixels);
+		int* base = static_cast<int*>(tp_ctx_scratch(ctx, n_int * sizeof(int)));
+		TP_REQUIRE(ctx, base != nullptr, "tp_cut_stamps_masked: out of device memory (pixel lists)");
+		int* count = base;
+		int* offsets = count + n_tiles;
+		uint32_t* items = reinterpret_cast<uint32_t*>(offsets + n_tiles + 2);
+		TP_HIP(ctx, hipMemsetAsync(count, 0, (size_t)n_tiles * sizeof(int), ctx->stream));
+		const dim3 bgrid((unsigned)((stamp_pixels + 255) / 256));
+		{
+			tp_prof_scope _ps(ctx, TPK_CUTOUT);
+			hipLaunchKernelGGL(tp_cut_bin_pixels_kernel<false>, bgrid, dim3(256), 0, ctx->stream, a, sp, (int)n_stacks, tg, (int)desc->n_targets, count, (const int*)offsets, items);
+			hipLaunchKernelGGL(tp_cut_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, count, offsets, (int)n_tiles);
+			hipLaunchKernelGGL(tp_cut_bin_pixels_kernel<true>, bgrid, dim3(256), 0, ctx->stream, a, sp, (int)n_stacks, tg, (int)desc->n_targets, count, (const int*)offsets, items);
+			dim3 grid((unsigned)n_tiles, (unsigned)((desc->t_pitch + kTileCad - 1) / kTileCad), (unsigned)n_stacks);
+			hipLaunchKernelGGL(tp_cut_tiles_pixels_kernel, grid, dim3(256), 0, ctx->stream, a, sp, tg, (const int*)offsets, (const uint32_t*)items);
+		}
+		TP_LAUNCH_CHECK(ctx, "tp_cut_tiles_pixels_kernel");
+		return TP_OK;
+	}
 	if (stamp_pixels * 8 >= (int64_t)frame_rows * frame_cols && n_tiles <= 16 * 1024 * 1024 && desc->n_targets * max_per_stamp < 2147483647ll) {
 		const size_t n_int = (size_t)(2 * n_tiles + 2 + desc->n_targets * max_per_stamp + desc->n_targets);
 		int* base = static_cast<int*>(tp_ctx_scratch(ctx, n_int * sizeof(int)));
@@ -340,5 +449,16 @@ extern "C" int tp_cut_stamps_multi(tp_ctx* ctx, int32_t n_stacks, const float* c
 	TP_CHECK_CTX(ctx);
 	TP_API_BEGIN
 	return cut_stamps_launch(ctx, n_stacks, d_frames, n_frames, frame_rows, frame_cols, row_pitch, frame_stride, row_offset, col_offset, d_stamps, desc, d_cubes);
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_cut_stamps_masked(tp_ctx* ctx, int32_t n_stacks, const float* const* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
+	int64_t row_pitch, int64_t frame_stride, int32_t row_offset, int32_t col_offset,
+	const int32_t* d_stamps, const tp_cube_desc* desc, const uint8_t* d_mask, float* const* d_cubes)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_mask != nullptr, "tp_cut_stamps_masked: null mask");
+	return cut_stamps_launch(ctx, n_stacks, d_frames, n_frames, frame_rows, frame_cols, row_pitch, frame_stride, row_offset, col_offset, d_stamps, desc, d_cubes, d_mask);
 	TP_API_END(ctx)
 }

@@ -34,7 +34,7 @@ constexpr uint32_t kBitmask = 1 | 2 | 4 | 8 | 32 | 64 | 128 | 4096;   // TESSQua
 constexpr int kStreams = 4;
 static int g_small_streams = 3;          // (experiment: TESSPHOT_FRAMES_STREAMS = 1 .. 3)
 constexpr int kResizeStep = 10;          // photometry.py:124-131
-constexpr int kFusedFrom = 1024;         // smaller groups take the three stand-alone kernels (latency-bound passes)
+constexpr int kFusedFrom = 1024;         // from this many targets on a group is "large": stream 0, the error / background stacks cut after the mask
 constexpr int kEdgeBits = 2 | 4 | 8 | 16;
 
 inline int64_t round_up(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
@@ -301,8 +301,10 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 		const float* frames[3] = {stack.d_images, stack.d_images_err, stack.d_backgrounds};
 		float* cubes[3];
 		for (int k = 0; k < 3; ++k) cubes[k] = static_cast<float*>(dalloc(cube_bytes));
-		// (one binning of the stamps and one launch for the three stacks)
-		ck(g, tp_cut_stamps_multi(g, 3, frames, stack.n_frames, stack.n_rows, stack.n_cols, stack.n_cols, (int64_t)stack.n_rows * stack.n_cols,
+		const bool large = m >= kFusedFrom;
+		// a small group: one binning of the stamps and one launch for the three stacks.  A large group: the images now, the error and
+		// background stacks once the masks are known -- only their in-mask pixel rows are ever read (below)
+		ck(g, tp_cut_stamps_multi(g, large ? 1 : 3, frames, stack.n_frames, stack.n_rows, stack.n_cols, stack.n_cols, (int64_t)stack.n_rows * stack.n_cols,
 			stack.row0, stack.col0, d_stamps, &desc, cubes));
 		// ---- the packed output block (comm.packed_block_layout with the catalogue flags, the sum image and the diagnostics)
 		const size_t P = (size_t)H * W;
@@ -334,22 +336,18 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 		int32_t* d_aperture = static_cast<int32_t*>(dalloc((size_t)m * P * 4));
 		ckh(hipMemsetAsync(d_aperture, 1, (size_t)m * P * 4, g->stream), "hipMemsetAsync(aperture)");
 		// ---- the pass: fused for a large group; a small one is latency-bound and spreads better as three kernels (bit-identical)
-		if (m >= kFusedFrom) {
-			// a few thousand targets are less than one round of the chip for the one-wavefront-per-target launch, and the sum image is
-			// most of its bytes: formed by the stand-alone kernel (every CU streams) the pair takes 1.1 ms where the fused launch with the
-			// sum image inside took 1.8 (2 500 targets; bit-identical: tests/test_gpu_pipeline.py)
-			ck(g, tp_sumimage(g, &desc, cubes[0], d_quality, 0, kBitmask, nullptr, 0, d_sum));
-			ck(g, tp_aperture_photometry_from_sumimage(g, &desc, cubes[0], cubes[1], cubes[2], 0, 0, nullptr, 0, d_quality, 0, kBitmask,
-				d_cat_offsets, d_cat_col_stamp, d_cat_row_stamp, d_cat_tmag, d_cat_col, d_cat_row, d_cat_starid,
-				d_t_row, d_t_col, d_t_tmag, d_t_starid, d_stamps, d_aperture, nullptr,
-				d_sum, d_mask, d_status, d_flags, d_cont, d_diag8, d_cim, lc[0], lc[1], lc[2], lc[3], lc[4], T));
-		} else {
-			ck(g, tp_sumimage(g, &desc, cubes[0], d_quality, 0, kBitmask, nullptr, 0, d_sum));
-			ck(g, tp_k2p2_masks(g, m, H, W, d_sum, d_cat_offsets, d_cat_col_stamp, d_cat_row_stamp, d_cat_tmag, d_cat_col, d_cat_row, d_cat_starid,
-				d_t_row, d_t_col, d_t_tmag, d_t_starid, d_stamps, d_aperture, nullptr, nullptr, d_mask, d_status, d_flags, d_cont, d_diag8, d_cim));
-			ck(g, tp_aperture_extract(g, &desc, cubes[0], cubes[1], cubes[2], 0, 0, nullptr, 0, d_mask, d_stamps, d_status,
-				lc[0], lc[1], lc[2], lc[3], lc[4], T));
-		}
+		// ---- the pass.  The three stand-alone kernels (bit-identical to the fused launch; a small group is latency-bound and spreads
+		// better over the chip this way).  For a large group the cut of the error and background stacks comes BETWEEN mask and extraction
+		// and writes in-mask rows only: of 8.9 GB of cubes per 2 500 stamps of 15 x 15 the passes read 4.4 (the images for the sum image,
+		// a sixth of the rows of all three for the extraction), so two thirds of the old cut's writes were never read
+		ck(g, tp_sumimage(g, &desc, cubes[0], d_quality, 0, kBitmask, nullptr, 0, d_sum));
+		ck(g, tp_k2p2_masks(g, m, H, W, d_sum, d_cat_offsets, d_cat_col_stamp, d_cat_row_stamp, d_cat_tmag, d_cat_col, d_cat_row, d_cat_starid,
+			d_t_row, d_t_col, d_t_tmag, d_t_starid, d_stamps, d_aperture, nullptr, nullptr, d_mask, d_status, d_flags, d_cont, d_diag8, d_cim));
+		if (large)
+			ck(g, tp_cut_stamps_masked(g, 2, frames + 1, stack.n_frames, stack.n_rows, stack.n_cols, stack.n_cols, (int64_t)stack.n_rows * stack.n_cols,
+				stack.row0, stack.col0, d_stamps, &desc, d_mask, cubes + 1));
+		ck(g, tp_aperture_extract(g, &desc, cubes[0], cubes[1], cubes[2], 0, 0, nullptr, 0, d_mask, d_stamps, d_status,
+			lc[0], lc[1], lc[2], lc[3], lc[4], T));
 		// ---- downloads: what the decisions read (status, flags, mask, catalogue flags, sum image) first, with an event; the
 		// diagnostics are computed behind it (nothing of a round is decided from them) and travel with the light curves
 		G.h_block = eng->pinned.get((size_t)G.nbytes, &G.h_cap);

@@ -125,3 +125,37 @@ def test_multi_stack_cut_equals_one_stack_at_a_time(ctx):
 			alone = engine.cut_stamps(ctx, stacks[k], d_stamps, H, W, 0, 44)
 			ctx.sync()
 			np.testing.assert_array_equal(together[k].data.to_host(), alone.data.to_host())
+
+
+def test_masked_cut_writes_the_in_mask_rows_only(ctx):
+	"""tp_cut_stamps_masked (the tile lists hold in-mask pixels instead of stamps): the rows of in-mask pixels equal the full cut's,
+	every other row of the cube is left as it was; stamps that reach beyond the frame (in-mask pixels there are NaN), an empty mask,
+	a full mask."""
+	import ctypes
+	from photometry_amd import engine
+	from photometry_amd.device import DeviceCube
+	rng = np.random.default_rng(23)
+	for (T, R, C, H, W, n) in ((70, 60, 130, 15, 15, 300), (33, 64, 64, 11, 7, 40)):
+		stacks = [ctx.array(rng.normal(0, 1, (T, R, C)).astype('float32')) for _ in range(2)]
+		r0 = rng.integers(-3, R - H + 4, n)
+		c0 = rng.integers(-3 + 44, C - W + 4 + 44, n)
+		d_stamps = ctx.array(np.stack((r0, r0 + H, c0, c0 + W), axis=1).astype('int32'))
+		mask = (rng.random((n, H, W)) < 0.16).astype('uint8')
+		mask[0] = 0
+		mask[1] = 1
+		d_mask = ctx.array(mask)
+		full = engine.cut_stamps_multi(ctx, stacks, d_stamps, H, W, 0, 44)
+		outs = [DeviceCube(ctx, n, T, H, W) for _ in stacks]
+		for o in outs:
+			o.data.fill_bytes(0x7b)                  # a pattern no cut produces
+		desc = outs[0].desc
+		fp = (ctypes.c_void_p * 2)(*[f.ptr for f in stacks])
+		cp = (ctypes.c_void_p * 2)(*[o.ptr for o in outs])
+		ctx._check(ctx.lib.tp_cut_stamps_masked(ctx.handle, 2, fp, T, R, C, C, R * C, 0, 44, d_stamps.ptr, ctypes.byref(desc), d_mask.ptr, cp))
+		ctx.sync()
+		pattern = np.array([0x7b7b7b7b], dtype='uint32').view('float32')[0]
+		for k in range(2):
+			got, want = outs[k].data.to_host(), full[k].data.to_host()
+			m = mask.astype(bool)
+			np.testing.assert_array_equal(got[m], want[m])
+			assert np.all(got[~m] == pattern)
