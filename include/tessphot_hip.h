@@ -403,7 +403,7 @@ int tp_radial_ring_modes_zoom(tp_ctx* ctx, const float* d_frames, int32_t n_fram
 /* d_out = float32(radial + square): the total background of backgrounds.py:209 from the two implicit images */
 int tp_radial_evaluate_zoom(tp_ctx* ctx, int32_t n_frames, int32_t frame_rows, int32_t frame_cols, int64_t frame_stride,
 	const tp_radial_image* radial, const tp_zoom_image* add, float* d_out);
-/* tp_background_mesh with the radial component to subtract (backgrounds.py:200) evaluated from its ring profile; max_knots <= 128 */
+/* tp_background_mesh with the radial component to subtract (backgrounds.py:200) evaluated from its ring profile; max_knots <= 72 */
 int tp_background_mesh_radial(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
 	int64_t row_pitch, int64_t frame_stride, const uint8_t* d_exclude, int64_t exclude_frame_stride,
 	const tp_radial_image* radial, double flux_cutoff, int32_t box_size, double* d_mesh, int32_t* d_nmasked);

@@ -26,7 +26,7 @@ namespace {
 constexpr int kMeshThreads = 256;
 constexpr int kKeysPerThread = 16;
 constexpr int kMeshKeys = kMeshThreads * kKeysPerThread;   // 4096 = 64 x 64
-constexpr int kMaxFusedKnots = 128;                        // knots + coefficients of a frame's ring profile staged in LDS by the mesh kernel
+constexpr int kMaxFusedKnots = 72;                         // knots + coefficients + reciprocals of a frame's ring profile staged in LDS by the mesh kernel (64 rings + 4 + pad: 4.6 KB)
 
 __device__ __forceinline__ double mesh_block_sum(double v, double* red) {
 	const int tid = threadIdx.x;
@@ -508,7 +508,7 @@ static int background_mesh_launch(tp_ctx* ctx, const char* who, const float* d_f
 	if (radial) {
 		TP_REQUIRE(ctx, d_subtract == nullptr, "tp_background_mesh_radial: a stored image and a ring profile to subtract");
 		TP_REQUIRE(ctx, radial->d_knots && radial->d_coefs && radial->d_n_knots && radial->d_zeropoint && radial->max_knots >= 8 && radial->max_knots <= kMaxFusedKnots,
-			"tp_background_mesh_radial: bad ring profile (max_knots 8..128)");
+			"tp_background_mesh_radial: bad ring profile (max_knots 8..72)");
 		a.radial_on = true;
 		a.radial = RadialSpline{radial->col_offset, radial->xcen, radial->ycen, radial->d_knots, radial->d_coefs, radial->d_n_knots, radial->max_knots, radial->d_zeropoint};
 	}

@@ -241,7 +241,7 @@ def fit_background_frames(ctx, frames, flux_cutoff=8e4, box=64, exclude=None, ou
 	# kernel (<= 64 rings: a 2048 x 2048 CCD has 39); otherwise on the host with the reference's own scipy call
 	on_device = geo.n_rings <= 64 and (radial_smooth or 0) <= 8
 	K = max(geo.n_rings + 4, 8)
-	implicit = bool(implicit) and K <= 128
+	implicit = bool(implicit) and K <= 72      # (what the mesh kernel stages in LDS: tp_background_mesh_radial)
 	d_bin_center = ctx.array(np.asarray(geo.bin_center, dtype='float64'))
 	d_knots, d_coefs, d_nk = ctx.zeros((T, K), 'float64'), ctx.zeros((T, K), 'float64'), ctx.zeros((T,), 'int32')
 	ny, nx = -(-R // box), -(-C // box)
