@@ -675,7 +675,15 @@ int tp_frames_submit(tp_frames_engine* eng, const tp_frames_stack* stack, const 
 	job->quality.assign(h_quality, h_quality + job->T);
 	job->budget = budget_bytes > 0 ? budget_bytes : (double)eng->hbm_bytes / 4.0;
 	eng->running.fetch_add(1);
-	job->worker = std::thread([job] { job->run(); job->eng->running.fetch_sub(1); });
+	try {
+		job->worker = std::thread([job] { job->run(); job->eng->running.fetch_sub(1); });
+	} catch (...) {          // no thread to be had: the slot is free again, the job never existed
+		eng->running.fetch_sub(1);
+		{ std::lock_guard<std::mutex> lk(eng->m); eng->busy[slot] = 0; }
+		delete job;
+		tp_global_err = "tp_frames_submit: could not start the job's worker thread";
+		return TP_ERR_INVALID;
+	}
 	*out = job;
 	return TP_OK;
 	TP_API_END((tp_ctx*)nullptr)
