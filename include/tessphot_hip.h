@@ -77,7 +77,7 @@ int tp_device_info(tp_ctx* ctx, char* name, int name_len, int32_t* n_cu, uint64_
 /* NUMA node of the device's PCIe slot (-1: unknown), for binding the host threads that feed it (device.bind_host_to_device). */
 int tp_device_numa_node(int device, int* node);
 
-/* Device memory.  tp_free keeps a block for the next tp_malloc of its size class (blocks up to 32 GiB, 64 GiB per context;
+/* Device memory.  tp_free keeps a block for the next tp_malloc of its size class (blocks up to 32 GiB, 160 GiB per context;
  * hipMalloc / hipFree of multi-GB blocks cost milliseconds and synchronise the device); a recycled block is handed out only
  * after everything that was queued on the context's stream when it was freed has run, so it is idle for whichever stream writes
  * it next.  tp_cache_trim gives the cached blocks back to the driver; when an allocation fails the library does so itself, for

@@ -62,7 +62,8 @@ struct tp_ctx {
 	// tp_malloc / tp_free: blocks a caller frees go to a size-keyed cache instead of back to the driver (hipFree synchronises the
 	// whole device, hipMalloc costs tens of microseconds -- and ~12 ms for a multi-GB block: the stamp cubes of the batched frames
 	// entry, measured -- a batch of 10 000 stamps of 15 x 15 is three blocks of 11.8 GB, and outside the cache every call paid 1.2 s
-	// for them); reuse is ordered by the context's stream.  Blocks up to cache_block (32 GiB), cache_limit (64 GiB) per context.
+	// for them); reuse is ordered by the context's stream.  Blocks up to cache_block (32 GiB), cache_limit (160 GiB) per context (a batch of
+	// 20 000 stamps is three blocks of 23.6 GB: with 64 GiB the third one went back to the driver every call, 1.2 s instead of 0.08).
 	// When an allocation fails the context's own cache goes back to the driver first, then the caches of every other context of
 	// the device (api.cpp keeps a registry; cache_mutex serialises a context's cache against such a visit from another thread).
 	// A cached block carries an event recorded on the context's stream when it was freed; tp_malloc hands it out again only once
@@ -72,7 +73,7 @@ struct tp_ctx {
 	struct cached_block { void* ptr; hipEvent_t freed; };
 	std::multimap<size_t, cached_block> cache;
 	std::map<void*, size_t> live;   // blocks handed out by tp_malloc -> capacity
-	size_t cache_bytes = 0, cache_limit = (size_t)64 << 30, cache_block = (size_t)32 << 30;
+	size_t cache_bytes = 0, cache_limit = (size_t)160 << 30, cache_block = (size_t)32 << 30;
 	std::recursive_mutex cache_mutex;
 	// pinned staging area of the synchronous copy entries (tp_memcpy_h2d / _d2h): pageable transfers go through it in pieces
 	void* stage = nullptr;
