@@ -335,7 +335,6 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 		ckh(hipMemsetAsync(d_diag8, 0, (size_t)m * 64, g->stream), "hipMemsetAsync(diag)");
 		int32_t* d_aperture = static_cast<int32_t*>(dalloc((size_t)m * P * 4));
 		ckh(hipMemsetAsync(d_aperture, 1, (size_t)m * P * 4, g->stream), "hipMemsetAsync(aperture)");
-		// ---- the pass: fused for a large group; a small one is latency-bound and spreads better as three kernels (bit-identical)
 		// ---- the pass.  The three stand-alone kernels (bit-identical to the fused launch; a small group is latency-bound and spreads
 		// better over the chip this way).  For a large group the cut of the error and background stacks comes BETWEEN mask and extraction
 		// and writes in-mask rows only: of 8.9 GB of cubes per 2 500 stamps of 15 x 15 the passes read 4.4 (the images for the sum image,
