@@ -312,3 +312,23 @@ def test_binned_catalogue_selection_equals_the_per_stamp_function():
 	e = {k: v[:0] for k, v in cat.items()}
 	off0, arr0 = pl._catalogs_of_stamps(pl._CatalogIndex(e), st[:3])
 	assert list(off0) == [0, 0, 0, 0] and len(arr0['starid']) == 0
+
+
+def test_bind_host_to_device_leaves_the_affinity_alone_without_a_gpu():
+	"""device.bind_host_to_device: the NUMA node of the GPU's PCIe slot when there is one (the process is then restricted to that
+	node's cores), None -- and an untouched affinity -- when the node is unknown (no GPU here)."""
+	import ctypes
+	from photometry_amd import _lib
+	from photometry_amd.device import bind_host_to_device
+	n = ctypes.c_int(0)
+	_lib.load().tp_device_count(ctypes.byref(n))
+	before = os.sched_getaffinity(0)
+	node = bind_host_to_device(0)
+	after = os.sched_getaffinity(0)
+	try:
+		if n.value <= 0:
+			assert node is None and after == before
+		else:
+			assert node is None or (isinstance(node, int) and node >= 0 and after <= before and len(after) > 0)
+	finally:
+		os.sched_setaffinity(0, before)
