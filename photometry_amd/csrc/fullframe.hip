@@ -4,9 +4,10 @@
 //     pixel mask (:89-97), photutils Background2D on 64 x 64 boxes with SigmaClip(3, maxiters = 5) and the SExtractor estimator
 //     (:200-206), cubic-spline zoom of the filtered mesh.  Alone it is the plain-image branch (bkgiters = 1, :156-157); for TESS
 //     frames it alternates with the radial component of csrc/radial.hip, whose image comes in as d_subtract.
-//     The mesh statistics (every pixel of every frame: the heavy part) and the zoom back to full resolution run here; the
-//     32 x 32 mesh in between (exclusion of mostly-masked boxes, IDW fill, 3 x 3 median filter, spline prefilter) is host
-//     work on a few KB per frame (photometry_amd/prepare.py).
+//     The mesh statistics (every pixel of every frame: the heavy part), the finishing of the 32 x 32 mesh (exclusion of mostly-masked
+//     boxes -- counted AFTER the sigma clip, as photutils does --, IDW fill, 3 x 3 median filter, spline prefilter:
+//     tp_mesh_finish_kernel) and the zoom back to full resolution all run here.  For TESS frames the radial component is not read
+//     from a stored image but evaluated in the mesh kernel from its ring profile (tp_background_mesh_radial, fullframe_dev.h).
 // B2  tp_frames_smooth_time: prepare.py:317-335 for per-pixel background images (nanmean over +-w frames, float32).
 // B3  tp_frames_subtract:    prepare.py:419-425 (image -= background, manual-exclude pixels -> NaN).
 // A1  tp_frames_sumimage:    prepare.py:450-453, 459 (mean over the good-quality frames, NaN pixels skipped).

@@ -5,8 +5,10 @@
 //   tp_radial_ring_modes  per ring of 15 pixels beyond 2400 pixels from the camera centre: the mode of log10(img - square +
 //                         zeropoint) -- argmax of statsmodels' FFT Gaussian KDE on 2048 grid points with the
 //                         normal-reference bandwidth (_reduce_mode :20-32, binned_statistic :171-176)
-//   (host, photometry_amd/prepare.py: 3-point median of the ~40 ring modes and the interpolating cubic spline, :179-187)
+//   tp_radial_profiles    3-point median of the ~40 ring modes and the interpolating cubic spline through them              (:179-187)
 //   tp_radial_evaluate    img_bkg_radial = 10**spline(r) - zeropoint for every pixel (ext = 3: constant beyond the end knots), :188
+//   The *_zoom entries take the square component (the previous iteration's zoomed mesh) as spline coefficients and evaluate it where
+//   it is read (fullframe_dev.h): inside the alternation no frame-sized image is stored.
 //
 // The geometry (distance of every pixel from the camera centre, ring membership) does not depend on the frame: the host
 // lists the pixels of every ring once (row-major inside a ring, like r[~mask] in the reference) and the ring kernel walks
