@@ -102,13 +102,17 @@ __global__ __launch_bounds__(kMeshThreads) void tp_bkg_mesh_kernel(MeshArgs a)
 	}
 	const int n = (int)mesh_block_sum((double)nvalid, red);
 	__syncthreads();
-	// ---- bitonic sort of the 4096 keys, ascending; thread t owns keys[16 t .. 16 t + 15]
+	// ---- bitonic sort of the 4096 keys, ascending; thread t owns keys[16 t .. 16 t + 15] in registers.  A compare-exchange stage
+	// of stride s pairs index i with i ^ s: s < 16 is another register of the thread, 16 <= s < 1024 the same register of lane
+	// ^ (s / 16) of the wavefront (DPP for lane ^ 1, ^ 2; ds_swizzle for ^ 4, ^ 8, ^ 16; ds_bpermute for ^ 32: no memory, no barrier),
+	// and only s = 1024, 2048 (another wavefront: 3 of the 78 stages) go through LDS.  Round 4 ran the 36 stages with s >= 16 through
+	// LDS with a barrier each (~135 instructions per stage and thread); a cross-lane stage is 16 x (move + v_med3).
 	float v[kKeysPerThread];
 	{
 		const float4* k4 = reinterpret_cast<const float4*>(keys + tid * kKeysPerThread);
 #pragma unroll
 		for (int q = 0; q < 4; ++q) { const float4 t = k4[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
-		// sizes 2, 4, 8 inside the thread: direction from the local index; size 16: from the thread index
+		// sizes 2, 4, 8 inside the thread: direction from the local index
 #pragma unroll
 		for (int size = 2; size <= 8; size <<= 1) {
 #pragma unroll
@@ -124,31 +128,52 @@ __global__ __launch_bounds__(kMeshThreads) void tp_bkg_mesh_kernel(MeshArgs a)
 				}
 			}
 		}
-		local_tail<8>(v, (tid & 1) == 0);     // size 16: up iff bit 4 of the global index is clear
+	}
+	__syncthreads();   // (every thread has its keys in registers: the LDS array is free for the cross-wavefront stages)
+	const int lane = tid & 63;
+	const int partner32 = (lane ^ 32) << 2;
+#pragma unroll 1
+	for (int size = 16; size <= kMeshKeys; size <<= 1) {
+		// ascending where bit `size` of the global index is clear; the last merge is ascending everywhere
+		const bool up = (size == kMeshKeys) || (((tid * kKeysPerThread) & size) == 0);
+		// ---- strides 2048, 1024: the partner is the same lane of another wavefront -- through LDS
+		for (int stride = size >> 1; stride >= 1024; stride >>= 1) {
+			float4* o4 = reinterpret_cast<float4*>(keys + tid * kKeysPerThread);
+#pragma unroll
+			for (int q = 0; q < 4; ++q) o4[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+			__syncthreads();
+			const int ptid = tid ^ (stride / kKeysPerThread);
+			const float sel = ((((tid * kKeysPerThread) & stride) == 0) == up) ? -inf : inf;   // the lower index keeps the minimum when ascending
+			const float4* p4 = reinterpret_cast<const float4*>(keys + ptid * kKeysPerThread);
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const float4 t = p4[q];
+				v[4 * q] = __builtin_amdgcn_fmed3f(v[4 * q], t.x, sel); v[4 * q + 1] = __builtin_amdgcn_fmed3f(v[4 * q + 1], t.y, sel);
+				v[4 * q + 2] = __builtin_amdgcn_fmed3f(v[4 * q + 2], t.z, sel); v[4 * q + 3] = __builtin_amdgcn_fmed3f(v[4 * q + 3], t.w, sel);
+			}
+			__syncthreads();
+		}
+		// ---- strides 512 .. 16: the same register of lane ^ 32 .. lane ^ 1
+		auto cross = [&](auto fetch, int lane_bit) {
+			const float sel = (((lane & lane_bit) == 0) == up) ? -inf : inf;
+#pragma unroll
+			for (int j = 0; j < kKeysPerThread; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], fetch(v[j]), sel);
+		};
+		if (size >= 1024) cross([&](float x) { return __int_as_float(__builtin_amdgcn_ds_bpermute(partner32, __float_as_int(x))); }, 32);
+		if (size >= 512) cross([](float x) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F)); }, 16);
+		if (size >= 256) cross([](float x) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x201F)); }, 8);
+		if (size >= 128) cross([](float x) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x101F)); }, 4);
+		if (size >= 64) cross([](float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true)); }, 2);
+		if (size >= 32) cross([](float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true)); }, 1);
+		// ---- strides 8 .. 1 inside the thread
+		local_tail<8>(v, up);
+	}
+	{
 		float4* o4 = reinterpret_cast<float4*>(keys + tid * kKeysPerThread);
 #pragma unroll
 		for (int q = 0; q < 4; ++q) o4[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 	}
 	__syncthreads();
-	for (int size = 32; size <= kMeshKeys; size <<= 1) {
-		for (int stride = size >> 1; stride >= kKeysPerThread; stride >>= 1) {
-			for (int t = tid; t < kMeshKeys / 2; t += kMeshThreads) {
-				const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)), hi = lo + stride;
-				const bool up = ((lo & size) == 0) || size == kMeshKeys;
-				const float x = keys[lo], y = keys[hi];
-				if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
-			}
-			__syncthreads();
-		}
-		const float4* k4 = reinterpret_cast<const float4*>(keys + tid * kKeysPerThread);
-#pragma unroll
-		for (int q = 0; q < 4; ++q) { const float4 t = k4[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
-		local_tail<8>(v, ((tid * kKeysPerThread) & size) == 0 || size == kMeshKeys);
-		float4* o4 = reinterpret_cast<float4*>(keys + tid * kKeysPerThread);
-#pragma unroll
-		for (int q = 0; q < 4; ++q) o4[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-		__syncthreads();
-	}
 	// ---- SigmaClip(3, maxiters = 5) on the rank range [lo, hi), then the SExtractor estimate
 	double result = __builtin_nan("");
 	int nkept = 0;
