@@ -32,6 +32,7 @@ namespace {
 constexpr int kRadThreads = 256;
 constexpr int kKdeGrid = 2048;
 constexpr int kKdeLog2 = 11;
+constexpr int kRadBatch = 8;    // loads of the ring's scratch row in flight per thread
 
 struct RadialImage {
 	const float* frames; int64_t frame_stride;
@@ -42,15 +43,19 @@ struct RadialImage {
 };
 
 // backgrounds.py:89-97 on the RAW image; value = img - square (float64 once a square component exists, float32 before)
-__device__ __forceinline__ bool radial_pixel(const RadialImage& a, int frame, int64_t p, double& value) {
-	const float x = a.frames[(int64_t)frame * a.frame_stride + p];
-	bool ok = (x >= 0.f) && (x <= a.flux_cutoff);
-	if (a.exclude && a.exclude[(int64_t)frame * a.exclude_stride + p]) ok = false;
+// (x, excluded: the pixel's value and manual-exclude flag, loaded by the caller -- the ring kernel keeps several in flight)
+__device__ __forceinline__ bool radial_pixel_loaded(const RadialImage& a, int frame, int64_t p, float x, bool excluded, double& value) {
+	bool ok = (x >= 0.f) && (x <= a.flux_cutoff) && !excluded;
 	if (a.square) value = (double)x - (double)a.square[(int64_t)frame * a.square_stride + p];
 	else if (a.zoom_on) { const uint32_t q = (uint32_t)p, row = q / (uint32_t)a.zoom.n_cols;   // (pixel indices fit 31 bits: radial_image_ok)
 		value = (double)x - (double)zoom_value(a.zoom, frame, (int)row, (int)(q - row * (uint32_t)a.zoom.n_cols)); }
 	else value = (double)x;
 	return ok;
+}
+__device__ __forceinline__ bool radial_pixel(const RadialImage& a, int frame, int64_t p, double& value) {
+	const float x = a.frames[(int64_t)frame * a.frame_stride + p];
+	const bool excluded = a.exclude && a.exclude[(int64_t)frame * a.exclude_stride + p];
+	return radial_pixel_loaded(a, frame, p, x, excluded, value);
 }
 
 __device__ __forceinline__ double wave_min(double v) {
@@ -155,9 +160,17 @@ __device__ void select_pair(const double* __restrict__ vals, int n, int k, int* 
 	for (int shift = 56; shift >= 0; shift -= 8) {
 		hist[tid] = 0;
 		__syncthreads();
-		for (int i = tid; i < n; i += kRadThreads) {
-			const uint64_t key = order_key(vals[i]);
-			if ((key & pmask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255u)], 1);
+		// (eight loads in flight per thread: the row lives in L2, and with one ring per workgroup and two or three workgroups per CU
+		// nothing else hides a load's latency -- a load per iteration was most of this kernel's time)
+		for (int i0 = tid; i0 < n; i0 += kRadBatch * kRadThreads) {
+			double x[kRadBatch];
+#pragma unroll
+			for (int u = 0; u < kRadBatch; ++u) { const int i = i0 + u * kRadThreads; x[u] = vals[(i < n) ? i : (n - 1)]; }
+#pragma unroll
+			for (int u = 0; u < kRadBatch; ++u) {
+				const uint64_t key = order_key(x[u]);
+				if (i0 + u * kRadThreads < n && (key & pmask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255u)], 1);
+			}
 		}
 		__syncthreads();
 		{
@@ -186,10 +199,16 @@ __device__ void select_pair(const double* __restrict__ vals, int n, int k, int* 
 	// the next order statistic: the same value if enough copies of it exist, else the smallest larger one
 	int le = 0;
 	double nxt = __builtin_inf();
-	for (int i = tid; i < n; i += kRadThreads) {
-		const double x = vals[i];
-		le += (x <= v0) ? 1 : 0;
-		if (x > v0) nxt = fmin(nxt, x);
+	for (int i0 = tid; i0 < n; i0 += kRadBatch * kRadThreads) {
+		double x[kRadBatch];
+#pragma unroll
+		for (int u = 0; u < kRadBatch; ++u) { const int i = i0 + u * kRadThreads; x[u] = vals[(i < n) ? i : (n - 1)]; }
+#pragma unroll
+		for (int u = 0; u < kRadBatch; ++u) {
+			if (i0 + u * kRadThreads >= n) continue;
+			le += (x[u] <= v0) ? 1 : 0;
+			if (x[u] > v0) nxt = fmin(nxt, x[u]);
+		}
 	}
 	const int n_le = (int)block_reduce<0>((double)le, red);
 	nxt = block_reduce<1>(nxt, red);
@@ -235,10 +254,26 @@ __global__ __launch_bounds__(kRadThreads) void tp_radial_ring_kernel(RingArgs a)
 	const int lane = tid & 63, wave = tid >> 6;
 	int base = 0;
 	double sum = 0.0, mn = __builtin_inf(), mx = -__builtin_inf();
-	for (int i0 = p0; i0 < p1; i0 += kRadThreads) {
+	for (int ib = p0; ib < p1; ib += kRadBatch * kRadThreads) {
+	// the pixel indices, then the pixels, of the next kRadBatch steps: two dependent loads per step would otherwise be waited
+	// for one step at a time
+	int pix[kRadBatch];
+	float xin[kRadBatch];
+	bool exc[kRadBatch];
+#pragma unroll
+	for (int u = 0; u < kRadBatch; ++u) { const int i = ib + u * kRadThreads + tid; pix[u] = a.ring_pixels[(i < p1) ? i : (p1 - 1)]; }
+#pragma unroll
+	for (int u = 0; u < kRadBatch; ++u) {
+		xin[u] = a.img.frames[(int64_t)frame * a.img.frame_stride + pix[u]];
+		exc[u] = a.img.exclude && a.img.exclude[(int64_t)frame * a.img.exclude_stride + pix[u]];
+	}
+#pragma unroll
+	for (int u = 0; u < kRadBatch; ++u) {
+		const int i0 = ib + u * kRadThreads;
+		if (i0 >= p1) break;                        // uniform
 		const int i = i0 + tid;
 		double v = 0.0, lg = 0.0;
-		const bool keep = (i < p1) && radial_pixel(a.img, frame, a.ring_pixels[i], v);
+		const bool keep = (i < p1) && radial_pixel_loaded(a.img, frame, pix[u], xin[u], exc[u], v);
 		if (keep) {
 			if (single) lg = (double)(float)log10((double)((float)v + zp32));
 			else lg = log10(v + zp);
@@ -256,6 +291,7 @@ __global__ __launch_bounds__(kRadThreads) void tp_radial_ring_kernel(RingArgs a)
 		base += total;
 		__syncthreads();
 	}
+	}
 	const int n = base;
 	__threadfence_block();
 	if (a.counts && tid == 0) a.counts[(int64_t)frame * a.n_rings + ring] = n;
@@ -272,7 +308,13 @@ __global__ __launch_bounds__(kRadThreads) void tp_radial_ring_kernel(RingArgs a)
 	// ---- 2. spread: std (ddof = 1) and inter-quartile range
 	const double mean = sum / (double)n;
 	double ss = 0.0;
-	for (int i = tid; i < n; i += kRadThreads) { const double d = vals[i] - mean; ss += d * d; }
+	for (int i0 = tid; i0 < n; i0 += kRadBatch * kRadThreads) {
+		double x[kRadBatch];
+#pragma unroll
+		for (int u = 0; u < kRadBatch; ++u) { const int i = i0 + u * kRadThreads; x[u] = vals[(i < n) ? i : (n - 1)]; }
+#pragma unroll
+		for (int u = 0; u < kRadBatch; ++u) if (i0 + u * kRadThreads < n) { const double d = x[u] - mean; ss += d * d; }   // (the order of round 4: i ascending)
+	}
 	ss = block_reduce<0>(ss, red);
 	const double sd = sqrt(ss / (double)(n - 1));
 	double a0, a1, b0, b1;
@@ -305,8 +347,14 @@ __global__ __launch_bounds__(kRadThreads) void tp_radial_ring_kernel(RingArgs a)
 	}
 	__syncthreads();
 	constexpr double kFix = 1099511627776.0;   // 2^40
-	for (int i = tid; i < n; i += kRadThreads) {
-		const double lx = (vals[i] - lo) / delta;
+	for (int i0 = tid; i0 < n; i0 += kRadBatch * kRadThreads) {
+		double xin[kRadBatch];
+#pragma unroll
+		for (int u = 0; u < kRadBatch; ++u) { const int i = i0 + u * kRadThreads; xin[u] = vals[(i < n) ? i : (n - 1)]; }
+#pragma unroll
+		for (int u = 0; u < kRadBatch; ++u) {
+		if (i0 + u * kRadThreads >= n) continue;
+		const double lx = (xin[u] - lo) / delta;
 		const int li = (int)lx;
 		const double rem = lx - (double)li;
 		if (li > 1 && li < kKdeGrid) {
@@ -314,6 +362,7 @@ __global__ __launch_bounds__(kRadThreads) void tp_radial_ring_kernel(RingArgs a)
 			// bit-reversed positions: the FFT below is decimation in time
 			atomicAdd(&bins[__brev((unsigned)li) >> (32 - kKdeLog2)], (unsigned long long)kFix - q);
 			if (li + 1 < kKdeGrid) atomicAdd(&bins[__brev((unsigned)(li + 1)) >> (32 - kKdeLog2)], q);
+		}
 		}
 	}
 	__syncthreads();
