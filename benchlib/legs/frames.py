@@ -71,14 +71,14 @@ def leg_frames(ctx, args, T, np, pipeline):
 	gc.collect()   # (the legs before this one leave a large heap: a full collection in the middle of a 70 ms timing is 10 % of it)
 	reps = []
 	okc = 0
-	for rep in range(9):
+	for rep in range(14):
 		t2 = time.perf_counter()
 		okc = 0
 		for res in tessphot_frames_pipelined(ctx, stack, iter(batches), cat, tstamp, quality, in_flight=4):
 			okc += int(np.sum((res.status == 1) | (res.status == 3)))
 			res = None
 		reps.append(time.perf_counter() - t2)
-	dp = sorted(reps[4:])[len(reps[4:]) // 2]      # median of the last five runs (the first ones fill the allocation pools of four jobs)
+	dp = sorted(reps[-5:])[2]      # median of the last five runs (the allocation pools of the four jobs' sixteen contexts fill over the first ones)
 	piped = {'what': f'tessphot_frames_pipelined: {NB} consecutive batches of {N} targets of the same region, four jobs of the native engine in flight '
 		'(submit / collect: the rounds of a batch are driven by a worker thread of the library; the first round of a batch runs under the '
 		'latency-bound stamp-resize rounds of the others; every batch equals a call of its own: tests/test_gpu_resize.py)',
