@@ -38,6 +38,17 @@ __device__ __forceinline__ double mesh_block_sum(double v, double* red) {
 	__syncthreads();
 	return (red[0] + red[1]) + (red[2] + red[3]);
 }
+// two sums at once (red: 8 doubles)
+__device__ __forceinline__ void mesh_block_sum2(double& x, double& y, double* red) {
+	const int tid = threadIdx.x;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) { x += __shfl_down(x, off, 64); y += __shfl_down(y, off, 64); }
+	__syncthreads();
+	if ((tid & 63) == 0) { red[tid >> 6] = x; red[4 + (tid >> 6)] = y; }
+	__syncthreads();
+	x = (red[0] + red[1]) + (red[2] + red[3]);
+	y = (red[4] + red[5]) + (red[6] + red[7]);
+}
 
 // ascending / descending compare-exchange network on 16 registers for strides 8, 4, 2, 1 (one merge tail)
 template <int STRIDE>
@@ -65,7 +76,7 @@ struct MeshArgs {
 __global__ __launch_bounds__(kMeshThreads) void tp_bkg_mesh_kernel(MeshArgs a)
 {
 	__shared__ __align__(16) float keys[kMeshKeys];
-	__shared__ double red[4];
+	__shared__ double red[8];
 	__shared__ double sp[kRadialStageDoubles(kMaxFusedKnots)];
 	const int bx = blockIdx.x, by = blockIdx.y, frame = blockIdx.z;
 	const int tid = threadIdx.x;
@@ -174,29 +185,47 @@ __global__ __launch_bounds__(kMeshThreads) void tp_bkg_mesh_kernel(MeshArgs a)
 		for (int q = 0; q < 4; ++q) o4[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 	}
 	__syncthreads();
-	// ---- SigmaClip(3, maxiters = 5) on the rank range [lo, hi), then the SExtractor estimate
+	// ---- SigmaClip(3, maxiters = 5) on the rank range [lo, hi), then the SExtractor estimate.  The keys are sorted, so what a pass
+	// clips is a piece at each end of the range: found by two binary searches, and the sums of the kept set follow by taking the
+	// clipped keys' contributions off running sums (round 4 made three strided passes over the whole range and four workgroup
+	// reductions per iteration).  The sums run over x - c, c = the first median: the one-pass variance then has nothing to cancel.
 	double result = __builtin_nan("");
 	int nkept = 0;
 	if (n > 0) {
 		int lo = 0, hi = n;
+		const double c0 = ((double)keys[(n - 1) >> 1] + (double)keys[n >> 1]) / 2.0;
+		double s1 = 0.0, s2 = 0.0;
+		for (int i = tid; i < n; i += kMeshThreads) { const double d = (double)keys[i] - c0; s1 += d; s2 += d * d; }
+		mesh_block_sum2(s1, s2, red);
 		double med = 0.0, mean = 0.0, sd = 0.0;
 		for (int it = 0; it <= 5; ++it) {
 			const int m = hi - lo;
 			const int m1 = lo + (m >> 1), m0 = (m & 1) ? m1 : (m1 - 1);
 			med = ((double)keys[m0] + (double)keys[m1]) / 2.0;
-			double s = 0.0;
-			for (int i = lo + tid; i < hi; i += kMeshThreads) s += (double)keys[i];
-			mean = mesh_block_sum(s, red) / (double)m;
-			double q = 0.0;
-			for (int i = lo + tid; i < hi; i += kMeshThreads) { const double d = (double)keys[i] - mean; q += d * d; }
-			sd = sqrt(mesh_block_sum(q, red) / (double)m);      // np.std: population, two-pass
+			const double mc = s1 / (double)m;
+			mean = c0 + mc;
+			double var = s2 / (double)m - mc * mc;     // np.std: population
+			if (!(var > 0.0)) var = 0.0;
+			sd = sqrt(var);
 			if (it == 5) break;
 			const double tlo = med - 3.0 * sd, thi = med + 3.0 * sd;
-			int below = 0, above = 0;
-			for (int i = lo + tid; i < hi; i += kMeshThreads) { const double x = (double)keys[i]; below += (x < tlo); above += (x > thi); }
-			const int nb = (int)mesh_block_sum((double)below, red), na = (int)mesh_block_sum((double)above, red);
+			// first key >= tlo, first key > thi (every thread the same search: broadcast reads)
+			int a0 = lo, a1 = hi;
+			while (a0 < a1) { const int mid = (a0 + a1) >> 1; if ((double)keys[mid] < tlo) a0 = mid + 1; else a1 = mid; }
+			const int nb = a0 - lo;
+			int b0 = lo, b1 = hi;
+			while (b0 < b1) { const int mid = (b0 + b1) >> 1; if ((double)keys[mid] > thi) b1 = mid; else b0 = mid + 1; }
+			const int na = hi - b0;
 			if (nb == 0 && na == 0) break;
+			double r1 = 0.0, r2 = 0.0;
+			for (int i = tid; i < nb + na; i += kMeshThreads) {
+				const double d = (double)keys[(i < nb) ? (lo + i) : (hi - na + (i - nb))] - c0;
+				r1 += d; r2 += d * d;
+			}
+			mesh_block_sum2(r1, r2, red);
+			s1 -= r1; s2 -= r2;
 			lo += nb; hi -= na;
+			if (hi <= lo) break;       // (cannot happen: the median is never clipped)
 		}
 		if (sd == 0.0) result = mean;
 		else if (fabs(mean - med) / sd < 0.3) result = 2.5 * med - 1.5 * mean;
