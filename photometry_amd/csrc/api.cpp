@@ -136,6 +136,7 @@ int tp_ctx_destroy(tp_ctx* ctx) {
 	(void)hipStreamSynchronize(ctx->stream);
 	(void)tp_comm_destroy(ctx);
 	if (ctx->twiddle) (void)hipFree(ctx->twiddle);
+	if (ctx->order) (void)hipFree(ctx->order);
 	if (ctx->scratch) (void)hipFree(ctx->scratch);
 	if (ctx->store) (void)hipFree(ctx->store);
 	tp_cache_release(ctx);

@@ -55,6 +55,8 @@ struct tp_ctx {
 	int64_t prof_n[TPK_COUNT] = {};
 	double prof_ms[TPK_COUNT] = {};
 	void* twiddle = nullptr;    // device table of the K2P2 128-point DFT (k2p2.hip)
+	// launch order of the fused aperture kernel (fused.hip): the targets of a batch brightest first, cached per (tmag array, size)
+	const void* order_key = nullptr; int order_n = 0; int32_t* order = nullptr;
 	void* scratch = nullptr;    // grow-only device scratch owned by the context (linpsf.hip)
 	size_t scratch_bytes = 0;
 	void* store = nullptr;      // second grow-only buffer: the polynomial coefficient store of tp_linpsf_fit

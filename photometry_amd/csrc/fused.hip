@@ -18,6 +18,8 @@
 #include "sumimage_dev.h"
 #include "aperture_dev.h"
 #include "k2p2_args.h"
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -29,10 +31,12 @@ constexpr int kRows = 8; // pixel rows per A1 step: 8 x 1 KiB loads in flight pe
 template <int VEC, bool VEC4, bool HAS_SUB, int BKG, bool A1>
 __global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a, k2p2::BatchArgs ka, k2p2::Params prm,
 	const double* __restrict__ twid, const int32_t* __restrict__ quality, int64_t quality_stride, uint32_t bitmask,
-	double* __restrict__ sumimage_out)
+	double* __restrict__ sumimage_out, const int32_t* __restrict__ order)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
-	const int target = blockIdx.x;
+	// workgroups start in the order of their index: `order` (a permutation of the targets, brightest first) makes the launch's last,
+	// partly filled round the one of the cheapest targets
+	const int target = order ? order[blockIdx.x] : (int)blockIdx.x;
 	const int lane = threadIdx.x;
 	k2p2::Shared k;
 	k2p2::shared_carve(k, smem, ka.H, ka.W, lane, twid);
@@ -182,6 +186,33 @@ __global__ __launch_bounds__(64, 2) void tp_aperture_fused_kernel(tp_ap::Args a,
 
 } // namespace
 
+// The order in which the targets of a large batch are launched: brightest first.  A target's work grows with its brightness (more
+// pixels above the threshold for the mask builder, a larger mask for the extraction) and a launch of 10 000 one-wavefront targets is
+// 3.26 rounds of the chip: with the cheap targets last the partly filled tail is short (1.40 -> 1.35 ms, measured).  ANY permutation
+// gives the same results, so the order is cached per (magnitude array, size) without regard to the array's contents: a stale order
+// costs time, never correctness.  Built on the host the first time (one small download).
+static const int32_t* fused_launch_order(tp_ctx* ctx, const double* d_tmag, int n)
+{
+	if (n < 4096 || d_tmag == nullptr) return nullptr;      // less than a round and a half: nothing to gain
+	if (ctx->order && ctx->order_key == (const void*)d_tmag && ctx->order_n == n) return ctx->order;
+	std::vector<double> tm((size_t)n);
+	if (hipMemcpyAsync(tm.data(), d_tmag, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return nullptr;
+	if (hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
+	std::vector<int32_t> idx((size_t)n);
+	for (int i = 0; i < n; ++i) idx[(size_t)i] = i;
+	std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return tm[(size_t)x] < tm[(size_t)y]; });   // (NaN magnitudes: wherever they fall)
+	if (ctx->order_n < n) {
+		if (ctx->order) (void)hipFree(ctx->order);
+		ctx->order = nullptr; ctx->order_n = 0;
+		void* p = nullptr;
+		if (tp_device_alloc(ctx, &p, (size_t)n * sizeof(int32_t)) != hipSuccess) return nullptr;
+		ctx->order = static_cast<int32_t*>(p);
+	}
+	if (hipMemcpy(ctx->order, idx.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { ctx->order_key = nullptr; return nullptr; }
+	ctx->order_key = d_tmag; ctx->order_n = n;
+	return ctx->order;
+}
+
 static int aperture_photometry_impl(tp_ctx* ctx, const tp_cube_desc* desc, bool given_sumimage,
 	const float* d_images, const float* d_images_err, const float* d_backgrounds, int32_t bkg_mode, int64_t bkg_series_pitch,
 	const float* d_subtract, int64_t subtract_pitch,
@@ -275,11 +306,12 @@ static int aperture_photometry_impl(tp_ctx* ctx, const tp_cube_desc* desc, bool 
 	else if (bkg_mode == 1) vec4 = vec4 && tp_vec4_ok(d_backgrounds, bkg_series_pitch);
 	if (d_subtract) vec4 = vec4 && tp_vec4_ok(d_subtract, subtract_pitch);
 
+	const int32_t* d_order = fused_launch_order(ctx, d_target_tmag, desc->n_targets);
 	const dim3 grid((unsigned)desc->n_targets), block(64);
 #define TP_FUSED_LAUNCH_A(V, V4, HS, BK, A1) do { \
 		auto kern = tp_aperture_fused_kernel<V, V4, HS, BK, A1>; \
 		if (shmem > 64 * 1024) TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-		TP_LAUNCH(ctx, TPK_FUSED, kern, grid, block, shmem, a, ka, prm, (const double*)ctx->twiddle, d_quality, quality_target_stride, bitmask, d_sumimage); \
+		TP_LAUNCH(ctx, TPK_FUSED, kern, grid, block, shmem, a, ka, prm, (const double*)ctx->twiddle, d_quality, quality_target_stride, bitmask, d_sumimage, d_order); \
 	} while (0)
 #define TP_FUSED_LAUNCH(V, V4, HS, BK) do { if (given_sumimage) TP_FUSED_LAUNCH_A(V, V4, HS, BK, false); else TP_FUSED_LAUNCH_A(V, V4, HS, BK, true); } while (0)
 #define TP_FUSED_BKG(V, V4, HS) do { \
