@@ -445,42 +445,57 @@ __device__ inline double nan_median(const double* v, int n) {
 __global__ __launch_bounds__(64) void tp_radial_profile_kernel(const double* __restrict__ modes, const double* __restrict__ bin_center, int n_rings,
 	int width, int n_frames, int max_knots, double* __restrict__ knots, double* __restrict__ coefs, int32_t* __restrict__ n_knots)
 {
+	// One wavefront per frame.  Round 4 let ONE lane do everything (182 us per launch: a chain of ~3 000 LDS round trips); now the
+	// lanes share what is independent -- the moving medians, the collocation rows, and inside every pivot step of the elimination the
+	// (row, column) entries of the up to four rows it touches -- with every value formed by the same operations in the same order.
 	__shared__ double A[kMaxRings][8];      // banded rows after elimination: columns j0 .. j0 + 6 of the row
-	__shared__ double prof[kMaxRings], x[kMaxRings], y[kMaxRings], trail[kMaxRings], t[kMaxRings + 8];
+	__shared__ double s2l[kMaxRings], prof[kMaxRings], x[kMaxRings], y[kMaxRings], trail[kMaxRings], t[kMaxRings + 8];
 	__shared__ int j0[kMaxRings];
-	const int frame = blockIdx.x;
-	if (frame >= n_frames || threadIdx.x != 0) return;
-	const double* s2 = modes + (int64_t)frame * n_rings;
+	const int frame = blockIdx.x, lane = threadIdx.x;
+	if (frame >= n_frames) return;
 	double* kt = knots + (int64_t)frame * max_knots;
 	double* kc = coefs + (int64_t)frame * max_knots;
 	const int n = n_rings;
+	if (lane < n) s2l[lane] = modes[(int64_t)frame * n_rings + lane];
+	__syncthreads();
 	// ---- move_median_central: trailing nan-median over `width` points (bottleneck.move_median, min_count = 1), shifted to the
 	// centre, the ends redone over the first / last k + 2 points
 	if (width > 1) {
-		for (int i = 0; i < n; ++i) {
-			const int a0 = (i - width + 1 > 0) ? (i - width + 1) : 0;
-			trail[i] = nan_median(s2 + a0, i + 1 - a0);
+		if (lane < n) {
+			const int a0 = (lane - width + 1 > 0) ? (lane - width + 1) : 0;
+			trail[lane] = nan_median(s2l + a0, lane + 1 - a0);
 		}
+		__syncthreads();
 		// np.roll(trail, -width // 2 + 1): Python floor division of the NEGATED width
 		const int shift = -((width + 1) / 2) + 1;
-		for (int i = 0; i < n; ++i) prof[i] = trail[((i - shift) % n + n) % n];
-		for (int k = 0; k < width / 2 + 1 && k < n; ++k) {
-			const int c0 = (k + 2 < n) ? (k + 2) : n;
-			prof[k] = nan_median(s2, c0);
-			prof[n - 1 - k] = nan_median(s2 + n - c0, c0);
+		if (lane < n) prof[lane] = trail[((lane - shift) % n + n) % n];
+		__syncthreads();
+		if (lane == 0) {   // (a handful of points; later ones overwrite earlier ones when the series is very short: in order)
+			for (int k = 0; k < width / 2 + 1 && k < n; ++k) {
+				const int c0 = (k + 2 < n) ? (k + 2) : n;
+				prof[k] = nan_median(s2l, c0);
+				prof[n - 1 - k] = nan_median(s2l + n - c0, c0);
+			}
 		}
-	} else {
-		for (int i = 0; i < n; ++i) prof[i] = s2[i];
+	} else if (lane < n) {
+		prof[lane] = s2l[lane];
 	}
-	int m = 0;
-	for (int i = 0; i < n; ++i) if (prof[i] == prof[i]) { x[m] = bin_center[i]; y[m] = prof[i]; ++m; }
+	__syncthreads();
+	// ---- the rings that have a mode, in order
+	const bool has = (lane < n) && (prof[lane] == prof[lane]);
+	const unsigned long long bal = __ballot(has);
+	const int m = __popcll(bal);
+	if (has) { const int pos = __popcll(bal & ((1ull << lane) - 1ull)); x[pos] = bin_center[lane]; y[pos] = prof[lane]; }
+	__syncthreads();
 	// fewer than 3 points: "The required number of points for qubic spline" (:183); exactly 3: FITPACK refuses (m > k)
-	if (m < 4 || m + 4 > max_knots) { n_knots[frame] = 0; return; }
+	if (m < 4 || m + 4 > max_knots) { if (lane == 0) n_knots[frame] = 0; return; }
 	// ---- knots
-	for (int i = 0; i < 4; ++i) { t[i] = x[0]; t[m + i] = x[m - 1]; }
-	for (int i = 4; i < m; ++i) t[i] = x[i - 2];
-	// ---- collocation rows: the four cubic B-splines that are non-zero at x[i] (de Boor's recurrence)
-	for (int i = 0; i < m; ++i) {
+	if (lane < 4) { t[lane] = x[0]; t[m + lane] = x[m - 1]; }
+	if (lane >= 4 && lane < m) t[lane] = x[lane - 2];
+	__syncthreads();
+	// ---- collocation rows: the four cubic B-splines that are non-zero at x[i] (de Boor's recurrence); lane i builds row i
+	if (lane < m) {
+		const int i = lane;
 		int l = 3;
 		while (l < m - 1 && x[i] >= t[l + 1]) ++l;     // t[l] <= x < t[l + 1]; the last point stays in the last interval
 		double h[4] = {1.0, 0.0, 0.0, 0.0}, hh[4];
@@ -495,46 +510,74 @@ __global__ __launch_bounds__(64) void tp_radial_profile_kernel(const double* __r
 			}
 		}
 		// row i: columns l - 3 .. l; stored relative to the first column the elimination can still touch (i - 3 clipped)
-		j0[i] = (i - 3 > 0) ? (i - 3) : 0;
+		const int jj = (i - 3 > 0) ? (i - 3) : 0;
+		j0[i] = jj;
 		for (int q = 0; q < 8; ++q) A[i][q] = 0.0;
-		for (int q = 0; q < 4; ++q) { const int col = l - 3 + q - j0[i]; if (col >= 0 && col < 8) A[i][col] = h[q]; }
+		for (int q = 0; q < 4; ++q) { const int col = l - 3 + q - jj; if (col >= 0 && col < 8) A[i][col] = h[q]; }
 	}
-	// ---- Gaussian elimination with partial pivoting inside the band (row i has non-zeros in columns i - 3 .. i + 3 at most)
+	__syncthreads();
+	// ---- Gaussian elimination with partial pivoting inside the band (row i has non-zeros in columns i - 3 .. i + 3 at most).
+	// Lane (rr, q) = (lane >> 3, lane & 7) of the first 32 holds entry q of row c + rr.
+	const int rr = lane >> 3, q = lane & 7;
 	for (int c = 0; c < m; ++c) {
+		const int r = c + rr;
+		const bool mine = (rr < 4) && (r < m);
 		// the rows that can have an entry in column c are c .. c + 3; left of column c they are already zero: re-base them to c
-		for (int r = c; r < m && r <= c + 3; ++r) {
+		double val = 0.0;
+		if (mine) {
 			const int sh = c - j0[r];
-			if (sh > 0) {
-				for (int q = 0; q < 8; ++q) A[r][q] = (q + sh < 8) ? A[r][q + sh] : 0.0;
-				j0[r] = c;
-			}
+			val = (sh > 0) ? ((q + sh < 8) ? A[r][q + sh] : 0.0) : A[r][q];
 		}
+		__syncthreads();
+		if (mine) { A[r][q] = val; if (q == 0) j0[r] = c; }
+		__syncthreads();
 		int piv = c;
 		double best = 0.0;
-		for (int r = c; r < m && r <= c + 3; ++r) {
-			const double v = fabs(A[r][0]);
-			if (v > best) { best = v; piv = r; }
+		for (int k = c; k < m && k <= c + 3; ++k) {
+			const double v = fabs(A[k][0]);
+			if (v > best) { best = v; piv = k; }
 		}
-		if (piv != c) {
-			for (int q = 0; q < 8; ++q) { const double tmp = A[c][q]; A[c][q] = A[piv][q]; A[piv][q] = tmp; }
-			const double ty = y[c]; y[c] = y[piv]; y[piv] = ty;
+		if (piv != c) {      // (uniform: every lane found the same pivot)
+			double u0 = 0.0, u1 = 0.0;
+			if (rr == 0) { u0 = A[c][q]; u1 = A[piv][q]; }
+			__syncthreads();
+			if (rr == 0) { A[c][q] = u1; A[piv][q] = u0; }
+			if (lane == 0) { const double ty = y[c]; y[c] = y[piv]; y[piv] = ty; }
+			__syncthreads();
 		}
 		const double d = A[c][0];
-		for (int r = c + 1; r < m && r <= c + 3; ++r) {
-			if (A[r][0] == 0.0) continue;
-			const double f = A[r][0] / d;
-			for (int q = 0; q < 7; ++q) A[r][q] -= f * A[c][q];   // after the exchanges a row reaches at most column c + 6
-			y[r] -= f * y[c];
+		double neu = 0.0, f = 0.0;
+		bool upd = false;
+		if (mine && rr >= 1) {
+			const double a0 = A[r][0];
+			if (a0 != 0.0) {
+				upd = true;
+				f = a0 / d;
+				if (q < 7) neu = A[r][q] - f * A[c][q];   // after the exchanges a row reaches at most column c + 6
+			}
+		}
+		__syncthreads();
+		if (upd) {
+			if (q < 7) A[r][q] = neu;
+			else y[r] -= f * y[c];
+		}
+		__syncthreads();
+	}
+	if (lane == 0) {
+		for (int c = m - 1; c >= 0; --c) {   // row c is stored from column c on
+			double ar[7], yr[7];
+#pragma unroll
+			for (int k = 0; k < 7; ++k) { ar[k] = A[c][k]; yr[k] = (k >= 1 && c + k < m) ? y[c + k] : 0.0; }
+			double acc = y[c];
+#pragma unroll
+			for (int k = 1; k < 7; ++k) if (c + k < m) acc -= ar[k] * yr[k];
+			y[c] = acc / ar[0];
 		}
 	}
-	for (int c = m - 1; c >= 0; --c) {   // row c is stored from column c on
-		double acc = y[c];
-		for (int q = 1; q < 7 && c + q < m; ++q) acc -= A[c][q] * y[c + q];
-		y[c] = acc / A[c][0];
-	}
-	for (int i = 0; i < m + 4; ++i) kt[i] = t[i];
-	for (int i = 0; i < m; ++i) kc[i] = y[i];
-	n_knots[frame] = m + 4;
+	__syncthreads();
+	for (int i = lane; i < m + 4; i += 64) kt[i] = t[i];
+	for (int i = lane; i < m; i += 64) kc[i] = y[i];
+	if (lane == 0) n_knots[frame] = m + 4;
 }
 
 struct EvalArgs {
