@@ -419,9 +419,13 @@ int tp_background_mesh_radial(tp_ctx* ctx, const float* d_frames, int32_t n_fram
  * tp_linpsf_fit (P2-P4) replaces PSF.integrate_to_image (psf.py:122-148), lsfit and the loop / status
  *   logic of LinPSFPhotometry.do_photometry (photometry/linpsf_photometry.py:22-34, 79-219).
  *   d_coef: [n_targets][n*n] spline coefficients, first axis = column direction (psf.py:119,146);
- *   d_knots_x / d_knots_y: [n+4] FITPACK knots; the PRF grid must be uniform with 9 samples per pixel
- *   (the SPOC PRF files) and cutoff_radius <= 5.25 px so that only the uniform part of the knot vector
- *   is touched (LinPSFPhotometry uses 5, linpsf_photometry.py:63).
+ *   d_knots_x / d_knots_y: [n+4] FITPACK knots of ANY strictly increasing sample grid, n = 4 .. 2048 (both axes alike);
+ *   cutoff_radius: any positive radius, +infinity = none (psf.py:142 `cutoff_radius is None`).  The SPOC layout -- evenly
+ *   spaced, 9 samples per pixel, n = 32 .. 140 -- with a radius whose pixel edges stay inside the evenly spaced knots
+ *   (cutoff_radius <= 5.25; LinPSFPhotometry uses 5, linpsf_photometry.py:63) runs on the fast kernels below; the library reads
+ *   that off the knots on the device, and everything else is fitted by general kernels that evaluate the FITPACK box integral
+ *   of psf.py:146 (dblint / fpintb: limits cut to the grid, so pixels beyond the PRF's support contribute zero) per star,
+ *   pixel and cadence, with run-time sized normal equations -- same results, ~100 x slower (tp_linpsf_last_counts [13]).
  *   fitted stars (ragged, CSR): d_star_offsets int64 [n_targets+1]; d_target_index int32 [n_targets]
  *   = index of the main target among its fitted stars (the selection of linpsf_photometry.py:93-104 is
  *   host catalogue work); d_pos_row / d_pos_col float64 [n_fit_stars][pos_pitch] = row_stamp /
@@ -447,7 +451,8 @@ int tp_linpsf_set_path(tp_ctx* ctx, int32_t path);
  * counts[0] targets on the matrix cores, [1] the segments their series were cut into (a star that drifts over more than three
  * knot intervals gets one spline per stretch of the series; without drift one segment per target), [2] targets on the
  * vector-ALU polynomial kernels, [3] on the general kernel (wide excursions inside 16 cadences), [4] with more than 8 fitted
- * stars, [5..8] matrix-core targets with 1..4 fitted stars, [9..12] their segments.  n <= 16 counters are copied. */
+ * stars, [5..8] matrix-core targets with 1..4 fitted stars, [9..12] their segments, [13] targets fitted by the any-grid / any-radius
+ * kernels (then all of them, and [0..12] are zero).  n <= 16 counters are copied. */
 int tp_linpsf_last_counts(tp_ctx* ctx, int64_t* counts, int32_t n);
 /* The positions a fit takes, for a field that moves as a whole: d_pos[s][k] = (double)(d_base[s] + d_shift[k]) -- the float32 sum the
  * plugin's catalogue holds after catalog_attime (BasePhotometry.py:1224-1258) for a translation, widened as
@@ -477,7 +482,10 @@ int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
  *     = the fitted (row_stamp, column_stamp) of the main target, as upstream (:176); a cadence whose fit did not finish within
  *     its iteration limit is NaN and does not update the starting point (:190-194);
  *   d_params_out optional float64 [n_fit_stars * 3][out_pitch] (every fitted parameter), d_nit optional int32
- *     [n_targets][out_pitch] (iterations used), d_status int32 (OK, :196).                                              */
+ *     [n_targets][out_pitch] (iterations used), d_status int32 (OK, :196).
+ *   PRF grid and cutoff_radius as for tp_linpsf_fit: any grid (n = 4 .. 2048), any positive radius or +infinity; the SPOC
+ *   layout with cutoff_radius <= 5.25 (PSFPhotometry uses 5, psf_photometry.py:26, :73)
+ *   runs on the cached-biquartic kernel, anything else on its general instantiation (FITPACK box integral per evaluation). */
 int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images, const float* d_backgrounds,
 	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis,
 	const int64_t* d_star_offsets, const double* d_params0, const uint8_t* d_mini_aperture,

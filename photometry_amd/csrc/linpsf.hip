@@ -256,6 +256,16 @@ __device__ __forceinline__ void emit_segment(SegPlan& g, int target, int t0, int
 	}
 }
 
+// Decides on the device (the knots live there) whether the uniform-grid forms apply: totals[kTotGeneral] = 1 if not.  The plan
+// kernel then does nothing and the host, which reads the totals anyway, sends every target to the general kernels.
+__global__ __launch_bounds__(64) void tp_linpsf_grid_kernel(const double* __restrict__ tx, const double* __restrict__ ty, int n, double cutoff, int force,
+	unsigned long long* __restrict__ totals)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	const bool ok = !force && (cutoff <= 5.25) && uniform_grid_ok(tx, n, cutoff) && uniform_grid_ok(ty, n, cutoff);
+	if (!ok) totals[kTotGeneral] = 1ull;
+}
+
 // totals: kTotPolyItems items (25 doubles each) of the polynomial store; kTotKDoubles doubles of the matrix-core store (laid behind
 // it); kTotPolyTargets targets left to the vector-ALU fit; kTotClass0 + c targets of class c of the matrix-core fit (class_lists[c][..])
 __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan* __restrict__ plans, int32_t* __restrict__ todo,
@@ -282,6 +292,7 @@ __global__ __launch_bounds__(256) void tp_linpsf_plan_kernel(FitArgs a, StarPlan
 	const int64_t s0 = a.star_offsets[target];
 	const int ns = (int)(a.star_offsets[target + 1] - s0);
 	int32_t* ord = order + (int64_t)target * a.n_cad;
+	if (totals[kTotGeneral] != 0) return;   // tp_linpsf_grid_kernel found a grid / cut-off the uniform forms cannot take: the general kernels fit every target
 	if (ns > kMaxStars) return;   // the many-star kernel's targets
 	if (tid == 0) { s_ok = 0; s_nkeys = 0; s_path = kPathPoly; s_nseg = 0; }
 	const bool want_segments = use_mfma && ns >= 1 && ns <= kMfmaStars;
@@ -1290,19 +1301,24 @@ struct ManyScratch {
 	__device__ __forceinline__ double& at(int e) const { return base[(int64_t)e * n_threads + gt]; }
 };
 
-__global__ __launch_bounds__(256) void tp_linpsf_fit_many_kernel(FitArgs a, const int32_t* __restrict__ big_targets, int smax, double* __restrict__ scratch)
+// GENERAL: any knot vectors and any cut-off radius (prf_pixel_general: the FITPACK box integral itself); `big_targets` may be
+// null (= every target, first_target + blockIdx.x) and the table stays in HBM when it does not fit the LDS (table_in_lds = 0).
+template <bool GENERAL>
+__global__ __launch_bounds__(256) void tp_linpsf_fit_many_kernel(FitArgs a, const int32_t* __restrict__ big_targets, int first_target, int smax, double* __restrict__ scratch,
+	int table_in_lds)
 {
-	extern __shared__ __align__(16) double lds[]; // [n*n] coefficient table + 2 x [n+4] knots
-	const int target = big_targets[blockIdx.x];
+	extern __shared__ __align__(16) double lds[]; // [n*n] coefficient table (if it fits) + 2 x [n+4] knots
+	const int target = big_targets ? big_targets[blockIdx.x] : (first_target + (int)blockIdx.x);
 	const int tid = threadIdx.x;
 	const int n = a.n;
-	double* C = lds;
-	double* kn = lds + (size_t)n * n;
-	double* kny = kn + n + 4;
 	const double* cg = a.coef + (int64_t)target * n * n;
-	for (int i = tid; i < n * n; i += blockDim.x) C[i] = cg[i];
+	double* Cl = lds;
+	double* kn = lds + (table_in_lds ? (size_t)n * n : 0);
+	double* kny = kn + n + 4;
+	if (table_in_lds) for (int i = tid; i < n * n; i += blockDim.x) Cl[i] = cg[i];
 	for (int i = tid; i < n + 4; i += blockDim.x) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
 	__syncthreads();
+	const double* C = table_in_lds ? Cl : cg;
 	const int k = blockIdx.y * blockDim.x + tid;
 	if (k >= a.n_cad) return;
 	const int64_t s0 = a.star_offsets[target];
@@ -1316,13 +1332,15 @@ __global__ __launch_bounds__(256) void tp_linpsf_fit_many_kernel(FitArgs a, cons
 		oax = omy + 4 * S, oby = oax + S;
 	for (int s = 0; s < ns; ++s) {
 		const double r = a.pos_row[(s0 + s) * a.pos_pitch + k], c = a.pos_col[(s0 + s) * a.pos_pitch + k];
-		double wx[4], wy[4];
-		int ax0, by0;
-		axis_weights(kn, n, c, h, wx, ax0);
-		axis_weights(kny, n, r, hy, wy, by0);
 		m.at(orow + s) = r; m.at(ocol + s) = c;
-		for (int q = 0; q < 4; ++q) { m.at(omx + 4 * s + q) = wx[q]; m.at(omy + 4 * s + q) = wy[q]; }
-		m.at(oax + s) = (double)ax0; m.at(oby + s) = (double)by0;
+		if (!GENERAL) {
+			double wx[4], wy[4];
+			int ax0, by0;
+			axis_weights(kn, n, c, h, wx, ax0);
+			axis_weights(kny, n, r, hy, wy, by0);
+			for (int q = 0; q < 4; ++q) { m.at(omx + 4 * s + q) = wx[q]; m.at(omy + 4 * s + q) = wy[q]; }
+			m.at(oax + s) = (double)ax0; m.at(oby + s) = (double)by0;
+		}
 		m.at(og + s) = 0.0;
 		for (int u = 0; u < ns; ++u) m.at(oG + s * S + u) = 0.0;
 	}
@@ -1339,12 +1357,17 @@ __global__ __launch_bounds__(256) void tp_linpsf_fit_many_kernel(FitArgs a, cons
 				double v = 0.0;
 				const double dc = (double)j - m.at(ocol + s), dr = (double)i - m.at(orow + s);
 				if (sqrt(dc * dc + dr * dr) < a.cutoff) {
-					double wx[4], wy[4];
-					for (int q = 0; q < 4; ++q) { wx[q] = m.at(omx + 4 * s + q); wy[q] = m.at(omy + 4 * s + q); }
-					int ax = (int)m.at(oax + s) + 9 * j, by = (int)m.at(oby + s) + 9 * i;
-					ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
-					by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
-					v = h2 * prf_pixel(C, n, ax, by, wx, wy);
+					if (GENERAL) {
+						// psf.py:146  integral(column_cen - 0.5, column_cen + 0.5, row_cen - 0.5, row_cen + 0.5)
+						v = prf_pixel_general(C, n, kn, kny, dc - 0.5, dc + 0.5, dr - 0.5, dr + 0.5);
+					} else {
+						double wx[4], wy[4];
+						for (int q = 0; q < 4; ++q) { wx[q] = m.at(omx + 4 * s + q); wy[q] = m.at(omy + 4 * s + q); }
+						int ax = (int)m.at(oax + s) + 9 * j, by = (int)m.at(oby + s) + 9 * i;
+						ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
+						by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
+						v = h2 * prf_pixel(C, n, ax, by, wx, wy);
+					}
 					any = true;
 				}
 				m.at(oav + s) = v;
@@ -1415,11 +1438,12 @@ __global__ __launch_bounds__(256) void tp_linpsf_fit_many_kernel(FitArgs a, cons
 }
 
 // finalise for the targets of the kernel above (same rules as tp_linpsf_finalize_kernel, star loops at run time)
-__global__ __launch_bounds__(256) void tp_linpsf_finalize_many_kernel(FinArgs fa, const int32_t* __restrict__ big_targets)
+template <bool GENERAL>
+__global__ __launch_bounds__(256) void tp_linpsf_finalize_many_kernel(FinArgs fa, const int32_t* __restrict__ big_targets, int first_target)
 {
 	extern __shared__ __align__(16) double lds[];
 	const FitArgs& a = fa.f;
-	const int target = big_targets[blockIdx.x];
+	const int target = big_targets ? big_targets[blockIdx.x] : (first_target + (int)blockIdx.x);
 	const int tid = threadIdx.x;
 	const int n = a.n;
 	const double* C = a.coef + (int64_t)target * n * n;
@@ -1471,14 +1495,18 @@ __global__ __launch_bounds__(256) void tp_linpsf_finalize_many_kernel(FinArgs fa
 			const double dc = (double)j - scol, dr = (double)i - srow;
 			double v = 0.0;
 			if (sqrt(dc * dc + dr * dr) < a.cutoff) {
-				double wx[4], wy[4];
-				int ax0, by0;
-				axis_weights(kn, n, scol, h, wx, ax0);
-				axis_weights(kny, n, srow, hy, wy, by0);
-				int ax = ax0 + 9 * j, by = by0 + 9 * i;
-				ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
-				by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
-				v = h2 * prf_pixel(C, n, ax, by, wx, wy);
+				if (GENERAL) {
+					v = prf_pixel_general(C, n, kn, kny, dc - 0.5, dc + 0.5, dr - 0.5, dr + 0.5);
+				} else {
+					double wx[4], wy[4];
+					int ax0, by0;
+					axis_weights(kn, n, scol, h, wx, ax0);
+					axis_weights(kny, n, srow, hy, wy, by0);
+					int ax = ax0 + 9 * j, by = by0 + 9 * i;
+					ax = ax < 0 ? 0 : (ax > n - 13 ? n - 13 : ax);
+					by = by < 0 ? 0 : (by > n - 13 ? n - 13 : by);
+					v = h2 * prf_pixel(C, n, ax, by, wx, wy);
+				}
 			}
 			if (s == ti) at = v; else others += v * mean[s];
 		}
@@ -1547,9 +1575,9 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	TP_REQUIRE(ctx, d_flux && d_flux_err && d_fluxes_all && d_contamination && d_status, "tp_linpsf_fit: null output pointer");
 	TP_REQUIRE(ctx, pos_pitch >= desc->n_cad && out_pitch >= desc->n_cad, "tp_linpsf_fit: pitch < n_cad");
 	TP_REQUIRE(ctx, d_subtract == nullptr || subtract_pitch >= desc->n_cad, "tp_linpsf_fit: bad subtract pitch");
-	TP_REQUIRE(ctx, n_coef_axis >= 32 && n_coef_axis <= 140, "tp_linpsf_fit: coefficient table must be 32..140 per axis (LDS resident)");
+	TP_REQUIRE(ctx, n_coef_axis >= 4 && n_coef_axis <= 2048, "tp_linpsf_fit: coefficient table must be 4..2048 per axis");
 	TP_REQUIRE(ctx, max_stars >= 1 && max_stars <= kMaxManyStars, "tp_linpsf_fit: at most 64 stars fitted per target");
-	TP_REQUIRE(ctx, cutoff_radius > 0 && cutoff_radius <= 5.25, "tp_linpsf_fit: cutoff_radius must be in (0, 5.25] (uniform-knot region of the PRF spline)");
+	TP_REQUIRE(ctx, cutoff_radius > 0, "tp_linpsf_fit: cutoff_radius must be positive (infinity = no cut-off, psf.py:142 `cutoff_radius is None`)");
 	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
 
 	FitArgs a;
@@ -1605,6 +1633,14 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	fa.todo = use_mfma ? d_todo : nullptr;
 	TP_HIP(ctx, hipMemsetAsync(d_todo, 0, todo_bytes, ctx->stream));
 	TP_HIP(ctx, hipMemsetAsync(d_total, 0, 256, ctx->stream));
+	// the uniform-grid kernels (everything below up to the many-star kernel) need the SPOC layout of the PRF grid: 9 samples per
+	// pixel, the table resident in LDS, the cut-off inside the evenly spaced part of the knots.  Whether that holds is decided
+	// where the knots are; anything else is fitted by the general kernels with the FITPACK box integral itself
+	{
+		const int force = (n_coef_axis < 32 || n_coef_axis > 140 || !(cutoff_radius <= 5.25)) ? 1 : 0;
+		hipLaunchKernelGGL(tp_linpsf_grid_kernel, dim3(1), dim3(64), 0, ctx->stream, d_knots_x, d_knots_y, (int)n_coef_axis, cutoff_radius, force, d_total);
+		TP_LAUNCH_CHECK(ctx, "tp_linpsf_grid_kernel");
+	}
 	if (sort_n > 4096) TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sort_n * sizeof(unsigned long long))));
 	TP_LAUNCH(ctx, TPK_LINPSF_PLAN, tp_linpsf_plan_kernel, dim3((unsigned)desc->n_targets), dim3(256), (size_t)sort_n * sizeof(unsigned long long), a, d_plans, d_todo, d_total, max_origins, d_order, sort_n,
 		d_mplans, d_ulist, d_usig, use_mfma, d_lists, (int)desc->n_targets, d_segs, d_seglists);
@@ -1623,6 +1659,39 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 			c[5 + k] = (int64_t)totals[kTotClass0 + k]; c[9 + k] = (int64_t)totals[kTotSeg0 + k];
 		}
 		c[2] = (int64_t)totals[kTotPolyTargets]; c[3] = (int64_t)totals[kTotDirectTargets];
+	}
+	if (totals[kTotGeneral] != 0) {
+		// ---- any grid, any cut-off: every target through the run-time sized kernel (normal equations in an HBM scratch) with the
+		// FITPACK box integral, a few GiB of scratch at a time
+		std::vector<int64_t> off((size_t)desc->n_targets + 1);
+		TP_HIP(ctx, hipMemcpyAsync(off.data(), d_star_offsets, off.size() * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+		TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		int smax = 1;
+		for (int t = 0; t < desc->n_targets; ++t) {
+			const int ns = (int)(off[t + 1] - off[t]);
+			TP_REQUIRE(ctx, ns >= 0 && ns <= kMaxManyStars, "tp_linpsf_fit: a target has more than 64 fitted stars");
+			if (ns > smax) smax = ns;
+		}
+		const int table_in_lds = (shmem <= (size_t)160 * 1024) ? 1 : 0;
+		const size_t shmem_g = table_in_lds ? shmem : (size_t)2 * (n_coef_axis + 4) * sizeof(double);
+		const int threads_m = 256, nblk_m = (desc->n_cad + threads_m - 1) / threads_m;
+		const size_t per_target = (size_t)(2 * smax * smax + 15 * smax) * sizeof(double) * nblk_m * threads_m;
+		int64_t chunk = (int64_t)(((size_t)4 << 30) / per_target);
+		if (chunk < 1) chunk = 1;
+		if (chunk > desc->n_targets) chunk = desc->n_targets;
+		TP_REQUIRE(ctx, tp_ctx_scratch(ctx, head_bytes + per_target * (size_t)chunk + 256) != nullptr, "tp_linpsf_fit: out of device memory for the scratch of the general kernels");
+		double* d_scr = reinterpret_cast<double*>(static_cast<char*>(ctx->scratch) + head_bytes);
+		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_many_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_g));
+		const size_t shmem_fin_m = shmem_fin + kMaxManyStars * sizeof(double);
+		for (int64_t first = 0; first < desc->n_targets; first += chunk) {
+			const int64_t cnt = (desc->n_targets - first < chunk) ? (desc->n_targets - first) : chunk;
+			TP_LAUNCH(ctx, TPK_LINPSF_FIT_DIRECT, tp_linpsf_fit_many_kernel<true>, dim3((unsigned)cnt, (unsigned)nblk_m), dim3(threads_m), shmem_g, a, (const int32_t*)nullptr, (int)first, smax, d_scr, table_in_lds);
+			TP_LAUNCH_CHECK(ctx, "tp_linpsf_fit_many_kernel (general)");
+			TP_LAUNCH(ctx, TPK_LINPSF_FIN, tp_linpsf_finalize_many_kernel<true>, dim3((unsigned)cnt), dim3(256), shmem_fin_m, fa, (const int32_t*)nullptr, (int)first);
+			TP_LAUNCH_CHECK(ctx, "tp_linpsf_finalize_many_kernel (general)");
+		}
+		ctx->linpsf_counts[13] = desc->n_targets;
+		return TP_OK;
 	}
 	const size_t poly_doubles = ((size_t)totals[kTotPolyItems] * 25 + 32 + 63) & ~(size_t)63;
 	const size_t store_need = (poly_doubles + (size_t)totals[kTotKDoubles] + 64) * sizeof(double);
@@ -1710,11 +1779,11 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 			int32_t* d_big = reinterpret_cast<int32_t*>(base);
 			double* d_scr = reinterpret_cast<double*>(base + list_bytes);
 			TP_HIP(ctx, hipMemcpyAsync(d_big, big.data(), big.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-			TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_many_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-			TP_LAUNCH(ctx, TPK_LINPSF_FIT_DIRECT, tp_linpsf_fit_many_kernel, dim3((unsigned)big.size(), (unsigned)nblk_m), dim3(threads), shmem, a, (const int32_t*)d_big, smax, d_scr);
+			TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_linpsf_fit_many_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+			TP_LAUNCH(ctx, TPK_LINPSF_FIT_DIRECT, tp_linpsf_fit_many_kernel<false>, dim3((unsigned)big.size(), (unsigned)nblk_m), dim3(threads), shmem, a, (const int32_t*)d_big, 0, smax, d_scr, 1);
 			TP_LAUNCH_CHECK(ctx, "tp_linpsf_fit_many_kernel");
 			const size_t shmem_fin_m = shmem_fin + kMaxManyStars * sizeof(double);
-			TP_LAUNCH(ctx, TPK_LINPSF_FIN, tp_linpsf_finalize_many_kernel, dim3((unsigned)big.size()), dim3(256), shmem_fin_m, fa, (const int32_t*)d_big);
+			TP_LAUNCH(ctx, TPK_LINPSF_FIN, tp_linpsf_finalize_many_kernel<false>, dim3((unsigned)big.size()), dim3(256), shmem_fin_m, fa, (const int32_t*)d_big, 0);
 			TP_LAUNCH_CHECK(ctx, "tp_linpsf_finalize_many_kernel");
 			TP_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `big` (host) must outlive the copy
 		}

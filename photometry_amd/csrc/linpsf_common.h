@@ -194,7 +194,7 @@ constexpr int kMfmaLdsSmall = 75776, kMfmaLdsLarge = 157696;
 // the plan kernel lists the targets and the segments of the matrix-core path by their number of fitted stars: class = stars - 1
 constexpr int kMfmaClasses = kMfmaStars;
 // counters the plan kernel keeps (64-bit words of one 256-byte block): kTotClass0 + c targets, kTotSeg0 + c segments of class c
-enum { kTotPolyItems = 0, kTotKDoubles = 1, kTotPolyTargets = 2, kTotDirectTargets = 3, kTotClass0 = 8, kTotSeg0 = 16, kTotCount = 24 };
+enum { kTotPolyItems = 0, kTotKDoubles = 1, kTotPolyTargets = 2, kTotDirectTargets = 3, kTotGeneral = 4, kTotClass0 = 8, kTotSeg0 = 16, kTotCount = 24 };
 
 // `todo` flag of a target (written by the plan kernel): which kernel fits it
 enum { kPathPoly = 0, kPathDirect = 1, kPathMfma = 2 };

@@ -180,4 +180,82 @@ __device__ __forceinline__ double poly_eval(const double* kp, double phx, double
 	return val;
 }
 
+
+// ---- any knot vector, any cut-off radius (psf.py:122-148 takes whatever RectBivariateSpline was built on): the FITPACK box integral
+// (dblint -> fpintb) written for the device.  integral over [a, b] of the cubic B-spline N_i on the knots t[i .. i + 4] is
+// J_i(b) - J_i(a) with J_i(e) = (t[i + 4] - t[i]) / 4 * sum_{j >= i} N4_j(e), N4 the quartic B-splines on the same knots: at an
+// edge e in [t[l], t[l + 1]) the sum is 1 for i <= l - 4, 0 for i > l, and a partial sum of the five non-zero quartics for
+// i = l - 3 .. l.  Like fpintb the limits are cut to [t[3], t[n]] (n = number of coefficients of the axis).
+struct EdgeInt { int l; double s[4]; };      // s[q]: the sum for i = l - 3 + q
+
+__device__ inline void edge_integrals(const double* __restrict__ t, int n, double e, EdgeInt& out)
+{
+	// knot interval of e: the last l in [3, n - 1] with t[l] <= e (e is already inside [t[3], t[n]])
+	int lo = 3, hi = n - 1;
+	while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (t[mid] <= e) lo = mid; else hi = mid - 1; }
+	const int l = lo;
+	// de Boor's recurrence up to degree 4: b[0 .. 4] = N4_{l-4 .. l}(e); it reads t[l - 3 .. l + 4]
+	double b[5] = {1.0, 0.0, 0.0, 0.0, 0.0};
+	for (int j = 1; j <= 4; ++j) {
+		double saved = 0.0;
+		for (int r = 0; r < j; ++r) {
+			const double tr = t[l + r + 1], tl = t[l + r + 1 - j];
+			const double f = b[r] / (tr - tl);
+			b[r] = saved + f * (tr - e);
+			saved = f * (e - tl);
+		}
+		b[j] = saved;
+	}
+	out.l = l;
+	out.s[3] = b[4];
+	out.s[2] = b[3] + out.s[3];
+	out.s[1] = b[2] + out.s[2];
+	out.s[0] = b[1] + out.s[1];
+}
+
+__device__ __forceinline__ double edge_cumulative(const EdgeInt& g, int i)   // J_i(e) / w_i
+{
+	const int q = i - (g.l - 3);
+	if (q < 0) return 1.0;
+	if (q > 3) return 0.0;
+	return (q == 0) ? g.s[0] : ((q == 1) ? g.s[1] : ((q == 2) ? g.s[2] : g.s[3]));
+}
+
+// integral of the unit PRF spline over the pixel [xa, xb] x [ya, yb] (x: first spline axis = column direction, psf.py:146)
+__device__ inline double prf_pixel_general(const double* __restrict__ C, int n, const double* __restrict__ tx, const double* __restrict__ ty,
+	double xa, double xb, double ya, double yb)
+{
+	if (!(xa < xb) || !(ya < yb)) return 0.0;
+	xa = fmax(xa, tx[3]); xb = fmin(xb, tx[n]); ya = fmax(ya, ty[3]); yb = fmin(yb, ty[n]);
+	if (!(xa < xb) || !(ya < yb)) return 0.0;     // the pixel lies outside the PRF grid
+	EdgeInt Xa, Xb, Ya, Yb;
+	edge_integrals(tx, n, xa, Xa); edge_integrals(tx, n, xb, Xb);
+	edge_integrals(ty, n, ya, Ya); edge_integrals(ty, n, yb, Yb);
+	double acc = 0.0;
+	for (int i = Xa.l - 3; i <= Xb.l; ++i) {
+		const double wx = (edge_cumulative(Xb, i) - edge_cumulative(Xa, i)) * ((tx[i + 4] - tx[i]) * 0.25);
+		const double* r = C + (int64_t)i * n;
+		double inner = 0.0;
+		for (int j = Ya.l - 3; j <= Yb.l; ++j) {
+			const double wy = (edge_cumulative(Yb, j) - edge_cumulative(Ya, j)) * ((ty[j + 4] - ty[j]) * 0.25);
+			inner += wy * r[j];
+		}
+		acc += wx * inner;
+	}
+	return acc;
+}
+
+// Can the uniform-grid forms above be used?  They need 9 knot intervals per pixel and every pixel edge within the cut-off
+// (|e| < cutoff + 1/2) inside the part of the knot vector where all five knots of the four straddling B-splines are evenly spaced:
+// the interpolating knots are t[0..3] = x[0], t[4 + q] = x[2 + q], so t[4 .. n - 1] is even and an edge in [t[7], t[n - 4]) sees
+// only it.  (For the SPOC grids, 117 samples over 13 pixels, that is cutoff <= 5.38.)
+__host__ __device__ inline bool uniform_grid_ok(const double* __restrict__ t, int n, double cutoff)
+{
+	if (n < 32) return false;
+	const double h = t[5] - t[4];
+	if (!(h > 0.0) || fabs(1.0 / h - 9.0) > 1e-6) return false;
+	for (int i = 4; i < n - 1; ++i) if (fabs((t[i + 1] - t[i]) - h) > 1e-9 * h) return false;
+	return (-t[7] >= cutoff + 0.5) && (t[n - 4] >= cutoff + 0.5);
+}
+
 } // namespace tp_prf

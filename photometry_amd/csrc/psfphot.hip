@@ -110,10 +110,20 @@ struct EvalCtx {
 
 // Star parameters of x for every thread; a star whose knot intervals are in none of its cached sets gets the oldest one rebuilt
 // (the only case with barriers: the cache state changes).  Same arithmetic, same replacement order as before.
-template <int NS>
+// GEN: any knot vectors, any cut-off radius -- nothing is cached, model_pixel integrates the spline over the pixel itself
+template <int NS, bool GEN>
 __device__ __forceinline__ void prepare_stars(const double* x, const EvalCtx& c, StarR (&st)[NS])
 {
 	const int tid = threadIdx.x;
+	if (GEN) {
+#pragma unroll
+		for (int s = 0; s < NS; ++s) {
+			st[s].row = x[3 * s]; st[s].col = x[3 * s + 1]; st[s].flux = x[3 * s + 2];
+			st[s].valid = ((fabs(st[s].row) < 1e6) && (fabs(st[s].col) < 1e6)) ? 1 : 0;   // (as axis_phase: a NaN position is never inside the cut-off)
+			st[s].phx = st[s].phy = 0.0; st[s].jstar = st[s].istar = 0; st[s].slot = -1;
+		}
+		return;
+	}
 	const int per = c.pool / NS;
 	bool miss = false;
 	int kxs[NS], kys[NS];
@@ -190,13 +200,19 @@ __device__ __forceinline__ void prepare_stars(const double* x, const EvalCtx& c,
 }
 
 // sum over the stars of flux * pixel-integrated PRF at pixel (i, j)
-template <int NS>
+template <int NS, bool GEN>
 __device__ __forceinline__ double model_pixel(int i, int j, const EvalCtx& c, const StarR (&st)[NS])
 {
 	double mdl = 0.0;
 #pragma unroll
 	for (int s = 0; s < NS; ++s) {
 		if (!st[s].valid) continue;
+		if (GEN) {
+			const double dc = (double)j - st[s].col, dr = (double)i - st[s].row;
+			if (sqrt(dc * dc + dr * dr) < c.cutoff)     // psf.py:142, :146
+				mdl += st[s].flux * prf_pixel_general(c.Cg, c.n, c.kn, c.kny, dc - 0.5, dc + 0.5, dr - 0.5, dr + 0.5);
+			continue;
+		}
 		const int di = i - st[s].istar, dj = j - st[s].jstar;
 		if (di < -kHalfBox || di > kHalfBox) continue;
 		const int half = row_half(di);
@@ -211,16 +227,16 @@ __device__ __forceinline__ double model_pixel(int i, int j, const EvalCtx& c, co
 // chi^2 of the parameter vector x (psf_photometry.py:52-90); all threads call it, all get the same value.  One barrier: the
 // partial sums of the wavefronts alternate between two places (`flip`), so the next evaluation never writes what a slower
 // wavefront still reads.
-template <int NS>
+template <int NS, bool GEN>
 __device__ double likelihood(const double* x, const EvalCtx& c, int& flip)
 {
 	const int tid = threadIdx.x;
 	StarR st[NS];
-	prepare_stars<NS>(x, c, st);
+	prepare_stars<NS, GEN>(x, c, st);
 	double acc = 0.0;
 	for (int p = tid; p < c.H * c.W; p += kThreads) {
 		const int i = p / c.W, j = p - i * c.W;
-		const double r = (double)c.img[p] - model_pixel<NS>(i, j, c, st);
+		const double r = (double)c.img[p] - model_pixel<NS, GEN>(i, j, c, st);
 		const double term = (double)c.wgt[p] * (r * r);
 		if (term == term) acc += term;                  // nansum
 	}
@@ -236,7 +252,7 @@ __device__ double likelihood(const double* x, const EvalCtx& c, int& flip)
 
 // `targets`: the targets of this launch (all with the same number of fitted stars, so that `pool` sets are what each needs)
 // NS: the number of fitted stars of the launch's targets (0: the targets without one)
-template <int NS>
+template <int NS, bool GEN>
 __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const int32_t* __restrict__ targets, int pool)
 {
 	extern __shared__ __align__(16) double lds[];
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 	ec.ns = ns; ec.n = n; ec.H = H; ec.W = W; ec.pool = pool; ec.h = h; ec.hy = hy; ec.cutoff = a.cutoff;
 	ec.Cg = a.coef + (int64_t)target * n * n; ec.kn = kn; ec.kny = kny; ec.img = img; ec.wgt = wgt; ec.Kc = Kc; ec.red = red; ec.keys = keys; ec.nxt = nxt; ec.rbs = rbs;
 	int flip = 0;
-#define EVAL(xp) likelihood<(NS > 0 ? NS : 1)>((xp), ec, flip)
+#define EVAL(xp) likelihood<(NS > 0 ? NS : 1), GEN>((xp), ec, flip)
 	for (int k = 0; k < a.n_cad; ++k) {
 		// ---- the cadence's image and weight map (float32 arithmetic of psf_photometry.py:75-86)
 		const float* ip = a.images + (int64_t)target * P * a.t_pitch + k;
@@ -423,12 +439,12 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 		if (success) {
 			// residuals in the mini aperture: one more model evaluation at the solution
 			StarR st[NS > 0 ? NS : 1];
-			prepare_stars<(NS > 0 ? NS : 1)>(sim, ec, st);
+			prepare_stars<(NS > 0 ? NS : 1), GEN>(sim, ec, st);
 			double acc = 0.0;
 			for (int p = tid; p < P; p += kThreads) {
 				if (!mini[p]) continue;
 				const int i = p / W, j = p - i * W;
-				const double r = (double)img[p] - model_pixel<(NS > 0 ? NS : 1)>(i, j, ec, st);
+				const double r = (double)img[p] - model_pixel<(NS > 0 ? NS : 1), GEN>(i, j, ec, st);
 				if (r == r) acc += r;
 			}
 #pragma unroll
@@ -470,8 +486,8 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 	TP_REQUIRE(ctx, d_images && d_coef && d_knots_x && d_knots_y && d_star_offsets && d_params0 && d_mini_aperture, "tp_psf_fit: null input pointer");
 	TP_REQUIRE(ctx, d_flux && d_flux_err && d_centroid_row && d_centroid_col && d_status, "tp_psf_fit: null output pointer");
 	TP_REQUIRE(ctx, out_pitch >= desc->n_cad, "tp_psf_fit: out_pitch < n_cad");
-	TP_REQUIRE(ctx, n_coef_axis >= 32 && n_coef_axis <= 140, "tp_psf_fit: coefficient table must be 32..140 per axis");
-	TP_REQUIRE(ctx, cutoff_radius > 0 && cutoff_radius <= 5.25, "tp_psf_fit: cutoff_radius must be in (0, 5.25] (uniform-knot region of the PRF spline)");
+	TP_REQUIRE(ctx, n_coef_axis >= 4 && n_coef_axis <= 2048, "tp_psf_fit: coefficient table must be 4..2048 per axis");
+	TP_REQUIRE(ctx, cutoff_radius > 0, "tp_psf_fit: cutoff_radius must be positive (infinity = no cut-off, psf.py:142 `cutoff_radius is None`)");
 	TP_REQUIRE(ctx, maxiter_first >= 1 && maxiter >= 1, "tp_psf_fit: bad iteration limits");
 	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
 	const size_t P = (size_t)desc->height * desc->width;
@@ -479,11 +495,18 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 		const size_t doubles = (kMaxDim + 1) * kMaxDim + (kMaxDim + 1) + 3 * kMaxDim + kMaxDim + 16 + 2 * ((size_t)n_coef_axis + 4) + (size_t)pool * kItems * 25;
 		return doubles * sizeof(double) + (2 * kPool + 2 * kMaxPsfStars + 1) * sizeof(int) + 2 * P * sizeof(float) + 16;
 	};
-	TP_REQUIRE(ctx, lds_bytes(kPool) <= 160 * 1024, "tp_psf_fit: stamp too large for the LDS-resident image and weight map");
-	// the targets by their number of fitted stars (one launch each, see psf_pool): the star offsets come to the host once
+	// the targets by their number of fitted stars (one launch each, see psf_pool): the star offsets come to the host once, and
+	// with them the knots: the cached biquartics need the SPOC layout of the PRF grid (9 samples per pixel, the cut-off inside
+	// the evenly spaced knots, <= 5.25 as the cached item set assumes); any other grid or radius takes the general instantiation
 	std::vector<int64_t> off((size_t)desc->n_targets + 1);
+	std::vector<double> hk(2 * ((size_t)n_coef_axis + 4));
 	TP_HIP(ctx, hipMemcpyAsync(off.data(), d_star_offsets, off.size() * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+	TP_HIP(ctx, hipMemcpyAsync(hk.data(), d_knots_x, ((size_t)n_coef_axis + 4) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	TP_HIP(ctx, hipMemcpyAsync(hk.data() + n_coef_axis + 4, d_knots_y, ((size_t)n_coef_axis + 4) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const bool general = !(n_coef_axis <= 140 && cutoff_radius <= 5.25 && uniform_grid_ok(hk.data(), n_coef_axis, cutoff_radius)
+		&& uniform_grid_ok(hk.data() + n_coef_axis + 4, n_coef_axis, cutoff_radius));
+	TP_REQUIRE(ctx, lds_bytes(general ? 0 : kPool) <= 160 * 1024, "tp_psf_fit: stamp too large for the LDS-resident image and weight map");
 	std::vector<int32_t> lists[kMaxPsfStars + 1];
 	for (int t = 0; t < desc->n_targets; ++t) {
 		int ns = (int)(off[(size_t)t + 1] - off[(size_t)t]);
@@ -524,16 +547,17 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 		if (lists[ns].empty()) continue;
 		size_t first = 0;
 		for (int m = 0; m < ns; ++m) first += lists[m].size();
-		const int pool = psf_pool(ns);
+		const int pool = general ? 0 : psf_pool(ns);
 		const int si = used++ % 3;
 		if (!waited[si]) { err = hipStreamWaitEvent(streams[si], before, 0); waited[si] = true; if (err != hipSuccess) break; }
-#define TP_PSF_LAUNCH(NSV) do { \
-			err = hipFuncSetAttribute(reinterpret_cast<const void*>(tp_psf_fit_kernel<NSV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(pool)); \
+#define TP_PSF_LAUNCH_G(NSV, GENV) do { \
+			err = hipFuncSetAttribute(reinterpret_cast<const void*>(tp_psf_fit_kernel<NSV, GENV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(pool)); \
 			if (err == hipSuccess) { \
-				TP_LAUNCH_ON(ctx, streams[si], TPK_PSF_FIT, tp_psf_fit_kernel<NSV>, dim3((unsigned)lists[ns].size()), dim3(kThreads), lds_bytes(pool), a, (const int32_t*)(d_lists + first), pool); \
+				TP_LAUNCH_ON(ctx, streams[si], TPK_PSF_FIT, (tp_psf_fit_kernel<NSV, GENV>), dim3((unsigned)lists[ns].size()), dim3(kThreads), lds_bytes(pool), a, (const int32_t*)(d_lists + first), pool); \
 				err = hipGetLastError(); \
 			} \
 		} while (0)
+#define TP_PSF_LAUNCH(NSV) do { if (general) TP_PSF_LAUNCH_G(NSV, true); else TP_PSF_LAUNCH_G(NSV, false); } while (0)
 		switch (ns) {
 			case 0: TP_PSF_LAUNCH(0); break;
 			case 1: TP_PSF_LAUNCH(1); break;
@@ -542,6 +566,7 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 			case 4: TP_PSF_LAUNCH(4); break;
 			default: TP_PSF_LAUNCH(5); break;
 		}
+#undef TP_PSF_LAUNCH_G
 #undef TP_PSF_LAUNCH
 	}
 	// the lists (host vectors, device copy) must outlive the copies and the launches

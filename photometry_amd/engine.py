@@ -313,11 +313,12 @@ def linpsf_set_path(ctx, path):
 
 def linpsf_last_counts(ctx):
 	"""Which kernels fitted the targets of the last :func:`linpsf_fit` call (``tp_linpsf_last_counts``), as a dict."""
-	c = (ctypes.c_int64 * 13)()
-	ctx._check(ctx.lib.tp_linpsf_last_counts(ctx.handle, c, 13))
+	c = (ctypes.c_int64 * 14)()
+	ctx._check(ctx.lib.tp_linpsf_last_counts(ctx.handle, c, 14))
 	return {'matrix_core_targets': int(c[0]), 'matrix_core_segments': int(c[1]), 'vector_alu_polynomial_targets': int(c[2]),
 		'vector_alu_general_targets': int(c[3]), 'many_star_targets': int(c[4]),
-		'matrix_core_targets_by_stars': [int(c[5 + i]) for i in range(4)], 'matrix_core_segments_by_stars': [int(c[9 + i]) for i in range(4)]}
+		'matrix_core_targets_by_stars': [int(c[5 + i]) for i in range(4)], 'matrix_core_segments_by_stars': [int(c[9 + i]) for i in range(4)],
+		'any_grid_targets': int(c[13])}
 
 
 def star_positions(ctx, base, shift):
@@ -332,8 +333,10 @@ def star_positions(ctx, base, shift):
 
 def linpsf_fit(ctx, images, coef, knots_x, knots_y, star_offsets, target_index, pos_row, pos_col, max_stars,
 	cutoff_radius=5.0, subtract=None, out=None):
-	"""P2-P4 (psf.py:122-148, linpsf_photometry.py:22-34, 79-219)."""
+	"""P2-P4 (psf.py:122-148, linpsf_photometry.py:22-34, 79-219).  ``cutoff_radius=None``: no cut-off (psf.py:142)."""
 	n = knots_x.shape[0] - 4
+	if cutoff_radius is None:
+		cutoff_radius = float('inf')
 	if out is None:
 		out = LinPSFResult(ctx, images.n_targets, pos_row.shape[0], images.n_cad)
 	assert pos_row.shape[1] >= images.n_cad and pos_col.shape == pos_row.shape
@@ -355,6 +358,8 @@ def psf_fit(ctx, images, backgrounds, coef, knots_x, knots_y, star_offsets, para
 	"""
 	Nt, T = images.n_targets, images.n_cad
 	n = knots_x.shape[0] - 4
+	if cutoff_radius is None:      # psf.py:142: no cut-off
+		cutoff_radius = float('inf')
 	out = {k: ctx.zeros((Nt, T), 'float64') for k in ('flux', 'flux_err', 'centroid_row', 'centroid_col')}
 	out['params'] = ctx.zeros((max(params0.shape[0], 1) * 3, T), 'float64')
 	out['nit'] = ctx.zeros((Nt, T), 'int32')

@@ -48,7 +48,7 @@ class PRFModel(object):
 	Parameters:
 		values: ``(n_hdu, xdim, ydim)`` PRF sample images (``mat['values']``; first axis = prfColumn).
 		ccd_column, ccd_row: ``(n_hdu,)`` CCD positions of the samples (``ccdColumn``, ``ccdRow``).
-		prf_x, prf_y: sub-pixel sample coordinates (``prfColumn``, ``prfRow``), 9 samples per pixel.
+		prf_x, prf_y: sub-pixel sample coordinates (``prfColumn``, ``prfRow``); the SPOC files hold 9 samples per pixel.
 	"""
 
 	def __init__(self, values, ccd_column, ccd_row, prf_x, prf_y):
@@ -62,9 +62,10 @@ class PRFModel(object):
 		if len(self.prf_x) != len(self.prf_y):
 			raise ValueError("the device kernel needs a square PRF grid")
 		for g in (self.prf_x, self.prf_y):
-			d = np.diff(g)
-			if not np.allclose(d, d[0], rtol=1e-9, atol=0) or abs(1.0/d[0] - 9.0) > 1e-6:
-				raise ValueError("the device kernel needs a uniform PRF grid with 9 samples per pixel (SPOC PRF files)")
+			if len(g) < 4 or not np.all(np.diff(g) > 0):
+				raise ValueError("PRF sample coordinates must be strictly increasing, at least 4 per axis (RectBivariateSpline's own rule)")
+		# (any spacing is taken: the SPOC layout -- evenly spaced, 9 samples per pixel -- runs on the fast kernels, anything else on the
+		# general ones with the FITPACK box integral; the library decides from the knots, tp_linpsf_fit in include/tessphot_hip.h)
 		self.n_hdu = values.shape[0]
 		self.ccd_column = np.asarray(ccd_column, dtype='float64').flatten()
 		self.ccd_row = np.asarray(ccd_row, dtype='float64').flatten()

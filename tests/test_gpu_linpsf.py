@@ -128,10 +128,72 @@ def test_linpsf_argument_checks(ctx):
 	from photometry_amd._lib import TessphotError
 	img = DeviceCube(ctx, 1, 8, 5, 5)
 	z = ctx.zeros((200,), 'float64')
-	with pytest.raises(TessphotError) as e:
-		engine.linpsf_fit(ctx, img, z, ctx.zeros((121,), 'float64'), ctx.zeros((121,), 'float64'), ctx.zeros((2,), 'int64'),
-			ctx.zeros((1,), 'int32'), ctx.zeros((1, 8), 'float64'), ctx.zeros((1, 8), 'float64'), 1, cutoff_radius=7.0)
-	assert 'cutoff_radius' in str(e.value)
+	for bad in (0.0, -1.0, float('nan')):
+		with pytest.raises(TessphotError) as e:
+			engine.linpsf_fit(ctx, img, z, ctx.zeros((121,), 'float64'), ctx.zeros((121,), 'float64'), ctx.zeros((2,), 'int64'),
+				ctx.zeros((1,), 'int32'), ctx.zeros((1, 8), 'float64'), ctx.zeros((1, 8), 'float64'), 1, cutoff_radius=bad)
+		assert 'cutoff_radius' in str(e.value)
+
+
+# include/tessphot_hip.h (tp_linpsf_fit): grids other than the SPOC layout and cut-off radii beyond its evenly spaced knots -- or none
+# at all (psf.py:142 ``cutoff_radius is None``) -- are fitted by the general kernels with the FITPACK box integral itself
+@pytest.mark.parametrize("kind,cutoff,max_neigh", [('warped', 5, 3), ('nsub7', 5, 2), ('spoc', 7.5, 3), ('spoc', None, 2), ('coarse', None, 3),
+	('warped', 6.0, 13), ('spoc', 5.3, 1)])
+def test_linpsf_any_grid_any_cutoff(ctx, kind, cutoff, max_neigh):
+	from photometry_amd import simulate, engine, psf as hpsf
+	from photometry_amd.device import DeviceCube
+	from oracle import psf as opsf, linpsf as olin
+	nt, T, H, W = 5, 37, 13, 12
+	s = simulate.make_scene(nt, T, H, W, seed=70 + max_neigh, max_neighbours=max_neigh, neighbour_tmag_range=(9.0, 17.0))
+	s.jitter = s.jitter * 3
+	simulate.fill_cubes(s, nan_fraction=0.01)
+	from prf_common import general_prf
+	prf = general_prf(kind)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	sel, star_offsets, target_index = hpsf.select_stars(s.catalog, s.cat_offsets, s.target_starid)
+	pos_row, pos_col = _positions(s, sel, T)
+	max_stars = int(np.diff(star_offsets).max())
+	coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(model.weights(s.stamps)))
+	res = engine.linpsf_fit(ctx, DeviceCube.from_host(ctx, s.images), coef, ctx.array(model.tx), ctx.array(model.ty),
+		ctx.array(star_offsets), ctx.array(target_index), ctx.array(pos_row), ctx.array(pos_col), max_stars, cutoff_radius=cutoff).to_host()
+	counts = engine.linpsf_last_counts(ctx)
+	assert counts['any_grid_targets'] == nt      # every target went through the general kernels ...
+	assert counts['matrix_core_targets'] + counts['vector_alu_polynomial_targets'] + counts['vector_alu_general_targets'] + counts['many_star_targets'] == 0
+	for i in range(s.n_targets):
+		cat = s.catalog_of(i)
+		ncat = len(cat['starid'])
+		positions = np.empty((T, ncat, 2))
+		positions[:, :, 0] = cat['row_stamp'][None, :] + s.jitter[:, 1][:, None]
+		positions[:, :, 1] = cat['column_stamp'][None, :] + s.jitter[:, 0][:, None]
+		p = opsf.PSF(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'], tuple(s.stamps[i]))
+		ref = olin.do_photometry(s.images[i], p, cat, s.target_starid[i], positions, tuple(s.stamps[i]),
+			s.target_pos_row[i], s.target_pos_column[i], s.aperture[i], cutoff_radius=cutoff)
+		scale = np.nanmax(np.abs(ref['flux']))
+		np.testing.assert_allclose(res['flux'][i], ref['flux'], rtol=1e-8, atol=1e-9*scale)
+		assert int(res['status'][i]) == ref['status']
+		np.testing.assert_allclose(res['contamination'][i], ref['contamination'], rtol=1e-7, atol=1e-11)
+		np.testing.assert_allclose(res['fluxes_mean'][star_offsets[i]:star_offsets[i+1]], ref['fluxes_mean'], rtol=1e-8, atol=1e-9*scale)
+
+
+def test_spoc_grid_and_default_cutoff_stay_on_the_fast_kernels(ctx):
+	"""The decision is made from the knots on the device: the SPOC layout with the plugin's cut-off (linpsf_photometry.py:63) never
+	reaches the general kernels."""
+	from photometry_amd import simulate, engine, psf as hpsf
+	from photometry_amd.device import DeviceCube
+	from oracle import psf as opsf
+	s = simulate.make_scene(4, 20, 11, 11, seed=5, max_neighbours=2)
+	simulate.fill_cubes(s)
+	prf = opsf.synthetic_prf(seed=7)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	sel, star_offsets, target_index = hpsf.select_stars(s.catalog, s.cat_offsets, s.target_starid)
+	pos_row, pos_col = _positions(s, sel, 20)
+	coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(model.weights(s.stamps)))
+	for cutoff, general in ((5, False), (5.25, False), (5.26, True)):
+		engine.linpsf_fit(ctx, DeviceCube.from_host(ctx, s.images), coef, ctx.array(model.tx), ctx.array(model.ty),
+			ctx.array(star_offsets), ctx.array(target_index), ctx.array(pos_row), ctx.array(pos_col), int(np.diff(star_offsets).max()), cutoff_radius=cutoff)
+		counts = engine.linpsf_last_counts(ctx)
+		fast = counts['matrix_core_targets'] + counts['vector_alu_polynomial_targets'] + counts['vector_alu_general_targets']
+		assert counts['any_grid_targets'] == (4 if general else 0) and fast == (0 if general else 4)
 
 
 def test_matrix_core_fit_takes_the_qualifying_targets(ctx):

@@ -33,7 +33,7 @@ def ctx():
 	c.close()
 
 
-def _run_device(ctx, images, backgrounds, model, stamps, catalogs, pos_row, pos_col, tmag, apertures):
+def _run_device(ctx, images, backgrounds, model, stamps, catalogs, pos_row, pos_col, tmag, apertures, **kw):
 	from photometry_amd import engine
 	from photometry_amd.device import DeviceCube
 	from photometry_amd.plugins import psf_star_selection, mag2flux
@@ -48,7 +48,7 @@ def _run_device(ctx, images, backgrounds, model, stamps, catalogs, pos_row, pos_
 		mini.append(minimum_aperture(tuple(stamps[i]), pos_row[i], pos_col[i], apertures[i]))
 	coef = engine.linpsf_prf(ctx, ctx.array(model.base_coef), ctx.array(model.weights(stamps)))
 	res = engine.psf_fit(ctx, DeviceCube.from_host(ctx, images), DeviceCube.from_host(ctx, backgrounds), coef, ctx.array(model.tx), ctx.array(model.ty),
-		ctx.array(np.asarray(offs, dtype='int64')), ctx.array(np.concatenate(params)), ctx.array(np.stack(mini).astype('uint8')))
+		ctx.array(np.asarray(offs, dtype='int64')), ctx.array(np.concatenate(params)), ctx.array(np.stack(mini).astype('uint8')), **kw)
 	return {k: v.to_host() for k, v in res.items()}
 
 
@@ -114,6 +114,40 @@ def test_psf_photometry_matches_oracle(ctx):
 	# the device walks scipy's simplex: until the first last-bit flip in a target's warm-start chain the iteration counts are scipy's
 	print(f"identical iteration counts on {n_same_nit} of {n_cad} cadences")
 	assert n_same_nit >= n_cad // 4
+
+
+@pytest.mark.parametrize("kind,cutoff", [('warped', 5), ('spoc', 6.5), ('nsub7', None)])
+def test_psf_photometry_any_grid_any_cutoff(ctx, kind, cutoff):
+	"""PRF grids other than the SPOC layout, cut-off radii beyond its evenly spaced knots or none (psf.py:119, :142): the general
+	instantiation of the fit kernel integrates the spline over every pixel itself.  Same comparison as above."""
+	from photometry_amd import simulate, psf as hpsf
+	from oracle import psf as opsf, psf_photometry as opp
+	from prf_common import general_prf
+	Nt, T, H, W = 4, 4, 11, 11
+	s = simulate.make_scene(Nt, T, H, W, seed=93, max_neighbours=2, neighbour_tmag_range=(9.0, 15.0))
+	simulate.fill_cubes(s, nan_fraction=0.004)
+	prf = general_prf(kind)
+	model = hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'])
+	cats = [s.catalog_of(i) for i in range(Nt)]
+	res = _run_device(ctx, s.images, s.backgrounds, model, s.stamps, cats, s.target_pos_row, s.target_pos_column, s.target_tmag, s.aperture,
+		cutoff_radius=cutoff)
+	n_flag_diff = n_ok = 0
+	for i in range(Nt):
+		p = opsf.PSF(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow'], tuple(s.stamps[i]))
+		ref = opp.do_photometry(s.images[i], s.backgrounds[i], p, cats[i], tuple(s.stamps[i]), s.target_pos_row[i], s.target_pos_column[i],
+			s.target_tmag[i], s.aperture[i], cutoff_radius=cutoff)
+		ok = ref['success'] & ~np.isnan(res['flux'][i])
+		differ = np.flatnonzero(ref['success'] != ~np.isnan(res['flux'][i]))
+		n_flag_diff += len(differ)
+		for k in differ:
+			limit = 1500 if k == 0 else 500
+			assert max(int(res['nit'][i][k]), int(ref['nit'][k])) >= limit, (i, k, res['nit'][i][k], ref['nit'][k])
+		print(kind, cutoff, i, 'nit device', res['nit'][i], 'oracle', ref['nit'])
+		np.testing.assert_allclose(res['flux'][i][ok], ref['flux'][ok], rtol=FLUX_RTOL)
+		np.testing.assert_allclose(res['centroid_row'][i][ok], ref['pos_centroid'][ok, 0], atol=POS_ATOL)
+		np.testing.assert_allclose(res['centroid_col'][i][ok], ref['pos_centroid'][ok, 1], atol=POS_ATOL)
+		n_ok += int(ok.sum())
+	assert n_flag_diff <= 1 and n_ok >= Nt * T // 2
 
 
 def test_psf_parity_by_distribution(ctx, golden_dir):
