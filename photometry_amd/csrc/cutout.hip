@@ -43,11 +43,20 @@ struct CutArgs {
 	const uint8_t* mask;                 // optional [n_targets][height * width]: only the pixels with a non-zero entry are written
 };
 
-__global__ __launch_bounds__(256) void tp_cut_stamps_kernel(CutArgs a, int band_rows)
+// up to kMaxStacks frame stacks cut in ONE launch (the three image groups of a CCD share stamps and geometry)
+constexpr int kMaxStacks = 4;
+struct StackPtrs { const float* frames[kMaxStacks]; float* cubes[kMaxStacks]; };
+
+// blockIdx.y = cadence block + n_cad_blocks * stack: a small group (the resized stamps of a few targets) is a chain of latency-bound
+// launches, and three stacks in three launches were three links of it
+__global__ __launch_bounds__(256) void tp_cut_stamps_kernel(CutArgs a, StackPtrs sp, int n_cad_blocks, int band_rows)
 {
 	extern __shared__ float tile[]; // [kCadBlock][ldp]
 	const int target = blockIdx.x;
-	const int k0 = blockIdx.y * kCadBlock;
+	const int stack = (int)blockIdx.y / n_cad_blocks;
+	a.frames = sp.frames[stack];
+	a.cube = sp.cubes[stack];
+	const int k0 = ((int)blockIdx.y - stack * n_cad_blocks) * kCadBlock;
 	const int tid = threadIdx.x;
 	const int W = a.width;
 	const int row_first = blockIdx.z * band_rows;                                   // first stamp row of this band
@@ -178,8 +187,6 @@ __global__ __launch_bounds__(1024) void tp_cut_scan_kernel(int* __restrict__ cou
 
 // up to kMaxStacks frame stacks cut with ONE binning of the stamps (the three image groups of a CCD share stamps and geometry):
 // blockIdx.z picks the stack
-constexpr int kMaxStacks = 4;
-struct StackPtrs { const float* frames[kMaxStacks]; float* cubes[kMaxStacks]; };
 
 __global__ __launch_bounds__(256) void tp_cut_nanfill_kernel(CutArgs a, StackPtrs sp, const int* __restrict__ outside)
 {
@@ -423,11 +430,10 @@ static int cut_stamps_launch(tp_ctx* ctx, int n_stacks, const float* const* d_fr
 	}
 	if (shmem > 64 * 1024)
 		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_cut_stamps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-	dim3 grid((unsigned)desc->n_targets, (unsigned)((desc->t_pitch + kCadBlock - 1) / kCadBlock), (unsigned)n_bands);
-	for (int k = 0; k < n_stacks; ++k) {
-		a.frames = d_frames[k]; a.cube = d_cubes[k];
-		TP_LAUNCH(ctx, TPK_CUTOUT, tp_cut_stamps_kernel, grid, dim3(256), shmem, a, band_rows);
-	}
+	const int n_cad_blocks = (int)((desc->t_pitch + kCadBlock - 1) / kCadBlock);
+	TP_REQUIRE(ctx, (int64_t)n_cad_blocks * n_stacks <= 65535, "tp_cut_stamps: too many cadence blocks");
+	dim3 grid((unsigned)desc->n_targets, (unsigned)(n_cad_blocks * n_stacks), (unsigned)n_bands);
+	TP_LAUNCH(ctx, TPK_CUTOUT, tp_cut_stamps_kernel, grid, dim3(256), shmem, a, sp, n_cad_blocks, band_rows);
 	TP_LAUNCH_CHECK(ctx, "tp_cut_stamps_kernel");
 	return TP_OK;
 }

@@ -342,19 +342,20 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 		ck(g, tp_sumimage(g, &desc, cubes[0], d_quality, 0, kBitmask, nullptr, 0, d_sum));
 		ck(g, tp_k2p2_masks(g, m, H, W, d_sum, d_cat_offsets, d_cat_col_stamp, d_cat_row_stamp, d_cat_tmag, d_cat_col, d_cat_row, d_cat_starid,
 			d_t_row, d_t_col, d_t_tmag, d_t_starid, d_stamps, d_aperture, nullptr, nullptr, d_mask, d_status, d_flags, d_cont, d_diag8, d_cim));
-		if (large)
-			ck(g, tp_cut_stamps_masked(g, 2, frames + 1, stack.n_frames, stack.n_rows, stack.n_cols, stack.n_cols, (int64_t)stack.n_rows * stack.n_cols,
-				stack.row0, stack.col0, d_stamps, &desc, d_mask, cubes + 1));
-		ck(g, tp_aperture_extract(g, &desc, cubes[0], cubes[1], cubes[2], 0, 0, nullptr, 0, d_mask, d_stamps, d_status,
-			lc[0], lc[1], lc[2], lc[3], lc[4], T));
-		// ---- downloads: what the decisions read (status, flags, mask, catalogue flags, sum image) first, with an event; the
-		// diagnostics are computed behind it (nothing of a round is decided from them) and travel with the light curves
+		// ---- downloads: what the decisions read (status, flags, mask, catalogue flags, sum image) is complete once the masks are --
+		// it leaves now, with an event, and the worker decides the job's next round while this group's extraction and diagnostics run
+		// (nothing of a round is decided from the light curves; a target that is cut again has its extraction redone anyway)
 		G.h_block = eng->pinned.get((size_t)G.nbytes, &G.h_cap);
 		const uint64_t lc_bytes = G.off_cont;
 		ckh(hipMemcpyAsync(static_cast<char*>(G.h_block) + lc_bytes, blk + lc_bytes, (size_t)(G.off_diag - lc_bytes), hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(results)");
 		if (event_pool.empty()) { hipEvent_t e = nullptr; ckh(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); event_pool.push_back(e); }
 		L.ev = event_pool.back(); event_pool.pop_back();
 		ckh(hipEventRecord(L.ev, g->stream), "hipEventRecord");
+		if (large)
+			ck(g, tp_cut_stamps_masked(g, 2, frames + 1, stack.n_frames, stack.n_rows, stack.n_cols, stack.n_cols, (int64_t)stack.n_rows * stack.n_cols,
+				stack.row0, stack.col0, d_stamps, &desc, d_mask, cubes + 1));
+		ck(g, tp_aperture_extract(g, &desc, cubes[0], cubes[1], cubes[2], 0, 0, nullptr, 0, d_mask, d_stamps, d_status,
+			lc[0], lc[1], lc[2], lc[3], lc[4], T));
 		ck(g, tp_lightcurve_diagnostics(g, m, T, lc[0], lc[1], lc[3], lc[4], T, d_time, d_quality, 0, kBitmask, d_status, d_sum, d_mask, H, W,
 			3600.0 / 86400.0, d_diagn));
 		ckh(hipMemcpyAsync(static_cast<char*>(G.h_block) + G.off_diag, blk + G.off_diag, (size_t)(G.nbytes - G.off_diag), hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(diagnostics)");

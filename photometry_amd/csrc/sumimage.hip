@@ -37,8 +37,10 @@ __global__ __launch_bounds__(kBlock) void tp_sumimage_kernel(
 
 	if (VEC4) {
 		// two rows (2 x 1 KiB loads in flight per lane and step) per wavefront and iteration
-		int p = wave * 2;
-		for (; p + 1 < n_pix; p += kWaves * 2) {
+		// (blockIdx.y: a small batch spreads the pixel rows of a target over several workgroups -- every row mean is one
+		// wavefront's own work, so the split changes nothing but the latency of a launch with a handful of targets)
+		int p = ((int)blockIdx.y * kWaves + wave) * 2;
+		for (; p + 1 < n_pix; p += kWaves * 2 * (int)gridDim.y) {
 			double m[2];
 			tp_sum::rows_mean_vec4<2>(base, t_pitch, p, sub, good, n_cad, lane, m);
 			if (lane == 0) { o[p] = m[0]; o[p + 1] = m[1]; }
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void tp_sumimage_kernel(
 			if (lane == 0) o[p] = m[0];
 		}
 	} else {
-		for (int p = wave; p < n_pix; p += kWaves) {
+		for (int p = (int)blockIdx.y * kWaves + wave; p < n_pix; p += kWaves * (int)gridDim.y) {
 			const double m = tp_sum::row_mean_scalar(base + (int64_t)p * t_pitch, sub, good, n_cad, lane);
 			if (lane == 0) o[p] = m;
 		}
@@ -74,7 +76,15 @@ extern "C" int tp_sumimage(tp_ctx* ctx, const tp_cube_desc* desc, const float* d
 	// VEC4 reads the row padding of the last quad: needs pitch % 4 == 0 (so the quad is inside the pitch)
 	TP_REQUIRE(ctx, d_subtract == nullptr || subtract_pitch >= desc->n_cad, "tp_sumimage: bad subtract pitch");
 	const bool vec4 = tp_vec4_ok(d_images, desc->t_pitch) && (d_subtract == nullptr || (tp_vec4_ok(d_subtract, subtract_pitch)));
-	dim3 grid((unsigned)desc->n_targets), block(kBlock);
+	// few targets: up to ~1024 workgroups in all, each with at least one pass of its wavefronts over two rows
+	int split = 1;
+	if (desc->n_targets < 512) {
+		split = 1024 / desc->n_targets;
+		const int most = (n_pix + 2 * kWaves - 1) / (2 * kWaves);
+		if (split > most) split = most;
+		if (split < 1) split = 1;
+	}
+	dim3 grid((unsigned)desc->n_targets, (unsigned)split), block(kBlock);
 	if (vec4) {
 		TP_LAUNCH(ctx, TPK_SUMIMAGE, tp_sumimage_kernel<true>, grid, block, shmem,
 			d_images, d_quality, quality_target_stride, bitmask, d_sumimage, desc->n_cad, n_pix, desc->t_pitch, d_subtract, subtract_pitch);
