@@ -537,6 +537,11 @@ int tp_cut_stamps_multi(tp_ctx* ctx, int32_t n_stacks, const float* const* d_fra
 /* The same, writing only the pixel rows of every stamp's aperture mask (d_mask uint8 [n_targets][height * width], non-zero = write;
  * e.g. tp_k2p2_masks' output): tp_aperture_extract reads nothing else of the error and background cubes, and a mask is a sixth of
  * a 15 x 15 stamp on average.  The other rows of d_cubes are left as they were. */
+/* The sum images of a group of stamps from the sum image of the frame (BasePhotometry.py:1001-1006: self._sumimage_full[ir1:ir2,
+ * ic1:ic2]): d_out float64 [n_targets][height * width]; d_full float64 [frame_rows][row_pitch] covering the CCD rows / columns from
+ * row_offset / col_offset; stamp pixels outside the frame are NaN.  d_stamps int32 [n_targets][4] as for tp_cut_stamps. */
+int tp_crop_sumimage(tp_ctx* ctx, const double* d_full, int32_t frame_rows, int32_t frame_cols, int64_t row_pitch,
+	int32_t row_offset, int32_t col_offset, const int32_t* d_stamps, int32_t n_targets, int32_t height, int32_t width, double* d_out);
 int tp_cut_stamps_masked(tp_ctx* ctx, int32_t n_stacks, const float* const* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
 	int64_t row_pitch, int64_t frame_stride, int32_t row_offset, int32_t col_offset,
 	const int32_t* d_stamps, const tp_cube_desc* desc, const uint8_t* d_mask, float* const* d_cubes);
@@ -579,6 +584,12 @@ typedef struct tp_frames_stack {
 	const float* d_images_err;
 	const float* d_backgrounds;
 	int32_t n_frames, n_rows, n_cols, row0, col0;
+	/* optional: the sum image of the region, float64 [n_rows][n_cols] -- what the reference keeps as the HDF5 dataset
+	 * 'sumimage' (prepare.py:450-453, 459; tp_frames_sumimage computes it) and BasePhotometry.sumimage crops for an FFI
+	 * target (BasePhotometry.py:1001-1006).  Given, every pass takes its sum images from it (tp_crop_sumimage), builds the
+	 * masks first and cuts only the in-mask pixel rows of the three stacks; NULL: the sum image of every stamp is formed from
+	 * its own image cube (tp_sumimage: the reference's postage-stamp branch, BasePhotometry.py:1007-1019). */
+	const double* d_sumimage;
 } tp_frames_stack;
 int tp_frames_engine_create(int device, int32_t n_slots, tp_frames_engine** out);
 int tp_frames_engine_destroy(tp_frames_engine* eng);        /* every job waited for and released first */

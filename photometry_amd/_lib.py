@@ -43,7 +43,8 @@ class tp_radial_image(Structure):
 
 class tp_frames_stack(Structure):
 	_fields_ = [('d_images', c_void_p), ('d_images_err', c_void_p), ('d_backgrounds', c_void_p),
-		('n_frames', c_int32), ('n_rows', c_int32), ('n_cols', c_int32), ('row0', c_int32), ('col0', c_int32)]
+		('n_frames', c_int32), ('n_rows', c_int32), ('n_cols', c_int32), ('row0', c_int32), ('col0', c_int32),
+		('d_sumimage', c_void_p)]
 
 
 class tp_k2p2_params(Structure):
@@ -157,6 +158,7 @@ SIGNATURES = {
 	'tp_frames_engine_info': (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_uint64)]),
 	'tp_frames_catalog_create': (c_int, [c_int64, _p, _p, _p, _p, POINTER(c_void_p)]),
 	'tp_frames_catalog_destroy': (c_int, [c_void_p]),
+	'tp_crop_sumimage': (c_int, [c_void_p, _p, c_int32, c_int32, c_int64, c_int32, c_int32, _p, c_int32, c_int32, c_int32, _p]),
 	'tp_frames_submit': (c_int, [c_void_p, POINTER(tp_frames_stack), c_void_p, c_int32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_double, POINTER(c_void_p)]),
 	'tp_frames_wait': (c_int, [c_void_p]),
 	'tp_frames_counts': (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int64)]),

@@ -351,6 +351,20 @@ __global__ __launch_bounds__(256) void tp_cut_tiles_pixels_kernel(CutArgs a, Sta
 	}
 }
 
+// BasePhotometry.py:1001-1006: the sum image of a stamp is a crop of the frame's
+__global__ __launch_bounds__(256) void tp_crop_sumimage_kernel(const double* __restrict__ full, int frame_rows, int frame_cols, int64_t row_pitch,
+	int row_offset, int col_offset, const int32_t* __restrict__ stamps, int64_t n_items, int height, int width, double* __restrict__ out)
+{
+	const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (it >= n_items) return;
+	const int P = height * width;
+	const int target = (int)(it / P), p = (int)(it - (int64_t)target * P);
+	const int i = p / width, j = p - i * width;
+	const int r = stamps[target * 4 + 0] - row_offset + i, c = stamps[target * 4 + 2] - col_offset + j;
+	const bool inside = r >= 0 && r < frame_rows && c >= 0 && c < frame_cols;
+	out[it] = inside ? full[(int64_t)r * row_pitch + c] : __builtin_nan("");
+}
+
 } // namespace
 
 static int cut_stamps_launch(tp_ctx* ctx, int n_stacks, const float* const* d_frames, int32_t n_frames, int32_t frame_rows, int32_t frame_cols,
@@ -385,7 +399,7 @@ static int cut_stamps_launch(tp_ctx* ctx, int n_stacks, const float* const* d_fr
 	tg.tiles_y = (frame_rows + kTileRows - 1) / kTileRows;
 	const int64_t n_tiles = (int64_t)tg.tiles_x * tg.tiles_y;
 	const int64_t max_per_stamp = (int64_t)((desc->height - 1) / kTileRows + 2) * ((desc->width - 1) / kTileCols + 2);
-	if (d_mask && n_tiles <= 16 * 1024 * 1024 && stamp_pixels < 1073741823ll) {
+	if (d_mask && stamp_pixels * 8 >= (int64_t)frame_rows * frame_cols && n_tiles <= 16 * 1024 * 1024 && stamp_pixels < 1073741823ll) {
 		// masked: the tiles serve lists of in-mask pixels (a tile without any exits at once: a sparse batch reads what it needs)
 		const size_t n_int = (size_t)(2 * n_tiles + 2 + 2 * stamp_pixels);
 		int* base = static_cast<int*>(tp_ctx_scratch(ctx, n_int * sizeof(int)));
@@ -455,6 +469,22 @@ extern "C" int tp_cut_stamps_multi(tp_ctx* ctx, int32_t n_stacks, const float* c
 	TP_CHECK_CTX(ctx);
 	TP_API_BEGIN
 	return cut_stamps_launch(ctx, n_stacks, d_frames, n_frames, frame_rows, frame_cols, row_pitch, frame_stride, row_offset, col_offset, d_stamps, desc, d_cubes);
+	TP_API_END(ctx)
+}
+
+extern "C" int tp_crop_sumimage(tp_ctx* ctx, const double* d_full, int32_t frame_rows, int32_t frame_cols, int64_t row_pitch,
+	int32_t row_offset, int32_t col_offset, const int32_t* d_stamps, int32_t n_targets, int32_t height, int32_t width, double* d_out)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_full && d_stamps && d_out, "tp_crop_sumimage: null pointer");
+	TP_REQUIRE(ctx, frame_rows > 0 && frame_cols > 0 && row_pitch >= frame_cols && n_targets >= 0 && height > 0 && width > 0, "tp_crop_sumimage: bad geometry");
+	const int64_t n_items = (int64_t)n_targets * height * width;
+	if (n_items == 0) return TP_OK;
+	TP_LAUNCH(ctx, TPK_SUMIMAGE, tp_crop_sumimage_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, d_full, (int)frame_rows, (int)frame_cols, row_pitch,
+		(int)row_offset, (int)col_offset, d_stamps, n_items, (int)height, (int)width, d_out);
+	TP_LAUNCH_CHECK(ctx, "tp_crop_sumimage_kernel");
+	return TP_OK;
 	TP_API_END(ctx)
 }
 

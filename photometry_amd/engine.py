@@ -311,6 +311,17 @@ def linpsf_set_path(ctx, path):
 	ctx._check(ctx.lib.tp_linpsf_set_path(ctx.handle, int(path)))
 
 
+def crop_sumimage(ctx, full, stamps, height, width, row0, col0, out=None):
+	"""The sum images of a group of stamps as crops of the region's (BasePhotometry.py:1001-1006, ``tp_crop_sumimage``): ``full`` float64
+	DeviceArray ``(R, C)`` covering the CCD from ``(row0, col0)``, ``stamps`` int32 DeviceArray ``(n, 4)``; float64 ``(n, height * width)``."""
+	n = int(stamps.shape[0])
+	if out is None:
+		out = ctx.empty((n, height * width), 'float64')
+	R, C = full.shape
+	ctx._check(ctx.lib.tp_crop_sumimage(ctx.handle, full.ptr, R, C, C, int(row0), int(col0), stamps.ptr, n, int(height), int(width), out.ptr))
+	return out
+
+
 def linpsf_last_counts(ctx):
 	"""Which kernels fitted the targets of the last :func:`linpsf_fit` call (``tp_linpsf_last_counts``), as a dict."""
 	c = (ctypes.c_int64 * 14)()

@@ -11,6 +11,7 @@ import ctypes
 import os
 import numpy as np
 from . import engine, _lib
+from .engine import TESS_DEFAULT_BITMASK
 from ._lib import TessphotError
 from .device import DeviceCube, device_view, round_up
 
@@ -192,7 +193,7 @@ class ApertureWork(object):
 		return v
 
 
-def aperture_step(ctx, batch, work, masks_from=None, fused=True):
+def aperture_step(ctx, batch, work, masks_from=None, fused=True, sumimage_given=False):
 	"""
 	One pass of the aperture hot path over the batch; everything stays in HBM.
 
@@ -202,6 +203,16 @@ def aperture_step(ctx, batch, work, masks_from=None, fused=True):
 	on-device K2P2 (used by tests that inject the oracle's masks; implies the stand-alone kernels).
 	"""
 	subtract, backgrounds = None, batch.backgrounds
+	if sumimage_given:
+		# ``work.sumimage`` already holds the sum images (the FFI branch of BasePhotometry.sumimage: crops of the region's): A2..A7
+		if batch.raw_mode or masks_from is not None:
+			raise ValueError('sumimage_given: calibrated cubes and the on-device masks only')
+		if fused:
+			engine.aperture_photometry(ctx, batch, work, backgrounds=backgrounds, sumimage_given=True)
+			return work
+		engine.k2p2_masks(ctx, batch, work)
+		engine.aperture_extract(ctx, batch.images, batch.images_err, backgrounds, work.mask, batch.stamps, status=work.status, out=work.lc)
+		return work
 	if batch.raw_mode and fused and masks_from is None:
 		# the raw cube is read ONCE: B*, B2 and the sum image of raw - background (A1 with B3 on the fly) in one pass,
 		# then the mask and the extraction, which read in-mask pixel rows only
@@ -338,8 +349,11 @@ class FrameStack(object):
 	``[row0, row0 + R)`` and columns ``[col0, col0 + C)`` (``row0 / col0`` = PIXEL_OFFSET_ROW / COLUMN of the file).
 	"""
 
-	def __init__(self, ctx, frames, row0, col0):
-		"""``frames``: host arrays (uploaded) or float32 DeviceArrays ``(T, R, C)`` already in HBM (e.g. from ``frameio.load_stack``)."""
+	def __init__(self, ctx, frames, row0, col0, sumimage=None):
+		"""``frames``: host arrays (uploaded) or float32 DeviceArrays ``(T, R, C)`` already in HBM (e.g. from ``frameio.load_stack``).
+		``sumimage`` (or ``frames['sumimage']``): the region's sum image, float64 ``(R, C)`` -- the HDF5 dataset ``sumimage`` of the
+		reference's file (prepare.py:450-453, 459; ``prepare.prepare_frames`` returns it); without one it is formed from the image
+		stack when a batch first needs it (:meth:`sumimage_for`)."""
 		from .device import DeviceArray
 		self.ctx = ctx
 		self.row0, self.col0 = int(row0), int(col0)
@@ -347,6 +361,38 @@ class FrameStack(object):
 		self.dev = {k: (frames[k] if isinstance(frames[k], DeviceArray) else ctx.array(np.ascontiguousarray(frames[k], dtype='float32'))) for k in self.names}
 		self.n_cad, self.n_rows, self.n_cols = self.dev['images'].shape
 		self.limits = (self.row0, self.row0 + self.n_rows, self.col0, self.col0 + self.n_cols)
+		if sumimage is None and hasattr(frames, 'get'):
+			sumimage = frames.get('sumimage')
+		self._sumimage = self._sumimage_key = None
+		if sumimage is not None:
+			self._sumimage = sumimage if isinstance(sumimage, DeviceArray) else ctx.array(np.ascontiguousarray(sumimage, dtype='float64'))
+			if tuple(self._sumimage.shape) != (self.n_rows, self.n_cols):
+				raise ValueError('the sum image must have the shape of a frame')
+			self._sumimage_key = 'given'
+			ctx.sync()
+
+	def sumimage_for(self, quality):
+		"""
+		The sum image of the region, float64 DeviceArray ``(R, C)``: the mean of the finite pixels of the frames with good quality
+		(prepare.py:450-453, 459).  For an FFI target the reference crops it (``BasePhotometry.sumimage``, BasePhotometry.py:1001-1006)
+		-- no sum over a stamp's own cube -- and so do the passes of :func:`aperture_frames`.  Given with the stack, or formed once per
+		quality series (``tp_frames_sumimage``: the float64 sums in cadence order, as prepare.py accumulates them).
+		"""
+		if self._sumimage_key == 'given':
+			return self._sumimage
+		q = np.ascontiguousarray(quality, dtype='int32')
+		key = q.tobytes()
+		if self._sumimage_key != key:
+			ctx = self.ctx
+			if self._sumimage is None:
+				self._sumimage = ctx.empty((self.n_rows, self.n_cols), 'float64')
+			dq = ctx.array(q)
+			ctx._check(ctx.lib.tp_frames_sumimage(ctx.handle, self.n_cad, self.n_rows * self.n_cols, self.n_rows * self.n_cols, self.dev['images'].ptr, dq.ptr,
+				int(TESS_DEFAULT_BITMASK), self._sumimage.ptr))
+			ctx.sync()      # other streams (the jobs' contexts) read it
+			dq.free()
+			self._sumimage_key = key
+		return self._sumimage
 
 	def cut_lazy(self, ctx, stamps, height, width):
 		"""The cut cubes of a group on ``ctx``'s stream, the stamp list uploaded there too."""
@@ -711,7 +757,7 @@ class FramesEngine(object):
 		if len(t) != stack.n_cad or len(q) != stack.n_cad:
 			raise ValueError('time and quality must have one entry per frame of the stack')
 		sdesc = _lib.tp_frames_stack(stack.dev['images'].ptr, stack.dev['images_err'].ptr, stack.dev['backgrounds'].ptr,
-			stack.n_cad, stack.n_rows, stack.n_cols, stack.row0, stack.col0)
+			stack.n_cad, stack.n_rows, stack.n_cols, stack.row0, stack.col0, stack.sumimage_for(q).ptr)
 		budget = float(os.environ.get('TESSPHOT_FRAMES_BUDGET_GB', 0)) * 1e9 or self.hbm_bytes / 4.0
 		h = ctypes.c_void_p()
 		rc = self.lib.tp_frames_submit(self.handle, ctypes.byref(sdesc), catalog.handle, n, sid.ctypes.data, tm.ctypes.data, row.ctypes.data, col.ctypes.data,
@@ -838,6 +884,7 @@ def _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s
 	quality = np.asarray(quality, dtype='int32')
 	tmags = np.asarray(targets['tmag'], dtype='float64')
 	out = FramesResult(n)
+	full_sumimage = stack.sumimage_for(quality)
 	log = {}
 	def logger_of(i):
 		if i not in log:
@@ -908,7 +955,9 @@ def _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s
 					work = ApertureWork(g, batch, packed=True, cat_capacity=max(int(cat_offsets[-1]), 1), extras=True)
 					# a small group is a latency-bound pass: the three stand-alone kernels spread A1 and A6 over the chip where the fused launch
 					# gives each target one wavefront (8 targets of 25 x 25: 1.03 against 1.47 ms; bit-identical outputs)
-					aperture_step(g, batch, work, fused=len(idx) >= 1024)
+					# the sum images: crops of the region's (BasePhotometry.py:1001-1006), as in the native engine
+					engine.crop_sumimage(g, full_sumimage, cut['_stamps'], H, W, stack.row0, stack.col0, out=work.sumimage)
+					aperture_step(g, batch, work, fused=len(idx) >= 1024, sumimage_given=True)
 					aperture_diagnostics(g, batch, work)
 					host = g.pinned_block(work.block.nbytes)
 					# two copies: what the decisions of this round read (flags, masks, sum images ...: everything behind the light curves in

@@ -337,3 +337,67 @@ def test_native_engine_equals_the_python_rounds():
 	for a, b in zip(alone, held):
 		_compare_frames_results(a, b)
 	ctx.close()
+
+
+@pytest.mark.parametrize("engine_kind", ['native', 'python'])
+def test_sum_images_are_crops_of_the_regions_sum_image(engine_kind):
+	"""BasePhotometry.sumimage, FFI branch (BasePhotometry.py:1001-1006): ``self._sumimage_full[ir1:ir2, ic1:ic2]`` -- the sum image a
+	target works with is a crop of the one prepare.py accumulated for the whole frame (prepare.py:450-453, 459: float64 sums of the
+	finite float32 pixels of the good frames, in cadence order, over their count).  Bit for bit, for the final (resized) stamps,
+	whether the stack computes the region's sum image itself or is handed the file's."""
+	from photometry_amd import pipeline
+	from photometry_amd.device import Context
+	frames, row0, col0, time, quality, cat, targets = _region()
+	fr = {k: np.moveaxis(v, 2, 0) for k, v in frames.items()}
+	# prepare.py:450-453, 459 on the host
+	full = np.zeros(fr['images'].shape[1:], dtype='float64')
+	nimg = np.zeros(full.shape, dtype='int64')
+	for k in range(len(time)):
+		if quality[k] & 4335 == 0:      # TESSQualityFlags.filter with the default bitmask (quality.py)
+			f = fr['images'][k].astype('float64')
+			ok = np.isfinite(f)
+			nimg += ok
+			full += np.where(ok, f, 0.0)
+	with np.errstate(invalid='ignore'):
+		full = full / nimg
+	ctx = Context(0)
+	for given in (False, True):
+		stack = pipeline.FrameStack(ctx, fr, row0, col0, sumimage=full if given else None)
+		np.testing.assert_array_equal(stack.sumimage_for(quality).to_host(), full)
+		res = pipeline.aperture_frames(ctx, stack, targets, cat, time, quality, engine=engine_kind)
+		n = 0
+		for i in range(len(targets['starid'])):
+			b = res[i]
+			if 'sumimage' not in b:
+				continue
+			r1, r2, c1, c2 = b['stamp']
+			np.testing.assert_array_equal(b['sumimage'], full[r1 - row0:r2 - row0, c1 - col0:c2 - col0])
+			n += 1
+		assert n >= 5
+	# another quality series: the stack forms the sum image anew
+	q2 = quality.copy(); q2[3] = 1
+	stack = pipeline.FrameStack(ctx, fr, row0, col0)
+	a = stack.sumimage_for(quality).to_host()
+	b = stack.sumimage_for(q2).to_host()
+	assert np.any(a != b)
+	np.testing.assert_array_equal(stack.sumimage_for(quality).to_host(), full)
+	ctx.close()
+
+
+def test_crop_sumimage_outside_the_frame_is_nan():
+	from photometry_amd import engine
+	from photometry_amd.device import Context
+	ctx = Context(0)
+	rng = np.random.default_rng(1)
+	full = rng.normal(size=(40, 37))
+	stamps = np.array([[95, 106, 200, 212], [130, 141, 230, 242], [100, 111, 195, 207], [120, 131, 210, 222]], dtype='int32')   # (row0, col0) = (100, 200)
+	out = engine.crop_sumimage(ctx, ctx.array(full), ctx.array(stamps), 11, 12, 100, 200).to_host().reshape(4, 11, 12)
+	for t, (r1, r2, c1, c2) in enumerate(stamps):
+		ref = np.full((11, 12), np.nan)
+		for i in range(11):
+			for j in range(12):
+				r, c = r1 - 100 + i, c1 - 200 + j
+				if 0 <= r < 40 and 0 <= c < 37:
+					ref[i, j] = full[r, c]
+		np.testing.assert_array_equal(out[t], ref)
+	ctx.close()

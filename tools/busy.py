@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""GPU-busy analysis of a rocprofv3 kernel trace database (rocpd sqlite): per kernel totals and the union of the kernel intervals
+inside the last `frac` of the traced time (how much of the wall time some kernel was running)."""
+import sqlite3, sys
+db = sqlite3.connect(sys.argv[1])
+frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.25
+rows = list(db.execute("select name, start, end from kernels order by start"))
+t0, t1 = rows[0][1], max(r[2] for r in rows)
+lo = t1 - (t1 - t0) * frac
+sel = [r for r in rows if r[1] >= lo]
+busy, cur_s, cur_e = 0, None, None
+for _, s, e in sel:
+	if cur_e is None or s > cur_e:
+		if cur_e is not None: busy += cur_e - cur_s
+		cur_s, cur_e = s, e
+	else:
+		cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+span = max(r[2] for r in sel) - sel[0][1]
+print(f'window {span/1e6:.2f} ms, some kernel running {busy/1e6:.2f} ms = {busy/span:.3f}; kernels {len(sel)}')
+tot = {}
+for n, s, e in sel:
+	k = n.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].split('<')[0][-48:]
+	a = tot.setdefault(k, [0, 0]); a[0] += 1; a[1] += e - s
+for k, (n, d) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:18]:
+	print(f'  {k:50s} {n:6d}  {d/1e6:9.3f} ms  ({d/span:.3f} of window)')
+if len(sys.argv) > 3:   # timeline of the last `n` kernels: start offset (us), duration (us), stream, name
+	n = int(sys.argv[3])
+	rows2 = list(db.execute("select name, start, end, stream_id, grid_x, workgroup_x from kernels order by start"))[-n:]
+	b = rows2[0][1]
+	for nm, s, e, st, gx, wx in rows2:
+		k = nm.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].split('<')[0][-40:]
+		print(f'{(s - b)/1e3:9.1f} {(e - s)/1e3:8.1f}  s{st} {gx // max(wx, 1):7d} wg  {k}')
