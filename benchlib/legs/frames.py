@@ -84,8 +84,9 @@ def leg_frames(ctx, args, T, np, pipeline):
 		'latency-bound stamp-resize rounds of the others; every batch equals a call of its own: tests/test_gpu_resize.py)',
 		'targets_per_s': NB * N / dp, 'seconds': dp, 'seconds_all_runs': reps, 'batches': NB, 'in_flight': 4, 'ok_or_warning': okc}
 	return {'what': f'tessphot_frames: {N} targets on a {FR} x {FR} x {T} region resident in HBM (three frame stacks) -> columnar results '
-		'(status, stamp, resizes, diagnostics, light curves, masks in arrays; per-target objects on demand): stamp cuts, fused pass, '
-		'stamp-resize rounds and diagnostics on the device; catalogue selection and the plugin rules by a worker thread of the library (csrc/frames.cpp): the host submits the batch and collects it',
+		'(status, stamp, resizes, diagnostics, light curves, masks in arrays; per-target objects on demand): sum images cropped from the region\'s '
+		'(BasePhotometry.py:1001-1006), masks, ONE cut of the in-mask rows of the three stacks, extraction, stamp-resize rounds and diagnostics on the device; '
+		'catalogue selection and the plugin rules by a worker thread of the library (csrc/frames.cpp): the host submits the batch and collects it',
 		'targets_per_s': N / dt, 'seconds': dt, 'seconds_all_calls': times, 'ok_or_warning': good, 'targets_resized': resized, 'engine': 'native (csrc/frames.cpp)',
 		'with_every_per_target_object': {'targets_per_s': N / (dt + dobj), 'seconds_for_the_objects': dobj, 'ok_or_warning': n_obj},
 		'pipelined': piped}

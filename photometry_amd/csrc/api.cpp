@@ -200,7 +200,10 @@ int tp_device_numa_node(int device, int* node) {
 // by a few bytes from group to group: with finer classes every one of them went to the driver, and a hipMalloc that has to map a
 // new chunk takes milliseconds), then steps of 1/8 of the power of two below
 static size_t tp_alloc_class(size_t n) {
-	if (n <= 65536) { size_t p = 4096; while (p < n) p *= 2; return p; }
+	// up to 16 MiB: powers of two (the metadata block of a group of the frames engine is 0.1 - 2 MB and changes with the number of
+	// catalogue stars in the batch: with steps of an eighth successive batches kept falling into classes the cache had not seen,
+	// and a hipMalloc issued while four jobs have work queued returns after 8 - 9 ms -- measured, TESSPHOT_FRAMES_TIMING)
+	if (n <= ((size_t)16 << 20)) { size_t p = 4096; while (p < n) p *= 2; return p; }
 	size_t p = 65536;
 	while (p * 2 <= n) p *= 2;
 	const size_t step = p / 8;
@@ -279,8 +282,8 @@ int tp_malloc(tp_ctx* ctx, uint64_t nbytes, void** d_ptr) {
 			if (!it->second.freed || hipEventQuery(it->second.freed) == hipSuccess) { pick = it; idle = true; break; }
 		(void)hipGetLastError();   // hipErrorNotReady of the queries
 		constexpr size_t kWaitAbove = (size_t)16 << 20;
-		if (idle || cap >= kWaitAbove) {
-			if (!idle) TP_HIP(ctx, hipEventSynchronize(pick->second.freed));
+		if (idle || cap >= kWaitAbove || ctx->reuse_in_stream_order) {
+			if (!idle && !ctx->reuse_in_stream_order) TP_HIP(ctx, hipEventSynchronize(pick->second.freed));
 			*d_ptr = pick->second.ptr;
 			if (pick->second.freed) ctx->pool.push_back(pick->second.freed);
 			ctx->cache.erase(pick);

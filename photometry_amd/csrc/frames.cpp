@@ -23,6 +23,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 namespace {
@@ -164,6 +165,11 @@ struct tp_frames_job {
 	std::map<int32_t, std::vector<Event>> pending;   // logged, not yet flushed into `events` (plugins._Messages of a target)
 	std::vector<std::pair<void*, size_t>> host_scratch;   // pinned metadata blocks: back to the pool when the job is done
 	std::thread worker;
+	// lab (TESSPHOT_FRAMES_TIMING=1): where the worker thread's time goes, microseconds -- [0] catalogue selection + metadata block,
+	// [1] queueing a group's device work, [2] waiting for the decisions of a round, [3] deciding, [4] waiting for the last light curves
+	double lab_us[5] = {0, 0, 0, 0, 0};
+	int lab_groups = 0, lab_rounds = 0;
+	std::map<std::string, double> lab_steps;   // the queueing of a group, step by step
 	int rc = TP_OK;
 	std::string err;
 	bool joined = false, released = false;
@@ -251,6 +257,8 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 	std::vector<void*> dev;                      // device blocks of this group: freed (stream-ordered) once everything is queued
 	void* h_meta = nullptr; size_t h_meta_cap = 0;
 	auto dalloc = [&](size_t nbytes) { void* p = nullptr; ck(g, tp_malloc(g, nbytes, &p)); dev.push_back(p); return p; };
+	const auto lab_t0 = std::chrono::steady_clock::now();
+	auto lab_t1 = lab_t0;
 	try {
 		if ((int64_t)H * W > 65535) throw Fail("a " + std::to_string(H) + "x" + std::to_string(W) + " stamp is beyond the 65 535 pixels of the mask builder");
 		G.n = m;
@@ -278,8 +286,16 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 		host_scratch.emplace_back(h_meta, h_meta_cap);
 		std::memset(h_meta, 0, total);
 		for (auto& x : f) if (x.nbytes) std::memcpy(static_cast<char*>(h_meta) + x.off, x.src, x.nbytes);
+		lab_t1 = std::chrono::steady_clock::now();
+		auto lab_prev = lab_t1;
+		auto lap = [&](const char* what) { const auto now = std::chrono::steady_clock::now(); lab_steps[what] += std::chrono::duration<double, std::micro>(now - lab_prev).count(); lab_prev = now; };
 		char* d_meta = static_cast<char*>(dalloc(total));
+		lap("alloc meta");
+		// (measured, TESSPHOT_FRAMES_TIMING: in the first runs of a process this call can return after 8 - 20 ms while other jobs have
+		// work queued; in the steady state it takes 30 us.  A kernel that reads the page-locked block through its device mapping never
+		// waits, but its system-scope accesses slowed every concurrent kernel: 3.0 x 10^5 targets/s pipelined instead of 5 x 10^5)
 		ckh(hipMemcpyAsync(d_meta, h_meta, total, hipMemcpyHostToDevice, g->stream), "hipMemcpyAsync(metadata)");
+		lap("alloc+h2d");
 		const int32_t* d_quality = reinterpret_cast<const int32_t*>(d_meta + f[0].off);
 		const double* d_time = reinterpret_cast<const double*>(d_meta + f[1].off);
 		const int32_t* d_stamps = reinterpret_cast<const int32_t*>(d_meta + f[2].off);
@@ -301,6 +317,7 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 		const float* frames[3] = {stack.d_images, stack.d_images_err, stack.d_backgrounds};
 		float* cubes[3];
 		for (int k = 0; k < 3; ++k) cubes[k] = static_cast<float*>(dalloc(cube_bytes));
+		lap("alloc cubes");
 		const bool large = m >= kFusedFrom;
 		// the region's sum image is at hand (the FFI branch of BasePhotometry.sumimage): no cube is needed before the masks are known
 		const bool crop = stack.d_sumimage != nullptr;
@@ -338,6 +355,7 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 		ckh(hipMemsetAsync(d_diag8, 0, (size_t)m * 64, g->stream), "hipMemsetAsync(diag)");
 		int32_t* d_aperture = static_cast<int32_t*>(dalloc((size_t)m * P * 4));
 		ckh(hipMemsetAsync(d_aperture, 1, (size_t)m * P * 4, g->stream), "hipMemsetAsync(aperture)");
+		lap("alloc+memsets");
 		// ---- the pass.  The three stand-alone kernels (bit-identical to the fused launch; a small group is latency-bound and spreads
 		// better over the chip this way).  For a large group the cut of the error and background stacks comes BETWEEN mask and extraction
 		// and writes in-mask rows only: of 8.9 GB of cubes per 2 500 stamps of 15 x 15 the passes read 4.4 (the images for the sum image,
@@ -346,31 +364,43 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 		// 5.5 GB of traffic per 2 500 stamps instead of 10.8, and the decisions leave after the mask kernel alone).
 		if (crop) ck(g, tp_crop_sumimage(g, stack.d_sumimage, stack.n_rows, stack.n_cols, stack.n_cols, stack.row0, stack.col0, d_stamps, m, H, W, d_sum));
 		else ck(g, tp_sumimage(g, &desc, cubes[0], d_quality, 0, kBitmask, nullptr, 0, d_sum));
+		lap("crop");
 		ck(g, tp_k2p2_masks(g, m, H, W, d_sum, d_cat_offsets, d_cat_col_stamp, d_cat_row_stamp, d_cat_tmag, d_cat_col, d_cat_row, d_cat_starid,
 			d_t_row, d_t_col, d_t_tmag, d_t_starid, d_stamps, d_aperture, nullptr, nullptr, d_mask, d_status, d_flags, d_cont, d_diag8, d_cim));
+		lap("k2p2");
 		// ---- downloads: what the decisions read (status, flags, mask, catalogue flags, sum image) is complete once the masks are --
 		// it leaves now, with an event, and the worker decides the job's next round while this group's extraction and diagnostics run
 		// (nothing of a round is decided from the light curves; a target that is cut again has its extraction redone anyway)
 		G.h_block = eng->pinned.get((size_t)G.nbytes, &G.h_cap);
+		lap("pinned");
 		const uint64_t lc_bytes = G.off_cont;
 		ckh(hipMemcpyAsync(static_cast<char*>(G.h_block) + lc_bytes, blk + lc_bytes, (size_t)(G.off_diag - lc_bytes), hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(results)");
 		if (event_pool.empty()) { hipEvent_t e = nullptr; ckh(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); event_pool.push_back(e); }
 		L.ev = event_pool.back(); event_pool.pop_back();
 		ckh(hipEventRecord(L.ev, g->stream), "hipEventRecord");
+		lap("d2h+event");
 		if (crop)
 			ck(g, tp_cut_stamps_masked(g, 3, frames, stack.n_frames, stack.n_rows, stack.n_cols, stack.n_cols, (int64_t)stack.n_rows * stack.n_cols,
 				stack.row0, stack.col0, d_stamps, &desc, d_mask, cubes));
 		else if (large)
 			ck(g, tp_cut_stamps_masked(g, 2, frames + 1, stack.n_frames, stack.n_rows, stack.n_cols, stack.n_cols, (int64_t)stack.n_rows * stack.n_cols,
 				stack.row0, stack.col0, d_stamps, &desc, d_mask, cubes + 1));
+		lap("masked cut");
 		ck(g, tp_aperture_extract(g, &desc, cubes[0], cubes[1], cubes[2], 0, 0, nullptr, 0, d_mask, d_stamps, d_status,
 			lc[0], lc[1], lc[2], lc[3], lc[4], T));
+		lap("extract");
 		ck(g, tp_lightcurve_diagnostics(g, m, T, lc[0], lc[1], lc[3], lc[4], T, d_time, d_quality, 0, kBitmask, d_status, d_sum, d_mask, H, W,
 			3600.0 / 86400.0, d_diagn));
+		lap("diagnostics");
 		ckh(hipMemcpyAsync(static_cast<char*>(G.h_block) + G.off_diag, blk + G.off_diag, (size_t)(G.nbytes - G.off_diag), hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(diagnostics)");
 		ckh(hipMemcpyAsync(G.h_block, blk, (size_t)lc_bytes, hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(light curves)");
+		lap("d2h light curves");
 		for (void* p : dev) (void)tp_free(g, p);      // stream-ordered: handed out again only after what is queued above has run
 		(void)gi;
+		const auto lab_t2 = std::chrono::steady_clock::now();
+		lab_us[0] += std::chrono::duration<double, std::micro>(lab_t1 - lab_t0).count();
+		lab_us[1] += std::chrono::duration<double, std::micro>(lab_t2 - lab_t1).count();
+		lab_groups += 1;
 	} catch (const std::exception& e) {
 		L.failed = true;
 		L.error = e.what();
@@ -506,11 +536,16 @@ void tp_frames_job::run()
 					launch(L, (int)gi, event_pool);
 				}
 				std::string lost;                        // a device error that surfaces at an event costs every group of the part
+				lab_rounds += 1;
 				for (auto& L : launched) {
+					const auto lab_a = std::chrono::steady_clock::now();
 					if (!L.failed && lost.empty()) {
 						const hipError_t e = hipEventSynchronize(L.ev);
 						if (e != hipSuccess) { lost = std::string("hipEventSynchronize: ") + hipGetErrorString(e); (void)hipGetLastError(); }
 					}
+					const auto lab_b = std::chrono::steady_clock::now();
+					lab_us[2] += std::chrono::duration<double, std::micro>(lab_b - lab_a).count();
+					struct LabDecide { double& acc; std::chrono::steady_clock::time_point t; ~LabDecide() { acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t).count(); } } lab_d{lab_us[3], lab_b};
 					if (L.ev) { event_pool.push_back(L.ev); L.ev = nullptr; }
 					if (L.failed || !lost.empty()) {
 						if (L.grp.h_block) { eng->pinned.put(L.grp.h_block, L.grp.h_cap); L.grp.h_block = nullptr; }
@@ -526,10 +561,22 @@ void tp_frames_job::run()
 		}
 		// ---- the light curves of every round have arrived
 		std::string copy_error;
+		const auto lab_w = std::chrono::steady_clock::now();
 		for (int s = 0; s < kStreams; ++s) {
 			const hipError_t e = hipStreamSynchronize(streams[s]->stream);
 			if (e != hipSuccess && copy_error.empty()) { copy_error = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); (void)hipGetLastError(); }
 		}
+		lab_us[4] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - lab_w).count();
+		if (const char* le = std::getenv("TESSPHOT_FRAMES_TIMING"))
+			if (le[0] == '1')
+				std::fprintf(stderr, "[frames job] %d targets, %d rounds, %d groups: select+metadata %.0f us, queueing %.0f, waiting for decisions %.0f, deciding %.0f, last light curves %.0f\n",
+					(int)n, lab_rounds, lab_groups, lab_us[0], lab_us[1], lab_us[2], lab_us[3], lab_us[4]);
+		if (const char* le = std::getenv("TESSPHOT_FRAMES_TIMING"))
+			if (le[0] == '1' && le[1] == '1') {
+				std::string line = "[frames job]   queueing:";
+				for (auto& kv : lab_steps) { char buf[96]; std::snprintf(buf, sizeof buf, " %s %.0f,", kv.first.c_str(), kv.second); line += buf; }
+				std::fprintf(stderr, "%s\n", line.c_str());
+			}
 		if (!copy_error.empty()) {       // nothing that was extracted can be trusted
 			const int32_t t = add_text(copy_error);
 			for (int32_t i = 0; i < n; ++i) if (has_result[i]) { has_result[i] = 0; direct(i, 11, 0, 0, 0.0, t); status[i] = TP_STATUS_ERROR; }
@@ -566,6 +613,7 @@ int tp_frames_engine_create(int device, int32_t n_slots, tp_frames_engine** out)
 			delete eng;
 			return rc;
 		}
+		c->reuse_in_stream_order = true;      // (every block of a group is allocated from, used on and freed to the context of its stream)
 		eng->ctxs.push_back(c);
 	}
 	eng->busy.assign(n_slots, 0);

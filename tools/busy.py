@@ -31,3 +31,17 @@ if len(sys.argv) > 3:   # timeline of the last `n` kernels: start offset (us), d
 	for nm, s, e, st, gx, wx in rows2:
 		k = nm.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].split('<')[0][-40:]
 		print(f'{(s - b)/1e3:9.1f} {(e - s)/1e3:8.1f}  s{st} {gx // max(wx, 1):7d} wg  {k}')
+if len(sys.argv) > 4:   # concurrency: share of the window with k kernels running; with a large (>= 1500 workgroups) kernel running
+	ev = []
+	for nm, s, e, st, gx, wx in db.execute("select name, start, end, stream_id, grid_x, workgroup_x from kernels where start >= ?", (lo,)):
+		big = 1 if gx // max(wx, 1) >= 1500 else 0
+		ev.append((s, 1, big)); ev.append((e, -1, -big))
+	ev.sort()
+	hist, bigt, cur, curb, last = {}, 0, 0, 0, ev[0][0]
+	for t, d, b in ev:
+		hist[cur] = hist.get(cur, 0) + (t - last)
+		if curb > 0: bigt += t - last
+		cur += d; curb += b; last = t
+	tot = sum(hist.values())
+	print('kernels running at once:', {k: round(v / tot, 3) for k, v in sorted(hist.items())})
+	print('a large kernel running:', round(bigt / tot, 3))
