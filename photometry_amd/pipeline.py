@@ -1210,7 +1210,7 @@ def psf_frames(ctx, stack, targets, catalog, time, quality, prf_model, readnoise
 		out.stamp[i] = (-1, -2, -1, -2)
 	cat_index = _CatalogIndex(catalog)
 	base_coef, tx, ty = ctx.array(prf_model.base_coef), ctx.array(prf_model.tx), ctx.array(prf_model.ty)
-	qual = ctx.array(np.asarray(quality, dtype='int32'))
+	full_sumimage = stack.sumimage_for(quality)
 	trow, tcol, ttmag = (np.asarray(targets[k], dtype='float64') for k in ('row', 'column', 'tmag'))
 	for H, W, idx in groups:
 		cat_offsets, cat = _catalogs_of_stamps(cat_index, cur[idx])
@@ -1218,7 +1218,8 @@ def psf_frames(ctx, stack, targets, catalog, time, quality, prf_model, readnoise
 		images = engine.cut_stamps(ctx, stack.dev['images'], stamps_dev, H, W, stack.row0, stack.col0)
 		backgrounds = engine.cut_stamps(ctx, stack.dev['backgrounds'], stamps_dev, H, W, stack.row0, stack.col0)
 		try:
-			finite = np.isfinite(engine.sumimage(ctx, images, qual).to_host())   # bit 1 of the aperture image (BasePhotometry.py:1033-1074)
+			# bit 1 of the aperture image (BasePhotometry.py:1033-1074) from the sum image -- for an FFI target a crop of the region's (:1001-1006)
+			finite = np.isfinite(engine.crop_sumimage(ctx, full_sumimage, stamps_dev, H, W, stack.row0, stack.col0).to_host()).reshape(len(idx), H, W)
 			offsets = [0]
 			params0 = []
 			mini = np.zeros((len(idx), H, W), dtype='uint8')
