@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU-busy analysis of a rocprofv3 kernel trace database (rocpd sqlite): per kernel totals and the union of the kernel intervals
-inside the last `frac` of the traced time (how much of the wall time some kernel was running)."""
+inside the last `frac` of the traced time (how much of the wall time some kernel was running).
+    python3 tools/busy.py results.db [frac = 0.25] [n: timeline of the last n kernels, 0 = none] [1: concurrency histogram]"""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.25
@@ -24,7 +25,7 @@ for n, s, e in sel:
 	a = tot.setdefault(k, [0, 0]); a[0] += 1; a[1] += e - s
 for k, (n, d) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:18]:
 	print(f'  {k:50s} {n:6d}  {d/1e6:9.3f} ms  ({d/span:.3f} of window)')
-if len(sys.argv) > 3:   # timeline of the last `n` kernels: start offset (us), duration (us), stream, name
+if len(sys.argv) > 3 and int(sys.argv[3]) > 0:   # timeline of the last `n` kernels: start offset (us), duration (us), stream, name
 	n = int(sys.argv[3])
 	rows2 = list(db.execute("select name, start, end, stream_id, grid_x, workgroup_x from kernels order by start"))[-n:]
 	b = rows2[0][1]
