@@ -138,12 +138,14 @@ def test_linpsf_argument_checks(ctx):
 # include/tessphot_hip.h (tp_linpsf_fit): grids other than the SPOC layout and cut-off radii beyond its evenly spaced knots -- or none
 # at all (psf.py:142 ``cutoff_radius is None``) -- are fitted by the general kernels with the FITPACK box integral itself
 @pytest.mark.parametrize("kind,cutoff,max_neigh", [('warped', 5, 3), ('nsub7', 5, 2), ('spoc', 7.5, 3), ('spoc', None, 2), ('coarse', None, 3),
-	('warped', 6.0, 13), ('spoc', 5.3, 1)])
+	('warped', 6.0, 13), ('spoc', 5.3, 1), ('nsub7', 6.5, -2)])      # (-2: two neighbours at most, 300 cadences: several workgroups per target)
 def test_linpsf_any_grid_any_cutoff(ctx, kind, cutoff, max_neigh):
 	from photometry_amd import simulate, engine, psf as hpsf
 	from photometry_amd.device import DeviceCube
 	from oracle import psf as opsf, linpsf as olin
 	nt, T, H, W = 5, 37, 13, 12
+	if max_neigh < 0:
+		nt, T, max_neigh = 3, 300, -max_neigh
 	s = simulate.make_scene(nt, T, H, W, seed=70 + max_neigh, max_neighbours=max_neigh, neighbour_tmag_range=(9.0, 17.0))
 	s.jitter = s.jitter * 3
 	simulate.fill_cubes(s, nan_fraction=0.01)
