@@ -383,15 +383,15 @@ class FrameStack(object):
 		q = np.ascontiguousarray(quality, dtype='int32')
 		key = q.tobytes()
 		if self._sumimage_key != key:
+			# (a NEW array per quality series: jobs in flight may still read the one of the series before; they keep it alive)
 			ctx = self.ctx
-			if self._sumimage is None:
-				self._sumimage = ctx.empty((self.n_rows, self.n_cols), 'float64')
+			sumimage = ctx.empty((self.n_rows, self.n_cols), 'float64')
 			dq = ctx.array(q)
 			ctx._check(ctx.lib.tp_frames_sumimage(ctx.handle, self.n_cad, self.n_rows * self.n_cols, self.n_rows * self.n_cols, self.dev['images'].ptr, dq.ptr,
-				int(TESS_DEFAULT_BITMASK), self._sumimage.ptr))
+				int(TESS_DEFAULT_BITMASK), sumimage.ptr))
 			ctx.sync()      # other streams (the jobs' contexts) read it
 			dq.free()
-			self._sumimage_key = key
+			self._sumimage, self._sumimage_key = sumimage, key
 		return self._sumimage
 
 	def cut_lazy(self, ctx, stamps, height, width):
@@ -756,15 +756,16 @@ class FramesEngine(object):
 		q = np.ascontiguousarray(quality, dtype='int32')
 		if len(t) != stack.n_cad or len(q) != stack.n_cad:
 			raise ValueError('time and quality must have one entry per frame of the stack')
+		sumimage = stack.sumimage_for(q)
 		sdesc = _lib.tp_frames_stack(stack.dev['images'].ptr, stack.dev['images_err'].ptr, stack.dev['backgrounds'].ptr,
-			stack.n_cad, stack.n_rows, stack.n_cols, stack.row0, stack.col0, stack.sumimage_for(q).ptr)
+			stack.n_cad, stack.n_rows, stack.n_cols, stack.row0, stack.col0, sumimage.ptr)
 		budget = float(os.environ.get('TESSPHOT_FRAMES_BUDGET_GB', 0)) * 1e9 or self.hbm_bytes / 4.0
 		h = ctypes.c_void_p()
 		rc = self.lib.tp_frames_submit(self.handle, ctypes.byref(sdesc), catalog.handle, n, sid.ctypes.data, tm.ctypes.data, row.ctypes.data, col.ctypes.data,
 			first.ctypes.data, valid8.ctypes.data, attempts.ctypes.data, budget_flux.ctypes.data, t.ctypes.data, q.ctypes.data, budget * budget_share, ctypes.byref(h))
 		if rc != 0:
 			raise TessphotError(rc, (self.lib.tp_last_error(None) or b'').decode())
-		return FramesJob(self, h.value, n, stack.n_cad, (stack, catalog))
+		return FramesJob(self, h.value, n, stack.n_cad, (stack, catalog, sumimage))
 
 	def close(self):
 		h, self.handle = self.handle, None
