@@ -602,6 +602,9 @@ int tp_frames_submit(tp_frames_engine* eng, const tp_frames_stack* stack, const 
 	const int64_t* h_stamps, const uint8_t* h_valid, const int32_t* h_attempts, const double* h_quick_break_budget,
 	const double* h_time, const int32_t* h_quality, double budget_bytes, tp_frames_job** out);
 int tp_frames_wait(tp_frames_job* job);
+/* has the job's worker finished (tp_frames_wait would return at once)?  A caller with several jobs in flight collects whichever
+ * is done and hands its slot to the next batch. */
+int tp_frames_poll(tp_frames_job* job, int32_t* done);
 int tp_frames_counts(tp_frames_job* job, int32_t* n_groups, int64_t* n_events);
 int tp_frames_targets(tp_frames_job* job, int32_t* status, int64_t* stamps, int32_t* stamp_resizes, uint8_t* has_result, int32_t* group, int32_t* pos);
 int tp_frames_group(tp_frames_job* job, int32_t g, int32_t* n_targets, int32_t* height, int32_t* width, int64_t* cat_capacity, int64_t* n_cat,

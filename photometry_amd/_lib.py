@@ -161,6 +161,7 @@ SIGNATURES = {
 	'tp_crop_sumimage': (c_int, [c_void_p, _p, c_int32, c_int32, c_int64, c_int32, c_int32, _p, c_int32, c_int32, c_int32, _p]),
 	'tp_frames_submit': (c_int, [c_void_p, POINTER(tp_frames_stack), c_void_p, c_int32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_double, POINTER(c_void_p)]),
 	'tp_frames_wait': (c_int, [c_void_p]),
+	'tp_frames_poll': (c_int, [c_void_p, POINTER(c_int32)]),
 	'tp_frames_counts': (c_int, [c_void_p, POINTER(c_int32), POINTER(c_int64)]),
 	'tp_frames_targets': (c_int, [c_void_p, _p, _p, _p, _p, _p, _p]),
 	'tp_frames_group': (c_int, [c_void_p, c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int64), POINTER(c_int64), POINTER(c_void_p), POINTER(c_uint64)]),

@@ -173,6 +173,7 @@ struct tp_frames_job {
 	int rc = TP_OK;
 	std::string err;
 	bool joined = false, released = false;
+	std::atomic<int> done{0};               // set by the worker when run() has returned (tp_frames_poll)
 
 	void log(int32_t i, int32_t code, int32_t a = 0, int32_t b = 0, double v = 0.0, int32_t text = -1) { pending[i].push_back(Event{i, code, a, b, v, text}); }
 	void direct(int32_t i, int32_t code, int32_t a = 0, int32_t b = 0, double v = 0.0, int32_t text = -1) { events.push_back(Event{i, code, a, b, v, text}); }
@@ -733,7 +734,7 @@ int tp_frames_submit(tp_frames_engine* eng, const tp_frames_stack* stack, const 
 	job->budget = budget_bytes > 0 ? budget_bytes : (double)eng->hbm_bytes / 4.0;
 	eng->running.fetch_add(1);
 	try {
-		job->worker = std::thread([job] { job->run(); job->eng->running.fetch_sub(1); });
+		job->worker = std::thread([job] { job->run(); job->done.store(1, std::memory_order_release); job->eng->running.fetch_sub(1); });
 	} catch (...) {          // no thread to be had: the slot is free again, the job never existed
 		eng->running.fetch_sub(1);
 		{ std::lock_guard<std::mutex> lk(eng->m); eng->busy[slot] = 0; }
@@ -758,6 +759,13 @@ int tp_frames_wait(tp_frames_job* job)
 	}
 	if (job->rc != TP_OK) tp_global_err = job->err;
 	return job->rc;
+}
+
+int tp_frames_poll(tp_frames_job* job, int32_t* done)
+{
+	if (!job || !done) { tp_global_err = "tp_frames_poll: null pointer"; return TP_ERR_INVALID; }
+	*done = (job->joined || job->done.load(std::memory_order_acquire)) ? 1 : 0;
+	return TP_OK;
 }
 
 int tp_frames_counts(tp_frames_job* job, int32_t* n_groups, int64_t* n_events)

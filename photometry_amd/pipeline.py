@@ -650,6 +650,12 @@ class FramesJob(object):
 		except Exception: # noqa: B902
 			pass
 
+	def done(self):
+		"""Has the job's worker finished (:meth:`collect` would not wait)?"""
+		d = ctypes.c_int32(0)
+		self.engine.lib.tp_frames_poll(self.handle, ctypes.byref(d))
+		return bool(d.value)
+
 	def collect(self):
 		from . import comm as tpcomm
 		lib, h, n, T = self.engine.lib, self.handle, self.n, self.T
@@ -820,13 +826,27 @@ def aperture_frames_pipelined(ctx, stack, batches, catalog, time, quality, setti
 		in_flight = max(1, min(int(in_flight), 5))
 		eng = FramesEngine.of(ctx, slots=in_flight)
 		cat = eng.catalog(catalog)
-		queue = deque()
+		# results are yielded in the order of the batches, but a slot is handed on as soon as ANY job is done: the jobs of a run take
+		# 5 - 15 ms each (three to ten groups, one to five rounds), and waiting for the oldest left finished ones holding their slots
+		queue, finished, serial, next_out = deque(), {}, 0, 0
 		for targets in batches:
 			while len(queue) >= in_flight:
-				yield queue.popleft().collect()
-			queue.append(eng.submit(stack, targets, cat, time, quality, settings=settings, datasource=datasource, budget_share=1.0 / in_flight))
+				# (at most in_flight results wait for an older batch: beyond that the oldest job is waited for)
+				k = 0 if len(finished) >= in_flight else next((k for k, (_, job) in enumerate(queue) if job.done()), 0)
+				s, job = queue[k]
+				del queue[k]
+				finished[s] = job.collect()
+				while next_out in finished:
+					yield finished.pop(next_out)
+					next_out += 1
+			queue.append((serial, eng.submit(stack, targets, cat, time, quality, settings=settings, datasource=datasource, budget_share=1.0 / in_flight)))
+			serial += 1
 		while queue:
-			yield queue.popleft().collect()
+			s, job = queue.popleft()
+			finished[s] = job.collect()
+			while next_out in finished:
+				yield finished.pop(next_out)
+				next_out += 1
 		return
 	catalog = {k: np.asarray(v) for k, v in catalog.items()}
 	cat_index = _CatalogIndex(catalog)
