@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void tp_cut_stamps_kernel(CutArgs a, StackPtrs
 	const int r0 = a.stamps[target * 4 + 0] - a.row_offset + row_first;
 	const int c0 = a.stamps[target * 4 + 2] - a.col_offset;
 	const float nan = __builtin_nanf("");
+	const uint8_t* mk0 = a.mask ? (a.mask + (int64_t)target * a.height * W + (int64_t)row_first * W) : nullptr;
 	// ---- load: (cadence, stamp row) pairs, 16 lanes across the columns of a row segment
 	const int wgrp = (W + 15) / 16;                 // 16-lane groups per stamp row (1 for W <= 16)
 	const int seg = tid >> 4, lane16 = tid & 15;    // 16 segments in flight per pass
@@ -87,7 +88,10 @@ __global__ __launch_bounds__(256) void tp_cut_stamps_kernel(CutArgs a, StackPtrs
 			const int k = k0 + kk;
 			const int r = r0 + i, c = c0 + j;
 			const bool want = (sidx < nseg) && (j < W);
-			const bool inside = want && k < a.n_frames && r >= 0 && r < a.frame_rows && c >= 0 && c < a.frame_cols;
+			// (with a mask only its pixels are fetched: a resized stamp of 35 x 35 holds a mask of a few dozen pixels, and the groups of
+			// resized stamps read 2.0 GB per batch of 2 500 targets to write 0.1 -- profiles/r5_frames_traffic.txt, before this test)
+			const bool wanted = want && (mk0 == nullptr || mk0[i * W + j] != 0);
+			const bool inside = wanted && k < a.n_frames && r >= 0 && r < a.frame_rows && c >= 0 && c < a.frame_cols;
 			// clamped address, unconditional load: nothing under a branch between the loads
 			const int64_t off = inside ? ((int64_t)k * a.frame_stride + (int64_t)r * a.row_pitch + c) : 0;
 			const float x = a.frames[off];
