@@ -23,7 +23,30 @@ analogue stated here keeps every ingredient that still has a meaning on a single
 * the 3x3 median filter and the bicubic zoom of a 1x1 mesh are identities -> the background is
   constant over the stamp for each cadence.
 
-Statistics are float64 on the float32 pixel values.  **Parity unpinned** against
+Being build-defined, B* is defined DOWN TO THE LAST BIT, once, here (:func:`bstar_frames`), and
+``csrc/background.hip`` implements the same arithmetic: which float64 operations, in which order.
+Every decision of the estimator -- is a pixel clipped, which branch of the mode estimator -- is a
+comparison of float64 numbers; were the two sides free to sum in different orders, a value within
+rounding of ``median +- 3 std`` (or of ``|mean - median| = 0.3 std``) could be clipped on one side
+only and move the estimate -- and through the sum image a pixel across K2P2's threshold -- by far
+more than rounding.  The definition:
+
+1. ``n`` kept pixels; the float64 sums ``s1 = sum x`` and ``s2 = sum x*x`` of the kept values run over EIGHT
+   interleaved accumulators (pixel ``p`` of the row-major stamp goes to accumulator ``p % 8``, in pixel order; masked pixels
+   add +0.0), combined as ``((a0+a1)+(a2+a3))+((a4+a5)+(a6+a7))`` (:func:`_tree8`).
+2. The kept values sorted ascending, ``k[0..n)``; the kept set of the clipping is a rank range ``[lo, hi)``.
+3. At most five clipping passes: ``m = hi - lo``; ``med = (k[lower middle] + k[upper middle]) * 0.5``;
+   ``q9 = 9 * (m*s2 - s1*s1)``, negative or NaN -> 0;  a value is clipped iff ``d = (x - med) * m`` has ``d*d > q9``
+   (above for ``d > 0``, below for ``d < 0``): the 3-sigma test ``|x - med| > 3 std`` with ``std**2 = (m s2 - s1**2) / m**2``,
+   without division or square root.  The clipped values are the ``na`` highest and ``nb`` lowest ranks of the range; their
+   sums again run over eight accumulators: accumulator ``g`` takes the ``(g + 8 s)``-th value from the top, then the
+   ``(g + 8 s)``-th from the bottom, for ``s = 0, 1, ...``; ``s1 -= tree8(r1)``, ``s2 -= tree8(r2)``.
+4. ``mean = s1 / m``; ``var = s2 / m - mean*mean`` (negative -> 0); ``sd = sqrt(var)``; the SExtractor rule on
+   ``(med, mean, sd)``; the result rounded to float32.
+
+Against the LITERAL astropy / photutils statements (:func:`fit_background_stamp_literal`: ``np.median``, ``np.std``,
+``np.mean`` -- numpy's pairwise sums, the two-pass variance) the defined arithmetic agrees to float32 rounding wherever no
+decision is within rounding of its threshold (``tests/test_oracle_background.py``).  **Parity unpinned** against
 photutils/astropy (not installable here); pinned by the reference's own known answer
 ``tests/test_background.py:36-54`` (constant image 1000 -> background 1000, nothing masked).
 """
@@ -73,9 +96,10 @@ def sextractor_background(data):
 	return med
 
 
-def fit_background_stamp(img, flux_cutoff=8e4, exclude=None, exclude_percentile=50.0):
+def fit_background_stamp_literal(img, flux_cutoff=8e4, exclude=None, exclude_percentile=50.0):
 	"""
-	B*: one cadence of one stamp.  Returns ``(background scalar float64, mask bool (H, W))``.
+	B* in the literal astropy / photutils statements (numpy's own summation orders): what :func:`bstar_frames` defines bit for
+	bit, up to rounding.  Returns ``(background scalar float64, mask bool (H, W))``.
 	"""
 	img = np.asarray(img)
 	mask = stamp_mask(img, flux_cutoff, exclude)
@@ -87,14 +111,112 @@ def fit_background_stamp(img, flux_cutoff=8e4, exclude=None, exclude_percentile=
 	return sextractor_background(data), mask
 
 
+def _tree8(a):
+	"""``((a0+a1)+(a2+a3))+((a4+a5)+(a6+a7))`` along the last axis (length 8)."""
+	return ((a[..., 0] + a[..., 1]) + (a[..., 2] + a[..., 3])) + ((a[..., 4] + a[..., 5]) + (a[..., 6] + a[..., 7]))
+
+
+def _sums8(Z):
+	"""float64 ``[F, P]`` -> (sum, sum of squares) per frame over eight interleaved accumulators, see the module header."""
+	F, P = Z.shape
+	J = -(-P // 8)
+	Zp = np.zeros((F, J*8), dtype='float64')
+	Zp[:, :P] = Z
+	Zp = Zp.reshape(F, J, 8)
+	a1 = np.zeros((F, 8), dtype='float64')
+	a2 = np.zeros((F, 8), dtype='float64')
+	for j in range(J):
+		z = Zp[:, j, :]
+		a1 = a1 + z
+		a2 = a2 + z*z            # z is a widened float32: the product is exact, so a fused multiply-add gives the same
+	return _tree8(a1), _tree8(a2)
+
+
+def bstar_frames(X, flux_cutoff=8e4, exclude=None, exclude_percentile=50.0, full=False):
+	"""
+	B*, THE DEFINITION (module header): ``X`` float32 ``(F, P)`` -- F frames of P pixels in row-major stamp order -> float32
+	``(F,)``.  ``exclude``: optional bool ``(F, P)``.  With ``full`` also a dict of the clipping's end state (``lo``, ``hi``,
+	``n``, ``passes``).  Vectorised over the frames; every float64 operation is written out in the order the header gives.
+	"""
+	X = np.ascontiguousarray(X, dtype='float32')
+	F, P = X.shape
+	with np.errstate(invalid='ignore'):
+		ok = (X >= np.float32(0)) & (X <= np.float32(flux_cutoff))      # backgrounds.py:91-94; NaN fails both
+	if exclude is not None:
+		ok &= ~np.asarray(exclude, dtype=bool).reshape(F, P)
+	n = ok.sum(axis=1).astype('int64')
+	frac = np.float32(exclude_percentile / 100.0)
+	usable = (n > 0) & ~((P - n).astype('float32') > frac * np.float32(P))
+	s1, s2 = _sums8(np.where(ok, X, np.float32(0)).astype('float64'))
+	K = np.sort(np.where(ok, X, np.float32(np.inf)), axis=1).astype('float64')   # kept values first, ascending
+	rows = np.arange(F)
+	idx = np.arange(P)[None, :]
+	lo = np.zeros(F, dtype='int64')
+	hi = np.where(usable, n, 1)
+	passes = np.zeros(F, dtype='int64')
+	g8 = np.arange(8)[None, :]
+	with np.errstate(invalid='ignore', over='ignore', divide='ignore'):
+		for it in range(6):
+			m = hi - lo
+			m1 = lo + (m >> 1)
+			m0 = np.where(m & 1, m1, m1 - 1)
+			med = (K[rows, m0] + K[rows, m1]) * 0.5
+			if it == 5:
+				break
+			mm = m.astype('float64')
+			q9 = 9.0 * (mm*s2 - s1*s1)
+			q9 = np.where(q9 > 0.0, q9, 0.0)
+			D = (K - med[:, None]) * mm[:, None]
+			inrange = (idx >= lo[:, None]) & (idx < hi[:, None]) & usable[:, None]
+			out = inrange & (D*D > q9[:, None])
+			na = np.sum(out & (D > 0.0), axis=1)
+			nb = np.sum(out & (D < 0.0), axis=1)
+			if not np.any(na | nb):
+				break
+			passes += ((na | nb) != 0)
+			r1 = np.zeros((F, 8), dtype='float64')
+			r2 = np.zeros((F, 8), dtype='float64')
+			for s in range(int(-(-max(na.max(), nb.max()) // 8))):
+				t = g8 + 8*s
+				for cnt, pos in ((na, hi[:, None] - 1 - t), (nb, lo[:, None] + t)):        # from the top, then from the bottom
+					take = t < cnt[:, None]
+					x = np.where(take, K[rows[:, None], np.clip(pos, 0, P - 1)], 0.0)
+					r1 = r1 + x
+					r2 = r2 + x*x
+			s1 = s1 - _tree8(r1)
+			s2 = s2 - _tree8(r2)
+			lo = lo + nb
+			hi = hi - na
+		mm = (hi - lo).astype('float64')
+		mean = s1 / mm
+		var = s2 / mm - mean*mean
+		var = np.where(var < 0.0, 0.0, var)
+		sd = np.sqrt(var)
+		with np.errstate(divide='ignore'):
+			bkg = np.where(sd == 0.0, mean, np.where(np.abs(mean - med) / sd < 0.3, 2.5*med - 1.5*mean, med))
+	result = np.where(usable, bkg, np.nan).astype('float32')
+	if full:
+		return result, {'lo': lo, 'hi': hi, 'n': n, 'passes': passes, 'usable': usable}
+	return result
+
+
+def fit_background_stamp(img, flux_cutoff=8e4, exclude=None, exclude_percentile=50.0):
+	"""
+	B*: one cadence of one stamp.  Returns ``(background scalar float64, mask bool (H, W))``; the value is the float32 of
+	:func:`bstar_frames`.
+	"""
+	img = np.asarray(img, dtype='float32')
+	mask = stamp_mask(img, flux_cutoff, exclude)
+	ex = None if exclude is None else np.asarray(exclude, dtype=bool).reshape(1, -1)
+	return float(bstar_frames(img.reshape(1, -1), flux_cutoff, ex, exclude_percentile)[0]), mask
+
+
 def background_series(raw, flux_cutoff=8e4, exclude=None):
 	"""B* for a ``(H, W, T)`` cube -> float32 ``(T,)`` (stored like the reference's float32 blocks, prepare.py:327)."""
-	T = raw.shape[2]
-	out = np.empty(T, dtype='float32')
-	for k in range(T):
-		ex = None if exclude is None else exclude[:, :, k]
-		out[k] = fit_background_stamp(raw[:, :, k], flux_cutoff, ex)[0]
-	return out
+	H, W, T = raw.shape
+	X = np.moveaxis(np.asarray(raw, dtype='float32'), 2, 0).reshape(T, H*W)
+	ex = None if exclude is None else np.moveaxis(np.asarray(exclude, dtype=bool), 2, 0).reshape(T, H*W)
+	return bstar_frames(X, flux_cutoff, ex)
 
 
 def time_smooth_width(cadence):

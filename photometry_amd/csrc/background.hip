@@ -850,6 +850,9 @@ __global__ __launch_bounds__(256) void tp_threshold_flags_kernel(const float* __
 
 // Generic fallback for stamps with more than 256 pixels: one wavefront per (target, cadence), values
 // sorted in LDS.  Correct for any size that fits LDS; not tuned (large stamps are the bright-star tail).
+// The arithmetic is B*'s definition (oracle/backgrounds.py, module header) operation for operation, like bkg_frame_sort /
+// bkg_frame_clip above: the sums over eight interleaved accumulators (lanes 0..7 here), the division-free 3-sigma test, the
+// clipped values taken off the sums eight at a time from the top and from the bottom.
 __global__ __launch_bounds__(64) void tp_bkg_stamp_generic_kernel(BkgArgs a, int np2)
 {
 	extern __shared__ float sv[];
@@ -867,13 +870,26 @@ __global__ __launch_bounds__(64) void tp_bkg_stamp_generic_kernel(BkgArgs a, int
 		float x = inf;
 		if (i < a.n_pix) {
 			x = base[(int64_t)i * a.t_pitch];
-			const bool ok = (fabsf(x) <= 3.402823466e+38f) && !(x > a.flux_cutoff) && !(x < 0.f);
+			const bool ok = (x >= 0.f) && (x <= a.flux_cutoff);
 			cnt += ok ? 1 : 0;
 			x = ok ? x : inf;
 		}
 		sv[i] = x;
 	}
 	atomicAdd(&s_n, cnt);
+	__syncthreads();
+	// the sums of the kept values in pixel order: accumulator g = lane g takes the pixels g, g + 8, ...
+	const int g = lane & 7;
+	double s1 = 0.0, s2 = 0.0;
+	if (lane < 8)
+		for (int i = g; i < a.n_pix; i += 8) {
+			const float x = sv[i];
+			const double zd = (double)((x < inf) ? x : 0.f);
+			s1 += zd;
+			s2 = __builtin_fma(zd, zd, s2);
+		}
+	s1 = frame_sum<8>(s1);
+	s2 = frame_sum<8>(s2);
 	__syncthreads();
 	for (int size = 2; size <= np2; size <<= 1) {
 		for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -887,35 +903,44 @@ __global__ __launch_bounds__(64) void tp_bkg_stamp_generic_kernel(BkgArgs a, int
 			__syncthreads();
 		}
 	}
-	if (lane != 0) return;
+	if (lane >= 8) return;
 	const int n = s_n;
 	float result = __builtin_nanf("");
 	const int nmasked = a.n_pix - n;
 	if (n > 0 && !((float)nmasked > a.exclude_fraction * (float)a.n_pix)) {
 		int lo_i = 0, hi_i = n;
-		double med = 0.0, mean = 0.0, sd = 0.0;
-		for (int it = 0; it <= 5; ++it) {
+		double med = 0.0;
+		for (int it = 0; ; ++it) {
 			const int m = hi_i - lo_i;
 			const int m1 = lo_i + (m >> 1);
 			const int m0 = (m & 1) ? m1 : (m1 - 1);
-			double s1 = 0.0, s2 = 0.0;
-			for (int i = lo_i; i < hi_i; ++i) { const double x = (double)sv[i]; s1 += x; s2 += x * x; }
-			med = ((double)sv[m0] + (double)sv[m1]) / 2.0;
-			mean = s1 / (double)m;
-			double var = s2 / (double)m - mean * mean;
-			if (var < 0.0) var = 0.0;
-			sd = sqrt(var);
+			med = ((double)sv[m0] + (double)sv[m1]) * 0.5;
 			if (it == 5) break;
-			const double lo = med - 3.0 * sd, hi = med + 3.0 * sd;
-			int below = 0, above = 0;
-			for (int i = lo_i; i < hi_i; ++i) { const double x = (double)sv[i]; below += (x < lo); above += (x > hi); }
-			if (below == 0 && above == 0) break;
-			lo_i += below;
-			hi_i -= above;
+			const double mm = (double)m;
+			double q9 = 9.0 * (mm * s2 - s1 * s1);
+			if (!(q9 > 0.0)) q9 = 0.0;
+			// the clipped ranks: na from the top, nb from the bottom (every lane counts them all: the test is monotone in the rank)
+			int na = 0, nb = 0;
+			while (na < m) { const double d = ((double)sv[hi_i - 1 - na] - med) * mm; if ((d > 0.0) && (d * d > q9)) ++na; else break; }
+			while (nb < m) { const double d = ((double)sv[lo_i + nb] - med) * mm; if ((d < 0.0) && (d * d > q9)) ++nb; else break; }
+			if (na == 0 && nb == 0) break;
+			double r1 = 0.0, r2 = 0.0;
+			for (int t = g; t < na || t < nb; t += 8) {
+				if (t < na) { const double x = (double)sv[hi_i - 1 - t]; r1 += x; r2 = __builtin_fma(x, x, r2); }
+				if (t < nb) { const double x = (double)sv[lo_i + t]; r1 += x; r2 = __builtin_fma(x, x, r2); }
+			}
+			s1 -= frame_sum<8>(r1);
+			s2 -= frame_sum<8>(r2);
+			lo_i += nb;
+			hi_i -= na;
 		}
-		result = sextractor_mode(med, mean, sd);
+		const double mm = (double)(hi_i - lo_i);
+		const double mean = s1 / mm;
+		double var = s2 / mm - mean * mean;
+		if (var < 0.0) var = 0.0;
+		result = sextractor_mode(med, mean, sqrt(var));
 	}
-	a.out[(int64_t)target * a.out_pitch + k] = result;
+	if (lane == 0) a.out[(int64_t)target * a.out_pitch + k] = result;
 }
 
 // B2: bottleneck.nanmean over the window [k-w, k+w] clipped to the series (float32 accumulate)

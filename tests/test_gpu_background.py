@@ -3,9 +3,8 @@
 GPU parity of B* (stamp background), B2 (time smoothing), B3 (subtraction) and of the on-the-fly
 subtraction inside A1 / A6.
 
-B* statistics are float64 on both sides but summed in a different order (sorted order on the device,
-numpy pairwise in the oracle): the float32 result agrees to 1 ulp (rtol 2e-7) -- asserted at 1e-6.
-B2 / B3 are float32 and bit-exact.
+B* is build-defined and defined down to the last bit (oracle/backgrounds.py, module header: which float64 operations in
+which order); the kernels implement that arithmetic, so B* is asserted BIT FOR BIT like B2 / B3.
 """
 import numpy as np
 import pytest
@@ -28,7 +27,7 @@ def _scene(nt, T, H, W, seed):
 	return s
 
 
-@pytest.mark.parametrize("nt,T,H,W", [(6, 70, 15, 15), (5, 33, 11, 11), (3, 9, 16, 16), (2, 12, 20, 21), (4, 40, 6, 5)])
+@pytest.mark.parametrize("nt,T,H,W", [(6, 70, 15, 15), (5, 33, 11, 11), (3, 9, 16, 16), (2, 12, 20, 21), (4, 40, 6, 5), (2, 7, 2, 2), (3, 37, 25, 25)])
 def test_background_stamp_parity(ctx, nt, T, H, W):
 	from photometry_amd import engine
 	from photometry_amd.device import DeviceCube
@@ -41,14 +40,67 @@ def test_background_stamp_parity(ctx, nt, T, H, W):
 	raw[0, 0, 0, 4] = 9e4; raw[0, 0, 1, 4] = np.inf; raw[0, 1, 0, 4] = -1.0
 	bkg = engine.background_stamp(ctx, DeviceCube.from_host(ctx, raw)).to_host()[:, :T]
 	ref = np.stack([ob.background_series(raw[i]) for i in range(nt)])
-	np.testing.assert_array_equal(np.isnan(bkg), np.isnan(ref))
-	np.testing.assert_allclose(bkg, ref, rtol=1e-6, equal_nan=True)
+	np.testing.assert_array_equal(bkg, ref)       # bit for bit, NaN positions included
 	assert bkg[0, 1] == 1000.0 and np.isnan(bkg[0, 2]) and np.isnan(bkg[0, 3])
 	# the estimate tracks the injected background (level +-5 % sinusoid), stars clipped away
 	truth = s.backgrounds[:, 0, 0, :]
 	ok = np.isfinite(bkg) & (np.arange(T)[None, :] > 4)
 	if H * W >= 121:
 		assert np.nanmedian(np.abs(bkg[ok] / truth[ok] - 1)) < 0.03
+
+
+def _hard_frames(rng, F, P):
+	"""Frames that exercise every branch of the clipping: deep clips at both ends (more than eight values a pass: several steps of
+	the walk), values on both sides of the thresholds within a few ulp, ties, constant frames, frames near the 50 % rule."""
+	X = rng.normal(100.0, 3.0, (F, P)).astype('float32')
+	kind = rng.integers(0, 8, F)
+	for f in range(F):
+		k = kind[f]
+		if k == 0:      # a bright star: 10-40 pixels far above the sky
+			idx = rng.choice(P, size=min(P, int(rng.integers(10, 41))), replace=False)
+			X[f, idx] += rng.uniform(50, 60000, len(idx)).astype('float32')
+		elif k == 1:    # low outliers as well (cold pixels): both ends clip, many at a time
+			idx = rng.choice(P, size=min(P, int(rng.integers(9, 30))), replace=False)
+			X[f, idx] = rng.uniform(0, 20, len(idx)).astype('float32')
+			idx = rng.choice(P, size=min(P, int(rng.integers(9, 30))), replace=False)
+			X[f, idx] += rng.uniform(100, 3000, len(idx)).astype('float32')
+		elif k == 2:    # heavy ties: quantised values
+			X[f] = np.round(X[f])
+		elif k == 3:    # constant but for a few
+			X[f] = np.float32(rng.uniform(1, 7e4))
+			X[f, rng.choice(P, size=min(P, 3), replace=False)] *= np.float32(1.0001)
+		elif k == 4:    # masked pixels close to the 50 % rule
+			nm = min(P, P // 2 + int(rng.integers(-2, 3)))
+			if nm > 0:
+				X[f, rng.choice(P, size=nm, replace=False)] = [np.nan, -1.0, 9e4, np.inf][int(rng.integers(0, 4))]
+		elif k == 5:    # a value a few ulp either side of med + 3 std of the first pass
+			x64 = X[f].astype('float64')
+			thr = np.median(x64) + 3 * x64.std()
+			X[f, 0] = np.nextafter(np.float32(thr), np.float32(np.inf if rng.integers(0, 2) else -np.inf))
+		elif k == 6:    # wide dynamic range
+			X[f] = np.exp(rng.uniform(-20, 11, P)).astype('float32')
+	return X
+
+
+@pytest.mark.parametrize("H,W", [(15, 15), (11, 11), (16, 16), (3, 3), (20, 21)])
+def test_background_stamp_bit_exact_on_hard_frames(ctx, H, W):
+	"""B* bit for bit on 4 x 1300 frames built to hit every decision (see _hard_frames); 20 x 21 goes through the generic kernel."""
+	from photometry_amd import engine
+	from photometry_amd.device import DeviceCube
+	from oracle import backgrounds as ob
+	rng = np.random.default_rng(1000 + H * W)
+	nt, T, P = 4, 1300, H * W
+	X = _hard_frames(rng, nt * T, P)
+	raw = np.ascontiguousarray(np.moveaxis(X.reshape(nt, T, H, W), 1, 3))
+	bkg = engine.background_stamp(ctx, DeviceCube.from_host(ctx, raw)).to_host()[:, :T]
+	ref, st = ob.bstar_frames(X, full=True)
+	np.testing.assert_array_equal(bkg.reshape(-1), ref)
+	if P >= 121:
+		assert (st['passes'] >= 3).sum() > 100 and ((st['lo'] > 8) & (st['n'] - st['hi'] > 8)).sum() > 20   # the branches were taken
+	# and the one-pass kernel's series is the same series
+	q = ctx.array(np.zeros(T, dtype='int32'))
+	b_raw, _, _ = engine.background_sumimage(ctx, DeviceCube.from_host(ctx, raw), q, 3)
+	np.testing.assert_array_equal(b_raw.to_host()[:, :T].reshape(-1), ref)
 
 
 @pytest.mark.parametrize("nt,T,H,W", [(6, 70, 15, 15), (5, 33, 11, 11), (3, 9, 16, 16), (4, 40, 6, 5), (3, 32, 15, 15), (2, 64, 13, 9), (2, 200, 17, 17)])

@@ -126,7 +126,7 @@ def test_config4_one_rank_share_aperture_plus_psf():
 	background + aperture photometry + the LinPSF fit, every per-target result in the packed block that is gathered -- at its
 	full per-GPU size, by size-independent properties: a second step reproduces the block bit for bit; the block unpacks
 	(``comm.unpack_block``, the layout the gloo test gathers) into the arrays the work object holds; a seeded sample of targets
-	equals the oracle (aperture: bit for bit given the device background; LinPSF: 1e-8).  The cross-rank part (sharding, the
+	equals the oracle from the raw cube alone (aperture: bit for bit, both background series included; LinPSF: 1e-8).  The cross-rank part (sharding, the
 	gather of the blocks, reassembly in global order) is covered on CPU by tests/test_distributed_gloo.py.
 	"""
 	from photometry_amd import simulate, engine, pipeline, psf as hpsf, comm as tpcomm
@@ -166,7 +166,11 @@ def test_config4_one_rank_share_aperture_plus_psf():
 		i = int(i)
 		raw = cubes['raw'].slice0(i, 1).to_host()[0]
 		err = cubes['images_err'].slice0(i, 1).to_host()[0]
-		series = bkg[i][None, None, :]
+		braw = ob.background_series(raw)                         # the oracle's own B* and B2: nothing of the device on its side
+		np.testing.assert_array_equal(work.bkg_raw.slice0(i, 1).to_host()[0, :T], braw)
+		bsm = ob.smooth_time(braw, 3)
+		np.testing.assert_array_equal(bkg[i], bsm)
+		series = bsm[None, None, :]
 		img, e2 = ob.subtract_background(raw, err, series)
 		S = osum.sumimage(img, scene.quality)
 		ref = oap.do_photometry(S, img, e2, np.broadcast_to(series.astype('float32'), img.shape), tuple(scene.stamps[i]), scene.target_pos_row[i],

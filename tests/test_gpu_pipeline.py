@@ -128,6 +128,11 @@ def test_raw_step_reads_the_cube_once(ctx, shape, time_smooth):
 	got = _collect(work)
 	np.testing.assert_array_equal(work.bkg_raw.to_host()[:, :T], ref_work.bkg_raw.to_host()[:, :T])
 	np.testing.assert_array_equal(work.bkg.to_host()[:, :T], ref_work.bkg.to_host()[:, :T])
+	from oracle import backgrounds as ob
+	for i in range(min(n, 6)):   # ... and the oracle's own series, bit for bit (B* is defined to the last bit)
+		braw = ob.background_series(s.raw[i])
+		np.testing.assert_array_equal(work.bkg_raw.to_host()[i, :T], braw)
+		np.testing.assert_array_equal(work.bkg.to_host()[i, :T], ob.smooth_time(braw, time_smooth))
 	np.testing.assert_allclose(got['sumimage'], ref['sumimage'], rtol=1e-13, atol=0, equal_nan=True)
 	diff = s.raw - work.bkg.to_host()[:, None, None, :T]           # float32, prepare.py:421
 	np.testing.assert_allclose(got['sumimage'], osum.sumimage_batch(diff, s.quality), rtol=1e-12, atol=0, equal_nan=True)

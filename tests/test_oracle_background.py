@@ -42,6 +42,112 @@ def test_sigma_clip_and_mode_estimator():
 	np.testing.assert_allclose(ob.sextractor_background(x), 2.5*10 - 1.5*x.mean())
 
 
+def _bstar_scalar(x, flux_cutoff=8e4, frac=0.5):
+	"""B*'s definition (oracle/backgrounds.py header) once more, one frame, plain Python loops: a second, independent writing of
+	the same text against which the vectorised :func:`oracle.backgrounds.bstar_frames` is checked."""
+	f64 = np.float64
+	x = np.asarray(x, dtype='float32').ravel()
+	P = len(x)
+	kept = [v for v in x if (v >= 0) and (v <= np.float32(flux_cutoff))]
+	n = len(kept)
+	if n == 0 or np.float32(P - n) > np.float32(frac) * np.float32(P):
+		return np.float32(np.nan)
+	tree = lambda a: ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))
+	a1, a2 = [f64(0)] * 8, [f64(0)] * 8
+	for p in range(P):
+		v = x[p]
+		if (v >= 0) and (v <= np.float32(flux_cutoff)):
+			a1[p % 8] = a1[p % 8] + f64(v)
+			a2[p % 8] = a2[p % 8] + f64(v) * f64(v)
+	s1, s2 = tree(a1), tree(a2)
+	k = sorted(f64(v) for v in kept)
+	lo, hi = 0, n
+	for it in range(6):
+		m = hi - lo
+		m1 = lo + m // 2
+		m0 = m1 if m % 2 else m1 - 1
+		med = (k[m0] + k[m1]) * f64(0.5)
+		if it == 5:
+			break
+		mm = f64(m)
+		q9 = f64(9) * (mm * s2 - s1 * s1)
+		if not q9 > 0:
+			q9 = f64(0)
+		na = 0
+		while na < m and (k[hi - 1 - na] - med) * mm > 0 and ((k[hi - 1 - na] - med) * mm)**2 > q9:
+			na += 1
+		nb = 0
+		while nb < m and (k[lo + nb] - med) * mm < 0 and ((k[lo + nb] - med) * mm)**2 > q9:
+			nb += 1
+		if na == 0 and nb == 0:
+			break
+		r1, r2 = [f64(0)] * 8, [f64(0)] * 8
+		s = 0
+		while 8 * s < max(na, nb):
+			for g in range(8):
+				t = 8 * s + g
+				if t < na:
+					r1[g] = r1[g] + k[hi - 1 - t]; r2[g] = r2[g] + k[hi - 1 - t] * k[hi - 1 - t]
+				if t < nb:
+					r1[g] = r1[g] + k[lo + t]; r2[g] = r2[g] + k[lo + t] * k[lo + t]
+			s += 1
+		s1, s2 = s1 - tree(r1), s2 - tree(r2)
+		lo, hi = lo + nb, hi - na
+	mm = f64(hi - lo)
+	mean = s1 / mm
+	var = s2 / mm - mean * mean
+	if var < 0:
+		var = f64(0)
+	sd = np.sqrt(var)
+	if sd == 0:
+		return np.float32(mean)
+	if abs(mean - med) / sd < 0.3:
+		return np.float32(f64(2.5) * med - f64(1.5) * mean)
+	return np.float32(med)
+
+
+def _frames(rng, F, P):
+	X = rng.normal(100.0, 3.0, (F, P)).astype('float32')
+	for f in range(F):
+		k = f % 6
+		if k == 0:
+			idx = rng.choice(P, size=min(P, 25), replace=False); X[f, idx] += rng.uniform(50, 60000, len(idx)).astype('float32')
+		elif k == 1:
+			idx = rng.choice(P, size=min(P, 12), replace=False); X[f, idx] = rng.uniform(0, 20, len(idx)).astype('float32')
+			idx = rng.choice(P, size=min(P, 12), replace=False); X[f, idx] += rng.uniform(100, 3000, len(idx)).astype('float32')
+		elif k == 2:
+			X[f] = np.round(X[f])
+		elif k == 3:
+			X[f, rng.choice(P, size=max(0, min(P, P // 2 + (f % 3) - 1)), replace=False)] = np.nan
+		elif k == 4:
+			X[f] = np.exp(rng.uniform(-20, 11, P)).astype('float32')
+	return X
+
+
+def test_bstar_definition_two_writings_agree():
+	"""The vectorised definition against the plain-loop writing of the same text, bit for bit; both ends clipping, more than eight
+	values a pass, ties, frames around the 50 % rule, stamps from 1 to 441 pixels."""
+	rng = np.random.default_rng(7)
+	for P in (225, 121, 256, 441, 30, 1, 9):
+		X = _frames(rng, 60, P)
+		got, st = ob.bstar_frames(X, full=True)
+		ref = np.array([_bstar_scalar(X[f]) for f in range(len(X))], dtype='float32')
+		np.testing.assert_array_equal(got, ref)
+		if P >= 121:
+			assert (st['passes'] >= 2).any() and (st['lo'] > 8).any() and (st['n'] - st['hi'] > 8).any()
+
+
+def test_bstar_definition_is_the_literal_estimator_up_to_rounding():
+	"""The defined arithmetic against the literal astropy / photutils statements with numpy's own summation orders: equal to
+	float32 rounding on frames where no decision sits within rounding of its threshold (all of these)."""
+	rng = np.random.default_rng(8)
+	X = _frames(rng, 300, 225)
+	got = ob.bstar_frames(X)
+	lit = np.array([ob.fit_background_stamp_literal(X[f].reshape(15, 15))[0] for f in range(len(X))])
+	np.testing.assert_array_equal(np.isnan(got), np.isnan(lit))
+	np.testing.assert_allclose(got, lit.astype('float32'), rtol=2.4e-7, equal_nan=True)   # 2 ulp of float32
+
+
 def test_smooth_time_matches_definition():
 	"""prepare.py:317-335"""
 	rng = np.random.default_rng(1)
