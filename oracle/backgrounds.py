@@ -41,8 +41,10 @@ more than rounding.  The definition:
    without division or square root.  The clipped values are the ``na`` highest and ``nb`` lowest ranks of the range; their
    sums again run over eight accumulators: accumulator ``g`` takes the ``(g + 8 s)``-th value from the top, then the
    ``(g + 8 s)``-th from the bottom, for ``s = 0, 1, ...``; ``s1 -= tree8(r1)``, ``s2 -= tree8(r2)``.
-4. ``mean = s1 / m``; ``var = s2 / m - mean*mean`` (negative -> 0); ``sd = sqrt(var)``; the SExtractor rule on
-   ``(med, mean, sd)``; the result rounded to float32.
+4. The SExtractor rule on the sums of the ``m`` kept values, with one division and no square root: ``q = m*s2 - s1*s1``
+   (``= m**2 var``), ``e = s1 - m*med`` (``= m (mean - med)``), ``mean = s1 / m``;  ``q <= 0`` (or NaN) -> ``mean``
+   (``std == 0``);  ``e*e < 0.09*q`` -> ``2.5*med - 1.5*mean`` (``|mean - med| / std < 0.3``);  else ``med``;  the result
+   rounded to float32.
 
 Against the LITERAL astropy / photutils statements (:func:`fit_background_stamp_literal`: ``np.median``, ``np.std``,
 ``np.mean`` -- numpy's pairwise sums, the two-pass variance) the defined arithmetic agrees to float32 rounding wherever no
@@ -188,12 +190,10 @@ def bstar_frames(X, flux_cutoff=8e4, exclude=None, exclude_percentile=50.0, full
 			lo = lo + nb
 			hi = hi - na
 		mm = (hi - lo).astype('float64')
+		q = mm*s2 - s1*s1
+		e = s1 - mm*med
 		mean = s1 / mm
-		var = s2 / mm - mean*mean
-		var = np.where(var < 0.0, 0.0, var)
-		sd = np.sqrt(var)
-		with np.errstate(divide='ignore'):
-			bkg = np.where(sd == 0.0, mean, np.where(np.abs(mean - med) / sd < 0.3, 2.5*med - 1.5*mean, med))
+		bkg = np.where(q > 0.0, np.where(e*e < 0.09*q, 2.5*med - 1.5*mean, med), mean)
 	result = np.where(usable, bkg, np.nan).astype('float32')
 	if full:
 		return result, {'lo': lo, 'hi': hi, 'n': n, 'passes': passes, 'usable': usable}

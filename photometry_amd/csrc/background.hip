@@ -116,12 +116,16 @@ struct BkgArgs {
 	float flux_cutoff; float exclude_fraction;
 };
 
-// SExtractorBackground (photutils 1.3.0) on the clipped statistics
-__device__ __forceinline__ float sextractor_mode(double med, double mean, double sd) {
-	double bkg;
-	if (sd == 0.0) bkg = mean;
-	else if (fabs(mean - med) / sd < 0.3) bkg = 2.5 * med - 1.5 * mean;
-	else bkg = med;
+// SExtractorBackground (photutils 1.3.0: sd == 0 -> mean; |mean - med| / sd < 0.3 -> 2.5 med - 1.5 mean; else med) on the sums of
+// the m kept values, as B*'s definition states it (oracle/backgrounds.py, step 4): no square root and one division.  With
+// q = m s2 - s1^2 = m^2 var and e = s1 - m med = m (mean - med):  sd == 0  <=>  q <= 0;  |mean - med| / sd < 0.3  <=>  e^2 < 0.09 q.
+__device__ __forceinline__ float sextractor_mode_sums(double med, double mm, double s1, double s2) {
+	const double q = mm * s2 - s1 * s1;
+	const double e = s1 - mm * med;
+	const double mean = s1 / mm;
+	double bkg = med;
+	if (e * e < 0.09 * q) bkg = 2.5 * med - 1.5 * mean;
+	if (!(q > 0.0)) bkg = mean;
 	return (float)bkg;
 }
 
@@ -151,19 +155,20 @@ template <int G> __device__ __forceinline__ double frame_sum(double x) {
 
 // Cross-lane compare-exchange stage: register j against register j (MIRROR: R-1 - j) of the partner lane; sel = -inf
 // keeps the minimum (v_med3_f32(a, b, -inf) = min), sel = +inf the maximum.
+template <int CTRL> __device__ __forceinline__ float xlane(float x) { return dpp_f<CTRL>(x); }
 template <int CTRL, bool MIRROR, int R>
 __device__ __forceinline__ void cross_stage(float (&v)[R], float sel) {
 	if (MIRROR) {
 #pragma unroll
 		for (int j = 0; j < R / 2; ++j) {
 			const float a = v[j], b = v[R - 1 - j];
-			const float pa = dpp_f<CTRL>(b), pb = dpp_f<CTRL>(a);
+			const float pa = xlane<CTRL>(b), pb = xlane<CTRL>(a);
 			v[j] = __builtin_amdgcn_fmed3f(a, pa, sel);
 			v[R - 1 - j] = __builtin_amdgcn_fmed3f(b, pb, sel);
 		}
 	} else {
 #pragma unroll
-		for (int j = 0; j < R; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], dpp_f<CTRL>(v[j]), sel);
+		for (int j = 0; j < R; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], xlane<CTRL>(v[j]), sel);
 	}
 }
 // ascending bitonic MERGE of a lane's R values (strides R/2..1)
@@ -172,6 +177,14 @@ template <int R> __device__ __forceinline__ void local_merge(float (&v)[R]) { Bi
 // LDS index of rank r of a staged frame: every run of 32 ranks is followed by 4 pad words, so that the 16-byte stores of the
 // lanes of a frame fall into different banks
 __device__ __forceinline__ int rank_idx(int r) { return r + ((r >> 5) << 2); }
+// the staged value of rank r (0 <= r < 256); unsigned index arithmetic: the signed form cost two more address instructions
+__device__ __forceinline__ float rank_read(const float* fr, int r) {
+	const unsigned u = (unsigned)r;
+	return fr[u + ((u >> 5) << 2)];
+}
+// wavefront votes on a bool (the header's __ballot / __any take an int: a select and a compare more per call)
+__device__ __forceinline__ uint64_t tp_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool tp_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 // One frame (cadence) per G lanes, from the loaded values to the background estimate: mask + float64 sums, distributed sort,
 // rank-staged sigma clipping, SExtractor mode.  `v` holds the lane's loaded pixel values (pixel i = G j + g in register j; the
@@ -250,7 +263,7 @@ __device__ __forceinline__ float bkg_frame_clip(const BkgArgs& a, float (&v)[256
 		const int m = hi_i - lo_i;
 		const int m1 = lo_i + (m >> 1);          // upper middle rank
 		const int m0 = (m & 1) ? m1 : (m1 - 1);  // lower middle rank
-		med = ((double)fr[rank_idx(m0)] + (double)fr[rank_idx(m1)]) * 0.5;
+		med = ((double)rank_read(fr, m0) + (double)rank_read(fr, m1)) * 0.5;
 		if (it == 5) break;                        // maxiters = 5 clipping passes, then the final statistics
 		const double mm = (double)m;
 		double q9 = 9.0 * (mm * s2 - s1 * s1);    // 9 m^2 var
@@ -263,23 +276,23 @@ __device__ __forceinline__ float bkg_frame_clip(const BkgArgs& a, float (&v)[256
 		// almost never the case (stars clip at the top), and the walk then runs for the upper end alone -- about half the
 		// instructions of a step.  Same sums, same order.
 		{
-			const double db0 = ((double)fr[rank_idx(lo_i)] - med) * mm;
+			const double db0 = ((double)rank_read(fr, lo_i) - med) * mm;
 			const bool ob0 = usable && (db0 < 0.0) && (db0 * db0 > q9);
-			general = __any(ob0) != 0;
+			general = tp_any(ob0);
 			if (!general) {
 #pragma unroll 1
 				for (int base = 0; ; base += G) {
 					const int rt = hi_i - 1 - g - base;
 					const bool vt = more_t && (rt >= lo_i);
-					const float xt = fr[rank_idx(vt ? rt : lo_i)];
+					const float xt = rank_read(fr, vt ? rt : lo_i);
 					const double dt = ((double)xt - med) * mm;
 					const bool ot = vt && (dt > 0.0) && (dt * dt > q9);
-					const unsigned bt = (unsigned)(__ballot(ot) >> bshift) & BMASK;
+					const unsigned bt = (unsigned)(tp_ballot(ot) >> bshift) & BMASK;
 					const int ct = __builtin_ctz(~bt);
-					if (g < ct) { const double x = (double)xt; r1 += x; r2 = __builtin_fma(x, x, r2); }
+					{ const double x = (double)((g < ct) ? xt : 0.f); r1 += x; r2 = __builtin_fma(x, x, r2); }   // + 0.0 changes nothing
 					top += ct;
 					more_t = (ct == G);
-					if (!__any(more_t)) break;
+					if (!tp_any(more_t)) break;
 				}
 			}
 		}
@@ -288,31 +301,28 @@ __device__ __forceinline__ float bkg_frame_clip(const BkgArgs& a, float (&v)[256
 		for (int base = 0; ; base += G) {
 			const int rt = hi_i - 1 - g - base, rb = lo_i + g + base;
 			const bool vt = more_t && (rt >= lo_i), vb = more_b && (rb < hi_i);
-			const float xt = fr[rank_idx(vt ? rt : lo_i)], xb = fr[rank_idx(vb ? rb : lo_i)];
+			const float xt = rank_read(fr, vt ? rt : lo_i), xb = rank_read(fr, vb ? rb : lo_i);
 			const double dt = ((double)xt - med) * mm, db = ((double)xb - med) * mm;
 			const bool ot = vt && (dt > 0.0) && (dt * dt > q9), ob = vb && (db < 0.0) && (db * db > q9);
 			// number of consecutive clipped ranks from the end of the range, among this step's G
-			const unsigned bt = (unsigned)(__ballot(ot) >> bshift) & BMASK, bb = (unsigned)(__ballot(ob) >> bshift) & BMASK;
+			const unsigned bt = (unsigned)(tp_ballot(ot) >> bshift) & BMASK, bb = (unsigned)(tp_ballot(ob) >> bshift) & BMASK;
 			const int ct = __builtin_ctz(~bt), cb = __builtin_ctz(~bb);
-			if (g < ct) { const double x = (double)xt; r1 += x; r2 = __builtin_fma(x, x, r2); }
-			if (g < cb) { const double x = (double)xb; r1 += x; r2 = __builtin_fma(x, x, r2); }
+			{ const double x = (double)((g < ct) ? xt : 0.f); r1 += x; r2 = __builtin_fma(x, x, r2); }
+			{ const double x = (double)((g < cb) ? xb : 0.f); r1 += x; r2 = __builtin_fma(x, x, r2); }
 			top += ct; bot += cb;
 			more_t = (ct == G); more_b = (cb == G);
-			if (!__any(more_t || more_b)) break;
+			if (!tp_any(more_t || more_b)) break;
 		}
-		if (!__any((top | bot) != 0)) break;       // nchanged == 0 in every frame of the wavefront: the statistics are final
+		if (!tp_any((top | bot) != 0)) break;       // nchanged == 0 in every frame of the wavefront: the statistics are final
 		s1 -= frame_sum<G>(r1);
 		s2 -= frame_sum<G>(r2);
 		lo_i += bot;
 		hi_i -= top;
 	}
 	float result = __builtin_nanf("");
-	if (usable) {
-		const double mm = (double)(hi_i - lo_i);
-		const double mean = s1 / mm;
-		double var = s2 / mm - mean * mean;
-		if (var < 0.0) var = 0.0;
-		result = sextractor_mode(med, mean, sqrt(var));
+	{
+		const double mm = usable ? (double)(hi_i - lo_i) : 1.0;
+		result = usable ? sextractor_mode_sums(med, mm, s1, s2) : result;
 	}
 	return result;
 }
@@ -934,11 +944,7 @@ __global__ __launch_bounds__(64) void tp_bkg_stamp_generic_kernel(BkgArgs a, int
 			lo_i += nb;
 			hi_i -= na;
 		}
-		const double mm = (double)(hi_i - lo_i);
-		const double mean = s1 / mm;
-		double var = s2 / mm - mean * mean;
-		if (var < 0.0) var = 0.0;
-		result = sextractor_mode(med, mean, sqrt(var));
+		result = sextractor_mode_sums(med, (double)(hi_i - lo_i), s1, s2);
 	}
 	if (lane == 0) a.out[(int64_t)target * a.out_pitch + k] = result;
 }

@@ -94,14 +94,12 @@ def _bstar_scalar(x, flux_cutoff=8e4, frac=0.5):
 		s1, s2 = s1 - tree(r1), s2 - tree(r2)
 		lo, hi = lo + nb, hi - na
 	mm = f64(hi - lo)
+	q = mm * s2 - s1 * s1
+	e = s1 - mm * med
 	mean = s1 / mm
-	var = s2 / mm - mean * mean
-	if var < 0:
-		var = f64(0)
-	sd = np.sqrt(var)
-	if sd == 0:
+	if not q > 0:
 		return np.float32(mean)
-	if abs(mean - med) / sd < 0.3:
+	if e * e < f64(0.09) * q:
 		return np.float32(f64(2.5) * med - f64(1.5) * mean)
 	return np.float32(med)
 

@@ -17,11 +17,18 @@ if len(sys.argv) > 1:
 	for _ in range(2):
 		engine.background_sumimage(ctx, raw, q, 3, bkg_raw=outs[0], bkg=outs[1], sumimage=outs[2])
 	ctx.sync()
+	ctx.profile(True)
+	ctx.profile_reset()
 	t0 = time.perf_counter()
 	for _ in range(5):
 		engine.background_sumimage(ctx, raw, q, 3, bkg_raw=outs[0], bkg=outs[1], sumimage=outs[2])
 	ctx.sync()
-	print(sys.argv[1], 'B*+B2+A1 ms', round((time.perf_counter() - t0) / 5 * 1e3, 3), flush=True)
+	wall = (time.perf_counter() - t0) / 5 * 1e3
+	ctx.profile(False)
+	print({k: round(v[1] / max(v[0], 1), 3) for k, v in ctx.profile_report().items() if v[0]}, 'wall', round(wall, 3))
+	import hashlib
+	h = hashlib.sha256(outs[0].to_host().tobytes() + outs[1].to_host().tobytes() + outs[2].to_host().tobytes()).hexdigest()[:12]
+	print(sys.argv[1], 'outputs', h, flush=True)
 else:
 	import glob
 	for v in sorted(os.path.basename(p)[4:-3] for p in glob.glob(os.path.join(ROOT, 'tools', 'lab', 'lib_*.so'))):
