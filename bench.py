@@ -61,8 +61,9 @@ def parse_args(argv=None):
 	p.add_argument('--seed', type=int, default=1)
 	p.add_argument('--no-gather', action='store_true')
 	p.add_argument('--no-bind', action='store_true', help="leave the CPU affinity alone (default: the process is bound to the cores of its GPU's NUMA node)")
-	p.add_argument('--gather-when', choices=('auto', 'step', 'final'), default='auto', help='N > 1: gather the output block every step (under the next '
-		"step's compute), once after the last step, or (auto) whichever the warm-up's measurement favours")
+	p.add_argument('--gather-when', choices=('auto', 'step', 'final'), default='final', help='N > 1: gather the output block once after the last step '
+		"(default: north_star's final light-curve gather), every step under the next step's compute, or (auto) whichever the warm-up's measurement favours")
+	p.add_argument('--no-compact', action='store_true', help='N > 1: gather the full float64 block instead of the compact one (flux, flux_err, flux_background as float32)')
 	p.add_argument('--host-group', choices=('socket', 'gloo'), default='socket', help='N > 1: the host-side group (rendezvous, barriers, RCCL id): '
 		'plain TCP sockets (no PyTorch) or torch.distributed gloo')
 	p.add_argument('--no-extra', action='store_true', help='skip the extra legs (premade cubes, LinPSF, end to end, stages)')
@@ -122,7 +123,7 @@ def main():
 	extras = (world == 1) and (workload == 'c2') and not args.no_extra
 	worker = sharded.DeviceShardWorker(ctx, scene, capacity=Nt, psf=psf, nbuf=2 if world > 1 else 1, extras=extras)
 	run = sharded.ShardedRun(worker, Nt * world, rank=rank, world=world, group=group,
-		gather='none' if args.no_gather else 'auto', when='step', shared_device=shared_device)
+		gather='none' if args.no_gather else 'auto', when='step', shared_device=shared_device, compact=not args.no_compact)
 	cubes, batch, lin = worker.cubes, worker.batch, worker.lin
 
 	def device_sync():
@@ -229,15 +230,16 @@ def main():
 				'frac_of_hbm_peak': step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 'mean_mask_pixels': n_mask / Nt,
 				'note': 'the raw cube is read once per step (rounds 1-3: twice -- the background kernel, then the sum-image phase of the fused kernel)'},
 			'kernels': rows,
-			'gather': {'mode': run.mode, 'when': run.when if run.gathers else None, 'bytes_per_rank_per_step': worker.block_nbytes if world > 1 else 0,
-				'block': 'light curves [5][Nt][T] f64 + contamination f64 + status, flags i32 + mask u8 per target' + (' + LinPSF light curve [Nt][T] f64, contamination f64, status i32' if psf else '') + ', one message per rank (comm.packed_block_layout)',
+			'gather': {'mode': run.mode, 'when': run.when if run.gathers else None, 'bytes_per_rank_per_step': run.send_nbytes if world > 1 else 0,
+				'bytes_per_rank_full_block': worker.block_nbytes if world > 1 else 0, 'compact': bool(run.compact),
+				'block': 'light curves [5][Nt][T] f64 + contamination f64 + status, flags i32 + mask u8 per target' + (' + LinPSF light curve [Nt][T] f64, contamination f64, status i32' if psf else '') + ', one message per rank (comm.packed_block_layout); sent compact: flux, flux_err, flux_background as the float32 values they are (comm.compact_block_layout)',
 				'issued': ('every step, second stream, double-buffered output block' if run.when == 'step' else 'once, after the last step (inside the timed region)') if run.gathers else None,
 				'issued_short': run.when if run.gathers else None,
 				'mean_ms': (sum(gms) / len(gms)) if gms else None,
 				'mean_ms_from': ('the timed region' if run.gather_ms else 'the warm-up steps (per-step gather, before the timed region chose "final")') if gms else None,
 				'final_ms': (sum(run.final_ms) / len(run.final_ms)) if run.final_ms else None,
 				'step_ms_without_gather': step_alone_ms,
-				'ideal_ms_one_xgmi_link': worker.block_nbytes / (XGMI_LINK_GBS * 1e9) * 1e3 if world > 1 else None,
+				'ideal_ms_one_xgmi_link': run.send_nbytes / (XGMI_LINK_GBS * 1e9) * 1e3 if world > 1 else None,
 				'measured_8gpu': False,
 				'measured_on': 'never on an 8-GPU node so far (this pool gives one GPU per call): the N > 1 lines come from the driver\'s node, if it has one; no 8-GPU scaling curve exists',
 				'host_group': type(group).__name__,

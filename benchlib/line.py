@@ -88,7 +88,7 @@ def compact(result):
 		out.update(_pick(r, ('speedup_vs_cpu_baseline', 'speedup_vs_one_core')))
 	g = r.get('gather')
 	if g and r.get('n_gpus', 1) > 1:
-		out['gather'] = _pick(g, ('mode', 'issued_short', 'bytes_per_rank_per_step', 'mean_ms', 'final_ms', 'step_ms_without_gather', 'ideal_ms_one_xgmi_link', 'measured_8gpu'))
+		out['gather'] = _pick(g, ('mode', 'issued_short', 'bytes_per_rank_per_step', 'mean_ms', 'final_ms', 'step_ms_without_gather', 'ideal_ms_one_xgmi_link', 'measured_8gpu', 'compact'))
 	if 'linpsf_roofline' in r:
 		out['linpsf_roofline'] = _pick(r['linpsf_roofline'], ('achieved', 'peak', 'unit', 'frac', 'kernel_ms_per_step', 'fitted_stars'))
 	if 'warning' in r:

@@ -297,7 +297,7 @@ int tp_background_mesh(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int
  *   inverse-distance weighted mean of the 10 nearest kept cells, the filter_size x filter_size NaN-ignoring median filter, then
  *   d_vmin / d_vmax (range of the filtered mesh) and d_coef float64 [n_frames][rows][cols] = the cubic B-spline coefficients
  *   scipy.ndimage.zoom(order 3, mode 'reflect') interpolates from (spline_filter1d along both axes) -- the inputs of
- *   tp_background_zoom.  d_filtered optional: the filtered mesh itself.  A frame without a kept cell is NaN.  <= 2048 cells.  */
+ *   tp_background_zoom.  d_filtered optional: the filtered mesh itself.  A frame without a kept cell is NaN.  <= 8192 cells.  */
 int tp_background_mesh_finish(tp_ctx* ctx, const double* d_mesh, const int32_t* d_nmasked, int32_t n_frames, int32_t mesh_rows,
 	int32_t mesh_cols, int32_t box_size, double exclude_percentile, int32_t filter_size, double* d_coef, double* d_vmin, double* d_vmax,
 	double* d_filtered);
@@ -626,6 +626,14 @@ int tp_comm_destroy(tp_ctx* ctx);
 int tp_comm_info(tp_ctx* ctx, int* rank, int* n_ranks);
 /* d_recv (root only) holds n_ranks * nbytes_per_rank bytes, rank r's block at r * nbytes_per_rank */
 int tp_comm_gather(tp_ctx* ctx, const void* d_send, void* d_recv, uint64_t nbytes_per_rank, int root);
+/* The COMPACT form of a rank's output block for the gather: the light curve's flux, flux_err and flux_background planes are
+ * float32 sums widened on store (AperturePhotometry/photometry.py:172-201), so the block a rank SENDS may carry them as float32
+ * and lose nothing (3 of the 5 planes halve); everything else travels as it is.  One field: `count` bytes (kind 0, copied) or
+ * `count` float64 values converted to float32 (kind 1) from byte `src_offset` of the full block to byte `dst_offset` of the
+ * compact one.  The layouts are the host's (photometry_amd/comm.py: packed_block_layout / compact_block_layout); rank 0 widens
+ * the gathered planes again (comm.expand_blocks).  Stream-ordered on the context's stream.                                      */
+typedef struct { uint64_t src_offset, dst_offset, count; int32_t kind; int32_t reserved; } tp_block_field;
+int tp_block_compact(tp_ctx* ctx, const void* d_block, void* d_compact, const tp_block_field* fields, int32_t n_fields);
 int tp_comm_allgather(tp_ctx* ctx, const void* d_send, void* d_recv, uint64_t nbytes_per_rank);
 
 /* ---- synthetic data (bench / test utility, not part of the reference path) -----------------

@@ -147,6 +147,7 @@ SIGNATURES = {
 	'tp_comm_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
 	'tp_comm_gather': (c_int, [c_void_p, _p, _p, c_uint64, c_int]),
 	'tp_comm_allgather': (c_int, [c_void_p, _p, _p, c_uint64]),
+	'tp_block_compact': (c_int, [c_void_p, _p, _p, _p, c_int32]),
 	'tp_cut_stamps_multi': (c_int, [c_void_p, c_int32, _p, c_int32, c_int32, c_int32, c_int64, c_int64, c_int32, c_int32, _p, _desc_p, _p]),
 	'tp_cut_stamps_masked': (c_int, [c_void_p, c_int32, _p, c_int32, c_int32, c_int32, c_int64, c_int64, c_int32, c_int32, _p, _desc_p, _p, _p]),
 	'tp_radial_zeropoint_zoom': (c_int, [c_void_p, _p, c_int32, c_int64, c_int64, POINTER(tp_zoom_image), _p, c_int64, c_double, _p, c_int32, _p]),
@@ -187,7 +188,10 @@ def load():
 	# share one run in turn.  The batched frames entry keeps several jobs of three streams each in flight, whose latency-bound
 	# passes over a few resized stamps are meant to run under the large passes of other jobs: with 4 queues they queue up behind
 	# them instead (measured: 2.3e5 -> 3.4e5 targets/s with 16).  Read when the HIP runtime initialises: set before the library loads.
-	os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
+	# This changes the environment of the embedding application (and of its child processes): a value the application set itself
+	# is never overwritten, and TESSPHOT_KEEP_HW_QUEUES=1 leaves the variable alone altogether.
+	if os.environ.get('TESSPHOT_KEEP_HW_QUEUES', '0') != '1':
+		os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
 	try:
 		lib = ctypes.CDLL(LIB_PATH)
 	except OSError as e:

@@ -55,6 +55,80 @@ def packed_block_layout(n_targets, n_cad, height, width, psf=False, align=256, n
 	return layout, off
 
 
+#: the planes of ``lc`` that are float32 sums widened on store (AperturePhotometry/photometry.py:172-201: flux, flux_err,
+#: flux_background) -- a gathered block carries them as float32 and loses nothing; planes 3, 4 (the centroids) are float64
+LC_FLOAT32_PLANES = 3
+
+
+def compact_block_layout(layout, align=256):
+	"""
+	The layout of the block a rank SENDS (``run_tessphot_mpi.py:151-196``: the result message of a worker): as
+	:func:`packed_block_layout`, but ``lc`` is split into ``lc32`` float32 ``(3, Nt, T)`` -- flux, flux_err, flux_background,
+	exact in float32 -- and ``lc_centroid`` float64 ``(2, Nt, T)``.  Returns ``(clayout, nbytes, fields)``; ``fields`` =
+	``[(src_offset, dst_offset, count, kind)]`` for ``tp_block_compact`` / :func:`compact_block` (kind 0: ``count`` bytes copied,
+	kind 1: ``count`` float64 -> float32).
+	"""
+	clayout, fields, off = {}, [], 0
+
+	def put(name, shape, dtype, src_off, kind):
+		nonlocal off
+		n = int(np.prod(shape))
+		clayout[name] = (off, shape, dtype)
+		fields.append((int(src_off), int(off), n if kind == 1 else n * np.dtype(dtype).itemsize, kind))
+		off = -(-(off + n * np.dtype(dtype).itemsize) // align) * align
+
+	for name, (src, shape, dtype) in layout.items():
+		if name == 'lc':
+			ncol, Nt, T = shape
+			assert dtype == 'float64' and ncol == 5
+			put('lc32', (LC_FLOAT32_PLANES, Nt, T), 'float32', src, 1)
+			put('lc_centroid', (ncol - LC_FLOAT32_PLANES, Nt, T), 'float64', src + LC_FLOAT32_PLANES * Nt * T * 8, 0)
+		else:
+			put(name, shape, dtype, src, 0)
+	return clayout, off, fields
+
+
+def compact_block(block, layout):
+	"""numpy counterpart of ``tp_block_compact``: the full block (uint8) -> the compact block (uint8)."""
+	clayout, nbytes, fields = compact_block_layout(layout)
+	block = np.asarray(block, dtype='uint8').ravel()
+	out = np.zeros(nbytes, dtype='uint8')
+	for src, dst, count, kind in fields:
+		if kind == 0:
+			out[dst:dst + count] = block[src:src + count]
+		else:
+			out[dst:dst + 4 * count].view('float32')[:] = block[src:src + 8 * count].view('float64').astype('float32')
+	return out
+
+
+def expand_block(cblock, layout, align=256):
+	"""A compact block back into the full one (rank 0, after the gather): the float32 planes widened again.  For the planes
+	that are float32 sums this is the identity on the original block, bit for bit (``tests/test_distributed_gloo.py``)."""
+	clayout, _, _ = compact_block_layout(layout)
+	c = unpack_block(cblock, clayout)
+	nbytes = max(off + int(np.prod(shape)) * np.dtype(dtype).itemsize for off, shape, dtype in layout.values())
+	out = np.zeros(-(-nbytes // align) * align, dtype='uint8')
+	full = unpack_block(out, layout)
+	for name in layout:
+		if name == 'lc':
+			full['lc'][:LC_FLOAT32_PLANES] = c['lc32']
+			full['lc'][LC_FLOAT32_PLANES:] = c['lc_centroid']
+		else:
+			full[name][...] = c[name]
+	return out
+
+
+def device_compact_block(ctx, block, out, layout):
+	"""``tp_block_compact`` on the context's stream: ``block`` (full, DeviceArray uint8) -> ``out`` (compact, DeviceArray uint8)."""
+	_, nbytes, fields = compact_block_layout(layout)
+	assert out.nbytes >= nbytes
+
+	class Field(ctypes.Structure):
+		_fields_ = [('src_offset', ctypes.c_uint64), ('dst_offset', ctypes.c_uint64), ('count', ctypes.c_uint64), ('kind', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+	arr = (Field * len(fields))(*[Field(s_, d_, c_, k_, 0) for s_, d_, c_, k_ in fields])
+	ctx._check(ctx.lib.tp_block_compact(ctx.handle, block.ptr, out.ptr, ctypes.cast(arr, ctypes.c_void_p), len(fields)))
+
+
 def unpack_block(block, layout):
 	"""Views of the arrays inside one rank's block (a uint8 array of the size ``packed_block_layout`` returned)."""
 	block = np.asarray(block, dtype='uint8').ravel()

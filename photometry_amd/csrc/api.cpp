@@ -1,6 +1,7 @@
 // api.cpp -- context, memory, timers and the per-kernel profile of libtessphot_hip.so.
 #include "common.h"
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include <cstring>
@@ -39,6 +40,7 @@ static const char* const kKernelNames[TPK_COUNT] = {
 	"tp_linpsf_fitm_kernel",
 	"tp_bkg_stamp_sum_kernel",
 	"tp_star_positions_kernel",
+	"tp_f64_to_f32_kernel",
 };
 
 extern "C" {
@@ -210,6 +212,29 @@ static size_t tp_alloc_class(size_t n) {
 	return (n + step - 1) / step * step;
 }
 
+// The caches of ALL contexts of a device together stay below a share of its memory (TESSPHOT_CACHE_FRACTION, default 0.6 of the
+// device's total): a context's own limit (cache_limit) bounds one context, but a frames engine alone brings twenty contexts, and
+// what they hold is invisible to allocations that do not go through tp_device_alloc (RCCL's buffers, another library, a second
+// process on the device) -- those cannot ask for it back.
+static std::atomic<size_t> tp_cache_total[64];
+static size_t tp_cache_device_limit(int device) {
+	static std::mutex m;
+	static size_t limit[64] = {};
+	if (device < 0 || device >= 64) return (size_t)-1;
+	std::lock_guard<std::mutex> lk(m);
+	if (limit[device] == 0) {
+		double frac = 0.6;
+		if (const char* e = std::getenv("TESSPHOT_CACHE_FRACTION")) { const double v = std::atof(e); if (v >= 0.0 && v <= 1.0) frac = v; }
+		hipDeviceProp_t prop;
+		size_t total = (size_t)64 << 30;
+		if (hipGetDeviceProperties(&prop, device) == hipSuccess) total = prop.totalGlobalMem;
+		(void)hipGetLastError();
+		limit[device] = (size_t)std::max(1.0, frac * (double)total);
+	}
+	return limit[device];
+}
+static inline std::atomic<size_t>& tp_cache_total_of(const tp_ctx* ctx) { return tp_cache_total[(ctx->device >= 0 && ctx->device < 64) ? ctx->device : 0]; }
+
 // every cached block back to the driver (their freeing events have to have completed: the stream is synchronised first)
 static void tp_cache_release(tp_ctx* ctx, bool own) {
 	std::lock_guard<std::recursive_mutex> lk(ctx->cache_mutex);
@@ -224,6 +249,7 @@ static void tp_cache_release(tp_ctx* ctx, bool own) {
 		}
 	}
 	ctx->cache.clear();
+	tp_cache_total_of(ctx) -= ctx->cache_bytes;
 	ctx->cache_bytes = 0;
 }
 
@@ -288,6 +314,7 @@ int tp_malloc(tp_ctx* ctx, uint64_t nbytes, void** d_ptr) {
 			if (pick->second.freed) ctx->pool.push_back(pick->second.freed);
 			ctx->cache.erase(pick);
 			ctx->cache_bytes -= cap;
+			tp_cache_total_of(ctx) -= cap;
 			ctx->live[*d_ptr] = cap;
 			return TP_OK;
 		}
@@ -307,13 +334,14 @@ int tp_free(tp_ctx* ctx, void* d_ptr) {
 	if (it != ctx->live.end()) {
 		const size_t cap = it->second;
 		ctx->live.erase(it);
-		if (cap <= ctx->cache_block && ctx->cache_bytes + cap <= ctx->cache_limit) {
+		if (cap <= ctx->cache_block && ctx->cache_bytes + cap <= ctx->cache_limit && tp_cache_total_of(ctx).load() + cap <= tp_cache_device_limit(ctx->device)) {
 			// kept for the next tp_malloc of this capacity; the event marks the end of what is queued on the context's stream for
 			// the block (tp_malloc hands it out again once that has run)
 			hipEvent_t ev = ctx->get_event();
 			if (ev) (void)hipEventRecord(ev, ctx->stream);
 			ctx->cache.emplace(cap, tp_ctx::cached_block{d_ptr, ev});
 			ctx->cache_bytes += cap;
+			tp_cache_total_of(ctx) += cap;
 			return TP_OK;
 		}
 	}

@@ -38,6 +38,7 @@ enum tp_kernel_id {
 	TPK_LINPSF_FIT_MFMA,
 	TPK_BKG_STAMP_SUM,
 	TPK_STAR_POSITIONS,
+	TPK_BLOCK_COMPACT,
 	TPK_COUNT
 };
 

@@ -537,6 +537,7 @@ void tp_frames_job::run()
 					launch(L, (int)gi, event_pool);
 				}
 				std::string lost;                        // a device error that surfaces at an event costs every group of the part
+				bool drained = false;                    // ... and the job's streams are drained once before any of its blocks is given back
 				lab_rounds += 1;
 				for (auto& L : launched) {
 					const auto lab_a = std::chrono::steady_clock::now();
@@ -549,6 +550,10 @@ void tp_frames_job::run()
 					struct LabDecide { double& acc; std::chrono::steady_clock::time_point t; ~LabDecide() { acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t).count(); } } lab_d{lab_us[3], lab_b};
 					if (L.ev) { event_pool.push_back(L.ev); L.ev = nullptr; }
 					if (L.failed || !lost.empty()) {
+						// the copies into this part's page-locked blocks may still be queued (on this group's stream, or -- once an error
+						// has surfaced and the remaining groups are no longer waited for one by one -- on any of the job's streams): a block
+						// goes back to the engine-wide pool, where another job's thread may take it, only after they have drained
+						if (!drained) { for (int s = 0; s < kStreams; ++s) (void)hipStreamSynchronize(streams[s]->stream); (void)hipGetLastError(); drained = true; }
 						if (L.grp.h_block) { eng->pinned.put(L.grp.h_block, L.grp.h_cap); L.grp.h_block = nullptr; }
 						const int32_t t = add_text(L.failed ? L.error : lost);
 						for (int32_t i : L.idx) { log(i, 10, L.grp.H, L.grp.W, 0.0, t); finish(i, TP_STATUS_ERROR); }

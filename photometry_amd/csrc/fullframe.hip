@@ -360,7 +360,8 @@ __global__ __launch_bounds__(256) void tp_frames_used_kernel(const uint8_t* __re
 //      initialisation for the half-sample symmetric boundary).
 // A frame without any kept cell comes back NaN.
 //--------------------------------------------------------------------------------------------------
-constexpr int kMaxMeshCells = 2048;
+constexpr int kMaxMeshCells = 8192;   // the kernel's work arrays live in LDS: 18 bytes per cell, 144 KB of the CU's 160 at the limit
+                                      // (a 2048 x 2048 frame in 64-pixel boxes has 1024 cells; 4096 x 4096, or boxes of 32 pixels, 4096)
 
 __device__ inline void prefilter_reflect(double* c, int n, int stride) {
 	if (n < 2) return;
@@ -384,8 +385,11 @@ __device__ inline void prefilter_reflect(double* c, int n, int stride) {
 __global__ __launch_bounds__(256) void tp_mesh_finish_kernel(const double* __restrict__ mesh, const int32_t* __restrict__ nmasked, int ny, int nx,
 	double max_masked, int filter_size, double* __restrict__ coef, double* __restrict__ vmin, double* __restrict__ vmax, double* __restrict__ filtered)
 {
-	__shared__ double a[kMaxMeshCells], b[kMaxMeshCells];
-	__shared__ unsigned short kept[kMaxMeshCells];
+	extern __shared__ __align__(16) double s_mesh_work[];          // [2][ncp] doubles + [ncp] unsigned shorts, ncp = cells rounded up to 4
+	const int ncp = (ny * nx + 3) & ~3;
+	double* a = s_mesh_work;
+	double* b = a + ncp;
+	unsigned short* kept = reinterpret_cast<unsigned short*>(b + ncp);
 	__shared__ int n_kept;
 	__shared__ double red[8];
 	const int frame = blockIdx.x, tid = threadIdx.x, nc = ny * nx;
@@ -607,10 +611,14 @@ extern "C" int tp_background_mesh_finish(tp_ctx* ctx, const double* d_mesh, cons
 	TP_CHECK_CTX(ctx);
 	TP_API_BEGIN
 	TP_REQUIRE(ctx, d_mesh && d_nmasked && d_coef && d_vmin && d_vmax, "tp_background_mesh_finish: null pointer");
-	TP_REQUIRE(ctx, n_frames >= 0 && mesh_rows > 0 && mesh_cols > 0 && mesh_rows * mesh_cols <= kMaxMeshCells, "tp_background_mesh_finish: at most 2048 cells per frame");
+	TP_REQUIRE(ctx, n_frames >= 0 && mesh_rows > 0 && mesh_cols > 0 && mesh_rows * mesh_cols <= kMaxMeshCells, "tp_background_mesh_finish: at most 8192 cells per frame");
 	TP_REQUIRE(ctx, box_size > 0 && filter_size >= 1 && filter_size <= 5 && (filter_size & 1), "tp_background_mesh_finish: filter_size must be 1, 3 or 5");
 	if (n_frames == 0) return TP_OK;
-	TP_LAUNCH(ctx, TPK_BKG_MESH, tp_mesh_finish_kernel, dim3((unsigned)n_frames), dim3(256), 0, d_mesh, d_nmasked, (int)mesh_rows, (int)mesh_cols,
+	const size_t ncp = ((size_t)mesh_rows * mesh_cols + 3) & ~(size_t)3;
+	const size_t shmem = ncp * (2 * sizeof(double) + sizeof(unsigned short));
+	if (shmem > 48 * 1024)
+		TP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tp_mesh_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+	TP_LAUNCH(ctx, TPK_BKG_MESH, tp_mesh_finish_kernel, dim3((unsigned)n_frames), dim3(256), shmem, d_mesh, d_nmasked, (int)mesh_rows, (int)mesh_cols,
 		exclude_percentile / 100.0 * (double)box_size * (double)box_size, (int)filter_size, d_coef, d_vmin, d_vmax, d_filtered);
 	TP_LAUNCH_CHECK(ctx, "tp_mesh_finish_kernel");
 	return TP_OK;

@@ -96,3 +96,37 @@ extern "C" int tp_sumimage(tp_ctx* ctx, const tp_cube_desc* desc, const float* d
 	return TP_OK;
 	TP_API_END(ctx)
 }
+
+// ---- the compact output block of a multi-GPU gather -------------------------------------------------------------------------
+// The light curve's flux, flux_err and flux_background are float32 sums (AperturePhotometry/photometry.py:172-201: nansum of
+// float32 stamps) widened to float64 on store, so a gathered block may carry them as float32 and lose nothing; the centroids
+// and the LinPSF light curve are genuine float64.  tp_block_compact copies the fields of a full block into their places in the
+// compact one: kind 0 = bytes as they are, kind 1 = float64 -> float32 (exact for the planes named above).
+__global__ __launch_bounds__(256) void tp_f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out, uint64_t n)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) out[i] = (float)in[i];
+}
+
+extern "C" int tp_block_compact(tp_ctx* ctx, const void* d_block, void* d_compact, const tp_block_field* fields, int32_t n_fields)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, n_fields >= 0 && (n_fields == 0 || (d_block && d_compact && fields)), "tp_block_compact: null pointer");
+	for (int i = 0; i < n_fields; ++i) {
+		const tp_block_field& f = fields[i];
+		if (f.count == 0) continue;
+		const char* src = static_cast<const char*>(d_block) + f.src_offset;
+		char* dst = static_cast<char*>(d_compact) + f.dst_offset;
+		if (f.kind == 0) {
+			TP_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)f.count, hipMemcpyDeviceToDevice, ctx->stream));
+		} else {
+			TP_REQUIRE(ctx, f.kind == 1 && f.src_offset % 8 == 0 && f.dst_offset % 4 == 0, "tp_block_compact: bad field kind or alignment");
+			const uint64_t blocks = (f.count + 255) / 256;
+			const dim3 grid((unsigned)(blocks < 65536 ? blocks : 65536)), block(256);
+			TP_LAUNCH(ctx, TPK_BLOCK_COMPACT, tp_f64_to_f32_kernel, grid, block, 0, reinterpret_cast<const double*>(src), reinterpret_cast<float*>(dst), f.count);
+			TP_LAUNCH_CHECK(ctx, "tp_f64_to_f32_kernel");
+		}
+	}
+	return TP_OK;
+	TP_API_END(ctx)
+}

@@ -11,10 +11,17 @@ Two implementations of one interface (``rank``, ``world``, ``barrier()``, ``max(
 ``allgather_int(i)``, ``gather_array(a, dst)``, ``close()``):
 
 * :class:`SocketGroup` -- plain TCP sockets in a star around rank 0, standard library only: **a multi-GPU run imports no
-  PyTorch**.  Rank 0 listens on an ephemeral port of ``MASTER_ADDR`` and announces it in a rendezvous file that the ranks of
-  one launcher share (they are children of one process: ``python -m torch.distributed.run``'s agent, or
-  ``sharded.spawn_ranks``); ``MASTER_PORT`` itself is NOT used as a listening port -- under torch.distributed.run it belongs
-  to the launcher's own store.
+  PyTorch**.  Two ways to find rank 0:
+
+  - ONE NODE (the default): rank 0 listens on an ephemeral port of ``MASTER_ADDR`` and announces it, with a random secret,
+    in a rendezvous file (mode 0600, in the local temporary directory) that the ranks of one launcher share -- they are
+    children of one process: ``python -m torch.distributed.run``'s agent, or ``sharded.spawn_ranks``.  ``MASTER_PORT`` itself
+    is NOT used as a listening port: under torch.distributed.run it belongs to the launcher's own store.  This way cannot
+    span nodes (the file is local).
+  - SEVERAL NODES: with ``TESSPHOT_RDZV_PORT`` set -- or, when the launcher's environment says the run spans nodes
+    (``WORLD_SIZE > LOCAL_WORLD_SIZE``), ``MASTER_PORT + 1`` -- rank 0 listens on that port on all interfaces and the other
+    ranks connect to ``MASTER_ADDR`` at it; no file.  The handshake token is then ``TESSPHOT_RDZV_SECRET`` if the launcher
+    exported one to every rank, else the run id (guessable: use the secret on a shared network).
 * :class:`TorchGroup` -- ``torch.distributed`` with the gloo backend (what the CPU tests of the sharded run also exercise).
 """
 
@@ -51,9 +58,29 @@ def _send_msg(sock, payload):
 		sock.sendall(payload)
 
 
-def _recv_msg(sock):
+_MAX_CONTROL = 64 << 20      # no control message comes near this (the largest is the allgather blob of small payloads)
+
+
+def _recv_msg(sock, limit=_MAX_CONTROL):
+	"""A length-prefixed message.  The length comes from the peer: it is checked against ``limit`` BEFORE anything is allocated."""
 	n, = struct.unpack('<Q', bytes(_recv_exact(sock, 8)))
+	if n > limit:
+		raise GroupError('a peer announced a message of %d bytes (limit %d): not one of ours' % (n, limit))
 	return bytes(_recv_exact(sock, n)) if n else b''
+
+
+def network_rendezvous_port():
+	"""The port of the several-node rendezvous (module docstring), or None for the one-node rendezvous file."""
+	p = os.environ.get('TESSPHOT_RDZV_PORT')
+	if p:
+		return int(p)
+	try:
+		world, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_WORLD_SIZE', '0'))
+	except ValueError:
+		return None
+	if local > 0 and world > local and os.environ.get('MASTER_PORT'):
+		return int(os.environ['MASTER_PORT']) + 1
+	return None
 
 
 def rendezvous_file():
@@ -81,19 +108,29 @@ class SocketGroup(object):
 		self._path = None
 		if self.world <= 1:
 			return
-		path = rendezvous_file()
-		token = ('%s:%d' % (path, self.world)).encode()
+		net_port = network_rendezvous_port()
+		path = None if net_port is not None else rendezvous_file()
+		if net_port is not None:
+			secret = os.environ.get('TESSPHOT_RDZV_SECRET') or '%s_%s' % (os.environ.get('TORCHELASTIC_RUN_ID', 'none'), os.environ.get('MASTER_PORT', '0'))
+			token = ('net:%s:%d' % (secret, self.world)).encode()
 		if self.rank == 0:
 			srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
 			srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-			srv.bind((self.addr, 0))
+			if net_port is not None:
+				srv.bind(('', net_port))
+			else:
+				srv.bind((self.addr, 0))
 			srv.listen(self.world + 8)
 			port = srv.getsockname()[1]
-			tmp = '%s.%d.tmp' % (path, os.getpid())
-			with open(tmp, 'w') as fh:
-				fh.write('%d %d\n' % (port, os.getpid()))
-			os.replace(tmp, path)               # atomic: a reader sees the old file or the whole new one
-			self._path = path
+			if path is not None:
+				secret = os.urandom(16).hex()
+				token = ('%s:%s:%d' % (path, secret, self.world)).encode()
+				tmp = '%s.%d.tmp' % (path, os.getpid())
+				fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+				with os.fdopen(fd, 'w') as fh:
+					fh.write('%d %d %s\n' % (port, os.getpid(), secret))
+				os.replace(tmp, path)               # atomic: a reader sees the old file or the whole new one
+				self._path = path
 			srv.settimeout(rendezvous_timeout)
 			try:
 				while len(self.peers) < self.world - 1:
@@ -103,7 +140,7 @@ class SocketGroup(object):
 						raise GroupError('rendezvous: %d of %d ranks arrived within %.0f s' % (len(self.peers) + 1, self.world, rendezvous_timeout))
 					c.settimeout(30.0)
 					try:
-						hello = _recv_msg(c)
+						hello = _recv_msg(c, limit=1 << 20)
 						if not hello.startswith(_MAGIC) or hello[len(_MAGIC) + 4:] != token:
 							c.close()               # not one of ours (a stale file pointed a stranger here)
 							continue
@@ -112,8 +149,8 @@ class SocketGroup(object):
 							c.close()
 							continue
 						_send_msg(c, _MAGIC)
-					except (GroupError, OSError):
-						c.close()
+					except (GroupError, OSError, MemoryError, OverflowError, struct.error):
+						c.close()                   # a stray connection must not take rank 0 down
 						continue
 					c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
 					c.settimeout(self.timeout)
@@ -122,21 +159,27 @@ class SocketGroup(object):
 				srv.close()
 		else:
 			deadline = time.monotonic() + rendezvous_timeout
-			last = 'no rendezvous file'
+			last = 'no rendezvous file' if path is not None else 'no connection'
 			while self.sock is None:
 				if time.monotonic() > deadline:
-					raise GroupError('rendezvous: rank %d could not reach rank 0 (%s; file %s)' % (self.rank, last, path))
-				try:
-					port = int(open(path).read().split()[0])
-				except (OSError, ValueError, IndexError):
-					time.sleep(0.05)
-					continue
+					raise GroupError('rendezvous: rank %d could not reach rank 0 (%s; %s)' % (self.rank, last,
+						('file %s' % path) if path is not None else ('%s port %d' % (self.addr, net_port))))
+				if path is not None:
+					try:
+						fields = open(path).read().split()
+						port = int(fields[0])
+						token = ('%s:%s:%d' % (path, fields[2], self.world)).encode()
+					except (OSError, ValueError, IndexError):
+						time.sleep(0.05)
+						continue
+				else:
+					port = net_port
 				s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
 				s.settimeout(10.0)
 				try:
 					s.connect((self.addr, port))
 					_send_msg(s, _MAGIC + struct.pack('<i', self.rank) + token)
-					if _recv_msg(s) != _MAGIC:
+					if _recv_msg(s, limit=1 << 20) != _MAGIC:
 						raise GroupError('handshake refused')
 				except (OSError, GroupError) as e:   # a stale file of an earlier launch, or rank 0 not listening yet
 					last = str(e)
@@ -147,7 +190,7 @@ class SocketGroup(object):
 				s.settimeout(self.timeout)
 				self.sock = s
 		self.barrier()
-		if self.rank == 0:                          # every rank is connected: the file has done its work
+		if self.rank == 0 and path is not None:     # every rank is connected: the file has done its work
 			try:
 				os.unlink(path)
 			except OSError:
@@ -313,7 +356,8 @@ class SingleGroup(object):
 
 
 def open_group(rank, world, kind='socket'):
-	"""``kind``: ``'socket'`` (no PyTorch) or ``'gloo'``."""
+	"""``kind``: ``'socket'`` (no PyTorch; ONE node unless ``TESSPHOT_RDZV_PORT`` / a multi-node launcher environment selects the
+	network rendezvous, see :class:`SocketGroup`) or ``'gloo'`` (``torch.distributed`` over MASTER_ADDR / MASTER_PORT)."""
 	if world <= 1:
 		return SingleGroup()
 	if kind == 'gloo':

@@ -727,14 +727,18 @@ class FramesEngine(object):
 		self.lib.tp_frames_engine_info(self.handle, None, None, ctypes.byref(hbm))
 		self.hbm_bytes = hbm.value
 
+	#: jobs in flight the engine of a context is made for -- the most that pays (aperture_frames_pipelined clamps to it); the engine
+	#: is made ONCE with all of them: remaking it for more slots would strand the jobs and results that point at the old one
+	MAX_SLOTS = 5
+
 	@classmethod
 	def of(cls, ctx, slots=4):
-		"""The engine of ``ctx`` (made on first use; remade with more slots when asked for more than it has)."""
+		"""The engine of ``ctx`` (made on first use with :attr:`MAX_SLOTS` slots and kept until the context closes)."""
+		if slots > cls.MAX_SLOTS:
+			raise ValueError('the frames engine has %d slots' % cls.MAX_SLOTS)
 		eng = ctx.__dict__.get('_frames_engine')
-		if eng is None or eng.slots < slots or eng.handle is None:
-			if eng is not None:
-				eng.close()
-			eng = ctx.__dict__['_frames_engine'] = cls(ctx, slots=max(int(slots), 4))
+		if eng is None or eng.handle is None:
+			eng = ctx.__dict__['_frames_engine'] = cls(ctx, slots=cls.MAX_SLOTS)
 		return eng
 
 	def catalog(self, catalog):
@@ -762,9 +766,11 @@ class FramesEngine(object):
 		q = np.ascontiguousarray(quality, dtype='int32')
 		if len(t) != stack.n_cad or len(q) != stack.n_cad:
 			raise ValueError('time and quality must have one entry per frame of the stack')
-		sumimage = stack.sumimage_for(q)
+		# an FFI target's sum image is a crop of the region's (BasePhotometry.py:1001-1006); a postage-stamp target ('tpf:...') sums its
+		# own stamp (:1007-1019): no region sum image is handed over and every pass forms the stamps' own (tp_sumimage)
+		sumimage = None if datasource.startswith('tpf:') else stack.sumimage_for(q)
 		sdesc = _lib.tp_frames_stack(stack.dev['images'].ptr, stack.dev['images_err'].ptr, stack.dev['backgrounds'].ptr,
-			stack.n_cad, stack.n_rows, stack.n_cols, stack.row0, stack.col0, sumimage.ptr)
+			stack.n_cad, stack.n_rows, stack.n_cols, stack.row0, stack.col0, None if sumimage is None else sumimage.ptr)
 		budget = float(os.environ.get('TESSPHOT_FRAMES_BUDGET_GB', 0)) * 1e9 or self.hbm_bytes / 4.0
 		h = ctypes.c_void_p()
 		rc = self.lib.tp_frames_submit(self.handle, ctypes.byref(sdesc), catalog.handle, n, sid.ctypes.data, tm.ctypes.data, row.ctypes.data, col.ctypes.data,
@@ -823,7 +829,7 @@ def aperture_frames_pipelined(ctx, stack, batches, catalog, time, quality, setti
 		from collections import deque
 		# four streams per job: beyond five jobs (20 streams + the caller's) the hardware queues of the process are oversubscribed and
 		# time-sliced -- measured: 3.8-4.2 x 10^5 targets/s with four or five jobs in flight, 2.4-2.9 x 10^5 with six
-		in_flight = max(1, min(int(in_flight), 5))
+		in_flight = max(1, min(int(in_flight), FramesEngine.MAX_SLOTS))
 		eng = FramesEngine.of(ctx, slots=in_flight)
 		cat = eng.catalog(catalog)
 		# results are yielded in the order of the batches, but a slot is handed on as soon as ANY job is done: the jobs of a run take
@@ -905,7 +911,7 @@ def _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s
 	quality = np.asarray(quality, dtype='int32')
 	tmags = np.asarray(targets['tmag'], dtype='float64')
 	out = FramesResult(n)
-	full_sumimage = stack.sumimage_for(quality)
+	full_sumimage = None if datasource.startswith('tpf:') else stack.sumimage_for(quality)   # (BasePhotometry.py:1001-1019: crop for FFI targets, own sum for stamps)
 	log = {}
 	def logger_of(i):
 		if i not in log:
@@ -977,8 +983,9 @@ def _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s
 					# a small group is a latency-bound pass: the three stand-alone kernels spread A1 and A6 over the chip where the fused launch
 					# gives each target one wavefront (8 targets of 25 x 25: 1.03 against 1.47 ms; bit-identical outputs)
 					# the sum images: crops of the region's (BasePhotometry.py:1001-1006), as in the native engine
-					engine.crop_sumimage(g, full_sumimage, cut['_stamps'], H, W, stack.row0, stack.col0, out=work.sumimage)
-					aperture_step(g, batch, work, fused=len(idx) >= 1024, sumimage_given=True)
+					if full_sumimage is not None:
+						engine.crop_sumimage(g, full_sumimage, cut['_stamps'], H, W, stack.row0, stack.col0, out=work.sumimage)
+					aperture_step(g, batch, work, fused=len(idx) >= 1024, sumimage_given=full_sumimage is not None)
 					aperture_diagnostics(g, batch, work)
 					host = g.pinned_block(work.block.nbytes)
 					# two copies: what the decisions of this round read (flags, masks, sum images ...: everything behind the light curves in

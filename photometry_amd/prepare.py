@@ -174,8 +174,8 @@ def _square_component(ctx, frames, flux_cutoff, box, exclude, estride, subtract,
 		work.update(mesh=ctx.empty((T, ny, nx), 'float64'), nmasked=ctx.empty((T, ny, nx), 'int32'), coef=ctx.empty((T, ny, nx), 'float64'),
 			vmin=ctx.empty((T,), 'float64'), vmax=ctx.empty((T,), 'float64'))
 	mesh, nmasked, coef, vmin, vmax = (work[k] for k in ('mesh', 'nmasked', 'coef', 'vmin', 'vmax'))
-	if ny * nx > 2048:
-		raise ValueError(f'fit_background_frames: a {R} x {C} frame has {ny} x {nx} cells of {box} pixels; the device finishes meshes of at most 2048 cells')
+	if ny * nx > 8192:   # (the finishing kernel's work arrays live in LDS: 2048 x 2048 in 64-pixel boxes is 1024 cells, 4096 x 4096 or 32-pixel boxes 4096)
+		raise ValueError(f'fit_background_frames: a {R} x {C} frame has {ny} x {nx} cells of {box} pixels; the device finishes meshes of at most 8192 cells')
 	if radial_spec is not None:
 		ctx._check(ctx.lib.tp_background_mesh_radial(ctx.handle, frames.ptr, T, R, C, C, R * C, None if exclude is None else exclude.ptr, estride,
 			ctypes.byref(radial_spec), float(flux_cutoff), int(box), mesh.ptr, nmasked.ptr))

@@ -8,17 +8,20 @@ This is what ``run_tessphot_mpi.py:74-209`` is to the reference (a master handin
 saving what comes back, ``taskmanager.py:460-532``) -- re-designed for a node of GPUs: targets are independent (SURVEY.md
 section 8e), so the division is static (``comm.shard_range``), there is **no data-path collective** except the gather of each
 step's output block, and that gather is issued on a second stream from the other half of a double-buffered block so that it
-overlaps the next step's compute.
+overlaps the next step's compute (``when='step'``) -- or, the default, issued ONCE after the last step (``when='final'``).
 
 Pieces (``bench.py`` and ``INTEGRATION.md`` section 3 call these; ``tests/test_distributed_gloo.py`` runs the whole entry on
 CPU ranks with uneven shards):
 
 * :func:`spawn_ranks` -- start the ranks as fresh child processes BEFORE anything touches the GPU;
-* :func:`rank_environment`, :func:`init_host_group` -- rank / world from the launcher's environment, the gloo group used for
+* :func:`rank_environment`, :func:`init_host_group` -- rank / world from the launcher's environment, the host group
+  (``hostgroup.SocketGroup`` by default: TCP, standard library only; ``kind='gloo'``: ``torch.distributed``) used for
   rendezvous, barriers and (on a box where the ranks share a device) the host fallback of the gather;
 * :class:`ShardWorker` -- what a rank does per step (protocol); :class:`DeviceShardWorker` -- the BASELINE workloads on the
   device (configs[2] aperture + background, configs[4] aperture + PSF) on synthetic cubes generated in HBM;
-* :class:`ShardedRun` -- the step loop with the double-buffered gather (RCCL: ``tp_comm_gather``; host fallback: gloo),
+* :class:`ShardedRun` -- the step loop with the gather (RCCL: ``tp_comm_gather``; host fallback: the host group) of the
+  COMPACT block (``comm.compact_block_layout``: the float32-exact light-curve planes travel as float32), once after the last
+  step by default (north_star's "final light-curve gather") or double-buffered under every next step,
   reassembly (``comm.assemble_blocks``: every rank sends the same padded capacity, the real sizes trim it) and the replay of
   the skip lists (``comm.replay_skip_targets``).
 """
@@ -168,17 +171,20 @@ class ShardedRun(object):
 	group, so the root receives from its N - 1 peers at once), ``'host'`` (the block goes through host memory and the host
 	group: CPU workers, and the control-flow fallback when ranks share a device), ``'auto'`` (RCCL when every rank has a device
 	of its own and the communicator comes up on all of them, else host), ``'none'``.
-	``when``: ``'step'`` -- the block of EVERY step is gathered, on the second stream from the other half of the double-buffered
-	block, under the next step's compute; ``'final'`` -- one gather after the last step of a ``run_steps`` call (north_star's
-	"final light-curve gather": nothing to hide, nothing in the way of the steps).  :meth:`choose_when` picks between them from
-	what was measured.  With one rank nothing is gathered: the block of the last step is the result.
+	``when``: ``'final'`` (the default) -- one gather after the last step of a ``run_steps`` call (north_star's "final light-curve
+	gather": nothing to hide, nothing in the way of the steps); ``'step'`` -- the block of EVERY step is gathered, on the second
+	stream from the other half of the double-buffered block, under the next step's compute.  :meth:`choose_when` picks between
+	them from what was measured.  With one rank nothing is gathered: the block of the last step is the result.
+	``compact`` (default): what travels is the compact block -- flux, flux_err and flux_background as the float32 values they
+	are (``comm.compact_block_layout``; ``tp_block_compact`` on the gather's stream), widened again on rank 0: bit-identical
+	results, ~25-30 % fewer bytes per rank.
 
 	``group``: the host-side group (``hostgroup.SocketGroup`` / ``TorchGroup``); ``dist`` + ``torch`` (an initialised
 	``torch.distributed`` group) are still accepted and wrapped.  ``run_steps`` may be called any number of times: which blocks
 	have a gather in flight is kept on the instance.
 	"""
 
-	def __init__(self, worker, n_total, rank=0, world=1, group=None, dist=None, torch=None, gather='auto', when='step', shared_device=False):
+	def __init__(self, worker, n_total, rank=0, world=1, group=None, dist=None, torch=None, gather='auto', when='final', shared_device=False, compact=True):
 		from . import hostgroup
 		if group is None:
 			group = hostgroup.TorchGroup(dist, torch, rank, world) if (dist is not None and world > 1) else hostgroup.SingleGroup()
@@ -195,6 +201,9 @@ class ShardedRun(object):
 		if world > 1 and worker.capacity < max(self.sizes):
 			raise ValueError('the block capacity must be the largest shard: every rank sends the same number of bytes')
 		self.nbuf = worker.nbuf
+		self.compact = bool(compact)
+		self.send_nbytes = tpcomm.compact_block_layout(worker.layout)[1] if self.compact else worker.block_nbytes
+		self.send = [None] * self.nbuf    # RCCL: the compact blocks on the device (made on the gather's stream)
 		self.cat_sizes = None
 		if 'cat_in_mask' in worker.layout:
 			self.cat_sizes = group.allgather_int(worker.n_cat_local) if world > 1 else [int(worker.n_cat_local)]
@@ -235,7 +244,9 @@ class ShardedRun(object):
 				ok, note = 0, f'RCCL communicator not created ({e})'
 		if int(self.group.min(ok)) == 1:
 			if self.rank == 0:
-				self.recv = [w.ctx.empty((self.world, w.block_nbytes), 'uint8') for _ in range(self.nbuf)]
+				self.recv = [w.ctx.empty((self.world, self.send_nbytes), 'uint8') for _ in range(self.nbuf)]
+			if self.compact:
+				self.send = [w.ctx.empty((self.send_nbytes,), 'uint8') for _ in range(self.nbuf)]
 			return 'rccl'
 		if gather == 'rccl':
 			raise RuntimeError('RCCL gather asked for but not available: ' + (note or 'another rank failed'))
@@ -260,7 +271,11 @@ class ShardedRun(object):
 			self._read_timer(b)
 			self.comm_ctx.wait_event(self.ev_done[b])
 			self.comm_ctx.timer_start(b)
-			tpcomm.gather(self.comm_ctx, w.block(b), self.recv[b], root=0)
+			blk = w.block(b)
+			if self.compact:
+				tpcomm.device_compact_block(self.comm_ctx, blk, self.send[b], w.layout)
+				blk = self.send[b]
+			tpcomm.gather(self.comm_ctx, blk, self.recv[b], root=0)
 			self.comm_ctx.timer_stop(b)
 			self.comm_ctx.record(self.ev_free[b])
 			self._timer[b] = into if into is not None else False
@@ -269,7 +284,10 @@ class ShardedRun(object):
 		w.sync()
 		t0 = time.perf_counter()
 		blk = w.block(b)
-		got = self.group.gather_array(blk.to_host() if hasattr(blk, 'to_host') else blk, dst=0)
+		blk = blk.to_host() if hasattr(blk, 'to_host') else blk
+		if self.compact:
+			blk = tpcomm.compact_block(blk, w.layout)
+		got = self.group.gather_array(blk, dst=0)
 		if self.rank == 0:
 			self._host_recv = got
 		if into is not None:
@@ -339,6 +357,8 @@ class ShardedRun(object):
 			blocks = list(self.recv[b].to_host())
 		else:
 			blocks = self._host_recv
+		if self.gathers and self.compact:
+			blocks = [tpcomm.expand_block(c, w.layout) for c in blocks]
 		return tpcomm.assemble_blocks(blocks, w.layout, self.sizes, cat_sizes=self.cat_sizes)
 
 	@staticmethod

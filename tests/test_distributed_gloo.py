@@ -120,6 +120,9 @@ class _NumpyWorker(object):
 		i = np.arange(self.a, self.b)
 		n = self.n_local
 		v['lc'][:, :n, :] = (i[None, :, None] * 0.5 + np.arange(5)[:, None, None] * 1e3 + np.arange(self.T)[None, None, :] + self.n_steps * 1e-3)
+		# flux, flux_err, flux_background are float32 sums widened on store (photometry.py:172-201), the centroids genuine float64
+		v['lc'][:3, :n, :] = v['lc'][:3, :n, :].astype('float32')
+		v['lc'][0, :n, 1][i % 7 == 0] = np.nan
 		v['contamination'][:n] = (i % 17) / 17.0
 		v['status'][:n] = 1 + (i % 3 == 0) * 2                            # OK / WARNING
 		v['flags'][:n] = i % 5
@@ -139,10 +142,11 @@ class _NumpyWorker(object):
 		pass
 
 
-def _sharded_run(n_total, world, rank, group=None, steps=3, when='step', calls=1):
+def _sharded_run(n_total, world, rank, group=None, steps=3, when='step', calls=1, compact=True):
 	from photometry_amd import sharded
 	w = _NumpyWorker(n_total, world, rank)
-	run = sharded.ShardedRun(w, n_total, rank=rank, world=world, group=group, gather='auto', when=when)
+	run = sharded.ShardedRun(w, n_total, rank=rank, world=world, group=group, gather='auto', when=when, compact=compact)
+	assert run.send_nbytes == (tpcomm_compact_nbytes(w) if compact else w.block_nbytes)
 	for _ in range(calls):                     # run_steps is re-entrant: the state of the double buffer lives on the instance
 		run.run_steps(steps, collect=True)
 	run.barrier()
@@ -160,7 +164,14 @@ def _sharded_run(n_total, world, rank, group=None, steps=3, when='step', calls=1
 	return out
 
 
-def _sharded_worker(rank, world, port, n_total, outfile, kind='gloo', when='step', calls=1):
+def tpcomm_compact_nbytes(w):
+	from photometry_amd import comm as tpcomm
+	n = tpcomm.compact_block_layout(w.layout)[1]
+	assert n < w.block_nbytes or w.capacity * w.T < 1000   # (tiny blocks: the alignment of one more field can outweigh the halved planes)
+	return n
+
+
+def _sharded_worker(rank, world, port, n_total, outfile, kind='gloo', when='step', calls=1, compact=True):
 	sys.path.insert(0, ROOT)
 	os.environ['MASTER_ADDR'] = '127.0.0.1'
 	os.environ['MASTER_PORT'] = str(port)
@@ -171,7 +182,7 @@ def _sharded_worker(rank, world, port, n_total, outfile, kind='gloo', when='step
 	assert type(group).__name__ == {'gloo': 'TorchGroup', 'socket': 'SocketGroup'}[kind]
 	if kind == 'socket':
 		assert 'torch' not in sys.modules or os.environ.get('TP_TEST_SPAWNED_BY_TORCH') == '1'
-	res = _sharded_run(n_total, world, rank, group=group, when=when, calls=calls)
+	res = _sharded_run(n_total, world, rank, group=group, when=when, calls=calls, compact=compact)
 	if rank == 0:
 		mode = res.pop('mode')
 		assert mode == 'host', mode
@@ -219,20 +230,46 @@ def _spawn_plain(target, args, world):
 	assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
 
 
-@pytest.mark.parametrize('when,calls', [('step', 1), ('final', 1), ('step', 2)])
-def test_sharded_run_over_the_socket_group_without_torch(tmp_path, when, calls):
+@pytest.mark.parametrize('when,calls,compact', [('step', 1, True), ('final', 1, True), ('step', 2, True), ('final', 1, False)])
+def test_sharded_run_over_the_socket_group_without_torch(tmp_path, when, calls, compact):
 	"""The same run with the host group on plain TCP sockets (hostgroup.SocketGroup: rank 0 on an ephemeral port announced in a
 	rendezvous file; no PyTorch imported in any rank), gathering every step, once at the end, and with run_steps called twice
-	back to back (the second call must wait for the first call's gathers before it overwrites their blocks)."""
+	back to back (the second call must wait for the first call's gathers before it overwrites their blocks).  What travels is the
+	COMPACT block (flux / flux_err / flux_background as float32: comm.compact_block_layout) unless ``compact`` is off: the results
+	are the same bit for bit either way, and equal to the single-process run, which gathers nothing."""
 	out = str(tmp_path / 'sock.npz')
 	n_total, world = 1003, 3
 	os.environ['TESSPHOT_RDZV_ID'] = 'test_%d_%s_%d' % (os.getpid(), when, calls)
 	try:
-		_spawn_plain(_sharded_worker, (world, 0, n_total, out, 'socket', when, calls), world)
+		_spawn_plain(_sharded_worker, (world, 0, n_total, out, 'socket', when, calls, compact), world)
 	finally:
 		del os.environ['TESSPHOT_RDZV_ID']
 	ng = _compare_with_single_process(dict(np.load(out)), n_total, steps_total=3 * calls)
 	assert ng == {('step', 1): [3, 0], ('final', 1): [0, 1], ('step', 2): [6, 0]}[(when, calls)]
+
+
+def test_compact_block_round_trip_and_size():
+	"""comm.compact_block / expand_block: the identity on a block whose first three light-curve planes are float32 values (NaN
+	included), field for field and padding included; at configs[4]'s shape the block a rank sends shrinks from 783 to 588 MB."""
+	from photometry_amd import comm as tpcomm
+	lay, nb = tpcomm.packed_block_layout(7, 13, 5, 5, psf=True, n_cat=20, extras=True)
+	rng = np.random.default_rng(0)
+	blk = np.zeros(nb, 'uint8')
+	u = tpcomm.unpack_block(blk, lay)
+	u['lc'][:3] = rng.normal(size=(3, 7, 13)).astype('float32')
+	u['lc'][0, 0, 0] = np.nan
+	u['lc'][1, 2, 3] = -np.inf
+	u['lc'][3:] = rng.normal(size=(2, 7, 13))
+	for k in u:
+		if k != 'lc':
+			u[k][...] = rng.integers(0, 200, u[k].shape).astype(u[k].dtype)
+	c = tpcomm.compact_block(blk, lay)
+	clay, cn, fields = tpcomm.compact_block_layout(lay)
+	assert len(c) == cn < nb and all(off % 256 == 0 for off, _, _ in clay.values())
+	np.testing.assert_array_equal(tpcomm.expand_block(c, lay), blk)
+	lay4, nb4 = tpcomm.packed_block_layout(12500, 1300, 15, 15, psf=True)
+	cn4 = tpcomm.compact_block_layout(lay4)[1]
+	assert nb4 > 780e6 and cn4 < 590e6
 
 
 def test_strong_scaling_100k_targets_over_8_cpu_ranks(tmp_path):

@@ -85,3 +85,34 @@ def test_rccl_two_ranks_gather(tmp_path):
 	if res < 0:
 		pytest.skip("RCCL refused two ranks on one device: " + open(out_file + '.msg').read()[:200])
 	assert res == 1.0
+
+
+def test_compact_block_on_device_equals_numpy_and_loses_nothing():
+	"""tp_block_compact on a real step's packed block (aperture + LinPSF, configs[4]'s block in small): equal to comm.compact_block
+	byte for byte, and expanding it gives the ORIGINAL block back bit for bit -- flux, flux_err and flux_background are float32
+	sums widened on store, so the compact block a rank sends loses nothing."""
+	from photometry_amd import simulate, engine, pipeline, psf as hpsf, comm as tpcomm
+	from photometry_amd.device import Context
+	ctx = Context(0)
+	Nt, T, H, W = 300, 203, 15, 15
+	scene = simulate.make_scene(Nt, T, H, W, seed=12)
+	scene.aperture = None
+	cubes = engine.synth_fill(ctx, scene, images=False, images_err=True, backgrounds=False, raw=True)
+	batch = pipeline.ApertureBatch(ctx, scene, cubes={'raw': cubes['raw'], 'raw_err': cubes['images_err']})
+	work = pipeline.ApertureWork(ctx, batch, packed=True, psf=True, capacity=Nt + 20)
+	prf = simulate.synthetic_prf(seed=1)
+	lin = pipeline.LinPSFBatch(ctx, scene, hpsf.PRFModel(prf['values'], prf['ccdColumn'], prf['ccdRow'], prf['prfColumn'], prf['prfRow']),
+		images=cubes['raw'], subtract=work.bkg, work=work)
+	pipeline.aperture_step(ctx, batch, work)
+	pipeline.linpsf_step(ctx, lin)
+	ctx.sync()
+	block = work.block.to_host()
+	clay, cn, fields = tpcomm.compact_block_layout(work.block_layout)
+	assert cn < 0.8 * block.nbytes
+	out = ctx.zeros((cn,), 'uint8')
+	tpcomm.device_compact_block(ctx, work.block, out, work.block_layout)
+	ctx.sync()
+	got = out.to_host()
+	np.testing.assert_array_equal(got, tpcomm.compact_block(block, work.block_layout))
+	np.testing.assert_array_equal(tpcomm.expand_block(got, work.block_layout), block)
+	ctx.close()

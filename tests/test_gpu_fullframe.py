@@ -50,6 +50,25 @@ def test_fit_background_reference_known_answer(ctx):
 	np.testing.assert_allclose(b, 1000)
 
 
+def test_fit_background_large_mesh(ctx):
+	"""A mesh above the 2048 cells of rounds 4-5 (here 88 x 81 = 7128 cells of 16 pixels: the finishing kernel's work arrays are
+	sized at launch, up to 8192 cells) against the oracle with the same box; more cells than that are refused, not mangled."""
+	from photometry_amd import prepare
+	from oracle import backgrounds as ob
+	R, C, box = 1408, 1296, 16
+	f = _frames(2, R, C, seed=5)[:1]
+	f[0, 400:432, 600:632] = np.nan          # four whole cells masked: filled from their neighbours
+	bkg, mesh, nmasked = prepare.fit_background_frames(ctx, ctx.array(f), box=box, return_mask=True)
+	mask = ob.stamp_mask(f[0])
+	ref_mesh, ref_nm = ob.mesh_statistics(f[0], mask, box=box)
+	np.testing.assert_array_equal(nmasked[0], ref_nm)
+	np.testing.assert_allclose(mesh[0], ref_mesh, rtol=1e-9, equal_nan=True)
+	ref = ob.mesh_to_background(ref_mesh, ref_nm, (R, C), box=box)
+	np.testing.assert_allclose(bkg.to_host()[0], ref, rtol=1e-6)
+	with pytest.raises(ValueError, match='at most 8192 cells'):
+		prepare.fit_background_frames(ctx, ctx.array(f), box=8)
+
+
 @pytest.mark.parametrize("T,R,C", [(3, 256, 320), (2, 200, 150)])
 def test_fit_background_matches_oracle(ctx, T, R, C):
 	from photometry_amd import prepare
@@ -200,7 +219,7 @@ def test_fit_background_tess_matches_oracle(ctx, T, R, C):
 			assert d.max() < 2e-5, (k, it, d)
 		errd = np.abs(b[k] - refd) / np.abs(refd)
 		worst_dev = max(worst_dev, float(errd.max()))
-		assert errd.max() < 1e-5, (k, float(errd.max()))
+		assert errd.max() < 2e-6, (k, float(errd.max()))   # measured on 32 full frames with the round-5/6 kernels: 6.4e-7 at worst (profiles/r6_tess_flip_stats.txt)
 		# --- the literal restatement of the reference
 		flipped = 0
 		ref, mask, inter = ob.fit_background_tess(f[k], 1, 1, full=True)
@@ -219,7 +238,7 @@ def test_fit_background_tess_matches_oracle(ctx, T, R, C):
 			flipped += int(ok.sum() - exact.sum())
 		err = np.abs(b[k] - ref) / np.abs(ref)
 		worst = max(worst, float(err.max()))
-		assert err.max() < (5e-4 if flipped else 1e-5), (k, flipped, float(err.max()))   # measured on 32 full frames (profiles/r4_tess_flip_stats.txt): 1.3e-4 at worst with a flipped ring
+		assert err.max() < (5e-4 if flipped else 1e-5), (k, flipped, float(err.max()))   # measured on 32 full frames (profiles/r6_tess_flip_stats.txt): 1.3e-4 at worst with a flipped ring
 		# the radial component matters here: without it the corner is off by far more than the tolerance
 		plain = ob.fit_background(f[k])[0]
 		assert np.max(np.abs(plain - ref) / ref) > 0.01
@@ -246,7 +265,7 @@ def test_fit_background_tess_full_frames(ctx):
 			assert d.max() < 2e-5, (k, it, d)
 		errd = np.abs(b[k] - refd) / np.abs(refd)
 		print('frame', k, 'max relative background deviation', float(errd.max()))
-		assert errd.max() < 1e-5
+		assert errd.max() < 2e-6          # profiles/r6_tess_flip_stats.txt: 6.4e-7 at worst on 32 full frames
 	ref, _, inter = ob.fit_background_tess(f[0], 1, 1, full=True)
 	flipped = sum(int(np.sum(np.abs(details['s2'][it][0] - inter['s2'][it]) >= 2e-5)) for it in range(3))
 	err = np.abs(b[0] - ref) / np.abs(ref)
@@ -402,10 +421,10 @@ def test_prepare_pixel_flags_and_headers(ctx):
 	us_t = prepare.fit_background_frames(ctx, ctx.array(f), exclude=flags, camera=1, ccd=4).to_host()
 	for k in (0, 5):
 		ref_bkg, _ = ob.fit_background_tess(f[k], 1, 4, exclude=manexcl[k], device_arithmetic=True)
-		np.testing.assert_allclose(us_t[k], ref_bkg, rtol=1e-5)
+		np.testing.assert_allclose(us_t[k], ref_bkg, rtol=2e-6)
 		ref_lit, _ = ob.fit_background_tess(f[k], 1, 4, exclude=manexcl[k])
 		# literal float32 log10 of numpy: a ring whose KDE argmax sits on a tie may land on the neighbouring grid point; measured on 32
-		# full frames (profiles/r4_tess_flip_stats.txt): 1.3e-4 at worst with a flipped ring, asserted at 5e-4 like the tests above
+		# full frames (profiles/r6_tess_flip_stats.txt): 1.3e-4 at worst with a flipped ring, asserted at 5e-4 like the tests above
 		np.testing.assert_allclose(us_t[k], ref_lit, rtol=5e-4)
 	smooth = np.moveaxis(ob.smooth_time(np.moveaxis(us_t, 0, -1), 3), -1, 0)
 	np.testing.assert_array_equal(res_h['backgrounds'].to_host(), smooth)

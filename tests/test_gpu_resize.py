@@ -401,3 +401,33 @@ def test_crop_sumimage_outside_the_frame_is_nan():
 					ref[i, j] = full[r, c]
 		np.testing.assert_array_equal(out[t], ref)
 	ctx.close()
+
+
+def test_postage_stamp_datasource_sums_its_own_stamps():
+	"""``datasource='tpf:...'``: the reference sums the stamp's own cube (BasePhotometry.py:1007-1019) instead of cropping the
+	region's sum image (:1001-1006), and the haloswitch quick break does not apply (photometry.py:146).  The native engine then
+	gets no region sum image (``tp_frames_stack.d_sumimage = NULL``: every pass cuts the images and runs ``tp_sumimage``) -- equal
+	to the Python rounds target for target, and its sum images equal to the oracle's sum over the cut stamp."""
+	from photometry_amd import pipeline
+	from photometry_amd.device import Context
+	from oracle import sumimage as osum
+	ctx = Context(0)
+	frames, row0, col0, time, quality, cat, targets = _region()
+	stack = pipeline.FrameStack(ctx, {k: np.moveaxis(v, 2, 0) for k, v in frames.items()}, row0, col0)
+	py = pipeline.aperture_frames(ctx, stack, targets, cat, time, quality, engine='python', datasource='tpf:1234')
+	nat = pipeline.aperture_frames(ctx, stack, targets, cat, time, quality, engine='native', datasource='tpf:1234')
+	_compare_frames_results(py, nat)
+	ffi = pipeline.aperture_frames(ctx, stack, targets, cat, time, quality, engine='native')
+	n_checked = 0
+	for i in range(nat.n):
+		r = nat[i]
+		if 'sumimage' not in r:
+			continue
+		r1, r2, c1, c2 = (int(v) for v in r['stamp'])
+		cube = frames['images'][r1 - row0:r2 - row0, c1 - col0:c2 - col0, :]
+		np.testing.assert_allclose(r['sumimage'], osum.sumimage(cube, quality), rtol=1e-12, equal_nan=True)
+		n_checked += 1
+	assert n_checked >= 3
+	# no quick break for a postage stamp: the bright target keeps resizing where the FFI target stops
+	assert (nat.stamp_resizes >= ffi.stamp_resizes).all()
+	ctx.close()
