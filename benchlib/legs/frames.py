@@ -134,8 +134,9 @@ def leg_psf_frames(ctx, args, T, np, pipeline):
 		out['linpsf_frames']['cpu_baseline'] = {'value': ns / (dc * T / tsub), 'unit': 'targets/s', 'cores': 1, 'kind': 'port',
 			'sample': f'{ns} targets x first {tsub} cadences (oracle restatement of LinPSFPhotometry.do_photometry on the host copy of their stamps), extrapolated to {T} cadences'}
 		out['linpsf_frames']['parity_sample'] = {'targets': ns, 'cadences': tsub, 'mismatches': int(bad), 'rtol': 1e-7}
-	# PSFPhotometry: a serial chain per target (tp_psf_fit); fewer targets
-	n2 = min(N, 256)
+	# PSFPhotometry: a serial chain per target (tp_psf_fit), one workgroup per target, 512 - 768 of them resident: a batch below
+	# that leaves workgroup slots empty for the length of the longest chain (round 5 ran 256 targets: half the chip idle)
+	n2 = min(N, 2000)
 	sub = {k: v[:n2] for k, v in targets.items()}
 	pipeline.psf_frames(ctx, stack, {k: v[:16] for k, v in targets.items()}, cat, tstamp, quality, model)
 	t0 = time.perf_counter()

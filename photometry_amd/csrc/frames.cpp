@@ -32,7 +32,7 @@ constexpr uint32_t kBitmask = 1 | 2 | 4 | 8 | 32 | 64 | 128 | 4096;   // TESSQua
 // Streams per job: stream 0 for the large groups, three for the small, latency-bound ones.  Four active streams is what a single
 // job runs fastest with (measured, 2 500 targets: 15 / 13 / 20 ms with 2 / 3 / 4 streams for the small groups: beyond four active
 // queues of a process the hardware time-slices them).
-constexpr int kStreams = 4;
+constexpr int kStreams = 4;               // per job: one for the large groups, three for the small ones
 static int g_small_streams = 3;          // (experiment: TESSPHOT_FRAMES_STREAMS = 1 .. 3)
 constexpr int kResizeStep = 10;          // photometry.py:124-131
 constexpr int kFusedFrom = 1024;         // from this many targets on a group is "large": stream 0, the error / background stacks cut after the mask
@@ -488,6 +488,9 @@ void tp_frames_job::run()
 {
 	(void)hipSetDevice(eng->device);
 	std::vector<hipEvent_t> event_pool;
+	hipEvent_t stream_busy[kStreams] = {};     // per small stream: recorded after the last group queued on it
+	double stream_load[kStreams] = {};         // ... and what has been queued on it since it was last seen idle (targets x pixels)
+	int next_small = 0;
 	try {
 		status.assign(n, 0); stamp_resizes.assign(n, 0); group.assign(n, -1); pos.assign(n, 0); has_result.assign(n, 0);
 		stamp.assign((size_t)n * 4, -1);
@@ -525,16 +528,39 @@ void tp_frames_job::run()
 			std::vector<int32_t> still;
 			for (auto& part : parts) {
 				std::vector<Launched> launched(part.size());
-				int n_small = 0;
 				for (size_t gi = 0; gi < part.size(); ++gi) {
 					Launched& L = launched[gi];
 					L.idx = std::move(part[gi].idx);
 					L.grp.H = part[gi].H; L.grp.W = part[gi].W;
 					// a large group is a throughput pass: stream 0.  A small one (the resized stamps of a few targets) is a chain of
-					// latency-bound launches that decides when the job's next round can start: its own high-priority stream, so that its
-					// few workgroups are placed ahead of the thousands another job's large pass has queued
-					L.g = (L.idx.size() < 256) ? streams[1 + (n_small++ % g_small_streams)] : streams[0];
+					// latency-bound launches that decides when the job's next round can start: a stream of its own -- one that is IDLE.
+					// What a group queues after its mask kernel (the masked cut, the extraction, the diagnostics, the copies: 0.3 - 1 ms for
+					// a group of large stamps) is not waited for by the round's decisions, but it would be by a group of the NEXT round
+					// queued behind it: with three small streams taken in turn, the third round of a job started 0.65 ms late behind the
+					// second round's extraction (kernel trace, round 6).  Every small stream is marked by an event when a group has been queued
+					// on it; a new group takes one whose event has completed, else the one with the least work queued since it was last
+					// seen idle.  (More streams per job do NOT help, measured in round 6: the streams of a process share its hardware
+					// queues -- with 7 per job, 35 in the engine, a call alone took 11 - 14 ms instead of 7.6; with 5 per job, 20 in the
+					// engine, a call alone took the same 7.6 ms and four jobs in flight fell from 4.8 - 5.8 to 3.7 - 4.5 x 10^5 targets/s.)
+					int si = 0;
+					const double work = (double)L.idx.size() * (double)L.grp.H * (double)L.grp.W;   // what its tail costs, roughly
+					if (L.idx.size() < 256) {
+						double best = 0.0;
+						for (int k = 0; k < g_small_streams; ++k) {
+							const int cand = 1 + ((next_small + k) % g_small_streams);
+							if (stream_busy[cand] && hipEventQuery(stream_busy[cand]) == hipSuccess) stream_load[cand] = 0.0;   // drained
+							if (si == 0 || stream_load[cand] < best) { si = cand; best = stream_load[cand]; }
+						}
+						(void)hipGetLastError();   // hipErrorNotReady of the queries
+						next_small = si;             // the next group starts looking behind this one
+						stream_load[si] += work;
+					}
+					L.g = streams[si];
 					launch(L, (int)gi, event_pool);
+					if (si != 0) {
+						if (!stream_busy[si]) (void)hipEventCreateWithFlags(&stream_busy[si], hipEventDisableTiming);
+						if (stream_busy[si]) (void)hipEventRecord(stream_busy[si], L.g->stream);
+					}
 				}
 				std::string lost;                        // a device error that surfaces at an event costs every group of the part
 				bool drained = false;                    // ... and the job's streams are drained once before any of its blocks is given back
@@ -594,6 +620,7 @@ void tp_frames_job::run()
 		(void)hipGetLastError();
 	}
 	for (auto e : event_pool) (void)hipEventDestroy(e);
+	for (int si = 0; si < kStreams; ++si) if (stream_busy[si]) { (void)hipEventDestroy(stream_busy[si]); stream_busy[si] = nullptr; }
 	for (auto& hs : host_scratch) eng->pinned.put(hs.first, hs.second);
 	host_scratch.clear();
 }

@@ -4,6 +4,11 @@
 // This stage is O(1) in the number of cadences (it sees only the 15x15 sum image), latency-bound
 // integer / float64 work; it is NOT on the HBM roofline -- 10 000 targets x 13 KB of LDS each (15x15 stamps).
 #include "common.h"
+#ifdef TP_LAB_K2P2_CLOCK
+// scratch build only (tools/k2p2_timing.py): cycles per phase of the mask builder, summed over the targets of a launch
+__device__ unsigned long long tp_lab_k2clk[24];
+#define TP_K2P2_CLOCK(k, i) do { const unsigned long long now_ = __builtin_readcyclecounter(); (k).clk[i] += now_ - (k).clk0; (k).clk0 = now_; } while (0)
+#endif
 #include "k2p2_args.h"
 #include <cmath>
 #include <cstdlib>
@@ -20,7 +25,14 @@ __global__ __launch_bounds__(64, 2) void tp_k2p2_kernel(k2p2::BatchArgs a, k2p2:
 	k2p2::shared_carve(k, smem, a.H, a.W, (int)threadIdx.x, twid);
 	k2p2::Target t;
 	k2p2::make_target(a, target, t);
+#ifdef TP_LAB_K2P2_CLOCK
+	for (int i = 0; i < 12; ++i) k.clk[i] = 0;
+	k.clk0 = __builtin_readcyclecounter();
+#endif
 	k2p2::run_target(k, prm, t);
+#ifdef TP_LAB_K2P2_CLOCK
+	if (threadIdx.x == 0) for (int i = 0; i < 12; ++i) atomicAdd(&tp_lab_k2clk[i], k.clk[i]);
+#endif
 }
 
 // Stamps whose work arrays do not fit the LDS (beyond about 54 x 54 pixels: the default stamps of stars brighter than
@@ -40,6 +52,14 @@ __global__ __launch_bounds__(64) void tp_k2p2_global_kernel(k2p2::BatchArgs a, k
 }
 
 } // namespace
+
+#ifdef TP_LAB_K2P2_CLOCK
+extern "C" int tp_lab_k2p2_clocks(unsigned long long* out, int reset) {
+	if (reset) { unsigned long long z[24] = {}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(tp_lab_k2clk), z, sizeof(z)); }
+	(void)hipDeviceSynchronize();
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tp_lab_k2clk), 24 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int tp_k2p2_masks(tp_ctx* ctx, int32_t n_targets, int32_t height, int32_t width,
 	const double* d_sumimage,

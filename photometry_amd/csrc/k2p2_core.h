@@ -41,6 +41,11 @@
 #define TP_ALWAYS_INLINE inline
 #endif
 
+// lab hook: a scratch build (-DTP_LAB_K2P2_CLOCK, k2p2.hip) accumulates the cycles between consecutive hooks per phase; nothing in the product
+#ifndef TP_K2P2_CLOCK
+#define TP_K2P2_CLOCK(k, i)
+#endif
+
 namespace k2p2 {
 
 constexpr int kGrid = 128;          // KDE FFT grid: gridsize=100 -> next power of two (kde.py kdensityfft)
@@ -106,6 +111,9 @@ typedef int16_t lab_t;
 
 // Shared (LDS) work arrays of one target.  Sizes in elements; P = H*W, Pp = pow2 >= P.
 struct Shared {
+#ifdef TP_LAB_K2P2_CLOCK
+	unsigned long long clk0, clk[12];
+#endif
 	int lane;
 	int P, Pp, H, W;
 	uint32_t wmagic;  // ceil(2^32 / W): row of a pixel index by one multiplication (exact for indices and widths below 2^16)
@@ -217,6 +225,30 @@ inline TP_DEV bool tp_isnan(double x) { return x != x; }
 // error term p * (ceil(2^32 / W) * W - 2^32) stays below 2^32.  (A division by a run-time W is ~30 instructions, and every phase
 // of the builder converts pixel indices to rows and columns.)
 inline TP_DEV int row_of(const Shared& k, int p) { return (k.W > 1) ? (int)(((uint64_t)(uint32_t)p * (uint64_t)k.wmagic) >> 32) : p; }
+
+// A WINDOW of the stamp: rows r0 .. r0 + h - 1, columns c0 .. c0 + w - 1.  The per-cluster passes of A4 (blur, peaks, marker labels,
+// the saturated-column test) touch a cluster's neighbourhood only: everywhere else their results are constants (zero) that a
+// plain store pass writes.  A pass over a window computes, for its pixels, exactly what the pass over the whole stamp computed:
+// the pixel index, its neighbours and the reflections at the STAMP's edges are those of the stamp.
+struct Win { int r0, c0, h, w, n; uint32_t magic; };
+inline TP_DEV Win win_make(const Shared& k, int r0, int r1, int c0, int c1) {   // inclusive limits, clipped to the stamp
+	Win v;
+	if (r0 < 0) r0 = 0;
+	if (c0 < 0) c0 = 0;
+	if (r1 > k.H - 1) r1 = k.H - 1;
+	if (c1 > k.W - 1) c1 = k.W - 1;
+	v.r0 = r0; v.c0 = c0; v.h = (r1 >= r0) ? (r1 - r0 + 1) : 0; v.w = (c1 >= c0) ? (c1 - c0 + 1) : 0;
+	v.n = v.h * v.w;
+	v.magic = (v.w > 1) ? (uint32_t)((0x100000000ull + (uint64_t)v.w - 1ull) / (uint64_t)v.w) : 0u;   // ceil(2^32 / w): exact below 2^16
+	return v;
+}
+inline TP_DEV Win win_full(const Shared& k) { return win_make(k, 0, k.H - 1, 0, k.W - 1); }
+inline TP_DEV bool win_is_full(const Shared& k, const Win& v) { return v.n == k.P; }
+// stamp pixel index of the q-th pixel of the window (row-major)
+inline TP_DEV int win_pix(const Shared& k, const Win& v, int q) {
+	const int rr = (v.w > 1) ? (int)(((uint64_t)(uint32_t)q * (uint64_t)v.magic) >> 32) : q;
+	return (v.r0 + rr) * k.W + v.c0 + (q - rr * v.w);
+}
 
 inline TP_DEV double tp_pow2(int e) { // 2^e for -1022 <= e <= 1023
 	union { uint64_t u; double d; } c;
@@ -689,14 +721,17 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 // Connected-component labelling of the non-zero pixels of `in` by min-index propagation;
 // conn8: 8- or 4-connectivity.  out[p] = 1-based component number in raster order of first pixel
 // (scipy.ndimage.label numbering), 0 for background.  Returns the number of components.
-inline TP_DEV int label_components(Shared& k, const uint8_t* in, lab_t* out, bool conn8) {
+// `win`: a window that holds every set pixel of `in` -- the propagation sweeps run over it alone (the other passes are single
+// reads or stores per pixel and stay on the whole stamp)
+inline TP_DEV int label_components(Shared& k, const uint8_t* in, lab_t* out, bool conn8, const Win& win) {
 	const int P = k.P, H = k.H, W = k.W;
 	TP_PAR_FOR(p, P) out[p] = in[p] ? p : -1;
 	TP_SYNC();
 	while (true) {
 		TP_LANE_LOOP(l) {
 			int changed = 0;
-			for (int p = l; p < P; p += 64) {
+			for (int q = l; q < win.n; q += 64) {
+				const int p = win_pix(k, win, q);
 				int cur = out[p];
 				if (cur < 0) continue;
 				const int r = row_of(k, p), c = p - r * W;
@@ -721,7 +756,7 @@ inline TP_DEV int label_components(Shared& k, const uint8_t* in, lab_t* out, boo
 		if (!any) break;
 		// pointer jumping: every pixel adopts the label of the pixel it points to (labels only decrease and
 		// stay inside the component, so the fixed point -- the component's smallest index -- is unchanged)
-		TP_PAR_FOR(p, P) { const int cur = out[p]; if (cur >= 0) { const int nxt = out[cur]; if (nxt < cur) out[p] = nxt; } }
+		TP_PAR_FOR(q, win.n) { const int p = win_pix(k, win, q); const int cur = out[p]; if (cur >= 0) { const int nxt = out[cur]; if (nxt < cur) out[p] = nxt; } }
 		TP_SYNC();
 	}
 	// roots -> consecutive numbers in raster order: every lane owns a contiguous chunk of pixels, counts its
@@ -746,6 +781,7 @@ inline TP_DEV int label_components(Shared& k, const uint8_t* in, lab_t* out, boo
 	TP_SYNC();
 	return n;
 }
+inline TP_DEV int label_components(Shared& k, const uint8_t* in, lab_t* out, bool conn8) { return label_components(k, in, out, conn8, win_full(k)); }
 
 // bottleneck.nanmedian of v[0..n) (n small); returns NaN for no valid value.  Serial.
 inline TP_DEV double nanmedian_small(const double* v, int n, double* scratch) {
@@ -765,13 +801,14 @@ inline TP_DEV double nanmedian_small(const double* v, int n, double* scratch) {
 // k2p2_saturated for ONE mask (k2p2v2.py:291-341): mask in k.msk -> additions in k.sat.
 // Uses k.tmp / k.dist as column scratch (dist holds no live data at either call site: before the cluster's blur, after the
 // watershed).  Returns (uniform) number of pixels set in k.sat.
-inline TP_DEV int saturated_one(Shared& k) {
+// `win`: a window that holds every pixel of the mask (the columns and rows outside it have no mask pixel: nothing to test there).
+inline TP_DEV int saturated_one(Shared& k, const Win& win) {
 	const int P = k.P, H = k.H, W = k.W;
 	TP_PAR_FOR(p, P) k.sat[p] = 0;
 	// mask_max = nanmax(S[mask])
 	TP_LANE_LOOP(l) {
 		double m = -tp_inf(); int any = 0;
-		for (int p = l; p < P; p += 64) if (k.msk[p] && !tp_isnan(k.S[p])) { if (!any || k.S[p] > m) m = k.S[p]; any = 1; }
+		for (int q = l; q < win.n; q += 64) { const int p = win_pix(k, win, q); if (k.msk[p] && !tp_isnan(k.S[p])) { if (!any || k.S[p] > m) m = k.S[p]; any = 1; } }
 		k.red[l] = m; k.ired[l] = any;
 	}
 	TP_SYNC();
@@ -783,11 +820,12 @@ inline TP_DEV int saturated_one(Shared& k) {
 	}
 	TP_SYNC();
 	// one column per lane (columns are independent: k2p2v2.py:312-339)
-	TP_PAR_FOR(c, W) {
+	TP_PAR_FOR(ci, win.w) {
+		const int c = win.c0 + ci;
 		double* pix = k.tmp + (size_t)c * H;      // [H] per column (W*H = P doubles)
 		double* scr = k.dist + (size_t)c * H;
 		int n = 0;
-		for (int r = 0; r < H; ++r) if (k.msk[r * W + c]) pix[n++] = k.S[r * W + c];
+		for (int r = win.r0; r < win.r0 + win.h; ++r) if (k.msk[r * W + c]) pix[n++] = k.S[r * W + c];
 		if (n == 0) continue;
 		// ratio = |nanmedian(diff(pixels))| / nanmax(pixels)
 		double pmax = tp_nan(); { int any = 0; for (int i = 0; i < n; ++i) if (!tp_isnan(pix[i])) { if (!any || pix[i] > pmax) pmax = pix[i]; any = 1; } }
@@ -835,6 +873,7 @@ inline TP_DEV int saturated_one(Shared& k) {
 	TP_SYNC();
 	return n;
 }
+inline TP_DEV int saturated_one(Shared& k) { return saturated_one(k, win_full(k)); }
 
 // ndimage.gaussian_filter(Z, 0.5): radius 2, correlate1d along axis 0 then axis 1, mode 'reflect',
 // symmetric-kernel summation order of ni_filters.c: c*w0 + (l1+r1)*w1 + (l2+r2)*w2
@@ -847,11 +886,21 @@ inline TP_DEV int reflect_idx(int i, int n) {
 	if (i >= n) i = n2 - 1 - i;
 	return i;
 }
-inline TP_DEV void gaussian_blur(Shared& k, const Params& prm, const double* in, double* out) {
+// `box`: a window outside which `in` is +0.0 (the cluster's bounding box).  The filter reaches two pixels: the row pass is non-zero
+// on the box grown by two ROWS only, the column pass on the box grown by two pixels all round; everywhere else both passes of the
+// whole-stamp filter give 0 * w0 + (0 + 0) * w1 + (0 + 0) * w2 = +0.0 -- written by a store pass instead of being computed.
+inline TP_DEV void gaussian_blur(Shared& k, const Params& prm, const double* in, double* out, const Win& box) {
 	const int P = k.P, H = k.H, W = k.W;
 	const double w0 = prm.gauss_w0, w1 = prm.gauss_w1, w2 = prm.gauss_w2;
+	const bool whole = win_is_full(k, box);
+	if (!whole) {
+		TP_PAR_FOR(p, P) { k.tmp[p] = 0.0; out[p] = 0.0; }
+		TP_SYNC();
+	}
 	// axis 0 (rows) -> tmp
-	TP_PAR_FOR(p, P) {
+	const Win rows = whole ? box : win_make(k, box.r0 - 2, box.r0 + box.h + 1, box.c0, box.c0 + box.w - 1);
+	TP_PAR_FOR(q, rows.n) {
+		const int p = win_pix(k, rows, q);
 		const int r = row_of(k, p), c = p - r * W;
 		double v = in[p] * w0;
 		v += (in[reflect_idx(r - 1, H) * W + c] + in[reflect_idx(r + 1, H) * W + c]) * w1;
@@ -859,7 +908,9 @@ inline TP_DEV void gaussian_blur(Shared& k, const Params& prm, const double* in,
 		k.tmp[p] = v;
 	}
 	TP_SYNC();
-	TP_PAR_FOR(p, P) {
+	const Win both = whole ? box : win_make(k, box.r0 - 2, box.r0 + box.h + 1, box.c0 - 2, box.c0 + box.w + 1);
+	TP_PAR_FOR(q, both.n) {
+		const int p = win_pix(k, both, q);
 		const int r = row_of(k, p), c = p - r * W;
 		double v = k.tmp[p] * w0;
 		v += (k.tmp[r * W + reflect_idx(c - 1, W)] + k.tmp[r * W + reflect_idx(c + 1, W)]) * w1;
@@ -868,6 +919,7 @@ inline TP_DEV void gaussian_blur(Shared& k, const Params& prm, const double* in,
 	}
 	TP_SYNC();
 }
+inline TP_DEV void gaussian_blur(Shared& k, const Params& prm, const double* in, double* out) { gaussian_blur(k, prm, in, out, win_full(k)); }
 
 // skimage.segmentation.watershed(-Z, markers, mask=Z) (connectivity 1, no compactness / lines):
 // priority flood, a neighbour is labelled when it is pushed, pops in (value, age) order.
@@ -1012,6 +1064,7 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 	double CUT = tp_nan();
 	if (t.cut_override) { CUT = *t.cut_override; if (t.diag) { TP_SERIAL { t.diag[0] = CUT; } } }
 	else err = threshold(k, prm, t, &CUT);
+	TP_K2P2_CLOCK(k, 0);
 
 	// target pixel (photometry.py:107): Python round() = round-half-even; negative indices wrap
 	int tr = (int)rint(t.tpos_row - (double)t.stamp_row0);
@@ -1076,24 +1129,96 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 				k.lab[p] = v;
 			}
 			TP_SYNC();
+			TP_K2P2_CLOCK(k, 1);
 			// ---------------- A4: watershed per cluster (segmentation=True, any cluster) ----------------
 			// Labels after k2p2WS: non-core -> noise (k2p2v2.py:112)
 			TP_PAR_FOR(p, P) k.lab2[p] = (k.idx[p]) ? ((k.core[p]) ? k.lab[p] : -1) : -2;
 			TP_SYNC();
 			int max_label = nclusters - 1;
+#ifdef TP_LAB_K2P2_CLOCK
+			k.clk[11] += (unsigned long long)nclusters;
+#endif
 			for (int lab = 0; lab < nclusters && !err; ++lab) {
 				// pre-pass saturated mask of the un-split cluster incl. border points (k2p2v2.py:465-492)
-				TP_PAR_FOR(p, P) k.msk[p] = (k.lab[p] == lab) ? 1 : 0;
+				// ... and the cluster's bounding box (core and border pixels): the passes below that cost more than a store per pixel
+				// run over windows around it (see struct Win), not over the stamp once per cluster -- on a 25 x 25 stamp of a crowded
+				// field, with a dozen clusters, they were half of the mask builder's time
+				TP_LANE_LOOP(l) {
+					int r0 = H, r1 = -1, c0 = W, c1 = -1;
+					double smax = 0.0;
+					for (int p = l; p < P; p += 64) {
+						const uint8_t m = (k.lab[p] == lab) ? 1 : 0;
+						k.msk[p] = m;
+						if (m) {
+							const int r = row_of(k, p), c = p - r * W;
+							r0 = (r < r0) ? r : r0; r1 = (r > r1) ? r : r1; c0 = (c < c0) ? c : c0; c1 = (c > c1) ? c : c1;
+							const double sv = k.S[p];
+							smax = (sv > smax) ? sv : smax;     // (cluster pixels have S > CUT: never NaN)
+						}
+					}
+					k.ired[l] = r1; k.red[l] = (double)(-r0); k.hval[l] = (double)c1; k.grid[l] = (double)(-c0); k.grid[64 + l] = smax;   // (the KDE grid is free after A2)
+				}
 				TP_SYNC();
-				const int nsat = saturated_one(k);
+				const int br1 = max_ired(k), br0 = -(int)max_arr(k, k.red), bc1 = (int)max_arr(k, k.hval), bc0 = -(int)max_arr(k, k.grid);
+				const double cluster_max = max_arr(k, k.grid + 64);
+				TP_SYNC();
+				const Win box = win_make(k, br0, br1, bc0, bc1);
+				// A cluster NO catalogue star can reach is rejected here, before anything is computed for it.  k2p2WS keeps a cluster only
+				// if a peak of its blurred image is matched by a star: a star takes its nearest peak if that lies within 5 sqrt 2 pixels
+				// (2 sqrt 2 for a star fainter than the saturation limit; k2p2v2.py:144-153), else none, and a cluster without a matched
+				// peak has no markers and is dropped (:218-223).  Peaks are pixels where the blurred image exceeds the threshold
+				// max(min, ws_thres * max) >= 0, i.e. pixels of the box grown by the filter's two pixels: a star whose distance to
+				// that rectangle -- the same expression sqrt(dx^2 + dy^2) on the nearest point of the rectangle; every rounding in it
+				// is monotone, so it bounds the distance to every pixel of the rectangle from below -- is not below its limit matches
+				// nothing.  What the skipped code could still do is raise "no peaks" (a cluster whose blurred image has no pixel above
+				// the threshold: the error of k2p2v2.py:146): impossible when the fluxes of the cluster are positive and finite
+				// (CUT >= 0), ws_thres is 0 and the grown box is not the whole stamp (there are zeros: the maximum is a peak above the
+				// minimum) -- otherwise the cluster takes the long way.  On a resized stamp of a crowded field most clusters are noise
+				// far from any star: 7 of 10 on 25 x 25 stamps, and they were 40 % of the mask builder's time there.
+				{
+					const Win grown = win_make(k, br0 - 2, br1 + 2, bc0 - 2, bc1 + 2);
+					bool far = false;
+					if (CUT >= 0.0 && prm.ws_thres == 0.0 && cluster_max < 1e300 && !win_is_full(k, grown)) {
+						const double xlo = (double)grown.c0, xhi = (double)(grown.c0 + grown.w - 1), ylo = (double)grown.r0, yhi = (double)(grown.r0 + grown.h - 1);
+						TP_LANE_LOOP(l) {
+							int reach = 0;
+							for (int sidx = l; sidx < t.ncat; sidx += 64) {
+								const double c0 = (double)t.cat_col[sidx], c1 = (double)t.cat_row[sidx];
+								double dx = 0.0, dy = 0.0;
+								if (c0 < xlo) dx = xlo - c0; else if (c0 > xhi) dx = xhi - c0;
+								if (c1 < ylo) dy = ylo - c1; else if (c1 > yhi) dy = yhi - c1;
+								if (!(c0 == c0) || !(c1 == c1)) { reach = 1; continue; }        // a NaN position: the long way decides
+								const double d = sqrt(dx * dx + dy * dy);
+								const double dist_factor = ((double)t.cat_tmag[sidx] > prm.saturation_limit) ? 2.0 : 5.0;
+								if (!(d >= dist_factor * 1.4142135623730951)) reach = 1;
+							}
+							k.ired[l] = reach;
+						}
+						TP_SYNC();
+						far = (or_ired(k) == 0);
+						TP_SYNC();
+					}
+					if (far) {
+						TP_PAR_FOR(p, P) if (k.lab2[p] == lab) k.lab2[p] = -1;
+						TP_SYNC();
+						TP_K2P2_CLOCK(k, 8);
+						continue;
+					}
+				}
+				const int nsat = saturated_one(k, box);
+				TP_K2P2_CLOCK(k, 2);
 				// Z = flux on the core pixels of this cluster
 				TP_PAR_FOR(p, P) k.Z[p] = (k.lab2[p] == lab) ? k.S[p] : 0.0;
 				TP_SYNC();
-				gaussian_blur(k, prm, k.Z, k.dist);
+				gaussian_blur(k, prm, k.Z, k.dist, box);
 				// peak_local_max(distance, exclude_border=False, threshold_rel=ws_thres, footprint=ones(3,3))
+				// the blurred image is zero outside the box grown by two pixels (gaussian_blur): its extrema are those of that window
+				// and, unless the window is the stamp, zero
+				const Win near2 = win_make(k, br0 - 2, br1 + 2, bc0 - 2, bc1 + 2);
 				TP_LANE_LOOP(l) {
 					double mn = tp_inf(), mx = -tp_inf();
-					for (int p = l; p < P; p += 64) { const double d = k.dist[p]; if (d < mn) mn = d; if (d > mx) mx = d; }
+					if (l == 0 && !win_is_full(k, near2)) { mn = 0.0; mx = 0.0; }
+					for (int q = l; q < near2.n; q += 64) { const double d = k.dist[win_pix(k, near2, q)]; if (d < mn) mn = d; if (d > mx) mx = d; }
 					k.red[l] = mn; k.hval[l] = mx;
 				}
 				TP_SYNC();
@@ -1101,9 +1226,18 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 				TP_SYNC();
 				double pk_thr = dmin;
 				{ const double rel = prm.ws_thres * dmax; if (rel > pk_thr) pk_thr = rel; } // max(min, rel*max)
+				// Candidate peaks: a pixel that equals the maximum of its 3 x 3 neighbourhood.  Three pixels or more from the box the
+				// neighbourhood is all zero: such a pixel is a candidate (0 == 0) that the threshold below drops as long as it is not
+				// negative (0 > pk_thr is false) -- so the test runs over the box grown by three, and `trivial` (every pixel of the
+				// STAMP is a candidate) is decided there.  A negative (or NaN) threshold -- only with negative fluxes above a negative
+				// CUT, or a negative ws_thres -- takes the pass over the whole stamp.
+				const Win near3 = (pk_thr >= 0.0) ? win_make(k, br0 - 3, br1 + 3, bc0 - 3, bc1 + 3) : win_full(k);
+				if (!win_is_full(k, near3)) { TP_PAR_FOR(p, P) k.lmax[p] = 0; }
+				TP_SYNC();
 				TP_LANE_LOOP(l) {
 					int allpk = 1;
-					for (int p = l; p < P; p += 64) {
+					for (int q = l; q < near3.n; q += 64) {
+						const int p = win_pix(k, near3, q);
 						const int r = row_of(k, p), c = p - r * W;
 						double m = 0.0; // mode='constant', cval=0: out-of-image neighbours count as 0
 						bool first = true;
@@ -1123,7 +1257,8 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 				TP_SYNC();
 				TP_LANE_LOOP(l) {
 					int c = 0;
-					for (int p = l; p < P; p += 64) {
+					for (int q = l; q < near3.n; q += 64) {
+						const int p = win_pix(k, near3, q);
 						const uint8_t pk = (!trivial && k.lmax[p] && k.dist[p] > pk_thr) ? 1 : 0;
 						k.lmax[p] = pk; c += pk;
 					}
@@ -1132,6 +1267,7 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 				TP_SYNC();
 				const int npeaks = sum_ired(k);
 				TP_SYNC();
+				TP_K2P2_CLOCK(k, 3);
 				// peaks matched to catalog stars (k2p2v2.py:144-153); candidates stay in lmax, selection in sat? no:
 				// selection goes to k.core-independent temp: reuse wsout as "selected" flags
 				TP_PAR_FOR(p, P) k.wsout[p] = 0;
@@ -1173,10 +1309,17 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 					}
 				}
 				TP_SYNC();
-				TP_PAR_FOR(p, P) k.lmax[p] = k.wsout[p] ? 1 : 0; // local_maxi
+				TP_LANE_LOOP(l) { // local_maxi
+					int c = 0;
+					for (int q = l; q < near3.n; q += 64) { const int p = win_pix(k, near3, q); const uint8_t v = k.wsout[p] ? 1 : 0; k.lmax[p] = v; c += v; }
+					k.ired[l] = c;
+				}
 				TP_SYNC();
-				// de-duplicate maxima inside saturated patches (k2p2v2.py:193-212)
-				if (nsat > 0) {
+				const int nselected = sum_ired(k);
+				TP_SYNC();
+				TP_K2P2_CLOCK(k, 4);
+				// de-duplicate maxima inside saturated patches (k2p2v2.py:193-212): only a patch that holds two selected maxima changes
+				if (nsat > 0 && nselected > 1) {
 					const int ncomp = label_components(k, k.sat, k.mark, false);
 					for (int cc = 1; cc <= ncomp; ++cc) {
 						TP_LANE_LOOP(l) {
@@ -1203,14 +1346,18 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 						}
 					}
 				}
+				TP_K2P2_CLOCK(k, 5);
 				// markers = ndimage.label(local_maxi) (4-connectivity)
-				const int nmark = label_components(k, k.lmax, k.mark, false);
+				// (no peak selected: no markers -- ndimage.label of an empty image -- without the labelling passes)
+				const int nmark = (nselected > 0) ? label_components(k, k.lmax, k.mark, false, near3) : 0;   // (the selected peaks lie inside the window of the candidates)
+				TP_K2P2_CLOCK(k, 6);
 				if (nmark == 0) {
 					// "No maxima were found": the cluster is rejected (k2p2v2.py:218-223)
 					TP_PAR_FOR(p, P) if (k.lab2[p] == lab) k.lab2[p] = -1;
 					TP_SYNC();
 				} else {
 					watershed(k, nmark); // k.mark -> k.wsout
+					TP_K2P2_CLOCK(k, 7);
 					// no_labels = number of distinct values in labels_ws, zero included (k2p2v2.py:230)
 					TP_PAR_FOR(m, nmark + 1) k.hage[m] = 0;
 					TP_SYNC();
@@ -1235,6 +1382,7 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 					TP_SYNC();
 					if (no_labels - 2 > 0) max_label += (no_labels - 2);
 				}
+				TP_K2P2_CLOCK(k, 8);
 			}
 
 			// ---------------- A5: mask assembly, one candidate mask at a time ----------------
@@ -1298,6 +1446,7 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 			}
 		}
 	}
+	TP_K2P2_CLOCK(k, 9);
 	bool using_min = false;
 	if (!err) {
 		if (!have_masks) { using_min = true; if (!(flags & FLAG_NOSTARS)) flags |= FLAG_NOMASKS; }
@@ -1385,6 +1534,7 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 		if (t.diag) t.diag[7] = (double)nmasks_total;
 	}
 	TP_SYNC();
+	TP_K2P2_CLOCK(k, 10);
 	return status;
 }
 

@@ -727,9 +727,10 @@ class FramesEngine(object):
 		self.lib.tp_frames_engine_info(self.handle, None, None, ctypes.byref(hbm))
 		self.hbm_bytes = hbm.value
 
-	#: jobs in flight the engine of a context is made for -- the most that pays (aperture_frames_pipelined clamps to it); the engine
+	#: jobs in flight the engine of a context is made for -- the most that pays (five measure the same as four, and every slot is five
+	#: streams of the process's two dozen hardware queues; aperture_frames_pipelined clamps to it); the engine
 	#: is made ONCE with all of them: remaking it for more slots would strand the jobs and results that point at the old one
-	MAX_SLOTS = 5
+	MAX_SLOTS = 4
 
 	@classmethod
 	def of(cls, ctx, slots=4):

@@ -17,6 +17,10 @@ def make_cases(kind, seed):
 		s = simulate.make_scene(24, 150, 15, 15, seed=seed, tmag_range=(4.0, 7.5), neighbour_tmag_range=(6.0, 9.0))
 	elif kind == 'tiny':
 		s = simulate.make_scene(12, 40, 6, 7, seed=seed, max_neighbours=1)
+	elif kind == 'wide':
+		# a resized stamp of a crowded field: a dozen clusters, several of them at the stamp's edges and corners -- the per-cluster
+		# passes of the mask builder run over windows around each cluster (k2p2_core.h: struct Win)
+		s = simulate.make_scene(20, 60, 29, 33, seed=seed, max_neighbours=14, neighbour_tmag_range=(7.5, 13.5))
 	elif kind == 'large':
 		# beyond the LDS-resident mask builder (about 54 x 54 pixels): the work arrays live in HBM
 		s = simulate.make_scene(5, 24, 62, 58, seed=seed, tmag_range=(4.0, 6.0), max_neighbours=6, neighbour_tmag_range=(6.0, 10.0), sigma_psf=1.6)

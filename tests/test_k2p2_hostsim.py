@@ -47,7 +47,7 @@ def run_hostsim(lib, s, S, cut_override=None):
 	return out
 
 
-@pytest.mark.parametrize("kind,seed", [('faint15', 1), ('small11', 2), ('crowded', 3), ('bright', 4), ('tiny', 5), ('faint15', 6)])
+@pytest.mark.parametrize("kind,seed", [('faint15', 1), ('small11', 2), ('crowded', 3), ('bright', 4), ('tiny', 5), ('faint15', 6), ('wide', 7), ('wide', 8)])
 def test_hostsim_matches_oracle(hostsim, kind, seed):
 	s, S = make_cases(kind, seed)
 	got = run_hostsim(hostsim, s, S)

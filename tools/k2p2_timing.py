@@ -1,10 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic: cycles per phase of the mask builder, summed over the 10 000 targets of the BASELINE batch, in the stand-alone
-kernel (tp_k2p2_masks).  Needs a scratch build with the in-kernel clocks, which are NOT in the product sources:
-    git apply tools/lab/clock_hooks.patch
+kernel (tp_k2p2_masks).  Needs a scratch build with the in-kernel clocks (the hooks TP_K2P2_CLOCK of k2p2_core.h are empty in the product):
     SRC=k2p2.hip bash tools/lab/build_variants.sh "k2clk:-DTP_LAB_K2P2_CLOCK"
-    git apply -R tools/lab/clock_hooks.patch
-    TP_LAB_LIB=tools/lab/lib_k2clk.so python tools/k2p2_timing.py        (on the GPU box)"""
+    TP_LAB_LIB=tools/lab/lib_k2clk.so H=25 W=25 NT=2000 python tools/k2p2_timing.py        (on the GPU box)"""
 import sys, os, ctypes, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if os.environ.get('TP_LAB_LIB'):
@@ -26,9 +24,17 @@ ctx.lib.tp_lab_k2p2_clocks(buf, 1)
 engine.k2p2_masks(ctx, batch, work); ctx.sync()
 ctx.lib.tp_lab_k2p2_clocks(buf, 0)
 c = np.array(list(buf), dtype='float64') / Nt
-names = ['sort', 'bandwidth', 'KDE by DFT + argmax', 'Powell / Brent on the Gaussian sum', 'MAD + CUT', 'idx, DBSCAN core, labels', 'saturated pre-pass', 'blur + peaks',
-	'label the markers', 'watershed + relabel', 'mask assembly', 'contamination + outputs', 'peak list', 'copy of the selected peaks', 'dedupe in saturated patches', 'minimum aperture + edges', 'star match loop', 'cat_in_mask', 'contamination: serial star loop', 'contamination: log10f / pow']
+names = ['A2 threshold (sort, KDE, Powell / Brent, MAD)', 'idx, DBSCAN core, labels', 'per cluster: saturated pre-pass', 'per cluster: blur + peaks', 'per cluster: star match', 'per cluster: dedupe in saturated patches',
+	'per cluster: label the markers', 'per cluster: watershed', 'per cluster: relabel', 'mask assembly', 'minimum aperture, edges, contamination, outputs']
+print('clusters per target %.1f' % c[11])
+c = c[:len(names)]
 tot = c.sum()
 for n, v in zip(names, c):
 	print('%-40s %9.0f ticks  %5.1f %%' % (n, v, 100 * v / tot))
 print('total per target %.0f ticks' % tot)
+import time
+t0 = time.perf_counter()
+for _ in range(5):
+	engine.k2p2_masks(ctx, batch, work)
+ctx.sync()
+print('launch of %d targets of %d x %d: %.3f ms; statuses' % (Nt, H, W, (time.perf_counter() - t0) / 5 * 1e3), np.bincount(work.status.to_host(), minlength=4))
