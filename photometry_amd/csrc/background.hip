@@ -185,6 +185,8 @@ __device__ __forceinline__ float rank_read(const float* fr, int r) {
 // wavefront votes on a bool (the header's __ballot / __any take an int: a select and a compare more per call)
 __device__ __forceinline__ uint64_t tp_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool tp_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// a where the lane's bit of the wavefront mask is set, else b (v_cndmask_b32 with the mask in a scalar register pair)
+__device__ __forceinline__ int tp_sel(uint64_t mask, int a, int b) { int r; asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask)); return r; }
 
 // One frame (cadence) per G lanes, from the loaded values to the background estimate: mask + float64 sums, distributed sort,
 // rank-staged sigma clipping, SExtractor mode.  `v` holds the lane's loaded pixel values (pixel i = G j + g in register j; the
@@ -255,6 +257,7 @@ __device__ __forceinline__ float bkg_frame_clip(const BkgArgs& a, float (&v)[256
 	const int nmasked = a.n_pix - n;
 	const bool usable = active && (n > 0) && !((float)nmasked > a.exclude_fraction * (float)a.n_pix);
 	int lo_i = 0, hi_i = usable ? n : 1;
+	const uint64_t um = tp_ballot(usable);
 	double med = 0.0;
 	const int bshift = lane & (64 - G);
 	constexpr unsigned BMASK = (1u << G) - 1u;
@@ -270,29 +273,30 @@ __device__ __forceinline__ float bkg_frame_clip(const BkgArgs& a, float (&v)[256
 		if (!(q9 > 0.0)) q9 = 0.0;
 		int top = 0, bot = 0;
 		double r1 = 0.0, r2 = 0.0;
-		bool more_t = usable, more_b = usable;
+		// The lanes' conditions are kept as wavefront masks in scalar registers (a comparison writes one directly; `and` between them is
+		// scalar work): as per-lane bools every vote cost a select and a compare to turn the bool back into a mask.
+		uint64_t mt = um, mb = um;                  // lanes whose frame is still walking in from the top / from the bottom
 		bool general;
 		// The lowest kept rank decides whether anything is clipped below (the ranks are sorted): on sky-dominated stamps that is
 		// almost never the case (stars clip at the top), and the walk then runs for the upper end alone -- about half the
 		// instructions of a step.  Same sums, same order.
 		{
 			const double db0 = ((double)rank_read(fr, lo_i) - med) * mm;
-			const bool ob0 = usable && (db0 < 0.0) && (db0 * db0 > q9);
-			general = tp_any(ob0);
+			general = (um & tp_ballot(db0 < 0.0) & tp_ballot(db0 * db0 > q9)) != 0ull;
 			if (!general) {
 #pragma unroll 1
 				for (int base = 0; ; base += G) {
 					const int rt = hi_i - 1 - g - base;
-					const bool vt = more_t && (rt >= lo_i);
-					const float xt = rank_read(fr, vt ? rt : lo_i);
+					const uint64_t vt = mt & tp_ballot(rt >= lo_i);
+					const float xt = rank_read(fr, tp_sel(vt, rt, lo_i));
 					const double dt = ((double)xt - med) * mm;
-					const bool ot = vt && (dt > 0.0) && (dt * dt > q9);
-					const unsigned bt = (unsigned)(tp_ballot(ot) >> bshift) & BMASK;
+					const uint64_t ot = vt & tp_ballot(dt > 0.0) & tp_ballot(dt * dt > q9);
+					const unsigned bt = (unsigned)(ot >> bshift) & BMASK;
 					const int ct = __builtin_ctz(~bt);
 					{ const double x = (double)((g < ct) ? xt : 0.f); r1 += x; r2 = __builtin_fma(x, x, r2); }   // + 0.0 changes nothing
 					top += ct;
-					more_t = (ct == G);
-					if (!tp_any(more_t)) break;
+					mt = tp_ballot(ct == G);
+					if (mt == 0ull) break;
 				}
 			}
 		}
@@ -300,20 +304,20 @@ __device__ __forceinline__ float bkg_frame_clip(const BkgArgs& a, float (&v)[256
 #pragma unroll 1
 		for (int base = 0; ; base += G) {
 			const int rt = hi_i - 1 - g - base, rb = lo_i + g + base;
-			const bool vt = more_t && (rt >= lo_i), vb = more_b && (rb < hi_i);
-			const float xt = rank_read(fr, vt ? rt : lo_i), xb = rank_read(fr, vb ? rb : lo_i);
+			const uint64_t vt = mt & tp_ballot(rt >= lo_i), vb = mb & tp_ballot(rb < hi_i);
+			const float xt = rank_read(fr, tp_sel(vt, rt, lo_i)), xb = rank_read(fr, tp_sel(vb, rb, lo_i));
 			const double dt = ((double)xt - med) * mm, db = ((double)xb - med) * mm;
-			const bool ot = vt && (dt > 0.0) && (dt * dt > q9), ob = vb && (db < 0.0) && (db * db > q9);
+			const uint64_t ot = vt & tp_ballot(dt > 0.0) & tp_ballot(dt * dt > q9), ob = vb & tp_ballot(db < 0.0) & tp_ballot(db * db > q9);
 			// number of consecutive clipped ranks from the end of the range, among this step's G
-			const unsigned bt = (unsigned)(tp_ballot(ot) >> bshift) & BMASK, bb = (unsigned)(tp_ballot(ob) >> bshift) & BMASK;
+			const unsigned bt = (unsigned)(ot >> bshift) & BMASK, bb = (unsigned)(ob >> bshift) & BMASK;
 			const int ct = __builtin_ctz(~bt), cb = __builtin_ctz(~bb);
 			{ const double x = (double)((g < ct) ? xt : 0.f); r1 += x; r2 = __builtin_fma(x, x, r2); }
 			{ const double x = (double)((g < cb) ? xb : 0.f); r1 += x; r2 = __builtin_fma(x, x, r2); }
 			top += ct; bot += cb;
-			more_t = (ct == G); more_b = (cb == G);
-			if (!tp_any(more_t || more_b)) break;
+			mt = tp_ballot(ct == G); mb = tp_ballot(cb == G);
+			if ((mt | mb) == 0ull) break;
 		}
-		if (!tp_any((top | bot) != 0)) break;       // nchanged == 0 in every frame of the wavefront: the statistics are final
+		if (tp_ballot((top | bot) != 0) == 0ull) break;       // nchanged == 0 in every frame of the wavefront: the statistics are final
 		s1 -= frame_sum<G>(r1);
 		s2 -= frame_sum<G>(r2);
 		lo_i += bot;
