@@ -191,8 +191,8 @@ def main():
 				'vector-ALU time of the B* part of this launch is ~%.1f ms at 2.4 GHz on 1 024 SIMDs; the smoothing and the sum image add ~200 '
 				'instructions per wavefront and block and one split-phase workgroup barrier per block' % (Nt * nblocks * 4 * 9500.0 / 1024 / 2.4e9 * 1e3),
 			'tp_aperture_fused_kernel': 'the aperture-sum kernel north_star names, from the K2P2 mask on (the sum image comes from the background pass): '
-				'one wavefront per target, in-mask pixel rows only; bound by the vector ALUs, not by HBM: 47 600 vector instructions per target '
-				'(counters: profiles/r4_step_kernel_counters.txt), about half the mask builder (scipy bracket / Brent / Powell replayed, DBSCAN, '
+				'one wavefront per target, in-mask pixel rows only; bound by the vector ALUs, not by HBM: 38 700 vector instructions per target '
+				'(counters: profiles/r6_step_kernel_counters.txt), about half the mask builder (scipy bracket / Brent / Powell replayed, DBSCAN, '
 				'watershed) and half the extraction, which takes the same time with its rows resident in L2 (DESIGN.md section 3)',
 		}
 		rooflines = [roofline_of(k, rows, traffic, notes.get(k)) for k in sorted(hbm_kernels, key=lambda k: -rows[k]['avg_ms'])]

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP64_VALU_TFLOPS = 78.6  # MI355X FP64 vector peak
 XGMI_LINK_GBS = 153.0
-TRAFFIC_FILE = os.path.join('profiles', 'r5_traffic.json')
+TRAFFIC_FILE = os.path.join('profiles', 'r6_traffic.json')
 
 
 def committed_traffic(key='traffic_bytes_per_launch', default_size=True):
