@@ -47,6 +47,8 @@
 #include "linpsf_dev.h"
 #include <cmath>
 #include <vector>
+#include <algorithm>
+#include <cstdlib>
 
 void* tp_ctx_scratch(tp_ctx* ctx, size_t bytes); // aperture.hip
 
@@ -66,6 +68,8 @@ struct PsfArgs {
 	float var_floor; double cutoff; int maxiter_first, maxiter;
 	double* flux; double* flux_err; double* cen_row; double* cen_col; int64_t out_pitch;
 	double* params_out; int32_t* nit; int32_t* status;
+	double* gstore;   // [gstore_targets][kStoreSlots][kItems * 25]: the sets a target has built, kept in HBM / L2 (nullptr: none)
+	int gstore_targets;   // targets with an index below this have a store
 };
 
 constexpr int kHalfBox = 5;                      // pixels inside the cut-off (<= 5.25) lie within +-5 of the pixel nearest to the star
@@ -79,6 +83,12 @@ constexpr int kBox = 2 * kHalfBox + 1;
 __device__ constexpr int kRowStart[kBox] = {0, 7, 16, 27, 38, 49, 60, 71, 82, 93, 102};
 constexpr int kItems = 109;
 
+// A target's store of built sets in HBM (L2-resident while the target runs): a simplex that straddles a knot alternates between
+// two to four pairs of knot intervals per star, and with ONE set per star in LDS (three-star targets) every such switch was a
+// rebuild -- four dependent rounds of table reads and ~700 dependent multiply-adds per thread, 12 % of the star evaluations and
+// the largest piece of an evaluation (round 6, in-kernel clocks).  A set that was built once is copied back instead: 2 725 doubles,
+// eleven coalesced loads per thread, one round trip.  The same numbers either way: bit-identical results.
+constexpr int kStoreSlots = 16;
 constexpr int kPool = 6;                         // most cached coefficient sets (24 KB each) a target gets; it uses psf_pool(ns) of them, pool / ns per star
 
 // Sets cached for a target with ns fitted stars: two for a single star, one per star otherwise.  The kernel is a chain of
@@ -106,6 +116,7 @@ struct EvalCtx {
 	const float* img; const float* wgt;    // float32 as psf_photometry.py:75-86 computes them
 	double* Kc; double* red; int* keys;    // keys[kPool][2]: the knot intervals of every cached set; red[2][4]
 	int* nxt; int* rbs;                    // per star: the set of its share that is replaced next; the set to rebuild now (-1: none)
+	double* gset; int* gkeys; int* gsrc;   // the target's store in HBM; its tags [kStoreSlots][3] = (star, kx, ky) and next slot [1] (LDS); per star: slot to copy from (>= 0) or -(slot + 1) to fill
 };
 
 // Star parameters of x for every thread; a star whose knot intervals are in none of its cached sets gets the oldest one rebuilt
@@ -158,6 +169,25 @@ __device__ __forceinline__ void prepare_stars(const double* x, const EvalCtx& c,
 			c.rbs[s] = rb;
 		}
 	}
+	if (c.gset) {
+		// (one thread: the stars of an evaluation share the store's tags and its replacement pointer)
+		if (tid == 0) {
+#pragma unroll
+			for (int s = 0; s < NS; ++s) {
+				int src = 0x7fffffff;
+				if (st[s].valid && st[s].slot < 0) {
+					for (int q = 0; q < kStoreSlots; ++q) if (c.gkeys[3 * q] == s && c.gkeys[3 * q + 1] == kxs[s] && c.gkeys[3 * q + 2] == kys[s]) src = q;
+					if (src == 0x7fffffff) {
+						const int q = c.gkeys[3 * kStoreSlots];
+						c.gkeys[3 * kStoreSlots] = (q + 1 == kStoreSlots) ? 0 : (q + 1);
+						c.gkeys[3 * q] = s; c.gkeys[3 * q + 1] = kxs[s]; c.gkeys[3 * q + 2] = kys[s];
+						src = -(q + 1);
+					}
+				}
+				c.gsrc[s] = src;
+			}
+		}
+	}
 	__syncthreads();
 	const double h2 = c.h * c.hy;
 #pragma unroll
@@ -167,6 +197,14 @@ __device__ __forceinline__ void prepare_stars(const double* x, const EvalCtx& c,
 		st[s].slot = rb;
 		const int kx = kxs[s], ky = kys[s];
 		double* K = c.Kc + (size_t)rb * kItems * 25;
+		const int gsrc = c.gset ? c.gsrc[s] : 0x7fffffff;   // uniform
+		if (gsrc >= 0 && gsrc != 0x7fffffff) {
+			// built before: back from the store
+			const double* G = c.gset + (size_t)gsrc * kItems * 25;
+			for (int w = tid; w < kItems * 25; w += kThreads) K[w] = G[w];
+			continue;
+		}
+
 		// two threads per item: one contracts columns 0..2 of the 25 coefficients, the other columns 3..4, each with one pass over
 		// the item's 13 x 13 patch of the table (round 3: a thread per (item, column) = five passes per item; the table is read
 		// from L2 and those reads, ~0.7 MB per rebuild, were what the kernel waited for)
@@ -197,6 +235,18 @@ __device__ __forceinline__ void prepare_stars(const double* x, const EvalCtx& c,
 		}
 	}
 	__syncthreads();
+	if (c.gset) {
+		// the sets built just now go to the target's store (a pass of its own: inside the contraction the store's address and
+		// the branch cost the kernel 60 registers)
+#pragma unroll
+		for (int s = 0; s < NS; ++s) {
+			const int gsrc = c.gsrc[s];
+			if (c.rbs[s] < 0 || gsrc >= 0) continue;   // uniform
+			const double* K = c.Kc + (size_t)c.rbs[s] * kItems * 25;
+			double* G = c.gset + (size_t)(-gsrc - 1) * kItems * 25;
+			for (int w = tid; w < kItems * 25; w += kThreads) G[w] = K[w];
+		}
+	}
 }
 
 // sum over the stars of flux * pixel-integrated PRF at pixel (i, j)
@@ -270,11 +320,15 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 	int* keys = reinterpret_cast<int*>(Kc + (size_t)pool * kItems * 25);   // [kPool][2]
 	int* nxt = keys + 2 * kPool;              // [kMaxPsfStars]
 	int* rbs = nxt + kMaxPsfStars;            // [kMaxPsfStars]
-	float* img = reinterpret_cast<float*>(rbs + kMaxPsfStars + 1);  // [P]   (2 kPool + 2 kMaxPsfStars + 1 ints: 4-byte aligned is enough)
+	int* gkeys = rbs + kMaxPsfStars + 1;      // [kStoreSlots][3] tags of the target's store + [1] the slot filled next
+	int* gsrc = gkeys + 3 * kStoreSlots + 1;  // [kMaxPsfStars]
+	float* img = reinterpret_cast<float*>(gsrc + kMaxPsfStars);  // [P]   (4-byte aligned is enough)
 	float* wgt = img + P;                     // [P]
 	for (int q = tid; q < n + 4; q += kThreads) { kn[q] = a.knots_x[q]; kny[q] = a.knots_y[q]; }
 	if (tid < kMaxPsfStars) { nxt[tid] = 0; rbs[tid] = -1; }
 	if (tid < 2 * pool) keys[tid] = -0x7fffffff;
+	if (tid < 3 * kStoreSlots) gkeys[tid] = -0x7fffffff;
+	if (tid == 0) gkeys[3 * kStoreSlots] = 0;
 	const int64_t s0 = a.star_offsets[target];
 	constexpr int ns = NS;   // (the host lists a target with more than five stars with the five-star ones: the first five are fitted)
 	constexpr int D = 3 * ns;
@@ -292,6 +346,7 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 	EvalCtx ec;
 	ec.ns = ns; ec.n = n; ec.H = H; ec.W = W; ec.pool = pool; ec.h = h; ec.hy = hy; ec.cutoff = a.cutoff;
 	ec.Cg = a.coef + (int64_t)target * n * n; ec.kn = kn; ec.kny = kny; ec.img = img; ec.wgt = wgt; ec.Kc = Kc; ec.red = red; ec.keys = keys; ec.nxt = nxt; ec.rbs = rbs;
+	ec.gset = (a.gstore && !GEN && target < a.gstore_targets) ? (a.gstore + (size_t)target * kStoreSlots * kItems * 25) : nullptr; ec.gkeys = gkeys; ec.gsrc = gsrc;
 	int flip = 0;
 #define EVAL(xp) likelihood<(NS > 0 ? NS : 1), GEN>((xp), ec, flip)
 	for (int k = 0; k < a.n_cad; ++k) {
@@ -493,7 +548,7 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 	const size_t P = (size_t)desc->height * desc->width;
 	auto lds_bytes = [&](int pool) {
 		const size_t doubles = (kMaxDim + 1) * kMaxDim + (kMaxDim + 1) + 3 * kMaxDim + kMaxDim + 16 + 2 * ((size_t)n_coef_axis + 4) + (size_t)pool * kItems * 25;
-		return doubles * sizeof(double) + (2 * kPool + 2 * kMaxPsfStars + 1) * sizeof(int) + 2 * P * sizeof(float) + 16;
+		return doubles * sizeof(double) + (2 * kPool + 2 * kMaxPsfStars + 1 + 3 * kStoreSlots + 1 + kMaxPsfStars) * sizeof(int) + 2 * P * sizeof(float) + 16;
 	};
 	// the targets by their number of fitted stars (one launch each, see psf_pool): the star offsets come to the host once, and
 	// with them the knots: the cached biquartics need the SPOC layout of the PRF grid (9 samples per pixel, the cut-off inside
@@ -522,6 +577,22 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 	a.var_floor = (float)variance_floor; a.cutoff = cutoff_radius; a.maxiter_first = maxiter_first; a.maxiter = maxiter;
 	a.flux = d_flux; a.flux_err = d_flux_err; a.cen_row = d_centroid_row; a.cen_col = d_centroid_col; a.out_pitch = out_pitch;
 	a.params_out = d_params_out; a.nit = d_nit; a.status = d_status;
+	// the store of built coefficient sets (kStoreSlots per target, 349 KB): as many targets as 8 GiB hold (23 000); a target beyond
+	// that rebuilds every set it needs, as every target did before round 6
+	a.gstore = nullptr; a.gstore_targets = 0;
+	const char* env_store = std::getenv("TESSPHOT_PSF_STORE");
+	if (!general && !(env_store && env_store[0] == '0')) {
+		const size_t per_target = (size_t)kStoreSlots * kItems * 25 * sizeof(double);
+		const size_t n_store = std::min((size_t)desc->n_targets, ((size_t)8 << 30) / per_target);
+		const size_t need = n_store * per_target;
+		if (ctx->store_bytes < need) {
+			if (ctx->store) (void)hipFree(ctx->store);
+			ctx->store = nullptr; ctx->store_bytes = 0;
+			if (tp_device_alloc(ctx, &ctx->store, need) == hipSuccess) ctx->store_bytes = need;
+			else (void)hipGetLastError();            // no store: the fit runs without it
+		}
+		if (ctx->store_bytes >= need && need > 0) { a.gstore = static_cast<double*>(ctx->store); a.gstore_targets = (int)n_store; }
+	}
 	// the launches are independent: the context's stream and two side streams in turn, so that their tails overlap (every launch
 	// ends with a few long-running workgroups on an otherwise idle chip)
 	hipStream_t streams[3] = {ctx->stream, nullptr, nullptr};

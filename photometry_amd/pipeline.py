@@ -517,6 +517,19 @@ class _GroupScene(object):
 		self.aperture = None
 
 
+class _RawBlock(object):
+	"""``nbytes`` bytes at ``address`` through the array interface (no ctypes array type per size)."""
+	__slots__ = ('__array_interface__',)
+
+	def __init__(self, address, nbytes):
+		self.__array_interface__ = {'shape': (int(nbytes),), 'typestr': '|u1', 'data': (int(address), True), 'version': 3}
+
+
+def _view_bytes(address, nbytes):
+	"""Read-only uint8 view of host memory owned by the library (a job's page-locked block: alive until the job is released)."""
+	return np.asarray(_RawBlock(address, nbytes))
+
+
 class FramesResult(object):
 	"""
 	Columnar result of :func:`aperture_frames`: one entry per target in arrays (``status``, ``stamp``, ``stamp_resizes``, ``has_result``),
@@ -676,15 +689,23 @@ class FramesJob(object):
 		for g in range(ng.value):
 			m, H, W, cap, ncat, blk, nb = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_void_p(), ctypes.c_uint64()
 			lib.tp_frames_group(h, g, ctypes.byref(m), ctypes.byref(H), ctypes.byref(W), ctypes.byref(cap), ctypes.byref(ncat), ctypes.byref(blk), ctypes.byref(nb))
-			layout, nbytes = tpcomm.packed_block_layout(m.value, T, H.value, W.value, n_cat=cap.value, extras=True)
-			if nbytes != nb.value:
+			# the fields of the packed block (comm.packed_block_layout with the catalogue flags and the extras), as read-only views of the
+			# page-locked block: offsets written out here -- this loop is the host's share of a batch (it was 1.0 ms of a 7.7 ms call
+			# through packed_block_layout / unpack_block and one ctypes array TYPE per block size)
+			mm, Hh, Ww, cc = m.value, H.value, W.value, cap.value
+			P = Hh * Ww
+			host = _view_bytes(blk.value, nb.value)
+			grp, off = {}, 0
+			for name, shape, dtype, size in (('lc', (5, mm, T), 'float64', 40 * mm * T), ('contamination', (mm,), 'float64', 8 * mm), ('status', (mm,), 'int32', 4 * mm),
+				('flags', (mm,), 'int32', 4 * mm), ('mask', (mm, Hh, Ww), 'uint8', mm * P), ('cat_in_mask', (cc,), 'uint8', cc),
+				('sumimage', (mm, Hh, Ww), 'float64', 8 * mm * P), ('diagnostics', (mm, 10), 'float64', 80 * mm)):
+				grp[name] = host[off:off + size].view(dtype).reshape(shape)
+				off = -(-(off + size) // 256) * 256
+			if off != nb.value:
 				raise RuntimeError('the packed block of the native engine does not have the layout of comm.packed_block_layout')
-			host = np.frombuffer((ctypes.c_uint8 * nbytes).from_address(blk.value), dtype='uint8')
-			host.flags.writeable = False
-			grp = tpcomm.unpack_block(host, layout)
-			offs = np.empty(m.value + 1, dtype='int64')
+			offs = np.empty(mm + 1, dtype='int64')
 			cat_ids = np.empty(max(ncat.value, 0), dtype='int64')
-			tids = np.empty(m.value, dtype='int64')
+			tids = np.empty(mm, dtype='int64')
 			lib.tp_frames_group_lists(h, g, offs.ctypes.data, cat_ids.ctypes.data, tids.ctypes.data)
 			grp.update(cat_offsets=offs, cat_starid=cat_ids, target_starid=tids)
 			out.groups.append(grp)
