@@ -148,7 +148,7 @@ int tp_sumimage(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
  * 220-254), for every target of the batch.  Stamps are fixed-size cubes: resize_stamp() cannot
  * grow them (BasePhotometry.py:605-612 -> False), so edge-touching masks are used as they are
  * and reported through the edge bits of d_flags for a host-side retry on a bigger cut-out.
- * Stamps of any size up to 65 535 pixels: up to about 54 x 54 the work arrays are in LDS, beyond that in a context-owned
+ * Stamps of any size up to 32 767 pixels (labels and pixel indices are signed 16-bit): up to about 54 x 54 the work arrays are in LDS, beyond that in a context-owned
  * HBM scratch (same code, same results, slow: the few bright stars of a CCD).
  *   catalog (ragged, CSR): d_cat_offsets int64 [n_targets+1]; per star float32 column_stamp,
  *     row_stamp, tmag, column, row (BasePhotometry.catalog, BasePhotometry.py:1153-1178), int64 starid.

@@ -261,7 +261,7 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 	const auto lab_t0 = std::chrono::steady_clock::now();
 	auto lab_t1 = lab_t0;
 	try {
-		if ((int64_t)H * W > 65535) throw Fail("a " + std::to_string(H) + "x" + std::to_string(W) + " stamp is beyond the 65 535 pixels of the mask builder");
+		if ((int64_t)H * W > 32767) throw Fail("a " + std::to_string(H) + "x" + std::to_string(W) + " stamp is beyond the 32 767 pixels of the mask builder");
 		G.n = m;
 		G.target_starid.resize(m);
 		std::vector<float> c_tmag, c_row, c_col, c_row_stamp, c_col_stamp;

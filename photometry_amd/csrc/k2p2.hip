@@ -78,7 +78,7 @@ extern "C" int tp_k2p2_masks(tp_ctx* ctx, int32_t n_targets, int32_t height, int
 	if (n_targets == 0) return TP_OK;
 	const size_t shmem = k2p2::shared_bytes(height * width);
 	const bool in_lds = shmem <= 160 * 1024;
-	TP_REQUIRE(ctx, (int64_t)height * width <= 65535, "tp_k2p2_masks: more than 65535 pixels per stamp (16-bit labels)");
+	TP_REQUIRE(ctx, (int64_t)height * width <= 32767, "tp_k2p2_masks: more than 32767 pixels per stamp (signed 16-bit labels and pixel indices)");
 
 	k2p2::Params prm = k2p2::default_params();
 	if (params) {

@@ -594,7 +594,13 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 		// handful of lanes walked 100+ dependent iterations while the others idled.
 		TP_LANE_LOOP(l) {
 			int lo[4] = {0, 0, 0, 0}, hi[4] = {nc, nc, nc, nc};
-			for (int step = 0; step < 9; ++step) { // nc <= 256
+			// (enough halvings for nc samples: nine sufficed for the 256 pixels of a 16 x 16 stamp and were what rounds 1-5 made for
+			// EVERY stamp -- above 512 samples the run boundaries came out up to two short, the binned counts and with them the
+			// KDE's argmax a grid step off on large stamps; the Powell search that starts there usually ended in the same mode,
+			// which is how it went unseen.  Found and fixed in round 6: tests/test_k2p2_hostsim.py::test_hostsim_kde_argmax_on_large_stamps)
+			int nsteps = 1;
+			while ((1 << nsteps) <= nc) ++nsteps;
+			for (int step = 0; step <= nsteps; ++step) {
 				for (int e = 0; e < 4; ++e) {
 					if (lo[e] < hi[e]) {
 						const int mid = (lo[e] + hi[e]) >> 1;
@@ -993,17 +999,9 @@ inline TP_DEV void watershed(Shared& k, int nmark) {
 	TP_PAR_FOR(p, P) if (k.wsout[p] != 0) { const int r = rank[p]; TP_ATOMIC_OR(&words[r >> 5], 1u << (r & 31)); }
 	TP_SYNC();
 	TP_SERIAL {
-		// summary: bit w of sum[w / 32] set <=> words[w] != 0.  Ranks count the in-mask pixels of ONE cluster, nwords <= 96
-		// covers the largest LDS-resident stamp (54 x 54) even if a single cluster filled it.
-		uint32_t sum0 = 0u, sum1 = 0u, sum2 = 0u;
-		for (int w = 0; w < nwords; ++w) if (words[w] != 0u) { if (w < 32) sum0 |= (1u << w); else if (w < 64) sum1 |= (1u << (w - 32)); else sum2 |= (1u << (w - 64)); }
-		while (sum0 | sum1 | sum2) {
-			const int w = sum0 ? __builtin_ctz(sum0) : (sum1 ? (32 + __builtin_ctz(sum1)) : (64 + __builtin_ctz(sum2)));
-			uint32_t bits = words[w];
-			const int b = __builtin_ctz(bits);
-			bits &= bits - 1u;
-			words[w] = bits;
-			if (bits == 0u) { if (w < 32) sum0 &= ~(1u << w); else if (w < 64) sum1 &= ~(1u << (w - 32)); else sum2 &= ~(1u << (w - 64)); }
+		// one pop of the flood: pixel of rank 32 w + b leaves the set, its unlabelled in-mask neighbours get its label and enter;
+		// `pushed(wn)` tells the caller's summary that word wn is non-zero
+		auto pop = [&](int w, int b, auto&& pushed) {
 			const int px = ord[w * 32 + b];
 			const int lbl = k.wsout[px];
 			const int r = row_of(k, px), c = px - r * W;
@@ -1026,7 +1024,38 @@ inline TP_DEV void watershed(Shared& k, int nmark) {
 				k.wsout[nb[q]] = lbl;
 				const int wn = rn[q] >> 5;
 				words[wn] |= (1u << (rn[q] & 31));
-				if (wn < 32) sum0 |= (1u << wn); else if (wn < 64) sum1 |= (1u << (wn - 32)); else sum2 |= (1u << (wn - 64));
+				pushed(wn);
+			}
+		};
+		const int nzw = (nz + 31) >> 5;      // words that can hold a rank of this cluster
+		if (nzw <= 96) {
+			// summary: bit w of sum[w / 32] set <=> words[w] != 0.  Ranks count the in-mask pixels of ONE cluster: 96 words cover the
+			// largest LDS-resident stamp (54 x 54) even if a single cluster filled it.
+			uint32_t sum0 = 0u, sum1 = 0u, sum2 = 0u;
+			for (int w = 0; w < nzw; ++w) if (words[w] != 0u) { if (w < 32) sum0 |= (1u << w); else if (w < 64) sum1 |= (1u << (w - 32)); else sum2 |= (1u << (w - 64)); }
+			while (sum0 | sum1 | sum2) {
+				const int w = sum0 ? __builtin_ctz(sum0) : (sum1 ? (32 + __builtin_ctz(sum1)) : (64 + __builtin_ctz(sum2)));
+				uint32_t bits = words[w];
+				const int b = __builtin_ctz(bits);
+				bits &= bits - 1u;
+				words[w] = bits;
+				if (bits == 0u) { if (w < 32) sum0 &= ~(1u << w); else if (w < 64) sum1 &= ~(1u << (w - 32)); else sum2 &= ~(1u << (w - 64)); }
+				pop(w, b, [&](int wn) { if (wn < 32) sum0 |= (1u << wn); else if (wn < 64) sum1 |= (1u << (wn - 32)); else sum2 |= (1u << (wn - 64)); });
+			}
+		} else {
+			// a cluster of more than 3 072 pixels (only in the stamps of the brightest stars, whose work arrays live in HBM): the
+			// three summary words do not reach -- rounds 1-5 shifted past them.  The lowest non-zero word is found by a scan from
+			// the lowest word that can be non-zero (a push below it moves it back).
+			int wscan = 0;
+			while (true) {
+				while (wscan < nzw && words[wscan] == 0u) ++wscan;
+				if (wscan >= nzw) break;
+				const int w = wscan;
+				uint32_t bits = words[w];
+				const int b = __builtin_ctz(bits);
+				bits &= bits - 1u;
+				words[w] = bits;
+				pop(w, b, [&](int wn) { if (wn < wscan) wscan = wn; });
 			}
 		}
 	}

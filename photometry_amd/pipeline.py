@@ -993,8 +993,8 @@ def _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s
 				g = streams[gi % len(streams)] if len(idx) < 256 or gi == 0 else streams[0]
 				cubes = host = None
 				try:
-					if H * W > 65535:
-						raise TessphotError(1, f'a {H}x{W} stamp is beyond the 65 535 pixels of the mask builder')
+					if H * W > 32767:
+						raise TessphotError(1, f'a {H}x{W} stamp is beyond the 32 767 pixels of the mask builder')
 					# the stamps are cut while the host selects the catalogue stars of the group
 					cut = stack.cut_lazy(g, cur[idx], H, W)
 					cubes = {k: cut[k] for k in stack.names}
@@ -1019,7 +1019,7 @@ def _frames_job(ctx, stack, targets, catalog, time, quality, settings, cadence_s
 					g.download_async(host, device_view(g, work.block.ptr, (lc_bytes,), 'uint8'))
 					launched.append((g, idx, H, W, scene, cat_offsets, cat_arrays, cubes, batch, work, host, ev))
 				except TessphotError as e:
-					# e.g. a stamp beyond 65 535 pixels (the mask builder's 16-bit labels): Halo territory upstream
+					# e.g. a stamp beyond 32 767 pixels (the mask builder's signed 16-bit labels): Halo territory upstream
 					try:
 						g.sync()
 					except TessphotError:

@@ -21,6 +21,10 @@ def make_cases(kind, seed):
 		# a resized stamp of a crowded field: a dozen clusters, several of them at the stamp's edges and corners -- the per-cluster
 		# passes of the mask builder run over windows around each cluster (k2p2_core.h: struct Win)
 		s = simulate.make_scene(20, 60, 29, 33, seed=seed, max_neighbours=14, neighbour_tmag_range=(7.5, 13.5))
+	elif kind == 'huge':
+		# blended very bright stars on a 100 x 96 stamp: ONE cluster of several thousand pixels split by the watershed -- more ranks
+		# than the three summary words of the flood's bit set hold (3 072): the scanning path of k2p2_core.h::watershed
+		s = simulate.make_scene(3, 8, 100, 96, seed=seed, tmag_range=(1.0, 2.0), max_neighbours=2, neighbour_tmag_range=(1.0, 2.5), sigma_psf=7.0)
 	elif kind == 'large':
 		# beyond the LDS-resident mask builder (about 54 x 54 pixels): the work arrays live in HBM
 		s = simulate.make_scene(5, 24, 62, 58, seed=seed, tmag_range=(4.0, 6.0), max_neighbours=6, neighbour_tmag_range=(6.0, 10.0), sigma_psf=1.6)
@@ -109,6 +113,9 @@ def compare(s, S, got, ref, check_cut=True):
 			if tie:
 				n_tie += 1
 			else:
+				# the KDE's argmax (the start of the Powell search): the same grid point.  (The search is forgiving -- a start one grid
+				# step off usually ends in the same mode -- which hid a linear binning that went wrong above 512 samples until round 6.)
+				assert abs(d[4] - thr['max_guess']) <= 1e-9*max(1.0, abs(thr['max_guess'])), f"target {i}: KDE argmax {d[4]} vs {thr['max_guess']}"
 				assert dcut <= 2e-6*max(1.0, abs(thr['CUT'])), f"target {i}: CUT {d[0]} vs {thr['CUT']}"
 				with np.errstate(invalid='ignore'):
 					margin = np.nanmin(np.abs(S[i] - thr['CUT']))

@@ -40,7 +40,7 @@ def run_device(ctx, s, S, cut_override=None):
 		'contamination': work.contamination.to_host(), 'diag': work.diag.to_host(), 'cat_in_mask': work.cat_in_mask.to_host()}
 
 
-@pytest.mark.parametrize("kind,seed", [('faint15', 1), ('small11', 2), ('crowded', 3), ('bright', 4), ('tiny', 5), ('faint15', 6)])
+@pytest.mark.parametrize("kind,seed", [('faint15', 1), ('small11', 2), ('crowded', 3), ('bright', 4), ('tiny', 5), ('faint15', 6), ('wide', 7), ('wide', 8), ('huge', 6)])
 def test_k2p2_matches_oracle(ctx, kind, seed):
 	s, S = make_cases(kind, seed)
 	got = run_device(ctx, s, S)
@@ -120,11 +120,27 @@ def test_full_aperture_pipeline(ctx):
 
 
 def test_k2p2_stamp_too_large_is_an_error(ctx):
-	"""The labels are 16-bit: beyond 65 535 pixels per stamp the call is refused (no fallback, no truncation)."""
+	"""The labels and pixel indices are signed 16-bit: beyond 32 767 pixels per stamp the call is refused (no fallback, no truncation;
+	rounds 1-5 refused above 65 535 only, and a stamp between the two limits would have been labelled wrongly)."""
 	from photometry_amd._lib import TessphotError
 	from photometry_amd import simulate
 	s = simulate.make_scene(1, 2, 300, 300, seed=1)
 	s.aperture = np.ones((1, 300, 300), dtype='int32')
 	with pytest.raises(TessphotError) as e:
 		run_device(ctx, s, np.ones((1, 300, 300)))
-	assert '65535 pixels' in str(e.value)
+	assert '32767 pixels' in str(e.value)
+
+
+def test_k2p2_kde_argmax_on_large_stamps(ctx):
+	"""More than 512 / 1 024 positive pixels per stamp: the linear binning's run boundaries need as many halvings as the sample has bits
+	(nine were made for every stamp until round 6, see tests/test_k2p2_hostsim.py); `compare` asserts the KDE's argmax itself."""
+	from photometry_amd import simulate
+	from oracle import sumimage as osum
+	for (H, W, seed) in [(45, 50, 2), (40, 40, 1)]:
+		s = simulate.make_scene(12, 40, H, W, seed=seed, max_neighbours=14, neighbour_tmag_range=(7.5, 13.5))
+		simulate.fill_cubes(s)
+		S = osum.sumimage_batch(s.images, s.quality)
+		got = run_device(ctx, s, S)
+		ref = oracle_batch(s, S)
+		stats = compare(s, S, got, ref)
+		assert stats['n_exact'] + stats['n_error_agree'] + stats['n_razor'] == s.n_targets and stats['n_exact'] >= 10
