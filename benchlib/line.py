@@ -79,7 +79,7 @@ def compact(result):
 	out['config']['stamp'] = cfg.get('stamp')
 	out['config']['parallelism'] = cfg.get('parallelism_short') or cfg.get('parallelism', '')[:MAX_STRING]
 	out['roofline'] = _roofline(r.get('roofline'))
-	out['rooflines'] = [_pick(x, ('kernel', 'achieved', 'frac', 'traffic', 'avg_kernel_ms')) for x in r.get('rooflines', [])]
+	out['rooflines'] = [_pick(x, ('kernel', 'achieved', 'frac', 'frac_counter_bytes', 'traffic', 'avg_kernel_ms')) for x in r.get('rooflines', [])]
 	if 'step_hbm' in r:
 		out['step_hbm'] = _pick(r['step_hbm'], ('necessary_bytes_per_step', 'GBps_over_whole_step', 'frac_of_hbm_peak', 'mean_mask_pixels'))
 	if 'cpu_baseline' in r:

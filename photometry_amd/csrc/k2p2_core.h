@@ -1172,24 +1172,39 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 				// ... and the cluster's bounding box (core and border pixels): the passes below that cost more than a store per pixel
 				// run over windows around it (see struct Win), not over the stamp once per cluster -- on a 25 x 25 stamp of a crowded
 				// field, with a dozen clusters, they were half of the mask builder's time
+				// (per-lane partials in k.ired / k.red / k.tmp, which lie outside the region the two phases of the builder share: the
+				// KDE grid of A2 overlaps A4's images and k.hval there.  Five extrema, three arrays: two sweeps.)
 				TP_LANE_LOOP(l) {
-					int r0 = H, r1 = -1, c0 = W, c1 = -1;
-					double smax = 0.0;
+					int r0 = H, r1 = -1, c1 = -1;
 					for (int p = l; p < P; p += 64) {
 						const uint8_t m = (k.lab[p] == lab) ? 1 : 0;
 						k.msk[p] = m;
 						if (m) {
 							const int r = row_of(k, p), c = p - r * W;
-							r0 = (r < r0) ? r : r0; r1 = (r > r1) ? r : r1; c0 = (c < c0) ? c : c0; c1 = (c > c1) ? c : c1;
+							r0 = (r < r0) ? r : r0; r1 = (r > r1) ? r : r1; c1 = (c > c1) ? c : c1;
+						}
+					}
+					k.ired[l] = r1; k.red[l] = (double)(-r0); k.tmp[l] = (double)c1;
+				}
+				TP_SYNC();
+				const int br1 = max_ired(k), br0 = -(int)max_arr(k, k.red), bc1 = (int)max_arr(k, k.tmp);
+				TP_SYNC();
+				TP_LANE_LOOP(l) {
+					int c0 = W;
+					double smax = 0.0;
+					for (int p = l; p < P; p += 64) {
+						if (k.msk[p]) {
+							const int r = row_of(k, p), c = p - r * W;
+							c0 = (c < c0) ? c : c0;
 							const double sv = k.S[p];
 							smax = (sv > smax) ? sv : smax;     // (cluster pixels have S > CUT: never NaN)
 						}
 					}
-					k.ired[l] = r1; k.red[l] = (double)(-r0); k.hval[l] = (double)c1; k.grid[l] = (double)(-c0); k.grid[64 + l] = smax;   // (the KDE grid is free after A2)
+					k.red[l] = (double)(-c0); k.tmp[l] = smax;
 				}
 				TP_SYNC();
-				const int br1 = max_ired(k), br0 = -(int)max_arr(k, k.red), bc1 = (int)max_arr(k, k.hval), bc0 = -(int)max_arr(k, k.grid);
-				const double cluster_max = max_arr(k, k.grid + 64);
+				const int bc0 = -(int)max_arr(k, k.red);
+				const double cluster_max = max_arr(k, k.tmp);
 				TP_SYNC();
 				const Win box = win_make(k, br0, br1, bc0, bc1);
 				// A cluster NO catalogue star can reach is rejected here, before anything is computed for it.  k2p2WS keeps a cluster only
