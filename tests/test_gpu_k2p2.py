@@ -144,3 +144,18 @@ def test_k2p2_kde_argmax_on_large_stamps(ctx):
 		ref = oracle_batch(s, S)
 		stats = compare(s, S, got, ref)
 		assert stats['n_exact'] + stats['n_error_agree'] + stats['n_razor'] == s.n_targets and stats['n_exact'] >= 10
+
+
+@pytest.mark.parametrize("H,W", [(9, 9), (10, 11), (12, 12), (13, 13), (13, 14), (8, 16)])
+def test_k2p2_crowded_small_stamps(ctx, H, W):
+	"""Crowded stamps of 66 - 191 pixels (see tests/test_k2p2_hostsim.py::test_hostsim_crowded_small_stamps): the per-cluster windows of
+	the builder on the sizes where a scratch overlap once made them too small."""
+	from photometry_amd import simulate
+	from oracle import sumimage as osum
+	s = simulate.make_scene(40, 30, H, W, seed=100 + H * W, max_neighbours=6, neighbour_tmag_range=(8.0, 13.0))
+	simulate.fill_cubes(s)
+	S = osum.sumimage_batch(s.images, s.quality)
+	got = run_device(ctx, s, S)
+	ref = oracle_batch(s, S)
+	stats = compare(s, S, got, ref)
+	assert stats['n_exact'] + stats['n_error_agree'] + stats['n_razor'] == s.n_targets and stats['n_exact'] >= 30 and stats['n_razor'] <= 1

@@ -100,3 +100,19 @@ def test_hostsim_kde_argmax_on_large_stamps(hostsim):
 		assert max(r['thr']['nflux_cut'] for r in ref if r.get('thr')) > (1024 if H * W > 2000 else 512)
 		stats = compare(s, S, got, ref)
 		assert stats['n_exact'] + stats['n_error_agree'] + stats['n_razor'] == s.n_targets and stats['n_exact'] >= 10
+
+
+@pytest.mark.parametrize("H,W", [(9, 9), (10, 11), (11, 11), (12, 12), (13, 13), (13, 14), (8, 16)])
+def test_hostsim_crowded_small_stamps(hostsim, H, W):
+	"""Crowded stamps of 66 - 191 pixels, several clusters each: the sizes at which the scratch of the per-cluster bounding box once
+	overlapped other per-lane scratch (the KDE grid of A2 shares its memory with A4's arrays) -- a window that comes out too small drops
+	peaks, and the masks differ from the oracle's."""
+	from photometry_amd import simulate
+	from oracle import sumimage as osum
+	s = simulate.make_scene(40, 30, H, W, seed=100 + H * W, max_neighbours=6, neighbour_tmag_range=(8.0, 13.0))
+	simulate.fill_cubes(s)
+	S = osum.sumimage_batch(s.images, s.quality)
+	got = run_hostsim(hostsim, s, S)
+	ref = oracle_batch(s, S)
+	stats = compare(s, S, got, ref)
+	assert stats['n_exact'] + stats['n_error_agree'] + stats['n_razor'] == s.n_targets and stats['n_exact'] >= 30 and stats['n_razor'] <= 1
