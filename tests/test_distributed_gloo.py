@@ -395,3 +395,60 @@ def test_bench_spawns_its_own_ranks_and_fails_loudly_without_gpu():
 	err = r.stderr.decode()
 	assert err.count('bench.py needs a GPU') >= 2, err[-2000:]   # both ranks started, both refused to run
 	assert '{' not in r.stdout.decode()   # no result line
+
+
+def _net_group_worker(rank, world, outdir, port):
+	sys.path.insert(0, ROOT)
+	os.environ['MASTER_ADDR'] = '127.0.0.1'
+	os.environ['TESSPHOT_RDZV_PORT'] = str(port)
+	os.environ['TESSPHOT_RDZV_SECRET'] = 'net-test-secret'
+	os.environ.pop('TESSPHOT_RDZV_ID', None)
+	from photometry_amd import hostgroup
+	assert hostgroup.network_rendezvous_port() == port
+	if rank == 1:
+		# a stranger reaches rank 0's port first and announces an absurd message: rank 0 must drop it and go on accepting
+		import socket, struct, time
+		for _ in range(200):
+			try:
+				s = socket.create_connection(('127.0.0.1', port), timeout=1.0)
+				break
+			except OSError:
+				time.sleep(0.05)
+		s.sendall(struct.pack('<Q', 1 << 62))
+		s.close()
+		s = socket.create_connection(('127.0.0.1', port), timeout=1.0)
+		s.sendall(struct.pack('<Q', 12) + b'not-the-magic')       # a well-formed stranger too
+		s.close()
+	g = hostgroup.SocketGroup(rank, world, rendezvous_timeout=60)
+	assert g.max(rank * 2.0) == (world - 1) * 2.0 and g.allgather_int(rank + 10) == [r + 10 for r in range(world)]
+	a = np.full((2, 3), rank, dtype='float32')
+	got = g.gather_array(a, dst=0)
+	if rank == 0:
+		assert [int(x[0, 0]) for x in got] == list(range(world))
+	g.barrier()
+	g.close()
+	open(os.path.join(outdir, 'ok%d' % rank), 'w').close()
+
+
+def test_socket_group_network_rendezvous_and_strangers(tmp_path):
+	"""The several-node rendezvous of hostgroup.SocketGroup (TESSPHOT_RDZV_PORT: rank 0 listens on a known port, no rendezvous file),
+	with the handshake secret, while strangers connect to the port: one announces a message of 2^62 bytes, one sends a well-formed
+	message that is not the handshake -- rank 0 drops both (the length is checked before anything is allocated) and the group comes up."""
+	import socket
+	s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+	_spawn_plain(_net_group_worker, (3, str(tmp_path), port), 3)
+	assert sorted(os.listdir(tmp_path)) == ['ok0', 'ok1', 'ok2']
+
+
+def test_network_rendezvous_port_from_the_launcher_environment(monkeypatch):
+	"""One node: no port (the rendezvous file).  A launcher environment that spans nodes (WORLD_SIZE > LOCAL_WORLD_SIZE): MASTER_PORT + 1."""
+	from photometry_amd import hostgroup
+	for k in ('TESSPHOT_RDZV_PORT', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_PORT'):
+		monkeypatch.delenv(k, raising=False)
+	assert hostgroup.network_rendezvous_port() is None
+	monkeypatch.setenv('WORLD_SIZE', '8'); monkeypatch.setenv('LOCAL_WORLD_SIZE', '8'); monkeypatch.setenv('MASTER_PORT', '29500')
+	assert hostgroup.network_rendezvous_port() is None
+	monkeypatch.setenv('WORLD_SIZE', '16')
+	assert hostgroup.network_rendezvous_port() == 29501
+	monkeypatch.setenv('TESSPHOT_RDZV_PORT', '40000')
+	assert hostgroup.network_rendezvous_port() == 40000
