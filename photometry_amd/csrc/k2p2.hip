@@ -26,12 +26,12 @@ __global__ __launch_bounds__(64, 2) void tp_k2p2_kernel(k2p2::BatchArgs a, k2p2:
 	k2p2::Target t;
 	k2p2::make_target(a, target, t);
 #ifdef TP_LAB_K2P2_CLOCK
-	for (int i = 0; i < 12; ++i) k.clk[i] = 0;
+	for (int i = 0; i < 16; ++i) k.clk[i] = 0;
 	k.clk0 = __builtin_readcyclecounter();
 #endif
 	k2p2::run_target(k, prm, t);
 #ifdef TP_LAB_K2P2_CLOCK
-	if (threadIdx.x == 0) for (int i = 0; i < 12; ++i) atomicAdd(&tp_lab_k2clk[i], k.clk[i]);
+	if (threadIdx.x == 0) for (int i = 0; i < 16; ++i) atomicAdd(&tp_lab_k2clk[i], k.clk[i]);
 #endif
 }
 

@@ -112,7 +112,7 @@ typedef int16_t lab_t;
 // Shared (LDS) work arrays of one target.  Sizes in elements; P = H*W, Pp = pow2 >= P.
 struct Shared {
 #ifdef TP_LAB_K2P2_CLOCK
-	unsigned long long clk0, clk[12];
+	unsigned long long clk0, clk[16];
 #endif
 	int lane;
 	int P, Pp, H, W;
@@ -230,7 +230,7 @@ inline TP_DEV int row_of(const Shared& k, int p) { return (k.W > 1) ? (int)(((ui
 // the saturated-column test) touch a cluster's neighbourhood only: everywhere else their results are constants (zero) that a
 // plain store pass writes.  A pass over a window computes, for its pixels, exactly what the pass over the whole stamp computed:
 // the pixel index, its neighbours and the reflections at the STAMP's edges are those of the stamp.
-struct Win { int r0, c0, h, w, n; uint32_t magic; };
+struct Win { int r0, c0, h, w, n; uint32_t magic; bool full; };
 inline TP_DEV Win win_make(const Shared& k, int r0, int r1, int c0, int c1) {   // inclusive limits, clipped to the stamp
 	Win v;
 	if (r0 < 0) r0 = 0;
@@ -239,13 +239,16 @@ inline TP_DEV Win win_make(const Shared& k, int r0, int r1, int c0, int c1) {   
 	if (c1 > k.W - 1) c1 = k.W - 1;
 	v.r0 = r0; v.c0 = c0; v.h = (r1 >= r0) ? (r1 - r0 + 1) : 0; v.w = (c1 >= c0) ? (c1 - c0 + 1) : 0;
 	v.n = v.h * v.w;
-	v.magic = (v.w > 1) ? (uint32_t)((0x100000000ull + (uint64_t)v.w - 1ull) / (uint64_t)v.w) : 0u;   // ceil(2^32 / w): exact below 2^16
+	v.full = (v.n == k.P);
+	// ceil(2^32 / w): exact below 2^16 (the whole stamp needs none: its q-th pixel is pixel q)
+	v.magic = (v.w > 1 && !v.full) ? (uint32_t)((0x100000000ull + (uint64_t)v.w - 1ull) / (uint64_t)v.w) : 0u;
 	return v;
 }
 inline TP_DEV Win win_full(const Shared& k) { return win_make(k, 0, k.H - 1, 0, k.W - 1); }
-inline TP_DEV bool win_is_full(const Shared& k, const Win& v) { return v.n == k.P; }
+inline TP_DEV bool win_is_full(const Shared& k, const Win& v) { (void)k; return v.full; }
 // stamp pixel index of the q-th pixel of the window (row-major)
 inline TP_DEV int win_pix(const Shared& k, const Win& v, int q) {
+	if (v.full) return q;      // (uniform: the passes over the whole stamp pay one scalar branch, not the index arithmetic)
 	const int rr = (v.w > 1) ? (int)(((uint64_t)(uint32_t)q * (uint64_t)v.magic) >> 32) : q;
 	return (v.r0 + rr) * k.W + v.c0 + (q - rr * v.w);
 }
@@ -299,7 +302,8 @@ inline TP_DEV double tp_exp(double x) {
 // Bitonic sort of k.srt[0..Pp) ascending (NaN-free input; +inf padding).
 inline TP_DEV void bitonic_sort(Shared& k) {
 #ifdef TP_HAVE_WAVE_SORT
-	if (k.Pp <= 256) { wave_sort_256(k); return; }   // the device's lane layer sorts small stamps in registers
+	if (k.Pp <= 256) { wave_sort_regs<4>(k); return; }     // the device's lane layer sorts in registers: four keys per lane,
+	if (k.Pp <= 1024) { wave_sort_regs<16>(k); return; }   // sixteen for stamps up to 32 x 32
 #endif
 	const int n = k.Pp;
 	for (int size = 2; size <= n; size <<= 1) {
@@ -529,6 +533,7 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 	TP_PAR_FOR(p, k.Pp) k.srt[p] = (p < P && k.S[p] > 0.0) ? k.S[p] : tp_inf();
 	TP_SYNC();
 	bitonic_sort(k);
+	TP_K2P2_CLOCK(k, 12);
 	// count of finite entries == nflux unless some flux is +inf (kept, as numpy would)
 	// trim1(sorted, 0.15): keep the n - int(0.15 n) smallest (scipy/stats trim1, tail='right')
 	int nc = nflux - (int)(0.15 * (double)nflux);
@@ -564,6 +569,7 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 		bw = 1.059 * A * pow((double)nc, -0.2);
 	}
 	if (nc == 0) bw = tp_nan();
+	TP_K2P2_CLOCK(k, 13);
 	if (bw == 0.0) return ERR_BANDWIDTH_ZERO;
 
 	// --- kdensityfft: linear binning on a 128-point grid, Silverman transform, inverse transform
@@ -693,7 +699,9 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 		max_guess = (am == M - 1) ? b : (a + (double)am * delta);
 		TP_SYNC();
 	}
+	TP_K2P2_CLOCK(k, 14);
 	const double MODE = powell_mode(k, nc, bw, max_guess);
+	TP_K2P2_CLOCK(k, 15);
 
 	// MAD1 = mad_to_sigma * nanmedian(|Flux[Flux < MODE] - MODE|)   (k2p2v2.py:424)
 	// Flux sorted ascending: the selection is the prefix [0, c)
@@ -1000,8 +1008,9 @@ inline TP_DEV void watershed(Shared& k, int nmark) {
 	TP_SYNC();
 	TP_SERIAL {
 		// one pop of the flood: pixel of rank 32 w + b leaves the set, its unlabelled in-mask neighbours get its label and enter;
-		// `pushed(wn)` tells the caller's summary that word wn is non-zero
-		auto pop = [&](int w, int b, auto&& pushed) {
+		// pw[q]: the word of the bit set that neighbour q's rank went into, or -1 (the caller keeps its summary of non-zero words in
+		// plain variables: captured by reference in a callback they were moved to scratch memory)
+		auto pop = [&](int w, int b, int (&pw)[4]) {
 			const int px = ord[w * 32 + b];
 			const int lbl = k.wsout[px];
 			const int r = row_of(k, px), c = px - r * W;
@@ -1019,12 +1028,13 @@ inline TP_DEV void watershed(Shared& k, int nmark) {
 				rn[q] = rank[nb[q]];
 			}
 			for (int q = 0; q < 4; ++q) {
+				pw[q] = -1;
 				if (zn[q] == 0.0) continue;      // not in mask
 				if (wl[q] != 0) continue;        // already labelled (or the out-of-image stand-in)
 				k.wsout[nb[q]] = lbl;
 				const int wn = rn[q] >> 5;
 				words[wn] |= (1u << (rn[q] & 31));
-				pushed(wn);
+				pw[q] = wn;
 			}
 		};
 		const int nzw = (nz + 31) >> 5;      // words that can hold a rank of this cluster
@@ -1040,7 +1050,13 @@ inline TP_DEV void watershed(Shared& k, int nmark) {
 				bits &= bits - 1u;
 				words[w] = bits;
 				if (bits == 0u) { if (w < 32) sum0 &= ~(1u << w); else if (w < 64) sum1 &= ~(1u << (w - 32)); else sum2 &= ~(1u << (w - 64)); }
-				pop(w, b, [&](int wn) { if (wn < 32) sum0 |= (1u << wn); else if (wn < 64) sum1 |= (1u << (wn - 32)); else sum2 |= (1u << (wn - 64)); });
+				int pw[4];
+				pop(w, b, pw);
+				for (int q = 0; q < 4; ++q) {
+					const int wn = pw[q];
+					if (wn < 0) continue;
+					if (wn < 32) sum0 |= (1u << wn); else if (wn < 64) sum1 |= (1u << (wn - 32)); else sum2 |= (1u << (wn - 64));
+				}
 			}
 		} else {
 			// a cluster of more than 3 072 pixels (only in the stamps of the brightest stars, whose work arrays live in HBM): the
@@ -1055,7 +1071,9 @@ inline TP_DEV void watershed(Shared& k, int nmark) {
 				const int b = __builtin_ctz(bits);
 				bits &= bits - 1u;
 				words[w] = bits;
-				pop(w, b, [&](int wn) { if (wn < wscan) wscan = wn; });
+				int pw[4];
+				pop(w, b, pw);
+				for (int q = 0; q < 4; ++q) if (pw[q] >= 0 && pw[q] < wscan) wscan = pw[q];
 			}
 		}
 	}
@@ -1081,6 +1099,7 @@ inline TP_DEV float mags_total_f32(const float* tmag, const uint8_t* sel, int n)
 // stack frame in scratch memory and the fused kernel its register allocation)
 TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Target& t) {
 	const int P = k.P, H = k.H, W = k.W;
+	const bool wide = P > 256;    // per-cluster windows and the early rejection of clusters: for stamps above 16 x 16 (see A4)
 	TP_PAR_FOR(p, P) { k.S[p] = t.S[p]; k.res[p] = 0; }
 	TP_SYNC();
 	int flags = 0;
@@ -1163,92 +1182,122 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 			// Labels after k2p2WS: non-core -> noise (k2p2v2.py:112)
 			TP_PAR_FOR(p, P) k.lab2[p] = (k.idx[p]) ? ((k.core[p]) ? k.lab[p] : -1) : -2;
 			TP_SYNC();
+			// A cluster NO catalogue star can reach is rejected here, before anything is computed for it.  k2p2WS keeps a cluster only
+			// if a peak of its blurred image is matched by a star: a star takes its nearest peak if that lies within 5 sqrt 2 pixels
+			// (2 sqrt 2 for a star fainter than the saturation limit; k2p2v2.py:144-153), else none, and a cluster without a matched
+			// peak has no markers and is dropped (:218-223).  Peaks are pixels where the blurred image exceeds the threshold
+			// max(min, ws_thres * max) >= 0, i.e. pixels of the cluster's bounding box grown by the filter's two pixels: a star whose
+			// distance to that rectangle -- the same expression sqrt(dx^2 + dy^2) on the nearest point of the rectangle; every
+			// rounding in it is monotone, so it bounds the distance to every pixel of the rectangle from below -- is not below its
+			// limit matches nothing.  What the skipped code could still do is raise "no peaks" (a cluster whose blurred image has no
+			// pixel above the threshold: the error of k2p2v2.py:146): impossible when the fluxes above the threshold are positive and
+			// finite (CUT >= 0), ws_thres is 0 and the grown box is not the whole stamp (there are zeros: the maximum is a peak above
+			// the minimum) -- otherwise the cluster takes the long way.  On a resized stamp of a crowded field most clusters are noise
+			// far from any star: 7 of 10 on 25 x 25 stamps, and they were 40 % of the mask builder's time there.
+			// All clusters at once: the bounding boxes by one sweep with LDS atomics (four ints per cluster in k.tmp, free until the
+			// loop below), the reach of the stars one cluster per lane, the flags in k.core (free from here on), ONE relabelling sweep.
+			{
+				int32_t* bb = (int32_t*)k.tmp;                 // [nclusters][4]: first row, last row, first column, last column; then [nclusters] reach flags
+				int32_t* reach = bb + 4 * nclusters;
+				const bool room = 5 * nclusters <= 2 * ((P < 64) ? 64 : P);
+				// (a stamp with ONE cluster -- the target star's -- skips all of this: the sweeps would cost a 15 x 15 target of the step a
+				// tenth of its builder time, measured)
+				// (stamps up to 16 x 16 take neither this nor the windows below: with 1.6 clusters per target, all within reach of the
+				// target star, the sweeps that find boxes cost more than they save -- 3 % of the step's mask + extraction launch, same-box A/B)
+				bool guard = wide && room && nclusters > 1 && t.ncat > 0 && CUT >= 0.0 && prm.ws_thres == 0.0;
+				if (guard) {
+					TP_LANE_LOOP(l) {
+						double smax = 0.0;
+						for (int p = l; p < P; p += 64) if (k.idx[p]) { const double sv = k.S[p]; smax = (sv > smax) ? sv : smax; }   // (S > CUT there: never NaN)
+						k.red[l] = smax;
+					}
+					TP_SYNC();
+					guard = max_arr(k, k.red) < 1e300;
+					TP_SYNC();
+				}
+				if (guard) {
+					TP_PAR_FOR(c, nclusters) { bb[4 * c] = H; bb[4 * c + 1] = -1; bb[4 * c + 2] = W; bb[4 * c + 3] = -1; reach[c] = 0; }
+					TP_SYNC();
+					TP_PAR_FOR(p, P) {
+						const int c = k.lab[p];
+						if (c >= 0) {
+							const int r = row_of(k, p), cc = p - r * W;
+							TP_ATOMIC_MIN(&bb[4 * c], r); TP_ATOMIC_MAX(&bb[4 * c + 1], r); TP_ATOMIC_MIN(&bb[4 * c + 2], cc); TP_ATOMIC_MAX(&bb[4 * c + 3], cc);
+						}
+					}
+					TP_SYNC();
+					// one (cluster, star) pair per lane and step: the stars' catalogue rows are read side by side, not one after the other
+					const int npairs = nclusters * t.ncat;
+					TP_PAR_FOR(q, npairs) {
+						const int c = q / t.ncat, sidx = q - c * t.ncat;
+						const Win grown = win_make(k, bb[4 * c] - 2, bb[4 * c + 1] + 2, bb[4 * c + 2] - 2, bb[4 * c + 3] + 2);
+						int hit = 1;
+						if (!win_is_full(k, grown)) {
+							const double xlo = (double)grown.c0, xhi = (double)(grown.c0 + grown.w - 1), ylo = (double)grown.r0, yhi = (double)(grown.r0 + grown.h - 1);
+							const double c0 = (double)t.cat_col[sidx], c1 = (double)t.cat_row[sidx];
+							if ((c0 == c0) && (c1 == c1)) {                                // (a NaN position: the long way decides)
+								double dx = 0.0, dy = 0.0;
+								if (c0 < xlo) dx = xlo - c0; else if (c0 > xhi) dx = xhi - c0;
+								if (c1 < ylo) dy = ylo - c1; else if (c1 > yhi) dy = yhi - c1;
+								const double d = sqrt(dx * dx + dy * dy);
+								const double dist_factor = ((double)t.cat_tmag[sidx] > prm.saturation_limit) ? 2.0 : 5.0;
+								if (d >= dist_factor * 1.4142135623730951) hit = 0;
+							}
+						}
+						if (hit) TP_ATOMIC_OR(&reach[c], 1);
+					}
+					TP_SYNC();
+				}
+				TP_PAR_FOR(c, nclusters) k.core[c] = (guard && reach[c] == 0) ? 1 : 0;
+				TP_SYNC();
+				if (guard) {
+					TP_PAR_FOR(p, P) { const int c = k.lab2[p]; if (c >= 0 && k.core[c]) k.lab2[p] = -1; }
+					TP_SYNC();
+				}
+			}
 			int max_label = nclusters - 1;
 #ifdef TP_LAB_K2P2_CLOCK
 			k.clk[11] += (unsigned long long)nclusters;
 #endif
 			for (int lab = 0; lab < nclusters && !err; ++lab) {
+				// a cluster no catalogue star can reach was rejected before the loop (below: `far`)
+				if (k.core[lab]) { TP_K2P2_CLOCK(k, 8); continue; }   // (uniform)
 				// pre-pass saturated mask of the un-split cluster incl. border points (k2p2v2.py:465-492)
 				// ... and the cluster's bounding box (core and border pixels): the passes below that cost more than a store per pixel
 				// run over windows around it (see struct Win), not over the stamp once per cluster -- on a 25 x 25 stamp of a crowded
 				// field, with a dozen clusters, they were half of the mask builder's time
 				// (per-lane partials in k.ired / k.red / k.tmp, which lie outside the region the two phases of the builder share: the
-				// KDE grid of A2 overlaps A4's images and k.hval there.  Five extrema, three arrays: two sweeps.)
-				TP_LANE_LOOP(l) {
-					int r0 = H, r1 = -1, c1 = -1;
-					for (int p = l; p < P; p += 64) {
-						const uint8_t m = (k.lab[p] == lab) ? 1 : 0;
-						k.msk[p] = m;
-						if (m) {
-							const int r = row_of(k, p), c = p - r * W;
-							r0 = (r < r0) ? r : r0; r1 = (r > r1) ? r : r1; c1 = (c > c1) ? c : c1;
-						}
-					}
-					k.ired[l] = r1; k.red[l] = (double)(-r0); k.tmp[l] = (double)c1;
-				}
-				TP_SYNC();
-				const int br1 = max_ired(k), br0 = -(int)max_arr(k, k.red), bc1 = (int)max_arr(k, k.tmp);
-				TP_SYNC();
-				TP_LANE_LOOP(l) {
-					int c0 = W;
-					double smax = 0.0;
-					for (int p = l; p < P; p += 64) {
-						if (k.msk[p]) {
-							const int r = row_of(k, p), c = p - r * W;
-							c0 = (c < c0) ? c : c0;
-							const double sv = k.S[p];
-							smax = (sv > smax) ? sv : smax;     // (cluster pixels have S > CUT: never NaN)
-						}
-					}
-					k.red[l] = (double)(-c0); k.tmp[l] = smax;
-				}
-				TP_SYNC();
-				const int bc0 = -(int)max_arr(k, k.red);
-				const double cluster_max = max_arr(k, k.tmp);
-				TP_SYNC();
-				const Win box = win_make(k, br0, br1, bc0, bc1);
-				// A cluster NO catalogue star can reach is rejected here, before anything is computed for it.  k2p2WS keeps a cluster only
-				// if a peak of its blurred image is matched by a star: a star takes its nearest peak if that lies within 5 sqrt 2 pixels
-				// (2 sqrt 2 for a star fainter than the saturation limit; k2p2v2.py:144-153), else none, and a cluster without a matched
-				// peak has no markers and is dropped (:218-223).  Peaks are pixels where the blurred image exceeds the threshold
-				// max(min, ws_thres * max) >= 0, i.e. pixels of the box grown by the filter's two pixels: a star whose distance to
-				// that rectangle -- the same expression sqrt(dx^2 + dy^2) on the nearest point of the rectangle; every rounding in it
-				// is monotone, so it bounds the distance to every pixel of the rectangle from below -- is not below its limit matches
-				// nothing.  What the skipped code could still do is raise "no peaks" (a cluster whose blurred image has no pixel above
-				// the threshold: the error of k2p2v2.py:146): impossible when the fluxes of the cluster are positive and finite
-				// (CUT >= 0), ws_thres is 0 and the grown box is not the whole stamp (there are zeros: the maximum is a peak above the
-				// minimum) -- otherwise the cluster takes the long way.  On a resized stamp of a crowded field most clusters are noise
-				// far from any star: 7 of 10 on 25 x 25 stamps, and they were 40 % of the mask builder's time there.
-				{
-					const Win grown = win_make(k, br0 - 2, br1 + 2, bc0 - 2, bc1 + 2);
-					bool far = false;
-					if (CUT >= 0.0 && prm.ws_thres == 0.0 && cluster_max < 1e300 && !win_is_full(k, grown)) {
-						const double xlo = (double)grown.c0, xhi = (double)(grown.c0 + grown.w - 1), ylo = (double)grown.r0, yhi = (double)(grown.r0 + grown.h - 1);
-						TP_LANE_LOOP(l) {
-							int reach = 0;
-							for (int sidx = l; sidx < t.ncat; sidx += 64) {
-								const double c0 = (double)t.cat_col[sidx], c1 = (double)t.cat_row[sidx];
-								double dx = 0.0, dy = 0.0;
-								if (c0 < xlo) dx = xlo - c0; else if (c0 > xhi) dx = xhi - c0;
-								if (c1 < ylo) dy = ylo - c1; else if (c1 > yhi) dy = yhi - c1;
-								if (!(c0 == c0) || !(c1 == c1)) { reach = 1; continue; }        // a NaN position: the long way decides
-								const double d = sqrt(dx * dx + dy * dy);
-								const double dist_factor = ((double)t.cat_tmag[sidx] > prm.saturation_limit) ? 2.0 : 5.0;
-								if (!(d >= dist_factor * 1.4142135623730951)) reach = 1;
+				// KDE grid of A2 overlaps A4's images and k.hval there.  Four extrema, three arrays: two sweeps.)
+				int br0 = 0, br1 = H - 1, bc0 = 0, bc1 = W - 1;
+				if (wide) {
+					TP_LANE_LOOP(l) {
+						int r0 = H, r1 = -1, c1 = -1;
+						for (int p = l; p < P; p += 64) {
+							const uint8_t m = (k.lab[p] == lab) ? 1 : 0;
+							k.msk[p] = m;
+							if (m) {
+								const int r = row_of(k, p), c = p - r * W;
+								r0 = (r < r0) ? r : r0; r1 = (r > r1) ? r : r1; c1 = (c > c1) ? c : c1;
 							}
-							k.ired[l] = reach;
 						}
-						TP_SYNC();
-						far = (or_ired(k) == 0);
-						TP_SYNC();
+						k.ired[l] = r1; k.red[l] = (double)(-r0); k.tmp[l] = (double)c1;
 					}
-					if (far) {
-						TP_PAR_FOR(p, P) if (k.lab2[p] == lab) k.lab2[p] = -1;
-						TP_SYNC();
-						TP_K2P2_CLOCK(k, 8);
-						continue;
+					TP_SYNC();
+					br1 = max_ired(k); br0 = -(int)max_arr(k, k.red); bc1 = (int)max_arr(k, k.tmp);
+					TP_SYNC();
+					TP_LANE_LOOP(l) {
+						int c0 = W;
+						for (int p = l; p < P; p += 64) if (k.msk[p]) { const int r = row_of(k, p), c = p - r * W; c0 = (c < c0) ? c : c0; }
+						k.ired[l] = -c0;
 					}
+					TP_SYNC();
+					bc0 = -max_ired(k);
+					TP_SYNC();
+				} else {
+					TP_PAR_FOR(p, P) k.msk[p] = (k.lab[p] == lab) ? 1 : 0;
+					TP_SYNC();
 				}
+				const Win box = win_make(k, br0, br1, bc0, bc1);
 				const int nsat = saturated_one(k, box);
 				TP_K2P2_CLOCK(k, 2);
 				// Z = flux on the core pixels of this cluster

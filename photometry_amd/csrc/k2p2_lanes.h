@@ -11,6 +11,8 @@
 #define TP_SERIAL if (k.lane == 0)
 #define TP_ATOMIC_INC(ptr) atomicAdd((ptr), 1)
 #define TP_ATOMIC_OR(ptr, v) atomicOr((ptr), (v))
+#define TP_ATOMIC_MIN(ptr, v) atomicMin((ptr), (v))
+#define TP_ATOMIC_MAX(ptr, v) atomicMax((ptr), (v))
 #define TP_NO_UNROLL _Pragma("unroll 1")
 #define TP_ALWAYS_INLINE __forceinline__
 #elif K2P2_LANES_SECTION == 2
@@ -46,34 +48,40 @@ inline TP_DEV int max_ired(const Shared& k) { TP_TREE(int, k.ired, (y_ > x_) ? y
 inline TP_DEV double min_arr(const Shared& k, const double* arr) { TP_TREE(double, arr, (y_ < x_) ? y_ : x_) }
 inline TP_DEV double max_arr(const Shared& k, const double* arr) { TP_TREE(double, arr, (y_ > x_) ? y_ : x_) }
 #undef TP_TREE
-// Ascending sort of k.srt[0 .. Pp), Pp <= 256 (stamps up to 16 x 16), in REGISTERS: a lane holds four consecutive keys, the
-// bitonic network's strides 1 and 2 are exchanges between its own registers, the strides from 4 up exchanges with the lane
-// l ^ (stride / 4) (21 cross-lane stages of four doubles each).  The LDS version (k2p2_core.h: 36 stages, two dependent LDS round
-// trips and a fence each) took 28 000 cycles of a target's ~360 000; a sorted array is a sorted array: same result.
+// Ascending sort of k.srt[0 .. Pp), Pp <= 64 K, in REGISTERS: a lane holds K consecutive keys (K = 4: stamps up to 16 x 16; K = 16:
+// up to 32 x 32, the resized stamps of the batched entry), the bitonic network's strides below K are exchanges between its own
+// registers, the strides from K up exchanges with the lane l ^ (stride / K).  The LDS version (k2p2_core.h: two dependent LDS round
+// trips and a fence per stage) took 28 000 cycles of a 15 x 15 target's ~360 000 (36 stages) and 15 % of a 25 x 25 target's time
+// (55 stages of 1 024 keys, one wavefront: round 6, in-kernel clocks); a sorted array is a sorted array: same result.
 #define TP_HAVE_WAVE_SORT 1
-inline TP_DEV void wave_sort_256(Shared& k) {
+template <int K>
+inline TP_DEV void wave_sort_regs(Shared& k) {
 	const int l = k.lane, n = k.Pp;
 	const double inf = __builtin_inf();
-	double v[4];
+	double v[K];
 #pragma unroll
-	for (int j = 0; j < 4; ++j) { const int i = 4 * l + j; v[j] = (i < n) ? k.srt[i] : inf; }
+	for (int j = 0; j < K; ++j) { const int i = K * l + j; v[j] = (i < n) ? k.srt[i] : inf; }
 	auto cx = [](double& a, double& b, bool up) { const double mn = fmin(a, b), mx = fmax(a, b); a = up ? mn : mx; b = up ? mx : mn; };
-	cx(v[0], v[1], true); cx(v[2], v[3], false);                       // size 2: direction from bit 1 of the index
-	{ const bool up = (l & 1) == 0; cx(v[0], v[2], up); cx(v[1], v[3], up); cx(v[0], v[1], up); cx(v[2], v[3], up); }   // size 4: from bit 2
 #pragma unroll
-	for (int size = 8; size <= 256; size <<= 1) {
-		const bool up = ((4 * l) & size) == 0;
+	for (int size = 2; size <= 64 * K; size <<= 1) {
+		// the direction of a key's block of `size`: from the key's index i = K l + j -- a bit of j below K, a bit of l from K up
+		const bool up_lane = ((K * l) & size) == 0;
 #pragma unroll
-		for (int stride = size >> 1; stride >= 4; stride >>= 1) {
-			const int lx = stride >> 2;
-			const bool keep_min = (((l & lx) == 0) == up);
+		for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+			if (stride >= K) {
+				const int lx = stride / K;
+				const bool keep_min = (((l & lx) == 0) == up_lane);
 #pragma unroll
-			for (int j = 0; j < 4; ++j) { const double o = __shfl_xor(v[j], lx, 64); v[j] = keep_min ? fmin(v[j], o) : fmax(v[j], o); }
+				for (int j = 0; j < K; ++j) { const double o = __shfl_xor(v[j], lx, 64); v[j] = keep_min ? fmin(v[j], o) : fmax(v[j], o); }
+			} else {
+#pragma unroll
+				for (int j = 0; j < K; ++j)
+					if ((j & stride) == 0) cx(v[j], v[j | stride], (size < K) ? ((j & size) == 0) : up_lane);
+			}
 		}
-		cx(v[0], v[2], up); cx(v[1], v[3], up); cx(v[0], v[1], up); cx(v[2], v[3], up);
 	}
 #pragma unroll
-	for (int j = 0; j < 4; ++j) { const int i = 4 * l + j; if (i < n) k.srt[i] = v[j]; }
+	for (int j = 0; j < K; ++j) { const int i = K * l + j; if (i < n) k.srt[i] = v[j]; }
 	__syncthreads();
 }
 // Tree sum (same association as sum_red) of per-lane partials produced by f(lane), without touching LDS: the partial stays

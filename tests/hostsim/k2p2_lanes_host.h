@@ -10,6 +10,8 @@
 #define TP_SERIAL if (true)
 #define TP_ATOMIC_INC(ptr) ((*(ptr))++)
 #define TP_ATOMIC_OR(ptr, v) (*(ptr) |= (v))
+#define TP_ATOMIC_MIN(ptr, v) do { if ((v) < *(ptr)) *(ptr) = (v); } while (0)
+#define TP_ATOMIC_MAX(ptr, v) do { if ((v) > *(ptr)) *(ptr) = (v); } while (0)
 #elif K2P2_LANES_SECTION == 2
 #define TP_TREE(T, arr, OP) T a_[64]; for (int l = 0; l < 64; ++l) a_[l] = (arr)[l]; \
 	for (int off = 32; off > 0; off >>= 1) for (int l = 0; l < off; ++l) { const T x_ = a_[l], y_ = a_[l + off]; a_[l] = OP; } return a_[0];

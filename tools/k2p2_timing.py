@@ -27,6 +27,8 @@ c = np.array(list(buf), dtype='float64') / Nt
 names = ['A2 threshold (sort, KDE, Powell / Brent, MAD)', 'idx, DBSCAN core, labels', 'per cluster: saturated pre-pass', 'per cluster: blur + peaks', 'per cluster: star match', 'per cluster: dedupe in saturated patches',
 	'per cluster: label the markers', 'per cluster: watershed', 'per cluster: relabel', 'mask assembly', 'minimum aperture, edges, contamination, outputs']
 print('clusters per target %.1f' % c[11])
+print('A2 in detail (ticks per target): sort %.0f, bandwidth %.0f, KDE grid + argmax %.0f, Powell / Brent %.0f, MAD + CUT %.0f' % (c[12], c[13], c[14], c[15], c[0]))
+c[0] += c[12] + c[13] + c[14] + c[15]
 c = c[:len(names)]
 tot = c.sum()
 for n, v in zip(names, c):
