@@ -737,7 +737,7 @@ inline TP_DEV int threshold(Shared& k, const Params& prm, const Target& t, doubl
 // (scipy.ndimage.label numbering), 0 for background.  Returns the number of components.
 // `win`: a window that holds every set pixel of `in` -- the propagation sweeps run over it alone (the other passes are single
 // reads or stores per pixel and stay on the whole stamp)
-inline TP_DEV int label_components(Shared& k, const uint8_t* in, lab_t* out, bool conn8, const Win& win) {
+inline TP_DEV int label_components_sweeps(Shared& k, const uint8_t* in, lab_t* out, bool conn8, const Win& win) {
 	const int P = k.P, H = k.H, W = k.W;
 	TP_PAR_FOR(p, P) out[p] = in[p] ? p : -1;
 	TP_SYNC();
@@ -794,6 +794,89 @@ inline TP_DEV int label_components(Shared& k, const uint8_t* in, lab_t* out, boo
 	TP_PAR_FOR(p, P) out[p] = k.hage[p];
 	TP_SYNC();
 	return n;
+}
+// The same labelling for stamps up to 64 x 64 with the ROWS AS BIT MASKS: lane r holds row r of `in` as a 64-bit word, a component is
+// flooded from its first pixel in raster order -- within a row a seed fills its whole run of set pixels by a parallel-prefix carry
+// (six shifts each way), between rows by the neighbours' words (for 8-connectivity widened by one bit each way) -- until no row changes.
+// One LDS word per row and step where the sweeps read nine labels per pixel and sweep; the numbering (components in raster order of
+// their first pixel, scipy.ndimage.label's) is the order the floods are started in.  Scratch: k.tmp (the rows), k.red (what is left),
+// k.hval and k.dist (the flood, double-buffered): 64 words each; callers for which k.dist is live take the sweeps.
+inline TP_DEV uint64_t fill_runs(uint64_t m, uint64_t s) {
+	// every run of consecutive set bits of m that holds a bit of s, entirely (Kogge-Stone carry towards both ends)
+	uint64_t g = s & m, p = m;
+	g |= p & (g << 1); p &= (p << 1);
+	g |= p & (g << 2); p &= (p << 2);
+	g |= p & (g << 4); p &= (p << 4);
+	g |= p & (g << 8); p &= (p << 8);
+	g |= p & (g << 16); p &= (p << 16);
+	g |= p & (g << 32);
+	uint64_t h = g; p = m;
+	h |= p & (h >> 1); p &= (p >> 1);
+	h |= p & (h >> 2); p &= (p >> 2);
+	h |= p & (h >> 4); p &= (p >> 4);
+	h |= p & (h >> 8); p &= (p >> 8);
+	h |= p & (h >> 16); p &= (p >> 16);
+	h |= p & (h >> 32);
+	return h;
+}
+inline TP_DEV int label_components_rows(Shared& k, const uint8_t* in, lab_t* out, bool conn8) {
+	const int P = k.P, H = k.H, W = k.W;
+	uint64_t* M = (uint64_t*)k.tmp;     // the rows of `in`
+	uint64_t* R = (uint64_t*)k.red;     // ... of the pixels not yet in a component
+	uint64_t* C = (uint64_t*)k.hval;    // the component being flooded
+	uint64_t* D = (uint64_t*)k.dist;    // ... after the step in work
+	TP_PAR_FOR(p, P) out[p] = 0;
+	TP_LANE_LOOP(l) {
+		uint64_t m = 0;
+		if (l < H) for (int c = 0; c < W; ++c) m |= (uint64_t)(in[l * W + c] ? 1 : 0) << c;
+		M[l] = m; R[l] = m;
+	}
+	TP_SYNC();
+	int n = 0;
+	while (true) {
+		// the first pixel, in raster order, that is in no component yet: the lowest row with one, its lowest column
+		TP_LANE_LOOP(l) { k.ired[l] = (l < H && R[l] != 0) ? (64 - l) : 0; }
+		TP_SYNC();
+		const int top = max_ired(k);
+		TP_SYNC();
+		if (top == 0) break;
+		const int r0 = 64 - top;
+		++n;
+		TP_LANE_LOOP(l) { const uint64_t r = R[l]; C[l] = (l == r0) ? fill_runs(M[l], r & (0 - r)) : 0; }
+		TP_SYNC();
+		while (true) {
+			TP_LANE_LOOP(l) {
+				int changed = 0;
+				uint64_t s = C[l];
+				if (l < H) {
+					uint64_t v = ((l > 0) ? C[l - 1] : 0) | ((l + 1 < H) ? C[l + 1] : 0);
+					if (conn8) v |= (v << 1) | (v >> 1);
+					const uint64_t m = M[l];
+					const uint64_t grown = s | (v & m);
+					if (grown != s) { s = fill_runs(m, grown); changed = 1; }
+				}
+				D[l] = s;
+				k.ired[l] = changed;
+			}
+			TP_SYNC();
+			const int any = or_ired(k);
+			TP_SYNC();
+			{ uint64_t* x = C; C = D; D = x; }
+			if (!any) break;
+		}
+		TP_LANE_LOOP(l) {
+			uint64_t c = C[l];
+			R[l] &= ~c;
+			while (c) { const int b = __builtin_ctzll(c); out[l * W + b] = (lab_t)n; c &= c - 1; }
+		}
+		TP_SYNC();
+	}
+	return n;
+}
+// `scratch_free`: k.dist holds nothing the caller still needs (the rows version uses its first 64 words)
+inline TP_DEV int label_components(Shared& k, const uint8_t* in, lab_t* out, bool conn8, const Win& win, bool scratch_free = true) {
+	if (scratch_free && k.H <= 64 && k.W <= 64) return label_components_rows(k, in, out, conn8);
+	return label_components_sweeps(k, in, out, conn8, win);
 }
 inline TP_DEV int label_components(Shared& k, const uint8_t* in, lab_t* out, bool conn8) { return label_components(k, in, out, conn8, win_full(k)); }
 
@@ -1413,7 +1496,7 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 				TP_K2P2_CLOCK(k, 4);
 				// de-duplicate maxima inside saturated patches (k2p2v2.py:193-212): only a patch that holds two selected maxima changes
 				if (nsat > 0 && nselected > 1) {
-					const int ncomp = label_components(k, k.sat, k.mark, false);
+					const int ncomp = label_components(k, k.sat, k.mark, false, win_full(k), false);   // (k.dist is read below: the sweeps)
 					for (int cc = 1; cc <= ncomp; ++cc) {
 						TP_LANE_LOOP(l) {
 							int c = 0;
@@ -1580,27 +1663,35 @@ TP_ALWAYS_INLINE TP_DEV int run_target(Shared& k, const Params& prm, const Targe
 		flags |= or_ired(k);
 		TP_SYNC();
 		// ---------------- A7: contamination (photometry.py:220-238) ----------------
-		TP_PAR_FOR(s, t.ncat) {
-			// rows == np.round(t['row'])+1 with 1-based grid rows: stamp index = round(row) - stamp_row0
-			const int r = (int)rintf(t.cat_ccd_row[s]) - t.stamp_row0;
-			const int c = (int)rintf(t.cat_ccd_col[s]) - t.stamp_col0;
-			uint8_t in = 0;
-			if (r >= 0 && r < H && c >= 0 && c < W) in = k.res[r * W + c] ? 1 : 0;
-			if (t.cat_in_mask) t.cat_in_mask[s] = in;
-		}
-		TP_SYNC();
-		// serial tail on every lane (uniform, reads global cat_in_mask written above)
+		// Which catalogue stars lie in the mask, and 10^(-0.4 Tmag) of those, 64 stars at a time with a lane per star (the catalogue
+		// rows come from global memory and powf is a hundred instructions: star after star, by every lane, this was an eighth of the
+		// builder's time on a 15 x 15 stamp); the float32 sum of photometry.py:233 is then taken in catalogue order from LDS.
 		int nin = 0, only = -1;
 		float ssum = 0.f;
-		for (int s = 0; s < t.ncat; ++s) {
-			const int r = (int)rintf(t.cat_ccd_row[s]) - t.stamp_row0;
-			const int c = (int)rintf(t.cat_ccd_col[s]) - t.stamp_col0;
-			bool in = false;
-			if (r >= 0 && r < H && c >= 0 && c < W) in = k.res[r * W + c] != 0;
-			if (!in) continue;
-			nin++; only = s;
-			const float v = powf(10.0f, -0.4f * t.cat_tmag[s]);
-			if (v == v) ssum += v;
+		for (int base = 0; base < t.ncat; base += 64) {
+			TP_LANE_LOOP(l) {
+				const int s2 = base + l;
+				int in = 0;
+				double v = 0.0;
+				if (s2 < t.ncat) {
+					// rows == np.round(t['row'])+1 with 1-based grid rows: stamp index = round(row) - stamp_row0
+					const int r = (int)rintf(t.cat_ccd_row[s2]) - t.stamp_row0;
+					const int c = (int)rintf(t.cat_ccd_col[s2]) - t.stamp_col0;
+					if (r >= 0 && r < H && c >= 0 && c < W) in = k.res[r * W + c] ? 1 : 0;
+					if (t.cat_in_mask) t.cat_in_mask[s2] = (uint8_t)in;
+					if (in) v = (double)powf(10.0f, -0.4f * t.cat_tmag[s2]);   // (a float widened: exact both ways, NaN included)
+				}
+				k.ired[l] = in; k.red[l] = v;
+			}
+			TP_SYNC();
+			const int cnt = (t.ncat - base < 64) ? (t.ncat - base) : 64;
+			for (int j = 0; j < cnt; ++j) {       // every lane, the same (uniform)
+				if (!k.ired[j]) continue;
+				nin++; only = base + j;
+				const float v = (float)k.red[j];
+				if (v == v) ssum += v;
+			}
+			TP_SYNC();
 		}
 		if (nin == 0) { err = ERR_NO_TARGETS_IN_MASK; }
 		else if (nin == 1 && t.cat_starid[only] == t.target_starid) contamination = 0.0;
