@@ -72,6 +72,7 @@ def parse_args(argv=None):
 	p.add_argument('--psf-targets', type=int, default=4096, help='targets of the non-linear PSF photometry leg (0 = skip)')
 	p.add_argument('--fullframe-frames', type=int, default=16, help='2048 x 2048 frames of the full-frame background / pixel-flag leg (0 = skip)')
 	p.add_argument('--linpsf-drift', type=int, default=1, help='1: the LinPSF leg also runs the scene with a pointing drift (0 = skip: the profiling passes, whose per-kernel means it would mix)')
+	p.add_argument('--frames-large', type=int, default=10000, help='targets of the second frames-to-results leg, on a 1024 x 1024 stack (0 = skip)')
 	p.add_argument('--frames-targets', type=int, default=2500, help='targets of the frames-to-results leg on a 512 x 512 stack (0 = skip)')
 	return p.parse_args(argv)
 
@@ -294,6 +295,9 @@ def main():
 		result['linpsf'] = leg_linpsf(ctx, scene, cubes, work, args, Nt, T, H, W, np, engine, pipeline)
 		if args.frames_targets > 0 and (T, H) == (1300, 15):
 			result['frames_to_results'] = leg_frames(ctx, args, T, np, pipeline)
+			if args.frames_large > 0:
+				# the same entry on a batch of the headline's size: four times the region (same star density), four times the targets
+				result['frames_to_results_large_batch'] = leg_frames(ctx, args, T, np, pipeline, N=args.frames_large, FR=1024, NB=6, runs=7)
 			result['psf_frames_to_results'] = leg_psf_frames(ctx, args, T, np, pipeline)
 		for k in ('raw', 'images_err'):
 			cubes[k].free()

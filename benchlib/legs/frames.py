@@ -25,14 +25,14 @@ def synthetic_region(np, N, FR, T, seed):
 	return frames, tstamp, quality, cat, targets
 
 
-def leg_frames(ctx, args, T, np, pipeline):
+def leg_frames(ctx, args, T, np, pipeline, N=None, FR=512, NB=12, runs=14):
 	"""
 	The batched drop-in entry as a scheduler would call it: a CCD region's frame stacks (images, errors, backgrounds) resident
 	in HBM, ``tessphot_frames`` from target list to per-target results -- default stamps, catalogue selection, stamp cuts on
 	the device, the fused pass, the stamp-resize rounds, diagnostics, download and the host-side bookkeeping per target.
 	"""
 	from photometry_amd import tessphot_frames
-	N, FR = args.frames_targets, 512
+	N = args.frames_targets if N is None else N
 	frames, tstamp, quality, cat, targets = synthetic_region(np, N, FR, T, args.seed + 7)
 	stack = pipeline.FrameStack(ctx, frames, 0, 44)
 	del frames
@@ -60,7 +60,6 @@ def leg_frames(ctx, args, T, np, pipeline):
 	# time, each result consumed (its counts read) and let go before the next is taken
 	from photometry_amd import tessphot_frames_pipelined
 	rng = np.random.default_rng(args.seed + 8)
-	NB = 12
 	batches = []
 	for _b in range(NB):
 		sel = rng.permutation(N)
@@ -71,7 +70,7 @@ def leg_frames(ctx, args, T, np, pipeline):
 	gc.collect()   # (the legs before this one leave a large heap: a full collection in the middle of a 70 ms timing is 10 % of it)
 	reps = []
 	okc = 0
-	for rep in range(14):
+	for rep in range(runs):
 		t2 = time.perf_counter()
 		okc = 0
 		for res in tessphot_frames_pipelined(ctx, stack, iter(batches), cat, tstamp, quality, in_flight=4):

@@ -590,7 +590,26 @@ typedef struct tp_frames_stack {
 	 * masks first and cuts only the in-mask pixel rows of the three stacks; NULL: the sum image of every stamp is formed from
 	 * its own image cube (tp_sumimage: the reference's postage-stamp branch, BasePhotometry.py:1007-1019). */
 	const double* d_sumimage;
+	/* optional (all three or none; needs d_sumimage): the TIME-MAJOR copies of the three stacks, float32 [n_rows * n_cols][t_pitch]
+	 * (tp_frames_transpose; t_pitch >= n_frames, a multiple of 4; the cadences past n_frames zero).  Given, no pass cuts anything:
+	 * the extraction reads a mask pixel's time series as one row of the stack (tp_aperture_extract_stack) -- the per-target cube of
+	 * BasePhotometry._load_cube (BasePhotometry.py:720-751) is never materialised.  NULL: in-mask rows are cut per pass. */
+	const float* d_images_t;
+	const float* d_images_err_t;
+	const float* d_backgrounds_t;
+	int64_t t_pitch;
 } tp_frames_stack;
+/* [n_frames][n_pixels] (frame_stride elements from frame to frame) -> [n_pixels][t_pitch], cadences past n_frames zero */
+int tp_frames_transpose(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride, float* d_out, int64_t t_pitch);
+/* tp_aperture_extract (A6, photometry.py:172-201) with the pixels' series taken from the time-major stacks of a region: stamp
+ * pixel (r, c) of target t is row (d_stamps[4 t] - stack_row0 + r) * stack_cols + d_stamps[4 t + 2] - stack_col0 + c of the
+ * stacks; d_backgrounds_t NULL = aperture-only (flux_background NaN).  Same kernels and operation order as on cut cubes. */
+int tp_aperture_extract_stack(tp_ctx* ctx, int32_t n_targets, int32_t n_cad, int32_t height, int32_t width,
+	const float* d_images_t, const float* d_images_err_t, const float* d_backgrounds_t, int64_t t_pitch,
+	int32_t stack_rows, int32_t stack_cols, int32_t stack_row0, int32_t stack_col0,
+	const uint8_t* d_mask, const int32_t* d_stamps, const int32_t* d_status,
+	double* d_flux, double* d_flux_err, double* d_flux_background,
+	double* d_centroid_col, double* d_centroid_row, int64_t out_pitch);
 int tp_frames_engine_create(int device, int32_t n_slots, tp_frames_engine** out);
 int tp_frames_engine_destroy(tp_frames_engine* eng);        /* every job waited for and released first */
 int tp_frames_engine_info(tp_frames_engine* eng, int32_t* n_slots, int32_t* n_free, uint64_t* hbm_bytes);

@@ -44,7 +44,7 @@ class tp_radial_image(Structure):
 class tp_frames_stack(Structure):
 	_fields_ = [('d_images', c_void_p), ('d_images_err', c_void_p), ('d_backgrounds', c_void_p),
 		('n_frames', c_int32), ('n_rows', c_int32), ('n_cols', c_int32), ('row0', c_int32), ('col0', c_int32),
-		('d_sumimage', c_void_p)]
+		('d_sumimage', c_void_p), ('d_images_t', c_void_p), ('d_images_err_t', c_void_p), ('d_backgrounds_t', c_void_p), ('t_pitch', c_int64)]
 
 
 class tp_k2p2_params(Structure):
@@ -119,6 +119,9 @@ SIGNATURES = {
 	'tp_background_zoom': (c_int, [c_void_p, _p, _p, _p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, _p]),
 	'tp_frames_smooth_time': (c_int, [c_void_p, c_int32, c_int64, c_int64, c_int32, _p, _p]),
 	'tp_frames_subtract': (c_int, [c_void_p, c_int64, _p, _p, _p, _p, c_uint32, _p, _p]),
+	'tp_frames_transpose': (c_int, [c_void_p, _p, c_int32, c_int64, c_int64, _p, c_int64]),
+	'tp_aperture_extract_stack': (c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, _p, _p, _p, c_int64, c_int32, c_int32, c_int32, c_int32,
+		_p, _p, _p, _p, _p, _p, _p, _p, c_int64]),
 	'tp_frames_sumimage': (c_int, [c_void_p, c_int32, c_int64, c_int64, _p, _p, c_uint32, _p]),
 	'tp_radial_zeropoint': (c_int, [c_void_p, _p, c_int32, c_int64, c_int64, _p, c_int64, _p, c_int64, c_double, _p, c_int32, _p]),
 	'tp_radial_ring_modes': (c_int, [c_void_p, _p, c_int32, c_int64, c_int64, _p, c_int64, _p, c_int64, c_double, _p, _p, _p, c_int32, c_int32,

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 
 	const int col0 = a.stamps[target * 4 + 2] + 1;
 	const int row0 = a.stamps[target * 4 + 0] + 1;
-	const int64_t tb = (int64_t)target * P * a.t_pitch;
+	const int64_t tb = target_base(a, target, P);
+	const int origin = stack_origin(a, target);
 	const float* img = a.images + tb;
 	const float* err = a.images_err + tb;
 	const float* bkg = (a.bkg_mode == 0) ? (a.backgrounds + tb) : (a.backgrounds + (int64_t)target * a.bkg_series_pitch);
@@ -158,7 +159,9 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 #pragma unroll
 						for (int j = 0; j < 8; j++) {
 							const int p = s_list[i + j];
-							const int64_t off = (int64_t)p * a.t_pitch + k0;
+							const int pr = p / a.width;
+							const int pc = p - pr * a.width;
+							const int64_t off = (int64_t)pixel_row(a, origin, p, pr, pc) * a.t_pitch + k0;
 							float v[VEC], ee[VEC], bb[VEC];
 							Vec<VEC>::load(img + off, v);
 							if (a.subtract) {
@@ -171,8 +174,6 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 #pragma unroll
 								for (int c = 0; c < VEC; c++) bb[c] = (a.bkg_mode == 1) ? bser[c] : 0.f;
 							}
-							const int pr = p / a.width;
-							const int pc = p - pr * a.width;
 							st.side(v, (double)(col0 + pc), (double)(row0 + pr));
 							float y[VEC];
 							st.bkg_terms(bb, y);
@@ -192,7 +193,9 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 					} else {
 						// tail element of the (last) leaf
 						const int p = s_list[i];
-						const int64_t off = (int64_t)p * a.t_pitch + k0;
+						const int pr = p / a.width;
+						const int pc = p - pr * a.width;
+						const int64_t off = (int64_t)pixel_row(a, origin, p, pr, pc) * a.t_pitch + k0;
 						float v[VEC], ee[VEC], bb[VEC];
 						Vec<VEC>::load(img + off, v);
 						if (a.subtract) {
@@ -205,8 +208,6 @@ __global__ __launch_bounds__(512) void tp_aperture_big_kernel(Args a)
 #pragma unroll
 							for (int c = 0; c < VEC; c++) bb[c] = (a.bkg_mode == 1) ? bser[c] : 0.f;
 						}
-						const int pr = p / a.width;
-						const int pc = p - pr * a.width;
 						st.side(v, (double)(col0 + pc), (double)(row0 + pr));
 						float y[VEC];
 						st.bkg_terms(bb, y);
@@ -271,6 +272,27 @@ int tp_aperture_extract_big(tp_ctx* ctx, const tp_ap::Args& a, bool vec4)
 	return TP_OK;
 }
 
+// the two extraction launches (masks up to 128 pixels; the others) for a filled argument block
+static int launch_extract(tp_ctx* ctx, const Args& a, bool vec4)
+{
+	// Small masks (the common case): 2 cadences per thread (64-bit loads, 512 B per wavefront instruction) keep the
+	// kernel near 100 VGPRs so that several 256-thread workgroups share a CU and overlap their mask-list prologue,
+	// loads and stores; 4 cadences per thread needed 256 VGPRs -> one workgroup per CU.
+	{
+		const int vec = vec4 ? 2 : 1;
+		const int nq = (a.n_cad + vec - 1) / vec;
+		const int threads = 256;
+		const unsigned gy = (unsigned)((a.n_targets < 65535) ? a.n_targets : 65535);
+		const unsigned gz = (unsigned)((a.n_targets + 65534) / 65535);
+		dim3 grid((unsigned)((nq + threads - 1) / threads), gy, gz), block((unsigned)threads);
+		if (vec4) TP_LAUNCH(ctx, TPK_APERTURE, tp_aperture_kernel<2>, grid, block, 0, a);
+		else TP_LAUNCH(ctx, TPK_APERTURE, tp_aperture_kernel<1>, grid, block, 0, a);
+		TP_LAUNCH_CHECK(ctx, "tp_aperture_kernel");
+	}
+	// Masks above 128 pixels (rare): the recursive pairwise tree, one workgroup per target
+	return tp_aperture_extract_big(ctx, a, vec4);
+}
+
 extern "C" int tp_aperture_extract(tp_ctx* ctx, const tp_cube_desc* desc,
 	const float* d_images, const float* d_images_err, const float* d_backgrounds,
 	int32_t bkg_mode, int64_t bkg_series_pitch, const float* d_subtract, int64_t subtract_pitch,
@@ -306,21 +328,43 @@ extern "C" int tp_aperture_extract(tp_ctx* ctx, const tp_cube_desc* desc,
 	else if (bkg_mode == 1) vec4 = vec4 && tp_vec4_ok(d_backgrounds, bkg_series_pitch);
 	TP_REQUIRE(ctx, d_subtract == nullptr || subtract_pitch >= desc->n_cad, "tp_aperture_extract: bad subtract pitch");
 	if (d_subtract) vec4 = vec4 && tp_vec4_ok(d_subtract, subtract_pitch);
-	// Small masks (the common case): 2 cadences per thread (64-bit loads, 512 B per wavefront instruction) keep the
-	// kernel near 100 VGPRs so that several 256-thread workgroups share a CU and overlap their mask-list prologue,
-	// loads and stores; 4 cadences per thread needed 256 VGPRs -> one workgroup per CU.
-	{
-		const int vec = vec4 ? 2 : 1;
-		const int nq = (desc->n_cad + vec - 1) / vec;
-		const int threads = 256;
-		const unsigned gy = (unsigned)((desc->n_targets < 65535) ? desc->n_targets : 65535);
-		const unsigned gz = (unsigned)((desc->n_targets + 65534) / 65535);
-		dim3 grid((unsigned)((nq + threads - 1) / threads), gy, gz), block((unsigned)threads);
-		if (vec4) TP_LAUNCH(ctx, TPK_APERTURE, tp_aperture_kernel<2>, grid, block, 0, a);
-		else TP_LAUNCH(ctx, TPK_APERTURE, tp_aperture_kernel<1>, grid, block, 0, a);
-		TP_LAUNCH_CHECK(ctx, "tp_aperture_kernel");
-	}
-	// Masks above 128 pixels (rare): the recursive pairwise tree, one workgroup per target
-	return tp_aperture_extract_big(ctx, a, vec4);
+	return launch_extract(ctx, a, vec4);
+	TP_API_END(ctx)
+}
+
+// The same extraction with the pixels' time series taken from the TIME-MAJOR stacks of a CCD region (tp_frames_transpose) instead of
+// per-target cubes: what BasePhotometry._load_cube + do_photometry's loop read (BasePhotometry.py:720-751, photometry.py:172-201),
+// without a cut -- the series of a mask pixel is one contiguous row of the stack.  Same kernels, same order of operations: the
+// results equal tp_aperture_extract's on the cut cubes bit for bit (tests/test_gpu_resize.py).
+extern "C" int tp_aperture_extract_stack(tp_ctx* ctx, int32_t n_targets, int32_t n_cad, int32_t height, int32_t width,
+	const float* d_images_t, const float* d_images_err_t, const float* d_backgrounds_t, int64_t t_pitch,
+	int32_t stack_rows, int32_t stack_cols, int32_t stack_row0, int32_t stack_col0,
+	const uint8_t* d_mask, const int32_t* d_stamps, const int32_t* d_status,
+	double* d_flux, double* d_flux_err, double* d_flux_background,
+	double* d_centroid_col, double* d_centroid_row, int64_t out_pitch)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, n_targets >= 0 && n_cad >= 0 && height > 0 && width > 0 && t_pitch >= n_cad, "tp_aperture_extract_stack: bad sizes");
+	TP_REQUIRE(ctx, stack_rows > 0 && stack_cols > 0 && (int64_t)stack_rows * stack_cols < ((int64_t)1 << 31), "tp_aperture_extract_stack: bad stack shape");
+	TP_REQUIRE(ctx, d_images_t && d_images_err_t && d_mask && d_stamps, "tp_aperture_extract_stack: null input pointer");
+	TP_REQUIRE(ctx, d_flux && d_flux_err && d_centroid_col && d_centroid_row, "tp_aperture_extract_stack: null output pointer");
+	TP_REQUIRE(ctx, d_flux_background || !d_backgrounds_t, "tp_aperture_extract_stack: backgrounds given but no flux_background output");
+	TP_REQUIRE(ctx, out_pitch >= n_cad, "tp_aperture_extract_stack: out_pitch < n_cad");
+	TP_REQUIRE(ctx, (int64_t)height * width <= (int64_t)kMaxLeaves * 64, "tp_aperture_extract_stack: stamp too large");
+	if (n_targets == 0 || n_cad == 0) return TP_OK;
+	Args a;
+	a.images = d_images_t; a.images_err = d_images_err_t; a.backgrounds = d_backgrounds_t;
+	a.bkg_mode = d_backgrounds_t ? 0 : 2; a.bkg_series_pitch = 0;
+	a.subtract = nullptr; a.subtract_pitch = 0;
+	a.mask = d_mask; a.stamps = d_stamps; a.status = d_status;
+	a.flux = d_flux; a.flux_err = d_flux_err; a.flux_bkg = d_flux_background;
+	a.ccol = d_centroid_col; a.crow = d_centroid_row;
+	a.out_pitch = out_pitch; a.n_cad = n_cad; a.height = height; a.width = width;
+	a.t_pitch = t_pitch; a.n_targets = n_targets; a.big_list = nullptr;
+	a.stack_cols = stack_cols; a.stack_row0 = stack_row0; a.stack_col0 = stack_col0;
+	bool vec4 = tp_vec4_ok(d_images_t, t_pitch) && tp_vec4_ok(d_images_err_t, t_pitch);
+	if (d_backgrounds_t) vec4 = vec4 && tp_vec4_ok(d_backgrounds_t, t_pitch);
+	return launch_extract(ctx, a, vec4);
 	TP_API_END(ctx)
 }

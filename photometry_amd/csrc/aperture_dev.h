@@ -84,7 +84,19 @@ struct Args {
 	int64_t out_pitch; int n_cad; int height; int width; int64_t t_pitch; int n_targets;
 	// optional work list of the big-mask kernel: big_list[0] = count, big_list[1..] = targets (filled by the fused kernel)
 	int32_t* big_list;
+	// STACK mode (stack_cols > 0; tp_aperture_extract_stack): images / images_err / backgrounds are not per-target cubes but the
+	// TIME-MAJOR stacks of a CCD region, [stack rows x stack_cols][t_pitch] (tp_frames_transpose): pixel (r, c) of a target's stamp
+	// is the stack's row (stamps[4 t] - stack_row0 + r) * stack_cols + stamps[4 t + 2] - stack_col0 + c.  Nothing is cut.
+	int32_t stack_cols = 0, stack_row0 = 0, stack_col0 = 0;
 };
+
+// where the time series of the pixels of `target` start (cube mode: its cube; stack mode: the stack) and which row of it holds
+// stamp pixel p = pr * width + pc
+__device__ __forceinline__ int64_t target_base(const Args& a, int target, int P) { return a.stack_cols ? 0 : (int64_t)target * P * a.t_pitch; }
+__device__ __forceinline__ int stack_origin(const Args& a, int target) {
+	return a.stack_cols ? ((a.stamps[target * 4 + 0] - a.stack_row0) * a.stack_cols + (a.stamps[target * 4 + 2] - a.stack_col0)) : 0;
+}
+__device__ __forceinline__ int pixel_row(const Args& a, int origin, int p, int pr, int pc) { return a.stack_cols ? (origin + pr * a.stack_cols + pc) : p; }
 
 template <int VEC>
 __device__ __forceinline__ void store_outputs(const Args& a, int target, int k0, const CadState<VEC>& st, int M) {
@@ -154,7 +166,8 @@ __device__ __forceinline__ void extract_small(const Args& a, int target, const i
 	const int P = a.height * a.width;
 	const int col0 = a.stamps[target * 4 + 2] + 1; // 1-based CCD column of stamp column 0
 	const int row0 = a.stamps[target * 4 + 0] + 1;
-	const int64_t tb = (int64_t)target * P * a.t_pitch;
+	const int64_t tb = target_base(a, target, P);
+	const int origin = stack_origin(a, target);
 	const float* img = a.images + tb;
 	const float* err = a.images_err + tb;
 	const float* bkg = (a.bkg_mode == 0) ? (a.backgrounds + tb) : (a.backgrounds + (int64_t)target * a.bkg_series_pitch);
@@ -173,7 +186,9 @@ __device__ __forceinline__ void extract_small(const Args& a, int target, const i
 		auto fetch = [&](int idx, float (&v)[VEC], float (&e2)[VEC], float (&y)[VEC]) {
 			const int pk = s_list[idx];
 			const int p = pk & 0xffff;
-			const int64_t off = (int64_t)p * a.t_pitch + k0;
+			const int pr = (int)((unsigned)pk >> 16);
+			const int pc = p - pr * a.width;
+			const int64_t off = (int64_t)pixel_row(a, origin, p, pr, pc) * a.t_pitch + k0;
 			float ee[VEC], bb[VEC];
 			Vec<VEC>::load(img + off, v);
 			if (a.subtract) {
@@ -186,8 +201,6 @@ __device__ __forceinline__ void extract_small(const Args& a, int target, const i
 #pragma unroll
 				for (int c = 0; c < VEC; c++) bb[c] = (a.bkg_mode == 1) ? bser[c] : 0.f;
 			}
-			const int pr = (int)((unsigned)pk >> 16);
-			const int pc = p - pr * a.width;
 #pragma unroll
 			for (int c = 0; c < VEC; c++) e2[c] = ee[c] * ee[c];
 			st.side(v, (double)(col0 + pc), (double)(row0 + pr));

@@ -41,6 +41,7 @@ static const char* const kKernelNames[TPK_COUNT] = {
 	"tp_bkg_stamp_sum_kernel",
 	"tp_star_positions_kernel",
 	"tp_f64_to_f32_kernel",
+	"tp_blit_kernel",
 };
 
 extern "C" {

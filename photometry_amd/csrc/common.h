@@ -39,6 +39,7 @@ enum tp_kernel_id {
 	TPK_BKG_STAMP_SUM,
 	TPK_STAR_POSITIONS,
 	TPK_BLOCK_COMPACT,
+	TPK_BLIT,
 	TPK_COUNT
 };
 
@@ -167,6 +168,11 @@ static inline bool tp_desc_ok(const tp_cube_desc* d) {
 static inline bool tp_vec4_ok(const void* p, int64_t pitch) {
 	return ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) && (pitch % 4 == 0);
 }
+
+// internal (sumimage.hip): nbytes from src to dst by a kernel on the context's stream -- either side may be page-locked host memory.
+// The frames engine moves a group's metadata and the data of its decisions this way: an asynchronous copy goes through a DMA engine
+// that streams share, and a small copy queued behind a large one that is still waiting for its kernels waits with it.
+int tp_blit(tp_ctx* ctx, void* dst, const void* src, uint64_t nbytes);
 
 #define TP_API_BEGIN try {
 #define TP_API_END(ctx) } catch (const std::exception& ex) { if (ctx) { (ctx)->err = ex.what(); } else { tp_global_err = ex.what(); } return TP_ERR_INVALID; } catch (...) { if (ctx) { (ctx)->err = "unknown C++ exception"; } return TP_ERR_INVALID; }

@@ -476,6 +476,45 @@ extern "C" int tp_cut_stamps_multi(tp_ctx* ctx, int32_t n_stacks, const float* c
 	TP_API_END(ctx)
 }
 
+// ---- the time-major copy of a frame stack ----------------------------------------------------------------------------------
+// [n_frames][n_pixels] -> [n_pixels][t_pitch] (the cadences past n_frames zero): tiles of 64 pixels x 64 frames through LDS, 256-byte
+// runs on both sides.  One pass per stack and region; every batch of targets on the region then reads a mask pixel's time series
+// as one contiguous row (tp_aperture_extract_stack) where it used to be cut out of 1 300 frames per call.
+__global__ __launch_bounds__(256) void tp_frames_transpose_kernel(const float* __restrict__ src, int n_frames, int64_t n_pixels, int64_t frame_stride,
+	float* __restrict__ dst, int64_t t_pitch)
+{
+	__shared__ float tile[64][65];
+	const int64_t p0 = (int64_t)blockIdx.x * 64;
+	const int f0 = blockIdx.y * 64;
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (int j = w; j < 64; j += 4) {
+		const int f = f0 + j;
+		const int64_t p = p0 + lane;
+		tile[j][lane] = (f < n_frames && p < n_pixels) ? src[(int64_t)f * frame_stride + p] : 0.f;
+	}
+	__syncthreads();
+	for (int j = w; j < 64; j += 4) {
+		const int64_t p = p0 + j;
+		const int f = f0 + lane;
+		if (p < n_pixels && f < t_pitch) dst[p * t_pitch + f] = tile[lane][j];
+	}
+}
+
+extern "C" int tp_frames_transpose(tp_ctx* ctx, const float* d_frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride, float* d_out, int64_t t_pitch)
+{
+	TP_CHECK_CTX(ctx);
+	TP_API_BEGIN
+	TP_REQUIRE(ctx, d_frames && d_out, "tp_frames_transpose: null pointer");
+	TP_REQUIRE(ctx, n_frames >= 0 && n_pixels >= 0 && frame_stride >= n_pixels && t_pitch >= n_frames, "tp_frames_transpose: bad sizes");
+	if (n_pixels == 0 || t_pitch == 0) return TP_OK;
+	const int64_t gx = (n_pixels + 63) / 64, gy = (t_pitch + 63) / 64;
+	TP_REQUIRE(ctx, gx < ((int64_t)1 << 31) && gy <= 65535, "tp_frames_transpose: stack too large for one launch");
+	TP_LAUNCH(ctx, TPK_CUTOUT, tp_frames_transpose_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, d_frames, (int)n_frames, n_pixels, frame_stride, d_out, t_pitch);
+	TP_LAUNCH_CHECK(ctx, "tp_frames_transpose_kernel");
+	return TP_OK;
+	TP_API_END(ctx)
+}
+
 extern "C" int tp_crop_sumimage(tp_ctx* ctx, const double* d_full, int32_t frame_rows, int32_t frame_cols, int64_t row_pitch,
 	int32_t row_offset, int32_t col_offset, const int32_t* d_stamps, int32_t n_targets, int32_t height, int32_t width, double* d_out)
 {

@@ -109,7 +109,16 @@ struct tp_frames_catalog {
 struct tp_frames_engine {
 	int device = 0;
 	int n_slots = 0;
-	std::vector<tp_ctx*> ctxs;          // kStreams per slot
+	std::vector<tp_ctx*> ctxs;          // kStreams per slot: the first is the slot's own (its job's throughput stream), the others
+	                                    // are the engine's pool of small streams, shared by the jobs in flight (SmallStream below)
+	// A small stream of the pool.  A job's worker CLAIMS one per small group of a round while it queues the round (nobody else queues
+	// on a claimed stream: a context's host-side state has one user at a time), marks it with an event when it lets go, and the next
+	// claimant -- of any job -- prefers a stream whose event has completed (idle), in index order (so that the same few contexts are
+	// used and their allocation caches stay warm), else the one with the least work queued since it was last seen idle.
+	struct SmallStream { tp_ctx* c = nullptr; hipEvent_t busy = nullptr; double load = 0.0; bool claimed = false; };
+	std::vector<SmallStream> small;
+	std::mutex sm;
+	std::vector<hipStream_t> copy_streams;   // one per slot (nullptr if it could not be created: the light curves then leave on the job's stream)
 	std::vector<char> busy;
 	std::mutex m;
 	PinnedPool pinned;
@@ -133,11 +142,19 @@ struct Group {
 // a group of one round while its pass is in flight
 struct Launched {
 	tp_ctx* g = nullptr;
+	int small = -1;                       // index of the claimed stream of the engine's pool (-1: the job's own stream)
 	std::vector<int32_t> idx;
 	Group grp;
-	hipEvent_t ev = nullptr;
+	hipEvent_t ev = nullptr;              // the decisions' data have arrived
 	bool failed = false;
 	std::string error;
+	// what the first half of the pass (metadata, masks, the decisions' download) leaves for the second (cut, extraction, diagnostics)
+	std::vector<void*> dev;               // device blocks of this group: freed (stream-ordered) once everything is queued
+	tp_cube_desc desc{};
+	float* cubes[3] = {nullptr, nullptr, nullptr};
+	char* blk = nullptr;
+	const int32_t* d_stamps = nullptr; const int32_t* d_quality = nullptr; const double* d_time = nullptr;
+	bool crop = false, large = false, time_major = false;
 };
 
 } // namespace
@@ -145,7 +162,9 @@ struct Launched {
 struct tp_frames_job {
 	tp_frames_engine* eng = nullptr;
 	int slot = -1;
-	tp_ctx* streams[kStreams] = {};
+	tp_ctx* own = nullptr;                    // the slot's stream: the large group of the first round
+	hipStream_t copy_stream = nullptr;        // the slot's copy stream: the light curves of that group, chunk by chunk
+	std::vector<hipEvent_t> tails;            // one per group: everything the group queued (its light curves last) has run
 	tp_frames_stack stack{};
 	const tp_frames_catalog* cat = nullptr;
 	int32_t n = 0, T = 0;
@@ -170,6 +189,13 @@ struct tp_frames_job {
 	double lab_us[5] = {0, 0, 0, 0, 0};
 	int lab_groups = 0, lab_rounds = 0;
 	std::map<std::string, double> lab_steps;   // the queueing of a group, step by step
+	std::string lab_timeline;                  // when the rounds were queued and decided, microseconds from the start of run()
+	std::chrono::steady_clock::time_point lab_run0;
+	void lab_mark(const char* what, int a, int b) {
+		char buf[96];
+		std::snprintf(buf, sizeof buf, " %s%d/%d@%.0f", what, a, b, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - lab_run0).count());
+		lab_timeline += buf;
+	}
 	int rc = TP_OK;
 	std::string err;
 	bool joined = false, released = false;
@@ -192,7 +218,11 @@ struct tp_frames_job {
 	void run();
 	void select_catalog(const std::vector<int32_t>& idx, Group& g, std::vector<float>& c_tmag, std::vector<float>& c_row, std::vector<float>& c_col,
 		std::vector<float>& c_row_stamp, std::vector<float>& c_col_stamp) const;
-	void launch(Launched& L, int gi, std::vector<hipEvent_t>& event_pool);
+	void launch_masks(Launched& L, std::vector<hipEvent_t>& event_pool);
+	void launch_tail(Launched& L, std::vector<hipEvent_t>& event_pool);
+	void fail_group(Launched& L, const char* what, std::vector<hipEvent_t>& event_pool);
+	void claim(Launched& L, double work, const std::vector<Launched>& round);
+	void drain_all();
 	void decide(Launched& L, std::vector<int32_t>& still);
 };
 
@@ -248,16 +278,32 @@ struct MetaField { const void* src; size_t nbytes; size_t off; };
 
 } // namespace
 
-// queue everything a group of same-sized stamps needs on stream g: metadata upload, the three cuts, the pass, the diagnostics and
-// the two downloads of the packed block (the light curves last); an event sits between the downloads
-void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_pool)
+// The pass of a group of same-sized stamps on stream L.g, queued in two halves.  launch_masks: metadata upload, the sum images, the
+// masks, the download of what the round's decisions read, an event behind it.  launch_tail: the cut of the in-mask rows, the
+// extraction, the diagnostics and the download of the light curves, an event behind everything.  The worker queues the first
+// halves of ALL groups of a round before any second half: a round is decided from the masks alone, and a mask kernel queued behind
+// another group's cut and extraction waited for them (round 6, timeline of a 2 500-target batch: the fourth and fifth group of the
+// second round delivered their decisions 2 and 3 ms after the first three).
+void tp_frames_job::fail_group(Launched& L, const char* what, std::vector<hipEvent_t>& event_pool)
+{
+	L.failed = true;
+	L.error = what;
+	if (L.g == own && copy_stream) (void)hipStreamSynchronize(copy_stream);
+	(void)hipStreamSynchronize(L.g->stream);
+	(void)hipGetLastError();
+	for (void* p : L.dev) (void)tp_free(L.g, p);
+	L.dev.clear();
+	if (L.grp.h_block) { eng->pinned.put(L.grp.h_block, L.grp.h_cap); L.grp.h_block = nullptr; }
+	if (L.ev) { event_pool.push_back(L.ev); L.ev = nullptr; }
+}
+
+void tp_frames_job::launch_masks(Launched& L, std::vector<hipEvent_t>& event_pool)
 {
 	tp_ctx* g = L.g;
 	Group& G = L.grp;
 	const int32_t m = (int32_t)L.idx.size(), H = G.H, W = G.W;
-	std::vector<void*> dev;                      // device blocks of this group: freed (stream-ordered) once everything is queued
 	void* h_meta = nullptr; size_t h_meta_cap = 0;
-	auto dalloc = [&](size_t nbytes) { void* p = nullptr; ck(g, tp_malloc(g, nbytes, &p)); dev.push_back(p); return p; };
+	auto dalloc = [&](size_t nbytes) { void* p = nullptr; ck(g, tp_malloc(g, nbytes, &p)); L.dev.push_back(p); return p; };
 	const auto lab_t0 = std::chrono::steady_clock::now();
 	auto lab_t1 = lab_t0;
 	try {
@@ -295,7 +341,10 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 		// (measured, TESSPHOT_FRAMES_TIMING: in the first runs of a process this call can return after 8 - 20 ms while other jobs have
 		// work queued; in the steady state it takes 30 us.  A kernel that reads the page-locked block through its device mapping never
 		// waits, but its system-scope accesses slowed every concurrent kernel: 3.0 x 10^5 targets/s pipelined instead of 5 x 10^5)
-		ckh(hipMemcpyAsync(d_meta, h_meta, total, hipMemcpyHostToDevice, g->stream), "hipMemcpyAsync(metadata)");
+		// by a kernel, not by a DMA engine: the streams of a process share the engines, and this upload -- the head of the chain that
+		// decides the round -- sat behind the first round's 130 MB of light curves on some streams until THEY had been extracted and
+		// copied (round 6, copy trace: the metadata of two of five groups arrived 4 ms late)
+		ck(g, tp_blit(g, d_meta, h_meta, total));
 		lap("alloc+h2d");
 		const int32_t* d_quality = reinterpret_cast<const int32_t*>(d_meta + f[0].off);
 		const double* d_time = reinterpret_cast<const double*>(d_meta + f[1].off);
@@ -311,17 +360,20 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 		const double* d_t_col = reinterpret_cast<const double*>(d_meta + f[11].off);
 		const double* d_t_tmag = reinterpret_cast<const double*>(d_meta + f[12].off);
 		const int64_t* d_t_starid = reinterpret_cast<const int64_t*>(d_meta + f[13].off);
+		L.d_stamps = d_stamps; L.d_quality = d_quality; L.d_time = d_time;
 		// ---- the three stamp cubes (BasePhotometry._load_cube for the whole group; the cutter writes the padding of the time axis)
-		tp_cube_desc desc;
+		tp_cube_desc& desc = L.desc;
 		desc.n_targets = m; desc.n_cad = T; desc.height = H; desc.width = W; desc.t_pitch = round_up(T, 32);
 		const size_t cube_bytes = (size_t)m * H * W * (size_t)desc.t_pitch * 4;
 		const float* frames[3] = {stack.d_images, stack.d_images_err, stack.d_backgrounds};
-		float* cubes[3];
-		for (int k = 0; k < 3; ++k) cubes[k] = static_cast<float*>(dalloc(cube_bytes));
-		lap("alloc cubes");
-		const bool large = m >= kFusedFrom;
+		float** cubes = L.cubes;
 		// the region's sum image is at hand (the FFI branch of BasePhotometry.sumimage): no cube is needed before the masks are known
-		const bool crop = stack.d_sumimage != nullptr;
+		const bool crop = L.crop = stack.d_sumimage != nullptr;
+		// ... and with the time-major stacks no cube is needed at all (launch_tail)
+		L.time_major = crop && stack.d_images_t != nullptr;
+		if (!L.time_major) for (int k = 0; k < 3; ++k) cubes[k] = static_cast<float*>(dalloc(cube_bytes));
+		lap("alloc cubes");
+		const bool large = L.large = m >= kFusedFrom;
 		// a small group: one binning of the stamps and one launch for the three stacks.  A large group: the images now, the error and
 		// background stacks once the masks are known -- only their in-mask pixel rows are ever read (below)
 		if (!crop)
@@ -340,29 +392,23 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 		G.off_sum = field((uint64_t)m * P * 8);
 		G.off_diag = field((uint64_t)m * 10 * 8);
 		G.nbytes = off;
-		char* blk = static_cast<char*>(dalloc((size_t)G.nbytes));
+		char* blk = L.blk = static_cast<char*>(dalloc((size_t)G.nbytes));
 		ckh(hipMemsetAsync(blk, 0, (size_t)G.nbytes, g->stream), "hipMemsetAsync(block)");
-		double* lc[5];
-		for (int k = 0; k < 5; ++k) lc[k] = reinterpret_cast<double*>(blk + G.off_lc) + (size_t)k * m * T;
 		double* d_cont = reinterpret_cast<double*>(blk + G.off_cont);
 		int32_t* d_status = reinterpret_cast<int32_t*>(blk + G.off_status);
 		int32_t* d_flags = reinterpret_cast<int32_t*>(blk + G.off_flags);
 		uint8_t* d_mask = reinterpret_cast<uint8_t*>(blk + G.off_mask);
 		uint8_t* d_cim = reinterpret_cast<uint8_t*>(blk + G.off_cim);
 		double* d_sum = reinterpret_cast<double*>(blk + G.off_sum);
-		double* d_diagn = reinterpret_cast<double*>(blk + G.off_diag);
 		// scratch: the mask builder's diagnostics and the aperture image (bit 1 = collected: every pixel, BasePhotometry.py:1043)
 		double* d_diag8 = static_cast<double*>(dalloc((size_t)m * 8 * 8));
 		ckh(hipMemsetAsync(d_diag8, 0, (size_t)m * 64, g->stream), "hipMemsetAsync(diag)");
 		int32_t* d_aperture = static_cast<int32_t*>(dalloc((size_t)m * P * 4));
 		ckh(hipMemsetAsync(d_aperture, 1, (size_t)m * P * 4, g->stream), "hipMemsetAsync(aperture)");
 		lap("alloc+memsets");
-		// ---- the pass.  The three stand-alone kernels (bit-identical to the fused launch; a small group is latency-bound and spreads
-		// better over the chip this way).  For a large group the cut of the error and background stacks comes BETWEEN mask and extraction
-		// and writes in-mask rows only: of 8.9 GB of cubes per 2 500 stamps of 15 x 15 the passes read 4.4 (the images for the sum image,
-		// a sixth of the rows of all three for the extraction), so two thirds of the old cut's writes were never read
-		// With the region's sum image: crop, masks, and then ONE cut of the in-mask rows of all three stacks (a sixth of a 15 x 15 stamp:
-		// 5.5 GB of traffic per 2 500 stamps instead of 10.8, and the decisions leave after the mask kernel alone).
+		// ---- the masks.  The three stand-alone kernels (bit-identical to the fused launch; a small group is latency-bound and spreads
+		// better over the chip this way).  With the region's sum image: crop, masks, and then (second half) ONE cut of the in-mask rows of
+		// all three stacks (a sixth of a 15 x 15 stamp: 5.5 GB of traffic per 2 500 stamps instead of 10.8).
 		if (crop) ck(g, tp_crop_sumimage(g, stack.d_sumimage, stack.n_rows, stack.n_cols, stack.n_cols, stack.row0, stack.col0, d_stamps, m, H, W, d_sum));
 		else ck(g, tp_sumimage(g, &desc, cubes[0], d_quality, 0, kBitmask, nullptr, 0, d_sum));
 		lap("crop");
@@ -375,41 +421,114 @@ void tp_frames_job::launch(Launched& L, int gi, std::vector<hipEvent_t>& event_p
 		G.h_block = eng->pinned.get((size_t)G.nbytes, &G.h_cap);
 		lap("pinned");
 		const uint64_t lc_bytes = G.off_cont;
-		ckh(hipMemcpyAsync(static_cast<char*>(G.h_block) + lc_bytes, blk + lc_bytes, (size_t)(G.off_diag - lc_bytes), hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(results)");
+		ck(g, tp_blit(g, static_cast<char*>(G.h_block) + lc_bytes, blk + lc_bytes, G.off_diag - lc_bytes));   // (by a kernel: see the metadata)
 		if (event_pool.empty()) { hipEvent_t e = nullptr; ckh(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); event_pool.push_back(e); }
 		L.ev = event_pool.back(); event_pool.pop_back();
 		ckh(hipEventRecord(L.ev, g->stream), "hipEventRecord");
 		lap("d2h+event");
-		if (crop)
-			ck(g, tp_cut_stamps_masked(g, 3, frames, stack.n_frames, stack.n_rows, stack.n_cols, stack.n_cols, (int64_t)stack.n_rows * stack.n_cols,
-				stack.row0, stack.col0, d_stamps, &desc, d_mask, cubes));
-		else if (large)
-			ck(g, tp_cut_stamps_masked(g, 2, frames + 1, stack.n_frames, stack.n_rows, stack.n_cols, stack.n_cols, (int64_t)stack.n_rows * stack.n_cols,
-				stack.row0, stack.col0, d_stamps, &desc, d_mask, cubes + 1));
-		lap("masked cut");
-		ck(g, tp_aperture_extract(g, &desc, cubes[0], cubes[1], cubes[2], 0, 0, nullptr, 0, d_mask, d_stamps, d_status,
-			lc[0], lc[1], lc[2], lc[3], lc[4], T));
-		lap("extract");
-		ck(g, tp_lightcurve_diagnostics(g, m, T, lc[0], lc[1], lc[3], lc[4], T, d_time, d_quality, 0, kBitmask, d_status, d_sum, d_mask, H, W,
-			3600.0 / 86400.0, d_diagn));
-		lap("diagnostics");
-		ckh(hipMemcpyAsync(static_cast<char*>(G.h_block) + G.off_diag, blk + G.off_diag, (size_t)(G.nbytes - G.off_diag), hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(diagnostics)");
-		ckh(hipMemcpyAsync(G.h_block, blk, (size_t)lc_bytes, hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(light curves)");
-		lap("d2h light curves");
-		for (void* p : dev) (void)tp_free(g, p);      // stream-ordered: handed out again only after what is queued above has run
-		(void)gi;
 		const auto lab_t2 = std::chrono::steady_clock::now();
 		lab_us[0] += std::chrono::duration<double, std::micro>(lab_t1 - lab_t0).count();
 		lab_us[1] += std::chrono::duration<double, std::micro>(lab_t2 - lab_t1).count();
 		lab_groups += 1;
 	} catch (const std::exception& e) {
-		L.failed = true;
-		L.error = e.what();
-		(void)hipStreamSynchronize(g->stream);
-		(void)hipGetLastError();
-		for (void* p : dev) (void)tp_free(g, p);
-		if (G.h_block) { eng->pinned.put(G.h_block, G.h_cap); G.h_block = nullptr; }
-		if (L.ev) { event_pool.push_back(L.ev); L.ev = nullptr; }
+		const std::string what = e.what();
+		fail_group(L, what.c_str(), event_pool);
+	}
+}
+
+void tp_frames_job::launch_tail(Launched& L, std::vector<hipEvent_t>& event_pool)
+{
+	if (L.failed) return;
+	tp_ctx* g = L.g;
+	Group& G = L.grp;
+	const int32_t m = G.n, H = G.H, W = G.W;
+	const auto lab_t1 = std::chrono::steady_clock::now();
+	try {
+		auto lab_prev = lab_t1;
+		auto lap = [&](const char* what) { const auto now = std::chrono::steady_clock::now(); lab_steps[what] += std::chrono::duration<double, std::micro>(now - lab_prev).count(); lab_prev = now; };
+		const tp_cube_desc& desc = L.desc;
+		float** cubes = L.cubes;
+		char* blk = L.blk;
+		const float* frames[3] = {stack.d_images, stack.d_images_err, stack.d_backgrounds};
+		double* lc[5];
+		for (int k = 0; k < 5; ++k) lc[k] = reinterpret_cast<double*>(blk + G.off_lc) + (size_t)k * m * T;
+		int32_t* d_status = reinterpret_cast<int32_t*>(blk + G.off_status);
+		uint8_t* d_mask = reinterpret_cast<uint8_t*>(blk + G.off_mask);
+		double* d_sum = reinterpret_cast<double*>(blk + G.off_sum);
+		double* d_diagn = reinterpret_cast<double*>(blk + G.off_diag);
+		const uint64_t lc_bytes = G.off_cont;
+		// For a large group the cut of the error and background stacks comes BETWEEN mask and extraction and writes in-mask rows only:
+		// of 8.9 GB of cubes per 2 500 stamps of 15 x 15 the passes read 4.4 (the images for the sum image, a sixth of the rows of all
+		// three for the extraction), so two thirds of the old cut's writes were never read
+		if (L.time_major) {}     // nothing to cut: the extraction reads the rows of the time-major stacks
+		else if (L.crop)
+			ck(g, tp_cut_stamps_masked(g, 3, frames, stack.n_frames, stack.n_rows, stack.n_cols, stack.n_cols, (int64_t)stack.n_rows * stack.n_cols,
+				stack.row0, stack.col0, L.d_stamps, &desc, d_mask, cubes));
+		else if (L.large)
+			ck(g, tp_cut_stamps_masked(g, 2, frames + 1, stack.n_frames, stack.n_rows, stack.n_cols, stack.n_cols, (int64_t)stack.n_rows * stack.n_cols,
+				stack.row0, stack.col0, L.d_stamps, &desc, d_mask, cubes + 1));
+		lap("masked cut");
+		auto new_event = [&]() {
+			if (event_pool.empty()) { hipEvent_t e = nullptr; ckh(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); event_pool.push_back(e); }
+			hipEvent_t e = event_pool.back(); event_pool.pop_back();
+			tails.push_back(e);               // (destroyed with the tail events when the job ends)
+			return e;
+		};
+		// The light curves of a large group are most of what the call downloads (130 MB per 2 500 targets: 2.3 ms of the link), and they
+		// used to leave when extraction AND diagnostics of the whole group were done.  Now the group is extracted in chunks of targets,
+		// and a chunk's five planes leave on the job's copy stream as soon as the chunk is extracted: the link starts 0.15 ms after the
+		// cut instead of 1.2 ms, and the diagnostics run under the copies.
+		const int32_t n_chunks = (g == own && copy_stream && m >= 2048) ? std::min<int32_t>(8, m / 1024) : 1;
+		for (int32_t c = 0; c < n_chunks; ++c) {
+			const int32_t j0 = (int32_t)((int64_t)m * c / n_chunks), j1 = (int32_t)((int64_t)m * (c + 1) / n_chunks);
+			tp_cube_desc part = desc;
+			part.n_targets = j1 - j0;
+			const size_t cube_off = (size_t)j0 * H * W * (size_t)desc.t_pitch;
+			if (L.time_major)
+				ck(g, tp_aperture_extract_stack(g, j1 - j0, T, H, W, stack.d_images_t, stack.d_images_err_t, stack.d_backgrounds_t, stack.t_pitch,
+					stack.n_rows, stack.n_cols, stack.row0, stack.col0,
+					d_mask + (size_t)j0 * H * W, L.d_stamps + (size_t)j0 * 4, d_status + j0,
+					lc[0] + (size_t)j0 * T, lc[1] + (size_t)j0 * T, lc[2] + (size_t)j0 * T, lc[3] + (size_t)j0 * T, lc[4] + (size_t)j0 * T, T));
+			else
+			ck(g, tp_aperture_extract(g, &part, cubes[0] + cube_off, cubes[1] + cube_off, cubes[2] + cube_off, 0, 0, nullptr, 0,
+				d_mask + (size_t)j0 * H * W, L.d_stamps + (size_t)j0 * 4, d_status + j0,
+				lc[0] + (size_t)j0 * T, lc[1] + (size_t)j0 * T, lc[2] + (size_t)j0 * T, lc[3] + (size_t)j0 * T, lc[4] + (size_t)j0 * T, T));
+			if (n_chunks > 1) {
+				hipEvent_t e = new_event();
+				ckh(hipEventRecord(e, g->stream), "hipEventRecord");
+				ckh(hipStreamWaitEvent(copy_stream, e, 0), "hipStreamWaitEvent");
+				for (int k = 0; k < 5; ++k) {
+					const size_t o = (size_t)G.off_lc + ((size_t)k * m + (size_t)j0) * T * 8;
+					ckh(hipMemcpyAsync(static_cast<char*>(G.h_block) + o, blk + o, (size_t)(j1 - j0) * T * 8, hipMemcpyDeviceToHost, copy_stream), "hipMemcpyAsync(light curves)");
+				}
+			}
+		}
+		lap("extract");
+		ck(g, tp_lightcurve_diagnostics(g, m, T, lc[0], lc[1], lc[3], lc[4], T, L.d_time, L.d_quality, 0, kBitmask, d_status, d_sum, d_mask, H, W,
+			3600.0 / 86400.0, d_diagn));
+		lap("diagnostics");
+		ckh(hipMemcpyAsync(static_cast<char*>(G.h_block) + G.off_diag, blk + G.off_diag, (size_t)(G.nbytes - G.off_diag), hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(diagnostics)");
+		if (n_chunks > 1) {
+			hipEvent_t e = new_event();          // the group's stream goes on (its tail event, the reuse of its blocks) when the copies have left
+			ckh(hipEventRecord(e, copy_stream), "hipEventRecord");
+			ckh(hipStreamWaitEvent(g->stream, e, 0), "hipStreamWaitEvent");
+		} else {
+			ckh(hipMemcpyAsync(G.h_block, blk, (size_t)lc_bytes, hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(light curves)");
+		}
+		lap("d2h light curves");
+		// the group's last word: the job ends when the tail events of all its groups have completed (its streams are shared)
+		if (event_pool.empty()) { hipEvent_t e = nullptr; ckh(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); event_pool.push_back(e); }
+		hipEvent_t te = event_pool.back(); event_pool.pop_back();
+		tails.push_back(te);
+		ckh(hipEventRecord(te, g->stream), "hipEventRecord");
+		for (void* p : L.dev) (void)tp_free(g, p);      // stream-ordered: handed out again only after what is queued above has run
+		L.dev.clear();
+		lab_us[1] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - lab_t1).count();
+	} catch (const std::exception& e) {
+		// (the round's decisions are taken after both halves of all its groups have been queued: the group counts as failed, as if
+		// its first half had)
+		const std::string what = e.what();
+		fail_group(L, what.c_str(), event_pool);
 	}
 }
 
@@ -484,13 +603,53 @@ void tp_frames_job::decide(Launched& L, std::vector<int32_t>& still)
 	groups.push_back(std::move(G));
 }
 
+// a stream of the engine's pool for a small group: an idle one (its last claimant's event has completed) in index order, else the one
+// with the least work queued since it was last seen idle; claimed until the round is queued
+void tp_frames_job::claim(Launched& L, double work, const std::vector<Launched>& round)
+{
+	for (;;) {
+		{
+			std::lock_guard<std::mutex> lk(eng->sm);
+			int pick = -1;
+			for (size_t k = 0; k < eng->small.size(); ++k) {
+				auto& S = eng->small[k];
+				if (S.claimed) continue;
+				if (S.busy && S.load > 0.0 && hipEventQuery(S.busy) == hipSuccess) S.load = 0.0;   // drained
+				if (S.load == 0.0) { pick = (int)k; break; }
+				if (pick < 0 || S.load < eng->small[(size_t)pick].load) pick = (int)k;
+			}
+			(void)hipGetLastError();   // hipErrorNotReady of the queries
+			if (pick < 0)                // none unclaimed.  A round with more groups than the pool has streams: one this job holds already
+				for (const Launched& o : round)
+					if (o.small >= 0 && (pick < 0 || eng->small[(size_t)o.small].load < eng->small[(size_t)pick].load)) pick = o.small;
+			if (pick >= 0) {
+				auto& S = eng->small[(size_t)pick];
+				S.claimed = true;
+				S.load += work;
+				L.small = pick;
+				L.g = S.c;
+				return;
+			}
+		}
+		std::this_thread::yield();     // every stream of the pool is being queued on by the other jobs' workers: a matter of microseconds
+	}
+}
+
+// error paths: everything this job may have queued anywhere has run (its own stream and the whole pool)
+void tp_frames_job::drain_all()
+{
+	(void)hipStreamSynchronize(own->stream);
+	if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+	for (auto& S : eng->small) (void)hipStreamSynchronize(S.c->stream);
+	(void)hipGetLastError();
+}
+
 void tp_frames_job::run()
 {
 	(void)hipSetDevice(eng->device);
+	lab_run0 = std::chrono::steady_clock::now();
 	std::vector<hipEvent_t> event_pool;
-	hipEvent_t stream_busy[kStreams] = {};     // per small stream: recorded after the last group queued on it
-	double stream_load[kStreams] = {};         // ... and what has been queued on it since it was last seen idle (targets x pixels)
-	int next_small = 0;
+	bool first_round = true;
 	try {
 		status.assign(n, 0); stamp_resizes.assign(n, 0); group.assign(n, -1); pos.assign(n, 0); has_result.assign(n, 0);
 		stamp.assign((size_t)n * 4, -1);
@@ -514,7 +673,8 @@ void tp_frames_job::run()
 			double acc = 0.0;
 			for (auto& kv : by_size) {
 				const int32_t H = (int32_t)(kv.first / 100000), W = (int32_t)(kv.first % 100000);
-				const double per_target = 3.0 * H * W * (double)pitch * 4 + 5.0 * T * 8 + (double)H * W * 9 + 256;
+				const bool cubes_needed = !(stack.d_sumimage && stack.d_images_t);
+				const double per_target = (cubes_needed ? 3.0 * H * W * (double)pitch * 4 : 0.0) + 5.0 * T * 8 + (double)H * W * 13 + 256;
 				const int64_t nmax = std::max<int64_t>(1, (int64_t)std::floor(budget / per_target));
 				for (size_t a0 = 0; a0 < kv.second.size(); a0 += (size_t)nmax) {
 					Piece p;
@@ -528,40 +688,43 @@ void tp_frames_job::run()
 			std::vector<int32_t> still;
 			for (auto& part : parts) {
 				std::vector<Launched> launched(part.size());
+				// the claims on the pool's streams end when the round is queued -- or when anything on the way throws
+				struct Claims {
+					tp_frames_engine* e; std::vector<Launched>& ls; bool held = true;
+					void release() {
+						if (!held) return;
+						held = false;
+						std::lock_guard<std::mutex> lk(e->sm);
+						for (auto& L : ls) {
+							if (L.small < 0) continue;
+							auto& S = e->small[(size_t)L.small];
+							if (!S.busy) (void)hipEventCreateWithFlags(&S.busy, hipEventDisableTiming);
+							if (S.busy) (void)hipEventRecord(S.busy, S.c->stream);
+							S.claimed = false;
+						}
+					}
+					~Claims() { release(); }
+				} claims{eng, launched};
 				for (size_t gi = 0; gi < part.size(); ++gi) {
 					Launched& L = launched[gi];
 					L.idx = std::move(part[gi].idx);
 					L.grp.H = part[gi].H; L.grp.W = part[gi].W;
-					// a large group is a throughput pass: stream 0.  A small one (the resized stamps of a few targets) is a chain of
-					// latency-bound launches that decides when the job's next round can start: a stream of its own -- one that is IDLE.
-					// What a group queues after its mask kernel (the masked cut, the extraction, the diagnostics, the copies: 0.3 - 1 ms for
-					// a group of large stamps) is not waited for by the round's decisions, but it would be by a group of the NEXT round
-					// queued behind it: with three small streams taken in turn, the third round of a job started 0.65 ms late behind the
-					// second round's extraction (kernel trace, round 6).  Every small stream is marked by an event when a group has been queued
-					// on it; a new group takes one whose event has completed, else the one with the least work queued since it was last
-					// seen idle.  (More streams per job do NOT help, measured in round 6: the streams of a process share its hardware
-					// queues -- with 7 per job, 35 in the engine, a call alone took 11 - 14 ms instead of 7.6; with 5 per job, 20 in the
-					// engine, a call alone took the same 7.6 ms and four jobs in flight fell from 4.8 - 5.8 to 3.7 - 4.5 x 10^5 targets/s.)
-					int si = 0;
+					// The large group of the first round is a throughput pass: the job's own stream.  Every other group (the resized stamps
+					// of a few targets, or of a few hundred in a batch of 10 000) is a chain of latency-bound launches that decides when the
+					// job's next round can start: a stream of the engine's pool, an IDLE one if there is one.  Until round 6 a job had three
+					// small streams of its own, taken in turn: the fourth and fifth group of a round queued behind the first two's cut,
+					// extraction and diagnostics, and a round of five groups was decided 3 ms after its first three masks were done.
+					// (More streams per JOB do not help: the streams of a process share its hardware queues -- with 7 per job, 35 in the
+					// engine, a call alone took 11 - 14 ms instead of 7.6.  The pool has the same twelve small streams as before, for
+					// whichever jobs are in flight.)
 					const double work = (double)L.idx.size() * (double)L.grp.H * (double)L.grp.W;   // what its tail costs, roughly
-					if (L.idx.size() < 256) {
-						double best = 0.0;
-						for (int k = 0; k < g_small_streams; ++k) {
-							const int cand = 1 + ((next_small + k) % g_small_streams);
-							if (stream_busy[cand] && hipEventQuery(stream_busy[cand]) == hipSuccess) stream_load[cand] = 0.0;   // drained
-							if (si == 0 || stream_load[cand] < best) { si = cand; best = stream_load[cand]; }
-						}
-						(void)hipGetLastError();   // hipErrorNotReady of the queries
-						next_small = si;             // the next group starts looking behind this one
-						stream_load[si] += work;
-					}
-					L.g = streams[si];
-					launch(L, (int)gi, event_pool);
-					if (si != 0) {
-						if (!stream_busy[si]) (void)hipEventCreateWithFlags(&stream_busy[si], hipEventDisableTiming);
-						if (stream_busy[si]) (void)hipEventRecord(stream_busy[si], L.g->stream);
-					}
+					if (first_round && L.idx.size() >= 256) L.g = own;
+					else claim(L, work, launched);
 				}
+				for (auto& L : launched) launch_masks(L, event_pool);
+				for (auto& L : launched) launch_tail(L, event_pool);
+				claims.release();
+				lab_mark("queued", lab_rounds + 1, (int)launched.size());
 				std::string lost;                        // a device error that surfaces at an event costs every group of the part
 				bool drained = false;                    // ... and the job's streams are drained once before any of its blocks is given back
 				lab_rounds += 1;
@@ -572,6 +735,7 @@ void tp_frames_job::run()
 						if (e != hipSuccess) { lost = std::string("hipEventSynchronize: ") + hipGetErrorString(e); (void)hipGetLastError(); }
 					}
 					const auto lab_b = std::chrono::steady_clock::now();
+					lab_mark("ev", lab_rounds, (int)L.idx.size());
 					lab_us[2] += std::chrono::duration<double, std::micro>(lab_b - lab_a).count();
 					struct LabDecide { double& acc; std::chrono::steady_clock::time_point t; ~LabDecide() { acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t).count(); } } lab_d{lab_us[3], lab_b};
 					if (L.ev) { event_pool.push_back(L.ev); L.ev = nullptr; }
@@ -579,7 +743,7 @@ void tp_frames_job::run()
 						// the copies into this part's page-locked blocks may still be queued (on this group's stream, or -- once an error
 						// has surfaced and the remaining groups are no longer waited for one by one -- on any of the job's streams): a block
 						// goes back to the engine-wide pool, where another job's thread may take it, only after they have drained
-						if (!drained) { for (int s = 0; s < kStreams; ++s) (void)hipStreamSynchronize(streams[s]->stream); (void)hipGetLastError(); drained = true; }
+						if (!drained) { drain_all(); drained = true; }
 						if (L.grp.h_block) { eng->pinned.put(L.grp.h_block, L.grp.h_cap); L.grp.h_block = nullptr; }
 						const int32_t t = add_text(L.failed ? L.error : lost);
 						for (int32_t i : L.idx) { log(i, 10, L.grp.H, L.grp.W, 0.0, t); finish(i, TP_STATUS_ERROR); }
@@ -590,13 +754,14 @@ void tp_frames_job::run()
 			}
 			std::sort(still.begin(), still.end());
 			active.swap(still);
+			first_round = false;
 		}
 		// ---- the light curves of every round have arrived
 		std::string copy_error;
 		const auto lab_w = std::chrono::steady_clock::now();
-		for (int s = 0; s < kStreams; ++s) {
-			const hipError_t e = hipStreamSynchronize(streams[s]->stream);
-			if (e != hipSuccess && copy_error.empty()) { copy_error = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); (void)hipGetLastError(); }
+		for (hipEvent_t te : tails) {
+			const hipError_t e = hipEventSynchronize(te);
+			if (e != hipSuccess && copy_error.empty()) { copy_error = std::string("hipEventSynchronize: ") + hipGetErrorString(e); (void)hipGetLastError(); }
 		}
 		lab_us[4] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - lab_w).count();
 		if (const char* le = std::getenv("TESSPHOT_FRAMES_TIMING"))
@@ -607,7 +772,8 @@ void tp_frames_job::run()
 			if (le[0] == '1' && le[1] == '1') {
 				std::string line = "[frames job]   queueing:";
 				for (auto& kv : lab_steps) { char buf[96]; std::snprintf(buf, sizeof buf, " %s %.0f,", kv.first.c_str(), kv.second); line += buf; }
-				std::fprintf(stderr, "%s\n", line.c_str());
+				std::fprintf(stderr, "%s\n[frames job]   timeline:%s end@%.0f\n", line.c_str(), lab_timeline.c_str(),
+					std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - lab_run0).count());
 			}
 		if (!copy_error.empty()) {       // nothing that was extracted can be trusted
 			const int32_t t = add_text(copy_error);
@@ -616,11 +782,11 @@ void tp_frames_job::run()
 	} catch (const std::exception& e) {
 		rc = TP_ERR_HIP;
 		err = e.what();
-		for (int s = 0; s < kStreams; ++s) (void)hipStreamSynchronize(streams[s]->stream);
-		(void)hipGetLastError();
+		drain_all();
 	}
+	for (auto e : tails) (void)hipEventDestroy(e);
+	tails.clear();
 	for (auto e : event_pool) (void)hipEventDestroy(e);
-	for (int si = 0; si < kStreams; ++si) if (stream_busy[si]) { (void)hipEventDestroy(stream_busy[si]); stream_busy[si] = nullptr; }
 	for (auto& hs : host_scratch) eng->pinned.put(hs.first, hs.second);
 	host_scratch.clear();
 }
@@ -648,8 +814,13 @@ int tp_frames_engine_create(int device, int32_t n_slots, tp_frames_engine** out)
 		}
 		c->reuse_in_stream_order = true;      // (every block of a group is allocated from, used on and freed to the context of its stream)
 		eng->ctxs.push_back(c);
+		if ((i % kStreams) != 0 && (i % kStreams) <= g_small_streams) { tp_frames_engine::SmallStream S; S.c = c; eng->small.push_back(S); }
 	}
 	eng->busy.assign(n_slots, 0);
+	eng->copy_streams.assign(n_slots, nullptr);
+	(void)hipSetDevice(device);
+	for (int i = 0; i < n_slots; ++i)
+		if (hipStreamCreateWithFlags(&eng->copy_streams[(size_t)i], hipStreamNonBlocking) != hipSuccess) { eng->copy_streams[(size_t)i] = nullptr; (void)hipGetLastError(); }
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) eng->hbm_bytes = (uint64_t)prop.totalGlobalMem;
 	*out = eng;
@@ -661,6 +832,8 @@ int tp_frames_engine_destroy(tp_frames_engine* eng)
 {
 	if (!eng) return TP_OK;
 	while (eng->running.load() > 0) std::this_thread::yield();   // (a job still running: its streams go only once it is through)
+	for (auto& S : eng->small) if (S.busy) (void)hipEventDestroy(S.busy);
+	for (hipStream_t cs : eng->copy_streams) if (cs) (void)hipStreamDestroy(cs);
 	for (tp_ctx* c : eng->ctxs) (void)tp_ctx_destroy(c);
 	delete eng;
 	return TP_OK;
@@ -741,6 +914,13 @@ int tp_frames_submit(tp_frames_engine* eng, const tp_frames_stack* stack, const 
 		tp_global_err = "tp_frames_submit: bad arguments";
 		return TP_ERR_INVALID;
 	}
+	if (stack->d_images_t || stack->d_images_err_t || stack->d_backgrounds_t) {
+		if (!(stack->d_images_t && stack->d_images_err_t && stack->d_backgrounds_t && stack->d_sumimage) || stack->t_pitch < stack->n_frames || stack->t_pitch % 4 != 0 ||
+			(int64_t)stack->n_rows * stack->n_cols >= ((int64_t)1 << 31)) {
+			tp_global_err = "tp_frames_submit: the time-major stacks come all three, with the region's sum image, and t_pitch >= n_frames, a multiple of 4";
+			return TP_ERR_INVALID;
+		}
+	}
 	TP_API_BEGIN
 	int slot = -1;
 	{
@@ -750,7 +930,8 @@ int tp_frames_submit(tp_frames_engine* eng, const tp_frames_stack* stack, const 
 	if (slot < 0) { tp_global_err = "tp_frames_submit: every slot of the engine holds a job (wait for and release one first)"; return TP_ERR_INVALID; }
 	tp_frames_job* job = new tp_frames_job();
 	job->eng = eng; job->slot = slot;
-	for (int s = 0; s < kStreams; ++s) job->streams[s] = eng->ctxs[(size_t)slot * kStreams + s];
+	job->own = eng->ctxs[(size_t)slot * kStreams];
+	job->copy_stream = eng->copy_streams[(size_t)slot];
 	job->stack = *stack; job->cat = cat;
 	job->n = n_targets; job->T = stack->n_frames;
 	job->starid.assign(h_starid, h_starid + n_targets);

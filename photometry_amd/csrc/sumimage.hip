@@ -107,6 +107,30 @@ __global__ __launch_bounds__(256) void tp_f64_to_f32_kernel(const double* __rest
 	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) out[i] = (float)in[i];
 }
 
+// 16 bytes per thread and step; the tail by bytes (both pointers 16-byte aligned, or the whole copy goes by bytes)
+__global__ __launch_bounds__(256) void tp_blit_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, uint64_t n16, uint64_t nbytes)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
+	const uint64_t done = n16 * 16;
+	unsigned char* d8 = reinterpret_cast<unsigned char*>(dst);
+	const unsigned char* s8 = reinterpret_cast<const unsigned char*>(src);
+	if (blockIdx.x == 0) for (uint64_t i = done + threadIdx.x; i < nbytes; i += 256) d8[i] = s8[i];
+}
+
+int tp_blit(tp_ctx* ctx, void* dst, const void* src, uint64_t nbytes)
+{
+	TP_CHECK_CTX(ctx);
+	if (nbytes == 0) return TP_OK;
+	TP_REQUIRE(ctx, dst && src, "tp_blit: null pointer");
+	const bool aligned = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0;
+	const uint64_t n16 = aligned ? nbytes / 16 : 0;
+	const uint64_t blocks = (n16 + 255) / 256;
+	const dim3 grid((unsigned)(blocks < 1 ? 1 : (blocks < 512 ? blocks : 512))), block(256);
+	TP_LAUNCH(ctx, TPK_BLIT, tp_blit_kernel, grid, block, 0, static_cast<uint4*>(dst), static_cast<const uint4*>(src), n16, nbytes);
+	TP_LAUNCH_CHECK(ctx, "tp_blit_kernel");
+	return TP_OK;
+}
+
 extern "C" int tp_block_compact(tp_ctx* ctx, const void* d_block, void* d_compact, const tp_block_field* fields, int32_t n_fields)
 {
 	TP_CHECK_CTX(ctx);

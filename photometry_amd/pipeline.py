@@ -364,6 +364,7 @@ class FrameStack(object):
 		if sumimage is None and hasattr(frames, 'get'):
 			sumimage = frames.get('sumimage')
 		self._sumimage = self._sumimage_key = None
+		self._time_major = None
 		if sumimage is not None:
 			self._sumimage = sumimage if isinstance(sumimage, DeviceArray) else ctx.array(np.ascontiguousarray(sumimage, dtype='float64'))
 			if tuple(self._sumimage.shape) != (self.n_rows, self.n_cols):
@@ -393,6 +394,34 @@ class FrameStack(object):
 			dq.free()
 			self._sumimage, self._sumimage_key = sumimage, key
 		return self._sumimage
+
+	def time_major(self):
+		"""
+		The three stacks once more, TIME-MAJOR: float32 DeviceArrays ``(R * C, t_pitch)`` (``tp_frames_transpose``; formed on first use,
+		kept with the stack), or ``None`` when ``TESSPHOT_FRAMES_TIME_MAJOR=0`` or the device has no room for them.  With them the
+		native engine cuts nothing: a mask pixel's time series is one row of the stack (``tp_aperture_extract_stack``), where every
+		batch of targets used to cut the in-mask rows out of all frames again -- the reference's ``_load_cube`` per target and per stamp
+		resize (BasePhotometry.py:720-751).  Costs the stacks' size a second time in HBM, and one pass over them per region.
+		"""
+		if self._time_major is False or os.environ.get('TESSPHOT_FRAMES_TIME_MAJOR', '1') == '0':
+			return None
+		if self._time_major is None:
+			ctx = self.ctx
+			t_pitch = (self.n_cad + 31) // 32 * 32
+			npix = self.n_rows * self.n_cols
+			out = {}
+			try:
+				for k in self.names:
+					out[k] = ctx.empty((npix, t_pitch), 'float32')
+					ctx._check(ctx.lib.tp_frames_transpose(ctx.handle, self.dev[k].ptr, self.n_cad, npix, npix, out[k].ptr, t_pitch))
+				ctx.sync()      # other streams (the jobs' contexts) read them
+			except TessphotError:
+				for a in out.values():
+					a.free()
+				self._time_major = False
+				return None
+			self._time_major = (out, t_pitch)
+		return self._time_major
 
 	def cut_lazy(self, ctx, stamps, height, width):
 		"""The cut cubes of a group on ``ctx``'s stream, the stamp list uploaded there too."""
@@ -791,8 +820,11 @@ class FramesEngine(object):
 		# an FFI target's sum image is a crop of the region's (BasePhotometry.py:1001-1006); a postage-stamp target ('tpf:...') sums its
 		# own stamp (:1007-1019): no region sum image is handed over and every pass forms the stamps' own (tp_sumimage)
 		sumimage = None if datasource.startswith('tpf:') else stack.sumimage_for(q)
+		tm_stacks = None if sumimage is None else stack.time_major()
 		sdesc = _lib.tp_frames_stack(stack.dev['images'].ptr, stack.dev['images_err'].ptr, stack.dev['backgrounds'].ptr,
-			stack.n_cad, stack.n_rows, stack.n_cols, stack.row0, stack.col0, None if sumimage is None else sumimage.ptr)
+			stack.n_cad, stack.n_rows, stack.n_cols, stack.row0, stack.col0, None if sumimage is None else sumimage.ptr,
+			None if tm_stacks is None else tm_stacks[0]['images'].ptr, None if tm_stacks is None else tm_stacks[0]['images_err'].ptr,
+			None if tm_stacks is None else tm_stacks[0]['backgrounds'].ptr, 0 if tm_stacks is None else tm_stacks[1])
 		budget = float(os.environ.get('TESSPHOT_FRAMES_BUDGET_GB', 0)) * 1e9 or self.hbm_bytes / 4.0
 		h = ctypes.c_void_p()
 		rc = self.lib.tp_frames_submit(self.handle, ctypes.byref(sdesc), catalog.handle, n, sid.ctypes.data, tm.ctypes.data, row.ctypes.data, col.ctypes.data,

@@ -178,9 +178,12 @@ def test_bright_star_large_stamp_three_way():
 	ctx.close()
 
 
-def test_aperture_frames_in_parts_under_a_memory_budget(monkeypatch):
+@pytest.mark.parametrize("time_major,budget_gb", [('1', '0.00004'), ('0', '0.004')])
+def test_aperture_frames_in_parts_under_a_memory_budget(monkeypatch, time_major, budget_gb):
 	"""A budget of device memory far below the batch cuts the groups of a round into parts (and a group into chunks of targets)
-	that are processed one after the other: same results as in one piece."""
+	that are processed one after the other: same results as in one piece.  With the time-major stacks (the default) a target costs
+	its output block only (40 KB of budget: eight targets per chunk); with the stamp cubes cut per pass 4 MB are a dozen targets."""
+	monkeypatch.setenv('TESSPHOT_FRAMES_TIME_MAJOR', time_major)
 	from photometry_amd import pipeline, tessphot_frames
 	from photometry_amd.device import Context
 	rng = np.random.default_rng(12)
@@ -202,7 +205,7 @@ def test_aperture_frames_in_parts_under_a_memory_budget(monkeypatch):
 	ctx = Context(0)
 	stack = pipeline.FrameStack(ctx, frames, 0, 44)
 	whole = tessphot_frames(ctx, stack, targets, cat, tstamp, quality)
-	monkeypatch.setenv('TESSPHOT_FRAMES_BUDGET_GB', '0.004')     # 4 MB: a dozen 15 x 15 x 40 targets per chunk
+	monkeypatch.setenv('TESSPHOT_FRAMES_BUDGET_GB', budget_gb)
 	parts = tessphot_frames(ctx, stack, targets, cat, tstamp, quality)
 	assert len(parts.frames.groups) > len(whole.frames.groups) + 3
 	np.testing.assert_array_equal(parts.status, whole.status)
@@ -249,7 +252,7 @@ def test_pipelined_batches_equal_separate_calls():
 	ctx.close()
 
 
-def _compare_frames_results(a, b):
+def _compare_frames_results(a, b, same_groups=True):
 	"""Two pipeline.FramesResult of the same batch: everything a caller can see, target by target."""
 	assert a.n == b.n
 	np.testing.assert_array_equal(a.status, b.status)
@@ -258,7 +261,7 @@ def _compare_frames_results(a, b):
 	np.testing.assert_array_equal(a.has_result, b.has_result)
 	assert a.errors == b.errors
 	assert a.edge_flux == b.edge_flux                       # (float64 sums in numpy's pairwise order on both sides: equal, not close)
-	assert len(a.groups) == len(b.groups)
+	assert len(a.groups) == len(b.groups) or not same_groups
 	for i in range(a.n):
 		x, y = a[i], b[i]
 		assert set(x) == set(y), (i, set(x) ^ set(y))
@@ -316,14 +319,16 @@ def test_native_engine_equals_the_python_rounds():
 	_compare_frames_results(py, nat)
 	assert int((nat.stamp_resizes > 0).sum()) >= 10 and len(nat.groups) >= 4 and len(nat.errors) >= 1
 	print('crowded region:', int((nat.stamp_resizes > 0).sum()), 'targets resized,', len(nat.groups), 'device passes,', len(nat.errors), 'targets with messages')
-	os.environ['TESSPHOT_FRAMES_BUDGET_GB'] = '0.003'
 	try:
+		# (the native engine reads the time-major stacks and cuts no cubes: a target costs it its output block only)
+		os.environ['TESSPHOT_FRAMES_BUDGET_GB'] = '0.00003'
 		parts = pipeline.aperture_frames(ctx, stack2, tg2, cat2, tstamp, q, engine='native')
+		os.environ['TESSPHOT_FRAMES_BUDGET_GB'] = '0.003'
 		parts_py = pipeline.aperture_frames(ctx, stack2, tg2, cat2, tstamp, q, engine='python')
 	finally:
 		del os.environ['TESSPHOT_FRAMES_BUDGET_GB']
 	assert len(parts.groups) > len(nat.groups) + 3
-	_compare_frames_results(parts_py, parts)
+	_compare_frames_results(parts_py, parts, same_groups=False)   # (cut into parts by different budgets)
 	# the group arrays are read-only views that go with the result
 	g0 = nat.groups[0]
 	with pytest.raises(ValueError):
@@ -430,4 +435,80 @@ def test_postage_stamp_datasource_sums_its_own_stamps():
 	assert n_checked >= 3
 	# no quick break for a postage stamp: the bright target keeps resizing where the FFI target stops
 	assert (nat.stamp_resizes >= ffi.stamp_resizes).all()
+	ctx.close()
+
+
+def test_time_major_stacks_change_nothing():
+	"""The native engine on the time-major stacks (no cut: tp_aperture_extract_stack reads a mask pixel's series as a row of the
+	transposed stack) against the same engine cutting the in-mask rows per pass (TESSPHOT_FRAMES_TIME_MAJOR=0): every array equal."""
+	import os
+	from photometry_amd import pipeline
+	from photometry_amd.device import Context
+	ctx = Context(0)
+	frames, row0, col0, time, quality, cat, targets = _region()
+	fr = {k: np.moveaxis(v, 2, 0) for k, v in frames.items()}
+	stack_a = pipeline.FrameStack(ctx, fr, row0, col0)
+	a = pipeline.aperture_frames(ctx, stack_a, targets, cat, time, quality, engine='native')
+	assert stack_a._time_major not in (None, False)
+	os.environ['TESSPHOT_FRAMES_TIME_MAJOR'] = '0'
+	try:
+		stack_b = pipeline.FrameStack(ctx, fr, row0, col0)
+		b = pipeline.aperture_frames(ctx, stack_b, targets, cat, time, quality, engine='native')
+		assert stack_b._time_major is None
+	finally:
+		del os.environ['TESSPHOT_FRAMES_TIME_MAJOR']
+	_compare_frames_results(a, b)
+	assert int(((a.status == 1) | (a.status == 3)).sum()) >= 3
+	ctx.close()
+
+
+def test_frames_transpose_and_extract_stack_equal_the_cut_cubes():
+	"""tp_frames_transpose is the transposition (padding zero), and tp_aperture_extract_stack on the transposed stacks gives, bit for
+	bit, what tp_aperture_extract gives on the cubes cut from the frames -- masks below and above 128 pixels (both kernels), stamps
+	of two sizes, a stack with an odd number of cadences."""
+	import ctypes
+	from photometry_amd import engine
+	from photometry_amd.device import Context
+	ctx = Context(0)
+	rng = np.random.default_rng(5)
+	T, R, C = 37, 70, 90
+	t_pitch = 64
+	fr = [rng.normal(100.0, 10.0, (T, R, C)).astype('float32') for _ in range(3)]
+	fr[0][3, 10:14, 20] = np.nan
+	d = [ctx.array(x) for x in fr]
+	dt = [ctx.empty((R * C, t_pitch), 'float32') for _ in range(3)]
+	for x, y in zip(d, dt):
+		ctx._check(ctx.lib.tp_frames_transpose(ctx.handle, x.ptr, T, R * C, R * C, y.ptr, t_pitch))
+	ctx.sync()
+	for x, y in zip(fr, dt):
+		got = y.to_host()
+		np.testing.assert_array_equal(got[:, :T], x.reshape(T, R * C).T)
+		assert not got[:, T:].any()
+	row0, col0 = 100, 44
+	for (H, W, n) in [(15, 15, 40), (24, 31, 9)]:
+		r0 = rng.integers(0, R - H + 1, n); c0 = rng.integers(0, C - W + 1, n)
+		stamps = np.stack([row0 + r0, row0 + r0 + H, col0 + c0, col0 + c0 + W], axis=1).astype('int32')
+		mask = (rng.random((n, H, W)) < 0.25).astype('uint8')
+		mask[0] = 0
+		mask[1] = 1                                   # every pixel: above 128 -> the recursive pairwise kernel
+		status = np.ones(n, dtype='int32'); status[2] = 2   # STATUS.ERROR: the target is skipped
+		ds, dm, dst = ctx.array(stamps), ctx.array(mask), ctx.array(status)
+		cubes = engine.cut_stamps_multi(ctx, d, ds, H, W, row0, col0)
+		outs = {}
+		for kind in ('cube', 'stack'):
+			lc = [ctx.empty((n, T), 'float64') for _ in range(5)]
+			for a in lc:
+				ctx._check(ctx.lib.tp_memset(ctx.handle, a.ptr, 0x7f, a.nbytes))
+			if kind == 'cube':
+				desc = cubes[0].desc
+				ctx._check(ctx.lib.tp_aperture_extract(ctx.handle, ctypes.byref(desc), cubes[0].ptr, cubes[1].ptr, cubes[2].ptr, 0, 0, None, 0,
+					dm.ptr, ds.ptr, dst.ptr, lc[0].ptr, lc[1].ptr, lc[2].ptr, lc[3].ptr, lc[4].ptr, T))
+			else:
+				ctx._check(ctx.lib.tp_aperture_extract_stack(ctx.handle, n, T, H, W, dt[0].ptr, dt[1].ptr, dt[2].ptr, t_pitch, R, C, row0, col0,
+					dm.ptr, ds.ptr, dst.ptr, lc[0].ptr, lc[1].ptr, lc[2].ptr, lc[3].ptr, lc[4].ptr, T))
+			ctx.sync()
+			outs[kind] = [a.to_host() for a in lc]
+		for a, b in zip(outs['cube'], outs['stack']):
+			np.testing.assert_array_equal(a.view('uint64'), b.view('uint64'))
+		assert np.isfinite(outs['stack'][0][1]).all() and np.isnan(outs['stack'][0][0]).all()
 	ctx.close()
