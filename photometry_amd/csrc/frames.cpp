@@ -4,11 +4,15 @@
 //
 // What the reference does one target at a time in Python -- cut the stamp out of the HDF5 groups, run the plugin, look at the mask,
 // grow the stamp, try again -- is here a JOB: the host submits a batch (tp_frames_submit) and collects it (tp_frames_wait); in
-// between a worker thread of the library drives the rounds on the job's own four streams: group the targets still in play by
-// stamp size, select the catalogue stars of every stamp from a cell-binned index, cut the stamps on the device (tp_cut_stamps), run
-// the fused pass (tp_aperture_photometry; the three stand-alone kernels for a small group) and the light-curve diagnostics,
-// download the packed output block into page-locked memory (the part the decisions read first, with an event; the light curves
-// behind it), decide with the plugin's rules who is finished, who gets a bigger stamp and who gives up.  No Python runs between
+// between a worker thread of the library drives the rounds: group the targets still in play by stamp size, select the catalogue
+// stars of every stamp from a cell-binned index, and queue each group's pass on a stream of the engine's pool -- first the halves
+// that produce the masks of ALL groups of the round (sum images cropped from the region's, tp_k2p2_masks, the download of what the
+// decisions read, an event), then their second halves (extraction, light-curve diagnostics, download of the packed output block
+// into page-locked memory).  With the region's TIME-MAJOR stacks at hand (tp_frames_stack.d_images_t ...) nothing is cut: the
+// extraction reads a mask pixel's series as one row of the stack (tp_aperture_extract_stack); without them the in-mask rows of
+// the stamps are cut per pass (tp_cut_stamps_masked).  The worker then decides with the plugin's rules who is finished, who gets a
+// bigger stamp and who gives up.  Small transfers go by a kernel (tp_blit), only the large group's light curves through a DMA
+// engine, chunk by chunk on the job's copy stream while the later chunks are still being extracted.  No Python runs between
 // submit and collect, so several jobs in flight (one per engine slot) keep the device busy: the first round of one batch runs
 // under the latency-bound resize rounds of another.  The rules are those of photometry_amd/stamps.py and plugins.mask_outcome
 // (which stay the per-target plugin's implementation and the reference of tests/test_gpu_resize.py); messages travel as codes
@@ -32,8 +36,8 @@ constexpr uint32_t kBitmask = 1 | 2 | 4 | 8 | 32 | 64 | 128 | 4096;   // TESSQua
 // Streams per job: stream 0 for the large groups, three for the small, latency-bound ones.  Four active streams is what a single
 // job runs fastest with (measured, 2 500 targets: 15 / 13 / 20 ms with 2 / 3 / 4 streams for the small groups: beyond four active
 // queues of a process the hardware time-slices them).
-constexpr int kStreams = 4;               // per job: one for the large groups, three for the small ones
-static int g_small_streams = 3;          // (experiment: TESSPHOT_FRAMES_STREAMS = 1 .. 3)
+constexpr int kStreams = 4;               // per slot: three streams of the engine's pool and a copy stream
+static int g_small_streams = 3;          // (experiment: TESSPHOT_FRAMES_STREAMS = 1 .. 3 pool streams per slot)
 constexpr int kResizeStep = 10;          // photometry.py:124-131
 constexpr int kFusedFrom = 1024;         // from this many targets on a group is "large": stream 0, the error / background stacks cut after the mask
 constexpr int kEdgeBits = 2 | 4 | 8 | 16;
@@ -109,9 +113,11 @@ struct tp_frames_catalog {
 struct tp_frames_engine {
 	int device = 0;
 	int n_slots = 0;
-	std::vector<tp_ctx*> ctxs;          // kStreams per slot: the first is the slot's own (its job's throughput stream), the others
-	                                    // are the engine's pool of small streams, shared by the jobs in flight (SmallStream below)
-	// A small stream of the pool.  A job's worker CLAIMS one per small group of a round while it queues the round (nobody else queues
+	std::vector<tp_ctx*> ctxs;          // kStreams - 1 per slot: the engine's pool of streams, shared by the jobs in flight (SmallStream
+	                                    // below); the kStreams-th stream of a slot is its copy stream.  The process should stay below
+	                                    // ~24 streams in all: beyond that the hardware queues are time-sliced, and with six idle streams
+	                                    // more in the process four jobs in flight fell from 8.1 to 4.8 x 10^5 targets/s (round 6)
+	// A stream of the pool.  A job's worker CLAIMS one per group of a round while it queues the round (nobody else queues
 	// on a claimed stream: a context's host-side state has one user at a time), marks it with an event when it lets go, and the next
 	// claimant -- of any job -- prefers a stream whose event has completed (idle), in index order (so that the same few contexts are
 	// used and their allocation caches stay warm), else the one with the least work queued since it was last seen idle.
@@ -142,7 +148,8 @@ struct Group {
 // a group of one round while its pass is in flight
 struct Launched {
 	tp_ctx* g = nullptr;
-	int small = -1;                       // index of the claimed stream of the engine's pool (-1: the job's own stream)
+	int small = -1;                       // index of the claimed stream of the engine's pool
+	bool chunked = false;                 // its light curves leave on the job's copy stream
 	std::vector<int32_t> idx;
 	Group grp;
 	hipEvent_t ev = nullptr;              // the decisions' data have arrived
@@ -162,7 +169,6 @@ struct Launched {
 struct tp_frames_job {
 	tp_frames_engine* eng = nullptr;
 	int slot = -1;
-	tp_ctx* own = nullptr;                    // the slot's stream: the large group of the first round
 	hipStream_t copy_stream = nullptr;        // the slot's copy stream: the light curves of that group, chunk by chunk
 	std::vector<hipEvent_t> tails;            // one per group: everything the group queued (its light curves last) has run
 	tp_frames_stack stack{};
@@ -288,7 +294,7 @@ void tp_frames_job::fail_group(Launched& L, const char* what, std::vector<hipEve
 {
 	L.failed = true;
 	L.error = what;
-	if (L.g == own && copy_stream) (void)hipStreamSynchronize(copy_stream);
+	if (L.chunked && copy_stream) (void)hipStreamSynchronize(copy_stream);
 	(void)hipStreamSynchronize(L.g->stream);
 	(void)hipGetLastError();
 	for (void* p : L.dev) (void)tp_free(L.g, p);
@@ -478,7 +484,8 @@ void tp_frames_job::launch_tail(Launched& L, std::vector<hipEvent_t>& event_pool
 		// used to leave when extraction AND diagnostics of the whole group were done.  Now the group is extracted in chunks of targets,
 		// and a chunk's five planes leave on the job's copy stream as soon as the chunk is extracted: the link starts 0.15 ms after the
 		// cut instead of 1.2 ms, and the diagnostics run under the copies.
-		const int32_t n_chunks = (g == own && copy_stream && m >= 2048) ? std::min<int32_t>(8, m / 1024) : 1;
+		const int32_t n_chunks = (copy_stream && m >= 2048) ? std::min<int32_t>(8, m / 1024) : 1;
+		L.chunked = n_chunks > 1;
 		for (int32_t c = 0; c < n_chunks; ++c) {
 			const int32_t j0 = (int32_t)((int64_t)m * c / n_chunks), j1 = (int32_t)((int64_t)m * (c + 1) / n_chunks);
 			tp_cube_desc part = desc;
@@ -507,11 +514,15 @@ void tp_frames_job::launch_tail(Launched& L, std::vector<hipEvent_t>& event_pool
 		ck(g, tp_lightcurve_diagnostics(g, m, T, lc[0], lc[1], lc[3], lc[4], T, L.d_time, L.d_quality, 0, kBitmask, d_status, d_sum, d_mask, H, W,
 			3600.0 / 86400.0, d_diagn));
 		lap("diagnostics");
-		ckh(hipMemcpyAsync(static_cast<char*>(G.h_block) + G.off_diag, blk + G.off_diag, (size_t)(G.nbytes - G.off_diag), hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(diagnostics)");
+		// (by a kernel, like everything but the large group's light curves: a copy that waits in a DMA engine's queue behind another
+		// job's 130 MB holds this STREAM, and the next round's masks queued on it, for as long)
+		ck(g, tp_blit(g, static_cast<char*>(G.h_block) + G.off_diag, blk + G.off_diag, G.nbytes - G.off_diag));
 		if (n_chunks > 1) {
 			hipEvent_t e = new_event();          // the group's stream goes on (its tail event, the reuse of its blocks) when the copies have left
 			ckh(hipEventRecord(e, copy_stream), "hipEventRecord");
 			ckh(hipStreamWaitEvent(g->stream, e, 0), "hipStreamWaitEvent");
+		} else if (lc_bytes <= ((uint64_t)32 << 20)) {
+			ck(g, tp_blit(g, G.h_block, blk, lc_bytes));
 		} else {
 			ckh(hipMemcpyAsync(G.h_block, blk, (size_t)lc_bytes, hipMemcpyDeviceToHost, g->stream), "hipMemcpyAsync(light curves)");
 		}
@@ -635,10 +646,9 @@ void tp_frames_job::claim(Launched& L, double work, const std::vector<Launched>&
 	}
 }
 
-// error paths: everything this job may have queued anywhere has run (its own stream and the whole pool)
+// error paths: everything this job may have queued anywhere has run (its copy stream and the whole pool)
 void tp_frames_job::drain_all()
 {
-	(void)hipStreamSynchronize(own->stream);
 	if (copy_stream) (void)hipStreamSynchronize(copy_stream);
 	for (auto& S : eng->small) (void)hipStreamSynchronize(S.c->stream);
 	(void)hipGetLastError();
@@ -649,7 +659,6 @@ void tp_frames_job::run()
 	(void)hipSetDevice(eng->device);
 	lab_run0 = std::chrono::steady_clock::now();
 	std::vector<hipEvent_t> event_pool;
-	bool first_round = true;
 	try {
 		status.assign(n, 0); stamp_resizes.assign(n, 0); group.assign(n, -1); pos.assign(n, 0); has_result.assign(n, 0);
 		stamp.assign((size_t)n * 4, -1);
@@ -709,17 +718,14 @@ void tp_frames_job::run()
 					Launched& L = launched[gi];
 					L.idx = std::move(part[gi].idx);
 					L.grp.H = part[gi].H; L.grp.W = part[gi].W;
-					// The large group of the first round is a throughput pass: the job's own stream.  Every other group (the resized stamps
-					// of a few targets, or of a few hundred in a batch of 10 000) is a chain of latency-bound launches that decides when the
-					// job's next round can start: a stream of the engine's pool, an IDLE one if there is one.  Until round 6 a job had three
-					// small streams of its own, taken in turn: the fourth and fifth group of a round queued behind the first two's cut,
-					// extraction and diagnostics, and a round of five groups was decided 3 ms after its first three masks were done.
-					// (More streams per JOB do not help: the streams of a process share its hardware queues -- with 7 per job, 35 in the
-					// engine, a call alone took 11 - 14 ms instead of 7.6.  The pool has the same twelve small streams as before, for
-					// whichever jobs are in flight.)
+					// Every group takes a stream of the engine's pool, an IDLE one if there is one: the large group of the first round as
+					// well as the resized stamps of a few targets -- chains of latency-bound launches that decide when the job's next
+					// round can start.  Until round 6 a job had four streams of its own, three of them for the small groups, taken in
+					// turn: the fourth and fifth group of a round queued behind the first two's cut, extraction and diagnostics, and a
+					// round of five groups was decided 3 ms after its first three masks were done.  (More streams per JOB do not help:
+					// with 7 per job, 35 in the engine, a call alone took 11 - 14 ms instead of 7.6 -- see the note at the pool.)
 					const double work = (double)L.idx.size() * (double)L.grp.H * (double)L.grp.W;   // what its tail costs, roughly
-					if (first_round && L.idx.size() >= 256) L.g = own;
-					else claim(L, work, launched);
+					claim(L, work, launched);
 				}
 				for (auto& L : launched) launch_masks(L, event_pool);
 				for (auto& L : launched) launch_tail(L, event_pool);
@@ -754,7 +760,6 @@ void tp_frames_job::run()
 			}
 			std::sort(still.begin(), still.end());
 			active.swap(still);
-			first_round = false;
 		}
 		// ---- the light curves of every round have arrived
 		std::string copy_error;
@@ -802,11 +807,11 @@ int tp_frames_engine_create(int device, int32_t n_slots, tp_frames_engine** out)
 	tp_frames_engine* eng = new tp_frames_engine();
 	eng->device = device;
 	eng->n_slots = n_slots;
-	for (int i = 0; i < n_slots * kStreams; ++i) {
+	if (const char* se = std::getenv("TESSPHOT_FRAMES_STREAMS")) { const int v = std::atoi(se); if (v >= 1 && v <= kStreams - 1) g_small_streams = v; }
+	for (int i = 0; i < n_slots * g_small_streams; ++i) {
 		tp_ctx* c = nullptr;
 		const char* pe = std::getenv("TESSPHOT_FRAMES_PRIO");
-		if (const char* se = std::getenv("TESSPHOT_FRAMES_STREAMS")) { const int v = std::atoi(se); if (v >= 1 && v <= kStreams - 1) g_small_streams = v; }
-		const int rc = tp_ctx_create_stream(device, (pe && pe[0] == '1' && (i % kStreams) != 0) ? 1 : 0, &c);
+		const int rc = tp_ctx_create_stream(device, (pe && pe[0] == '1') ? 1 : 0, &c);
 		if (rc != TP_OK) {
 			for (tp_ctx* x : eng->ctxs) (void)tp_ctx_destroy(x);
 			delete eng;
@@ -814,7 +819,7 @@ int tp_frames_engine_create(int device, int32_t n_slots, tp_frames_engine** out)
 		}
 		c->reuse_in_stream_order = true;      // (every block of a group is allocated from, used on and freed to the context of its stream)
 		eng->ctxs.push_back(c);
-		if ((i % kStreams) != 0 && (i % kStreams) <= g_small_streams) { tp_frames_engine::SmallStream S; S.c = c; eng->small.push_back(S); }
+		tp_frames_engine::SmallStream S; S.c = c; eng->small.push_back(S);
 	}
 	eng->busy.assign(n_slots, 0);
 	eng->copy_streams.assign(n_slots, nullptr);
@@ -930,7 +935,6 @@ int tp_frames_submit(tp_frames_engine* eng, const tp_frames_stack* stack, const 
 	if (slot < 0) { tp_global_err = "tp_frames_submit: every slot of the engine holds a job (wait for and release one first)"; return TP_ERR_INVALID; }
 	tp_frames_job* job = new tp_frames_job();
 	job->eng = eng; job->slot = slot;
-	job->own = eng->ctxs[(size_t)slot * kStreams];
 	job->copy_stream = eng->copy_streams[(size_t)slot];
 	job->stack = *stack; job->cat = cat;
 	job->n = n_targets; job->T = stack->n_frames;
