@@ -121,6 +121,12 @@ def compact(result):
 		if f.get('with_every_per_target_object'):
 			d['with_objects_targets_per_s'] = _num(f['with_every_per_target_object'].get('targets_per_s'))
 		legs['frames_to_results'] = d
+	fl = r.get('frames_to_results_large_batch')
+	if fl:
+		d = _pick(fl, ('targets_per_s', 'seconds', 'targets_resized'))
+		if fl.get('pipelined'):
+			d['pipelined'] = _pick(fl['pipelined'], ('targets_per_s', 'batches', 'in_flight'))
+		legs['frames_to_results_large_batch'] = d
 	pf = r.get('psf_frames_to_results')
 	if pf:
 		legs['psf_frames_to_results'] = {k: _pick(v, ('targets_per_s', 'finite_fraction')) for k, v in pf.items() if isinstance(v, dict)}

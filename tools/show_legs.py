@@ -8,6 +8,9 @@ for r in d['rooflines']:
 if 'frames_to_results' in d:
 	f = d['frames_to_results']
 	print('frames', f['targets_per_s'], f.get('seconds_all_calls'), 'pipelined', f['pipelined']['targets_per_s'], f['pipelined'].get('seconds_all_runs'))
+if 'frames_to_results_large_batch' in d:
+	f = d['frames_to_results_large_batch']
+	print('frames (10 000 targets)', f['targets_per_s'], f.get('seconds_all_calls'), 'pipelined', f['pipelined']['targets_per_s'], f['pipelined'].get('seconds_all_runs'))
 if 'fit_background_frames' in d:
 	fb = d['fit_background_frames']
 	print('tess', fb['tess']['kernel_ms_per_frame'], 'plain', fb['plain']['kernel_ms_per_frame'], fb.get('parity_sample'))
