@@ -37,6 +37,18 @@ def short(name):
 	return (m.group(1) + (m.group(2) or '')) if m else name
 
 
+# the step kernels launch by launch (the stats below average the warm-up launches of the run in: the first launches of a process run
+# at lower clocks; bench.py's HIP-event average covers the timed steps only -- the last TIMED_STEPS launches of the trace)
+TIMED = int(os.environ.get('TIMED_STEPS', 5))
+for f in find('trace/**/*kernel_trace.csv'):
+	with open(f) as fh:
+		rows = list(csv.DictReader(fh))
+	print("== the step kernels launch by launch (rocprofv3 --kernel-trace), ms ==")
+	for name in ('tp_bkg_stamp_sum_kernel', 'tp_aperture_fused_kernel<2, true, true, 1, false>'):
+		r = sorted((x for x in rows if name in x.get('Kernel_Name', '')), key=lambda x: int(x['Start_Timestamp']))
+		d = [(int(x['End_Timestamp']) - int(x['Start_Timestamp'])) / 1e6 for x in r]
+		if d:
+			print(f"{name:52s} " + ' '.join(f'{v:.3f}' for v in d) + f"   average of the last {min(TIMED, len(d))} (the timed steps): {sum(d[-TIMED:]) / len(d[-TIMED:]):.3f}")
 print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
 for f in find('trace/**/*kernel_stats.csv'):
 	with open(f) as fh:
