@@ -552,7 +552,8 @@ int tp_cut_stamps_masked(tp_ctx* ctx, int32_t n_stacks, const float* const* d_fr
  * catalogue of the stamp (BasePhotometry.catalog, :1094-1181), AperturePhotometry.do_photometry WITH its stamp-resize loop
  * (photometry/AperturePhotometry/photometry.py:75-170; resize_stamp / _set_stamp, BasePhotometry.py:567-693) and the
  * diagnostics of BasePhotometry.photometry (:1343-1407).  The frame stacks of the region stay in HBM; the host submits a batch
- * of targets and collects it, a worker thread of the library drives the rounds in between on the job's own four streams
+ * of targets and collects it, a worker thread of the library drives the rounds in between on streams of the engine's pool (three per slot, shared by the
+ * jobs in flight, and a copy stream per slot)
  * (group by stamp size, catalogue selection, tp_cut_stamps, tp_aperture_photometry / the three stand-alone kernels for small
  * groups, tp_lightcurve_diagnostics, download, the plugin's decisions), so several jobs -- one per engine slot -- overlap.
  *

@@ -881,8 +881,8 @@ def aperture_frames_pipelined(ctx, stack, batches, catalog, time, quality, setti
 	"""
 	if engine != 'python':
 		from collections import deque
-		# four streams per job: beyond five jobs (20 streams + the caller's) the hardware queues of the process are oversubscribed and
-		# time-sliced -- measured: 3.8-4.2 x 10^5 targets/s with four or five jobs in flight, 2.4-2.9 x 10^5 with six
+		# four streams per slot (three of the engine's pool and a copy stream): beyond ~24 streams in the process its hardware queues
+		# are oversubscribed and time-sliced -- measured in round 5: 3.8-4.2 x 10^5 targets/s with four or five jobs in flight, 2.4-2.9 x 10^5 with six
 		in_flight = max(1, min(int(in_flight), FramesEngine.MAX_SLOTS))
 		eng = FramesEngine.of(ctx, slots=in_flight)
 		cat = eng.catalog(catalog)
