@@ -60,7 +60,9 @@ def test_frames_engine_fuzz_native_equals_python_rounds():
 	from test_gpu_resize import _compare_frames_results
 	ctx = Context(0)
 	tot = {'targets': 0, 'resized': 0, 'messages': 0, 'errors': 0, 'passes': 0}
-	for seed in range(201, 209):
+	import os
+	lo, hi = [int(x) for x in os.environ.get('TESSPHOT_FUZZ_SEEDS', '201..209').split('..')]   # (a wider net by hand: TESSPHOT_FUZZ_SEEDS=300..340)
+	for seed in range(lo, hi):
 		rng = np.random.default_rng(seed)
 		N, FR, T = int(rng.integers(150, 500)), int(rng.integers(96, 200)), 24
 		rows, cols = rng.uniform(2, FR - 2, N), rng.uniform(2, FR - 2, N)      # (stars right at the limits: clipped default stamps)

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from multiprocessing import Pool
 
-KINDS = ('faint15', 'small11', 'crowded', 'bright', 'tiny')
+KINDS = tuple(os.environ.get('KINDS', 'faint15,small11,crowded,bright,tiny').split(','))   # also: wide, huge (tests/k2p2_common.py)
 
 def oracle_job(job):
 	from k2p2_common import make_cases, oracle_batch
