@@ -171,6 +171,7 @@ struct tp_frames_job {
 	int slot = -1;
 	hipStream_t copy_stream = nullptr;        // the slot's copy stream: the light curves of that group, chunk by chunk
 	std::vector<hipEvent_t> tails;            // one per group: everything the group queued (its light curves last) has run
+	std::vector<std::pair<tp_ctx*, void*>> late_frees;   // output blocks still read by the copy stream when their group was queued
 	tp_frames_stack stack{};
 	const tp_frames_catalog* cat = nullptr;
 	int32_t n = 0, T = 0;
@@ -520,9 +521,13 @@ void tp_frames_job::launch_tail(Launched& L, std::vector<hipEvent_t>& event_pool
 		// job's 130 MB holds this STREAM, and the next round's masks queued on it, for as long)
 		ck(g, tp_blit(g, static_cast<char*>(G.h_block) + G.off_diag, blk + G.off_diag, G.nbytes - G.off_diag));
 		if (n_chunks > 1) {
-			hipEvent_t e = new_event();          // the group's stream goes on (its tail event, the reuse of its blocks) when the copies have left
+			// the copies' end is one of the job's tail events.  The group's stream does NOT wait for them (it would be held, and whatever
+			// another job queues on it next, for the 2 - 10 ms the link takes): the output block they read is the one block of the group
+			// that is not given back in stream order below -- it goes back when the job has seen its tail events
+			hipEvent_t e = new_event();
 			ckh(hipEventRecord(e, copy_stream), "hipEventRecord");
-			ckh(hipStreamWaitEvent(g->stream, e, 0), "hipStreamWaitEvent");
+			for (size_t i = 0; i < L.dev.size(); ++i)
+				if (L.dev[i] == static_cast<void*>(blk)) { L.dev.erase(L.dev.begin() + (long)i); late_frees.emplace_back(g, static_cast<void*>(blk)); break; }
 		} else if (lc_bytes <= ((uint64_t)32 << 20)) {
 			ck(g, tp_blit(g, G.h_block, blk, lc_bytes));
 		} else {
@@ -770,6 +775,8 @@ void tp_frames_job::run()
 			const hipError_t e = hipEventSynchronize(te);
 			if (e != hipSuccess && copy_error.empty()) { copy_error = std::string("hipEventSynchronize: ") + hipGetErrorString(e); (void)hipGetLastError(); }
 		}
+		for (auto& lf : late_frees) (void)tp_free(lf.first, lf.second);   // (the allocator of a context is serialised by its own mutex)
+		late_frees.clear();
 		lab_us[4] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - lab_w).count();
 		if (const char* le = std::getenv("TESSPHOT_FRAMES_TIMING"))
 			if (le[0] == '1')
@@ -790,6 +797,8 @@ void tp_frames_job::run()
 		rc = TP_ERR_HIP;
 		err = e.what();
 		drain_all();
+		for (auto& lf : late_frees) (void)tp_free(lf.first, lf.second);
+		late_frees.clear();
 	}
 	for (auto e : tails) (void)hipEventDestroy(e);
 	tails.clear();
