@@ -507,6 +507,15 @@ void tp_frames_job::launch_tail(Launched& L, std::vector<hipEvent_t>& event_pool
 				hipEvent_t e = new_event();
 				ckh(hipEventRecord(e, g->stream), "hipEventRecord");
 				ckh(hipStreamWaitEvent(copy_stream, e, 0), "hipStreamWaitEvent");
+				// the five planes of the chunk as ONE rectangular copy (five rows, a plane apart): 48 DMA commands per 2 500 targets instead
+				// of 240, each followed by ~20 us of idle link (copy trace of four jobs in flight: the link was busy 87 % of the time;
+				// 7.55 -> 7.98 x 10^5 targets/s).  TESSPHOT_FRAMES_RECT=0: plane by plane
+				static const bool rect = [] { const char* e = std::getenv("TESSPHOT_FRAMES_RECT"); return !(e && e[0] == '0'); }();
+				if (rect) {
+					const size_t o = (size_t)G.off_lc + (size_t)j0 * T * 8;
+					ckh(hipMemcpy2DAsync(static_cast<char*>(G.h_block) + o, (size_t)m * T * 8, blk + o, (size_t)m * T * 8, (size_t)(j1 - j0) * T * 8, 5,
+						hipMemcpyDeviceToHost, copy_stream), "hipMemcpy2DAsync(light curves)");
+				} else
 				for (int k = 0; k < 5; ++k) {
 					const size_t o = (size_t)G.off_lc + ((size_t)k * m + (size_t)j0) * T * 8;
 					ckh(hipMemcpyAsync(static_cast<char*>(G.h_block) + o, blk + o, (size_t)(j1 - j0) * T * 8, hipMemcpyDeviceToHost, copy_stream), "hipMemcpyAsync(light curves)");
