@@ -13,8 +13,9 @@
 //   mask_size, edge_flux = sum(mask), nansum(sumimage[mask & stamp edge])                (:1394-1403)
 // "good" = cadences whose quality passes the TESS default bitmask (:1353).
 //
-// Mapping (gfx950): one 256-thread workgroup per target, the good-cadence series in LDS; every median is a bitonic
-// sort in LDS (NaN -> +inf sentinels, element picked by rank), sums are fixed-shape tree reductions (deterministic).
+// Mapping (gfx950): one 256-thread workgroup per target, the good-cadence series in LDS; every median is a radix SELECT
+// on order-preserving 64-bit keys (block_median: one 256-bin LDS histogram per digit below the keys' common prefix; the
+// first version sorted bitonically, 66 barrier-separated stages per median), sums are fixed-shape tree reductions (deterministic).
 // The cubic fit is done on the time axis mapped to [-1, 1] (the fitted polynomial is invariant under an affine change
 // of variable, the normal equations then have a condition number of ~1e3 instead of ~1e12).
 // Bytes: 4 series x T x 8 per target in, 80 B out -- negligible next to the cubes; latency-bound.
