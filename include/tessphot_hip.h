@@ -419,7 +419,8 @@ int tp_background_mesh_radial(tp_ctx* ctx, const float* d_frames, int32_t n_fram
  * tp_linpsf_fit (P2-P4) replaces PSF.integrate_to_image (psf.py:122-148), lsfit and the loop / status
  *   logic of LinPSFPhotometry.do_photometry (photometry/linpsf_photometry.py:22-34, 79-219).
  *   d_coef: [n_targets][n*n] spline coefficients, first axis = column direction (psf.py:119,146);
- *   d_knots_x / d_knots_y: [n+4] FITPACK knots of ANY strictly increasing sample grid, n = 4 .. 2048 (both axes alike);
+ *   d_knots_x / d_knots_y: [n+4] FITPACK knots of ANY strictly increasing sample grid, n = 4 .. 2048 (both axes alike; different
+ *   lengths: tp_linpsf_fit_xy);
  *   cutoff_radius: any positive radius, +infinity = none (psf.py:142 `cutoff_radius is None`).  The SPOC layout -- evenly
  *   spaced, 9 samples per pixel, n = 32 .. 140 -- with a radius whose pixel edges stay inside the evenly spaced knots
  *   (cutoff_radius <= 5.25; LinPSFPhotometry uses 5, linpsf_photometry.py:63) runs on the fast kernels below; the library reads
@@ -444,6 +445,23 @@ int tp_background_mesh_radial(tp_ctx* ctx, const float* d_frames, int32_t n_fram
  *   their natural order, the target's coefficients resident in LDS); 0 the vector-ALU kernels (one cadence per lane, cadences
  *   sorted by table origin, scalar-loaded polynomial coefficients) for every target.  Targets that do not qualify take the
  *   vector-ALU kernels either way.  Same results to rounding (1e-13).   */
+/* tp_linpsf_fit / tp_psf_fit for a PRF spline whose two axes have different numbers of samples (psf.py:119 accepts any
+ * RectBivariateSpline): d_coef [n_targets][n_coef_axis_x * n_coef_axis_y] (first axis = column direction), d_knots_x
+ * [n_coef_axis_x + 4], d_knots_y [n_coef_axis_y + 4]; such a table is never the SPOC layout and is fitted by the any-grid kernels
+ * (the FITPACK box integral).  With equal axis lengths they ARE tp_linpsf_fit / tp_psf_fit. */
+int tp_linpsf_fit_xy(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
+	const float* d_subtract, int64_t subtract_pitch,
+	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis_x, int32_t n_coef_axis_y, int32_t max_stars,
+	const int64_t* d_star_offsets, const int32_t* d_target_index,
+	const double* d_pos_row, const double* d_pos_col, int64_t pos_pitch, double cutoff_radius,
+	double* d_flux, double* d_flux_err, double* d_fluxes_all, int64_t out_pitch,
+	double* d_contamination, int32_t* d_status, double* d_fluxes_mean);
+int tp_psf_fit_xy(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images, const float* d_backgrounds,
+	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis_x, int32_t n_coef_axis_y,
+	const int64_t* d_star_offsets, const double* d_params0, const uint8_t* d_mini_aperture,
+	double variance_floor, double cutoff_radius, int32_t maxiter_first, int32_t maxiter,
+	double* d_flux, double* d_flux_err, double* d_centroid_row, double* d_centroid_col, int64_t out_pitch,
+	double* d_params_out, int32_t* d_nit, int32_t* d_status);
 int tp_linpsf_prf(tp_ctx* ctx, int32_t n_targets, int32_t n_samples, int32_t n_coef,
 	const double* d_base_coef, const double* d_weights, double* d_coef);
 int tp_linpsf_set_path(tp_ctx* ctx, int32_t path);

@@ -141,6 +141,10 @@ SIGNATURES = {
 		_p, _p, _p, c_int64, _p, _p, _p]),
 	'tp_psf_fit': (c_int, [c_void_p, _desc_p, _p, _p, _p, _p, _p, c_int32, _p, _p, _p, c_double, c_double, c_int32, c_int32,
 		_p, _p, _p, _p, c_int64, _p, _p, _p]),
+	'tp_linpsf_fit_xy': (c_int, [c_void_p, _desc_p, _p, _p, c_int64, _p, _p, _p, c_int32, c_int32, c_int32, _p, _p, _p, _p, c_int64, c_double,
+		_p, _p, _p, c_int64, _p, _p, _p]),
+	'tp_psf_fit_xy': (c_int, [c_void_p, _desc_p, _p, _p, _p, _p, _p, c_int32, c_int32, _p, _p, _p, c_double, c_double, c_int32, c_int32,
+		_p, _p, _p, _p, c_int64, _p, _p, _p]),
 	'tp_lightcurve_diagnostics': (c_int, [c_void_p, c_int32, c_int32, _p, _p, _p, _p, c_int64, _p, _p, c_int64, c_uint32,
 		_p, _p, _p, c_int32, c_int32, c_double, _p]),
 	'tp_cut_stamps': (c_int, [c_void_p, _p, c_int32, c_int32, c_int32, c_int64, c_int64, c_int32, c_int32, _p, _desc_p, _p]),

@@ -1307,16 +1307,17 @@ template <bool GENERAL>
 __global__ __launch_bounds__(256) void tp_linpsf_fit_many_kernel(FitArgs a, const int32_t* __restrict__ big_targets, int first_target, int smax, double* __restrict__ scratch,
 	int table_in_lds)
 {
-	extern __shared__ __align__(16) double lds[]; // [n*n] coefficient table (if it fits) + 2 x [n+4] knots
+	extern __shared__ __align__(16) double lds[]; // [n*ny] coefficient table (if it fits) + [n+4] + [ny+4] knots
 	const int target = big_targets ? big_targets[blockIdx.x] : (first_target + (int)blockIdx.x);
 	const int tid = threadIdx.x;
-	const int n = a.n;
-	const double* cg = a.coef + (int64_t)target * n * n;
+	const int n = a.n, ny = a.ny;   // (ny != n only in the GENERAL instantiation)
+	const double* cg = a.coef + (int64_t)target * n * ny;
 	double* Cl = lds;
-	double* kn = lds + (table_in_lds ? (size_t)n * n : 0);
+	double* kn = lds + (table_in_lds ? (size_t)n * ny : 0);
 	double* kny = kn + n + 4;
-	if (table_in_lds) for (int i = tid; i < n * n; i += blockDim.x) Cl[i] = cg[i];
-	for (int i = tid; i < n + 4; i += blockDim.x) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
+	if (table_in_lds) for (int i = tid; i < n * ny; i += blockDim.x) Cl[i] = cg[i];
+	for (int i = tid; i < n + 4; i += blockDim.x) kn[i] = a.knots_x[i];
+	for (int i = tid; i < ny + 4; i += blockDim.x) kny[i] = a.knots_y[i];
 	__syncthreads();
 	const double* C = table_in_lds ? Cl : cg;
 	const int k = blockIdx.y * blockDim.x + tid;
@@ -1359,7 +1360,7 @@ __global__ __launch_bounds__(256) void tp_linpsf_fit_many_kernel(FitArgs a, cons
 				if (sqrt(dc * dc + dr * dr) < a.cutoff) {
 					if (GENERAL) {
 						// psf.py:146  integral(column_cen - 0.5, column_cen + 0.5, row_cen - 0.5, row_cen + 0.5)
-						v = prf_pixel_general(C, n, kn, kny, dc - 0.5, dc + 0.5, dr - 0.5, dr + 0.5);
+						v = prf_pixel_general(C, n, ny, kn, kny, dc - 0.5, dc + 0.5, dr - 0.5, dr + 0.5);
 					} else {
 						double wx[4], wy[4];
 						for (int q = 0; q < 4; ++q) { wx[q] = m.at(omx + 4 * s + q); wy[q] = m.at(omy + 4 * s + q); }
@@ -1445,13 +1446,14 @@ __global__ __launch_bounds__(256) void tp_linpsf_finalize_many_kernel(FinArgs fa
 	const FitArgs& a = fa.f;
 	const int target = big_targets ? big_targets[blockIdx.x] : (first_target + (int)blockIdx.x);
 	const int tid = threadIdx.x;
-	const int n = a.n;
-	const double* C = a.coef + (int64_t)target * n * n;
+	const int n = a.n, ny = a.ny;
+	const double* C = a.coef + (int64_t)target * n * ny;
 	double* kn = lds;
 	double* kny = kn + n + 4;
-	double* red = kny + n + 4;            // [256]
+	double* red = kny + ny + 4;           // [256]
 	double* mean = red + 256;             // [kMaxManyStars]
-	for (int i = tid; i < n + 4; i += blockDim.x) { kn[i] = a.knots_x[i]; kny[i] = a.knots_y[i]; }
+	for (int i = tid; i < n + 4; i += blockDim.x) kn[i] = a.knots_x[i];
+	for (int i = tid; i < ny + 4; i += blockDim.x) kny[i] = a.knots_y[i];
 	__syncthreads();
 	const int64_t s0 = a.star_offsets[target];
 	const int ns = (int)(a.star_offsets[target + 1] - s0);
@@ -1496,7 +1498,7 @@ __global__ __launch_bounds__(256) void tp_linpsf_finalize_many_kernel(FinArgs fa
 			double v = 0.0;
 			if (sqrt(dc * dc + dr * dr) < a.cutoff) {
 				if (GENERAL) {
-					v = prf_pixel_general(C, n, kn, kny, dc - 0.5, dc + 0.5, dr - 0.5, dr + 0.5);
+					v = prf_pixel_general(C, n, ny, kn, kny, dc - 0.5, dc + 0.5, dr - 0.5, dr + 0.5);
 				} else {
 					double wx[4], wy[4];
 					int ax0, by0;
@@ -1560,9 +1562,9 @@ extern "C" int tp_linpsf_last_counts(tp_ctx* ctx, int64_t* counts, int32_t n)
 	return TP_OK;
 }
 
-extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
+static int linpsf_fit_impl(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
 	const float* d_subtract, int64_t subtract_pitch,
-	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis, int32_t max_stars,
+	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis, int32_t n_coef_axis_y, int32_t max_stars,
 	const int64_t* d_star_offsets, const int32_t* d_target_index,
 	const double* d_pos_row, const double* d_pos_col, int64_t pos_pitch, double cutoff_radius,
 	double* d_flux, double* d_flux_err, double* d_fluxes_all, int64_t out_pitch,
@@ -1575,7 +1577,7 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	TP_REQUIRE(ctx, d_flux && d_flux_err && d_fluxes_all && d_contamination && d_status, "tp_linpsf_fit: null output pointer");
 	TP_REQUIRE(ctx, pos_pitch >= desc->n_cad && out_pitch >= desc->n_cad, "tp_linpsf_fit: pitch < n_cad");
 	TP_REQUIRE(ctx, d_subtract == nullptr || subtract_pitch >= desc->n_cad, "tp_linpsf_fit: bad subtract pitch");
-	TP_REQUIRE(ctx, n_coef_axis >= 4 && n_coef_axis <= 2048, "tp_linpsf_fit: coefficient table must be 4..2048 per axis");
+	TP_REQUIRE(ctx, n_coef_axis >= 4 && n_coef_axis <= 2048 && n_coef_axis_y >= 4 && n_coef_axis_y <= 2048, "tp_linpsf_fit: coefficient table must be 4..2048 per axis");
 	TP_REQUIRE(ctx, max_stars >= 1 && max_stars <= kMaxManyStars, "tp_linpsf_fit: at most 64 stars fitted per target");
 	TP_REQUIRE(ctx, cutoff_radius > 0, "tp_linpsf_fit: cutoff_radius must be positive (infinity = no cut-off, psf.py:142 `cutoff_radius is None`)");
 	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
@@ -1583,16 +1585,16 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	FitArgs a;
 	a.images = d_images; a.subtract = d_subtract; a.subtract_pitch = subtract_pitch;
 	a.n_cad = desc->n_cad; a.height = desc->height; a.width = desc->width; a.t_pitch = desc->t_pitch;
-	a.coef = d_coef; a.knots_x = d_knots_x; a.knots_y = d_knots_y; a.n = n_coef_axis;
+	a.coef = d_coef; a.knots_x = d_knots_x; a.knots_y = d_knots_y; a.n = n_coef_axis; a.ny = n_coef_axis_y;
 	a.star_offsets = d_star_offsets; a.target_index = d_target_index;
 	a.pos_row = d_pos_row; a.pos_col = d_pos_col; a.pos_pitch = pos_pitch; a.cutoff = cutoff_radius;
 	a.flux = d_flux; a.flux_err = d_flux_err; a.fluxes_all = d_fluxes_all; a.out_pitch = out_pitch;
 
-	const size_t shmem = ((size_t)n_coef_axis * n_coef_axis + 2 * (n_coef_axis + 4)) * sizeof(double);
+	const size_t shmem = ((size_t)n_coef_axis * n_coef_axis_y + (n_coef_axis + 4) + (n_coef_axis_y + 4)) * sizeof(double);
 	const int nblk = (desc->n_cad + 511) / 512;
 	int threads = (((desc->n_cad + nblk - 1) / nblk) + 63) / 64 * 64;
 	dim3 grid((unsigned)desc->n_targets, (unsigned)nblk), block((unsigned)threads);
-	const size_t shmem_fin = (2 * ((size_t)n_coef_axis + 4) + 256) * sizeof(double);
+	const size_t shmem_fin = (((size_t)n_coef_axis + 4) + ((size_t)n_coef_axis_y + 4) + 256) * sizeof(double);
 	FinArgs fa; fa.f = a; fa.contamination = d_contamination; fa.status = d_status; fa.fluxes_mean = d_fluxes_mean; fa.todo = nullptr;
 	// polynomial path: plan (boxes, item counts) -> coefficient store -> fit; targets whose stars visit more table origins than
 	// max_origins are flagged and redone by the general kernel
@@ -1628,7 +1630,7 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	if (sort_n > 8192) sort_n = 0;
 	// the matrix-core path needs the table in LDS (beside the job list of its coefficient kernel), and 32-bit element offsets
 	// into a target's cube
-	const int use_mfma = (ctx->linpsf_path == 1 && (size_t)n_coef_axis * n_coef_axis * sizeof(double) + 2048 <= 160 * 1024   // (2 KB: the kernel's job table)
+	const int use_mfma = (ctx->linpsf_path == 1 && n_coef_axis == n_coef_axis_y && (size_t)n_coef_axis * n_coef_axis * sizeof(double) + 2048 <= 160 * 1024   // (2 KB: the kernel's job table)
 		&& (int64_t)desc->height * desc->width * desc->t_pitch < (1ll << 30)) ? 1 : 0;
 	fa.todo = use_mfma ? d_todo : nullptr;
 	TP_HIP(ctx, hipMemsetAsync(d_todo, 0, todo_bytes, ctx->stream));
@@ -1637,7 +1639,8 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	// pixel, the table resident in LDS, the cut-off inside the evenly spaced part of the knots.  Whether that holds is decided
 	// where the knots are; anything else is fitted by the general kernels with the FITPACK box integral itself
 	{
-		const int force = (n_coef_axis < 32 || n_coef_axis > 140 || !(cutoff_radius <= 5.25)) ? 1 : 0;
+		// (a table with axes of different lengths is never the SPOC layout: the general kernels, the only ones that read a.ny)
+		const int force = (n_coef_axis != n_coef_axis_y || n_coef_axis < 32 || n_coef_axis > 140 || !(cutoff_radius <= 5.25)) ? 1 : 0;
 		hipLaunchKernelGGL(tp_linpsf_grid_kernel, dim3(1), dim3(64), 0, ctx->stream, d_knots_x, d_knots_y, (int)n_coef_axis, cutoff_radius, force, d_total);
 		TP_LAUNCH_CHECK(ctx, "tp_linpsf_grid_kernel");
 	}
@@ -1673,7 +1676,7 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 			if (ns > smax) smax = ns;
 		}
 		const int table_in_lds = (shmem <= (size_t)160 * 1024) ? 1 : 0;
-		const size_t shmem_g = table_in_lds ? shmem : (size_t)2 * (n_coef_axis + 4) * sizeof(double);
+		const size_t shmem_g = table_in_lds ? shmem : ((size_t)(n_coef_axis + 4) + (size_t)(n_coef_axis_y + 4)) * sizeof(double);
 		const int threads_m = 256, nblk_m = (desc->n_cad + threads_m - 1) / threads_m;
 		const size_t per_target = (size_t)(2 * smax * smax + 15 * smax) * sizeof(double) * nblk_m * threads_m;
 		int64_t chunk = (int64_t)(((size_t)4 << 30) / per_target);
@@ -1790,6 +1793,34 @@ extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float*
 	}
 	return TP_OK;
 	TP_API_END(ctx)
+}
+
+extern "C" int tp_linpsf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
+	const float* d_subtract, int64_t subtract_pitch,
+	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis, int32_t max_stars,
+	const int64_t* d_star_offsets, const int32_t* d_target_index,
+	const double* d_pos_row, const double* d_pos_col, int64_t pos_pitch, double cutoff_radius,
+	double* d_flux, double* d_flux_err, double* d_fluxes_all, int64_t out_pitch,
+	double* d_contamination, int32_t* d_status, double* d_fluxes_mean)
+{
+	return linpsf_fit_impl(ctx, desc, d_images, d_subtract, subtract_pitch, d_coef, d_knots_x, d_knots_y, n_coef_axis, n_coef_axis, max_stars,
+		d_star_offsets, d_target_index, d_pos_row, d_pos_col, pos_pitch, cutoff_radius, d_flux, d_flux_err, d_fluxes_all, out_pitch,
+		d_contamination, d_status, d_fluxes_mean);
+}
+
+// the same for a PRF spline whose two axes have different numbers of samples (psf.py:119 takes any RectBivariateSpline): d_coef
+// [n_targets][n_coef_axis_x * n_coef_axis_y], d_knots_x [n_coef_axis_x + 4], d_knots_y [n_coef_axis_y + 4]; fitted by the any-grid kernels
+extern "C" int tp_linpsf_fit_xy(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images,
+	const float* d_subtract, int64_t subtract_pitch,
+	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis_x, int32_t n_coef_axis_y, int32_t max_stars,
+	const int64_t* d_star_offsets, const int32_t* d_target_index,
+	const double* d_pos_row, const double* d_pos_col, int64_t pos_pitch, double cutoff_radius,
+	double* d_flux, double* d_flux_err, double* d_fluxes_all, int64_t out_pitch,
+	double* d_contamination, int32_t* d_status, double* d_fluxes_mean)
+{
+	return linpsf_fit_impl(ctx, desc, d_images, d_subtract, subtract_pitch, d_coef, d_knots_x, d_knots_y, n_coef_axis_x, n_coef_axis_y, max_stars,
+		d_star_offsets, d_target_index, d_pos_row, d_pos_col, pos_pitch, cutoff_radius, d_flux, d_flux_err, d_fluxes_all, out_pitch,
+		d_contamination, d_status, d_fluxes_mean);
 }
 
 // positions of the fitted stars of a field that moves as a whole (see tessphot_hip.h)

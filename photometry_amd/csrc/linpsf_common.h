@@ -23,6 +23,7 @@ struct FitArgs {
 	const double* knots_x;       // [n+4] knots along the first spline axis (columns)
 	const double* knots_y;       // [n+4] knots along the second spline axis (rows)
 	int n;                       // coefficients per axis (117)
+	int ny;                      // ... along the second axis (= n for every kernel but the general ones: tp_linpsf_fit_xy)
 	const int64_t* star_offsets; // [n_targets+1] into the fitted-star arrays
 	const int32_t* target_index; // [n_targets] index of the main target inside its fitted stars
 	const double* pos_row;       // [n_fit_stars][pos_pitch] row_stamp per cadence

@@ -222,19 +222,20 @@ __device__ __forceinline__ double edge_cumulative(const EdgeInt& g, int i)   // 
 }
 
 // integral of the unit PRF spline over the pixel [xa, xb] x [ya, yb] (x: first spline axis = column direction, psf.py:146)
-__device__ inline double prf_pixel_general(const double* __restrict__ C, int n, const double* __restrict__ tx, const double* __restrict__ ty,
+// (n, ny: coefficients along the first / the second axis; the table is [n][ny], RectBivariateSpline's layout)
+__device__ inline double prf_pixel_general(const double* __restrict__ C, int n, int ny, const double* __restrict__ tx, const double* __restrict__ ty,
 	double xa, double xb, double ya, double yb)
 {
 	if (!(xa < xb) || !(ya < yb)) return 0.0;
-	xa = fmax(xa, tx[3]); xb = fmin(xb, tx[n]); ya = fmax(ya, ty[3]); yb = fmin(yb, ty[n]);
+	xa = fmax(xa, tx[3]); xb = fmin(xb, tx[n]); ya = fmax(ya, ty[3]); yb = fmin(yb, ty[ny]);
 	if (!(xa < xb) || !(ya < yb)) return 0.0;     // the pixel lies outside the PRF grid
 	EdgeInt Xa, Xb, Ya, Yb;
 	edge_integrals(tx, n, xa, Xa); edge_integrals(tx, n, xb, Xb);
-	edge_integrals(ty, n, ya, Ya); edge_integrals(ty, n, yb, Yb);
+	edge_integrals(ty, ny, ya, Ya); edge_integrals(ty, ny, yb, Yb);
 	double acc = 0.0;
 	for (int i = Xa.l - 3; i <= Xb.l; ++i) {
 		const double wx = (edge_cumulative(Xb, i) - edge_cumulative(Xa, i)) * ((tx[i + 4] - tx[i]) * 0.25);
-		const double* r = C + (int64_t)i * n;
+		const double* r = C + (int64_t)i * ny;
 		double inner = 0.0;
 		for (int j = Ya.l - 3; j <= Yb.l; ++j) {
 			const double wy = (edge_cumulative(Yb, j) - edge_cumulative(Ya, j)) * ((ty[j + 4] - ty[j]) * 0.25);

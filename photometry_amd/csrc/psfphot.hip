@@ -63,7 +63,7 @@ constexpr int kThreads = 256;
 struct PsfArgs {
 	const float* images; const float* backgrounds;
 	int n_cad, height, width; int64_t t_pitch;
-	const double* coef; const double* knots_x; const double* knots_y; int n;
+	const double* coef; const double* knots_x; const double* knots_y; int n; int ny;   // ny != n: the general instantiation only (tp_psf_fit_xy)
 	const int64_t* star_offsets; const double* params0; const uint8_t* mini_aperture;
 	float var_floor; double cutoff; int maxiter_first, maxiter;
 	double* flux; double* flux_err; double* cen_row; double* cen_col; int64_t out_pitch;
@@ -110,7 +110,7 @@ struct StarR { double row, col, flux, phx, phy; int jstar, istar, slot, valid; }
 
 // everything an evaluation needs besides the parameter vector
 struct EvalCtx {
-	int ns, n, H, W, pool; double h, hy, cutoff;
+	int ns, n, ny, H, W, pool; double h, hy, cutoff;
 	const double* Cg;            // the target's coefficient table in HBM
 	const double* kn; const double* kny;   // the knot vectors (LDS)
 	const float* img; const float* wgt;    // float32 as psf_photometry.py:75-86 computes them
@@ -260,7 +260,7 @@ __device__ __forceinline__ double model_pixel(int i, int j, const EvalCtx& c, co
 		if (GEN) {
 			const double dc = (double)j - st[s].col, dr = (double)i - st[s].row;
 			if (sqrt(dc * dc + dr * dr) < c.cutoff)     // psf.py:142, :146
-				mdl += st[s].flux * prf_pixel_general(c.Cg, c.n, c.kn, c.kny, dc - 0.5, dc + 0.5, dr - 0.5, dr + 0.5);
+				mdl += st[s].flux * prf_pixel_general(c.Cg, c.n, c.ny, c.kn, c.kny, dc - 0.5, dc + 0.5, dr - 0.5, dr + 0.5);
 			continue;
 		}
 		const int di = i - st[s].istar, dj = j - st[s].jstar;
@@ -308,15 +308,15 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 	extern __shared__ __align__(16) double lds[];
 	const int target = targets[blockIdx.x];
 	const int tid = threadIdx.x;
-	const int n = a.n, H = a.height, W = a.width, P = H * W;
+	const int n = a.n, ny = a.ny, H = a.height, W = a.width, P = H * W;
 	double* sim = lds;                        // [(D+1)][kMaxDim]
 	double* fsim = sim + (kMaxDim + 1) * kMaxDim;   // [D+1]
 	double* xt = fsim + (kMaxDim + 1);        // trial points: xbar, xr, xe / xc [3][kMaxDim]
 	double* x0 = xt + 3 * kMaxDim;            // warm start [kMaxDim]
 	double* red = x0 + kMaxDim;               // [2][4] partial sums of the evaluations, [8] the convergence test's
 	double* kn = red + 16;                    // [n + 4] knots of the first spline axis (every evaluation reads a few: LDS, not L2)
-	double* kny = kn + (n + 4);               // [n + 4]
-	double* Kc = kny + (n + 4);               // [kPool][kItems][25] cached polynomial coefficients
+	double* kny = kn + (n + 4);               // [ny + 4]
+	double* Kc = kny + (ny + 4);              // [kPool][kItems][25] cached polynomial coefficients
 	int* keys = reinterpret_cast<int*>(Kc + (size_t)pool * kItems * 25);   // [kPool][2]
 	int* nxt = keys + 2 * kPool;              // [kMaxPsfStars]
 	int* rbs = nxt + kMaxPsfStars;            // [kMaxPsfStars]
@@ -324,7 +324,8 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 	int* gsrc = gkeys + 3 * kStoreSlots + 1;  // [kMaxPsfStars]
 	float* img = reinterpret_cast<float*>(gsrc + kMaxPsfStars);  // [P]   (4-byte aligned is enough)
 	float* wgt = img + P;                     // [P]
-	for (int q = tid; q < n + 4; q += kThreads) { kn[q] = a.knots_x[q]; kny[q] = a.knots_y[q]; }
+	for (int q = tid; q < n + 4; q += kThreads) kn[q] = a.knots_x[q];
+	for (int q = tid; q < ny + 4; q += kThreads) kny[q] = a.knots_y[q];
 	if (tid < kMaxPsfStars) { nxt[tid] = 0; rbs[tid] = -1; }
 	if (tid < 2 * pool) keys[tid] = -0x7fffffff;
 	if (tid < 3 * kStoreSlots) gkeys[tid] = -0x7fffffff;
@@ -344,8 +345,8 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 		return;
 	}
 	EvalCtx ec;
-	ec.ns = ns; ec.n = n; ec.H = H; ec.W = W; ec.pool = pool; ec.h = h; ec.hy = hy; ec.cutoff = a.cutoff;
-	ec.Cg = a.coef + (int64_t)target * n * n; ec.kn = kn; ec.kny = kny; ec.img = img; ec.wgt = wgt; ec.Kc = Kc; ec.red = red; ec.keys = keys; ec.nxt = nxt; ec.rbs = rbs;
+	ec.ns = ns; ec.n = n; ec.ny = ny; ec.H = H; ec.W = W; ec.pool = pool; ec.h = h; ec.hy = hy; ec.cutoff = a.cutoff;
+	ec.Cg = a.coef + (int64_t)target * n * ny; ec.kn = kn; ec.kny = kny; ec.img = img; ec.wgt = wgt; ec.Kc = Kc; ec.red = red; ec.keys = keys; ec.nxt = nxt; ec.rbs = rbs;
 	ec.gset = (a.gstore && !GEN && target < a.gstore_targets) ? (a.gstore + (size_t)target * kStoreSlots * kItems * 25) : nullptr; ec.gkeys = gkeys; ec.gsrc = gsrc;
 	int flip = 0;
 #define EVAL(xp) likelihood<(NS > 0 ? NS : 1), GEN>((xp), ec, flip)
@@ -528,8 +529,8 @@ __global__ __launch_bounds__(kThreads) void tp_psf_fit_kernel(PsfArgs a, const i
 } // namespace
 
 
-extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images, const float* d_backgrounds,
-	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis,
+static int psf_fit_impl(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images, const float* d_backgrounds,
+	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis, int32_t n_coef_axis_y,
 	const int64_t* d_star_offsets, const double* d_params0, const uint8_t* d_mini_aperture,
 	double variance_floor, double cutoff_radius, int32_t maxiter_first, int32_t maxiter,
 	double* d_flux, double* d_flux_err, double* d_centroid_row, double* d_centroid_col, int64_t out_pitch,
@@ -541,25 +542,25 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 	TP_REQUIRE(ctx, d_images && d_coef && d_knots_x && d_knots_y && d_star_offsets && d_params0 && d_mini_aperture, "tp_psf_fit: null input pointer");
 	TP_REQUIRE(ctx, d_flux && d_flux_err && d_centroid_row && d_centroid_col && d_status, "tp_psf_fit: null output pointer");
 	TP_REQUIRE(ctx, out_pitch >= desc->n_cad, "tp_psf_fit: out_pitch < n_cad");
-	TP_REQUIRE(ctx, n_coef_axis >= 4 && n_coef_axis <= 2048, "tp_psf_fit: coefficient table must be 4..2048 per axis");
+	TP_REQUIRE(ctx, n_coef_axis >= 4 && n_coef_axis <= 2048 && n_coef_axis_y >= 4 && n_coef_axis_y <= 2048, "tp_psf_fit: coefficient table must be 4..2048 per axis");
 	TP_REQUIRE(ctx, cutoff_radius > 0, "tp_psf_fit: cutoff_radius must be positive (infinity = no cut-off, psf.py:142 `cutoff_radius is None`)");
 	TP_REQUIRE(ctx, maxiter_first >= 1 && maxiter >= 1, "tp_psf_fit: bad iteration limits");
 	if (desc->n_targets == 0 || desc->n_cad == 0) return TP_OK;
 	const size_t P = (size_t)desc->height * desc->width;
 	auto lds_bytes = [&](int pool) {
-		const size_t doubles = (kMaxDim + 1) * kMaxDim + (kMaxDim + 1) + 3 * kMaxDim + kMaxDim + 16 + 2 * ((size_t)n_coef_axis + 4) + (size_t)pool * kItems * 25;
+		const size_t doubles = (kMaxDim + 1) * kMaxDim + (kMaxDim + 1) + 3 * kMaxDim + kMaxDim + 16 + ((size_t)n_coef_axis + 4) + ((size_t)n_coef_axis_y + 4) + (size_t)pool * kItems * 25;
 		return doubles * sizeof(double) + (2 * kPool + 2 * kMaxPsfStars + 1 + 3 * kStoreSlots + 1 + kMaxPsfStars) * sizeof(int) + 2 * P * sizeof(float) + 16;
 	};
 	// the targets by their number of fitted stars (one launch each, see psf_pool): the star offsets come to the host once, and
 	// with them the knots: the cached biquartics need the SPOC layout of the PRF grid (9 samples per pixel, the cut-off inside
 	// the evenly spaced knots, <= 5.25 as the cached item set assumes); any other grid or radius takes the general instantiation
 	std::vector<int64_t> off((size_t)desc->n_targets + 1);
-	std::vector<double> hk(2 * ((size_t)n_coef_axis + 4));
+	std::vector<double> hk(((size_t)n_coef_axis + 4) + ((size_t)n_coef_axis_y + 4));
 	TP_HIP(ctx, hipMemcpyAsync(off.data(), d_star_offsets, off.size() * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
 	TP_HIP(ctx, hipMemcpyAsync(hk.data(), d_knots_x, ((size_t)n_coef_axis + 4) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-	TP_HIP(ctx, hipMemcpyAsync(hk.data() + n_coef_axis + 4, d_knots_y, ((size_t)n_coef_axis + 4) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+	TP_HIP(ctx, hipMemcpyAsync(hk.data() + n_coef_axis + 4, d_knots_y, ((size_t)n_coef_axis_y + 4) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
 	TP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	const bool general = !(n_coef_axis <= 140 && cutoff_radius <= 5.25 && uniform_grid_ok(hk.data(), n_coef_axis, cutoff_radius)
+	const bool general = !(n_coef_axis == n_coef_axis_y && n_coef_axis <= 140 && cutoff_radius <= 5.25 && uniform_grid_ok(hk.data(), n_coef_axis, cutoff_radius)
 		&& uniform_grid_ok(hk.data() + n_coef_axis + 4, n_coef_axis, cutoff_radius));
 	TP_REQUIRE(ctx, lds_bytes(general ? 0 : kPool) <= 160 * 1024, "tp_psf_fit: stamp too large for the LDS-resident image and weight map");
 	std::vector<int32_t> lists[kMaxPsfStars + 1];
@@ -572,7 +573,7 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 	TP_REQUIRE(ctx, d_lists != nullptr, "tp_psf_fit: out of device memory for the target lists");
 	PsfArgs a;
 	a.images = d_images; a.backgrounds = d_backgrounds; a.n_cad = desc->n_cad; a.height = desc->height; a.width = desc->width; a.t_pitch = desc->t_pitch;
-	a.coef = d_coef; a.knots_x = d_knots_x; a.knots_y = d_knots_y; a.n = n_coef_axis;
+	a.coef = d_coef; a.knots_x = d_knots_x; a.knots_y = d_knots_y; a.n = n_coef_axis; a.ny = n_coef_axis_y;
 	a.star_offsets = d_star_offsets; a.params0 = d_params0; a.mini_aperture = d_mini_aperture;
 	a.var_floor = (float)variance_floor; a.cutoff = cutoff_radius; a.maxiter_first = maxiter_first; a.maxiter = maxiter;
 	a.flux = d_flux; a.flux_err = d_flux_err; a.cen_row = d_centroid_row; a.cen_col = d_centroid_col; a.out_pitch = out_pitch;
@@ -646,4 +647,30 @@ extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_
 	if (err != hipSuccess) return ctx->fail(TP_ERR_HIP, "tp_psf_fit_kernel", err);
 	return TP_OK;
 	TP_API_END(ctx)
+}
+
+extern "C" int tp_psf_fit(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images, const float* d_backgrounds,
+	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis,
+	const int64_t* d_star_offsets, const double* d_params0, const uint8_t* d_mini_aperture,
+	double variance_floor, double cutoff_radius, int32_t maxiter_first, int32_t maxiter,
+	double* d_flux, double* d_flux_err, double* d_centroid_row, double* d_centroid_col, int64_t out_pitch,
+	double* d_params_out, int32_t* d_nit, int32_t* d_status)
+{
+	return psf_fit_impl(ctx, desc, d_images, d_backgrounds, d_coef, d_knots_x, d_knots_y, n_coef_axis, n_coef_axis, d_star_offsets, d_params0,
+		d_mini_aperture, variance_floor, cutoff_radius, maxiter_first, maxiter, d_flux, d_flux_err, d_centroid_row, d_centroid_col, out_pitch,
+		d_params_out, d_nit, d_status);
+}
+
+// the same for a PRF spline whose two axes have different numbers of samples (psf.py:119 takes any RectBivariateSpline): d_coef
+// [n_targets][n_coef_axis_x * n_coef_axis_y], d_knots_x [n_coef_axis_x + 4], d_knots_y [n_coef_axis_y + 4]; the general instantiation
+extern "C" int tp_psf_fit_xy(tp_ctx* ctx, const tp_cube_desc* desc, const float* d_images, const float* d_backgrounds,
+	const double* d_coef, const double* d_knots_x, const double* d_knots_y, int32_t n_coef_axis_x, int32_t n_coef_axis_y,
+	const int64_t* d_star_offsets, const double* d_params0, const uint8_t* d_mini_aperture,
+	double variance_floor, double cutoff_radius, int32_t maxiter_first, int32_t maxiter,
+	double* d_flux, double* d_flux_err, double* d_centroid_row, double* d_centroid_col, int64_t out_pitch,
+	double* d_params_out, int32_t* d_nit, int32_t* d_status)
+{
+	return psf_fit_impl(ctx, desc, d_images, d_backgrounds, d_coef, d_knots_x, d_knots_y, n_coef_axis_x, n_coef_axis_y, d_star_offsets, d_params0,
+		d_mini_aperture, variance_floor, cutoff_radius, maxiter_first, maxiter, d_flux, d_flux_err, d_centroid_row, d_centroid_col, out_pitch,
+		d_params_out, d_nit, d_status);
 }

@@ -345,15 +345,15 @@ def star_positions(ctx, base, shift):
 def linpsf_fit(ctx, images, coef, knots_x, knots_y, star_offsets, target_index, pos_row, pos_col, max_stars,
 	cutoff_radius=5.0, subtract=None, out=None):
 	"""P2-P4 (psf.py:122-148, linpsf_photometry.py:22-34, 79-219).  ``cutoff_radius=None``: no cut-off (psf.py:142)."""
-	n = knots_x.shape[0] - 4
+	n, ny = knots_x.shape[0] - 4, knots_y.shape[0] - 4      # (axes of different lengths: tp_linpsf_fit_xy, the any-grid kernels)
 	if cutoff_radius is None:
 		cutoff_radius = float('inf')
 	if out is None:
 		out = LinPSFResult(ctx, images.n_targets, pos_row.shape[0], images.n_cad)
 	assert pos_row.shape[1] >= images.n_cad and pos_col.shape == pos_row.shape
 	desc = images.desc
-	ctx._check(ctx.lib.tp_linpsf_fit(ctx.handle, ctypes.byref(desc), images.ptr, _ptr(subtract), 0 if subtract is None else subtract.shape[1],
-		coef.ptr, knots_x.ptr, knots_y.ptr, n, int(max_stars), star_offsets.ptr, target_index.ptr,
+	ctx._check(ctx.lib.tp_linpsf_fit_xy(ctx.handle, ctypes.byref(desc), images.ptr, _ptr(subtract), 0 if subtract is None else subtract.shape[1],
+		coef.ptr, knots_x.ptr, knots_y.ptr, n, ny, int(max_stars), star_offsets.ptr, target_index.ptr,
 		pos_row.ptr, pos_col.ptr, pos_row.shape[1], float(cutoff_radius),
 		out.flux.ptr, out.flux_err.ptr, out.fluxes_all.ptr, out.n_cad, out.contamination.ptr, out.status.ptr, out.fluxes_mean.ptr))
 	return out
@@ -368,7 +368,7 @@ def psf_fit(ctx, images, backgrounds, coef, knots_x, knots_y, star_offsets, para
 	``(Nt, T)``, ``status`` int32 ``(Nt,)``.
 	"""
 	Nt, T = images.n_targets, images.n_cad
-	n = knots_x.shape[0] - 4
+	n, ny = knots_x.shape[0] - 4, knots_y.shape[0] - 4
 	if cutoff_radius is None:      # psf.py:142: no cut-off
 		cutoff_radius = float('inf')
 	out = {k: ctx.zeros((Nt, T), 'float64') for k in ('flux', 'flux_err', 'centroid_row', 'centroid_col')}
@@ -376,7 +376,7 @@ def psf_fit(ctx, images, backgrounds, coef, knots_x, knots_y, star_offsets, para
 	out['nit'] = ctx.zeros((Nt, T), 'int32')
 	out['status'] = ctx.zeros((Nt,), 'int32')
 	desc = images.desc
-	ctx._check(ctx.lib.tp_psf_fit(ctx.handle, ctypes.byref(desc), images.ptr, _ptr(backgrounds), coef.ptr, knots_x.ptr, knots_y.ptr, n,
+	ctx._check(ctx.lib.tp_psf_fit_xy(ctx.handle, ctypes.byref(desc), images.ptr, _ptr(backgrounds), coef.ptr, knots_x.ptr, knots_y.ptr, n, ny,
 		star_offsets.ptr, params0.ptr, mini_aperture.ptr, float(variance_floor), float(cutoff_radius), int(maxiter_first), int(maxiter),
 		out['flux'].ptr, out['flux_err'].ptr, out['centroid_row'].ptr, out['centroid_col'].ptr, T, out['params'].ptr, out['nit'].ptr,
 		out['status'].ptr))

@@ -59,8 +59,6 @@ class PRFModel(object):
 			raise ValueError("PRF values must be (n_hdu, len(prf_x), len(prf_y))")
 		if not np.all(np.isfinite(values)):
 			raise ValueError("non-finite PRF samples are not supported")
-		if len(self.prf_x) != len(self.prf_y):
-			raise ValueError("the device kernel needs a square PRF grid")
 		for g in (self.prf_x, self.prf_y):
 			if len(g) < 4 or not np.all(np.diff(g) > 0):
 				raise ValueError("PRF sample coordinates must be strictly increasing, at least 4 per axis (RectBivariateSpline's own rule)")
@@ -78,8 +76,8 @@ class PRFModel(object):
 			tx, ty, c = spl.tck
 			coefs.append(np.asarray(c, dtype='float64'))
 		self.tx, self.ty = np.asarray(tx, dtype='float64'), np.asarray(ty, dtype='float64')
-		self.n = len(self.tx) - 4
-		self.base_coef = np.ascontiguousarray(np.stack(coefs)) # (n_hdu, n*n)
+		self.n, self.ny = len(self.tx) - 4, len(self.ty) - 4   # (different lengths: the any-grid kernels, tp_linpsf_fit_xy / tp_psf_fit_xy)
+		self.base_coef = np.ascontiguousarray(np.stack(coefs)) # (n_hdu, n*ny)
 
 	@classmethod
 	def from_mat(cls, path):
@@ -111,7 +109,7 @@ class PRFModel(object):
 		self = cls.__new__(cls)
 		tx, ty, c = spline.tck
 		self.tx, self.ty = np.asarray(tx, dtype='float64'), np.asarray(ty, dtype='float64')
-		self.n = len(self.tx) - 4
+		self.n, self.ny = len(self.tx) - 4, len(self.ty) - 4
 		self.n_hdu = 1
 		self.base_coef = np.ascontiguousarray(np.asarray(c, dtype='float64')[None, :])
 		self.ccd_column = self.ccd_row = np.zeros(1)

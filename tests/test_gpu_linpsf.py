@@ -137,7 +137,7 @@ def test_linpsf_argument_checks(ctx):
 
 # include/tessphot_hip.h (tp_linpsf_fit): grids other than the SPOC layout and cut-off radii beyond its evenly spaced knots -- or none
 # at all (psf.py:142 ``cutoff_radius is None``) -- are fitted by the general kernels with the FITPACK box integral itself
-@pytest.mark.parametrize("kind,cutoff,max_neigh", [('warped', 5, 3), ('nsub7', 5, 2), ('spoc', 7.5, 3), ('spoc', None, 2), ('coarse', None, 3),
+@pytest.mark.parametrize("kind,cutoff,max_neigh", [('warped', 5, 3), ('nsub7', 5, 2), ('spoc', 7.5, 3), ('spoc', None, 2), ('coarse', None, 3), ('rect', 5, 3), ('rect', None, 2),
 	('warped', 6.0, 13), ('spoc', 5.3, 1), ('nsub7', 6.5, -2)])      # (-2: two neighbours at most, 300 cadences: several workgroups per target)
 def test_linpsf_any_grid_any_cutoff(ctx, kind, cutoff, max_neigh):
 	from photometry_amd import simulate, engine, psf as hpsf

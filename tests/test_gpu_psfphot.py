@@ -116,7 +116,7 @@ def test_psf_photometry_matches_oracle(ctx):
 	assert n_same_nit >= n_cad // 4
 
 
-@pytest.mark.parametrize("kind,cutoff", [('warped', 5), ('spoc', 6.5), ('nsub7', None)])
+@pytest.mark.parametrize("kind,cutoff", [('warped', 5), ('spoc', 6.5), ('nsub7', None), ('rect', 5)])
 def test_psf_photometry_any_grid_any_cutoff(ctx, kind, cutoff):
 	"""PRF grids other than the SPOC layout, cut-off radii beyond its evenly spaced knots or none (psf.py:119, :142): the general
 	instantiation of the fit kernel integrates the spline over every pixel itself.  Same comparison as above."""

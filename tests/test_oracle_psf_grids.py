@@ -11,7 +11,7 @@ from oracle import psf as opsf
 from prf_common import general_prf
 
 
-@pytest.mark.parametrize("kind,cutoff", [('warped', 5), ('warped', None), ('nsub7', 6.5), ('coarse', None), ('spoc', 7.5), ('spoc', None)])
+@pytest.mark.parametrize("kind,cutoff", [('warped', 5), ('warped', None), ('nsub7', 6.5), ('coarse', None), ('spoc', 7.5), ('spoc', None), ('rect', 5), ('rect', None)])
 def test_box_integral_on_any_grid_equals_scipy(kind, cutoff):
 	prf = general_prf(kind)
 	stamp = (100, 117, 300, 316)      # 17 x 16: wider than every grid here, so pixels beyond the PRF's support are included
