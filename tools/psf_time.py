@@ -58,3 +58,5 @@ if os.environ.get('TP_LAB_LIB') and os.environ.get('CLOCKS'):
 	it = max(c[5], 1)
 	print('workgroup 0 of every launch, both calls: iterations', c[5], '; cycles per iteration (100 MHz clock64 ticks x 24 at 2.4 GHz?):')
 	print('  loop total %.0f; prepare %.0f, rebuild %.0f, pixels %.0f, reduce %.0f ticks per iteration' % (c[4] / it, c[0] / it, c[1] / it, c[2] / it, c[3] / it))
+if os.environ.get('DUMP'):   # the fit's outputs, for a bit-by-bit comparison of two builds
+	np.savez(os.environ['DUMP'], flux=res['flux'].to_host(), nit=nit, cr=res['centroid_row'].to_host(), cc=res['centroid_col'].to_host())
