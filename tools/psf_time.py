@@ -48,7 +48,7 @@ if os.environ.get('STATS'):
 		sel = ns_of == k
 		if sel.any():
 			print(f'  {k} stars: {int(sel.sum())} targets, iterations per target: mean {tot[sel].mean():.0f}, max {tot[sel].max():.0f}, share of all iterations {tot[sel].sum() / tot.sum():.2f}')
-# CLOCKS=1: phases of an iteration from in-kernel clocks -- a scratch build: git apply tools/lab/clock_hooks.patch;
+# CLOCKS=1: phases of an iteration from in-kernel clocks -- a scratch build (tools/lab/clock_hooks.patch: made against the round-4 sources, to be re-made before use):
 # SRC=psfphot.hip bash tools/lab/build_variants.sh "psfclk:-DTP_LAB_PSF_CLOCK"; git apply -R tools/lab/clock_hooks.patch
 if os.environ.get('TP_LAB_LIB') and os.environ.get('CLOCKS'):
 	import ctypes

@@ -36,7 +36,7 @@ wall = (time.perf_counter() - t0) / n * 1e3
 ctx.profile(False)
 rep = ctx.profile_report()
 print('step ms', round(wall, 3), {k: round(v[1] / max(v[0], 1), 3) for k, v in rep.items() if v[0]})
-# FCLK=1: phases of the fused launch from in-kernel clocks -- a scratch build: git apply tools/lab/clock_hooks.patch;
+# FCLK=1: phases of the fused launch from in-kernel clocks -- a scratch build (tools/lab/clock_hooks.patch: made against the round-4 sources, to be re-made before use):
 # SRC=fused.hip bash tools/lab/build_variants.sh "fclk:-DTP_LAB_FUSED_CLOCK"; git apply -R tools/lab/clock_hooks.patch
 if os.environ.get('TP_LAB_LIB') and os.environ.get('FCLK'):
 	import ctypes
