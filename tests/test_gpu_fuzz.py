@@ -102,3 +102,15 @@ def test_frames_engine_fuzz_native_equals_python_rounds():
 	ctx.close()
 	print('frames engine fuzz:', tot)
 	assert tot['targets'] > 1500 and tot['resized'] > 50 and tot['messages'] > 20 and tot['passes'] > 40
+
+
+def test_frames_engine_pool_under_four_jobs_in_flight(monkeypatch):
+	"""The engine's shared stream pool under load: 16 batches of random sizes (1 .. 3 000 targets of a region with bright stars and
+	bleed trails: several resize rounds and size groups per batch), four jobs in flight, every batch equal to a call of its own
+	(tools/lab/frames_stress.py; by hand with NB=30 T=200: 22 273 targets, 873 device passes per run)."""
+	import os, runpy
+	monkeypatch.setenv('BRIGHT', '1')
+	monkeypatch.setenv('NB', '16')
+	monkeypatch.setenv('T', '48')
+	monkeypatch.setenv('REPS', '2')
+	runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'lab', 'frames_stress.py'), run_name='__main__')
