@@ -609,7 +609,9 @@ typedef struct tp_frames_stack {
 	 * masks first and cuts only the in-mask pixel rows of the three stacks; NULL: the sum image of every stamp is formed from
 	 * its own image cube (tp_sumimage: the reference's postage-stamp branch, BasePhotometry.py:1007-1019). */
 	const double* d_sumimage;
-	/* optional (all three or none; needs d_sumimage): the TIME-MAJOR copies of the three stacks, float32 [n_rows * n_cols][t_pitch]
+	/* (round 6: the struct grew by the four fields below -- callers built against the older header must be recompiled; zero them
+	 * for the cutting path)
+	 * optional (all three or none; needs d_sumimage): the TIME-MAJOR copies of the three stacks, float32 [n_rows * n_cols][t_pitch]
 	 * (tp_frames_transpose; t_pitch >= n_frames, a multiple of 4; the cadences past n_frames zero).  Given, no pass cuts anything:
 	 * the extraction reads a mask pixel's time series as one row of the stack (tp_aperture_extract_stack) -- the per-target cube of
 	 * BasePhotometry._load_cube (BasePhotometry.py:720-751) is never materialised.  NULL: in-mask rows are cut per pass. */
