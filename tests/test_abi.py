@@ -74,3 +74,34 @@ def test_ctypes_arity_matches_the_header(built_lib):
 		params = m.group(1).strip()
 		n = 0 if params in ('', 'void') else len([p for p in params.split(',') if p.strip()])
 		assert n == len(argtypes), f"{name}: header has {n} parameters, ctypes table has {len(argtypes)}"
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+	"""The ctypes mirrors of the header's structs (photometry_amd/_lib.py) have the size and the field offsets a C compiler gives the
+	header's own definitions: a C program that includes include/tessphot_hip.h prints them (gcc; no GPU, no library needed)."""
+	import shutil, subprocess
+	from photometry_amd import _lib
+	if shutil.which('gcc') is None:
+		pytest.skip('no C compiler')
+	structs = {name: getattr(_lib, name) for name in ('tp_cube_desc', 'tp_k2p2_params', 'tp_zoom_image', 'tp_radial_image', 'tp_frames_stack')}
+	lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "tessphot_hip.h"', 'int main(void) {']
+	for name, cls in structs.items():
+		lines.append(f'	printf("{name} size %zu\\n", sizeof({name}));')
+		for field, _ in cls._fields_:
+			lines.append(f'	printf("{name} {field} %zu\\n", offsetof({name}, {field}));')
+	lines += ['	return 0;', '}']
+	src = tmp_path / 'layout.c'
+	src.write_text('\n'.join(lines))
+	exe = tmp_path / 'layout'
+	subprocess.run(['gcc', '-I', os.path.dirname(HEADER), str(src), '-o', str(exe)], check=True)
+	out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+	seen = 0
+	for line in out.splitlines():
+		name, what, value = line.split()
+		cls = structs[name]
+		if what == 'size':
+			assert ctypes.sizeof(cls) == int(value), (name, ctypes.sizeof(cls), value)
+		else:
+			assert getattr(cls, what).offset == int(value), (name, what, getattr(cls, what).offset, value)
+		seen += 1
+	assert seen == sum(len(c._fields_) + 1 for c in structs.values())
